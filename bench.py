@@ -1,0 +1,224 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of the MI355X-native fqtk demux barcode matcher.
+
+Metric (BASELINE.json): M reads/sec demuxed (bit-exact assigns) + achieved HBM GB/s vs peak.
+Workload at N=1: BASELINE.json configs[2] -- the config the north_star target is quoted on -- dual-index
+400 M reads x 384 samples (8+8 bp), max-mismatches 1, min-mismatch-delta 2; it fits one GPU
+(6.4 GB of observed barcodes + 1.6 GB of results in HBM).  A "step" = one pass of the hot path
+(fqtk_matcher_assign_batch_device through the C ABI) over the rank's HBM-resident batch.
+Multi-GPU: reads shard across ranks with no data-path collective (weak scaling: every rank owns a
+full batch); the only collective is the final per-sample count all-reduce over RCCL.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config 3] [--reads R]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+Prints ONE JSON line on rank 0.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBPS = 8000.0   # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def cpu_baseline(workload, seconds: float):
+    """The oracle (literal C restatement of the reference algorithm, memo cache ON exactly as
+    demux.rs:925 drives it) on ONE host core, over a bounded prefix of the same synthetic workload."""
+    from oracle import oracle as O
+    cfg = workload.cfg
+    lit = O.RefLiteral(workload.barcodes, cfg.max_mismatches, cfg.min_mismatch_delta, True, native=True)
+    probe_n = 200_000
+    probe = workload.fill_host(0, probe_n)
+    t0 = time.perf_counter()
+    lit.assign_batch(probe)
+    probe_rate = probe_n / (time.perf_counter() - t0)
+    n = int(min(max(probe_rate * seconds, 1_000_000), 30_000_000))
+    # fresh matcher so the timed run starts with a cold memo cache, like a real demux run
+    lit = O.RefLiteral(workload.barcodes, cfg.max_mismatches, cfg.min_mismatch_delta, True, native=True)
+    chunk = 2_000_000
+    total_t = 0.0
+    done = 0
+    while done < n:
+        cur = min(chunk, n - done)
+        host = workload.fill_host(done, cur)       # generation is NOT timed
+        t0 = time.perf_counter()
+        lit.assign_batch(host)
+        total_t += time.perf_counter() - t0
+        done += cur
+    hits, misses = lit.cache_stats
+    return {
+        "value": round(done / total_t / 1e6, 4),
+        "unit": "M reads/s",
+        "cores": 1,
+        "kind": "port",
+        "sample": f"first {done} reads of the same synthetic workload, oracle/ref_literal.c (gcc -O3 "
+                  f"-march=native), memo cache on (hit rate {hits / max(hits + misses, 1):.3f}), "
+                  f"{total_t:.1f} s of CPU work; host has {os.cpu_count()} logical cores",
+    }
+
+
+def main() -> int:
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--config", type=int, default=3, help="BASELINE.json config id (1-5), default 3")
+    ap.add_argument("--reads", type=int, default=0, help="reads per rank per step (default: the config's N)")
+    ap.add_argument("--cpu-seconds", type=float, default=15.0, help="CPU-baseline budget (0 = skip)")
+    ap.add_argument("--no-verify", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    from fqtk_amd import BarcodeMatcher, synth
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", rank=rank, world_size=world)
+    if args.gpus != world and rank == 0 and world > 1:
+        print(f"warning: --gpus {args.gpus} != WORLD_SIZE {world}", file=sys.stderr)
+    if not torch.cuda.is_available():
+        print("bench.py needs a GPU: the matcher has no CPU fallback", file=sys.stderr)
+        return 2
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+
+    cfg = synth.CONFIGS[args.config]
+    n = args.reads or cfg.n_reads
+    workload = synth.Workload(cfg)
+    stream = torch.cuda.current_stream().cuda_stream
+
+    # ---- inputs resident in HBM before the timed region ------------------------------------------
+    d_obs = torch.empty((n, cfg.stride), dtype=torch.uint8, device=dev)
+    gen_chunk = 50_000_000
+    base = rank * n                                # every rank owns a distinct shard of the stream
+    for lo in range(0, n, gen_chunk):
+        cur = min(gen_chunk, n - lo)
+        workload.fill_device(base + lo, cur, d_obs.data_ptr() + lo * cfg.stride, stream)
+    d_out = torch.empty(n, dtype=torch.int32, device=dev)
+    d_counts = torch.zeros(cfg.n_samples + 1, dtype=torch.int64, device=dev)
+
+    matcher = BarcodeMatcher(workload.barcodes, cfg.max_mismatches, cfg.min_mismatch_delta, device=local_rank)
+
+    def step():
+        matcher.assign_batch_device(d_obs.data_ptr(), cfg.stride, n, d_out.data_ptr(), d_counts.data_ptr(),
+                                    stream=stream)
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    d_counts.zero_()
+
+    # ---- timed region: EXACTLY K steps, barrier + synchronize on both sides ------------------------
+    ev0 = torch.cuda.Event(enable_timing=True)
+    ev1 = torch.cuda.Event(enable_timing=True)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    ev0.record()
+    for _ in range(args.steps):
+        step()
+    ev1.record()                                   # same stream as the kernels
+    total_counts = d_counts
+    if world > 1:                                  # the one collective: per-sample counts over RCCL
+        total_counts = d_counts.clone()
+        dist.all_reduce(total_counts, op=dist.ReduceOp.SUM)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    kernel_ms = ev0.elapsed_time(ev1) / args.steps  # HIP events around the K launches, per launch
+    matcher.poll_error(stream)
+
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # ---- correctness gates outside the timed region -------------------------------------------------
+    counts_host = d_counts.cpu().numpy()
+    assert int(counts_host.sum()) == n * args.steps, "per-sample counts do not add up to reads x steps"
+    if world > 1:
+        assert int(total_counts.sum().item()) == n * args.steps * world
+    parity = None
+    if not args.no_verify and rank == 0:
+        from oracle import oracle as O
+        lit = O.RefLiteral(workload.barcodes, cfg.max_mismatches, cfg.min_mismatch_delta, True)
+        dt = np.dtype([("idx", "<u2"), ("best", "u1"), ("next", "u1")])
+        checked = 0
+        for start in (0, n // 2, max(n - 100_000, 0)):
+            m = min(100_000, n - start)
+            host = workload.fill_host(base + start, m)
+            i, b, nx, _ = lit.assign_batch(host)
+            got = d_out[start:start + m].cpu().numpy().view(dt)
+            ok = np.array_equal(got["idx"], i) and np.array_equal(got["best"], b) and np.array_equal(got["next"], nx)
+            assert ok, f"GPU results differ from the oracle in window starting at read {start}"
+            checked += m
+        parity = f"bit-exact vs oracle on {checked} reads (3 windows)"
+
+    if rank == 0:
+        reads_total = n * args.steps * world
+        value = reads_total / elapsed / 1e6
+        achieved = n * cfg.bytes_per_read / (kernel_ms * 1e-3) / 1e9
+        out = {
+            "metric": "M reads/sec demuxed (bit-exact assigns)",
+            "value": round(value, 2),
+            "unit": "M reads/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 4),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "u8",
+            "data": "synthetic",
+            "config": {
+                "workload": cfg.name,
+                "reads_per_gpu_per_step": n,
+                "samples": cfg.n_samples,
+                "barcode_len": cfg.barcode_len,
+                "max_mismatches": cfg.max_mismatches,
+                "min_mismatch_delta": cfg.min_mismatch_delta,
+                "sharding": f"reads sharded over {world} rank(s), table replicated, RCCL all-reduce of counts only",
+                "parity": parity,
+            },
+            "roofline": {
+                "bound": "hbm",
+                "kernel": "fqtk::match_kernel",
+                "achieved": round(achieved, 2),
+                "peak": HBM_PEAK_GBPS,
+                "unit": "GB/s",
+                "frac": round(achieved / HBM_PEAK_GBPS, 5),
+                "traffic": None,
+                "kernel_ms": round(kernel_ms, 4),
+                "algorithmic_bytes_per_read": cfg.bytes_per_read,
+            },
+        }
+        if world == 1 and args.cpu_seconds > 0:
+            out["cpu_baseline"] = cpu_baseline(workload, args.cpu_seconds)
+            out["cpu_baseline"]["gpu_over_cpu"] = round(value / out["cpu_baseline"]["value"], 1)
+        print(json.dumps(out), flush=True)
+
+    if world > 1:
+        dist.destroy_process_group()
+    return 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())

@@ -1,0 +1,67 @@
+"""ctypes binding of include/fqtk_match.h.  Fails loudly when the HIP library is missing."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "lib", "libfqtk_match.so")
+
+FQTK_OK, FQTK_EINVAL, FQTK_ELEN, FQTK_EHIP, FQTK_ENOMEM, FQTK_ENODEV = 0, 1, 2, 3, 4, 5
+FQTK_NO_MATCH = 0xFFFF
+FQTK_MAX_SLOTS = 8
+
+
+class fqtk_match_t(C.Structure):
+    _fields_ = [("idx", C.c_uint16), ("best", C.c_uint8), ("next", C.c_uint8)]
+
+
+_lib = None
+
+# (name, restype, argtypes) for EVERY symbol include/fqtk_match.h declares
+SIGNATURES = [
+    ("fqtk_last_error", C.c_char_p, []),
+    ("fqtk_abi_version", C.c_int, []),
+    ("fqtk_device_count", C.c_int, [C.POINTER(C.c_int)]),
+    ("fqtk_matcher_create", C.c_int, [C.POINTER(C.c_char_p), C.c_uint32, C.c_uint32, C.c_uint8,
+                                      C.c_uint8, C.c_int, C.POINTER(C.c_void_p)]),
+    ("fqtk_matcher_destroy", None, [C.c_void_p]),
+    ("fqtk_matcher_n_samples", C.c_uint32, [C.c_void_p]),
+    ("fqtk_matcher_barcode_len", C.c_uint32, [C.c_void_p]),
+    ("fqtk_matcher_max_ns_in_barcodes", C.c_uint32, [C.c_void_p]),
+    ("fqtk_matcher_device", C.c_int, [C.c_void_p]),
+    ("fqtk_matcher_assign_batch", C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p,
+                                            C.c_uint64, C.c_void_p, C.c_void_p]),
+    ("fqtk_matcher_assign_batch_device", C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p,
+                                                   C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p]),
+    ("fqtk_matcher_poll_error", C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(C.c_uint64)]),
+    ("fqtk_matcher_assign1", C.c_int, [C.c_void_p, C.c_char_p, C.c_uint32, C.POINTER(fqtk_match_t)]),
+    ("fqtk_pinned_alloc", C.c_int, [C.c_size_t, C.POINTER(C.c_void_p)]),
+    ("fqtk_pinned_free", C.c_int, [C.c_void_p]),
+    ("fqtk_matcher_enqueue", C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_uint32, C.c_void_p,
+                                       C.c_uint64, C.c_void_p]),
+    ("fqtk_matcher_wait", C.c_int, [C.c_void_p, C.c_int]),
+    ("fqtk_matcher_counts", C.c_int, [C.c_void_p, C.c_void_p]),
+]
+
+
+def load() -> C.CDLL:
+    """Loads libfqtk_match.so (the hand-written HIP product library).  No fallback of any kind."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} is missing: build it with `python -m fqtk_amd.build` (hipcc, gfx950). "
+            "fqtk_amd has no CPU fallback.")
+    lib = C.CDLL(LIB_PATH)
+    for name, res, args in SIGNATURES:
+        fn = getattr(lib, name)   # AttributeError if the symbol is not exported
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def last_error() -> str:
+    return load().fqtk_last_error().decode(errors="replace")

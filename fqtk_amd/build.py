@@ -1,0 +1,53 @@
+"""Builds the in-tree native libraries with hipcc for gfx950 (cross-compiles without a GPU).
+
+    python -m fqtk_amd.build            # build if stale
+    python -m fqtk_amd.build --force
+"""
+from __future__ import annotations
+
+import glob
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+LIBDIR = os.path.join(HERE, "lib")
+INCLUDE = os.path.join(os.path.dirname(HERE), "include")
+
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+ARCH = "gfx950"
+
+# name -> (sources, extra flags)
+TARGETS = {
+    "libfqtk_match.so": (["fqtk_match.hip"], []),
+    "libfqtk_synth.so": (["synth.hip"], []),
+}
+
+
+def _stale(out: str, deps) -> bool:
+    if not os.path.exists(out):
+        return True
+    t = os.path.getmtime(out)
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build(force: bool = False, verbose: bool = False) -> None:
+    os.makedirs(LIBDIR, exist_ok=True)
+    deps_common = glob.glob(os.path.join(CSRC, "*.h")) + glob.glob(os.path.join(INCLUDE, "*.h"))
+    for name, (srcs, extra) in TARGETS.items():
+        srcs_abs = [os.path.join(CSRC, s) for s in srcs]
+        if not all(os.path.exists(s) for s in srcs_abs):
+            continue
+        out = os.path.join(LIBDIR, name)
+        if not force and not _stale(out, srcs_abs + deps_common):
+            continue
+        cmd = [HIPCC, f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-shared", "-fPIC",
+               "-I", INCLUDE, "-o", out] + extra + srcs_abs
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.run(cmd, check=True)
+
+
+if __name__ == "__main__":
+    build(force="--force" in sys.argv, verbose=True)

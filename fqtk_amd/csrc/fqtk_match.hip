@@ -1,0 +1,473 @@
+// fqtk_match.hip -- C-ABI implementation (include/fqtk_match.h) over the gfx950 kernels.
+//
+// Host side of the drop-in boundary for the reference's BarcodeMatcher
+// (/root/reference/src/lib/barcode_matching.rs:29-186).  No CPU compute path exists here: table
+// preparation is host work (once per run, as in BarcodeMatcher::new :55-86); every assign goes to
+// the device.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "../../include/fqtk_match.h"
+#include "match_kernels.hip.h"
+
+namespace {
+
+thread_local std::string g_last_error;
+
+int fail(int code, const std::string &msg) {
+    g_last_error = msg;
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                       \
+    do {                                                                                    \
+        hipError_t _e = (expr);                                                             \
+        if (_e != hipSuccess) {                                                             \
+            return fail(FQTK_EHIP, std::string(#expr) + ": " + hipGetErrorString(_e));      \
+        }                                                                                   \
+    } while (0)
+
+// enc(): reference src/lib/mod.rs:26-61.  'N','n','.' -> 15 (checked before upper-casing), else the
+// IUPAC mask of the upper-cased byte, else 0.
+uint8_t enc_byte(uint8_t b) {
+    if (b == 'N' || b == 'n' || b == '.') return 15;
+    if (b >= 'a' && b <= 'z') b = (uint8_t)(b - 32);
+    switch (b) {
+        case 'A': return 1;
+        case 'C': return 2;
+        case 'G': return 4;
+        case 'T': return 8;
+        case 'U': return 8;
+        case 'M': return 3;
+        case 'R': return 5;
+        case 'W': return 9;
+        case 'S': return 6;
+        case 'Y': return 10;
+        case 'K': return 12;
+        case 'V': return 7;
+        case 'H': return 11;
+        case 'D': return 13;
+        case 'B': return 14;
+        default: return 0;
+    }
+}
+
+struct Slot {
+    hipStream_t stream = nullptr;
+    uint8_t *d_obs = nullptr;
+    size_t obs_cap = 0;
+    uint32_t *d_len = nullptr;
+    size_t len_cap = 0;  // elements
+    uint32_t *d_out = nullptr;
+    size_t out_cap = 0;  // elements
+    bool busy = false;
+};
+
+}  // namespace
+
+struct fqtk_matcher {
+    int device = 0;
+    uint32_t S = 0, L = 0, NW = 0;
+    uint32_t max_mm = 0, delta = 0, max_ns = 0;
+    int num_cus = 256;
+    uint32_t *d_table = nullptr;
+    uint32_t *d_lut = nullptr;
+    unsigned long long *d_err = nullptr;     // [0] min offending index, ~0 = none
+    unsigned long long *d_counts = nullptr;  // S+1, used by the host-pointer entry points
+    unsigned long long *h_err = nullptr;     // pinned mirror
+    Slot slots[FQTK_MAX_SLOTS];
+};
+
+namespace {
+
+template <typename T>
+int ensure_cap(T *&ptr, size_t &cap, size_t want) {
+    if (want <= cap) return FQTK_OK;
+    if (ptr) {
+        HIP_TRY(hipFree(ptr));
+        ptr = nullptr;
+        cap = 0;
+    }
+    size_t ncap = std::max(want, cap + cap / 2);
+    HIP_TRY(hipMalloc(reinterpret_cast<void **>(&ptr), ncap * sizeof(T)));
+    cap = ncap;
+    return FQTK_OK;
+}
+
+int ensure_slot(fqtk_matcher *m, int slot) {
+    if (slot < 0 || slot >= FQTK_MAX_SLOTS) return fail(FQTK_EINVAL, "slot out of range");
+    Slot &s = m->slots[slot];
+    if (!s.stream) HIP_TRY(hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking));
+    return FQTK_OK;
+}
+
+template <int NW, int R, int VEC>
+int launch_t(const fqtk::MatchParams &P, int num_cus, hipStream_t stream) {
+    const uint64_t tile = (uint64_t)fqtk::kBlock * R;
+    const uint64_t ntiles = (P.n + tile - 1) / tile;
+    if (ntiles == 0) return FQTK_OK;
+    // persistent-ish grid: enough workgroups to fill every CU at full occupancy, grid-stride beyond
+    const uint64_t max_blocks = (uint64_t)num_cus * 8;
+    const uint32_t grid = (uint32_t)std::min<uint64_t>(ntiles, max_blocks);
+    size_t shmem = 256 * sizeof(uint32_t);
+    if (P.counts && P.lds_hist) shmem += (size_t)(P.S + 1) * sizeof(uint32_t);
+    hipLaunchKernelGGL((fqtk::match_kernel<NW, R, VEC>), dim3(grid), dim3(fqtk::kBlock), shmem, stream, P);
+    HIP_TRY(hipGetLastError());
+    return FQTK_OK;
+}
+
+template <int NW, int R>
+int launch_vec(const fqtk::MatchParams &P, int num_cus, hipStream_t stream) {
+    const uintptr_t base = reinterpret_cast<uintptr_t>(P.obs);
+    const uint32_t nwords = (P.L + 3) / 4;
+    if (P.stride % 4 == 0 && base % 4 == 0 && P.stride >= nwords * 4) {
+        const uint32_t sw = P.stride / 4;
+        if (sw == nwords) {  // the read fills its slot: one vector load per read
+            if (sw == 4 && base % 16 == 0) return launch_t<NW, R, 4>(P, num_cus, stream);
+            if (sw == 2 && base % 8 == 0) return launch_t<NW, R, 2>(P, num_cus, stream);
+            if (sw == 1) return launch_t<NW, R, 1>(P, num_cus, stream);
+            if (sw == 3) return launch_t<NW, R, 3>(P, num_cus, stream);
+        }
+        return launch_t<NW, R, -1>(P, num_cus, stream);
+    }
+    return launch_t<NW, R, 0>(P, num_cus, stream);
+}
+
+int launch(const fqtk_matcher *m, const fqtk::MatchParams &P, hipStream_t stream) {
+    switch (m->NW) {
+        case 1: return launch_vec<1, 4>(P, m->num_cus, stream);
+        case 2: return launch_vec<2, 2>(P, m->num_cus, stream);
+        case 3: return launch_vec<3, 1>(P, m->num_cus, stream);
+        case 4: return launch_vec<4, 1>(P, m->num_cus, stream);
+        default: return fail(FQTK_EINVAL, "unsupported barcode length");
+    }
+}
+
+fqtk::MatchParams make_params(const fqtk_matcher *m, const void *d_obs, uint32_t stride,
+                              const void *d_len, uint64_t n, void *d_out, void *d_counts) {
+    fqtk::MatchParams P;
+    P.obs = static_cast<const uint8_t *>(d_obs);
+    P.lens = static_cast<const uint32_t *>(d_len);
+    P.out = static_cast<uint32_t *>(d_out);
+    P.counts = static_cast<unsigned long long *>(d_counts);
+    P.table = m->d_table;
+    P.lut = m->d_lut;
+    P.err = m->d_err;
+    P.n = n;
+    P.stride = stride;
+    P.S = m->S;
+    P.L = m->L;
+    P.max_mm = m->max_mm;
+    P.delta = m->delta;
+    P.nocall_limit = m->max_mm + m->max_ns;
+    P.lds_hist = (m->S + 1 <= fqtk::kMaxLdsHist) ? 1u : 0u;
+    return P;
+}
+
+int check_batch_args(const fqtk_matcher *m, const void *obs, uint32_t stride, const void *lens,
+                     uint64_t n, const void *out) {
+    if (!m) return fail(FQTK_EINVAL, "matcher is NULL");
+    if (n == 0) return FQTK_OK;
+    if (!obs || !out) return fail(FQTK_EINVAL, "obs/out is NULL");
+    if (!lens && stride < m->L)
+        return fail(FQTK_EINVAL, "stride < barcode_len and no obs_len given");
+    if (stride == 0) return fail(FQTK_EINVAL, "stride is 0");
+    return FQTK_OK;
+}
+
+// Reads + clears the latched error word.  Stream must be idle for the value to be final.
+int collect_error(fqtk_matcher *m, hipStream_t stream, uint64_t *read_index) {
+    HIP_TRY(hipMemcpyAsync(m->h_err, m->d_err, sizeof(unsigned long long), hipMemcpyDeviceToHost, stream));
+    HIP_TRY(hipStreamSynchronize(stream));
+    const unsigned long long e = *m->h_err;
+    if (e == ~0ull) return FQTK_OK;
+    HIP_TRY(hipMemsetAsync(m->d_err, 0xFF, sizeof(unsigned long long), stream));
+    HIP_TRY(hipStreamSynchronize(stream));
+    if (read_index) *read_index = (uint64_t)e;
+    char buf[160];
+    std::snprintf(buf, sizeof buf,
+                  "Read barcode length differs from expected barcode length (%u): read index %llu is longer",
+                  m->L, e);
+    return fail(FQTK_ELEN, buf);
+}
+
+}  // namespace
+
+extern "C" {
+
+const char *fqtk_last_error(void) { return g_last_error.c_str(); }
+
+int fqtk_abi_version(void) { return 1; }
+
+int fqtk_device_count(int *n_devices) {
+    if (!n_devices) return fail(FQTK_EINVAL, "n_devices is NULL");
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        n = 0;
+    }
+    *n_devices = n;
+    return FQTK_OK;
+}
+
+int fqtk_matcher_create(const char *const *barcodes, uint32_t n_samples, uint32_t barcode_len,
+                        uint8_t max_mismatches, uint8_t min_mismatch_delta, int device,
+                        fqtk_matcher **out) {
+    if (!out) return fail(FQTK_EINVAL, "out is NULL");
+    *out = nullptr;
+    // barcode_matching.rs:61-65
+    if (n_samples == 0 || !barcodes) return fail(FQTK_EINVAL, "Must provide at least one sample");
+    if (n_samples > FQTK_MAX_SAMPLES) return fail(FQTK_EINVAL, "too many samples (max 65534)");
+    for (uint32_t s = 0; s < n_samples; ++s)
+        if (!barcodes[s] || barcodes[s][0] == '\0')
+            return fail(FQTK_EINVAL, "Sample barcode cannot be empty string");
+    if (barcode_len == 0) return fail(FQTK_EINVAL, "Sample barcode cannot be empty string");
+    if (barcode_len > FQTK_MAX_BARCODE_LEN)
+        return fail(FQTK_EINVAL, "barcode_len > 128 is not supported");
+    for (uint32_t s = 0; s < n_samples; ++s)
+        if (std::strlen(barcodes[s]) != barcode_len)
+            return fail(FQTK_EINVAL, "All barcodes must have the same length");  // samples.rs:117-122
+
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
+        (void)hipGetLastError();
+        return fail(FQTK_ENODEV, "no HIP device available (this library has no CPU fallback)");
+    }
+    if (device < 0 || device >= ndev) return fail(FQTK_ENODEV, "device index out of range");
+    HIP_TRY(hipSetDevice(device));
+
+    fqtk_matcher *m = new (std::nothrow) fqtk_matcher();
+    if (!m) return fail(FQTK_ENOMEM, "out of host memory");
+    m->device = device;
+    m->S = n_samples;
+    m->L = barcode_len;
+    m->NW = (barcode_len + 31) / 32;
+    m->max_mm = max_mismatches;
+    m->delta = min_mismatch_delta;
+
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0)
+        m->num_cus = prop.multiProcessorCount;
+
+    // Table: upper-case (:71), count no-calls (:73-74), encode (:75); stored as PRE-INVERTED
+    // bit-planes [S][NW][4] so the kernel's inner op is (o & ~e) with no NOT.
+    std::vector<uint32_t> table((size_t)n_samples * m->NW * 4, 0u);
+    uint32_t max_ns = 0;
+    for (uint32_t s = 0; s < n_samples; ++s) {
+        uint32_t ns = 0;
+        for (uint32_t i = 0; i < barcode_len; ++i) {
+            uint8_t b = (uint8_t)barcodes[s][i];
+            if (b >= 'a' && b <= 'z') b = (uint8_t)(b - 32);
+            if (b == 'N' || b == 'n' || b == '.') ns++;
+            const uint8_t e = enc_byte(b);
+            const uint32_t w = i / 32, bit = i % 32;
+            for (uint32_t j = 0; j < 4; ++j)
+                if (!((e >> j) & 1u)) table[((size_t)s * m->NW + w) * 4 + j] |= (1u << bit);
+        }
+        max_ns = std::max(max_ns, ns);
+    }
+    m->max_ns = max_ns;
+
+    std::vector<uint32_t> lut(256);
+    for (int b = 0; b < 256; ++b) {
+        const uint32_t e = enc_byte((uint8_t)b);
+        lut[b] = (e & 1u) | (((e >> 1) & 1u) << 8) | (((e >> 2) & 1u) << 16) | (((e >> 3) & 1u) << 24);
+    }
+
+    auto cleanup = [&](int code) {
+        fqtk_matcher_destroy(m);
+        return code;
+    };
+#define HIP_TRY_C(expr)                                                                      \
+    do {                                                                                     \
+        hipError_t _e = (expr);                                                              \
+        if (_e != hipSuccess) {                                                              \
+            return cleanup(fail(FQTK_EHIP, std::string(#expr) + ": " + hipGetErrorString(_e))); \
+        }                                                                                    \
+    } while (0)
+    HIP_TRY_C(hipMalloc(reinterpret_cast<void **>(&m->d_table), table.size() * sizeof(uint32_t)));
+    HIP_TRY_C(hipMemcpy(m->d_table, table.data(), table.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+    HIP_TRY_C(hipMalloc(reinterpret_cast<void **>(&m->d_lut), 256 * sizeof(uint32_t)));
+    HIP_TRY_C(hipMemcpy(m->d_lut, lut.data(), 256 * sizeof(uint32_t), hipMemcpyHostToDevice));
+    HIP_TRY_C(hipMalloc(reinterpret_cast<void **>(&m->d_err), sizeof(unsigned long long)));
+    HIP_TRY_C(hipMemset(m->d_err, 0xFF, sizeof(unsigned long long)));
+    HIP_TRY_C(hipMalloc(reinterpret_cast<void **>(&m->d_counts), (size_t)(n_samples + 1) * sizeof(unsigned long long)));
+    HIP_TRY_C(hipMemset(m->d_counts, 0, (size_t)(n_samples + 1) * sizeof(unsigned long long)));
+    HIP_TRY_C(hipHostMalloc(reinterpret_cast<void **>(&m->h_err), sizeof(unsigned long long), hipHostMallocDefault));
+    *m->h_err = ~0ull;
+#undef HIP_TRY_C
+    *out = m;
+    return FQTK_OK;
+}
+
+void fqtk_matcher_destroy(fqtk_matcher *m) {
+    if (!m) return;
+    (void)hipSetDevice(m->device);
+    for (Slot &s : m->slots) {
+        if (s.stream) {
+            (void)hipStreamSynchronize(s.stream);
+            (void)hipStreamDestroy(s.stream);
+        }
+        if (s.d_obs) (void)hipFree(s.d_obs);
+        if (s.d_len) (void)hipFree(s.d_len);
+        if (s.d_out) (void)hipFree(s.d_out);
+    }
+    if (m->d_table) (void)hipFree(m->d_table);
+    if (m->d_lut) (void)hipFree(m->d_lut);
+    if (m->d_err) (void)hipFree(m->d_err);
+    if (m->d_counts) (void)hipFree(m->d_counts);
+    if (m->h_err) (void)hipHostFree(m->h_err);
+    delete m;
+}
+
+uint32_t fqtk_matcher_n_samples(const fqtk_matcher *m) { return m ? m->S : 0; }
+uint32_t fqtk_matcher_barcode_len(const fqtk_matcher *m) { return m ? m->L : 0; }
+uint32_t fqtk_matcher_max_ns_in_barcodes(const fqtk_matcher *m) { return m ? m->max_ns : 0; }
+int fqtk_matcher_device(const fqtk_matcher *m) { return m ? m->device : -1; }
+
+int fqtk_matcher_assign_batch_device(fqtk_matcher *m, const void *d_obs, uint32_t stride,
+                                     const void *d_obs_len, uint64_t n, void *d_out, void *d_counts,
+                                     void *hip_stream) {
+    int rc = check_batch_args(m, d_obs, stride, d_obs_len, n, d_out);
+    if (rc != FQTK_OK || n == 0) return rc;
+    HIP_TRY(hipSetDevice(m->device));
+    const fqtk::MatchParams P = make_params(m, d_obs, stride, d_obs_len, n, d_out, d_counts);
+    return launch(m, P, static_cast<hipStream_t>(hip_stream));
+}
+
+int fqtk_matcher_poll_error(fqtk_matcher *m, void *hip_stream, uint64_t *read_index) {
+    if (!m) return fail(FQTK_EINVAL, "matcher is NULL");
+    HIP_TRY(hipSetDevice(m->device));
+    return collect_error(m, static_cast<hipStream_t>(hip_stream), read_index);
+}
+
+int fqtk_matcher_enqueue(fqtk_matcher *m, int slot, const uint8_t *obs, uint32_t stride,
+                         const uint32_t *obs_len, uint64_t n, fqtk_match_t *out) {
+    int rc = check_batch_args(m, obs, stride, obs_len, n, out);
+    if (rc != FQTK_OK) return rc;
+    HIP_TRY(hipSetDevice(m->device));
+    rc = ensure_slot(m, slot);
+    if (rc != FQTK_OK) return rc;
+    Slot &s = m->slots[slot];
+    if (s.busy) return fail(FQTK_EINVAL, "slot is busy: call fqtk_matcher_wait() first");
+    if (n == 0) return FQTK_OK;
+    const size_t obs_bytes = (size_t)n * stride;
+    if ((rc = ensure_cap(s.d_obs, s.obs_cap, obs_bytes + 16)) != FQTK_OK) return rc;
+    if ((rc = ensure_cap(s.d_out, s.out_cap, (size_t)n)) != FQTK_OK) return rc;
+    if (obs_len && (rc = ensure_cap(s.d_len, s.len_cap, (size_t)n)) != FQTK_OK) return rc;
+    HIP_TRY(hipMemcpyAsync(s.d_obs, obs, obs_bytes, hipMemcpyHostToDevice, s.stream));
+    if (obs_len)
+        HIP_TRY(hipMemcpyAsync(s.d_len, obs_len, (size_t)n * sizeof(uint32_t), hipMemcpyHostToDevice, s.stream));
+    const fqtk::MatchParams P =
+        make_params(m, s.d_obs, stride, obs_len ? s.d_len : nullptr, n, s.d_out, m->d_counts);
+    rc = launch(m, P, s.stream);
+    if (rc != FQTK_OK) return rc;
+    HIP_TRY(hipMemcpyAsync(out, s.d_out, (size_t)n * sizeof(fqtk_match_t), hipMemcpyDeviceToHost, s.stream));
+    s.busy = true;
+    return FQTK_OK;
+}
+
+int fqtk_matcher_wait(fqtk_matcher *m, int slot) {
+    if (!m) return fail(FQTK_EINVAL, "matcher is NULL");
+    if (slot < 0 || slot >= FQTK_MAX_SLOTS) return fail(FQTK_EINVAL, "slot out of range");
+    Slot &s = m->slots[slot];
+    if (!s.busy) return FQTK_OK;
+    HIP_TRY(hipSetDevice(m->device));
+    HIP_TRY(hipStreamSynchronize(s.stream));
+    s.busy = false;
+    return collect_error(m, s.stream, nullptr);
+}
+
+int fqtk_matcher_counts(fqtk_matcher *m, uint64_t *counts) {
+    if (!m || !counts) return fail(FQTK_EINVAL, "NULL argument");
+    HIP_TRY(hipSetDevice(m->device));
+    for (Slot &s : m->slots)
+        if (s.stream) HIP_TRY(hipStreamSynchronize(s.stream));
+    const size_t bins = (size_t)m->S + 1;
+    std::vector<unsigned long long> tmp(bins);
+    HIP_TRY(hipMemcpy(tmp.data(), m->d_counts, bins * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemset(m->d_counts, 0, bins * sizeof(unsigned long long)));
+    for (size_t b = 0; b < bins; ++b) counts[b] += (uint64_t)tmp[b];
+    return FQTK_OK;
+}
+
+int fqtk_matcher_assign_batch(fqtk_matcher *m, const uint8_t *obs, uint32_t stride,
+                              const uint32_t *obs_len, uint64_t n, fqtk_match_t *out,
+                              uint64_t *counts) {
+    int rc = check_batch_args(m, obs, stride, obs_len, n, out);
+    if (rc != FQTK_OK || n == 0) return rc;
+    // Chunk so staging stays bounded, ping-pong over two slots so copy and compute overlap.
+    const uint64_t chunk = std::max<uint64_t>(1, std::min<uint64_t>(n, (256ull << 20) / stride));
+    int first_err = FQTK_OK;
+    std::string first_msg;
+    uint64_t done = 0;
+    int k = 0;
+    uint64_t pending_base[2] = {0, 0};
+    auto drain = [&](int slot) {
+        int w = fqtk_matcher_wait(m, slot);
+        if (w != FQTK_OK && first_err == FQTK_OK) {
+            first_err = w;
+            first_msg = g_last_error;
+            if (w == FQTK_ELEN) first_msg += " (chunk base " + std::to_string(pending_base[slot]) + ")";
+        }
+    };
+    while (done < n) {
+        const int slot = k & 1;
+        drain(slot);
+        const uint64_t cur = std::min(chunk, n - done);
+        pending_base[slot] = done;
+        rc = fqtk_matcher_enqueue(m, slot, obs + done * stride, stride, obs_len ? obs_len + done : nullptr,
+                                  cur, out + done);
+        if (rc != FQTK_OK) {
+            drain(0);
+            drain(1);
+            return rc;
+        }
+        done += cur;
+        ++k;
+    }
+    drain(0);
+    drain(1);
+    if (counts) {
+        rc = fqtk_matcher_counts(m, counts);
+        if (rc != FQTK_OK) return rc;
+    } else {
+        HIP_TRY(hipMemset(m->d_counts, 0, ((size_t)m->S + 1) * sizeof(unsigned long long)));
+    }
+    if (first_err != FQTK_OK) return fail(first_err, first_msg);
+    return FQTK_OK;
+}
+
+int fqtk_matcher_assign1(fqtk_matcher *m, const uint8_t *read_bases, uint32_t len, fqtk_match_t *out) {
+    if (!m || !out) return fail(FQTK_EINVAL, "NULL argument");
+    if (len == 0 || !read_bases) {  // barcode_matching.rs:167-169: shorter than expected -> None
+        out->idx = FQTK_NO_MATCH;
+        out->best = 255;
+        out->next = 255;
+        return FQTK_OK;
+    }
+    const uint32_t l = len;
+    return fqtk_matcher_assign_batch(m, read_bases, len, &l, 1, out, nullptr);
+}
+
+int fqtk_pinned_alloc(size_t bytes, void **out) {
+    if (!out) return fail(FQTK_EINVAL, "out is NULL");
+    *out = nullptr;
+    HIP_TRY(hipHostMalloc(out, bytes ? bytes : 1, hipHostMallocDefault));
+    return FQTK_OK;
+}
+
+int fqtk_pinned_free(void *p) {
+    if (!p) return FQTK_OK;
+    HIP_TRY(hipHostFree(p));
+    return FQTK_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,303 @@
+// match_kernels.hip.h -- gfx950 (CDNA4) device code of the sample-barcode matcher.
+//
+// What it computes (bit-exact with the reference):
+//   reference src/lib/mod.rs:49-61 (encode), src/lib/bitenc.rs:432-459 (hamming = AND-NOT + count
+//   of non-zero nibbles), src/lib/barcode_matching.rs:119-186 (best / next-best / decision).
+//
+// How (MI355X-first, nothing here is a translation of the Rust):
+//   * one LANE per read; the expected-barcode table is WAVE-UNIFORM, so it is fetched with scalar
+//     loads (s_load_dwordxN through the scalar cache) and used as SGPR operands of the VALU ops --
+//     no LDS traffic, no cross-lane reduction, no divergence in the inner loop;
+//   * observed barcodes are transposed once per read into 4 BIT-PLANES (A,C,G,T; bit i = base i),
+//     the table holds the PRE-INVERTED planes, so a mismatch word for <=32 bases is
+//         m = (oA & ~eA) | (oC & ~eC) | (oG & ~eG) | (oT & ~eT)    (1 v_and_b32 + 3 v_and_or_b32)
+//     and the mismatch count is one v_bcnt_u32_b32 -- 5 VALU per (read, sample, 32 bases) instead of
+//     the reference's 8-iteration nibble scan per u32 block;
+//   * best/next-best are tracked as packed keys (mm << 16 | sample) so "lowest index wins" and
+//     "next == best on ties" fall out of integer min / med3 (v_min_u32 + v_med3_u32);
+//   * ASCII -> plane bits goes through a 256-entry LDS LUT (1 KiB) whose entries carry the 4 plane
+//     bits in 4 separate bytes, so 8 bases accumulate with one v_lshl_or_b32 each;
+//   * per-sample counts: LDS histogram per workgroup, flushed with one global atomic per non-empty
+//     bin per workgroup.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace fqtk {
+
+constexpr int kBlock = 256;          // 4 waves; launch_bounds lets the allocator use <=64 VGPRs
+constexpr uint32_t kNoMatch = 0xFFFFu;
+constexpr uint32_t kKeyInit = 0x00FFFFFFu;  // mm = 255, idx = 0xFFFF: larger than any real key
+constexpr uint32_t kMaxLdsHist = 8192;      // bins; above this counts go straight to global atomics
+
+struct MatchParams {
+    const uint8_t *obs;          // n x stride ASCII
+    const uint32_t *lens;        // nullable
+    uint32_t *out;               // n x fqtk_match_t
+    unsigned long long *counts;  // nullable, S+1
+    const uint32_t *table;       // [S][NW][4] pre-inverted planes (A,C,G,T), bits >= L cleared
+    const uint32_t *lut;         // [256] spread LUT (bit0 A, bit8 C, bit16 G, bit24 T)
+    unsigned long long *err;     // [0]: min offending read index (init ~0ull)
+    uint64_t n;
+    uint32_t stride;
+    uint32_t S;
+    uint32_t L;
+    uint32_t max_mm;
+    uint32_t delta;
+    uint32_t nocall_limit;       // max_mismatches + max_ns_in_barcodes (barcode_matching.rs:171)
+    uint32_t lds_hist;           // 1: histogram in LDS, 0: global atomics
+};
+
+__device__ __forceinline__ uint32_t med3_u32(uint32_t a, uint32_t b, uint32_t c) {
+    uint32_t d;
+    asm("v_med3_u32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+    return d;
+}
+
+// Observed barcode of one read as bit-planes: pl[w][j], w = 32-base word, j = A,C,G,T.
+template <int NW>
+struct Planes {
+    uint32_t p[NW][4];
+};
+
+// Accumulate the 4 bases held in one dword of ASCII into `acc` (8 bases per accumulator).
+// lut entries: plane bit j of the base in byte j, so (entry << k) lands base k of this group.
+template <int BASE_IN_GROUP>
+__device__ __forceinline__ void add4(uint32_t word, const uint32_t *lds_lut, uint32_t &acc) {
+    uint32_t b0 = word & 0xFFu, b1 = (word >> 8) & 0xFFu, b2 = (word >> 16) & 0xFFu, b3 = word >> 24;
+    acc = (lds_lut[b0] << (BASE_IN_GROUP + 0)) | acc;
+    acc = (lds_lut[b1] << (BASE_IN_GROUP + 1)) | acc;
+    acc = (lds_lut[b2] << (BASE_IN_GROUP + 2)) | acc;
+    acc = (lds_lut[b3] << (BASE_IN_GROUP + 3)) | acc;
+}
+
+// Gather byte `J` of four 8-base accumulators into one 32-base plane word.
+template <int J>
+__device__ __forceinline__ uint32_t gather_plane(uint32_t a0, uint32_t a1, uint32_t a2, uint32_t a3) {
+    // v_perm_b32: selector bytes 0-3 pick from the 2nd operand, 4-7 from the 1st, 0x0c = 0x00
+    constexpr uint32_t lo_sel = 0x0c0c0000u | ((4u + J) << 8) | (uint32_t)J;
+    constexpr uint32_t hi_sel = 0x00000c0cu | ((4u + J) << 24) | ((uint32_t)J << 16);
+    return __builtin_amdgcn_perm(a1, a0, lo_sel) | __builtin_amdgcn_perm(a3, a2, hi_sel);
+}
+
+// words[] = the read's ASCII as dwords (little-endian), nwords = ceil(L/4) (wave-uniform).
+template <int NW>
+__device__ __forceinline__ void encode_planes(const uint32_t *words, uint32_t nwords, uint32_t L,
+                                              const uint32_t *lds_lut, Planes<NW> &o) {
+#pragma unroll
+    for (int w = 0; w < NW; ++w) {
+        uint32_t a[4] = {0u, 0u, 0u, 0u};
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int dw = w * 8 + g * 2;
+            if ((uint32_t)dw < nwords) add4<0>(words[dw], lds_lut, a[g]);
+            if ((uint32_t)dw + 1 < nwords) add4<4>(words[dw + 1], lds_lut, a[g]);
+        }
+        // bases >= L inside the last dword are padding: clear them
+        const int rem = (int)L - w * 32;
+        const uint32_t keep = rem >= 32 ? 0xFFFFFFFFu : (rem <= 0 ? 0u : ((1u << rem) - 1u));
+        o.p[w][0] = gather_plane<0>(a[0], a[1], a[2], a[3]) & keep;
+        o.p[w][1] = gather_plane<1>(a[0], a[1], a[2], a[3]) & keep;
+        o.p[w][2] = gather_plane<2>(a[0], a[1], a[2], a[3]) & keep;
+        o.p[w][3] = gather_plane<3>(a[0], a[1], a[2], a[3]) & keep;
+    }
+}
+
+// Load the first ceil(L/4) dwords of read `i`.  VEC = stride in dwords when the fast, aligned vector
+// path applies (1,2,3,4), 0 = generic byte path (any stride / alignment).
+template <int NW, int VEC>
+__device__ __forceinline__ void load_words(const MatchParams &P, uint64_t i, uint32_t nwords,
+                                           uint32_t (&words)[NW * 8]) {
+    const uint8_t *src = P.obs + i * (uint64_t)P.stride;
+    if constexpr (VEC == 4) {
+        const uint4 v = *reinterpret_cast<const uint4 *>(src);
+        words[0] = v.x; words[1] = v.y; words[2] = v.z; words[3] = v.w;
+    } else if constexpr (VEC == 2) {
+        const uint2 v = *reinterpret_cast<const uint2 *>(src);
+        words[0] = v.x; words[1] = v.y;
+    } else if constexpr (VEC == 1) {
+        words[0] = *reinterpret_cast<const uint32_t *>(src);
+    } else if constexpr (VEC == 3) {
+        const uint32_t *s32 = reinterpret_cast<const uint32_t *>(src);
+        words[0] = s32[0]; words[1] = s32[1]; words[2] = s32[2];
+    } else if constexpr (VEC == -1) {   // stride % 4 == 0, base 4-aligned, any length
+#pragma unroll
+        for (int w = 0; w < NW * 8; ++w)
+            if ((uint32_t)w < nwords) words[w] = reinterpret_cast<const uint32_t *>(src)[w];
+    } else {
+#pragma unroll
+        for (int w = 0; w < NW * 8; ++w) {
+            if ((uint32_t)w < nwords) {
+                uint32_t x = 0;
+#pragma unroll
+                for (int b = 0; b < 4; ++b) {
+                    const uint32_t k = (uint32_t)w * 4 + b;
+                    if (k < P.L) x |= (uint32_t)src[k] << (8 * b);
+                }
+                words[w] = x;
+            }
+        }
+    }
+}
+
+// Expected-barcode table viewed through the CONSTANT address space: loads with a wave-uniform
+// address become s_load_dwordxN (scalar cache -> SGPRs) regardless of the stores the kernel makes.
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef const __attribute__((address_space(4))) u32x4 *const_u32x4_ptr;
+
+template <int NW, int G>
+struct SampleGroup {
+    u32x4 e[G][NW];   // [sample in group][32-base word] = {~A, ~C, ~G, ~T} planes
+    __device__ __forceinline__ void load(const_u32x4_ptr tab, uint32_t s0) {
+#pragma unroll
+        for (int q = 0; q < G; ++q)
+#pragma unroll
+            for (int w = 0; w < NW; ++w) e[q][w] = tab[(size_t)(s0 + q) * NW + w];
+    }
+};
+
+// One (read, sample) step: mismatch count over all words, then fold the packed key into the
+// running (best, second) pair: 4*NW logic ops + NW v_bcnt + v_lshl_or + v_med3 + v_min.
+// The logic chain and the key are written as single-instruction asm statements so that (a) the table
+// words stay SGPR operands (one constant-bus read per VALU op) and (b) the OR of four ANDs is the
+// 4-op v_and / v_and_or chain, not the 5-op tree the optimiser prefers.  They are not volatile: the
+// scheduler still interleaves the R independent chains of a lane.
+__device__ __forceinline__ uint32_t v_and_sv(uint32_t s, uint32_t v) {
+    uint32_t d;
+    asm("v_and_b32 %0, %1, %2" : "=v"(d) : "s"(s), "v"(v));
+    return d;
+}
+__device__ __forceinline__ uint32_t v_and_or_vsv(uint32_t v, uint32_t s, uint32_t acc) {
+    uint32_t d;
+    asm("v_and_or_b32 %0, %1, %2, %3" : "=v"(d) : "v"(v), "s"(s), "v"(acc));
+    return d;
+}
+__device__ __forceinline__ uint32_t v_lshl_or_vs(uint32_t v, uint32_t s) {
+    uint32_t d;
+    asm("v_lshl_or_b32 %0, %1, 16, %2" : "=v"(d) : "v"(v), "s"(s));
+    return d;
+}
+
+template <int NW>
+__device__ __forceinline__ void update(const Planes<NW> &o, const u32x4 (&e)[NW], uint32_t s,
+                                       uint32_t &best, uint32_t &second) {
+    uint32_t mm = 0;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) {
+        uint32_t m = v_and_sv(e[w].x, o.p[w][0]);
+        m = v_and_or_vsv(o.p[w][1], e[w].y, m);
+        m = v_and_or_vsv(o.p[w][2], e[w].z, m);
+        m = v_and_or_vsv(o.p[w][3], e[w].w, m);
+        mm += __builtin_popcount(m);
+    }
+    const uint32_t key = v_lshl_or_vs(mm, s);
+    second = med3_u32(best, second, key);
+    best = min(best, key);
+}
+
+__device__ __forceinline__ bool byte_is_nocall(uint8_t b) { return b == 'N' || b == 'n' || b == '.'; }
+
+// The kernel.  NW = 32-base words per plane (L <= 32*NW), R = reads per lane (amortises the scalar
+// table loads), VEC = load path (see load_words).
+template <int NW, int R, int VEC>
+__global__ __launch_bounds__(kBlock) void match_kernel(const MatchParams P) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
+    uint32_t *lds_lut = smem;          // 256 entries
+    uint32_t *lds_hist = smem + 256;   // S+1 entries when P.lds_hist
+
+    const uint32_t tid = threadIdx.x;
+    lds_lut[tid] = P.lut[tid];
+    const uint32_t bins = P.S + 1;
+    if (P.counts && P.lds_hist)
+        for (uint32_t b = tid; b < bins; b += kBlock) lds_hist[b] = 0;
+    __syncthreads();
+
+    const uint32_t nwords = (P.L + 3u) >> 2;
+    const const_u32x4_ptr tab = (const_u32x4_ptr)(uintptr_t)P.table;
+    const uint64_t tile = (uint64_t)kBlock * R;
+    const uint64_t ntiles = (P.n + tile - 1) / tile;
+
+    for (uint64_t t = blockIdx.x; t < ntiles; t += gridDim.x) {
+        Planes<NW> o[R];
+        bool live[R];
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const uint64_t i = t * tile + (uint64_t)r * kBlock + tid;
+            live[r] = i < P.n;
+            uint32_t words[NW * 8];
+#pragma unroll
+            for (int w = 0; w < NW * 8; ++w) words[w] = 0;
+            if (live[r]) load_words<NW, VEC>(P, i, nwords, words);
+            encode_planes<NW>(words, nwords, P.L, lds_lut, o[r]);
+        }
+
+        uint32_t best[R], second[R];
+#pragma unroll
+        for (int r = 0; r < R; ++r) best[r] = second[r] = kKeyInit;
+
+        // ---- hot loop: S samples x R reads, table operands are wave-uniform (SGPR) -------------
+        // Samples go in groups of G (16 dwords = one s_load_dwordx16); the next group's scalar load
+        // is issued before the current group's VALU work so SMEM latency hides under it.
+        constexpr int G = NW == 1 ? 4 : (NW == 2 ? 2 : 1);
+        const uint32_t ngroups = P.S / G;
+        SampleGroup<NW, G> cur, nxt;
+        if (ngroups) cur.load(tab, 0);
+        for (uint32_t g = 0; g < ngroups; ++g) {
+            if (g + 1 < ngroups) nxt.load(tab, (g + 1) * G);
+#pragma unroll
+            for (int q = 0; q < G; ++q) {
+                const uint32_t s = g * G + q;
+#pragma unroll
+                for (int r = 0; r < R; ++r) update<NW>(o[r], cur.e[q], s, best[r], second[r]);
+            }
+            cur = nxt;
+        }
+        for (uint32_t s = ngroups * G; s < P.S; ++s) {   // S % G tail
+            SampleGroup<NW, 1> one;
+            one.load(tab, s);
+#pragma unroll
+            for (int r = 0; r < R; ++r) update<NW>(o[r], one.e[0], s, best[r], second[r]);
+        }
+
+        // ---- decision (barcode_matching.rs:150-159) + length rules (:165-172) ------------------
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            if (!live[r]) continue;
+            const uint64_t i = t * tile + (uint64_t)r * kBlock + tid;
+            const uint32_t bm = best[r] >> 16;
+            const uint32_t nm = second[r] >> 16;
+            bool none = bm > P.max_mm || (nm - bm) < P.delta;
+            if (P.lens) {
+                const uint32_t len = P.lens[i];
+                if (len < P.L) {
+                    none = true;
+                } else if (len > P.L) {
+                    // the reference counts no-calls over the WHOLE read before it can panic
+                    const uint8_t *src = P.obs + i * (uint64_t)P.stride;
+                    uint32_t nc = 0;
+                    for (uint32_t k = 0; k < len; ++k) nc += byte_is_nocall(src[k]) ? 1u : 0u;
+                    none = true;
+                    if (nc <= P.nocall_limit) atomicMin(P.err, (unsigned long long)i);
+                }
+            }
+            const uint32_t idx = none ? kNoMatch : (best[r] & 0xFFFFu);
+            const uint32_t res = none ? 0xFFFFFFFFu : (idx | (bm << 16) | (nm << 24));
+            P.out[i] = res;
+            if (P.counts) {
+                const uint32_t bin = none ? P.S : idx;
+                if (P.lds_hist) atomicAdd(&lds_hist[bin], 1u);
+                else atomicAdd(&P.counts[bin], 1ull);
+            }
+        }
+    }
+
+    if (P.counts && P.lds_hist) {
+        __syncthreads();
+        for (uint32_t b = tid; b < bins; b += kBlock) {
+            const uint32_t c = lds_hist[b];
+            if (c) atomicAdd(&P.counts[b], (unsigned long long)c);
+        }
+    }
+}
+
+}  // namespace fqtk

@@ -1,0 +1,145 @@
+/*
+ * fqtk_match.h -- C ABI of the MI355X-native sample-barcode matcher (libfqtk_match.so).
+ *
+ * This is the drop-in boundary for the ONE hot path of `fqtk demux`: the reference's
+ * `BarcodeMatcher` (reference: /root/reference/src/lib/barcode_matching.rs).  The reference has no
+ * FFI of its own; each entry point below names the Rust item it replaces so a maintainer can bind it
+ * from Rust (`extern "C"`), C++ or ctypes.  Plain pointers and sizes only.
+ *
+ * Semantics every entry point implements, bit for bit:
+ *   enc(b):  'N','n','.' -> 0xF; else IUPAC mask of the upper-cased byte (A1 C2 G4 T8 U8 M3 R5 W9 S6
+ *            Y10 K12 V7 H11 D13 B14 N15); any other byte -> 0            (src/lib/mod.rs:26-61)
+ *   mm[s]  = #{ i < L : enc(read[i]) & ~enc(barcode_s[i]) != 0 }          (src/lib/bitenc.rs:432-459)
+ *   best   = min_s mm[s]; idx = LOWEST s attaining it; next = second smallest with multiplicity
+ *            (255 when there is one sample)                      (barcode_matching.rs:119-160)
+ *   None   when len < L, when best > max_mismatches, or when next - best < min_mismatch_delta
+ *                                                                 (barcode_matching.rs:150-186)
+ *   error  when len > L and the no-call prefilter (barcode_matching.rs:170-172) does not reject the
+ *            read first -- the reference panics there (barcode_matching.rs:95-107) -> FQTK_ELEN.
+ *
+ * There is NO CPU fallback behind this ABI: every compute entry point needs a gfx950 device and
+ * returns FQTK_ENODEV / FQTK_EHIP otherwise.
+ *
+ * Threading: a handle is not thread-safe (the reference's matcher is `&mut self`); use one handle per
+ * (device, host thread).  Batches on one handle complete in submission order.
+ */
+#ifndef FQTK_MATCH_H
+#define FQTK_MATCH_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- status codes (the reference aborts with panic!/assert!; nothing here aborts) ------------ */
+#define FQTK_OK 0
+#define FQTK_EINVAL 1 /* bad argument / table precondition (barcode_matching.rs:61-65, samples.rs:101-133) */
+#define FQTK_ELEN 2   /* observed barcode longer than expected: the reference's panic (barcode_matching.rs:95-107) */
+#define FQTK_EHIP 3   /* a HIP runtime call failed; see fqtk_last_error() */
+#define FQTK_ENOMEM 4
+#define FQTK_ENODEV 5 /* no usable gfx950 device */
+
+#define FQTK_NO_MATCH 0xFFFFu /* fqtk_match_t.idx of a read the reference assigns None */
+#define FQTK_MAX_BARCODE_LEN 128u
+#define FQTK_MAX_SAMPLES 65534u
+
+/* Replaces `BarcodeMatch { best_match: usize, best_mismatches: u8, next_best_mismatches: u8 }`
+ * (barcode_matching.rs:16-25) / `Option<BarcodeMatch>`.  idx == FQTK_NO_MATCH <=> None; then best and
+ * next are both 255 (the reference exposes no values for None). 4 bytes, little-endian. */
+typedef struct fqtk_match_t {
+    uint16_t idx;
+    uint8_t best;
+    uint8_t next;
+} fqtk_match_t;
+
+/* Opaque; owns the device-resident expected-barcode table, error word and staging buffers.
+ * Replaces `struct BarcodeMatcher` (barcode_matching.rs:29-45). */
+typedef struct fqtk_matcher fqtk_matcher;
+
+/* Thread-local message of the last non-OK status returned on this thread. */
+const char *fqtk_last_error(void);
+
+/* ABI version of this header (bumped on any signature change). */
+int fqtk_abi_version(void);
+
+/* Number of visible HIP devices (0 without a GPU; FQTK_OK either way). */
+int fqtk_device_count(int *n_devices);
+
+/* Replaces `BarcodeMatcher::new(samples, max_mismatches, min_mismatch_delta, use_cache)`
+ * (barcode_matching.rs:55-86; sole call site demux.rs:921-926).  `barcodes[s]` are NUL-terminated
+ * ASCII strings of exactly `barcode_len` bytes; they are upper-cased and encoded like the reference
+ * does (:71-75) and copied -- the caller keeps ownership.  There is no `use_cache`: the reference's
+ * memo cache is result-neutral (:174-181).  Errors: n_samples == 0 ("Must provide at least one
+ * sample"), empty barcode ("Sample barcode cannot be empty string"), unequal lengths (the reference
+ * would panic on the first assign), barcode_len > FQTK_MAX_BARCODE_LEN, n_samples >
+ * FQTK_MAX_SAMPLES -> FQTK_EINVAL; no device -> FQTK_ENODEV. */
+int fqtk_matcher_create(const char *const *barcodes, uint32_t n_samples, uint32_t barcode_len,
+                        uint8_t max_mismatches, uint8_t min_mismatch_delta, int device,
+                        fqtk_matcher **out);
+
+void fqtk_matcher_destroy(fqtk_matcher *m);
+
+/* Introspection (fields of BarcodeMatcher, barcode_matching.rs:29-45). */
+uint32_t fqtk_matcher_n_samples(const fqtk_matcher *m);
+uint32_t fqtk_matcher_barcode_len(const fqtk_matcher *m);
+uint32_t fqtk_matcher_max_ns_in_barcodes(const fqtk_matcher *m); /* :73-74 */
+int fqtk_matcher_device(const fqtk_matcher *m);
+
+/* Replaces one `BarcodeMatcher::assign(&mut self, read_bases: &[u8]) -> Option<BarcodeMatch>` call
+ * per template (barcode_matching.rs:165-186; sole call site demux.rs:968) with one call per batch.
+ * HOST pointers; synchronous.
+ *   obs      n x stride ASCII bytes, read i at obs + i*stride (the SoA form of
+ *            ReadSet::sample_barcode_sequence, demux.rs:121-123)
+ *   obs_len  per-read length, or NULL when every read has exactly barcode_len bases
+ *            (stride must then be >= barcode_len); obs_len[i] <= stride
+ *   out      n results
+ *   counts   NULL, or S+1 counters that are ADDED to: counts[idx] for Some, counts[S] for None --
+ *            the per-sample `templates` metric of demux.rs:970-974
+ * Returns FQTK_ELEN when some read is longer than barcode_len and not rejected by the no-call
+ * prefilter (its index is in fqtk_last_error()); results for the other reads are still written. */
+int fqtk_matcher_assign_batch(fqtk_matcher *m, const uint8_t *obs, uint32_t stride,
+                              const uint32_t *obs_len, uint64_t n, fqtk_match_t *out,
+                              uint64_t *counts);
+
+/* Same, but every pointer is a DEVICE pointer on the matcher's device and the work is enqueued on
+ * `hip_stream` (a hipStream_t, NULL = the default stream) without synchronising: the zero-copy form
+ * used when reads are already resident in HBM.  d_counts: NULL or S+1 uint64 accumulated with
+ * atomics.  Length errors are latched in the handle; collect them with fqtk_matcher_poll_error(). */
+int fqtk_matcher_assign_batch_device(fqtk_matcher *m, const void *d_obs, uint32_t stride,
+                                     const void *d_obs_len, uint64_t n, void *d_out, void *d_counts,
+                                     void *hip_stream);
+
+/* Synchronises `hip_stream`, then reports and clears the latched length error of earlier
+ * *_device / enqueue calls: FQTK_OK, or FQTK_ELEN with the lowest offending read index of the
+ * batch that raised it in *read_index (may be NULL). */
+int fqtk_matcher_poll_error(fqtk_matcher *m, void *hip_stream, uint64_t *read_index);
+
+/* Scalar convenience with the reference's exact call shape (one read in, Option out): returns
+ * FQTK_OK and writes *out (idx == FQTK_NO_MATCH for None), or FQTK_ELEN. */
+int fqtk_matcher_assign1(fqtk_matcher *m, const uint8_t *read_bases, uint32_t len,
+                         fqtk_match_t *out);
+
+/* ---- pinned-buffer pipeline: decompress -> match -> write overlap (north_star) --------------- */
+/* Page-locked host memory for the SoA chunk buffers so H2D/D2H run as async DMA. */
+int fqtk_pinned_alloc(size_t bytes, void **out);
+int fqtk_pinned_free(void *p);
+
+#define FQTK_MAX_SLOTS 8
+/* Enqueue one chunk on pipeline slot `slot` (0..FQTK_MAX_SLOTS-1; each slot = its own HIP stream +
+ * device staging): async H2D of obs (and obs_len if non-NULL), kernel, async D2H into `out`.
+ * Returns immediately.  Buffers must stay valid (and should be pinned) until fqtk_matcher_wait().
+ * Per-sample counts are accumulated on the device; read them with fqtk_matcher_counts(). */
+int fqtk_matcher_enqueue(fqtk_matcher *m, int slot, const uint8_t *obs, uint32_t stride,
+                         const uint32_t *obs_len, uint64_t n, fqtk_match_t *out);
+/* Blocks until the chunk on `slot` is complete; FQTK_ELEN as for assign_batch. */
+int fqtk_matcher_wait(fqtk_matcher *m, int slot);
+/* Adds the device-side accumulated counts (S+1) of all completed enqueue() chunks into `counts`
+ * and resets the device accumulator.  Synchronises all slots. */
+int fqtk_matcher_counts(fqtk_matcher *m, uint64_t *counts);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FQTK_MATCH_H */

@@ -1,0 +1,276 @@
+"""Parity tests proper: the hand-written HIP path, called through the C ABI (include/fqtk_match.h),
+against the CPU oracle (oracle/ref_literal.c) and the reference's golden vectors.  Bit-exact: this is
+integer work, every (idx, best, next) triple and every per-sample count must be identical.
+
+Reads like the reference's own tests (/root/reference/src/lib/barcode_matching.rs:326-447)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+from fqtk_amd import BarcodeMatch, BarcodeMatcher, FqtkLengthError, _lib  # noqa: E402
+from fqtk_amd import synth  # noqa: E402
+from oracle import oracle as O  # noqa: E402
+
+
+def _loaded_native():
+    """The test must be exercising the in-tree HIP library, not anything else."""
+    maps = open("/proc/self/maps").read()
+    assert "libfqtk_match.so" in maps
+
+
+def _compare(barcodes, mm, delta, obs, lens=None):
+    gm = BarcodeMatcher(barcodes, mm, delta)
+    got, counts = gm.assign_batch(obs, lens)
+    lit = O.RefLiteral(barcodes, mm, delta, True)
+    L = len(barcodes[0])
+    if lens is None:
+        i, b, nx, c = lit.assign_batch(np.ascontiguousarray(obs[:, :L]))
+    else:
+        i, b, nx, c = lit.assign_batch(obs, lens)
+    assert np.array_equal(got["idx"], i)
+    assert np.array_equal(got["best"], b)
+    assert np.array_equal(got["next"], nx)
+    assert np.array_equal(counts, c)
+    _loaded_native()
+    return got, counts
+
+
+# ------------------------------------------------------------------------------------------------
+# golden vectors (the reference's own known answers)
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("use_cache", [True, False])
+def test_assign_known_answers(kat, use_cache):
+    for c in kat["assign"]["cases"]:
+        matcher = BarcodeMatcher(c["barcodes"], c["max_mismatches"], c["min_mismatch_delta"], use_cache)
+        expected = None if c["expect"] is None else BarcodeMatch(*c["expect"])
+        assert matcher.assign(c["read"].encode()) == expected, c["name"]
+
+
+def test_count_mismatches_known_answers_via_single_sample_tables(kat):
+    # count_mismatches(observed, expected) == best_mismatches of a one-sample matcher
+    for c in kat["count_mismatches"]["cases"]:
+        if not c["expected"]:
+            continue
+        m = BarcodeMatcher([c["expected"]], 255, 0)
+        got = m.assign(c["observed"].encode())
+        assert got == BarcodeMatch(0, c["expect"], 255), c
+
+
+def test_demux_level_assigns(kat):
+    for c in kat["demux_assign"]["cases"]:
+        m = BarcodeMatcher(c["barcodes"], c["max_mismatches"], c["min_mismatch_delta"])
+        for r in c["reads"]:
+            got = m.assign(r["observed"].encode())
+            assert (None if got is None else got.best_match) == r["expect"], (c["name"], r)
+
+
+def test_encode_all_256_byte_values_and_all_nibble_pairs():
+    """enc() over every byte value x every expected IUPAC code, through the device LUT + AND-NOT path
+    (enumerate all 16x16 nibble pairs and all 256 bytes)."""
+    codes = "ACGTMRWSYKVHDBN"
+    obs = np.arange(256, dtype=np.uint8)[:, None]
+    for e in codes:
+        m = BarcodeMatcher([e], 255, 0)
+        got, _ = m.assign_batch(obs)
+        exp = ((O.ENC[np.arange(256)] & ~O.ENC[ord(e)] & 0xF) != 0).astype(np.uint8)
+        assert np.array_equal(got["best"], exp), e
+        assert np.all(got["idx"] == 0)
+
+
+def test_length_rules():
+    m = BarcodeMatcher(["ACGT", "TTTT"], 1, 1)
+    assert m.assign(b"ACG") is None                 # shorter -> None (barcode_matching.rs:167-169)
+    assert m.assign(b"") is None
+    with pytest.raises(FqtkLengthError):            # longer -> the reference panics (:95-107)
+        m.assign(b"ACGTA")
+    assert m.assign(b"NNNNN") is None               # ...unless the no-call prefilter fires first
+    assert m.assign(b"ACGT") == BarcodeMatch(0, 0, 4)   # the handle stays usable after an error
+
+
+def test_single_sample_and_ties():
+    m = BarcodeMatcher(["ACGT"], 1, 2)
+    assert m.assign(b"ACGT") == BarcodeMatch(0, 0, 255)
+    assert m.assign(b"AGGA") is None
+    t = BarcodeMatcher(["AAAA", "AAAC", "AAAG"], 3, 0)
+    assert t.assign(b"AAAT") == BarcodeMatch(0, 1, 1)   # lowest index wins, next == best
+
+
+def test_empty_batch():
+    m = BarcodeMatcher(["ACGT", "TTTT"], 1, 1)
+    got, counts = m.assign_batch(np.empty((0, 4), dtype=np.uint8))
+    assert got.shape == (0,) and counts.sum() == 0
+
+
+# ------------------------------------------------------------------------------------------------
+# seeded random parity vs the oracle
+# ------------------------------------------------------------------------------------------------
+ALPHABET = np.frombuffer(b"ACGTACGTACGTACGTNn.acgtRYKMSWBDHVXx-*0", dtype=np.uint8)
+SAMPLE_ALPHABET = list("ACGTACGTACGTNMRWSYKVHDBn.")
+
+
+@pytest.mark.parametrize("seed", range(16))
+def test_random_tables_and_reads(seed):
+    rng = np.random.default_rng(99 + seed)
+    S = int(rng.choice([1, 2, 3, 4, 5, 7, 16, 33, 100]))
+    L = int(rng.choice([1, 3, 7, 8, 9, 12, 16, 17, 24, 32, 33, 40, 64, 65, 100, 128]))
+    if 4 ** min(L, 6) < S * 2:
+        S = 1
+    seen, barcodes = set(), []
+    while len(barcodes) < S:
+        b = "".join(rng.choice(SAMPLE_ALPHABET, size=L))
+        if b not in seen:
+            seen.add(b)
+            barcodes.append(b)
+    mm = int(rng.choice([0, 1, 2, 3, 100, 255]))
+    delta = int(rng.choice([0, 1, 2, 3, 100, 255]))
+    n = 5000 + int(rng.integers(0, 3000))           # not a multiple of the tile: ragged tail
+    stride = L + int(rng.choice([0, 0, 1, 3, 4]))   # aligned, unaligned and padded strides
+    obs = ALPHABET[rng.integers(0, len(ALPHABET), size=(n, stride))]
+    src = rng.integers(0, S, size=n)
+    bc = np.stack([np.frombuffer(b.encode(), dtype=np.uint8) for b in barcodes])[src]
+    near = rng.random((n, L)) < 0.9
+    obs[:, :L] = np.where(near, bc, obs[:, :L])
+    _compare(barcodes, mm, delta, obs)
+
+
+def test_ragged_lengths_vs_oracle():
+    rng = np.random.default_rng(7)
+    barcodes = ["ACGTAC", "TTGCAA", "NNGCAT"]
+    n, stride, L = 4000, 8, 6
+    obs = np.frombuffer(b"ACGTN", dtype=np.uint8)[rng.integers(0, 5, size=(n, stride))]
+    lens = rng.integers(0, L + 1, size=n).astype(np.uint32)
+    got, _ = _compare(barcodes, 1, 1, obs, lens)
+    assert np.all(got["idx"][lens < L] == 0xFFFF)
+
+
+def test_overlong_reads_in_a_batch_report_lowest_index_and_still_fill_results():
+    barcodes = ["ACGT", "TTTT"]
+    obs = np.frombuffer(b"ACGTAA" b"TTTTAA" b"NNNNNN" b"ACGTAA", dtype=np.uint8).reshape(4, 6).copy()
+    lens = np.array([4, 6, 6, 5], dtype=np.uint32)
+    m = BarcodeMatcher(barcodes, 1, 1)
+    with pytest.raises(FqtkLengthError, match="read index 1"):
+        m.assign_batch(obs, lens)
+    # same batch without the offending reads is fine, and the prefiltered over-long read is None
+    lens2 = np.array([4, 4, 6, 4], dtype=np.uint32)
+    got, _ = m.assign_batch(obs, lens2)
+    assert list(got["idx"]) == [0, 1, 0xFFFF, 0]
+
+
+@pytest.mark.parametrize("k", [1, 2, 3, 4, 5])
+def test_baseline_configs_reduced_size_vs_oracle(k):
+    """The five BASELINE.json configs at a size the oracle finishes in seconds."""
+    cfg = synth.CONFIGS[k]
+    w = synth.Workload(cfg)
+    n = {1: 300_000, 2: 300_000, 3: 200_000, 4: 300_000, 5: 60_000}[k]
+    obs = w.fill_host(0, n)
+    got, counts = _compare(w.barcodes, cfg.max_mismatches, cfg.min_mismatch_delta, obs)
+    assert int(counts.sum()) == n
+    if k == 5:   # also the 0/0 parameters of demux.rs:1494-1495
+        _compare(w.barcodes, 0, 0, obs[:20000])
+
+
+def test_device_generator_matches_host_twin_and_zero_copy_entry_point():
+    import torch
+    cfg = synth.CONFIGS[3]
+    w = synth.Workload(cfg)
+    n = 1_000_003
+    dev = torch.device("cuda:0")
+    d_obs = torch.empty((n, cfg.stride), dtype=torch.uint8, device=dev)
+    stream = torch.cuda.current_stream().cuda_stream
+    w.fill_device(0, n, d_obs.data_ptr(), stream)
+    host = w.fill_host(0, n)
+    assert np.array_equal(d_obs.cpu().numpy(), host)
+    m = BarcodeMatcher(w.barcodes, cfg.max_mismatches, cfg.min_mismatch_delta)
+    d_out = torch.empty(n, dtype=torch.int32, device=dev)
+    d_counts = torch.zeros(cfg.n_samples + 1, dtype=torch.int64, device=dev)
+    m.assign_batch_device(d_obs.data_ptr(), cfg.stride, n, d_out.data_ptr(), d_counts.data_ptr(),
+                          stream=stream)
+    m.poll_error(stream)
+    got = d_out.cpu().numpy().view(np.dtype([("idx", "<u2"), ("best", "u1"), ("next", "u1")]))
+    lit = O.RefLiteral(w.barcodes, cfg.max_mismatches, cfg.min_mismatch_delta, True)
+    i, b, nx, c = lit.assign_batch(host)
+    assert np.array_equal(got["idx"], i) and np.array_equal(got["best"], b) and np.array_equal(got["next"], nx)
+    assert np.array_equal(d_counts.cpu().numpy().astype(np.uint64), c)
+
+
+def test_full_size_properties_cfg3_slice():
+    """Size-independent properties at a size the oracle cannot finish: counts sum to n, the histogram
+    of the result array equals the device counts, a permuted input gives the permuted output, and
+    running twice accumulates exactly 2x (idempotent results, additive counts)."""
+    import torch
+    cfg = synth.CONFIGS[3]
+    w = synth.Workload(cfg)
+    n = 40_000_000
+    dev = torch.device("cuda:0")
+    d_obs = torch.empty((n, cfg.stride), dtype=torch.uint8, device=dev)
+    stream = torch.cuda.current_stream().cuda_stream
+    w.fill_device(0, n, d_obs.data_ptr(), stream)
+    m = BarcodeMatcher(w.barcodes, cfg.max_mismatches, cfg.min_mismatch_delta)
+    d_out = torch.empty(n, dtype=torch.int32, device=dev)
+    d_counts = torch.zeros(cfg.n_samples + 1, dtype=torch.int64, device=dev)
+    m.assign_batch_device(d_obs.data_ptr(), cfg.stride, n, d_out.data_ptr(), d_counts.data_ptr(), stream=stream)
+    m.poll_error(stream)
+    counts = d_counts.cpu().numpy()
+    assert counts.sum() == n
+    idx = (d_out & 0xFFFF).to(torch.int64)
+    idx = torch.where(idx == 0xFFFF, torch.full_like(idx, cfg.n_samples), idx)
+    hist = torch.bincount(idx, minlength=cfg.n_samples + 1).cpu().numpy()
+    assert np.array_equal(hist, counts)
+    # second pass: same results, counts doubled
+    d_out2 = torch.empty_like(d_out)
+    m.assign_batch_device(d_obs.data_ptr(), cfg.stride, n, d_out2.data_ptr(), d_counts.data_ptr(), stream=stream)
+    m.poll_error(stream)
+    assert torch.equal(d_out, d_out2)
+    assert np.array_equal(d_counts.cpu().numpy(), 2 * counts)
+    # permutation equivariance on a slice
+    k = 5_000_000
+    perm = torch.randperm(k, device=dev)
+    d_p = d_obs[:k][perm].contiguous()
+    d_outp = torch.empty(k, dtype=torch.int32, device=dev)
+    m.assign_batch_device(d_p.data_ptr(), cfg.stride, k, d_outp.data_ptr(), 0, stream=stream)
+    m.poll_error(stream)
+    assert torch.equal(d_outp, d_out[:k][perm])
+    # oracle spot-check of three far-apart windows of the big run
+    lit = O.RefLiteral(w.barcodes, cfg.max_mismatches, cfg.min_mismatch_delta, True)
+    for start in (0, 17_000_001, n - 50_000):
+        host = w.fill_host(start, 50_000)
+        i, b, nx, _ = lit.assign_batch(host)
+        got = d_out[start:start + 50_000].cpu().numpy().view(np.dtype([("idx", "<u2"), ("best", "u1"), ("next", "u1")]))
+        assert np.array_equal(got["idx"], i) and np.array_equal(got["best"], b) and np.array_equal(got["next"], nx)
+
+
+def test_pinned_pipeline_slots_match_sync_path():
+    cfg = synth.CONFIGS[2]
+    w = synth.Workload(cfg)
+    lib = _lib.load()
+    m = BarcodeMatcher(w.barcodes, cfg.max_mismatches, cfg.min_mismatch_delta)
+    n_chunk, chunks = 200_000, 5
+    ref_out, ref_counts = m.assign_batch(w.fill_host(0, n_chunk * chunks))
+    bufs = []
+    for s in range(2):
+        p_obs, p_out = C.c_void_p(), C.c_void_p()
+        assert lib.fqtk_pinned_alloc(n_chunk * cfg.stride, C.byref(p_obs)) == 0
+        assert lib.fqtk_pinned_alloc(n_chunk * 4, C.byref(p_out)) == 0
+        bufs.append((p_obs, p_out))
+    outs = []
+    for c in range(chunks + 2):
+        slot = c % 2
+        if c >= 2:
+            assert lib.fqtk_matcher_wait(m.handle, slot) == 0
+            outs.append(np.ctypeslib.as_array(C.cast(bufs[slot][1], C.POINTER(C.c_uint32)), (n_chunk,)).copy())
+        if c < chunks:
+            host = w.fill_host(c * n_chunk, n_chunk)
+            C.memmove(bufs[slot][0], host.ctypes.data, host.nbytes)
+            assert lib.fqtk_matcher_enqueue(m.handle, slot, bufs[slot][0], cfg.stride, None, n_chunk,
+                                            bufs[slot][1]) == 0, _lib.last_error()
+    got = np.concatenate(outs).view(ref_out.dtype)
+    assert np.array_equal(got, ref_out)
+    counts = np.zeros(cfg.n_samples + 1, dtype=np.uint64)
+    assert lib.fqtk_matcher_counts(m.handle, counts.ctypes.data) == 0
+    assert np.array_equal(counts, ref_counts)
+    for p_obs, p_out in bufs:
+        lib.fqtk_pinned_free(p_obs)
+        lib.fqtk_pinned_free(p_out)

@@ -1,0 +1,90 @@
+"""Host-side mirror of the reference's table preconditions (src/lib/samples.rs tests :151-398) and the
+synthetic workload generator (host twin of the device generator)."""
+import numpy as np
+import pytest
+
+from fqtk_amd import Sample, SampleGroup
+from fqtk_amd.samples import DelimFileHeaderError, is_valid_iupac
+from fqtk_amd import synth
+
+
+def test_is_valid_iupac(kat):
+    for ch in kat["valid_iupac"]["true"]:
+        assert is_valid_iupac(ord(ch))
+    for ch in kat["valid_iupac"]["false"]:
+        assert not is_valid_iupac(ord(ch))
+
+
+def test_sample_new_validation():
+    s = Sample.new(0, "s1", "GATTACA")
+    assert (s.sample_id, s.barcode, s.ordinal) == ("s1", "GATTACA", 0)
+    with pytest.raises(ValueError, match="Sample name cannot be empty"):
+        Sample.new(0, "", "GATTACA")
+    with pytest.raises(ValueError, match="Sample barcode cannot be empty"):
+        Sample.new(0, "s", "")
+    with pytest.raises(ValueError, match="All sample barcode bases must be one of"):
+        Sample.new(0, "s", "GATTANX")
+    with pytest.raises(ValueError, match="All sample barcode bases must be one of"):
+        Sample.new(0, "s", "gattaca")
+    Sample.new(0, "s", "NNn..RYKM")
+
+
+def test_sample_group_validation():
+    a, b = Sample("s1", "GATTACA"), Sample("s2", "CATGCTA")
+    g = SampleGroup.from_samples([a, b])
+    assert [s.ordinal for s in g.samples] == [0, 1]
+    with pytest.raises(ValueError, match="Must provide one or more sample"):
+        SampleGroup.from_samples([])
+    with pytest.raises(ValueError, match="Each sample name must be unique"):
+        SampleGroup.from_samples([a, Sample("s1", "CATGCTA")])
+    with pytest.raises(ValueError, match="Each sample barcode must be unique"):
+        SampleGroup.from_samples([a, Sample("s2", "GATTACA")])
+    with pytest.raises(ValueError, match="All barcodes must have the same length"):
+        SampleGroup.from_samples([a, Sample("s2", "CATGCT")])
+
+
+def test_sample_group_from_file(tmp_path):
+    p = tmp_path / "meta.tsv"
+    p.write_text("sample_id\tbarcode\nsample1\tGATTACA\nsample2\tCATGCTA\n\n\n")
+    g = SampleGroup.from_file(str(p))
+    assert [(s.sample_id, s.barcode, s.ordinal) for s in g.samples] == [("sample1", "GATTACA", 0),
+                                                                        ("sample2", "CATGCTA", 1)]
+    bad = tmp_path / "bad.tsv"
+    bad.write_text("sample\tbarcode\nsample1\tGATTACA\n")
+    with pytest.raises(DelimFileHeaderError) as ei:
+        SampleGroup.from_file(str(bad))
+    assert ei.value.expected == "sample_id\tbarcode" and ei.value.found == "sample\tbarcode"
+    assert Sample.deserialize_header_line() == "sample_id\tbarcode"
+    assert str(Sample("test-sample", "GATTACA", 2)) == "Sample(0002) - { name: test-sample\tbarcode: GATTACA }"
+
+
+@pytest.mark.parametrize("k", [1, 2, 3, 4, 5])
+def test_synthetic_tables_meet_their_spec(k):
+    cfg = synth.CONFIGS[k]
+    bcs = synth.make_barcodes(cfg)
+    assert len(bcs) == cfg.n_samples and len(set(bcs)) == cfg.n_samples
+    assert all(len(b) == cfg.barcode_len for b in bcs)
+    SampleGroup.from_samples([Sample(f"S{i}", b) for i, b in enumerate(bcs)])
+    arr = np.stack([np.frombuffer(b.encode(), dtype=np.uint8) for b in bcs])
+    if not cfg.iupac:
+        d = (arr[:, None, :] != arr[None, :, :]).sum(axis=2)
+        np.fill_diagonal(d, 99)
+        assert d.min() >= 3
+    else:
+        assert any(ch in b for b in bcs for ch in "MRWSYKVHDBN")
+
+
+def test_synthetic_reads_are_deterministic_and_range_consistent():
+    w = synth.Workload(synth.CONFIGS[3])
+    a = w.fill_host(1000, 5000)
+    b = w.fill_host(1000, 5000)
+    c = w.fill_host(3000, 100)
+    assert np.array_equal(a, b)
+    assert np.array_equal(a[2000:2100], c)          # read i depends only on (seed, i)
+    assert a.shape == (5000, 16)
+    frac_n = float((a == ord("N")).mean())
+    assert 0.002 < frac_n < 0.01
+    w5 = synth.Workload(synth.CONFIGS[5])
+    x = w5.fill_host(0, 50000)
+    assert x.shape == (50000, 12) and np.all(x[:, 10:] == 0)
+    assert (x[:, :10] == ord(".")).sum() > 0 and ((x[:, :10] >= ord("a")) & (x[:, :10] <= ord("t"))).sum() > 0
