@@ -17,6 +17,28 @@ class fqtk_match_t(C.Structure):
 
 
 _lib = None
+_hip_preloaded = False
+
+
+def preload_hip_runtime() -> None:
+    """One HIP runtime per process.  libfqtk_match.so needs `libamdhip64.so.7`; PyTorch-ROCm wheels
+    bundle their own copy with that soname but link it as plain `libamdhip64.so`, so whichever side
+    loads second would otherwise pull in a SECOND runtime (which then sees no GPU).  If a PyTorch-ROCm
+    install is present, load its copy first (RTLD_GLOBAL) so both sides share it; otherwise the
+    system ROCm runtime is found through the library's RUNPATH.  torch itself is NOT imported."""
+    global _hip_preloaded
+    if _hip_preloaded:
+        return
+    _hip_preloaded = True
+    try:
+        import importlib.util
+        spec = importlib.util.find_spec("torch")
+        if spec and spec.origin:
+            cand = os.path.join(os.path.dirname(spec.origin), "lib", "libamdhip64.so")
+            if os.path.exists(cand):
+                C.CDLL(cand, mode=C.RTLD_GLOBAL)
+    except Exception:
+        pass
 
 # (name, restype, argtypes) for EVERY symbol include/fqtk_match.h declares
 SIGNATURES = [
@@ -54,6 +76,7 @@ def load() -> C.CDLL:
         raise ImportError(
             f"{LIB_PATH} is missing: build it with `python -m fqtk_amd.build` (hipcc, gfx950). "
             "fqtk_amd has no CPU fallback.")
+    preload_hip_runtime()
     lib = C.CDLL(LIB_PATH)
     for name, res, args in SIGNATURES:
         fn = getattr(lib, name)   # AttributeError if the symbol is not exported

@@ -109,6 +109,8 @@ def _load() -> C.CDLL:
     if _lib is None:
         if not os.path.exists(LIB_PATH):
             raise ImportError(f"{LIB_PATH} missing: run `python -m fqtk_amd.build`")
+        from ._lib import preload_hip_runtime
+        preload_hip_runtime()
         lib = C.CDLL(LIB_PATH)
         common = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint64, C.c_void_p,
                   C.c_uint64, C.c_uint64, C.c_void_p]

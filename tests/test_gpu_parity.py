@@ -87,7 +87,7 @@ def test_length_rules():
     with pytest.raises(FqtkLengthError):            # longer -> the reference panics (:95-107)
         m.assign(b"ACGTA")
     assert m.assign(b"NNNNN") is None               # ...unless the no-call prefilter fires first
-    assert m.assign(b"ACGT") == BarcodeMatch(0, 0, 4)   # the handle stays usable after an error
+    assert m.assign(b"ACGT") == BarcodeMatch(0, 0, 3)   # the handle stays usable after an error
 
 
 def test_single_sample_and_ties():
