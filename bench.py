@@ -75,6 +75,8 @@ def main() -> int:
     ap.add_argument("--reads", type=int, default=0, help="reads per rank per step (default: the config's N)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="CPU-baseline budget (0 = skip)")
     ap.add_argument("--no-verify", action="store_true")
+    ap.add_argument("--no-cache", action="store_true",
+                    help="use_cache=false: exhaustive per-sample scan for every read (no memo table)")
     args = ap.parse_args()
 
     import torch
@@ -112,7 +114,10 @@ def main() -> int:
     d_out = torch.empty(n, dtype=torch.int32, device=dev)
     d_counts = torch.zeros(cfg.n_samples + 1, dtype=torch.int64, device=dev)
 
-    matcher = BarcodeMatcher(workload.barcodes, cfg.max_mismatches, cfg.min_mismatch_delta, device=local_rank)
+    matcher = BarcodeMatcher(workload.barcodes, cfg.max_mismatches, cfg.min_mismatch_delta,
+                             use_cache=not args.no_cache, device=local_rank)
+    memo_on = (not args.no_cache) and matcher.memo_entries > 0
+    kernel_name = "fqtk::memo_kernel" if memo_on else "fqtk::match_kernel"
 
     def step():
         matcher.assign_batch_device(d_obs.data_ptr(), cfg.stride, n, d_out.data_ptr(), d_counts.data_ptr(),
@@ -197,10 +202,12 @@ def main() -> int:
                 "min_mismatch_delta": cfg.min_mismatch_delta,
                 "sharding": f"reads sharded over {world} rank(s), table replicated, RCCL all-reduce of counts only",
                 "parity": parity,
+                "use_cache": not args.no_cache,
+                "memo_entries": matcher.memo_entries,
             },
             "roofline": {
                 "bound": "hbm",
-                "kernel": "fqtk::match_kernel",
+                "kernel": kernel_name,
                 "achieved": round(achieved, 2),
                 "peak": HBM_PEAK_GBPS,
                 "unit": "GB/s",

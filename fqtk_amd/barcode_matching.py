@@ -3,8 +3,9 @@
 Mirrors /root/reference/src/lib/barcode_matching.rs: `BarcodeMatcher::new(samples, max_mismatches,
 min_mismatch_delta, use_cache)` (:55-86) and `assign(read_bases) -> Option<BarcodeMatch>` (:165-186),
 so parity tests read like the reference's own tests (:326-447).  Every call lands in the hand-written
-HIP kernels behind include/fqtk_match.h; `use_cache` is accepted for signature parity and ignored --
-the reference's memo cache is result-neutral (:174-181).
+HIP kernels behind include/fqtk_match.h; `use_cache` selects the precomputed complete memo (True, demux's
+setting) or the exhaustive scan for every read (False); results are identical, as in the reference
+(:174-181).
 """
 from __future__ import annotations
 
@@ -68,6 +69,7 @@ class BarcodeMatcher:
         _check(self._lib.fqtk_matcher_create(arr, n, L, max_mismatches, min_mismatch_delta, device,
                                              C.byref(h)))
         self._h = h
+        _check(self._lib.fqtk_matcher_set_use_cache(h, 1 if use_cache else 0))
         self.use_cache = use_cache
         self.max_mismatches = max_mismatches
         self.min_mismatch_delta = min_mismatch_delta
@@ -97,6 +99,11 @@ class BarcodeMatcher:
     @property
     def max_ns_in_barcodes(self) -> int:
         return int(self._lib.fqtk_matcher_max_ns_in_barcodes(self._h))
+
+    @property
+    def memo_entries(self) -> int:
+        """Entries of the precomputed complete memo (0 = exhaustive scan only)."""
+        return int(self._lib.fqtk_matcher_memo_entries(self._h))
 
     @property
     def handle(self) -> C.c_void_p:

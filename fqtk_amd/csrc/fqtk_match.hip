@@ -15,6 +15,7 @@
 
 #include "../../include/fqtk_match.h"
 #include "match_kernels.hip.h"
+#include "memo_kernels.hip.h"
 
 namespace {
 
@@ -81,6 +82,14 @@ struct fqtk_matcher {
     unsigned long long *d_err = nullptr;     // [0] min offending index, ~0 = none
     unsigned long long *d_counts = nullptr;  // S+1, used by the host-pointer entry points
     unsigned long long *h_err = nullptr;     // pinned mirror
+    // complete memo (memo_kernels.hip.h); absent when the candidate set is over budget or L > 20
+    void *d_memo = nullptr;
+    uint32_t *d_code_lut = nullptr;
+    uint32_t memo_mask = 0;
+    bool memo_key64 = false;
+    uint64_t memo_entries = 0;
+    uint64_t memo_candidates = 0;
+    int use_cache = 1;                       // BarcodeMatcher.use_cache (barcode_matching.rs:41-42)
     Slot slots[FQTK_MAX_SLOTS];
 };
 
@@ -139,7 +148,54 @@ int launch_vec(const fqtk::MatchParams &P, int num_cus, hipStream_t stream) {
     return launch_t<NW, R, 0>(P, num_cus, stream);
 }
 
+template <bool KEY64>
+int launch_memo_vec(const fqtk_matcher *m, const fqtk::MemoParams &Q, hipStream_t stream) {
+    const fqtk::MatchParams &P = Q.m;
+    constexpr int R = 2;
+    const uint64_t tile = (uint64_t)fqtk::kBlock * R;
+    const uint64_t ntiles = (P.n + tile - 1) / tile;
+    if (ntiles == 0) return FQTK_OK;
+    const uint32_t grid = (uint32_t)std::min<uint64_t>(ntiles, (uint64_t)m->num_cus * 8);
+    size_t shmem = (256 + 64) * sizeof(uint32_t);
+    if (P.counts && P.lds_hist) shmem += (size_t)(P.S + 1) * sizeof(uint32_t);
+    const uintptr_t base = reinterpret_cast<uintptr_t>(P.obs);
+    const uint32_t nwords = (P.L + 3) / 4;
+    int vec = 0;
+    if (P.stride % 4 == 0 && base % 4 == 0 && P.stride >= nwords * 4) {
+        const uint32_t sw = P.stride / 4;
+        vec = -1;
+        if (sw == nwords) {
+            if (sw == 4 && base % 16 == 0) vec = 4;
+            else if (sw == 2 && base % 8 == 0) vec = 2;
+            else if (sw == 1) vec = 1;
+            else if (sw == 3) vec = 3;
+        }
+    }
+#define FQTK_MEMO_LAUNCH(V) \
+    hipLaunchKernelGGL((fqtk::memo_kernel<V, KEY64, R>), dim3(grid), dim3(fqtk::kBlock), shmem, stream, Q)
+    switch (vec) {
+        case 4: FQTK_MEMO_LAUNCH(4); break;
+        case 3: FQTK_MEMO_LAUNCH(3); break;
+        case 2: FQTK_MEMO_LAUNCH(2); break;
+        case 1: FQTK_MEMO_LAUNCH(1); break;
+        case -1: FQTK_MEMO_LAUNCH(-1); break;
+        default: FQTK_MEMO_LAUNCH(0); break;
+    }
+#undef FQTK_MEMO_LAUNCH
+    HIP_TRY(hipGetLastError());
+    return FQTK_OK;
+}
+
 int launch(const fqtk_matcher *m, const fqtk::MatchParams &P, hipStream_t stream) {
+    // memo path: reads all exactly L long (no obs_len), table present, caller did not opt out
+    if (m->use_cache && m->d_memo && !P.lens) {
+        fqtk::MemoParams Q;
+        Q.m = P;
+        Q.slots = m->d_memo;
+        Q.code_lut = m->d_code_lut;
+        Q.mask = m->memo_mask;
+        return m->memo_key64 ? launch_memo_vec<true>(m, Q, stream) : launch_memo_vec<false>(m, Q, stream);
+    }
     switch (m->NW) {
         case 1: return launch_vec<1, 4>(P, m->num_cus, stream);
         case 2: return launch_vec<2, 2>(P, m->num_cus, stream);
@@ -195,6 +251,115 @@ int collect_error(fqtk_matcher *m, hipStream_t stream, uint64_t *read_index) {
                   "Read barcode length differs from expected barcode length (%u): read index %llu is longer",
                   m->L, e);
     return fail(FQTK_ELEN, buf);
+}
+
+
+// ---- complete-memo construction (see memo_kernels.hip.h) -----------------------------------------
+constexpr uint64_t kMemoCandidateBudget = 6000000;   // strings scanned at create time, at most
+const uint8_t kCanonNib[5] = {1, 2, 4, 8, 15};
+const char kCanonChr[5] = {'A', 'C', 'G', 'T', 'N'};
+
+// #canonical strings within <= max_mm mismatches of one expected barcode (saturating).
+uint64_t count_candidates(const uint8_t *e, uint32_t L, uint32_t max_mm, uint64_t cap) {
+    std::vector<double> ways(max_mm + 1, 0.0);   // ways[k] = #strings with exactly k mismatches so far
+    ways[0] = 1.0;
+    for (uint32_t i = 0; i < L; ++i) {
+        uint32_t a = 0;
+        for (int c = 0; c < 5; ++c) a += ((kCanonNib[c] & ~e[i] & 0xF) == 0) ? 1u : 0u;
+        const uint32_t x = 5 - a;
+        for (int k = (int)max_mm; k >= 0; --k)
+            ways[k] = ways[k] * a + (k > 0 ? ways[k - 1] * x : 0.0);
+    }
+    double tot = 0;
+    for (double w : ways) tot += w;
+    return tot > (double)cap ? cap + 1 : (uint64_t)tot;
+}
+
+void enumerate_candidates(const uint8_t *e, uint32_t L, uint32_t budget, uint32_t pos, char *cur,
+                          std::vector<char> &out) {
+    if (pos == L) {
+        out.insert(out.end(), cur, cur + L);
+        return;
+    }
+    for (int c = 0; c < 5; ++c) {
+        const bool mis = (kCanonNib[c] & ~e[pos] & 0xF) != 0;
+        if (mis && budget == 0) continue;
+        cur[pos] = kCanonChr[c];
+        enumerate_candidates(e, L, budget - (mis ? 1u : 0u), pos + 1, cur, out);
+    }
+}
+
+void memo_key_of(const char *q, uint32_t L, uint32_t &lo, uint32_t &hi) {
+    lo = hi = 0;
+    for (uint32_t k = 0; k < L; ++k) {
+        uint32_t c = q[k] == 'A' ? 0u : q[k] == 'C' ? 1u : q[k] == 'G' ? 2u : q[k] == 'T' ? 3u : 4u;
+        if (k < 10) lo |= c << (3 * k); else hi |= c << (3 * (k - 10));
+    }
+}
+
+int build_memo(fqtk_matcher *m, const std::vector<std::vector<uint8_t>> &enc) {
+    if (m->L > fqtk::kMemoMaxLen) return FQTK_OK;
+    uint64_t total = 0;
+    for (uint32_t s = 0; s < m->S && total <= kMemoCandidateBudget; ++s)
+        total += count_candidates(enc[s].data(), m->L, m->max_mm, kMemoCandidateBudget);
+    if (total > kMemoCandidateBudget) return FQTK_OK;   // over budget: exhaustive scan only
+    std::vector<char> cand;
+    cand.reserve((size_t)total * m->L);
+    std::vector<char> cur(m->L);
+    for (uint32_t s = 0; s < m->S; ++s) enumerate_candidates(enc[s].data(), m->L, m->max_mm, 0, cur.data(), cand);
+    const uint64_t nc = cand.size() / m->L;
+    m->memo_candidates = nc;
+    std::vector<fqtk_match_t> res(nc);
+    if (nc) {
+        int rc = fqtk_matcher_assign_batch(m, reinterpret_cast<const uint8_t *>(cand.data()), m->L, nullptr, nc,
+                                           res.data(), nullptr);   // d_memo is still NULL: scan kernel
+        if (rc != FQTK_OK) return rc;
+    }
+    uint64_t n_some = 0;
+    for (uint64_t i = 0; i < nc; ++i) n_some += res[i].idx != FQTK_NO_MATCH;
+    uint64_t nslots = 1024;
+    while (nslots < n_some * 4) nslots <<= 1;
+    m->memo_key64 = m->L > 10;
+    const uint32_t mask = (uint32_t)(nslots - 1);
+    const size_t words_per_slot = m->memo_key64 ? 4 : 2;
+    std::vector<uint32_t> slots(nslots * words_per_slot, 0xFFFFFFFFu);
+    uint64_t entries = 0;
+    for (uint64_t i = 0; i < nc; ++i) {
+        if (res[i].idx == FQTK_NO_MATCH) continue;
+        uint32_t lo, hi, val;
+        memo_key_of(cand.data() + i * m->L, m->L, lo, hi);
+        std::memcpy(&val, &res[i], 4);
+        uint32_t slot = fqtk::memo_hash(lo, m->memo_key64 ? hi : 0u) & mask;
+        for (;;) {
+            uint32_t *e = &slots[(size_t)slot * words_per_slot];
+            const uint32_t eval = m->memo_key64 ? e[2] : e[1];
+            if (eval == fqtk::kMemoEmpty) {
+                e[0] = lo;
+                if (m->memo_key64) { e[1] = hi; e[2] = val; e[3] = 0; } else { e[1] = val; }
+                ++entries;
+                break;
+            }
+            if (e[0] == lo && (!m->memo_key64 || e[1] == hi)) break;   // duplicate candidate
+            slot = (slot + 1) & mask;
+        }
+    }
+    std::vector<uint32_t> code(64, 0x08080808u);
+    auto set_code = [&](char ch, uint32_t c) {
+        uint8_t *b = reinterpret_cast<uint8_t *>(code.data());
+        b[(uint8_t)ch] = (uint8_t)c;
+    };
+    set_code('A', 0); set_code('a', 0); set_code('C', 1); set_code('c', 1); set_code('G', 2); set_code('g', 2);
+    set_code('T', 3); set_code('t', 3); set_code('U', 3); set_code('u', 3);
+    set_code('N', 4); set_code('n', 4); set_code('.', 4);
+    HIP_TRY(hipMalloc(reinterpret_cast<void **>(&m->d_code_lut), 64 * sizeof(uint32_t)));
+    HIP_TRY(hipMemcpy(m->d_code_lut, code.data(), 64 * sizeof(uint32_t), hipMemcpyHostToDevice));
+    void *d = nullptr;
+    HIP_TRY(hipMalloc(&d, slots.size() * sizeof(uint32_t)));
+    HIP_TRY(hipMemcpy(d, slots.data(), slots.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+    m->memo_mask = mask;
+    m->memo_entries = entries;
+    m->d_memo = d;   // last: enables the memo path
+    return FQTK_OK;
 }
 
 }  // namespace
@@ -259,6 +424,7 @@ int fqtk_matcher_create(const char *const *barcodes, uint32_t n_samples, uint32_
     // Table: upper-case (:71), count no-calls (:73-74), encode (:75); stored as PRE-INVERTED
     // bit-planes [S][NW][4] so the kernel's inner op is (o & ~e) with no NOT.
     std::vector<uint32_t> table((size_t)n_samples * m->NW * 4, 0u);
+    std::vector<std::vector<uint8_t>> enc(n_samples, std::vector<uint8_t>(barcode_len));
     uint32_t max_ns = 0;
     for (uint32_t s = 0; s < n_samples; ++s) {
         uint32_t ns = 0;
@@ -267,6 +433,7 @@ int fqtk_matcher_create(const char *const *barcodes, uint32_t n_samples, uint32_
             if (b >= 'a' && b <= 'z') b = (uint8_t)(b - 32);
             if (b == 'N' || b == 'n' || b == '.') ns++;
             const uint8_t e = enc_byte(b);
+            enc[s][i] = e;
             const uint32_t w = i / 32, bit = i % 32;
             for (uint32_t j = 0; j < 4; ++j)
                 if (!((e >> j) & 1u)) table[((size_t)s * m->NW + w) * 4 + j] |= (1u << bit);
@@ -303,6 +470,10 @@ int fqtk_matcher_create(const char *const *barcodes, uint32_t n_samples, uint32_
     HIP_TRY_C(hipHostMalloc(reinterpret_cast<void **>(&m->h_err), sizeof(unsigned long long), hipHostMallocDefault));
     *m->h_err = ~0ull;
 #undef HIP_TRY_C
+    {
+        const int rc = build_memo(m, enc);
+        if (rc != FQTK_OK) return cleanup(rc);
+    }
     *out = m;
     return FQTK_OK;
 }
@@ -319,6 +490,8 @@ void fqtk_matcher_destroy(fqtk_matcher *m) {
         if (s.d_len) (void)hipFree(s.d_len);
         if (s.d_out) (void)hipFree(s.d_out);
     }
+    if (m->d_memo) (void)hipFree(m->d_memo);
+    if (m->d_code_lut) (void)hipFree(m->d_code_lut);
     if (m->d_table) (void)hipFree(m->d_table);
     if (m->d_lut) (void)hipFree(m->d_lut);
     if (m->d_err) (void)hipFree(m->d_err);
@@ -331,6 +504,14 @@ uint32_t fqtk_matcher_n_samples(const fqtk_matcher *m) { return m ? m->S : 0; }
 uint32_t fqtk_matcher_barcode_len(const fqtk_matcher *m) { return m ? m->L : 0; }
 uint32_t fqtk_matcher_max_ns_in_barcodes(const fqtk_matcher *m) { return m ? m->max_ns : 0; }
 int fqtk_matcher_device(const fqtk_matcher *m) { return m ? m->device : -1; }
+
+int fqtk_matcher_set_use_cache(fqtk_matcher *m, int use_cache) {
+    if (!m) return fail(FQTK_EINVAL, "matcher is NULL");
+    m->use_cache = use_cache ? 1 : 0;
+    return FQTK_OK;
+}
+uint64_t fqtk_matcher_memo_entries(const fqtk_matcher *m) { return (m && m->d_memo) ? m->memo_entries : 0; }
+uint64_t fqtk_matcher_memo_candidates(const fqtk_matcher *m) { return (m && m->d_memo) ? m->memo_candidates : 0; }
 
 int fqtk_matcher_assign_batch_device(fqtk_matcher *m, const void *d_obs, uint32_t stride,
                                      const void *d_obs_len, uint64_t n, void *d_out, void *d_counts,

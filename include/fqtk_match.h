@@ -70,8 +70,8 @@ int fqtk_device_count(int *n_devices);
 /* Replaces `BarcodeMatcher::new(samples, max_mismatches, min_mismatch_delta, use_cache)`
  * (barcode_matching.rs:55-86; sole call site demux.rs:921-926).  `barcodes[s]` are NUL-terminated
  * ASCII strings of exactly `barcode_len` bytes; they are upper-cased and encoded like the reference
- * does (:71-75) and copied -- the caller keeps ownership.  There is no `use_cache`: the reference's
- * memo cache is result-neutral (:174-181).  Errors: n_samples == 0 ("Must provide at least one
+ * does (:71-75) and copied -- the caller keeps ownership.  `use_cache` has its own setter below
+ * (default on, like demux.rs:925); the complete memo table is built here, on the device.  Errors: n_samples == 0 ("Must provide at least one
  * sample"), empty barcode ("Sample barcode cannot be empty string"), unequal lengths (the reference
  * would panic on the first assign), barcode_len > FQTK_MAX_BARCODE_LEN, n_samples >
  * FQTK_MAX_SAMPLES -> FQTK_EINVAL; no device -> FQTK_ENODEV. */
@@ -86,6 +86,17 @@ uint32_t fqtk_matcher_n_samples(const fqtk_matcher *m);
 uint32_t fqtk_matcher_barcode_len(const fqtk_matcher *m);
 uint32_t fqtk_matcher_max_ns_in_barcodes(const fqtk_matcher *m); /* :73-74 */
 int fqtk_matcher_device(const fqtk_matcher *m);
+
+/* Replaces the `use_cache` argument/field of BarcodeMatcher (barcode_matching.rs:41-42,59; demux
+ * passes true, demux.rs:925).  The reference's cache is a lazily filled AHashMap of Some results
+ * keyed on the read bytes (:174-181); here it is a COMPLETE table, precomputed at create time on the
+ * device, of every canonical (A/C/G/T/N) read within max_mismatches of a sample -- so a miss proves
+ * None.  Default 1.  0 forces the exhaustive per-sample scan for every read.  Results are identical
+ * either way (as in the reference).  The table is absent (scan only) when barcode_len > 20 or the
+ * candidate set exceeds the build budget; fqtk_matcher_memo_entries() then returns 0. */
+int fqtk_matcher_set_use_cache(fqtk_matcher *m, int use_cache);
+uint64_t fqtk_matcher_memo_entries(const fqtk_matcher *m);
+uint64_t fqtk_matcher_memo_candidates(const fqtk_matcher *m);
 
 /* Replaces one `BarcodeMatcher::assign(&mut self, read_bases: &[u8]) -> Option<BarcodeMatch>` call
  * per template (barcode_matching.rs:165-186; sole call site demux.rs:968) with one call per batch.

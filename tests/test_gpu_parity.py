@@ -22,18 +22,21 @@ def _loaded_native():
 
 
 def _compare(barcodes, mm, delta, obs, lens=None):
-    gm = BarcodeMatcher(barcodes, mm, delta)
-    got, counts = gm.assign_batch(obs, lens)
+    """Both device paths -- use_cache=True (complete memo + wave-cooperative fallback) and
+    use_cache=False (exhaustive scan) -- against the literal oracle."""
     lit = O.RefLiteral(barcodes, mm, delta, True)
     L = len(barcodes[0])
     if lens is None:
         i, b, nx, c = lit.assign_batch(np.ascontiguousarray(obs[:, :L]))
     else:
         i, b, nx, c = lit.assign_batch(obs, lens)
-    assert np.array_equal(got["idx"], i)
-    assert np.array_equal(got["best"], b)
-    assert np.array_equal(got["next"], nx)
-    assert np.array_equal(counts, c)
+    for use_cache in (True, False):
+        gm = BarcodeMatcher(barcodes, mm, delta, use_cache)
+        got, counts = gm.assign_batch(obs, lens)
+        assert np.array_equal(got["idx"], i), use_cache
+        assert np.array_equal(got["best"], b), use_cache
+        assert np.array_equal(got["next"], nx), use_cache
+        assert np.array_equal(counts, c), use_cache
     _loaded_native()
     return got, counts
 
@@ -73,7 +76,7 @@ def test_encode_all_256_byte_values_and_all_nibble_pairs():
     codes = "ACGTMRWSYKVHDBN"
     obs = np.arange(256, dtype=np.uint8)[:, None]
     for e in codes:
-        m = BarcodeMatcher([e], 255, 0)
+        m = BarcodeMatcher([e], 255, 0, use_cache=False)
         got, _ = m.assign_batch(obs)
         exp = ((O.ENC[np.arange(256)] & ~O.ENC[ord(e)] & 0xF) != 0).astype(np.uint8)
         assert np.array_equal(got["best"], exp), e
@@ -102,6 +105,32 @@ def test_empty_batch():
     m = BarcodeMatcher(["ACGT", "TTTT"], 1, 1)
     got, counts = m.assign_batch(np.empty((0, 4), dtype=np.uint8))
     assert got.shape == (0,) and counts.sum() == 0
+
+
+def test_memo_table_is_built_when_it_should_be():
+    w = synth.Workload(synth.CONFIGS[3])
+    m = BarcodeMatcher(w.barcodes, 1, 2)
+    # every canonical string within 1 mismatch of a sample: 1 + 16*4 per sample; all are Some here
+    # because the table has pairwise distance >= 3
+    assert m.memo_entries == 384 * (1 + 16 * 4)
+    assert BarcodeMatcher(["A" * 21, "C" * 21], 1, 2).memo_entries == 0      # L > 20: scan only
+    assert BarcodeMatcher(w.barcodes, 6, 2).memo_entries == 0                # over the build budget
+    assert BarcodeMatcher(["NNNNNNN"], 0, 2).memo_entries == 5 ** 7          # catch-all barcode
+
+
+def test_memo_path_handles_non_canonical_reads_in_every_lane_position():
+    """IUPAC / unknown bytes in the READ cannot use the memo: the wave-cooperative fallback must give
+    the scan kernel's answer wherever such reads sit in the wavefront, including all 64 lanes."""
+    rng = np.random.default_rng(5)
+    w = synth.Workload(synth.CONFIGS[3])
+    cfg = w.cfg
+    obs = w.fill_host(0, 4096).copy()
+    obs[rng.integers(0, 4096, 300), rng.integers(0, 16, 300)] = ord("R")     # scattered
+    obs[1024:1088, 3] = ord("X")                                             # one full wavefront
+    obs[2048:2049, :] = ord("Y")
+    obs[4095, 0] = ord("-")                                                  # last lane of last tile
+    _compare(w.barcodes, cfg.max_mismatches, cfg.min_mismatch_delta, obs)
+    _compare(w.barcodes, 2, 1, obs)
 
 
 # ------------------------------------------------------------------------------------------------
