@@ -8,6 +8,7 @@
 
 #include <algorithm>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
@@ -85,6 +86,8 @@ struct fqtk_matcher {
     // complete memo (memo_kernels.hip.h); absent when the candidate set is over budget or L > 20
     void *d_memo = nullptr;
     uint32_t *d_code_lut = nullptr;
+    uint32_t *d_hot = nullptr;               // hot subset (0-mismatch entries) for the LDS table
+    uint32_t hot_mask = 0;
     uint32_t memo_mask = 0;
     bool memo_key64 = false;
     uint64_t memo_entries = 0;
@@ -157,6 +160,7 @@ int launch_memo_vec(const fqtk_matcher *m, const fqtk::MemoParams &Q, hipStream_
     if (ntiles == 0) return FQTK_OK;
     const uint32_t grid = (uint32_t)std::min<uint64_t>(ntiles, (uint64_t)m->num_cus * 8);
     size_t shmem = (256 + 64) * sizeof(uint32_t);
+    if (Q.hot_mask) shmem += (size_t)(Q.hot_mask + 1) * (KEY64 ? 16 : 8);
     if (P.counts && P.lds_hist) shmem += (size_t)(P.S + 1) * sizeof(uint32_t);
     const uintptr_t base = reinterpret_cast<uintptr_t>(P.obs);
     const uint32_t nwords = (P.L + 3) / 4;
@@ -173,6 +177,22 @@ int launch_memo_vec(const fqtk_matcher *m, const fqtk::MemoParams &Q, hipStream_
     }
 #define FQTK_MEMO_LAUNCH(V) \
     hipLaunchKernelGGL((fqtk::memo_kernel<V, KEY64, R>), dim3(grid), dim3(fqtk::kBlock), shmem, stream, Q)
+#ifdef FQTK_DEV_ABLATE
+    if (const char *ab = std::getenv("FQTK_MEMO_ABLATE")) {
+        const int a = std::atoi(ab);
+#define FQTK_AB(A) case A: hipLaunchKernelGGL((fqtk::memo_kernel<4, KEY64, R, A>), dim3(grid), dim3(fqtk::kBlock), shmem, stream, Q); break;
+        if (vec == 4 && a > 0) {
+            switch (a) {
+                FQTK_AB(1) FQTK_AB(2) FQTK_AB(3) FQTK_AB(4) FQTK_AB(5) FQTK_AB(6) FQTK_AB(7) FQTK_AB(8)
+                FQTK_AB(9) FQTK_AB(12) FQTK_AB(13) FQTK_AB(14) FQTK_AB(15) FQTK_AB(16) FQTK_AB(17) FQTK_AB(18)
+                default: break;
+            }
+            HIP_TRY(hipGetLastError());
+            return FQTK_OK;
+        }
+#undef FQTK_AB
+    }
+#endif
     switch (vec) {
         case 4: FQTK_MEMO_LAUNCH(4); break;
         case 3: FQTK_MEMO_LAUNCH(3); break;
@@ -194,6 +214,8 @@ int launch(const fqtk_matcher *m, const fqtk::MatchParams &P, hipStream_t stream
         Q.slots = m->d_memo;
         Q.code_lut = m->d_code_lut;
         Q.mask = m->memo_mask;
+        Q.hot = m->d_hot;
+        Q.hot_mask = m->hot_mask;
         return m->memo_key64 ? launch_memo_vec<true>(m, Q, stream) : launch_memo_vec<false>(m, Q, stream);
     }
     switch (m->NW) {
@@ -317,30 +339,94 @@ int build_memo(fqtk_matcher *m, const std::vector<std::vector<uint8_t>> &enc) {
     }
     uint64_t n_some = 0;
     for (uint64_t i = 0; i < nc; ++i) n_some += res[i].idx != FQTK_NO_MATCH;
-    uint64_t nslots = 1024;
-    while (nslots < n_some * 4) nslots <<= 1;
     m->memo_key64 = m->L > 10;
-    const uint32_t mask = (uint32_t)(nslots - 1);
-    const size_t words_per_slot = m->memo_key64 ? 4 : 2;
-    std::vector<uint32_t> slots(nslots * words_per_slot, 0xFFFFFFFFu);
-    uint64_t entries = 0;
+    const size_t wps = m->memo_key64 ? 4 : 2;   // words per slot
+    // distinct Some entries (a string can neighbour several samples)
+    struct Entry { uint32_t lo, hi, val; };
+    std::vector<Entry> ents;
+    ents.reserve(n_some);
     for (uint64_t i = 0; i < nc; ++i) {
         if (res[i].idx == FQTK_NO_MATCH) continue;
-        uint32_t lo, hi, val;
-        memo_key_of(cand.data() + i * m->L, m->L, lo, hi);
-        std::memcpy(&val, &res[i], 4);
-        uint32_t slot = fqtk::memo_hash(lo, m->memo_key64 ? hi : 0u) & mask;
-        for (;;) {
-            uint32_t *e = &slots[(size_t)slot * words_per_slot];
-            const uint32_t eval = m->memo_key64 ? e[2] : e[1];
-            if (eval == fqtk::kMemoEmpty) {
-                e[0] = lo;
-                if (m->memo_key64) { e[1] = hi; e[2] = val; e[3] = 0; } else { e[1] = val; }
-                ++entries;
-                break;
+        Entry e;
+        memo_key_of(cand.data() + i * m->L, m->L, e.lo, e.hi);
+        std::memcpy(&e.val, &res[i], 4);
+        ents.push_back(e);
+    }
+    std::sort(ents.begin(), ents.end(), [](const Entry &a, const Entry &b) {
+        return a.hi != b.hi ? a.hi < b.hi : a.lo < b.lo;
+    });
+    ents.erase(std::unique(ents.begin(), ents.end(),
+                           [](const Entry &a, const Entry &b) { return a.lo == b.lo && a.hi == b.hi; }),
+               ents.end());
+    // two-choice (cuckoo) placement with random-walk eviction; grow on the (unlikely) failure
+    uint64_t nslots = 1024;
+    while (nslots < ents.size() * 4) nslots <<= 1;
+    std::vector<uint32_t> slots;
+    uint32_t mask = 0;
+    for (int attempt = 0;; ++attempt) {
+        if (attempt == 6) return fail(FQTK_EINVAL, "memo table construction failed");
+        mask = (uint32_t)(nslots - 1);
+        slots.assign(nslots * wps, 0xFFFFFFFFu);
+        std::vector<int64_t> owner(nslots, -1);
+        bool ok = true;
+        uint64_t rng = 0x9E3779B97F4A7C15ull;
+        for (size_t i = 0; i < ents.size() && ok; ++i) {
+            int64_t cur = (int64_t)i;
+            uint32_t a1, a2;
+            fqtk::memo_hash2(ents[cur].lo, m->memo_key64 ? ents[cur].hi : 0u, mask, a1, a2);
+            uint32_t pos = owner[a1] < 0 ? a1 : a2;
+            for (int kick = 0;; ++kick) {
+                if (owner[pos] < 0) { owner[pos] = cur; break; }
+                if (kick == 1000) { ok = false; break; }
+                std::swap(cur, owner[pos]);   // evict the occupant, re-home it
+                fqtk::memo_hash2(ents[cur].lo, m->memo_key64 ? ents[cur].hi : 0u, mask, a1, a2);
+                rng = rng * 6364136223846793005ull + 1442695040888963407ull;
+                pos = (a1 == pos) ? a2 : ((a2 == pos) ? a1 : ((rng >> 33) & 1 ? a1 : a2));
+                if (a1 == a2 && owner[pos] >= 0 && kick > 8) { ok = false; break; }
             }
-            if (e[0] == lo && (!m->memo_key64 || e[1] == hi)) break;   // duplicate candidate
-            slot = (slot + 1) & mask;
+        }
+        if (!ok) { nslots <<= 1; continue; }
+        for (uint64_t p = 0; p < nslots; ++p) {
+            if (owner[p] < 0) continue;
+            const Entry &e = ents[owner[p]];
+            uint32_t *w = &slots[p * wps];
+            w[0] = e.lo;
+            if (m->memo_key64) { w[1] = e.hi; w[2] = e.val; w[3] = 0; } else { w[1] = e.val; }
+        }
+        break;
+    }
+    const uint64_t entries = ents.size();
+    // hot table for LDS: 0-mismatch entries, two-choice without eviction (it is only a cache: an
+    // entry that finds both of its slots taken is simply served by the global table)
+    {
+        const uint32_t slot_bytes = m->memo_key64 ? 16 : 8;
+        uint32_t hot_slots = fqtk::kHotBytes / slot_bytes;
+        uint64_t n_hot = 0;
+        for (const Entry &e : ents) n_hot += ((e.val >> 16) & 0xFFu) == 0;
+        while (hot_slots > 64 && hot_slots / 2 >= n_hot * 2) hot_slots >>= 1;
+        if (n_hot) {
+            const uint32_t hmask = hot_slots - 1;
+            std::vector<uint32_t> hot((size_t)hot_slots * wps, 0xFFFFFFFFu);
+            std::vector<Entry> order;
+            for (const Entry &e : ents) if (((e.val >> 16) & 0xFFu) == 0) order.push_back(e);
+            std::sort(order.begin(), order.end(), [](const Entry &a, const Entry &b) {
+                return (a.val & 0xFFFFu) < (b.val & 0xFFFFu);   // low sample index first
+            });
+            for (const Entry &e : order) {
+                uint32_t a1, a2;
+                fqtk::memo_hash2(e.lo, m->memo_key64 ? e.hi : 0u, mask, a1, a2);
+                for (uint32_t a : {a1 & hmask, a2 & hmask}) {
+                    uint32_t *w = &hot[(size_t)a * wps];
+                    const uint32_t v = m->memo_key64 ? w[2] : w[1];
+                    if (v != fqtk::kMemoEmpty) continue;
+                    w[0] = e.lo;
+                    if (m->memo_key64) { w[1] = e.hi; w[2] = e.val; w[3] = 0; } else { w[1] = e.val; }
+                    break;
+                }
+            }
+            HIP_TRY(hipMalloc(reinterpret_cast<void **>(&m->d_hot), hot.size() * sizeof(uint32_t)));
+            HIP_TRY(hipMemcpy(m->d_hot, hot.data(), hot.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+            m->hot_mask = hmask;
         }
     }
     std::vector<uint32_t> code(64, 0x08080808u);
@@ -491,6 +577,7 @@ void fqtk_matcher_destroy(fqtk_matcher *m) {
         if (s.d_out) (void)hipFree(s.d_out);
     }
     if (m->d_memo) (void)hipFree(m->d_memo);
+    if (m->d_hot) (void)hipFree(m->d_hot);
     if (m->d_code_lut) (void)hipFree(m->d_code_lut);
     if (m->d_table) (void)hipFree(m->d_table);
     if (m->d_lut) (void)hipFree(m->d_lut);

@@ -8,7 +8,7 @@
 //   * canonical reads  = every base is one of A C G T N (any case; '.' = N; U = T).  At create time
 //     the host enumerates EVERY canonical string within max_mismatches of some sample, runs the
 //     exhaustive-scan kernel (match_kernels.hip.h) on them, and stores the ones whose result is
-//     Some(idx,best,next) in an open-addressing hash table in HBM (L2/MALL resident, <= a few MB);
+//     Some(idx,best,next) in a two-choice (cuckoo) hash table in HBM (L2/MALL resident, <= a few MB);
 //   * per read the kernel packs the barcode to a 3-bit-per-base key (LDS byte LUT), hashes, probes:
 //       hit  -> the stored (idx,best,next) -- computed by the scan kernel, so bit-identical to it;
 //       miss -> the read is canonical and NOT within max_mismatches of any sample, therefore
@@ -28,20 +28,31 @@ namespace fqtk {
 constexpr uint32_t kMemoMaxLen = 20;       // 3 bits/base, 10 bases per 32-bit half
 constexpr uint32_t kMemoEmpty = 0xFFFFFFFFu;
 
+constexpr uint32_t kHotBytes = 16384;      // LDS budget of the hot table per workgroup
+
 struct MemoParams {
     MatchParams m;
     const void *slots;        // KEY64: uint4 {lo, hi, val, 0}; else uint2 {lo, val}
     const uint32_t *code_lut; // [64] dwords = 256 bytes: A0 C1 G2 T3 N4, anything else 8
+    const uint32_t *hot;      // hot subset (exact matches) in the same slot format, copied to LDS
     uint32_t mask;            // n_slots - 1
+    uint32_t hot_mask;        // hot slots - 1 (0 = no hot table)
 };
 
-__host__ __device__ inline uint32_t memo_hash(uint32_t lo, uint32_t hi) {
+// Two-choice (cuckoo) placement: a key lives in slot h1 or slot h2, nowhere else, so a lookup is two
+// INDEPENDENT loads issued back to back -- no probe loop, no divergence, one memory round trip.
+__host__ __device__ inline void memo_hash2(uint32_t lo, uint32_t hi, uint32_t mask, uint32_t &s1,
+                                           uint32_t &s2) {
     uint32_t h = lo * 0x9E3779B1u;
     h ^= hi * 0x85EBCA77u;
     h ^= h >> 15;
     h *= 0x2C1B3C6Du;
     h ^= h >> 13;
-    return h;
+    s1 = h & mask;
+    uint32_t g = (h >> 16) | (h << 16);
+    g *= 0xC2B2AE3Du;
+    g ^= g >> 14;
+    s2 = g & mask;
 }
 
 // (best, second) packed keys -> result word (barcode_matching.rs:150-159).
@@ -85,17 +96,26 @@ __device__ __forceinline__ void wave_scan(const Planes<NW> &mine, int src, const
     }
 }
 
-template <int VEC, bool KEY64, int R>
+// ABL: developer-only ablation mask (tools/ablate.sh builds with -DFQTK_DEV_ABLATE); 0 in the product.
+//   1 = skip table probes, 2 = skip LDS code lookups, 4 = skip histogram, 8 = skip result store,
+//   16 = skip the LDS hot table
+template <int VEC, bool KEY64, int R, int ABL = 0>
 __global__ __launch_bounds__(kBlock) void memo_kernel(const MemoParams Q) {
     const MatchParams &P = Q.m;
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
     uint32_t *lds_lut = smem;                                        // 256 x u32 spread LUT (fallback)
     const uint8_t *lds_code = reinterpret_cast<const uint8_t *>(smem + 256);   // 256 x u8 code LUT
-    uint32_t *lds_hist = smem + 256 + 64;
+    // hot table: the memo entries with 0 mismatches (a read that IS a sample barcode -- the bulk of
+    // real data) live in LDS, so most lanes never touch the global table; the rest probe it with
+    // the hit lanes masked off, which shrinks the gather traffic by the hit rate.
+    const uint32_t hot_words = Q.hot_mask ? (Q.hot_mask + 1) * (KEY64 ? 4u : 2u) : 0u;
+    uint32_t *lds_hot = smem + 256 + 64;
+    uint32_t *lds_hist = lds_hot + hot_words;
 
     const uint32_t tid = threadIdx.x;
     lds_lut[tid] = P.lut[tid];
     if (tid < 64) smem[256 + tid] = Q.code_lut[tid];
+    for (uint32_t w = tid; w < hot_words; w += kBlock) lds_hot[w] = Q.hot[w];
     const uint32_t bins = P.S + 1;
     if (P.counts && P.lds_hist)
         for (uint32_t b = tid; b < bins; b += kBlock) lds_hist[b] = 0;
@@ -126,31 +146,74 @@ __global__ __launch_bounds__(kBlock) void memo_kernel(const MemoParams Q) {
             for (int k = 0; k < (int)kMemoMaxLen; ++k) {
                 if ((uint32_t)k < L) {   // wave-uniform
                     const uint32_t byte = (words[r][k >> 2] >> (8 * (k & 3))) & 0xFFu;
-                    const uint32_t c = lds_code[byte];
+                    const uint32_t c = (ABL & 2) ? (byte & 3u) : lds_code[byte];
                     b |= c;
                     if (k < 10) l |= c << (3 * k); else h |= c << (3 * (k - 10));
                 }
             }
             lo[r] = l; hi[r] = h; bad[r] = (b & 8u) && live[r];
         }
-        // ---- probe (linear probing; EMPTY slots carry val = 0xFFFFFFFF = the None encoding) -------
+        // ---- probe: both candidate slots of every read are loaded up front (2*R independent
+        //      gathers in flight), then compared.  Empty slots carry key = ~0 and val = None. -------
+        uint32_t s1[R], s2[R];
 #pragma unroll
-        for (int r = 0; r < R; ++r) {
-            uint32_t slot = memo_hash(lo[r], KEY64 ? hi[r] : 0u) & Q.mask;
-            uint32_t v = kMemoEmpty;
-            if (!bad[r]) {
-                for (;;) {
-                    if constexpr (KEY64) {
-                        const uint4 e = reinterpret_cast<const uint4 *>(Q.slots)[slot];
-                        if ((e.x == lo[r] && e.y == hi[r]) || e.z == kMemoEmpty) { v = e.z; break; }
-                    } else {
-                        const uint2 e = reinterpret_cast<const uint2 *>(Q.slots)[slot];
-                        if (e.x == lo[r] || e.y == kMemoEmpty) { v = e.y; break; }
-                    }
-                    slot = (slot + 1) & Q.mask;
+        for (int r = 0; r < R; ++r) memo_hash2(lo[r], KEY64 ? hi[r] : 0u, Q.mask, s1[r], s2[r]);
+        bool hit[R];
+#pragma unroll
+        for (int r = 0; r < R; ++r) { hit[r] = false; res[r] = kMemoEmpty; }
+        if (Q.hot_mask && !(ABL & 16)) {   // wave-uniform
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                const uint32_t a1 = s1[r] & Q.hot_mask, a2 = s2[r] & Q.hot_mask;
+                if constexpr (KEY64) {
+                    const uint4 h1 = reinterpret_cast<const uint4 *>(lds_hot)[a1];
+                    const uint4 h2 = reinterpret_cast<const uint4 *>(lds_hot)[a2];
+                    const bool m1 = h1.x == lo[r] && h1.y == hi[r];
+                    const bool m2 = h2.x == lo[r] && h2.y == hi[r];
+                    hit[r] = m1 || m2;
+                    res[r] = m1 ? h1.z : (m2 ? h2.z : kMemoEmpty);
+                } else {
+                    const uint2 h1 = reinterpret_cast<const uint2 *>(lds_hot)[a1];
+                    const uint2 h2 = reinterpret_cast<const uint2 *>(lds_hot)[a2];
+                    const bool m1 = h1.x == lo[r], m2 = h2.x == lo[r];
+                    hit[r] = m1 || m2;
+                    res[r] = m1 ? h1.y : (m2 ? h2.y : kMemoEmpty);
                 }
             }
-            res[r] = v;
+        }
+        if constexpr (ABL & 1) {
+#pragma unroll
+            for (int r = 0; r < R; ++r) res[r] = (s1[r] ^ s2[r]) | 0xFFFFu;
+        } else if constexpr (KEY64) {
+            uint4 e1[R], e2[R];
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                if (!hit[r] && !bad[r]) {
+                    e1[r] = reinterpret_cast<const uint4 *>(Q.slots)[s1[r]];
+                    e2[r] = reinterpret_cast<const uint4 *>(Q.slots)[s2[r]];
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                if (!hit[r] && !bad[r]) {
+                    const bool m1 = e1[r].x == lo[r] && e1[r].y == hi[r];
+                    const bool m2 = e2[r].x == lo[r] && e2[r].y == hi[r];
+                    res[r] = m1 ? e1[r].z : (m2 ? e2[r].z : kMemoEmpty);
+                }
+            }
+        } else {
+            uint2 e1[R], e2[R];
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                if (!hit[r] && !bad[r]) {
+                    e1[r] = reinterpret_cast<const uint2 *>(Q.slots)[s1[r]];
+                    e2[r] = reinterpret_cast<const uint2 *>(Q.slots)[s2[r]];
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < R; ++r)
+                if (!hit[r] && !bad[r])
+                    res[r] = e1[r].x == lo[r] ? e1[r].y : (e2[r].x == lo[r] ? e2[r].y : kMemoEmpty);
         }
         // ---- rare: non-canonical reads -> wave-cooperative exhaustive scan ---------------------
 #pragma unroll
@@ -173,8 +236,9 @@ __global__ __launch_bounds__(kBlock) void memo_kernel(const MemoParams Q) {
         for (int r = 0; r < R; ++r) {
             if (!live[r]) continue;
             const uint64_t i = t * tile + (uint64_t)r * kBlock + tid;
+            if constexpr (ABL & 8) { if (res[r] == 0x12345u) P.out[i] = res[r]; } else
             P.out[i] = res[r];
-            if (P.counts) {
+            if (P.counts && !(ABL & 4)) {
                 const uint32_t idx = res[r] & 0xFFFFu;
                 const uint32_t bin = idx == kNoMatch ? P.S : idx;
                 if (P.lds_hist) atomicAdd(&lds_hist[bin], 1u);
