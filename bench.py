@@ -84,6 +84,7 @@ def main() -> int:
     import torch.distributed as dist
 
     from fqtk_amd import BarcodeMatcher, synth
+    from fqtk_amd.sharding import allreduce_counts
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -142,8 +143,7 @@ def main() -> int:
     ev1.record()                                   # same stream as the kernels
     total_counts = d_counts
     if world > 1:                                  # the one collective: per-sample counts over RCCL
-        total_counts = d_counts.clone()
-        dist.all_reduce(total_counts, op=dist.ReduceOp.SUM)
+        total_counts = allreduce_counts(d_counts.clone())
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
