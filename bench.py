@@ -178,6 +178,18 @@ def main() -> int:
             checked += m
         parity = f"bit-exact vs oracle on {checked} reads (3 windows)"
 
+    # HBM traffic of the dominant kernel: measured separately with the PMC counters (they cannot be
+    # read live) by tools/profile_bench.sh and committed under profiles/; reported only when it was
+    # collected for this exact workload and kernel, else null.
+    traffic = None
+    try:
+        with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as fh:
+            t = json.load(fh).get(f"cfg{args.config}")
+        if t and t["reads_per_launch"] == n and kernel_name.startswith(t["kernel_prefix"]):
+            traffic = t["traffic_bytes_per_launch"]
+    except (OSError, ValueError, KeyError):
+        pass
+
     if rank == 0:
         reads_total = n * args.steps * world
         value = reads_total / elapsed / 1e6
@@ -214,7 +226,9 @@ def main() -> int:
                 "peak": HBM_PEAK_GBPS,
                 "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBPS, 5),
-                "traffic": None,
+                "traffic": traffic,
+                "traffic_unit": "bytes per launch (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, profiles/)",
+                "algorithmic_bytes_per_launch": n * cfg.bytes_per_read,
                 "kernel_ms": round(kernel_ms, 4),
                 "algorithmic_bytes_per_read": cfg.bytes_per_read,
             },
