@@ -151,10 +151,9 @@ int launch_vec(const fqtk::MatchParams &P, int num_cus, hipStream_t stream) {
     return launch_t<NW, R, 0>(P, num_cus, stream);
 }
 
-template <bool KEY64>
+template <bool KEY64, int R = 2>
 int launch_memo_vec(const fqtk_matcher *m, const fqtk::MemoParams &Q, hipStream_t stream) {
     const fqtk::MatchParams &P = Q.m;
-    constexpr int R = 2;
     const uint64_t tile = (uint64_t)fqtk::kBlock * R;
     const uint64_t ntiles = (P.n + tile - 1) / tile;
     if (ntiles == 0) return FQTK_OK;
@@ -183,8 +182,8 @@ int launch_memo_vec(const fqtk_matcher *m, const fqtk::MemoParams &Q, hipStream_
 #define FQTK_AB(A) case A: hipLaunchKernelGGL((fqtk::memo_kernel<4, KEY64, R, A>), dim3(grid), dim3(fqtk::kBlock), shmem, stream, Q); break;
         if (vec == 4 && a > 0) {
             switch (a) {
-                FQTK_AB(1) FQTK_AB(2) FQTK_AB(3) FQTK_AB(4) FQTK_AB(5) FQTK_AB(6) FQTK_AB(7) FQTK_AB(8)
-                FQTK_AB(9) FQTK_AB(12) FQTK_AB(13) FQTK_AB(14) FQTK_AB(15) FQTK_AB(16) FQTK_AB(17) FQTK_AB(18)
+                FQTK_AB(1) FQTK_AB(3) FQTK_AB(4)
+                FQTK_AB(7) FQTK_AB(16) FQTK_AB(32) FQTK_AB(33) FQTK_AB(39)
                 default: break;
             }
             HIP_TRY(hipGetLastError());
@@ -216,6 +215,12 @@ int launch(const fqtk_matcher *m, const fqtk::MatchParams &P, hipStream_t stream
         Q.mask = m->memo_mask;
         Q.hot = m->d_hot;
         Q.hot_mask = m->hot_mask;
+#ifdef FQTK_DEV_ABLATE
+        if (const char *rr = std::getenv("FQTK_MEMO_R")) {
+            if (std::atoi(rr) == 4) return m->memo_key64 ? launch_memo_vec<true, 4>(m, Q, stream) : launch_memo_vec<false, 4>(m, Q, stream);
+            if (std::atoi(rr) == 1) return m->memo_key64 ? launch_memo_vec<true, 1>(m, Q, stream) : launch_memo_vec<false, 1>(m, Q, stream);
+        }
+#endif
         return m->memo_key64 ? launch_memo_vec<true>(m, Q, stream) : launch_memo_vec<false>(m, Q, stream);
     }
     switch (m->NW) {

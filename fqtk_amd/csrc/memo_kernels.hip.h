@@ -100,7 +100,8 @@ __device__ __forceinline__ void wave_scan(const Planes<NW> &mine, int src, const
 //   1 = skip table probes, 2 = skip LDS code lookups, 4 = skip histogram, 8 = skip result store,
 //   16 = skip the LDS hot table
 template <int VEC, bool KEY64, int R, int ABL = 0>
-__global__ __launch_bounds__(kBlock) void memo_kernel(const MemoParams Q) {
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(8, 8)))
+void memo_kernel(const MemoParams Q) {
     const MatchParams &P = Q.m;
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
     uint32_t *lds_lut = smem;                                        // 256 x u32 spread LUT (fallback)

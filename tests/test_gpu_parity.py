@@ -101,6 +101,17 @@ def test_single_sample_and_ties():
     assert t.assign(b"AAAT") == BarcodeMatch(0, 1, 1)   # lowest index wins, next == best
 
 
+def test_all_0xff_reads_do_not_alias_empty_table_slots():
+    # enc(0xFF) = 0 never mismatches: with delta 0 the reference answers Some(0, 0, 0)
+    barcodes = ["ACGTACGTACGTACGT", "TTTTACGTACGTACGA"]
+    obs = np.full((300, 16), 0xFF, dtype=np.uint8)
+    obs[7] = np.frombuffer(b"ACGTACGTACGTACGT", dtype=np.uint8)
+    for delta in (0, 2):
+        got, _ = _compare(barcodes, 1, delta, obs)
+    b8 = ["ACGTACGT", "TTTTACGA"]
+    _compare(b8, 1, 0, np.full((300, 8), 0xFF, dtype=np.uint8))
+
+
 def test_empty_batch():
     m = BarcodeMatcher(["ACGT", "TTTT"], 1, 1)
     got, counts = m.assign_batch(np.empty((0, 4), dtype=np.uint8))
