@@ -32,6 +32,32 @@ def _stale(out: str, deps) -> bool:
     return any(os.path.getmtime(d) > t for d in deps)
 
 
+HOST = os.path.join(CSRC, "host")
+BINDIR = os.path.join(HERE, "bin")
+CXX = os.environ.get("CXX", "g++")
+
+
+def build_host(force: bool = False, verbose: bool = False) -> None:
+    """The C++ host side above the C ABI: `fqtk demux` binary + a ctypes shim for the CPU tests."""
+    os.makedirs(BINDIR, exist_ok=True)
+    deps = glob.glob(os.path.join(HOST, "*.hpp")) + glob.glob(os.path.join(INCLUDE, "*.h"))
+    shim = os.path.join(LIBDIR, "libfqtk_host.so")
+    src = os.path.join(HOST, "host_capi.cpp")
+    if force or _stale(shim, [src] + deps):
+        cmd = [CXX, "-O2", "-std=c++17", "-shared", "-fPIC", "-Wall", "-o", shim, src, "-lz"]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.run(cmd, check=True)
+    exe = os.path.join(BINDIR, "fqtk")
+    src = os.path.join(HOST, "demux.cpp")
+    if force or _stale(exe, [src] + deps + [os.path.join(LIBDIR, "libfqtk_match.so")]):
+        cmd = [CXX, "-O2", "-std=c++17", "-Wall", "-pthread", "-o", exe, src, "-L", LIBDIR, "-lfqtk_match",
+               "-lz", "-Wl,-rpath,$ORIGIN/../lib", "-Wl,-rpath,/opt/rocm/lib"]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.run(cmd, check=True)
+
+
 def build(force: bool = False, verbose: bool = False) -> None:
     os.makedirs(LIBDIR, exist_ok=True)
     deps_common = glob.glob(os.path.join(CSRC, "*.h")) + glob.glob(os.path.join(INCLUDE, "*.h"))
@@ -47,6 +73,7 @@ def build(force: bool = False, verbose: bool = False) -> None:
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.run(cmd, check=True)
+    build_host(force=force, verbose=verbose)
 
 
 if __name__ == "__main__":

@@ -1,0 +1,613 @@
+// demux.cpp -- `fqtk demux`: host pipeline around the MI355X barcode matcher.
+//
+// the callers and data formats either side of the hot path.  Mirrors
+// Demux::execute (/root/reference/src/bin/commands/demux.rs:881-1001) with the same flags
+// (:597-652), validation messages (:806-875), file naming (:674-688), skip rule (:300-306,954-957),
+// record routing (:968-975), header rewriting (:171-267) and metrics file (:994-998).
+//
+// What is different, by design (MI355X-first; nothing here is translated from the Rust):
+//   * the matcher is NOT called per template: templates are gathered into chunks, their sample
+//     barcodes packed into a pinned SoA buffer (demux.rs:121-123 defines the concatenation) and
+//     matched on the GPU through the C ABI (include/fqtk_match.h) on alternating pipeline slots, so
+//     gunzip/parse of chunk k+1, H2D+kernel+D2H of chunk k and BGZF-compress/write of chunk k-1 overlap;
+//   * routing/compression is partitioned BY SAMPLE across worker threads (each output file has one
+//     owner, no locks, input order preserved per file as in the sequential reference loop).
+// All matching goes through libfqtk_match.so; there is no CPU matching path here.
+#include <sys/resource.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
+#include <atomic>
+#include <condition_variable>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <deque>
+#include <memory>
+#include <mutex>
+#include <string>
+#include <string_view>
+#include <thread>
+#include <vector>
+
+#include "../../../include/fqtk_match.h"
+#include "bgzf.hpp"
+#include "fastq_io.hpp"
+#include "header.hpp"
+#include "metrics.hpp"
+#include "read_structure.hpp"
+#include "samples.hpp"
+
+using namespace fqtk_host;
+
+namespace {
+
+void info(const char *fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    std::fputs("[INFO fqtk] ", stderr);
+    std::vfprintf(stderr, fmt, ap);
+    std::fputc('\n', stderr);
+    va_end(ap);
+}
+
+[[noreturn]] void die(const std::string &msg) {
+    std::fprintf(stderr, "Error: %s\n", msg.c_str());
+    std::fflush(stderr);
+    std::_Exit(1);
+}
+
+struct Options {
+    std::vector<std::string> inputs, read_structures, skip_reasons;
+    std::vector<char> output_types{'T'};
+    std::string sample_metadata, output, unmatched_prefix = "unmatched";
+    unsigned long max_mismatches = 1, min_mismatch_delta = 2, threads = 8, compression_level = 5;
+    int device = 0;
+    unsigned long chunk_reads = 1ul << 18;
+};
+
+const char *kUsage =
+    "Usage: fqtk demux [OPTIONS] --inputs <INPUTS>... --read-structures <READ_STRUCTURES>... \\\n"
+    "                  --sample-metadata <SAMPLE_METADATA> --output <OUTPUT>\n"
+    "  -i, --inputs <INPUTS>...                    input FASTQ files, one per sequencing read\n"
+    "  -r, --read-structures <READ_STRUCTURES>...  read structures, one per input FASTQ\n"
+    "  -b, --output-types <OUTPUT_TYPES>...        segment types to write: T B M C [default: T]\n"
+    "  -s, --sample-metadata <SAMPLE_METADATA>     TSV with columns sample_id, barcode\n"
+    "  -o, --output <OUTPUT>                       output directory\n"
+    "  -u, --unmatched-prefix <PREFIX>             [default: unmatched]\n"
+    "      --max-mismatches <N>                    [default: 1]\n"
+    "  -d, --min-mismatch-delta <N>                [default: 2]\n"
+    "  -t, --threads <N>                           [default: 8] (must be 5 or more)\n"
+    "  -c, --compression-level <N>                 [default: 5]\n"
+    "  -S, --skip-reasons <REASON>...              too-few-bases\n"
+    "      --device <N>                            GPU to use [default: 0] (additive flag)\n"
+    "      --chunk-reads <N>                       templates per GPU chunk [default: 262144] (additive flag)\n";
+
+bool parse_ulong(const std::string &s, unsigned long *out) {
+    if (s.empty()) return false;
+    char *end = nullptr;
+    unsigned long v = std::strtoul(s.c_str(), &end, 10);
+    if (*end != '\0' || s[0] == '-') return false;
+    *out = v;
+    return true;
+}
+
+Options parse_args(int argc, char **argv) {
+    Options o;
+    std::vector<std::string> args(argv, argv + argc);
+    size_t i = 0;
+    auto canon = [](const std::string &a) -> std::string {
+        static const std::pair<const char *, const char *> shorts[] = {
+            {"-i", "--inputs"}, {"-r", "--read-structures"}, {"-b", "--output-types"}, {"-s", "--sample-metadata"},
+            {"-o", "--output"}, {"-u", "--unmatched-prefix"}, {"-d", "--min-mismatch-delta"}, {"-t", "--threads"},
+            {"-c", "--compression-level"}, {"-S", "--skip-reasons"}};
+        for (auto &p : shorts) if (a == p.first) return p.second;
+        return a;
+    };
+    bool types_given = false;
+    while (i < args.size()) {
+        std::string a = args[i++];
+        std::string inline_val;
+        bool has_inline = false;
+        const size_t eq = a.find('=');
+        if (a.rfind("--", 0) == 0 && eq != std::string::npos) {
+            inline_val = a.substr(eq + 1);
+            a = a.substr(0, eq);
+            has_inline = true;
+        }
+        a = canon(a);
+        auto multi = [&](std::vector<std::string> &dst) {
+            if (has_inline) { dst.push_back(inline_val); return; }
+            size_t start = dst.size();
+            while (i < args.size() && !(args[i].size() > 1 && args[i][0] == '-' && !std::isdigit((unsigned char)args[i][1]) && args[i] != "-"))
+                dst.push_back(args[i++]);
+            if (dst.size() == start) die("a value is required for '" + a + "' but none was supplied");
+        };
+        auto single = [&]() -> std::string {
+            if (has_inline) return inline_val;
+            if (i >= args.size()) die("a value is required for '" + a + "' but none was supplied");
+            return args[i++];
+        };
+        auto num = [&](unsigned long *dst) {
+            const std::string v = single();
+            if (!parse_ulong(v, dst)) die("invalid value '" + v + "' for '" + a + "': invalid digit found in string");
+        };
+        if (a == "--inputs") multi(o.inputs);
+        else if (a == "--read-structures") multi(o.read_structures);
+        else if (a == "--output-types") {
+            std::vector<std::string> v;
+            multi(v);
+            if (!types_given) o.output_types.clear();
+            types_given = true;
+            for (const std::string &t : v) {
+                if (t.size() != 1) die("invalid value '" + t + "' for '--output-types': too many characters in string");
+                o.output_types.push_back(t[0]);
+            }
+        } else if (a == "--sample-metadata") o.sample_metadata = single();
+        else if (a == "--output") o.output = single();
+        else if (a == "--unmatched-prefix") o.unmatched_prefix = single();
+        else if (a == "--max-mismatches") num(&o.max_mismatches);
+        else if (a == "--min-mismatch-delta") num(&o.min_mismatch_delta);
+        else if (a == "--threads") num(&o.threads);
+        else if (a == "--compression-level") num(&o.compression_level);
+        else if (a == "--skip-reasons") multi(o.skip_reasons);
+        else if (a == "--device") { unsigned long d; num(&d); o.device = (int)d; }
+        else if (a == "--chunk-reads") num(&o.chunk_reads);
+        else if (a == "--help" || a == "-h") { std::fputs(kUsage, stdout); std::exit(0); }
+        else die("unexpected argument '" + a + "' found\n\n" + kUsage);
+    }
+    std::string missing;
+    if (o.inputs.empty()) missing += " --inputs <INPUTS>...";
+    if (o.read_structures.empty()) missing += " --read-structures <READ_STRUCTURES>...";
+    if (o.sample_metadata.empty()) missing += " --sample-metadata <SAMPLE_METADATA>";
+    if (o.output.empty()) missing += " --output <OUTPUT>";
+    if (!missing.empty()) die("the following required arguments were not provided:" + missing + "\n\n" + kUsage);
+    return o;
+}
+
+template <typename T>
+class BoundedQueue {
+  public:
+    explicit BoundedQueue(size_t cap) : cap_(cap) {}
+    void push(T v) {
+        std::unique_lock<std::mutex> lk(mu_);
+        not_full_.wait(lk, [&] { return q_.size() < cap_; });
+        q_.push_back(std::move(v));
+        not_empty_.notify_one();
+    }
+    T pop() {
+        std::unique_lock<std::mutex> lk(mu_);
+        not_empty_.wait(lk, [&] { return !q_.empty(); });
+        T v = std::move(q_.front());
+        q_.pop_front();
+        not_full_.notify_one();
+        return v;
+    }
+  private:
+    size_t cap_;
+    std::mutex mu_;
+    std::condition_variable not_full_, not_empty_;
+    std::deque<T> q_;
+};
+
+struct ReadResult {   // one batch from one input, or an error
+    std::unique_ptr<RecBatch> batch;
+    std::string error;
+};
+
+struct Chunk {
+    std::vector<std::unique_ptr<RecBatch>> batches;   // one per input
+    size_t n = 0;
+    std::vector<uint8_t> skip;          // per template
+    std::vector<fqtk_match_t> res;      // per template (skipped ones hold NO_MATCH and are never routed)
+};
+
+struct SegRef { uint32_t input, seg; };
+
+// One BGZF output file, owned by exactly one router thread.
+struct OutFile {
+    FILE *f = nullptr;
+    std::string path;
+    std::string buf;
+};
+
+struct Plan {
+    std::vector<ReadStructure> rs;
+    std::vector<SegRef> by_type[4];   // T, B, M, C in (input, segment) order
+    bool want[4] = {false, false, false, false};
+    size_t files_per_sample = 0;
+    size_t file_base[4] = {0, 0, 0, 0};
+};
+
+const SegType kTypes[4] = {SegType::Template, SegType::SampleBarcode, SegType::MolecularBarcode, SegType::CellularBarcode};
+const char kCodes[4] = {'R', 'I', 'U', 'C'};
+
+void flush_blocks(OutFile &of, int level, bool final) {
+    std::vector<uint8_t> comp;
+    std::string err;
+    size_t off = 0;
+    while (of.buf.size() - off >= kBgzfBlockSize || (final && off < of.buf.size())) {
+        const size_t n = std::min(kBgzfBlockSize, of.buf.size() - off);
+        comp.clear();
+        if (!bgzf_compress_block(reinterpret_cast<const uint8_t *>(of.buf.data()) + off, n, level, comp, &err)) die(err);
+        if (std::fwrite(comp.data(), 1, comp.size(), of.f) != comp.size()) die("write failed: " + of.path);
+        off += n;
+    }
+    of.buf.erase(0, off);
+    if (final) {
+        if (std::fwrite(kBgzfEof, 1, sizeof kBgzfEof, of.f) != sizeof kBgzfEof) die("write failed: " + of.path);
+        if (std::fclose(of.f) != 0) die("close failed: " + of.path);
+        of.f = nullptr;
+    }
+}
+
+}  // namespace
+
+int main(int argc, char **argv) {
+    if (argc < 2 || std::string(argv[1]) == "--help" || std::string(argv[1]) == "-h") {
+        std::fputs("fqtk (MI355X-native demux)\n\nUsage: fqtk <COMMAND>\n\nCommands:\n  demux  Performs sample demultiplexing on FASTQs\n", stdout);
+        return argc < 2 ? 2 : 0;
+    }
+    if (std::string(argv[1]) != "demux") die(std::string("unrecognized subcommand '") + argv[1] + "' (only `demux` is in scope, see DESIGN.md)");
+    Options opt = parse_args(argc - 2, argv + 2);
+
+    // ---- read structures are parsed at argument time by clap in the reference ---------------------
+    Plan plan;
+    for (const std::string &t : opt.read_structures) {
+        ReadStructure r;
+        std::string err;
+        if (!ReadStructure::parse(t, &r, &err)) die("invalid value '" + t + "' for '--read-structures <READ_STRUCTURES>...': " + err);
+        plan.rs.push_back(r);
+    }
+    bool skip_few = false;
+    for (const std::string &s : opt.skip_reasons) {   // demux.rs:69-77
+        if (s == "too few bases" || s == "too-few-bases" || s == "toofewbases") skip_few = true;
+        else die("invalid value '" + s + "' for '--skip-reasons <SKIP_REASONS>': Invalid skip reason: " + s);
+    }
+
+    // ---- validate_and_prepare_inputs (demux.rs:806-875): all problems reported together ----------
+    std::vector<std::string> problems;
+    if (opt.inputs.size() != plan.rs.size())
+        problems.push_back("The same number of read structures should be given as FASTQs " +
+                           std::to_string(plan.rs.size()) + " read-structures provided for " +
+                           std::to_string(opt.inputs.size()) + " FASTQs");
+    struct stat st;
+    if (stat(opt.output.c_str(), &st) != 0) {
+        info("Output directory \"%s\" didn't exist, creating it.", opt.output.c_str());
+        std::string cmd;
+        // mkdir -p
+        for (size_t p = 1; p <= opt.output.size(); ++p)
+            if (p == opt.output.size() || opt.output[p] == '/') {
+                std::string sub = opt.output.substr(0, p);
+                if (!sub.empty() && stat(sub.c_str(), &st) != 0 && mkdir(sub.c_str(), 0777) != 0) die("cannot create " + sub);
+            }
+    }
+    if (stat(opt.output.c_str(), &st) == 0 && (st.st_mode & 0222) == 0)
+        problems.push_back("Ouput directory \"" + opt.output + "\" cannot be read-only");
+    for (char c : opt.output_types) {
+        SegType t;
+        if (!seg_type_from_char(c, &t)) problems.push_back(std::string("Error parsing segment types to report: Read structure had unknown type: ") + c);
+    }
+    for (const std::string &in : opt.inputs)
+        if (access(in.c_str(), F_OK) != 0) problems.push_back("Provided input file \"" + in + "\" doesn't exist");
+    std::vector<std::unique_ptr<FastqSource>> sources;
+    for (const std::string &in : opt.inputs) {
+        auto src = std::make_unique<FastqSource>();
+        std::string err;
+        if (access(in.c_str(), F_OK) == 0 && !src->open(in, &err)) problems.push_back("Error opening input files for reading: " + err);
+        sources.push_back(std::move(src));
+    }
+    if (opt.threads < 5) problems.push_back("Threads provided " + std::to_string(opt.threads) + " was too low! Must be 5 or more.");
+    if (problems.empty()) {
+        for (char c : opt.output_types)
+            for (int k = 0; k < 4; ++k) if ((char)kTypes[k] == c) plan.want[k] = true;
+        if (opt.output_types.empty()) problems.push_back("No output types requested, must request at least one output segment type.");
+    }
+    if (!problems.empty()) {
+        std::string details = "Inputs failed validation!\n";
+        for (const std::string &p : problems) details += "    - " + p + "\n";
+        die("The following errors with the input(s) were detected:\n" + details);
+    }
+
+    // ---- samples (demux.rs:884) ----------------------------------------------------------------------
+    std::vector<Sample> samples;
+    {
+        std::string err;
+        if (!load_samples(opt.sample_metadata, &samples, &err)) die(err);
+    }
+    info("%zu samples loaded from file \"%s\"", samples.size(), opt.sample_metadata.c_str());
+    if (opt.max_mismatches > 255 || opt.min_mismatch_delta > 255) die("out of range integral type conversion attempted");   // u8::try_from, demux.rs:923-924
+    if (opt.compression_level > 255) die("out of range integral type conversion attempted");
+    const int zlevel = (int)std::min<unsigned long>(opt.compression_level, 9);
+
+    // ---- output plan (demux.rs:660-743): per sample, per requested type, one file per segment -----
+    const size_t n_inputs = plan.rs.size();
+    for (uint32_t i = 0; i < n_inputs; ++i)
+        for (uint32_t s = 0; s < plan.rs[i].segments.size(); ++s)
+            for (int k = 0; k < 4; ++k)
+                if (plan.rs[i].segments[s].kind == kTypes[k]) plan.by_type[k].push_back({i, s});
+    for (int k = 0; k < 4; ++k) {
+        plan.file_base[k] = plan.files_per_sample;
+        if (plan.want[k]) plan.files_per_sample += plan.by_type[k].size();
+    }
+    const size_t S = samples.size();
+    const size_t n_outs = (S + 1) * plan.files_per_sample;
+    {
+        rlimit rl;
+        if (getrlimit(RLIMIT_NOFILE, &rl) == 0 && rl.rlim_cur < n_outs + 64) {
+            rl.rlim_cur = std::min<rlim_t>(rl.rlim_max, n_outs + 64);
+            setrlimit(RLIMIT_NOFILE, &rl);
+        }
+    }
+    std::vector<OutFile> outs(n_outs);
+    for (size_t s = 0; s <= S; ++s) {
+        const std::string &prefix = s < S ? samples[s].sample_id : opt.unmatched_prefix;
+        for (int k = 0; k < 4; ++k) {
+            if (!plan.want[k]) continue;
+            for (size_t j = 0; j < plan.by_type[k].size(); ++j) {
+                OutFile &of = outs[s * plan.files_per_sample + plan.file_base[k] + j];
+                of.path = opt.output + "/" + prefix + "." + kCodes[k] + std::to_string(j + 1) + ".fq.gz";
+                of.f = std::fopen(of.path.c_str(), "wb");
+                if (!of.f) die("cannot create " + of.path + ": " + std::strerror(errno));
+            }
+        }
+    }
+    info("Created sample and %s writers.", opt.unmatched_prefix.c_str());
+
+    // ---- the matcher (demux.rs:921-926), use_cache = true as the reference passes -----------------
+    std::vector<const char *> bc;
+    for (const Sample &s : samples) bc.push_back(s.barcode.c_str());
+    fqtk_matcher *matcher = nullptr;
+    const uint32_t L = (uint32_t)samples[0].barcode.size();
+    if (fqtk_matcher_create(bc.data(), (uint32_t)S, L, (uint8_t)opt.max_mismatches, (uint8_t)opt.min_mismatch_delta,
+                            opt.device, &matcher) != FQTK_OK)
+        die(std::string("cannot create the GPU barcode matcher: ") + fqtk_last_error());
+
+    // sample-barcode layout of one template: fixed total length, or variable when a B segment is '+'
+    bool variable_barcode = false;
+    size_t fixed_barcode_len = 0;
+    for (const SegRef &r : plan.by_type[1]) {
+        const ReadSegment &seg = plan.rs[r.input].segments[r.seg];
+        if (seg.has_length()) fixed_barcode_len += (size_t)seg.length; else variable_barcode = true;
+    }
+
+    // ---- stage A: one reader thread per input ------------------------------------------------------
+    const size_t chunk_reads = std::max<unsigned long>(1, opt.chunk_reads);
+    std::vector<std::unique_ptr<BoundedQueue<ReadResult>>> rq;
+    std::vector<std::thread> readers;
+    for (size_t i = 0; i < n_inputs; ++i) rq.push_back(std::make_unique<BoundedQueue<ReadResult>>(3));
+    for (size_t i = 0; i < n_inputs; ++i)
+        readers.emplace_back([&, i] {
+            for (;;) {
+                ReadResult r;
+                r.batch = std::make_unique<RecBatch>();
+                if (!sources[i]->next_batch(chunk_reads, r.batch.get(), &r.error)) {
+                    rq[i]->push(std::move(r));
+                    return;
+                }
+                const bool last = r.batch->recs.empty();
+                rq[i]->push(std::move(r));
+                if (last) return;
+            }
+        });
+
+    // ---- stage C: router/compressor threads, partitioned by sample ----------------------------------
+    const size_t n_workers = std::max<size_t>(1, opt.threads - 1);
+    std::vector<std::unique_ptr<BoundedQueue<std::shared_ptr<Chunk>>>> wq;
+    for (size_t w = 0; w < n_workers; ++w) wq.push_back(std::make_unique<BoundedQueue<std::shared_ptr<Chunk>>>(4));
+    std::vector<std::thread> workers;
+    for (size_t w = 0; w < n_workers; ++w)
+        workers.emplace_back([&, w] {
+            std::string hdr[64];
+            std::vector<std::string_view> bsegs, msegs;
+            for (;;) {
+                std::shared_ptr<Chunk> ch = wq[w]->pop();
+                if (!ch) break;
+                for (size_t i = 0; i < ch->n; ++i) {
+                    if (ch->skip[i]) continue;
+                    const size_t s = ch->res[i].idx == FQTK_NO_MATCH ? S : ch->res[i].idx;
+                    if (s % n_workers != w) continue;
+                    auto span = [&](const SegRef &r, std::string_view *bases, std::string_view *quals) {
+                        const RecBatch &b = *ch->batches[r.input];
+                        size_t lo, hi;
+                        segment_span(plan.rs[r.input].segments[r.seg], b.recs[i].seq_len, &lo, &hi);
+                        *bases = std::string_view(b.seq(i) + lo, hi - lo);
+                        *quals = std::string_view(b.qual(i) + lo, hi - lo);
+                    };
+                    bsegs.clear();
+                    msegs.clear();
+                    std::string_view sv, qv;
+                    for (const SegRef &r : plan.by_type[1]) { span(r, &sv, &qv); bsegs.push_back(sv); }
+                    for (const SegRef &r : plan.by_type[2]) { span(r, &sv, &qv); msegs.push_back(sv); }
+                    const RecBatch &b0 = *ch->batches[0];   // header of the FIRST input (combine_readsets, demux.rs:126-139)
+                    const std::string_view header(b0.head(i), b0.recs[i].head_len);
+                    size_t max_num = 0;
+                    for (int k = 0; k < 4; ++k) if (plan.want[k]) max_num = std::max(max_num, plan.by_type[k].size());
+                    if (max_num > 64) die("more than 64 segments of one type are not supported");
+                    for (size_t j = 0; j < max_num; ++j) {
+                        hdr[j].clear();
+                        std::string err;
+                        if (!write_header(hdr[j], j + 1, header, bsegs, msegs, &err)) die(err);
+                    }
+                    for (int k = 0; k < 4; ++k) {
+                        if (!plan.want[k]) continue;
+                        for (size_t j = 0; j < plan.by_type[k].size(); ++j) {
+                            OutFile &of = outs[s * plan.files_per_sample + plan.file_base[k] + j];
+                            span(plan.by_type[k][j], &sv, &qv);
+                            of.buf.append(hdr[j]);
+                            of.buf.push_back('\n');
+                            of.buf.append(sv);
+                            of.buf.append("\n+\n");
+                            of.buf.append(qv);
+                            of.buf.push_back('\n');
+                            if (of.buf.size() >= 4 * kBgzfBlockSize) flush_blocks(of, zlevel, false);
+                        }
+                    }
+                }
+            }
+            for (size_t s = w; s <= S; s += n_workers)
+                for (size_t j = 0; j < plan.files_per_sample; ++j) flush_blocks(outs[s * plan.files_per_sample + j], zlevel, true);
+        });
+
+    // ---- stage B (this thread): chunk assembly, barcode SoA packing, GPU pipeline -------------------
+    constexpr int kSlots = 2;
+    struct SlotBuf { uint8_t *obs = nullptr; uint32_t *lens = nullptr; fqtk_match_t *out = nullptr; size_t obs_cap = 0, n_cap = 0; };
+    SlotBuf sb[kSlots];
+    auto ensure_slot = [&](SlotBuf &b, size_t n, size_t stride) {
+        if (n * stride > b.obs_cap) {
+            if (b.obs) fqtk_pinned_free(b.obs);
+            void *p = nullptr;
+            b.obs_cap = n * stride + (n * stride) / 4 + 64;
+            if (fqtk_pinned_alloc(b.obs_cap, &p) != FQTK_OK) die(fqtk_last_error());
+            b.obs = (uint8_t *)p;
+        }
+        if (n > b.n_cap) {
+            if (b.out) fqtk_pinned_free(b.out);
+            if (b.lens) fqtk_pinned_free(b.lens);
+            void *p = nullptr, *q = nullptr;
+            b.n_cap = n + n / 4 + 16;
+            if (fqtk_pinned_alloc(b.n_cap * sizeof(fqtk_match_t), &p) != FQTK_OK) die(fqtk_last_error());
+            if (fqtk_pinned_alloc(b.n_cap * sizeof(uint32_t), &q) != FQTK_OK) die(fqtk_last_error());
+            b.out = (fqtk_match_t *)p;
+            b.lens = (uint32_t *)q;
+        }
+    };
+    struct Pending { std::shared_ptr<Chunk> chunk; std::vector<uint32_t> rows; int slot = -1; };
+    auto finish = [&](Pending &p) {
+        if (!p.chunk) return;
+        if (p.slot >= 0) {
+            if (fqtk_matcher_wait(matcher, p.slot) != FQTK_OK)
+                die(std::string(fqtk_last_error()));   // over-long barcode: the reference panics too (barcode_matching.rs:95-107)
+            for (size_t j = 0; j < p.rows.size(); ++j) p.chunk->res[p.rows[j]] = sb[p.slot].out[j];
+        }
+        for (size_t w = 0; w < n_workers; ++w) wq[w]->push(p.chunk);
+        p.chunk.reset();
+    };
+    Pending pending[kSlots];
+    uint64_t total_templates = 0, skipped = 0, k = 0, next_log = 1000000;
+    for (;; ++k) {
+        auto ch = std::make_shared<Chunk>();
+        size_t n_nonempty = 0;
+        for (size_t i = 0; i < n_inputs; ++i) {
+            ReadResult r = rq[i]->pop();
+            if (!r.error.empty()) die(r.error);
+            if (!r.batch->recs.empty()) ++n_nonempty;
+            ch->batches.push_back(std::move(r.batch));
+        }
+        if (n_nonempty == 0) break;
+        ch->n = ch->batches[0]->recs.size();
+        for (size_t i = 0; i < n_inputs; ++i)
+            if (ch->batches[i]->recs.size() != ch->n)
+                die("FASTQ sources out of sync at records: input " + opt.inputs[i] + " ended after a different number of records");
+        ch->skip.assign(ch->n, 0);
+        ch->res.assign(ch->n, fqtk_match_t{FQTK_NO_MATCH, 255, 255});
+        // too-few-bases rule (demux.rs:298-313): skip the whole template, or fail with the reference's
+        // text for the FIRST offending template (templates in order, inputs in order within one)
+        {
+            size_t bad_j = ch->n, bad_i = 0;
+            for (size_t i = 0; i < n_inputs; ++i) {
+                const size_t min_len = plan.rs[i].min_length();
+                const RecBatch &b = *ch->batches[i];
+                for (size_t j = 0; j < ch->n; ++j)
+                    if (b.recs[j].seq_len < min_len) {
+                        ch->skip[j] = 1;
+                        if (j < bad_j) { bad_j = j; bad_i = i; }
+                        if (!skip_few) break;   // only the first one matters when it is fatal
+                    }
+            }
+            if (bad_j < ch->n && !skip_few) {
+                const RecBatch &b = *ch->batches[bad_i];
+                die("Read " + std::string(b.head(bad_j), b.recs[bad_j].head_len) + " had too few bases to demux " +
+                    std::to_string(b.recs[bad_j].seq_len) + " vs. " + std::to_string(plan.rs[bad_i].min_length()) +
+                    " needed in read structure " + plan.rs[bad_i].to_string() + ".");
+            }
+        }
+        const int slot = (int)(k % kSlots);
+        finish(pending[slot]);   // the chunk that used this slot two iterations ago
+        Pending &p = pending[slot];
+        p.chunk = ch;
+        p.rows.clear();
+        p.slot = -1;
+        // pack the sample barcodes: concatenation of all B segments in input order (demux.rs:121-123)
+        size_t stride = (fixed_barcode_len + 3) / 4 * 4;
+        if (variable_barcode) {
+            size_t mx = fixed_barcode_len;
+            for (size_t j = 0; j < ch->n; ++j) {
+                if (ch->skip[j]) continue;
+                size_t len = 0;
+                for (const SegRef &r : plan.by_type[1]) {
+                    size_t lo, hi;
+                    segment_span(plan.rs[r.input].segments[r.seg], ch->batches[r.input]->recs[j].seq_len, &lo, &hi);
+                    len += hi - lo;
+                }
+                mx = std::max(mx, len);
+            }
+            stride = (mx + 3) / 4 * 4;
+        }
+        if (stride == 0) stride = 4;
+        ensure_slot(sb[slot], ch->n, stride);
+        size_t row = 0;
+        for (size_t j = 0; j < ch->n; ++j) {
+            if (ch->skip[j]) { ++skipped; continue; }
+            uint8_t *dst = sb[slot].obs + row * stride;
+            size_t len = 0;
+            for (const SegRef &r : plan.by_type[1]) {
+                const RecBatch &b = *ch->batches[r.input];
+                size_t lo, hi;
+                segment_span(plan.rs[r.input].segments[r.seg], b.recs[j].seq_len, &lo, &hi);
+                std::memcpy(dst + len, b.seq(j) + lo, hi - lo);
+                len += hi - lo;
+            }
+            std::memset(dst + len, 0, stride - len);
+            sb[slot].lens[row] = (uint32_t)len;
+            p.rows.push_back((uint32_t)j);
+            ++row;
+        }
+        total_templates += row;
+        if (row > 0) {
+            const bool need_lens = variable_barcode || fixed_barcode_len != L;
+            if (fqtk_matcher_enqueue(matcher, slot, sb[slot].obs, (uint32_t)stride, need_lens ? sb[slot].lens : nullptr, row,
+                                     sb[slot].out) != FQTK_OK)
+                die(fqtk_last_error());
+            p.slot = slot;
+        }
+        while (total_templates >= next_log) { info("demultiplexed %llu records", (unsigned long long)next_log); next_log += 1000000; }
+    }
+    for (int d = 0; d < kSlots; ++d) finish(pending[(k + d) % kSlots]);
+    for (auto &t : readers) t.join();
+    info("Finished reading input FASTQs.");
+    for (size_t w = 0; w < n_workers; ++w) wq[w]->push(nullptr);
+    for (auto &t : workers) t.join();
+    info("Output FASTQ writing complete.");
+    if (skipped == 0) info("No records were skipped.");
+    else info("%llu records were skipped due to Too few bases", (unsigned long long)skipped);
+
+    // ---- metrics (demux.rs:994-998): counts come from the device-side per-sample histogram --------
+    std::vector<uint64_t> counts(S + 1, 0);
+    if (fqtk_matcher_counts(matcher, counts.data()) != FQTK_OK) die(fqtk_last_error());
+    uint64_t sum = 0;
+    for (uint64_t c : counts) sum += c;
+    if (sum != total_templates) die("internal error: device counts do not add up to the number of templates");
+    std::vector<DemuxMetric> rows(S);
+    for (size_t s = 0; s < S; ++s) {
+        rows[s].sample_id = samples[s].sample_id;
+        rows[s].barcode = samples[s].barcode;
+        rows[s].templates = counts[s];
+    }
+    DemuxMetric unmatched;
+    unmatched.sample_id = opt.unmatched_prefix;
+    unmatched.barcode = ".";
+    unmatched.templates = counts[S];
+    update_metrics(rows, unmatched);
+    rows.push_back(unmatched);
+    std::string err;
+    if (!write_metrics_tsv(opt.output + "/demux-metrics.txt", rows, &err)) die(err);
+    fqtk_matcher_destroy(matcher);
+    for (SlotBuf &b : sb) {
+        fqtk_pinned_free(b.obs);
+        fqtk_pinned_free(b.lens);
+        fqtk_pinned_free(b.out);
+    }
+    return 0;
+}

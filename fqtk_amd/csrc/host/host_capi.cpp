@@ -1,0 +1,125 @@
+// host_capi.cpp -- tiny C shim over the host-side components so the CPU test-suite can exercise them
+// through ctypes (no GPU needed): read structures, header rewriting, FASTQ parsing, BGZF, metrics.
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "bgzf.hpp"
+#include "fastq_io.hpp"
+#include "header.hpp"
+#include "metrics.hpp"
+#include "read_structure.hpp"
+#include "samples.hpp"
+
+using namespace fqtk_host;
+
+static int put(const std::string &s, char *out, size_t cap) {
+    if (s.size() + 1 > cap) return -2;
+    std::memcpy(out, s.c_str(), s.size() + 1);
+    return 0;
+}
+
+extern "C" {
+
+// Parses `text`; writes the canonical string, min length and per-segment (offset, length|-1, kind).
+int fqtk_host_read_structure(const char *text, char *canon, size_t cap, uint64_t *min_len, int64_t *segs,
+                             size_t max_segs, size_t *n_segs, char *err, size_t errcap) {
+    ReadStructure rs;
+    std::string e;
+    if (!ReadStructure::parse(text, &rs, &e)) { put(e, err, errcap); return 1; }
+    *min_len = rs.min_length();
+    *n_segs = rs.segments.size();
+    for (size_t i = 0; i < rs.segments.size() && i < max_segs; ++i) {
+        segs[3 * i] = (int64_t)rs.segments[i].offset;
+        segs[3 * i + 1] = rs.segments[i].length;
+        segs[3 * i + 2] = (int64_t)(char)rs.segments[i].kind;
+    }
+    return put(rs.to_string(), canon, cap);
+}
+
+// [begin,end) of every segment for a read of read_len bases.
+int fqtk_host_segment_spans(const char *text, uint64_t read_len, uint64_t *spans, size_t max_segs) {
+    ReadStructure rs;
+    std::string e;
+    if (!ReadStructure::parse(text, &rs, &e)) return 1;
+    for (size_t i = 0; i < rs.segments.size() && i < max_segs; ++i) {
+        size_t lo, hi;
+        segment_span(rs.segments[i], (size_t)read_len, &lo, &hi);
+        spans[2 * i] = lo;
+        spans[2 * i + 1] = hi;
+    }
+    return 0;
+}
+
+int fqtk_host_write_header(uint64_t read_num, const char *header, const char *const *bsegs, size_t nb,
+                           const char *const *msegs, size_t nm, char *out, size_t cap, char *err, size_t errcap) {
+    std::vector<std::string_view> b, m;
+    for (size_t i = 0; i < nb; ++i) b.emplace_back(bsegs[i]);
+    for (size_t i = 0; i < nm; ++i) m.emplace_back(msegs[i]);
+    std::string o, e;
+    if (!write_header(o, (size_t)read_num, header, b, m, &e)) { put(e, err, errcap); return 1; }
+    return put(o, out, cap);
+}
+
+// Parses a FASTQ (plain or gz) and writes "head\tseq\tqual\n" per record.  Returns #records or -1.
+int64_t fqtk_host_parse_fastq(const char *path, uint64_t batch, char *out, size_t cap, char *err, size_t errcap) {
+    FastqSource src;
+    std::string e, text;
+    if (!src.open(path, &e)) { put(e, err, errcap); return -1; }
+    int64_t n = 0;
+    for (;;) {
+        RecBatch b;
+        if (!src.next_batch((size_t)batch, &b, &e)) { put(e, err, errcap); return -1; }
+        if (b.recs.empty()) break;
+        for (size_t i = 0; i < b.recs.size(); ++i) {
+            text.append(b.head(i), b.recs[i].head_len);
+            text.push_back('\t');
+            text.append(b.seq(i), b.recs[i].seq_len);
+            text.push_back('\t');
+            text.append(b.qual(i), b.recs[i].seq_len);
+            text.push_back('\n');
+            ++n;
+        }
+    }
+    if (put(text, out, cap) != 0) { put("output buffer too small", err, errcap); return -1; }
+    return n;
+}
+
+// BGZF-compresses a whole buffer (blocks of kBgzfBlockSize + EOF marker).
+int fqtk_host_bgzf(const uint8_t *in, size_t n, int level, uint8_t *out, size_t cap, size_t *out_len) {
+    std::vector<uint8_t> o;
+    std::string e;
+    for (size_t off = 0; off < n; off += kBgzfBlockSize)
+        if (!bgzf_compress_block(in + off, std::min(kBgzfBlockSize, n - off), level, o, &e)) return 1;
+    o.insert(o.end(), kBgzfEof, kBgzfEof + sizeof kBgzfEof);
+    if (o.size() > cap) return 2;
+    std::memcpy(out, o.data(), o.size());
+    *out_len = o.size();
+    return 0;
+}
+
+int fqtk_host_format_f64(double v, char *out, size_t cap) { return put(format_f64(v), out, cap); }
+
+// counts: S sample counts followed by the unmatched count.  Writes the three derived columns.
+void fqtk_host_metrics(const uint64_t *counts, size_t S, double *frac, double *to_mean, double *to_best) {
+    std::vector<DemuxMetric> rows(S);
+    for (size_t i = 0; i < S; ++i) rows[i].templates = counts[i];
+    DemuxMetric un;
+    un.templates = counts[S];
+    update_metrics(rows, un);
+    rows.push_back(un);
+    for (size_t i = 0; i <= S; ++i) {
+        frac[i] = rows[i].frac_templates;
+        to_mean[i] = rows[i].ratio_to_mean;
+        to_best[i] = rows[i].ratio_to_best;
+    }
+}
+
+int64_t fqtk_host_load_samples(const char *path, char *err, size_t errcap) {
+    std::vector<Sample> s;
+    std::string e;
+    if (!load_samples(path, &s, &e)) { put(e, err, errcap); return -1; }
+    return (int64_t)s.size();
+}
+
+}  // extern "C"

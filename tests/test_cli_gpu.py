@@ -1,0 +1,207 @@
+"""`fqtk demux` end to end on the GPU box: ports of the reference's Demux.execute() integration tests
+(/root/reference/src/bin/commands/demux.rs:1103-2073) driven through the C++ CLI, comparing the
+DECOMPRESSED per-sample FASTQs exactly as the reference's tests do (read_fastq/assert_equal,
+demux.rs:1069-1093), plus a synthetic multi-chunk run checked against the CPU oracle."""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+from tests import hostlib as H  # noqa: E402
+
+S1 = "AAAAAAAAGATTACAGA"
+FOUR = [S1, "CCCCCCCCGATTACAGA", "GGGGGGGGGATTACAGA", "GGGGGGTTGATTACAGA"]
+
+
+def _ok(r):
+    assert r.returncode == 0, r.stderr
+    return r
+
+
+def test_validate_inputs_can_succeed(tmp_path):   # demux.rs:1104-1135
+    inputs = [H.fastq_file(tmp_path, "read1", "ex", ["GATTACA"]), H.fastq_file(tmp_path, "read2", "ex", ["TAGGATTA"]),
+              H.fastq_file(tmp_path, "index1", "ex", ["GAT"]), H.fastq_file(tmp_path, "index2", "ex", ["TGGG"])]
+    meta = H.metadata_file(tmp_path, ["GATTGGG"])
+    _ok(H.run_demux(inputs, ["+T", "+T", "+B", "+B"], meta, tmp_path / "output"))
+    assert H.read_fastq(tmp_path / "output" / "Sample0000.R1.fq.gz") == [("ex_0 1:N:0:GAT+TGGG", "GATTACA", ";" * 7)]
+    assert H.read_fastq(tmp_path / "output" / "Sample0000.R2.fq.gz") == [("ex_0 2:N:0:GAT+TGGG", "TAGGATTA", ";" * 8)]
+
+
+def test_demux_fragment_reads(tmp_path):   # demux.rs:1293-1333
+    meta = H.metadata_file(tmp_path, FOUR)
+    fq = H.fastq_file(tmp_path, "ex", "ex", [S1 + "A" * 100])
+    out = tmp_path / "output"
+    _ok(H.run_demux([fq], ["17B100T"], meta, out))
+    assert H.read_fastq(out / "Sample0000.R1.fq.gz") == [("ex_0 1:N:0:" + S1, "A" * 100, ";" * 100)]
+    for s in ("Sample0001", "Sample0002", "Sample0003", "unmatched"):
+        assert H.read_fastq(out / f"{s}.R1.fq.gz") == []
+    lines = open(out / "demux-metrics.txt").read().splitlines()
+    assert lines[0] == "sample_id\tbarcode\ttemplates\tfrac_templates\tratio_to_mean\tratio_to_best"
+    assert lines[1].split("\t")[:4] == ["Sample0000", S1, "1", "1.0"]
+    assert lines[-1].split("\t")[:3] == ["unmatched", ".", "0"]
+
+
+def test_output_type_reads(tmp_path):   # demux.rs:1336-1418
+    meta = H.metadata_file(tmp_path, ["AAAAAAAA", "CCCCCCCC", "GGGGGGGG", "TTTTTTTT"])
+    fq = H.fastq_file(tmp_path, "ex", "ex", ["ATCGATCGAT" + "AAAAAAAA" + "GATTACA" + "A" * 100])
+    out = tmp_path / "output"
+    _ok(H.run_demux([fq], ["10M8B7C100T"], meta, out, output_types=["T", "B", "M", "C"]))
+    head = "ex_0:ATCGATCGAT 1:N:0:AAAAAAAA"
+    assert H.read_fastq(out / "Sample0000.R1.fq.gz") == [(head, "A" * 100, ";" * 100)]
+    assert H.read_fastq(out / "Sample0000.I1.fq.gz") == [(head, "AAAAAAAA", ";" * 8)]
+    assert H.read_fastq(out / "Sample0000.U1.fq.gz") == [(head, "ATCGATCGAT", ";" * 10)]
+    assert H.read_fastq(out / "Sample0000.C1.fq.gz") == [(head, "GATTACA", ";" * 7)]
+
+
+def test_demux_with_catchall_barcode(tmp_path):   # demux.rs:1421-1462
+    meta = H.metadata_file(tmp_path, ["NNNNNNN"])
+    fq = H.fastq_file(tmp_path, "ex", "ex", ["NNNNNNN" + "A" * 100])
+    out = tmp_path / "output"
+    _ok(H.run_demux([fq], ["7B+T"], meta, out, max_mismatches=0))
+    assert H.read_fastq(out / "unmatched.R1.fq.gz") == []
+    assert H.read_fastq(out / "Sample0000.R1.fq.gz") == [("ex_0 1:N:0:NNNNNNN", "A" * 100, ";" * 100)]
+
+
+def test_demux_with_iupac_bases_in_barcode(tmp_path):   # demux.rs:1465-1538
+    meta = H.metadata_file(tmp_path, ["MMMMMMM", "KKKKKKK"])
+    reads = ["AAAAAAA" + "A" * 5, "CCCCCCC" + "A" * 5, "ACACACA" + "A" * 5, "GTGTGTG" + "C" * 5, "TGTGTGT" + "C" * 5,
+             "CGCGCGC" + "T" * 5]
+    fq = H.fastq_file(tmp_path, "ex", "ex", reads)
+    out = tmp_path / "output"
+    _ok(H.run_demux([fq], ["7B+T"], meta, out, max_mismatches=0, min_mismatch_delta=0))
+    s0 = H.read_fastq(out / "Sample0000.R1.fq.gz")
+    assert [h for h, _, _ in s0] == ["ex_0 1:N:0:AAAAAAA", "ex_1 1:N:0:CCCCCCC", "ex_2 1:N:0:ACACACA"]
+    s1 = H.read_fastq(out / "Sample0001.R1.fq.gz")
+    assert s1 == [("ex_3 1:N:0:GTGTGTG", "C" * 5, ";" * 5), ("ex_4 1:N:0:TGTGTGT", "C" * 5, ";" * 5)]
+    assert H.read_fastq(out / "unmatched.R1.fq.gz") == [("ex_5 1:N:0:CGCGCGC", "T" * 5, ";" * 5)]
+
+
+def test_demux_with_ns_in_barcode(tmp_path):   # demux.rs:1541-1611
+    meta = H.metadata_file(tmp_path, ["NNAAAAA", "NNCCCCC"])
+    fq = H.fastq_file(tmp_path, "ex", "ex", ["ANAAAAA" + "A" * 5, "ANCCCCC" + "C" * 5, "NNNAAAA" + "T" * 5])
+    out = tmp_path / "output"
+    _ok(H.run_demux([fq], ["7B+T"], meta, out, max_mismatches=0, min_mismatch_delta=0))
+    assert H.read_fastq(out / "Sample0000.R1.fq.gz") == [("ex_0 1:N:0:ANAAAAA", "A" * 5, ";" * 5)]
+    assert H.read_fastq(out / "Sample0001.R1.fq.gz") == [("ex_1 1:N:0:ANCCCCC", "C" * 5, ";" * 5)]
+    assert H.read_fastq(out / "unmatched.R1.fq.gz") == [("ex_2 1:N:0:NNNAAAA", "T" * 5, ";" * 5)]
+
+
+def test_demux_paired_reads_with_in_line_sample_barcodes(tmp_path):   # demux.rs:1614-1672
+    meta = H.metadata_file(tmp_path, FOUR)
+    r1 = H.fastq_file(tmp_path, "ex_R1", "ex", [S1[:8] + "A" * 100])
+    r2 = H.fastq_file(tmp_path, "ex_R2", "ex", [S1[8:] + "T" * 100])
+    out = tmp_path / "output"
+    _ok(H.run_demux([r1, r2], ["8B100T", "9B100T"], meta, out))
+    assert H.read_fastq(out / "Sample0000.R1.fq.gz") == [("ex_0 1:N:0:AAAAAAAA+GATTACAGA", "A" * 100, ";" * 100)]
+    assert H.read_fastq(out / "Sample0000.R2.fq.gz") == [("ex_0 2:N:0:AAAAAAAA+GATTACAGA", "T" * 100, ";" * 100)]
+
+
+def test_demux_dual_indexed_paired_end_reads(tmp_path):   # demux.rs:1675-1736
+    meta = H.metadata_file(tmp_path, FOUR)
+    ins = [H.fastq_file(tmp_path, "ex_I1", "ex", [S1[:8]]), H.fastq_file(tmp_path, "ex_R1", "ex", ["A" * 100]),
+           H.fastq_file(tmp_path, "ex_R2", "ex", ["T" * 100]), H.fastq_file(tmp_path, "ex_I2", "ex", [S1[8:]])]
+    out = tmp_path / "output"
+    _ok(H.run_demux(ins, ["8B", "100T", "100T", "9B"], meta, out))
+    assert H.read_fastq(out / "Sample0000.R1.fq.gz") == [("ex_0 1:N:0:AAAAAAAA+GATTACAGA", "A" * 100, ";" * 100)]
+    assert H.read_fastq(out / "Sample0000.R2.fq.gz") == [("ex_0 2:N:0:AAAAAAAA+GATTACAGA", "T" * 100, ";" * 100)]
+
+
+def test_demux_a_weird_set_of_reads(tmp_path):   # demux.rs:1739-1800
+    meta = H.metadata_file(tmp_path, FOUR)
+    ins = [H.fastq_file(tmp_path, "example_1", "ex", ["AAAACCCCGGGGTTTT"]), H.fastq_file(tmp_path, "example_2", "ex", ["A" * 104]),
+           H.fastq_file(tmp_path, "example_3", "ex", ["T" * 100 + "GAT"]), H.fastq_file(tmp_path, "example_4", "ex", ["TACAGAAAT"])]
+    out = tmp_path / "output"
+    _ok(H.run_demux(ins, ["4B4M8S", "4B100T", "100S3B", "6B1S1M1T"], meta, out))
+    head = "ex_0:CCCC+A 1:N:0:AAAA+AAAA+GAT+TACAGA"
+    assert H.read_fastq(out / "Sample0000.R1.fq.gz") == [(head, "A" * 100, ";" * 100)]
+    assert H.read_fastq(out / "Sample0000.R2.fq.gz") == [(head.replace(" 1:", " 2:"), "T", ";")]
+
+
+def test_demux_multiple_templates_in_one_read(tmp_path):   # demux.rs:1803-1876
+    meta = H.metadata_file(tmp_path, FOUR)
+    fq = H.fastq_file(tmp_path, "ex", "ex", [S1 + "A" * 20 + "C" * 20 + "T" * 20 + "C" * 20 + "G" * 20])
+    out = tmp_path / "output"
+    _ok(H.run_demux([fq], ["17B20T20S20T20S20T"], meta, out))
+    for n, base in ((1, "A"), (2, "T"), (3, "G")):
+        assert H.read_fastq(out / f"Sample0000.R{n}.fq.gz") == [(f"ex_0 {n}:N:0:" + S1, base * 20, ";" * 20)]
+
+
+def _short_read_inputs(tmp_path):
+    bc = "GATTGGG"
+    r1 = H.fastq_file(tmp_path, "read1", "ex", ["AAAAAAA", "CCCCCCC", ""])
+    i1 = H.fastq_file(tmp_path, "index1", "ex", [bc, bc, bc])
+    return r1, i1, H.metadata_file(tmp_path, [bc])
+
+
+def test_fails_if_reads_too_short(tmp_path):   # demux.rs:1984-2020
+    r1, i1, meta = _short_read_inputs(tmp_path)
+    r = H.run_demux([r1, i1], ["+T", "7B"], meta, tmp_path / "output", output_types=["T", "B"])
+    assert r.returncode != 0
+    assert "Read ex_2 had too few bases to demux 0 vs. 1 needed in read structure +T." in r.stderr
+
+
+def test_skip_reads_too_short(tmp_path):   # demux.rs:2023-2073
+    r1, i1, meta = _short_read_inputs(tmp_path)
+    out = tmp_path / "output"
+    _ok(H.run_demux([r1, i1], ["+T", "7B"], meta, out, output_types=["T", "B"], skip_reasons=["too-few-bases"]))
+    rows = [l.split("\t") for l in open(out / "demux-metrics.txt").read().splitlines()[1:]]
+    assert sum(int(r[2]) for r in rows) == 2
+    assert [r for r in rows if r[0] == "Sample0000"][0][2] == "2"
+    assert len(H.read_fastq(out / "Sample0000.R1.fq.gz")) == 2
+    assert len(H.read_fastq(out / "Sample0000.I1.fq.gz")) == 2
+
+
+def test_sources_out_of_sync_is_fatal(tmp_path):
+    r1 = H.fastq_file(tmp_path, "read1", "ex", ["AAAAAAA", "CCCCCCC"])
+    i1 = H.fastq_file(tmp_path, "index1", "ex", ["GATTGGG"])
+    r = H.run_demux([r1, i1], ["+T", "7B"], H.metadata_file(tmp_path, ["GATTGGG"]), tmp_path / "output")
+    assert r.returncode != 0 and "FASTQ sources out of sync" in r.stderr
+
+
+def test_overlong_barcode_is_fatal_like_the_reference_panic(tmp_path):
+    fq = H.fastq_file(tmp_path, "ex", "ex", ["ACGTACGTAA" + "A" * 10])
+    r = H.run_demux([fq], ["10B+T"], H.metadata_file(tmp_path, ["ACGTACGT", "TTTTACGT"]), tmp_path / "output")
+    assert r.returncode != 0 and "differs from expected barcode length" in r.stderr
+
+
+def test_synthetic_multi_chunk_gz_inputs_match_the_oracle(tmp_path):
+    """cfg 4 shape (R1 16C8B126T + R2 150T, outputs T and C), several GPU chunks, gz inputs, all worker
+    threads: per-sample record lists must equal the ones the CPU oracle's assignments imply, in input
+    order, and demux-metrics.txt must carry the oracle's counts."""
+    from fqtk_amd import synth
+    from oracle import oracle as O
+    cfg = synth.CONFIGS[4]
+    w = synth.Workload(cfg)
+    n = 30_000
+    bcs = w.fill_host(0, n)[:, :8]
+    rng = np.random.default_rng(3)
+    acgt = np.frombuffer(b"ACGT", dtype=np.uint8)
+    cell = acgt[rng.integers(0, 4, size=(n, 16))]
+    t1 = acgt[rng.integers(0, 4, size=(n, 30))]
+    t2 = acgt[rng.integers(0, 4, size=(n, 40))]
+    r1 = [bytes(cell[i]).decode() + bytes(bcs[i]).decode() + bytes(t1[i]).decode() for i in range(n)]
+    r2 = [bytes(t2[i]).decode() for i in range(n)]
+    f1 = H.fastq_file(tmp_path, "r1", "q", r1, gz=True)
+    f2 = H.fastq_file(tmp_path, "r2", "q", r2, gz=True)
+    meta = os.path.join(str(tmp_path), "metadata.tsv")
+    with open(meta, "w") as fh:
+        fh.write("sample_id\tbarcode\n" + "".join(f"S{i}\t{b}\n" for i, b in enumerate(w.barcodes)))
+    out = tmp_path / "output"
+    _ok(H.run_demux([f1, f2], ["16C8B30T", "40T"], meta, out, output_types=["T", "C"], threads=8,
+                    extra=["--chunk-reads", "7000"]))
+    lit = O.RefLiteral(w.barcodes, 1, 2, True)
+    idx, _, _, counts = lit.assign_batch(np.ascontiguousarray(bcs))
+    names = [f"S{i}" for i in range(cfg.n_samples)] + ["unmatched"]
+    for s, name in enumerate(names):
+        sel = np.nonzero(idx == (0xFFFF if s == cfg.n_samples else s))[0]
+        exp_r1 = [(f"q_{i} 1:N:0:" + bytes(bcs[i]).decode(), bytes(t1[i]).decode(), ";" * 30) for i in sel]
+        exp_r2 = [(f"q_{i} 2:N:0:" + bytes(bcs[i]).decode(), bytes(t2[i]).decode(), ";" * 40) for i in sel]
+        exp_c1 = [(f"q_{i} 1:N:0:" + bytes(bcs[i]).decode(), bytes(cell[i]).decode(), ";" * 16) for i in sel]
+        assert H.read_fastq(out / f"{name}.R1.fq.gz") == exp_r1
+        assert H.read_fastq(out / f"{name}.R2.fq.gz") == exp_r2
+        assert H.read_fastq(out / f"{name}.C1.fq.gz") == exp_c1
+    rows = [l.split("\t") for l in open(out / "demux-metrics.txt").read().splitlines()[1:]]
+    assert [r[0] for r in rows] == names
+    assert [int(r[2]) for r in rows] == [int(c) for c in counts]

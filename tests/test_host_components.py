@@ -1,0 +1,217 @@
+"""CPU tests of the C++ host components either side of the hot path, through the
+ctypes shim: read structures, header rewriting (the reference's own vectors, demux.rs:2084-2196),
+FASTQ parsing, BGZF, metrics, and the CLI validation that happens before any GPU work."""
+import gzip
+import math
+import os
+import stat
+import struct
+import zlib
+
+import pytest
+
+from tests import hostlib as H
+
+
+# ---- read structures (read-structure 0.2.0; pinned by demux.rs call sites/tests) ---------------------
+@pytest.mark.parametrize("text", ["17B100T", "10M8B7C100T", "7B+T", "8B100T", "9B100T", "8B", "100T", "9B",
+                                  "4B4M8S", "4B100T", "100S3B", "6B1S1M1T", "17B20T20S20T20S20T", "+T", "+B",
+                                  "+M", "7B", "16C8B126T", "150T"])
+def test_read_structure_round_trips(text):
+    canon, _, segs = H.read_structure(text)
+    assert canon == text
+    off = 0
+    for o, l, _ in segs:
+        assert o == off
+        off += max(l, 0)
+
+
+def test_read_structure_min_length_and_kinds():
+    # demux.rs:298: sum of fixed lengths + 1 per variable segment
+    assert H.read_structure("8B92T")[1] == 100
+    assert H.read_structure("+T")[1] == 1
+    assert H.read_structure("7B+T")[1] == 8
+    assert H.read_structure("10M8B7C100T")[2] == [(0, 10, "M"), (10, 8, "B"), (18, 7, "C"), (25, 100, "T")]
+    assert H.read_structure("7B+T")[2] == [(0, 7, "B"), (7, -1, "T")]
+    assert H.read_structure(" 8b 92t ")[0] == "8B92T"          # whitespace / case tolerated (fgbio behaviour)
+
+
+@pytest.mark.parametrize("bad", ["", "8", "B", "8X", "0T", "+T8B", "8B+", "++T", "8BT", "-8B"])
+def test_read_structure_rejects_malformed(bad):
+    with pytest.raises(ValueError):
+        H.read_structure(bad)
+
+
+def test_segment_spans():
+    assert H.segment_spans("10M8B7C100T", 125) == [(0, 10), (10, 18), (18, 25), (25, 125)]
+    assert H.segment_spans("7B+T", 12) == [(0, 7), (7, 12)]
+    assert H.segment_spans("8B", 20) == [(0, 8)]               # bases past a fixed structure are ignored
+    assert H.segment_spans("4B4M8S", 16) == [(0, 4), (4, 8), (8, 16)]
+
+
+# ---- header rewriting: the reference's own vectors (demux.rs:2084-2196) -----------------------------
+def test_write_header_reference_vectors():
+    b, umi = ["ACGT", "GGTT"], ["AACCGGTT"]
+    assert H.write_header(1, "inst:123:ABCDE:1:204:1022:2108 1:N:0:0", b, []) == \
+        "@inst:123:ABCDE:1:204:1022:2108 1:N:0:ACGT+GGTT"
+    assert H.write_header(2, "inst:123:ABCDE:1:204:1022:2108 1:Y:0:0", b, umi) == \
+        "@inst:123:ABCDE:1:204:1022:2108:AACCGGTT 2:Y:0:ACGT+GGTT"
+    assert H.write_header(2, "inst:123:ABCDE:1:204:1022:2108:AAAA 1:Y:0:TTTT", b, umi) == \
+        "@inst:123:ABCDE:1:204:1022:2108:AAAA+AACCGGTT 2:Y:0:TTTT+ACGT+GGTT"
+    assert H.write_header(1, "q1", b, umi) == "@q1:AACCGGTT 1:N:0:ACGT+GGTT"
+    assert H.write_header(1, "q1 0:0", b, umi) == "@q1:AACCGGTT 0:0:ACGT+GGTT"
+    with pytest.raises(ValueError, match="8 segments"):
+        H.write_header(1, "q1:1:2:3:4:5:6:7:8:9:10", b, umi)
+
+
+def test_write_header_more_cases():
+    assert H.write_header(1, "ex_0", ["AAAAAAAAGATTACAGA"], []) == "@ex_0 1:N:0:AAAAAAAAGATTACAGA"   # demux.rs:1327
+    assert H.write_header(1, "ex_0", ["AAAAAAAA"], ["ATCGATCGAT"]) == "@ex_0:ATCGATCGAT 1:N:0:AAAAAAAA"  # :1383
+    assert H.write_header(3, "q 1:N:0:ACGT", ["TT"], ["AA", "CC"]) == "@q:AA+CC 3:N:0:ACGT+TT"
+    assert H.write_header(1, "q 1:N:0:", ["TT"], []) == "@q 1:N:0:TT"
+    assert H.write_header(1, "a:b:c:d:e:f:g:h:i", ["TT"], []) == "@a:b:c:d:e:f:g:h:i 1:N:0:TT"   # no UMI: name untouched
+    with pytest.raises(ValueError, match="4 segments"):
+        H.write_header(1, "q 1:N:0:A:B", ["TT"], [])
+
+
+# ---- FASTQ parsing ------------------------------------------------------------------------------------
+def test_parse_fastq_plain_gz_multimember_crlf_and_empty_reads(tmp_path):
+    recs = [("r0 1:N:0:1", "ACGT", "IIII"), ("r1", "", ""), ("r2", "NNNNNNNN", "########")]
+    text = "".join(f"@{h}\n{s}\n+\n{q}\n" for h, s, q in recs)
+    p = tmp_path / "a.fastq"
+    p.write_text(text)
+    assert H.parse_fastq(p) == recs
+    assert H.parse_fastq(p, batch=1) == recs
+    g = tmp_path / "a.fastq.gz"
+    with open(g, "wb") as fh:                       # two gzip members
+        fh.write(gzip.compress(text[: len(text) // 2].encode()))
+        fh.write(gzip.compress(text[len(text) // 2:].encode()))
+    assert H.parse_fastq(g) == recs
+    b = tmp_path / "b.fastq.gz"
+    b.write_bytes(H.bgzf(text.encode()))            # our own BGZF output is readable too
+    assert H.parse_fastq(b) == recs
+    c = tmp_path / "c.fastq"
+    c.write_bytes(text.replace("\n", "\r\n").encode())
+    assert H.parse_fastq(c) == recs
+    d = tmp_path / "d.fastq"
+    d.write_text(text.rstrip("\n"))                 # no trailing newline
+    assert H.parse_fastq(d) == recs
+    assert H.parse_fastq(tmp_path / "a.fastq", batch=2) == recs
+    e = tmp_path / "e.fastq"
+    e.write_text("")
+    assert H.parse_fastq(e) == []
+
+
+@pytest.mark.parametrize("text", ["r0\nACGT\n+\nIIII\n", "@r0\nACGT\n-\nIIII\n", "@r0\nACGT\n+\nIII\n", "@r0\nACGT\n+\n"])
+def test_parse_fastq_rejects_malformed(tmp_path, text):
+    p = tmp_path / "bad.fastq"
+    p.write_text(text)
+    with pytest.raises(ValueError, match="Unexpected error parsing FASTQs"):
+        H.parse_fastq(p)
+
+
+# ---- BGZF ---------------------------------------------------------------------------------------------
+def test_bgzf_is_valid_multi_member_gzip_with_bc_fields_and_eof_marker():
+    import numpy as np
+    rng = np.random.default_rng(0)
+    data = bytes(rng.choice(np.frombuffer(b"ACGT\n@+I", dtype=np.uint8), size=300_000))
+    blob = H.bgzf(data, level=5)
+    assert gzip.decompress(blob) == data
+    # walk the blocks: 'BC' extra field, BSIZE, ISIZE <= 64 KiB; last block is the 28-byte EOF marker
+    off, total, nblocks = 0, 0, 0
+    while off < len(blob):
+        assert blob[off:off + 4] == b"\x1f\x8b\x08\x04"
+        xlen = struct.unpack_from("<H", blob, off + 10)[0]
+        assert xlen == 6 and blob[off + 12:off + 14] == b"BC"
+        bsize = struct.unpack_from("<H", blob, off + 16)[0] + 1
+        isize = struct.unpack_from("<I", blob, off + bsize - 4)[0]
+        crc = struct.unpack_from("<I", blob, off + bsize - 8)[0]
+        payload = zlib.decompress(blob[off + 18:off + bsize - 8], -15)
+        assert len(payload) == isize <= 65536 and zlib.crc32(payload) == crc
+        total += isize
+        off += bsize
+        nblocks += 1
+    assert total == len(data) and nblocks == math.ceil(len(data) / 65280) + 1
+    assert blob[-28:] == bytes.fromhex("1f8b08040000000000ff0600424302001b0003000000000000000000")
+    assert H.bgzf(b"") == blob[-28:]
+
+
+# ---- metrics ------------------------------------------------------------------------------------------
+def test_metrics_follow_demux_metric_update():
+    frac, to_mean, to_best = H.metrics([30, 10, 0, 60])      # 3 samples + unmatched
+    assert frac == [0.3, 0.1, 0.0, 0.6]
+    mean = 40 / 3
+    assert to_mean == [30 / mean, 10 / mean, 0.0, 60 / mean]
+    assert to_best == [1.0, 10 / 30, 0.0, 2.0]
+    f, m, b = H.metrics([0, 0])                              # nothing demultiplexed: 0/0
+    assert all(math.isnan(x) for x in f + m + b)
+
+
+def test_format_f64_is_shortest_round_trip():
+    for v, s in [(1.0, "1.0"), (0.5, "0.5"), (0.1, "0.1"), (1 / 3, "0.3333333333333333"), (0.0, "0.0"),
+                 (2.0, "2.0"), (1e-7, "1e-7"), (123456.0, "123456.0"), (float("nan"), "NaN"), (float("inf"), "inf")]:
+        assert H.format_f64(v) == s
+    for v in (0.30000000000000004, 7.123456789012345e-5, 12345.678901234567):
+        assert float(H.format_f64(v)) == v
+
+
+def test_load_samples_matches_sample_group_rules(tmp_path):
+    p = tmp_path / "m.tsv"
+    p.write_text("sample_id\tbarcode\ns1\tGATTACA\ns2\tCATGCTA\n\n")
+    assert H.load_samples(p) == 2
+    for body, msg in [("sample\tbarcode\ns1\tGATTACA\n", "header mismatch"),
+                      ("sample_id\tbarcode\ns1\tGATTACA\ns1\tCATGCTA\n", "Each sample name must be unique"),
+                      ("sample_id\tbarcode\ns1\tGATTACA\ns2\tGATTACA\n", "Each sample barcode must be unique"),
+                      ("sample_id\tbarcode\ns1\tGATTACA\ns2\tGATTAC\n", "All barcodes must have the same length"),
+                      ("sample_id\tbarcode\ns1\tgattaca\n", "All sample barcode bases must be one of"),
+                      ("sample_id\tbarcode\n", "Must provide one or more sample")]:
+        p.write_text(body)
+        with pytest.raises(ValueError, match=msg):
+            H.load_samples(p)
+
+
+# ---- CLI validation that fails before any GPU work (demux.rs:1137-1290,1879-1981) ---------------------
+def _basic(tmp_path):
+    r1 = H.fastq_file(tmp_path, "read1", "ex", ["GATTACA"])
+    i1 = H.fastq_file(tmp_path, "index1", "ex", ["GATTGGG"])
+    meta = H.metadata_file(tmp_path, ["GATTGGG"])
+    return r1, i1, meta
+
+
+def test_cli_different_number_of_read_structures_and_inputs_fails(tmp_path):
+    r1, i1, meta = _basic(tmp_path)
+    for rs in (["+T"], ["+T", "+B", "+T"]):
+        r = H.run_demux([r1, i1], rs, meta, tmp_path / "out")
+        assert r.returncode != 0
+        assert "The same number of read structures should be given as FASTQs" in r.stderr
+        assert f"{len(rs)} read-structures provided for 2 FASTQs" in r.stderr
+
+
+def test_cli_read_only_output_dir_fails(tmp_path):
+    r1, i1, meta = _basic(tmp_path)
+    out = tmp_path / "ro"
+    out.mkdir()
+    os.chmod(out, stat.S_IRUSR | stat.S_IXUSR | stat.S_IRGRP | stat.S_IXGRP)
+    r = H.run_demux([r1, i1], ["+T", "+B"], meta, out)
+    os.chmod(out, 0o755)
+    assert r.returncode != 0 and "cannot be read-only" in r.stderr
+
+
+def test_cli_missing_input_and_too_few_threads_are_reported_together(tmp_path):
+    r1, i1, meta = _basic(tmp_path)
+    r = H.run_demux([r1, str(tmp_path / "nope.fastq")], ["+T", "+B"], meta, tmp_path / "out", threads=2)
+    assert r.returncode != 0
+    assert "doesn't exist" in r.stderr and "Threads provided 2 was too low! Must be 5 or more." in r.stderr
+    assert "The following errors with the input(s) were detected:" in r.stderr
+
+
+def test_cli_rejects_bad_flags_before_touching_anything(tmp_path):
+    r1, i1, meta = _basic(tmp_path)
+    r = H.run_demux([r1, i1], ["+T", "8Q"], meta, tmp_path / "out")
+    assert r.returncode != 0 and "unknown type" in r.stderr
+    r = H.run_demux([r1, i1], ["+T", "+B"], meta, tmp_path / "out", skip_reasons=["because"])
+    assert r.returncode != 0 and "Invalid skip reason: because" in r.stderr
+    r = H.run_demux([r1, i1], ["+T", "+B"], meta, tmp_path / "out", output_types=["Q"])
+    assert r.returncode != 0 and "Error parsing segment types to report" in r.stderr
+    r = H.run_demux([r1, i1], ["+T", "+B"], meta, tmp_path / "out", max_mismatches=300)
+    assert r.returncode != 0 and "out of range integral type conversion" in r.stderr
