@@ -44,7 +44,7 @@ def build_host(force: bool = False, verbose: bool = False) -> None:
     shim = os.path.join(LIBDIR, "libfqtk_host.so")
     src = os.path.join(HOST, "host_capi.cpp")
     if force or _stale(shim, [src] + deps):
-        cmd = [CXX, "-O2", "-std=c++17", "-shared", "-fPIC", "-Wall", "-o", shim, src, "-lz"]
+        cmd = [CXX, "-O2", "-std=c++17", "-shared", "-fPIC", "-Wall", "-o", shim, src, "-lz", "-ldl"]
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.run(cmd, check=True)
@@ -52,7 +52,7 @@ def build_host(force: bool = False, verbose: bool = False) -> None:
     src = os.path.join(HOST, "demux.cpp")
     if force or _stale(exe, [src] + deps + [os.path.join(LIBDIR, "libfqtk_match.so")]):
         cmd = [CXX, "-O2", "-std=c++17", "-Wall", "-pthread", "-o", exe, src, "-L", LIBDIR, "-lfqtk_match",
-               "-lz", "-Wl,-rpath,$ORIGIN/../lib", "-Wl,-rpath,/opt/rocm/lib"]
+               "-lz", "-ldl", "-Wl,-rpath,$ORIGIN/../lib", "-Wl,-rpath,/opt/rocm/lib"]
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.run(cmd, check=True)

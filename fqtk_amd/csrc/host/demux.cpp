@@ -18,12 +18,14 @@
 #include <unistd.h>
 
 #include <atomic>
+#include <chrono>
 #include <condition_variable>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <deque>
+#include <map>
 #include <memory>
 #include <mutex>
 #include <string>
@@ -43,10 +45,15 @@ using namespace fqtk_host;
 
 namespace {
 
+double now_s() {
+    static const auto t0 = std::chrono::steady_clock::now();
+    return std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+}
+
 void info(const char *fmt, ...) {
     va_list ap;
     va_start(ap, fmt);
-    std::fputs("[INFO fqtk] ", stderr);
+    std::fprintf(stderr, "[%8.3f INFO fqtk] ", now_s());
     std::vfprintf(stderr, fmt, ap);
     std::fputc('\n', stderr);
     va_end(ap);
@@ -209,7 +216,24 @@ struct SegRef { uint32_t input, seg; };
 struct OutFile {
     FILE *f = nullptr;
     std::string path;
-    std::string buf;
+    std::string buf;                 // router side: uncompressed tail, < one block
+    uint64_t next_submit = 0;        // router side: sequence number of the next block handed out
+    std::mutex mu;                   // writer side: blocks may finish out of order
+    uint64_t next_write = 0;
+    std::map<uint64_t, std::vector<uint8_t>> ready;
+};
+
+struct StageTimes {   // FQTK_TIMING=1: where the host threads spend their time (seconds, summed over threads)
+    std::atomic<uint64_t> router_wait{0}, router_format{0}, router_submit{0}, comp_wait{0}, comp_deflate{0}, comp_write{0};
+};
+StageTimes g_times;
+bool g_timing = false;
+inline uint64_t tick() { return g_timing ? (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count() : 0; }
+
+struct CompressJob {
+    OutFile *of = nullptr;           // nullptr = shut down
+    uint64_t seq = 0;
+    std::string data;
 };
 
 struct Plan {
@@ -223,28 +247,45 @@ struct Plan {
 const SegType kTypes[4] = {SegType::Template, SegType::SampleBarcode, SegType::MolecularBarcode, SegType::CellularBarcode};
 const char kCodes[4] = {'R', 'I', 'U', 'C'};
 
-void flush_blocks(OutFile &of, int level, bool final) {
-    std::vector<uint8_t> comp;
-    std::string err;
+// Router side: cut full 65280-byte blocks (or the final partial one) off the file's buffer and hand
+// them to the compression pool.  Sequence numbers keep the file's block order.
+void submit_blocks(OutFile &of, BoundedQueue<CompressJob> &jobs, bool final) {
     size_t off = 0;
     while (of.buf.size() - off >= kBgzfBlockSize || (final && off < of.buf.size())) {
         const size_t n = std::min(kBgzfBlockSize, of.buf.size() - off);
-        comp.clear();
-        if (!bgzf_compress_block(reinterpret_cast<const uint8_t *>(of.buf.data()) + off, n, level, comp, &err)) die(err);
-        if (std::fwrite(comp.data(), 1, comp.size(), of.f) != comp.size()) die("write failed: " + of.path);
+        CompressJob j;
+        j.of = &of;
+        j.seq = of.next_submit++;
+        j.data.assign(of.buf, off, n);
+        jobs.push(std::move(j));
         off += n;
     }
     of.buf.erase(0, off);
-    if (final) {
-        if (std::fwrite(kBgzfEof, 1, sizeof kBgzfEof, of.f) != sizeof kBgzfEof) die("write failed: " + of.path);
-        if (std::fclose(of.f) != 0) die("close failed: " + of.path);
-        of.f = nullptr;
+}
+
+// Pool side: compress one block, then write it -- and any successors already waiting -- in order.
+void compress_and_write(CompressJob &j, BlockCompressor &bc) {
+    std::vector<uint8_t> comp;
+    std::string err;
+    const uint64_t t0 = tick();
+    if (!bc.compress(reinterpret_cast<const uint8_t *>(j.data.data()), j.data.size(), comp, &err)) die(err);
+    const uint64_t t1 = tick();
+    g_times.comp_deflate += t1 - t0;
+    OutFile &of = *j.of;
+    std::lock_guard<std::mutex> lk(of.mu);
+    of.ready.emplace(j.seq, std::move(comp));
+    for (auto it = of.ready.begin(); it != of.ready.end() && it->first == of.next_write; it = of.ready.erase(it)) {
+        if (std::fwrite(it->second.data(), 1, it->second.size(), of.f) != it->second.size()) die("write failed: " + of.path);
+        ++of.next_write;
     }
+    g_times.comp_write += tick() - t1;
 }
 
 }  // namespace
 
 int main(int argc, char **argv) {
+    now_s();
+    g_timing = std::getenv("FQTK_TIMING") != nullptr;
     if (argc < 2 || std::string(argv[1]) == "--help" || std::string(argv[1]) == "-h") {
         std::fputs("fqtk (MI355X-native demux)\n\nUsage: fqtk <COMMAND>\n\nCommands:\n  demux  Performs sample demultiplexing on FASTQs\n", stdout);
         return argc < 2 ? 2 : 0;
@@ -319,7 +360,7 @@ int main(int argc, char **argv) {
     info("%zu samples loaded from file \"%s\"", samples.size(), opt.sample_metadata.c_str());
     if (opt.max_mismatches > 255 || opt.min_mismatch_delta > 255) die("out of range integral type conversion attempted");   // u8::try_from, demux.rs:923-924
     if (opt.compression_level > 255) die("out of range integral type conversion attempted");
-    const int zlevel = (int)std::min<unsigned long>(opt.compression_level, 9);
+    if (opt.compression_level > 12) die("compression level must be at most 12");
 
     // ---- output plan (demux.rs:660-743): per sample, per requested type, one file per segment -----
     const size_t n_inputs = plan.rs.size();
@@ -363,6 +404,8 @@ int main(int argc, char **argv) {
     if (fqtk_matcher_create(bc.data(), (uint32_t)S, L, (uint8_t)opt.max_mismatches, (uint8_t)opt.min_mismatch_delta,
                             opt.device, &matcher) != FQTK_OK)
         die(std::string("cannot create the GPU barcode matcher: ") + fqtk_last_error());
+    info("GPU barcode matcher ready on device %d (%llu memo entries).", opt.device,
+         (unsigned long long)fqtk_matcher_memo_entries(matcher));
 
     // sample-barcode layout of one template: fixed total length, or variable when a B segment is '+'
     bool variable_barcode = false;
@@ -392,22 +435,51 @@ int main(int argc, char **argv) {
             }
         });
 
-    // ---- stage C: router/compressor threads, partitioned by sample ----------------------------------
-    const size_t n_workers = std::max<size_t>(1, opt.threads - 1);
+    // ---- stage C: routers (partitioned by sample: one owner per file, input order kept) format the
+    //      records; a shared pool BGZF-compresses the 64 KiB blocks and writes them in order ---------
+    const size_t n_threads_c = std::max<size_t>(2, opt.threads - 1);
+    const size_t n_workers = std::max<size_t>(1, n_threads_c / 3);          // routers
+    const size_t n_comp = std::max<size_t>(1, n_threads_c - n_workers);     // compressors
+    BoundedQueue<CompressJob> jobs(n_comp * 8);
+    std::vector<std::thread> compressors;
+    for (size_t c = 0; c < n_comp; ++c)
+        compressors.emplace_back([&] {
+            BlockCompressor bc((int)opt.compression_level);
+            for (;;) {
+                const uint64_t t0 = tick();
+                CompressJob j = jobs.pop();
+                g_times.comp_wait += tick() - t0;
+                if (!j.of) break;
+                compress_and_write(j, bc);
+            }
+        });
     std::vector<std::unique_ptr<BoundedQueue<std::shared_ptr<Chunk>>>> wq;
     for (size_t w = 0; w < n_workers; ++w) wq.push_back(std::make_unique<BoundedQueue<std::shared_ptr<Chunk>>>(4));
     std::vector<std::thread> workers;
     for (size_t w = 0; w < n_workers; ++w)
         workers.emplace_back([&, w] {
-            std::string hdr[64];
+            // this router owns output file f (all samples) iff f % n_workers == w: one owner per file
+            struct Owned { int k; uint32_t j; };
+            std::vector<std::vector<Owned>> owned(S + 1);
+            for (size_t s = 0; s <= S; ++s)
+                for (int k = 0; k < 4; ++k) {
+                    if (!plan.want[k]) continue;
+                    for (uint32_t j = 0; j < plan.by_type[k].size(); ++j)
+                        if ((s * plan.files_per_sample + plan.file_base[k] + j) % n_workers == w) owned[s].push_back({k, j});
+                }
             std::vector<std::string_view> bsegs, msegs;
             for (;;) {
+                const uint64_t tw = tick();
                 std::shared_ptr<Chunk> ch = wq[w]->pop();
+                const uint64_t tf = tick();
+                g_times.router_wait += tf - tw;
                 if (!ch) break;
+                uint64_t t_sub = 0;
+                const RecBatch &b0 = *ch->batches[0];   // header of the FIRST input (combine_readsets, demux.rs:126-139)
                 for (size_t i = 0; i < ch->n; ++i) {
                     if (ch->skip[i]) continue;
                     const size_t s = ch->res[i].idx == FQTK_NO_MATCH ? S : ch->res[i].idx;
-                    if (s % n_workers != w) continue;
+                    if (owned[s].empty()) continue;
                     auto span = [&](const SegRef &r, std::string_view *bases, std::string_view *quals) {
                         const RecBatch &b = *ch->batches[r.input];
                         size_t lo, hi;
@@ -420,34 +492,28 @@ int main(int argc, char **argv) {
                     std::string_view sv, qv;
                     for (const SegRef &r : plan.by_type[1]) { span(r, &sv, &qv); bsegs.push_back(sv); }
                     for (const SegRef &r : plan.by_type[2]) { span(r, &sv, &qv); msegs.push_back(sv); }
-                    const RecBatch &b0 = *ch->batches[0];   // header of the FIRST input (combine_readsets, demux.rs:126-139)
                     const std::string_view header(b0.head(i), b0.recs[i].head_len);
-                    size_t max_num = 0;
-                    for (int k = 0; k < 4; ++k) if (plan.want[k]) max_num = std::max(max_num, plan.by_type[k].size());
-                    if (max_num > 64) die("more than 64 segments of one type are not supported");
-                    for (size_t j = 0; j < max_num; ++j) {
-                        hdr[j].clear();
+                    for (const Owned &o : owned[s]) {
+                        OutFile &of = outs[s * plan.files_per_sample + plan.file_base[o.k] + o.j];
                         std::string err;
-                        if (!write_header(hdr[j], j + 1, header, bsegs, msegs, &err)) die(err);
-                    }
-                    for (int k = 0; k < 4; ++k) {
-                        if (!plan.want[k]) continue;
-                        for (size_t j = 0; j < plan.by_type[k].size(); ++j) {
-                            OutFile &of = outs[s * plan.files_per_sample + plan.file_base[k] + j];
-                            span(plan.by_type[k][j], &sv, &qv);
-                            of.buf.append(hdr[j]);
-                            of.buf.push_back('\n');
-                            of.buf.append(sv);
-                            of.buf.append("\n+\n");
-                            of.buf.append(qv);
-                            of.buf.push_back('\n');
-                            if (of.buf.size() >= 4 * kBgzfBlockSize) flush_blocks(of, zlevel, false);
+                        if (!write_header(of.buf, o.j + 1, header, bsegs, msegs, &err)) die(err);
+                        span(plan.by_type[o.k][o.j], &sv, &qv);
+                        of.buf.push_back('\n');
+                        of.buf.append(sv);
+                        of.buf.append("\n+\n");
+                        of.buf.append(qv);
+                        of.buf.push_back('\n');
+                        if (of.buf.size() >= kBgzfBlockSize) {
+                            const uint64_t ts = tick();
+                            submit_blocks(of, jobs, false);
+                            t_sub += tick() - ts;
                         }
                     }
                 }
+                g_times.router_submit += t_sub;
+                g_times.router_format += tick() - tf - t_sub;
             }
-            for (size_t s = w; s <= S; s += n_workers)
-                for (size_t j = 0; j < plan.files_per_sample; ++j) flush_blocks(outs[s * plan.files_per_sample + j], zlevel, true);
+            for (size_t f = w; f < outs.size(); f += n_workers) submit_blocks(outs[f], jobs, true);
         });
 
     // ---- stage B (this thread): chunk assembly, barcode SoA packing, GPU pipeline -------------------
@@ -579,7 +645,19 @@ int main(int argc, char **argv) {
     info("Finished reading input FASTQs.");
     for (size_t w = 0; w < n_workers; ++w) wq[w]->push(nullptr);
     for (auto &t : workers) t.join();
+    for (size_t c = 0; c < n_comp; ++c) jobs.push(CompressJob{});
+    for (auto &t : compressors) t.join();
+    for (OutFile &of : outs) {   // every block is on disk: terminate the BGZF streams
+        if (!of.ready.empty() || of.next_write != of.next_submit) die("internal error: unwritten blocks in " + of.path);
+        if (std::fwrite(kBgzfEof, 1, sizeof kBgzfEof, of.f) != sizeof kBgzfEof) die("write failed: " + of.path);
+        if (std::fclose(of.f) != 0) die("close failed: " + of.path);
+        of.f = nullptr;
+    }
     info("Output FASTQ writing complete.");
+    if (g_timing)
+        info("thread-seconds: routers(%zu) wait %.2f format %.2f submit %.2f | compressors(%zu) wait %.2f deflate %.2f write %.2f",
+             n_workers, g_times.router_wait / 1e9, g_times.router_format / 1e9, g_times.router_submit / 1e9, n_comp,
+             g_times.comp_wait / 1e9, g_times.comp_deflate / 1e9, g_times.comp_write / 1e9);
     if (skipped == 0) info("No records were skipped.");
     else info("%llu records were skipped due to Too few bases", (unsigned long long)skipped);
 
