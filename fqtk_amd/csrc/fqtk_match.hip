@@ -221,7 +221,8 @@ int launch(const fqtk_matcher *m, const fqtk::MatchParams &P, hipStream_t stream
             if (std::atoi(rr) == 1) return m->memo_key64 ? launch_memo_vec<true, 1>(m, Q, stream) : launch_memo_vec<false, 1>(m, Q, stream);
         }
 #endif
-        return m->memo_key64 ? launch_memo_vec<true>(m, Q, stream) : launch_memo_vec<false>(m, Q, stream);
+        // reads per lane: 2 for 64-bit keys, 4 for 32-bit keys (both stay within 64 VGPRs = 8 waves/SIMD)
+        return m->memo_key64 ? launch_memo_vec<true, 2>(m, Q, stream) : launch_memo_vec<false, 4>(m, Q, stream);
     }
     switch (m->NW) {
         case 1: return launch_vec<1, 4>(P, m->num_cus, stream);

@@ -212,6 +212,15 @@ def test_baseline_configs_reduced_size_vs_oracle(k):
         _compare(w.barcodes, 0, 0, obs[:20000])
 
 
+def test_cfg1_full_size_vs_oracle():
+    """BASELINE config 1 at its FULL size (1 M reads x 16 samples): every result and every count."""
+    cfg = synth.CONFIGS[1]
+    w = synth.Workload(cfg)
+    obs = w.fill_host(0, cfg.n_reads)
+    _, counts = _compare(w.barcodes, cfg.max_mismatches, cfg.min_mismatch_delta, obs)
+    assert int(counts.sum()) == cfg.n_reads
+
+
 def test_device_generator_matches_host_twin_and_zero_copy_entry_point():
     import torch
     cfg = synth.CONFIGS[3]
