@@ -92,6 +92,7 @@ struct fqtk_matcher {
     bool memo_key64 = false;
     uint64_t memo_entries = 0;
     uint64_t memo_candidates = 0;
+    uint64_t memo_second_slot = 0;             // entries living in their second-choice slot
     int use_cache = 1;                       // BarcodeMatcher.use_cache (barcode_matching.rs:41-42)
     Slot slots[FQTK_MAX_SLOTS];
 };
@@ -151,16 +152,9 @@ int launch_vec(const fqtk::MatchParams &P, int num_cus, hipStream_t stream) {
     return launch_t<NW, R, 0>(P, num_cus, stream);
 }
 
-template <bool KEY64, int R = 2>
+template <bool KEY64>
 int launch_memo_vec(const fqtk_matcher *m, const fqtk::MemoParams &Q, hipStream_t stream) {
     const fqtk::MatchParams &P = Q.m;
-    const uint64_t tile = (uint64_t)fqtk::kBlock * R;
-    const uint64_t ntiles = (P.n + tile - 1) / tile;
-    if (ntiles == 0) return FQTK_OK;
-    const uint32_t grid = (uint32_t)std::min<uint64_t>(ntiles, (uint64_t)m->num_cus * 8);
-    size_t shmem = (256 + 64) * sizeof(uint32_t);
-    if (Q.hot_mask) shmem += (size_t)(Q.hot_mask + 1) * (KEY64 ? 16 : 8);
-    if (P.counts && P.lds_hist) shmem += (size_t)(P.S + 1) * sizeof(uint32_t);
     const uintptr_t base = reinterpret_cast<uintptr_t>(P.obs);
     const uint32_t nwords = (P.L + 3) / 4;
     int vec = 0;
@@ -174,32 +168,50 @@ int launch_memo_vec(const fqtk_matcher *m, const fqtk::MemoParams &Q, hipStream_
             else if (sw == 3) vec = 3;
         }
     }
-#define FQTK_MEMO_LAUNCH(V) \
-    hipLaunchKernelGGL((fqtk::memo_kernel<V, KEY64, R>), dim3(grid), dim3(fqtk::kBlock), shmem, stream, Q)
+    // reads per lane: 2 on the vector-load paths (every such variant stays inside 64 VGPRs = 8
+    // waves/SIMD with no scratch, hipcc -Rpass-analysis=kernel-resource-usage); 1 on the generic
+    // paths (2 would spill) and for very large tables, where the extra probes in flight only add
+    // cache pressure (measured on cfg 5: 95 vs 87 G reads/s)
+    int R = (vec > 0 && m->memo_entries <= 65536) ? 2 : 1;
+    int abl = 0;
 #ifdef FQTK_DEV_ABLATE
-    if (const char *ab = std::getenv("FQTK_MEMO_ABLATE")) {
-        const int a = std::atoi(ab);
-#define FQTK_AB(A) case A: hipLaunchKernelGGL((fqtk::memo_kernel<4, KEY64, R, A>), dim3(grid), dim3(fqtk::kBlock), shmem, stream, Q); break;
-        if (vec == 4 && a > 0) {
-            switch (a) {
-                FQTK_AB(1) FQTK_AB(3) FQTK_AB(4)
-                FQTK_AB(7) FQTK_AB(16) FQTK_AB(32) FQTK_AB(33) FQTK_AB(39)
-                default: break;
-            }
-            HIP_TRY(hipGetLastError());
-            return FQTK_OK;
-        }
-#undef FQTK_AB
-    }
+    if (const char *rr = std::getenv("FQTK_MEMO_R")) R = std::atoi(rr);
+    if (const char *ab = std::getenv("FQTK_MEMO_ABLATE")) abl = std::atoi(ab);
 #endif
-    switch (vec) {
-        case 4: FQTK_MEMO_LAUNCH(4); break;
-        case 3: FQTK_MEMO_LAUNCH(3); break;
-        case 2: FQTK_MEMO_LAUNCH(2); break;
-        case 1: FQTK_MEMO_LAUNCH(1); break;
-        case -1: FQTK_MEMO_LAUNCH(-1); break;
-        default: FQTK_MEMO_LAUNCH(0); break;
+    const uint64_t tile = (uint64_t)fqtk::kBlock * R;
+    const uint64_t ntiles = (P.n + tile - 1) / tile;
+    if (ntiles == 0) return FQTK_OK;
+    const uint32_t grid = (uint32_t)std::min<uint64_t>(ntiles, (uint64_t)m->num_cus * 8);
+    size_t shmem = 256 * sizeof(uint32_t);   // + 256 B static (code LUT)
+    if (Q.hot_mask) shmem += (size_t)(Q.hot_mask + 1) * (KEY64 ? 16 : 8);
+    if (P.counts && P.lds_hist) shmem += (size_t)(P.S + 1) * sizeof(uint32_t);
+#define FQTK_MEMO_LAUNCH(V, RR, A) \
+    hipLaunchKernelGGL((fqtk::memo_kernel<V, KEY64, RR, A>), dim3(grid), dim3(fqtk::kBlock), shmem, stream, Q)
+#define FQTK_MEMO_BY_VEC(RR, A)                         \
+    switch (vec) {                                      \
+        case 4: FQTK_MEMO_LAUNCH(4, RR, A); break;      \
+        case 3: FQTK_MEMO_LAUNCH(3, RR, A); break;      \
+        case 2: FQTK_MEMO_LAUNCH(2, RR, A); break;      \
+        case 1: FQTK_MEMO_LAUNCH(1, RR, A); break;      \
+        case -1: FQTK_MEMO_LAUNCH(-1, RR, A); break;    \
+        default: FQTK_MEMO_LAUNCH(0, RR, A); break;     \
     }
+#ifdef FQTK_DEV_ABLATE
+    if (abl > 0 && vec == 4) {
+        switch (abl * 10 + R) {
+#define FQTK_AB(A, RR) case A * 10 + RR: FQTK_MEMO_LAUNCH(4, RR, A); break;
+            FQTK_AB(1, 1) FQTK_AB(3, 1) FQTK_AB(4, 1) FQTK_AB(7, 1) FQTK_AB(16, 1)
+            FQTK_AB(1, 2) FQTK_AB(3, 2) FQTK_AB(4, 2) FQTK_AB(7, 2) FQTK_AB(16, 2)
+#undef FQTK_AB
+            default: return fail(FQTK_EINVAL, "ablation variant not built");
+        }
+        HIP_TRY(hipGetLastError());
+        return FQTK_OK;
+    }
+    if (R == 4) { FQTK_MEMO_BY_VEC(4, 0) HIP_TRY(hipGetLastError()); return FQTK_OK; }
+#endif
+    if (R == 2) { FQTK_MEMO_BY_VEC(2, 0) } else { FQTK_MEMO_BY_VEC(1, 0) }
+#undef FQTK_MEMO_BY_VEC
 #undef FQTK_MEMO_LAUNCH
     HIP_TRY(hipGetLastError());
     return FQTK_OK;
@@ -215,14 +227,7 @@ int launch(const fqtk_matcher *m, const fqtk::MatchParams &P, hipStream_t stream
         Q.mask = m->memo_mask;
         Q.hot = m->d_hot;
         Q.hot_mask = m->hot_mask;
-#ifdef FQTK_DEV_ABLATE
-        if (const char *rr = std::getenv("FQTK_MEMO_R")) {
-            if (std::atoi(rr) == 4) return m->memo_key64 ? launch_memo_vec<true, 4>(m, Q, stream) : launch_memo_vec<false, 4>(m, Q, stream);
-            if (std::atoi(rr) == 1) return m->memo_key64 ? launch_memo_vec<true, 1>(m, Q, stream) : launch_memo_vec<false, 1>(m, Q, stream);
-        }
-#endif
-        // reads per lane: 2 for 64-bit keys, 4 for 32-bit keys (both stay within 64 VGPRs = 8 waves/SIMD)
-        return m->memo_key64 ? launch_memo_vec<true, 2>(m, Q, stream) : launch_memo_vec<false, 4>(m, Q, stream);
+        return m->memo_key64 ? launch_memo_vec<true>(m, Q, stream) : launch_memo_vec<false>(m, Q, stream);
     }
     switch (m->NW) {
         case 1: return launch_vec<1, 4>(P, m->num_cus, stream);
@@ -392,12 +397,32 @@ int build_memo(fqtk_matcher *m, const std::vector<std::vector<uint8_t>> &enc) {
             }
         }
         if (!ok) { nslots <<= 1; continue; }
+        // pull keys back into their FIRST slot where it has become free, then mark the slots whose
+        // would-be first-slot owner still lives in its second slot (the kernel's SPILL bit)
+        for (bool moved = true; moved;) {
+            moved = false;
+            for (uint64_t p = 0; p < nslots; ++p) {
+                if (owner[p] < 0) continue;
+                uint32_t a1, a2;
+                fqtk::memo_hash2(ents[owner[p]].lo, m->memo_key64 ? ents[owner[p]].hi : 0u, mask, a1, a2);
+                if (a1 != p && owner[a1] < 0) { owner[a1] = owner[p]; owner[p] = -1; moved = true; }
+            }
+        }
+        std::vector<uint8_t> spill(nslots, 0);
+        uint64_t n_second = 0;
         for (uint64_t p = 0; p < nslots; ++p) {
             if (owner[p] < 0) continue;
-            const Entry &e = ents[owner[p]];
+            uint32_t a1, a2;
+            fqtk::memo_hash2(ents[owner[p]].lo, m->memo_key64 ? ents[owner[p]].hi : 0u, mask, a1, a2);
+            if (a1 != p) { spill[a1] = 1; ++n_second; }
+        }
+        m->memo_second_slot = n_second;
+        for (uint64_t p = 0; p < nslots; ++p) {
             uint32_t *w = &slots[p * wps];
-            w[0] = e.lo;
-            if (m->memo_key64) { w[1] = e.hi; w[2] = e.val; w[3] = 0; } else { w[1] = e.val; }
+            if (m->memo_key64) w[3] = spill[p]; else w[0] = 0x7FFFFFFFu | ((uint32_t)spill[p] << 31);
+            if (owner[p] < 0) continue;
+            const Entry &e = ents[owner[p]];
+            if (m->memo_key64) { w[0] = e.lo; w[1] = e.hi; w[2] = e.val; } else { w[0] = e.lo | ((uint32_t)spill[p] << 31); w[1] = e.val; }
         }
         break;
     }

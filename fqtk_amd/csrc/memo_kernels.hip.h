@@ -32,7 +32,7 @@ constexpr uint32_t kHotBytes = 16384;      // LDS budget of the hot table per wo
 
 struct MemoParams {
     MatchParams m;
-    const void *slots;        // KEY64: uint4 {lo, hi, val, 0}; else uint2 {lo, val}
+    const void *slots;        // KEY64: uint4 {lo, hi, val, spill}; else uint2 {lo | spill << 31, val}
     const uint32_t *code_lut; // [64] dwords = 256 bytes: A0 C1 G2 T3 N4, anything else 8
     const uint32_t *hot;      // hot subset (exact matches) in the same slot format, copied to LDS
     uint32_t mask;            // n_slots - 1
@@ -41,18 +41,58 @@ struct MemoParams {
 
 // Two-choice (cuckoo) placement: a key lives in slot h1 or slot h2, nowhere else, so a lookup is two
 // INDEPENDENT loads issued back to back -- no probe loop, no divergence, one memory round trip.
+// 24-bit multiplies only: v_mul_u32_u24 / v_mad_u32_u24 issue at the full VALU rate on gfx950, while
+// v_mul_lo_u32 is quarter rate.  The 60-bit key is cut into three <=24-bit limbs.
+__host__ __device__ inline uint32_t mul24(uint32_t a, uint32_t b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __umul24(a, b);
+#else
+    return (a & 0xFFFFFFu) * (b & 0xFFFFFFu);
+#endif
+}
 __host__ __device__ inline void memo_hash2(uint32_t lo, uint32_t hi, uint32_t mask, uint32_t &s1,
                                            uint32_t &s2) {
-    uint32_t h = lo * 0x9E3779B1u;
-    h ^= hi * 0x85EBCA77u;
+    const uint32_t a = lo;                       // mul24 reads bits 0..23: bases 0-7
+    const uint32_t b = (lo >> 24) | (hi << 6);   // bases 8-9 and 10-15
+    const uint32_t c = hi >> 18;                 // bases 16-19
+    uint32_t h = mul24(a, 0x9E3779u) + mul24(b, 0x85EBCBu) + mul24(c, 0xC2B2AFu);
     h ^= h >> 15;
-    h *= 0x2C1B3C6Du;
+    h = mul24(h, 0x2C1B3Du) + (h >> 9);
     h ^= h >> 13;
     s1 = h & mask;
-    uint32_t g = (h >> 16) | (h << 16);
-    g *= 0xC2B2AE3Du;
+    uint32_t g = mul24(h >> 7, 0xD6E8FFu) + h;
     g ^= g >> 14;
     s2 = g & mask;
+}
+
+// acc | (v << SH) as one v_lshl_or_b32 (the optimiser otherwise builds a shift + v_or3 tree)
+template <int SH>
+__device__ __forceinline__ uint32_t lshl_or_imm(uint32_t v, uint32_t acc) {
+    uint32_t d;
+    asm("v_lshl_or_b32 %0, %1, %2, %3" : "=v"(d) : "v"(v), "n"(SH), "v"(acc));
+    return d;
+}
+
+// Compile-time unrolled ASCII -> 3-bit-code packing, two bases per step: byte extract (1 VALU each),
+// LDS byte LUT (address = byte value), one v_or3 for the non-canonical flag, one v_lshl_or per base.
+template <int K, int NB, int ABL>
+__device__ __forceinline__ void encode_codes(const uint32_t (&words)[8], const uint8_t *lds_code, uint32_t &l,
+                                             uint32_t &h, uint32_t &b) {
+    if constexpr (K < NB) {
+        uint32_t c[2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const uint32_t wv = words[(K + u) >> 2];
+            constexpr int by0 = K & 3;
+            const int by = by0 + u;
+            const uint32_t byte = by == 0 ? (wv & 0xFFu) : (by == 3 ? (wv >> 24) : __builtin_amdgcn_ubfe(wv, 8 * by, 8));
+            c[u] = (ABL & 2) ? (byte & 3u) : lds_code[byte];
+        }
+        b = b | c[0] | c[1];
+        if constexpr (K < 10) l = lshl_or_imm<3 * K>(c[0], l); else h = lshl_or_imm<3 * (K - 10)>(c[0], h);
+        if constexpr (K + 1 < 10) l = lshl_or_imm<3 * (K + 1)>(c[1], l); else h = lshl_or_imm<3 * (K + 1 - 10)>(c[1], h);
+        encode_codes<K + 2, NB, ABL>(words, lds_code, l, h, b);
+    }
 }
 
 // (best, second) packed keys -> result word (barcode_matching.rs:150-159).
@@ -99,23 +139,29 @@ __device__ __forceinline__ void wave_scan(const Planes<NW> &mine, int src, const
 // ABL: developer-only ablation mask (tools/ablate.sh builds with -DFQTK_DEV_ABLATE); 0 in the product.
 //   1 = skip table probes, 2 = skip LDS code lookups, 4 = skip histogram, 8 = skip result store,
 //   16 = skip the LDS hot table
-template <int VEC, bool KEY64, int R, int ABL = 0>
-__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(8, 8)))
+#ifndef FQTK_MEMO_WAVES
+#define FQTK_MEMO_WAVES 8
+#endif
+template <int VEC, bool KEY64, int R, int ABL>
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(FQTK_MEMO_WAVES, 8)))
 void memo_kernel(const MemoParams Q) {
     const MatchParams &P = Q.m;
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
-    uint32_t *lds_lut = smem;                                        // 256 x u32 spread LUT (fallback)
-    const uint8_t *lds_code = reinterpret_cast<const uint8_t *>(smem + 256);   // 256 x u8 code LUT
+    // the byte-code LUT is a STATIC LDS object (compile-time address 0): a base's byte value is its
+    // LDS address, so the 16 lookups per read need no address arithmetic at all
+    __shared__ uint32_t s_code[64];                                      // 256 x u8 code LUT
+    const uint8_t *lds_code = reinterpret_cast<const uint8_t *>(s_code);
+    uint32_t *lds_lut = smem;                                            // 256 x u32 spread LUT (fallback)
     // hot table: the memo entries with 0 mismatches (a read that IS a sample barcode -- the bulk of
     // real data) live in LDS, so most lanes never touch the global table; the rest probe it with
     // the hit lanes masked off, which shrinks the gather traffic by the hit rate.
     const uint32_t hot_words = Q.hot_mask ? (Q.hot_mask + 1) * (KEY64 ? 4u : 2u) : 0u;
-    uint32_t *lds_hot = smem + 256 + 64;
+    uint32_t *lds_hot = smem + 256;
     uint32_t *lds_hist = lds_hot + hot_words;
 
     const uint32_t tid = threadIdx.x;
     lds_lut[tid] = P.lut[tid];
-    if (tid < 64) smem[256 + tid] = Q.code_lut[tid];
+    if (tid < 64) s_code[tid] = Q.code_lut[tid];
     for (uint32_t w = tid; w < hot_words; w += kBlock) lds_hot[w] = Q.hot[w];
     const uint32_t bins = P.S + 1;
     if (P.counts && P.lds_hist)
@@ -124,6 +170,14 @@ void memo_kernel(const MemoParams Q) {
 
     const uint32_t L = P.L;
     const uint32_t nwords = (L + 3u) >> 2;
+    // bases encoded per read: exactly the packed stride on the vector paths, the 20-base maximum else
+    constexpr int NB = VEC >= 1 ? VEC * 4 : (int)kMemoMaxLen;
+    uint32_t keep[NB / 4];   // byte masks of the real bases (< L) in each word; wave-uniform
+#pragma unroll
+    for (int w = 0; w < NB / 4; ++w) {
+        const int rem = (int)L - 4 * w;
+        keep[w] = rem >= 4 ? 0xFFFFFFFFu : (rem <= 0 ? 0u : ((1u << (8 * rem)) - 1u));
+    }
     const uint64_t tile = (uint64_t)kBlock * R;
     const uint64_t ntiles = (P.n + tile - 1) / tile;
 
@@ -140,18 +194,15 @@ void memo_kernel(const MemoParams Q) {
             if (live[r]) load_words<1, VEC>(P, i, nwords, words[r]);
         }
         // ---- ASCII -> 3-bit codes, 10 bases per 32-bit half; bit 3 of any code = non-canonical ----
+        // Straight-line on purpose: NB is a compile-time constant and pad positions (>= L) are forced
+        // to 'A' (= code 0 = "absent" in the key), so all NB LUT reads are in flight together instead
+        // of one LDS round trip per base behind a wave-uniform `k < L` branch.
 #pragma unroll
         for (int r = 0; r < R; ++r) {
-            uint32_t l = 0, h = 0, b = 0;
 #pragma unroll
-            for (int k = 0; k < (int)kMemoMaxLen; ++k) {
-                if ((uint32_t)k < L) {   // wave-uniform
-                    const uint32_t byte = (words[r][k >> 2] >> (8 * (k & 3))) & 0xFFu;
-                    const uint32_t c = (ABL & 2) ? (byte & 3u) : lds_code[byte];
-                    b |= c;
-                    if (k < 10) l |= c << (3 * k); else h |= c << (3 * (k - 10));
-                }
-            }
+            for (int w = 0; w < NB / 4; ++w) words[r][w] = (words[r][w] & keep[w]) | (0x41414141u & ~keep[w]);
+            uint32_t l = 0, h = 0, b = 0;
+            encode_codes<0, NB, ABL>(words[r], lds_code, l, h, b);
             lo[r] = l; hi[r] = h; bad[r] = (b & 8u) && live[r];
         }
         // ---- probe: both candidate slots of every read are loaded up front (2*R independent
@@ -185,36 +236,39 @@ void memo_kernel(const MemoParams Q) {
         if constexpr (ABL & 1) {
 #pragma unroll
             for (int r = 0; r < R; ++r) res[r] = (s1[r] ^ s2[r]) | 0xFFFFu;
-        } else if constexpr (KEY64) {
-            uint4 e1[R], e2[R];
-#pragma unroll
-            for (int r = 0; r < R; ++r) {
-                if (!hit[r] && !bad[r]) {
-                    e1[r] = reinterpret_cast<const uint4 *>(Q.slots)[s1[r]];
-                    e2[r] = reinterpret_cast<const uint4 *>(Q.slots)[s2[r]];
-                }
-            }
-#pragma unroll
-            for (int r = 0; r < R; ++r) {
-                if (!hit[r] && !bad[r]) {
-                    const bool m1 = e1[r].x == lo[r] && e1[r].y == hi[r];
-                    const bool m2 = e2[r].x == lo[r] && e2[r].y == hi[r];
-                    res[r] = m1 ? e1[r].z : (m2 ? e2[r].z : kMemoEmpty);
-                }
-            }
         } else {
-            uint2 e1[R], e2[R];
+            // Global table, two-choice placement with a per-slot SPILL bit: the builder keeps a key in
+            // its first slot whenever it can and marks a slot whose would-be owner lives in its second
+            // slot.  So one gather settles ~90 % of the probing lanes (hit, or miss with spill = 0);
+            // only the rest issue the second, dependent gather -- with almost every lane masked off.
+            bool again[R];
 #pragma unroll
             for (int r = 0; r < R; ++r) {
+                again[r] = false;
                 if (!hit[r] && !bad[r]) {
-                    e1[r] = reinterpret_cast<const uint2 *>(Q.slots)[s1[r]];
-                    e2[r] = reinterpret_cast<const uint2 *>(Q.slots)[s2[r]];
+                    if constexpr (KEY64) {
+                        const uint4 e = reinterpret_cast<const uint4 *>(Q.slots)[s1[r]];
+                        if (e.x == lo[r] && e.y == hi[r]) res[r] = e.z;
+                        else again[r] = (e.w & 1u) != 0;
+                    } else {
+                        const uint2 e = reinterpret_cast<const uint2 *>(Q.slots)[s1[r]];
+                        if ((e.x & 0x7FFFFFFFu) == lo[r]) res[r] = e.y;
+                        else again[r] = (e.x >> 31) != 0;
+                    }
                 }
             }
 #pragma unroll
-            for (int r = 0; r < R; ++r)
-                if (!hit[r] && !bad[r])
-                    res[r] = e1[r].x == lo[r] ? e1[r].y : (e2[r].x == lo[r] ? e2[r].y : kMemoEmpty);
+            for (int r = 0; r < R; ++r) {
+                if (again[r]) {
+                    if constexpr (KEY64) {
+                        const uint4 e = reinterpret_cast<const uint4 *>(Q.slots)[s2[r]];
+                        if (e.x == lo[r] && e.y == hi[r]) res[r] = e.z;
+                    } else {
+                        const uint2 e = reinterpret_cast<const uint2 *>(Q.slots)[s2[r]];
+                        if ((e.x & 0x7FFFFFFFu) == lo[r]) res[r] = e.y;
+                    }
+                }
+            }
         }
         // ---- rare: non-canonical reads -> wave-cooperative exhaustive scan ---------------------
 #pragma unroll
