@@ -35,26 +35,19 @@ def cpu_baseline(workload, seconds: float):
     demux.rs:925 drives it) on ONE host core, over a bounded prefix of the same synthetic workload."""
     from oracle import oracle as O
     cfg = workload.cfg
-    lit = O.RefLiteral(workload.barcodes, cfg.max_mismatches, cfg.min_mismatch_delta, True, native=True)
-    probe_n = 200_000
     L = cfg.barcode_len
-    probe = np.ascontiguousarray(workload.fill_host(0, probe_n)[:, :L])
-    t0 = time.perf_counter()
-    lit.assign_batch(probe)
-    probe_rate = probe_n / (time.perf_counter() - t0)
-    n = int(min(max(probe_rate * seconds, 1_000_000), 30_000_000))
-    # fresh matcher so the timed run starts with a cold memo cache, like a real demux run
+    # one matcher for the whole sample, memo cache cold at the start, exactly like a real demux run;
+    # chunks are consumed until `seconds` of matcher time have been spent (input generation untimed)
     lit = O.RefLiteral(workload.barcodes, cfg.max_mismatches, cfg.min_mismatch_delta, True, native=True)
-    chunk = 2_000_000
+    chunk = 1_000_000
     total_t = 0.0
     done = 0
-    while done < n:
-        cur = min(chunk, n - done)
-        host = np.ascontiguousarray(workload.fill_host(done, cur)[:, :L])   # generation is NOT timed
+    while total_t < seconds and done < 200_000_000:
+        host = np.ascontiguousarray(workload.fill_host(done, chunk)[:, :L])
         t0 = time.perf_counter()
         lit.assign_batch(host)
         total_t += time.perf_counter() - t0
-        done += cur
+        done += chunk
     hits, misses = lit.cache_stats
     return {
         "value": round(done / total_t / 1e6, 4),
@@ -89,17 +82,20 @@ def main() -> int:
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", rank=rank, world_size=world)
-    if args.gpus != world and rank == 0 and world > 1:
-        print(f"warning: --gpus {args.gpus} != WORLD_SIZE {world}", file=sys.stderr)
     if not torch.cuda.is_available():
         print("bench.py needs a GPU: the matcher has no CPU fallback", file=sys.stderr)
         return 2
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    # FQTK_BENCH_FORCE_DIST=1 exercises the RCCL code path (init, barrier, all-reduce) even with one rank
+    use_dist = world > 1 or bool(os.environ.get("FQTK_BENCH_FORCE_DIST"))
+    if use_dist:    # one process per GPU; backend "nccl" is RCCL on ROCm
+        os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    if args.gpus != world and rank == 0 and world > 1:
+        print(f"warning: --gpus {args.gpus} != WORLD_SIZE {world}", file=sys.stderr)
 
     cfg = synth.CONFIGS[args.config]
     n = args.reads or cfg.n_reads
@@ -133,7 +129,7 @@ def main() -> int:
     # ---- timed region: EXACTLY K steps, barrier + synchronize on both sides ------------------------
     ev0 = torch.cuda.Event(enable_timing=True)
     ev1 = torch.cuda.Event(enable_timing=True)
-    if world > 1:
+    if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -142,16 +138,16 @@ def main() -> int:
         step()
     ev1.record()                                   # same stream as the kernels
     total_counts = d_counts
-    if world > 1:                                  # the one collective: per-sample counts over RCCL
+    if use_dist:                                   # the one collective: per-sample counts over RCCL
         total_counts = allreduce_counts(d_counts.clone())
     torch.cuda.synchronize()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     elapsed = time.perf_counter() - t0
     kernel_ms = ev0.elapsed_time(ev1) / args.steps  # HIP events around the K launches, per launch
     matcher.poll_error(stream)
 
-    if world > 1:
+    if use_dist:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -160,7 +156,7 @@ def main() -> int:
     counts_host = d_counts.cpu().numpy()
     if not os.environ.get("FQTK_MEMO_ABLATE"):
         assert int(counts_host.sum()) == n * args.steps, "per-sample counts do not add up to reads x steps"
-    if world > 1:
+    if use_dist:
         assert int(total_counts.sum().item()) == n * args.steps * world
     parity = None
     if not args.no_verify and rank == 0:
@@ -190,6 +186,7 @@ def main() -> int:
     except (OSError, ValueError, KeyError):
         pass
 
+    out = None
     if rank == 0:
         reads_total = n * args.steps * world
         value = reads_total / elapsed / 1e6
@@ -236,10 +233,14 @@ def main() -> int:
         if world == 1 and args.cpu_seconds > 0:
             out["cpu_baseline"] = cpu_baseline(workload, args.cpu_seconds)
             out["cpu_baseline"]["gpu_over_cpu"] = round(value / out["cpu_baseline"]["value"], 1)
-        print(json.dumps(out), flush=True)
-
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
+    if rank == 0:
+        # RCCL prints its version banner through C stdio, which is flushed at exit: push it out now so
+        # that the JSON line is the LAST thing on stdout
+        import ctypes
+        ctypes.CDLL(None).fflush(None)
+        print(json.dumps(out), flush=True)
     return 0
 
 

@@ -212,6 +212,67 @@ def test_baseline_configs_reduced_size_vs_oracle(k):
         _compare(w.barcodes, 0, 0, obs[:20000])
 
 
+def test_many_samples_lds_and_global_histogram_paths():
+    """S+1 <= 8192 keeps the per-sample histogram in LDS; above that counts go straight to global
+    atomics.  Both must agree with the oracle (S = 3000 and S = 9000, L = 12, ragged tail)."""
+    rng = np.random.default_rng(11)
+    acgt = np.frombuffer(b"ACGT", dtype=np.uint8)
+    for S in (3000, 9000):
+        codes = rng.choice(4 ** 12, size=S, replace=False)
+        bcs = ["".join("ACGT"[(int(c) >> (2 * k)) & 3] for k in range(12)) for c in codes]
+        n = 20_011
+        src = rng.integers(0, S, size=n)
+        obs = np.stack([np.frombuffer(bcs[i].encode(), dtype=np.uint8) for i in src]).copy()
+        flip = rng.random((n, 12)) < 0.03
+        obs[flip] = acgt[rng.integers(0, 4, size=int(flip.sum()))]
+        obs[rng.integers(0, n, 50), rng.integers(0, 12, 50)] = ord("N")
+        _compare(bcs, 1, 1, obs)
+
+
+def test_longest_memo_key_and_longer_barcodes():
+    """L = 20 is the longest barcode the memo covers (two 30-bit key halves); L = 21..128 are scan-only."""
+    rng = np.random.default_rng(12)
+    acgt = np.frombuffer(b"ACGTN", dtype=np.uint8)
+    for L in (19, 20, 21, 31, 32, 33, 96, 128):
+        bcs = ["".join(rng.choice(list("ACGT"), size=L)) for _ in range(40)]
+        m = BarcodeMatcher(bcs, 1, 1)
+        assert (m.memo_entries > 0) == (L <= 20)
+        n = 3000
+        src = rng.integers(0, 40, size=n)
+        obs = np.stack([np.frombuffer(bcs[i].encode(), dtype=np.uint8) for i in src]).copy()
+        flip = rng.random((n, L)) < 0.02
+        obs[flip] = acgt[rng.integers(0, 5, size=int(flip.sum()))]
+        _compare(bcs, 1, 1, obs)
+        _compare(bcs, 2, 1, obs[:500])
+
+
+def test_device_entry_point_with_misaligned_and_padded_buffers():
+    """The zero-copy entry point must not assume alignment: an odd base pointer and a stride larger
+    than the barcode take the generic load path and still match the oracle."""
+    import torch
+    cfg = synth.CONFIGS[2]
+    w = synth.Workload(cfg)
+    n = 100_003
+    host = w.fill_host(0, n)                      # [n, 8]
+    lit = O.RefLiteral(w.barcodes, cfg.max_mismatches, cfg.min_mismatch_delta, True)
+    i, b, nx, _ = lit.assign_batch(host)
+    dev = torch.device("cuda:0")
+    stream = torch.cuda.current_stream().cuda_stream
+    dt = np.dtype([("idx", "<u2"), ("best", "u1"), ("next", "u1")])
+    for off, stride in ((1, 8), (0, 11), (3, 13), (4, 12), (0, 16)):
+        padded = np.full((n, stride), ord("#"), dtype=np.uint8)
+        padded[:, :8] = host
+        raw = torch.zeros(off + n * stride + 16, dtype=torch.uint8, device=dev)
+        raw[off:off + n * stride] = torch.from_numpy(padded.reshape(-1)).to(dev)
+        d_out = torch.empty(n, dtype=torch.int32, device=dev)
+        for use_cache in (True, False):
+            m = BarcodeMatcher(w.barcodes, cfg.max_mismatches, cfg.min_mismatch_delta, use_cache)
+            m.assign_batch_device(raw.data_ptr() + off, stride, n, d_out.data_ptr(), stream=stream)
+            m.poll_error(stream)
+            got = d_out.cpu().numpy().view(dt)
+            assert np.array_equal(got["idx"], i) and np.array_equal(got["best"], b) and np.array_equal(got["next"], nx), (off, stride, use_cache)
+
+
 def test_cfg1_full_size_vs_oracle():
     """BASELINE config 1 at its FULL size (1 M reads x 16 samples): every result and every count."""
     cfg = synth.CONFIGS[1]
