@@ -71,6 +71,7 @@ struct Options {
     std::string sample_metadata, output, unmatched_prefix = "unmatched";
     unsigned long max_mismatches = 1, min_mismatch_delta = 2, threads = 8, compression_level = 5;
     int device = 0;
+    std::vector<int> devices;        // --devices a,b,..: chunk k goes to devices[k mod G]
     unsigned long chunk_reads = 1ul << 18;
 };
 
@@ -89,6 +90,7 @@ const char *kUsage =
     "  -c, --compression-level <N>                 [default: 5]\n"
     "  -S, --skip-reasons <REASON>...              too-few-bases\n"
     "      --device <N>                            GPU to use [default: 0] (additive flag)\n"
+    "      --devices <A,B,..>                      several GPUs: chunk k is matched on devices[k mod G] (additive flag)\n"
     "      --chunk-reads <N>                       templates per GPU chunk [default: 262144] (additive flag)\n";
 
 bool parse_ulong(const std::string &s, unsigned long *out) {
@@ -160,6 +162,19 @@ Options parse_args(int argc, char **argv) {
         else if (a == "--compression-level") num(&o.compression_level);
         else if (a == "--skip-reasons") multi(o.skip_reasons);
         else if (a == "--device") { unsigned long d; num(&d); o.device = (int)d; }
+        else if (a == "--devices") {
+            const std::string v = single();
+            size_t p = 0;
+            while (p <= v.size()) {
+                const size_t q = v.find(',', p);
+                const std::string tok = v.substr(p, q == std::string::npos ? std::string::npos : q - p);
+                unsigned long d;
+                if (!parse_ulong(tok, &d)) die("invalid value '" + v + "' for '--devices': expected a comma-separated list of device indices");
+                o.devices.push_back((int)d);
+                if (q == std::string::npos) break;
+                p = q + 1;
+            }
+        }
         else if (a == "--chunk-reads") num(&o.chunk_reads);
         else if (a == "--help" || a == "-h") { std::fputs(kUsage, stdout); std::exit(0); }
         else die("unexpected argument '" + a + "' found\n\n" + kUsage);
@@ -399,13 +414,19 @@ int main(int argc, char **argv) {
     // ---- the matcher (demux.rs:921-926), use_cache = true as the reference passes -----------------
     std::vector<const char *> bc;
     for (const Sample &s : samples) bc.push_back(s.barcode.c_str());
-    fqtk_matcher *matcher = nullptr;
+    // One matcher (replicated table) per device; chunk k is matched on device k mod G.  Templates are
+    // independent, so there is no data-path exchange; the per-device counts are summed at the end.
+    if (opt.devices.empty()) opt.devices.push_back(opt.device);
+    const size_t G = opt.devices.size();
+    std::vector<fqtk_matcher *> matchers(G, nullptr);
     const uint32_t L = (uint32_t)samples[0].barcode.size();
-    if (fqtk_matcher_create(bc.data(), (uint32_t)S, L, (uint8_t)opt.max_mismatches, (uint8_t)opt.min_mismatch_delta,
-                            opt.device, &matcher) != FQTK_OK)
-        die(std::string("cannot create the GPU barcode matcher: ") + fqtk_last_error());
-    info("GPU barcode matcher ready on device %d (%llu memo entries).", opt.device,
-         (unsigned long long)fqtk_matcher_memo_entries(matcher));
+    for (size_t g = 0; g < G; ++g) {
+        if (fqtk_matcher_create(bc.data(), (uint32_t)S, L, (uint8_t)opt.max_mismatches, (uint8_t)opt.min_mismatch_delta,
+                                opt.devices[g], &matchers[g]) != FQTK_OK)
+            die(std::string("cannot create the GPU barcode matcher: ") + fqtk_last_error());
+        info("GPU barcode matcher ready on device %d (%llu memo entries).", opt.devices[g],
+             (unsigned long long)fqtk_matcher_memo_entries(matchers[g]));
+    }
 
     // sample-barcode layout of one template: fixed total length, or variable when a B segment is '+'
     bool variable_barcode = false;
@@ -517,9 +538,9 @@ int main(int argc, char **argv) {
         });
 
     // ---- stage B (this thread): chunk assembly, barcode SoA packing, GPU pipeline -------------------
-    constexpr int kSlots = 2;
+    const int kSlots = 2 * (int)G;   // two pipeline slots per device; global slot gs -> device gs % G, local slot gs / G
     struct SlotBuf { uint8_t *obs = nullptr; uint32_t *lens = nullptr; fqtk_match_t *out = nullptr; size_t obs_cap = 0, n_cap = 0; };
-    SlotBuf sb[kSlots];
+    std::vector<SlotBuf> sb(kSlots);
     auto ensure_slot = [&](SlotBuf &b, size_t n, size_t stride) {
         if (n * stride > b.obs_cap) {
             if (b.obs) fqtk_pinned_free(b.obs);
@@ -543,14 +564,14 @@ int main(int argc, char **argv) {
     auto finish = [&](Pending &p) {
         if (!p.chunk) return;
         if (p.slot >= 0) {
-            if (fqtk_matcher_wait(matcher, p.slot) != FQTK_OK)
+            if (fqtk_matcher_wait(matchers[p.slot % G], p.slot / (int)G) != FQTK_OK)
                 die(std::string(fqtk_last_error()));   // over-long barcode: the reference panics too (barcode_matching.rs:95-107)
             for (size_t j = 0; j < p.rows.size(); ++j) p.chunk->res[p.rows[j]] = sb[p.slot].out[j];
         }
         for (size_t w = 0; w < n_workers; ++w) wq[w]->push(p.chunk);
         p.chunk.reset();
     };
-    Pending pending[kSlots];
+    std::vector<Pending> pending(kSlots);
     uint64_t total_templates = 0, skipped = 0, k = 0, next_log = 1000000;
     for (;; ++k) {
         auto ch = std::make_shared<Chunk>();
@@ -633,7 +654,7 @@ int main(int argc, char **argv) {
         total_templates += row;
         if (row > 0) {
             const bool need_lens = variable_barcode || fixed_barcode_len != L;
-            if (fqtk_matcher_enqueue(matcher, slot, sb[slot].obs, (uint32_t)stride, need_lens ? sb[slot].lens : nullptr, row,
+            if (fqtk_matcher_enqueue(matchers[slot % G], slot / (int)G, sb[slot].obs, (uint32_t)stride, need_lens ? sb[slot].lens : nullptr, row,
                                      sb[slot].out) != FQTK_OK)
                 die(fqtk_last_error());
             p.slot = slot;
@@ -663,7 +684,8 @@ int main(int argc, char **argv) {
 
     // ---- metrics (demux.rs:994-998): counts come from the device-side per-sample histogram --------
     std::vector<uint64_t> counts(S + 1, 0);
-    if (fqtk_matcher_counts(matcher, counts.data()) != FQTK_OK) die(fqtk_last_error());
+    for (fqtk_matcher *mt : matchers)   // fqtk_matcher_counts ADDS into `counts`
+        if (fqtk_matcher_counts(mt, counts.data()) != FQTK_OK) die(fqtk_last_error());
     uint64_t sum = 0;
     for (uint64_t c : counts) sum += c;
     if (sum != total_templates) die("internal error: device counts do not add up to the number of templates");
@@ -681,7 +703,7 @@ int main(int argc, char **argv) {
     rows.push_back(unmatched);
     std::string err;
     if (!write_metrics_tsv(opt.output + "/demux-metrics.txt", rows, &err)) die(err);
-    fqtk_matcher_destroy(matcher);
+    for (fqtk_matcher *mt : matchers) fqtk_matcher_destroy(mt);
     for (SlotBuf &b : sb) {
         fqtk_pinned_free(b.obs);
         fqtk_pinned_free(b.lens);

@@ -166,6 +166,35 @@ def test_overlong_barcode_is_fatal_like_the_reference_panic(tmp_path):
     assert r.returncode != 0 and "differs from expected barcode length" in r.stderr
 
 
+def test_chunk_round_robin_over_devices_keeps_order_and_counts(tmp_path):
+    """SURVEY 8e in the CLI: chunk k is matched on devices[k mod G] (table replicated, counts summed).
+    The GPU box has one device, so the list repeats it -- the routing logic is what is under test:
+    outputs must be byte-identical (after decompression) to the single-device run."""
+    from fqtk_amd import synth
+    cfg = synth.CONFIGS[2]
+    w = synth.Workload(cfg)
+    n = 20_000
+    bcs = w.fill_host(0, n)
+    reads = [bytes(bcs[i]).decode() + "ACGTACGTAC" for i in range(n)]
+    fq = H.fastq_file(tmp_path, "r", "q", reads)
+    meta = os.path.join(str(tmp_path), "metadata.tsv")
+    with open(meta, "w") as fh:
+        fh.write("sample_id\tbarcode\n" + "".join(f"S{i}\t{b}\n" for i, b in enumerate(w.barcodes)))
+    outs = []
+    for tag, extra in (("one", ["--chunk-reads", "1500"]), ("three", ["--chunk-reads", "1500", "--devices", "0,0,0"])):
+        out = tmp_path / tag
+        _ok(H.run_demux([fq], ["8B10T"], meta, out, threads=6, extra=extra))
+        outs.append(out)
+    names = [f"S{i}" for i in range(cfg.n_samples)] + ["unmatched"]
+    total = 0
+    for name in names:
+        a = H.read_fastq(outs[0] / f"{name}.R1.fq.gz")
+        assert a == H.read_fastq(outs[1] / f"{name}.R1.fq.gz")
+        total += len(a)
+    assert total == n
+    assert open(outs[0] / "demux-metrics.txt").read() == open(outs[1] / "demux-metrics.txt").read()
+
+
 def test_synthetic_multi_chunk_gz_inputs_match_the_oracle(tmp_path):
     """cfg 4 shape (R1 16C8B126T + R2 150T, outputs T and C), several GPU chunks, gz inputs, all worker
     threads: per-sample record lists must equal the ones the CPU oracle's assignments imply, in input
