@@ -178,13 +178,13 @@ int launch_memo_vec(const fqtk_matcher *m, const fqtk::MemoParams &Q, hipStream_
     if (const char *rr = std::getenv("FQTK_MEMO_R")) R = std::atoi(rr);
     if (const char *ab = std::getenv("FQTK_MEMO_ABLATE")) abl = std::atoi(ab);
 #endif
+    size_t shmem = 256 * sizeof(uint32_t);   // + 256 B static (code LUT)
+    if (Q.hot_mask) shmem += (size_t)(Q.hot_mask + 1) * (KEY64 ? 16 : 8);
+    if (P.counts && P.lds_hist) shmem += (size_t)(P.S + 1) * sizeof(uint32_t);
     const uint64_t tile = (uint64_t)fqtk::kBlock * R;
     const uint64_t ntiles = (P.n + tile - 1) / tile;
     if (ntiles == 0) return FQTK_OK;
     const uint32_t grid = (uint32_t)std::min<uint64_t>(ntiles, (uint64_t)m->num_cus * 8);
-    size_t shmem = 256 * sizeof(uint32_t);   // + 256 B static (code LUT)
-    if (Q.hot_mask) shmem += (size_t)(Q.hot_mask + 1) * (KEY64 ? 16 : 8);
-    if (P.counts && P.lds_hist) shmem += (size_t)(P.S + 1) * sizeof(uint32_t);
 #define FQTK_MEMO_LAUNCH(V, RR, A) \
     hipLaunchKernelGGL((fqtk::memo_kernel<V, KEY64, RR, A>), dim3(grid), dim3(fqtk::kBlock), shmem, stream, Q)
 #define FQTK_MEMO_BY_VEC(RR, A)                         \
