@@ -384,3 +384,19 @@ def test_pinned_pipeline_slots_match_sync_path():
     for p_obs, p_out in bufs:
         lib.fqtk_pinned_free(p_obs)
         lib.fqtk_pinned_free(p_out)
+
+
+def test_full_parity_tool_reduced_size():
+    """tools/full_parity.py is the full-size gate (results for all 751 M reads of the five configs are
+    in profiles/r01_full_parity.jsonl); here it runs on a 3 M-read prefix of cfg 2 and cfg 5."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for c in ("2", "5"):
+        r = subprocess.run([sys.executable, os.path.join(root, "tools", "full_parity.py"), "--config", c,
+                            "--reads", "3000000", "--procs", "4"], capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        d = json.loads(r.stdout.strip().splitlines()[-1])
+        assert d["mismatching_reads"] == 0 and d["counts_equal"] and d["reads"] == 3000000

@@ -1,0 +1,92 @@
+#!/usr/bin/env python3
+"""Full-size parity gate: the GPU path over EVERY read of a BASELINE config, checked
+bit-for-bit against the CPU oracle -- (idx, best, next) of every read and the per-sample count vector.
+The oracle side is fanned out over host processes (each regenerates its slice of the counter-based
+synthetic stream and runs oracle/ref_literal.c on it), so 400 M reads finish in about a minute on the
+GPU box.   python tools/full_parity.py --config 3 [--reads N] [--procs P] [--no-cache]
+Prints one JSON object (kept under profiles/)."""
+import argparse
+import json
+import multiprocessing as mp
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+DT = np.dtype([("idx", "<u2"), ("best", "u1"), ("next", "u1")])
+
+
+def _check(args):
+    cfg_id, lo, hi, path = args
+    from fqtk_amd import synth
+    from oracle import oracle as O
+    cfg = synth.CONFIGS[cfg_id]
+    w = synth.Workload(cfg)
+    lit = O.RefLiteral(w.barcodes, cfg.max_mismatches, cfg.min_mismatch_delta, True)
+    got = np.memmap(path, dtype=DT, mode="r")
+    counts = np.zeros(cfg.n_samples + 1, dtype=np.uint64)
+    bad = 0
+    step = 2_000_000
+    for a in range(lo, hi, step):
+        b = min(hi, a + step)
+        host = np.ascontiguousarray(w.fill_host(a, b - a)[:, :cfg.barcode_len])
+        i, be, nx, c = lit.assign_batch(host)
+        g = got[a:b]
+        bad += int(np.count_nonzero((g["idx"] != i) | (g["best"] != be) | (g["next"] != nx)))
+        counts += c
+    return bad, counts
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--config", type=int, default=3)
+    ap.add_argument("--reads", type=int, default=0)
+    ap.add_argument("--procs", type=int, default=0)
+    ap.add_argument("--no-cache", action="store_true")
+    a = ap.parse_args()
+    import torch
+    from fqtk_amd import BarcodeMatcher, synth
+    cfg = synth.CONFIGS[a.config]
+    n = a.reads or cfg.n_reads
+    procs = a.procs or max(1, min(128, (os.cpu_count() or 2) // 2))
+    w = synth.Workload(cfg)
+    dev = torch.device("cuda:0")
+    stream = torch.cuda.current_stream().cuda_stream
+    d_obs = torch.empty((n, cfg.stride), dtype=torch.uint8, device=dev)
+    for lo in range(0, n, 50_000_000):
+        cur = min(50_000_000, n - lo)
+        w.fill_device(lo, cur, d_obs.data_ptr() + lo * cfg.stride, stream)
+    d_out = torch.empty(n, dtype=torch.int32, device=dev)
+    d_counts = torch.zeros(cfg.n_samples + 1, dtype=torch.int64, device=dev)
+    m = BarcodeMatcher(w.barcodes, cfg.max_mismatches, cfg.min_mismatch_delta, use_cache=not a.no_cache)
+    t0 = time.perf_counter()
+    m.assign_batch_device(d_obs.data_ptr(), cfg.stride, n, d_out.data_ptr(), d_counts.data_ptr(), stream=stream)
+    m.poll_error(stream)
+    gpu_s = time.perf_counter() - t0
+    path = f"/dev/shm/fqtk_parity_{os.getpid()}.bin"
+    d_out.cpu().numpy().tofile(path)
+    gpu_counts = d_counts.cpu().numpy().astype(np.uint64)
+    del d_obs, d_out
+    bounds = np.linspace(0, n, procs + 1).astype(np.int64)
+    jobs = [(a.config, int(bounds[i]), int(bounds[i + 1]), path) for i in range(procs) if bounds[i] < bounds[i + 1]]
+    t0 = time.perf_counter()
+    with mp.get_context("spawn").Pool(len(jobs)) as pool:
+        res = pool.map(_check, jobs)
+    cpu_s = time.perf_counter() - t0
+    os.unlink(path)
+    mism = sum(r[0] for r in res)
+    oracle_counts = sum((r[1] for r in res), np.zeros(cfg.n_samples + 1, dtype=np.uint64))
+    out = {"config": cfg.name, "reads": n, "path": "scan" if a.no_cache else "memo", "memo_entries": m.memo_entries,
+           "mismatching_reads": mism, "counts_equal": bool(np.array_equal(oracle_counts, gpu_counts)),
+           "matched_fraction": round(float(1 - gpu_counts[-1] / gpu_counts.sum()), 6),
+           "gpu_seconds_incl_launch": round(gpu_s, 4), "oracle_processes": len(jobs), "oracle_wall_seconds": round(cpu_s, 1)}
+    print(json.dumps(out))
+    return 0 if mism == 0 and out["counts_equal"] else 1
+
+
+if __name__ == "__main__":
+    sys.exit(main())
