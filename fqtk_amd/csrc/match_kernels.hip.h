@@ -103,6 +103,18 @@ __device__ __forceinline__ void encode_planes(const uint32_t *words, uint32_t nw
     }
 }
 
+// The barcode stream is read once and the result stream written once: mark both non-temporal so that
+// they do not evict the (re-used) memo table from the XCD's L2.
+typedef uint32_t u32x4v __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x2v __attribute__((ext_vector_type(2)));
+#ifndef FQTK_NO_NT
+#define FQTK_STREAM_LOAD(p) __builtin_nontemporal_load(p)
+#define FQTK_STREAM_STORE(v, p) __builtin_nontemporal_store(v, p)
+#else
+#define FQTK_STREAM_LOAD(p) (*(p))
+#define FQTK_STREAM_STORE(v, p) (*(p) = (v))
+#endif
+
 // Load the first ceil(L/4) dwords of read `i`.  VEC = stride in dwords when the fast, aligned vector
 // path applies (1,2,3,4), 0 = generic byte path (any stride / alignment).
 template <int NW, int VEC>
@@ -110,10 +122,10 @@ __device__ __forceinline__ void load_words(const MatchParams &P, uint64_t i, uin
                                            uint32_t (&words)[NW * 8]) {
     const uint8_t *src = P.obs + i * (uint64_t)P.stride;
     if constexpr (VEC == 4) {
-        const uint4 v = *reinterpret_cast<const uint4 *>(src);
+        const u32x4v v = FQTK_STREAM_LOAD(reinterpret_cast<const u32x4v *>(src));
         words[0] = v.x; words[1] = v.y; words[2] = v.z; words[3] = v.w;
     } else if constexpr (VEC == 2) {
-        const uint2 v = *reinterpret_cast<const uint2 *>(src);
+        const u32x2v v = FQTK_STREAM_LOAD(reinterpret_cast<const u32x2v *>(src));
         words[0] = v.x; words[1] = v.y;
     } else if constexpr (VEC == 1) {
         words[0] = *reinterpret_cast<const uint32_t *>(src);
@@ -282,7 +294,7 @@ __global__ __launch_bounds__(kBlock) void match_kernel(const MatchParams P) {
             }
             const uint32_t idx = none ? kNoMatch : (best[r] & 0xFFFFu);
             const uint32_t res = none ? 0xFFFFFFFFu : (idx | (bm << 16) | (nm << 24));
-            P.out[i] = res;
+            FQTK_STREAM_STORE(res, &P.out[i]);
             if (P.counts) {
                 const uint32_t bin = none ? P.S : idx;
                 if (P.lds_hist) atomicAdd(&lds_hist[bin], 1u);

@@ -292,7 +292,7 @@ void memo_kernel(const MemoParams Q) {
             if (!live[r]) continue;
             const uint64_t i = t * tile + (uint64_t)r * kBlock + tid;
             if constexpr (ABL & 8) { if (res[r] == 0x12345u) P.out[i] = res[r]; } else
-            P.out[i] = res[r];
+            FQTK_STREAM_STORE(res[r], &P.out[i]);
             if (P.counts && !(ABL & 4)) {
                 const uint32_t idx = res[r] & 0xFFFFu;
                 const uint32_t bin = idx == kNoMatch ? P.S : idx;
