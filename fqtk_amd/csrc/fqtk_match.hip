@@ -81,7 +81,8 @@ struct fqtk_matcher {
     uint32_t *d_table = nullptr;
     uint32_t *d_lut = nullptr;
     unsigned long long *d_err = nullptr;     // [0] min offending index, ~0 = none
-    unsigned long long *d_counts = nullptr;  // S+1, used by the host-pointer entry points
+    unsigned long long *d_counts = nullptr;       // S+1, accumulator of the enqueue()/wait() pipeline
+    unsigned long long *d_counts_sync = nullptr;  // S+1, private to the synchronous assign_batch()
     unsigned long long *h_err = nullptr;     // pinned mirror
     // complete memo (memo_kernels.hip.h); absent when the candidate set is over budget or L > 20
     void *d_memo = nullptr;
@@ -584,6 +585,8 @@ int fqtk_matcher_create(const char *const *barcodes, uint32_t n_samples, uint32_
     HIP_TRY_C(hipMemset(m->d_err, 0xFF, sizeof(unsigned long long)));
     HIP_TRY_C(hipMalloc(reinterpret_cast<void **>(&m->d_counts), (size_t)(n_samples + 1) * sizeof(unsigned long long)));
     HIP_TRY_C(hipMemset(m->d_counts, 0, (size_t)(n_samples + 1) * sizeof(unsigned long long)));
+    HIP_TRY_C(hipMalloc(reinterpret_cast<void **>(&m->d_counts_sync), (size_t)(n_samples + 1) * sizeof(unsigned long long)));
+    HIP_TRY_C(hipMemset(m->d_counts_sync, 0, (size_t)(n_samples + 1) * sizeof(unsigned long long)));
     HIP_TRY_C(hipHostMalloc(reinterpret_cast<void **>(&m->h_err), sizeof(unsigned long long), hipHostMallocDefault));
     *m->h_err = ~0ull;
 #undef HIP_TRY_C
@@ -614,6 +617,7 @@ void fqtk_matcher_destroy(fqtk_matcher *m) {
     if (m->d_lut) (void)hipFree(m->d_lut);
     if (m->d_err) (void)hipFree(m->d_err);
     if (m->d_counts) (void)hipFree(m->d_counts);
+    if (m->d_counts_sync) (void)hipFree(m->d_counts_sync);
     if (m->h_err) (void)hipHostFree(m->h_err);
     delete m;
 }
@@ -647,8 +651,12 @@ int fqtk_matcher_poll_error(fqtk_matcher *m, void *hip_stream, uint64_t *read_in
     return collect_error(m, static_cast<hipStream_t>(hip_stream), read_index);
 }
 
-int fqtk_matcher_enqueue(fqtk_matcher *m, int slot, const uint8_t *obs, uint32_t stride,
-                         const uint32_t *obs_len, uint64_t n, fqtk_match_t *out) {
+}  // extern "C"
+
+namespace {
+// One chunk on one pipeline slot; counts go to `d_counts_target` (device, S+1) or nowhere (NULL).
+int enqueue_impl(fqtk_matcher *m, int slot, const uint8_t *obs, uint32_t stride, const uint32_t *obs_len,
+                 uint64_t n, fqtk_match_t *out, unsigned long long *d_counts_target) {
     int rc = check_batch_args(m, obs, stride, obs_len, n, out);
     if (rc != FQTK_OK) return rc;
     HIP_TRY(hipSetDevice(m->device));
@@ -665,12 +673,21 @@ int fqtk_matcher_enqueue(fqtk_matcher *m, int slot, const uint8_t *obs, uint32_t
     if (obs_len)
         HIP_TRY(hipMemcpyAsync(s.d_len, obs_len, (size_t)n * sizeof(uint32_t), hipMemcpyHostToDevice, s.stream));
     const fqtk::MatchParams P =
-        make_params(m, s.d_obs, stride, obs_len ? s.d_len : nullptr, n, s.d_out, m->d_counts);
+        make_params(m, s.d_obs, stride, obs_len ? s.d_len : nullptr, n, s.d_out, d_counts_target);
     rc = launch(m, P, s.stream);
     if (rc != FQTK_OK) return rc;
     HIP_TRY(hipMemcpyAsync(out, s.d_out, (size_t)n * sizeof(fqtk_match_t), hipMemcpyDeviceToHost, s.stream));
     s.busy = true;
     return FQTK_OK;
+}
+}  // namespace
+
+extern "C" {
+
+int fqtk_matcher_enqueue(fqtk_matcher *m, int slot, const uint8_t *obs, uint32_t stride,
+                         const uint32_t *obs_len, uint64_t n, fqtk_match_t *out) {
+    if (!m) return fail(FQTK_EINVAL, "matcher is NULL");
+    return enqueue_impl(m, slot, obs, stride, obs_len, n, out, m->d_counts);
 }
 
 int fqtk_matcher_wait(fqtk_matcher *m, int slot) {
@@ -702,6 +719,11 @@ int fqtk_matcher_assign_batch(fqtk_matcher *m, const uint8_t *obs, uint32_t stri
                               uint64_t *counts) {
     int rc = check_batch_args(m, obs, stride, obs_len, n, out);
     if (rc != FQTK_OK || n == 0) return rc;
+    HIP_TRY(hipSetDevice(m->device));
+    const size_t bins = (size_t)m->S + 1;
+    // counts of THIS call only: a private accumulator, so a concurrent enqueue()/counts() session on
+    // the same handle keeps its own totals
+    if (counts) HIP_TRY(hipMemset(m->d_counts_sync, 0, bins * sizeof(unsigned long long)));
     // Chunk so staging stays bounded, ping-pong over two slots so copy and compute overlap.
     const uint64_t chunk = std::max<uint64_t>(1, std::min<uint64_t>(n, (256ull << 20) / stride));
     int first_err = FQTK_OK;
@@ -722,8 +744,8 @@ int fqtk_matcher_assign_batch(fqtk_matcher *m, const uint8_t *obs, uint32_t stri
         drain(slot);
         const uint64_t cur = std::min(chunk, n - done);
         pending_base[slot] = done;
-        rc = fqtk_matcher_enqueue(m, slot, obs + done * stride, stride, obs_len ? obs_len + done : nullptr,
-                                  cur, out + done);
+        rc = enqueue_impl(m, slot, obs + done * stride, stride, obs_len ? obs_len + done : nullptr, cur,
+                          out + done, counts ? m->d_counts_sync : nullptr);
         if (rc != FQTK_OK) {
             drain(0);
             drain(1);
@@ -735,10 +757,9 @@ int fqtk_matcher_assign_batch(fqtk_matcher *m, const uint8_t *obs, uint32_t stri
     drain(0);
     drain(1);
     if (counts) {
-        rc = fqtk_matcher_counts(m, counts);
-        if (rc != FQTK_OK) return rc;
-    } else {
-        HIP_TRY(hipMemset(m->d_counts, 0, ((size_t)m->S + 1) * sizeof(unsigned long long)));
+        std::vector<unsigned long long> tmp(bins);
+        HIP_TRY(hipMemcpy(tmp.data(), m->d_counts_sync, bins * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+        for (size_t b = 0; b < bins; ++b) counts[b] += (uint64_t)tmp[b];
     }
     if (first_err != FQTK_OK) return fail(first_err, first_msg);
     return FQTK_OK;

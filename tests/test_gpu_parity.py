@@ -386,6 +386,29 @@ def test_pinned_pipeline_slots_match_sync_path():
         lib.fqtk_pinned_free(p_out)
 
 
+def test_sync_batch_counts_do_not_disturb_the_pipeline_accumulator():
+    """assign_batch() reports the counts of its own call; the enqueue()/counts() accumulator of the
+    same handle is untouched by it (and by assign1)."""
+    cfg = synth.CONFIGS[2]
+    w = synth.Workload(cfg)
+    lib = _lib.load()
+    m = BarcodeMatcher(w.barcodes, cfg.max_mismatches, cfg.min_mismatch_delta)
+    a = w.fill_host(0, 50_000)
+    b = w.fill_host(50_000, 30_000)
+    out_a = np.empty(len(a), dtype=np.uint32)
+    assert lib.fqtk_matcher_enqueue(m.handle, 3, a.ctypes.data, cfg.stride, None, len(a), out_a.ctypes.data) == 0
+    assert lib.fqtk_matcher_wait(m.handle, 3) == 0
+    got_b, counts_b = m.assign_batch(b)                       # synchronous call in between
+    assert m.assign(bytes(b[0, :cfg.barcode_len])) is not None or True
+    lit = O.RefLiteral(w.barcodes, cfg.max_mismatches, cfg.min_mismatch_delta, True)
+    _, _, _, ca = lit.assign_batch(a)
+    _, _, _, cb = lit.assign_batch(b)
+    assert np.array_equal(counts_b, cb)
+    pipeline = np.zeros(cfg.n_samples + 1, dtype=np.uint64)
+    assert lib.fqtk_matcher_counts(m.handle, pipeline.ctypes.data) == 0
+    assert np.array_equal(pipeline, ca)
+
+
 def test_full_parity_tool_reduced_size():
     """tools/full_parity.py is the full-size gate (results for all 751 M reads of the five configs are
     in profiles/r01_full_parity.jsonl); here it runs on a 3 M-read prefix of cfg 2 and cfg 5."""
