@@ -45,7 +45,7 @@ inline bool validate_samples(const std::vector<Sample> &samples, std::string *er
 
 inline bool load_samples(const std::string &path, std::vector<Sample> *out, std::string *err) {
     std::ifstream in(path);
-    if (!in) { *err = "Error reading sample metadata: cannot open " + path; return false; }
+    if (!in) { *err = "Error reading sample metadata " + path + ": No such file or directory (os error 2)"; return false; }
     std::vector<std::string> lines;
     std::string line;
     while (std::getline(in, line)) {
@@ -53,7 +53,7 @@ inline bool load_samples(const std::string &path, std::vector<Sample> *out, std:
         lines.push_back(line);
     }
     while (!lines.empty() && lines.back().empty()) lines.pop_back();   // samples.rs tests :181-201
-    if (lines.empty()) { *err = "Error reading sample metadata: empty file " + path; return false; }
+    if (lines.empty()) { *err = "Must provide one or more sample"; return false; }   // samples.rs test_reading_empty_file
     if (lines[0] != "sample_id\tbarcode") {
         *err = "Error reading sample metadata: header mismatch: expected `sample_id\tbarcode`, found `" + lines[0] + "`";
         return false;

@@ -84,8 +84,8 @@ class SampleGroup:
             lines = fh.read().split("\n")
         while lines and lines[-1].strip("\r") == "":
             lines.pop()
-        if not lines:
-            raise ValueError("sample metadata file is empty")
+        if not lines:   # samples.rs test_reading_empty_file: an empty file reaches from_samples(&[])
+            return SampleGroup.from_samples([])
         header = lines[0].rstrip("\r")
         expected = Sample.deserialize_header_line()
         if header != expected:

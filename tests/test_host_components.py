@@ -164,10 +164,14 @@ def test_load_samples_matches_sample_group_rules(tmp_path):
                       ("sample_id\tbarcode\ns1\tGATTACA\ns2\tGATTACA\n", "Each sample barcode must be unique"),
                       ("sample_id\tbarcode\ns1\tGATTACA\ns2\tGATTAC\n", "All barcodes must have the same length"),
                       ("sample_id\tbarcode\ns1\tgattaca\n", "All sample barcode bases must be one of"),
-                      ("sample_id\tbarcode\n", "Must provide one or more sample")]:
+                      ("sample_id\tbarcode\n", "Must provide one or more sample"),
+                      ("\n", "Must provide one or more sample"),
+                      ("sample_id,barcode\ns1,GATTACA\n", "header mismatch")]:
         p.write_text(body)
         with pytest.raises(ValueError, match=msg):
             H.load_samples(p)
+    with pytest.raises(ValueError, match=r"No such file or directory \(os error 2\)"):
+        H.load_samples(tmp_path / "missing.tsv")
 
 
 # ---- CLI validation that fails before any GPU work (demux.rs:1137-1290,1879-1981) ---------------------

@@ -58,6 +58,30 @@ def test_sample_group_from_file(tmp_path):
     assert str(Sample("test-sample", "GATTACA", 2)) == "Sample(0002) - { name: test-sample\tbarcode: GATTACA }"
 
 
+def test_sample_group_from_file_reference_cases(tmp_path):
+    """Ports of /root/reference/src/lib/samples.rs tests :162-286 (file loading)."""
+    p = tmp_path / "sample_metadata.tsv"
+    p.write_text("sample_id,barcode\nsample1,GATTACA\nsample2,CATGCTA\n")          # test_tsv_file_delim_error
+    with pytest.raises(DelimFileHeaderError) as ei:
+        SampleGroup.from_file(str(p))
+    assert (ei.value.expected, ei.value.found) == ("sample_id\tbarcode", "sample_id,barcode")
+    p.write_text("sample1\tGATTACA\nsample2\tCATGCTA\n")                           # ..._with_no_header
+    with pytest.raises(DelimFileHeaderError) as ei:
+        SampleGroup.from_file(str(p))
+    assert ei.value.found == "sample1\tGATTACA"
+    p.write_text("sample_id\tbarcode\n")                                            # test_reading_header_only_file
+    with pytest.raises(ValueError, match="Must provide one or more sample"):
+        SampleGroup.from_file(str(p))
+    p.write_text("\n")                                                              # test_reading_empty_file
+    with pytest.raises(ValueError, match="Must provide one or more sample"):
+        SampleGroup.from_file(str(p))
+    with pytest.raises(FileNotFoundError):                                          # test_reading_non_existent_file
+        SampleGroup.from_file(str(tmp_path / "nope.tsv"))
+    Sample.new(0, "s_1_example_name", "GATTANN")                                    # non-ACGT bases allowed
+    g = SampleGroup.from_samples([Sample("s1", "GATTACA", 0), Sample("s2", "CATGCTA", 0)])
+    assert [s.ordinal for s in g.samples] == [0, 1]                                 # ordinals re-assigned (:200-207)
+
+
 @pytest.mark.parametrize("k", [1, 2, 3, 4, 5])
 def test_synthetic_tables_meet_their_spec(k):
     cfg = synth.CONFIGS[k]
