@@ -69,6 +69,8 @@ def main() -> int:
     ap.add_argument("--reads", type=int, default=0, help="reads per rank per step (default: the config's N)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="CPU-baseline budget (0 = skip)")
     ap.add_argument("--no-verify", action="store_true")
+    ap.add_argument("--max-mismatches", type=int, default=-1, help="override the config's value (exploration only)")
+    ap.add_argument("--min-mismatch-delta", type=int, default=-1, help="override the config's value (exploration only)")
     ap.add_argument("--no-cache", action="store_true",
                     help="use_cache=false: exhaustive per-sample scan for every read (no memo table)")
     args = ap.parse_args()
@@ -98,8 +100,15 @@ def main() -> int:
         print(f"warning: --gpus {args.gpus} != WORLD_SIZE {world}", file=sys.stderr)
 
     cfg = synth.CONFIGS[args.config]
+    if args.max_mismatches >= 0 or args.min_mismatch_delta >= 0:
+        import dataclasses
+        cfg = dataclasses.replace(cfg,
+                                  max_mismatches=args.max_mismatches if args.max_mismatches >= 0 else cfg.max_mismatches,
+                                  min_mismatch_delta=args.min_mismatch_delta if args.min_mismatch_delta >= 0 else cfg.min_mismatch_delta,
+                                  name=cfg.name + " [overridden mismatch parameters]")
     n = args.reads or cfg.n_reads
-    workload = synth.Workload(cfg)
+    workload = synth.Workload(synth.CONFIGS[args.config])
+    workload.cfg = cfg
     stream = torch.cuda.current_stream().cuda_stream
 
     # ---- inputs resident in HBM before the timed region ------------------------------------------
