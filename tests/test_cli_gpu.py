@@ -234,3 +234,32 @@ def test_synthetic_multi_chunk_gz_inputs_match_the_oracle(tmp_path):
     rows = [l.split("\t") for l in open(out / "demux-metrics.txt").read().splitlines()[1:]]
     assert [r[0] for r in rows] == names
     assert [int(r[2]) for r in rows] == [int(c) for c in counts]
+
+
+def test_cfg5_shape_1536_iupac_samples_inline_barcode_plus_template(tmp_path):
+    """cfg 5 shape end to end: 1536 IUPAC-degenerate samples (1537 output files: the CLI must raise its
+    fd limit), `10B+T` with variable-length templates, counts and routing checked against the oracle."""
+    from fqtk_amd import synth
+    from oracle import oracle as O
+    cfg = synth.CONFIGS[5]
+    w = synth.Workload(cfg)
+    n = 6000
+    bcs = w.fill_host(0, n)[:, :10]
+    rng = np.random.default_rng(8)
+    acgt = np.frombuffer(b"ACGT", dtype=np.uint8)
+    reads = [bytes(bcs[i]).decode() + bytes(acgt[rng.integers(0, 4, size=int(rng.integers(1, 40)))]).decode() for i in range(n)]
+    fq = H.fastq_file(tmp_path, "r", "q", reads, gz=True)
+    meta = os.path.join(str(tmp_path), "metadata.tsv")
+    with open(meta, "w") as fh:
+        fh.write("sample_id\tbarcode\n" + "".join(f"S{i:04}\t{b}\n" for i, b in enumerate(w.barcodes)))
+    out = tmp_path / "output"
+    _ok(H.run_demux([fq], ["10B+T"], meta, out, threads=8))
+    lit = O.RefLiteral(w.barcodes, 1, 2, True)
+    idx, _, _, counts = lit.assign_batch(np.ascontiguousarray(bcs))
+    rows = [l.split("\t") for l in open(out / "demux-metrics.txt").read().splitlines()[1:]]
+    assert len(rows) == 1537 and [int(r[2]) for r in rows] == [int(c) for c in counts]
+    for s in list(np.unique(idx[idx != 0xFFFF])[:25]) + [0xFFFF]:
+        name = "unmatched" if s == 0xFFFF else f"S{int(s):04}"
+        sel = np.nonzero(idx == s)[0]
+        exp = [(f"q_{i} 1:N:0:" + bytes(bcs[i]).decode(), reads[i][10:], ";" * (len(reads[i]) - 10)) for i in sel]
+        assert H.read_fastq(out / f"{name}.R1.fq.gz") == exp
