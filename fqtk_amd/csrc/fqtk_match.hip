@@ -474,6 +474,7 @@ int build_memo(fqtk_matcher *m, const std::vector<std::vector<uint8_t>> &enc) {
     void *d = nullptr;
     HIP_TRY(hipMalloc(&d, slots.size() * sizeof(uint32_t)));
     HIP_TRY(hipMemcpy(d, slots.data(), slots.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+    HIP_TRY(hipDeviceSynchronize());   // pageable H2D copies may still be in flight; slot streams are non-blocking
     m->memo_mask = mask;
     m->memo_entries = entries;
     m->d_memo = d;   // last: enables the memo path
@@ -589,6 +590,9 @@ int fqtk_matcher_create(const char *const *barcodes, uint32_t n_samples, uint32_
     HIP_TRY_C(hipMemset(m->d_counts_sync, 0, (size_t)(n_samples + 1) * sizeof(unsigned long long)));
     HIP_TRY_C(hipHostMalloc(reinterpret_cast<void **>(&m->h_err), sizeof(unsigned long long), hipHostMallocDefault));
     *m->h_err = ~0ull;
+    // The pipeline slots use NON-BLOCKING streams, which do not order against the legacy NULL stream the
+    // initialisation above ran on: make it all visible before any slot stream touches these buffers.
+    HIP_TRY_C(hipDeviceSynchronize());
 #undef HIP_TRY_C
     {
         const int rc = build_memo(m, enc);
@@ -710,6 +714,7 @@ int fqtk_matcher_counts(fqtk_matcher *m, uint64_t *counts) {
     std::vector<unsigned long long> tmp(bins);
     HIP_TRY(hipMemcpy(tmp.data(), m->d_counts, bins * sizeof(unsigned long long), hipMemcpyDeviceToHost));
     HIP_TRY(hipMemset(m->d_counts, 0, bins * sizeof(unsigned long long)));
+    HIP_TRY(hipStreamSynchronize(nullptr));   // NULL-stream memset vs. the next chunk on a non-blocking slot stream
     for (size_t b = 0; b < bins; ++b) counts[b] += (uint64_t)tmp[b];
     return FQTK_OK;
 }
@@ -723,7 +728,10 @@ int fqtk_matcher_assign_batch(fqtk_matcher *m, const uint8_t *obs, uint32_t stri
     const size_t bins = (size_t)m->S + 1;
     // counts of THIS call only: a private accumulator, so a concurrent enqueue()/counts() session on
     // the same handle keeps its own totals
-    if (counts) HIP_TRY(hipMemset(m->d_counts_sync, 0, bins * sizeof(unsigned long long)));
+    if (counts) {
+        HIP_TRY(hipMemset(m->d_counts_sync, 0, bins * sizeof(unsigned long long)));
+        HIP_TRY(hipStreamSynchronize(nullptr));   // must land before the kernels on the non-blocking slot streams
+    }
     // Chunk so staging stays bounded, ping-pong over two slots so copy and compute overlap.
     const uint64_t chunk = std::max<uint64_t>(1, std::min<uint64_t>(n, (256ull << 20) / stride));
     int first_err = FQTK_OK;

@@ -151,7 +151,7 @@ ALPHABET = np.frombuffer(b"ACGTACGTACGTACGTNn.acgtRYKMSWBDHVXx-*0", dtype=np.uin
 SAMPLE_ALPHABET = list("ACGTACGTACGTNMRWSYKVHDBn.")
 
 
-@pytest.mark.parametrize("seed", range(16))
+@pytest.mark.parametrize("seed", range(int(__import__("os").environ.get("FQTK_SOAK_SEEDS", "16"))))
 def test_random_tables_and_reads(seed):
     rng = np.random.default_rng(99 + seed)
     S = int(rng.choice([1, 2, 3, 4, 5, 7, 16, 33, 100]))
