@@ -1,0 +1,179 @@
+#!/usr/bin/env python3
+"""Soak test of `fqtk demux` (run on the GPU box): random read structures / inputs / chunking / threads,
+checked against the CPU oracle's assignments and an independent Python segment extraction:
+  * every non-skipped template appears exactly once, in the file set of the sample the oracle assigns;
+  * within each output file records keep input order; bases/quals are the right segment;
+  * the header carries the read number, the '+'-joined sample barcodes and (if any) the UMIs;
+  * demux-metrics.txt counts equal the oracle's.
+usage: python tools/soak_cli.py [--iters 40] [--seed 1]"""
+import argparse
+import gzip
+import os
+import random
+import re
+import shutil
+import subprocess
+import sys
+import tempfile
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from oracle import oracle as O  # noqa: E402
+
+EXE = os.path.join(ROOT, "fqtk_amd", "bin", "fqtk")
+CODES = {"T": "R", "B": "I", "M": "U", "C": "C"}
+
+
+def parse_rs(rs):
+    segs, off = [], 0
+    for m in re.finditer(r"(\d+|\+)([TBMCS])", rs):
+        ln = None if m.group(1) == "+" else int(m.group(1))
+        segs.append((off, ln, m.group(2)))
+        off += ln or 0
+    return segs
+
+
+def read_fq(path):
+    with gzip.open(path, "rt") as fh:
+        lines = fh.read().split("\n")
+    if lines and lines[-1] == "":
+        lines.pop()
+    return [(lines[i][1:], lines[i + 1], lines[i + 3]) for i in range(0, len(lines), 4)]
+
+
+def one(rng, it, tmp):
+    n_inputs = rng.randint(1, 4)
+    kinds_pool = ["T", "B", "M", "C", "S"]
+    structures = []
+    for _ in range(n_inputs):
+        nseg = rng.randint(1, 4)
+        segs = [(rng.randint(1, 9), rng.choice(kinds_pool)) for _ in range(nseg)]
+        variable_last = rng.random() < 0.3
+        rs = "".join(f"{l}{k}" for l, k in segs[:-1]) + (f"+{segs[-1][1]}" if variable_last else f"{segs[-1][0]}{segs[-1][1]}")
+        structures.append(rs)
+    if not any("B" in s for s in structures):
+        structures[0] = "6B" + structures[0]
+    if not any("T" in s for s in structures):
+        structures[-1] = structures[-1] + "" if structures[-1].endswith("T") else "5T" if False else structures[-1]
+    parsed = [parse_rs(s) for s in structures]
+    # fixed total barcode length required for a sensible table; variable B segments get length 1..6 per read
+    n = rng.randint(1, 20000)
+    nprng = np.random.default_rng(rng.randint(0, 1 << 30))
+    S = rng.randint(1, 40)
+    fixed_L = sum(l for p in parsed for (_, l, k) in p if k == "B" and l is not None)
+    var_b = [(i, j) for i, p in enumerate(parsed) for j, (_, l, k) in enumerate(p) if k == "B" and l is None]
+    L = fixed_L + (3 if var_b else 0)      # variable B segments mostly carry 3 bases
+    if L == 0 or L > 40:
+        return "skipped-degenerate"
+    barcodes = set()
+    while len(barcodes) < S:
+        barcodes.add("".join(nprng.choice(list("ACGT"), size=L)))
+        if len(barcodes) < S and 4 ** L <= len(barcodes):
+            break
+    barcodes = sorted(barcodes)
+    S = len(barcodes)
+    reads = [[None] * n for _ in range(n_inputs)]
+    skip_ok = rng.random() < 0.5
+    short_any = False
+    for t in range(n):
+        src = barcodes[nprng.integers(0, S)] if nprng.random() < 0.85 else "".join(nprng.choice(list("ACGTN"), size=L))
+        src = "".join(c if nprng.random() > 0.03 else "ACGTN"[nprng.integers(0, 5)] for c in src)
+        pos = 0
+        for i, p in enumerate(parsed):
+            s = ""
+            for (_, ln, k) in p:
+                if k == "B":
+                    take = ln if ln is not None else (3 if nprng.random() < 0.9 else int(nprng.integers(1, 6)))
+                    piece = src[pos:pos + take]
+                    piece = piece + "A" * (take - len(piece))
+                    pos += ln if ln is not None else 3
+                    s += piece
+                else:
+                    take = ln if ln is not None else int(nprng.integers(1, 12))
+                    s += "".join(nprng.choice(list("ACGT"), size=take))
+            if skip_ok and nprng.random() < 0.01:
+                s = s[: max(0, len(s) - int(nprng.integers(1, 4)))]
+            reads[i][t] = s
+    files = []
+    gz = rng.random() < 0.5
+    for i in range(n_inputs):
+        path = os.path.join(tmp, f"in{it}_{i}.fastq" + (".gz" if gz else ""))
+        text = "".join(f"@q_{t} {i + 1}:N:0:0\n{reads[i][t]}\n+\n{'I' * len(reads[i][t])}\n" for t in range(n))
+        (gzip.open(path, "wt") if gz else open(path, "w")).write(text)
+        files.append(path)
+    meta = os.path.join(tmp, f"meta{it}.tsv")
+    open(meta, "w").write("sample_id\tbarcode\n" + "".join(f"S{i}\t{b}\n" for i, b in enumerate(barcodes)))
+    out = os.path.join(tmp, f"out{it}")
+    types = [k for k in "TBMC" if rng.random() < 0.6 and any(k in s for s in structures)] or ["B"]
+    mm, delta = rng.choice([0, 1, 1, 2]), rng.choice([0, 1, 2, 2])
+    cmd = [EXE, "demux", "-i", *files, "-r", *structures, "-s", meta, "-o", out, "-b", *types, "--max-mismatches", str(mm),
+           "-d", str(delta), "-t", str(rng.randint(5, 16)), "--chunk-reads", str(rng.choice([1, 7, 100, 1000, 5000, 262144]))]
+    if skip_ok:
+        cmd += ["-S", "too-few-bases"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=300)
+    # expected
+    minlen = [sum((l if l is not None else 1) for (_, l, _) in p) for p in parsed]
+    skipped = [any(len(reads[i][t]) < minlen[i] for i in range(n_inputs)) for t in range(n)]
+    if any(skipped) and not skip_ok:
+        assert r.returncode != 0 and "had too few bases" in r.stderr, (cmd, r.stderr[-500:])
+        return "fatal-short-ok"
+
+    def seg(i, j, t):
+        off, ln, _ = parsed[i][j]
+        s = reads[i][t]
+        return s[off:off + ln] if ln is not None else s[off:]
+    bsegs = [[seg(i, j, t) for i, p in enumerate(parsed) for j, (_, _, k) in enumerate(p) if k == "B"] for t in range(n)]
+    obs = ["".join(b) for b in bsegs]
+    lit = O.RefLiteral(barcodes, mm, delta, True)
+    assign, too_long = [], False
+    for t in range(n):
+        if skipped[t]:
+            assign.append(None)
+            continue
+        try:
+            a = lit.assign(obs[t].encode())
+        except O.OracleLengthError:
+            too_long = True
+            break
+        assign.append(S if a is None else a[0])
+    if too_long:
+        assert r.returncode != 0 and "differs from expected barcode length" in r.stderr, (cmd, r.stderr[-500:])
+        return "fatal-long-ok"
+    assert r.returncode == 0, (cmd, r.stderr[-800:])
+    names = [f"S{i}" for i in range(S)] + ["unmatched"]
+    counts = [sum(1 for a in assign if a == s) for s in range(S + 1)]
+    rows = [l.split("\t") for l in open(os.path.join(out, "demux-metrics.txt")).read().splitlines()[1:]]
+    assert [int(x[2]) for x in rows] == counts, (cmd, counts[:5])
+    umis = [[seg(i, j, t) for i, p in enumerate(parsed) for j, (_, _, k) in enumerate(p) if k == "M"] for t in range(n)]
+    for k in types:
+        refs = [(i, j) for i, p in enumerate(parsed) for j, (_, _, kk) in enumerate(p) if kk == k]
+        for num, (i, j) in enumerate(refs, start=1):
+            for s, name in enumerate(names):
+                recs = read_fq(os.path.join(out, f"{name}.{CODES[k]}{num}.fq.gz"))
+                exp_t = [t for t in range(n) if assign[t] == s]
+                assert len(recs) == len(exp_t), (cmd, name, k, num)
+                for (h, sq, ql), t in zip(recs, exp_t):
+                    nm = f"q_{t}" + (":" + "+".join(umis[t]) if umis[t] else "")
+                    assert h == f"{nm} {num}:N:0:" + "+".join(bsegs[t]), (cmd, h, t)
+                    assert sq == seg(i, j, t) and ql == "I" * len(sq), (cmd, name, t)
+    return "ok"
+
+
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--iters", type=int, default=40)
+    ap.add_argument("--seed", type=int, default=1)
+    a = ap.parse_args()
+    rng = random.Random(a.seed)
+    tmp = tempfile.mkdtemp(prefix="fqtk_soak_", dir="/tmp")
+    tally = {}
+    try:
+        for it in range(a.iters):
+            res = one(rng, it, tmp)
+            tally[res] = tally.get(res, 0) + 1
+            shutil.rmtree(os.path.join(tmp, f"out{it}"), ignore_errors=True)
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    print("soak_cli", tally)
