@@ -86,11 +86,10 @@ struct fqtk_matcher {
     unsigned long long *h_err = nullptr;     // pinned mirror
     // complete memo (memo_kernels.hip.h); absent when the candidate set is over budget or L > 20
     void *d_memo = nullptr;
-    uint32_t *d_code_lut = nullptr;
     uint32_t *d_hot = nullptr;               // hot subset (0-mismatch entries) for the LDS table
     uint32_t hot_mask = 0;
     uint32_t memo_mask = 0;
-    bool memo_key64 = false;
+    int memo_kw = 1;   // key words per entry (fqtk::memo_key_words)
     uint64_t memo_entries = 0;
     uint64_t memo_candidates = 0;
     uint64_t memo_second_slot = 0;             // entries living in their second-choice slot
@@ -153,7 +152,7 @@ int launch_vec(const fqtk::MatchParams &P, int num_cus, hipStream_t stream) {
     return launch_t<NW, R, 0>(P, num_cus, stream);
 }
 
-template <bool KEY64>
+template <int KW>
 int launch_memo_vec(const fqtk_matcher *m, const fqtk::MemoParams &Q, hipStream_t stream) {
     const fqtk::MatchParams &P = Q.m;
     const uintptr_t base = reinterpret_cast<uintptr_t>(P.obs);
@@ -169,25 +168,32 @@ int launch_memo_vec(const fqtk_matcher *m, const fqtk::MemoParams &Q, hipStream_
             else if (sw == 3) vec = 3;
         }
     }
-    // reads per lane: 2 on the vector-load paths (every such variant stays inside 64 VGPRs = 8
-    // waves/SIMD with no scratch, hipcc -Rpass-analysis=kernel-resource-usage); 1 on the generic
-    // paths (2 would spill) and for very large tables, where the extra probes in flight only add
-    // cache pressure (measured on cfg 5: 95 vs 87 G reads/s)
-    int R = (vec > 0 && m->memo_entries <= 65536) ? 2 : 1;
+    // reads per lane: 4 on the vector-load paths (every such variant stays inside 64 VGPRs = 8
+    // waves/SIMD with no scratch, hipcc -Rpass-analysis=kernel-resource-usage; measured +3-5 % over 2
+    // on cfg 2/3/4), 2 there for very large tables, where more probes in flight only add cache
+    // pressure, and 1 on the generic paths (4 would spill)
+    int R = vec > 0 ? (m->memo_entries <= 65536 ? 4 : 2) : 1;
     int abl = 0;
 #ifdef FQTK_DEV_ABLATE
     if (const char *rr = std::getenv("FQTK_MEMO_R")) R = std::atoi(rr);
     if (const char *ab = std::getenv("FQTK_MEMO_ABLATE")) abl = std::atoi(ab);
 #endif
-    size_t shmem = 256 * sizeof(uint32_t);   // + 256 B static (code LUT)
-    if (Q.hot_mask) shmem += (size_t)(Q.hot_mask + 1) * (KEY64 ? 16 : 8);
+    size_t shmem = 256 * sizeof(uint32_t);
+    if (Q.hot_mask) shmem += (size_t)(Q.hot_mask + 1) * (KW >= 2 ? 16 : 8);
     if (P.counts && P.lds_hist) shmem += (size_t)(P.S + 1) * sizeof(uint32_t);
     const uint64_t tile = (uint64_t)fqtk::kBlock * R;
     const uint64_t ntiles = (P.n + tile - 1) / tile;
     if (ntiles == 0) return FQTK_OK;
     const uint32_t grid = (uint32_t)std::min<uint64_t>(ntiles, (uint64_t)m->num_cus * 8);
-#define FQTK_MEMO_LAUNCH(V, RR, A) \
-    hipLaunchKernelGGL((fqtk::memo_kernel<V, KEY64, RR, A>), dim3(grid), dim3(fqtk::kBlock), shmem, stream, Q)
+    // the packed vector paths imply the key width (stride 16 B -> 2 key words, 12 B -> 1 or 2, 8/4 B -> 1)
+#define FQTK_MEMO_LAUNCH(V, RR, A)                                                                         \
+    do {                                                                                                   \
+        if constexpr ((V) <= 0 || ((V) == 3 && KW <= 2) || KW == ((V) == 4 ? 2 : 1))                       \
+            hipLaunchKernelGGL((fqtk::memo_kernel<V, KW, RR, A>), dim3(grid), dim3(fqtk::kBlock), shmem,   \
+                               stream, Q);                                                                 \
+        else                                                                                               \
+            return fail(FQTK_EINVAL, "memo: load width and key width disagree");                           \
+    } while (0)
 #define FQTK_MEMO_BY_VEC(RR, A)                         \
     switch (vec) {                                      \
         case 4: FQTK_MEMO_LAUNCH(4, RR, A); break;      \
@@ -209,9 +215,15 @@ int launch_memo_vec(const fqtk_matcher *m, const fqtk::MemoParams &Q, hipStream_
         HIP_TRY(hipGetLastError());
         return FQTK_OK;
     }
-    if (R == 4) { FQTK_MEMO_BY_VEC(4, 0) HIP_TRY(hipGetLastError()); return FQTK_OK; }
 #endif
-    if (R == 2) { FQTK_MEMO_BY_VEC(2, 0) } else { FQTK_MEMO_BY_VEC(1, 0) }
+    if (R == 4 && vec > 0) {
+        switch (vec) {
+            case 4: FQTK_MEMO_LAUNCH(4, 4, 0); break;
+            case 3: FQTK_MEMO_LAUNCH(3, 4, 0); break;
+            case 2: FQTK_MEMO_LAUNCH(2, 4, 0); break;
+            default: FQTK_MEMO_LAUNCH(1, 4, 0); break;
+        }
+    } else if (R >= 2) { FQTK_MEMO_BY_VEC(2, 0) } else { FQTK_MEMO_BY_VEC(1, 0) }
 #undef FQTK_MEMO_BY_VEC
 #undef FQTK_MEMO_LAUNCH
     HIP_TRY(hipGetLastError());
@@ -224,11 +236,14 @@ int launch(const fqtk_matcher *m, const fqtk::MatchParams &P, hipStream_t stream
         fqtk::MemoParams Q;
         Q.m = P;
         Q.slots = m->d_memo;
-        Q.code_lut = m->d_code_lut;
         Q.mask = m->memo_mask;
         Q.hot = m->d_hot;
         Q.hot_mask = m->hot_mask;
-        return m->memo_key64 ? launch_memo_vec<true>(m, Q, stream) : launch_memo_vec<false>(m, Q, stream);
+        switch (m->memo_kw) {
+            case 1: return launch_memo_vec<1>(m, Q, stream);
+            case 2: return launch_memo_vec<2>(m, Q, stream);
+            default: return launch_memo_vec<3>(m, Q, stream);
+        }
     }
     switch (m->NW) {
         case 1: return launch_vec<1, 4>(P, m->num_cus, stream);
@@ -323,11 +338,19 @@ void enumerate_candidates(const uint8_t *e, uint32_t L, uint32_t budget, uint32_
     }
 }
 
-void memo_key_of(const char *q, uint32_t L, uint32_t &lo, uint32_t &hi) {
-    lo = hi = 0;
+// 4 bits per base, base k in nibble k of {lo, hi, ext}: the same key memo_kernel's encode_nibbles builds
+void memo_key_of(const char *q, uint32_t L, uint32_t &lo, uint32_t &hi, uint32_t &ext) {
+    lo = hi = ext = 0;
     for (uint32_t k = 0; k < L; ++k) {
-        uint32_t c = q[k] == 'A' ? 0u : q[k] == 'C' ? 1u : q[k] == 'G' ? 2u : q[k] == 'T' ? 3u : 4u;
-        if (k < 10) lo |= c << (3 * k); else hi |= c << (3 * (k - 10));
+        const uint32_t c = fqtk::memo_code_of(q[k]);
+        if (k < 8) lo |= c << (4 * k);
+        else if (k < 16) hi |= c << (4 * (k - 8));
+        else ext |= c << (4 * (k - 16));
+    }
+    if (fqtk::memo_key_words(L) == 1 && L > 8) {   // bases 8-9 ride in lo's spare bits (kFoldMul)
+        const uint32_t x = (hi & 7u) | (((hi >> 4) & 7u) << 8);
+        lo |= (x * fqtk::kFoldMul) & fqtk::kFoldMask;
+        hi = 0;
     }
 }
 
@@ -351,24 +374,25 @@ int build_memo(fqtk_matcher *m, const std::vector<std::vector<uint8_t>> &enc) {
     }
     uint64_t n_some = 0;
     for (uint64_t i = 0; i < nc; ++i) n_some += res[i].idx != FQTK_NO_MATCH;
-    m->memo_key64 = m->L > 10;
-    const size_t wps = m->memo_key64 ? 4 : 2;   // words per slot
+    m->memo_kw = fqtk::memo_key_words(m->L);
+    const bool wide = m->memo_kw >= 2;
+    const size_t wps = wide ? 4 : 2;   // words per slot
     // distinct Some entries (a string can neighbour several samples)
-    struct Entry { uint32_t lo, hi, val; };
+    struct Entry { uint32_t lo, hi, ext, val; };
     std::vector<Entry> ents;
     ents.reserve(n_some);
     for (uint64_t i = 0; i < nc; ++i) {
         if (res[i].idx == FQTK_NO_MATCH) continue;
         Entry e;
-        memo_key_of(cand.data() + i * m->L, m->L, e.lo, e.hi);
+        memo_key_of(cand.data() + i * m->L, m->L, e.lo, e.hi, e.ext);
         std::memcpy(&e.val, &res[i], 4);
         ents.push_back(e);
     }
     std::sort(ents.begin(), ents.end(), [](const Entry &a, const Entry &b) {
-        return a.hi != b.hi ? a.hi < b.hi : a.lo < b.lo;
+        return a.ext != b.ext ? a.ext < b.ext : (a.hi != b.hi ? a.hi < b.hi : a.lo < b.lo);
     });
     ents.erase(std::unique(ents.begin(), ents.end(),
-                           [](const Entry &a, const Entry &b) { return a.lo == b.lo && a.hi == b.hi; }),
+                           [](const Entry &a, const Entry &b) { return a.lo == b.lo && a.hi == b.hi && a.ext == b.ext; }),
                ents.end());
     // two-choice (cuckoo) placement with random-walk eviction; grow on the (unlikely) failure
     uint64_t nslots = 1024;
@@ -385,13 +409,13 @@ int build_memo(fqtk_matcher *m, const std::vector<std::vector<uint8_t>> &enc) {
         for (size_t i = 0; i < ents.size() && ok; ++i) {
             int64_t cur = (int64_t)i;
             uint32_t a1, a2;
-            fqtk::memo_hash2(ents[cur].lo, m->memo_key64 ? ents[cur].hi : 0u, mask, a1, a2);
+            fqtk::memo_hash2(ents[cur].lo, ents[cur].hi, ents[cur].ext, mask, a1, a2);
             uint32_t pos = owner[a1] < 0 ? a1 : a2;
             for (int kick = 0;; ++kick) {
                 if (owner[pos] < 0) { owner[pos] = cur; break; }
                 if (kick == 1000) { ok = false; break; }
                 std::swap(cur, owner[pos]);   // evict the occupant, re-home it
-                fqtk::memo_hash2(ents[cur].lo, m->memo_key64 ? ents[cur].hi : 0u, mask, a1, a2);
+                fqtk::memo_hash2(ents[cur].lo, ents[cur].hi, ents[cur].ext, mask, a1, a2);
                 rng = rng * 6364136223846793005ull + 1442695040888963407ull;
                 pos = (a1 == pos) ? a2 : ((a2 == pos) ? a1 : ((rng >> 33) & 1 ? a1 : a2));
                 if (a1 == a2 && owner[pos] >= 0 && kick > 8) { ok = false; break; }
@@ -405,7 +429,7 @@ int build_memo(fqtk_matcher *m, const std::vector<std::vector<uint8_t>> &enc) {
             for (uint64_t p = 0; p < nslots; ++p) {
                 if (owner[p] < 0) continue;
                 uint32_t a1, a2;
-                fqtk::memo_hash2(ents[owner[p]].lo, m->memo_key64 ? ents[owner[p]].hi : 0u, mask, a1, a2);
+                fqtk::memo_hash2(ents[owner[p]].lo, ents[owner[p]].hi, ents[owner[p]].ext, mask, a1, a2);
                 if (a1 != p && owner[a1] < 0) { owner[a1] = owner[p]; owner[p] = -1; moved = true; }
             }
         }
@@ -414,16 +438,17 @@ int build_memo(fqtk_matcher *m, const std::vector<std::vector<uint8_t>> &enc) {
         for (uint64_t p = 0; p < nslots; ++p) {
             if (owner[p] < 0) continue;
             uint32_t a1, a2;
-            fqtk::memo_hash2(ents[owner[p]].lo, m->memo_key64 ? ents[owner[p]].hi : 0u, mask, a1, a2);
+            fqtk::memo_hash2(ents[owner[p]].lo, ents[owner[p]].hi, ents[owner[p]].ext, mask, a1, a2);
             if (a1 != p) { spill[a1] = 1; ++n_second; }
         }
         m->memo_second_slot = n_second;
         for (uint64_t p = 0; p < nslots; ++p) {
             uint32_t *w = &slots[p * wps];
-            if (m->memo_key64) w[3] = spill[p]; else w[0] = 0x7FFFFFFFu | ((uint32_t)spill[p] << 31);
+            if (wide) w[3] = spill[p]; else w[0] = 0x7FFFFFFFu | ((uint32_t)spill[p] << 31);
             if (owner[p] < 0) continue;
             const Entry &e = ents[owner[p]];
-            if (m->memo_key64) { w[0] = e.lo; w[1] = e.hi; w[2] = e.val; } else { w[0] = e.lo | ((uint32_t)spill[p] << 31); w[1] = e.val; }
+            if (wide) { w[0] = e.lo; w[1] = e.hi; w[2] = e.val; w[3] = spill[p] | (e.ext << 16); }
+            else { w[0] = e.lo | ((uint32_t)spill[p] << 31); w[1] = e.val; }
         }
         break;
     }
@@ -431,7 +456,7 @@ int build_memo(fqtk_matcher *m, const std::vector<std::vector<uint8_t>> &enc) {
     // hot table for LDS: 0-mismatch entries, two-choice without eviction (it is only a cache: an
     // entry that finds both of its slots taken is simply served by the global table)
     {
-        const uint32_t slot_bytes = m->memo_key64 ? 16 : 8;
+        const uint32_t slot_bytes = wide ? 16 : 8;
         uint32_t hot_slots = fqtk::kHotBytes / slot_bytes;
         uint64_t n_hot = 0;
         for (const Entry &e : ents) n_hot += ((e.val >> 16) & 0xFFu) == 0;
@@ -446,13 +471,13 @@ int build_memo(fqtk_matcher *m, const std::vector<std::vector<uint8_t>> &enc) {
             });
             for (const Entry &e : order) {
                 uint32_t a1, a2;
-                fqtk::memo_hash2(e.lo, m->memo_key64 ? e.hi : 0u, mask, a1, a2);
+                fqtk::memo_hash2(e.lo, e.hi, e.ext, mask, a1, a2);
                 for (uint32_t a : {a1 & hmask, a2 & hmask}) {
                     uint32_t *w = &hot[(size_t)a * wps];
-                    const uint32_t v = m->memo_key64 ? w[2] : w[1];
+                    const uint32_t v = wide ? w[2] : w[1];
                     if (v != fqtk::kMemoEmpty) continue;
                     w[0] = e.lo;
-                    if (m->memo_key64) { w[1] = e.hi; w[2] = e.val; w[3] = 0; } else { w[1] = e.val; }
+                    if (wide) { w[1] = e.hi; w[2] = e.val; w[3] = e.ext << 16; } else { w[1] = e.val; }
                     break;
                 }
             }
@@ -461,16 +486,6 @@ int build_memo(fqtk_matcher *m, const std::vector<std::vector<uint8_t>> &enc) {
             m->hot_mask = hmask;
         }
     }
-    std::vector<uint32_t> code(64, 0x08080808u);
-    auto set_code = [&](char ch, uint32_t c) {
-        uint8_t *b = reinterpret_cast<uint8_t *>(code.data());
-        b[(uint8_t)ch] = (uint8_t)c;
-    };
-    set_code('A', 0); set_code('a', 0); set_code('C', 1); set_code('c', 1); set_code('G', 2); set_code('g', 2);
-    set_code('T', 3); set_code('t', 3); set_code('U', 3); set_code('u', 3);
-    set_code('N', 4); set_code('n', 4); set_code('.', 4);
-    HIP_TRY(hipMalloc(reinterpret_cast<void **>(&m->d_code_lut), 64 * sizeof(uint32_t)));
-    HIP_TRY(hipMemcpy(m->d_code_lut, code.data(), 64 * sizeof(uint32_t), hipMemcpyHostToDevice));
     void *d = nullptr;
     HIP_TRY(hipMalloc(&d, slots.size() * sizeof(uint32_t)));
     HIP_TRY(hipMemcpy(d, slots.data(), slots.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
@@ -616,7 +631,6 @@ void fqtk_matcher_destroy(fqtk_matcher *m) {
     }
     if (m->d_memo) (void)hipFree(m->d_memo);
     if (m->d_hot) (void)hipFree(m->d_hot);
-    if (m->d_code_lut) (void)hipFree(m->d_code_lut);
     if (m->d_table) (void)hipFree(m->d_table);
     if (m->d_lut) (void)hipFree(m->d_lut);
     if (m->d_err) (void)hipFree(m->d_err);

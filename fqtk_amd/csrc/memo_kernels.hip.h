@@ -9,7 +9,8 @@
 //     the host enumerates EVERY canonical string within max_mismatches of some sample, runs the
 //     exhaustive-scan kernel (match_kernels.hip.h) on them, and stores the ones whose result is
 //     Some(idx,best,next) in a two-choice (cuckoo) hash table in HBM (L2/MALL resident, <= a few MB);
-//   * per read the kernel packs the barcode to a 3-bit-per-base key (LDS byte LUT), hashes, probes:
+//   * per read the kernel packs the barcode to a 4-bit-per-base key (SWAR on the packed ASCII words:
+//     code = bits 1..2 of the byte, N = 7; validated with one v_perm_b32 per word), hashes, probes:
 //       hit  -> the stored (idx,best,next) -- computed by the scan kernel, so bit-identical to it;
 //       miss -> the read is canonical and NOT within max_mismatches of any sample, therefore
 //               best > max_mismatches and the reference returns None (barcode_matching.rs:150-153);
@@ -18,31 +19,49 @@
 //     v_readlane, the 64 lanes stripe the samples, and a wavefront min / second-min butterfly
 //     (DPP / ds_bpermute via __shfl_xor) folds the packed keys.  Same arithmetic as the scan kernel.
 //
-// Per read this is ~L byte-LUT lookups + one or two 8/16-byte probes instead of S x 8 VALU ops, which
-// moves the kernel from VALU-bound (~3 % of HBM peak at S=384) towards the HBM roofline.
+// Per read this is ~7 VALU ops per 4 bases + one or two 8/16-byte probes instead of S x 8 VALU ops,
+// which moves the kernel from VALU-bound (~3 % of HBM peak at S=384) towards the HBM roofline.
 #pragma once
 #include "match_kernels.hip.h"
 
 namespace fqtk {
 
-constexpr uint32_t kMemoMaxLen = 20;       // 3 bits/base, 10 bases per 32-bit half
+constexpr uint32_t kMemoMaxLen = 20;       // 4 bits/base: lo = bases 0-7, hi = 8-15, ext = 16-19
 constexpr uint32_t kMemoEmpty = 0xFFFFFFFFu;
 
 constexpr uint32_t kHotBytes = 16384;      // LDS budget of the hot table per workgroup
 
+// Key words: 1 (L <= 10: bases 8-9 are folded into the spare top bits of lo's nibbles, see kFoldMul),
+// 2 (L <= 16), 3 (L <= 20).
+__host__ __device__ constexpr int memo_key_words(uint32_t L) { return L <= 10 ? 1 : (L <= 16 ? 2 : 3); }
+// Fold of the third word's codes x = code8 | code9 << 8 into bits {3,7,19} / {11,15,27} of lo: the three
+// shifted copies of x (<< 3, << 6, << 17) have disjoint supports, so one 24-bit multiply and one AND
+// deposit the six bits with no carries; bit 31 stays free for the slot's SPILL flag.
+constexpr uint32_t kFoldMul = (1u << 3) | (1u << 6) | (1u << 17);
+constexpr uint32_t kFoldMask = 0x08088888u;
+
 struct MemoParams {
     MatchParams m;
-    const void *slots;        // KEY64: uint4 {lo, hi, val, spill}; else uint2 {lo | spill << 31, val}
-    const uint32_t *code_lut; // [64] dwords = 256 bytes: A0 C1 G2 T3 N4, anything else 8
+    const void *slots;        // KW=1: uint2 {lo | spill << 31, val}; KW>=2: uint4 {lo, hi, val, spill | ext << 16}
     const uint32_t *hot;      // hot subset (exact matches) in the same slot format, copied to LDS
     uint32_t mask;            // n_slots - 1
     uint32_t hot_mask;        // hot slots - 1 (0 = no hot table)
 };
 
+// The canonical code of a base is bits 1..2 of its ASCII byte -- A 0x41 -> 0, C 0x43 -> 1, T 0x54 -> 2,
+// G 0x47 -> 3 -- and N 0x4E -> 7 with bit 3 included; lower case gives the same codes.  kCodePool maps a
+// code back to the upper-case byte it must have come from (0xFF = no such base), which is how the
+// kernel proves a byte canonical: ((byte ^ pool[code]) & 0xDF) == 0.
+constexpr uint32_t kCodePoolLo = 0x47544341u;   // codes 0..3: 'A' 'C' 'T' 'G'
+constexpr uint32_t kCodePoolHi = 0x4EFFFFFFu;   // codes 4..6: none, 7: 'N'
+__host__ inline uint32_t memo_code_of(char ch) {   // host mirror (the builder only sees A C G T N)
+    return ((uint32_t)(uint8_t)ch >> 1) & 7u;
+}
+
 // Two-choice (cuckoo) placement: a key lives in slot h1 or slot h2, nowhere else, so a lookup is two
 // INDEPENDENT loads issued back to back -- no probe loop, no divergence, one memory round trip.
 // 24-bit multiplies only: v_mul_u32_u24 / v_mad_u32_u24 issue at the full VALU rate on gfx950, while
-// v_mul_lo_u32 is quarter rate.  The 60-bit key is cut into three <=24-bit limbs.
+// v_mul_lo_u32 is quarter rate.  The 80-bit key is cut into four <=24-bit limbs.
 __host__ __device__ inline uint32_t mul24(uint32_t a, uint32_t b) {
 #if defined(__HIP_DEVICE_COMPILE__)
     return __umul24(a, b);
@@ -50,12 +69,13 @@ __host__ __device__ inline uint32_t mul24(uint32_t a, uint32_t b) {
     return (a & 0xFFFFFFu) * (b & 0xFFFFFFu);
 #endif
 }
-__host__ __device__ inline void memo_hash2(uint32_t lo, uint32_t hi, uint32_t mask, uint32_t &s1,
-                                           uint32_t &s2) {
-    const uint32_t a = lo;                       // mul24 reads bits 0..23: bases 0-7
-    const uint32_t b = (lo >> 24) | (hi << 6);   // bases 8-9 and 10-15
-    const uint32_t c = hi >> 18;                 // bases 16-19
-    uint32_t h = mul24(a, 0x9E3779u) + mul24(b, 0x85EBCBu) + mul24(c, 0xC2B2AFu);
+__host__ __device__ inline void memo_hash2(uint32_t lo, uint32_t hi, uint32_t ext, uint32_t mask,
+                                           uint32_t &s1, uint32_t &s2) {
+    const uint32_t a = lo;                         // mul24 reads bits 0..23: bases 0-5
+    const uint32_t b = (lo >> 24) | (hi << 8);     // bases 6-7 and 8-11
+    const uint32_t c = (hi >> 16) | (ext << 16);   // bases 12-15 and 16-17
+    const uint32_t d = ext >> 8;                   // bases 18-19
+    uint32_t h = mul24(a, 0x9E3779u) + mul24(b, 0x85EBCBu) + mul24(c, 0xC2B2AFu) + mul24(d, 0xA54FF5u);
     h ^= h >> 15;
     h = mul24(h, 0x2C1B3Du) + (h >> 9);
     h ^= h >> 13;
@@ -65,34 +85,41 @@ __host__ __device__ inline void memo_hash2(uint32_t lo, uint32_t hi, uint32_t ma
     s2 = g & mask;
 }
 
-// acc | (v << SH) as one v_lshl_or_b32 (the optimiser otherwise builds a shift + v_or3 tree)
-template <int SH>
-__device__ __forceinline__ uint32_t lshl_or_imm(uint32_t v, uint32_t acc) {
-    uint32_t d;
-    asm("v_lshl_or_b32 %0, %1, %2, %3" : "=v"(d) : "v"(v), "n"(SH), "v"(acc));
-    return d;
-}
-
-// Compile-time unrolled ASCII -> 3-bit-code packing, two bases per step: byte extract (1 VALU each),
-// LDS byte LUT (address = byte value), one v_or3 for the non-canonical flag, one v_lshl_or per base.
-template <int K, int NB, int ABL>
-__device__ __forceinline__ void encode_codes(const uint32_t (&words)[8], const uint8_t *lds_code, uint32_t &l,
-                                             uint32_t &h, uint32_t &b) {
-    if constexpr (K < NB) {
-        uint32_t c[2];
+// ASCII -> 4-bit codes, SWAR on the packed words (no LDS, no per-base work).  Per 4-base word:
+//   c   = (w >> 1) & 0x07070707          the four codes, one per byte            (2 VALU)
+//   e   = v_perm_b32(pool, c)            the bytes those codes stand for         (1)
+//   bad |= (w ^ e) & 0xDFDFDFDF          any other byte (IUPAC, '.', junk) flags (2)
+//   t   = c | (c >> 4)                   two codes per byte in bytes 0 and 2     (2)
+// and one v_perm_b32 per PAIR of words gathers bytes {0,2} of both into a key word.  kc / kv are the
+// two masks above cut down to the real bases of a word (pad positions encode as 'A' = 0 = absent);
+// FULL says all words but the last are complete, so only the last one needs its masks from SGPRs.
+template <int NWD, bool FULL, bool FOLD>
+__device__ __forceinline__ void encode_nibbles(const uint32_t (&words)[8], const uint32_t (&kc)[NWD],
+                                               const uint32_t (&kv)[NWD], uint32_t &lo, uint32_t &hi,
+                                               uint32_t &ext, uint32_t &bad) {
+    static_assert(!FOLD || NWD == 3, "the fold is for the 9-10 base keys only");
+    uint32_t t[6] = {0, 0, 0, 0, 0, 0};
+    uint32_t c2 = 0;
+    bad = 0;
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {
-            const uint32_t wv = words[(K + u) >> 2];
-            constexpr int by0 = K & 3;
-            const int by = by0 + u;
-            const uint32_t byte = by == 0 ? (wv & 0xFFu) : (by == 3 ? (wv >> 24) : __builtin_amdgcn_ubfe(wv, 8 * by, 8));
-            c[u] = (ABL & 2) ? (byte & 3u) : lds_code[byte];
-        }
-        b = b | c[0] | c[1];
-        if constexpr (K < 10) l = lshl_or_imm<3 * K>(c[0], l); else h = lshl_or_imm<3 * (K - 10)>(c[0], h);
-        if constexpr (K + 1 < 10) l = lshl_or_imm<3 * (K + 1)>(c[1], l); else h = lshl_or_imm<3 * (K + 1 - 10)>(c[1], h);
-        encode_codes<K + 2, NB, ABL>(words, lds_code, l, h, b);
+    for (int w = 0; w < NWD; ++w) {
+        const bool full = FULL && w < NWD - 1;
+        const uint32_t c = (words[w] >> 1) & (full ? 0x07070707u : kc[w]);
+        const uint32_t e = __builtin_amdgcn_perm(kCodePoolHi, kCodePoolLo, c);
+        bad |= (words[w] ^ e) & (full ? 0xDFDFDFDFu : kv[w]);
+        t[w] = c | (c >> 4);
+        if (w == 2) c2 = c;
     }
+    if constexpr (FOLD) {   // L <= 10: kc[2] leaves only codes 8 and 9 in c2
+        lo = __builtin_amdgcn_perm(t[1], t[0], 0x06040200u) | (mul24(c2, kFoldMul) & kFoldMask);
+        hi = ext = 0;
+        return;
+    }
+    // selector: byte0 <- lo.b0, byte1 <- lo.b2, byte2 <- hi.b0, byte3 <- hi.b2 (0x0c = constant 0)
+    lo = NWD >= 2 ? __builtin_amdgcn_perm(t[1], t[0], 0x06040200u) : __builtin_amdgcn_perm(0u, t[0], 0x0C0C0200u);
+    hi = NWD >= 4 ? __builtin_amdgcn_perm(t[3], t[2], 0x06040200u)
+                  : (NWD == 3 ? __builtin_amdgcn_perm(0u, t[2], 0x0C0C0200u) : 0u);
+    ext = NWD >= 5 ? __builtin_amdgcn_perm(0u, t[4], 0x0C0C0200u) : 0u;
 }
 
 // (best, second) packed keys -> result word (barcode_matching.rs:150-159).
@@ -137,31 +164,26 @@ __device__ __forceinline__ void wave_scan(const Planes<NW> &mine, int src, const
 }
 
 // ABL: developer-only ablation mask (tools/ablate.sh builds with -DFQTK_DEV_ABLATE); 0 in the product.
-//   1 = skip table probes, 2 = skip LDS code lookups, 4 = skip histogram, 8 = skip result store,
-//   16 = skip the LDS hot table
+//   1 = skip table probes, 2 = skip the canonical-byte validation, 4 = skip histogram,
+//   8 = skip result store, 16 = skip the LDS hot table
 #ifndef FQTK_MEMO_WAVES
 #define FQTK_MEMO_WAVES 8
 #endif
-template <int VEC, bool KEY64, int R, int ABL>
+template <int VEC, int KW, int R, int ABL>
 __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(FQTK_MEMO_WAVES, 8)))
 void memo_kernel(const MemoParams Q) {
     const MatchParams &P = Q.m;
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
-    // the byte-code LUT is a STATIC LDS object (compile-time address 0): a base's byte value is its
-    // LDS address, so the 16 lookups per read need no address arithmetic at all
-    __shared__ uint32_t s_code[64];                                      // 256 x u8 code LUT
-    const uint8_t *lds_code = reinterpret_cast<const uint8_t *>(s_code);
     uint32_t *lds_lut = smem;                                            // 256 x u32 spread LUT (fallback)
     // hot table: the memo entries with 0 mismatches (a read that IS a sample barcode -- the bulk of
     // real data) live in LDS, so most lanes never touch the global table; the rest probe it with
     // the hit lanes masked off, which shrinks the gather traffic by the hit rate.
-    const uint32_t hot_words = Q.hot_mask ? (Q.hot_mask + 1) * (KEY64 ? 4u : 2u) : 0u;
+    const uint32_t hot_words = Q.hot_mask ? (Q.hot_mask + 1) * (KW >= 2 ? 4u : 2u) : 0u;
     uint32_t *lds_hot = smem + 256;
     uint32_t *lds_hist = lds_hot + hot_words;
 
     const uint32_t tid = threadIdx.x;
     lds_lut[tid] = P.lut[tid];
-    if (tid < 64) s_code[tid] = Q.code_lut[tid];
     for (uint32_t w = tid; w < hot_words; w += kBlock) lds_hot[w] = Q.hot[w];
     const uint32_t bins = P.S + 1;
     if (P.counts && P.lds_hist)
@@ -170,21 +192,25 @@ void memo_kernel(const MemoParams Q) {
 
     const uint32_t L = P.L;
     const uint32_t nwords = (L + 3u) >> 2;
-    // bases encoded per read: exactly the packed stride on the vector paths, the 20-base maximum else
-    constexpr int NB = VEC >= 1 ? VEC * 4 : (int)kMemoMaxLen;
-    uint32_t keep[NB / 4];   // byte masks of the real bases (< L) in each word; wave-uniform
+    // words encoded per read: exactly the packed stride on the vector paths, the key's capacity else
+    constexpr int NWD = VEC >= 1 ? VEC : (KW == 1 ? 3 : (KW == 2 ? 4 : 5));
+    constexpr bool FOLD = KW == 1 && NWD == 3;
+    static_assert(NWD <= 2 * KW || FOLD, "key too narrow for the load width");
+    uint32_t kc[NWD], kv[NWD];   // code / validation masks of the real bases (< L) per word; wave-uniform
 #pragma unroll
-    for (int w = 0; w < NB / 4; ++w) {
+    for (int w = 0; w < NWD; ++w) {
         const int rem = (int)L - 4 * w;
-        keep[w] = rem >= 4 ? 0xFFFFFFFFu : (rem <= 0 ? 0u : ((1u << (8 * rem)) - 1u));
+        const uint32_t keep = rem >= 4 ? 0xFFFFFFFFu : (rem <= 0 ? 0u : ((1u << (8 * rem)) - 1u));
+        kc[w] = keep & 0x07070707u;
+        kv[w] = (ABL & 2) ? 0u : (keep & 0xDFDFDFDFu);
     }
     const uint64_t tile = (uint64_t)kBlock * R;
     const uint64_t ntiles = (P.n + tile - 1) / tile;
 
     for (uint64_t t = blockIdx.x; t < ntiles; t += gridDim.x) {
         uint32_t words[R][8];
-        uint32_t lo[R], hi[R], bad[R], res[R];
-        bool live[R];
+        uint32_t lo[R], hi[R], ext[R], res[R];
+        bool live[R], bad[R];
 #pragma unroll
         for (int r = 0; r < R; ++r) {
             const uint64_t i = t * tile + (uint64_t)r * kBlock + tid;
@@ -193,23 +219,19 @@ void memo_kernel(const MemoParams Q) {
             for (int w = 0; w < 8; ++w) words[r][w] = 0x41414141u;   // dead lanes look like "AAAA"
             if (live[r]) load_words<1, VEC>(P, i, nwords, words[r]);
         }
-        // ---- ASCII -> 3-bit codes, 10 bases per 32-bit half; bit 3 of any code = non-canonical ----
-        // Straight-line on purpose: NB is a compile-time constant and pad positions (>= L) are forced
-        // to 'A' (= code 0 = "absent" in the key), so all NB LUT reads are in flight together instead
-        // of one LDS round trip per base behind a wave-uniform `k < L` branch.
+        // ---- ASCII -> 4-bit codes (SWAR, see encode_nibbles); `bad` = some base is not A C G T N ----
 #pragma unroll
         for (int r = 0; r < R; ++r) {
-#pragma unroll
-            for (int w = 0; w < NB / 4; ++w) words[r][w] = (words[r][w] & keep[w]) | (0x41414141u & ~keep[w]);
-            uint32_t l = 0, h = 0, b = 0;
-            encode_codes<0, NB, ABL>(words[r], lds_code, l, h, b);
-            lo[r] = l; hi[r] = h; bad[r] = (b & 8u) && live[r];
+            uint32_t b;
+            encode_nibbles<NWD, (VEC >= 1 && !(ABL & 2)), FOLD>(words[r], kc, kv, lo[r], hi[r], ext[r], b);
+            bad[r] = b != 0 && live[r];
         }
-        // ---- probe: both candidate slots of every read are loaded up front (2*R independent
-        //      gathers in flight), then compared.  Empty slots carry key = ~0 and val = None. -------
+        // ---- probe: both candidate slots of every read are known up front.  Empty slots carry
+        //      key = ~0 (no real key has a nibble's top bit set) and val = None. ---------------------
         uint32_t s1[R], s2[R];
 #pragma unroll
-        for (int r = 0; r < R; ++r) memo_hash2(lo[r], KEY64 ? hi[r] : 0u, Q.mask, s1[r], s2[r]);
+        for (int r = 0; r < R; ++r)
+            memo_hash2(lo[r], KW >= 2 ? hi[r] : 0u, KW >= 3 ? ext[r] : 0u, Q.mask, s1[r], s2[r]);
         bool hit[R];
 #pragma unroll
         for (int r = 0; r < R; ++r) { hit[r] = false; res[r] = kMemoEmpty; }
@@ -217,11 +239,11 @@ void memo_kernel(const MemoParams Q) {
 #pragma unroll
             for (int r = 0; r < R; ++r) {
                 const uint32_t a1 = s1[r] & Q.hot_mask, a2 = s2[r] & Q.hot_mask;
-                if constexpr (KEY64) {
+                if constexpr (KW >= 2) {
                     const uint4 h1 = reinterpret_cast<const uint4 *>(lds_hot)[a1];
                     const uint4 h2 = reinterpret_cast<const uint4 *>(lds_hot)[a2];
-                    const bool m1 = h1.x == lo[r] && h1.y == hi[r];
-                    const bool m2 = h2.x == lo[r] && h2.y == hi[r];
+                    const bool m1 = h1.x == lo[r] && h1.y == hi[r] && (KW < 3 || (h1.w >> 16) == ext[r]);
+                    const bool m2 = h2.x == lo[r] && h2.y == hi[r] && (KW < 3 || (h2.w >> 16) == ext[r]);
                     hit[r] = m1 || m2;
                     res[r] = m1 ? h1.z : (m2 ? h2.z : kMemoEmpty);
                 } else {
@@ -246,9 +268,9 @@ void memo_kernel(const MemoParams Q) {
             for (int r = 0; r < R; ++r) {
                 again[r] = false;
                 if (!hit[r] && !bad[r]) {
-                    if constexpr (KEY64) {
+                    if constexpr (KW >= 2) {
                         const uint4 e = reinterpret_cast<const uint4 *>(Q.slots)[s1[r]];
-                        if (e.x == lo[r] && e.y == hi[r]) res[r] = e.z;
+                        if (e.x == lo[r] && e.y == hi[r] && (KW < 3 || (e.w >> 16) == ext[r])) res[r] = e.z;
                         else again[r] = (e.w & 1u) != 0;
                     } else {
                         const uint2 e = reinterpret_cast<const uint2 *>(Q.slots)[s1[r]];
@@ -260,9 +282,9 @@ void memo_kernel(const MemoParams Q) {
 #pragma unroll
             for (int r = 0; r < R; ++r) {
                 if (again[r]) {
-                    if constexpr (KEY64) {
+                    if constexpr (KW >= 2) {
                         const uint4 e = reinterpret_cast<const uint4 *>(Q.slots)[s2[r]];
-                        if (e.x == lo[r] && e.y == hi[r]) res[r] = e.z;
+                        if (e.x == lo[r] && e.y == hi[r] && (KW < 3 || (e.w >> 16) == ext[r])) res[r] = e.z;
                     } else {
                         const uint2 e = reinterpret_cast<const uint2 *>(Q.slots)[s2[r]];
                         if ((e.x & 0x7FFFFFFFu) == lo[r]) res[r] = e.y;

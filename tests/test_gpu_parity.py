@@ -230,7 +230,7 @@ def test_many_samples_lds_and_global_histogram_paths():
 
 
 def test_longest_memo_key_and_longer_barcodes():
-    """L = 20 is the longest barcode the memo covers (two 30-bit key halves); L = 21..128 are scan-only."""
+    """L = 20 is the longest barcode the memo covers (80-bit key: lo, hi, ext); L = 21..128 are scan-only."""
     rng = np.random.default_rng(12)
     acgt = np.frombuffer(b"ACGTN", dtype=np.uint8)
     for L in (19, 20, 21, 31, 32, 33, 96, 128):
@@ -244,6 +244,54 @@ def test_longest_memo_key_and_longer_barcodes():
         obs[flip] = acgt[rng.integers(0, 5, size=int(flip.sum()))]
         _compare(bcs, 1, 1, obs)
         _compare(bcs, 2, 1, obs[:500])
+
+
+@pytest.mark.parametrize("L", range(1, 22))
+def test_every_memo_key_width_and_load_path(L):
+    """Every barcode length the memo covers (and one it does not), on every load path: the packed
+    stride (vector loads for L <= 16), a dword-padded stride and an odd stride.  L <= 8 is one key word,
+    9-10 the folded single word, 11-16 two words, 17-20 three; reads include lower case, N, '.', U and
+    IUPAC/junk bytes (the wave-cooperative fallback) and pad bytes that must be ignored."""
+    rng = np.random.default_rng(500 + L)
+    S = min(48, 4 ** L // 2) or 1
+    seen = set()
+    while len(seen) < S:
+        seen.add("".join(rng.choice(list("ACGT"), size=L)))
+    bcs = sorted(seen)
+    m = BarcodeMatcher(bcs, 1, 1)
+    assert (m.memo_entries > 0) == (L <= 20)
+    n = 4099
+    noise = np.frombuffer(b"ACGTNacgtn.URY#", dtype=np.uint8)
+    for stride in sorted({(L + 3) // 4 * 4, (L + 3) // 4 * 4 + 4, L | 1, L + 2}):
+        if stride < L:
+            continue
+        obs = noise[rng.integers(0, len(noise), size=(n, stride))]
+        src = rng.integers(0, S, size=n)
+        bc = np.stack([np.frombuffer(b.encode(), dtype=np.uint8) for b in bcs])[src]
+        keep = rng.random((n, L)) < 0.93
+        obs[:, :L] = np.where(keep, bc, obs[:, :L])
+        lower = rng.random(n) < 0.1
+        obs[lower, :L] |= np.where(obs[lower, :L] >= 0x41, 0x20, 0).astype(np.uint8)   # lower case encodes the same
+        _compare(bcs, 1, 1, obs)
+        _compare(bcs, 2, 0, obs[:700])
+
+
+def test_memo_keys_do_not_alias_near_identical_reads():
+    """Reads that differ from a sample in exactly one base at every position and to every other
+    canonical base (and N): each must resolve to its own memo entry, for all four key layouts."""
+    for L in (8, 10, 16, 20):
+        bcs = ["ACGT" * 5, "TGCA" * 5, "GGGGGCCCCCAAAAATTTTT", "ATATATATATCGCGCGCGCG"]
+        bcs = [b[:L] for b in bcs]
+        rows = []
+        for b in bcs:
+            for k in range(L):
+                for ch in "ACGTN":
+                    rows.append(b[:k] + ch + b[k + 1:])
+                    for k2 in range(k + 1, L, 3):
+                        rows.append(b[:k] + ch + b[k + 1:k2] + "N" + b[k2 + 1:])
+        obs = np.frombuffer("".join(rows).encode(), dtype=np.uint8).reshape(-1, L)
+        for mm, delta in ((1, 1), (2, 1), (2, 2), (0, 1)):
+            _compare(bcs, mm, delta, obs)
 
 
 def test_device_entry_point_with_misaligned_and_padded_buffers():
