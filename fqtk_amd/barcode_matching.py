@@ -105,6 +105,17 @@ class BarcodeMatcher:
         """Entries of the precomputed complete memo (0 = exhaustive scan only)."""
         return int(self._lib.fqtk_matcher_memo_entries(self._h))
 
+    MEMO_NONE, MEMO_TABLE, MEMO_LDS = 0, 1, 2
+
+    @property
+    def memo_kind(self) -> int:
+        """Form of the memo the next batch uses: MEMO_NONE (scan), MEMO_TABLE (HBM/L2), MEMO_LDS (LDS-resident)."""
+        return int(self._lib.fqtk_matcher_memo_kind(self._h))
+
+    @memo_kind.setter
+    def memo_kind(self, kind: int) -> None:
+        _check(self._lib.fqtk_matcher_set_memo_kind(self._h, int(kind)))
+
     @property
     def handle(self) -> C.c_void_p:
         return self._h

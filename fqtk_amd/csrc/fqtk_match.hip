@@ -7,6 +7,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -16,7 +17,8 @@
 
 #include "../../include/fqtk_match.h"
 #include "match_kernels.hip.h"
-#include "memo_kernels.hip.h"
+#include "lds_memo_kernels.hip.h"
+#include "lds_memo_plan.hpp"
 
 namespace {
 
@@ -93,6 +95,13 @@ struct fqtk_matcher {
     uint64_t memo_entries = 0;
     uint64_t memo_candidates = 0;
     uint64_t memo_second_slot = 0;             // entries living in their second-choice slot
+    // LDS-resident compact memo (lds_memo_kernels.hip.h); present only when every entry is "sample idx
+    // with at most one base replaced" and the table fits one CU's LDS
+    uint32_t *d_ldsm = nullptr;
+    fqtk::LdsMemoParams ldsm{};                // image / masks / salt (m is filled per launch)
+    int ldsm_kw = 0;
+    int memo_kind_wanted = 0;                  // 0 = best available, 1 = force the HBM/L2 table (tests, A/B)
+    size_t ldsm_lds_bytes = 0;                 // image + LUT (histogram added at launch)
     int use_cache = 1;                       // BarcodeMatcher.use_cache (barcode_matching.rs:41-42)
     Slot slots[FQTK_MAX_SLOTS];
 };
@@ -177,10 +186,15 @@ int launch_memo_vec(const fqtk_matcher *m, const fqtk::MemoParams &Q, hipStream_
 #ifdef FQTK_DEV_ABLATE
     if (const char *rr = std::getenv("FQTK_MEMO_R")) R = std::atoi(rr);
     if (const char *ab = std::getenv("FQTK_MEMO_ABLATE")) abl = std::atoi(ab);
+    size_t lds_pad = 0;   // occupancy experiments: pad the workgroup's LDS so fewer fit on a CU
+    if (const char *lp = std::getenv("FQTK_MEMO_LDS_PAD")) lds_pad = (size_t)std::atol(lp);
 #endif
     size_t shmem = 256 * sizeof(uint32_t);
     if (Q.hot_mask) shmem += (size_t)(Q.hot_mask + 1) * (KW >= 2 ? 16 : 8);
     if (P.counts && P.lds_hist) shmem += (size_t)(P.S + 1) * sizeof(uint32_t);
+#ifdef FQTK_DEV_ABLATE
+    shmem += lds_pad;
+#endif
     const uint64_t tile = (uint64_t)fqtk::kBlock * R;
     const uint64_t ntiles = (P.n + tile - 1) / tile;
     if (ntiles == 0) return FQTK_OK;
@@ -205,10 +219,10 @@ int launch_memo_vec(const fqtk_matcher *m, const fqtk::MemoParams &Q, hipStream_
     }
 #ifdef FQTK_DEV_ABLATE
     if (abl > 0 && vec == 4) {
-        switch (abl * 10 + R) {
+        switch (abl * 10 + R) {   // NOLINT
 #define FQTK_AB(A, RR) case A * 10 + RR: FQTK_MEMO_LAUNCH(4, RR, A); break;
-            FQTK_AB(1, 1) FQTK_AB(3, 1) FQTK_AB(4, 1) FQTK_AB(7, 1) FQTK_AB(16, 1)
-            FQTK_AB(1, 2) FQTK_AB(3, 2) FQTK_AB(4, 2) FQTK_AB(7, 2) FQTK_AB(16, 2)
+            FQTK_AB(1, 1) FQTK_AB(2, 1) FQTK_AB(3, 1) FQTK_AB(4, 1) FQTK_AB(7, 1) FQTK_AB(16, 1) FQTK_AB(17, 1) FQTK_AB(19, 1) FQTK_AB(23, 1) FQTK_AB(32, 1) FQTK_AB(64, 1) FQTK_AB(128, 1)
+            FQTK_AB(1, 4) FQTK_AB(2, 4) FQTK_AB(3, 4) FQTK_AB(4, 4) FQTK_AB(7, 4) FQTK_AB(16, 4) FQTK_AB(17, 4) FQTK_AB(19, 4) FQTK_AB(23, 4) FQTK_AB(32, 4) FQTK_AB(64, 4) FQTK_AB(128, 4)
 #undef FQTK_AB
             default: return fail(FQTK_EINVAL, "ablation variant not built");
         }
@@ -230,8 +244,93 @@ int launch_memo_vec(const fqtk_matcher *m, const fqtk::MemoParams &Q, hipStream_
     return FQTK_OK;
 }
 
+template <int KW>
+int launch_lds_memo(const fqtk_matcher *m, fqtk::LdsMemoParams Q, hipStream_t stream) {
+    const fqtk::MatchParams &P = Q.m;
+    const uintptr_t base = reinterpret_cast<uintptr_t>(P.obs);
+    const uint32_t nwords = (P.L + 3) / 4;
+    int vec = 0;
+    if (P.stride % 4 == 0 && base % 4 == 0 && P.stride >= nwords * 4) {
+        const uint32_t sw = P.stride / 4;
+        vec = -1;
+        if (sw == nwords) {
+            if (sw == 4 && base % 16 == 0) vec = 4;
+            else if (sw == 2 && base % 8 == 0) vec = 2;
+            else if (sw == 1) vec = 1;
+            else if (sw == 3) vec = 3;
+        }
+    }
+    size_t shmem = m->ldsm_lds_bytes;
+    if (P.counts && P.lds_hist) shmem += (size_t)(P.S + 1) * sizeof(uint32_t);
+    if (shmem > fqtk::kLdsMemoMaxBytes) return fail(FQTK_EINVAL, "lds memo: table does not fit LDS");
+    int R = vec > 0 ? 4 : 1;
+#ifdef FQTK_DEV_ABLATE
+    if (const char *rr = std::getenv("FQTK_MEMO_R")) R = std::atoi(rr) >= 4 && vec > 0 ? 4 : (std::atoi(rr) >= 2 ? 2 : 1);
+#endif
+    const uint64_t tile = (uint64_t)fqtk::kLdsBlock * R;
+    const uint64_t ntiles = (P.n + tile - 1) / tile;
+    if (ntiles == 0) return FQTK_OK;
+    // workgroups per CU: LDS-limited, and never more than 2 x 1024 lanes
+    const uint32_t per_cu = (uint32_t)std::max<size_t>(1, std::min<size_t>(2, fqtk::kLdsMemoMaxBytes / (shmem + 1024)));
+    const uint32_t grid = (uint32_t)std::min<uint64_t>(ntiles, (uint64_t)m->num_cus * per_cu);
+#define FQTK_LDSM_LAUNCH(V, RR)                                                                            \
+    do {                                                                                                   \
+        if constexpr ((V) <= 0 || KW == ((V) >= 3 ? 2 : 1)) {                                              \
+            auto kern = fqtk::lds_memo_kernel<V, KW, RR>;                                                  \
+            static std::atomic<size_t> allowed{64 * 1024};                                                 \
+            if (shmem > allowed.load()) {                                                                  \
+                HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),                          \
+                                            hipFuncAttributeMaxDynamicSharedMemorySize,                    \
+                                            (int)fqtk::kLdsMemoMaxBytes));                                 \
+                allowed.store(fqtk::kLdsMemoMaxBytes);                                                     \
+            }                                                                                              \
+            hipLaunchKernelGGL(kern, dim3(grid), dim3(fqtk::kLdsBlock), shmem, stream, Q);                \
+        } else {                                                                                           \
+            return fail(FQTK_EINVAL, "lds memo: load width and key width disagree");                       \
+        }                                                                                                  \
+    } while (0)
+    if (R == 4) {
+        switch (vec) {
+            case 4: FQTK_LDSM_LAUNCH(4, 4); break;
+            case 3: FQTK_LDSM_LAUNCH(3, 4); break;
+            case 2: FQTK_LDSM_LAUNCH(2, 4); break;
+            default: FQTK_LDSM_LAUNCH(1, 4); break;
+        }
+    } else if (R == 2) {
+        switch (vec) {
+            case 4: FQTK_LDSM_LAUNCH(4, 2); break;
+            case 3: FQTK_LDSM_LAUNCH(3, 2); break;
+            case 2: FQTK_LDSM_LAUNCH(2, 2); break;
+            case 1: FQTK_LDSM_LAUNCH(1, 2); break;
+            case -1: FQTK_LDSM_LAUNCH(-1, 2); break;
+            default: FQTK_LDSM_LAUNCH(0, 2); break;
+        }
+    } else {
+        switch (vec) {
+            case 4: FQTK_LDSM_LAUNCH(4, 1); break;
+            case 3: FQTK_LDSM_LAUNCH(3, 1); break;
+            case 2: FQTK_LDSM_LAUNCH(2, 1); break;
+            case 1: FQTK_LDSM_LAUNCH(1, 1); break;
+            case -1: FQTK_LDSM_LAUNCH(-1, 1); break;
+            default: FQTK_LDSM_LAUNCH(0, 1); break;
+        }
+    }
+#undef FQTK_LDSM_LAUNCH
+    HIP_TRY(hipGetLastError());
+    return FQTK_OK;
+}
+
 int launch(const fqtk_matcher *m, const fqtk::MatchParams &P, hipStream_t stream) {
     // memo path: reads all exactly L long (no obs_len), table present, caller did not opt out
+    if (m->use_cache && m->d_ldsm && !P.lens && m->memo_kind_wanted != 1) {
+        fqtk::LdsMemoParams Q = m->ldsm;
+        Q.m = P;
+        switch (m->ldsm_kw) {
+            case 1: return launch_lds_memo<1>(m, Q, stream);
+            case 2: return launch_lds_memo<2>(m, Q, stream);
+            default: return launch_lds_memo<3>(m, Q, stream);
+        }
+    }
     if (m->use_cache && m->d_memo && !P.lens) {
         fqtk::MemoParams Q;
         Q.m = P;
@@ -339,7 +438,7 @@ void enumerate_candidates(const uint8_t *e, uint32_t L, uint32_t budget, uint32_
 }
 
 // 4 bits per base, base k in nibble k of {lo, hi, ext}: the same key memo_kernel's encode_nibbles builds
-void memo_key_of(const char *q, uint32_t L, uint32_t &lo, uint32_t &hi, uint32_t &ext) {
+void memo_key_of(const char *q, uint32_t L, uint32_t &lo, uint32_t &hi, uint32_t &ext, bool fold = true) {
     lo = hi = ext = 0;
     for (uint32_t k = 0; k < L; ++k) {
         const uint32_t c = fqtk::memo_code_of(q[k]);
@@ -347,11 +446,29 @@ void memo_key_of(const char *q, uint32_t L, uint32_t &lo, uint32_t &hi, uint32_t
         else if (k < 16) hi |= c << (4 * (k - 8));
         else ext |= c << (4 * (k - 16));
     }
-    if (fqtk::memo_key_words(L) == 1 && L > 8) {   // bases 8-9 ride in lo's spare bits (kFoldMul)
+    if (fold && fqtk::memo_key_words(L) == 1 && L > 8) {   // bases 8-9 ride in lo's spare bits (kFoldMul)
         const uint32_t x = (hi & 7u) | (((hi >> 4) & 7u) << 8);
         lo |= (x * fqtk::kFoldMul) & fqtk::kFoldMask;
         hi = 0;
     }
+}
+
+// ---- LDS-resident compact memo (lds_memo_kernels.hip.h; planned on the host by lds_memo_plan.hpp) ----
+int build_lds_memo(fqtk_matcher *m, const std::vector<fqtk::LdsEntry> &ents,
+                   const std::vector<std::vector<uint8_t>> &enc) {
+    fqtk::LdsMemoPlan plan = fqtk::plan_lds_memo(m->S, m->L, ents, enc);
+    if (!plan.ok) return FQTK_OK;   // not of that shape / does not fit: the HBM/L2 table serves
+    HIP_TRY(hipMalloc(reinterpret_cast<void **>(&m->d_ldsm), plan.image.size() * 4));
+    HIP_TRY(hipMemcpy(m->d_ldsm, plan.image.data(), plan.image.size() * 4, hipMemcpyHostToDevice));
+    m->ldsm.image = m->d_ldsm;
+    m->ldsm.slot_mask_b = plan.slot_mask_b;
+    m->ldsm.idx_bits = plan.idx_bits;
+    m->ldsm.image_words = (uint32_t)plan.image.size();
+    m->ldsm.skey_off_b = plan.skey_off_b;
+    m->ldsm.salt = plan.salt;
+    m->ldsm_kw = plan.kw;
+    m->ldsm_lds_bytes = plan.image.size() * 4 + 1024;
+    return FQTK_OK;
 }
 
 int build_memo(fqtk_matcher *m, const std::vector<std::vector<uint8_t>> &enc) {
@@ -378,7 +495,7 @@ int build_memo(fqtk_matcher *m, const std::vector<std::vector<uint8_t>> &enc) {
     const bool wide = m->memo_kw >= 2;
     const size_t wps = wide ? 4 : 2;   // words per slot
     // distinct Some entries (a string can neighbour several samples)
-    struct Entry { uint32_t lo, hi, ext, val; };
+    struct Entry { uint32_t lo, hi, ext, val; uint64_t ci; };
     std::vector<Entry> ents;
     ents.reserve(n_some);
     for (uint64_t i = 0; i < nc; ++i) {
@@ -386,6 +503,7 @@ int build_memo(fqtk_matcher *m, const std::vector<std::vector<uint8_t>> &enc) {
         Entry e;
         memo_key_of(cand.data() + i * m->L, m->L, e.lo, e.hi, e.ext);
         std::memcpy(&e.val, &res[i], 4);
+        e.ci = i;
         ents.push_back(e);
     }
     std::sort(ents.begin(), ents.end(), [](const Entry &a, const Entry &b) {
@@ -453,6 +571,15 @@ int build_memo(fqtk_matcher *m, const std::vector<std::vector<uint8_t>> &enc) {
         break;
     }
     const uint64_t entries = ents.size();
+    {
+        std::vector<fqtk::LdsEntry> le(ents.size());
+        for (size_t i = 0; i < ents.size(); ++i) {
+            memo_key_of(cand.data() + ents[i].ci * m->L, m->L, le[i].k[0], le[i].k[1], le[i].k[2], false);
+            le[i].val = ents[i].val;
+        }
+        int rc = build_lds_memo(m, le, enc);
+        if (rc != FQTK_OK) return rc;
+    }
     // hot table for LDS: 0-mismatch entries, two-choice without eviction (it is only a cache: an
     // entry that finds both of its slots taken is simply served by the global table)
     {
@@ -502,7 +629,7 @@ extern "C" {
 
 const char *fqtk_last_error(void) { return g_last_error.c_str(); }
 
-int fqtk_abi_version(void) { return 1; }
+int fqtk_abi_version(void) { return 2; }
 
 int fqtk_device_count(int *n_devices) {
     if (!n_devices) return fail(FQTK_EINVAL, "n_devices is NULL");
@@ -631,6 +758,7 @@ void fqtk_matcher_destroy(fqtk_matcher *m) {
     }
     if (m->d_memo) (void)hipFree(m->d_memo);
     if (m->d_hot) (void)hipFree(m->d_hot);
+    if (m->d_ldsm) (void)hipFree(m->d_ldsm);
     if (m->d_table) (void)hipFree(m->d_table);
     if (m->d_lut) (void)hipFree(m->d_lut);
     if (m->d_err) (void)hipFree(m->d_err);
@@ -652,6 +780,19 @@ int fqtk_matcher_set_use_cache(fqtk_matcher *m, int use_cache) {
 }
 uint64_t fqtk_matcher_memo_entries(const fqtk_matcher *m) { return (m && m->d_memo) ? m->memo_entries : 0; }
 uint64_t fqtk_matcher_memo_candidates(const fqtk_matcher *m) { return (m && m->d_memo) ? m->memo_candidates : 0; }
+
+int fqtk_matcher_memo_kind(const fqtk_matcher *m) {
+    if (!m || !m->use_cache) return FQTK_MEMO_NONE;
+    if (m->d_ldsm && m->memo_kind_wanted != FQTK_MEMO_TABLE) return FQTK_MEMO_LDS;
+    return m->d_memo ? FQTK_MEMO_TABLE : FQTK_MEMO_NONE;
+}
+
+int fqtk_matcher_set_memo_kind(fqtk_matcher *m, int kind) {
+    if (!m) return fail(FQTK_EINVAL, "matcher is NULL");
+    if (kind != FQTK_MEMO_TABLE && kind != FQTK_MEMO_LDS) return fail(FQTK_EINVAL, "memo kind must be FQTK_MEMO_TABLE or FQTK_MEMO_LDS");
+    m->memo_kind_wanted = kind == FQTK_MEMO_TABLE ? FQTK_MEMO_TABLE : 0;
+    return FQTK_OK;
+}
 
 int fqtk_matcher_assign_batch_device(fqtk_matcher *m, const void *d_obs, uint32_t stride,
                                      const void *d_obs_len, uint64_t n, void *d_out, void *d_counts,

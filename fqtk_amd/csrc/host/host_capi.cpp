@@ -1,5 +1,6 @@
 // host_capi.cpp -- tiny C shim over the host-side components so the CPU test-suite can exercise them
-// through ctypes (no GPU needed): read structures, header rewriting, FASTQ parsing, BGZF, metrics.
+// through ctypes (no GPU needed): read structures, header rewriting, FASTQ parsing, BGZF, metrics, and
+// the host-side planner of the LDS-resident memo (csrc/lds_memo_plan.hpp).
 #include <cstring>
 #include <string>
 #include <vector>
@@ -10,6 +11,7 @@
 #include "metrics.hpp"
 #include "read_structure.hpp"
 #include "samples.hpp"
+#include "../lds_memo_plan.hpp"
 
 using namespace fqtk_host;
 
@@ -122,4 +124,36 @@ int64_t fqtk_host_load_samples(const char *path, char *err, size_t errcap) {
     return (int64_t)s.size();
 }
 
+
+// Plans the LDS-resident memo from `n_ents` (key[3], val) entries and the S x L encoded sample barcodes.
+// meta = {ok, n_slots, slot_mask_b, idx_bits, skey_off_b, salt, kw, key_stride, 0, image_words}.
+// Returns 0 (also when the memo is not of the LDS shape: meta[0] = 0), -2 if `image` is too small.
+int fqtk_host_plan_lds_memo(uint32_t S, uint32_t L, const uint8_t *enc, uint64_t n_ents, const uint32_t *keys,
+                            const uint32_t *vals, uint32_t *image, uint64_t cap_words, uint32_t *meta) {
+    std::vector<std::vector<uint8_t>> e(S, std::vector<uint8_t>(L));
+    for (uint32_t s = 0; s < S; ++s) std::memcpy(e[s].data(), enc + (size_t)s * L, L);
+    std::vector<fqtk::LdsEntry> ents(n_ents);
+    for (uint64_t i = 0; i < n_ents; ++i) {
+        for (int w = 0; w < 3; ++w) ents[i].k[w] = keys[3 * i + w];
+        ents[i].val = vals[i];
+    }
+    const fqtk::LdsMemoPlan p = fqtk::plan_lds_memo(S, L, ents, e);
+    const uint32_t m[10] = {p.ok ? 1u : 0u, p.n_slots, p.slot_mask_b, p.idx_bits, p.skey_off_b, p.salt,
+                            (uint32_t)p.kw, (uint32_t)p.key_stride, 0u, (uint32_t)p.image.size()};
+    std::memcpy(meta, m, sizeof m);
+    if (!p.ok) return 0;
+    if (p.image.size() > cap_words) return -2;
+    std::memcpy(image, p.image.data(), p.image.size() * 4);
+    return 0;
+}
+
+// The kernel's lookup (csrc/lds_memo_plan.hpp: lds_memo_lookup) over n keys.
+void fqtk_host_lds_memo_lookup(const uint32_t *image, const uint32_t *meta, uint64_t n, const uint32_t *keys,
+                               uint32_t *out) {
+    fqtk::LdsMemoPlan p;
+    p.image.assign(image, image + meta[9]);
+    p.n_slots = meta[1]; p.slot_mask_b = meta[2]; p.idx_bits = meta[3]; p.skey_off_b = meta[4];
+    p.salt = meta[5]; p.kw = (int)meta[6]; p.key_stride = (int)meta[7];
+    for (uint64_t i = 0; i < n; ++i) out[i] = fqtk::lds_memo_lookup(p, keys + 3 * i);
+}
 }  // extern "C"

@@ -1,0 +1,182 @@
+// lds_memo_kernels.hip.h -- the LDS-resident form of the complete memo (gfx950).
+//
+// memo_kernels.hip.h keeps the memo in HBM/L2 and pays one dependent L2 gather per read that is not an
+// exact sample barcode; measured on MI355X that gather phase is ~30 % of the kernel and is what makes
+// it occupancy-hungry (rocprofv3 + tools/ablate.sh).  When every sample barcode
+// is plain A/C/G/T and max_mismatches <= 1 -- fqtk's defaults and the common case -- a memo entry is
+// fully described RELATIVE to the sample it resolves to:
+//
+//     the read is sample idx's barcode, possibly with ONE base replaced at position pos
+//
+// so an entry shrinks from 16 bytes (key + value) to ONE dword
+//
+//     [ fp | idx : IB | pos : 5 | xnib : 3 | next : 5 ]          xnib = code(read base) ^ code(sample base)
+//
+// and the whole table (cfg 3: 24 960 entries -> 128 KiB) fits the CU's 160 KiB LDS next to the S
+// sample keys.  A lookup is three independent ds_read_b32 (3-choice cuckoo), a fingerprint select,
+// one ds_read_b64 of the candidate sample's key and an exact check
+//
+//     key ^ sample_key[idx] == xnib << 4*pos
+//
+// -- no vector-memory gather at all: the only HBM/L2 traffic left is the barcode stream in and the
+// result stream out.  Exactness does not rest on the fingerprint: it only picks which candidate to
+// VERIFY against the sample key first; if that fails and another slot carries the same fingerprint
+// (rare) it is verified too.  No candidate verifies = "not in the memo" = None, as in memo_kernels.hip.h.
+//
+// One workgroup of 1024 lanes per CU (two when the table is small): the table is loaded once per
+// workgroup; without gathers 16 waves/CU stream as fast as 32 (measured).
+#pragma once
+#include "memo_kernels.hip.h"
+
+namespace fqtk {
+
+constexpr int kLdsBlock = 1024;
+struct LdsMemoParams {
+    MatchParams m;
+    const uint32_t *image;    // [n_slots] entries, then (S + 1) sample keys of key_stride words each
+    uint32_t slot_mask_b;     // (n_slots - 1) << 2: byte-address mask of the entry table
+    uint32_t idx_bits;        // IB
+    uint32_t image_words;     // dwords to stage into LDS
+    uint32_t skey_off_b;      // byte offset of the sample keys inside LDS
+    uint32_t salt;            // hash salt the builder settled on
+};
+
+template <int VEC, int KW, int R>
+__global__ __launch_bounds__(kLdsBlock) __attribute__((amdgpu_waves_per_eu(4, 8)))
+void lds_memo_kernel(const LdsMemoParams Q) {
+    const MatchParams &P = Q.m;
+    extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
+    // LDS: [entry table | sample keys | spread LUT (fallback scan) | histogram]; the entry table sits
+    // at byte 0 so a masked hash is used as the ds_read address as is
+    constexpr int KS = KW == 3 ? 4 : KW;                      // key stride in dwords (b128 reads for KW 3)
+    const uint32_t tid = threadIdx.x;
+    for (uint32_t w = tid; w < Q.image_words; w += kLdsBlock) smem[w] = Q.image[w];
+    uint32_t *lds_lut = smem + Q.image_words;
+    uint32_t *lds_hist = lds_lut + 256;
+    if (tid < 256) lds_lut[tid] = P.lut[tid];
+    const uint32_t bins = P.S + 1;
+    if (P.counts && P.lds_hist)
+        for (uint32_t b = tid; b < bins; b += kLdsBlock) lds_hist[b] = 0;
+    __syncthreads();
+    const uint8_t *lds_bytes = reinterpret_cast<const uint8_t *>(smem);
+
+    const uint32_t L = P.L;
+    const uint32_t nwords = (L + 3u) >> 2;
+    constexpr int NWD = VEC >= 1 ? VEC : (KW == 1 ? 2 : (KW == 2 ? 4 : 5));
+    static_assert(NWD <= 2 * KW, "key too narrow for the load width");
+    uint32_t kc[NWD], kv[NWD];
+#pragma unroll
+    for (int w = 0; w < NWD; ++w) {
+        const int rem = (int)L - 4 * w;
+        const uint32_t keep = rem >= 4 ? 0xFFFFFFFFu : (rem <= 0 ? 0u : ((1u << (8 * rem)) - 1u));
+        kc[w] = keep & 0x07070707u;
+        kv[w] = keep & 0xDFDFDFDFu;
+    }
+    const uint32_t fp_shift = kLdsFieldBits + Q.idx_bits;
+    const uint32_t fp_lim = 1u << fp_shift;          // (entry ^ fp word) < fp_lim  <=>  fingerprints agree
+    const uint32_t fp_mask = ~(fp_lim - 1u);
+    const uint64_t tile = (uint64_t)kLdsBlock * R;
+    const uint64_t ntiles = (P.n + tile - 1) / tile;
+
+    for (uint64_t t = blockIdx.x; t < ntiles; t += gridDim.x) {
+        uint32_t words[R][8];
+        uint32_t res[R];
+        bool live[R], bad[R];
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const uint64_t i = t * tile + (uint64_t)r * kLdsBlock + tid;
+            live[r] = i < P.n;
+#pragma unroll
+            for (int w = 0; w < 8; ++w) words[r][w] = 0x41414141u;
+            if (live[r]) load_words<1, VEC>(P, i, nwords, words[r]);
+        }
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            uint32_t lo, hi, ext, b;
+            encode_nibbles<NWD, (VEC >= 1), false>(words[r], kc, kv, lo, hi, ext, b);
+            bad[r] = b != 0 && live[r];
+            uint32_t h1, h2, h3;
+            memo_hash3(lo, KW >= 2 ? hi : 0u, KW >= 3 ? ext : 0u, Q.salt, h1, h2, h3);
+            const uint32_t e1 = *reinterpret_cast<const uint32_t *>(lds_bytes + (h1 & Q.slot_mask_b));
+            const uint32_t e2 = *reinterpret_cast<const uint32_t *>(lds_bytes + (h2 & Q.slot_mask_b));
+            const uint32_t e3 = *reinterpret_cast<const uint32_t *>(lds_bytes + (h3 & Q.slot_mask_b));
+            const uint32_t fpw = h3 & fp_mask;
+            const bool m1 = (e1 ^ fpw) < fp_lim, m2 = (e2 ^ fpw) < fp_lim, m3 = (e3 ^ fpw) < fp_lim;
+            // candidate -> exact check against the sample's own key: key ^ sample_key == xnib << 4*pos
+            auto verify = [&](uint32_t e) -> uint32_t {
+                const uint32_t idx = __builtin_amdgcn_ubfe(e, kLdsFieldBits, Q.idx_bits);
+                const uint32_t pos = __builtin_amdgcn_ubfe(e, 8, 5);
+                const uint32_t xnib = __builtin_amdgcn_ubfe(e, 5, 3);
+                const uint32_t tsh = xnib << ((pos << 2) & 31u);       // the differing nibble, in its word
+                const uint32_t wsel = pos >> 3;
+                const uint8_t *kp = lds_bytes + Q.skey_off_b + idx * (KS * 4u);
+                uint32_t diff;
+                if constexpr (KW == 1) {
+                    diff = lo ^ *reinterpret_cast<const uint32_t *>(kp) ^ tsh;
+                } else if constexpr (KW == 2) {
+                    const uint2 sk = *reinterpret_cast<const uint2 *>(kp);
+                    diff = (lo ^ sk.x ^ (wsel == 0 ? tsh : 0u)) | (hi ^ sk.y ^ (wsel == 0 ? 0u : tsh));
+                } else {
+                    const uint4 sk = *reinterpret_cast<const uint4 *>(kp);
+                    diff = (lo ^ sk.x ^ (wsel == 0 ? tsh : 0u)) | (hi ^ sk.y ^ (wsel == 1 ? tsh : 0u)) |
+                           (ext ^ sk.z ^ (wsel == 2 ? tsh : 0u));
+                }
+                const uint32_t val = idx | (min(xnib, 1u) << 16) | ((e & 31u) << 24);
+                return diff == 0 ? val : kMemoEmpty;
+            };
+            // the first fingerprint match in probe order (e3 if none: it then cannot verify either) ...
+            uint32_t v = verify(m1 ? e1 : (m2 ? e2 : e3));
+            // ... and, rarely (two entries among the three slots share the fingerprint: ~0.1 % of lanes),
+            // the later matches, behind wave-uniform branches
+            const bool need2 = v == kMemoEmpty && ((m1 && (m2 || m3)) || (m2 && m3));
+            if (__ballot(need2)) {
+                const uint32_t v2 = verify((m1 && m2) ? e2 : e3);
+                if (need2) v = v2;
+                const bool need3 = need2 && v2 == kMemoEmpty && m1 && m2 && m3;
+                if (__ballot(need3)) {
+                    const uint32_t v3 = verify(e3);
+                    if (need3) v = v3;
+                }
+            }
+            res[r] = v;
+        }
+        // ---- rare: non-canonical reads -> wave-cooperative exhaustive scan ---------------------
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            uint64_t todo = __ballot(bad[r]);
+            if (todo) {   // wave-uniform
+                Planes<1> mine;
+                encode_planes<1>(words[r], nwords, L, lds_lut, mine);
+                while (todo) {
+                    const int src = __ffsll((unsigned long long)todo) - 1;
+                    todo &= todo - 1;
+                    uint32_t b, s;
+                    wave_scan<1>(mine, src, P, b, s);
+                    if ((int)__lane_id() == src) res[r] = decide(b, s, P.max_mm, P.delta);
+                }
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            if (!live[r]) continue;
+            const uint64_t i = t * tile + (uint64_t)r * kLdsBlock + tid;
+            FQTK_STREAM_STORE(res[r], &P.out[i]);
+            if (P.counts) {
+                const uint32_t idx = res[r] & 0xFFFFu;
+                const uint32_t bin = idx == kNoMatch ? P.S : idx;
+                if (P.lds_hist) atomicAdd(&lds_hist[bin], 1u);
+                else atomicAdd(&P.counts[bin], 1ull);
+            }
+        }
+    }
+
+    if (P.counts && P.lds_hist) {
+        __syncthreads();
+        for (uint32_t b = tid; b < bins; b += kLdsBlock) {
+            const uint32_t c = lds_hist[b];
+            if (c) atomicAdd(&P.counts[b], (unsigned long long)c);
+        }
+    }
+}
+
+}  // namespace fqtk

@@ -1,0 +1,148 @@
+// lds_memo_plan.hpp -- host-side construction of the LDS-resident compact memo that
+// lds_memo_kernels.hip.h probes.  Plain C++17 (no HIP): the matcher calls it at create time, and the
+// CPU test-suite calls it through libfqtk_host.so and replays the kernel's lookup in numpy.
+//
+// Input: the distinct Some entries of the complete memo (unfolded 4-bit keys + result word) and the
+// encoded sample barcodes.  Output: the LDS image [entry table | sample keys], or ok = false when the
+// memo is not of the required shape (a sample with an IUPAC code / N, an entry more than one base
+// away from its sample, S = 1, too many samples for the index field) or does not fit one CU's LDS.
+#pragma once
+#include <stdint.h>
+
+#include <algorithm>
+#include <vector>
+
+#include "memo_hash.hpp"
+
+namespace fqtk {
+
+struct LdsEntry { uint32_t k[3]; uint32_t val; };
+
+struct LdsMemoPlan {
+    bool ok = false;
+    std::vector<uint32_t> image;   // n_slots entry dwords, then (S + 1) sample keys (key_stride dwords each)
+    uint32_t n_slots = 0;
+    uint32_t slot_mask_b = 0;      // (n_slots - 1) << 2
+    uint32_t idx_bits = 0;
+    uint32_t skey_off_b = 0;
+    uint32_t salt = 0;
+    int kw = 0;                    // key words: 1 (L <= 8), 2 (L <= 16), 3 (L <= 20) -- never folded
+    int key_stride = 0;            // dwords per sample key (4 for kw = 3)
+};
+
+// The kernel's lookup, for the builder's self-check and for tests: returns the result word or kMemoEmpty.
+// A candidate whose fingerprint agrees is VERIFIED against its sample's key; candidates are tried in
+// probe order until one verifies (the kernel does the same, the later rounds behind wave-uniform branches).
+inline uint32_t lds_memo_lookup(const LdsMemoPlan &p, const uint32_t key[3]) {
+    uint32_t h[3];
+    memo_hash3(key[0], key[1], key[2], p.salt, h[0], h[1], h[2]);
+    const uint32_t fp_lim = 1u << (kLdsFieldBits + p.idx_bits), fpw = h[2] & ~(fp_lim - 1u);
+    for (int c = 0; c < 3; ++c) {
+        const uint32_t e = p.image[(h[c] & p.slot_mask_b) >> 2];
+        if ((e ^ fpw) >= fp_lim) continue;
+        const uint32_t idx = (e >> kLdsFieldBits) & ((1u << p.idx_bits) - 1u), pos = (e >> 8) & 31u, xnib = (e >> 5) & 7u;
+        const uint32_t *sk = &p.image[(p.skey_off_b >> 2) + (size_t)idx * p.key_stride];
+        uint32_t diff = 0;
+        for (int w = 0; w < p.kw; ++w)
+            diff |= key[w] ^ sk[w] ^ ((pos >> 3) == (uint32_t)w ? xnib << ((pos & 7u) * 4u) : 0u);
+        if (diff == 0) return idx | (std::min(xnib, 1u) << 16) | ((e & 31u) << 24);
+    }
+    return kMemoEmpty;
+}
+
+inline LdsMemoPlan plan_lds_memo(uint32_t S, uint32_t L, const std::vector<LdsEntry> &ents,
+                                 const std::vector<std::vector<uint8_t>> &enc) {
+    LdsMemoPlan plan;
+    if (S < 2 || ents.empty() || L > kMemoMaxLen) return plan;
+    uint32_t idx_bits = 1;
+    while ((1u << idx_bits) < S + 1) ++idx_bits;
+    if (idx_bits > kLdsMaxIdxBits) return plan;
+    const int kw = L <= 8 ? 1 : (L <= 16 ? 2 : 3);
+    const int ks = kw == 3 ? 4 : kw;
+    // sample keys; only plain A/C/G/T samples have one (an IUPAC / N sample matches several strings)
+    std::vector<uint32_t> skeys((size_t)(S + 1) * ks, 0xFFFFFFFFu);   // row S = "no sample": equals no key
+    for (uint32_t s = 0; s < S; ++s) {
+        uint32_t k[3] = {0, 0, 0};
+        for (uint32_t i = 0; i < L; ++i) {
+            const uint8_t nib = enc[s][i];
+            if (nib != 1 && nib != 2 && nib != 4 && nib != 8) return plan;
+            const uint32_t code = nib == 1 ? 0u : nib == 2 ? 1u : nib == 8 ? 2u : 3u;   // A C T G, as memo_code_of
+            k[i >> 3] |= code << (4 * (i & 7));
+        }
+        for (int w = 0; w < ks; ++w) skeys[(size_t)s * ks + w] = w < kw ? k[w] : 0u;
+    }
+    // every entry must be "its sample's barcode with `best` (<= 1) bases replaced"
+    std::vector<uint32_t> fields(ents.size());
+    for (size_t i = 0; i < ents.size(); ++i) {
+        const uint32_t idx = ents[i].val & 0xFFFFu, best = (ents[i].val >> 16) & 0xFFu, next = ents[i].val >> 24;
+        if (idx >= S || next > 31 || best > 1) return plan;
+        uint32_t pos = 0, xnib = 0, ndiff = 0;
+        for (uint32_t b = 0; b < 24; ++b) {
+            const uint32_t w = b >> 3;
+            const uint32_t sk = w < (uint32_t)kw ? skeys[(size_t)idx * ks + w] : 0u;
+            const uint32_t x = ((ents[i].k[w] ^ sk) >> (4 * (b & 7))) & 0xFu;
+            if (x) { ++ndiff; pos = b; xnib = x; }
+        }
+        if (ndiff != best || xnib > 7) return plan;
+        fields[i] = next | (xnib << 5) | (pos << 8) | (idx << kLdsFieldBits);
+    }
+    const uint32_t fp_mask = ~((1u << (kLdsFieldBits + idx_bits)) - 1u);
+    const uint32_t empty = S << kLdsFieldBits;   // idx = S (the sentinel key row), fingerprint 0
+    uint64_t nslots = 256;
+    while ((double)nslots * 0.86 < (double)ents.size()) nslots <<= 1;
+    const size_t fixed = skeys.size() * 4 + 1024 + (size_t)(S + 1) * 4;   // keys + LUT + histogram
+    std::vector<int64_t> owner;
+    std::vector<uint32_t> h(ents.size() * 3);
+    for (int attempt = 0; attempt < 12; ++attempt) {
+        if (nslots * 4 + fixed > kLdsMemoMaxBytes) return plan;   // does not fit one CU's LDS
+        const uint32_t mask_b = (uint32_t)(nslots - 1) << 2;
+        const uint32_t salt = 0x51ED27u * (uint32_t)(attempt + 1);
+        owner.assign(nslots, -1);
+        for (size_t i = 0; i < ents.size(); ++i)
+            memo_hash3(ents[i].k[0], ents[i].k[1], ents[i].k[2], salt, h[3 * i], h[3 * i + 1], h[3 * i + 2]);
+        auto slot_of = [&](size_t i, int c) { return (h[3 * i + c] & mask_b) >> 2; };
+        auto fp_of = [&](size_t i) { return h[3 * i + 2] & fp_mask; };
+        uint64_t rng = 0x9E3779B97F4A7C15ull ^ salt;
+        auto next_rand = [&]() { rng = rng * 6364136223846793005ull + 1442695040888963407ull; return (uint32_t)(rng >> 33); };
+        // cuckoo insert of entry `cur` (random-walk eviction); false = gave up
+        auto insert = [&](int64_t cur) {
+            int64_t avoid = -1;
+            for (int kick = 0; kick < 5000; ++kick) {
+                for (int c = 0; c < 3; ++c) {
+                    const uint32_t p = slot_of((size_t)cur, c);
+                    if (owner[p] < 0) { owner[p] = cur; return true; }
+                }
+                uint32_t p = 0;
+                int tries = 0;
+                do { p = slot_of((size_t)cur, (int)(next_rand() % 3u)); } while ((int64_t)p == avoid && ++tries < 8);
+                std::swap(cur, owner[p]);
+                avoid = p;
+            }
+            return false;
+        };
+        bool ok = true;
+        for (size_t i = 0; i < ents.size() && ok; ++i) ok = insert((int64_t)i);
+        const bool clean = ok;
+        if (clean) {
+            plan.image.assign(nslots, empty);
+            for (uint64_t p = 0; p < nslots; ++p)
+                if (owner[p] >= 0) plan.image[p] = fields[(size_t)owner[p]] | fp_of((size_t)owner[p]);
+            plan.image.insert(plan.image.end(), skeys.begin(), skeys.end());
+            plan.n_slots = (uint32_t)nslots;
+            plan.slot_mask_b = mask_b;
+            plan.idx_bits = idx_bits;
+            plan.skey_off_b = (uint32_t)(nslots * 4);
+            plan.salt = salt;
+            plan.kw = kw;
+            plan.key_stride = ks;
+            // self-check: replay the kernel's lookup for every stored key
+            bool good = true;
+            for (size_t i = 0; i < ents.size() && good; ++i) good = lds_memo_lookup(plan, ents[i].k) == ents[i].val;
+            if (good) { plan.ok = true; return plan; }
+        }
+        if (attempt % 3 == 2) nslots <<= 1;
+    }
+    return plan;
+}
+
+}  // namespace fqtk

@@ -1,0 +1,90 @@
+// memo_hash.hpp -- key layout, hashes and table constants shared by the memo kernels (device) and the
+// memo builders (host).  Plain C++17: compiles under hipcc (host + device) and under g++ (host tools / tests).
+#pragma once
+#include <stdint.h>
+
+#if defined(__HIPCC__)
+#define FQTK_HD __host__ __device__
+#else
+#define FQTK_HD
+#endif
+
+namespace fqtk {
+
+constexpr uint32_t kMemoMaxLen = 20;       // 4 bits/base: lo = bases 0-7, hi = 8-15, ext = 16-19
+constexpr uint32_t kMemoEmpty = 0xFFFFFFFFu;
+
+constexpr uint32_t kHotBytes = 16384;      // LDS budget of the hot table per workgroup
+
+// Key words: 1 (L <= 10: bases 8-9 are folded into the spare top bits of lo's nibbles, see kFoldMul),
+// 2 (L <= 16), 3 (L <= 20).
+FQTK_HD constexpr int memo_key_words(uint32_t L) { return L <= 10 ? 1 : (L <= 16 ? 2 : 3); }
+// Fold of the third word's codes x = code8 | code9 << 8 into bits {3,7,19} / {11,15,27} of lo: the three
+// shifted copies of x (<< 3, << 6, << 17) have disjoint supports, so one 24-bit multiply and one AND
+// deposit the six bits with no carries; bit 31 stays free for the slot's SPILL flag.
+constexpr uint32_t kFoldMul = (1u << 3) | (1u << 6) | (1u << 17);
+constexpr uint32_t kFoldMask = 0x08088888u;
+
+// The canonical code of a base is bits 1..2 of its ASCII byte -- A 0x41 -> 0, C 0x43 -> 1, T 0x54 -> 2,
+// G 0x47 -> 3 -- and N 0x4E -> 7 with bit 3 included; lower case gives the same codes.  kCodePool maps a
+// code back to the upper-case byte it must have come from (0xFF = no such base), which is how the
+// kernel proves a byte canonical: ((byte ^ pool[code]) & 0xDF) == 0.
+constexpr uint32_t kCodePoolLo = 0x47544341u;   // codes 0..3: 'A' 'C' 'T' 'G'
+constexpr uint32_t kCodePoolHi = 0x4EFFFFFFu;   // codes 4..6: none, 7: 'N'
+inline uint32_t memo_code_of(char ch) {   // host mirror (the builder only sees A C G T N)
+    return ((uint32_t)(uint8_t)ch >> 1) & 7u;
+}
+
+// Two-choice (cuckoo) placement: a key lives in slot h1 or slot h2, nowhere else, so a lookup is two
+// INDEPENDENT loads issued back to back -- no probe loop, no divergence, one memory round trip.
+// 24-bit multiplies only: v_mul_u32_u24 / v_mad_u32_u24 issue at the full VALU rate on gfx950, while
+// v_mul_lo_u32 is quarter rate.  The 80-bit key is cut into four <=24-bit limbs.
+FQTK_HD inline uint32_t mul24(uint32_t a, uint32_t b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __umul24(a, b);
+#else
+    return (a & 0xFFFFFFu) * (b & 0xFFFFFFu);
+#endif
+}
+FQTK_HD inline void memo_hash2(uint32_t lo, uint32_t hi, uint32_t ext, uint32_t mask,
+                                           uint32_t &s1, uint32_t &s2) {
+    const uint32_t a = lo;                         // mul24 reads bits 0..23: bases 0-5
+    const uint32_t b = (lo >> 24) | (hi << 8);     // bases 6-7 and 8-11
+    const uint32_t c = (hi >> 16) | (ext << 16);   // bases 12-15 and 16-17
+    const uint32_t d = ext >> 8;                   // bases 18-19
+    uint32_t h = mul24(a, 0x9E3779u) + mul24(b, 0x85EBCBu) + mul24(c, 0xC2B2AFu) + mul24(d, 0xA54FF5u);
+    h ^= h >> 15;
+    h = mul24(h, 0x2C1B3Du) + (h >> 9);
+    h ^= h >> 13;
+    s1 = h & mask;
+    uint32_t g = mul24(h >> 7, 0xD6E8FFu) + h;
+    g ^= g >> 14;
+    s2 = g & mask;
+}
+
+
+// ---- LDS-resident compact memo (lds_memo_kernels.hip.h, lds_memo_plan.hpp) ---------------------------
+constexpr uint32_t kLdsMemoMaxBytes = 160u * 1024u;   // LDS per CU = per workgroup limit on gfx950
+constexpr uint32_t kLdsFieldBits = 13;                // next:5 | xnib:3 | pos:5
+constexpr uint32_t kLdsMaxIdxBits = 13;               // leaves >= 6 fingerprint bits
+
+// Three slot hashes + fingerprint source.  Slots are taken from bits 2.. of h1/h2/h3 (so the masked
+// value IS the LDS byte address), the fingerprint from the top bits of h3.
+FQTK_HD inline void memo_hash3(uint32_t lo, uint32_t hi, uint32_t ext, uint32_t salt,
+                               uint32_t &h1, uint32_t &h2, uint32_t &h3) {
+    const uint32_t a = lo;
+    const uint32_t b = (lo >> 24) | (hi << 8);
+    const uint32_t c = (hi >> 16) | (ext << 16);
+    const uint32_t d = ext >> 8;
+    uint32_t h = mul24(a, 0x9E3779u) + mul24(b, 0x85EBCBu) + mul24(c, 0xC2B2AFu) + mul24(d, 0xA54FF5u) + salt;
+    h ^= h >> 15;
+    h = mul24(h, 0x2C1B3Du) + (h >> 9);
+    h ^= h >> 13;
+    uint32_t g = mul24(h >> 7, 0xD6E8FFu) + h;
+    g ^= g >> 14;
+    uint32_t k = mul24(g >> 6, 0xB5297Bu) + (h >> 5) + g;
+    k ^= k >> 16;
+    h1 = h; h2 = g; h3 = k;
+}
+
+}  // namespace fqtk

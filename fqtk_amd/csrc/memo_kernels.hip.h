@@ -23,67 +23,17 @@
 // which moves the kernel from VALU-bound (~3 % of HBM peak at S=384) towards the HBM roofline.
 #pragma once
 #include "match_kernels.hip.h"
+#include "memo_hash.hpp"
 
 namespace fqtk {
 
-constexpr uint32_t kMemoMaxLen = 20;       // 4 bits/base: lo = bases 0-7, hi = 8-15, ext = 16-19
-constexpr uint32_t kMemoEmpty = 0xFFFFFFFFu;
-
-constexpr uint32_t kHotBytes = 16384;      // LDS budget of the hot table per workgroup
-
-// Key words: 1 (L <= 10: bases 8-9 are folded into the spare top bits of lo's nibbles, see kFoldMul),
-// 2 (L <= 16), 3 (L <= 20).
-__host__ __device__ constexpr int memo_key_words(uint32_t L) { return L <= 10 ? 1 : (L <= 16 ? 2 : 3); }
-// Fold of the third word's codes x = code8 | code9 << 8 into bits {3,7,19} / {11,15,27} of lo: the three
-// shifted copies of x (<< 3, << 6, << 17) have disjoint supports, so one 24-bit multiply and one AND
-// deposit the six bits with no carries; bit 31 stays free for the slot's SPILL flag.
-constexpr uint32_t kFoldMul = (1u << 3) | (1u << 6) | (1u << 17);
-constexpr uint32_t kFoldMask = 0x08088888u;
-
 struct MemoParams {
     MatchParams m;
-    const void *slots;        // KW=1: uint2 {lo | spill << 31, val}; KW>=2: uint4 {lo, hi, val, spill | ext << 16}
+    const void *slots;        // KW=1: uint2 {lo | spill << 31, val}.  KW>=2: uint4 {lo, hi, val, spill | ext << 16}
     const uint32_t *hot;      // hot subset (exact matches) in the same slot format, copied to LDS
     uint32_t mask;            // n_slots - 1
     uint32_t hot_mask;        // hot slots - 1 (0 = no hot table)
 };
-
-// The canonical code of a base is bits 1..2 of its ASCII byte -- A 0x41 -> 0, C 0x43 -> 1, T 0x54 -> 2,
-// G 0x47 -> 3 -- and N 0x4E -> 7 with bit 3 included; lower case gives the same codes.  kCodePool maps a
-// code back to the upper-case byte it must have come from (0xFF = no such base), which is how the
-// kernel proves a byte canonical: ((byte ^ pool[code]) & 0xDF) == 0.
-constexpr uint32_t kCodePoolLo = 0x47544341u;   // codes 0..3: 'A' 'C' 'T' 'G'
-constexpr uint32_t kCodePoolHi = 0x4EFFFFFFu;   // codes 4..6: none, 7: 'N'
-__host__ inline uint32_t memo_code_of(char ch) {   // host mirror (the builder only sees A C G T N)
-    return ((uint32_t)(uint8_t)ch >> 1) & 7u;
-}
-
-// Two-choice (cuckoo) placement: a key lives in slot h1 or slot h2, nowhere else, so a lookup is two
-// INDEPENDENT loads issued back to back -- no probe loop, no divergence, one memory round trip.
-// 24-bit multiplies only: v_mul_u32_u24 / v_mad_u32_u24 issue at the full VALU rate on gfx950, while
-// v_mul_lo_u32 is quarter rate.  The 80-bit key is cut into four <=24-bit limbs.
-__host__ __device__ inline uint32_t mul24(uint32_t a, uint32_t b) {
-#if defined(__HIP_DEVICE_COMPILE__)
-    return __umul24(a, b);
-#else
-    return (a & 0xFFFFFFu) * (b & 0xFFFFFFu);
-#endif
-}
-__host__ __device__ inline void memo_hash2(uint32_t lo, uint32_t hi, uint32_t ext, uint32_t mask,
-                                           uint32_t &s1, uint32_t &s2) {
-    const uint32_t a = lo;                         // mul24 reads bits 0..23: bases 0-5
-    const uint32_t b = (lo >> 24) | (hi << 8);     // bases 6-7 and 8-11
-    const uint32_t c = (hi >> 16) | (ext << 16);   // bases 12-15 and 16-17
-    const uint32_t d = ext >> 8;                   // bases 18-19
-    uint32_t h = mul24(a, 0x9E3779u) + mul24(b, 0x85EBCBu) + mul24(c, 0xC2B2AFu) + mul24(d, 0xA54FF5u);
-    h ^= h >> 15;
-    h = mul24(h, 0x2C1B3Du) + (h >> 9);
-    h ^= h >> 13;
-    s1 = h & mask;
-    uint32_t g = mul24(h >> 7, 0xD6E8FFu) + h;
-    g ^= g >> 14;
-    s2 = g & mask;
-}
 
 // ASCII -> 4-bit codes, SWAR on the packed words (no LDS, no per-base work).  Per 4-base word:
 //   c   = (w >> 1) & 0x07070707          the four codes, one per byte            (2 VALU)
@@ -165,7 +115,8 @@ __device__ __forceinline__ void wave_scan(const Planes<NW> &mine, int src, const
 
 // ABL: developer-only ablation mask (tools/ablate.sh builds with -DFQTK_DEV_ABLATE); 0 in the product.
 //   1 = skip table probes, 2 = skip the canonical-byte validation, 4 = skip histogram,
-//   8 = skip result store, 16 = skip the LDS hot table
+//   8 = skip result store, 16 = skip the LDS hot table, 32 = fold the global probes into 4 KB (L1 hits),
+//   64 = skip the second (spill) probe, 128 = second probe goes to the first probe's neighbour slot
 #ifndef FQTK_MEMO_WAVES
 #define FQTK_MEMO_WAVES 8
 #endif
@@ -235,6 +186,9 @@ void memo_kernel(const MemoParams Q) {
         bool hit[R];
 #pragma unroll
         for (int r = 0; r < R; ++r) { hit[r] = false; res[r] = kMemoEmpty; }
+        uint32_t g1[R], g2[R];   // global-table slots (ABL 32: folded into a 4 KB corner = L1-resident)
+#pragma unroll
+        for (int r = 0; r < R; ++r) { g1[r] = (ABL & 32) ? (s1[r] & 0xFFu) : s1[r]; g2[r] = (ABL & 32) ? (s2[r] & 0xFFu) : ((ABL & 128) ? (s1[r] ^ 1u) : s2[r]); }
         if (Q.hot_mask && !(ABL & 16)) {   // wave-uniform
 #pragma unroll
             for (int r = 0; r < R; ++r) {
@@ -269,11 +223,11 @@ void memo_kernel(const MemoParams Q) {
                 again[r] = false;
                 if (!hit[r] && !bad[r]) {
                     if constexpr (KW >= 2) {
-                        const uint4 e = reinterpret_cast<const uint4 *>(Q.slots)[s1[r]];
+                        const uint4 e = reinterpret_cast<const uint4 *>(Q.slots)[g1[r]];
                         if (e.x == lo[r] && e.y == hi[r] && (KW < 3 || (e.w >> 16) == ext[r])) res[r] = e.z;
                         else again[r] = (e.w & 1u) != 0;
                     } else {
-                        const uint2 e = reinterpret_cast<const uint2 *>(Q.slots)[s1[r]];
+                        const uint2 e = reinterpret_cast<const uint2 *>(Q.slots)[g1[r]];
                         if ((e.x & 0x7FFFFFFFu) == lo[r]) res[r] = e.y;
                         else again[r] = (e.x >> 31) != 0;
                     }
@@ -281,12 +235,12 @@ void memo_kernel(const MemoParams Q) {
             }
 #pragma unroll
             for (int r = 0; r < R; ++r) {
-                if (again[r]) {
+                if (again[r] && !(ABL & 64)) {
                     if constexpr (KW >= 2) {
-                        const uint4 e = reinterpret_cast<const uint4 *>(Q.slots)[s2[r]];
+                        const uint4 e = reinterpret_cast<const uint4 *>(Q.slots)[g2[r]];
                         if (e.x == lo[r] && e.y == hi[r] && (KW < 3 || (e.w >> 16) == ext[r])) res[r] = e.z;
                     } else {
-                        const uint2 e = reinterpret_cast<const uint2 *>(Q.slots)[s2[r]];
+                        const uint2 e = reinterpret_cast<const uint2 *>(Q.slots)[g2[r]];
                         if ((e.x & 0x7FFFFFFFu) == lo[r]) res[r] = e.y;
                     }
                 }

@@ -98,6 +98,19 @@ int fqtk_matcher_set_use_cache(fqtk_matcher *m, int use_cache);
 uint64_t fqtk_matcher_memo_entries(const fqtk_matcher *m);
 uint64_t fqtk_matcher_memo_candidates(const fqtk_matcher *m);
 
+/* Where the memo lives (tuning / test knob, no counterpart in the reference; results never depend on it).
+ *   FQTK_MEMO_NONE   no memo: every read takes the exhaustive scan
+ *   FQTK_MEMO_TABLE  two-choice hash table in HBM/L2 + LDS hot subset (any sample alphabet, any max_mismatches)
+ *   FQTK_MEMO_LDS    one-dword entries, whole table resident in each CU's LDS -- built when all sample
+ *                    barcodes are plain A/C/G/T, max_mismatches <= 1 and the table fits 160 KiB
+ * fqtk_matcher_memo_kind() reports the form the next batch will use; fqtk_matcher_set_memo_kind(m,
+ * FQTK_MEMO_TABLE) pins the HBM/L2 form, FQTK_MEMO_LDS (the default) means "best available". */
+#define FQTK_MEMO_NONE 0
+#define FQTK_MEMO_TABLE 1
+#define FQTK_MEMO_LDS 2
+int fqtk_matcher_memo_kind(const fqtk_matcher *m);
+int fqtk_matcher_set_memo_kind(fqtk_matcher *m, int kind);
+
 /* Replaces one `BarcodeMatcher::assign(&mut self, read_bases: &[u8]) -> Option<BarcodeMatch>` call
  * per template (barcode_matching.rs:165-186; sole call site demux.rs:968) with one call per batch.
  * HOST pointers; synchronous.

@@ -22,21 +22,27 @@ def _loaded_native():
 
 
 def _compare(barcodes, mm, delta, obs, lens=None):
-    """Both device paths -- use_cache=True (complete memo + wave-cooperative fallback) and
-    use_cache=False (exhaustive scan) -- against the literal oracle."""
+    """Every device path -- use_cache=True in both memo forms (LDS-resident where it can be built, and
+    the HBM/L2 table pinned with memo_kind), use_cache=False (exhaustive scan) -- against the literal oracle."""
     lit = O.RefLiteral(barcodes, mm, delta, True)
     L = len(barcodes[0])
     if lens is None:
         i, b, nx, c = lit.assign_batch(np.ascontiguousarray(obs[:, :L]))
     else:
         i, b, nx, c = lit.assign_batch(obs, lens)
-    for use_cache in (True, False):
+    for use_cache, pin_table in ((True, False), (True, True), (False, False)):
         gm = BarcodeMatcher(barcodes, mm, delta, use_cache)
+        if pin_table:
+            if gm.memo_kind != BarcodeMatcher.MEMO_LDS:
+                continue          # the default already was the table (or the scan)
+            gm.memo_kind = BarcodeMatcher.MEMO_TABLE
+            assert gm.memo_kind in (BarcodeMatcher.MEMO_TABLE, BarcodeMatcher.MEMO_NONE)
         got, counts = gm.assign_batch(obs, lens)
-        assert np.array_equal(got["idx"], i), use_cache
-        assert np.array_equal(got["best"], b), use_cache
-        assert np.array_equal(got["next"], nx), use_cache
-        assert np.array_equal(counts, c), use_cache
+        tag = (use_cache, pin_table, gm.memo_kind)
+        assert np.array_equal(got["idx"], i), tag
+        assert np.array_equal(got["best"], b), tag
+        assert np.array_equal(got["next"], nx), tag
+        assert np.array_equal(counts, c), tag
     _loaded_native()
     return got, counts
 
@@ -127,6 +133,29 @@ def test_memo_table_is_built_when_it_should_be():
     assert BarcodeMatcher(["A" * 21, "C" * 21], 1, 2).memo_entries == 0      # L > 20: scan only
     assert BarcodeMatcher(w.barcodes, 6, 2).memo_entries == 0                # over the build budget
     assert BarcodeMatcher(["NNNNNNN"], 0, 2).memo_entries == 5 ** 7          # catch-all barcode
+
+
+def test_memo_kind_selection():
+    """The LDS-resident form needs plain A/C/G/T samples, max_mismatches <= 1 and a table that fits
+    160 KiB; everything else uses the HBM/L2 table (or the scan)."""
+    M = BarcodeMatcher
+    cfg3 = synth.CONFIGS[3]
+    assert M(synth.make_barcodes(cfg3), 1, 2).memo_kind == M.MEMO_LDS           # 24 960 entries -> 128 KiB
+    assert M(synth.make_barcodes(synth.CONFIGS[2]), 1, 2).memo_kind == M.MEMO_LDS
+    assert M(synth.make_barcodes(synth.CONFIGS[5]), 1, 2).memo_kind == M.MEMO_TABLE    # IUPAC samples
+    assert M(["ACGTACGT", "TTTTGGGG", "CCCCAAAA"], 2, 1).memo_kind == M.MEMO_TABLE     # two mismatches
+    assert M(["ACGTACGN", "TTTTGGGG"], 1, 1).memo_kind == M.MEMO_TABLE                 # N in a sample
+    assert M(["ACGTACGT"], 1, 1).memo_kind == M.MEMO_TABLE                             # S = 1: next = 255
+    assert M(["ACGTACGT", "TTTTGGGG"], 1, 1, use_cache=False).memo_kind == M.MEMO_NONE
+    assert M(["A" * 24, "C" * 24], 1, 1).memo_kind == M.MEMO_NONE                      # L > 20
+    m = M(["ACGTACGT", "TTTTGGGG"], 1, 1)
+    assert m.memo_kind == M.MEMO_LDS
+    m.memo_kind = M.MEMO_TABLE
+    assert m.memo_kind == M.MEMO_TABLE
+    m.memo_kind = M.MEMO_LDS
+    assert m.memo_kind == M.MEMO_LDS
+    with pytest.raises(ValueError):
+        m.memo_kind = 7
 
 
 def test_memo_path_handles_non_canonical_reads_in_every_lane_position():

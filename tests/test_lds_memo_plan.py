@@ -1,0 +1,110 @@
+"""Host logic of the LDS-resident memo (fqtk_amd/csrc/lds_memo_plan.hpp), no GPU: the planner is fed the
+memo entries the CPU oracle computes, and the kernel's lookup (lds_memo_lookup, the same arithmetic the
+HIP kernel runs) is replayed for every stored key, for near-miss keys and for random keys."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from fqtk_amd import synth
+from oracle import oracle as O
+from tests import hostlib
+
+NONE = 0xFFFFFFFF
+
+
+def _keys(strings: np.ndarray) -> np.ndarray:
+    """uint8 [n, L] ASCII -> uint32 [n, 3] unfolded 4-bit keys (code = bits 1..2 of the byte, N = 7)."""
+    n, L = strings.shape
+    code = ((strings.astype(np.uint32) >> 1) & 7)
+    keys = np.zeros((n, 3), dtype=np.uint32)
+    for k in range(L):
+        keys[:, k >> 3] |= code[:, k] << np.uint32(4 * (k & 7))
+    return keys
+
+
+def _neighbours(barcodes, mm):
+    """Every A/C/G/T/N string within `mm` (<= 1 here) substitutions of a sample barcode."""
+    L = len(barcodes[0])
+    base = np.stack([np.frombuffer(b.encode(), dtype=np.uint8) for b in barcodes])
+    out = [base]
+    if mm >= 1:
+        for k in range(L):
+            for ch in b"ACGTN":
+                v = base.copy()
+                v[:, k] = ch
+                out.append(v)
+    return np.unique(np.concatenate(out), axis=0)
+
+
+def _plan(barcodes, mm, delta):
+    S, L = len(barcodes), len(barcodes[0])
+    cand = _neighbours(barcodes, min(mm, 1))
+    idx, best, nxt, _ = O.RefLiteral(barcodes, mm, delta, True).assign_batch(cand)
+    some = idx != O.NONE_IDX
+    cand, vals = cand[some], (idx[some].astype(np.uint32) | (best[some].astype(np.uint32) << 16) | (nxt[some].astype(np.uint32) << 24))
+    keys = np.ascontiguousarray(_keys(cand))
+    enc = np.ascontiguousarray(np.stack([O.ENC[np.frombuffer(b.upper().encode(), dtype=np.uint8)] for b in barcodes]).astype(np.uint8))
+    image = np.zeros(48 * 1024, dtype=np.uint32)
+    meta = np.zeros(10, dtype=np.uint32)
+    lib = hostlib.lib()
+    rc = lib.fqtk_host_plan_lds_memo(C.c_uint32(S), C.c_uint32(L), enc.ctypes.data_as(C.c_void_p), C.c_uint64(len(keys)),
+                                     keys.ctypes.data_as(C.c_void_p), np.ascontiguousarray(vals).ctypes.data_as(C.c_void_p),
+                                     image.ctypes.data_as(C.c_void_p), C.c_uint64(image.size), meta.ctypes.data_as(C.c_void_p))
+    assert rc == 0
+    return meta, image, cand, keys, vals
+
+
+def _lookup(meta, image, keys):
+    keys = np.ascontiguousarray(keys, dtype=np.uint32)
+    out = np.zeros(len(keys), dtype=np.uint32)
+    hostlib.lib().fqtk_host_lds_memo_lookup(image.ctypes.data_as(C.c_void_p), meta.ctypes.data_as(C.c_void_p),
+                                            C.c_uint64(len(keys)), keys.ctypes.data_as(C.c_void_p),
+                                            out.ctypes.data_as(C.c_void_p))
+    return out
+
+
+@pytest.mark.parametrize("k", [1, 2, 3, 4])
+def test_baseline_config_tables_plan_and_every_lookup_is_exact(k):
+    cfg = synth.CONFIGS[k]
+    barcodes = synth.make_barcodes(cfg)
+    meta, image, cand, keys, vals = _plan(barcodes, cfg.max_mismatches, cfg.min_mismatch_delta)
+    assert meta[0] == 1, "baseline configs 1-4 are plain ACGT with one mismatch: the LDS form must exist"
+    lds_bytes = int(meta[9]) * 4 + 1024 + (cfg.n_samples + 1) * 4
+    assert lds_bytes <= 160 * 1024
+    # (1) every stored key returns exactly its (idx, best, next)
+    assert np.array_equal(_lookup(meta, image, keys), vals)
+    # (2) keys that are NOT in the memo return None: two-substitution neighbours and random strings
+    rng = np.random.default_rng(k)
+    L = cfg.barcode_len
+    far = cand[rng.integers(0, len(cand), 20000)].copy()
+    for _ in range(2):
+        far[np.arange(len(far)), rng.integers(0, L, len(far))] = np.frombuffer(b"ACGTN", dtype=np.uint8)[rng.integers(0, 5, len(far))]
+    rnd = np.frombuffer(b"ACGTN", dtype=np.uint8)[rng.integers(0, 5, size=(20000, L))]
+    probe = np.concatenate([far, rnd])
+    idx, best, nxt, _ = O.RefLiteral(barcodes, cfg.max_mismatches, cfg.min_mismatch_delta, True).assign_batch(probe)
+    want = np.where(idx == O.NONE_IDX, NONE, idx.astype(np.uint32) | (best.astype(np.uint32) << 16) | (nxt.astype(np.uint32) << 24)).astype(np.uint32)
+    assert np.array_equal(_lookup(meta, image, _keys(probe)), want)
+
+
+def test_shapes_the_lds_form_does_not_cover():
+    assert _plan(["ACGTACGN", "TTTTGGGG"], 1, 1)[0][0] == 0          # N in a sample
+    assert _plan(["ACGTACGR", "TTTTGGGG"], 1, 1)[0][0] == 0          # IUPAC code in a sample
+    assert _plan(["ACGTACGT"], 1, 1)[0][0] == 0                      # S = 1 (next = 255)
+    # tiny tables still plan, at the minimum size
+    meta, image, cand, keys, vals = _plan(["ACGT", "TTTT", "GGCC"], 1, 1)
+    assert meta[0] == 1 and meta[1] == 256
+    assert np.array_equal(_lookup(meta, image, keys), vals)
+
+
+@pytest.mark.parametrize("L", [5, 8, 9, 12, 16, 17, 20])
+def test_all_key_widths(L):
+    rng = np.random.default_rng(L)
+    barcodes = sorted({"".join(rng.choice(list("ACGT"), size=L)) for _ in range(60)})
+    meta, image, cand, keys, vals = _plan(barcodes, 1, 1)
+    assert meta[0] == 1 and meta[6] == (1 if L <= 8 else 2 if L <= 16 else 3)
+    assert np.array_equal(_lookup(meta, image, keys), vals)
+    rnd = np.frombuffer(b"ACGTN", dtype=np.uint8)[rng.integers(0, 5, size=(5000, L))]
+    idx, best, nxt, _ = O.RefLiteral(barcodes, 1, 1, True).assign_batch(rnd)
+    want = np.where(idx == O.NONE_IDX, NONE, idx.astype(np.uint32) | (best.astype(np.uint32) << 16) | (nxt.astype(np.uint32) << 24)).astype(np.uint32)
+    assert np.array_equal(_lookup(meta, image, _keys(rnd)), want)

@@ -14,10 +14,11 @@ pass sq3 SQ_INST_LEVEL_VMEM SQ_INST_LEVEL_LDS SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_
 pass tcp1 TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TCP_PENDING_STALL_CYCLES_sum TCP_TCP_TA_DATA_STALL_CYCLES_sum
 pass tcp2 TCP_READ_TAGCONFLICT_STALL_CYCLES_sum TCP_TCR_TCP_STALL_CYCLES_sum TCP_GATE_EN1_sum TCP_GATE_EN2_sum
 pass tcc TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum GRBM_GUI_ACTIVE
+pass tcc2 TCC_BUSY_sum TCC_TAG_STALL_sum TCC_READ_sum TCC_CYCLE_sum
 python - <<PY
 import csv,collections,os
 O="$O"
-for d in ("sq1","sq2","sq3","tcp1","tcp2","tcc"):
+for d in ("sq1","sq2","sq3","tcp1","tcp2","tcc","tcc2"):
     f=f"{O}/{d}/p_counter_collection.csv"
     if not os.path.exists(f): print(d,"missing"); continue
     agg=collections.defaultdict(list)
