@@ -265,7 +265,7 @@ int launch_lds_memo(const fqtk_matcher *m, fqtk::LdsMemoParams Q, hipStream_t st
     if (shmem > fqtk::kLdsMemoMaxBytes) return fail(FQTK_EINVAL, "lds memo: table does not fit LDS");
     int R = vec > 0 ? 4 : 1;
 #ifdef FQTK_DEV_ABLATE
-    if (const char *rr = std::getenv("FQTK_MEMO_R")) R = std::atoi(rr) >= 4 && vec > 0 ? 4 : (std::atoi(rr) >= 2 ? 2 : 1);
+    if (const char *rr = std::getenv("FQTK_MEMO_R")) R = std::atoi(rr);
 #endif
     const uint64_t tile = (uint64_t)fqtk::kLdsBlock * R;
     const uint64_t ntiles = (P.n + tile - 1) / tile;
@@ -289,14 +289,21 @@ int launch_lds_memo(const fqtk_matcher *m, fqtk::LdsMemoParams Q, hipStream_t st
             return fail(FQTK_EINVAL, "lds memo: load width and key width disagree");                       \
         }                                                                                                  \
     } while (0)
-    if (R == 4) {
+#ifdef FQTK_DEV_ABLATE
+    if (R == 8 && (vec == 4 || vec == 2)) {
+        if (vec == 4) FQTK_LDSM_LAUNCH(4, 8); else FQTK_LDSM_LAUNCH(2, 8);
+        HIP_TRY(hipGetLastError());
+        return FQTK_OK;
+    }
+#endif
+    if (R >= 4 && vec > 0) {
         switch (vec) {
             case 4: FQTK_LDSM_LAUNCH(4, 4); break;
             case 3: FQTK_LDSM_LAUNCH(3, 4); break;
             case 2: FQTK_LDSM_LAUNCH(2, 4); break;
             default: FQTK_LDSM_LAUNCH(1, 4); break;
         }
-    } else if (R == 2) {
+    } else if (R >= 2) {
         switch (vec) {
             case 4: FQTK_LDSM_LAUNCH(4, 2); break;
             case 3: FQTK_LDSM_LAUNCH(3, 2); break;

@@ -41,6 +41,16 @@ struct LdsMemoParams {
     uint32_t salt;            // hash salt the builder settled on
 };
 
+// Raw LDS accesses by BYTE ADDRESS.  The kernel has no static LDS, so its dynamic LDS starts at address
+// 0 (checked once per workgroup) and a masked hash can be used as the ds_read address as is -- no base
+// add per probe.
+typedef __attribute__((address_space(3))) const uint32_t lds_u32;
+typedef __attribute__((address_space(3))) const u32x2v lds_u2;
+typedef __attribute__((address_space(3))) const u32x4v lds_u4;
+__device__ __forceinline__ uint32_t lds_word(uint32_t byte_addr) {
+    return *reinterpret_cast<lds_u32 *>((uintptr_t)byte_addr);
+}
+
 template <int VEC, int KW, int R>
 __global__ __launch_bounds__(kLdsBlock) __attribute__((amdgpu_waves_per_eu(4, 8)))
 void lds_memo_kernel(const LdsMemoParams Q) {
@@ -58,7 +68,7 @@ void lds_memo_kernel(const LdsMemoParams Q) {
     if (P.counts && P.lds_hist)
         for (uint32_t b = tid; b < bins; b += kLdsBlock) lds_hist[b] = 0;
     __syncthreads();
-    const uint8_t *lds_bytes = reinterpret_cast<const uint8_t *>(smem);
+    if ((uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint32_t *)smem != 0u) __builtin_trap();
 
     const uint32_t L = P.L;
     const uint32_t nwords = (L + 3u) >> 2;
@@ -90,51 +100,53 @@ void lds_memo_kernel(const LdsMemoParams Q) {
             for (int w = 0; w < 8; ++w) words[r][w] = 0x41414141u;
             if (live[r]) load_words<1, VEC>(P, i, nwords, words[r]);
         }
+        // One read at a time: hash, three entry reads, select, verify; the rare extra verification
+        // rounds sit behind wave-uniform branches.
+        uint32_t lo[R], hi[R], ext[R];
+        // candidate -> exact check against the sample's own key: key ^ sample_key == xnib << 4*pos
+        auto verify = [&](int r, uint32_t e) -> uint32_t {
+            const uint32_t idx = __builtin_amdgcn_ubfe(e, kLdsFieldBits, Q.idx_bits);
+            const uint32_t pos = __builtin_amdgcn_ubfe(e, 8, 5);
+            const uint32_t xnib = __builtin_amdgcn_ubfe(e, 5, 3);
+            const uint32_t tsh = xnib << ((pos << 2) & 31u);       // the differing nibble, in its word
+            const uint32_t wsel = pos >> 3;
+            const uint32_t ka = Q.skey_off_b + idx * (KS * 4u);
+            uint32_t diff;
+            if constexpr (KW == 1) {
+                diff = lo[r] ^ lds_word(ka) ^ tsh;
+            } else if constexpr (KW == 2) {
+                const u32x2v sk = *reinterpret_cast<lds_u2 *>((uintptr_t)ka);
+                diff = (lo[r] ^ sk.x ^ (wsel == 0 ? tsh : 0u)) | (hi[r] ^ sk.y ^ (wsel == 0 ? 0u : tsh));
+            } else {
+                const u32x4v sk = *reinterpret_cast<lds_u4 *>((uintptr_t)ka);
+                diff = (lo[r] ^ sk.x ^ (wsel == 0 ? tsh : 0u)) | (hi[r] ^ sk.y ^ (wsel == 1 ? tsh : 0u)) |
+                       (ext[r] ^ sk.z ^ (wsel == 2 ? tsh : 0u));
+            }
+            const uint32_t val = idx | (min(xnib, 1u) << 16) | ((e & 31u) << 24);
+            return diff == 0 ? val : kMemoEmpty;
+        };
 #pragma unroll
         for (int r = 0; r < R; ++r) {
-            uint32_t lo, hi, ext, b;
-            encode_nibbles<NWD, (VEC >= 1), false>(words[r], kc, kv, lo, hi, ext, b);
+            uint32_t b;
+            encode_nibbles<NWD, (VEC >= 1), false>(words[r], kc, kv, lo[r], hi[r], ext[r], b);
             bad[r] = b != 0 && live[r];
-            uint32_t h1, h2, h3;
-            memo_hash3(lo, KW >= 2 ? hi : 0u, KW >= 3 ? ext : 0u, Q.salt, h1, h2, h3);
-            const uint32_t e1 = *reinterpret_cast<const uint32_t *>(lds_bytes + (h1 & Q.slot_mask_b));
-            const uint32_t e2 = *reinterpret_cast<const uint32_t *>(lds_bytes + (h2 & Q.slot_mask_b));
-            const uint32_t e3 = *reinterpret_cast<const uint32_t *>(lds_bytes + (h3 & Q.slot_mask_b));
-            const uint32_t fpw = h3 & fp_mask;
+            uint32_t h1, h2, h3, fps;
+            memo_hash3(lo[r], KW >= 2 ? hi[r] : 0u, KW >= 3 ? ext[r] : 0u, Q.salt, h1, h2, h3, fps);
+            const uint32_t e1 = lds_word(h1 & Q.slot_mask_b), e2 = lds_word(h2 & Q.slot_mask_b),
+                           e3 = lds_word(h3 & Q.slot_mask_b);
+            const uint32_t fpw = fps & fp_mask;
             const bool m1 = (e1 ^ fpw) < fp_lim, m2 = (e2 ^ fpw) < fp_lim, m3 = (e3 ^ fpw) < fp_lim;
-            // candidate -> exact check against the sample's own key: key ^ sample_key == xnib << 4*pos
-            auto verify = [&](uint32_t e) -> uint32_t {
-                const uint32_t idx = __builtin_amdgcn_ubfe(e, kLdsFieldBits, Q.idx_bits);
-                const uint32_t pos = __builtin_amdgcn_ubfe(e, 8, 5);
-                const uint32_t xnib = __builtin_amdgcn_ubfe(e, 5, 3);
-                const uint32_t tsh = xnib << ((pos << 2) & 31u);       // the differing nibble, in its word
-                const uint32_t wsel = pos >> 3;
-                const uint8_t *kp = lds_bytes + Q.skey_off_b + idx * (KS * 4u);
-                uint32_t diff;
-                if constexpr (KW == 1) {
-                    diff = lo ^ *reinterpret_cast<const uint32_t *>(kp) ^ tsh;
-                } else if constexpr (KW == 2) {
-                    const uint2 sk = *reinterpret_cast<const uint2 *>(kp);
-                    diff = (lo ^ sk.x ^ (wsel == 0 ? tsh : 0u)) | (hi ^ sk.y ^ (wsel == 0 ? 0u : tsh));
-                } else {
-                    const uint4 sk = *reinterpret_cast<const uint4 *>(kp);
-                    diff = (lo ^ sk.x ^ (wsel == 0 ? tsh : 0u)) | (hi ^ sk.y ^ (wsel == 1 ? tsh : 0u)) |
-                           (ext ^ sk.z ^ (wsel == 2 ? tsh : 0u));
-                }
-                const uint32_t val = idx | (min(xnib, 1u) << 16) | ((e & 31u) << 24);
-                return diff == 0 ? val : kMemoEmpty;
-            };
             // the first fingerprint match in probe order (e3 if none: it then cannot verify either) ...
-            uint32_t v = verify(m1 ? e1 : (m2 ? e2 : e3));
+            uint32_t v = verify(r, m1 ? e1 : (m2 ? e2 : e3));
             // ... and, rarely (two entries among the three slots share the fingerprint: ~0.1 % of lanes),
-            // the later matches, behind wave-uniform branches
+            // the later matches
             const bool need2 = v == kMemoEmpty && ((m1 && (m2 || m3)) || (m2 && m3));
-            if (__ballot(need2)) {
-                const uint32_t v2 = verify((m1 && m2) ? e2 : e3);
+            if (__ballot(need2)) {   // wave-uniform
+                const uint32_t v2 = verify(r, (m1 && m2) ? e2 : e3);
                 if (need2) v = v2;
                 const bool need3 = need2 && v2 == kMemoEmpty && m1 && m2 && m3;
                 if (__ballot(need3)) {
-                    const uint32_t v3 = verify(e3);
+                    const uint32_t v3 = verify(r, e3);
                     if (need3) v = v3;
                 }
             }

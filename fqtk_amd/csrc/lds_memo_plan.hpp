@@ -34,9 +34,9 @@ struct LdsMemoPlan {
 // A candidate whose fingerprint agrees is VERIFIED against its sample's key; candidates are tried in
 // probe order until one verifies (the kernel does the same, the later rounds behind wave-uniform branches).
 inline uint32_t lds_memo_lookup(const LdsMemoPlan &p, const uint32_t key[3]) {
-    uint32_t h[3];
-    memo_hash3(key[0], key[1], key[2], p.salt, h[0], h[1], h[2]);
-    const uint32_t fp_lim = 1u << (kLdsFieldBits + p.idx_bits), fpw = h[2] & ~(fp_lim - 1u);
+    uint32_t h[3], fps;
+    memo_hash3(key[0], key[1], key[2], p.salt, h[0], h[1], h[2], fps);
+    const uint32_t fp_lim = 1u << (kLdsFieldBits + p.idx_bits), fpw = fps & ~(fp_lim - 1u);
     for (int c = 0; c < 3; ++c) {
         const uint32_t e = p.image[(h[c] & p.slot_mask_b) >> 2];
         if ((e ^ fpw) >= fp_lim) continue;
@@ -92,16 +92,16 @@ inline LdsMemoPlan plan_lds_memo(uint32_t S, uint32_t L, const std::vector<LdsEn
     while ((double)nslots * 0.86 < (double)ents.size()) nslots <<= 1;
     const size_t fixed = skeys.size() * 4 + 1024 + (size_t)(S + 1) * 4;   // keys + LUT + histogram
     std::vector<int64_t> owner;
-    std::vector<uint32_t> h(ents.size() * 3);
+    std::vector<uint32_t> h(ents.size() * 3), fps(ents.size());
     for (int attempt = 0; attempt < 12; ++attempt) {
-        if (nslots * 4 + fixed > kLdsMemoMaxBytes) return plan;   // does not fit one CU's LDS
+        if (nslots * 4 + fixed > kLdsMemoMaxBytes || nslots > 32768) return plan;   // does not fit one CU's LDS
         const uint32_t mask_b = (uint32_t)(nslots - 1) << 2;
         const uint32_t salt = 0x51ED27u * (uint32_t)(attempt + 1);
         owner.assign(nslots, -1);
         for (size_t i = 0; i < ents.size(); ++i)
-            memo_hash3(ents[i].k[0], ents[i].k[1], ents[i].k[2], salt, h[3 * i], h[3 * i + 1], h[3 * i + 2]);
+            memo_hash3(ents[i].k[0], ents[i].k[1], ents[i].k[2], salt, h[3 * i], h[3 * i + 1], h[3 * i + 2], fps[i]);
         auto slot_of = [&](size_t i, int c) { return (h[3 * i + c] & mask_b) >> 2; };
-        auto fp_of = [&](size_t i) { return h[3 * i + 2] & fp_mask; };
+        auto fp_of = [&](size_t i) { return fps[i] & fp_mask; };
         uint64_t rng = 0x9E3779B97F4A7C15ull ^ salt;
         auto next_rand = [&]() { rng = rng * 6364136223846793005ull + 1442695040888963407ull; return (uint32_t)(rng >> 33); };
         // cuckoo insert of entry `cur` (random-walk eviction); false = gave up

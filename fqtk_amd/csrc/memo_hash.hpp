@@ -68,10 +68,11 @@ constexpr uint32_t kLdsMemoMaxBytes = 160u * 1024u;   // LDS per CU = per workgr
 constexpr uint32_t kLdsFieldBits = 13;                // next:5 | xnib:3 | pos:5
 constexpr uint32_t kLdsMaxIdxBits = 13;               // leaves >= 6 fingerprint bits
 
-// Three slot hashes + fingerprint source.  Slots are taken from bits 2.. of h1/h2/h3 (so the masked
-// value IS the LDS byte address), the fingerprint from the top bits of h3.
+// Slot hashes + fingerprint source of the LDS table: two mixed words.  The three slots are bits 2..
+// of h, of g and of h >> 15 (so each masked value IS an LDS byte address; with at most 2^15 slots the
+// first and third use disjoint bits of h), the fingerprint is the top bits of g (above the slot bits).
 FQTK_HD inline void memo_hash3(uint32_t lo, uint32_t hi, uint32_t ext, uint32_t salt,
-                               uint32_t &h1, uint32_t &h2, uint32_t &h3) {
+                               uint32_t &h1, uint32_t &h2, uint32_t &h3, uint32_t &fp_src) {
     const uint32_t a = lo;
     const uint32_t b = (lo >> 24) | (hi << 8);
     const uint32_t c = (hi >> 16) | (ext << 16);
@@ -82,9 +83,7 @@ FQTK_HD inline void memo_hash3(uint32_t lo, uint32_t hi, uint32_t ext, uint32_t 
     h ^= h >> 13;
     uint32_t g = mul24(h >> 7, 0xD6E8FFu) + h;
     g ^= g >> 14;
-    uint32_t k = mul24(g >> 6, 0xB5297Bu) + (h >> 5) + g;
-    k ^= k >> 16;
-    h1 = h; h2 = g; h3 = k;
+    h1 = h; h2 = g; h3 = h >> 15; fp_src = g;
 }
 
 }  // namespace fqtk
