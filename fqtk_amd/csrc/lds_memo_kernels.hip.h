@@ -26,6 +26,8 @@
 // One workgroup of 1024 lanes per CU (two when the table is small): the table is loaded once per
 // workgroup; without gathers 16 waves/CU stream as fast as 32 (measured).
 #pragma once
+#include <type_traits>
+
 #include "memo_kernels.hip.h"
 
 namespace fqtk {
@@ -49,6 +51,16 @@ typedef __attribute__((address_space(3))) const u32x2v lds_u2;
 typedef __attribute__((address_space(3))) const u32x4v lds_u4;
 __device__ __forceinline__ uint32_t lds_word(uint32_t byte_addr) {
     return *reinterpret_cast<lds_u32 *>((uintptr_t)byte_addr);
+}
+__device__ __forceinline__ void lds_atomic_inc(uint32_t byte_addr) {
+    __hip_atomic_fetch_add(reinterpret_cast<__attribute__((address_space(3))) uint32_t *>((uintptr_t)byte_addr), 1u,
+                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+// mask ? a : b with the condition given as a 64-lane mask in SGPRs (one v_cndmask_b32)
+__device__ __forceinline__ uint32_t lane_select(uint64_t mask, uint32_t a, uint32_t b) {
+    uint32_t d;
+    asm("v_cndmask_b32 %0, %1, %2, %3" : "=v"(d) : "v"(b), "v"(a), "s"(mask));
+    return d;
 }
 
 template <int VEC, int KW, int R>
@@ -87,18 +99,49 @@ void lds_memo_kernel(const LdsMemoParams Q) {
     const uint32_t fp_mask = ~(fp_lim - 1u);
     const uint64_t tile = (uint64_t)kLdsBlock * R;
     const uint64_t ntiles = (P.n + tile - 1) / tile;
+    // per-lane byte offsets inside a tile: loop-invariant, so a full tile's loads and stores are
+    // "uniform 64-bit base (SGPRs) + 32-bit lane offset" with no per-read address arithmetic
+    uint32_t in_off[R], out_off[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        in_off[r] = (uint32_t)(r * kLdsBlock + tid) * P.stride;
+        out_off[r] = (uint32_t)(r * kLdsBlock + tid) * 4u;
+    }
+    const uint32_t hist_on = (P.counts && P.lds_hist) ? 1u : 0u;
+    const uint32_t hist_base_b = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint32_t *)lds_hist;
 
-    for (uint64_t t = blockIdx.x; t < ntiles; t += gridDim.x) {
+    // FULL = every read of the tile exists and the packed vector load applies: the lean path.
+    auto process = [&](uint64_t t, auto full_tag) {
+        constexpr bool FULL = decltype(full_tag)::value;
         uint32_t words[R][8];
-        uint32_t res[R];
-        bool live[R], bad[R];
+        uint32_t res[R], bflag[R];
+        bool live[R];
+        const uint8_t *tile_in = P.obs + t * tile * (uint64_t)P.stride;   // wave-uniform
+        uint32_t *tile_out = P.out + t * tile;
 #pragma unroll
         for (int r = 0; r < R; ++r) {
-            const uint64_t i = t * tile + (uint64_t)r * kLdsBlock + tid;
-            live[r] = i < P.n;
+            if constexpr (FULL) {
+                live[r] = true;
+                const uint8_t *src = tile_in + in_off[r];
+                if constexpr (VEC == 4) {
+                    const u32x4v v = FQTK_STREAM_LOAD(reinterpret_cast<const u32x4v *>(src));
+                    words[r][0] = v.x; words[r][1] = v.y; words[r][2] = v.z; words[r][3] = v.w;
+                } else if constexpr (VEC == 3) {
+                    const uint32_t *s32 = reinterpret_cast<const uint32_t *>(src);
+                    words[r][0] = s32[0]; words[r][1] = s32[1]; words[r][2] = s32[2];
+                } else if constexpr (VEC == 2) {
+                    const u32x2v v = FQTK_STREAM_LOAD(reinterpret_cast<const u32x2v *>(src));
+                    words[r][0] = v.x; words[r][1] = v.y;
+                } else {
+                    words[r][0] = *reinterpret_cast<const uint32_t *>(src);
+                }
+            } else {
+                const uint64_t i = t * tile + (uint64_t)r * kLdsBlock + tid;
+                live[r] = i < P.n;
 #pragma unroll
-            for (int w = 0; w < 8; ++w) words[r][w] = 0x41414141u;
-            if (live[r]) load_words<1, VEC>(P, i, nwords, words[r]);
+                for (int w = 0; w < 8; ++w) words[r][w] = 0x41414141u;   // dead lanes look like "AAAA"
+                if (live[r]) load_words<1, VEC>(P, i, nwords, words[r]);
+            }
         }
         // One read at a time: hash, three entry reads, select, verify; the rare extra verification
         // rounds sit behind wave-uniform branches.
@@ -127,60 +170,76 @@ void lds_memo_kernel(const LdsMemoParams Q) {
         };
 #pragma unroll
         for (int r = 0; r < R; ++r) {
-            uint32_t b;
-            encode_nibbles<NWD, (VEC >= 1), false>(words[r], kc, kv, lo[r], hi[r], ext[r], b);
-            bad[r] = b != 0 && live[r];
+            encode_nibbles<NWD, (VEC >= 1), false>(words[r], kc, kv, lo[r], hi[r], ext[r], bflag[r]);
             uint32_t h1, h2, h3, fps;
             memo_hash3(lo[r], KW >= 2 ? hi[r] : 0u, KW >= 3 ? ext[r] : 0u, Q.salt, h1, h2, h3, fps);
             const uint32_t e1 = lds_word(h1 & Q.slot_mask_b), e2 = lds_word(h2 & Q.slot_mask_b),
                            e3 = lds_word(h3 & Q.slot_mask_b);
             const uint32_t fpw = fps & fp_mask;
-            const bool m1 = (e1 ^ fpw) < fp_lim, m2 = (e2 ^ fpw) < fp_lim, m3 = (e3 ^ fpw) < fp_lim;
+            // fingerprint matches as LANE MASKS (SGPR pairs): the "more than one match" test below is
+            // then scalar ALU + one scalar branch instead of per-lane selects
+            const uint64_t M1 = __builtin_amdgcn_uicmp(e1 ^ fpw, fp_lim, 36 /* ult */);
+            const uint64_t M2 = __builtin_amdgcn_uicmp(e2 ^ fpw, fp_lim, 36);
+            const uint64_t M3 = __builtin_amdgcn_uicmp(e3 ^ fpw, fp_lim, 36);
             // the first fingerprint match in probe order (e3 if none: it then cannot verify either) ...
-            uint32_t v = verify(r, m1 ? e1 : (m2 ? e2 : e3));
+            uint32_t v = verify(r, lane_select(M1, e1, lane_select(M2, e2, e3)));
             // ... and, rarely (two entries among the three slots share the fingerprint: ~0.1 % of lanes),
             // the later matches
-            const bool need2 = v == kMemoEmpty && ((m1 && (m2 || m3)) || (m2 && m3));
-            if (__ballot(need2)) {   // wave-uniform
+            const uint64_t multi = (M1 & (M2 | M3)) | (M2 & M3);
+            if (multi) {   // wave-uniform, scalar
+                const bool m1 = (e1 ^ fpw) < fp_lim, m2 = (e2 ^ fpw) < fp_lim, m3 = (e3 ^ fpw) < fp_lim;
+                const bool need2 = v == kMemoEmpty && ((m1 && (m2 || m3)) || (m2 && m3));
                 const uint32_t v2 = verify(r, (m1 && m2) ? e2 : e3);
                 if (need2) v = v2;
                 const bool need3 = need2 && v2 == kMemoEmpty && m1 && m2 && m3;
-                if (__ballot(need3)) {
-                    const uint32_t v3 = verify(r, e3);
-                    if (need3) v = v3;
-                }
+                const uint32_t v3 = verify(r, e3);
+                if (need3) v = v3;
             }
             res[r] = v;
         }
         // ---- rare: non-canonical reads -> wave-cooperative exhaustive scan ---------------------
+        uint32_t any_bad = 0;
 #pragma unroll
-        for (int r = 0; r < R; ++r) {
-            uint64_t todo = __ballot(bad[r]);
-            if (todo) {   // wave-uniform
-                Planes<1> mine;
-                encode_planes<1>(words[r], nwords, L, lds_lut, mine);
-                while (todo) {
-                    const int src = __ffsll((unsigned long long)todo) - 1;
-                    todo &= todo - 1;
-                    uint32_t b, s;
-                    wave_scan<1>(mine, src, P, b, s);
-                    if ((int)__lane_id() == src) res[r] = decide(b, s, P.max_mm, P.delta);
+        for (int r = 0; r < R; ++r) any_bad |= live[r] ? bflag[r] : 0u;
+        if (__builtin_amdgcn_uicmp(any_bad, 0u, 33 /* ne */)) {   // wave-uniform; one test per tile
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                uint64_t todo = __builtin_amdgcn_uicmp(live[r] ? bflag[r] : 0u, 0u, 33);
+                if (todo) {
+                    Planes<1> mine;
+                    encode_planes<1>(words[r], nwords, L, lds_lut, mine);
+                    while (todo) {
+                        const int src = __ffsll((unsigned long long)todo) - 1;
+                        todo &= todo - 1;
+                        uint32_t b, s;
+                        wave_scan<1>(mine, src, P, b, s);
+                        if ((int)__lane_id() == src) res[r] = decide(b, s, P.max_mm, P.delta);
+                    }
                 }
             }
         }
+        // ---- results + per-sample counts ---------------------------------------------------------
 #pragma unroll
         for (int r = 0; r < R; ++r) {
             if (!live[r]) continue;
-            const uint64_t i = t * tile + (uint64_t)r * kLdsBlock + tid;
-            FQTK_STREAM_STORE(res[r], &P.out[i]);
+            if constexpr (FULL) {
+                FQTK_STREAM_STORE(res[r], reinterpret_cast<uint32_t *>(reinterpret_cast<uint8_t *>(tile_out) + out_off[r]));
+            } else {
+                FQTK_STREAM_STORE(res[r], &P.out[t * tile + (uint64_t)r * kLdsBlock + tid]);
+            }
             if (P.counts) {
-                const uint32_t idx = res[r] & 0xFFFFu;
-                const uint32_t bin = idx == kNoMatch ? P.S : idx;
-                if (P.lds_hist) atomicAdd(&lds_hist[bin], 1u);
+                const uint32_t bin = min(res[r] & 0xFFFFu, P.S);   // None (0xFFFF) -> bin S
+                if (hist_on) lds_atomic_inc(hist_base_b + bin * 4u);
                 else atomicAdd(&P.counts[bin], 1ull);
             }
         }
-    }
+    };
+
+    const uint64_t full_tiles = (VEC >= 1) ? P.n / tile : 0;
+    for (uint64_t t = blockIdx.x; t < full_tiles; t += gridDim.x) process(t, std::true_type{});
+    // whatever is left (the ragged last tile; every tile on the generic load paths)
+    for (uint64_t t = full_tiles + (blockIdx.x + gridDim.x - full_tiles % gridDim.x) % gridDim.x; t < ntiles; t += gridDim.x)
+        process(t, std::false_type{});
 
     if (P.counts && P.lds_hist) {
         __syncthreads();
