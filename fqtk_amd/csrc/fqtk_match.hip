@@ -444,17 +444,18 @@ void enumerate_candidates(const uint8_t *e, uint32_t L, uint32_t budget, uint32_
     }
 }
 
-// 4 bits per base, base k in nibble k of {lo, hi, ext}: the same key memo_kernel's encode_nibbles builds
+// 4 bits per base at memo_nibble_shift(k) of {lo, hi, ext}: the same key the kernels' encode_nibbles builds
 void memo_key_of(const char *q, uint32_t L, uint32_t &lo, uint32_t &hi, uint32_t &ext, bool fold = true) {
     lo = hi = ext = 0;
     for (uint32_t k = 0; k < L; ++k) {
         const uint32_t c = fqtk::memo_code_of(q[k]);
-        if (k < 8) lo |= c << (4 * k);
-        else if (k < 16) hi |= c << (4 * (k - 8));
-        else ext |= c << (4 * (k - 16));
+        const uint32_t sh = fqtk::memo_nibble_shift(k);
+        if (k < 8) lo |= c << sh;
+        else if (k < 16) hi |= c << sh;
+        else ext |= c << sh;
     }
     if (fold && fqtk::memo_key_words(L) == 1 && L > 8) {   // bases 8-9 ride in lo's spare bits (kFoldMul)
-        const uint32_t x = (hi & 7u) | (((hi >> 4) & 7u) << 8);
+        const uint32_t x = (hi & 7u) | (((hi >> 8) & 7u) << 8);   // c[2] as the kernel sees it: codes in bytes 0, 1
         lo |= (x * fqtk::kFoldMul) & fqtk::kFoldMask;
         hi = 0;
     }
@@ -463,7 +464,16 @@ void memo_key_of(const char *q, uint32_t L, uint32_t &lo, uint32_t &hi, uint32_t
 // ---- LDS-resident compact memo (lds_memo_kernels.hip.h; planned on the host by lds_memo_plan.hpp) ----
 int build_lds_memo(fqtk_matcher *m, const std::vector<fqtk::LdsEntry> &ents,
                    const std::vector<std::vector<uint8_t>> &enc) {
-    fqtk::LdsMemoPlan plan = fqtk::plan_lds_memo(m->S, m->L, ents, enc);
+    uint32_t salt_offset = 0;
+#ifdef FQTK_DEV_ABLATE
+    if (const char *so = std::getenv("FQTK_LDSM_SALT")) salt_offset = (uint32_t)std::atoi(so);
+    int trials = 8;
+    if (const char *st = std::getenv("FQTK_LDSM_TRIALS")) trials = std::atoi(st);
+    fqtk::LdsMemoPlan plan = fqtk::plan_lds_memo(m->S, m->L, ents, enc, salt_offset, trials);
+    if (std::getenv("FQTK_LDSM_TRIALS")) std::fprintf(stderr, "ldsm salt_offset %u score %llu slots %u\n", salt_offset, (unsigned long long)plan.multi_score, plan.n_slots);
+#else
+    fqtk::LdsMemoPlan plan = fqtk::plan_lds_memo(m->S, m->L, ents, enc, salt_offset);
+#endif
     if (!plan.ok) return FQTK_OK;   // not of that shape / does not fit: the HBM/L2 table serves
     HIP_TRY(hipMalloc(reinterpret_cast<void **>(&m->d_ldsm), plan.image.size() * 4));
     HIP_TRY(hipMemcpy(m->d_ldsm, plan.image.data(), plan.image.size() * 4, hipMemcpyHostToDevice));

@@ -129,7 +129,8 @@ int64_t fqtk_host_load_samples(const char *path, char *err, size_t errcap) {
 // meta = {ok, n_slots, slot_mask_b, idx_bits, skey_off_b, salt, kw, key_stride, 0, image_words}.
 // Returns 0 (also when the memo is not of the LDS shape: meta[0] = 0), -2 if `image` is too small.
 int fqtk_host_plan_lds_memo(uint32_t S, uint32_t L, const uint8_t *enc, uint64_t n_ents, const uint32_t *keys,
-                            const uint32_t *vals, uint32_t *image, uint64_t cap_words, uint32_t *meta) {
+                            const uint32_t *vals, uint32_t *image, uint64_t cap_words, uint32_t *meta,
+                            uint32_t salt_offset, int salt_trials) {
     std::vector<std::vector<uint8_t>> e(S, std::vector<uint8_t>(L));
     for (uint32_t s = 0; s < S; ++s) std::memcpy(e[s].data(), enc + (size_t)s * L, L);
     std::vector<fqtk::LdsEntry> ents(n_ents);
@@ -137,7 +138,7 @@ int fqtk_host_plan_lds_memo(uint32_t S, uint32_t L, const uint8_t *enc, uint64_t
         for (int w = 0; w < 3; ++w) ents[i].k[w] = keys[3 * i + w];
         ents[i].val = vals[i];
     }
-    const fqtk::LdsMemoPlan p = fqtk::plan_lds_memo(S, L, ents, e);
+    const fqtk::LdsMemoPlan p = fqtk::plan_lds_memo(S, L, ents, e, salt_offset, salt_trials);
     const uint32_t m[10] = {p.ok ? 1u : 0u, p.n_slots, p.slot_mask_b, p.idx_bits, p.skey_off_b, p.salt,
                             (uint32_t)p.kw, (uint32_t)p.key_stride, 0u, (uint32_t)p.image.size()};
     std::memcpy(meta, m, sizeof m);

@@ -10,7 +10,9 @@
 //
 // so an entry shrinks from 16 bytes (key + value) to ONE dword
 //
-//     [ fp | idx : IB | pos : 5 | xnib : 3 | next : 5 ]          xnib = code(read base) ^ code(sample base)
+//     [ fp | next : 5 | pos : 4-5 | xnib : 3 | best : 1 | fp | idx : IB ]    xnib = code(read base) ^ code(sample base)
+//
+// (idx, best, next sit where fqtk_match_t wants them: entry & mask IS the result, memo_hash.hpp)
 //
 // and the whole table (cfg 3: 24 960 entries -> 128 KiB) fits the CU's 160 KiB LDS next to the S
 // sample keys.  A lookup is three independent ds_read_b32 (3-choice cuckoo), a fingerprint select,
@@ -94,9 +96,9 @@ void lds_memo_kernel(const LdsMemoParams Q) {
         kc[w] = keep & 0x07070707u;
         kv[w] = keep & 0xDFDFDFDFu;
     }
-    const uint32_t fp_shift = kLdsFieldBits + Q.idx_bits;
-    const uint32_t fp_lim = 1u << fp_shift;          // (entry ^ fp word) < fp_lim  <=>  fingerprints agree
-    const uint32_t fp_mask = ~(fp_lim - 1u);
+    const uint32_t fp_mask = lds_fp_mask(Q.idx_bits, KW);     // ((entry ^ g) & fp_mask) == 0 <=> fingerprints agree
+    const uint32_t idx_mask = (1u << Q.idx_bits) - 1u;
+    const uint32_t res_mask = lds_res_mask(Q.idx_bits);       // entry & res_mask = the fqtk_match_t word
     const uint64_t tile = (uint64_t)kLdsBlock * R;
     const uint64_t ntiles = (P.n + tile - 1) / tile;
     // per-lane byte offsets inside a tile: loop-invariant, so a full tile's loads and stores are
@@ -148,25 +150,23 @@ void lds_memo_kernel(const LdsMemoParams Q) {
         uint32_t lo[R], hi[R], ext[R];
         // candidate -> exact check against the sample's own key: key ^ sample_key == xnib << 4*pos
         auto verify = [&](int r, uint32_t e) -> uint32_t {
-            const uint32_t idx = __builtin_amdgcn_ubfe(e, kLdsFieldBits, Q.idx_bits);
-            const uint32_t pos = __builtin_amdgcn_ubfe(e, 8, 5);
-            const uint32_t xnib = __builtin_amdgcn_ubfe(e, 5, 3);
-            const uint32_t tsh = xnib << ((pos << 2) & 31u);       // the differing nibble, in its word
-            const uint32_t wsel = pos >> 3;
-            const uint32_t ka = Q.skey_off_b + idx * (KS * 4u);
+            const uint32_t ka = Q.skey_off_b + (e & idx_mask) * (KS * 4u);
+            const uint32_t xnib = __builtin_amdgcn_ubfe(e, 17, 3);
+            const uint32_t tsh = xnib << ((e >> 18) & 28u);        // the differing nibble, in its word
             uint32_t diff;
             if constexpr (KW == 1) {
                 diff = lo[r] ^ lds_word(ka) ^ tsh;
             } else if constexpr (KW == 2) {
                 const u32x2v sk = *reinterpret_cast<lds_u2 *>((uintptr_t)ka);
-                diff = (lo[r] ^ sk.x ^ (wsel == 0 ? tsh : 0u)) | (hi[r] ^ sk.y ^ (wsel == 0 ? 0u : tsh));
+                const bool w1 = (e & (1u << 23)) != 0;
+                diff = (lo[r] ^ sk.x ^ (w1 ? 0u : tsh)) | (hi[r] ^ sk.y ^ (w1 ? tsh : 0u));
             } else {
                 const u32x4v sk = *reinterpret_cast<lds_u4 *>((uintptr_t)ka);
-                diff = (lo[r] ^ sk.x ^ (wsel == 0 ? tsh : 0u)) | (hi[r] ^ sk.y ^ (wsel == 1 ? tsh : 0u)) |
-                       (ext[r] ^ sk.z ^ (wsel == 2 ? tsh : 0u));
+                const bool w1 = (e & (1u << 23)) != 0, w2 = (e & (1u << 29)) != 0;
+                diff = (lo[r] ^ sk.x ^ ((w1 || w2) ? 0u : tsh)) | (hi[r] ^ sk.y ^ (w1 ? tsh : 0u)) |
+                       (ext[r] ^ sk.z ^ (w2 ? tsh : 0u));
             }
-            const uint32_t val = idx | (min(xnib, 1u) << 16) | ((e & 31u) << 24);
-            return diff == 0 ? val : kMemoEmpty;
+            return diff == 0 ? (e & res_mask) : kMemoEmpty;
         };
 #pragma unroll
         for (int r = 0; r < R; ++r) {
@@ -175,19 +175,18 @@ void lds_memo_kernel(const LdsMemoParams Q) {
             memo_hash3(lo[r], KW >= 2 ? hi[r] : 0u, KW >= 3 ? ext[r] : 0u, Q.salt, h1, h2, h3, fps);
             const uint32_t e1 = lds_word(h1 & Q.slot_mask_b), e2 = lds_word(h2 & Q.slot_mask_b),
                            e3 = lds_word(h3 & Q.slot_mask_b);
-            const uint32_t fpw = fps & fp_mask;
             // fingerprint matches as LANE MASKS (SGPR pairs): the "more than one match" test below is
             // then scalar ALU + one scalar branch instead of per-lane selects
-            const uint64_t M1 = __builtin_amdgcn_uicmp(e1 ^ fpw, fp_lim, 36 /* ult */);
-            const uint64_t M2 = __builtin_amdgcn_uicmp(e2 ^ fpw, fp_lim, 36);
-            const uint64_t M3 = __builtin_amdgcn_uicmp(e3 ^ fpw, fp_lim, 36);
+            const uint64_t M1 = __builtin_amdgcn_uicmp((e1 ^ fps) & fp_mask, 0u, 32 /* eq */);
+            const uint64_t M2 = __builtin_amdgcn_uicmp((e2 ^ fps) & fp_mask, 0u, 32);
+            const uint64_t M3 = __builtin_amdgcn_uicmp((e3 ^ fps) & fp_mask, 0u, 32);
             // the first fingerprint match in probe order (e3 if none: it then cannot verify either) ...
             uint32_t v = verify(r, lane_select(M1, e1, lane_select(M2, e2, e3)));
             // ... and, rarely (two entries among the three slots share the fingerprint: ~0.1 % of lanes),
             // the later matches
             const uint64_t multi = (M1 & (M2 | M3)) | (M2 & M3);
             if (multi) {   // wave-uniform, scalar
-                const bool m1 = (e1 ^ fpw) < fp_lim, m2 = (e2 ^ fpw) < fp_lim, m3 = (e3 ^ fpw) < fp_lim;
+                const bool m1 = ((e1 ^ fps) & fp_mask) == 0, m2 = ((e2 ^ fps) & fp_mask) == 0, m3 = ((e3 ^ fps) & fp_mask) == 0;
                 const bool need2 = v == kMemoEmpty && ((m1 && (m2 || m3)) || (m2 && m3));
                 const uint32_t v2 = verify(r, (m1 && m2) ? e2 : e3);
                 if (need2) v = v2;

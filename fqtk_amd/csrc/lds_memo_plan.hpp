@@ -28,6 +28,7 @@ struct LdsMemoPlan {
     uint32_t salt = 0;
     int kw = 0;                    // key words: 1 (L <= 8), 2 (L <= 16), 3 (L <= 20) -- never folded
     int key_stride = 0;            // dwords per sample key (4 for kw = 3)
+    uint64_t multi_score = 0;      // (exact-match keys with > 1 fingerprint match) << 32 | all such keys
 };
 
 // The kernel's lookup, for the builder's self-check and for tests: returns the result word or kMemoEmpty.
@@ -36,22 +37,23 @@ struct LdsMemoPlan {
 inline uint32_t lds_memo_lookup(const LdsMemoPlan &p, const uint32_t key[3]) {
     uint32_t h[3], fps;
     memo_hash3(key[0], key[1], key[2], p.salt, h[0], h[1], h[2], fps);
-    const uint32_t fp_lim = 1u << (kLdsFieldBits + p.idx_bits), fpw = fps & ~(fp_lim - 1u);
+    const uint32_t fp_mask = lds_fp_mask(p.idx_bits, p.kw);
     for (int c = 0; c < 3; ++c) {
         const uint32_t e = p.image[(h[c] & p.slot_mask_b) >> 2];
-        if ((e ^ fpw) >= fp_lim) continue;
-        const uint32_t idx = (e >> kLdsFieldBits) & ((1u << p.idx_bits) - 1u), pos = (e >> 8) & 31u, xnib = (e >> 5) & 7u;
+        if ((e ^ fps) & fp_mask) continue;
+        const uint32_t idx = e & ((1u << p.idx_bits) - 1u), pos = lds_entry_pos(e, p.kw), xnib = (e >> 17) & 7u;
         const uint32_t *sk = &p.image[(p.skey_off_b >> 2) + (size_t)idx * p.key_stride];
         uint32_t diff = 0;
         for (int w = 0; w < p.kw; ++w)
             diff |= key[w] ^ sk[w] ^ ((pos >> 3) == (uint32_t)w ? xnib << ((pos & 7u) * 4u) : 0u);
-        if (diff == 0) return idx | (std::min(xnib, 1u) << 16) | ((e & 31u) << 24);
+        if (diff == 0) return e & lds_res_mask(p.idx_bits);
     }
     return kMemoEmpty;
 }
 
 inline LdsMemoPlan plan_lds_memo(uint32_t S, uint32_t L, const std::vector<LdsEntry> &ents,
-                                 const std::vector<std::vector<uint8_t>> &enc) {
+                                 const std::vector<std::vector<uint8_t>> &enc, uint32_t salt_offset = 0,
+                                 int salt_trials = 8) {
     LdsMemoPlan plan;
     if (S < 2 || ents.empty() || L > kMemoMaxLen) return plan;
     uint32_t idx_bits = 1;
@@ -67,7 +69,7 @@ inline LdsMemoPlan plan_lds_memo(uint32_t S, uint32_t L, const std::vector<LdsEn
             const uint8_t nib = enc[s][i];
             if (nib != 1 && nib != 2 && nib != 4 && nib != 8) return plan;
             const uint32_t code = nib == 1 ? 0u : nib == 2 ? 1u : nib == 8 ? 2u : 3u;   // A C T G, as memo_code_of
-            k[i >> 3] |= code << (4 * (i & 7));
+            k[i >> 3] |= code << memo_nibble_shift(i);
         }
         for (int w = 0; w < ks; ++w) skeys[(size_t)s * ks + w] = w < kw ? k[w] : 0u;
     }
@@ -84,19 +86,28 @@ inline LdsMemoPlan plan_lds_memo(uint32_t S, uint32_t L, const std::vector<LdsEn
             if (x) { ++ndiff; pos = b; xnib = x; }
         }
         if (ndiff != best || xnib > 7) return plan;
-        fields[i] = next | (xnib << 5) | (pos << 8) | (idx << kLdsFieldBits);
+        fields[i] = lds_entry_fields(idx, best, next, xnib, pos);
     }
-    const uint32_t fp_mask = ~((1u << (kLdsFieldBits + idx_bits)) - 1u);
-    const uint32_t empty = S << kLdsFieldBits;   // idx = S (the sentinel key row), fingerprint 0
+    const uint32_t fp_mask = lds_fp_mask(idx_bits, kw);
+    const uint32_t empty = S;   // idx = S (the sentinel key row), everything else 0
     uint64_t nslots = 256;
     while ((double)nslots * 0.86 < (double)ents.size()) nslots <<= 1;
     const size_t fixed = skeys.size() * 4 + 1024 + (size_t)(S + 1) * 4;   // keys + LUT + histogram
     std::vector<int64_t> owner;
     std::vector<uint32_t> h(ents.size() * 3), fps(ents.size());
-    for (int attempt = 0; attempt < 12; ++attempt) {
-        if (nslots * 4 + fixed > kLdsMemoMaxBytes || nslots > 32768) return plan;   // does not fit one CU's LDS
+    // The salt matters for speed, not only for feasibility.  Most reads ARE a sample barcode, so nearly
+    // every wave looks up exact-match keys; if such a key finds a second entry with its fingerprint
+    // among its three slots, every wave carrying that sample pays the extra verification round
+    // (measured on MI355X: -20 % at S = 24 for ONE such key).  So several salts are built and the one
+    // with the fewest multi-match exact keys (then the fewest multi-match keys overall) is kept.
+    const int kSaltTrials = salt_trials < 1 ? 1 : salt_trials;
+    LdsMemoPlan best;
+    uint64_t best_score = ~0ull;
+    int successes = 0, failures = 0;
+    for (int attempt = 0; attempt < 12 + kSaltTrials && successes < kSaltTrials; ++attempt) {
+        if (nslots * 4 + fixed > kLdsMemoMaxBytes || nslots > 32768) break;   // does not fit one CU's LDS
         const uint32_t mask_b = (uint32_t)(nslots - 1) << 2;
-        const uint32_t salt = 0x51ED27u * (uint32_t)(attempt + 1);
+        const uint32_t salt = 0x51ED27u * (uint32_t)(attempt + 1 + salt_offset);
         owner.assign(nslots, -1);
         for (size_t i = 0; i < ents.size(); ++i)
             memo_hash3(ents[i].k[0], ents[i].k[1], ents[i].k[2], salt, h[3 * i], h[3 * i + 1], h[3 * i + 2], fps[i]);
@@ -138,11 +149,27 @@ inline LdsMemoPlan plan_lds_memo(uint32_t S, uint32_t L, const std::vector<LdsEn
             // self-check: replay the kernel's lookup for every stored key
             bool good = true;
             for (size_t i = 0; i < ents.size() && good; ++i) good = lds_memo_lookup(plan, ents[i].k) == ents[i].val;
-            if (good) { plan.ok = true; return plan; }
+            if (good) {
+                uint64_t hot_multi = 0, all_multi = 0;
+                for (size_t i = 0; i < ents.size(); ++i) {
+                    int matches = 0;
+                    for (int c = 0; c < 3; ++c) {
+                        bool seen = false;   // the same slot reached through two hashes is one entry
+                        for (int d = 0; d < c; ++d) seen = seen || slot_of(i, d) == slot_of(i, c);
+                        if (!seen && ((plan.image[slot_of(i, c)] ^ fps[i]) & fp_mask) == 0) ++matches;
+                    }
+                    if (matches > 1) { ++all_multi; if (((ents[i].val >> 16) & 0xFFu) == 0) ++hot_multi; }
+                }
+                const uint64_t score = (hot_multi << 32) | all_multi;
+                ++successes;
+                if (score < best_score) { best_score = score; best = plan; best.ok = true; best.multi_score = score; }
+                if (score == 0) break;
+                continue;
+            }
         }
-        if (attempt % 3 == 2) nslots <<= 1;
+        if (successes == 0 && ++failures % 3 == 0) nslots <<= 1;
     }
-    return plan;
+    return best;
 }
 
 }  // namespace fqtk

@@ -12,6 +12,12 @@
 namespace fqtk {
 
 constexpr uint32_t kMemoMaxLen = 20;       // 4 bits/base: lo = bases 0-7, hi = 8-15, ext = 16-19
+// Inside a key word, byte k holds base k in its low nibble and base 4+k in its high nibble: the kernel
+// packs two 4-base input words with ONE v_lshl_or_b32 (codes_hi << 4 | codes_lo).
+// The third word (bases 16-19) keeps its 4 nibbles contiguous: it has to fit 16 bits of a table slot.
+FQTK_HD constexpr uint32_t memo_nibble_shift(uint32_t base) {   // bit offset of `base` inside its key word
+    return base >= 16u ? 4u * (base - 16u) : 4u * (((base & 3u) << 1) | ((base & 7u) >> 2));
+}
 constexpr uint32_t kMemoEmpty = 0xFFFFFFFFu;
 
 constexpr uint32_t kHotBytes = 16384;      // LDS budget of the hot table per workgroup
@@ -65,12 +71,25 @@ FQTK_HD inline void memo_hash2(uint32_t lo, uint32_t hi, uint32_t ext, uint32_t 
 
 // ---- LDS-resident compact memo (lds_memo_kernels.hip.h, lds_memo_plan.hpp) ---------------------------
 constexpr uint32_t kLdsMemoMaxBytes = 160u * 1024u;   // LDS per CU = per workgroup limit on gfx950
-constexpr uint32_t kLdsFieldBits = 13;                // next:5 | xnib:3 | pos:5
-constexpr uint32_t kLdsMaxIdxBits = 13;               // leaves >= 6 fingerprint bits
+// Entry dword.  The result bits sit where fqtk_match_t wants them, so "entry & res_mask" IS the result:
+//   [0, IB) idx | [IB, 16) fingerprint | 16 best | 17-19 xnib | 20-23 pos (nibble index; bit 23 = hi word)
+//   | 24-28 next | 29 pos bit 4 (ext word; 3-word keys only, else fingerprint) | 30-31 fingerprint
+constexpr uint32_t kLdsMaxIdxBits = 12;               // leaves >= 6 fingerprint bits
+FQTK_HD constexpr uint32_t lds_fp_mask(uint32_t idx_bits, int kw) {
+    return (kw >= 3 ? 0xC0000000u : 0xE0000000u) | (0xFFFFu & ~((1u << idx_bits) - 1u));
+}
+FQTK_HD constexpr uint32_t lds_res_mask(uint32_t idx_bits) { return 0x1F010000u | ((1u << idx_bits) - 1u); }
+FQTK_HD constexpr uint32_t lds_entry_fields(uint32_t idx, uint32_t best, uint32_t next, uint32_t xnib, uint32_t pos) {
+    return idx | (best << 16) | (xnib << 17) | ((pos & 15u) << 20) | (next << 24) | ((pos >> 4) << 29);
+}
+FQTK_HD constexpr uint32_t lds_entry_pos(uint32_t e, int kw) { return ((e >> 20) & 15u) | (kw >= 3 ? ((e >> 29) & 1u) << 4 : 0u); }
 
 // Slot hashes + fingerprint source of the LDS table: two mixed words.  The three slots are bits 2..
 // of h, of g and of h >> 15 (so each masked value IS an LDS byte address; with at most 2^15 slots the
-// first and third use disjoint bits of h), the fingerprint is the top bits of g (above the slot bits).
+// first and third use disjoint bits of h).  The fingerprint must be independent of the slot bits --
+// two keys that share a slot share those bits -- so it is taken from g[16..31], which no slot index
+// reads (slot 2 uses g[2..16]): one v_perm_b32 moves g's upper half under the entry's fingerprint
+// fields (bits IB..15 <- g[16+IB..31], bits 29..31 <- g[21..23]).
 FQTK_HD inline void memo_hash3(uint32_t lo, uint32_t hi, uint32_t ext, uint32_t salt,
                                uint32_t &h1, uint32_t &h2, uint32_t &h3, uint32_t &fp_src) {
     const uint32_t a = lo;
@@ -83,7 +102,12 @@ FQTK_HD inline void memo_hash3(uint32_t lo, uint32_t hi, uint32_t ext, uint32_t 
     h ^= h >> 13;
     uint32_t g = mul24(h >> 7, 0xD6E8FFu) + h;
     g ^= g >> 14;
-    h1 = h; h2 = g; h3 = h >> 15; fp_src = g;
+    h1 = h; h2 = g; h3 = h >> 15;
+#if defined(__HIP_DEVICE_COMPILE__)
+    fp_src = __builtin_amdgcn_perm(g, g, 0x02000302u);   // bytes: g.b2, g.b3, g.b0, g.b2
+#else
+    fp_src = (g >> 16) | ((g & 0xFFu) << 16) | (((g >> 16) & 0xFFu) << 24);
+#endif
 }
 
 }  // namespace fqtk

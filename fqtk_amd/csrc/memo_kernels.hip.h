@@ -38,38 +38,33 @@ struct MemoParams {
 // ASCII -> 4-bit codes, SWAR on the packed words (no LDS, no per-base work).  Per 4-base word:
 //   c   = (w >> 1) & 0x07070707          the four codes, one per byte            (2 VALU)
 //   e   = v_perm_b32(pool, c)            the bytes those codes stand for         (1)
-//   bad |= (w ^ e) & 0xDFDFDFDF          any other byte (IUPAC, '.', junk) flags (2)
-//   t   = c | (c >> 4)                   two codes per byte in bytes 0 and 2     (2)
-// and one v_perm_b32 per PAIR of words gathers bytes {0,2} of both into a key word.  kc / kv are the
-// two masks above cut down to the real bases of a word (pad positions encode as 'A' = 0 = absent);
-// FULL says all words but the last are complete, so only the last one needs its masks from SGPRs.
+//   bad |= (w ^ e) & 0xDFDFDFDF          any other byte (IUPAC, '.', junk) flags (1, v_bitop3)
+// and ONE v_lshl_or_b32 per PAIR of words makes a key word: codes of the second word << 4 | codes of
+// the first (memo_nibble_shift is the host's view of that order).  kc / kv are the two masks above cut
+// down to the real bases of a word (pad positions encode as 'A' = 0 = absent); FULL says all words but
+// the last are complete, so only the last one needs its masks from SGPRs.
 template <int NWD, bool FULL, bool FOLD>
 __device__ __forceinline__ void encode_nibbles(const uint32_t (&words)[8], const uint32_t (&kc)[NWD],
                                                const uint32_t (&kv)[NWD], uint32_t &lo, uint32_t &hi,
                                                uint32_t &ext, uint32_t &bad) {
     static_assert(!FOLD || NWD == 3, "the fold is for the 9-10 base keys only");
-    uint32_t t[6] = {0, 0, 0, 0, 0, 0};
-    uint32_t c2 = 0;
+    uint32_t c[6] = {0, 0, 0, 0, 0, 0};
     bad = 0;
 #pragma unroll
     for (int w = 0; w < NWD; ++w) {
         const bool full = FULL && w < NWD - 1;
-        const uint32_t c = (words[w] >> 1) & (full ? 0x07070707u : kc[w]);
-        const uint32_t e = __builtin_amdgcn_perm(kCodePoolHi, kCodePoolLo, c);
+        c[w] = (words[w] >> 1) & (full ? 0x07070707u : kc[w]);
+        const uint32_t e = __builtin_amdgcn_perm(kCodePoolHi, kCodePoolLo, c[w]);
         bad |= (words[w] ^ e) & (full ? 0xDFDFDFDFu : kv[w]);
-        t[w] = c | (c >> 4);
-        if (w == 2) c2 = c;
     }
-    if constexpr (FOLD) {   // L <= 10: kc[2] leaves only codes 8 and 9 in c2
-        lo = __builtin_amdgcn_perm(t[1], t[0], 0x06040200u) | (mul24(c2, kFoldMul) & kFoldMask);
+    lo = NWD >= 2 ? ((c[1] << 4) | c[0]) : c[0];
+    if constexpr (FOLD) {   // L <= 10: kc[2] leaves only codes 8 and 9 in c[2]
+        lo |= mul24(c[2], kFoldMul) & kFoldMask;
         hi = ext = 0;
         return;
     }
-    // selector: byte0 <- lo.b0, byte1 <- lo.b2, byte2 <- hi.b0, byte3 <- hi.b2 (0x0c = constant 0)
-    lo = NWD >= 2 ? __builtin_amdgcn_perm(t[1], t[0], 0x06040200u) : __builtin_amdgcn_perm(0u, t[0], 0x0C0C0200u);
-    hi = NWD >= 4 ? __builtin_amdgcn_perm(t[3], t[2], 0x06040200u)
-                  : (NWD == 3 ? __builtin_amdgcn_perm(0u, t[2], 0x0C0C0200u) : 0u);
-    ext = NWD >= 5 ? __builtin_amdgcn_perm(0u, t[4], 0x0C0C0200u) : 0u;
+    hi = NWD >= 4 ? ((c[3] << 4) | c[2]) : (NWD == 3 ? c[2] : 0u);
+    ext = NWD >= 5 ? __builtin_amdgcn_perm(0u, c[4] | (c[4] >> 4), 0x0C0C0200u) : 0u;   // 4 contiguous nibbles
 }
 
 // (best, second) packed keys -> result word (barcode_matching.rs:150-159).

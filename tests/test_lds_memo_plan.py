@@ -18,8 +18,8 @@ def _keys(strings: np.ndarray) -> np.ndarray:
     n, L = strings.shape
     code = ((strings.astype(np.uint32) >> 1) & 7)
     keys = np.zeros((n, 3), dtype=np.uint32)
-    for k in range(L):
-        keys[:, k >> 3] |= code[:, k] << np.uint32(4 * (k & 7))
+    for k in range(L):   # memo_hash.hpp memo_nibble_shift: byte k&3 of the word, high nibble for bases 4-7
+        keys[:, k >> 3] |= code[:, k] << np.uint32(4 * (k - 16) if k >= 16 else 4 * (((k & 3) << 1) | ((k & 7) >> 2)))
     return keys
 
 
@@ -37,7 +37,7 @@ def _neighbours(barcodes, mm):
     return np.unique(np.concatenate(out), axis=0)
 
 
-def _plan(barcodes, mm, delta):
+def _plan(barcodes, mm, delta, salt_offset=0, salt_trials=8):
     S, L = len(barcodes), len(barcodes[0])
     cand = _neighbours(barcodes, min(mm, 1))
     idx, best, nxt, _ = O.RefLiteral(barcodes, mm, delta, True).assign_batch(cand)
@@ -50,7 +50,8 @@ def _plan(barcodes, mm, delta):
     lib = hostlib.lib()
     rc = lib.fqtk_host_plan_lds_memo(C.c_uint32(S), C.c_uint32(L), enc.ctypes.data_as(C.c_void_p), C.c_uint64(len(keys)),
                                      keys.ctypes.data_as(C.c_void_p), np.ascontiguousarray(vals).ctypes.data_as(C.c_void_p),
-                                     image.ctypes.data_as(C.c_void_p), C.c_uint64(image.size), meta.ctypes.data_as(C.c_void_p))
+                                     image.ctypes.data_as(C.c_void_p), C.c_uint64(image.size), meta.ctypes.data_as(C.c_void_p),
+                                     C.c_uint32(salt_offset), C.c_int(salt_trials))
     assert rc == 0
     return meta, image, cand, keys, vals
 
