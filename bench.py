@@ -73,6 +73,8 @@ def main() -> int:
     ap.add_argument("--min-mismatch-delta", type=int, default=-1, help="override the config's value (exploration only)")
     ap.add_argument("--no-cache", action="store_true",
                     help="use_cache=false: exhaustive per-sample scan for every read (no memo table)")
+    ap.add_argument("--memo-table", action="store_true",
+                    help="pin the HBM/L2 table form of the memo (default: LDS-resident form when it can be built)")
     args = ap.parse_args()
 
     import torch
@@ -123,8 +125,11 @@ def main() -> int:
 
     matcher = BarcodeMatcher(workload.barcodes, cfg.max_mismatches, cfg.min_mismatch_delta,
                              use_cache=not args.no_cache, device=local_rank)
+    if args.memo_table:
+        matcher.memo_kind = BarcodeMatcher.MEMO_TABLE
     memo_on = (not args.no_cache) and matcher.memo_entries > 0
-    kernel_name = "fqtk::memo_kernel" if memo_on else "fqtk::match_kernel"
+    kernel_name = {BarcodeMatcher.MEMO_NONE: "fqtk::match_kernel", BarcodeMatcher.MEMO_TABLE: "fqtk::memo_kernel",
+                   BarcodeMatcher.MEMO_LDS: "fqtk::lds_memo_kernel"}[matcher.memo_kind]
 
     def step():
         matcher.assign_batch_device(d_obs.data_ptr(), cfg.stride, n, d_out.data_ptr(), d_counts.data_ptr(),
@@ -224,6 +229,7 @@ def main() -> int:
                 "parity": parity,
                 "use_cache": not args.no_cache,
                 "memo_entries": matcher.memo_entries,
+                "memo_kind": {0: "none (scan)", 1: "table in HBM/L2 + LDS hot subset", 2: "LDS-resident"}[matcher.memo_kind],
             },
             "roofline": {
                 "bound": "hbm",

@@ -47,6 +47,7 @@ def main():
     ap.add_argument("--reads", type=int, default=0)
     ap.add_argument("--procs", type=int, default=0)
     ap.add_argument("--no-cache", action="store_true")
+    ap.add_argument("--table", action="store_true", help="pin the HBM/L2 table form of the memo")
     a = ap.parse_args()
     import torch
     from fqtk_amd import BarcodeMatcher, synth
@@ -63,6 +64,9 @@ def main():
     d_out = torch.empty(n, dtype=torch.int32, device=dev)
     d_counts = torch.zeros(cfg.n_samples + 1, dtype=torch.int64, device=dev)
     m = BarcodeMatcher(w.barcodes, cfg.max_mismatches, cfg.min_mismatch_delta, use_cache=not a.no_cache)
+    if a.table:
+        m.memo_kind = BarcodeMatcher.MEMO_TABLE
+    kind = {0: "scan", 1: "memo-table", 2: "memo-lds"}[m.memo_kind]
     t0 = time.perf_counter()
     m.assign_batch_device(d_obs.data_ptr(), cfg.stride, n, d_out.data_ptr(), d_counts.data_ptr(), stream=stream)
     m.poll_error(stream)
@@ -80,7 +84,7 @@ def main():
     os.unlink(path)
     mism = sum(r[0] for r in res)
     oracle_counts = sum((r[1] for r in res), np.zeros(cfg.n_samples + 1, dtype=np.uint64))
-    out = {"config": cfg.name, "reads": n, "path": "scan" if a.no_cache else "memo", "memo_entries": m.memo_entries,
+    out = {"config": cfg.name, "reads": n, "path": kind, "memo_entries": m.memo_entries,
            "mismatching_reads": mism, "counts_equal": bool(np.array_equal(oracle_counts, gpu_counts)),
            "matched_fraction": round(float(1 - gpu_counts[-1] / gpu_counts.sum()), 6),
            "gpu_seconds_incl_launch": round(gpu_s, 4), "oracle_processes": len(jobs), "oracle_wall_seconds": round(cpu_s, 1)}
