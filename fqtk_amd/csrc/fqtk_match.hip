@@ -531,7 +531,11 @@ int build_memo(fqtk_matcher *m, const std::vector<std::vector<uint8_t>> &enc) {
                ents.end());
     // two-choice (cuckoo) placement with random-walk eviction; grow on the (unlikely) failure
     uint64_t nslots = 1024;
-    while (nslots < ents.size() * 4) nslots <<= 1;
+    uint64_t slot_factor = 4;
+#ifdef FQTK_DEV_ABLATE
+    if (const char *sf = std::getenv("FQTK_MEMO_SLOT_FACTOR")) slot_factor = (uint64_t)std::atoi(sf);
+#endif
+    while (nslots < ents.size() * slot_factor) nslots <<= 1;
     std::vector<uint32_t> slots;
     uint32_t mask = 0;
     for (int attempt = 0;; ++attempt) {
