@@ -205,6 +205,39 @@ def test_random_tables_and_reads(seed):
     _compare(barcodes, mm, delta, obs)
 
 
+@pytest.mark.parametrize("seed", range(int(__import__("os").environ.get("FQTK_SOAK_SEEDS", "16"))))
+def test_random_plain_tables_lds_form(seed):
+    """Random plain-A/C/G/T tables with max_mismatches <= 1 -- the shape the LDS-resident memo is built
+    for -- over random S, L, delta, strides and read noise (lower case, N, '.', IUPAC and junk bytes in
+    the READS, which take the in-kernel fallback)."""
+    rng = np.random.default_rng(7000 + seed)
+    L = int(rng.integers(1, 21))
+    S = int(rng.choice([2, 3, 5, 16, 24, 96, 200, 384, 500]))
+    S = max(2, min(S, 4 ** L // 2))
+    seen = set()
+    while len(seen) < S:
+        seen.add("".join(rng.choice(list("ACGTacgt") if rng.random() < 0.1 else list("ACGT"), size=L)))
+    barcodes = list(seen)
+    if len({b.upper() for b in barcodes}) < S:      # case-insensitive duplicates would be duplicate samples
+        barcodes = sorted({b.upper() for b in barcodes})
+        if len(barcodes) < 2:
+            barcodes = ["A" * L, "C" * L]
+    S = len(barcodes)
+    mm, delta = int(rng.choice([0, 1, 1, 1])), int(rng.choice([0, 1, 2, 2, 3, 255]))
+    m = BarcodeMatcher(barcodes, mm, delta)
+    if m.memo_entries and S * (1 + 4 * L) <= 20000:   # (no Some entry at all, or > LDS capacity: table form)
+        assert m.memo_kind == BarcodeMatcher.MEMO_LDS, (S, L, mm, delta)
+    n = 3000 + int(rng.integers(0, 6000))
+    stride = L + int(rng.choice([0, 0, 0, 1, 3, 4])) if rng.random() < 0.5 else (L + 3) // 4 * 4
+    noise = np.frombuffer(b"ACGTACGTACGTNNacgtn.URYK#", dtype=np.uint8)
+    obs = noise[rng.integers(0, len(noise), size=(n, stride))]
+    src = rng.integers(0, S, size=n)
+    bc = np.stack([np.frombuffer(b.encode(), dtype=np.uint8) for b in barcodes])[src]
+    keep = rng.random((n, L)) < float(rng.choice([0.8, 0.95, 0.99]))
+    obs[:, :L] = np.where(keep, bc, obs[:, :L])
+    _compare(barcodes, mm, delta, obs)
+
+
 def test_ragged_lengths_vs_oracle():
     rng = np.random.default_rng(7)
     barcodes = ["ACGTAC", "TTGCAA", "NNGCAT"]
