@@ -96,10 +96,11 @@ FQTK_HD inline void memo_hash3(uint32_t lo, uint32_t hi, uint32_t ext, uint32_t 
     const uint32_t b = (lo >> 24) | (hi << 8);
     const uint32_t c = (hi >> 16) | (ext << 16);
     const uint32_t d = ext >> 8;
+    // one multiply-add per 24-bit limb, one xor-shift to bring the well-mixed top bits down, one more
+    // multiply for the second word: 3-choice cuckoo at load 0.76 does not need more (the planner
+    // verifies every placement and falls back to the table form if a build ever failed)
     uint32_t h = mul24(a, 0x9E3779u) + mul24(b, 0x85EBCBu) + mul24(c, 0xC2B2AFu) + mul24(d, 0xA54FF5u) + salt;
     h ^= h >> 15;
-    h = mul24(h, 0x2C1B3Du) + (h >> 9);
-    h ^= h >> 13;
     uint32_t g = mul24(h >> 7, 0xD6E8FFu) + h;
     g ^= g >> 14;
     h1 = h; h2 = g; h3 = h >> 15;

@@ -87,17 +87,29 @@ __device__ __forceinline__ void wave_scan(const Planes<NW> &mine, int src, const
     const uint32_t lane = __lane_id();
     best = second = kKeyInit;
     const u32x4 *tab = reinterpret_cast<const u32x4 *>(P.table);
-    for (uint32_t s = lane; s < P.S; s += 64) {
-        uint32_t mm = 0;
+    // four table rows per lane in flight per round (one memory round trip per 256 samples, not per 64)
+    for (uint32_t s0 = lane; s0 < P.S; s0 += 256) {
+        u32x4 e[4][NW];
 #pragma unroll
-        for (int w = 0; w < NW; ++w) {
-            const u32x4 e = tab[(size_t)s * NW + w];
-            const uint32_t m = (pl[w][0] & e.x) | (pl[w][1] & e.y) | (pl[w][2] & e.z) | (pl[w][3] & e.w);
-            mm += __builtin_popcount(m);
+        for (int k = 0; k < 4; ++k) {
+            const uint32_t s = s0 + 64u * k;
+#pragma unroll
+            for (int w = 0; w < NW; ++w) e[k][w] = s < P.S ? tab[(size_t)s * NW + w] : u32x4{0u, 0u, 0u, 0u};
         }
-        const uint32_t key = (mm << 16) | s;
-        second = med3_u32(best, second, key);
-        best = min(best, key);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const uint32_t s = s0 + 64u * k;
+            uint32_t mm = 0;
+#pragma unroll
+            for (int w = 0; w < NW; ++w) {
+                const uint32_t m = (pl[w][0] & e[k][w].x) | (pl[w][1] & e[k][w].y) | (pl[w][2] & e[k][w].z) |
+                                   (pl[w][3] & e[k][w].w);
+                mm += __builtin_popcount(m);
+            }
+            const uint32_t key = s < P.S ? ((mm << 16) | s) : kKeyInit;
+            second = med3_u32(best, second, key);
+            best = min(best, key);
+        }
     }
 #pragma unroll
     for (int off = 1; off < 64; off <<= 1) {   // min / second-min butterfly across the wavefront
