@@ -103,11 +103,16 @@ void lds_memo_kernel(const LdsMemoParams Q) {
     const uint64_t ntiles = (P.n + tile - 1) / tile;
     // per-lane byte offsets inside a tile: loop-invariant, so a full tile's loads and stores are
     // "uniform 64-bit base (SGPRs) + 32-bit lane offset" with no per-read address arithmetic
-    uint32_t in_off[R], out_off[R];
+    // Lane -> read inside a tile is WAVE-CONTIGUOUS: a wave's R loads cover R x 64 consecutive reads (R KiB
+    // in a row at 16 B/read), not R slices a whole workgroup apart.  tools/hbm_stream.hip: the same
+    // 16 B-in / 4 B-out stream with nothing else runs at 5.4 TB/s in this order vs 4.9 TB/s block-strided
+    // (8 B-in: 5.3 vs 3.9 TB/s) -- DRAM locality across the chip's 256 concurrent tiles.
+    uint32_t local[R], in_off[R], out_off[R];
 #pragma unroll
     for (int r = 0; r < R; ++r) {
-        in_off[r] = (uint32_t)(r * kLdsBlock + tid) * P.stride;
-        out_off[r] = (uint32_t)(r * kLdsBlock + tid) * 4u;
+        local[r] = (tid >> 6) * (64u * R) + (uint32_t)r * 64u + (tid & 63u);
+        in_off[r] = local[r] * P.stride;
+        out_off[r] = local[r] * 4u;
     }
     const uint32_t hist_on = (P.counts && P.lds_hist) ? 1u : 0u;
     const uint32_t hist_base_b = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint32_t *)lds_hist;
@@ -138,7 +143,7 @@ void lds_memo_kernel(const LdsMemoParams Q) {
                     words[r][0] = *reinterpret_cast<const uint32_t *>(src);
                 }
             } else {
-                const uint64_t i = t * tile + (uint64_t)r * kLdsBlock + tid;
+                const uint64_t i = t * tile + local[r];
                 live[r] = i < P.n;
 #pragma unroll
                 for (int w = 0; w < 8; ++w) words[r][w] = 0x41414141u;   // dead lanes look like "AAAA"
@@ -224,7 +229,7 @@ void lds_memo_kernel(const LdsMemoParams Q) {
             if constexpr (FULL) {
                 FQTK_STREAM_STORE(res[r], reinterpret_cast<uint32_t *>(reinterpret_cast<uint8_t *>(tile_out) + out_off[r]));
             } else {
-                FQTK_STREAM_STORE(res[r], &P.out[t * tile + (uint64_t)r * kLdsBlock + tid]);
+                FQTK_STREAM_STORE(res[r], &P.out[t * tile + local[r]]);
             }
             if (P.counts) {
                 const uint32_t bin = min(res[r] & 0xFFFFu, P.S);   // None (0xFFFF) -> bin S
