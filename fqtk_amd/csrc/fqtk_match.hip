@@ -100,6 +100,7 @@ struct fqtk_matcher {
     uint32_t *d_ldsm = nullptr;
     fqtk::LdsMemoParams ldsm{};                // image / masks / salt (m is filled per launch)
     int ldsm_kw = 0;
+    bool ldsm_pow2 = true;
     int memo_kind_wanted = 0;                  // 0 = best available, 1 = force the HBM/L2 table (tests, A/B)
     size_t ldsm_lds_bytes = 0;                 // image + LUT (histogram added at launch)
     int use_cache = 1;                       // BarcodeMatcher.use_cache (barcode_matching.rs:41-42)
@@ -175,6 +176,7 @@ int launch_memo_vec(const fqtk_matcher *m, const fqtk::MemoParams &Q, hipStream_
             else if (sw == 2 && base % 8 == 0) vec = 2;
             else if (sw == 1) vec = 1;
             else if (sw == 3) vec = 3;
+            else if (sw == 5) vec = 5;
         }
     }
     // reads per lane: 4 on the vector-load paths (every such variant stays inside 64 VGPRs = 8
@@ -182,6 +184,7 @@ int launch_memo_vec(const fqtk_matcher *m, const fqtk::MemoParams &Q, hipStream_
     // on cfg 2/3/4), 2 there for very large tables, where more probes in flight only add cache
     // pressure, and 1 on the generic paths (4 would spill)
     int R = vec > 0 ? (m->memo_entries <= 65536 ? 4 : 2) : 1;
+    if (vec == 5) R = 2;   // 20-byte reads: 4 per lane would spill at 64 VGPRs
     int abl = 0;
 #ifdef FQTK_DEV_ABLATE
     if (const char *rr = std::getenv("FQTK_MEMO_R")) R = std::atoi(rr);
@@ -202,7 +205,7 @@ int launch_memo_vec(const fqtk_matcher *m, const fqtk::MemoParams &Q, hipStream_
     // the packed vector paths imply the key width (stride 16 B -> 2 key words, 12 B -> 1 or 2, 8/4 B -> 1)
 #define FQTK_MEMO_LAUNCH(V, RR, A)                                                                         \
     do {                                                                                                   \
-        if constexpr ((V) <= 0 || ((V) == 3 && KW <= 2) || KW == ((V) == 4 ? 2 : 1))                       \
+        if constexpr ((V) <= 0 || ((V) == 3 && KW <= 2) || KW == ((V) == 5 ? 3 : ((V) == 4 ? 2 : 1)))      \
             hipLaunchKernelGGL((fqtk::memo_kernel<V, KW, RR, A>), dim3(grid), dim3(fqtk::kBlock), shmem,   \
                                stream, Q);                                                                 \
         else                                                                                               \
@@ -210,6 +213,7 @@ int launch_memo_vec(const fqtk_matcher *m, const fqtk::MemoParams &Q, hipStream_
     } while (0)
 #define FQTK_MEMO_BY_VEC(RR, A)                         \
     switch (vec) {                                      \
+        case 5: FQTK_MEMO_LAUNCH(5, RR, A); break;      \
         case 4: FQTK_MEMO_LAUNCH(4, RR, A); break;      \
         case 3: FQTK_MEMO_LAUNCH(3, RR, A); break;      \
         case 2: FQTK_MEMO_LAUNCH(2, RR, A); break;      \
@@ -244,7 +248,7 @@ int launch_memo_vec(const fqtk_matcher *m, const fqtk::MemoParams &Q, hipStream_
     return FQTK_OK;
 }
 
-template <int KW>
+template <int KW, bool POW2>
 int launch_lds_memo(const fqtk_matcher *m, fqtk::LdsMemoParams Q, hipStream_t stream) {
     const fqtk::MatchParams &P = Q.m;
     const uintptr_t base = reinterpret_cast<uintptr_t>(P.obs);
@@ -258,6 +262,7 @@ int launch_lds_memo(const fqtk_matcher *m, fqtk::LdsMemoParams Q, hipStream_t st
             else if (sw == 2 && base % 8 == 0) vec = 2;
             else if (sw == 1) vec = 1;
             else if (sw == 3) vec = 3;
+            else if (sw == 5) vec = 5;
         }
     }
     size_t shmem = m->ldsm_lds_bytes;
@@ -275,8 +280,8 @@ int launch_lds_memo(const fqtk_matcher *m, fqtk::LdsMemoParams Q, hipStream_t st
     const uint32_t grid = (uint32_t)std::min<uint64_t>(ntiles, (uint64_t)m->num_cus * per_cu);
 #define FQTK_LDSM_LAUNCH(V, RR)                                                                            \
     do {                                                                                                   \
-        if constexpr ((V) <= 0 || KW == ((V) >= 3 ? 2 : 1)) {                                              \
-            auto kern = fqtk::lds_memo_kernel<V, KW, RR>;                                                  \
+        if constexpr ((V) <= 0 || KW == ((V) == 5 ? 3 : ((V) >= 3 ? 2 : 1))) {                             \
+            auto kern = fqtk::lds_memo_kernel<V, KW, RR, POW2>;                                                  \
             static std::atomic<size_t> allowed{64 * 1024};                                                 \
             if (shmem > allowed.load()) {                                                                  \
                 HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),                          \
@@ -298,13 +303,16 @@ int launch_lds_memo(const fqtk_matcher *m, fqtk::LdsMemoParams Q, hipStream_t st
 #endif
     if (R >= 4 && vec > 0) {
         switch (vec) {
+            case 5: FQTK_LDSM_LAUNCH(5, 4); break;
             case 4: FQTK_LDSM_LAUNCH(4, 4); break;
             case 3: FQTK_LDSM_LAUNCH(3, 4); break;
             case 2: FQTK_LDSM_LAUNCH(2, 4); break;
             default: FQTK_LDSM_LAUNCH(1, 4); break;
         }
+#ifdef FQTK_DEV_ABLATE
     } else if (R >= 2) {
         switch (vec) {
+            case 5: FQTK_LDSM_LAUNCH(5, 2); break;
             case 4: FQTK_LDSM_LAUNCH(4, 2); break;
             case 3: FQTK_LDSM_LAUNCH(3, 2); break;
             case 2: FQTK_LDSM_LAUNCH(2, 2); break;
@@ -312,8 +320,10 @@ int launch_lds_memo(const fqtk_matcher *m, fqtk::LdsMemoParams Q, hipStream_t st
             case -1: FQTK_LDSM_LAUNCH(-1, 2); break;
             default: FQTK_LDSM_LAUNCH(0, 2); break;
         }
+#endif
     } else {
         switch (vec) {
+            case 5: FQTK_LDSM_LAUNCH(5, 1); break;
             case 4: FQTK_LDSM_LAUNCH(4, 1); break;
             case 3: FQTK_LDSM_LAUNCH(3, 1); break;
             case 2: FQTK_LDSM_LAUNCH(2, 1); break;
@@ -332,10 +342,13 @@ int launch(const fqtk_matcher *m, const fqtk::MatchParams &P, hipStream_t stream
     if (m->use_cache && m->d_ldsm && !P.lens && m->memo_kind_wanted != 1) {
         fqtk::LdsMemoParams Q = m->ldsm;
         Q.m = P;
-        switch (m->ldsm_kw) {
-            case 1: return launch_lds_memo<1>(m, Q, stream);
-            case 2: return launch_lds_memo<2>(m, Q, stream);
-            default: return launch_lds_memo<3>(m, Q, stream);
+        switch (m->ldsm_kw * 2 + (m->ldsm_pow2 ? 1 : 0)) {
+            case 3: return launch_lds_memo<1, true>(m, Q, stream);
+            case 2: return launch_lds_memo<1, false>(m, Q, stream);
+            case 5: return launch_lds_memo<2, true>(m, Q, stream);
+            case 4: return launch_lds_memo<2, false>(m, Q, stream);
+            case 7: return launch_lds_memo<3, true>(m, Q, stream);
+            default: return launch_lds_memo<3, false>(m, Q, stream);
         }
     }
     if (m->use_cache && m->d_memo && !P.lens) {
@@ -479,6 +492,8 @@ int build_lds_memo(fqtk_matcher *m, const std::vector<fqtk::LdsEntry> &ents,
     HIP_TRY(hipMemcpy(m->d_ldsm, plan.image.data(), plan.image.size() * 4, hipMemcpyHostToDevice));
     m->ldsm.image = m->d_ldsm;
     m->ldsm.slot_mask_b = plan.slot_mask_b;
+    m->ldsm.n_slots = plan.n_slots;
+    m->ldsm_pow2 = plan.pow2;
     m->ldsm.idx_bits = plan.idx_bits;
     m->ldsm.image_words = (uint32_t)plan.image.size();
     m->ldsm.skey_off_b = plan.skey_off_b;

@@ -38,7 +38,8 @@ constexpr int kLdsBlock = 1024;
 struct LdsMemoParams {
     MatchParams m;
     const uint32_t *image;    // [n_slots] entries, then (S + 1) sample keys of key_stride words each
-    uint32_t slot_mask_b;     // (n_slots - 1) << 2: byte-address mask of the entry table
+    uint32_t slot_mask_b;     // (n_slots - 1) << 2: byte-address mask of the entry table (power-of-two tables)
+    uint32_t n_slots;         // slot count (any-size tables: slot = hash16 * n_slots >> 16)
     uint32_t idx_bits;        // IB
     uint32_t image_words;     // dwords to stage into LDS
     uint32_t skey_off_b;      // byte offset of the sample keys inside LDS
@@ -65,7 +66,7 @@ __device__ __forceinline__ uint32_t lane_select(uint64_t mask, uint32_t a, uint3
     return d;
 }
 
-template <int VEC, int KW, int R>
+template <int VEC, int KW, int R, bool POW2>
 __global__ __launch_bounds__(kLdsBlock) __attribute__((amdgpu_waves_per_eu(4, 8)))
 void lds_memo_kernel(const LdsMemoParams Q) {
     const MatchParams &P = Q.m;
@@ -136,6 +137,10 @@ void lds_memo_kernel(const LdsMemoParams Q) {
                 } else if constexpr (VEC == 3) {
                     const uint32_t *s32 = reinterpret_cast<const uint32_t *>(src);
                     words[r][0] = s32[0]; words[r][1] = s32[1]; words[r][2] = s32[2];
+                } else if constexpr (VEC == 5) {
+                    const uint32_t *s32 = reinterpret_cast<const uint32_t *>(src);
+                    words[r][0] = s32[0]; words[r][1] = s32[1]; words[r][2] = s32[2];
+                    words[r][3] = s32[3]; words[r][4] = s32[4];
                 } else if constexpr (VEC == 2) {
                     const u32x2v v = FQTK_STREAM_LOAD(reinterpret_cast<const u32x2v *>(src));
                     words[r][0] = v.x; words[r][1] = v.y;
@@ -178,8 +183,10 @@ void lds_memo_kernel(const LdsMemoParams Q) {
             encode_nibbles<NWD, (VEC >= 1), false>(words[r], kc, kv, lo[r], hi[r], ext[r], bflag[r]);
             uint32_t h1, h2, h3, fps;
             memo_hash3(lo[r], KW >= 2 ? hi[r] : 0u, KW >= 3 ? ext[r] : 0u, Q.salt, h1, h2, h3, fps);
-            const uint32_t e1 = lds_word(h1 & Q.slot_mask_b), e2 = lds_word(h2 & Q.slot_mask_b),
-                           e3 = lds_word(h3 & Q.slot_mask_b);
+            (void)h3;
+            uint32_t a1, a2, a3;
+            lds_slots(POW2, h1, h2, Q.slot_mask_b, Q.n_slots, a1, a2, a3);
+            const uint32_t e1 = lds_word(a1), e2 = lds_word(a2), e3 = lds_word(a3);
             // fingerprint matches as LANE MASKS (SGPR pairs): the "more than one match" test below is
             // then scalar ALU + one scalar branch instead of per-lane selects
             const uint64_t M1 = __builtin_amdgcn_uicmp((e1 ^ fps) & fp_mask, 0u, 32 /* eq */);

@@ -22,6 +22,7 @@ struct LdsMemoPlan {
     bool ok = false;
     std::vector<uint32_t> image;   // n_slots entry dwords, then (S + 1) sample keys (key_stride dwords each)
     uint32_t n_slots = 0;
+    bool pow2 = true;              // slot = hash & mask; false: slot = hash16 * n_slots >> 16 (lds_slot_any)
     uint32_t slot_mask_b = 0;      // (n_slots - 1) << 2
     uint32_t idx_bits = 0;
     uint32_t skey_off_b = 0;
@@ -38,8 +39,10 @@ inline uint32_t lds_memo_lookup(const LdsMemoPlan &p, const uint32_t key[3]) {
     uint32_t h[3], fps;
     memo_hash3(key[0], key[1], key[2], p.salt, h[0], h[1], h[2], fps);
     const uint32_t fp_mask = lds_fp_mask(p.idx_bits, p.kw);
+    uint32_t a[3];
+    lds_slots(p.pow2, h[0], h[1], p.slot_mask_b, p.n_slots, a[0], a[1], a[2]);
     for (int c = 0; c < 3; ++c) {
-        const uint32_t e = p.image[(h[c] & p.slot_mask_b) >> 2];
+        const uint32_t e = p.image[a[c] >> 2];
         if ((e ^ fps) & fp_mask) continue;
         const uint32_t idx = e & ((1u << p.idx_bits) - 1u), pos = lds_entry_pos(e, p.kw), xnib = (e >> 17) & 7u;
         const uint32_t *sk = &p.image[(p.skey_off_b >> 2) + (size_t)idx * p.key_stride];
@@ -93,6 +96,16 @@ inline LdsMemoPlan plan_lds_memo(uint32_t S, uint32_t L, const std::vector<LdsEn
     uint64_t nslots = 256;
     while ((double)nslots * 0.86 < (double)ents.size()) nslots <<= 1;
     const size_t fixed = skeys.size() * 4 + 1024 + (size_t)(S + 1) * 4;   // keys + LUT + histogram
+    bool pow2 = true;
+    if (nslots * 4 + fixed > kLdsMemoMaxBytes) {
+        // the power of two does not fit one CU's LDS: take every slot that does (multiply-shift slot
+        // mapping in the kernel, a few more VALU ops per read) if that leaves the cuckoo table <= 0.88 full
+        const uint64_t room = (kLdsMemoMaxBytes - fixed) / 4;
+        nslots = room < 65535 ? room : 65535;
+        nslots &= ~3ull;                                   // keep the sample keys 16-byte aligned
+        pow2 = false;
+        if ((double)nslots * 0.88 < (double)ents.size()) return plan;
+    }
     std::vector<int64_t> owner;
     std::vector<uint32_t> h(ents.size() * 3), fps(ents.size());
     // The salt matters for speed, not only for feasibility.  Most reads ARE a sample barcode, so nearly
@@ -105,13 +118,17 @@ inline LdsMemoPlan plan_lds_memo(uint32_t S, uint32_t L, const std::vector<LdsEn
     uint64_t best_score = ~0ull;
     int successes = 0, failures = 0;
     for (int attempt = 0; attempt < 12 + kSaltTrials && successes < kSaltTrials; ++attempt) {
-        if (nslots * 4 + fixed > kLdsMemoMaxBytes || nslots > 32768) break;   // does not fit one CU's LDS
-        const uint32_t mask_b = (uint32_t)(nslots - 1) << 2;
+        if (nslots * 4 + fixed > kLdsMemoMaxBytes || (pow2 && nslots > 32768)) break;   // does not fit one CU's LDS
+        const uint32_t mask_b = pow2 ? (uint32_t)(nslots - 1) << 2 : 0u;
         const uint32_t salt = 0x51ED27u * (uint32_t)(attempt + 1 + salt_offset);
         owner.assign(nslots, -1);
         for (size_t i = 0; i < ents.size(); ++i)
             memo_hash3(ents[i].k[0], ents[i].k[1], ents[i].k[2], salt, h[3 * i], h[3 * i + 1], h[3 * i + 2], fps[i]);
-        auto slot_of = [&](size_t i, int c) { return (h[3 * i + c] & mask_b) >> 2; };
+        auto slot_of = [&](size_t i, int c) {
+            uint32_t a[3];
+            lds_slots(pow2, h[3 * i], h[3 * i + 1], mask_b, (uint32_t)nslots, a[0], a[1], a[2]);
+            return a[c] >> 2;
+        };
         auto fp_of = [&](size_t i) { return fps[i] & fp_mask; };
         uint64_t rng = 0x9E3779B97F4A7C15ull ^ salt;
         auto next_rand = [&]() { rng = rng * 6364136223846793005ull + 1442695040888963407ull; return (uint32_t)(rng >> 33); };
@@ -140,6 +157,7 @@ inline LdsMemoPlan plan_lds_memo(uint32_t S, uint32_t L, const std::vector<LdsEn
                 if (owner[p] >= 0) plan.image[p] = fields[(size_t)owner[p]] | fp_of((size_t)owner[p]);
             plan.image.insert(plan.image.end(), skeys.begin(), skeys.end());
             plan.n_slots = (uint32_t)nslots;
+            plan.pow2 = pow2;
             plan.slot_mask_b = mask_b;
             plan.idx_bits = idx_bits;
             plan.skey_off_b = (uint32_t)(nslots * 4);
@@ -167,7 +185,7 @@ inline LdsMemoPlan plan_lds_memo(uint32_t S, uint32_t L, const std::vector<LdsEn
                 continue;
             }
         }
-        if (successes == 0 && ++failures % 3 == 0) nslots <<= 1;
+        if (successes == 0 && ++failures % 3 == 0) { if (!pow2) break; nslots <<= 1; }
     }
     return best;
 }

@@ -116,7 +116,7 @@ typedef uint32_t u32x2v __attribute__((ext_vector_type(2)));
 #endif
 
 // Load the first ceil(L/4) dwords of read `i`.  VEC = stride in dwords when the fast, aligned vector
-// path applies (1,2,3,4), 0 = generic byte path (any stride / alignment).
+// path applies (1,2,3,4,5), 0 = generic byte path (any stride / alignment).
 template <int NW, int VEC>
 __device__ __forceinline__ void load_words(const MatchParams &P, uint64_t i, uint32_t nwords,
                                            uint32_t (&words)[NW * 8]) {
@@ -132,6 +132,9 @@ __device__ __forceinline__ void load_words(const MatchParams &P, uint64_t i, uin
     } else if constexpr (VEC == 3) {
         const uint32_t *s32 = reinterpret_cast<const uint32_t *>(src);
         words[0] = s32[0]; words[1] = s32[1]; words[2] = s32[2];
+    } else if constexpr (VEC == 5) {   // 20-byte reads (10+10 dual index): rows are only 4-byte aligned
+        const uint32_t *s32 = reinterpret_cast<const uint32_t *>(src);
+        words[0] = s32[0]; words[1] = s32[1]; words[2] = s32[2]; words[3] = s32[3]; words[4] = s32[4];
     } else if constexpr (VEC == -1) {   // stride % 4 == 0, base 4-aligned, any length
 #pragma unroll
         for (int w = 0; w < NW * 8; ++w)

@@ -103,12 +103,22 @@ FQTK_HD inline void memo_hash3(uint32_t lo, uint32_t hi, uint32_t ext, uint32_t 
     h ^= h >> 15;
     uint32_t g = mul24(h >> 7, 0xD6E8FFu) + h;
     g ^= g >> 14;
-    h1 = h; h2 = g; h3 = h >> 15;
+    h1 = h; h2 = g; h3 = h >> 15;   // (power-of-two tables; lds_slot_any below reads h and g directly)
 #if defined(__HIP_DEVICE_COMPILE__)
     fp_src = __builtin_amdgcn_perm(g, g, 0x02000302u);   // bytes: g.b2, g.b3, g.b0, g.b2
 #else
     fp_src = (g >> 16) | ((g & 0xFFu) << 16) | (((g >> 16) & 0xFFu) << 24);
 #endif
+}
+
+// Slot byte addresses.  Power-of-two tables mask the hash words (memo_hash3's h1/h2/h3 & slot_mask_b).
+// Any other slot count n (< 2^16; used when the next power of two would not fit LDS) maps a 16-bit
+// hash piece x to floor(x * n / 2^16) with one 24-bit multiply: pieces h[0..15], g[0..15], h[16..31].
+FQTK_HD inline uint32_t lds_slot_any(uint32_t x16, uint32_t n_slots) { return (mul24(x16, n_slots) >> 14) & ~3u; }
+FQTK_HD inline void lds_slots(bool pow2, uint32_t h, uint32_t g, uint32_t slot_mask_b, uint32_t n_slots,
+                              uint32_t &a1, uint32_t &a2, uint32_t &a3) {
+    if (pow2) { a1 = h & slot_mask_b; a2 = g & slot_mask_b; a3 = (h >> 15) & slot_mask_b; }
+    else { a1 = lds_slot_any(h & 0xFFFFu, n_slots); a2 = lds_slot_any(g & 0xFFFFu, n_slots); a3 = lds_slot_any(h >> 16, n_slots); }
 }
 
 }  // namespace fqtk

@@ -158,6 +158,27 @@ def test_memo_kind_selection():
         m.memo_kind = 7
 
 
+def test_lds_form_with_any_size_table_384_samples_x_20_bases():
+    """10+10 dual index, 384 samples: 31 104 memo entries need more than 32 768 slots; the LDS form then
+    uses every slot that fits (multiply-shift slot mapping).  Packed and padded strides."""
+    rng = np.random.default_rng(2020)
+    seen = set()
+    while len(seen) < 384:
+        seen.add("".join(rng.choice(list("ACGT"), size=20)))
+    bcs = sorted(seen)
+    m = BarcodeMatcher(bcs, 1, 2)
+    assert m.memo_kind == BarcodeMatcher.MEMO_LDS and m.memo_entries > 29000
+    n = 20011
+    noise = np.frombuffer(b"ACGTNacgtn.R", dtype=np.uint8)
+    for stride in (20, 24, 21):
+        obs = noise[rng.integers(0, len(noise), size=(n, stride))]
+        src = rng.integers(0, 384, size=n)
+        bc = np.stack([np.frombuffer(b.encode(), dtype=np.uint8) for b in bcs])[src]
+        keep = rng.random((n, 20)) < 0.97
+        obs[:, :20] = np.where(keep, bc, obs[:, :20])
+        _compare(bcs, 1, 2, obs)
+
+
 def test_memo_path_handles_non_canonical_reads_in_every_lane_position():
     """IUPAC / unknown bytes in the READ cannot use the memo: the wave-cooperative fallback must give
     the scan kernel's answer wherever such reads sit in the wavefront, including all 64 lanes."""

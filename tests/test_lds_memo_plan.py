@@ -109,3 +109,26 @@ def test_all_key_widths(L):
     idx, best, nxt, _ = O.RefLiteral(barcodes, 1, 1, True).assign_batch(rnd)
     want = np.where(idx == O.NONE_IDX, NONE, idx.astype(np.uint32) | (best.astype(np.uint32) << 16) | (nxt.astype(np.uint32) << 24)).astype(np.uint32)
     assert np.array_equal(_lookup(meta, image, _keys(rnd)), want)
+
+
+def test_table_that_needs_every_lds_slot_uses_the_any_size_mapping():
+    """384 samples x 20 bases (10+10 dual index): 31 104 entries do not fit 32 768 slots at a workable
+    load, and 65 536 slots do not fit LDS; the planner then takes every slot LDS has room for and the
+    multiply-shift slot mapping (meta[8] = pow2 flag = 0)."""
+    rng = np.random.default_rng(20)
+    seen = set()
+    while len(seen) < 384:
+        seen.add("".join(rng.choice(list("ACGT"), size=20)))
+    barcodes = sorted(seen)
+    meta, image, cand, keys, vals = _plan(barcodes, 1, 2)
+    assert meta[0] == 1 and meta[8] == 0 and 32768 < meta[1] < 65536
+    assert int(meta[9]) * 4 + 1024 + 385 * 4 <= 160 * 1024
+    assert len(vals) > 0.86 * 32768
+    assert np.array_equal(_lookup(meta, image, keys), vals)
+    rnd = np.frombuffer(b"ACGTN", dtype=np.uint8)[rng.integers(0, 5, size=(20000, 20))]
+    near = cand[rng.integers(0, len(cand), 20000)].copy()
+    near[np.arange(20000), rng.integers(0, 20, 20000)] = np.frombuffer(b"ACGTN", dtype=np.uint8)[rng.integers(0, 5, 20000)]
+    probe = np.concatenate([rnd, near])
+    idx, best, nxt, _ = O.RefLiteral(barcodes, 1, 2, True).assign_batch(probe)
+    want = np.where(idx == O.NONE_IDX, NONE, idx.astype(np.uint32) | (best.astype(np.uint32) << 16) | (nxt.astype(np.uint32) << 24)).astype(np.uint32)
+    assert np.array_equal(_lookup(meta, image, _keys(probe)), want)
