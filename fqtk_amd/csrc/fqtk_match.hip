@@ -268,7 +268,8 @@ int launch_lds_memo(const fqtk_matcher *m, fqtk::LdsMemoParams Q, hipStream_t st
     size_t shmem = m->ldsm_lds_bytes;
     if (P.counts && P.lds_hist) shmem += (size_t)(P.S + 1) * sizeof(uint32_t);
     if (shmem > fqtk::kLdsMemoMaxBytes) return fail(FQTK_EINVAL, "lds memo: table does not fit LDS");
-    int R = vec > 0 ? 4 : 1;
+    // reads per lane on the packed paths: 4 (8-byte keys: +15 % over 2), 2 for 16-byte keys (+1-2 % over 4)
+    int R = vec > 0 ? (KW == 2 ? 2 : 4) : 1;
 #ifdef FQTK_DEV_ABLATE
     if (const char *rr = std::getenv("FQTK_MEMO_R")) R = std::atoi(rr);
 #endif
@@ -276,7 +277,7 @@ int launch_lds_memo(const fqtk_matcher *m, fqtk::LdsMemoParams Q, hipStream_t st
     const uint64_t ntiles = (P.n + tile - 1) / tile;
     if (ntiles == 0) return FQTK_OK;
     // workgroups per CU: LDS-limited, and never more than 2 x 1024 lanes
-    const uint32_t per_cu = (uint32_t)std::max<size_t>(1, std::min<size_t>(2, fqtk::kLdsMemoMaxBytes / (shmem + 1024)));
+    const uint32_t per_cu = (uint32_t)std::max<size_t>(1, std::min<size_t>(2048 / fqtk::kLdsBlock, fqtk::kLdsMemoMaxBytes / (shmem + 1024)));
     const uint32_t grid = (uint32_t)std::min<uint64_t>(ntiles, (uint64_t)m->num_cus * per_cu);
 #define FQTK_LDSM_LAUNCH(V, RR)                                                                            \
     do {                                                                                                   \
@@ -309,7 +310,6 @@ int launch_lds_memo(const fqtk_matcher *m, fqtk::LdsMemoParams Q, hipStream_t st
             case 2: FQTK_LDSM_LAUNCH(2, 4); break;
             default: FQTK_LDSM_LAUNCH(1, 4); break;
         }
-#ifdef FQTK_DEV_ABLATE
     } else if (R >= 2) {
         switch (vec) {
             case 5: FQTK_LDSM_LAUNCH(5, 2); break;
@@ -320,7 +320,6 @@ int launch_lds_memo(const fqtk_matcher *m, fqtk::LdsMemoParams Q, hipStream_t st
             case -1: FQTK_LDSM_LAUNCH(-1, 2); break;
             default: FQTK_LDSM_LAUNCH(0, 2); break;
         }
-#endif
     } else {
         switch (vec) {
             case 5: FQTK_LDSM_LAUNCH(5, 1); break;

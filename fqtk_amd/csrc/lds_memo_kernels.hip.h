@@ -34,7 +34,10 @@
 
 namespace fqtk {
 
-constexpr int kLdsBlock = 1024;
+#ifndef FQTK_LDS_BLOCK
+#define FQTK_LDS_BLOCK 1024
+#endif
+constexpr int kLdsBlock = FQTK_LDS_BLOCK;
 struct LdsMemoParams {
     MatchParams m;
     const uint32_t *image;    // [n_slots] entries, then (S + 1) sample keys of key_stride words each
