@@ -101,6 +101,7 @@ struct fqtk_matcher {
     fqtk::LdsMemoParams ldsm{};                // image / masks / salt (m is filled per launch)
     int ldsm_kw = 0;
     bool ldsm_pow2 = true;
+    mutable std::vector<const void *> ldsm_big_lds_ok;   // kernels already allowed > 64 KiB LDS on this device
     int memo_kind_wanted = 0;                  // 0 = best available, 1 = force the HBM/L2 table (tests, A/B)
     size_t ldsm_lds_bytes = 0;                 // image + LUT (histogram added at launch)
     int use_cache = 1;                       // BarcodeMatcher.use_cache (barcode_matching.rs:41-42)
@@ -283,12 +284,13 @@ int launch_lds_memo(const fqtk_matcher *m, fqtk::LdsMemoParams Q, hipStream_t st
     do {                                                                                                   \
         if constexpr ((V) <= 0 || KW == ((V) == 5 ? 3 : ((V) >= 3 ? 2 : 1))) {                             \
             auto kern = fqtk::lds_memo_kernel<V, KW, RR, POW2>;                                                  \
-            static std::atomic<size_t> allowed{64 * 1024};                                                 \
-            if (shmem > allowed.load()) {                                                                  \
-                HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),                          \
-                                            hipFuncAttributeMaxDynamicSharedMemorySize,                    \
+            /* > 64 KiB of dynamic LDS must be allowed per kernel AND per device: remembered per matcher */ \
+            const void *fn = reinterpret_cast<const void *>(kern);                                         \
+            if (shmem > 64 * 1024 &&                                                                       \
+                std::find(m->ldsm_big_lds_ok.begin(), m->ldsm_big_lds_ok.end(), fn) == m->ldsm_big_lds_ok.end()) { \
+                HIP_TRY(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize,                \
                                             (int)fqtk::kLdsMemoMaxBytes));                                 \
-                allowed.store(fqtk::kLdsMemoMaxBytes);                                                     \
+                m->ldsm_big_lds_ok.push_back(fn);                                                          \
             }                                                                                              \
             hipLaunchKernelGGL(kern, dim3(grid), dim3(fqtk::kLdsBlock), shmem, stream, Q);                \
         } else {                                                                                           \
