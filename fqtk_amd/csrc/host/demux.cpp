@@ -194,6 +194,7 @@ class BoundedQueue {
     explicit BoundedQueue(size_t cap) : cap_(cap) {}
     void push(T v) {
         std::unique_lock<std::mutex> lk(mu_);
+        if (q_.size() >= cap_) ++full_waits;
         not_full_.wait(lk, [&] { return q_.size() < cap_; });
         q_.push_back(std::move(v));
         not_empty_.notify_one();
@@ -206,6 +207,7 @@ class BoundedQueue {
         not_full_.notify_one();
         return v;
     }
+    uint64_t full_waits = 0;   // pushes that found the queue full (FQTK_TIMING report)
   private:
     size_t cap_;
     std::mutex mu_;
@@ -240,6 +242,7 @@ struct OutFile {
 
 struct StageTimes {   // FQTK_TIMING=1: where the host threads spend their time (seconds, summed over threads)
     std::atomic<uint64_t> router_wait{0}, router_format{0}, router_submit{0}, comp_wait{0}, comp_deflate{0}, comp_write{0};
+    std::atomic<uint64_t> submit_calls{0}, submit_cut{0}, submit_push{0};
 };
 StageTimes g_times;
 bool g_timing = false;
@@ -262,20 +265,51 @@ struct Plan {
 const SegType kTypes[4] = {SegType::Template, SegType::SampleBarcode, SegType::MolecularBarcode, SegType::CellularBarcode};
 const char kCodes[4] = {'R', 'I', 'U', 'C'};
 
+// Block buffers travel router -> compressor -> back: allocating and freeing a 64 KiB string per block
+// across threads was the routers' largest cost (glibc arena traffic), so they are recycled.
+class BufferPool {
+  public:
+    std::string get() {
+        std::lock_guard<std::mutex> lk(mu_);
+        if (free_.empty()) { std::string s; s.reserve(kBgzfBlockSize + 4096); return s; }
+        std::string s = std::move(free_.back());
+        free_.pop_back();
+        return s;
+    }
+    void put(std::string &&s) {
+        s.clear();
+        std::lock_guard<std::mutex> lk(mu_);
+        if (free_.size() < 4096) free_.push_back(std::move(s));
+    }
+  private:
+    std::mutex mu_;
+    std::vector<std::string> free_;
+};
+BufferPool g_pool;
+
 // Router side: cut full 65280-byte blocks (or the final partial one) off the file's buffer and hand
-// them to the compression pool.  Sequence numbers keep the file's block order.
-void submit_blocks(OutFile &of, BoundedQueue<CompressJob> &jobs, bool final) {
-    size_t off = 0;
-    while (of.buf.size() - off >= kBgzfBlockSize || (final && off < of.buf.size())) {
-        const size_t n = std::min(kBgzfBlockSize, of.buf.size() - off);
+// them to the compression pool.  Sequence numbers keep the file's block order.  The file's buffer itself
+// becomes the job (no copy of the block): only the few hundred bytes past the cut move to a fresh buffer.
+using JobQueues = std::vector<std::unique_ptr<BoundedQueue<CompressJob>>>;   // one per compressor thread
+void submit_blocks(OutFile &of, JobQueues &jobs, bool final) {
+    while (of.buf.size() >= kBgzfBlockSize || (final && !of.buf.empty())) {
+        const uint64_t ta = tick();
+        const size_t n = std::min(kBgzfBlockSize, of.buf.size());
+        std::string rest = g_pool.get();
+        rest.assign(of.buf, n, std::string::npos);
+        of.buf.resize(n);
         CompressJob j;
         j.of = &of;
         j.seq = of.next_submit++;
-        j.data.assign(of.buf, off, n);
-        jobs.push(std::move(j));
-        off += n;
+        j.data = std::move(of.buf);
+        of.buf = std::move(rest);
+        // one queue per compressor (a single shared queue was a lock convoy at 30+ threads); blocks of a
+        // file go round-robin over them, so uneven sample sizes do not unbalance the compressors
+        const size_t q = (reinterpret_cast<uintptr_t>(&of) / sizeof(OutFile) + j.seq) % jobs.size();
+        const uint64_t tb = tick();
+        jobs[q]->push(std::move(j));
+        if (g_timing) { g_times.submit_calls += 1; g_times.submit_cut += tb - ta; g_times.submit_push += tick() - tb; }
     }
-    of.buf.erase(0, off);
 }
 
 // Pool side: compress one block, then write it -- and any successors already waiting -- in order.
@@ -461,17 +495,24 @@ int main(int argc, char **argv) {
     const size_t n_threads_c = std::max<size_t>(2, opt.threads - 1);
     const size_t n_workers = std::max<size_t>(1, n_threads_c / 3);          // routers
     const size_t n_comp = std::max<size_t>(1, n_threads_c - n_workers);     // compressors
-    BoundedQueue<CompressJob> jobs(n_comp * 8);
+    // Output files fill in lock-step (samples are hit in proportion, so hundreds of files reach a full
+    // 64 KiB block within the same few chunks): the queue must absorb such a burst or the routers stall
+    // on it while the compressors idle between bursts (measured: 1 push in 26 found a 73-deep queue full
+    // and waited 4 ms).
+    JobQueues jobs;
+    for (size_t c = 0; c < n_comp; ++c)
+        jobs.push_back(std::make_unique<BoundedQueue<CompressJob>>(std::max<size_t>(64, 8192 / n_comp)));   // <= 512 MiB of blocks in flight
     std::vector<std::thread> compressors;
     for (size_t c = 0; c < n_comp; ++c)
-        compressors.emplace_back([&] {
+        compressors.emplace_back([&, c] {
             BlockCompressor bc((int)opt.compression_level);
             for (;;) {
                 const uint64_t t0 = tick();
-                CompressJob j = jobs.pop();
+                CompressJob j = jobs[c]->pop();
                 g_times.comp_wait += tick() - t0;
                 if (!j.of) break;
                 compress_and_write(j, bc);
+                g_pool.put(std::move(j.data));
             }
         });
     std::vector<std::unique_ptr<BoundedQueue<std::shared_ptr<Chunk>>>> wq;
@@ -666,7 +707,7 @@ int main(int argc, char **argv) {
     info("Finished reading input FASTQs.");
     for (size_t w = 0; w < n_workers; ++w) wq[w]->push(nullptr);
     for (auto &t : workers) t.join();
-    for (size_t c = 0; c < n_comp; ++c) jobs.push(CompressJob{});
+    for (size_t c = 0; c < n_comp; ++c) jobs[c]->push(CompressJob{});
     for (auto &t : compressors) t.join();
     for (OutFile &of : outs) {   // every block is on disk: terminate the BGZF streams
         if (!of.ready.empty() || of.next_write != of.next_submit) die("internal error: unwritten blocks in " + of.path);
@@ -679,6 +720,13 @@ int main(int argc, char **argv) {
         info("thread-seconds: routers(%zu) wait %.2f format %.2f submit %.2f | compressors(%zu) wait %.2f deflate %.2f write %.2f",
              n_workers, g_times.router_wait / 1e9, g_times.router_format / 1e9, g_times.router_submit / 1e9, n_comp,
              g_times.comp_wait / 1e9, g_times.comp_deflate / 1e9, g_times.comp_write / 1e9);
+    {
+        uint64_t fw = 0;
+        for (auto &q : jobs) fw += q->full_waits;
+        if (g_timing)
+            info("submit: %llu blocks, cut %.2f s, push %.2f s, %llu pushes found their queue full", (unsigned long long)g_times.submit_calls.load(),
+                 g_times.submit_cut / 1e9, g_times.submit_push / 1e9, (unsigned long long)fw);
+    }
     if (skipped == 0) info("No records were skipped.");
     else info("%llu records were skipped due to Too few bases", (unsigned long long)skipped);
 
