@@ -102,15 +102,19 @@ class FastqSource {
                        std::to_string(nrec_) + " of " + path_;
                 return false;
             }
+            // one copy per record: the four lines are contiguous in the read buffer, so the whole span from
+            // the header (after '@') to the end of the quality line goes over as is; offsets skip the rest
             FastqRec r;
-            r.head_off = (uint32_t)out->data.size();
+            const char *rec0 = line[0].data() + 1;
+            const size_t span = (size_t)(line[3].data() + line[3].size() - rec0);
+            const size_t base = out->data.size();
+            if (base == 0) out->data.reserve(std::min<size_t>(max_records, 1u << 20) * (span + 16));
+            out->data.insert(out->data.end(), rec0, rec0 + span);
+            r.head_off = (uint32_t)base;
             r.head_len = (uint32_t)line[0].size() - 1;
-            out->data.insert(out->data.end(), line[0].begin() + 1, line[0].end());
-            r.seq_off = (uint32_t)out->data.size();
+            r.seq_off = (uint32_t)(base + (size_t)(line[1].data() - rec0));
             r.seq_len = (uint32_t)line[1].size();
-            out->data.insert(out->data.end(), line[1].begin(), line[1].end());
-            r.qual_off = (uint32_t)out->data.size();
-            out->data.insert(out->data.end(), line[3].begin(), line[3].end());
+            r.qual_off = (uint32_t)(base + (size_t)(line[3].data() - rec0));
             out->recs.push_back(r);
             pos_ += consumed;
             ++nrec_;
