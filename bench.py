@@ -30,6 +30,38 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBPS = 8000.0   # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
 
+def _cpu_all_cores_worker(job):
+    """One host process of the all-cores row: its own matcher (memo cache on), its own slice of the stream."""
+    cfg_id, mm, delta, start, seconds = job
+    import dataclasses as _dc
+    from fqtk_amd import synth
+    from oracle import oracle as O
+    cfg = _dc.replace(synth.CONFIGS[cfg_id], max_mismatches=mm, min_mismatch_delta=delta)
+    w = synth.Workload(synth.CONFIGS[cfg_id])
+    lit = O.RefLiteral(w.barcodes, cfg.max_mismatches, cfg.min_mismatch_delta, True, native=True)
+    L, chunk, done, t = cfg.barcode_len, 500_000, 0, 0.0
+    while t < seconds:
+        host = np.ascontiguousarray(w.fill_host(start + done, chunk)[:, :L])
+        t0 = time.perf_counter()
+        lit.assign_batch(host)
+        t += time.perf_counter() - t0
+        done += chunk
+    return done, t
+
+
+def cpu_all_cores(cfg_id: int, cfg, seconds: float):
+    """The same oracle on MANY host cores (one process per core, each with its own memo cache and slice):
+    the row to read the GPU number against when the host is not limited to the reference's one thread."""
+    import multiprocessing as mp
+    procs = max(1, min(64, (os.cpu_count() or 2) // 2))
+    jobs = [(cfg_id, cfg.max_mismatches, cfg.min_mismatch_delta, 10_000_000 + i * 5_000_000, seconds) for i in range(procs)]
+    with mp.get_context("spawn").Pool(procs) as pool:
+        res = pool.map(_cpu_all_cores_worker, jobs)
+    rate = sum(d / t for d, t in res)   # every process was timed on its own matcher calls only
+    return {"value": round(rate / 1e6, 2), "unit": "M reads/s", "cores": procs,
+            "sample": f"{procs} processes x {seconds:.0f} s of matcher time, {sum(d for d, _ in res)} reads"}
+
+
 def cpu_baseline(workload, seconds: float):
     """The oracle (literal C restatement of the reference algorithm, memo cache ON exactly as
     demux.rs:925 drives it) on ONE host core, over a bounded prefix of the same synthetic workload."""
@@ -68,6 +100,8 @@ def main() -> int:
     ap.add_argument("--config", type=int, default=3, help="BASELINE.json config id (1-5), default 3")
     ap.add_argument("--reads", type=int, default=0, help="reads per rank per step (default: the config's N)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="CPU-baseline budget (0 = skip)")
+    ap.add_argument("--cpu-all-cores", action="store_true",
+                    help="also time the oracle on many host cores (one process per core); adds ~10 s")
     ap.add_argument("--no-verify", action="store_true")
     ap.add_argument("--max-mismatches", type=int, default=-1, help="override the config's value (exploration only)")
     ap.add_argument("--min-mismatch-delta", type=int, default=-1, help="override the config's value (exploration only)")
@@ -247,6 +281,8 @@ def main() -> int:
         }
         if world == 1 and args.cpu_seconds > 0:
             out["cpu_baseline"] = cpu_baseline(workload, args.cpu_seconds)
+            if args.cpu_all_cores:
+                out["cpu_baseline"]["all_cores"] = cpu_all_cores(args.config, cfg, min(5.0, args.cpu_seconds))
             out["cpu_baseline"]["gpu_over_cpu"] = round(value / out["cpu_baseline"]["value"], 1)
     if use_dist:
         dist.destroy_process_group()
