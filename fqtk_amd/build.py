@@ -40,7 +40,8 @@ CXX = os.environ.get("CXX", "g++")
 def build_host(force: bool = False, verbose: bool = False) -> None:
     """The C++ host side above the C ABI: `fqtk demux` binary + a ctypes shim for the CPU tests."""
     os.makedirs(BINDIR, exist_ok=True)
-    deps = glob.glob(os.path.join(HOST, "*.hpp")) + glob.glob(os.path.join(INCLUDE, "*.h"))
+    deps = (glob.glob(os.path.join(HOST, "*.hpp")) + glob.glob(os.path.join(INCLUDE, "*.h")) +
+            glob.glob(os.path.join(CSRC, "*.hpp")))   # host_capi.cpp uses csrc/lds_memo_plan.hpp + memo_hash.hpp
     shim = os.path.join(LIBDIR, "libfqtk_host.so")
     src = os.path.join(HOST, "host_capi.cpp")
     if force or _stale(shim, [src] + deps):
@@ -60,7 +61,8 @@ def build_host(force: bool = False, verbose: bool = False) -> None:
 
 def build(force: bool = False, verbose: bool = False) -> None:
     os.makedirs(LIBDIR, exist_ok=True)
-    deps_common = glob.glob(os.path.join(CSRC, "*.h")) + glob.glob(os.path.join(INCLUDE, "*.h"))
+    deps_common = (glob.glob(os.path.join(CSRC, "*.h")) + glob.glob(os.path.join(CSRC, "*.hpp")) +
+                   glob.glob(os.path.join(INCLUDE, "*.h")))
     for name, (srcs, extra) in TARGETS.items():
         srcs_abs = [os.path.join(CSRC, s) for s in srcs]
         if not all(os.path.exists(s) for s in srcs_abs):
