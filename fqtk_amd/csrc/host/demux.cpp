@@ -243,6 +243,7 @@ struct OutFile {
 struct StageTimes {   // FQTK_TIMING=1: where the host threads spend their time (seconds, summed over threads)
     std::atomic<uint64_t> router_wait{0}, router_format{0}, router_submit{0}, comp_wait{0}, comp_deflate{0}, comp_write{0};
     std::atomic<uint64_t> submit_calls{0}, submit_cut{0}, submit_push{0};
+    std::atomic<uint64_t> main_wait{0}, main_gpu_wait{0}, main_handoff{0}, reader_parse{0}, reader_push{0};
 };
 StageTimes g_times;
 bool g_timing = false;
@@ -480,12 +481,17 @@ int main(int argc, char **argv) {
             for (;;) {
                 ReadResult r;
                 r.batch = std::make_unique<RecBatch>();
-                if (!sources[i]->next_batch(chunk_reads, r.batch.get(), &r.error)) {
+                const uint64_t t0 = tick();
+                const bool ok = sources[i]->next_batch(chunk_reads, r.batch.get(), &r.error);
+                const uint64_t t1 = tick();
+                g_times.reader_parse += t1 - t0;
+                if (!ok) {
                     rq[i]->push(std::move(r));
                     return;
                 }
                 const bool last = r.batch->recs.empty();
                 rq[i]->push(std::move(r));
+                g_times.reader_push += tick() - t1;
                 if (last) return;
             }
         });
@@ -605,11 +611,15 @@ int main(int argc, char **argv) {
     auto finish = [&](Pending &p) {
         if (!p.chunk) return;
         if (p.slot >= 0) {
+            const uint64_t tg = tick();
             if (fqtk_matcher_wait(matchers[p.slot % G], p.slot / (int)G) != FQTK_OK)
                 die(std::string(fqtk_last_error()));   // over-long barcode: the reference panics too (barcode_matching.rs:95-107)
+            g_times.main_gpu_wait += tick() - tg;
             for (size_t j = 0; j < p.rows.size(); ++j) p.chunk->res[p.rows[j]] = sb[p.slot].out[j];
         }
+        const uint64_t th = tick();
         for (size_t w = 0; w < n_workers; ++w) wq[w]->push(p.chunk);
+        g_times.main_handoff += tick() - th;
         p.chunk.reset();
     };
     std::vector<Pending> pending(kSlots);
@@ -618,7 +628,9 @@ int main(int argc, char **argv) {
         auto ch = std::make_shared<Chunk>();
         size_t n_nonempty = 0;
         for (size_t i = 0; i < n_inputs; ++i) {
+            const uint64_t tw = tick();
             ReadResult r = rq[i]->pop();
+            g_times.main_wait += tick() - tw;
             if (!r.error.empty()) die(r.error);
             if (!r.batch->recs.empty()) ++n_nonempty;
             ch->batches.push_back(std::move(r.batch));
@@ -723,6 +735,10 @@ int main(int argc, char **argv) {
     {
         uint64_t fw = 0;
         for (auto &q : jobs) fw += q->full_waits;
+        if (g_timing)
+            if (g_timing)
+            info("main thread: waiting for readers %.2f s, for the GPU %.2f s, handing chunks to routers %.2f s | readers: parse %.2f s, push %.2f s",
+                 g_times.main_wait / 1e9, g_times.main_gpu_wait / 1e9, g_times.main_handoff / 1e9, g_times.reader_parse / 1e9, g_times.reader_push / 1e9);
         if (g_timing)
             info("submit: %llu blocks, cut %.2f s, push %.2f s, %llu pushes found their queue full", (unsigned long long)g_times.submit_calls.load(),
                  g_times.submit_cut / 1e9, g_times.submit_push / 1e9, (unsigned long long)fw);

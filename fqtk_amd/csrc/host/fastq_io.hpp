@@ -41,109 +41,107 @@ class FastqSource {
         if (!gz_) { *err = "Error opening input files for reading: " + path; return false; }
         gzbuffer(gz_, 1 << 20);
         path_ = path;
-        buf_.resize(4 << 20);
         return true;
     }
     // Reads up to max_records records.  Returns false on a malformed file (*err set).  An empty batch = EOF.
+    //
+    // Parsed IN PLACE: gzread fills the batch's own data vector, lines are located with memchr and a
+    // record is four (offset, length) pairs into that vector -- no per-record copy.  Bytes read past the
+    // last record of this batch (at most one read piece) are carried into the next batch.
     bool next_batch(size_t max_records, RecBatch *out, std::string *err) {
-        out->data.clear();
         out->recs.clear();
-        out->recs.reserve(max_records);
+        out->recs.reserve(std::min<size_t>(max_records, 1u << 20));
+        std::vector<char> &d = out->data;
+        d.clear();
+        d.reserve(cap_hint_);           // batches of one input are alike: no regrowth copies after the first
+        d.insert(d.end(), carry_.begin(), carry_.end());   // bytes already read that belong to this batch
+        size_t pos = 0;                 // first unparsed byte
+        carry_.clear();
         while (out->recs.size() < max_records) {
-            std::string_view line[4];
-            size_t consumed = 0;
+            // four complete lines starting at pos?
+            size_t lo[4], len[4], p = pos;
             int got = 0;
-            // need four complete lines starting at pos_
-            for (;;) {
-                got = 0;
-                size_t p = pos_;
-                while (got < 4) {
-                    const char *nl = (const char *)memchr(buf_.data() + p, '\n', end_ - p);
-                    if (!nl) break;
-                    size_t len = (size_t)(nl - (buf_.data() + p));
-                    line[got] = std::string_view(buf_.data() + p, len);
-                    p += len + 1;
-                    ++got;
-                }
-                if (got == 4) { consumed = p - pos_; break; }
-                if (eof_) {
-                    // final line without '\n'
-                    if (got == 3 && p < end_) {
-                        line[3] = std::string_view(buf_.data() + p, end_ - p);
-                        got = 4;
-                        consumed = end_ - pos_;
-                    }
-                    break;
-                }
-                if (!fill(err)) return false;
+            while (got < 4) {
+                const char *nl = p < d.size() ? (const char *)memchr(d.data() + p, '\n', d.size() - p) : nullptr;
+                if (!nl) break;
+                lo[got] = p;
+                len[got] = (size_t)(nl - (d.data() + p));
+                p += len[got] + 1;
+                ++got;
             }
             if (got < 4) {
-                // EOF: anything left must be blank
-                for (size_t q = pos_; q < end_; ++q)
-                    if (buf_[q] != '\n' && buf_[q] != '\r') {
-                        *err = "Unexpected error parsing FASTQs: truncated record at end of " + path_;
-                        return false;
-                    }
-                pos_ = end_;
-                break;
+                if (!eof_) {            // need more bytes: append one piece to the batch
+                    if (!fill(d, err)) return false;
+                    continue;
+                }
+                if (got == 3 && p < d.size()) {   // final line without '\n'
+                    lo[3] = p;
+                    len[3] = d.size() - p;
+                    p = d.size();
+                    got = 4;
+                } else {
+                    // EOF: anything left must be blank
+                    for (size_t q = pos; q < d.size(); ++q)
+                        if (d[q] != '\n' && d[q] != '\r') {
+                            *err = "Unexpected error parsing FASTQs: truncated record at end of " + path_;
+                            return false;
+                        }
+                    pos = d.size();
+                    break;
+                }
             }
-            for (auto &l : line)
-                if (!l.empty() && l.back() == '\r') l.remove_suffix(1);
-            if (line[0].empty() || line[0][0] != '@') {
+            for (int k = 0; k < 4; ++k)
+                if (len[k] > 0 && d[lo[k] + len[k] - 1] == '\r') --len[k];
+            if (len[0] == 0 || d[lo[0]] != '@') {
                 *err = "Unexpected error parsing FASTQs: expected '@' at record " + std::to_string(nrec_) + " of " + path_;
                 return false;
             }
-            if (line[2].empty() || line[2][0] != '+') {
+            if (len[2] == 0 || d[lo[2]] != '+') {
                 *err = "Unexpected error parsing FASTQs: expected '+' at record " + std::to_string(nrec_) + " of " + path_;
                 return false;
             }
-            if (line[1].size() != line[3].size()) {
+            if (len[1] != len[3]) {
                 *err = "Unexpected error parsing FASTQs: sequence and quality lengths differ at record " +
                        std::to_string(nrec_) + " of " + path_;
                 return false;
             }
-            // one copy per record: the four lines are contiguous in the read buffer, so the whole span from
-            // the header (after '@') to the end of the quality line goes over as is; offsets skip the rest
+            if (p > 0xFFFFFFFFull) { *err = "Unexpected error parsing FASTQs: batch larger than 4 GiB in " + path_; return false; }
             FastqRec r;
-            const char *rec0 = line[0].data() + 1;
-            const size_t span = (size_t)(line[3].data() + line[3].size() - rec0);
-            const size_t base = out->data.size();
-            if (base == 0) out->data.reserve(std::min<size_t>(max_records, 1u << 20) * (span + 16));
-            out->data.insert(out->data.end(), rec0, rec0 + span);
-            r.head_off = (uint32_t)base;
-            r.head_len = (uint32_t)line[0].size() - 1;
-            r.seq_off = (uint32_t)(base + (size_t)(line[1].data() - rec0));
-            r.seq_len = (uint32_t)line[1].size();
-            r.qual_off = (uint32_t)(base + (size_t)(line[3].data() - rec0));
+            r.head_off = (uint32_t)lo[0] + 1;
+            r.head_len = (uint32_t)len[0] - 1;
+            r.seq_off = (uint32_t)lo[1];
+            r.seq_len = (uint32_t)len[1];
+            r.qual_off = (uint32_t)lo[3];
             out->recs.push_back(r);
-            pos_ += consumed;
+            pos = p;
             ++nrec_;
         }
+        // what was read beyond this batch's last record starts the next batch
+        carry_.assign(d.begin() + (std::ptrdiff_t)pos, d.end());
+        cap_hint_ = std::max(cap_hint_, d.size() + (8u << 20));
+        d.resize(pos);
         return true;
     }
 
   private:
-    bool fill(std::string *err) {
-        if (pos_ > 0) {   // compact
-            memmove(buf_.data(), buf_.data() + pos_, end_ - pos_);
-            end_ -= pos_;
-            pos_ = 0;
-        }
-        if (end_ == buf_.size()) buf_.resize(buf_.size() * 2);   // one very long line
-        int n = gzread(gz_, buf_.data() + end_, (unsigned)std::min<size_t>(buf_.size() - end_, 1u << 30));
+    bool fill(std::vector<char> &d, std::string *err) {
+        const size_t piece = 4u << 20;
+        const size_t old = d.size();
+        d.resize(old + piece);
+        int n = gzread(gz_, d.data() + old, (unsigned)piece);
         if (n < 0) {
             int e = 0;
             *err = std::string("Unexpected error parsing FASTQs: ") + gzerror(gz_, &e) + " in " + path_;
             return false;
         }
         if (n == 0) eof_ = true;
-        end_ += (size_t)n;
+        d.resize(old + (size_t)n);
         return true;
     }
     gzFile gz_ = nullptr;
     std::string path_;
-    std::vector<char> buf_;
-    size_t pos_ = 0, end_ = 0;
+    std::vector<char> carry_;
+    size_t cap_hint_ = 8u << 20;
     bool eof_ = false;
     uint64_t nrec_ = 0;
 };
