@@ -199,6 +199,13 @@ class BoundedQueue {
         q_.push_back(std::move(v));
         not_empty_.notify_one();
     }
+    bool try_push(T &v) {   // false (v untouched) when the queue is full
+        std::unique_lock<std::mutex> lk(mu_);
+        if (q_.size() >= cap_) return false;
+        q_.push_back(std::move(v));
+        not_empty_.notify_one();
+        return true;
+    }
     T pop() {
         std::unique_lock<std::mutex> lk(mu_);
         not_empty_.wait(lk, [&] { return !q_.empty(); });
@@ -308,7 +315,10 @@ void submit_blocks(OutFile &of, JobQueues &jobs, bool final) {
         // file go round-robin over them, so uneven sample sizes do not unbalance the compressors
         const size_t q = (reinterpret_cast<uintptr_t>(&of) / sizeof(OutFile) + j.seq) % jobs.size();
         const uint64_t tb = tick();
-        jobs[q]->push(std::move(j));
+        // work-conserving: a compressor stalled in a write must not hold up the router while others idle
+        bool placed = false;
+        for (size_t k = 0; k < jobs.size() && !placed; ++k) placed = jobs[(q + k) % jobs.size()]->try_push(j);
+        if (!placed) jobs[q]->push(std::move(j));
         if (g_timing) { g_times.submit_calls += 1; g_times.submit_cut += tb - ta; g_times.submit_push += tick() - tb; }
     }
 }
