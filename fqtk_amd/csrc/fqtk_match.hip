@@ -199,17 +199,24 @@ int launch_memo_vec(const fqtk_matcher *m, const fqtk::MemoParams &Q, hipStream_
 #ifdef FQTK_DEV_ABLATE
     shmem += lds_pad;
 #endif
-    const uint64_t tile = (uint64_t)fqtk::kBlock * R;
+    const uint64_t tile = (uint64_t)fqtk::kMemoBlock * R;
     const uint64_t ntiles = (P.n + tile - 1) / tile;
     if (ntiles == 0) return FQTK_OK;
-    const uint32_t grid = (uint32_t)std::min<uint64_t>(ntiles, (uint64_t)m->num_cus * 8);
+    const uint32_t grid = (uint32_t)std::min<uint64_t>(ntiles, (uint64_t)m->num_cus * (2048 / fqtk::kMemoBlock));
     // the packed vector paths imply the key width (stride 16 B -> 2 key words, 12 B -> 1 or 2, 8/4 B -> 1)
 #define FQTK_MEMO_LAUNCH(V, RR, A)                                                                         \
     do {                                                                                                   \
-        if constexpr ((V) <= 0 || ((V) == 3 && KW <= 2) || KW == ((V) == 5 ? 3 : ((V) == 4 ? 2 : 1)))      \
-            hipLaunchKernelGGL((fqtk::memo_kernel<V, KW, RR, A>), dim3(grid), dim3(fqtk::kBlock), shmem,   \
-                               stream, Q);                                                                 \
-        else                                                                                               \
+        if constexpr ((V) <= 0 || ((V) == 3 && KW <= 2) || KW == ((V) == 5 ? 3 : ((V) == 4 ? 2 : 1))) {    \
+            auto kern = fqtk::memo_kernel<V, KW, RR, A>;                                                   \
+            const void *fn = reinterpret_cast<const void *>(kern);                                         \
+            if (shmem > 64 * 1024 &&                                                                       \
+                std::find(m->ldsm_big_lds_ok.begin(), m->ldsm_big_lds_ok.end(), fn) == m->ldsm_big_lds_ok.end()) { \
+                HIP_TRY(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize,                \
+                                            (int)fqtk::kLdsMemoMaxBytes));                                 \
+                m->ldsm_big_lds_ok.push_back(fn);                                                          \
+            }                                                                                              \
+            hipLaunchKernelGGL(kern, dim3(grid), dim3(fqtk::kMemoBlock), shmem, stream, Q);                \
+        } else                                                                                             \
             return fail(FQTK_EINVAL, "memo: load width and key width disagree");                           \
     } while (0)
 #define FQTK_MEMO_BY_VEC(RR, A)                         \

@@ -20,7 +20,10 @@ FQTK_HD constexpr uint32_t memo_nibble_shift(uint32_t base) {   // bit offset of
 }
 constexpr uint32_t kMemoEmpty = 0xFFFFFFFFu;
 
-constexpr uint32_t kHotBytes = 16384;      // LDS budget of the hot table per workgroup
+#ifndef FQTK_HOT_BYTES
+#define FQTK_HOT_BYTES 65536
+#endif
+constexpr uint32_t kHotBytes = FQTK_HOT_BYTES;   // LDS budget of the hot table per workgroup
 
 // Key words: 1 (L <= 10: bases 8-9 are folded into the spare top bits of lo's nibbles, see kFoldMul),
 // 2 (L <= 16), 3 (L <= 20).

@@ -124,11 +124,19 @@ __device__ __forceinline__ void wave_scan(const Planes<NW> &mine, int src, const
 //   1 = skip table probes, 2 = skip the canonical-byte validation, 4 = skip histogram,
 //   8 = skip result store, 16 = skip the LDS hot table, 32 = fold the global probes into 4 KB (L1 hits),
 //   64 = skip the second (spill) probe, 128 = second probe goes to the first probe's neighbour slot
+// Workgroup of the table-form kernel: 1024 lanes, two per CU, so that the LDS hot table can be 64 KiB
+// instead of 16 KiB at the same 32 waves/CU.  Measured (tools/ab_memo_block.sh): 768 samples x 16 bases
+// 114 -> 168 G reads/s, 1536 x 10 152 -> 213, cfg 5 82 -> 120; tables whose exact-match entries already
+// fit 16 KiB (cfg 3) are unchanged.
+#ifndef FQTK_MEMO_BLOCK
+#define FQTK_MEMO_BLOCK 1024
+#endif
+constexpr int kMemoBlock = FQTK_MEMO_BLOCK;
 #ifndef FQTK_MEMO_WAVES
 #define FQTK_MEMO_WAVES 8
 #endif
 template <int VEC, int KW, int R, int ABL>
-__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(FQTK_MEMO_WAVES, 8)))
+__global__ __launch_bounds__(kMemoBlock) __attribute__((amdgpu_waves_per_eu(FQTK_MEMO_WAVES, 8)))
 void memo_kernel(const MemoParams Q) {
     const MatchParams &P = Q.m;
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
@@ -141,11 +149,11 @@ void memo_kernel(const MemoParams Q) {
     uint32_t *lds_hist = lds_hot + hot_words;
 
     const uint32_t tid = threadIdx.x;
-    lds_lut[tid] = P.lut[tid];
-    for (uint32_t w = tid; w < hot_words; w += kBlock) lds_hot[w] = Q.hot[w];
+    if (tid < 256) lds_lut[tid] = P.lut[tid];
+    for (uint32_t w = tid; w < hot_words; w += kMemoBlock) lds_hot[w] = Q.hot[w];
     const uint32_t bins = P.S + 1;
     if (P.counts && P.lds_hist)
-        for (uint32_t b = tid; b < bins; b += kBlock) lds_hist[b] = 0;
+        for (uint32_t b = tid; b < bins; b += kMemoBlock) lds_hist[b] = 0;
     __syncthreads();
 
     const uint32_t L = P.L;
@@ -162,7 +170,7 @@ void memo_kernel(const MemoParams Q) {
         kc[w] = keep & 0x07070707u;
         kv[w] = (ABL & 2) ? 0u : (keep & 0xDFDFDFDFu);
     }
-    const uint64_t tile = (uint64_t)kBlock * R;
+    const uint64_t tile = (uint64_t)kMemoBlock * R;
     const uint64_t ntiles = (P.n + tile - 1) / tile;
 
     for (uint64_t t = blockIdx.x; t < ntiles; t += gridDim.x) {
@@ -171,7 +179,7 @@ void memo_kernel(const MemoParams Q) {
         bool live[R], bad[R];
 #pragma unroll
         for (int r = 0; r < R; ++r) {
-            const uint64_t i = t * tile + (uint64_t)r * kBlock + tid;
+            const uint64_t i = t * tile + (uint64_t)r * kMemoBlock + tid;
             live[r] = i < P.n;
 #pragma unroll
             for (int w = 0; w < 8; ++w) words[r][w] = 0x41414141u;   // dead lanes look like "AAAA"
@@ -273,7 +281,7 @@ void memo_kernel(const MemoParams Q) {
 #pragma unroll
         for (int r = 0; r < R; ++r) {
             if (!live[r]) continue;
-            const uint64_t i = t * tile + (uint64_t)r * kBlock + tid;
+            const uint64_t i = t * tile + (uint64_t)r * kMemoBlock + tid;
             if constexpr (ABL & 8) { if (res[r] == 0x12345u) P.out[i] = res[r]; } else
             FQTK_STREAM_STORE(res[r], &P.out[i]);
             if (P.counts && !(ABL & 4)) {
@@ -287,7 +295,7 @@ void memo_kernel(const MemoParams Q) {
 
     if (P.counts && P.lds_hist) {
         __syncthreads();
-        for (uint32_t b = tid; b < bins; b += kBlock) {
+        for (uint32_t b = tid; b < bins; b += kMemoBlock) {
             const uint32_t c = lds_hist[b];
             if (c) atomicAdd(&P.counts[b], (unsigned long long)c);
         }
