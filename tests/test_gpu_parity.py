@@ -312,6 +312,28 @@ def test_many_samples_lds_and_global_histogram_paths():
         _compare(bcs, 1, 1, obs)
 
 
+def test_maximum_sample_count_65534():
+    """S = 65 534 is the largest table the 16-bit index allows (0xFFFF = None).  Samples differ in their
+    first 8 bases (a base-4 counter), so the last sample's index 0xFFFD/0xFFFE must come back intact."""
+    S, L = 65534, 12
+    digits = np.array([(np.arange(S) >> (2 * k)) & 3 for k in range(8)]).T           # [S, 8]
+    bc_bytes = np.frombuffer(b"ACGT", dtype=np.uint8)[digits]
+    bc_bytes = np.concatenate([bc_bytes, np.full((S, 4), ord("A"), dtype=np.uint8)], axis=1)
+    barcodes = [row.tobytes().decode() for row in bc_bytes]
+    rng = np.random.default_rng(65534)
+    pick = np.concatenate([[0, 1, S - 2, S - 1], rng.integers(0, S, 396)])
+    obs = bc_bytes[pick].copy()
+    obs[5:200, 10] = ord("C")          # one mismatch in the constant tail: best = 1 everywhere
+    obs[200:260, 3] = ord("N")
+    for use_cache in (True, False):
+        m = BarcodeMatcher(barcodes, 1, 0, use_cache)
+        got, counts = m.assign_batch(obs)
+        i, b, nx, c = O.ref_simple_assign_batch(barcodes, 1, 0, obs)
+        assert np.array_equal(got["idx"], i) and np.array_equal(got["best"], b) and np.array_equal(got["next"], nx)
+        assert np.array_equal(counts, c)
+        assert got["idx"][3] == S - 1 and got["idx"][2] == S - 2
+
+
 def test_longest_memo_key_and_longer_barcodes():
     """L = 20 is the longest barcode the memo covers (80-bit key: lo, hi, ext); L = 21..128 are scan-only."""
     rng = np.random.default_rng(12)
