@@ -334,6 +334,16 @@ def test_maximum_sample_count_65534():
         assert got["idx"][3] == S - 1 and got["idx"][2] == S - 2
 
 
+def test_limits_are_rejected_at_create():
+    """More than 65 534 samples (the 16-bit index) or barcodes longer than 128 bases (u8 mismatch counts
+    must not saturate) are argument errors, not silent truncation."""
+    with pytest.raises(ValueError):
+        BarcodeMatcher(["ACGTACGTACGT"] * 65535, 1, 1)
+    with pytest.raises(ValueError):
+        BarcodeMatcher(["A" * 129, "C" * 129], 1, 1)
+    BarcodeMatcher(["A" * 128, "C" * 128], 1, 1)
+
+
 def test_longest_memo_key_and_longer_barcodes():
     """L = 20 is the longest barcode the memo covers (80-bit key: lo, hi, ext); L = 21..128 are scan-only."""
     rng = np.random.default_rng(12)
