@@ -112,3 +112,23 @@ def test_synthetic_reads_are_deterministic_and_range_consistent():
     x = w5.fill_host(0, 50000)
     assert x.shape == (50000, 12) and np.all(x[:, 10:] == 0)
     assert (x[:, :10] == ord(".")).sum() > 0 and ((x[:, :10] >= ord("a")) & (x[:, :10] <= ord("t"))).sum() > 0
+
+
+def test_product_package_never_touches_the_oracle():
+    """oracle/ is test infrastructure: nothing under fqtk_amd/ (Python or native sources) may import,
+    link or execute it -- the product path has no CPU compute fallback."""
+    import glob
+    import os
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    offenders = []
+    for path in glob.glob(os.path.join(root, "fqtk_amd", "**", "*"), recursive=True):
+        if not os.path.isfile(path) or path.endswith((".so", ".pyc")) or os.sep + "bin" + os.sep in path:
+            continue
+        text = open(path, errors="replace").read()
+        for m in re.finditer(r"^.*\boracle\b.*$", text, flags=re.M):
+            line = m.group(0).strip()
+            if line.startswith(("//", "#", "*")) or "//" in line.split("oracle")[0]:
+                continue   # prose in a comment
+            offenders.append((os.path.relpath(path, root), line))
+    assert offenders == []
