@@ -97,6 +97,8 @@ def zipf_cdf(S: int, s: float = 0.5) -> np.ndarray:
 def thresholds(cfg: Config) -> np.ndarray:
     p_sample, p_n, p_sub = 0.90, 0.005, 0.01
     p_lower, p_dot = (0.001, 0.0001) if cfg.iupac else (0.0, 0.0)
+    if os.environ.get("FQTK_SYNTH_PSAMPLE"):  # developer knob: fraction of reads drawn from a sample
+        p_sample = float(os.environ["FQTK_SYNTH_PSAMPLE"])
     if os.environ.get("FQTK_SYNTH_PDOT"):     # developer knob: rate of '.' no-calls per base
         p_dot = float(os.environ["FQTK_SYNTH_PDOT"])
     t = [p_sample, p_n, p_sub, p_lower, p_dot]
