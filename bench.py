@@ -6,19 +6,29 @@ Workload at N=1: BASELINE.json configs[2] -- the config the north_star target is
 400 M reads x 384 samples (8+8 bp), max-mismatches 1, min-mismatch-delta 2; it fits one GPU
 (6.4 GB of observed barcodes + 1.6 GB of results in HBM).  A "step" = one pass of the hot path
 (fqtk_matcher_assign_batch_device through the C ABI) over the rank's HBM-resident batch.
-Multi-GPU: reads shard across ranks with no data-path collective (weak scaling: every rank owns a
-full batch); the only collective is the final per-sample count all-reduce over RCCL.
+
+`value` is scope K (inputs resident in HBM).  The same JSON line carries, never conflated
+with it: `scopes.B` (C ABI with pinned host buffers, PCIe inclusive), `scopes.E` (the `fqtk demux` binary,
+files -> files), `create_ms` (memo build at fqtk_matcher_create) and the CPU rows C1 / cache-off / all-cores.
+
+Multi-GPU: reads shard across ranks with no data-path collective; the only collective is the final
+per-sample count all-reduce over RCCL.  `--scaling weak` (default): every rank owns a full batch;
+`--scaling strong`: the config's N reads are split over the ranks (BASELINE config 3's wording).
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--config 3] [--reads R]
-    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+        --gpus N > 1 without a torchrun environment re-launches itself as N ranks:
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py --gpus N
 
 Prints ONE JSON line on rank 0.
 """
 from __future__ import annotations
 
 import argparse
+import hashlib
 import json
 import os
+import shutil
+import subprocess
 import sys
 import time
 
@@ -26,70 +36,141 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tools"))
 
 HBM_PEAK_GBPS = 8000.0   # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+DT = np.dtype([("idx", "<u2"), ("best", "u1"), ("next", "u1")])
 
 
-def _cpu_all_cores_worker(job):
-    """One host process of the all-cores row: its own matcher (memo cache on), its own slice of the stream."""
-    cfg_id, mm, delta, start, seconds = job
-    import dataclasses as _dc
+# ---- CPU rows: the oracle timed on this box's host cores --------------------------
+def _cpu_worker(job):
+    """One host process: its own matcher, its own slice of the synthetic stream; timed on matcher calls only."""
+    cfg_id, mm, delta, use_cache, start, seconds, max_reads = job
     from fqtk_amd import synth
     from oracle import oracle as O
-    cfg = _dc.replace(synth.CONFIGS[cfg_id], max_mismatches=mm, min_mismatch_delta=delta)
     w = synth.Workload(synth.CONFIGS[cfg_id])
-    lit = O.RefLiteral(w.barcodes, cfg.max_mismatches, cfg.min_mismatch_delta, True, native=True)
-    L, chunk, done, t = cfg.barcode_len, 500_000, 0, 0.0
-    while t < seconds:
+    L = w.cfg.barcode_len
+    lit = O.RefLiteral(w.barcodes, mm, delta, use_cache, native=True)
+    chunk = 1_000_000 if use_cache else 100_000
+    done, t = 0, 0.0
+    while t < seconds and done < max_reads:
         host = np.ascontiguousarray(w.fill_host(start + done, chunk)[:, :L])
         t0 = time.perf_counter()
         lit.assign_batch(host)
         t += time.perf_counter() - t0
         done += chunk
-    return done, t
-
-
-def cpu_all_cores(cfg_id: int, cfg, seconds: float):
-    """The same oracle on MANY host cores (one process per core, each with its own memo cache and slice):
-    the row to read the GPU number against when the host is not limited to the reference's one thread."""
-    import multiprocessing as mp
-    procs = max(1, min(64, (os.cpu_count() or 2) // 2))
-    jobs = [(cfg_id, cfg.max_mismatches, cfg.min_mismatch_delta, 10_000_000 + i * 5_000_000, seconds) for i in range(procs)]
-    with mp.get_context("spawn").Pool(procs) as pool:
-        res = pool.map(_cpu_all_cores_worker, jobs)
-    rate = sum(d / t for d, t in res)   # every process was timed on its own matcher calls only
-    return {"value": round(rate / 1e6, 2), "unit": "M reads/s", "cores": procs,
-            "sample": f"{procs} processes x {seconds:.0f} s of matcher time, {sum(d for d, _ in res)} reads"}
-
-
-def cpu_baseline(workload, seconds: float):
-    """The oracle (literal C restatement of the reference algorithm, memo cache ON exactly as
-    demux.rs:925 drives it) on ONE host core, over a bounded prefix of the same synthetic workload."""
-    from oracle import oracle as O
-    cfg = workload.cfg
-    L = cfg.barcode_len
-    # one matcher for the whole sample, memo cache cold at the start, exactly like a real demux run;
-    # chunks are consumed until `seconds` of matcher time have been spent (input generation untimed)
-    lit = O.RefLiteral(workload.barcodes, cfg.max_mismatches, cfg.min_mismatch_delta, True, native=True)
-    chunk = 1_000_000
-    total_t = 0.0
-    done = 0
-    while total_t < seconds and done < 200_000_000:
-        host = np.ascontiguousarray(workload.fill_host(done, chunk)[:, :L])
-        t0 = time.perf_counter()
-        lit.assign_batch(host)
-        total_t += time.perf_counter() - t0
-        done += chunk
     hits, misses = lit.cache_stats
-    return {
-        "value": round(done / total_t / 1e6, 4),
-        "unit": "M reads/s",
-        "cores": 1,
-        "kind": "port",
-        "sample": f"first {done} reads of the same synthetic workload, oracle/ref_literal.c (gcc -O3 "
-                  f"-march=native), memo cache on (hit rate {hits / max(hits + misses, 1):.3f}), "
-                  f"{total_t:.1f} s of CPU work; host has {os.cpu_count()} logical cores",
+    return done, t, hits, misses
+
+
+def cpu_rows(cfg_id: int, cfg, seconds: float, pool):
+    """C1: cache on, 1 core, cold cache at read 0 -- exactly how demux drives the matcher (demux.rs:925,968).
+    cache_off_1core: the arithmetic the GPU replaces.  all_cores: C1 on many processes."""
+    done, t, hits, misses = _cpu_worker((cfg_id, cfg.max_mismatches, cfg.min_mismatch_delta, True, 0, seconds, 200_000_000))
+    out = {
+        "value": round(done / t / 1e6, 4), "unit": "M reads/s", "cores": 1, "kind": "port", "row": "C1",
+        "sample": f"first {done} reads of the same synthetic workload, oracle/ref_literal.c (gcc -O3 -march=native), "
+                  f"memo cache on (hit rate {hits / max(hits + misses, 1):.3f}), {t:.1f} s of CPU work; "
+                  f"host has {os.cpu_count()} logical cores",
     }
+    d2, t2, _, _ = _cpu_worker((cfg_id, cfg.max_mismatches, cfg.min_mismatch_delta, False, 0, min(seconds, 5.0), 50_000_000))
+    out["cache_off_1core"] = {"value": round(d2 / t2 / 1e6, 4), "unit": "M reads/s", "cores": 1, "row": "C2",
+                              "sample": f"first {d2} reads, memo cache off (every read scans all samples), {t2:.1f} s"}
+    if pool is not None:
+        procs = pool.n_procs
+        jobs = [(cfg_id, cfg.max_mismatches, cfg.min_mismatch_delta, True, 10_000_000 + i * 5_000_000, min(seconds, 5.0),
+                 5_000_000) for i in range(procs)]
+        res = pool.map(_cpu_worker, jobs)
+        out["all_cores"] = {"value": round(sum(d / tt for d, tt, _, _ in res) / 1e6, 2), "unit": "M reads/s", "cores": procs,
+                            "sample": f"{procs} processes (own matcher + memo cache + slice each), "
+                                      f"{sum(d for d, _, _, _ in res)} reads; sum of per-process rates"}
+    return out
+
+
+# ---- parity gate (SURVEY.md 8d): triples on a prefix, per-sample count vector on everything ----------------
+def _parity_worker(job):
+    cfg_id, mm, delta, seed_base, lo, hi, triple_hi, path = job
+    from fqtk_amd import synth
+    from oracle import oracle as O
+    w = synth.Workload(synth.CONFIGS[cfg_id])
+    L = w.cfg.barcode_len
+    lit = O.RefLiteral(w.barcodes, mm, delta, True, native=True)
+    got = np.memmap(path, dtype=DT, mode="r") if (path and lo < triple_hi) else None
+    counts = np.zeros(w.cfg.n_samples + 1, dtype=np.uint64)
+    bad = 0
+    for a in range(lo, hi, 2_000_000):
+        b = min(hi, a + 2_000_000)
+        host = np.ascontiguousarray(w.fill_host(seed_base + a, b - a)[:, :L])
+        i, be, nx, c = lit.assign_batch(host)
+        counts += c
+        if got is not None and a < triple_hi:
+            m = min(b, triple_hi) - a
+            g = got[a:a + m]
+            bad += int(np.count_nonzero((g["idx"] != i[:m]) | (g["best"] != be[:m]) | (g["next"] != nx[:m])))
+    return bad, counts
+
+
+def parity_gate(pool, cfg_id, cfg, total_reads, triple_reads, d_out, gpu_counts_per_step):
+    """Oracle fanned over host processes: every (idx, best, next) of the first `triple_reads` reads of rank 0
+    and the per-sample counts of all `total_reads` reads of the job (all ranks' shards are one stream)."""
+    path = f"/dev/shm/fqtk_bench_parity_{os.getpid()}.bin"
+    d_out[:triple_reads].cpu().numpy().tofile(path)
+    try:
+        procs = pool.n_procs
+        bounds = np.linspace(0, total_reads, procs * 4 + 1).astype(np.int64)
+        jobs = [(cfg_id, cfg.max_mismatches, cfg.min_mismatch_delta, 0, int(bounds[i]), int(bounds[i + 1]), triple_reads, path)
+                for i in range(len(bounds) - 1) if bounds[i] < bounds[i + 1]]
+        t0 = time.perf_counter()
+        res = pool.map(_parity_worker, jobs, chunksize=1)
+        wall = time.perf_counter() - t0
+    finally:
+        os.unlink(path)
+    bad = sum(r[0] for r in res)
+    oracle_counts = sum((r[1] for r in res), np.zeros(cfg.n_samples + 1, dtype=np.uint64))
+    ok_counts = bool(np.array_equal(oracle_counts, gpu_counts_per_step))
+    assert bad == 0, f"{bad} reads of the first {triple_reads} differ from the oracle"
+    assert ok_counts, "per-sample count vector differs from the oracle's"
+    return (f"bit-exact vs oracle: all (idx,best,next) of the first {triple_reads} reads + the per-sample count vector "
+            f"of all {total_reads} reads ({procs} host processes, {wall:.1f} s)")
+
+
+def pmc_traffic(cfg_id: int, n: int, kernel_name: str):
+    """HBM bytes per launch of the dominant kernel from the PMC counters: they cannot be read live, so
+    tools/profile_bench.sh collects them (separate --pmc passes, gfx950 correction) and records the digest of
+    the kernel sources they were measured on; a kernel edited since then reports null, not a stale number."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as fh:
+            t = json.load(fh).get(f"cfg{cfg_id}")
+        if t and t["reads_per_launch"] == n and kernel_name.startswith(t["kernel_prefix"]) \
+                and t.get("kernel_sources_sha1") == kernel_sources_digest():
+            return t["traffic_bytes_per_launch"]
+    except (OSError, ValueError, KeyError):
+        pass
+    return None
+
+
+def kernel_sources_digest() -> str:
+    h = hashlib.sha1()
+    d = os.path.join(ROOT, "fqtk_amd", "csrc")
+    for f in sorted(os.listdir(d)):
+        if f.endswith((".h", ".hpp", ".hip")):
+            h.update(open(os.path.join(d, f), "rb").read())
+    return h.hexdigest()
+
+
+def self_launch(n_gpus: int) -> int:
+    """--gpus N without a torchrun environment: start N ranks (one process per GPU) and relay the result."""
+    import torch
+    have = torch.cuda.device_count()
+    if have < n_gpus:
+        print(f"bench.py: --gpus {n_gpus} but only {have} GPU(s) are visible; refusing to report a smaller job "
+              f"under that label", file=sys.stderr)
+        return 2
+    port = 29500 + os.getpid() % 2000
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n_gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    return subprocess.run(cmd, env=env).returncode
 
 
 def main() -> int:
@@ -99,10 +180,17 @@ def main() -> int:
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--config", type=int, default=3, help="BASELINE.json config id (1-5), default 3")
     ap.add_argument("--reads", type=int, default=0, help="reads per rank per step (default: the config's N)")
-    ap.add_argument("--cpu-seconds", type=float, default=15.0, help="CPU-baseline budget (0 = skip)")
-    ap.add_argument("--cpu-all-cores", action="store_true",
-                    help="also time the oracle on many host cores (one process per core); adds ~10 s")
-    ap.add_argument("--no-verify", action="store_true")
+    ap.add_argument("--scaling", choices=("weak", "strong"), default="weak",
+                    help="weak: every rank owns --reads reads; strong: they are split over the ranks")
+    ap.add_argument("--cpu-seconds", type=float, default=15.0, help="CPU-baseline budget for row C1 (0 = skip all CPU rows)")
+    ap.add_argument("--parity", choices=("full", "windows", "none"), default=None,
+                    help="full: first 50 M triples + count vector of all reads (default at 1 rank); windows: 3 x 100 k")
+    ap.add_argument("--no-verify", action="store_true", help="same as --parity none")
+    ap.add_argument("--no-scopes", action="store_true", help="skip scopes B and E")
+    ap.add_argument("--e2e-templates", type=int, default=4_000_000, help="templates of the scope E run")
+    ap.add_argument("--e2e-threads", type=int, default=32)
+    ap.add_argument("--e2e-gz", action="store_true", help="gzip the scope E inputs (single-stream gunzip per file)")
+    ap.add_argument("--lens", action="store_true", help="pass an obs_len array (all == L): the variable-length '+B' path")
     ap.add_argument("--max-mismatches", type=int, default=-1, help="override the config's value (exploration only)")
     ap.add_argument("--min-mismatch-delta", type=int, default=-1, help="override the config's value (exploration only)")
     ap.add_argument("--no-cache", action="store_true",
@@ -111,17 +199,23 @@ def main() -> int:
                     help="pin the HBM/L2 table form of the memo (default: LDS-resident form when it can be built)")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return self_launch(args.gpus)
+
     import torch
     import torch.distributed as dist
 
     from fqtk_amd import BarcodeMatcher, synth
-    from fqtk_amd.sharding import allreduce_counts
+    from fqtk_amd.sharding import allreduce_counts, shard_range
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         print("bench.py needs a GPU: the matcher has no CPU fallback", file=sys.stderr)
+        return 2
+    if world != args.gpus and not (world == 1 and args.gpus == 1):
+        print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE is {world}", file=sys.stderr)
         return 2
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
@@ -132,8 +226,7 @@ def main() -> int:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
-    if args.gpus != world and rank == 0 and world > 1:
-        print(f"warning: --gpus {args.gpus} != WORLD_SIZE {world}", file=sys.stderr)
+        assert dist.get_world_size() == args.gpus, "process group size != --gpus"
 
     cfg = synth.CONFIGS[args.config]
     if args.max_mismatches >= 0 or args.min_mismatch_delta >= 0:
@@ -142,7 +235,9 @@ def main() -> int:
                                   max_mismatches=args.max_mismatches if args.max_mismatches >= 0 else cfg.max_mismatches,
                                   min_mismatch_delta=args.min_mismatch_delta if args.min_mismatch_delta >= 0 else cfg.min_mismatch_delta,
                                   name=cfg.name + " [overridden mismatch parameters]")
-    n = args.reads or cfg.n_reads
+    job_reads = (args.reads or cfg.n_reads) * (world if args.scaling == "weak" else 1)   # one step of the whole job
+    base, hi = shard_range(job_reads, rank, world)     # this rank's contiguous shard of the read stream
+    n = hi - base
     workload = synth.Workload(synth.CONFIGS[args.config])
     workload.cfg = cfg
     stream = torch.cuda.current_stream().cuda_stream
@@ -150,24 +245,27 @@ def main() -> int:
     # ---- inputs resident in HBM before the timed region ------------------------------------------
     d_obs = torch.empty((n, cfg.stride), dtype=torch.uint8, device=dev)
     gen_chunk = 50_000_000
-    base = rank * n                                # every rank owns a distinct shard of the stream
     for lo in range(0, n, gen_chunk):
         cur = min(gen_chunk, n - lo)
         workload.fill_device(base + lo, cur, d_obs.data_ptr() + lo * cfg.stride, stream)
     d_out = torch.empty(n, dtype=torch.int32, device=dev)
     d_counts = torch.zeros(cfg.n_samples + 1, dtype=torch.int64, device=dev)
+    d_lens = torch.full((n,), cfg.barcode_len, dtype=torch.int32, device=dev) if args.lens else None
 
+    # ---- fqtk_matcher_create: table upload + complete-memo build (enumerate, scan on the device, place) ----
+    BarcodeMatcher(workload.barcodes, cfg.max_mismatches, cfg.min_mismatch_delta, device=local_rank).close()  # HIP context, code objects
+    t0 = time.perf_counter()
     matcher = BarcodeMatcher(workload.barcodes, cfg.max_mismatches, cfg.min_mismatch_delta,
                              use_cache=not args.no_cache, device=local_rank)
+    create_ms = (time.perf_counter() - t0) * 1e3
     if args.memo_table:
         matcher.memo_kind = BarcodeMatcher.MEMO_TABLE
-    memo_on = (not args.no_cache) and matcher.memo_entries > 0
     kernel_name = {BarcodeMatcher.MEMO_NONE: "fqtk::match_kernel", BarcodeMatcher.MEMO_TABLE: "fqtk::memo_kernel",
                    BarcodeMatcher.MEMO_LDS: "fqtk::lds_memo_kernel"}[matcher.memo_kind]
 
     def step():
         matcher.assign_batch_device(d_obs.data_ptr(), cfg.stride, n, d_out.data_ptr(), d_counts.data_ptr(),
-                                    stream=stream)
+                                    d_lens=d_lens.data_ptr() if d_lens is not None else 0, stream=stream)
 
     for _ in range(args.warmup):
         step()
@@ -195,49 +293,57 @@ def main() -> int:
     kernel_ms = ev0.elapsed_time(ev1) / args.steps  # HIP events around the K launches, per launch
     matcher.poll_error(stream)
 
+    per_rank_kernel_ms = [round(kernel_ms, 4)]
     if use_dist:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+        km = torch.zeros(world, dtype=torch.float64, device=dev)
+        km[rank] = kernel_ms
+        dist.all_reduce(km)
+        per_rank_kernel_ms = [round(float(x), 4) for x in km.tolist()]
 
     # ---- correctness gates outside the timed region -------------------------------------------------
     counts_host = d_counts.cpu().numpy()
     if not os.environ.get("FQTK_MEMO_ABLATE"):
         assert int(counts_host.sum()) == n * args.steps, "per-sample counts do not add up to reads x steps"
+    job_counts = total_counts.cpu().numpy().astype(np.uint64)
     if use_dist:
-        assert int(total_counts.sum().item()) == n * args.steps * world
+        assert int(job_counts.sum()) == job_reads * args.steps, "all-reduced counts do not add up to the job's reads"
+    assert np.all(job_counts % args.steps == 0), "the K passes over the same batch disagree with each other"
+    mode = "none" if args.no_verify else (args.parity or ("full" if world == 1 else "windows"))
+    host_cores = os.cpu_count() or 2
+    pool = None
+    if rank == 0 and (mode == "full" or (world == 1 and args.cpu_seconds > 0)):
+        import multiprocessing as mp
+        n_procs = max(1, min(128, host_cores // 2))
+        pool = mp.get_context("spawn").Pool(n_procs)
+        pool.n_procs = n_procs
     parity = None
-    if not args.no_verify and rank == 0:
+    if rank == 0 and mode == "full":
+        # the oracle must finish in about a minute: on a small host the count vector covers a prefix only
+        budget = job_reads if host_cores >= 32 else min(job_reads, 50_000_000)
+        if budget == job_reads:
+            parity = parity_gate(pool, args.config, cfg, job_reads, min(n, 50_000_000), d_out, job_counts // args.steps)
+        else:
+            mode = "windows"
+    if rank == 0 and mode == "windows":
         from oracle import oracle as O
         lit = O.RefLiteral(workload.barcodes, cfg.max_mismatches, cfg.min_mismatch_delta, True)
-        dt = np.dtype([("idx", "<u2"), ("best", "u1"), ("next", "u1")])
         checked = 0
         for start in (0, n // 2, max(n - 100_000, 0)):
             m = min(100_000, n - start)
             host = workload.fill_host(base + start, m)
             i, b, nx, _ = lit.assign_batch(np.ascontiguousarray(host[:, :cfg.barcode_len]))
-            got = d_out[start:start + m].cpu().numpy().view(dt)
+            got = d_out[start:start + m].cpu().numpy().view(DT)
             ok = np.array_equal(got["idx"], i) and np.array_equal(got["best"], b) and np.array_equal(got["next"], nx)
             assert ok, f"GPU results differ from the oracle in window starting at read {start}"
             checked += m
-        parity = f"bit-exact vs oracle on {checked} reads (3 windows)"
-
-    # HBM traffic of the dominant kernel: measured separately with the PMC counters (they cannot be
-    # read live) by tools/profile_bench.sh and committed under profiles/; reported only when it was
-    # collected for this exact workload and kernel, else null.
-    traffic = None
-    try:
-        with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as fh:
-            t = json.load(fh).get(f"cfg{args.config}")
-        if t and t["reads_per_launch"] == n and kernel_name.startswith(t["kernel_prefix"]):
-            traffic = t["traffic_bytes_per_launch"]
-    except (OSError, ValueError, KeyError):
-        pass
+        parity = f"bit-exact vs oracle on {checked} reads (3 windows of rank 0's shard)"
 
     out = None
     if rank == 0:
-        reads_total = n * args.steps * world
-        value = reads_total / elapsed / 1e6
+        value = job_reads * args.steps / elapsed / 1e6
         achieved = n * cfg.bytes_per_read / (kernel_ms * 1e-3) / 1e9
         out = {
             "metric": "M reads/sec demuxed (bit-exact assigns)",
@@ -248,13 +354,15 @@ def main() -> int:
             "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 4),
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": args.scaling,
             "vs_baseline": None,
             "dtype": "u8",
             "data": "synthetic",
+            "scope": "K: observed barcodes resident in HBM, results left in HBM (SURVEY.md 8d); B and E are in `scopes`",
             "config": {
                 "workload": cfg.name,
                 "reads_per_gpu_per_step": n,
+                "reads_per_step_whole_job": job_reads,
                 "samples": cfg.n_samples,
                 "barcode_len": cfg.barcode_len,
                 "max_mismatches": cfg.max_mismatches,
@@ -262,9 +370,11 @@ def main() -> int:
                 "sharding": f"reads sharded over {world} rank(s), table replicated, RCCL all-reduce of counts only",
                 "parity": parity,
                 "use_cache": not args.no_cache,
+                "obs_len": bool(args.lens),
                 "memo_entries": matcher.memo_entries,
                 "memo_kind": {0: "none (scan)", 1: "table in HBM/L2 + LDS hot subset", 2: "LDS-resident"}[matcher.memo_kind],
             },
+            "create_ms": round(create_ms, 2),
             "roofline": {
                 "bound": "hbm",
                 "kernel": kernel_name,
@@ -272,18 +382,40 @@ def main() -> int:
                 "peak": HBM_PEAK_GBPS,
                 "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBPS, 5),
-                "traffic": traffic,
+                "traffic": pmc_traffic(args.config, n, kernel_name),
                 "traffic_unit": "bytes per launch (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, profiles/)",
-                "algorithmic_bytes_per_launch": n * cfg.bytes_per_read,
+                "algorithmic_bytes_per_launch": n * (cfg.bytes_per_read + (4 if args.lens else 0)),
                 "kernel_ms": round(kernel_ms, 4),
+                "kernel_ms_per_rank": per_rank_kernel_ms,
                 "algorithmic_bytes_per_read": cfg.bytes_per_read,
             },
         }
+        if world == 1 and not args.no_scopes:
+            import scope_bench
+            scopes = {"K": {"M_reads_per_s": round(value, 1), "what": "this line's `value`"}}
+            del d_obs, d_out
+            torch.cuda.empty_cache()
+            scopes["B"] = scope_bench.scope_b(args.config, matcher=matcher, workload=workload,
+                                              n_chunk=min(8_000_000, max(job_reads // 4, 1)))
+            tmp = scope_bench.scratch_dir(args.e2e_templates * 1100)
+            try:
+                expect = None
+                if pool is not None and args.config == 3:   # metrics file vs the oracle's count vector
+                    res = pool.map(_parity_worker, [(3, 1, 2, 0, lo, min(lo + 500_000, args.e2e_templates), 0, None)
+                                                    for lo in range(0, args.e2e_templates, 500_000)])
+                    expect = sum((r[1] for r in res), np.zeros(385, dtype=np.uint64))
+                scopes["E"] = scope_bench.scope_e(args.e2e_templates, args.e2e_threads, args.e2e_gz, tmp, expect)
+            finally:
+                shutil.rmtree(tmp, ignore_errors=True)
+            out["scopes"] = scopes
         if world == 1 and args.cpu_seconds > 0:
-            out["cpu_baseline"] = cpu_baseline(workload, args.cpu_seconds)
-            if args.cpu_all_cores:
-                out["cpu_baseline"]["all_cores"] = cpu_all_cores(args.config, cfg, min(5.0, args.cpu_seconds))
+            out["cpu_baseline"] = cpu_rows(args.config, cfg, args.cpu_seconds, pool)
             out["cpu_baseline"]["gpu_over_cpu"] = round(value / out["cpu_baseline"]["value"], 1)
+            if "scopes" in out:   # north_star's >= 10x target is a scope-B statement against row C1
+                out["cpu_baseline"]["scope_B_over_C1"] = round(out["scopes"]["B"]["M_reads_per_s"] / out["cpu_baseline"]["value"], 1)
+    if pool is not None:
+        pool.close()
+        pool.join()
     if use_dist:
         dist.destroy_process_group()
     if rank == 0:

@@ -48,6 +48,7 @@ SIGNATURES = [
     ("fqtk_matcher_create", C.c_int, [C.POINTER(C.c_char_p), C.c_uint32, C.c_uint32, C.c_uint8,
                                       C.c_uint8, C.c_int, C.POINTER(C.c_void_p)]),
     ("fqtk_matcher_destroy", None, [C.c_void_p]),
+    ("fqtk_matcher_set_sample_ids", C.c_int, [C.c_void_p, C.POINTER(C.c_char_p)]),
     ("fqtk_matcher_n_samples", C.c_uint32, [C.c_void_p]),
     ("fqtk_matcher_barcode_len", C.c_uint32, [C.c_void_p]),
     ("fqtk_matcher_max_ns_in_barcodes", C.c_uint32, [C.c_void_p]),

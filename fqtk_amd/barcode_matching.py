@@ -69,6 +69,9 @@ class BarcodeMatcher:
         _check(self._lib.fqtk_matcher_create(arr, n, L, max_mismatches, min_mismatch_delta, device,
                                              C.byref(h)))
         self._h = h
+        if n and all(isinstance(s, Sample) for s in samples):   # ids word the length-error message (:95-107)
+            ids = (C.c_char_p * n)(*[s.sample_id.encode("latin-1") for s in samples])
+            _check(self._lib.fqtk_matcher_set_sample_ids(h, ids))
         _check(self._lib.fqtk_matcher_set_use_cache(h, 1 if use_cache else 0))
         self.use_cache = use_cache
         self.max_mismatches = max_mismatches

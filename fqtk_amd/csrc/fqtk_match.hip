@@ -62,6 +62,16 @@ uint8_t enc_byte(uint8_t b) {
     }
 }
 
+// What a latched length error refers to: the batch whose kernel raised it (so that the reference's
+// panic sentence -- which quotes the read -- can be rebuilt on the host, barcode_matching.rs:95-107).
+struct ErrCtx {
+    const uint8_t *obs = nullptr;    // host pointers (enqueue / assign_batch) or device pointers (*_device)
+    const uint32_t *lens = nullptr;
+    uint32_t stride = 0;
+    uint64_t n = 0;
+    bool device = false;
+};
+
 struct Slot {
     hipStream_t stream = nullptr;
     uint8_t *d_obs = nullptr;
@@ -71,7 +81,16 @@ struct Slot {
     uint32_t *d_out = nullptr;
     size_t out_cap = 0;  // elements
     bool busy = false;
+    ErrCtx ctx;          // the chunk in flight on this slot
 };
+
+// Pipeline slots 0..FQTK_MAX_SLOTS-1 belong to the caller (enqueue/wait); two more are private to the
+// synchronous fqtk_matcher_assign_batch(), so a caller's chunk in flight is never waited on or
+// re-used behind its back.  Every slot has its OWN latched error word (device + pinned mirror), so an
+// error is reported by the wait() of the chunk that raised it; one more word serves the *_device entry.
+constexpr int kSyncSlot0 = FQTK_MAX_SLOTS;
+constexpr int kNumSlots = FQTK_MAX_SLOTS + 2;
+constexpr int kDeviceErrWord = kNumSlots;
 
 }  // namespace
 
@@ -82,10 +101,13 @@ struct fqtk_matcher {
     int num_cus = 256;
     uint32_t *d_table = nullptr;
     uint32_t *d_lut = nullptr;
-    unsigned long long *d_err = nullptr;     // [0] min offending index, ~0 = none
+    unsigned long long *d_err = nullptr;     // [kNumSlots + 1] min offending index per slot (+ *_device entry), ~0 = none
     unsigned long long *d_counts = nullptr;       // S+1, accumulator of the enqueue()/wait() pipeline
     unsigned long long *d_counts_sync = nullptr;  // S+1, private to the synchronous assign_batch()
-    unsigned long long *h_err = nullptr;     // pinned mirror
+    unsigned long long *h_err = nullptr;     // pinned mirror, same layout
+    ErrCtx device_ctx;                       // last *_device batch (for the error sentence)
+    std::vector<std::string> barcodes_upper; // as the reference keeps them (:71)
+    std::vector<std::string> sample_ids;     // optional (fqtk_matcher_set_sample_ids); default "sample_<i>"
     // complete memo (memo_kernels.hip.h); absent when the candidate set is over budget or L > 20
     void *d_memo = nullptr;
     uint32_t *d_hot = nullptr;               // hot subset (0-mismatch entries) for the LDS table
@@ -105,7 +127,7 @@ struct fqtk_matcher {
     int memo_kind_wanted = 0;                  // 0 = best available, 1 = force the HBM/L2 table (tests, A/B)
     size_t ldsm_lds_bytes = 0;                 // image + LUT (histogram added at launch)
     int use_cache = 1;                       // BarcodeMatcher.use_cache (barcode_matching.rs:41-42)
-    Slot slots[FQTK_MAX_SLOTS];
+    Slot slots[kNumSlots];
 };
 
 namespace {
@@ -125,7 +147,7 @@ int ensure_cap(T *&ptr, size_t &cap, size_t want) {
 }
 
 int ensure_slot(fqtk_matcher *m, int slot) {
-    if (slot < 0 || slot >= FQTK_MAX_SLOTS) return fail(FQTK_EINVAL, "slot out of range");
+    if (slot < 0 || slot >= kNumSlots) return fail(FQTK_EINVAL, "slot out of range");
     Slot &s = m->slots[slot];
     if (!s.stream) HIP_TRY(hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking));
     return FQTK_OK;
@@ -186,6 +208,7 @@ int launch_memo_vec(const fqtk_matcher *m, const fqtk::MemoParams &Q, hipStream_
     // pressure, and 1 on the generic paths (4 would spill)
     int R = vec > 0 ? (m->memo_entries <= 65536 ? 4 : 2) : 1;
     if (vec == 5) R = 2;   // 20-byte reads: 4 per lane would spill at 64 VGPRs
+    if (P.lens) R = 1;
     int abl = 0;
 #ifdef FQTK_DEV_ABLATE
     if (const char *rr = std::getenv("FQTK_MEMO_R")) R = std::atoi(rr);
@@ -204,10 +227,11 @@ int launch_memo_vec(const fqtk_matcher *m, const fqtk::MemoParams &Q, hipStream_
     if (ntiles == 0) return FQTK_OK;
     const uint32_t grid = (uint32_t)std::min<uint64_t>(ntiles, (uint64_t)m->num_cus * (2048 / fqtk::kMemoBlock));
     // the packed vector paths imply the key width (stride 16 B -> 2 key words, 12 B -> 1 or 2, 8/4 B -> 1)
-#define FQTK_MEMO_LAUNCH(V, RR, A)                                                                         \
+#define FQTK_MEMO_LAUNCH(V, RR, A) FQTK_MEMO_LAUNCH_L(V, RR, A, false)
+#define FQTK_MEMO_LAUNCH_L(V, RR, A, LENS)                                                                 \
     do {                                                                                                   \
         if constexpr ((V) <= 0 || ((V) == 3 && KW <= 2) || KW == ((V) == 5 ? 3 : ((V) == 4 ? 2 : 1))) {    \
-            auto kern = fqtk::memo_kernel<V, KW, RR, A>;                                                   \
+            auto kern = fqtk::memo_kernel<V, KW, RR, A, LENS>;                                             \
             const void *fn = reinterpret_cast<const void *>(kern);                                         \
             if (shmem > 64 * 1024 &&                                                                       \
                 std::find(m->ldsm_big_lds_ok.begin(), m->ldsm_big_lds_ok.end(), fn) == m->ldsm_big_lds_ok.end()) { \
@@ -242,7 +266,17 @@ int launch_memo_vec(const fqtk_matcher *m, const fqtk::MemoParams &Q, hipStream_
         return FQTK_OK;
     }
 #endif
-    if (R == 4 && vec > 0) {
+    if (P.lens) {   // variable-length batch: one read per lane on every load path (the LENS instantiations)
+        switch (vec) {
+            case 5: FQTK_MEMO_LAUNCH_L(5, 1, 0, true); break;
+            case 4: FQTK_MEMO_LAUNCH_L(4, 1, 0, true); break;
+            case 3: FQTK_MEMO_LAUNCH_L(3, 1, 0, true); break;
+            case 2: FQTK_MEMO_LAUNCH_L(2, 1, 0, true); break;
+            case 1: FQTK_MEMO_LAUNCH_L(1, 1, 0, true); break;
+            case -1: FQTK_MEMO_LAUNCH_L(-1, 1, 0, true); break;
+            default: FQTK_MEMO_LAUNCH_L(0, 1, 0, true); break;
+        }
+    } else if (R == 4 && vec > 0) {
         switch (vec) {
             case 4: FQTK_MEMO_LAUNCH(4, 4, 0); break;
             case 3: FQTK_MEMO_LAUNCH(3, 4, 0); break;
@@ -252,6 +286,7 @@ int launch_memo_vec(const fqtk_matcher *m, const fqtk::MemoParams &Q, hipStream_
     } else if (R >= 2) { FQTK_MEMO_BY_VEC(2, 0) } else { FQTK_MEMO_BY_VEC(1, 0) }
 #undef FQTK_MEMO_BY_VEC
 #undef FQTK_MEMO_LAUNCH
+#undef FQTK_MEMO_LAUNCH_L
     HIP_TRY(hipGetLastError());
     return FQTK_OK;
 }
@@ -281,16 +316,18 @@ int launch_lds_memo(const fqtk_matcher *m, fqtk::LdsMemoParams Q, hipStream_t st
 #ifdef FQTK_DEV_ABLATE
     if (const char *rr = std::getenv("FQTK_MEMO_R")) R = std::atoi(rr);
 #endif
+    if (P.lens) R = 1;
     const uint64_t tile = (uint64_t)fqtk::kLdsBlock * R;
     const uint64_t ntiles = (P.n + tile - 1) / tile;
     if (ntiles == 0) return FQTK_OK;
     // workgroups per CU: LDS-limited, and never more than 2 x 1024 lanes
     const uint32_t per_cu = (uint32_t)std::max<size_t>(1, std::min<size_t>(2048 / fqtk::kLdsBlock, fqtk::kLdsMemoMaxBytes / (shmem + 1024)));
     const uint32_t grid = (uint32_t)std::min<uint64_t>(ntiles, (uint64_t)m->num_cus * per_cu);
-#define FQTK_LDSM_LAUNCH(V, RR)                                                                            \
+#define FQTK_LDSM_LAUNCH(V, RR) FQTK_LDSM_LAUNCH_L(V, RR, false)
+#define FQTK_LDSM_LAUNCH_L(V, RR, LENS)                                                                    \
     do {                                                                                                   \
         if constexpr ((V) <= 0 || KW == ((V) == 5 ? 3 : ((V) >= 3 ? 2 : 1))) {                             \
-            auto kern = fqtk::lds_memo_kernel<V, KW, RR, POW2>;                                                  \
+            auto kern = fqtk::lds_memo_kernel<V, KW, RR, POW2, LENS>;                                      \
             /* > 64 KiB of dynamic LDS must be allowed per kernel AND per device: remembered per matcher */ \
             const void *fn = reinterpret_cast<const void *>(kern);                                         \
             if (shmem > 64 * 1024 &&                                                                       \
@@ -311,7 +348,17 @@ int launch_lds_memo(const fqtk_matcher *m, fqtk::LdsMemoParams Q, hipStream_t st
         return FQTK_OK;
     }
 #endif
-    if (R >= 4 && vec > 0) {
+    if (P.lens) {   // variable-length batch: the LENS instantiations, one read per lane
+        switch (vec) {
+            case 5: FQTK_LDSM_LAUNCH_L(5, 1, true); break;
+            case 4: FQTK_LDSM_LAUNCH_L(4, 1, true); break;
+            case 3: FQTK_LDSM_LAUNCH_L(3, 1, true); break;
+            case 2: FQTK_LDSM_LAUNCH_L(2, 1, true); break;
+            case 1: FQTK_LDSM_LAUNCH_L(1, 1, true); break;
+            case -1: FQTK_LDSM_LAUNCH_L(-1, 1, true); break;
+            default: FQTK_LDSM_LAUNCH_L(0, 1, true); break;
+        }
+    } else if (R >= 4 && vec > 0) {
         switch (vec) {
             case 5: FQTK_LDSM_LAUNCH(5, 4); break;
             case 4: FQTK_LDSM_LAUNCH(4, 4); break;
@@ -341,13 +388,24 @@ int launch_lds_memo(const fqtk_matcher *m, fqtk::LdsMemoParams Q, hipStream_t st
         }
     }
 #undef FQTK_LDSM_LAUNCH
+#undef FQTK_LDSM_LAUNCH_L
     HIP_TRY(hipGetLastError());
     return FQTK_OK;
 }
 
 int launch(const fqtk_matcher *m, const fqtk::MatchParams &P, hipStream_t stream) {
-    // memo path: reads all exactly L long (no obs_len), table present, caller did not opt out
-    if (m->use_cache && m->d_ldsm && !P.lens && m->memo_kind_wanted != 1) {
+    // Rows shorter than a barcode (only legal with obs_len, check_batch_args): every read is shorter
+    // than L, so every result is None (barcode_matching.rs:167-169) -- and no kernel below may read L
+    // bytes from rows that do not hold them.
+    if (P.stride < P.L) {
+        const uint32_t grid = (uint32_t)std::min<uint64_t>((P.n + 255) / 256, (uint64_t)m->num_cus * 8);
+        hipLaunchKernelGGL(fqtk::none_kernel, dim3(grid), dim3(256), 0, stream, P);
+        HIP_TRY(hipGetLastError());
+        return FQTK_OK;
+    }
+    // memo path (table present, caller did not opt out).  With obs_len the memo serves the reads whose
+    // length is exactly L; the others follow the length rules inside the same kernel.
+    if (m->use_cache && m->d_ldsm && m->memo_kind_wanted != 1) {
         fqtk::LdsMemoParams Q = m->ldsm;
         Q.m = P;
         switch (m->ldsm_kw * 2 + (m->ldsm_pow2 ? 1 : 0)) {
@@ -359,7 +417,7 @@ int launch(const fqtk_matcher *m, const fqtk::MatchParams &P, hipStream_t stream
             default: return launch_lds_memo<3, false>(m, Q, stream);
         }
     }
-    if (m->use_cache && m->d_memo && !P.lens) {
+    if (m->use_cache && m->d_memo) {
         fqtk::MemoParams Q;
         Q.m = P;
         Q.slots = m->d_memo;
@@ -382,7 +440,7 @@ int launch(const fqtk_matcher *m, const fqtk::MatchParams &P, hipStream_t stream
 }
 
 fqtk::MatchParams make_params(const fqtk_matcher *m, const void *d_obs, uint32_t stride,
-                              const void *d_len, uint64_t n, void *d_out, void *d_counts) {
+                              const void *d_len, uint64_t n, void *d_out, void *d_counts, int err_word) {
     fqtk::MatchParams P;
     P.obs = static_cast<const uint8_t *>(d_obs);
     P.lens = static_cast<const uint32_t *>(d_len);
@@ -390,7 +448,7 @@ fqtk::MatchParams make_params(const fqtk_matcher *m, const void *d_obs, uint32_t
     P.counts = static_cast<unsigned long long *>(d_counts);
     P.table = m->d_table;
     P.lut = m->d_lut;
-    P.err = m->d_err;
+    P.err = m->d_err + err_word;
     P.n = n;
     P.stride = stride;
     P.S = m->S;
@@ -413,20 +471,64 @@ int check_batch_args(const fqtk_matcher *m, const void *obs, uint32_t stride, co
     return FQTK_OK;
 }
 
-// Reads + clears the latched error word.  Stream must be idle for the value to be final.
-int collect_error(fqtk_matcher *m, hipStream_t stream, uint64_t *read_index) {
-    HIP_TRY(hipMemcpyAsync(m->h_err, m->d_err, sizeof(unsigned long long), hipMemcpyDeviceToHost, stream));
+// decode(encode(read)) as the reference's panic message prints it (mod.rs:62-80): every base becomes
+// the FIRST letter of "ACGTMRWSYKVHDBN" with its mask; a byte with no mask makes decode() itself panic.
+bool decode_like_reference(const uint8_t *read, uint32_t len, std::string *out) {
+    static const char kIupacBases[] = "ACGTMRWSYKVHDBN";
+    out->clear();
+    for (uint32_t i = 0; i < len; ++i) {
+        const uint8_t e = enc_byte(read[i]);
+        char c = 0;
+        for (const char *b = kIupacBases; *b; ++b)
+            if (enc_byte((uint8_t)*b) == e) { c = *b; break; }
+        if (!c) return false;
+        out->push_back(c);
+    }
+    return true;
+}
+
+// Reads + clears one latched error word.  Stream must be idle for the value to be final.  On an error
+// the message is the reference's own sentence (barcode_matching.rs:95-107: assign_internal compares
+// with sample 0 first, so that is the sample it names), followed by the read's index in its batch.
+int collect_error(fqtk_matcher *m, hipStream_t stream, int err_word, const ErrCtx &ctx, uint64_t *read_index) {
+    unsigned long long *d_err = m->d_err + err_word, *h_err = m->h_err + err_word;
+    HIP_TRY(hipMemcpyAsync(h_err, d_err, sizeof(unsigned long long), hipMemcpyDeviceToHost, stream));
     HIP_TRY(hipStreamSynchronize(stream));
-    const unsigned long long e = *m->h_err;
+    const unsigned long long e = *h_err;
     if (e == ~0ull) return FQTK_OK;
-    HIP_TRY(hipMemsetAsync(m->d_err, 0xFF, sizeof(unsigned long long), stream));
+    HIP_TRY(hipMemsetAsync(d_err, 0xFF, sizeof(unsigned long long), stream));
     HIP_TRY(hipStreamSynchronize(stream));
     if (read_index) *read_index = (uint64_t)e;
-    char buf[160];
-    std::snprintf(buf, sizeof buf,
-                  "Read barcode length differs from expected barcode length (%u): read index %llu is longer",
-                  m->L, e);
-    return fail(FQTK_ELEN, buf);
+    std::string msg;
+    std::vector<uint8_t> read;
+    uint32_t len = 0;
+    bool have = false;
+    if (ctx.obs && ctx.lens && e < ctx.n) {
+        read.resize(ctx.stride);
+        if (ctx.device) {
+            have = hipMemcpy(&len, ctx.lens + e, sizeof len, hipMemcpyDeviceToHost) == hipSuccess &&
+                   hipMemcpy(read.data(), ctx.obs + e * (uint64_t)ctx.stride, ctx.stride, hipMemcpyDeviceToHost) == hipSuccess;
+            if (!have) (void)hipGetLastError();
+        } else {
+            len = ctx.lens[e];
+            std::memcpy(read.data(), ctx.obs + e * (uint64_t)ctx.stride, ctx.stride);
+            have = true;
+        }
+        len = std::min(len, ctx.stride);
+    }
+    const std::string id = m->sample_ids.empty() ? std::string("sample_0") : m->sample_ids[0];
+    std::string decoded;
+    if (have && !decode_like_reference(read.data(), len, &decoded)) {
+        msg = "Invalid bit mask for base: 0";   // decode() panics first on a byte with no IUPAC mask (mod.rs:80)
+    } else if (have) {
+        msg = "Read barcode (" + decoded + ") length (" + std::to_string(len) + ") differs from expected barcode (" +
+              m->barcodes_upper[0] + ") length (" + std::to_string(m->L) + ") for sample " + id;
+    } else {
+        msg = "Read barcode length differs from expected barcode (" + m->barcodes_upper[0] + ") length (" +
+              std::to_string(m->L) + ") for sample " + id;
+    }
+    msg += " [read index " + std::to_string(e) + " of its batch]";
+    return fail(FQTK_ELEN, msg);
 }
 
 
@@ -673,7 +775,7 @@ extern "C" {
 
 const char *fqtk_last_error(void) { return g_last_error.c_str(); }
 
-int fqtk_abi_version(void) { return 2; }
+int fqtk_abi_version(void) { return 3; }
 
 int fqtk_device_count(int *n_devices) {
     if (!n_devices) return fail(FQTK_EINVAL, "n_devices is NULL");
@@ -731,11 +833,13 @@ int fqtk_matcher_create(const char *const *barcodes, uint32_t n_samples, uint32_
     std::vector<uint32_t> table((size_t)n_samples * m->NW * 4, 0u);
     std::vector<std::vector<uint8_t>> enc(n_samples, std::vector<uint8_t>(barcode_len));
     uint32_t max_ns = 0;
+    m->barcodes_upper.resize(n_samples);
     for (uint32_t s = 0; s < n_samples; ++s) {
         uint32_t ns = 0;
         for (uint32_t i = 0; i < barcode_len; ++i) {
             uint8_t b = (uint8_t)barcodes[s][i];
             if (b >= 'a' && b <= 'z') b = (uint8_t)(b - 32);
+            m->barcodes_upper[s].push_back((char)b);
             if (b == 'N' || b == 'n' || b == '.') ns++;
             const uint8_t e = enc_byte(b);
             enc[s][i] = e;
@@ -768,14 +872,15 @@ int fqtk_matcher_create(const char *const *barcodes, uint32_t n_samples, uint32_
     HIP_TRY_C(hipMemcpy(m->d_table, table.data(), table.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
     HIP_TRY_C(hipMalloc(reinterpret_cast<void **>(&m->d_lut), 256 * sizeof(uint32_t)));
     HIP_TRY_C(hipMemcpy(m->d_lut, lut.data(), 256 * sizeof(uint32_t), hipMemcpyHostToDevice));
-    HIP_TRY_C(hipMalloc(reinterpret_cast<void **>(&m->d_err), sizeof(unsigned long long)));
-    HIP_TRY_C(hipMemset(m->d_err, 0xFF, sizeof(unsigned long long)));
+    constexpr size_t kErrBytes = (size_t)(kNumSlots + 1) * sizeof(unsigned long long);
+    HIP_TRY_C(hipMalloc(reinterpret_cast<void **>(&m->d_err), kErrBytes));
+    HIP_TRY_C(hipMemset(m->d_err, 0xFF, kErrBytes));
     HIP_TRY_C(hipMalloc(reinterpret_cast<void **>(&m->d_counts), (size_t)(n_samples + 1) * sizeof(unsigned long long)));
     HIP_TRY_C(hipMemset(m->d_counts, 0, (size_t)(n_samples + 1) * sizeof(unsigned long long)));
     HIP_TRY_C(hipMalloc(reinterpret_cast<void **>(&m->d_counts_sync), (size_t)(n_samples + 1) * sizeof(unsigned long long)));
     HIP_TRY_C(hipMemset(m->d_counts_sync, 0, (size_t)(n_samples + 1) * sizeof(unsigned long long)));
-    HIP_TRY_C(hipHostMalloc(reinterpret_cast<void **>(&m->h_err), sizeof(unsigned long long), hipHostMallocDefault));
-    *m->h_err = ~0ull;
+    HIP_TRY_C(hipHostMalloc(reinterpret_cast<void **>(&m->h_err), kErrBytes, hipHostMallocDefault));
+    std::memset(m->h_err, 0xFF, kErrBytes);
     // The pipeline slots use NON-BLOCKING streams, which do not order against the legacy NULL stream the
     // initialisation above ran on: make it all visible before any slot stream touches these buffers.
     HIP_TRY_C(hipDeviceSynchronize());
@@ -817,6 +922,17 @@ uint32_t fqtk_matcher_barcode_len(const fqtk_matcher *m) { return m ? m->L : 0; 
 uint32_t fqtk_matcher_max_ns_in_barcodes(const fqtk_matcher *m) { return m ? m->max_ns : 0; }
 int fqtk_matcher_device(const fqtk_matcher *m) { return m ? m->device : -1; }
 
+int fqtk_matcher_set_sample_ids(fqtk_matcher *m, const char *const *sample_ids) {
+    if (!m) return fail(FQTK_EINVAL, "matcher is NULL");
+    m->sample_ids.clear();
+    if (!sample_ids) return FQTK_OK;
+    for (uint32_t s = 0; s < m->S; ++s) {
+        if (!sample_ids[s]) { m->sample_ids.clear(); return fail(FQTK_EINVAL, "sample id is NULL"); }
+        m->sample_ids.emplace_back(sample_ids[s]);
+    }
+    return FQTK_OK;
+}
+
 int fqtk_matcher_set_use_cache(fqtk_matcher *m, int use_cache) {
     if (!m) return fail(FQTK_EINVAL, "matcher is NULL");
     m->use_cache = use_cache ? 1 : 0;
@@ -844,14 +960,15 @@ int fqtk_matcher_assign_batch_device(fqtk_matcher *m, const void *d_obs, uint32_
     int rc = check_batch_args(m, d_obs, stride, d_obs_len, n, d_out);
     if (rc != FQTK_OK || n == 0) return rc;
     HIP_TRY(hipSetDevice(m->device));
-    const fqtk::MatchParams P = make_params(m, d_obs, stride, d_obs_len, n, d_out, d_counts);
+    const fqtk::MatchParams P = make_params(m, d_obs, stride, d_obs_len, n, d_out, d_counts, kDeviceErrWord);
+    m->device_ctx = ErrCtx{static_cast<const uint8_t *>(d_obs), static_cast<const uint32_t *>(d_obs_len), stride, n, true};
     return launch(m, P, static_cast<hipStream_t>(hip_stream));
 }
 
 int fqtk_matcher_poll_error(fqtk_matcher *m, void *hip_stream, uint64_t *read_index) {
     if (!m) return fail(FQTK_EINVAL, "matcher is NULL");
     HIP_TRY(hipSetDevice(m->device));
-    return collect_error(m, static_cast<hipStream_t>(hip_stream), read_index);
+    return collect_error(m, static_cast<hipStream_t>(hip_stream), kDeviceErrWord, m->device_ctx, read_index);
 }
 
 }  // extern "C"
@@ -868,6 +985,11 @@ int enqueue_impl(fqtk_matcher *m, int slot, const uint8_t *obs, uint32_t stride,
     Slot &s = m->slots[slot];
     if (s.busy) return fail(FQTK_EINVAL, "slot is busy: call fqtk_matcher_wait() first");
     if (n == 0) return FQTK_OK;
+    if (obs_len)   // a length beyond its row would make the kernels (and the error report) read past it
+        for (uint64_t i = 0; i < n; ++i)
+            if (obs_len[i] > stride)
+                return fail(FQTK_EINVAL, "obs_len[" + std::to_string(i) + "] = " + std::to_string(obs_len[i]) +
+                                             " exceeds stride " + std::to_string(stride));
     const size_t obs_bytes = (size_t)n * stride;
     if ((rc = ensure_cap(s.d_obs, s.obs_cap, obs_bytes + 16)) != FQTK_OK) return rc;
     if ((rc = ensure_cap(s.d_out, s.out_cap, (size_t)n)) != FQTK_OK) return rc;
@@ -876,7 +998,8 @@ int enqueue_impl(fqtk_matcher *m, int slot, const uint8_t *obs, uint32_t stride,
     if (obs_len)
         HIP_TRY(hipMemcpyAsync(s.d_len, obs_len, (size_t)n * sizeof(uint32_t), hipMemcpyHostToDevice, s.stream));
     const fqtk::MatchParams P =
-        make_params(m, s.d_obs, stride, obs_len ? s.d_len : nullptr, n, s.d_out, d_counts_target);
+        make_params(m, s.d_obs, stride, obs_len ? s.d_len : nullptr, n, s.d_out, d_counts_target, slot);
+    s.ctx = ErrCtx{obs, obs_len, stride, n, false};
     rc = launch(m, P, s.stream);
     if (rc != FQTK_OK) return rc;
     HIP_TRY(hipMemcpyAsync(out, s.d_out, (size_t)n * sizeof(fqtk_match_t), hipMemcpyDeviceToHost, s.stream));
@@ -885,23 +1008,30 @@ int enqueue_impl(fqtk_matcher *m, int slot, const uint8_t *obs, uint32_t stride,
 }
 }  // namespace
 
+namespace {
+int wait_impl(fqtk_matcher *m, int slot) {
+    Slot &s = m->slots[slot];
+    if (!s.busy) return FQTK_OK;
+    HIP_TRY(hipSetDevice(m->device));
+    HIP_TRY(hipStreamSynchronize(s.stream));
+    s.busy = false;
+    return collect_error(m, s.stream, slot, s.ctx, nullptr);   // this slot's own error word
+}
+}  // namespace
+
 extern "C" {
 
 int fqtk_matcher_enqueue(fqtk_matcher *m, int slot, const uint8_t *obs, uint32_t stride,
                          const uint32_t *obs_len, uint64_t n, fqtk_match_t *out) {
     if (!m) return fail(FQTK_EINVAL, "matcher is NULL");
+    if (slot < 0 || slot >= FQTK_MAX_SLOTS) return fail(FQTK_EINVAL, "slot out of range");
     return enqueue_impl(m, slot, obs, stride, obs_len, n, out, m->d_counts);
 }
 
 int fqtk_matcher_wait(fqtk_matcher *m, int slot) {
     if (!m) return fail(FQTK_EINVAL, "matcher is NULL");
     if (slot < 0 || slot >= FQTK_MAX_SLOTS) return fail(FQTK_EINVAL, "slot out of range");
-    Slot &s = m->slots[slot];
-    if (!s.busy) return FQTK_OK;
-    HIP_TRY(hipSetDevice(m->device));
-    HIP_TRY(hipStreamSynchronize(s.stream));
-    s.busy = false;
-    return collect_error(m, s.stream, nullptr);
+    return wait_impl(m, slot);
 }
 
 int fqtk_matcher_counts(fqtk_matcher *m, uint64_t *counts) {
@@ -938,31 +1068,32 @@ int fqtk_matcher_assign_batch(fqtk_matcher *m, const uint8_t *obs, uint32_t stri
     uint64_t done = 0;
     int k = 0;
     uint64_t pending_base[2] = {0, 0};
-    auto drain = [&](int slot) {
-        int w = fqtk_matcher_wait(m, slot);
+    auto drain = [&](int slot) {   // slot = kSyncSlot0 + {0, 1}: private to this call
+        int w = wait_impl(m, slot);
         if (w != FQTK_OK && first_err == FQTK_OK) {
             first_err = w;
             first_msg = g_last_error;
-            if (w == FQTK_ELEN) first_msg += " (chunk base " + std::to_string(pending_base[slot]) + ")";
+            if (w == FQTK_ELEN) first_msg += " (chunk base " + std::to_string(pending_base[slot - kSyncSlot0]) + ")";
         }
     };
     while (done < n) {
-        const int slot = k & 1;
+        const int slot = kSyncSlot0 + (k & 1);
         drain(slot);
         const uint64_t cur = std::min(chunk, n - done);
-        pending_base[slot] = done;
+        pending_base[slot - kSyncSlot0] = done;
         rc = enqueue_impl(m, slot, obs + done * stride, stride, obs_len ? obs_len + done : nullptr, cur,
                           out + done, counts ? m->d_counts_sync : nullptr);
         if (rc != FQTK_OK) {
-            drain(0);
-            drain(1);
-            return rc;
+            const std::string msg = g_last_error;
+            drain(kSyncSlot0);
+            drain(kSyncSlot0 + 1);
+            return fail(rc, msg);
         }
         done += cur;
         ++k;
     }
-    drain(0);
-    drain(1);
+    drain(kSyncSlot0);
+    drain(kSyncSlot0 + 1);
     if (counts) {
         std::vector<unsigned long long> tmp(bins);
         HIP_TRY(hipMemcpy(tmp.data(), m->d_counts_sync, bins * sizeof(unsigned long long), hipMemcpyDeviceToHost));

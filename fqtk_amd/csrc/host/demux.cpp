@@ -469,6 +469,9 @@ int main(int argc, char **argv) {
         if (fqtk_matcher_create(bc.data(), (uint32_t)S, L, (uint8_t)opt.max_mismatches, (uint8_t)opt.min_mismatch_delta,
                                 opt.devices[g], &matchers[g]) != FQTK_OK)
             die(std::string("cannot create the GPU barcode matcher: ") + fqtk_last_error());
+        std::vector<const char *> ids;   // so that a length error names the sample like the reference's panic does
+        for (const Sample &s : samples) ids.push_back(s.sample_id.c_str());
+        fqtk_matcher_set_sample_ids(matchers[g], ids.data());
         info("GPU barcode matcher ready on device %d (%llu memo entries).", opt.devices[g],
              (unsigned long long)fqtk_matcher_memo_entries(matchers[g]));
     }

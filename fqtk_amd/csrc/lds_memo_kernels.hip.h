@@ -69,7 +69,7 @@ __device__ __forceinline__ uint32_t lane_select(uint64_t mask, uint32_t a, uint3
     return d;
 }
 
-template <int VEC, int KW, int R, bool POW2>
+template <int VEC, int KW, int R, bool POW2, bool LENS = false>   // LENS: see memo_kernel
 __global__ __launch_bounds__(kLdsBlock) __attribute__((amdgpu_waves_per_eu(4, 8)))
 void lds_memo_kernel(const LdsMemoParams Q) {
     const MatchParams &P = Q.m;
@@ -210,6 +210,21 @@ void lds_memo_kernel(const LdsMemoParams Q) {
                 if (need3) v = v3;
             }
             res[r] = v;
+        }
+        // ---- variable-length batches: the memo served the reads of length L; shorter -> None
+        //      (barcode_matching.rs:167-169), longer -> None or the reference's panic (:170-172, :95-107)
+        if constexpr (LENS) {
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                if (!live[r]) continue;
+                const uint64_t i = t * tile + local[r];
+                const uint32_t len = P.lens[i];
+                if (len != L) {
+                    res[r] = kMemoEmpty;
+                    bflag[r] = 0;
+                    if (len > L) overlong_read(P, i, len);
+                }
+            }
         }
         // ---- rare: non-canonical reads -> wave-cooperative exhaustive scan ---------------------
         uint32_t any_bad = 0;

@@ -212,6 +212,25 @@ __device__ __forceinline__ void update(const Planes<NW> &o, const u32x4 (&e)[NW]
 
 __device__ __forceinline__ bool byte_is_nocall(uint8_t b) { return b == 'N' || b == 'n' || b == '.'; }
 
+// A read LONGER than the expected barcodes (barcode_matching.rs:170-172, then :95-107): the reference counts
+// the no-calls of the WHOLE read; above max_mismatches + max_ns_in_barcodes it returns None, otherwise it
+// panics in count_mismatches -> the lowest such read index is latched in P.err (FQTK_ELEN).  Rare;
+// `len` is clamped to the row so a bad length can never read past it.
+__device__ __forceinline__ void overlong_read(const MatchParams &P, uint64_t i, uint32_t len) {
+    const uint8_t *src = P.obs + i * (uint64_t)P.stride;
+    const uint32_t lim = len < P.stride ? len : P.stride;
+    uint32_t nc = 0;
+    for (uint32_t k = 0; k < lim; ++k) nc += byte_is_nocall(src[k]) ? 1u : 0u;
+    if (nc <= P.nocall_limit) atomicMin(P.err, (unsigned long long)i);
+}
+
+// Every read None: used when the rows are shorter than a barcode (stride < L, so every obs_len < L).
+__global__ __launch_bounds__(256) void none_kernel(const MatchParams P) {
+    const uint64_t step = (uint64_t)gridDim.x * 256;
+    for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < P.n; i += step) P.out[i] = 0xFFFFFFFFu;
+    if (P.counts && blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&P.counts[P.S], (unsigned long long)P.n);
+}
+
 // The kernel.  NW = 32-base words per plane (L <= 32*NW), R = reads per lane (amortises the scalar
 // table loads), VEC = load path (see load_words).
 template <int NW, int R, int VEC>
@@ -287,12 +306,8 @@ __global__ __launch_bounds__(kBlock) void match_kernel(const MatchParams P) {
                 if (len < P.L) {
                     none = true;
                 } else if (len > P.L) {
-                    // the reference counts no-calls over the WHOLE read before it can panic
-                    const uint8_t *src = P.obs + i * (uint64_t)P.stride;
-                    uint32_t nc = 0;
-                    for (uint32_t k = 0; k < len; ++k) nc += byte_is_nocall(src[k]) ? 1u : 0u;
                     none = true;
-                    if (nc <= P.nocall_limit) atomicMin(P.err, (unsigned long long)i);
+                    overlong_read(P, i, len);
                 }
             }
             const uint32_t idx = none ? kNoMatch : (best[r] & 0xFFFFu);

@@ -135,7 +135,10 @@ constexpr int kMemoBlock = FQTK_MEMO_BLOCK;
 #ifndef FQTK_MEMO_WAVES
 #define FQTK_MEMO_WAVES 8
 #endif
-template <int VEC, int KW, int R, int ABL>
+// LENS: the batch carries obs_len (variable-length '+B' structures): the memo serves the reads of length
+// exactly L, the others follow the length rules of barcode_matching.rs:165-172.  A separate instantiation,
+// so that the fixed-length kernels carry none of it.
+template <int VEC, int KW, int R, int ABL, bool LENS = false>
 __global__ __launch_bounds__(kMemoBlock) __attribute__((amdgpu_waves_per_eu(FQTK_MEMO_WAVES, 8)))
 void memo_kernel(const MemoParams Q) {
     const MatchParams &P = Q.m;
@@ -191,6 +194,7 @@ void memo_kernel(const MemoParams Q) {
             uint32_t b;
             encode_nibbles<NWD, (VEC >= 1 && !(ABL & 2)), FOLD>(words[r], kc, kv, lo[r], hi[r], ext[r], b);
             bad[r] = b != 0 && live[r];
+            if constexpr (LENS) { if (live[r]) bad[r] = bad[r] && P.lens[t * tile + (uint64_t)r * kMemoBlock + tid] == L; }
         }
         // ---- probe: both candidate slots of every read are known up front.  Empty slots carry
         //      key = ~0 (no real key has a nibble's top bit set) and val = None. ---------------------
@@ -282,6 +286,13 @@ void memo_kernel(const MemoParams Q) {
         for (int r = 0; r < R; ++r) {
             if (!live[r]) continue;
             const uint64_t i = t * tile + (uint64_t)r * kMemoBlock + tid;
+            if constexpr (LENS) {   // variable-length batch: the memo served the reads of length L
+                const uint32_t len = P.lens[i];
+                if (len != L) {   // shorter -> None (barcode_matching.rs:167-169); longer -> None or the panic
+                    res[r] = kMemoEmpty;
+                    if (len > L) overlong_read(P, i, len);
+                }
+            }
             if constexpr (ABL & 8) { if (res[r] == 0x12345u) P.out[i] = res[r]; } else
             FQTK_STREAM_STORE(res[r], &P.out[i]);
             if (P.counts && !(ABL & 4)) {

@@ -81,6 +81,12 @@ int fqtk_matcher_create(const char *const *barcodes, uint32_t n_samples, uint32_
 
 void fqtk_matcher_destroy(fqtk_matcher *m);
 
+/* Optional: the `sample_id` of each sample (Sample.sample_id, samples.rs:19), in table order; copied.
+ * Only used to word FQTK_ELEN messages exactly like the reference's panic, which names the sample
+ * (barcode_matching.rs:95-107).  Without it samples are called "sample_<index>", as the reference's own
+ * test helper names them (barcode_matching.rs:195-211).  NULL clears. */
+int fqtk_matcher_set_sample_ids(fqtk_matcher *m, const char *const *sample_ids);
+
 /* Introspection (fields of BarcodeMatcher, barcode_matching.rs:29-45). */
 uint32_t fqtk_matcher_n_samples(const fqtk_matcher *m);
 uint32_t fqtk_matcher_barcode_len(const fqtk_matcher *m);
@@ -117,12 +123,20 @@ int fqtk_matcher_set_memo_kind(fqtk_matcher *m, int kind);
  *   obs      n x stride ASCII bytes, read i at obs + i*stride (the SoA form of
  *            ReadSet::sample_barcode_sequence, demux.rs:121-123)
  *   obs_len  per-read length, or NULL when every read has exactly barcode_len bases
- *            (stride must then be >= barcode_len); obs_len[i] <= stride
+ *            (stride must then be >= barcode_len); obs_len[i] <= stride is CHECKED here (FQTK_EINVAL).
+ *            With obs_len the memo still serves every read of length barcode_len; shorter reads are
+ *            None, longer ones None or FQTK_ELEN (rules above).  stride < barcode_len is legal with
+ *            obs_len: every read is then shorter than a barcode and every result None.
  *   out      n results
  *   counts   NULL, or S+1 counters that are ADDED to: counts[idx] for Some, counts[S] for None --
  *            the per-sample `templates` metric of demux.rs:970-974
  * Returns FQTK_ELEN when some read is longer than barcode_len and not rejected by the no-call
- * prefilter (its index is in fqtk_last_error()); results for the other reads are still written. */
+ * prefilter; results for the other reads are still written.  fqtk_last_error() is then the
+ * reference's panic sentence for the lowest such read (barcode_matching.rs:95-107),
+ *   "Read barcode (<decoded read>) length (<n>) differs from expected barcode (<sample 0's barcode>)
+ *    length (<L>) for sample <sample 0's id>"   followed by " [read index <i> of its batch]".
+ * Uses two pipeline slots of its own: chunks a caller has in flight on slots 0..FQTK_MAX_SLOTS-1 are
+ * neither waited on nor disturbed. */
 int fqtk_matcher_assign_batch(fqtk_matcher *m, const uint8_t *obs, uint32_t stride,
                               const uint32_t *obs_len, uint64_t n, fqtk_match_t *out,
                               uint64_t *counts);
@@ -130,7 +144,9 @@ int fqtk_matcher_assign_batch(fqtk_matcher *m, const uint8_t *obs, uint32_t stri
 /* Same, but every pointer is a DEVICE pointer on the matcher's device and the work is enqueued on
  * `hip_stream` (a hipStream_t, NULL = the default stream) without synchronising: the zero-copy form
  * used when reads are already resident in HBM.  d_counts: NULL or S+1 uint64 accumulated with
- * atomics.  Length errors are latched in the handle; collect them with fqtk_matcher_poll_error(). */
+ * atomics.  Length errors are latched in the handle; collect them with fqtk_matcher_poll_error().
+ * d_obs_len[i] <= stride is the caller's contract here (device memory is not inspected on the host);
+ * the kernels clamp every access to the read's row regardless. */
 int fqtk_matcher_assign_batch_device(fqtk_matcher *m, const void *d_obs, uint32_t stride,
                                      const void *d_obs_len, uint64_t n, void *d_out, void *d_counts,
                                      void *hip_stream);
@@ -157,7 +173,8 @@ int fqtk_pinned_free(void *p);
  * Per-sample counts are accumulated on the device; read them with fqtk_matcher_counts(). */
 int fqtk_matcher_enqueue(fqtk_matcher *m, int slot, const uint8_t *obs, uint32_t stride,
                          const uint32_t *obs_len, uint64_t n, fqtk_match_t *out);
-/* Blocks until the chunk on `slot` is complete; FQTK_ELEN as for assign_batch. */
+/* Blocks until the chunk on `slot` is complete; FQTK_ELEN as for assign_batch.  Every slot latches its
+ * own error: the status belongs to the chunk that was enqueued on THIS slot. */
 int fqtk_matcher_wait(fqtk_matcher *m, int slot);
 /* Adds the device-side accumulated counts (S+1) of all completed enqueue() chunks into `counts`
  * and resets the device accumulator.  Synchronises all slots. */

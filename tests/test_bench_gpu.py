@@ -1,0 +1,71 @@
+"""bench.py on the GPU box: the scopes / CPU rows / parity gate of the JSON line, the RCCL code path with
+one rank, and the --gpus N self-launch (N real ranks when the box has them, a loud refusal when not)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BENCH = os.path.join(ROOT, "bench.py")
+
+
+def _run(args, env=None, timeout=900):
+    r = subprocess.run([sys.executable, BENCH] + args, capture_output=True, text=True, timeout=timeout,
+                       env=dict(os.environ, **(env or {})))
+    return r
+
+
+def _line(r):
+    assert r.returncode == 0, r.stderr[-3000:]
+    return json.loads(r.stdout.strip().splitlines()[-1])
+
+
+@pytest.mark.gpu
+def test_bench_line_carries_scopes_create_time_cpu_rows_and_the_full_parity_gate():
+    d = _line(_run(["--reads", "3000000", "--steps", "3", "--warmup", "1", "--cpu-seconds", "1",
+                    "--e2e-templates", "200000", "--e2e-threads", "8"]))
+    assert d["n_gpus"] == 1 and d["unit"] == "M reads/s" and d["value"] > 0
+    assert "bit-exact" in d["config"]["parity"] and "count vector of all 3000000 reads" in d["config"]["parity"]
+    assert set(d["scopes"]) == {"K", "B", "E"}
+    assert d["scopes"]["B"]["M_reads_per_s"] > 0 and d["scopes"]["B"]["GB_per_s_over_pcie"] > 0
+    assert d["scopes"]["E"]["templates"] == 200000 and d["scopes"]["E"]["metrics_vs_oracle"] == "per-sample counts identical"
+    assert d["create_ms"] > 0
+    cb = d["cpu_baseline"]
+    assert cb["cores"] == 1 and cb["kind"] == "port" and cb["value"] > 0
+    assert cb["cache_off_1core"]["value"] > 0 and cb["all_cores"]["cores"] >= 1
+    rf = d["roofline"]
+    assert rf["bound"] == "hbm" and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-4
+    assert rf["kernel_ms"] <= d["ms_per_step"] * 1.05
+
+
+@pytest.mark.gpu
+def test_rccl_path_with_one_rank_allreduced_counts_match_the_oracle():
+    d = _line(_run(["--reads", "4000000", "--steps", "2", "--warmup", "1", "--cpu-seconds", "0", "--no-scopes",
+                    "--parity", "full"], env={"FQTK_BENCH_FORCE_DIST": "1"}))
+    assert d["n_gpus"] == 1 and "count vector of all 4000000 reads" in d["config"]["parity"]
+
+
+@pytest.mark.gpu
+def test_gpus_n_launches_n_ranks_itself_or_refuses():
+    import torch
+    have = torch.cuda.device_count()
+    if have >= 2:
+        for scaling in ("weak", "strong"):
+            d = _line(_run(["--gpus", "2", "--reads", "4000000", "--steps", "2", "--warmup", "1", "--cpu-seconds", "0",
+                            "--scaling", scaling, "--parity", "full"]))
+            assert d["n_gpus"] == 2 and d["scaling"] == scaling and len(d["roofline"]["kernel_ms_per_rank"]) == 2
+            assert d["config"]["reads_per_step_whole_job"] == (8000000 if scaling == "weak" else 4000000)
+            assert "count vector of all" in d["config"]["parity"]
+    else:
+        r = _run(["--gpus", str(have + 1), "--reads", "1000000"])
+        assert r.returncode == 2 and "refusing" in r.stderr and not r.stdout.strip()
+
+
+def test_gpus_n_without_gpus_refuses_loudly_and_prints_no_json_line():
+    import torch
+    if torch.cuda.is_available() and torch.cuda.device_count() >= 8:
+        pytest.skip("8 GPUs present")
+    r = _run(["--gpus", "8", "--reads", "1000"], timeout=300)
+    assert r.returncode == 2 and not r.stdout.strip()

@@ -9,7 +9,7 @@ mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 python $R/bench.py > $O/bench.json 2> $O/bench.err
 tail -1 $O/bench.json | cut -c1-200
-B="python $R/bench.py --cpu-seconds 0 --no-verify"
+B="python $R/bench.py --cpu-seconds 0 --no-verify --no-scopes"
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -o bench -- $B > $O/stats.log 2>&1
 timeout 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/fetch -o p -- $B > $O/fetch.log 2>&1
 timeout 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/write -o p -- $B > $O/write.log 2>&1
@@ -27,6 +27,11 @@ for d,c in (("fetch","FETCH_SIZE"),("write","WRITE_SIZE")):
 out["hbm_read_bytes_corrected"]=out["FETCH_SIZE_KB_per_launch"]*1024*2
 out["hbm_write_bytes"]=out["WRITE_SIZE_KB_per_launch"]*1024
 out["traffic_bytes_per_launch"]=out["hbm_read_bytes_corrected"]+out["hbm_write_bytes"]
+import hashlib, os
+h=hashlib.sha1(); d="$R/fqtk_amd/csrc"
+for f in sorted(os.listdir(d)):
+    if f.endswith((".h",".hpp",".hip")): h.update(open(os.path.join(d,f),"rb").read())
+out["kernel_sources_sha1"]=h.hexdigest()   # bench.py reports this traffic only for the kernels it was measured on
 json.dump(out, open(f"{O}/pmc_traffic.json","w"), indent=1)
 print(out)
 PY

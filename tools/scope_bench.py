@@ -1,9 +1,11 @@
 #!/usr/bin/env python3
-"""Scopes B and E of SURVEY.md 8(d) (the headline bench.py is scope K, HBM-resident):
+"""Scopes B and E of SURVEY.md 8(d) (scope K, HBM-resident, is bench.py's `value`):
   B  boundary level: pinned host SoA barcodes -> fqtk_matcher_enqueue/wait -> host results (PCIe incl.)
-  E  end to end: `fqtk demux` on synthetic dual-index FASTQ files (gz or plain) -> per-sample BGZF
-Run on the GPU box:  python tools/scope_bench.py [--templates 2000000] [--threads 32] [--gz]
-Prints one JSON object; numbers go to DESIGN.md, never into bench.py's `value`."""
+  E  end to end: the `fqtk demux` binary on synthetic dual-index FASTQ files (plain or gz) -> per-sample
+     BGZF files + metrics; covers what Demux::execute covers (/root/reference/src/bin/commands/demux.rs:881-1001)
+bench.py imports scope_b()/scope_e() and prints them inside its JSON line (`scopes`); standalone:
+    python tools/scope_bench.py [--templates 4000000] [--threads 32] [--gz] [--skip-b]
+prints one JSON object.  Neither number is ever bench.py's `value`."""
 import argparse
 import ctypes as C
 import json
@@ -21,44 +23,58 @@ sys.path.insert(0, ROOT)
 from fqtk_amd import BarcodeMatcher, _lib, synth  # noqa: E402
 
 
-def scope_b(cfg_id=3, n_chunk=8_000_000, chunks=12):
+def scope_b(cfg_id=3, n_chunk=8_000_000, chunks=12, matcher=None, workload=None):
+    """Two pinned slots, `chunks` chunks of n_chunk reads: H2D of chunk k+1 overlaps kernel + D2H of chunk k."""
     cfg = synth.CONFIGS[cfg_id]
-    w = synth.Workload(cfg)
+    w = workload or synth.Workload(cfg)
     lib = _lib.load()
-    m = BarcodeMatcher(w.barcodes, cfg.max_mismatches, cfg.min_mismatch_delta)
+    m = matcher or BarcodeMatcher(w.barcodes, cfg.max_mismatches, cfg.min_mismatch_delta)
     bufs = []
     for s in range(2):
         po, pr = C.c_void_p(), C.c_void_p()
-        assert lib.fqtk_pinned_alloc(n_chunk * cfg.stride, C.byref(po)) == 0
-        assert lib.fqtk_pinned_alloc(n_chunk * 4, C.byref(pr)) == 0
+        assert lib.fqtk_pinned_alloc(n_chunk * cfg.stride, C.byref(po)) == 0, _lib.last_error()
+        assert lib.fqtk_pinned_alloc(n_chunk * 4, C.byref(pr)) == 0, _lib.last_error()
         host = w.fill_host(s * n_chunk, n_chunk)
         C.memmove(po, host.ctypes.data, host.nbytes)
         bufs.append((po, pr))
-    for s in range(2):   # warm-up
-        assert lib.fqtk_matcher_enqueue(m.handle, s, bufs[s][0], cfg.stride, None, n_chunk, bufs[s][1]) == 0
-    for s in range(2):
-        assert lib.fqtk_matcher_wait(m.handle, s) == 0
-    t0 = time.perf_counter()
-    for c in range(chunks):
-        s = c % 2
-        if c >= 2:
+    try:
+        for s in range(2):   # warm-up (staging buffers are allocated on first use)
+            assert lib.fqtk_matcher_enqueue(m.handle, s, bufs[s][0], cfg.stride, None, n_chunk, bufs[s][1]) == 0
+        for s in range(2):
             assert lib.fqtk_matcher_wait(m.handle, s) == 0
-        assert lib.fqtk_matcher_enqueue(m.handle, s, bufs[s][0], cfg.stride, None, n_chunk, bufs[s][1]) == 0
-    for s in range(2):
-        assert lib.fqtk_matcher_wait(m.handle, s) == 0
-    dt = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        for c in range(chunks):
+            s = c % 2
+            if c >= 2:
+                assert lib.fqtk_matcher_wait(m.handle, s) == 0
+            assert lib.fqtk_matcher_enqueue(m.handle, s, bufs[s][0], cfg.stride, None, n_chunk, bufs[s][1]) == 0
+        for s in range(2):
+            assert lib.fqtk_matcher_wait(m.handle, s) == 0
+        dt = time.perf_counter() - t0
+        # the results that came back are the matcher's: spot-check one slot against the sync path
+        got = np.ctypeslib.as_array(C.cast(bufs[1][1], C.POINTER(C.c_uint32)), (n_chunk,))[:100_000].copy()
+        ref, _ = m.assign_batch(w.fill_host(n_chunk, 100_000), counts=False)
+        assert np.array_equal(got, ref.view(np.uint32)), "scope B results differ from the synchronous path"
+        scratch = np.zeros(cfg.n_samples + 1, dtype=np.uint64)
+        lib.fqtk_matcher_counts(m.handle, scratch.ctypes.data)   # leave the handle's accumulator empty
+    finally:
+        for po, pr in bufs:
+            lib.fqtk_pinned_free(po)
+            lib.fqtk_pinned_free(pr)
     reads = n_chunk * chunks
-    return {"reads": reads, "seconds": round(dt, 4), "M_reads_per_s": round(reads / dt / 1e6, 1),
-            "GB_per_s_over_pcie": round(reads * (cfg.stride + 4) / dt / 1e9, 2), "chunk_reads": n_chunk}
+    return {"what": "fqtk_matcher_enqueue/wait on 2 pinned slots: host SoA barcodes -> host results, PCIe inclusive",
+            "workload": cfg.name, "reads": reads, "chunk_reads": n_chunk, "seconds": round(dt, 4),
+            "M_reads_per_s": round(reads / dt / 1e6, 1),
+            "GB_per_s_over_pcie": round(reads * (cfg.stride + 4) / dt / 1e9, 2)}
 
 
-def fixed_fastq(path, n, seqs, read_no, gz):
-    """n records with fixed-width fields, built as one numpy byte matrix."""
+def fixed_fastq(path, start, n, seqs, read_no, append):
+    """n records with fixed-width fields, built as one numpy byte matrix; names carry start + row."""
     L = seqs.shape[1]
     head = np.frombuffer(b"@inst:1:FC:1:0000000000 %d:N:0:0\n" % read_no, dtype=np.uint8)
     rec = np.empty((n, len(head) + L + 1 + 2 + L + 1), dtype=np.uint8)
     rec[:, :len(head)] = head
-    digits = np.arange(n)[:, None] // (10 ** np.arange(9, -1, -1))[None, :] % 10
+    digits = (start + np.arange(n))[:, None] // (10 ** np.arange(9, -1, -1))[None, :] % 10
     rec[:, 13:23] = digits.astype(np.uint8) + ord("0")
     o = len(head)
     rec[:, o:o + L] = seqs
@@ -67,59 +83,91 @@ def fixed_fastq(path, n, seqs, read_no, gz):
     rec[:, o + L + 2] = ord("\n")
     rec[:, o + L + 3:o + 2 * L + 3] = ord("I")
     rec[:, -1] = ord("\n")
-    with open(path, "wb") as fh:
+    with open(path, "ab" if append else "wb") as fh:
         fh.write(rec.tobytes())
-    if gz:
-        subprocess.run(["gzip", "-1", "-f", path], check=True)
-        return path + ".gz"
-    return path
 
 
-def scope_e(n, threads, gz, tmp):
+def make_inputs(tmp, n, gz, block=1_000_000):
+    """cfg 3's shape as files: R1 150T, I1 8B, I2 8B, R2 150T; barcodes from the same synthetic stream as
+    scopes K/B; template bases are one random 1 M x 150 block reused per block (names differ)."""
     cfg = synth.CONFIGS[3]
     w = synth.Workload(cfg)
-    bcs = w.fill_host(0, n)
     rng = np.random.default_rng(1)
     acgt = np.frombuffer(b"ACGT", dtype=np.uint8)
-    t = acgt[rng.integers(0, 4, size=(n, 150))]
-    files = [fixed_fastq(os.path.join(tmp, "R1.fastq"), n, t, 1, gz),
-             fixed_fastq(os.path.join(tmp, "I1.fastq"), n, bcs[:, :8], 1, gz),
-             fixed_fastq(os.path.join(tmp, "I2.fastq"), n, bcs[:, 8:16], 2, gz),
-             fixed_fastq(os.path.join(tmp, "R2.fastq"), n, t[::-1].copy(), 2, gz)]
-    in_bytes = sum(os.path.getsize(f) for f in files)
+    t1 = acgt[rng.integers(0, 4, size=(min(block, n), 150))]
+    t2 = t1[::-1].copy()
+    names = ["R1.fastq", "I1.fastq", "I2.fastq", "R2.fastq"]
+    paths = [os.path.join(tmp, x) for x in names]
+    for lo in range(0, n, block):
+        cur = min(block, n - lo)
+        bcs = w.fill_host(lo, cur)
+        fixed_fastq(paths[0], lo, cur, t1[:cur], 1, lo > 0)
+        fixed_fastq(paths[1], lo, cur, bcs[:, :8], 1, lo > 0)
+        fixed_fastq(paths[2], lo, cur, bcs[:, 8:16], 2, lo > 0)
+        fixed_fastq(paths[3], lo, cur, t2[:cur], 2, lo > 0)
+    if gz:
+        procs = [subprocess.Popen(["gzip", "-1", "-f", p]) for p in paths]
+        assert all(p.wait() == 0 for p in procs)
+        paths = [p + ".gz" for p in paths]
     meta = os.path.join(tmp, "meta.tsv")
     with open(meta, "w") as fh:
         fh.write("sample_id\tbarcode\n" + "".join(f"S{i:04}\t{b}\n" for i, b in enumerate(w.barcodes)))
+    return paths, meta, w
+
+
+def scope_e(n, threads, gz, tmp, expect_counts=None, extra_args=()):
+    paths, meta, w = make_inputs(tmp, n, gz)
+    in_bytes = sum(os.path.getsize(f) for f in paths)
     out = os.path.join(tmp, "out")
     exe = os.path.join(ROOT, "fqtk_amd", "bin", "fqtk")
-    cmd = [exe, "demux", "-i", *files, "-r", "150T", "8B", "8B", "150T", "-s", meta, "-o", out, "-t", str(threads),
-           ]
+    cmd = [exe, "demux", "-i", *paths, "-r", "150T", "8B", "8B", "150T", "-s", meta, "-o", out, "-t", str(threads),
+           *extra_args]
     t0 = time.perf_counter()
     r = subprocess.run(cmd, capture_output=True, text=True, env=dict(os.environ, FQTK_TIMING="1"))
     dt = time.perf_counter() - t0
     assert r.returncode == 0, r.stderr[-2000:]
-    rows = [l.split("\t") for l in open(os.path.join(out, "demux-metrics.txt")).read().splitlines()[1:]]
-    assert sum(int(x[2]) for x in rows) == n
-    out_bytes = sum(os.path.getsize(os.path.join(out, f)) for f in os.listdir(out))
-    return {"templates": n, "threads": threads, "gz_inputs": gz, "seconds": round(dt, 3),
-            "M_templates_per_s": round(n / dt / 1e6, 3), "input_MB": round(in_bytes / 1e6, 1),
-            "output_MB": round(out_bytes / 1e6, 1), "host_cores": os.cpu_count(),
-            "log": [l for l in r.stderr.splitlines() if "INFO" in l and "demultiplexed" not in l]}
+    rows = [ln.split("\t") for ln in open(os.path.join(out, "demux-metrics.txt")).read().splitlines()[1:]]
+    got = np.array([int(x[2]) for x in rows], dtype=np.uint64)
+    assert int(got.sum()) == n
+    if expect_counts is not None:     # per-sample templates of the metrics file == the oracle's count vector
+        assert np.array_equal(got, expect_counts), "demux-metrics.txt differs from the oracle's per-sample counts"
+    out_files = os.listdir(out)
+    out_bytes = sum(os.path.getsize(os.path.join(out, f)) for f in out_files)
+    stage = [ln.split("fqtk] ", 1)[1] for ln in r.stderr.splitlines() if "thread-seconds" in ln or "main thread" in ln]
+    return {"what": "fqtk_amd/bin/fqtk demux, files -> files (gunzip/parse -> GPU match -> BGZF), "
+                    "as Demux::execute demux.rs:881-1001",
+            "workload": "cfg3 shape: R1 150T, I1 8B, I2 8B, R2 150T; 384 samples", "templates": n, "threads": threads,
+            "gz_inputs": gz, "seconds": round(dt, 3), "M_templates_per_s": round(n / dt / 1e6, 3),
+            "M_input_records_per_s": round(4 * n / dt / 1e6, 3),
+            "input_MB": round(in_bytes / 1e6, 1), "output_MB": round(out_bytes / 1e6, 1), "output_files": len(out_files),
+            "files_on": tmp, "host_cores": os.cpu_count(),
+            "metrics_vs_oracle": None if expect_counts is None else "per-sample counts identical", "stages": stage}
+
+
+def scratch_dir(need_bytes):
+    """RAM-backed scratch when it has room (so the number is host compute, not this box's disk), else /tmp."""
+    for base in ("/dev/shm", "/tmp"):
+        try:
+            if shutil.disk_usage(base).free > need_bytes * 1.3:
+                return tempfile.mkdtemp(prefix="fqtk_e2e_", dir=base)
+        except OSError:
+            pass
+    return tempfile.mkdtemp(prefix="fqtk_e2e_")
 
 
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
-    ap.add_argument("--templates", type=int, default=2_000_000)
+    ap.add_argument("--templates", type=int, default=4_000_000)
     ap.add_argument("--threads", type=int, default=32)
     ap.add_argument("--gz", action="store_true")
     ap.add_argument("--skip-b", action="store_true")
     a = ap.parse_args()
     res = {}
     if not a.skip_b:
-        res["scope_B_boundary"] = scope_b()
-    tmp = tempfile.mkdtemp(prefix="fqtk_e2e_", dir="/tmp")
+        res["B"] = scope_b()
+    tmp = scratch_dir(a.templates * 1100)
     try:
-        res["scope_E_cli"] = scope_e(a.templates, a.threads, a.gz, tmp)
+        res["E"] = scope_e(a.templates, a.threads, a.gz, tmp)
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
     print(json.dumps(res))
