@@ -316,6 +316,8 @@ def main() -> int:
     pool = None
     if rank == 0 and (mode == "full" or (world == 1 and args.cpu_seconds > 0)):
         import multiprocessing as mp
+        from oracle import oracle as O
+        O.build(native=True)                       # once, before the workers all ask for it
         n_procs = max(1, min(128, host_cores // 2))
         pool = mp.get_context("spawn").Pool(n_procs)
         pool.n_procs = n_procs

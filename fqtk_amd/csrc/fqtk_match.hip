@@ -324,10 +324,11 @@ int launch_lds_memo(const fqtk_matcher *m, fqtk::LdsMemoParams Q, hipStream_t st
     const uint32_t per_cu = (uint32_t)std::max<size_t>(1, std::min<size_t>(2048 / fqtk::kLdsBlock, fqtk::kLdsMemoMaxBytes / (shmem + 1024)));
     const uint32_t grid = (uint32_t)std::min<uint64_t>(ntiles, (uint64_t)m->num_cus * per_cu);
 #define FQTK_LDSM_LAUNCH(V, RR) FQTK_LDSM_LAUNCH_L(V, RR, false)
-#define FQTK_LDSM_LAUNCH_L(V, RR, LENS)                                                                    \
+#define FQTK_LDSM_LAUNCH_L(V, RR, LENS) FQTK_LDSM_LAUNCH_P(V, RR, LENS, false)
+#define FQTK_LDSM_LAUNCH_P(V, RR, LENS, PF)                                                                \
     do {                                                                                                   \
         if constexpr ((V) <= 0 || KW == ((V) == 5 ? 3 : ((V) >= 3 ? 2 : 1))) {                             \
-            auto kern = fqtk::lds_memo_kernel<V, KW, RR, POW2, LENS>;                                      \
+            auto kern = fqtk::lds_memo_kernel<V, KW, RR, POW2, LENS, PF>;                                  \
             /* > 64 KiB of dynamic LDS must be allowed per kernel AND per device: remembered per matcher */ \
             const void *fn = reinterpret_cast<const void *>(kern);                                         \
             if (shmem > 64 * 1024 &&                                                                       \
@@ -344,6 +345,18 @@ int launch_lds_memo(const fqtk_matcher *m, fqtk::LdsMemoParams Q, hipStream_t st
 #ifdef FQTK_DEV_ABLATE
     if (R == 8 && (vec == 4 || vec == 2)) {
         if (vec == 4) FQTK_LDSM_LAUNCH(4, 8); else FQTK_LDSM_LAUNCH(2, 8);
+        HIP_TRY(hipGetLastError());
+        return FQTK_OK;
+    }
+    if (std::getenv("FQTK_LDSM_PF") && !P.lens && (vec == 4 || vec == 2) && (R == 1 || R == 2 || R == 4)) {
+        switch (vec * 10 + R) {
+            case 41: FQTK_LDSM_LAUNCH_P(4, 1, false, true); break;
+            case 42: FQTK_LDSM_LAUNCH_P(4, 2, false, true); break;
+            case 44: FQTK_LDSM_LAUNCH_P(4, 4, false, true); break;
+            case 21: FQTK_LDSM_LAUNCH_P(2, 1, false, true); break;
+            case 22: FQTK_LDSM_LAUNCH_P(2, 2, false, true); break;
+            default: FQTK_LDSM_LAUNCH_P(2, 4, false, true); break;
+        }
         HIP_TRY(hipGetLastError());
         return FQTK_OK;
     }
@@ -389,6 +402,7 @@ int launch_lds_memo(const fqtk_matcher *m, fqtk::LdsMemoParams Q, hipStream_t st
     }
 #undef FQTK_LDSM_LAUNCH
 #undef FQTK_LDSM_LAUNCH_L
+#undef FQTK_LDSM_LAUNCH_P
     HIP_TRY(hipGetLastError());
     return FQTK_OK;
 }

@@ -69,7 +69,31 @@ __device__ __forceinline__ uint32_t lane_select(uint64_t mask, uint32_t a, uint3
     return d;
 }
 
-template <int VEC, int KW, int R, bool POW2, bool LENS = false>   // LENS: see memo_kernel
+// The cheap per-tile test flags every byte that is not A/C/G/T/N in either case -- including '.', the
+// legacy no-call, which encodes exactly like 'N' (mod.rs:85-87: 'N', 'n' and '.' are the no-calls) and has
+// the same 4-bit key code.  So a read whose only offence is '.' was ALREADY looked up under the right key;
+// this exact test (rare branch only) keeps such reads out of the wave-cooperative scan.
+template <int NWD>
+__device__ __forceinline__ uint32_t noncanonical_beyond_dots(const uint32_t (&words)[8], const uint32_t (&kc)[NWD],
+                                                             const uint32_t (&kv)[NWD]) {
+    uint32_t bad = 0;
+#pragma unroll
+    for (int w = 0; w < NWD; ++w) {
+        const uint32_t t = words[w] ^ 0x2E2E2E2Eu;
+        const uint32_t dot = ~(((t & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | t | 0x7F7F7F7Fu);   // 0x80 in every byte that is '.'
+        const uint32_t ww = words[w] ^ ((dot >> 7) * 0x60u);                             // '.' (0x2E) -> 'N' (0x4E)
+        const uint32_t c = (ww >> 1) & kc[w];
+        const uint32_t e = __builtin_amdgcn_perm(kCodePoolHi, kCodePoolLo, c);
+        bad |= (ww ^ e) & kv[w];
+    }
+    return bad;
+}
+
+// PF: software pipeline of the full-tile loop -- the loads of tile t + grid are issued BEFORE tile t is
+// looked up, so a wave always has a load in flight while it computes.  With R = 1 this is the stream shape
+// the memory system likes best (tools/hbm_stream.hip: one 1-KiB request per wave at a time, 256 tiles = a
+// 4-MiB window sweeping the buffer) without the compute latency serialised behind every load.
+template <int VEC, int KW, int R, bool POW2, bool LENS = false, bool PF = false>   // LENS: see memo_kernel
 __global__ __launch_bounds__(kLdsBlock) __attribute__((amdgpu_waves_per_eu(4, 8)))
 void lds_memo_kernel(const LdsMemoParams Q) {
     const MatchParams &P = Q.m;
@@ -121,43 +145,47 @@ void lds_memo_kernel(const LdsMemoParams Q) {
     const uint32_t hist_on = (P.counts && P.lds_hist) ? 1u : 0u;
     const uint32_t hist_base_b = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint32_t *)lds_hist;
 
-    // FULL = every read of the tile exists and the packed vector load applies: the lean path.
-    auto process = [&](uint64_t t, auto full_tag) {
-        constexpr bool FULL = decltype(full_tag)::value;
-        uint32_t words[R][8];
-        uint32_t res[R], bflag[R];
-        bool live[R];
+    // The packed vector loads of one full tile (every read exists, the rows are VEC dwords).
+    auto load_full = [&](uint64_t t, uint32_t (&words)[R][8]) {
         const uint8_t *tile_in = P.obs + t * tile * (uint64_t)P.stride;   // wave-uniform
-        uint32_t *tile_out = P.out + t * tile;
 #pragma unroll
         for (int r = 0; r < R; ++r) {
-            if constexpr (FULL) {
-                live[r] = true;
-                const uint8_t *src = tile_in + in_off[r];
-                if constexpr (VEC == 4) {
-                    const u32x4v v = FQTK_STREAM_LOAD(reinterpret_cast<const u32x4v *>(src));
-                    words[r][0] = v.x; words[r][1] = v.y; words[r][2] = v.z; words[r][3] = v.w;
-                } else if constexpr (VEC == 3) {
-                    const uint32_t *s32 = reinterpret_cast<const uint32_t *>(src);
-                    words[r][0] = s32[0]; words[r][1] = s32[1]; words[r][2] = s32[2];
-                } else if constexpr (VEC == 5) {
-                    const uint32_t *s32 = reinterpret_cast<const uint32_t *>(src);
-                    words[r][0] = s32[0]; words[r][1] = s32[1]; words[r][2] = s32[2];
-                    words[r][3] = s32[3]; words[r][4] = s32[4];
-                } else if constexpr (VEC == 2) {
-                    const u32x2v v = FQTK_STREAM_LOAD(reinterpret_cast<const u32x2v *>(src));
-                    words[r][0] = v.x; words[r][1] = v.y;
-                } else {
-                    words[r][0] = *reinterpret_cast<const uint32_t *>(src);
-                }
+            const uint8_t *src = tile_in + in_off[r];
+            if constexpr (VEC == 4) {
+                const u32x4v v = FQTK_STREAM_LOAD(reinterpret_cast<const u32x4v *>(src));
+                words[r][0] = v.x; words[r][1] = v.y; words[r][2] = v.z; words[r][3] = v.w;
+            } else if constexpr (VEC == 3) {
+                const uint32_t *s32 = reinterpret_cast<const uint32_t *>(src);
+                words[r][0] = s32[0]; words[r][1] = s32[1]; words[r][2] = s32[2];
+            } else if constexpr (VEC == 5) {
+                const uint32_t *s32 = reinterpret_cast<const uint32_t *>(src);
+                words[r][0] = s32[0]; words[r][1] = s32[1]; words[r][2] = s32[2];
+                words[r][3] = s32[3]; words[r][4] = s32[4];
+            } else if constexpr (VEC == 2) {
+                const u32x2v v = FQTK_STREAM_LOAD(reinterpret_cast<const u32x2v *>(src));
+                words[r][0] = v.x; words[r][1] = v.y;
             } else {
-                const uint64_t i = t * tile + local[r];
-                live[r] = i < P.n;
-#pragma unroll
-                for (int w = 0; w < 8; ++w) words[r][w] = 0x41414141u;   // dead lanes look like "AAAA"
-                if (live[r]) load_words<1, VEC>(P, i, nwords, words[r]);
+                words[r][0] = *reinterpret_cast<const uint32_t *>(src);
             }
         }
+    };
+    // Any tile through the generic path (ragged last tile, unaligned strides): bounds-checked loads.
+    auto load_any = [&](uint64_t t, uint32_t (&words)[R][8], bool (&live)[R]) {
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const uint64_t i = t * tile + local[r];
+            live[r] = i < P.n;
+#pragma unroll
+            for (int w = 0; w < 8; ++w) words[r][w] = 0x41414141u;   // dead lanes look like "AAAA"
+            if (live[r]) load_words<1, VEC>(P, i, nwords, words[r]);
+        }
+    };
+
+    // FULL = every read of the tile exists and the packed vector load applies: the lean path.
+    auto compute = [&](uint64_t t, uint32_t (&words)[R][8], const bool (&live)[R], auto full_tag) {
+        constexpr bool FULL = decltype(full_tag)::value;
+        uint32_t res[R], bflag[R];
+        uint32_t *tile_out = P.out + t * tile;
         // One read at a time: hash, three entry reads, select, verify; the rare extra verification
         // rounds sit behind wave-uniform branches.
         uint32_t lo[R], hi[R], ext[R];
@@ -233,7 +261,9 @@ void lds_memo_kernel(const LdsMemoParams Q) {
         if (__builtin_amdgcn_uicmp(any_bad, 0u, 33 /* ne */)) {   // wave-uniform; one test per tile
 #pragma unroll
             for (int r = 0; r < R; ++r) {
-                uint64_t todo = __builtin_amdgcn_uicmp(live[r] ? bflag[r] : 0u, 0u, 33);
+                // '.' no-calls were looked up under N's key already: only IUPAC / junk bytes need the scan
+                const uint32_t really = (live[r] && bflag[r]) ? noncanonical_beyond_dots<NWD>(words[r], kc, kv) : 0u;
+                uint64_t todo = __builtin_amdgcn_uicmp(really, 0u, 33);
                 if (todo) {
                     Planes<1> mine;
                     encode_planes<1>(words[r], nwords, L, lds_lut, mine);
@@ -265,10 +295,36 @@ void lds_memo_kernel(const LdsMemoParams Q) {
     };
 
     const uint64_t full_tiles = (VEC >= 1) ? P.n / tile : 0;
-    for (uint64_t t = blockIdx.x; t < full_tiles; t += gridDim.x) process(t, std::true_type{});
+    bool all_live[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) all_live[r] = true;
+    if constexpr (PF && VEC >= 1) {
+        uint32_t cur[R][8], nxt[R][8];
+        uint64_t t = blockIdx.x;
+        if (t < full_tiles) load_full(t, cur);
+        for (; t < full_tiles; t += gridDim.x) {
+            const uint64_t tn = t + gridDim.x;
+            if (tn < full_tiles) load_full(tn, nxt);   // wave-uniform: in flight while tile t is looked up
+            compute(t, cur, all_live, std::true_type{});
+#pragma unroll
+            for (int r = 0; r < R; ++r)
+#pragma unroll
+                for (int w = 0; w < NWD; ++w) cur[r][w] = nxt[r][w];
+        }
+    } else {
+        for (uint64_t t = blockIdx.x; t < full_tiles; t += gridDim.x) {
+            uint32_t words[R][8];
+            load_full(t, words);
+            compute(t, words, all_live, std::true_type{});
+        }
+    }
     // whatever is left (the ragged last tile; every tile on the generic load paths)
-    for (uint64_t t = full_tiles + (blockIdx.x + gridDim.x - full_tiles % gridDim.x) % gridDim.x; t < ntiles; t += gridDim.x)
-        process(t, std::false_type{});
+    for (uint64_t t = full_tiles + (blockIdx.x + gridDim.x - full_tiles % gridDim.x) % gridDim.x; t < ntiles; t += gridDim.x) {
+        uint32_t words[R][8];
+        bool live[R];
+        load_any(t, words, live);
+        compute(t, words, live, std::false_type{});
+    }
 
     if (P.counts && P.lds_hist) {
         __syncthreads();

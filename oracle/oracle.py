@@ -24,14 +24,27 @@ NONE_IDX = 0xFFFF
 def build(native: bool = False, force: bool = False) -> str:
     """Compile ref_literal.c with gcc.  native=True adds -march=native (used by bench.py's
     cpu_baseline leg, which rebuilds on the box it runs on)."""
-    out = os.path.join(_HERE, "liboracle_native.so" if native else "liboracle.so")
+    out = os.path.join(_HERE, f"liboracle_native_{_cpu_tag()}.so" if native else "liboracle.so")
     if not force and os.path.exists(out) and os.path.getmtime(out) >= os.path.getmtime(_SRC):
         return out
-    cmd = ["gcc", "-O3", "-fPIC", "-std=c11", "-shared", "-o", out, _SRC]
+    tmp = f"{out}.{os.getpid()}.tmp"      # several processes may build at once: compile aside, rename into place
+    cmd = ["gcc", "-O3", "-fPIC", "-std=c11", "-shared", "-o", tmp, _SRC]
     if native:
         cmd.insert(2, "-march=native")
     subprocess.run(cmd, check=True)
+    os.replace(tmp, out)
     return out
+
+
+def _cpu_tag() -> str:
+    """-march=native code is only valid on the CPU model it was built on (this tree travels between boxes)."""
+    import hashlib
+    try:
+        with open("/proc/cpuinfo") as fh:
+            lines = [ln for ln in fh if ln.startswith(("model name", "flags"))][:2]
+    except OSError:
+        lines = []
+    return hashlib.sha1("".join(lines).encode()).hexdigest()[:10]
 
 
 def _load(native: bool = False) -> C.CDLL:
