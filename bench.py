@@ -374,7 +374,9 @@ def main() -> int:
                 "use_cache": not args.no_cache,
                 "obs_len": bool(args.lens),
                 "memo_entries": matcher.memo_entries,
-                "memo_kind": {0: "none (scan)", 1: "table in HBM/L2 + LDS hot subset", 2: "LDS-resident"}[matcher.memo_kind],
+                "memo_kind": {0: "none (scan)", 1: "table in HBM/L2 + LDS hot subset", 2: "LDS-resident"}[matcher.memo_kind] +
+                             (f", direct-indexed ({matcher.memo_direct_bytes}-byte entries) for reads without a no-call"
+                              if matcher.memo_kind == 1 and matcher.memo_direct_bytes else ""),
             },
             "create_ms": round(create_ms, 2),
             "roofline": {

@@ -58,6 +58,7 @@ SIGNATURES = [
     ("fqtk_matcher_memo_candidates", C.c_uint64, [C.c_void_p]),
     ("fqtk_matcher_memo_kind", C.c_int, [C.c_void_p]),
     ("fqtk_matcher_set_memo_kind", C.c_int, [C.c_void_p, C.c_int]),
+    ("fqtk_matcher_memo_direct_bytes", C.c_int, [C.c_void_p]),
     ("fqtk_matcher_assign_batch", C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p,
                                             C.c_uint64, C.c_void_p, C.c_void_p]),
     ("fqtk_matcher_assign_batch_device", C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p,

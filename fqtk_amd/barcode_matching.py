@@ -120,6 +120,11 @@ class BarcodeMatcher:
         _check(self._lib.fqtk_matcher_set_memo_kind(self._h, int(kind)))
 
     @property
+    def memo_direct_bytes(self) -> int:
+        """2 or 4 when MEMO_TABLE is the direct-indexed variant (barcodes of <= 10 bases), else 0."""
+        return int(self._lib.fqtk_matcher_memo_direct_bytes(self._h))
+
+    @property
     def handle(self) -> C.c_void_p:
         return self._h
 

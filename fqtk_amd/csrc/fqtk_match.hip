@@ -19,6 +19,7 @@
 #include "match_kernels.hip.h"
 #include "lds_memo_kernels.hip.h"
 #include "lds_memo_plan.hpp"
+#include "direct_memo_plan.hpp"
 
 namespace {
 
@@ -114,6 +115,14 @@ struct fqtk_matcher {
     uint32_t hot_mask = 0;
     uint32_t memo_mask = 0;
     int memo_kw = 1;   // key words per entry (fqtk::memo_key_words)
+    // direct-indexed form (L <= 10; memo_hash.hpp): flat result array + LDS cache of its exact-match entries;
+    // d_memo then holds only the entries with a no-call
+    void *d_direct = nullptr;
+    int direct_bytes = 0;                      // 0 = not built, 2 = packed 16-bit entries, 4 = result words
+    uint32_t *d_hot2 = nullptr;
+    uint32_t hot2_bits = 0;
+    uint32_t direct_ib = 0, direct_bb = 0;     // 16-bit entry layout
+    uint64_t hot2_placed = 0, hot2_wanted = 0;
     uint64_t memo_entries = 0;
     uint64_t memo_candidates = 0;
     uint64_t memo_second_slot = 0;             // entries living in their second-choice slot
@@ -206,9 +215,11 @@ int launch_memo_vec(const fqtk_matcher *m, const fqtk::MemoParams &Q, hipStream_
     // waves/SIMD with no scratch, hipcc -Rpass-analysis=kernel-resource-usage; measured +3-5 % over 2
     // on cfg 2/3/4), 2 there for very large tables, where more probes in flight only add cache
     // pressure, and 1 on the generic paths (4 would spill)
-    int R = vec > 0 ? (m->memo_entries <= 65536 ? 4 : 2) : 1;
+    const int direct_form = (KW == 1 && Q.direct) ? m->direct_bytes : 0;
+    int R = vec > 0 ? ((m->memo_entries <= 65536 || direct_form) ? 4 : 2) : 1;
     if (vec == 5) R = 2;   // 20-byte reads: 4 per lane would spill at 64 VGPRs
     if (P.lens) R = 1;
+    if (R != 1 && R != 2 && R != 4) R = 1;
     int abl = 0;
 #ifdef FQTK_DEV_ABLATE
     if (const char *rr = std::getenv("FQTK_MEMO_R")) R = std::atoi(rr);
@@ -217,7 +228,9 @@ int launch_memo_vec(const fqtk_matcher *m, const fqtk::MemoParams &Q, hipStream_
     if (const char *lp = std::getenv("FQTK_MEMO_LDS_PAD")) lds_pad = (size_t)std::atol(lp);
 #endif
     size_t shmem = 256 * sizeof(uint32_t);
-    if (Q.hot_mask) shmem += (size_t)(Q.hot_mask + 1) * (KW >= 2 ? 16 : 8);
+    const int direct = (KW == 1 && Q.direct) ? m->direct_bytes : 0;
+    if (direct) shmem += Q.hot2 ? ((size_t)8 << Q.hot2_bits) : 0;
+    else if (Q.hot_mask) shmem += (size_t)(Q.hot_mask + 1) * (KW >= 2 ? 16 : 8);
     if (P.counts && P.lds_hist) shmem += (size_t)(P.S + 1) * sizeof(uint32_t);
 #ifdef FQTK_DEV_ABLATE
     shmem += lds_pad;
@@ -228,10 +241,12 @@ int launch_memo_vec(const fqtk_matcher *m, const fqtk::MemoParams &Q, hipStream_
     const uint32_t grid = (uint32_t)std::min<uint64_t>(ntiles, (uint64_t)m->num_cus * (2048 / fqtk::kMemoBlock));
     // the packed vector paths imply the key width (stride 16 B -> 2 key words, 12 B -> 1 or 2, 8/4 B -> 1)
 #define FQTK_MEMO_LAUNCH(V, RR, A) FQTK_MEMO_LAUNCH_L(V, RR, A, false)
-#define FQTK_MEMO_LAUNCH_L(V, RR, A, LENS)                                                                 \
+#define FQTK_MEMO_LAUNCH_L(V, RR, A, LENS) FQTK_MEMO_LAUNCH_D(V, RR, A, LENS, 0)
+#define FQTK_MEMO_LAUNCH_D(V, RR, A, LENS, D)                                                              \
     do {                                                                                                   \
-        if constexpr ((V) <= 0 || ((V) == 3 && KW <= 2) || KW == ((V) == 5 ? 3 : ((V) == 4 ? 2 : 1))) {    \
-            auto kern = fqtk::memo_kernel<V, KW, RR, A, LENS>;                                             \
+        if constexpr (((V) <= 0 || ((V) == 3 && KW <= 2) || KW == ((V) == 5 ? 3 : ((V) == 4 ? 2 : 1))) && \
+                      ((D) == 0 || KW == 1)) {                                                             \
+            auto kern = fqtk::memo_kernel<V, KW, RR, A, LENS, D>;                                          \
             const void *fn = reinterpret_cast<const void *>(kern);                                         \
             if (shmem > 64 * 1024 &&                                                                       \
                 std::find(m->ldsm_big_lds_ok.begin(), m->ldsm_big_lds_ok.end(), fn) == m->ldsm_big_lds_ok.end()) { \
@@ -266,7 +281,40 @@ int launch_memo_vec(const fqtk_matcher *m, const fqtk::MemoParams &Q, hipStream_
         return FQTK_OK;
     }
 #endif
-    if (P.lens) {   // variable-length batch: one read per lane on every load path (the LENS instantiations)
+    if (direct) {   // barcodes of <= 10 bases: the direct-indexed form (KW == 1, so vec is 1, 2, 3, -1 or 0)
+#define FQTK_MEMO_DIRECT(D)                                                                       \
+        if (P.lens) {                                                                             \
+            switch (vec) {                                                                        \
+                case 3: FQTK_MEMO_LAUNCH_D(3, 1, 0, true, D); break;                              \
+                case 2: FQTK_MEMO_LAUNCH_D(2, 1, 0, true, D); break;                              \
+                case 1: FQTK_MEMO_LAUNCH_D(1, 1, 0, true, D); break;                              \
+                case -1: FQTK_MEMO_LAUNCH_D(-1, 1, 0, true, D); break;                            \
+                default: FQTK_MEMO_LAUNCH_D(0, 1, 0, true, D); break;                             \
+            }                                                                                     \
+        } else if (vec > 0 && R == 4) {                                                           \
+            switch (vec) {                                                                        \
+                case 3: FQTK_MEMO_LAUNCH_D(3, 4, 0, false, D); break;                             \
+                case 2: FQTK_MEMO_LAUNCH_D(2, 4, 0, false, D); break;                             \
+                default: FQTK_MEMO_LAUNCH_D(1, 4, 0, false, D); break;                            \
+            }                                                                                     \
+        } else if (vec > 0 && R == 2) {                                                           \
+            switch (vec) {                                                                        \
+                case 3: FQTK_MEMO_LAUNCH_D(3, 2, 0, false, D); break;                             \
+                case 2: FQTK_MEMO_LAUNCH_D(2, 2, 0, false, D); break;                             \
+                default: FQTK_MEMO_LAUNCH_D(1, 2, 0, false, D); break;                            \
+            }                                                                                     \
+        } else {                                                                                  \
+            switch (vec) {                                                                        \
+                case 3: FQTK_MEMO_LAUNCH_D(3, 1, 0, false, D); break;                             \
+                case 2: FQTK_MEMO_LAUNCH_D(2, 1, 0, false, D); break;                             \
+                case 1: FQTK_MEMO_LAUNCH_D(1, 1, 0, false, D); break;                             \
+                case -1: FQTK_MEMO_LAUNCH_D(-1, 1, 0, false, D); break;                           \
+                default: FQTK_MEMO_LAUNCH_D(0, 1, 0, false, D); break;                            \
+            }                                                                                     \
+        }
+        if (direct == 2) { FQTK_MEMO_DIRECT(2) } else { FQTK_MEMO_DIRECT(4) }
+#undef FQTK_MEMO_DIRECT
+    } else if (P.lens) {   // variable-length batch: one read per lane on every load path (the LENS instantiations)
         switch (vec) {
             case 5: FQTK_MEMO_LAUNCH_L(5, 1, 0, true); break;
             case 4: FQTK_MEMO_LAUNCH_L(4, 1, 0, true); break;
@@ -287,6 +335,7 @@ int launch_memo_vec(const fqtk_matcher *m, const fqtk::MemoParams &Q, hipStream_
 #undef FQTK_MEMO_BY_VEC
 #undef FQTK_MEMO_LAUNCH
 #undef FQTK_MEMO_LAUNCH_L
+#undef FQTK_MEMO_LAUNCH_D
     HIP_TRY(hipGetLastError());
     return FQTK_OK;
 }
@@ -438,6 +487,11 @@ int launch(const fqtk_matcher *m, const fqtk::MatchParams &P, hipStream_t stream
         Q.mask = m->memo_mask;
         Q.hot = m->d_hot;
         Q.hot_mask = m->hot_mask;
+        Q.direct = m->d_direct;
+        Q.hot2 = m->d_hot2;
+        Q.hot2_bits = m->hot2_bits;
+        Q.d_ib = m->direct_ib;
+        Q.d_bb = m->direct_bb;
         switch (m->memo_kw) {
             case 1: return launch_memo_vec<1>(m, Q, stream);
             case 2: return launch_memo_vec<2>(m, Q, stream);
@@ -627,6 +681,45 @@ int build_lds_memo(fqtk_matcher *m, const std::vector<fqtk::LdsEntry> &ents,
     return FQTK_OK;
 }
 
+struct Entry { uint32_t lo, hi, ext, val; uint64_t ci; };   // one Some entry of the memo; ci = its candidate string
+
+// Direct-indexed form of the memo for barcodes of <= 10 bases: planned on the host (direct_memo_plan.hpp),
+// uploaded here.
+int build_direct(fqtk_matcher *m, const std::vector<char> &cand, const std::vector<Entry> &ents) {
+#ifdef FQTK_DEV_ABLATE
+    if (std::getenv("FQTK_NO_DIRECT")) return FQTK_OK;
+#endif
+    std::vector<fqtk::DirectEntry> dir;
+    for (const Entry &e : ents) {
+        const char *q = cand.data() + e.ci * m->L;
+        if (std::memchr(q, 'N', m->L)) continue;
+        fqtk::DirectEntry d;
+        uint32_t ext;
+        memo_key_of(q, m->L, d.lo, d.hi, ext, false);
+        d.val = e.val;
+        dir.push_back(d);
+    }
+    const fqtk::DirectMemoPlan plan = fqtk::plan_direct_memo(m->S, m->L, dir);
+    if (!plan.entry_bytes) return FQTK_OK;
+    for (const fqtk::DirectEntry &d : dir)   // self-check: the kernel's lookup returns every stored entry
+        if (fqtk::direct_memo_lookup(plan, d.lo, d.hi) != d.val) return fail(FQTK_EINVAL, "direct memo: self-check failed");
+    const void *src = plan.entry_bytes == 2 ? (const void *)plan.table16.data() : (const void *)plan.table32.data();
+    const size_t bytes = plan.entry_bytes == 2 ? plan.table16.size() * 2 : plan.table32.size() * 4;
+    HIP_TRY(hipMalloc(&m->d_direct, bytes));
+    HIP_TRY(hipMemcpy(m->d_direct, src, bytes, hipMemcpyHostToDevice));
+    if (!plan.hot2.empty()) {
+        HIP_TRY(hipMalloc(reinterpret_cast<void **>(&m->d_hot2), plan.hot2.size() * 4));
+        HIP_TRY(hipMemcpy(m->d_hot2, plan.hot2.data(), plan.hot2.size() * 4, hipMemcpyHostToDevice));
+    }
+    m->direct_bytes = plan.entry_bytes;
+    m->direct_ib = plan.ib;
+    m->direct_bb = plan.bb;
+    m->hot2_bits = plan.hot2_bits;
+    m->hot2_placed = plan.hot2_placed;
+    m->hot2_wanted = plan.hot2_wanted;
+    return FQTK_OK;
+}
+
 int build_memo(fqtk_matcher *m, const std::vector<std::vector<uint8_t>> &enc) {
     if (m->L > fqtk::kMemoMaxLen) return FQTK_OK;
     uint64_t total = 0;
@@ -651,7 +744,6 @@ int build_memo(fqtk_matcher *m, const std::vector<std::vector<uint8_t>> &enc) {
     const bool wide = m->memo_kw >= 2;
     const size_t wps = wide ? 4 : 2;   // words per slot
     // distinct Some entries (a string can neighbour several samples)
-    struct Entry { uint32_t lo, hi, ext, val; uint64_t ci; };
     std::vector<Entry> ents;
     ents.reserve(n_some);
     for (uint64_t i = 0; i < nc; ++i) {
@@ -668,6 +760,19 @@ int build_memo(fqtk_matcher *m, const std::vector<std::vector<uint8_t>> &enc) {
     ents.erase(std::unique(ents.begin(), ents.end(),
                            [](const Entry &a, const Entry &b) { return a.lo == b.lo && a.hi == b.hi && a.ext == b.ext; }),
                ents.end());
+    const std::vector<Entry> all_ents = ents;   // the LDS form and the entry count see every entry
+    // ---- direct-indexed form (L <= 10): entries without a no-call go to a flat array indexed by the read
+    //      itself; the cuckoo table below keeps only the entries WITH one -------------------------------
+    if (m->L <= fqtk::kDirectMaxLen) {
+        int rc = build_direct(m, cand, ents);
+        if (rc != FQTK_OK) return rc;
+        if (m->d_direct) {
+            std::vector<Entry> with_n;
+            for (const Entry &e : ents)
+                if (std::memchr(cand.data() + e.ci * m->L, 'N', m->L)) with_n.push_back(e);
+            ents.swap(with_n);
+        }
+    }
     // two-choice (cuckoo) placement with random-walk eviction; grow on the (unlikely) failure
     uint64_t nslots = 1024;
     uint64_t slot_factor = 4;
@@ -730,12 +835,12 @@ int build_memo(fqtk_matcher *m, const std::vector<std::vector<uint8_t>> &enc) {
         }
         break;
     }
-    const uint64_t entries = ents.size();
+    const uint64_t entries = all_ents.size();
     {
-        std::vector<fqtk::LdsEntry> le(ents.size());
-        for (size_t i = 0; i < ents.size(); ++i) {
-            memo_key_of(cand.data() + ents[i].ci * m->L, m->L, le[i].k[0], le[i].k[1], le[i].k[2], false);
-            le[i].val = ents[i].val;
+        std::vector<fqtk::LdsEntry> le(all_ents.size());
+        for (size_t i = 0; i < all_ents.size(); ++i) {
+            memo_key_of(cand.data() + all_ents[i].ci * m->L, m->L, le[i].k[0], le[i].k[1], le[i].k[2], false);
+            le[i].val = all_ents[i].val;
         }
         int rc = build_lds_memo(m, le, enc);
         if (rc != FQTK_OK) return rc;
@@ -748,7 +853,7 @@ int build_memo(fqtk_matcher *m, const std::vector<std::vector<uint8_t>> &enc) {
         uint64_t n_hot = 0;
         for (const Entry &e : ents) n_hot += ((e.val >> 16) & 0xFFu) == 0;
         while (hot_slots > 64 && hot_slots / 2 >= n_hot * 2) hot_slots >>= 1;
-        if (n_hot) {
+        if (n_hot && !m->d_direct) {
             const uint32_t hmask = hot_slots - 1;
             std::vector<uint32_t> hot((size_t)hot_slots * wps, 0xFFFFFFFFu);
             std::vector<Entry> order;
@@ -921,6 +1026,8 @@ void fqtk_matcher_destroy(fqtk_matcher *m) {
     }
     if (m->d_memo) (void)hipFree(m->d_memo);
     if (m->d_hot) (void)hipFree(m->d_hot);
+    if (m->d_direct) (void)hipFree(m->d_direct);
+    if (m->d_hot2) (void)hipFree(m->d_hot2);
     if (m->d_ldsm) (void)hipFree(m->d_ldsm);
     if (m->d_table) (void)hipFree(m->d_table);
     if (m->d_lut) (void)hipFree(m->d_lut);
@@ -954,6 +1061,7 @@ int fqtk_matcher_set_use_cache(fqtk_matcher *m, int use_cache) {
 }
 uint64_t fqtk_matcher_memo_entries(const fqtk_matcher *m) { return (m && m->d_memo) ? m->memo_entries : 0; }
 uint64_t fqtk_matcher_memo_candidates(const fqtk_matcher *m) { return (m && m->d_memo) ? m->memo_candidates : 0; }
+int fqtk_matcher_memo_direct_bytes(const fqtk_matcher *m) { return (m && m->d_memo && m->d_direct) ? m->direct_bytes : 0; }
 
 int fqtk_matcher_memo_kind(const fqtk_matcher *m) {
     if (!m || !m->use_cache) return FQTK_MEMO_NONE;

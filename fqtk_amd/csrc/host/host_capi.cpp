@@ -1,6 +1,7 @@
 // host_capi.cpp -- tiny C shim over the host-side components so the CPU test-suite can exercise them
 // through ctypes (no GPU needed): read structures, header rewriting, FASTQ parsing, BGZF, metrics, and
-// the host-side planner of the LDS-resident memo (csrc/lds_memo_plan.hpp).
+// the host-side planners of the LDS-resident memo (csrc/lds_memo_plan.hpp) and of the direct-indexed memo
+// (csrc/direct_memo_plan.hpp).
 #include <cstring>
 #include <string>
 #include <vector>
@@ -12,6 +13,7 @@
 #include "read_structure.hpp"
 #include "samples.hpp"
 #include "../lds_memo_plan.hpp"
+#include "../direct_memo_plan.hpp"
 
 using namespace fqtk_host;
 
@@ -156,5 +158,26 @@ void fqtk_host_lds_memo_lookup(const uint32_t *image, const uint32_t *meta, uint
     p.n_slots = meta[1]; p.slot_mask_b = meta[2]; p.idx_bits = meta[3]; p.skey_off_b = meta[4];
     p.salt = meta[5]; p.kw = (int)meta[6]; p.key_stride = (int)meta[7]; p.pow2 = meta[8] != 0;
     for (uint64_t i = 0; i < n; ++i) out[i] = fqtk::lds_memo_lookup(p, keys + 3 * i);
+}
+
+// Plans the direct-indexed memo (csrc/direct_memo_plan.hpp) from n_ents no-call-free entries given as
+// unfolded key words (lo = bases 0-7, hi = bases 8-9) + result words, then replays the kernel's lookup for
+// n_q query keys: out[i] = result word or 0xFFFFFFFF, cached[i] = 1 when the LDS cache answered.
+// meta = {entry_bytes, ib, bb, hot2_bits, hot2_slots, hot2_wanted, hot2_placed, table_entries}.
+int fqtk_host_direct_memo(uint32_t S, uint32_t L, uint64_t n_ents, const uint32_t *keys, const uint32_t *vals,
+                          uint64_t n_q, const uint32_t *qkeys, uint32_t *out, uint8_t *cached, uint32_t *meta) {
+    std::vector<fqtk::DirectEntry> ents(n_ents);
+    for (uint64_t i = 0; i < n_ents; ++i) ents[i] = fqtk::DirectEntry{keys[2 * i], keys[2 * i + 1], vals[i]};
+    const fqtk::DirectMemoPlan p = fqtk::plan_direct_memo(S, L, ents);
+    const uint32_t m[8] = {(uint32_t)p.entry_bytes, p.ib, p.bb, p.hot2_bits, (uint32_t)p.hot2.size(), (uint32_t)p.hot2_wanted,
+                           (uint32_t)p.hot2_placed, (uint32_t)(p.entry_bytes == 2 ? p.table16.size() : p.table32.size())};
+    std::memcpy(meta, m, sizeof m);
+    if (!p.entry_bytes) return 0;
+    for (uint64_t i = 0; i < n_q; ++i) {
+        bool c = false;
+        out[i] = fqtk::direct_memo_lookup(p, qkeys[2 * i], qkeys[2 * i + 1], &c);
+        cached[i] = c ? 1 : 0;
+    }
+    return 0;
 }
 }  // extern "C"

@@ -69,26 +69,6 @@ __device__ __forceinline__ uint32_t lane_select(uint64_t mask, uint32_t a, uint3
     return d;
 }
 
-// The cheap per-tile test flags every byte that is not A/C/G/T/N in either case -- including '.', the
-// legacy no-call, which encodes exactly like 'N' (mod.rs:85-87: 'N', 'n' and '.' are the no-calls) and has
-// the same 4-bit key code.  So a read whose only offence is '.' was ALREADY looked up under the right key;
-// this exact test (rare branch only) keeps such reads out of the wave-cooperative scan.
-template <int NWD>
-__device__ __forceinline__ uint32_t noncanonical_beyond_dots(const uint32_t (&words)[8], const uint32_t (&kc)[NWD],
-                                                             const uint32_t (&kv)[NWD]) {
-    uint32_t bad = 0;
-#pragma unroll
-    for (int w = 0; w < NWD; ++w) {
-        const uint32_t t = words[w] ^ 0x2E2E2E2Eu;
-        const uint32_t dot = ~(((t & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | t | 0x7F7F7F7Fu);   // 0x80 in every byte that is '.'
-        const uint32_t ww = words[w] ^ ((dot >> 7) * 0x60u);                             // '.' (0x2E) -> 'N' (0x4E)
-        const uint32_t c = (ww >> 1) & kc[w];
-        const uint32_t e = __builtin_amdgcn_perm(kCodePoolHi, kCodePoolLo, c);
-        bad |= (ww ^ e) & kv[w];
-    }
-    return bad;
-}
-
 // PF: software pipeline of the full-tile loop -- the loads of tile t + grid are issued BEFORE tile t is
 // looked up, so a wave always has a load in flight while it computes.  With R = 1 this is the stream shape
 // the memory system likes best (tools/hbm_stream.hip: one 1-KiB request per wave at a time, 256 tiles = a

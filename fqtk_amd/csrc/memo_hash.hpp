@@ -71,6 +71,46 @@ FQTK_HD inline void memo_hash2(uint32_t lo, uint32_t hi, uint32_t ext, uint32_t 
     s2 = g & mask;
 }
 
+// ---- direct-indexed memo for short barcodes (table form, L <= kDirectMaxLen) ----------------------------
+// A read of L <= 10 plain A/C/G/T bases IS a 2L-bit number: the memo of those reads is a flat array in
+// HBM (L2-resident: 4^10 x 2 B = 2 MiB) indexed by the read itself -- no hash, no key compare, no second
+// probe, and "absent" is just the stored None.  Reads that carry a no-call keep using the cuckoo table
+// (which then holds only the N-containing entries).
+// Index = the 2-bit codes of the bases (A0 C1 T2 G3, memo_code_of & 3), taken straight from the 4-bit key
+// BEFORE the fold: lo_unf = bases 0-7 in memo_nibble_shift order, c2 = codes of bases 8, 9 in bytes 0, 1.
+// Bit layout (what three VALU ops give): base0 0-1, base2 2-3, base4 4-5, base6 6-7, base1 8-9, base3 10-11,
+// base5 12-13, base7 14-15, base8 16-17, base9 18-19.
+constexpr uint32_t kDirectMaxLen = 10;
+FQTK_HD inline uint32_t memo_direct_index(uint32_t lo_unf, uint32_t c2) {
+    const uint32_t x = lo_unf & 0x33333333u;
+    const uint32_t i16 = (x & 0xFFFFu) | (x >> 14);            // nibbles 4-7 drop into the gaps of nibbles 0-3
+    return (mul24(c2 & 0x0303u, 0x10400u) & 0xF0000u) | i16;   // codes 8, 9 -> bits 16-19 (one 24-bit multiply)
+}
+FQTK_HD inline uint32_t memo_nocall_bits(uint32_t lo_unf, uint32_t c2) {   // != 0 <=> some base is N (code 7)
+    return (lo_unf & 0x44444444u) | (c2 & 0x0404u);
+}
+FQTK_HD constexpr uint32_t memo_direct_entries(uint32_t L) { return L <= 8 ? (1u << 16) : (L == 9 ? (1u << 18) : (1u << 20)); }
+// 2-byte entries [idx : ib | best : bb | next : rest] when idx, best and next of every entry fit 16 bits with
+// the all-ones pattern left over (the builder picks ib and bb; cfg 5: 11 + 1 + 4), else the 4-byte result
+// word itself; None = all ones either way.
+FQTK_HD inline uint32_t memo_direct_unpack16(uint32_t e, uint32_t ib, uint32_t bb) {
+    const uint32_t idx = e & ((1u << ib) - 1u), best = (e >> ib) & ((1u << bb) - 1u), next = e >> (ib + bb);
+    return e == 0xFFFFu ? kMemoEmpty : (idx | (best << 16) | (next << 24));
+}
+FQTK_HD inline uint32_t memo_direct_pack16(uint32_t val, uint32_t ib, uint32_t bb) {   // val = idx | best << 16 | next << 24
+    return (val & 0xFFFFu) | (((val >> 16) & 0xFFu) << ib) | ((val >> 24) << (ib + bb));
+}
+// LDS cache of the direct table's EXACT-match entries (the bulk of real reads): two-choice cuckoo over
+// buckets of two 4-byte slots, so one ds_read_b64 fetches a bucket.  A slot is [which : 1 | tag | val16]:
+// the bucket index is a slice of the (rotated) 20-bit read index and the tag is the rest of it, so a tag
+// match is an EXACT key match without storing the key.  Choice 0 buckets by the low bits of the index,
+// choice 1 by the low bits of the index rotated by 10 (the two tags cover disjoint bases).
+FQTK_HD inline uint32_t memo_hot2_rot(uint32_t didx) { return ((didx >> 10) | (didx << 10)) & 0xFFFFFu; }
+FQTK_HD inline uint32_t memo_hot2_want(uint32_t key20, uint32_t bucket_bits, uint32_t which) {
+    return (key20 >> bucket_bits) | (which << 15);   // upper half-word of a matching slot (tag <= 14 bits)
+}
+constexpr uint32_t kHot2MaxBucketBits = 13;           // 8192 buckets x 8 B = 64 KiB
+
 
 // ---- LDS-resident compact memo (lds_memo_kernels.hip.h, lds_memo_plan.hpp) ---------------------------
 constexpr uint32_t kLdsMemoMaxBytes = 160u * 1024u;   // LDS per CU = per workgroup limit on gfx950

@@ -33,6 +33,11 @@ struct MemoParams {
     const uint32_t *hot;      // hot subset (exact matches) in the same slot format, copied to LDS
     uint32_t mask;            // n_slots - 1
     uint32_t hot_mask;        // hot slots - 1 (0 = no hot table)
+    // direct-indexed form (short barcodes, memo_hash.hpp): `slots` then holds only the N-containing entries
+    const void *direct;       // [memo_direct_entries(L)] uint16 (packed) or uint32 results, indexed by the read itself
+    const uint32_t *hot2;     // [2 << hot2_bits] LDS cache of the exact-match entries (two-slot buckets), or NULL
+    uint32_t hot2_bits;       // log2(buckets)
+    uint32_t d_ib, d_bb;      // 16-bit entries: bits of idx and of best (memo_direct_unpack16)
 };
 
 // ASCII -> 4-bit codes, SWAR on the packed words (no LDS, no per-base work).  Per 4-base word:
@@ -46,7 +51,7 @@ struct MemoParams {
 template <int NWD, bool FULL, bool FOLD>
 __device__ __forceinline__ void encode_nibbles(const uint32_t (&words)[8], const uint32_t (&kc)[NWD],
                                                const uint32_t (&kv)[NWD], uint32_t &lo, uint32_t &hi,
-                                               uint32_t &ext, uint32_t &bad) {
+                                               uint32_t &ext, uint32_t &bad, uint32_t &lo_unf, uint32_t &c2) {
     static_assert(!FOLD || NWD == 3, "the fold is for the 9-10 base keys only");
     uint32_t c[6] = {0, 0, 0, 0, 0, 0};
     bad = 0;
@@ -58,6 +63,8 @@ __device__ __forceinline__ void encode_nibbles(const uint32_t (&words)[8], const
         bad |= (words[w] ^ e) & (full ? 0xDFDFDFDFu : kv[w]);
     }
     lo = NWD >= 2 ? ((c[1] << 4) | c[0]) : c[0];
+    lo_unf = lo;    // bases 0-7 before the fold, and the codes of bases 8.. : what memo_direct_index reads
+    c2 = c[2];
     if constexpr (FOLD) {   // L <= 10: kc[2] leaves only codes 8 and 9 in c[2]
         lo |= mul24(c[2], kFoldMul) & kFoldMask;
         hi = ext = 0;
@@ -65,6 +72,14 @@ __device__ __forceinline__ void encode_nibbles(const uint32_t (&words)[8], const
     }
     hi = NWD >= 4 ? ((c[3] << 4) | c[2]) : (NWD == 3 ? c[2] : 0u);
     ext = NWD >= 5 ? __builtin_amdgcn_perm(0u, c[4] | (c[4] >> 4), 0x0C0C0200u) : 0u;   // 4 contiguous nibbles
+}
+
+template <int NWD, bool FULL, bool FOLD>
+__device__ __forceinline__ void encode_nibbles(const uint32_t (&words)[8], const uint32_t (&kc)[NWD],
+                                               const uint32_t (&kv)[NWD], uint32_t &lo, uint32_t &hi,
+                                               uint32_t &ext, uint32_t &bad) {
+    uint32_t lo_unf, c2;
+    encode_nibbles<NWD, FULL, FOLD>(words, kc, kv, lo, hi, ext, bad, lo_unf, c2);
 }
 
 // (best, second) packed keys -> result word (barcode_matching.rs:150-159).
@@ -135,25 +150,51 @@ constexpr int kMemoBlock = FQTK_MEMO_BLOCK;
 #ifndef FQTK_MEMO_WAVES
 #define FQTK_MEMO_WAVES 8
 #endif
+// The cheap per-tile test flags every byte that is not A/C/G/T/N in either case -- including '.', the
+// legacy no-call, which encodes exactly like 'N' (mod.rs:85-87: 'N', 'n' and '.' are the no-calls) and has
+// the same 4-bit key code.  So a read whose only offence is '.' was ALREADY looked up under the right key;
+// this exact test (rare branch only) keeps such reads out of the wave-cooperative scan.
+template <int NWD>
+__device__ __forceinline__ uint32_t noncanonical_beyond_dots(const uint32_t (&words)[8], const uint32_t (&kc)[NWD],
+                                                             const uint32_t (&kv)[NWD]) {
+    uint32_t bad = 0;
+#pragma unroll
+    for (int w = 0; w < NWD; ++w) {
+        const uint32_t t = words[w] ^ 0x2E2E2E2Eu;
+        const uint32_t dot = ~(((t & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | t | 0x7F7F7F7Fu);   // 0x80 in every byte that is '.'
+        const uint32_t ww = words[w] ^ ((dot >> 7) * 0x60u);                             // '.' (0x2E) -> 'N' (0x4E)
+        const uint32_t c = (ww >> 1) & kc[w];
+        const uint32_t e = __builtin_amdgcn_perm(kCodePoolHi, kCodePoolLo, c);
+        bad |= (ww ^ e) & kv[w];
+    }
+    return bad;
+}
+
 // LENS: the batch carries obs_len (variable-length '+B' structures): the memo serves the reads of length
 // exactly L, the others follow the length rules of barcode_matching.rs:165-172.  A separate instantiation,
 // so that the fixed-length kernels carry none of it.
-template <int VEC, int KW, int R, int ABL, bool LENS = false>
+// DIRECT (0 = off, 2 / 4 = bytes per entry): barcodes of <= 10 bases -- reads without a no-call index a flat
+// array by their own 2-bit codes (memo_hash.hpp), exact matches are caught by a compact LDS cache of that
+// array, and only reads with an N go to the cuckoo table.
+template <int VEC, int KW, int R, int ABL, bool LENS = false, int DIRECT = 0>
 __global__ __launch_bounds__(kMemoBlock) __attribute__((amdgpu_waves_per_eu(FQTK_MEMO_WAVES, 8)))
 void memo_kernel(const MemoParams Q) {
+    static_assert(DIRECT == 0 || KW == 1, "the direct index is for keys of <= 10 bases");
     const MatchParams &P = Q.m;
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
     uint32_t *lds_lut = smem;                                            // 256 x u32 spread LUT (fallback)
     // hot table: the memo entries with 0 mismatches (a read that IS a sample barcode -- the bulk of
     // real data) live in LDS, so most lanes never touch the global table; the rest probe it with
     // the hit lanes masked off, which shrinks the gather traffic by the hit rate.
-    const uint32_t hot_words = Q.hot_mask ? (Q.hot_mask + 1) * (KW >= 2 ? 4u : 2u) : 0u;
+    const uint32_t hot_words = DIRECT ? (Q.hot2 ? (2u << Q.hot2_bits) : 0u)
+                                      : (Q.hot_mask ? (Q.hot_mask + 1) * (KW >= 2 ? 4u : 2u) : 0u);
     uint32_t *lds_hot = smem + 256;
     uint32_t *lds_hist = lds_hot + hot_words;
 
     const uint32_t tid = threadIdx.x;
     if (tid < 256) lds_lut[tid] = P.lut[tid];
-    for (uint32_t w = tid; w < hot_words; w += kMemoBlock) lds_hot[w] = Q.hot[w];
+    const uint32_t *hot_src = DIRECT ? Q.hot2 : Q.hot;
+    for (uint32_t w = tid; w < hot_words; w += kMemoBlock) lds_hot[w] = hot_src[w];
     const uint32_t bins = P.S + 1;
     if (P.counts && P.lds_hist)
         for (uint32_t b = tid; b < bins; b += kMemoBlock) lds_hist[b] = 0;
@@ -175,11 +216,12 @@ void memo_kernel(const MemoParams Q) {
     }
     const uint64_t tile = (uint64_t)kMemoBlock * R;
     const uint64_t ntiles = (P.n + tile - 1) / tile;
+    const uint32_t hot2_mask = (1u << Q.hot2_bits) - 1u;
 
     for (uint64_t t = blockIdx.x; t < ntiles; t += gridDim.x) {
         uint32_t words[R][8];
-        uint32_t lo[R], hi[R], ext[R], res[R];
-        bool live[R], bad[R];
+        uint32_t lo[R], hi[R], ext[R], res[R], didx[R];
+        bool live[R], bad[R], has_n[R];
 #pragma unroll
         for (int r = 0; r < R; ++r) {
             const uint64_t i = t * tile + (uint64_t)r * kMemoBlock + tid;
@@ -191,10 +233,17 @@ void memo_kernel(const MemoParams Q) {
         // ---- ASCII -> 4-bit codes (SWAR, see encode_nibbles); `bad` = some base is not A C G T N ----
 #pragma unroll
         for (int r = 0; r < R; ++r) {
-            uint32_t b;
-            encode_nibbles<NWD, (VEC >= 1 && !(ABL & 2)), FOLD>(words[r], kc, kv, lo[r], hi[r], ext[r], b);
+            uint32_t b, lo_unf, c2;
+            encode_nibbles<NWD, (VEC >= 1 && !(ABL & 2)), FOLD>(words[r], kc, kv, lo[r], hi[r], ext[r], b, lo_unf, c2);
             bad[r] = b != 0 && live[r];
             if constexpr (LENS) { if (live[r]) bad[r] = bad[r] && P.lens[t * tile + (uint64_t)r * kMemoBlock + tid] == L; }
+            if constexpr (DIRECT) {
+                didx[r] = memo_direct_index(lo_unf, c2);
+                has_n[r] = memo_nocall_bits(lo_unf, c2) != 0;
+            } else {
+                didx[r] = 0;
+                has_n[r] = true;   // every read takes the cuckoo table
+            }
         }
         // ---- probe: both candidate slots of every read are known up front.  Empty slots carry
         //      key = ~0 (no real key has a nibble's top bit set) and val = None. ---------------------
@@ -208,7 +257,21 @@ void memo_kernel(const MemoParams Q) {
         uint32_t g1[R], g2[R];   // global-table slots (ABL 32: folded into a 4 KB corner = L1-resident)
 #pragma unroll
         for (int r = 0; r < R; ++r) { g1[r] = (ABL & 32) ? (s1[r] & 0xFFu) : s1[r]; g2[r] = (ABL & 32) ? (s2[r] & 0xFFu) : ((ABL & 128) ? (s1[r] ^ 1u) : s2[r]); }
-        if (Q.hot_mask && !(ABL & 16)) {   // wave-uniform
+        if constexpr (DIRECT != 0) {
+            if (Q.hot2 && !(ABL & 16)) {   // wave-uniform
+#pragma unroll
+                for (int r = 0; r < R; ++r) {
+                    const uint32_t p = didx[r], q = memo_hot2_rot(didx[r]);
+                    const u32x2v b1 = reinterpret_cast<const u32x2v *>(lds_hot)[p & hot2_mask];
+                    const u32x2v b2 = reinterpret_cast<const u32x2v *>(lds_hot)[q & hot2_mask];
+                    const uint32_t w1 = memo_hot2_want(p, Q.hot2_bits, 0), w2 = memo_hot2_want(q, Q.hot2_bits, 1);
+                    const bool m0 = (b1.x >> 16) == w1, m1 = (b1.y >> 16) == w1, m2 = (b2.x >> 16) == w2, m3 = (b2.y >> 16) == w2;
+                    const uint32_t e = m0 ? b1.x : (m1 ? b1.y : (m2 ? b2.x : b2.y));
+                    hit[r] = (m0 || m1 || m2 || m3) && !has_n[r];   // an N aliases G in the 2-bit index: never trust it
+                    if (hit[r]) res[r] = memo_direct_unpack16(e & 0xFFFFu, Q.d_ib, Q.d_bb);   // the cache exists for 16-bit entries only
+                }
+            }
+        } else if (Q.hot_mask && !(ABL & 16)) {   // wave-uniform
 #pragma unroll
             for (int r = 0; r < R; ++r) {
                 const uint32_t a1 = s1[r] & Q.hot_mask, a2 = s2[r] & Q.hot_mask;
@@ -232,6 +295,17 @@ void memo_kernel(const MemoParams Q) {
 #pragma unroll
             for (int r = 0; r < R; ++r) res[r] = (s1[r] ^ s2[r]) | 0xFFFFu;
         } else {
+            // Direct form: one 2/4-byte gather settles every no-call-free read that missed the LDS cache.
+            // (Non-canonical lanes probe too -- harmless, see below -- so a '.' read is already right.)
+            if constexpr (DIRECT != 0) {
+#pragma unroll
+                for (int r = 0; r < R; ++r) {
+                    if (!hit[r] && !has_n[r]) {
+                        if constexpr (DIRECT == 2) res[r] = memo_direct_unpack16(reinterpret_cast<const uint16_t *>(Q.direct)[didx[r]], Q.d_ib, Q.d_bb);
+                        else res[r] = reinterpret_cast<const uint32_t *>(Q.direct)[didx[r]];
+                    }
+                }
+            }
             // Global table, two-choice placement with a per-slot SPILL bit: the builder keeps a key in
             // its first slot whenever it can and marks a slot whose would-be owner lives in its second
             // slot.  So one gather settles ~90 % of the probing lanes (hit, or miss with spill = 0);
@@ -240,7 +314,7 @@ void memo_kernel(const MemoParams Q) {
 #pragma unroll
             for (int r = 0; r < R; ++r) {
                 again[r] = false;
-                if (!hit[r] && !bad[r]) {
+                if (!hit[r] && has_n[r]) {
                     if constexpr (KW >= 2) {
                         const uint4 e = reinterpret_cast<const uint4 *>(Q.slots)[g1[r]];
                         if (e.x == lo[r] && e.y == hi[r] && (KW < 3 || (e.w >> 16) == ext[r])) res[r] = e.z;
@@ -265,19 +339,24 @@ void memo_kernel(const MemoParams Q) {
                 }
             }
         }
-        // ---- rare: non-canonical reads -> wave-cooperative exhaustive scan ---------------------
+        // ---- rare: non-canonical reads -> wave-cooperative exhaustive scan.  Every lane was looked up
+        //      above under its 4-bit key; '.' has N's code, so a read whose only non-canonical bytes are
+        //      '.' no-calls already holds its answer -- only IUPAC / junk bytes need the scan. ----------
 #pragma unroll
         for (int r = 0; r < R; ++r) {
-            uint64_t todo = __ballot(bad[r]);
-            if (todo) {   // wave-uniform
-                Planes<1> mine;
-                encode_planes<1>(words[r], nwords, L, lds_lut, mine);
-                while (todo) {
-                    const int src = __ffsll((unsigned long long)todo) - 1;
-                    todo &= todo - 1;
-                    uint32_t b, s;
-                    wave_scan<1>(mine, src, P, b, s);
-                    if ((int)__lane_id() == src) res[r] = decide(b, s, P.max_mm, P.delta);
+            if (__ballot(bad[r])) {   // wave-uniform
+                const bool really = bad[r] && noncanonical_beyond_dots<NWD>(words[r], kc, kv) != 0;
+                uint64_t todo = __ballot(really);
+                if (todo) {
+                    Planes<1> mine;
+                    encode_planes<1>(words[r], nwords, L, lds_lut, mine);
+                    while (todo) {
+                        const int src = __ffsll((unsigned long long)todo) - 1;
+                        todo &= todo - 1;
+                        uint32_t b, s;
+                        wave_scan<1>(mine, src, P, b, s);
+                        if ((int)__lane_id() == src) res[r] = decide(b, s, P.max_mm, P.delta);
+                    }
                 }
             }
         }

@@ -116,6 +116,11 @@ uint64_t fqtk_matcher_memo_candidates(const fqtk_matcher *m);
 #define FQTK_MEMO_LDS 2
 int fqtk_matcher_memo_kind(const fqtk_matcher *m);
 int fqtk_matcher_set_memo_kind(fqtk_matcher *m, int kind);
+/* FQTK_MEMO_TABLE has a direct-indexed variant for barcodes of <= 10 bases: reads without a no-call index a
+ * flat result array by their own 2-bit base codes (no hash, no probe sequence), an LDS cache holds its
+ * exact-match entries, and only reads with an N go to the hash table.  Returns the bytes per array entry
+ * (2 or 4) when that variant is what FQTK_MEMO_TABLE means for this matcher, else 0. */
+int fqtk_matcher_memo_direct_bytes(const fqtk_matcher *m);
 
 /* Replaces one `BarcodeMatcher::assign(&mut self, read_bases: &[u8]) -> Option<BarcodeMatch>` call
  * per template (barcode_matching.rs:165-186; sole call site demux.rs:968) with one call per batch.

@@ -301,6 +301,39 @@ def test_variable_length_batches_use_the_memo_and_match_the_oracle(k):
         assert (got["idx"][lens == L] != 0xFFFF).mean() > 0.4     # the memo did serve the full-length reads
 
 
+def test_direct_indexed_table_form_for_short_barcodes():
+    """Barcodes of <= 10 bases: FQTK_MEMO_TABLE is the direct-indexed variant (flat array + LDS cache of the
+    exact matches + cuckoo table for reads with an N); '.' no-calls are served under N's key, IUPAC / junk
+    bytes in a read still take the wave scan.  All of it bit-exact vs the oracle, in every lane position."""
+    cfg = synth.CONFIGS[5]
+    w = synth.Workload(cfg)
+    m = BarcodeMatcher(w.barcodes, cfg.max_mismatches, cfg.min_mismatch_delta)
+    assert m.memo_kind == BarcodeMatcher.MEMO_TABLE and m.memo_direct_bytes == 2
+    m16 = BarcodeMatcher(["ACGTACGTACGTACGT", "TTTTACGTACGTACGA"], 2, 1)
+    assert m16.memo_direct_bytes == 0                         # 16 bases: no direct index
+    n = 40_000
+    obs = w.fill_host(0, n)
+    rng = np.random.default_rng(11)
+    for ch, frac in ((b".", 0.2), (b"R", 0.02), (b"-", 0.02), (b"n", 0.1), (b"u", 0.02)):
+        hit = rng.random(n) < frac
+        obs[hit, rng.integers(0, cfg.barcode_len, int(hit.sum()))] = ch[0]
+    _compare(w.barcodes, cfg.max_mismatches, cfg.min_mismatch_delta, obs)
+    _compare(w.barcodes, 0, 0, obs)                           # demux.rs:1494-1495 runs the IUPAC tables at 0/0
+    # plain plates of 8, 9, 10 bases with the table form pinned (the default would be the LDS form where it fits)
+    for L, S in ((8, 700), (9, 300), (10, 1536)):
+        seen = set()
+        while len(seen) < S:
+            seen.add("".join(rng.choice(list("ACGT"), size=L)))
+        bcs = sorted(seen)
+        stride = (L + 3) // 4 * 4
+        o = np.zeros((30_000, stride), dtype=np.uint8)
+        src = np.stack([np.frombuffer(b.encode(), dtype=np.uint8) for b in bcs])[rng.integers(0, S, 30_000)]
+        flip = rng.random(src.shape) < 0.03
+        src[flip] = np.frombuffer(b"ACGTN.", dtype=np.uint8)[rng.integers(0, 6, int(flip.sum()))]
+        o[:, :L] = src
+        _compare(bcs, 1, 1, o)
+
+
 def test_rows_shorter_than_a_barcode_are_all_none_and_never_read_past_the_buffer():
     barcodes = ["ACGTACGTACGTACGTACGTACGTACGTACGT" * 4]        # L = 128, the longest the ABI takes
     m = BarcodeMatcher(barcodes + [barcodes[0][::-1]], 1, 1)
