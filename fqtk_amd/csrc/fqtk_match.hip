@@ -25,6 +25,14 @@ namespace {
 
 thread_local std::string g_last_error;
 
+#ifdef FQTK_DEV_ABLATE
+// developer switches: set and neither empty nor "0"
+bool env_flag(const char *name) {
+    const char *v = std::getenv(name);
+    return v && *v && !(v[0] == '0' && v[1] == '\0');
+}
+#endif
+
 int fail(int code, const std::string &msg) {
     g_last_error = msg;
     return code;
@@ -397,7 +405,7 @@ int launch_lds_memo(const fqtk_matcher *m, fqtk::LdsMemoParams Q, hipStream_t st
         HIP_TRY(hipGetLastError());
         return FQTK_OK;
     }
-    if (std::getenv("FQTK_LDSM_PF") && !P.lens && (vec == 4 || vec == 2) && (R == 1 || R == 2 || R == 4)) {
+    if (env_flag("FQTK_LDSM_PF") && !P.lens && (vec == 4 || vec == 2) && (R == 1 || R == 2 || R == 4)) {
         switch (vec * 10 + R) {
             case 41: FQTK_LDSM_LAUNCH_P(4, 1, false, true); break;
             case 42: FQTK_LDSM_LAUNCH_P(4, 2, false, true); break;
@@ -687,7 +695,7 @@ struct Entry { uint32_t lo, hi, ext, val; uint64_t ci; };   // one Some entry of
 // uploaded here.
 int build_direct(fqtk_matcher *m, const std::vector<char> &cand, const std::vector<Entry> &ents) {
 #ifdef FQTK_DEV_ABLATE
-    if (std::getenv("FQTK_NO_DIRECT")) return FQTK_OK;
+    if (env_flag("FQTK_NO_DIRECT")) return FQTK_OK;
 #endif
     std::vector<fqtk::DirectEntry> dir;
     for (const Entry &e : ents) {

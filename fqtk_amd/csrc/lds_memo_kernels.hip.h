@@ -161,11 +161,9 @@ void lds_memo_kernel(const LdsMemoParams Q) {
         }
     };
 
-    // FULL = every read of the tile exists and the packed vector load applies: the lean path.
-    auto compute = [&](uint64_t t, uint32_t (&words)[R][8], const bool (&live)[R], auto full_tag) {
-        constexpr bool FULL = decltype(full_tag)::value;
-        uint32_t res[R], bflag[R];
-        uint32_t *tile_out = P.out + t * tile;
+    // Looks one tile up: res[r] = the result word of the tile's r-th read; also feeds the LDS histogram.
+    auto compute = [&](uint64_t t, uint32_t (&words)[R][8], const bool (&live)[R], uint32_t (&res)[R]) {
+        uint32_t bflag[R];
         // One read at a time: hash, three entry reads, select, verify; the rare extra verification
         // rounds sit behind wave-uniform branches.
         uint32_t lo[R], hi[R], ext[R];
@@ -257,21 +255,27 @@ void lds_memo_kernel(const LdsMemoParams Q) {
                 }
             }
         }
-        // ---- results + per-sample counts ---------------------------------------------------------
+        // ---- per-sample counts ---------------------------------------------------------------------
+        if (P.counts) {
 #pragma unroll
-        for (int r = 0; r < R; ++r) {
-            if (!live[r]) continue;
-            if constexpr (FULL) {
-                FQTK_STREAM_STORE(res[r], reinterpret_cast<uint32_t *>(reinterpret_cast<uint8_t *>(tile_out) + out_off[r]));
-            } else {
-                FQTK_STREAM_STORE(res[r], &P.out[t * tile + local[r]]);
-            }
-            if (P.counts) {
+            for (int r = 0; r < R; ++r) {
+                if (!live[r]) continue;
                 const uint32_t bin = min(res[r] & 0xFFFFu, P.S);   // None (0xFFFF) -> bin S
                 if (hist_on) lds_atomic_inc(hist_base_b + bin * 4u);
                 else atomicAdd(&P.counts[bin], 1ull);
             }
         }
+    };
+    // The result stream of one tile.
+    auto store_full = [&](uint64_t t, const uint32_t (&res)[R]) {
+        uint8_t *tile_out = reinterpret_cast<uint8_t *>(P.out + t * tile);   // wave-uniform
+#pragma unroll
+        for (int r = 0; r < R; ++r) FQTK_STREAM_STORE(res[r], reinterpret_cast<uint32_t *>(tile_out + out_off[r]));
+    };
+    auto store_any = [&](uint64_t t, const uint32_t (&res)[R], const bool (&live)[R]) {
+#pragma unroll
+        for (int r = 0; r < R; ++r)
+            if (live[r]) FQTK_STREAM_STORE(res[r], &P.out[t * tile + local[r]]);
     };
 
     const uint64_t full_tiles = (VEC >= 1) ? P.n / tile : 0;
@@ -279,31 +283,48 @@ void lds_memo_kernel(const LdsMemoParams Q) {
 #pragma unroll
     for (int r = 0; r < R; ++r) all_live[r] = true;
     if constexpr (PF && VEC >= 1) {
-        uint32_t cur[R][8], nxt[R][8];
-        uint64_t t = blockIdx.x;
+        // Software pipeline, one tile deep on both streams.  gfx950 counts loads AND stores in vmcnt and
+        // they complete out of order with respect to each other, so "wait for my loads" also waits for every
+        // store issued since: the plain loop (load, look up, store) pays a store acknowledgement plus a load
+        // round trip, back to back, per tile.  Here a wave waits ONCE per tile, at the top, for operations it
+        // issued a whole look-up phase earlier (the loads of `cur`, the stores of the tile before), and only
+        // then issues the next tile's loads and the previous tile's stores, which fly during the look-up.
+        uint32_t cur[R][8], nxt[R][8], held[R];
+        uint64_t t = blockIdx.x, t_held = 0;
+        bool have = false;
         if (t < full_tiles) load_full(t, cur);
         for (; t < full_tiles; t += gridDim.x) {
+#pragma unroll
+            for (int r = 0; r < R; ++r)
+#pragma unroll
+                for (int w = 0; w < NWD; ++w) asm volatile("" : "+v"(cur[r][w]) : : "memory");   // cur has landed; nothing moves above
             const uint64_t tn = t + gridDim.x;
-            if (tn < full_tiles) load_full(tn, nxt);   // wave-uniform: in flight while tile t is looked up
-            compute(t, cur, all_live, std::true_type{});
+            if (tn < full_tiles) load_full(tn, nxt);   // wave-uniform
+            if (have) store_full(t_held, held);
+            compute(t, cur, all_live, held);
+            have = true;
+            t_held = t;
 #pragma unroll
             for (int r = 0; r < R; ++r)
 #pragma unroll
                 for (int w = 0; w < NWD; ++w) cur[r][w] = nxt[r][w];
         }
+        if (have) store_full(t_held, held);
     } else {
         for (uint64_t t = blockIdx.x; t < full_tiles; t += gridDim.x) {
-            uint32_t words[R][8];
+            uint32_t words[R][8], res[R];
             load_full(t, words);
-            compute(t, words, all_live, std::true_type{});
+            compute(t, words, all_live, res);
+            store_full(t, res);
         }
     }
     // whatever is left (the ragged last tile; every tile on the generic load paths)
     for (uint64_t t = full_tiles + (blockIdx.x + gridDim.x - full_tiles % gridDim.x) % gridDim.x; t < ntiles; t += gridDim.x) {
-        uint32_t words[R][8];
+        uint32_t words[R][8], res[R];
         bool live[R];
         load_any(t, words, live);
-        compute(t, words, live, std::false_type{});
+        compute(t, words, live, res);
+        store_any(t, res, live);
     }
 
     if (P.counts && P.lds_hist) {

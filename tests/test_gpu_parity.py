@@ -99,8 +99,8 @@ def test_length_rules():
     with pytest.raises(FqtkLengthError, match=re.escape(
             "Read barcode (ACGTA) length (5) differs from expected barcode (ACGT) length (4) for sample sample_0")):
         m.assign(b"ACGTA")
-    with pytest.raises(FqtkLengthError, match=re.escape("Read barcode (ANGTNA) length (6)")):
-        m.assign(b"a.gtnA")                         # decode(encode(read)): upper case, '.' -> N (mod.rs:49-80)
+    with pytest.raises(FqtkLengthError, match=re.escape("Read barcode (ANGTCA) length (6)")):
+        m.assign(b"a.gtcA")                         # decode(encode(read)): upper case, '.' -> N (mod.rs:49-80)
     with pytest.raises(FqtkLengthError, match="Invalid bit mask for base: 0"):
         m.assign(b"ACGTX")                          # decode() itself panics on a byte with no mask (mod.rs:80)
     assert m.assign(b"NNNNN") is None               # ...unless the no-call prefilter fires first
