@@ -289,6 +289,19 @@ int launch_memo_vec(const fqtk_matcher *m, const fqtk::MemoParams &Q, hipStream_
         return FQTK_OK;
     }
 #endif
+#ifdef FQTK_DEV_ABLATE
+    if (abl > 0 && direct == 2 && vec == 3 && !P.lens) {
+        switch (abl * 10 + R) {   // NOLINT
+#define FQTK_AB(A, RR) case A * 10 + RR: FQTK_MEMO_LAUNCH_D(3, RR, A, false, 2); break;
+            FQTK_AB(1, 4) FQTK_AB(4, 4) FQTK_AB(16, 4) FQTK_AB(17, 4) FQTK_AB(256, 4) FQTK_AB(2, 4) FQTK_AB(8, 4) FQTK_AB(272, 4)
+            FQTK_AB(1, 2) FQTK_AB(4, 2) FQTK_AB(16, 2) FQTK_AB(256, 2)
+#undef FQTK_AB
+            default: return fail(FQTK_EINVAL, "ablation variant not built");
+        }
+        HIP_TRY(hipGetLastError());
+        return FQTK_OK;
+    }
+#endif
     if (direct) {   // barcodes of <= 10 bases: the direct-indexed form (KW == 1, so vec is 1, 2, 3, -1 or 0)
 #define FQTK_MEMO_DIRECT(D)                                                                       \
         if (P.lens) {                                                                             \
@@ -368,8 +381,8 @@ int launch_lds_memo(const fqtk_matcher *m, fqtk::LdsMemoParams Q, hipStream_t st
     size_t shmem = m->ldsm_lds_bytes;
     if (P.counts && P.lds_hist) shmem += (size_t)(P.S + 1) * sizeof(uint32_t);
     if (shmem > fqtk::kLdsMemoMaxBytes) return fail(FQTK_EINVAL, "lds memo: table does not fit LDS");
-    // reads per lane on the packed paths: 4 (8-byte keys: +15 % over 2), 2 for 16-byte keys (+1-2 % over 4)
-    int R = vec > 0 ? (KW == 2 ? 2 : 4) : 1;
+    // reads per lane: 2 on the packed paths, 1 on the generic ones
+    int R = vec > 0 ? 2 : 1;
 #ifdef FQTK_DEV_ABLATE
     if (const char *rr = std::getenv("FQTK_MEMO_R")) R = std::atoi(rr);
 #endif
@@ -428,31 +441,46 @@ int launch_lds_memo(const fqtk_matcher *m, fqtk::LdsMemoParams Q, hipStream_t st
             case -1: FQTK_LDSM_LAUNCH_L(-1, 1, true); break;
             default: FQTK_LDSM_LAUNCH_L(0, 1, true); break;
         }
-    } else if (R >= 4 && vec > 0) {
+    } else if (vec > 0) {
+        // packed rows: two reads per lane, full tiles software-pipelined one tile deep on both streams
+        // (measured on MI355X, tools/ab_pf.sh: cfg 3 272.8 -> 278.7 G reads/s over R = 2 unpipelined,
+        //  cfg 2 458.6 (R = 4, unpipelined) -> 464.0; R = 1 pipelined 275 / 347, R = 4 pipelined 269 / 451)
+#ifdef FQTK_DEV_ABLATE
+        if (R == 4) {
+            switch (vec) {
+                case 5: FQTK_LDSM_LAUNCH(5, 4); break;
+                case 4: FQTK_LDSM_LAUNCH(4, 4); break;
+                case 3: FQTK_LDSM_LAUNCH(3, 4); break;
+                case 2: FQTK_LDSM_LAUNCH(2, 4); break;
+                default: FQTK_LDSM_LAUNCH(1, 4); break;
+            }
+        } else if (R == 1) {
+            switch (vec) {
+                case 5: FQTK_LDSM_LAUNCH(5, 1); break;
+                case 4: FQTK_LDSM_LAUNCH(4, 1); break;
+                case 3: FQTK_LDSM_LAUNCH(3, 1); break;
+                case 2: FQTK_LDSM_LAUNCH(2, 1); break;
+                default: FQTK_LDSM_LAUNCH(1, 1); break;
+            }
+        } else if (env_flag("FQTK_LDSM_NOPF")) {
+            switch (vec) {
+                case 5: FQTK_LDSM_LAUNCH(5, 2); break;
+                case 4: FQTK_LDSM_LAUNCH(4, 2); break;
+                case 3: FQTK_LDSM_LAUNCH(3, 2); break;
+                case 2: FQTK_LDSM_LAUNCH(2, 2); break;
+                default: FQTK_LDSM_LAUNCH(1, 2); break;
+            }
+        } else
+#endif
         switch (vec) {
-            case 5: FQTK_LDSM_LAUNCH(5, 4); break;
-            case 4: FQTK_LDSM_LAUNCH(4, 4); break;
-            case 3: FQTK_LDSM_LAUNCH(3, 4); break;
-            case 2: FQTK_LDSM_LAUNCH(2, 4); break;
-            default: FQTK_LDSM_LAUNCH(1, 4); break;
-        }
-    } else if (R >= 2) {
-        switch (vec) {
-            case 5: FQTK_LDSM_LAUNCH(5, 2); break;
-            case 4: FQTK_LDSM_LAUNCH(4, 2); break;
-            case 3: FQTK_LDSM_LAUNCH(3, 2); break;
-            case 2: FQTK_LDSM_LAUNCH(2, 2); break;
-            case 1: FQTK_LDSM_LAUNCH(1, 2); break;
-            case -1: FQTK_LDSM_LAUNCH(-1, 2); break;
-            default: FQTK_LDSM_LAUNCH(0, 2); break;
+            case 5: FQTK_LDSM_LAUNCH_P(5, 2, false, true); break;
+            case 4: FQTK_LDSM_LAUNCH_P(4, 2, false, true); break;
+            case 3: FQTK_LDSM_LAUNCH_P(3, 2, false, true); break;
+            case 2: FQTK_LDSM_LAUNCH_P(2, 2, false, true); break;
+            default: FQTK_LDSM_LAUNCH_P(1, 2, false, true); break;
         }
     } else {
         switch (vec) {
-            case 5: FQTK_LDSM_LAUNCH(5, 1); break;
-            case 4: FQTK_LDSM_LAUNCH(4, 1); break;
-            case 3: FQTK_LDSM_LAUNCH(3, 1); break;
-            case 2: FQTK_LDSM_LAUNCH(2, 1); break;
-            case 1: FQTK_LDSM_LAUNCH(1, 1); break;
             case -1: FQTK_LDSM_LAUNCH(-1, 1); break;
             default: FQTK_LDSM_LAUNCH(0, 1); break;
         }

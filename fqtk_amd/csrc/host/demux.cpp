@@ -59,8 +59,23 @@ void info(const char *fmt, ...) {
     va_end(ap);
 }
 
+// Output files this run has created.  A fatal error (from any thread) must not leave truncated BGZF files
+// behind -- a .fq.gz without its EOF block looks complete to most tools -- so die() removes them before
+// the process ends.  (The reference panics; whatever its pooled writers had flushed stays on disk.)
+std::mutex g_created_mu;
+std::vector<std::string> g_created;
+std::atomic<bool> g_dying{false};
+
 [[noreturn]] void die(const std::string &msg) {
+    if (g_dying.exchange(true))          // another thread is already reporting: let it finish, never return
+        for (;;) pause();
     std::fprintf(stderr, "Error: %s\n", msg.c_str());
+    {
+        std::lock_guard<std::mutex> lk(g_created_mu);
+        for (const std::string &p : g_created) unlink(p.c_str());   // open handles of other threads stay valid
+        if (!g_created.empty())
+            std::fprintf(stderr, "Error: removed %zu partially written output file(s)\n", g_created.size());
+    }
     std::fflush(stderr);
     std::_Exit(1);
 }
@@ -451,6 +466,8 @@ int main(int argc, char **argv) {
                 of.path = opt.output + "/" + prefix + "." + kCodes[k] + std::to_string(j + 1) + ".fq.gz";
                 of.f = std::fopen(of.path.c_str(), "wb");
                 if (!of.f) die("cannot create " + of.path + ": " + std::strerror(errno));
+                std::lock_guard<std::mutex> lk(g_created_mu);
+                g_created.push_back(of.path);
             }
         }
     }
@@ -484,6 +501,24 @@ int main(int argc, char **argv) {
         if (seg.has_length()) fixed_barcode_len += (size_t)seg.length; else variable_barcode = true;
     }
 
+    // Per input: where its fixed-length sample-barcode segments sit inside a read and inside the packed row.
+    // Reader threads pack them (and flag too-short reads) while the record is still hot in their cache;
+    // the main thread then only interleaves one small fixed-width copy per barcode-carrying input.
+    struct InputPack { std::vector<std::pair<size_t, size_t>> segs; size_t width = 0, col = 0, min_len = 0; };
+    std::vector<InputPack> ipack(n_inputs);
+    {
+        size_t col = 0;
+        for (const SegRef &r : plan.by_type[1]) {
+            const ReadSegment &seg = plan.rs[r.input].segments[r.seg];
+            if (!seg.has_length()) continue;
+            if (ipack[r.input].width == 0) ipack[r.input].col = col;
+            ipack[r.input].segs.emplace_back(seg.offset, (size_t)seg.length);
+            ipack[r.input].width += (size_t)seg.length;
+            col += (size_t)seg.length;
+        }
+        for (size_t i = 0; i < n_inputs; ++i) ipack[i].min_len = plan.rs[i].min_length();
+    }
+
     // ---- stage A: one reader thread per input ------------------------------------------------------
     const size_t chunk_reads = std::max<unsigned long>(1, opt.chunk_reads);
     std::vector<std::unique_ptr<BoundedQueue<ReadResult>>> rq;
@@ -496,6 +531,21 @@ int main(int argc, char **argv) {
                 r.batch = std::make_unique<RecBatch>();
                 const uint64_t t0 = tick();
                 const bool ok = sources[i]->next_batch(chunk_reads, r.batch.get(), &r.error);
+                if (ok) {   // too-few-bases flags + this input's slice of the packed sample-barcode rows
+                    RecBatch &b = *r.batch;
+                    const InputPack &ip = ipack[i];
+                    const size_t n = b.recs.size();
+                    b.n_short = 0;
+                    b.too_short.assign(n, 0);
+                    if (!variable_barcode && ip.width) b.bc.resize(n * ip.width);
+                    for (size_t j = 0; j < n; ++j) {
+                        if (b.recs[j].seq_len < ip.min_len) { b.too_short[j] = 1; ++b.n_short; continue; }
+                        if (variable_barcode || !ip.width) continue;
+                        uint8_t *dst = b.bc.data() + j * ip.width;
+                        const char *seq = b.seq(j);
+                        for (const auto &sg : ip.segs) { std::memcpy(dst, seq + sg.first, sg.second); dst += sg.second; }
+                    }
+                }
                 const uint64_t t1 = tick();
                 g_times.reader_parse += t1 - t0;
                 if (!ok) {
@@ -620,7 +670,7 @@ int main(int argc, char **argv) {
             b.lens = (uint32_t *)q;
         }
     };
-    struct Pending { std::shared_ptr<Chunk> chunk; std::vector<uint32_t> rows; int slot = -1; };
+    struct Pending { std::shared_ptr<Chunk> chunk; std::vector<uint32_t> rows; int slot = -1; bool identity = false; size_t n_rows = 0; };
     auto finish = [&](Pending &p) {
         if (!p.chunk) return;
         if (p.slot >= 0) {
@@ -628,7 +678,8 @@ int main(int argc, char **argv) {
             if (fqtk_matcher_wait(matchers[p.slot % G], p.slot / (int)G) != FQTK_OK)
                 die(std::string(fqtk_last_error()));   // over-long barcode: the reference panics too (barcode_matching.rs:95-107)
             g_times.main_gpu_wait += tick() - tg;
-            for (size_t j = 0; j < p.rows.size(); ++j) p.chunk->res[p.rows[j]] = sb[p.slot].out[j];
+            if (p.identity) std::memcpy(p.chunk->res.data(), sb[p.slot].out, p.n_rows * sizeof(fqtk_match_t));   // no skipped template
+            else for (size_t j = 0; j < p.rows.size(); ++j) p.chunk->res[p.rows[j]] = sb[p.slot].out[j];
         }
         const uint64_t th = tick();
         for (size_t w = 0; w < n_workers; ++w) wq[w]->push(p.chunk);
@@ -656,17 +707,18 @@ int main(int argc, char **argv) {
         ch->skip.assign(ch->n, 0);
         ch->res.assign(ch->n, fqtk_match_t{FQTK_NO_MATCH, 255, 255});
         // too-few-bases rule (demux.rs:298-313): skip the whole template, or fail with the reference's
-        // text for the FIRST offending template (templates in order, inputs in order within one)
+        // text for the FIRST offending template (templates in order, inputs in order within one).
+        // The readers flagged the short reads; the common chunk has none.
+        size_t n_skip = 0;
         {
             size_t bad_j = ch->n, bad_i = 0;
             for (size_t i = 0; i < n_inputs; ++i) {
-                const size_t min_len = plan.rs[i].min_length();
                 const RecBatch &b = *ch->batches[i];
+                if (b.n_short == 0) continue;
                 for (size_t j = 0; j < ch->n; ++j)
-                    if (b.recs[j].seq_len < min_len) {
-                        ch->skip[j] = 1;
+                    if (b.too_short[j]) {
+                        if (!ch->skip[j]) { ch->skip[j] = 1; ++n_skip; }
                         if (j < bad_j) { bad_j = j; bad_i = i; }
-                        if (!skip_few) break;   // only the first one matters when it is fatal
                     }
             }
             if (bad_j < ch->n && !skip_few) {
@@ -682,6 +734,7 @@ int main(int argc, char **argv) {
         p.chunk = ch;
         p.rows.clear();
         p.slot = -1;
+        p.identity = n_skip == 0;
         // pack the sample barcodes: concatenation of all B segments in input order (demux.rs:121-123)
         size_t stride = (fixed_barcode_len + 3) / 4 * 4;
         if (variable_barcode) {
@@ -701,25 +754,60 @@ int main(int argc, char **argv) {
         if (stride == 0) stride = 4;
         ensure_slot(sb[slot], ch->n, stride);
         size_t row = 0;
-        for (size_t j = 0; j < ch->n; ++j) {
-            if (ch->skip[j]) { ++skipped; continue; }
-            uint8_t *dst = sb[slot].obs + row * stride;
-            size_t len = 0;
-            for (const SegRef &r : plan.by_type[1]) {
-                const RecBatch &b = *ch->batches[r.input];
-                size_t lo, hi;
-                segment_span(plan.rs[r.input].segments[r.seg], b.recs[j].seq_len, &lo, &hi);
-                std::memcpy(dst + len, b.seq(j) + lo, hi - lo);
-                len += hi - lo;
+        if (!variable_barcode) {
+            // fixed layout: every row is the readers' pre-packed slices side by side, pad bytes zero
+            uint8_t *base = sb[slot].obs;
+            if (stride != fixed_barcode_len) std::memset(base, 0, (ch->n - n_skip) * stride);
+            for (size_t i = 0; i < n_inputs; ++i) {
+                const InputPack &ip = ipack[i];
+                if (!ip.width) continue;
+                const uint8_t *src = ch->batches[i]->bc.data();
+                uint8_t *dst = base + ip.col;
+                if (n_skip == 0) {
+                    if (ip.width == 8) {
+                        for (size_t j = 0; j < ch->n; ++j) std::memcpy(dst + j * stride, src + j * 8, 8);
+                    } else {
+                        for (size_t j = 0; j < ch->n; ++j) std::memcpy(dst + j * stride, src + j * ip.width, ip.width);
+                    }
+                } else {
+                    size_t rr = 0;
+                    for (size_t j = 0; j < ch->n; ++j) {
+                        if (ch->skip[j]) continue;
+                        std::memcpy(dst + rr * stride, src + j * ip.width, ip.width);
+                        ++rr;
+                    }
+                }
             }
-            std::memset(dst + len, 0, stride - len);
-            sb[slot].lens[row] = (uint32_t)len;
-            p.rows.push_back((uint32_t)j);
-            ++row;
+            row = ch->n - n_skip;
+            if (n_skip)
+                for (size_t j = 0; j < ch->n; ++j) if (!ch->skip[j]) p.rows.push_back((uint32_t)j);
+        } else {
+            for (size_t j = 0; j < ch->n; ++j) {
+                if (ch->skip[j]) continue;
+                uint8_t *dst = sb[slot].obs + row * stride;
+                size_t len = 0;
+                for (const SegRef &r : plan.by_type[1]) {
+                    const RecBatch &b = *ch->batches[r.input];
+                    size_t lo, hi;
+                    segment_span(plan.rs[r.input].segments[r.seg], b.recs[j].seq_len, &lo, &hi);
+                    std::memcpy(dst + len, b.seq(j) + lo, hi - lo);
+                    len += hi - lo;
+                }
+                std::memset(dst + len, 0, stride - len);
+                sb[slot].lens[row] = (uint32_t)len;
+                p.rows.push_back((uint32_t)j);
+                ++row;
+            }
+            p.identity = false;
         }
+        skipped += n_skip;
+        p.n_rows = row;
         total_templates += row;
         if (row > 0) {
+            // read structures whose B segments do not add up to the expected barcode length: the length rules
+            // decide (shorter -> unmatched, longer -> the reference's panic), so the lengths must travel
             const bool need_lens = variable_barcode || fixed_barcode_len != L;
+            if (!variable_barcode && need_lens) std::fill(sb[slot].lens, sb[slot].lens + row, (uint32_t)fixed_barcode_len);
             if (fqtk_matcher_enqueue(matchers[slot % G], slot / (int)G, sb[slot].obs, (uint32_t)stride, need_lens ? sb[slot].lens : nullptr, row,
                                      sb[slot].out) != FQTK_OK)
                 die(fqtk_last_error());

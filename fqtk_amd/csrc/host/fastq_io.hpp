@@ -3,18 +3,33 @@
 // SURVEY.md section 8(f) row 3 (input side).  The reference reads through fgoxide's Io::new_reader
 // (gz-aware, 1 MiB buffer; /root/reference/src/bin/commands/demux.rs:844-849) and seq_io's
 // fastq::Reader (demux.rs:16-17,289-294,891): four-line records, `head` = line 1 without '@'.
-// zlib's gzread transparently handles plain files, gzip, multi-member gzip and BGZF.
+// Three byte sources behind one interface, chosen by looking at the file (not at its name):
+//   plain text      read(2) straight into the piece buffer
+//   gzip            zlib inflate (gzread: single- and multi-member streams); one stream cannot be split
+//   BGZF            independent <= 64 KiB members ('BC' extra field): a group of blocks is inflated IN PARALLEL
+//                   by a few helper threads (libdeflate through dlopen, zlib's inflate if it is absent)
+// In every case a producer thread runs ahead of the parser (bounded queue of 4 MiB pieces), so decompression
+// and record parsing overlap -- the reference gets the same from fgoxide's read-ahead (demux.rs:928-934).
 // Unpinned by the reference's tests (choices here): a trailing '\r' is stripped from every line;
 // multi-line FASTQ is not supported (seq_io's fastq reader does not support it either).
 #pragma once
+#include <dlfcn.h>
+#include <fcntl.h>
+#include <unistd.h>
 #include <zlib.h>
 
 #include <algorithm>
+#include <atomic>
+#include <condition_variable>
 #include <cstdint>
+#include <cstdlib>
 #include <cstring>
+#include <deque>
 #include <memory>
+#include <mutex>
 #include <string>
 #include <string_view>
+#include <thread>
 #include <vector>
 
 namespace fqtk_host {
@@ -28,27 +43,113 @@ struct FastqRec {
 struct RecBatch {
     std::vector<char> data;
     std::vector<FastqRec> recs;
+    // filled by the demux reader threads (not by the parser): reads shorter than the read structure needs,
+    // and this input's fixed-length sample-barcode segments, packed side by side (one row per record)
+    std::vector<uint8_t> too_short, bc;
+    size_t n_short = 0;
     const char *head(size_t i) const { return data.data() + recs[i].head_off; }
     const char *seq(size_t i) const { return data.data() + recs[i].seq_off; }
     const char *qual(size_t i) const { return data.data() + recs[i].qual_off; }
 };
 
+// libdeflate's decompressor, bound at run time (the image ships libdeflate.so.0 without its header).
+struct LibInflate {
+    bool ok = false;
+    void *(*alloc)() = nullptr;
+    int (*run)(void *, const void *, size_t, void *, size_t, size_t *) = nullptr;
+    void (*free_)(void *) = nullptr;
+    static const LibInflate &get() {
+        static const LibInflate l = [] {
+            LibInflate x;
+            if (std::getenv("FQTK_NO_LIBDEFLATE")) return x;
+            void *h = dlopen("libdeflate.so.0", RTLD_NOW | RTLD_LOCAL);
+            if (!h) h = dlopen("libdeflate.so", RTLD_NOW | RTLD_LOCAL);
+            if (!h) return x;
+            x.alloc = reinterpret_cast<void *(*)()>(dlsym(h, "libdeflate_alloc_decompressor"));
+            x.run = reinterpret_cast<int (*)(void *, const void *, size_t, void *, size_t, size_t *)>(dlsym(h, "libdeflate_deflate_decompress"));
+            x.free_ = reinterpret_cast<void (*)(void *)>(dlsym(h, "libdeflate_free_decompressor"));
+            x.ok = x.alloc && x.run && x.free_;
+            return x;
+        }();
+        return l;
+    }
+};
+
+// Raw DEFLATE payload of one BGZF member -> out (exactly out_len bytes).  Per-thread state.
+class BlockInflater {
+  public:
+    BlockInflater() { if (LibInflate::get().ok) d_ = LibInflate::get().alloc(); }
+    ~BlockInflater() { if (d_) LibInflate::get().free_(d_); }
+    BlockInflater(const BlockInflater &) = delete;
+    BlockInflater &operator=(const BlockInflater &) = delete;
+    bool inflate_block(const uint8_t *in, size_t in_len, uint8_t *out, size_t out_len) {
+        if (d_) {
+            size_t got = 0;
+            return LibInflate::get().run(d_, in, in_len, out, out_len, &got) == 0 && got == out_len;
+        }
+        z_stream zs;
+        std::memset(&zs, 0, sizeof zs);
+        if (inflateInit2(&zs, -15) != Z_OK) return false;
+        zs.next_in = const_cast<Bytef *>(in);
+        zs.avail_in = (uInt)in_len;
+        zs.next_out = out;
+        zs.avail_out = (uInt)out_len;
+        const int rc = ::inflate(&zs, Z_FINISH);
+        const bool ok = rc == Z_STREAM_END && zs.total_out == out_len;
+        inflateEnd(&zs);
+        return ok;
+    }
+  private:
+    void *d_ = nullptr;
+};
+
 class FastqSource {
   public:
-    ~FastqSource() { if (gz_) gzclose(gz_); }
-    bool open(const std::string &path, std::string *err) {
-        gz_ = gzopen(path.c_str(), "rb");
-        if (!gz_) { *err = "Error opening input files for reading: " + path; return false; }
-        gzbuffer(gz_, 1 << 20);
+    enum class Kind { Plain, Gzip, Bgzf };
+    ~FastqSource() {
+        {
+            std::lock_guard<std::mutex> lk(mu_);
+            stop_ = true;
+        }
+        cv_space_.notify_all();
+        cv_work_.notify_all();
+        if (producer_.joinable()) producer_.join();
+        for (auto &t : helpers_) if (t.joinable()) t.join();
+        if (gz_) gzclose(gz_);
+        if (fd_ >= 0) ::close(fd_);
+    }
+    // inflate_helpers: extra threads that inflate BGZF blocks next to the producer (ignored for other kinds)
+    bool open(const std::string &path, std::string *err, unsigned inflate_helpers = 2) {
         path_ = path;
+        fd_ = ::open(path.c_str(), O_RDONLY);
+        if (fd_ < 0) { *err = "Error opening input files for reading: " + path; return false; }
+        uint8_t hdr[18];
+        const ssize_t n = ::pread(fd_, hdr, sizeof hdr, 0);
+        kind_ = Kind::Plain;
+        if (n >= 2 && hdr[0] == 0x1f && hdr[1] == 0x8b) {
+            kind_ = Kind::Gzip;
+            if (n == 18 && hdr[2] == 8 && (hdr[3] & 4) && hdr[10] == 6 && hdr[11] == 0 && hdr[12] == 'B' && hdr[13] == 'C' &&
+                hdr[14] == 2 && hdr[15] == 0)
+                kind_ = Kind::Bgzf;
+        }
+        if (kind_ == Kind::Gzip) {
+            gz_ = gzdopen(fd_, "rb");
+            if (!gz_) { *err = "Error opening input files for reading: " + path; return false; }
+            fd_ = -1;               // owned by gz_ now
+            gzbuffer(gz_, 1 << 20);
+        }
+        n_helpers_ = kind_ == Kind::Bgzf ? inflate_helpers : 0;
         return true;
     }
+    Kind kind() const { return kind_; }
+
     // Reads up to max_records records.  Returns false on a malformed file (*err set).  An empty batch = EOF.
     //
-    // Parsed IN PLACE: gzread fills the batch's own data vector, lines are located with memchr and a
+    // Parsed IN PLACE: pieces are appended to the batch's own data vector, lines are located with memchr and a
     // record is four (offset, length) pairs into that vector -- no per-record copy.  Bytes read past the
-    // last record of this batch (at most one read piece) are carried into the next batch.
+    // last record of this batch (at most one piece) are carried into the next batch.
     bool next_batch(size_t max_records, RecBatch *out, std::string *err) {
+        if (!producer_.joinable()) start();
         out->recs.clear();
         out->recs.reserve(std::min<size_t>(max_records, 1u << 20));
         std::vector<char> &d = out->data;
@@ -124,26 +225,199 @@ class FastqSource {
     }
 
   private:
+    static constexpr size_t kPiece = 4u << 20;
+    struct Piece { std::vector<char> data; std::string error; bool eof = false; };
+
+    // consumer side: next piece from the producer's queue
     bool fill(std::vector<char> &d, std::string *err) {
-        const size_t piece = 4u << 20;
-        const size_t old = d.size();
-        d.resize(old + piece);
-        int n = gzread(gz_, d.data() + old, (unsigned)piece);
-        if (n < 0) {
-            int e = 0;
-            *err = std::string("Unexpected error parsing FASTQs: ") + gzerror(gz_, &e) + " in " + path_;
-            return false;
+        Piece pc;
+        {
+            std::unique_lock<std::mutex> lk(mu_);
+            cv_data_.wait(lk, [&] { return !q_.empty(); });
+            pc = std::move(q_.front());
+            q_.pop_front();
         }
-        if (n == 0) eof_ = true;
-        d.resize(old + (size_t)n);
+        cv_space_.notify_one();
+        if (!pc.error.empty()) { *err = pc.error; return false; }
+        if (pc.eof) { eof_ = true; return true; }
+        d.insert(d.end(), pc.data.begin(), pc.data.end());
+        {
+            std::lock_guard<std::mutex> lk(mu_);
+            if (spare_.size() < 8) spare_.push_back(std::move(pc.data));   // piece buffers go round
+        }
         return true;
     }
+    void push(Piece &&pc) {
+        std::unique_lock<std::mutex> lk(mu_);
+        cv_space_.wait(lk, [&] { return q_.size() < 4 || stop_; });
+        if (stop_) return;
+        q_.push_back(std::move(pc));
+        cv_data_.notify_one();
+    }
+    std::vector<char> buffer() {
+        std::lock_guard<std::mutex> lk(mu_);
+        if (spare_.empty()) return {};
+        std::vector<char> b = std::move(spare_.back());
+        spare_.pop_back();
+        return b;
+    }
+    void start() {
+        for (unsigned h = 0; h < n_helpers_; ++h) helpers_.emplace_back([this] { helper_loop(); });
+        producer_ = std::thread([this] {
+            for (;;) {
+                Piece pc;
+                pc.data = buffer();
+                bool more = kind_ == Kind::Plain ? produce_plain(pc) : (kind_ == Kind::Gzip ? produce_gzip(pc) : produce_bgzf(pc));
+                const bool last = !more || !pc.error.empty() || pc.eof;
+                push(std::move(pc));
+                {
+                    std::lock_guard<std::mutex> lk(mu_);
+                    if (stop_) return;
+                }
+                if (last) return;
+            }
+        });
+    }
+    bool produce_plain(Piece &pc) {
+        pc.data.resize(kPiece);
+        const ssize_t n = ::read(fd_, pc.data.data(), kPiece);
+        if (n < 0) { pc.error = "Unexpected error parsing FASTQs: read failed in " + path_; return false; }
+        if (n == 0) { pc.eof = true; return false; }
+        pc.data.resize((size_t)n);
+        return true;
+    }
+    bool produce_gzip(Piece &pc) {
+        pc.data.resize(kPiece);
+        const int n = gzread(gz_, pc.data.data(), (unsigned)kPiece);
+        if (n < 0) {
+            int e = 0;
+            pc.error = std::string("Unexpected error parsing FASTQs: ") + gzerror(gz_, &e) + " in " + path_;
+            return false;
+        }
+        if (n == 0) { pc.eof = true; return false; }
+        pc.data.resize((size_t)n);
+        return true;
+    }
+    // ---- BGZF: read a group of whole members, inflate them in parallel into one piece --------------------
+    struct Block { size_t in_off, in_len, out_off, out_len; };
+    bool produce_bgzf(Piece &pc) {
+        // top the compressed buffer up, then cut it at member boundaries (header: 18 bytes, BSIZE at 16)
+        if (!craw_eof_ && craw_.size() - cpos_ < kPiece) {
+            craw_.erase(craw_.begin(), craw_.begin() + (std::ptrdiff_t)cpos_);
+            cpos_ = 0;
+            const size_t old = craw_.size();
+            craw_.resize(old + kPiece);
+            const ssize_t n = ::read(fd_, craw_.data() + old, kPiece);
+            if (n < 0) { pc.error = "Unexpected error parsing FASTQs: read failed in " + path_; return false; }
+            craw_.resize(old + (size_t)std::max<ssize_t>(n, 0));
+            if (n == 0) craw_eof_ = true;
+        }
+        blocks_.clear();
+        size_t p = cpos_, out_total = 0;
+        while (p + 18 <= craw_.size() && out_total < kPiece) {
+            const uint8_t *h = craw_.data() + p;
+            if (h[0] != 0x1f || h[1] != 0x8b || h[12] != 'B' || h[13] != 'C') {
+                pc.error = "Unexpected error parsing FASTQs: not a BGZF member at compressed offset in " + path_;
+                return false;
+            }
+            const size_t bsize = (size_t)h[16] + ((size_t)h[17] << 8) + 1;
+            if (bsize < 26) { pc.error = "Unexpected error parsing FASTQs: bad BGZF block size in " + path_; return false; }
+            if (p + bsize > craw_.size()) break;
+            const uint8_t *t = h + bsize - 4;
+            const size_t isize = (size_t)t[0] | ((size_t)t[1] << 8) | ((size_t)t[2] << 16) | ((size_t)t[3] << 24);
+            blocks_.push_back(Block{p + 18, bsize - 26, out_total, isize});
+            out_total += isize;
+            p += bsize;
+        }
+        if (blocks_.empty()) {
+            if (craw_eof_) {
+                if (cpos_ != craw_.size()) { pc.error = "Unexpected error parsing FASTQs: truncated BGZF member at end of " + path_; return false; }
+                pc.eof = true;
+                return false;
+            }
+            return true;   // a member larger than what is buffered: read more next round (empty piece)
+        }
+        cpos_ = p;
+        pc.data.resize(out_total);
+        // fan the blocks out: helpers and this thread claim them one by one
+        {
+            std::lock_guard<std::mutex> lk(mu_);
+            job_out_ = reinterpret_cast<uint8_t *>(pc.data.data());
+            job_next_.store(0);
+            job_done_ = 0;
+            job_failed_ = false;
+            job_size_.store(blocks_.size());   // opens the job: blocks_, craw_ and job_out_ are frozen until it closes
+            ++job_epoch_;
+        }
+        cv_work_.notify_all();
+        work(own_inflater_);
+        {
+            std::unique_lock<std::mutex> lk(mu_);
+            cv_done_.wait(lk, [&] { return job_done_ == blocks_.size(); });
+            job_size_.store(0);                // closed: a helper that wakes late claims nothing
+            if (job_failed_) { pc.error = "Unexpected error parsing FASTQs: corrupt BGZF block in " + path_; return false; }
+        }
+        return true;
+    }
+    void work(BlockInflater &inf) {
+        size_t done = 0;
+        bool failed = false;
+        for (;;) {
+            const size_t i = job_next_.fetch_add(1);
+            if (i >= job_size_.load()) break;
+            const Block &b = blocks_[i];
+            if (!inf.inflate_block(craw_.data() + b.in_off, b.in_len, job_out_ + b.out_off, b.out_len)) failed = true;
+            ++done;
+        }
+        if (done || failed) {
+            std::lock_guard<std::mutex> lk(mu_);
+            job_done_ += done;
+            job_failed_ = job_failed_ || failed;
+            cv_done_.notify_all();
+        }
+    }
+    void helper_loop() {
+        BlockInflater inf;
+        uint64_t seen = 0;
+        for (;;) {
+            {
+                std::unique_lock<std::mutex> lk(mu_);
+                cv_work_.wait(lk, [&] { return stop_ || job_epoch_ != seen; });
+                if (stop_) return;
+                seen = job_epoch_;
+            }
+            work(inf);
+        }
+    }
+
+    Kind kind_ = Kind::Plain;
     gzFile gz_ = nullptr;
+    int fd_ = -1;
     std::string path_;
     std::vector<char> carry_;
     size_t cap_hint_ = 8u << 20;
     bool eof_ = false;
     uint64_t nrec_ = 0;
+    // producer / consumer
+    std::thread producer_;
+    std::mutex mu_;
+    std::condition_variable cv_data_, cv_space_, cv_work_, cv_done_;
+    std::deque<Piece> q_;
+    std::vector<std::vector<char>> spare_;
+    bool stop_ = false;
+    // BGZF group state
+    unsigned n_helpers_ = 0;
+    std::vector<std::thread> helpers_;
+    std::vector<uint8_t> craw_;
+    size_t cpos_ = 0;
+    bool craw_eof_ = false;
+    std::vector<Block> blocks_;
+    BlockInflater own_inflater_;
+    uint8_t *job_out_ = nullptr;
+    std::atomic<size_t> job_next_{0}, job_size_{0};
+    size_t job_done_ = 0;
+    bool job_failed_ = false;
+    uint64_t job_epoch_ = 0;
 };
 
 }  // namespace fqtk_host

@@ -89,6 +89,35 @@ int64_t fqtk_host_parse_fastq(const char *path, uint64_t batch, char *out, size_
     return n;
 }
 
+// Parses a whole file and folds every record (head, seq, qual) into a 64-bit FNV-1a digest: lets the tests
+// compare large plain / gzip / BGZF inputs without shipping the text back.  kind: 0 plain, 1 gzip, 2 BGZF.
+int64_t fqtk_host_fastq_digest(const char *path, uint64_t batch, uint32_t inflate_helpers, uint64_t *digest, int *kind,
+                               char *err, size_t errcap) {
+    FastqSource src;
+    std::string e;
+    if (!src.open(path, &e, inflate_helpers)) { put(e, err, errcap); return -1; }
+    *kind = (int)src.kind();
+    uint64_t h = 1469598103934665603ull;
+    auto fold = [&](const char *p, size_t n) {
+        for (size_t i = 0; i < n; ++i) { h ^= (uint8_t)p[i]; h *= 1099511628211ull; }
+        h ^= 0xFF; h *= 1099511628211ull;
+    };
+    int64_t n = 0;
+    for (;;) {
+        RecBatch b;
+        if (!src.next_batch((size_t)batch, &b, &e)) { put(e, err, errcap); return -1; }
+        if (b.recs.empty()) break;
+        for (size_t i = 0; i < b.recs.size(); ++i) {
+            fold(b.head(i), b.recs[i].head_len);
+            fold(b.seq(i), b.recs[i].seq_len);
+            fold(b.qual(i), b.recs[i].seq_len);
+            ++n;
+        }
+    }
+    *digest = h;
+    return n;
+}
+
 // BGZF-compresses a whole buffer (blocks of kBgzfBlockSize + EOF marker).
 int fqtk_host_bgzf(const uint8_t *in, size_t n, int level, uint8_t *out, size_t cap, size_t *out_len) {
     std::vector<uint8_t> o;

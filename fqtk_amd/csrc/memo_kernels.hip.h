@@ -138,7 +138,8 @@ __device__ __forceinline__ void wave_scan(const Planes<NW> &mine, int src, const
 // ABL: developer-only ablation mask (tools/ablate.sh builds with -DFQTK_DEV_ABLATE); 0 in the product.
 //   1 = skip table probes, 2 = skip the canonical-byte validation, 4 = skip histogram,
 //   8 = skip result store, 16 = skip the LDS hot table, 32 = fold the global probes into 4 KB (L1 hits),
-//   64 = skip the second (spill) probe, 128 = second probe goes to the first probe's neighbour slot
+//   64 = skip the second (spill) probe, 128 = second probe goes to the first probe's neighbour slot,
+//   256 = skip the cuckoo table (direct form: reads with an N come out None)
 // Workgroup of the table-form kernel: 1024 lanes, two per CU, so that the LDS hot table can be 64 KiB
 // instead of 16 KiB at the same 32 waves/CU.  Measured (tools/ab_memo_block.sh): 768 samples x 16 bases
 // 114 -> 168 G reads/s, 1536 x 10 152 -> 213, cfg 5 82 -> 120; tables whose exact-match entries already
@@ -314,7 +315,7 @@ void memo_kernel(const MemoParams Q) {
 #pragma unroll
             for (int r = 0; r < R; ++r) {
                 again[r] = false;
-                if (!hit[r] && has_n[r]) {
+                if (!hit[r] && has_n[r] && !(ABL & 256)) {
                     if constexpr (KW >= 2) {
                         const uint4 e = reinterpret_cast<const uint4 *>(Q.slots)[g1[r]];
                         if (e.x == lo[r] && e.y == hi[r] && (KW < 3 || (e.w >> 16) == ext[r])) res[r] = e.z;

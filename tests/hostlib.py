@@ -66,6 +66,18 @@ def parse_fastq(path, batch=1000):
     return recs
 
 
+def fastq_digest(path, batch=50_000, helpers=2):
+    """(records, 64-bit digest of every record, kind) -- kind 0 plain, 1 gzip, 2 BGZF (block-parallel inflate)."""
+    err = C.create_string_buffer(512)
+    dig, kind = C.c_uint64(0), C.c_int(-1)
+    fn = lib().fqtk_host_fastq_digest
+    fn.restype = C.c_int64
+    n = fn(str(path).encode(), C.c_uint64(batch), C.c_uint32(helpers), C.byref(dig), C.byref(kind), err, C.c_size_t(512))
+    if n < 0:
+        raise ValueError(err.value.decode())
+    return int(n), int(dig.value), int(kind.value)
+
+
 def bgzf(data: bytes, level=5) -> bytes:
     cap = len(data) + len(data) // 8 + 65536
     out = (C.c_uint8 * cap)()

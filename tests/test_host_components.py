@@ -219,3 +219,40 @@ def test_cli_rejects_bad_flags_before_touching_anything(tmp_path):
     assert r.returncode != 0 and "Error parsing segment types to report" in r.stderr
     r = H.run_demux([r1, i1], ["+T", "+B"], meta, tmp_path / "out", max_mismatches=300)
     assert r.returncode != 0 and "out of range integral type conversion" in r.stderr
+
+
+def test_large_inputs_plain_gzip_multimember_and_bgzf_block_parallel_agree(tmp_path):
+    """The three byte sources of the FASTQ reader (read(2), zlib stream, BGZF blocks inflated in parallel by
+    helper threads) deliver the same records; a corrupt or truncated BGZF member is an error, not silence."""
+    import gzip
+    import numpy as np
+    rng = np.random.default_rng(3)
+    n = 120_000
+    seqs = np.frombuffer(b"ACGTN", dtype=np.uint8)[rng.integers(0, 5, size=(n, 60))]
+    text = b"".join(b"@r%d 1:N:0:AC\n%s\n+\n%s\n" % (i, seqs[i].tobytes(), b"I" * 60) for i in range(n))
+    plain = tmp_path / "big.fastq"
+    plain.write_bytes(text)
+    gz = tmp_path / "big.fastq.gz"
+    gz.write_bytes(gzip.compress(text, 1))
+    multi = tmp_path / "multi.fastq.gz"
+    cut = [0, len(text) // 3, len(text) // 2, len(text)]
+    multi.write_bytes(b"".join(gzip.compress(text[a:b], 1) for a, b in zip(cut, cut[1:])))
+    bg = tmp_path / "big.bgzf.fastq.gz"
+    blob = H.bgzf(text, 1)
+    bg.write_bytes(blob)
+    want = H.fastq_digest(plain)
+    assert want[0] == n and want[2] == 0
+    assert H.fastq_digest(gz)[:2] == want[:2] and H.fastq_digest(gz)[2] == 1
+    assert H.fastq_digest(multi)[:2] == want[:2]
+    for helpers in (0, 1, 3):
+        for batch in (1000, 50_000):
+            got = H.fastq_digest(bg, batch=batch, helpers=helpers)
+            assert got[:2] == want[:2] and got[2] == 2, (helpers, batch)
+    bad = bytearray(blob)
+    bad[len(blob) // 2] ^= 0x55                       # somewhere inside a deflate payload / trailer
+    (tmp_path / "bad.gz").write_bytes(bytes(bad))
+    with pytest.raises(ValueError):
+        H.fastq_digest(tmp_path / "bad.gz")
+    (tmp_path / "cut.gz").write_bytes(blob[:len(blob) // 2])
+    with pytest.raises(ValueError):
+        H.fastq_digest(tmp_path / "cut.gz")

@@ -87,6 +87,24 @@ def fixed_fastq(path, start, n, seqs, read_no, append):
         fh.write(rec.tobytes())
 
 
+def bgzf_file(path, level=1):
+    """path -> path.gz as BGZF (blocks of 65280 bytes + EOF marker) through the host shim's block compressor."""
+    lib = C.CDLL(os.path.join(ROOT, "fqtk_amd", "lib", "libfqtk_host.so"))
+    with open(path, "rb") as fi, open(path + ".gz", "wb") as fo:
+        while True:
+            data = fi.read(64 * 65280)
+            if not data:
+                break
+            cap = len(data) + len(data) // 8 + 65536
+            out = (C.c_uint8 * cap)()
+            n = C.c_size_t()
+            assert lib.fqtk_host_bgzf(data, C.c_size_t(len(data)), level, out, C.c_size_t(cap), C.byref(n)) == 0
+            fo.write(bytes(out[:n.value - 28]))          # drop the per-call EOF marker
+        fo.write(bytes([0x1f, 0x8b, 0x08, 0x04, 0, 0, 0, 0, 0, 0xff, 0x06, 0, 0x42, 0x43, 0x02, 0, 0x1b, 0, 0x03, 0, 0, 0, 0, 0, 0, 0, 0, 0]))
+    os.unlink(path)
+    return path + ".gz"
+
+
 def make_inputs(tmp, n, gz, block=1_000_000):
     """cfg 3's shape as files: R1 150T, I1 8B, I2 8B, R2 150T; barcodes from the same synthetic stream as
     scopes K/B; template bases are one random 1 M x 150 block reused per block (names differ)."""
@@ -105,7 +123,11 @@ def make_inputs(tmp, n, gz, block=1_000_000):
         fixed_fastq(paths[1], lo, cur, bcs[:, :8], 1, lo > 0)
         fixed_fastq(paths[2], lo, cur, bcs[:, 8:16], 2, lo > 0)
         fixed_fastq(paths[3], lo, cur, t2[:cur], 2, lo > 0)
-    if gz:
+    if gz == "bgzf":
+        from concurrent.futures import ThreadPoolExecutor
+        with ThreadPoolExecutor(4) as ex:
+            paths = list(ex.map(bgzf_file, paths))
+    elif gz:
         procs = [subprocess.Popen(["gzip", "-1", "-f", p]) for p in paths]
         assert all(p.wait() == 0 for p in procs)
         paths = [p + ".gz" for p in paths]
@@ -134,6 +156,8 @@ def scope_e(n, threads, gz, tmp, expect_counts=None, extra_args=()):
     out_files = os.listdir(out)
     out_bytes = sum(os.path.getsize(os.path.join(out, f)) for f in out_files)
     stage = [ln.split("fqtk] ", 1)[1] for ln in r.stderr.splitlines() if "thread-seconds" in ln or "main thread" in ln]
+    timeline = [ln.strip() for ln in r.stderr.splitlines() if "INFO fqtk" in ln and "demultiplexed" not in ln
+                and "thread-seconds" not in ln and "main thread" not in ln and "submit:" not in ln]
     return {"what": "fqtk_amd/bin/fqtk demux, files -> files (gunzip/parse -> GPU match -> BGZF), "
                     "as Demux::execute demux.rs:881-1001",
             "workload": "cfg3 shape: R1 150T, I1 8B, I2 8B, R2 150T; 384 samples", "templates": n, "threads": threads,
@@ -141,7 +165,8 @@ def scope_e(n, threads, gz, tmp, expect_counts=None, extra_args=()):
             "M_input_records_per_s": round(4 * n / dt / 1e6, 3),
             "input_MB": round(in_bytes / 1e6, 1), "output_MB": round(out_bytes / 1e6, 1), "output_files": len(out_files),
             "files_on": tmp, "host_cores": os.cpu_count(),
-            "metrics_vs_oracle": None if expect_counts is None else "per-sample counts identical", "stages": stage}
+            "metrics_vs_oracle": None if expect_counts is None else "per-sample counts identical", "stages": stage,
+            "timeline": timeline}
 
 
 def scratch_dir(need_bytes):
@@ -160,14 +185,16 @@ if __name__ == "__main__":
     ap.add_argument("--templates", type=int, default=4_000_000)
     ap.add_argument("--threads", type=int, default=32)
     ap.add_argument("--gz", action="store_true")
+    ap.add_argument("--bgzf", action="store_true", help="BGZF-compress the inputs (block-parallel inflate in the reader)")
     ap.add_argument("--skip-b", action="store_true")
+    ap.add_argument("--extra", default="", help="extra arguments for fqtk demux, space separated")
     a = ap.parse_args()
     res = {}
     if not a.skip_b:
         res["B"] = scope_b()
     tmp = scratch_dir(a.templates * 1100)
     try:
-        res["E"] = scope_e(a.templates, a.threads, a.gz, tmp)
+        res["E"] = scope_e(a.templates, a.threads, "bgzf" if a.bgzf else a.gz, tmp, extra_args=tuple(a.extra.split()))
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
     print(json.dumps(res))
