@@ -7,7 +7,7 @@ import os
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "lib", "libfqtk_match.so")
 
-FQTK_OK, FQTK_EINVAL, FQTK_ELEN, FQTK_EHIP, FQTK_ENOMEM, FQTK_ENODEV = 0, 1, 2, 3, 4, 5
+FQTK_OK, FQTK_EINVAL, FQTK_ELEN, FQTK_EHIP, FQTK_ENOMEM, FQTK_ENODEV, FQTK_ENCCL = 0, 1, 2, 3, 4, 5, 6
 FQTK_NO_MATCH = 0xFFFF
 FQTK_MAX_SLOTS = 8
 
@@ -71,6 +71,7 @@ SIGNATURES = [
                                        C.c_uint64, C.c_void_p]),
     ("fqtk_matcher_wait", C.c_int, [C.c_void_p, C.c_int]),
     ("fqtk_matcher_counts", C.c_int, [C.c_void_p, C.c_void_p]),
+    ("fqtk_matchers_allreduce_counts", C.c_int, [C.POINTER(C.c_void_p), C.c_int, C.c_int, C.c_void_p]),
 ]
 
 

@@ -4,6 +4,7 @@
 // (/root/reference/src/lib/barcode_matching.rs:29-186).  No CPU compute path exists here: table
 // preparation is host work (once per run, as in BarcodeMatcher::new :55-86); every assign goes to
 // the device.
+#include <dlfcn.h>
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
@@ -219,24 +220,24 @@ int launch_memo_vec(const fqtk_matcher *m, const fqtk::MemoParams &Q, hipStream_
             else if (sw == 5) vec = 5;
         }
     }
-    // reads per lane: 4 on the vector-load paths (every such variant stays inside 64 VGPRs = 8
-    // waves/SIMD with no scratch, hipcc -Rpass-analysis=kernel-resource-usage; measured +3-5 % over 2
-    // on cfg 2/3/4), 2 there for very large tables, where more probes in flight only add cache
-    // pressure, and 1 on the generic paths (4 would spill)
-    const int direct_form = (KW == 1 && Q.direct) ? m->direct_bytes : 0;
-    int R = vec > 0 ? ((m->memo_entries <= 65536 || direct_form) ? 4 : 2) : 1;
-    if (vec == 5) R = 2;   // 20-byte reads: 4 per lane would spill at 64 VGPRs
-    if (P.lens) R = 1;
-    if (R != 1 && R != 2 && R != 4) R = 1;
+    // One read per lane.  The packed vector paths run their full tiles software-pipelined one tile deep
+    // (current + prefetched words + held result stay inside 64 VGPRs = 8 waves/SIMD with no scratch: hipcc
+    // -Rpass-analysis=kernel-resource-usage; two reads per lane pipelined would spill 28-60 bytes per lane);
+    // with 32 waves per CU the gathers of 2048 reads are in flight per CU, which is all the parallelism
+    // the L2 round trip needs.
+    const int direct = (KW == 1 && Q.direct) ? m->direct_bytes : 0;
+    int R = 1;
     int abl = 0;
+    bool pf = vec > 0 && !P.lens;
 #ifdef FQTK_DEV_ABLATE
-    if (const char *rr = std::getenv("FQTK_MEMO_R")) R = std::atoi(rr);
+    if (!P.lens && vec > 0)
+        if (const char *rr = std::getenv("FQTK_MEMO_R")) R = std::atoi(rr);
     if (const char *ab = std::getenv("FQTK_MEMO_ABLATE")) abl = std::atoi(ab);
+    pf = pf && R <= 2 && !env_flag("FQTK_MEMO_NOPF");
     size_t lds_pad = 0;   // occupancy experiments: pad the workgroup's LDS so fewer fit on a CU
     if (const char *lp = std::getenv("FQTK_MEMO_LDS_PAD")) lds_pad = (size_t)std::atol(lp);
 #endif
     size_t shmem = 256 * sizeof(uint32_t);
-    const int direct = (KW == 1 && Q.direct) ? m->direct_bytes : 0;
     if (direct) shmem += Q.hot2 ? ((size_t)8 << Q.hot2_bits) : 0;
     else if (Q.hot_mask) shmem += (size_t)(Q.hot_mask + 1) * (KW >= 2 ? 16 : 8);
     if (P.counts && P.lds_hist) shmem += (size_t)(P.S + 1) * sizeof(uint32_t);
@@ -247,14 +248,14 @@ int launch_memo_vec(const fqtk_matcher *m, const fqtk::MemoParams &Q, hipStream_
     const uint64_t ntiles = (P.n + tile - 1) / tile;
     if (ntiles == 0) return FQTK_OK;
     const uint32_t grid = (uint32_t)std::min<uint64_t>(ntiles, (uint64_t)m->num_cus * (2048 / fqtk::kMemoBlock));
-    // the packed vector paths imply the key width (stride 16 B -> 2 key words, 12 B -> 1 or 2, 8/4 B -> 1)
-#define FQTK_MEMO_LAUNCH(V, RR, A) FQTK_MEMO_LAUNCH_L(V, RR, A, false)
-#define FQTK_MEMO_LAUNCH_L(V, RR, A, LENS) FQTK_MEMO_LAUNCH_D(V, RR, A, LENS, 0)
-#define FQTK_MEMO_LAUNCH_D(V, RR, A, LENS, D)                                                              \
+    // One launch; the `if constexpr` drops the (load width, key width, form) combinations that cannot occur:
+    // the packed vector paths imply the key width (stride 16 B -> 2 key words, 12 B -> 1 or 2, 8/4 B -> 1, 20 B -> 3)
+    // and the direct form exists for one-word keys only.
+#define FQTK_MEMO_LAUNCH_P(V, RR, A, LENS, D, PFV)                                                         \
     do {                                                                                                   \
         if constexpr (((V) <= 0 || ((V) == 3 && KW <= 2) || KW == ((V) == 5 ? 3 : ((V) == 4 ? 2 : 1))) && \
-                      ((D) == 0 || KW == 1)) {                                                             \
-            auto kern = fqtk::memo_kernel<V, KW, RR, A, LENS, D>;                                          \
+                      ((D) == 0 || (KW == 1 && (V) <= 3))) {                                               \
+            auto kern = fqtk::memo_kernel<V, KW, RR, A, LENS, D, PFV>;                                     \
             const void *fn = reinterpret_cast<const void *>(kern);                                         \
             if (shmem > 64 * 1024 &&                                                                       \
                 std::find(m->ldsm_big_lds_ok.begin(), m->ldsm_big_lds_ok.end(), fn) == m->ldsm_big_lds_ok.end()) { \
@@ -264,99 +265,83 @@ int launch_memo_vec(const fqtk_matcher *m, const fqtk::MemoParams &Q, hipStream_
             }                                                                                              \
             hipLaunchKernelGGL(kern, dim3(grid), dim3(fqtk::kMemoBlock), shmem, stream, Q);                \
         } else                                                                                             \
-            return fail(FQTK_EINVAL, "memo: load width and key width disagree");                           \
+            return fail(FQTK_EINVAL, "memo: load width, key width and table form disagree");               \
     } while (0)
-#define FQTK_MEMO_BY_VEC(RR, A)                         \
-    switch (vec) {                                      \
-        case 5: FQTK_MEMO_LAUNCH(5, RR, A); break;      \
-        case 4: FQTK_MEMO_LAUNCH(4, RR, A); break;      \
-        case 3: FQTK_MEMO_LAUNCH(3, RR, A); break;      \
-        case 2: FQTK_MEMO_LAUNCH(2, RR, A); break;      \
-        case 1: FQTK_MEMO_LAUNCH(1, RR, A); break;      \
-        case -1: FQTK_MEMO_LAUNCH(-1, RR, A); break;    \
-        default: FQTK_MEMO_LAUNCH(0, RR, A); break;     \
+    // every load path of one (reads per lane, ablation, lens, form, pipelined) combination
+#define FQTK_MEMO_ALL_VEC(RR, A, LENS, D, PFV)                          \
+    switch (vec) {                                                      \
+        case 5: FQTK_MEMO_LAUNCH_P(5, RR, A, LENS, D, PFV); break;      \
+        case 4: FQTK_MEMO_LAUNCH_P(4, RR, A, LENS, D, PFV); break;      \
+        case 3: FQTK_MEMO_LAUNCH_P(3, RR, A, LENS, D, PFV); break;      \
+        case 2: FQTK_MEMO_LAUNCH_P(2, RR, A, LENS, D, PFV); break;      \
+        case 1: FQTK_MEMO_LAUNCH_P(1, RR, A, LENS, D, PFV); break;      \
+        case -1: FQTK_MEMO_LAUNCH_P(-1, RR, A, LENS, D, PFV); break;    \
+        default: FQTK_MEMO_LAUNCH_P(0, RR, A, LENS, D, PFV); break;     \
     }
+    // packed paths only (vec > 0)
+#define FQTK_MEMO_PACKED(RR, A, D, PFV)                                 \
+    switch (vec) {                                                      \
+        case 5: FQTK_MEMO_LAUNCH_P(5, RR, A, false, D, PFV); break;     \
+        case 4: FQTK_MEMO_LAUNCH_P(4, RR, A, false, D, PFV); break;     \
+        case 3: FQTK_MEMO_LAUNCH_P(3, RR, A, false, D, PFV); break;     \
+        case 2: FQTK_MEMO_LAUNCH_P(2, RR, A, false, D, PFV); break;     \
+        default: FQTK_MEMO_LAUNCH_P(1, RR, A, false, D, PFV); break;    \
+    }
+#define FQTK_MEMO_BY_FORM(WHAT, ...)                                    \
+    do {                                                                \
+        if (direct == 2) { WHAT(__VA_ARGS__, 2); }                      \
+        else if (direct == 4) { WHAT(__VA_ARGS__, 4); }                 \
+        else { WHAT(__VA_ARGS__, 0); }                                  \
+    } while (0)
 #ifdef FQTK_DEV_ABLATE
-    if (abl > 0 && vec == 4) {
-        switch (abl * 10 + R) {   // NOLINT
-#define FQTK_AB(A, RR) case A * 10 + RR: FQTK_MEMO_LAUNCH(4, RR, A); break;
-            FQTK_AB(1, 1) FQTK_AB(2, 1) FQTK_AB(3, 1) FQTK_AB(4, 1) FQTK_AB(7, 1) FQTK_AB(16, 1) FQTK_AB(17, 1) FQTK_AB(19, 1) FQTK_AB(23, 1) FQTK_AB(32, 1) FQTK_AB(64, 1) FQTK_AB(128, 1)
-            FQTK_AB(1, 4) FQTK_AB(2, 4) FQTK_AB(3, 4) FQTK_AB(4, 4) FQTK_AB(7, 4) FQTK_AB(16, 4) FQTK_AB(17, 4) FQTK_AB(19, 4) FQTK_AB(23, 4) FQTK_AB(32, 4) FQTK_AB(64, 4) FQTK_AB(128, 4)
-#undef FQTK_AB
+    if (abl > 0 && !P.lens && (vec == 4 || (vec == 3 && direct == 2)) && R == 1) {   // ablations of the product shape
+#define FQTK_AB(A)                                                                                   \
+        case A:                                                                                      \
+            if (vec == 4) FQTK_MEMO_LAUNCH_P(4, 1, A, false, 0, true);                               \
+            else FQTK_MEMO_LAUNCH_P(3, 1, A, false, 2, true);                                        \
+            break;
+        switch (abl) {
+            FQTK_AB(1) FQTK_AB(2) FQTK_AB(4) FQTK_AB(8) FQTK_AB(16) FQTK_AB(17) FQTK_AB(32) FQTK_AB(64) FQTK_AB(128) FQTK_AB(256) FQTK_AB(272)
             default: return fail(FQTK_EINVAL, "ablation variant not built");
         }
+#undef FQTK_AB
+        HIP_TRY(hipGetLastError());
+        return FQTK_OK;
+    }
+    if (!P.lens && vec > 0 && (R != 1 || !pf)) {   // A/B of reads per lane and of the pipeline
+#define FQTK_X(RR, D) FQTK_MEMO_PACKED(RR, 0, D, false)
+#define FQTK_Y(RR, D) FQTK_MEMO_PACKED(RR, 0, D, true)
+        if (R == 4) FQTK_MEMO_BY_FORM(FQTK_X, 4);
+        else if (R == 2 && pf) FQTK_MEMO_BY_FORM(FQTK_Y, 2);
+        else if (R == 2) FQTK_MEMO_BY_FORM(FQTK_X, 2);
+        else FQTK_MEMO_BY_FORM(FQTK_X, 1);
+#undef FQTK_X
+#undef FQTK_Y
         HIP_TRY(hipGetLastError());
         return FQTK_OK;
     }
 #endif
-#ifdef FQTK_DEV_ABLATE
-    if (abl > 0 && direct == 2 && vec == 3 && !P.lens) {
-        switch (abl * 10 + R) {   // NOLINT
-#define FQTK_AB(A, RR) case A * 10 + RR: FQTK_MEMO_LAUNCH_D(3, RR, A, false, 2); break;
-            FQTK_AB(1, 4) FQTK_AB(4, 4) FQTK_AB(16, 4) FQTK_AB(17, 4) FQTK_AB(256, 4) FQTK_AB(2, 4) FQTK_AB(8, 4) FQTK_AB(272, 4)
-            FQTK_AB(1, 2) FQTK_AB(4, 2) FQTK_AB(16, 2) FQTK_AB(256, 2)
-#undef FQTK_AB
-            default: return fail(FQTK_EINVAL, "ablation variant not built");
-        }
-        HIP_TRY(hipGetLastError());
-        return FQTK_OK;
+    (void)abl;
+    (void)pf;
+    if (P.lens) {          // variable-length batch: one read per lane on every load path (the LENS instantiations)
+#define FQTK_X(D) FQTK_MEMO_ALL_VEC(1, 0, true, D, false)
+        if (direct == 2) { FQTK_X(2) } else if (direct == 4) { FQTK_X(4) } else { FQTK_X(0) }
+#undef FQTK_X
+    } else if (vec > 0) {  // packed rows: pipelined
+#define FQTK_X(D) FQTK_MEMO_PACKED(1, 0, D, true)
+        if (direct == 2) { FQTK_X(2) } else if (direct == 4) { FQTK_X(4) } else { FQTK_X(0) }
+#undef FQTK_X
+    } else {               // generic load paths: one read per lane
+#define FQTK_X(D)                                                       \
+        if (vec == -1) FQTK_MEMO_LAUNCH_P(-1, 1, 0, false, D, false);   \
+        else FQTK_MEMO_LAUNCH_P(0, 1, 0, false, D, false);
+        if (direct == 2) { FQTK_X(2) } else if (direct == 4) { FQTK_X(4) } else { FQTK_X(0) }
+#undef FQTK_X
     }
-#endif
-    if (direct) {   // barcodes of <= 10 bases: the direct-indexed form (KW == 1, so vec is 1, 2, 3, -1 or 0)
-#define FQTK_MEMO_DIRECT(D)                                                                       \
-        if (P.lens) {                                                                             \
-            switch (vec) {                                                                        \
-                case 3: FQTK_MEMO_LAUNCH_D(3, 1, 0, true, D); break;                              \
-                case 2: FQTK_MEMO_LAUNCH_D(2, 1, 0, true, D); break;                              \
-                case 1: FQTK_MEMO_LAUNCH_D(1, 1, 0, true, D); break;                              \
-                case -1: FQTK_MEMO_LAUNCH_D(-1, 1, 0, true, D); break;                            \
-                default: FQTK_MEMO_LAUNCH_D(0, 1, 0, true, D); break;                             \
-            }                                                                                     \
-        } else if (vec > 0 && R == 4) {                                                           \
-            switch (vec) {                                                                        \
-                case 3: FQTK_MEMO_LAUNCH_D(3, 4, 0, false, D); break;                             \
-                case 2: FQTK_MEMO_LAUNCH_D(2, 4, 0, false, D); break;                             \
-                default: FQTK_MEMO_LAUNCH_D(1, 4, 0, false, D); break;                            \
-            }                                                                                     \
-        } else if (vec > 0 && R == 2) {                                                           \
-            switch (vec) {                                                                        \
-                case 3: FQTK_MEMO_LAUNCH_D(3, 2, 0, false, D); break;                             \
-                case 2: FQTK_MEMO_LAUNCH_D(2, 2, 0, false, D); break;                             \
-                default: FQTK_MEMO_LAUNCH_D(1, 2, 0, false, D); break;                            \
-            }                                                                                     \
-        } else {                                                                                  \
-            switch (vec) {                                                                        \
-                case 3: FQTK_MEMO_LAUNCH_D(3, 1, 0, false, D); break;                             \
-                case 2: FQTK_MEMO_LAUNCH_D(2, 1, 0, false, D); break;                             \
-                case 1: FQTK_MEMO_LAUNCH_D(1, 1, 0, false, D); break;                             \
-                case -1: FQTK_MEMO_LAUNCH_D(-1, 1, 0, false, D); break;                           \
-                default: FQTK_MEMO_LAUNCH_D(0, 1, 0, false, D); break;                            \
-            }                                                                                     \
-        }
-        if (direct == 2) { FQTK_MEMO_DIRECT(2) } else { FQTK_MEMO_DIRECT(4) }
-#undef FQTK_MEMO_DIRECT
-    } else if (P.lens) {   // variable-length batch: one read per lane on every load path (the LENS instantiations)
-        switch (vec) {
-            case 5: FQTK_MEMO_LAUNCH_L(5, 1, 0, true); break;
-            case 4: FQTK_MEMO_LAUNCH_L(4, 1, 0, true); break;
-            case 3: FQTK_MEMO_LAUNCH_L(3, 1, 0, true); break;
-            case 2: FQTK_MEMO_LAUNCH_L(2, 1, 0, true); break;
-            case 1: FQTK_MEMO_LAUNCH_L(1, 1, 0, true); break;
-            case -1: FQTK_MEMO_LAUNCH_L(-1, 1, 0, true); break;
-            default: FQTK_MEMO_LAUNCH_L(0, 1, 0, true); break;
-        }
-    } else if (R == 4 && vec > 0) {
-        switch (vec) {
-            case 4: FQTK_MEMO_LAUNCH(4, 4, 0); break;
-            case 3: FQTK_MEMO_LAUNCH(3, 4, 0); break;
-            case 2: FQTK_MEMO_LAUNCH(2, 4, 0); break;
-            default: FQTK_MEMO_LAUNCH(1, 4, 0); break;
-        }
-    } else if (R >= 2) { FQTK_MEMO_BY_VEC(2, 0) } else { FQTK_MEMO_BY_VEC(1, 0) }
-#undef FQTK_MEMO_BY_VEC
-#undef FQTK_MEMO_LAUNCH
-#undef FQTK_MEMO_LAUNCH_L
-#undef FQTK_MEMO_LAUNCH_D
+#undef FQTK_MEMO_BY_FORM
+#undef FQTK_MEMO_PACKED
+#undef FQTK_MEMO_ALL_VEC
+#undef FQTK_MEMO_LAUNCH_P
     HIP_TRY(hipGetLastError());
     return FQTK_OK;
 }
@@ -1283,6 +1268,99 @@ int fqtk_pinned_alloc(size_t bytes, void **out) {
 int fqtk_pinned_free(void *p) {
     if (!p) return FQTK_OK;
     HIP_TRY(hipHostFree(p));
+    return FQTK_OK;
+}
+
+
+// ---- the one collective: per-sample counts over RCCL (single process, one communicator rank per device) ----
+namespace {
+struct Rccl {   // the six entry points used, bound at first use (libfqtk_match.so does not link RCCL)
+    bool ok = false;
+    std::string why;
+    int (*CommInitAll)(void **, int, const int *) = nullptr;
+    int (*CommDestroy)(void *) = nullptr;
+    int (*AllReduce)(const void *, void *, size_t, int, int, void *, hipStream_t) = nullptr;
+    int (*GroupStart)() = nullptr;
+    int (*GroupEnd)() = nullptr;
+    const char *(*GetErrorString)(int) = nullptr;
+    static const Rccl &get() {
+        static const Rccl r = [] {
+            Rccl x;
+            void *h = nullptr;
+            for (const char *name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"})
+                if ((h = dlopen(name, RTLD_NOW | RTLD_LOCAL))) break;
+            if (!h) { x.why = std::string("cannot load librccl: ") + dlerror(); return x; }
+            x.CommInitAll = reinterpret_cast<int (*)(void **, int, const int *)>(dlsym(h, "ncclCommInitAll"));
+            x.CommDestroy = reinterpret_cast<int (*)(void *)>(dlsym(h, "ncclCommDestroy"));
+            x.AllReduce = reinterpret_cast<int (*)(const void *, void *, size_t, int, int, void *, hipStream_t)>(dlsym(h, "ncclAllReduce"));
+            x.GroupStart = reinterpret_cast<int (*)()>(dlsym(h, "ncclGroupStart"));
+            x.GroupEnd = reinterpret_cast<int (*)()>(dlsym(h, "ncclGroupEnd"));
+            x.GetErrorString = reinterpret_cast<const char *(*)(int)>(dlsym(h, "ncclGetErrorString"));
+            x.ok = x.CommInitAll && x.CommDestroy && x.AllReduce && x.GroupStart && x.GroupEnd && x.GetErrorString;
+            if (!x.ok) x.why = "librccl lacks an expected symbol";
+            return x;
+        }();
+        return r;
+    }
+};
+constexpr int kNcclUint64 = 5, kNcclSum = 0;   // rccl.h: ncclDataType_t / ncclRedOp_t
+}  // namespace
+
+int fqtk_matchers_allreduce_counts(fqtk_matcher *const *ms, int n, int force_collective, uint64_t *counts) {
+    if (!ms || n <= 0 || !counts) return fail(FQTK_EINVAL, "NULL / empty argument");
+    for (int i = 0; i < n; ++i) {
+        if (!ms[i]) return fail(FQTK_EINVAL, "matcher is NULL");
+        if (ms[i]->S != ms[0]->S) return fail(FQTK_EINVAL, "matchers with different sample tables");
+        for (int j = 0; j < i; ++j)
+            if (ms[j]->device == ms[i]->device)
+                return fail(FQTK_EINVAL, "fqtk_matchers_allreduce_counts needs one matcher per DISTINCT device");
+    }
+    if (n == 1 && !force_collective) return fqtk_matcher_counts(ms[0], counts);
+    const Rccl &R = Rccl::get();
+    if (!R.ok) return fail(FQTK_ENCCL, R.why);
+    const size_t bins = (size_t)ms[0]->S + 1;
+    std::vector<int> devs(n);
+    std::vector<void *> comms(n, nullptr);
+    std::vector<hipStream_t> streams(n, nullptr);
+    std::vector<unsigned long long *> recv(n, nullptr);
+    for (int i = 0; i < n; ++i) devs[i] = ms[i]->device;
+    int rc = FQTK_OK;
+    auto nccl_fail = [&](int e, const char *what) { rc = fail(FQTK_ENCCL, std::string(what) + ": " + R.GetErrorString(e)); };
+    auto hip_fail = [&](hipError_t e, const char *what) { rc = fail(FQTK_EHIP, std::string(what) + ": " + hipGetErrorString(e)); };
+    int e = R.CommInitAll(comms.data(), n, devs.data());
+    if (e != 0) { nccl_fail(e, "ncclCommInitAll"); return rc; }
+    for (int i = 0; i < n && rc == FQTK_OK; ++i) {
+        hipError_t he = hipSetDevice(devs[i]);
+        if (he == hipSuccess) he = hipDeviceSynchronize();   // every chunk of every slot has been counted
+        if (he == hipSuccess) he = hipStreamCreateWithFlags(&streams[i], hipStreamNonBlocking);
+        if (he == hipSuccess) he = hipMalloc(reinterpret_cast<void **>(&recv[i]), bins * sizeof(unsigned long long));
+        if (he != hipSuccess) hip_fail(he, "preparing the count reduction");
+    }
+    if (rc == FQTK_OK) {
+        if ((e = R.GroupStart()) != 0) nccl_fail(e, "ncclGroupStart");
+        for (int i = 0; i < n && rc == FQTK_OK; ++i)
+            if ((e = R.AllReduce(ms[i]->d_counts, recv[i], bins, kNcclUint64, kNcclSum, comms[i], streams[i])) != 0)
+                nccl_fail(e, "ncclAllReduce");
+        if ((e = R.GroupEnd()) != 0 && rc == FQTK_OK) nccl_fail(e, "ncclGroupEnd");
+    }
+    std::vector<unsigned long long> total(bins, 0);
+    for (int i = 0; i < n && rc == FQTK_OK; ++i) {
+        hipError_t he = hipSetDevice(devs[i]);
+        if (he == hipSuccess) he = hipStreamSynchronize(streams[i]);
+        if (he == hipSuccess && i == 0)   // every rank holds the same sum: read rank 0's
+            he = hipMemcpy(total.data(), recv[0], bins * sizeof(unsigned long long), hipMemcpyDeviceToHost);
+        if (he == hipSuccess) he = hipMemset(ms[i]->d_counts, 0, bins * sizeof(unsigned long long));
+        if (he == hipSuccess) he = hipDeviceSynchronize();
+        if (he != hipSuccess) hip_fail(he, "finishing the count reduction");
+    }
+    for (int i = 0; i < n; ++i) {
+        (void)hipSetDevice(devs[i]);
+        if (recv[i]) (void)hipFree(recv[i]);
+        if (streams[i]) (void)hipStreamDestroy(streams[i]);
+        if (comms[i]) (void)R.CommDestroy(comms[i]);
+    }
+    if (rc != FQTK_OK) return rc;
+    for (size_t b = 0; b < bins; ++b) counts[b] += (uint64_t)total[b];
     return FQTK_OK;
 }
 

@@ -177,7 +177,10 @@ __device__ __forceinline__ uint32_t noncanonical_beyond_dots(const uint32_t (&wo
 // DIRECT (0 = off, 2 / 4 = bytes per entry): barcodes of <= 10 bases -- reads without a no-call index a flat
 // array by their own 2-bit codes (memo_hash.hpp), exact matches are caught by a compact LDS cache of that
 // array, and only reads with an N go to the cuckoo table.
-template <int VEC, int KW, int R, int ABL, bool LENS = false, int DIRECT = 0>
+// PF: the full-tile loop is software-pipelined one tile deep on both streams (see lds_memo_kernels.hip.h: on
+// gfx950 a wait for loads is also a wait for every store issued since, so the next tile's loads and the
+// previous tile's stores are issued together at the top of an iteration and fly during the look-up).
+template <int VEC, int KW, int R, int ABL, bool LENS = false, int DIRECT = 0, bool PF = false>
 __global__ __launch_bounds__(kMemoBlock) __attribute__((amdgpu_waves_per_eu(FQTK_MEMO_WAVES, 8)))
 void memo_kernel(const MemoParams Q) {
     static_assert(DIRECT == 0 || KW == 1, "the direct index is for keys of <= 10 bases");
@@ -218,26 +221,63 @@ void memo_kernel(const MemoParams Q) {
     const uint64_t tile = (uint64_t)kMemoBlock * R;
     const uint64_t ntiles = (P.n + tile - 1) / tile;
     const uint32_t hot2_mask = (1u << Q.hot2_bits) - 1u;
+    // lane -> read inside a tile is WAVE-CONTIGUOUS (a wave's R loads cover 64 R consecutive reads), and a full
+    // tile is addressed as "uniform 64-bit base + loop-invariant 32-bit lane offset" (as in the LDS form)
+    uint32_t local[R], in_off[R], out_off[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        local[r] = (tid >> 6) * (64u * R) + (uint32_t)r * 64u + (tid & 63u);
+        in_off[r] = local[r] * P.stride;
+        out_off[r] = local[r] * 4u;
+    }
 
-    for (uint64_t t = blockIdx.x; t < ntiles; t += gridDim.x) {
-        uint32_t words[R][8];
-        uint32_t lo[R], hi[R], ext[R], res[R], didx[R];
-        bool live[R], bad[R], has_n[R];
+    // The packed vector loads of one full tile (every read exists, the rows are VEC dwords).
+    auto load_full = [&](uint64_t t, uint32_t (&words)[R][8]) {
+        const uint8_t *tile_in = P.obs + t * tile * (uint64_t)P.stride;   // wave-uniform
 #pragma unroll
         for (int r = 0; r < R; ++r) {
-            const uint64_t i = t * tile + (uint64_t)r * kMemoBlock + tid;
+            const uint8_t *src = tile_in + in_off[r];
+            if constexpr (VEC == 4) {
+                const u32x4v v = FQTK_STREAM_LOAD(reinterpret_cast<const u32x4v *>(src));
+                words[r][0] = v.x; words[r][1] = v.y; words[r][2] = v.z; words[r][3] = v.w;
+            } else if constexpr (VEC == 3) {
+                const uint32_t *s32 = reinterpret_cast<const uint32_t *>(src);
+                words[r][0] = s32[0]; words[r][1] = s32[1]; words[r][2] = s32[2];
+            } else if constexpr (VEC == 5) {
+                const uint32_t *s32 = reinterpret_cast<const uint32_t *>(src);
+                words[r][0] = s32[0]; words[r][1] = s32[1]; words[r][2] = s32[2];
+                words[r][3] = s32[3]; words[r][4] = s32[4];
+            } else if constexpr (VEC == 2) {
+                const u32x2v v = FQTK_STREAM_LOAD(reinterpret_cast<const u32x2v *>(src));
+                words[r][0] = v.x; words[r][1] = v.y;
+            } else {
+                words[r][0] = *reinterpret_cast<const uint32_t *>(src);
+            }
+        }
+    };
+    // Any tile through the generic path (ragged last tile, unaligned strides): bounds-checked loads.
+    auto load_any = [&](uint64_t t, uint32_t (&words)[R][8], bool (&live)[R]) {
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const uint64_t i = t * tile + local[r];
             live[r] = i < P.n;
 #pragma unroll
             for (int w = 0; w < 8; ++w) words[r][w] = 0x41414141u;   // dead lanes look like "AAAA"
             if (live[r]) load_words<1, VEC>(P, i, nwords, words[r]);
         }
+    };
+
+    // Looks one tile up: res[r] = the result word of the tile's r-th read; also feeds the histogram.
+    auto lookup = [&](uint64_t t, uint32_t (&words)[R][8], const bool (&live)[R], uint32_t (&res)[R]) {
+        uint32_t lo[R], hi[R], ext[R], didx[R];
+        bool bad[R], has_n[R];
         // ---- ASCII -> 4-bit codes (SWAR, see encode_nibbles); `bad` = some base is not A C G T N ----
 #pragma unroll
         for (int r = 0; r < R; ++r) {
             uint32_t b, lo_unf, c2;
             encode_nibbles<NWD, (VEC >= 1 && !(ABL & 2)), FOLD>(words[r], kc, kv, lo[r], hi[r], ext[r], b, lo_unf, c2);
             bad[r] = b != 0 && live[r];
-            if constexpr (LENS) { if (live[r]) bad[r] = bad[r] && P.lens[t * tile + (uint64_t)r * kMemoBlock + tid] == L; }
+            if constexpr (LENS) { if (live[r]) bad[r] = bad[r] && P.lens[t * tile + local[r]] == L; }
             if constexpr (DIRECT) {
                 didx[r] = memo_direct_index(lo_unf, c2);
                 has_n[r] = memo_nocall_bits(lo_unf, c2) != 0;
@@ -361,20 +401,18 @@ void memo_kernel(const MemoParams Q) {
                 }
             }
         }
-        // ---- results + per-sample counts -------------------------------------------------------
+        // ---- length rules of a variable-length batch, per-sample counts ---------------------------
 #pragma unroll
         for (int r = 0; r < R; ++r) {
             if (!live[r]) continue;
-            const uint64_t i = t * tile + (uint64_t)r * kMemoBlock + tid;
-            if constexpr (LENS) {   // variable-length batch: the memo served the reads of length L
+            if constexpr (LENS) {   // the memo served the reads of length L
+                const uint64_t i = t * tile + local[r];
                 const uint32_t len = P.lens[i];
                 if (len != L) {   // shorter -> None (barcode_matching.rs:167-169); longer -> None or the panic
                     res[r] = kMemoEmpty;
                     if (len > L) overlong_read(P, i, len);
                 }
             }
-            if constexpr (ABL & 8) { if (res[r] == 0x12345u) P.out[i] = res[r]; } else
-            FQTK_STREAM_STORE(res[r], &P.out[i]);
             if (P.counts && !(ABL & 4)) {
                 const uint32_t idx = res[r] & 0xFFFFu;
                 const uint32_t bin = idx == kNoMatch ? P.S : idx;
@@ -382,6 +420,61 @@ void memo_kernel(const MemoParams Q) {
                 else atomicAdd(&P.counts[bin], 1ull);
             }
         }
+    };
+    // The result stream of one tile.
+    auto store_full = [&](uint64_t t, const uint32_t (&res)[R]) {
+        if constexpr (ABL & 8) { if (res[0] == 0x12345u) P.out[t * tile + local[0]] = res[0]; return; }
+        uint8_t *tile_out = reinterpret_cast<uint8_t *>(P.out + t * tile);   // wave-uniform
+#pragma unroll
+        for (int r = 0; r < R; ++r) FQTK_STREAM_STORE(res[r], reinterpret_cast<uint32_t *>(tile_out + out_off[r]));
+    };
+    auto store_any = [&](uint64_t t, const uint32_t (&res)[R], const bool (&live)[R]) {
+#pragma unroll
+        for (int r = 0; r < R; ++r)
+            if (live[r]) FQTK_STREAM_STORE(res[r], &P.out[t * tile + local[r]]);
+    };
+
+    const uint64_t full_tiles = (VEC >= 1) ? P.n / tile : 0;
+    bool all_live[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) all_live[r] = true;
+    if constexpr (PF && VEC >= 1) {
+        uint32_t cur[R][8], nxt[R][8], held[R];
+        uint64_t t = blockIdx.x, t_held = 0;
+        bool have = false;
+        if (t < full_tiles) load_full(t, cur);
+        for (; t < full_tiles; t += gridDim.x) {
+#pragma unroll
+            for (int r = 0; r < R; ++r)
+#pragma unroll
+                for (int w = 0; w < NWD; ++w) asm volatile("" : "+v"(cur[r][w]) : : "memory");   // cur has landed; nothing moves above
+            const uint64_t tn = t + gridDim.x;
+            if (tn < full_tiles) load_full(tn, nxt);   // wave-uniform
+            if (have) store_full(t_held, held);
+            lookup(t, cur, all_live, held);
+            have = true;
+            t_held = t;
+#pragma unroll
+            for (int r = 0; r < R; ++r)
+#pragma unroll
+                for (int w = 0; w < NWD; ++w) cur[r][w] = nxt[r][w];
+        }
+        if (have) store_full(t_held, held);
+    } else {
+        for (uint64_t t = blockIdx.x; t < full_tiles; t += gridDim.x) {
+            uint32_t words[R][8], res[R];
+            load_full(t, words);
+            lookup(t, words, all_live, res);
+            store_full(t, res);
+        }
+    }
+    // whatever is left (the ragged last tile; every tile on the generic load paths)
+    for (uint64_t t = full_tiles + (blockIdx.x + gridDim.x - full_tiles % gridDim.x) % gridDim.x; t < ntiles; t += gridDim.x) {
+        uint32_t words[R][8], res[R];
+        bool live[R];
+        load_any(t, words, live);
+        lookup(t, words, live, res);
+        store_any(t, res, live);
     }
 
     if (P.counts && P.lds_hist) {

@@ -6,7 +6,7 @@
 // Workload model: with probability p_sample the read is drawn from a sample
 // barcode (sample popularity ~ Zipf, given as a 32-bit CDF), degenerate IUPAC positions resolved to
 // a concrete base; otherwise a uniform random ACGT L-mer.  Then per base: no-call 'N' with p_n,
-// substitution with p_sub, lower-casing with p_lower, '.' with p_dot.
+// substitution with p_sub, lower-casing with p_lower, '.' with p_dot, the IUPAC code 'R' with p_iupac.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -17,7 +17,7 @@ struct SynthParams {
     const uint32_t *cdf;      // [S] inclusive upper bounds scaled to 2^32 (last = 0xFFFFFFFF)
     uint32_t S, L, stride;
     uint64_t seed;
-    uint32_t thr_sample, thr_n, thr_sub, thr_lower, thr_dot;  // probabilities * 2^32
+    uint32_t thr_sample, thr_n, thr_sub, thr_lower, thr_dot, thr_iupac;  // probabilities * 2^32
 };
 
 __host__ __device__ inline uint64_t splitmix64(uint64_t &x) {
@@ -82,6 +82,7 @@ __host__ __device__ inline void synth_read(const SynthParams &P, uint64_t i, uin
         const uint32_t ev2 = (alt * 2654435761u);
         if (ev2 < P.thr_dot) base = '.';
         else if (ev2 - P.thr_dot < P.thr_lower) base = (uint8_t)(base | 0x20);
+        else if (ev2 - P.thr_dot - P.thr_lower < P.thr_iupac) base = 'R';   // an IUPAC code IN THE READ (cliff studies only)
         dst[k] = base;
     }
     for (uint32_t k = P.L; k < P.stride; ++k) dst[k] = 0;
@@ -106,10 +107,10 @@ extern "C" {
 
 // Fills out[0 .. n*stride) with reads start .. start+n on the HOST.  barcodes: S*L bytes.
 int fqtk_synth_fill_host(const uint8_t *barcodes, const uint32_t *cdf, uint32_t S, uint32_t L,
-                         uint32_t stride, uint64_t seed, const uint32_t *thr5, uint64_t start,
+                         uint32_t stride, uint64_t seed, const uint32_t *thr6, uint64_t start,
                          uint64_t n, uint8_t *out) {
     if (L > 128 || stride < L || S == 0) return 1;
-    SynthParams P{barcodes, cdf, S, L, stride, seed, thr5[0], thr5[1], thr5[2], thr5[3], thr5[4]};
+    SynthParams P{barcodes, cdf, S, L, stride, seed, thr6[0], thr6[1], thr6[2], thr6[3], thr6[4], thr6[5]};
     for (uint64_t i = 0; i < n; ++i) synth_read(P, start + i, out + i * (uint64_t)stride);
     return 0;
 }
@@ -117,7 +118,7 @@ int fqtk_synth_fill_host(const uint8_t *barcodes, const uint32_t *cdf, uint32_t 
 // Same bytes, written to DEVICE memory d_out on hip_stream.  Copies the (small) table to the device
 // for the duration of the call; synchronises the stream before returning.
 int fqtk_synth_fill_device(const uint8_t *barcodes, const uint32_t *cdf, uint32_t S, uint32_t L,
-                           uint32_t stride, uint64_t seed, const uint32_t *thr5, uint64_t start,
+                           uint32_t stride, uint64_t seed, const uint32_t *thr6, uint64_t start,
                            uint64_t n, void *d_out, void *hip_stream) {
     if (L > 128 || stride < L || S == 0) return 1;
     hipStream_t stream = static_cast<hipStream_t>(hip_stream);
@@ -129,7 +130,7 @@ int fqtk_synth_fill_device(const uint8_t *barcodes, const uint32_t *cdf, uint32_
     if (hipMemcpyAsync(d_bc, barcodes, (size_t)S * L, hipMemcpyHostToDevice, stream) != hipSuccess) rc = 3;
     if (hipMemcpyAsync(d_cdf, cdf, (size_t)S * 4, hipMemcpyHostToDevice, stream) != hipSuccess) rc = 3;
     if (rc == 0 && n > 0) {
-        SynthParams P{d_bc, d_cdf, S, L, stride, seed, thr5[0], thr5[1], thr5[2], thr5[3], thr5[4]};
+        SynthParams P{d_bc, d_cdf, S, L, stride, seed, thr6[0], thr6[1], thr6[2], thr6[3], thr6[4], thr6[5]};
         const uint64_t want = (n + 255) / 256;
         const uint32_t grid = (uint32_t)(want < 16384 ? want : 16384);
         hipLaunchKernelGGL(synth_kernel, dim3(grid), dim3(256), 0, stream, P, start, n,

@@ -101,7 +101,8 @@ def thresholds(cfg: Config) -> np.ndarray:
         p_sample = float(os.environ["FQTK_SYNTH_PSAMPLE"])
     if os.environ.get("FQTK_SYNTH_PDOT"):     # developer knob: rate of '.' no-calls per base
         p_dot = float(os.environ["FQTK_SYNTH_PDOT"])
-    t = [p_sample, p_n, p_sub, p_lower, p_dot]
+    p_iupac = float(os.environ.get("FQTK_SYNTH_PIUPAC", "0"))   # developer knob: rate of IUPAC 'R' bytes per base of a READ
+    t = [p_sample, p_n, p_sub, p_lower, p_dot, p_iupac]
     return np.array([min(int(p * 2**32), 2**32 - 1) for p in t], dtype=np.uint32)
 
 

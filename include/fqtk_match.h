@@ -40,6 +40,7 @@ extern "C" {
 #define FQTK_EHIP 3   /* a HIP runtime call failed; see fqtk_last_error() */
 #define FQTK_ENOMEM 4
 #define FQTK_ENODEV 5 /* no usable gfx950 device */
+#define FQTK_ENCCL 6  /* RCCL could not be loaded or a collective failed (fqtk_matchers_allreduce_counts) */
 
 #define FQTK_NO_MATCH 0xFFFFu /* fqtk_match_t.idx of a read the reference assigns None */
 #define FQTK_MAX_BARCODE_LEN 128u
@@ -184,6 +185,18 @@ int fqtk_matcher_wait(fqtk_matcher *m, int slot);
 /* Adds the device-side accumulated counts (S+1) of all completed enqueue() chunks into `counts`
  * and resets the device accumulator.  Synchronises all slots. */
 int fqtk_matcher_counts(fqtk_matcher *m, uint64_t *counts);
+
+/* ---- several GPUs in one process ------------------------------------------------ */
+/* Templates are independent, so chunks shard over devices with no data-path exchange: one matcher per
+ * device (the table is replicated by fqtk_matcher_create), chunk k goes to matcher k mod n.  The ONE
+ * collective of the path is the end-of-run reduction of the per-sample counts (the `templates` column of
+ * demux-metrics.txt, demux.rs:970-974, 994-998): this call all-reduces the enqueue()/wait() accumulators of
+ * `n` matchers living on `n` DISTINCT devices with RCCL (ncclAllReduce, ncclUint64, ncclSum over xGMI; the
+ * library is loaded with dlopen on first use), ADDS the total into counts[0..S] and resets every
+ * accumulator -- what fqtk_matcher_counts does for one matcher.  With n == 1 no collective is needed and
+ * none is made unless `force_collective` is non-zero (a one-rank communicator; exercises the RCCL path
+ * on a single-GPU box).  All matchers must have the same number of samples. */
+int fqtk_matchers_allreduce_counts(fqtk_matcher *const *matchers, int n, int force_collective, uint64_t *counts);
 
 #ifdef __cplusplus
 }

@@ -15,6 +15,8 @@ from fqtk_amd import BarcodeMatch, BarcodeMatcher, FqtkLengthError, _lib  # noqa
 from fqtk_amd import synth  # noqa: E402
 from oracle import oracle as O  # noqa: E402
 
+MATCH = np.dtype([("idx", "<u2"), ("best", "u1"), ("next", "u1")])
+
 
 def _loaded_native():
     """The test must be exercising the in-tree HIP library, not anything else."""
@@ -697,3 +699,38 @@ def test_full_parity_tool_reduced_size():
         assert r.returncode == 0, r.stderr[-2000:]
         d = json.loads(r.stdout.strip().splitlines()[-1])
         assert d["mismatching_reads"] == 0 and d["counts_equal"] and d["reads"] == 3000000
+
+
+def test_rccl_count_allreduce_entry_point():
+    """fqtk_matchers_allreduce_counts: the path's one collective, natively over RCCL.  One matcher per visible
+    device (a one-rank communicator is forced on a single-GPU box), chunks dealt round-robin, the all-reduced
+    per-sample counts equal the oracle's for the whole stream; the accumulators are reset afterwards."""
+    lib = _lib.load()
+    ndev = C.c_int(0)
+    assert lib.fqtk_device_count(C.byref(ndev)) == 0 and ndev.value >= 1
+    G = min(ndev.value, 4)
+    cfg = synth.CONFIGS[2]
+    w = synth.Workload(cfg)
+    ms = [BarcodeMatcher(w.barcodes, cfg.max_mismatches, cfg.min_mismatch_delta, device=d) for d in range(G)]
+    n_chunk, chunks = 100_000, 6
+    outs = [np.empty(n_chunk, dtype=np.uint32) for _ in range(chunks)]
+    hosts = [w.fill_host(c * n_chunk, n_chunk) for c in range(chunks)]
+    for c in range(chunks):                       # chunk k -> device k mod G (SURVEY.md 8e), slot k // G
+        assert lib.fqtk_matcher_enqueue(ms[c % G].handle, (c // G) % 4, hosts[c].ctypes.data, cfg.stride, None, n_chunk,
+                                        outs[c].ctypes.data) == 0, _lib.last_error()
+        if (c // G) % 4 == 3 or c >= chunks - G:
+            pass
+    for c in range(chunks):
+        assert lib.fqtk_matcher_wait(ms[c % G].handle, (c // G) % 4) == 0
+    handles = (C.c_void_p * G)(*[m.handle for m in ms])
+    counts = np.zeros(cfg.n_samples + 1, dtype=np.uint64)
+    rc = lib.fqtk_matchers_allreduce_counts(handles, G, 1, counts.ctypes.data)
+    assert rc == 0, _lib.last_error()
+    lit = O.RefLiteral(w.barcodes, cfg.max_mismatches, cfg.min_mismatch_delta, True)
+    i, b, nx, want = lit.assign_batch(np.concatenate(hosts))
+    assert np.array_equal(counts, want)
+    assert np.array_equal(np.concatenate(outs).view(MATCH)["idx"], i)
+    again = np.zeros_like(counts)
+    assert lib.fqtk_matchers_allreduce_counts(handles, G, 1, again.ctypes.data) == 0 and again.sum() == 0   # reset
+    dup = (C.c_void_p * 2)(ms[0].handle, ms[0].handle)
+    assert lib.fqtk_matchers_allreduce_counts(dup, 2, 0, again.ctypes.data) == _lib.FQTK_EINVAL   # one matcher per DISTINCT device
