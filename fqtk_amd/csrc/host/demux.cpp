@@ -447,51 +447,31 @@ int main(int argc, char **argv) {
         plan.file_base[k] = plan.files_per_sample;
         if (plan.want[k]) plan.files_per_sample += plan.by_type[k].size();
     }
-    const size_t S = samples.size();
-    const size_t n_outs = (S + 1) * plan.files_per_sample;
-    {
-        rlimit rl;
-        if (getrlimit(RLIMIT_NOFILE, &rl) == 0 && rl.rlim_cur < n_outs + 64) {
-            rl.rlim_cur = std::min<rlim_t>(rl.rlim_max, n_outs + 64);
-            setrlimit(RLIMIT_NOFILE, &rl);
-        }
-    }
-    std::vector<OutFile> outs(n_outs);
-    for (size_t s = 0; s <= S; ++s) {
-        const std::string &prefix = s < S ? samples[s].sample_id : opt.unmatched_prefix;
-        for (int k = 0; k < 4; ++k) {
-            if (!plan.want[k]) continue;
-            for (size_t j = 0; j < plan.by_type[k].size(); ++j) {
-                OutFile &of = outs[s * plan.files_per_sample + plan.file_base[k] + j];
-                of.path = opt.output + "/" + prefix + "." + kCodes[k] + std::to_string(j + 1) + ".fq.gz";
-                of.f = std::fopen(of.path.c_str(), "wb");
-                if (!of.f) die("cannot create " + of.path + ": " + std::strerror(errno));
-                std::lock_guard<std::mutex> lk(g_created_mu);
-                g_created.push_back(of.path);
-            }
-        }
-    }
-    info("Created sample and %s writers.", opt.unmatched_prefix.c_str());
-
     // ---- the matcher (demux.rs:921-926), use_cache = true as the reference passes -----------------
+    // Bringing the GPU up (HIP runtime, code objects, table upload, memo build) takes about a second: it runs
+    // on its own thread while the readers already decompress and parse the first chunks and this thread
+    // creates the output files.
+    const size_t S = samples.size();
     std::vector<const char *> bc;
     for (const Sample &s : samples) bc.push_back(s.barcode.c_str());
     // One matcher (replicated table) per device; chunk k is matched on device k mod G.  Templates are
-    // independent, so there is no data-path exchange; the per-device counts are summed at the end.
+    // independent, so there is no data-path exchange; the per-device counts are reduced at the end.
     if (opt.devices.empty()) opt.devices.push_back(opt.device);
     const size_t G = opt.devices.size();
     std::vector<fqtk_matcher *> matchers(G, nullptr);
     const uint32_t L = (uint32_t)samples[0].barcode.size();
-    for (size_t g = 0; g < G; ++g) {
-        if (fqtk_matcher_create(bc.data(), (uint32_t)S, L, (uint8_t)opt.max_mismatches, (uint8_t)opt.min_mismatch_delta,
-                                opt.devices[g], &matchers[g]) != FQTK_OK)
-            die(std::string("cannot create the GPU barcode matcher: ") + fqtk_last_error());
-        std::vector<const char *> ids;   // so that a length error names the sample like the reference's panic does
-        for (const Sample &s : samples) ids.push_back(s.sample_id.c_str());
-        fqtk_matcher_set_sample_ids(matchers[g], ids.data());
-        info("GPU barcode matcher ready on device %d (%llu memo entries).", opt.devices[g],
-             (unsigned long long)fqtk_matcher_memo_entries(matchers[g]));
-    }
+    std::thread gpu_init([&] {
+        for (size_t g = 0; g < G; ++g) {
+            if (fqtk_matcher_create(bc.data(), (uint32_t)S, L, (uint8_t)opt.max_mismatches, (uint8_t)opt.min_mismatch_delta,
+                                    opt.devices[g], &matchers[g]) != FQTK_OK)
+                die(std::string("cannot create the GPU barcode matcher: ") + fqtk_last_error());
+            std::vector<const char *> ids;   // so that a length error names the sample like the reference's panic does
+            for (const Sample &s : samples) ids.push_back(s.sample_id.c_str());
+            fqtk_matcher_set_sample_ids(matchers[g], ids.data());
+            info("GPU barcode matcher ready on device %d (%llu memo entries).", opt.devices[g],
+                 (unsigned long long)fqtk_matcher_memo_entries(matchers[g]));
+        }
+    });
 
     // sample-barcode layout of one template: fixed total length, or variable when a B segment is '+'
     bool variable_barcode = false;
@@ -558,6 +538,33 @@ int main(int argc, char **argv) {
                 if (last) return;
             }
         });
+
+    const size_t n_outs = (S + 1) * plan.files_per_sample;
+    {
+        rlimit rl;
+        if (getrlimit(RLIMIT_NOFILE, &rl) == 0 && rl.rlim_cur < n_outs + 64) {
+            rl.rlim_cur = std::min<rlim_t>(rl.rlim_max, n_outs + 64);
+            setrlimit(RLIMIT_NOFILE, &rl);
+        }
+    }
+    std::vector<OutFile> outs(n_outs);
+    for (size_t s = 0; s <= S; ++s) {
+        const std::string &prefix = s < S ? samples[s].sample_id : opt.unmatched_prefix;
+        for (int k = 0; k < 4; ++k) {
+            if (!plan.want[k]) continue;
+            for (size_t j = 0; j < plan.by_type[k].size(); ++j) {
+                OutFile &of = outs[s * plan.files_per_sample + plan.file_base[k] + j];
+                of.path = opt.output + "/" + prefix + "." + kCodes[k] + std::to_string(j + 1) + ".fq.gz";
+                of.f = std::fopen(of.path.c_str(), "wb");
+                if (!of.f) die("cannot create " + of.path + ": " + std::strerror(errno));
+                std::lock_guard<std::mutex> lk(g_created_mu);
+                g_created.push_back(of.path);
+            }
+        }
+    }
+    info("Created sample and %s writers.", opt.unmatched_prefix.c_str());
+
+    gpu_init.join();
 
     // ---- stage C: routers (partitioned by sample: one owner per file, input order kept) format the
     //      records; a shared pool BGZF-compresses the 64 KiB blocks and writes them in order ---------

@@ -134,18 +134,15 @@ void lds_memo_kernel(const LdsMemoParams Q) {
             if constexpr (VEC == 4) {
                 const u32x4v v = FQTK_STREAM_LOAD(reinterpret_cast<const u32x4v *>(src));
                 words[r][0] = v.x; words[r][1] = v.y; words[r][2] = v.z; words[r][3] = v.w;
-            } else if constexpr (VEC == 3) {
-                const uint32_t *s32 = reinterpret_cast<const uint32_t *>(src);
-                words[r][0] = s32[0]; words[r][1] = s32[1]; words[r][2] = s32[2];
-            } else if constexpr (VEC == 5) {
-                const uint32_t *s32 = reinterpret_cast<const uint32_t *>(src);
-                words[r][0] = s32[0]; words[r][1] = s32[1]; words[r][2] = s32[2];
-                words[r][3] = s32[3]; words[r][4] = s32[4];
+            } else if constexpr (VEC == 3 || VEC == 5) {   // 12- / 20-byte rows are only 4-byte aligned: dword pieces,
+                const uint32_t *s32 = reinterpret_cast<const uint32_t *>(src);   // non-temporal like the rest of the stream
+#pragma unroll
+                for (int w = 0; w < VEC; ++w) words[r][w] = FQTK_STREAM_LOAD(s32 + w);
             } else if constexpr (VEC == 2) {
                 const u32x2v v = FQTK_STREAM_LOAD(reinterpret_cast<const u32x2v *>(src));
                 words[r][0] = v.x; words[r][1] = v.y;
             } else {
-                words[r][0] = *reinterpret_cast<const uint32_t *>(src);
+                words[r][0] = FQTK_STREAM_LOAD(reinterpret_cast<const uint32_t *>(src));
             }
         }
     };
@@ -287,29 +284,55 @@ void lds_memo_kernel(const LdsMemoParams Q) {
         // they complete out of order with respect to each other, so "wait for my loads" also waits for every
         // store issued since: the plain loop (load, look up, store) pays a store acknowledgement plus a load
         // round trip, back to back, per tile.  Here a wave waits ONCE per tile, at the top, for operations it
-        // issued a whole look-up phase earlier (the loads of `cur`, the stores of the tile before), and only
+        // issued a whole look-up phase earlier (the loads of this tile, the stores of the tile before), and only
         // then issues the next tile's loads and the previous tile's stores, which fly during the look-up.
-        uint32_t cur[R][8], nxt[R][8], held[R];
-        uint64_t t = blockIdx.x, t_held = 0;
-        bool have = false;
-        if (t < full_tiles) load_full(t, cur);
-        for (; t < full_tiles; t += gridDim.x) {
+        // Two word buffers used alternately (no register rotation); the prefetch is unconditional -- past the
+        // end it re-reads the last full tile and the words are never used -- so that it cannot sit in a branch.
+        uint32_t wa[R][8], wb[R][8], held[R];
+        auto landed = [&](uint32_t (&w)[R][8]) {   // the words are in registers; nothing below moves above this point
 #pragma unroll
             for (int r = 0; r < R; ++r)
 #pragma unroll
-                for (int w = 0; w < NWD; ++w) asm volatile("" : "+v"(cur[r][w]) : : "memory");   // cur has landed; nothing moves above
-            const uint64_t tn = t + gridDim.x;
-            if (tn < full_tiles) load_full(tn, nxt);   // wave-uniform
-            if (have) store_full(t_held, held);
-            compute(t, cur, all_live, held);
-            have = true;
-            t_held = t;
+                for (int k = 0; k < NWD; ++k) asm volatile("" : "+v"(w[r][k]) : : "memory");
+        };
+        auto computed = [&](uint32_t (&v)[R]) {     // the results exist now (their gathers / LDS reads were waited for HERE)
 #pragma unroll
-            for (int r = 0; r < R; ++r)
+            for (int r = 0; r < R; ++r) asm volatile("" : "+v"(v[r]) : : "memory");
+        };
+        uint64_t t = blockIdx.x;
+        if (t < full_tiles) {
+            const uint64_t last = full_tiles - 1;
+            uint32_t res[R];
+            load_full(t, wa);
+            landed(wa);
+            load_full(min(t + gridDim.x, last), wb);
+            compute(t, wa, all_live, held);
+            computed(held);
+            uint64_t t_held = t;
+            t += gridDim.x;
+            while (t < full_tiles) {
+                landed(wb);
+                load_full(min(t + gridDim.x, last), wa);
+                store_full(t_held, held);
+                compute(t, wb, all_live, res);
+                computed(res);
 #pragma unroll
-                for (int w = 0; w < NWD; ++w) cur[r][w] = nxt[r][w];
+                for (int r = 0; r < R; ++r) held[r] = res[r];
+                t_held = t;
+                t += gridDim.x;
+                if (t >= full_tiles) break;
+                landed(wa);
+                load_full(min(t + gridDim.x, last), wb);
+                store_full(t_held, held);
+                compute(t, wa, all_live, res);
+                computed(res);
+#pragma unroll
+                for (int r = 0; r < R; ++r) held[r] = res[r];
+                t_held = t;
+                t += gridDim.x;
+            }
+            store_full(t_held, held);
         }
-        if (have) store_full(t_held, held);
     } else {
         for (uint64_t t = blockIdx.x; t < full_tiles; t += gridDim.x) {
             uint32_t words[R][8], res[R];

@@ -8,9 +8,9 @@ import sys,json
 d=json.loads(sys.stdin.readline()); r=d['roofline']
 print(json.dumps({'row': '$1', 'G_reads_s': round(d['value']/1000,1), 'frac': r['frac'], 'kernel_ms': r['kernel_ms'], 'kernel': r['kernel'], 'parity': d['config']['parity']}))"; }
 row "cfg3, no non-canonical reads" 0 0
-row "cfg3, 1% of reads carry a '.'" 0.00063 0
-row "cfg3, 10% of reads carry a '.'" 0.0066 0
+row "cfg3, 1% of reads carry a dot" 0.00063 0
+row "cfg3, 10% of reads carry a dot" 0.0066 0
 row "cfg3, 0.1% of reads carry an IUPAC byte" 0 0.0000625
 row "cfg3, 1% of reads carry an IUPAC byte" 0 0.00063
-row "cfg3 table form, 1% '.'" 0.00063 0 --memo-table
+row "cfg3 table form, 1% dot" 0.00063 0 --memo-table
 row "cfg3 table form, 1% IUPAC" 0 0.00063 --memo-table
