@@ -187,7 +187,8 @@ def main() -> int:
                     help="full: first 50 M triples + count vector of all reads (default at 1 rank); windows: 3 x 100 k")
     ap.add_argument("--no-verify", action="store_true", help="same as --parity none")
     ap.add_argument("--no-scopes", action="store_true", help="skip scopes B and E")
-    ap.add_argument("--e2e-templates", type=int, default=4_000_000, help="templates of the scope E run")
+    ap.add_argument("--e2e-templates", type=int, default=16_000_000,
+                    help="templates of the scope E run (multiples of 1 M above 1 M: the first 1 M templates repeated)")
     ap.add_argument("--e2e-threads", type=int, default=32)
     ap.add_argument("--e2e-gz", action="store_true", help="gzip the scope E inputs (single-stream gunzip per file)")
     ap.add_argument("--lens", action="store_true", help="pass an obs_len array (all == L): the variable-length '+B' path")
@@ -401,14 +402,17 @@ def main() -> int:
             torch.cuda.empty_cache()
             scopes["B"] = scope_bench.scope_b(args.config, matcher=matcher, workload=workload,
                                               n_chunk=min(8_000_000, max(job_reads // 4, 1)))
-            tmp = scope_bench.scratch_dir(args.e2e_templates * 1100)
+            tmp = scope_bench.scratch_dir(args.e2e_templates * 900)
             try:
                 expect = None
+                n_e = args.e2e_templates
+                rep = n_e > 1_000_000 and n_e % 1_000_000 == 0       # a 1 M-template block written n_e / 1 M times
+                uniq = 1_000_000 if rep else n_e
                 if pool is not None and args.config == 3:   # metrics file vs the oracle's count vector
-                    res = pool.map(_parity_worker, [(3, 1, 2, 0, lo, min(lo + 500_000, args.e2e_templates), 0, None)
-                                                    for lo in range(0, args.e2e_templates, 500_000)])
-                    expect = sum((r[1] for r in res), np.zeros(385, dtype=np.uint64))
-                scopes["E"] = scope_bench.scope_e(args.e2e_templates, args.e2e_threads, args.e2e_gz, tmp, expect)
+                    res = pool.map(_parity_worker, [(3, 1, 2, 0, lo, min(lo + 250_000, uniq), 0, None)
+                                                    for lo in range(0, uniq, 250_000)])
+                    expect = sum((r[1] for r in res), np.zeros(385, dtype=np.uint64)) * np.uint64(n_e // uniq)
+                scopes["E"] = scope_bench.scope_e(n_e, args.e2e_threads, args.e2e_gz, tmp, expect, repeat_first_block=rep)
             finally:
                 shutil.rmtree(tmp, ignore_errors=True)
             out["scopes"] = scopes

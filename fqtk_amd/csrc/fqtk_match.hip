@@ -204,7 +204,7 @@ int launch_vec(const fqtk::MatchParams &P, int num_cus, hipStream_t stream) {
 }
 
 template <int KW>
-int launch_memo_vec(const fqtk_matcher *m, const fqtk::MemoParams &Q, hipStream_t stream) {
+int launch_memo_vec(const fqtk_matcher *m, fqtk::MemoParams Q, hipStream_t stream) {
     const fqtk::MatchParams &P = Q.m;
     const uintptr_t base = reinterpret_cast<uintptr_t>(P.obs);
     const uint32_t nwords = (P.L + 3) / 4;
@@ -220,20 +220,23 @@ int launch_memo_vec(const fqtk_matcher *m, const fqtk::MemoParams &Q, hipStream_
             else if (sw == 5) vec = 5;
         }
     }
-    // One read per lane.  The packed vector paths run their full tiles software-pipelined one tile deep
-    // (current + prefetched words + held result stay inside 64 VGPRs = 8 waves/SIMD with no scratch: hipcc
-    // -Rpass-analysis=kernel-resource-usage; two reads per lane pipelined would spill 28-60 bytes per lane);
-    // with 32 waves per CU the gathers of 2048 reads are in flight per CU, which is all the parallelism
-    // the L2 round trip needs.
+    // Two reads per lane on the packed vector paths, one on the generic ones and for variable-length batches.
+    // 4- and 8-byte rows run their full tiles software-pipelined one tile deep; wider rows would spill 28-60
+    // bytes per lane out of the 64 VGPRs that keep 8 waves per SIMD (hipcc -Rpass-analysis=kernel-resource-usage)
+    // and take the plain loop.  Measured on MI355X (tools/ab_table.sh, G reads/s, R=1 pipelined / R=1 plain /
+    // R=2 pipelined / R=2 plain / R=4 plain):  cfg 5 (12-byte rows) 181.6 / 173.1 / 165.8 (spills) / 188.1 / 136.7;
+    // cfg 3 table pinned (16-byte rows) 148.0 / 141.6 / 139.4 (spills) / 178.0 / 91.2;
+    // cfg 2 table pinned (8-byte rows) 236.4 / 203.0 / 248.2 / 234.1 / 182.9.
     const int direct = (KW == 1 && Q.direct) ? m->direct_bytes : 0;
-    int R = 1;
+    int R = (vec > 0 && !P.lens) ? 2 : 1;
     int abl = 0;
-    bool pf = vec > 0 && !P.lens;
+    bool pf = vec == 1 || vec == 2;
 #ifdef FQTK_DEV_ABLATE
     if (!P.lens && vec > 0)
         if (const char *rr = std::getenv("FQTK_MEMO_R")) R = std::atoi(rr);
     if (const char *ab = std::getenv("FQTK_MEMO_ABLATE")) abl = std::atoi(ab);
-    pf = pf && R <= 2 && !env_flag("FQTK_MEMO_NOPF");
+    if (env_flag("FQTK_MEMO_PF")) pf = vec > 0;
+    pf = pf && R <= 2 && !P.lens && !env_flag("FQTK_MEMO_NOPF");
     size_t lds_pad = 0;   // occupancy experiments: pad the workgroup's LDS so fewer fit on a CU
     if (const char *lp = std::getenv("FQTK_MEMO_LDS_PAD")) lds_pad = (size_t)std::atol(lp);
 #endif
@@ -241,6 +244,13 @@ int launch_memo_vec(const fqtk_matcher *m, const fqtk::MemoParams &Q, hipStream_
     if (direct) shmem += Q.hot2 ? ((size_t)8 << Q.hot2_bits) : 0;
     else if (Q.hot_mask) shmem += (size_t)(Q.hot_mask + 1) * (KW >= 2 ? 16 : 8);
     if (P.counts && P.lds_hist) shmem += (size_t)(P.S + 1) * sizeof(uint32_t);
+    {   // the expected-barcode planes for the wave scan of non-canonical reads, while two workgroups still fit a CU
+        const size_t with_tab = ((shmem + 15) & ~(size_t)15) + (size_t)P.S * 16;
+        if (P.L <= 32 && 2 * (with_tab + 1024) <= fqtk::kLdsMemoMaxBytes) {
+            Q.m.scan_tab_lds = 1;
+            shmem = with_tab;
+        }
+    }
 #ifdef FQTK_DEV_ABLATE
     shmem += lds_pad;
 #endif
@@ -294,11 +304,11 @@ int launch_memo_vec(const fqtk_matcher *m, const fqtk::MemoParams &Q, hipStream_
         else { WHAT(__VA_ARGS__, 0); }                                  \
     } while (0)
 #ifdef FQTK_DEV_ABLATE
-    if (abl > 0 && !P.lens && (vec == 4 || (vec == 3 && direct == 2)) && R == 1) {   // ablations of the product shape
+    if (abl > 0 && !P.lens && (vec == 4 || (vec == 3 && direct == 2)) && R == 2) {   // ablations of the product shape
 #define FQTK_AB(A)                                                                                   \
         case A:                                                                                      \
-            if (vec == 4) FQTK_MEMO_LAUNCH_P(4, 1, A, false, 0, true);                               \
-            else FQTK_MEMO_LAUNCH_P(3, 1, A, false, 2, true);                                        \
+            if (vec == 4) FQTK_MEMO_LAUNCH_P(4, 2, A, false, 0, false);                              \
+            else FQTK_MEMO_LAUNCH_P(3, 2, A, false, 2, false);                                       \
             break;
         switch (abl) {
             FQTK_AB(1) FQTK_AB(2) FQTK_AB(4) FQTK_AB(8) FQTK_AB(16) FQTK_AB(17) FQTK_AB(32) FQTK_AB(64) FQTK_AB(128) FQTK_AB(256) FQTK_AB(272)
@@ -308,12 +318,13 @@ int launch_memo_vec(const fqtk_matcher *m, const fqtk::MemoParams &Q, hipStream_
         HIP_TRY(hipGetLastError());
         return FQTK_OK;
     }
-    if (!P.lens && vec > 0 && (R != 1 || !pf)) {   // A/B of reads per lane and of the pipeline
+    if (!P.lens && vec > 0 && (R != 2 || pf != (vec <= 2))) {   // A/B of reads per lane and of the pipeline
 #define FQTK_X(RR, D) FQTK_MEMO_PACKED(RR, 0, D, false)
 #define FQTK_Y(RR, D) FQTK_MEMO_PACKED(RR, 0, D, true)
         if (R == 4) FQTK_MEMO_BY_FORM(FQTK_X, 4);
         else if (R == 2 && pf) FQTK_MEMO_BY_FORM(FQTK_Y, 2);
         else if (R == 2) FQTK_MEMO_BY_FORM(FQTK_X, 2);
+        else if (pf) FQTK_MEMO_BY_FORM(FQTK_Y, 1);
         else FQTK_MEMO_BY_FORM(FQTK_X, 1);
 #undef FQTK_X
 #undef FQTK_Y
@@ -327,8 +338,17 @@ int launch_memo_vec(const fqtk_matcher *m, const fqtk::MemoParams &Q, hipStream_
 #define FQTK_X(D) FQTK_MEMO_ALL_VEC(1, 0, true, D, false)
         if (direct == 2) { FQTK_X(2) } else if (direct == 4) { FQTK_X(4) } else { FQTK_X(0) }
 #undef FQTK_X
-    } else if (vec > 0) {  // packed rows: pipelined
-#define FQTK_X(D) FQTK_MEMO_PACKED(1, 0, D, true)
+    } else if (vec == 1 || vec == 2) {  // 4- / 8-byte rows: two reads per lane, pipelined
+#define FQTK_X(D)                                                       \
+        if (vec == 2) FQTK_MEMO_LAUNCH_P(2, 2, 0, false, D, true);      \
+        else FQTK_MEMO_LAUNCH_P(1, 2, 0, false, D, true);
+        if (direct == 2) { FQTK_X(2) } else if (direct == 4) { FQTK_X(4) } else { FQTK_X(0) }
+#undef FQTK_X
+    } else if (vec > 0) {               // 12- / 16- / 20-byte rows: two reads per lane, plain loop
+#define FQTK_X(D)                                                       \
+        if (vec == 3) FQTK_MEMO_LAUNCH_P(3, 2, 0, false, D, false);     \
+        else if (vec == 4) FQTK_MEMO_LAUNCH_P(4, 2, 0, false, D, false);\
+        else FQTK_MEMO_LAUNCH_P(5, 2, 0, false, D, false);
         if (direct == 2) { FQTK_X(2) } else if (direct == 4) { FQTK_X(4) } else { FQTK_X(0) }
 #undef FQTK_X
     } else {               // generic load paths: one read per lane
@@ -366,8 +386,17 @@ int launch_lds_memo(const fqtk_matcher *m, fqtk::LdsMemoParams Q, hipStream_t st
     size_t shmem = m->ldsm_lds_bytes;
     if (P.counts && P.lds_hist) shmem += (size_t)(P.S + 1) * sizeof(uint32_t);
     if (shmem > fqtk::kLdsMemoMaxBytes) return fail(FQTK_EINVAL, "lds memo: table does not fit LDS");
-    // reads per lane: 2 on the packed paths, 1 on the generic ones
-    int R = vec > 0 ? 2 : 1;
+    {   // the expected-barcode planes next to it, for the wave scan of non-canonical reads -- when there is room
+        // and it does not cost a workgroup per CU
+        const size_t with_tab = ((shmem + 15) & ~(size_t)15) + (size_t)P.S * 16;
+        const bool two_before = 2 * (shmem + 1024) <= fqtk::kLdsMemoMaxBytes, two_after = 2 * (with_tab + 1024) <= fqtk::kLdsMemoMaxBytes;
+        if (P.L <= 32 && with_tab <= fqtk::kLdsMemoMaxBytes && (two_after || !two_before)) {
+            Q.m.scan_tab_lds = 1;
+            shmem = with_tab;
+        }
+    }
+    // reads per lane: 16 bytes of barcode per lane on the packed paths, one read on the generic ones
+    int R = vec >= 3 ? 1 : (vec == 2 ? 2 : (vec == 1 ? 4 : 1));
 #ifdef FQTK_DEV_ABLATE
     if (const char *rr = std::getenv("FQTK_MEMO_R")) R = std::atoi(rr);
 #endif
@@ -403,18 +432,6 @@ int launch_lds_memo(const fqtk_matcher *m, fqtk::LdsMemoParams Q, hipStream_t st
         HIP_TRY(hipGetLastError());
         return FQTK_OK;
     }
-    if (env_flag("FQTK_LDSM_PF") && !P.lens && (vec == 4 || vec == 2) && (R == 1 || R == 2 || R == 4)) {
-        switch (vec * 10 + R) {
-            case 41: FQTK_LDSM_LAUNCH_P(4, 1, false, true); break;
-            case 42: FQTK_LDSM_LAUNCH_P(4, 2, false, true); break;
-            case 44: FQTK_LDSM_LAUNCH_P(4, 4, false, true); break;
-            case 21: FQTK_LDSM_LAUNCH_P(2, 1, false, true); break;
-            case 22: FQTK_LDSM_LAUNCH_P(2, 2, false, true); break;
-            default: FQTK_LDSM_LAUNCH_P(2, 4, false, true); break;
-        }
-        HIP_TRY(hipGetLastError());
-        return FQTK_OK;
-    }
 #endif
     if (P.lens) {   // variable-length batch: the LENS instantiations, one read per lane
         switch (vec) {
@@ -427,42 +444,35 @@ int launch_lds_memo(const fqtk_matcher *m, fqtk::LdsMemoParams Q, hipStream_t st
             default: FQTK_LDSM_LAUNCH_L(0, 1, true); break;
         }
     } else if (vec > 0) {
-        // packed rows: two reads per lane, full tiles software-pipelined one tile deep on both streams
-        // (measured on MI355X, tools/ab_pf.sh: cfg 3 272.8 -> 278.7 G reads/s over R = 2 unpipelined,
-        //  cfg 2 458.6 (R = 4, unpipelined) -> 464.0; R = 1 pipelined 275 / 347, R = 4 pipelined 269 / 451)
+        // packed rows: full tiles software-pipelined one tile deep on both streams, 16 bytes of barcode per lane
+        // and tile -- one read of 12-20 bytes, two of 8, four of 4.  Measured on MI355X (tools/ab_pf.sh, G reads/s):
+        //   cfg 3 (16-byte rows)  R=1 plain 243.5  R=1 pipelined 282.8  R=2 plain 281.3  R=2 pipelined 269.7  R=4 plain 263.8
+        //   cfg 2 ( 8-byte rows)  R=1 plain 283.1  R=1 pipelined 377.7  R=2 plain 378.8  R=2 pipelined 472.0  R=4 plain 452.4
 #ifdef FQTK_DEV_ABLATE
-        if (R == 4) {
-            switch (vec) {
-                case 5: FQTK_LDSM_LAUNCH(5, 4); break;
-                case 4: FQTK_LDSM_LAUNCH(4, 4); break;
-                case 3: FQTK_LDSM_LAUNCH(3, 4); break;
-                case 2: FQTK_LDSM_LAUNCH(2, 4); break;
-                default: FQTK_LDSM_LAUNCH(1, 4); break;
+        const int product_r = vec >= 3 ? 1 : (vec == 2 ? 2 : 4);
+        if (env_flag("FQTK_LDSM_NOPF")) {   // A/B: the plain loop at the requested reads per lane
+            switch (R * 10 + vec) {
+                case 15: FQTK_LDSM_LAUNCH(5, 1); break; case 14: FQTK_LDSM_LAUNCH(4, 1); break; case 13: FQTK_LDSM_LAUNCH(3, 1); break;
+                case 12: FQTK_LDSM_LAUNCH(2, 1); break; case 11: FQTK_LDSM_LAUNCH(1, 1); break;
+                case 25: FQTK_LDSM_LAUNCH(5, 2); break; case 24: FQTK_LDSM_LAUNCH(4, 2); break; case 23: FQTK_LDSM_LAUNCH(3, 2); break;
+                case 22: FQTK_LDSM_LAUNCH(2, 2); break; case 21: FQTK_LDSM_LAUNCH(1, 2); break;
+                case 45: FQTK_LDSM_LAUNCH(5, 4); break; case 44: FQTK_LDSM_LAUNCH(4, 4); break; case 43: FQTK_LDSM_LAUNCH(3, 4); break;
+                case 42: FQTK_LDSM_LAUNCH(2, 4); break; default: FQTK_LDSM_LAUNCH(1, 4); break;
             }
-        } else if (R == 1) {
-            switch (vec) {
-                case 5: FQTK_LDSM_LAUNCH(5, 1); break;
-                case 4: FQTK_LDSM_LAUNCH(4, 1); break;
-                case 3: FQTK_LDSM_LAUNCH(3, 1); break;
-                case 2: FQTK_LDSM_LAUNCH(2, 1); break;
-                default: FQTK_LDSM_LAUNCH(1, 1); break;
-            }
-        } else if (env_flag("FQTK_LDSM_NOPF")) {
-            switch (vec) {
-                case 5: FQTK_LDSM_LAUNCH(5, 2); break;
-                case 4: FQTK_LDSM_LAUNCH(4, 2); break;
-                case 3: FQTK_LDSM_LAUNCH(3, 2); break;
-                case 2: FQTK_LDSM_LAUNCH(2, 2); break;
-                default: FQTK_LDSM_LAUNCH(1, 2); break;
+        } else if (R != product_r && (vec == 4 || vec == 2)) {   // A/B: pipelined at another reads-per-lane
+            switch (R * 10 + vec) {
+                case 14: FQTK_LDSM_LAUNCH_P(4, 1, false, true); break; case 24: FQTK_LDSM_LAUNCH_P(4, 2, false, true); break;
+                case 44: FQTK_LDSM_LAUNCH_P(4, 4, false, true); break; case 12: FQTK_LDSM_LAUNCH_P(2, 1, false, true); break;
+                case 22: FQTK_LDSM_LAUNCH_P(2, 2, false, true); break; default: FQTK_LDSM_LAUNCH_P(2, 4, false, true); break;
             }
         } else
 #endif
         switch (vec) {
-            case 5: FQTK_LDSM_LAUNCH_P(5, 2, false, true); break;
-            case 4: FQTK_LDSM_LAUNCH_P(4, 2, false, true); break;
-            case 3: FQTK_LDSM_LAUNCH_P(3, 2, false, true); break;
+            case 5: FQTK_LDSM_LAUNCH_P(5, 1, false, true); break;
+            case 4: FQTK_LDSM_LAUNCH_P(4, 1, false, true); break;
+            case 3: FQTK_LDSM_LAUNCH_P(3, 1, false, true); break;
             case 2: FQTK_LDSM_LAUNCH_P(2, 2, false, true); break;
-            default: FQTK_LDSM_LAUNCH_P(1, 2, false, true); break;
+            default: FQTK_LDSM_LAUNCH_P(1, 4, false, true); break;
         }
     } else {
         switch (vec) {
@@ -546,6 +556,7 @@ fqtk::MatchParams make_params(const fqtk_matcher *m, const void *d_obs, uint32_t
     P.delta = m->delta;
     P.nocall_limit = m->max_mm + m->max_ns;
     P.lds_hist = (m->S + 1 <= fqtk::kMaxLdsHist) ? 1u : 0u;
+    P.scan_tab_lds = 0;   // the memo launchers turn it on when the table fits their LDS budget
     return P;
 }
 
@@ -784,7 +795,15 @@ int build_memo(fqtk_matcher *m, const std::vector<std::vector<uint8_t>> &enc) {
     const std::vector<Entry> all_ents = ents;   // the LDS form and the entry count see every entry
     // ---- direct-indexed form (L <= 10): entries without a no-call go to a flat array indexed by the read
     //      itself; the cuckoo table below keeps only the entries WITH one -------------------------------
-    if (m->L <= fqtk::kDirectMaxLen) {
+    // Measured on MI355X (tools/ab_direct.sh, G reads/s, direct / hash table only): it pays where the hash
+    // table is big or most non-exact reads are unmatched -- cfg 5 (1536 IUPAC x 10) 177.5 / 149.3, 1536 x 10 plain
+    // 215.9 / 207.7, 1536 x 8 227.2 / 203.2 -- and costs a little where the old LDS hot table already held every
+    // exact match of a small table -- cfg 2 pinned (96 x 8) 243.3 / 276.2, 96 x 8 with two mismatches 257.5 / 276.3.
+    bool want_direct = m->L <= fqtk::kDirectMaxLen && (m->L >= 9 || m->S >= 512);
+#ifdef FQTK_DEV_ABLATE
+    if (env_flag("FQTK_FORCE_DIRECT")) want_direct = m->L <= fqtk::kDirectMaxLen;
+#endif
+    if (want_direct) {
         int rc = build_direct(m, cand, ents);
         if (rc != FQTK_OK) return rc;
         if (m->d_direct) {

@@ -569,7 +569,9 @@ int main(int argc, char **argv) {
     // ---- stage C: routers (partitioned by sample: one owner per file, input order kept) format the
     //      records; a shared pool BGZF-compresses the 64 KiB blocks and writes them in order ---------
     const size_t n_threads_c = std::max<size_t>(2, opt.threads - 1);
-    const size_t n_workers = std::max<size_t>(1, n_threads_c / 3);          // routers
+    // Formatting a template costs ~1.2 us of router time, compressing its ~680 bytes at level 5 ~5.7 us of
+    // libdeflate time (measured, FQTK_TIMING): one router feeds four to five compressors.
+    const size_t n_workers = std::max<size_t>(1, (n_threads_c + 2) / 5);    // routers
     const size_t n_comp = std::max<size_t>(1, n_threads_c - n_workers);     // compressors
     // Output files fill in lock-step (samples are hit in proportion, so hundreds of files reach a full
     // 64 KiB block within the same few chunks): the queue must absorb such a burst or the routers stall
@@ -884,11 +886,9 @@ int main(int argc, char **argv) {
     rows.push_back(unmatched);
     std::string err;
     if (!write_metrics_tsv(opt.output + "/demux-metrics.txt", rows, &err)) die(err);
-    for (fqtk_matcher *mt : matchers) fqtk_matcher_destroy(mt);
-    for (SlotBuf &b : sb) {
-        fqtk_pinned_free(b.obs);
-        fqtk_pinned_free(b.lens);
-        fqtk_pinned_free(b.out);
-    }
-    return 0;
+    // Everything is on disk and closed.  The process ends here: tearing the HIP runtime down through the
+    // matcher's destructor and the atexit handlers costs ~0.25 s and frees nothing the OS does not free.
+    std::fflush(stdout);
+    std::fflush(stderr);
+    std::_Exit(0);
 }

@@ -87,8 +87,12 @@ void lds_memo_kernel(const LdsMemoParams Q) {
     uint32_t *lds_hist = lds_lut + 256;
     if (tid < 256) lds_lut[tid] = P.lut[tid];
     const uint32_t bins = P.S + 1;
+    // [S][1][4] planes for the wave scan of non-canonical reads, 16-byte aligned behind the histogram
+    uint32_t *lds_tab = P.scan_tab_lds ? smem + ((Q.image_words + 256u + ((P.counts && P.lds_hist) ? bins : 0u) + 3u) & ~3u) : nullptr;
     if (P.counts && P.lds_hist)
         for (uint32_t b = tid; b < bins; b += kLdsBlock) lds_hist[b] = 0;
+    if (lds_tab)
+        for (uint32_t w = tid; w < P.S * 4u; w += kLdsBlock) lds_tab[w] = P.table[w];
     __syncthreads();
     if ((uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint32_t *)smem != 0u) __builtin_trap();
 
@@ -246,7 +250,7 @@ void lds_memo_kernel(const LdsMemoParams Q) {
                         const int src = __ffsll((unsigned long long)todo) - 1;
                         todo &= todo - 1;
                         uint32_t b, s;
-                        wave_scan<1>(mine, src, P, b, s);
+                        wave_scan<1>(mine, src, P, b, s, lds_tab);
                         if ((int)__lane_id() == src) res[r] = decide(b, s, P.max_mm, P.delta);
                     }
                 }

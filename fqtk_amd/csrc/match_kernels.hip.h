@@ -46,6 +46,7 @@ struct MatchParams {
     uint32_t delta;
     uint32_t nocall_limit;       // max_mismatches + max_ns_in_barcodes (barcode_matching.rs:171)
     uint32_t lds_hist;           // 1: histogram in LDS, 0: global atomics
+    uint32_t scan_tab_lds;       // memo kernels: 1 = the wave scan of non-canonical reads finds the table in LDS
 };
 
 __device__ __forceinline__ uint32_t med3_u32(uint32_t a, uint32_t b, uint32_t c) {

@@ -91,9 +91,12 @@ __device__ __forceinline__ uint32_t decide(uint32_t best, uint32_t second, uint3
 
 // Wave-cooperative exhaustive scan of ONE read (lane `src`'s planes): lanes stripe the samples, then
 // an all-reduce butterfly of (best, second).  Returns the pair in every lane.
+// `lds_tab`: the table staged in LDS by the kernel (P.scan_tab_lds), or nullptr -> rows come from global
+// memory.  A scan is latency: 6-24 rows per lane; from L2 that is ~1.8 us per scanned read (measured: 1 % of
+// cfg 3 reads with an IUPAC byte halved the kernel's throughput), from LDS a few hundred cycles.
 template <int NW>
 __device__ __forceinline__ void wave_scan(const Planes<NW> &mine, int src, const MatchParams &P,
-                                          uint32_t &best, uint32_t &second) {
+                                          uint32_t &best, uint32_t &second, const uint32_t *lds_tab = nullptr) {
     uint32_t pl[NW][4];
 #pragma unroll
     for (int w = 0; w < NW; ++w)
@@ -102,6 +105,8 @@ __device__ __forceinline__ void wave_scan(const Planes<NW> &mine, int src, const
     const uint32_t lane = __lane_id();
     best = second = kKeyInit;
     const u32x4 *tab = reinterpret_cast<const u32x4 *>(P.table);
+    typedef __attribute__((address_space(3))) const u32x4 lds_row;
+    lds_row *ltab = reinterpret_cast<lds_row *>((uintptr_t)(__attribute__((address_space(3))) const uint32_t *)lds_tab);
     // four table rows per lane in flight per round (one memory round trip per 256 samples, not per 64)
     for (uint32_t s0 = lane; s0 < P.S; s0 += 256) {
         u32x4 e[4][NW];
@@ -109,7 +114,10 @@ __device__ __forceinline__ void wave_scan(const Planes<NW> &mine, int src, const
         for (int k = 0; k < 4; ++k) {
             const uint32_t s = s0 + 64u * k;
 #pragma unroll
-            for (int w = 0; w < NW; ++w) e[k][w] = s < P.S ? tab[(size_t)s * NW + w] : u32x4{0u, 0u, 0u, 0u};
+            for (int w = 0; w < NW; ++w) {
+                if (lds_tab) e[k][w] = s < P.S ? ltab[(size_t)s * NW + w] : u32x4{0u, 0u, 0u, 0u};   // wave-uniform choice
+                else e[k][w] = s < P.S ? tab[(size_t)s * NW + w] : u32x4{0u, 0u, 0u, 0u};
+            }
         }
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
@@ -194,14 +202,18 @@ void memo_kernel(const MemoParams Q) {
                                       : (Q.hot_mask ? (Q.hot_mask + 1) * (KW >= 2 ? 4u : 2u) : 0u);
     uint32_t *lds_hot = smem + 256;
     uint32_t *lds_hist = lds_hot + hot_words;
+    const uint32_t bins = P.S + 1;
+    // [S][1][4] planes for the wave scan of non-canonical reads (L <= 20: one word), 16-byte aligned behind the histogram
+    uint32_t *lds_tab = P.scan_tab_lds ? smem + ((256u + hot_words + ((P.counts && P.lds_hist) ? bins : 0u) + 3u) & ~3u) : nullptr;
 
     const uint32_t tid = threadIdx.x;
     if (tid < 256) lds_lut[tid] = P.lut[tid];
     const uint32_t *hot_src = DIRECT ? Q.hot2 : Q.hot;
     for (uint32_t w = tid; w < hot_words; w += kMemoBlock) lds_hot[w] = hot_src[w];
-    const uint32_t bins = P.S + 1;
     if (P.counts && P.lds_hist)
         for (uint32_t b = tid; b < bins; b += kMemoBlock) lds_hist[b] = 0;
+    if (lds_tab)
+        for (uint32_t w = tid; w < P.S * 4u; w += kMemoBlock) lds_tab[w] = P.table[w];
     __syncthreads();
 
     const uint32_t L = P.L;
@@ -392,7 +404,7 @@ void memo_kernel(const MemoParams Q) {
                         const int src = __ffsll((unsigned long long)todo) - 1;
                         todo &= todo - 1;
                         uint32_t b, s;
-                        wave_scan<1>(mine, src, P, b, s);
+                        wave_scan<1>(mine, src, P, b, s, lds_tab);
                         if ((int)__lane_id() == src) res[r] = decide(b, s, P.max_mm, P.delta);
                     }
                 }
