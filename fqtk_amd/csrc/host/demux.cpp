@@ -87,7 +87,7 @@ struct Options {
     unsigned long max_mismatches = 1, min_mismatch_delta = 2, threads = 8, compression_level = 5;
     int device = 0;
     std::vector<int> devices;        // --devices a,b,..: chunk k goes to devices[k mod G]
-    unsigned long chunk_reads = 1ul << 18;
+    unsigned long chunk_reads = 1ul << 17;
 };
 
 const char *kUsage =
@@ -106,7 +106,7 @@ const char *kUsage =
     "  -S, --skip-reasons <REASON>...              too-few-bases\n"
     "      --device <N>                            GPU to use [default: 0] (additive flag)\n"
     "      --devices <A,B,..>                      several GPUs: chunk k is matched on devices[k mod G] (additive flag)\n"
-    "      --chunk-reads <N>                       templates per GPU chunk [default: 262144] (additive flag)\n";
+    "      --chunk-reads <N>                       templates per GPU chunk [default: 131072] (additive flag)\n";
 
 bool parse_ulong(const std::string &s, unsigned long *out) {
     if (s.empty()) return false;
@@ -569,9 +569,9 @@ int main(int argc, char **argv) {
     // ---- stage C: routers (partitioned by sample: one owner per file, input order kept) format the
     //      records; a shared pool BGZF-compresses the 64 KiB blocks and writes them in order ---------
     const size_t n_threads_c = std::max<size_t>(2, opt.threads - 1);
-    // Formatting a template costs ~1.2 us of router time, compressing its ~680 bytes at level 5 ~5.7 us of
-    // libdeflate time (measured, FQTK_TIMING): one router feeds four to five compressors.
-    const size_t n_workers = std::max<size_t>(1, (n_threads_c + 2) / 5);    // routers
+    // Formatting a template costs ~1.15 us of router time, compressing its ~680 bytes at level 5 ~5.2 us of
+    // libdeflate time (measured, FQTK_TIMING, 16 M dual-index templates): two routers feed seven compressors.
+    const size_t n_workers = std::max<size_t>(1, (n_threads_c * 2 + 4) / 9);   // routers
     const size_t n_comp = std::max<size_t>(1, n_threads_c - n_workers);     // compressors
     // Output files fill in lock-step (samples are hit in proportion, so hundreds of files reach a full
     // 64 KiB block within the same few chunks): the queue must absorb such a burst or the routers stall
@@ -594,25 +594,34 @@ int main(int argc, char **argv) {
             }
         });
     std::vector<std::unique_ptr<BoundedQueue<std::shared_ptr<Chunk>>>> wq;
-    for (size_t w = 0; w < n_workers; ++w) wq.push_back(std::make_unique<BoundedQueue<std::shared_ptr<Chunk>>>(4));
+    for (size_t w = 0; w < n_workers; ++w) wq.push_back(std::make_unique<BoundedQueue<std::shared_ptr<Chunk>>>(8));
+    // Which router owns which output file.  One owner per file keeps every file in input order without locks;
+    // WHICH owner is decided when the first chunk comes back from the GPU, by the per-sample counts of that
+    // chunk (longest-processing-time-first over the files): samples are far from equally popular -- the
+    // unmatched pair alone takes 10-20 % of the records -- and a modulo assignment left one router with twice the
+    // work of the others.  Written once by the main thread before chunk 0 is handed to the routers.
+    std::vector<uint16_t> file_owner(n_outs, 0);
     std::vector<std::thread> workers;
     for (size_t w = 0; w < n_workers; ++w)
         workers.emplace_back([&, w] {
-            // this router owns output file f (all samples) iff f % n_workers == w: one owner per file
             struct Owned { int k; uint32_t j; };
             std::vector<std::vector<Owned>> owned(S + 1);
-            for (size_t s = 0; s <= S; ++s)
-                for (int k = 0; k < 4; ++k) {
-                    if (!plan.want[k]) continue;
-                    for (uint32_t j = 0; j < plan.by_type[k].size(); ++j)
-                        if ((s * plan.files_per_sample + plan.file_base[k] + j) % n_workers == w) owned[s].push_back({k, j});
-                }
+            bool have_plan = false;
             std::vector<std::string_view> bsegs, msegs;
             for (;;) {
                 const uint64_t tw = tick();
                 std::shared_ptr<Chunk> ch = wq[w]->pop();
                 const uint64_t tf = tick();
                 g_times.router_wait += tf - tw;
+                if (ch && !have_plan) {   // file_owner is final once a chunk has been queued
+                    have_plan = true;
+                    for (size_t s = 0; s <= S; ++s)
+                        for (int k = 0; k < 4; ++k) {
+                            if (!plan.want[k]) continue;
+                            for (uint32_t j = 0; j < plan.by_type[k].size(); ++j)
+                                if (file_owner[s * plan.files_per_sample + plan.file_base[k] + j] == w) owned[s].push_back({k, j});
+                        }
+                }
                 if (!ch) break;
                 uint64_t t_sub = 0;
                 const RecBatch &b0 = *ch->batches[0];   // header of the FIRST input (combine_readsets, demux.rs:126-139)
@@ -653,7 +662,8 @@ int main(int argc, char **argv) {
                 g_times.router_submit += t_sub;
                 g_times.router_format += tick() - tf - t_sub;
             }
-            for (size_t f = w; f < outs.size(); f += n_workers) submit_blocks(outs[f], jobs, true);
+            for (size_t f = 0; f < outs.size(); ++f)
+                if (file_owner[f] == w) submit_blocks(outs[f], jobs, true);
         });
 
     // ---- stage B (this thread): chunk assembly, barcode SoA packing, GPU pipeline -------------------
@@ -680,6 +690,7 @@ int main(int argc, char **argv) {
         }
     };
     struct Pending { std::shared_ptr<Chunk> chunk; std::vector<uint32_t> rows; int slot = -1; bool identity = false; size_t n_rows = 0; };
+    bool owners_assigned = false;
     auto finish = [&](Pending &p) {
         if (!p.chunk) return;
         if (p.slot >= 0) {
@@ -689,6 +700,25 @@ int main(int argc, char **argv) {
             g_times.main_gpu_wait += tick() - tg;
             if (p.identity) std::memcpy(p.chunk->res.data(), sb[p.slot].out, p.n_rows * sizeof(fqtk_match_t));   // no skipped template
             else for (size_t j = 0; j < p.rows.size(); ++j) p.chunk->res[p.rows[j]] = sb[p.slot].out[j];
+        }
+        if (!owners_assigned) {   // first chunk back from the GPU: balance the files over the routers by its counts
+            owners_assigned = true;
+            std::vector<uint64_t> cnt(S + 1, 0);
+            for (size_t j = 0; j < p.chunk->n; ++j)
+                if (!p.chunk->skip[j]) ++cnt[p.chunk->res[j].idx == FQTK_NO_MATCH ? S : p.chunk->res[j].idx];
+            std::vector<size_t> order(n_outs);
+            for (size_t f = 0; f < n_outs; ++f) order[f] = f;
+            auto weight = [&](size_t f) { return cnt[f / plan.files_per_sample]; };
+            std::stable_sort(order.begin(), order.end(), [&](size_t a, size_t b) { return weight(a) > weight(b); });
+            std::vector<uint64_t> load(n_workers, 0);
+            size_t rr = 0;
+            for (size_t f : order) {
+                size_t best = 0;
+                if (weight(f) == 0) best = rr++ % n_workers;   // nothing seen yet: spread evenly
+                else for (size_t w = 1; w < n_workers; ++w) if (load[w] < load[best]) best = w;
+                file_owner[f] = (uint16_t)best;
+                load[best] += weight(f) + 1;
+            }
         }
         const uint64_t th = tick();
         for (size_t w = 0; w < n_workers; ++w) wq[w]->push(p.chunk);
