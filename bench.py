@@ -71,7 +71,7 @@ def cpu_rows(cfg_id: int, cfg, seconds: float, pool):
         "value": round(done / t / 1e6, 4), "unit": "M reads/s", "cores": 1, "kind": "port", "row": "C1",
         "sample": f"first {done} reads of the same synthetic workload, oracle/ref_literal.c (gcc -O3 -march=native), "
                   f"memo cache on (hit rate {hits / max(hits + misses, 1):.3f}), {t:.1f} s of CPU work; "
-                  f"host has {os.cpu_count()} logical cores",
+                  f"host shows {os.cpu_count()} logical CPUs, {effective_cpus()} usable (affinity / cgroup quota)",
     }
     d2, t2, _, _ = _cpu_worker((cfg_id, cfg.max_mismatches, cfg.min_mismatch_delta, False, 0, min(seconds, 5.0), 50_000_000))
     out["cache_off_1core"] = {"value": round(d2 / t2 / 1e6, 4), "unit": "M reads/s", "cores": 1, "row": "C2",
@@ -82,7 +82,7 @@ def cpu_rows(cfg_id: int, cfg, seconds: float, pool):
                  5_000_000) for i in range(procs)]
         res = pool.map(_cpu_worker, jobs)
         out["all_cores"] = {"value": round(sum(d / tt for d, tt, _, _ in res) / 1e6, 2), "unit": "M reads/s", "cores": procs,
-                            "sample": f"{procs} processes (own matcher + memo cache + slice each), "
+                            "sample": f"{procs} processes (own matcher + memo cache + slice each) on {effective_cpus()} usable CPUs, "
                                       f"{sum(d for d, _, _, _ in res)} reads; sum of per-process rates"}
     return out
 
@@ -149,6 +149,25 @@ def pmc_traffic(cfg_id: int, n: int, kernel_name: str):
     return None
 
 
+def effective_cpus() -> int:
+    """Logical CPUs this process may actually use: the affinity mask, capped by the cgroup CPU quota
+    (cpu.max / cfs_quota) -- the GPU boxes of this pool show 256 logical CPUs under a 16-CPU quota."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                n = min(n, max(1, q // per))
+        except (OSError, ValueError):
+            pass
+    return n
+
+
 def kernel_sources_digest() -> str:
     h = hashlib.sha1()
     d = os.path.join(ROOT, "fqtk_amd", "csrc")
@@ -189,7 +208,7 @@ def main() -> int:
     ap.add_argument("--no-scopes", action="store_true", help="skip scopes B and E")
     ap.add_argument("--e2e-templates", type=int, default=16_000_000,
                     help="templates of the scope E run (multiples of 1 M above 1 M: the first 1 M templates repeated)")
-    ap.add_argument("--e2e-threads", type=int, default=32)
+    ap.add_argument("--e2e-threads", type=int, default=0, help="--threads of the scope E run (default: the usable CPUs, at most 32)")
     ap.add_argument("--e2e-gz", action="store_true", help="gzip the scope E inputs (single-stream gunzip per file)")
     ap.add_argument("--lens", action="store_true", help="pass an obs_len array (all == L): the variable-length '+B' path")
     ap.add_argument("--max-mismatches", type=int, default=-1, help="override the config's value (exploration only)")
@@ -313,19 +332,19 @@ def main() -> int:
         assert int(job_counts.sum()) == job_reads * args.steps, "all-reduced counts do not add up to the job's reads"
     assert np.all(job_counts % args.steps == 0), "the K passes over the same batch disagree with each other"
     mode = "none" if args.no_verify else (args.parity or ("full" if world == 1 else "windows"))
-    host_cores = os.cpu_count() or 2
+    host_cores = effective_cpus()
     pool = None
     if rank == 0 and (mode == "full" or (world == 1 and args.cpu_seconds > 0)):
         import multiprocessing as mp
         from oracle import oracle as O
         O.build(native=True)                       # once, before the workers all ask for it
-        n_procs = max(1, min(128, host_cores // 2))
+        n_procs = max(1, min(128, host_cores))
         pool = mp.get_context("spawn").Pool(n_procs)
         pool.n_procs = n_procs
     parity = None
     if rank == 0 and mode == "full":
         # the oracle must finish in about a minute: on a small host the count vector covers a prefix only
-        budget = job_reads if host_cores >= 32 else min(job_reads, 50_000_000)
+        budget = job_reads if host_cores >= 12 else min(job_reads, 50_000_000)
         if budget == job_reads:
             parity = parity_gate(pool, args.config, cfg, job_reads, min(n, 50_000_000), d_out, job_counts // args.steps)
         else:
@@ -412,7 +431,9 @@ def main() -> int:
                     res = pool.map(_parity_worker, [(3, 1, 2, 0, lo, min(lo + 250_000, uniq), 0, None)
                                                     for lo in range(0, uniq, 250_000)])
                     expect = sum((r[1] for r in res), np.zeros(385, dtype=np.uint64)) * np.uint64(n_e // uniq)
-                scopes["E"] = scope_bench.scope_e(n_e, args.e2e_threads, args.e2e_gz, tmp, expect, repeat_first_block=rep)
+                e_threads = args.e2e_threads or max(5, min(32, host_cores))
+                scopes["E"] = scope_bench.scope_e(n_e, e_threads, args.e2e_gz, tmp, expect, repeat_first_block=rep)
+                scopes["E"]["host_cpus_usable"] = host_cores
             finally:
                 shutil.rmtree(tmp, ignore_errors=True)
             out["scopes"] = scopes

@@ -16,6 +16,13 @@ class fqtk_match_t(C.Structure):
     _fields_ = [("idx", C.c_uint16), ("best", C.c_uint8), ("next", C.c_uint8)]
 
 
+class fqtk_bgzf_block(C.Structure):   # include/fqtk_bgzf.h
+    _fields_ = [("in_", C.c_void_p), ("out", C.c_void_p), ("n_in", C.c_uint32), ("reserved", C.c_uint32)]
+
+
+FQTK_BGZF_MAX_IN, FQTK_BGZF_OUT_STRIDE, FQTK_BGZF_SLOTS = 65280, 65536, 4
+
+
 _lib = None
 _hip_preloaded = False
 
@@ -72,6 +79,12 @@ SIGNATURES = [
     ("fqtk_matcher_wait", C.c_int, [C.c_void_p, C.c_int]),
     ("fqtk_matcher_counts", C.c_int, [C.c_void_p, C.c_void_p]),
     ("fqtk_matchers_allreduce_counts", C.c_int, [C.POINTER(C.c_void_p), C.c_int, C.c_int, C.c_void_p]),
+    # include/fqtk_bgzf.h
+    ("fqtk_bgzf_last_error", C.c_char_p, []),
+    ("fqtk_bgzf_create", C.c_int, [C.c_int, C.POINTER(C.c_void_p)]),
+    ("fqtk_bgzf_destroy", None, [C.c_void_p]),
+    ("fqtk_bgzf_deflate_enqueue", C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_uint32, C.c_void_p]),
+    ("fqtk_bgzf_wait", C.c_int, [C.c_void_p, C.c_int]),
 ]
 
 

@@ -1,0 +1,398 @@
+// bgzf_deflate.hpp -- DEFLATE block compressor for BGZF output, written for one 256-lane workgroup per block.
+//
+// SURVEY.md section 8(f) row 3 (output side).  End to end `fqtk demux` is bound by BGZF compression on the
+// host (the reference: pooled-writer -> bgzf -> libdeflater, /root/reference/src/bin/commands/demux.rs:755-798)
+// while the GPU matcher idles.  This is the MI355X form of that stage: every <= 65 280-byte block becomes one
+// dynamic-Huffman DEFLATE block (RFC 1951), produced by 256 lanes:
+//   P0  the block is copied into LDS, the LZ hash table and the histograms are cleared
+//   P1  LZ77: every lane parses its own 256-byte slice greedily against ONE shared hash table of 4-byte
+//       sequences (racy on purpose: a candidate is only a hint and is verified byte by byte, so any stale or
+//       torn entry costs compression, never correctness); tokens go to a global scratch, symbol counts to LDS
+//   P2  one lane builds the two Huffman codes (two-queue construction on the sorted counts, zlib's overflow
+//       rule for the 15-bit limit), the code-length code, and writes the block header
+//   P3  every lane adds up the bits of its tokens; exclusive prefix sum -> its bit offset; if the result would
+//       not be smaller than the input, the block is emitted STORED instead
+//   P4  every lane ORs its tokens' bits into the output image (LDS), the end-of-block code follows
+//   P5  the image is copied out
+// The compressed bytes are unpinned by the reference's tests (they compare decompressed content only,
+// demux.rs:1069-1076); parity here = any inflate implementation returns the input bytes.
+//
+// Plain C++17, no HIP: compiles under hipcc for the device (bgzf_kernel.hip.h runs the phases with barriers
+// in between) and under g++ for the CPU test-suite, which runs the SAME phase functions lane by lane through
+// libfqtk_host.so and inflates the result with zlib.
+#pragma once
+#include <stdint.h>
+#include <string.h>
+
+#if defined(__HIPCC__)
+#define FQTK_HD __host__ __device__
+#else
+#ifndef FQTK_HD
+#define FQTK_HD
+#endif
+#endif
+
+namespace fqtk {
+namespace bgzf {
+
+constexpr int kLanes = 256;
+constexpr uint32_t kMaxIn = 65280;        // uncompressed payload of a BGZF block (as the bgzf crate cuts them)
+constexpr uint32_t kChunk = 256;          // bytes parsed by one lane: 255 lanes x 256 = 65 280
+constexpr uint32_t kHashBits = 14;
+constexpr uint32_t kOutStride = 65536;    // bytes reserved per block in the output arena (stored worst case: n + 5)
+constexpr uint32_t kTokensPerBlock = kLanes * kChunk;   // token scratch, u32 each, [t][lane]
+constexpr int kNumLitLen = 286, kNumDist = 30, kNumCl = 19;
+constexpr int kMinMatch = 4;              // shorter matches cost more bits than their literals on FASTQ
+
+// Everything a block's workgroup shares.  LDS on the device (~107 KiB: one workgroup per CU), heap in the CPU tests.
+struct Shared {
+    uint32_t buf[kOutStride / 4];         // P0-P1: the input bytes.  P2-P5: the output bit stream.
+    uint16_t htab[1u << kHashBits];
+    uint32_t freq_ll[288], freq_d[32];
+    uint16_t code_ll[288], code_d[32];    // bit-reversed canonical codes (appended LSB first)
+    uint8_t len_ll[288], len_d[32];
+    uint32_t lane_bits[kLanes];           // bits of a lane's tokens, then their exclusive prefix sum
+    uint32_t ntok[kLanes];
+    uint32_t header_bits, total_bits, stored;
+    // scratch of the code builder (one lane)
+    uint16_t sorted[288];                 // used symbols, ascending by (count, symbol)
+    uint32_t weight[576];                 // leaves then internal nodes
+    uint16_t parent[576];
+    uint8_t depth[576];
+    uint8_t cl_sym[320], cl_extra[320];   // run-length coded code lengths
+    uint32_t freq_cl[kNumCl];
+    uint16_t code_cl[kNumCl];
+    uint8_t len_cl[kNumCl];
+};
+
+// ---- symbol arithmetic (RFC 1951 3.2.5), computed rather than tabulated -------------------------------------
+FQTK_HD inline int floor_log2(uint32_t x) {   // x >= 1
+    int r = 0;
+    while (x >>= 1) ++r;
+    return r;
+}
+// length 3..258 -> literal/length symbol 257..285, number of extra bits and their value
+FQTK_HD inline void length_symbol(uint32_t len, uint32_t &sym, uint32_t &nextra, uint32_t &extra) {
+    const uint32_t l = len - 3;
+    if (l < 8) { sym = 257 + l; nextra = 0; extra = 0; return; }
+    if (len == 258) { sym = 285; nextra = 0; extra = 0; return; }
+    const int m = floor_log2(l);              // 3..7
+    sym = 265 + 4 * (uint32_t)(m - 3) + ((l >> (m - 2)) & 3u);
+    nextra = (uint32_t)(m - 2);
+    extra = l & ((1u << (m - 2)) - 1u);
+}
+// distance 1..32768 -> distance symbol 0..29, extra bits
+FQTK_HD inline void dist_symbol(uint32_t dist, uint32_t &sym, uint32_t &nextra, uint32_t &extra) {
+    const uint32_t d = dist - 1;
+    if (d < 4) { sym = d; nextra = 0; extra = 0; return; }
+    const int m = floor_log2(d);              // 2..14
+    sym = 2 * (uint32_t)m + ((d >> (m - 1)) & 1u);
+    nextra = (uint32_t)(m - 1);
+    extra = d & ((1u << (m - 1)) - 1u);
+}
+FQTK_HD inline uint32_t reverse_bits(uint32_t code, int len) {
+    uint32_t r = 0;
+    for (int i = 0; i < len; ++i) { r = (r << 1) | (code & 1u); code >>= 1; }
+    return r;
+}
+
+// token: literal = the byte; match = bit 31 | (len - 3) << 16 | (dist - 1)
+FQTK_HD inline uint32_t match_token(uint32_t len, uint32_t dist) { return 0x80000000u | ((len - 3) << 16) | (dist - 1); }
+
+// ---- append bits to the output image -------------------------------------------------------------------------
+// The image is zero before P2; several lanes may touch one word, so words are ORed in (atomic on the device).
+#if defined(__HIP_DEVICE_COMPILE__)
+#define FQTK_BGZF_OR(ptr, v) atomicOr((ptr), (v))
+#define FQTK_BGZF_ADD(ptr, v) atomicAdd((ptr), (v))
+#else
+#define FQTK_BGZF_OR(ptr, v) (*(ptr) |= (v))
+#define FQTK_BGZF_ADD(ptr, v) (*(ptr) += (v))
+#endif
+struct BitWriter {
+    uint32_t *words;
+    uint64_t acc;      // pending bits, aligned to the 32-bit word `word`
+    uint32_t nacc;     // number of valid low bits in acc (including the offset inside the first word)
+    uint32_t word;
+    FQTK_HD void start(uint32_t *w, uint32_t bitpos) { words = w; word = bitpos >> 5; nacc = bitpos & 31u; acc = 0; }
+    FQTK_HD void put(uint32_t value, uint32_t nbits) {   // nbits <= 24
+        acc |= (uint64_t)value << nacc;
+        nacc += nbits;
+        if (nacc >= 32) {
+            FQTK_BGZF_OR(&words[word], (uint32_t)acc);
+            acc >>= 32;
+            nacc -= 32;
+            ++word;
+        }
+    }
+    FQTK_HD void finish() { if (nacc) FQTK_BGZF_OR(&words[word], (uint32_t)acc); }
+    FQTK_HD uint32_t bitpos() const { return (word << 5) + nacc; }
+};
+
+// ---- Huffman code lengths ---------------------------------------------------------------------------------------
+// counts[0..n) -> len[0..n) (0 = unused symbol), no code longer than max_bits, Kraft sum exactly 1 (inflate
+// implementations reject incomplete literal/length sets).  At least two symbols get a code (as zlib does).
+FQTK_HD inline void huffman_lengths(Shared &S, const uint32_t *counts, int n, int max_bits, uint8_t *len) {
+    for (int i = 0; i < n; ++i) len[i] = 0;
+    int m = 0;
+    for (int i = 0; i < n; ++i) {   // insertion sort of the used symbols by (count, symbol)
+        if (!counts[i]) continue;
+        int j = m++;
+        while (j > 0 && counts[S.sorted[j - 1]] > counts[i]) { S.sorted[j] = S.sorted[j - 1]; --j; }
+        S.sorted[j] = (uint16_t)i;
+    }
+    if (m == 0) { len[0] = 1; len[1] = 1; return; }
+    if (m == 1) { len[S.sorted[0]] = 1; len[S.sorted[0] == 0 ? 1 : 0] = 1; return; }
+    // two-queue construction: leaves 0..m-1 in ascending order, internal nodes m.. in creation (= ascending) order
+    for (int i = 0; i < m; ++i) S.weight[i] = counts[S.sorted[i]];
+    int li = 0, ii = m, made = m;
+    for (int k = 0; k < m - 1; ++k) {
+        int pick[2];
+        for (int t = 0; t < 2; ++t) {
+            if (li < m && (ii >= made || S.weight[li] <= S.weight[ii])) pick[t] = li++;
+            else pick[t] = ii++;
+        }
+        S.weight[made] = S.weight[pick[0]] + S.weight[pick[1]];
+        S.parent[pick[0]] = (uint16_t)made;
+        S.parent[pick[1]] = (uint16_t)made;
+        ++made;
+    }
+    const int root = made - 1;
+    S.depth[root] = 0;
+    for (int v = root - 1; v >= 0; --v) {
+        const uint32_t d = (uint32_t)S.depth[S.parent[v]] + 1u;
+        S.depth[v] = (uint8_t)(d > 255u ? 255u : d);
+    }
+    // lengths per depth, zlib's overflow rule for the limit (trees.c gen_bitlen), then the longest codes go to
+    // the rarest symbols
+    uint32_t bl_count[17];
+    for (int b = 0; b <= 16; ++b) bl_count[b] = 0;
+    int overflow = 0;
+    for (int i = 0; i < m; ++i) {
+        int bits = S.depth[i];
+        if (bits > max_bits) { bits = max_bits; ++overflow; }
+        ++bl_count[bits];
+    }
+    while (overflow > 0) {
+        int bits = max_bits - 1;
+        while (bl_count[bits] == 0) --bits;
+        --bl_count[bits];
+        bl_count[bits + 1] += 2;
+        --bl_count[max_bits];
+        overflow -= 2;
+    }
+    int idx = 0;   // sorted[] ascends by count: rarest first
+    for (int bits = max_bits; bits >= 1; --bits)
+        for (uint32_t c = bl_count[bits]; c > 0; --c) len[S.sorted[idx++]] = (uint8_t)bits;
+}
+
+// canonical codes (RFC 1951 3.2.2), stored bit-reversed
+FQTK_HD inline void canonical_codes(const uint8_t *len, int n, int max_bits, uint16_t *code) {
+    uint32_t bl_count[17], next_code[17];
+    for (int b = 0; b <= 16; ++b) bl_count[b] = 0;
+    for (int i = 0; i < n; ++i) ++bl_count[len[i]];
+    bl_count[0] = 0;
+    uint32_t c = 0;
+    for (int b = 1; b <= max_bits; ++b) { c = (c + bl_count[b - 1]) << 1; next_code[b] = c; }
+    for (int i = 0; i < n; ++i) code[i] = len[i] ? (uint16_t)reverse_bits(next_code[len[i]]++, len[i]) : 0;
+}
+
+// ---- the phases ----------------------------------------------------------------------------------------------------
+FQTK_HD inline uint32_t load_le32(const uint8_t *p) {
+    return (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((uint32_t)p[3] << 24);
+}
+FQTK_HD inline uint32_t hash4(uint32_t x) { return (x * 2654435761u) >> (32 - kHashBits); }
+
+// P0: clear the shared state, bring the block in.  `in` may be device or (pinned, device-visible) host memory.
+FQTK_HD inline void phase_load(Shared &S, int lane, const uint8_t *in, uint32_t n) {
+    for (uint32_t i = (uint32_t)lane; i < (1u << kHashBits); i += kLanes) S.htab[i] = 0xFFFFu;
+    for (uint32_t i = (uint32_t)lane; i < 288; i += kLanes) S.freq_ll[i] = 0;
+    if (lane < 32) S.freq_d[lane] = 0;
+    uint8_t *b = reinterpret_cast<uint8_t *>(S.buf);
+    if ((reinterpret_cast<uintptr_t>(in) & 15u) == 0) {
+        const uint32_t n16 = n >> 4;
+        for (uint32_t i = (uint32_t)lane; i < n16; i += kLanes) {
+            const uint32_t *src = reinterpret_cast<const uint32_t *>(in) + 4 * i;
+            uint32_t *dst = S.buf + 4 * i;
+            dst[0] = src[0]; dst[1] = src[1]; dst[2] = src[2]; dst[3] = src[3];
+        }
+        for (uint32_t i = (n16 << 4) + (uint32_t)lane; i < n; i += kLanes) b[i] = in[i];
+    } else {
+        for (uint32_t i = (uint32_t)lane; i < n; i += kLanes) b[i] = in[i];
+    }
+}
+
+// P1: greedy LZ77 over this lane's slice; tokens to tok[t * kLanes + lane]
+FQTK_HD inline void phase_lz(Shared &S, int lane, uint32_t n, uint32_t *tok) {
+    const uint8_t *b = reinterpret_cast<const uint8_t *>(S.buf);
+    uint32_t p = (uint32_t)lane * kChunk;
+    const uint32_t end = p + kChunk < n ? p + kChunk : n;
+    uint32_t nt = 0;
+    while (p < end) {
+        uint32_t mlen = 0, mdist = 0;
+        if (p + 4 <= n) {
+            const uint32_t h = hash4(load_le32(b + p));
+            const uint32_t cand = S.htab[h];
+            S.htab[h] = (uint16_t)p;
+            if (cand < p && p - cand <= 32768u) {
+                const uint32_t maxl = end - p < 258u ? end - p : 258u;   // a match never leaves the lane's slice
+                uint32_t l = 0;
+                while (l < maxl && b[cand + l] == b[p + l]) ++l;
+                if (l >= (uint32_t)kMinMatch) { mlen = l; mdist = p - cand; }
+            }
+        }
+        if (mlen) {
+            uint32_t sym, ne, ev;
+            length_symbol(mlen, sym, ne, ev);
+            FQTK_BGZF_ADD(&S.freq_ll[sym], 1u);
+            dist_symbol(mdist, sym, ne, ev);
+            FQTK_BGZF_ADD(&S.freq_d[sym], 1u);
+            tok[nt * kLanes + (uint32_t)lane] = match_token(mlen, mdist);
+            // the skipped positions are still worth finding later
+            const uint32_t stop = p + mlen;
+            for (uint32_t q = p + 1; q < stop && q + 4 <= n; ++q) S.htab[hash4(load_le32(b + q))] = (uint16_t)q;
+            p = stop;
+        } else {
+            FQTK_BGZF_ADD(&S.freq_ll[b[p]], 1u);
+            tok[nt * kLanes + (uint32_t)lane] = b[p];
+            ++p;
+        }
+        ++nt;
+    }
+    S.ntok[lane] = nt;
+}
+
+// P2a (all lanes): the input copy is no longer needed: the same LDS becomes the (zeroed) output image
+FQTK_HD inline void phase_clear_out(Shared &S, int lane) {
+    for (uint32_t i = (uint32_t)lane; i < kOutStride / 4; i += kLanes) S.buf[i] = 0;
+}
+
+// P2b (one lane): both codes, the code-length code, the block header (BFINAL = 1, BTYPE = 2)
+FQTK_HD inline void phase_codes_and_header(Shared &S) {
+    S.freq_ll[256] = 1;   // end of block
+    huffman_lengths(S, S.freq_ll, kNumLitLen, 15, S.len_ll);
+    huffman_lengths(S, S.freq_d, kNumDist, 15, S.len_d);
+    canonical_codes(S.len_ll, kNumLitLen, 15, S.code_ll);
+    canonical_codes(S.len_d, kNumDist, 15, S.code_d);
+    int hlit = kNumLitLen, hdist = kNumDist;
+    while (hlit > 257 && S.len_ll[hlit - 1] == 0) --hlit;
+    while (hdist > 1 && S.len_d[hdist - 1] == 0) --hdist;
+    // run-length code the hlit + hdist lengths (RFC 1951 3.2.7: 16 = repeat previous 3-6, 17 = 3-10 zeros, 18 = 11-138 zeros)
+    for (int i = 0; i < kNumCl; ++i) S.freq_cl[i] = 0;
+    const int total = hlit + hdist;
+    int nsym = 0, i = 0;
+    while (i < total) {
+        const uint8_t v = i < hlit ? S.len_ll[i] : S.len_d[i - hlit];
+        int run = 1;
+        while (i + run < total && (i + run < hlit ? S.len_ll[i + run] : S.len_d[i + run - hlit]) == v) ++run;
+        int left = run;
+        if (v == 0) {
+            while (left >= 11) { const int r = left < 138 ? left : 138; S.cl_sym[nsym] = 18; S.cl_extra[nsym++] = (uint8_t)(r - 11); left -= r; }
+            if (left >= 3) { S.cl_sym[nsym] = 17; S.cl_extra[nsym++] = (uint8_t)(left - 3); left = 0; }
+            while (left-- > 0) { S.cl_sym[nsym] = 0; S.cl_extra[nsym++] = 0; }
+        } else {
+            S.cl_sym[nsym] = v; S.cl_extra[nsym++] = 0; --left;     // the length itself, then repeats of it
+            while (left >= 3) { const int r = left < 6 ? left : 6; S.cl_sym[nsym] = 16; S.cl_extra[nsym++] = (uint8_t)(r - 3); left -= r; }
+            while (left-- > 0) { S.cl_sym[nsym] = v; S.cl_extra[nsym++] = 0; }
+        }
+        i += run;
+    }
+    for (int k = 0; k < nsym; ++k) ++S.freq_cl[S.cl_sym[k]];
+    huffman_lengths(S, S.freq_cl, kNumCl, 7, S.len_cl);
+    canonical_codes(S.len_cl, kNumCl, 7, S.code_cl);
+    const uint8_t order[kNumCl] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
+    int hclen = kNumCl;
+    while (hclen > 4 && S.len_cl[order[hclen - 1]] == 0) --hclen;
+    BitWriter w;
+    w.start(S.buf, 0);
+    w.put(1, 1);                        // BFINAL
+    w.put(2, 2);                        // BTYPE = dynamic Huffman
+    w.put((uint32_t)(hlit - 257), 5);
+    w.put((uint32_t)(hdist - 1), 5);
+    w.put((uint32_t)(hclen - 4), 4);
+    for (int k = 0; k < hclen; ++k) w.put(S.len_cl[order[k]], 3);
+    for (int k = 0; k < nsym; ++k) {
+        const int s = S.cl_sym[k];
+        w.put(S.code_cl[s], S.len_cl[s]);
+        if (s == 16) w.put(S.cl_extra[k], 2);
+        else if (s == 17) w.put(S.cl_extra[k], 3);
+        else if (s == 18) w.put(S.cl_extra[k], 7);
+    }
+    w.finish();
+    S.header_bits = w.bitpos();
+}
+
+// P3a (all lanes): bits this lane's tokens will take
+FQTK_HD inline void phase_count_bits(Shared &S, int lane, const uint32_t *tok) {
+    uint32_t bits = 0;
+    const uint32_t nt = S.ntok[lane];
+    for (uint32_t t = 0; t < nt; ++t) {
+        const uint32_t k = tok[t * kLanes + (uint32_t)lane];
+        if (k & 0x80000000u) {
+            uint32_t sym, ne, ev;
+            length_symbol(((k >> 16) & 0xFFu) + 3, sym, ne, ev);
+            bits += S.len_ll[sym] + ne;
+            dist_symbol((k & 0x7FFFu) + 1, sym, ne, ev);
+            bits += S.len_d[sym] + ne;
+        } else {
+            bits += S.len_ll[k];
+        }
+    }
+    S.lane_bits[lane] = bits;
+}
+// P3b (one lane): exclusive prefix sum, total size, stored-block decision
+FQTK_HD inline void phase_offsets(Shared &S, uint32_t n) {
+    uint32_t run = S.header_bits;
+    for (int l = 0; l < kLanes; ++l) { const uint32_t b = S.lane_bits[l]; S.lane_bits[l] = run; run += b; }
+    S.total_bits = run + S.len_ll[256];
+    S.stored = ((S.total_bits + 7) >> 3) >= n + 5 ? 1u : 0u;
+}
+
+// P4 (all lanes): the tokens' bits; lane 0 also appends the end-of-block code
+FQTK_HD inline void phase_emit(Shared &S, int lane, const uint32_t *tok) {
+    if (S.stored) return;
+    BitWriter w;
+    w.start(S.buf, S.lane_bits[lane]);
+    const uint32_t nt = S.ntok[lane];
+    for (uint32_t t = 0; t < nt; ++t) {
+        const uint32_t k = tok[t * kLanes + (uint32_t)lane];
+        if (k & 0x80000000u) {
+            uint32_t sym, ne, ev;
+            length_symbol(((k >> 16) & 0xFFu) + 3, sym, ne, ev);
+            w.put(S.code_ll[sym], S.len_ll[sym]);
+            if (ne) w.put(ev, ne);
+            dist_symbol((k & 0x7FFFu) + 1, sym, ne, ev);
+            w.put(S.code_d[sym], S.len_d[sym]);
+            if (ne) w.put(ev, ne);
+        } else {
+            w.put(S.code_ll[k], S.len_ll[k]);
+        }
+    }
+    w.finish();
+    if (lane == 0) {
+        BitWriter e;
+        e.start(S.buf, S.total_bits - S.len_ll[256]);
+        e.put(S.code_ll[256], S.len_ll[256]);
+        e.finish();
+    }
+}
+
+// P5 (all lanes): the payload leaves LDS (or, stored: 5 header bytes + the raw input).  Returns the payload size.
+FQTK_HD inline uint32_t phase_store(Shared &S, int lane, const uint8_t *in, uint32_t n, uint8_t *out) {
+    if (S.stored) {
+        if (lane == 0) {
+            out[0] = 1;                                   // BFINAL = 1, BTYPE = 00, padding
+            out[1] = (uint8_t)(n & 0xFF); out[2] = (uint8_t)(n >> 8);
+            out[3] = (uint8_t)(~n & 0xFF); out[4] = (uint8_t)((~n >> 8) & 0xFF);
+        }
+        for (uint32_t i = (uint32_t)lane; i < n; i += kLanes) out[5 + i] = in[i];
+        return n + 5;
+    }
+    const uint32_t bytes = (S.total_bits + 7) >> 3;
+    const uint32_t words = (bytes + 3) >> 2;              // out is 4-byte aligned and kOutStride long
+    uint32_t *o = reinterpret_cast<uint32_t *>(out);
+    for (uint32_t i = (uint32_t)lane; i < words; i += kLanes) o[i] = S.buf[i];
+    return bytes;
+}
+
+}  // namespace bgzf
+}  // namespace fqtk

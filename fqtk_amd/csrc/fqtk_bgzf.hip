@@ -1,0 +1,137 @@
+// fqtk_bgzf.hip -- device side and C ABI (include/fqtk_bgzf.h) of the BGZF block compressor.
+// The algorithm lives in bgzf_deflate.hpp (phase functions shared with the CPU test-suite); this file runs
+// the phases of one block on one 256-lane workgroup with barriers in between.
+#include <hip/hip_runtime.h>
+
+#include <new>
+#include <string>
+
+#include "../../include/fqtk_bgzf.h"
+#include "../../include/fqtk_match.h"
+#include "bgzf_deflate.hpp"
+
+namespace fqtk {
+namespace bgzf {
+
+__global__ __launch_bounds__(kLanes) void deflate_kernel(const fqtk_bgzf_block *blocks, uint32_t n_blocks,
+                                                         uint32_t *out_len, uint32_t *tok_all) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem_raw[];
+    Shared &S = *reinterpret_cast<Shared *>(smem_raw);
+    const int lane = (int)threadIdx.x;
+    uint32_t *tok = tok_all + (size_t)blockIdx.x * kTokensPerBlock;   // token scratch of this workgroup
+    for (uint32_t j = blockIdx.x; j < n_blocks; j += gridDim.x) {
+        const uint8_t *in = blocks[j].in;
+        uint8_t *out = blocks[j].out;
+        const uint32_t n = blocks[j].n_in;
+        phase_load(S, lane, in, n);
+        __syncthreads();
+        phase_lz(S, lane, n, tok);
+        __syncthreads();
+        phase_clear_out(S, lane);
+        __syncthreads();
+        if (lane == 0) phase_codes_and_header(S);
+        __syncthreads();
+        phase_count_bits(S, lane, tok);
+        __syncthreads();
+        if (lane == 0) phase_offsets(S, n);
+        __syncthreads();
+        phase_emit(S, lane, tok);
+        __syncthreads();
+        const uint32_t bytes = phase_store(S, lane, in, n, out);
+        if (lane == 0) out_len[j] = bytes;
+        __syncthreads();   // S is reused by the next block
+    }
+}
+
+}  // namespace bgzf
+}  // namespace fqtk
+
+namespace {
+thread_local std::string g_bgzf_error;
+int bfail(int code, const std::string &msg) { g_bgzf_error = msg; return code; }
+#define BGZF_TRY(expr)                                                                       \
+    do {                                                                                     \
+        hipError_t _e = (expr);                                                              \
+        if (_e != hipSuccess) return bfail(FQTK_EHIP, std::string(#expr) + ": " + hipGetErrorString(_e)); \
+    } while (0)
+}  // namespace
+
+struct fqtk_bgzf {
+    int device = 0;
+    int num_cus = 256;
+    hipStream_t streams[FQTK_BGZF_SLOTS] = {};
+    uint32_t *d_tok[FQTK_BGZF_SLOTS] = {};   // per slot: one token scratch per resident workgroup
+    bool busy[FQTK_BGZF_SLOTS] = {};
+};
+
+extern "C" {
+
+const char *fqtk_bgzf_last_error(void) { return g_bgzf_error.c_str(); }
+
+int fqtk_bgzf_create(int device, fqtk_bgzf **out) {
+    if (!out) return bfail(FQTK_EINVAL, "out is NULL");
+    *out = nullptr;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
+        (void)hipGetLastError();
+        return bfail(FQTK_ENODEV, "no HIP device available (the BGZF compressor has no CPU fallback)");
+    }
+    if (device < 0 || device >= ndev) return bfail(FQTK_ENODEV, "device index out of range");
+    BGZF_TRY(hipSetDevice(device));
+    fqtk_bgzf *z = new (std::nothrow) fqtk_bgzf();
+    if (!z) return bfail(FQTK_ENOMEM, "out of host memory");
+    z->device = device;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) z->num_cus = prop.multiProcessorCount;
+    const void *fn = reinterpret_cast<const void *>(fqtk::bgzf::deflate_kernel);
+    if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(fqtk::bgzf::Shared)) != hipSuccess) {
+        delete z;
+        return bfail(FQTK_EHIP, "cannot reserve LDS for the BGZF kernel");
+    }
+    for (int s = 0; s < FQTK_BGZF_SLOTS; ++s) {
+        if (hipStreamCreateWithFlags(&z->streams[s], hipStreamNonBlocking) != hipSuccess ||
+            hipMalloc(reinterpret_cast<void **>(&z->d_tok[s]), (size_t)z->num_cus * fqtk::bgzf::kTokensPerBlock * sizeof(uint32_t)) != hipSuccess) {
+            fqtk_bgzf_destroy(z);
+            return bfail(FQTK_EHIP, "cannot allocate the BGZF compressor's streams / scratch");
+        }
+    }
+    *out = z;
+    return FQTK_OK;
+}
+
+void fqtk_bgzf_destroy(fqtk_bgzf *z) {
+    if (!z) return;
+    (void)hipSetDevice(z->device);
+    for (int s = 0; s < FQTK_BGZF_SLOTS; ++s) {
+        if (z->streams[s]) { (void)hipStreamSynchronize(z->streams[s]); (void)hipStreamDestroy(z->streams[s]); }
+        if (z->d_tok[s]) (void)hipFree(z->d_tok[s]);
+    }
+    delete z;
+}
+
+int fqtk_bgzf_deflate_enqueue(fqtk_bgzf *z, int slot, const fqtk_bgzf_block *blocks, uint32_t n, uint32_t *out_len) {
+    if (!z) return bfail(FQTK_EINVAL, "compressor is NULL");
+    if (slot < 0 || slot >= FQTK_BGZF_SLOTS) return bfail(FQTK_EINVAL, "slot out of range");
+    if (z->busy[slot]) return bfail(FQTK_EINVAL, "slot is busy: call fqtk_bgzf_wait() first");
+    if (n == 0) return FQTK_OK;
+    if (!blocks || !out_len) return bfail(FQTK_EINVAL, "blocks / out_len is NULL");
+    BGZF_TRY(hipSetDevice(z->device));
+    const uint32_t grid = n < (uint32_t)z->num_cus ? n : (uint32_t)z->num_cus;   // one workgroup per CU (107 KiB of LDS each)
+    hipLaunchKernelGGL(fqtk::bgzf::deflate_kernel, dim3(grid), dim3(fqtk::bgzf::kLanes), sizeof(fqtk::bgzf::Shared),
+                       z->streams[slot], blocks, n, out_len, z->d_tok[slot]);
+    BGZF_TRY(hipGetLastError());
+    z->busy[slot] = true;
+    return FQTK_OK;
+}
+
+int fqtk_bgzf_wait(fqtk_bgzf *z, int slot) {
+    if (!z) return bfail(FQTK_EINVAL, "compressor is NULL");
+    if (slot < 0 || slot >= FQTK_BGZF_SLOTS) return bfail(FQTK_EINVAL, "slot out of range");
+    if (!z->busy[slot]) return FQTK_OK;
+    BGZF_TRY(hipSetDevice(z->device));
+    BGZF_TRY(hipStreamSynchronize(z->streams[slot]));
+    z->busy[slot] = false;
+    return FQTK_OK;
+}
+
+}  // extern "C"

@@ -14,6 +14,7 @@
 #include "samples.hpp"
 #include "../lds_memo_plan.hpp"
 #include "../direct_memo_plan.hpp"
+#include "../bgzf_deflate.hpp"
 
 using namespace fqtk_host;
 
@@ -208,5 +209,27 @@ int fqtk_host_direct_memo(uint32_t S, uint32_t L, uint64_t n_ents, const uint32_
         cached[i] = c ? 1 : 0;
     }
     return 0;
+}
+
+// The GPU BGZF compressor's phase functions (csrc/bgzf_deflate.hpp) run lane by lane on the CPU -- the same
+// code the HIP kernel runs with barriers in between.  Test infrastructure: lets the CPU suite inflate what
+// the algorithm produces (zlib) without a GPU.  Returns the DEFLATE payload size, or -1 on a bad argument.
+int64_t fqtk_host_bgzf_deflate_emulated(const uint8_t *in, uint32_t n, uint8_t *out, size_t cap, int *stored) {
+    using namespace fqtk::bgzf;
+    if (n == 0 || n > kMaxIn || cap < kOutStride) return -1;
+    std::vector<uint8_t> mem(sizeof(Shared));
+    Shared &S = *reinterpret_cast<Shared *>(mem.data());
+    std::vector<uint32_t> tok(kTokensPerBlock);
+    for (int l = 0; l < kLanes; ++l) phase_load(S, l, in, n);
+    for (int l = 0; l < kLanes; ++l) phase_lz(S, l, n, tok.data());
+    for (int l = 0; l < kLanes; ++l) phase_clear_out(S, l);
+    phase_codes_and_header(S);
+    for (int l = 0; l < kLanes; ++l) phase_count_bits(S, l, tok.data());
+    phase_offsets(S, n);
+    for (int l = 0; l < kLanes; ++l) phase_emit(S, l, tok.data());
+    uint32_t bytes = 0;
+    for (int l = 0; l < kLanes; ++l) bytes = phase_store(S, l, in, n, out);
+    if (stored) *stored = (int)S.stored;
+    return (int64_t)bytes;
 }
 }  // extern "C"

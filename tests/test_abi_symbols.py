@@ -12,23 +12,30 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def _declared_symbols():
-    src = open(os.path.join(ROOT, "include", "fqtk_match.h")).read()
-    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
-    return sorted(set(re.findall(r"\b(fqtk_[a-z0-9_]+)\s*\(", src)))
+    """Every function any header under include/ declares (fqtk_match.h: the matcher; fqtk_bgzf.h: the BGZF compressor)."""
+    syms = set()
+    for h in sorted(os.listdir(os.path.join(ROOT, "include"))):
+        if not h.endswith(".h"):
+            continue
+        src = open(os.path.join(ROOT, "include", h)).read()
+        src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+        syms |= set(re.findall(r"\b(fqtk_[a-z0-9_]+)\s*\(", src))
+    return sorted(syms)
 
 
 def test_header_declares_expected_entry_points():
     syms = _declared_symbols()
     for must in ["fqtk_matcher_create", "fqtk_matcher_assign_batch", "fqtk_matcher_assign_batch_device",
                  "fqtk_matcher_assign1", "fqtk_matcher_destroy", "fqtk_last_error", "fqtk_pinned_alloc",
-                 "fqtk_matcher_enqueue", "fqtk_matcher_wait", "fqtk_matcher_counts"]:
+                 "fqtk_matcher_enqueue", "fqtk_matcher_wait", "fqtk_matcher_counts", "fqtk_matchers_allreduce_counts",
+                 "fqtk_bgzf_create", "fqtk_bgzf_deflate_enqueue", "fqtk_bgzf_wait", "fqtk_bgzf_destroy"]:
         assert must in syms
 
 
 def test_library_exports_every_declared_symbol():
     lib = C.CDLL(_lib.LIB_PATH)
     for name in _declared_symbols():
-        assert hasattr(lib, name), f"{name} declared in include/fqtk_match.h but not exported"
+        assert hasattr(lib, name), f"{name} declared under include/ but not exported"
 
 
 def test_binding_covers_every_declared_symbol():

@@ -1,0 +1,95 @@
+"""The GPU BGZF block compressor's algorithm (fqtk_amd/csrc/bgzf_deflate.hpp), no GPU: the phase functions the
+HIP kernel runs are executed lane by lane through libfqtk_host.so, and zlib must inflate every payload back to
+the input -- FASTQ-like text, every block size around the lane / chunk boundaries, degenerate alphabets (code
+length limit, single symbol, no matches), incompressible data (stored block)."""
+import ctypes as C
+import zlib
+
+import numpy as np
+import pytest
+
+from tests import hostlib
+
+MAX_IN = 65280
+
+
+def deflate(data: bytes):
+    lib = hostlib.lib()
+    fn = lib.fqtk_host_bgzf_deflate_emulated
+    fn.restype = C.c_int64
+    out = (C.c_uint8 * 65536)()
+    stored = C.c_int(0)
+    n = fn(data, C.c_uint32(len(data)), out, C.c_size_t(65536), C.byref(stored))
+    assert n > 0
+    return bytes(out[:n]), bool(stored.value)
+
+
+def roundtrip(data: bytes):
+    payload, stored = deflate(data)
+    assert zlib.decompress(payload, -15) == data
+    assert len(payload) <= len(data) + 5
+    return len(payload), stored
+
+
+def fastq_text(n_records, rng, read_len=150, qual=b"I"):
+    recs = []
+    for i in range(n_records):
+        s = bytes(np.frombuffer(b"ACGT", dtype=np.uint8)[rng.integers(0, 4, read_len)])
+        q = qual * read_len if len(qual) == 1 else bytes(np.frombuffer(qual, dtype=np.uint8)[rng.integers(0, len(qual), read_len)])
+        recs.append(b"@inst:1:FC:1:%010d 1:N:0:ACGTACGT+TTGCAATG\n%s\n+\n%s\n" % (i, s, q))
+    return b"".join(recs)
+
+
+def test_fastq_blocks_round_trip_and_compress():
+    rng = np.random.default_rng(1)
+    text = fastq_text(400, rng)
+    sizes = []
+    for off in range(0, len(text) - MAX_IN, MAX_IN):
+        n, stored = roundtrip(text[off:off + MAX_IN])
+        assert not stored
+        sizes.append(n / MAX_IN)
+    # constant quality, random bases: ~2 bits per base + cheap headers/qualities -> well under a third
+    assert max(sizes) < 0.33, sizes
+    # realistic quality strings (a dozen distinct values): still a real compressor, not a stored-block emitter
+    text = fastq_text(200, rng, qual=b"FFFFFFFF:,#IIJJ")
+    n, stored = roundtrip(text[:MAX_IN])
+    assert not stored and n / MAX_IN < 0.6
+
+
+@pytest.mark.parametrize("n", [1, 2, 3, 4, 5, 255, 256, 257, 511, 512, 513, 4095, 4096, 65279, 65280])
+def test_every_size_around_the_lane_boundaries(n):
+    rng = np.random.default_rng(n)
+    text = fastq_text(n // 300 + 2, rng)[:n]
+    roundtrip(text)
+    roundtrip(bytes(rng.integers(0, 256, n, dtype=np.uint8)))       # random bytes
+    roundtrip(b"A" * n)                                             # one symbol, long runs
+    roundtrip((b"ACGT" * (n // 4 + 1))[:n])                         # period 4
+
+
+def test_incompressible_data_is_stored_and_degenerate_alphabets_are_valid():
+    rng = np.random.default_rng(9)
+    n, stored = roundtrip(bytes(rng.integers(0, 256, MAX_IN, dtype=np.uint8)))
+    assert stored and n == MAX_IN + 5
+    # two symbols, no repeats longer than 3: literals only, a 2-symbol literal code + end of block
+    roundtrip(bytes(np.frombuffer(b"AC", dtype=np.uint8)[rng.integers(0, 2, 5000)]))
+    # Fibonacci-like counts force the 15-bit length limit (zlib's overflow rule)
+    fib = [1, 1]
+    while len(fib) < 24:
+        fib.append(fib[-1] + fib[-2])
+    data = b"".join(bytes([65 + i]) * min(c, 20000) for i, c in enumerate(fib))
+    perm = rng.permutation(len(data))
+    roundtrip(bytes(np.frombuffer(data, dtype=np.uint8)[perm][:MAX_IN]))
+    # all 256 byte values, each once, then a long match-rich tail
+    roundtrip(bytes(range(256)) + b"@header:1:2:3 1:N:0\n" * 2000)
+    # distances near the 32 KiB window limit
+    block = bytes(rng.integers(0, 256, 300, dtype=np.uint8))
+    roundtrip(block + bytes(32768 - 300 - 7) + block + bytes(100) + block)
+
+
+def test_output_is_a_single_final_dynamic_block():
+    payload, stored = deflate(fastq_text(150, np.random.default_rng(3))[:40000])
+    assert not stored
+    assert payload[0] & 1 == 1 and (payload[0] >> 1) & 3 == 2      # BFINAL = 1, BTYPE = 10 (dynamic Huffman)
+    d = zlib.decompressobj(-15)
+    d.decompress(payload)
+    assert d.eof and d.unused_data == b""

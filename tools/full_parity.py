@@ -53,7 +53,7 @@ def main():
     from fqtk_amd import BarcodeMatcher, synth
     cfg = synth.CONFIGS[a.config]
     n = a.reads or cfg.n_reads
-    procs = a.procs or max(1, min(128, (os.cpu_count() or 2) // 2))
+    procs = a.procs or max(1, min(64, (os.cpu_count() or 2) // 2))
     w = synth.Workload(cfg)
     dev = torch.device("cuda:0")
     stream = torch.cuda.current_stream().cuda_stream

@@ -195,7 +195,7 @@ def scratch_dir(need_bytes):
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--templates", type=int, default=4_000_000)
-    ap.add_argument("--threads", type=int, default=32)
+    ap.add_argument("--threads", type=int, default=16)
     ap.add_argument("--gz", action="store_true")
     ap.add_argument("--bgzf", action="store_true", help="BGZF-compress the inputs (block-parallel inflate in the reader)")
     ap.add_argument("--skip-b", action="store_true")
