@@ -5,9 +5,15 @@
 // while the GPU matcher idles.  This is the MI355X form of that stage: every <= 65 280-byte block becomes one
 // dynamic-Huffman DEFLATE block (RFC 1951), produced by 256 lanes:
 //   P0  the block is copied into LDS, the LZ hash table and the histograms are cleared
-//   P1  LZ77: every lane parses its own 256-byte slice greedily against ONE shared hash table of 4-byte
-//       sequences (racy on purpose: a candidate is only a hint and is verified byte by byte, so any stale or
-//       torn entry costs compression, never correctness); tokens go to a global scratch, symbol counts to LDS
+//   P1a every lane counts the bytes of its 256-byte slice (-> estimated literal costs) and enters all its
+//       positions into a shared table keyed by (16 KiB region of the block, hash of 4 bytes) holding the SMALLEST
+//       and the LARGEST position seen -- min / max, so the table does not depend on how the lanes interleave and
+//       the output is deterministic
+//   P1b LZ77: every lane parses its slice greedily; candidates for a position are the largest entry of the
+//       region before it (always behind it and inside the 32 KiB window), the smallest entry of its own region,
+//       the distance of its previous match, and distance 1; each is verified byte by byte and must pay for
+//       itself (estimated literal bits saved > bits of the match); tokens go to a global scratch, symbol
+//       counts to LDS
 //   P2  one lane builds the two Huffman codes (two-queue construction on the sorted counts, zlib's overflow
 //       rule for the 15-bit limit), the code-length code, and writes the block header
 //   P3  every lane adds up the bits of its tokens; exclusive prefix sum -> its bit offset; if the result would
@@ -38,16 +44,20 @@ namespace bgzf {
 constexpr int kLanes = 256;
 constexpr uint32_t kMaxIn = 65280;        // uncompressed payload of a BGZF block (as the bgzf crate cuts them)
 constexpr uint32_t kChunk = 256;          // bytes parsed by one lane: 255 lanes x 256 = 65 280
-constexpr uint32_t kHashBits = 14;
+constexpr uint32_t kHashBits = 11;        // per region; 4 regions x 2048 entries x {min, max}
+constexpr uint32_t kNearSlots = 64;       // per lane: direct-mapped table of its recent positions (local repeats)
 constexpr uint32_t kOutStride = 65536;    // bytes reserved per block in the output arena (stored worst case: n + 5)
 constexpr uint32_t kTokensPerBlock = kLanes * kChunk;   // token scratch, u32 each, [t][lane]
 constexpr int kNumLitLen = 286, kNumDist = 30, kNumCl = 19;
 constexpr int kMinMatch = 4;              // shorter matches cost more bits than their literals on FASTQ
 
-// Everything a block's workgroup shares.  LDS on the device (~107 KiB: one workgroup per CU), heap in the CPU tests.
+// Everything a block's workgroup shares.  LDS on the device (~141 KiB: one workgroup per CU), heap in the CPU tests.
 struct Shared {
     uint32_t buf[kOutStride / 4];         // P0-P1: the input bytes.  P2-P5: the output bit stream.
-    uint16_t htab[1u << kHashBits];
+    uint32_t tminmax[4u << kHashBits];      // per (region, hash): smallest position in the low half, largest in the high half
+    uint16_t near_tab[kNearSlots * kLanes];  // [slot][lane]: every lane's private table of recent positions
+    uint32_t byte_cnt[256];                  // P1a: how often each byte value occurs in the block
+    uint8_t lit_cost[256];                   // estimated cost of a literal, in half-bits (from byte_cnt)
     uint32_t freq_ll[288], freq_d[32];
     uint16_t code_ll[288], code_d[32];    // bit-reversed canonical codes (appended LSB first)
     uint8_t len_ll[288], len_d[32];
@@ -104,9 +114,11 @@ FQTK_HD inline uint32_t match_token(uint32_t len, uint32_t dist) { return 0x8000
 #if defined(__HIP_DEVICE_COMPILE__)
 #define FQTK_BGZF_OR(ptr, v) atomicOr((ptr), (v))
 #define FQTK_BGZF_ADD(ptr, v) atomicAdd((ptr), (v))
+#define FQTK_BGZF_CAS(ptr, expect, v) atomicCAS((ptr), (expect), (v))
 #else
 #define FQTK_BGZF_OR(ptr, v) (*(ptr) |= (v))
 #define FQTK_BGZF_ADD(ptr, v) (*(ptr) += (v))
+#define FQTK_BGZF_CAS(ptr, expect, v) (*(ptr) == (expect) ? (*(ptr) = (v), (expect)) : *(ptr))
 #endif
 struct BitWriter {
     uint32_t *words;
@@ -204,9 +216,11 @@ FQTK_HD inline uint32_t hash4(uint32_t x) { return (x * 2654435761u) >> (32 - kH
 
 // P0: clear the shared state, bring the block in.  `in` may be device or (pinned, device-visible) host memory.
 FQTK_HD inline void phase_load(Shared &S, int lane, const uint8_t *in, uint32_t n) {
-    for (uint32_t i = (uint32_t)lane; i < (1u << kHashBits); i += kLanes) S.htab[i] = 0xFFFFu;
+    for (uint32_t i = (uint32_t)lane; i < (4u << kHashBits); i += kLanes) S.tminmax[i] = 0x0000FFFFu;   // min = none (0xFFFF), max = none (0)
+    for (uint32_t i = 0; i < kNearSlots; ++i) S.near_tab[i * kLanes + (uint32_t)lane] = 0xFFFFu;
     for (uint32_t i = (uint32_t)lane; i < 288; i += kLanes) S.freq_ll[i] = 0;
     if (lane < 32) S.freq_d[lane] = 0;
+    S.byte_cnt[lane] = 0;
     uint8_t *b = reinterpret_cast<uint8_t *>(S.buf);
     if ((reinterpret_cast<uintptr_t>(in) & 15u) == 0) {
         const uint32_t n16 = n >> 4;
@@ -221,44 +235,126 @@ FQTK_HD inline void phase_load(Shared &S, int lane, const uint8_t *in, uint32_t 
     }
 }
 
-// P1: greedy LZ77 over this lane's slice; tokens to tok[t * kLanes + lane]
-FQTK_HD inline void phase_lz(Shared &S, int lane, uint32_t n, uint32_t *tok) {
+// P1a: every position of this lane's slice into the (region, hash) table.  One word holds the smallest position
+// (low half, 0xFFFF = none) and the largest position + 1 (high half, 0 = none) of its bucket; min and max are
+// order-independent, so the table -- and with it the whole output -- does not depend on how the lanes interleave.
+FQTK_HD inline uint32_t region_slot(uint32_t p, uint32_t h) { return ((p >> 14) << kHashBits) | h; }
+FQTK_HD inline void phase_index(Shared &S, int lane, uint32_t n) {
     const uint8_t *b = reinterpret_cast<const uint8_t *>(S.buf);
-    uint32_t p = (uint32_t)lane * kChunk;
-    const uint32_t end = p + kChunk < n ? p + kChunk : n;
-    uint32_t nt = 0;
-    while (p < end) {
-        uint32_t mlen = 0, mdist = 0;
-        if (p + 4 <= n) {
-            const uint32_t h = hash4(load_le32(b + p));
-            const uint32_t cand = S.htab[h];
-            S.htab[h] = (uint16_t)p;
-            if (cand < p && p - cand <= 32768u) {
-                const uint32_t maxl = end - p < 258u ? end - p : 258u;   // a match never leaves the lane's slice
-                uint32_t l = 0;
-                while (l < maxl && b[cand + l] == b[p + l]) ++l;
-                if (l >= (uint32_t)kMinMatch) { mlen = l; mdist = p - cand; }
-            }
+    const uint32_t lo = (uint32_t)lane * kChunk;
+    const uint32_t hi = lo + kChunk < n ? lo + kChunk : n;
+    for (uint32_t p = lo; p < hi; ++p) FQTK_BGZF_ADD(&S.byte_cnt[b[p]], 1u);
+    for (uint32_t p = lo; p < hi && p + 4 <= n; ++p) {
+        uint32_t *w = &S.tminmax[region_slot(p, hash4(load_le32(b + p)))];
+        uint32_t old = *w;
+        for (;;) {
+            const uint32_t mn = (old & 0xFFFFu) < p ? (old & 0xFFFFu) : p;
+            const uint32_t mx = (old >> 16) > p + 1 ? (old >> 16) : p + 1;
+            const uint32_t want = (mx << 16) | mn;
+            if (want == old) break;
+            const uint32_t seen = FQTK_BGZF_CAS(w, old, want);
+            if (seen == old) break;
+            old = seen;
         }
-        if (mlen) {
-            uint32_t sym, ne, ev;
-            length_symbol(mlen, sym, ne, ev);
-            FQTK_BGZF_ADD(&S.freq_ll[sym], 1u);
-            dist_symbol(mdist, sym, ne, ev);
-            FQTK_BGZF_ADD(&S.freq_d[sym], 1u);
-            tok[nt * kLanes + (uint32_t)lane] = match_token(mlen, mdist);
-            // the skipped positions are still worth finding later
-            const uint32_t stop = p + mlen;
-            for (uint32_t q = p + 1; q < stop && q + 4 <= n; ++q) S.htab[hash4(load_le32(b + q))] = (uint16_t)q;
-            p = stop;
-        } else {
-            FQTK_BGZF_ADD(&S.freq_ll[b[p]], 1u);
-            tok[nt * kLanes + (uint32_t)lane] = b[p];
-            ++p;
-        }
-        ++nt;
     }
-    S.ntok[lane] = nt;
+}
+
+// What a literal will cost after Huffman coding, roughly: -log2 of the byte's share of the block, in half-bits
+// (integer arithmetic only: the CPU tests expect the device's bytes).  A match is taken only when the literals it
+// replaces would cost more than the match itself -- in FASTQ text the bases cost ~2.3 bits each and a frequent
+// quality value less than that, so short matches rarely pay.
+FQTK_HD inline uint32_t log2_halfbits(uint32_t x) {   // ~ 2 * log2(x), x >= 1
+    const int m = floor_log2(x);
+    return 2u * (uint32_t)m + (m > 0 ? ((x >> (m - 1)) & 1u) : 0u);
+}
+FQTK_HD inline void phase_literal_costs(Shared &S, int lane, uint32_t n) {   // lane = byte value
+    const uint32_t c = S.byte_cnt[lane];
+    uint32_t cost = 30;
+    if (c) {
+        const uint32_t a = log2_halfbits(n), b = log2_halfbits(c);
+        cost = a > b ? a - b : 0u;
+        if (cost < 2u) cost = 2u;
+        if (cost > 30u) cost = 30u;
+    }
+    S.lit_cost[lane] = (uint8_t)cost;
+}
+FQTK_HD inline uint32_t match_cost(uint32_t len, uint32_t dist) {   // half-bits: length code + distance code + extras
+    uint32_t sym, ne_l, ne_d, ev;
+    length_symbol(len, sym, ne_l, ev);
+    dist_symbol(dist, sym, ne_d, ev);
+    return 2u * (7u + 5u + ne_l + ne_d);
+}
+
+// P1b: greedy LZ77 over this lane's slice; tokens to tok[t * kLanes + lane].  Deterministic: reads the tables
+// of P1a and the lane's own state only.
+struct LzLane { uint32_t p, end, nt, last_dist; };
+FQTK_HD inline void lz_begin(Shared &S, int lane, uint32_t n, LzLane &st) {
+    st.p = (uint32_t)lane * kChunk;
+    st.end = st.p + kChunk < n ? st.p + kChunk : n;
+    st.nt = 0;
+    st.last_dist = 0;
+    // the private table starts with the slice before this one (the neighbour's bytes, read-only here)
+    const uint8_t *b = reinterpret_cast<const uint8_t *>(S.buf);
+    for (uint32_t q = st.p >= kChunk ? st.p - kChunk : 0u; q < st.p && q + 4 <= n; ++q)
+        S.near_tab[((hash4(load_le32(b + q)) >> 5) & (kNearSlots - 1u)) * kLanes + (uint32_t)lane] = (uint16_t)q;
+}
+// one token; false when the slice is done
+FQTK_HD inline bool lz_step(Shared &S, int lane, uint32_t n, uint32_t *tok, LzLane &st) {
+    if (st.p >= st.end) return false;
+    const uint8_t *b = reinterpret_cast<const uint8_t *>(S.buf);
+    const uint32_t p = st.p;
+    uint32_t mlen = 0, mdist = 0, msave = 0;
+    if (p + 4 <= n) {
+        const uint32_t w = load_le32(b + p);
+        const uint32_t h = hash4(w);
+        const uint32_t near_slot = ((h >> 5) & (kNearSlots - 1u)) * kLanes + (uint32_t)lane;
+        const uint32_t own = S.tminmax[region_slot(p, h)] & 0xFFFFu;
+        uint32_t cand[5];                                                  // position + 1; 0 = none
+        cand[0] = (uint32_t)S.near_tab[near_slot] + 1u;                    // 0xFFFF + 1 = 0x10000: fails q < p below
+        cand[1] = st.last_dist && p >= st.last_dist ? p - st.last_dist + 1 : 0u;
+        cand[2] = p;                                                       // distance 1
+        cand[3] = own == 0xFFFFu ? 0u : own + 1u;
+        cand[4] = p >= 16384u ? (S.tminmax[region_slot(p - 16384u, h)] >> 16) : 0u;
+        S.near_tab[near_slot] = (uint16_t)p;
+        const uint32_t maxl = st.end - p < 258u ? st.end - p : 258u;       // a match never leaves the lane's slice
+        for (int c = 0; c < 5; ++c) {
+            if (cand[c] == 0u) continue;
+            const uint32_t q = cand[c] - 1;
+            if (q >= p || p - q > 32768u || load_le32(b + q) != w) continue;
+            uint32_t l = 4;
+            while (l < maxl && b[q + l] == b[p + l]) ++l;
+            if (l > maxl) l = maxl;
+            if (l < (uint32_t)kMinMatch) continue;
+            uint32_t lit = 0;
+            for (uint32_t k = 0; k < l; ++k) lit += S.lit_cost[b[p + k]];
+            const uint32_t cost = match_cost(l, p - q);
+            if (lit > cost && lit - cost > msave) { msave = lit - cost; mlen = l; mdist = p - q; }
+        }
+    }
+    if (mlen) {
+        uint32_t sym, ne, ev;
+        length_symbol(mlen, sym, ne, ev);
+        FQTK_BGZF_ADD(&S.freq_ll[sym], 1u);
+        dist_symbol(mdist, sym, ne, ev);
+        FQTK_BGZF_ADD(&S.freq_d[sym], 1u);
+        tok[st.nt * kLanes + (uint32_t)lane] = match_token(mlen, mdist);
+        st.last_dist = mdist;
+        for (uint32_t q = p + 1; q < p + mlen && q + 4 <= n; ++q)         // the positions skipped are recent history too
+            S.near_tab[((hash4(load_le32(b + q)) >> 5) & (kNearSlots - 1u)) * kLanes + (uint32_t)lane] = (uint16_t)q;
+        st.p = p + mlen;
+    } else {
+        FQTK_BGZF_ADD(&S.freq_ll[b[p]], 1u);
+        tok[st.nt * kLanes + (uint32_t)lane] = b[p];
+        st.p = p + 1;
+    }
+    ++st.nt;
+    return true;
+}
+FQTK_HD inline void phase_lz(Shared &S, int lane, uint32_t n, uint32_t *tok) {
+    LzLane st;
+    lz_begin(S, lane, n, st);
+    while (lz_step(S, lane, n, tok, st)) {}
+    S.ntok[lane] = st.nt;
 }
 
 // P2a (all lanes): the input copy is no longer needed: the same LDS becomes the (zeroed) output image

@@ -25,6 +25,10 @@ __global__ __launch_bounds__(kLanes) void deflate_kernel(const fqtk_bgzf_block *
         const uint32_t n = blocks[j].n_in;
         phase_load(S, lane, in, n);
         __syncthreads();
+        phase_index(S, lane, n);
+        __syncthreads();
+        phase_literal_costs(S, lane, n);
+        __syncthreads();
         phase_lz(S, lane, n, tok);
         __syncthreads();
         phase_clear_out(S, lane);

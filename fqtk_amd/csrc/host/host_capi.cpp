@@ -214,13 +214,27 @@ int fqtk_host_direct_memo(uint32_t S, uint32_t L, uint64_t n_ents, const uint32_
 // The GPU BGZF compressor's phase functions (csrc/bgzf_deflate.hpp) run lane by lane on the CPU -- the same
 // code the HIP kernel runs with barriers in between.  Test infrastructure: lets the CPU suite inflate what
 // the algorithm produces (zlib) without a GPU.  Returns the DEFLATE payload size, or -1 on a bad argument.
-int64_t fqtk_host_bgzf_deflate_emulated(const uint8_t *in, uint32_t n, uint8_t *out, size_t cap, int *stored) {
+// lockstep != 0: the LZ phase advances all lanes one token at a time, round robin, instead of lane after lane --
+// the algorithm is built so that the interleaving cannot matter (min / max tables, lane-private parse state), and
+// the tests check that both orders give identical bytes.
+int64_t fqtk_host_bgzf_deflate_emulated(const uint8_t *in, uint32_t n, uint8_t *out, size_t cap, int *stored, int lockstep) {
     using namespace fqtk::bgzf;
     if (n == 0 || n > kMaxIn || cap < kOutStride) return -1;
     std::vector<uint8_t> mem(sizeof(Shared));
     Shared &S = *reinterpret_cast<Shared *>(mem.data());
     std::vector<uint32_t> tok(kTokensPerBlock);
     for (int l = 0; l < kLanes; ++l) phase_load(S, l, in, n);
+    for (int l = 0; l < kLanes; ++l) phase_index(S, l, n);
+    for (int l = 0; l < kLanes; ++l) phase_literal_costs(S, l, n);
+    if (lockstep) {
+        std::vector<LzLane> st(kLanes);
+        for (int l = 0; l < kLanes; ++l) lz_begin(S, l, n, st[l]);
+        for (bool any = true; any;) {
+            any = false;
+            for (int l = 0; l < kLanes; ++l) any = lz_step(S, l, n, tok.data(), st[l]) || any;
+        }
+        for (int l = 0; l < kLanes; ++l) S.ntok[l] = st[l].nt;
+    } else
     for (int l = 0; l < kLanes; ++l) phase_lz(S, l, n, tok.data());
     for (int l = 0; l < kLanes; ++l) phase_clear_out(S, l);
     phase_codes_and_header(S);

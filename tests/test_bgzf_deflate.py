@@ -13,21 +13,24 @@ from tests import hostlib
 MAX_IN = 65280
 
 
-def deflate(data: bytes):
+def deflate(data: bytes, lockstep: int = 1):
+    """lockstep=1: the 256 lanes advance token by token, round robin (the GPU's interleaving, approximately);
+    lockstep=0: lane after lane."""
     lib = hostlib.lib()
     fn = lib.fqtk_host_bgzf_deflate_emulated
     fn.restype = C.c_int64
     out = (C.c_uint8 * 65536)()
     stored = C.c_int(0)
-    n = fn(data, C.c_uint32(len(data)), out, C.c_size_t(65536), C.byref(stored))
+    n = fn(data, C.c_uint32(len(data)), out, C.c_size_t(65536), C.byref(stored), C.c_int(lockstep))
     assert n > 0
     return bytes(out[:n]), bool(stored.value)
 
 
 def roundtrip(data: bytes):
-    payload, stored = deflate(data)
-    assert zlib.decompress(payload, -15) == data
-    assert len(payload) <= len(data) + 5
+    for lockstep in (0, 1):
+        payload, stored = deflate(data, lockstep)
+        assert zlib.decompress(payload, -15) == data
+        assert len(payload) <= len(data) + 5
     return len(payload), stored
 
 

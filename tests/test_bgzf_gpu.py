@@ -1,8 +1,7 @@
 """The BGZF block compressor on the GPU (include/fqtk_bgzf.h), through the C ABI with page-locked host buffers the
-kernel reads and writes directly: every payload must inflate (zlib) to its input, and must be byte-identical to what
-the same phase functions produce lane by lane on the CPU (tests/test_bgzf_deflate.py) whenever the parse is
-deterministic (single-lane blocks); larger blocks race on the shared hash table by design, so there the check is
-the round trip and the size."""
+kernel reads and writes directly: every payload must inflate (zlib) to its input AND be byte-identical to what the
+same phase functions produce lane by lane on the CPU (tests/test_bgzf_deflate.py) -- the algorithm is built to be
+independent of how the 256 lanes interleave (min / max tables, lane-private parse state)."""
 import ctypes as C
 import zlib
 
@@ -64,8 +63,7 @@ def test_blocks_round_trip_through_the_gpu_compressor():
                 assert 0 < len(p) <= len(b) + 5
                 d = zlib.decompressobj(-15)
                 assert d.decompress(p) == b and d.eof and d.unused_data == b"", (i, len(b))
-                if len(b) <= 256:                                                            # one lane parses it all: deterministic
-                    assert p == cpu_deflate(b)[0], (i, len(b))
+                assert p == cpu_deflate(b)[0], (i, len(b))                                   # bit-exact vs the CPU run of the same phases
                 ratios.append(len(p) / len(b))
             assert max(ratios[:15]) < 0.45                                                   # real compression on FASTQ text
         # a slot must be waited on before it is reused; bad arguments are refused
@@ -94,6 +92,8 @@ def test_many_blocks_more_than_workgroups_resident():
         assert lib.fqtk_bgzf_wait(z, 0) == 0
         for i, b in enumerate(blocks):
             assert zlib.decompress(a.payload(i), -15) == b, i
+            if i % 50 == 0:
+                assert a.payload(i) == cpu_deflate(b)[0], i
     finally:
         a.free()
         lib.fqtk_bgzf_destroy(z)
