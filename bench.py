@@ -434,6 +434,11 @@ def main() -> int:
                 e_threads = args.e2e_threads or max(5, min(32, host_cores))
                 scopes["E"] = scope_bench.scope_e(n_e, e_threads, args.e2e_gz, tmp, expect, repeat_first_block=rep)
                 scopes["E"]["host_cpus_usable"] = host_cores
+                shutil.rmtree(os.path.join(tmp, "out"), ignore_errors=True)
+                # the same run with the output blocks compressed on the GPU (include/fqtk_bgzf.h) instead of by libdeflate
+                scopes["E_gpu_bgzf"] = scope_bench.scope_e(n_e, e_threads, args.e2e_gz, tmp, expect, extra_args=("--gpu-bgzf",),
+                                                           repeat_first_block=rep, reuse_inputs=True)
+                scopes["E_gpu_bgzf"]["host_cpus_usable"] = host_cores
             finally:
                 shutil.rmtree(tmp, ignore_errors=True)
             out["scopes"] = scopes

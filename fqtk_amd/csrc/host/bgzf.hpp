@@ -115,6 +115,24 @@ class BlockCompressor {
     int level_;
 };
 
+// CRC32 of a block's uncompressed bytes (the BGZF trailer): libdeflate's (PCLMUL, several GB/s) when the library is
+// there, zlib's otherwise.
+class BgzfCrc {
+  public:
+    BgzfCrc() {
+        if (std::getenv("FQTK_NO_LIBDEFLATE")) return;
+        void *h = dlopen("libdeflate.so.0", RTLD_NOW | RTLD_LOCAL);
+        if (!h) h = dlopen("libdeflate.so", RTLD_NOW | RTLD_LOCAL);
+        if (h) fn_ = reinterpret_cast<uint32_t (*)(uint32_t, const void *, size_t)>(dlsym(h, "libdeflate_crc32"));
+    }
+    uint32_t operator()(const void *p, size_t n) const {
+        if (fn_) return fn_(0, p, n);
+        return (uint32_t)::crc32(::crc32(0L, Z_NULL, 0), static_cast<const Bytef *>(p), (uInt)n);
+    }
+  private:
+    uint32_t (*fn_)(uint32_t, const void *, size_t) = nullptr;
+};
+
 // One-shot convenience (tests, small buffers).
 inline bool bgzf_compress_block(const uint8_t *in, size_t n, int level, std::vector<uint8_t> &out, std::string *err) {
     BlockCompressor c(level);

@@ -36,6 +36,7 @@
 #include "../../../include/fqtk_match.h"
 #include "bgzf.hpp"
 #include "fastq_io.hpp"
+#include "gpu_bgzf_stage.hpp"
 #include "header.hpp"
 #include "metrics.hpp"
 #include "read_structure.hpp"
@@ -88,6 +89,7 @@ struct Options {
     int device = 0;
     std::vector<int> devices;        // --devices a,b,..: chunk k goes to devices[k mod G]
     unsigned long chunk_reads = 1ul << 17;
+    bool gpu_bgzf = false;           // --gpu-bgzf: DEFLATE the output blocks on the GPU (additive flag)
 };
 
 const char *kUsage =
@@ -106,7 +108,10 @@ const char *kUsage =
     "  -S, --skip-reasons <REASON>...              too-few-bases\n"
     "      --device <N>                            GPU to use [default: 0] (additive flag)\n"
     "      --devices <A,B,..>                      several GPUs: chunk k is matched on devices[k mod G] (additive flag)\n"
-    "      --chunk-reads <N>                       templates per GPU chunk [default: 131072] (additive flag)\n";
+    "      --chunk-reads <N>                       templates per GPU chunk [default: 131072] (additive flag)\n"
+    "      --gpu-bgzf                              compress the output BGZF blocks on the GPU instead of with the\n"
+    "                                              libdeflate thread pool (additive flag; --compression-level does\n"
+    "                                              not apply: ~7 % larger files than level 5 on FASTQ text)\n";
 
 bool parse_ulong(const std::string &s, unsigned long *out) {
     if (s.empty()) return false;
@@ -191,6 +196,7 @@ Options parse_args(int argc, char **argv) {
             }
         }
         else if (a == "--chunk-reads") num(&o.chunk_reads);
+        else if (a == "--gpu-bgzf") o.gpu_bgzf = true;
         else if (a == "--help" || a == "-h") { std::fputs(kUsage, stdout); std::exit(0); }
         else die("unexpected argument '" + a + "' found\n\n" + kUsage);
     }
@@ -338,6 +344,55 @@ void submit_blocks(OutFile &of, JobQueues &jobs, bool final) {
     }
 }
 
+// --gpu-bgzf: the cut block goes into a slab of the page-locked arena instead (the kernel reads it from there),
+// with the CRC32 the BGZF trailer needs.
+GpuBgzfStage *g_gpu_stage = nullptr;
+void submit_blocks_gpu(OutFile &of, bool final) {
+    static const BgzfCrc crc32;
+    while (of.buf.size() >= kBgzfBlockSize || (final && !of.buf.empty())) {
+        const uint64_t ta = tick();
+        const size_t n = std::min(kBgzfBlockSize, of.buf.size());
+        GpuBlock b;
+        b.file = &of;
+        b.seq = of.next_submit++;
+        b.in_slab = g_gpu_stage->in_pool.get();
+        b.n = (uint32_t)n;
+        std::memcpy(g_gpu_stage->in_slab(b.in_slab), of.buf.data(), n);
+        b.crc = crc32(of.buf.data(), n);
+        of.buf.erase(0, n);
+        const uint64_t tb = tick();
+        g_gpu_stage->to_gpu.push(b);
+        if (g_timing) { g_times.submit_calls += 1; g_times.submit_cut += tb - ta; g_times.submit_push += tick() - tb; }
+    }
+}
+
+// writer side of --gpu-bgzf: payload -> BGZF member, written in sequence order
+void write_gpu_block(const GpuBlock &b) {
+    OutFile &of = *static_cast<OutFile *>(b.file);
+    const uint64_t t0 = tick();
+    const size_t bsize = 18 + (size_t)b.out_len + 8;
+    if (bsize > 65536) die("BGZF block overflow");
+    std::vector<uint8_t> member(bsize);
+    const uint8_t hdr[18] = {0x1f, 0x8b, 0x08, 0x04, 0, 0, 0, 0, 0, 0xff, 0x06, 0, 0x42, 0x43, 0x02, 0,
+                             (uint8_t)((bsize - 1) & 0xff), (uint8_t)((bsize - 1) >> 8)};
+    std::memcpy(member.data(), hdr, 18);
+    std::memcpy(member.data() + 18, g_gpu_stage->out_slab(b.out_slab), b.out_len);
+    uint8_t *t = member.data() + 18 + b.out_len;
+    t[0] = b.crc & 0xff; t[1] = (b.crc >> 8) & 0xff; t[2] = (b.crc >> 16) & 0xff; t[3] = (b.crc >> 24) & 0xff;
+    t[4] = b.n & 0xff; t[5] = (b.n >> 8) & 0xff; t[6] = (b.n >> 16) & 0xff; t[7] = (b.n >> 24) & 0xff;
+    g_gpu_stage->out_pool.put(b.out_slab);
+    g_gpu_stage->in_pool.put(b.in_slab);
+    const uint64_t t1 = tick();
+    g_times.comp_deflate += t1 - t0;
+    std::lock_guard<std::mutex> lk(of.mu);
+    of.ready.emplace(b.seq, std::move(member));
+    for (auto it = of.ready.begin(); it != of.ready.end() && it->first == of.next_write; it = of.ready.erase(it)) {
+        if (std::fwrite(it->second.data(), 1, it->second.size(), of.f) != it->second.size()) die("write failed: " + of.path);
+        ++of.next_write;
+    }
+    g_times.comp_write += tick() - t1;
+}
+
 // Pool side: compress one block, then write it -- and any successors already waiting -- in order.
 void compress_and_write(CompressJob &j, BlockCompressor &bc) {
     std::vector<uint8_t> comp;
@@ -460,6 +515,7 @@ int main(int argc, char **argv) {
     const size_t G = opt.devices.size();
     std::vector<fqtk_matcher *> matchers(G, nullptr);
     const uint32_t L = (uint32_t)samples[0].barcode.size();
+    GpuBgzfStage gpu_stage;
     std::thread gpu_init([&] {
         for (size_t g = 0; g < G; ++g) {
             if (fqtk_matcher_create(bc.data(), (uint32_t)S, L, (uint8_t)opt.max_mismatches, (uint8_t)opt.min_mismatch_delta,
@@ -470,6 +526,12 @@ int main(int argc, char **argv) {
             fqtk_matcher_set_sample_ids(matchers[g], ids.data());
             info("GPU barcode matcher ready on device %d (%llu memo entries).", opt.devices[g],
                  (unsigned long long)fqtk_matcher_memo_entries(matchers[g]));
+        }
+        if (opt.gpu_bgzf) {   // 2048 + 2048 slabs of 64 KiB: 256 MiB of page-locked memory the kernel works in directly
+            std::string err;
+            if (!gpu_stage.init(opt.devices[0], 2048, &err)) die("cannot set up the GPU BGZF compressor: " + err);
+            g_gpu_stage = &gpu_stage;
+            info("GPU BGZF compressor ready on device %d.", opt.devices[0]);
         }
     });
 
@@ -571,8 +633,10 @@ int main(int argc, char **argv) {
     const size_t n_threads_c = std::max<size_t>(2, opt.threads - 1);
     // Formatting a template costs ~1.15 us of router time, compressing its ~680 bytes at level 5 ~5.2 us of
     // libdeflate time (measured, FQTK_TIMING, 16 M dual-index templates): two routers feed seven compressors.
-    const size_t n_workers = std::max<size_t>(1, (n_threads_c * 2 + 4) / 9);   // routers
-    const size_t n_comp = std::max<size_t>(1, n_threads_c - n_workers);     // compressors
+    // With --gpu-bgzf the compressors only wrap and write what the GPU produced: three routers per writer.
+    const size_t n_workers = opt.gpu_bgzf ? std::max<size_t>(1, (n_threads_c * 3) / 4)
+                                          : std::max<size_t>(1, (n_threads_c * 2 + 4) / 9);   // routers
+    const size_t n_comp = std::max<size_t>(1, n_threads_c - n_workers);     // compressors / writers
     // Output files fill in lock-step (samples are hit in proportion, so hundreds of files reach a full
     // 64 KiB block within the same few chunks): the queue must absorb such a burst or the routers stall
     // on it while the compressors idle between bursts (measured: 1 push in 26 found a 73-deep queue full
@@ -581,7 +645,24 @@ int main(int argc, char **argv) {
     for (size_t c = 0; c < n_comp; ++c)
         jobs.push_back(std::make_unique<BoundedQueue<CompressJob>>(std::max<size_t>(64, 8192 / n_comp)));   // <= 512 MiB of blocks in flight
     std::vector<std::thread> compressors;
-    for (size_t c = 0; c < n_comp; ++c)
+    std::thread gpu_stage_thread;
+    if (opt.gpu_bgzf) {
+        gpu_stage_thread = std::thread([&] {
+            std::string err;
+            if (!gpu_stage.run(n_workers, n_comp, &err)) die("GPU BGZF stage: " + err);
+        });
+        for (size_t c = 0; c < n_comp; ++c)
+            compressors.emplace_back([&] {
+                for (;;) {
+                    const uint64_t t0 = tick();
+                    const GpuBlock b = gpu_stage.to_writers.pop();
+                    g_times.comp_wait += tick() - t0;
+                    if (!b.file) break;
+                    write_gpu_block(b);
+                }
+            });
+    }
+    for (size_t c = 0; c < (opt.gpu_bgzf ? 0 : n_comp); ++c)
         compressors.emplace_back([&, c] {
             BlockCompressor bc((int)opt.compression_level);
             for (;;) {
@@ -654,7 +735,7 @@ int main(int argc, char **argv) {
                         of.buf.push_back('\n');
                         if (of.buf.size() >= kBgzfBlockSize) {
                             const uint64_t ts = tick();
-                            submit_blocks(of, jobs, false);
+                            if (opt.gpu_bgzf) submit_blocks_gpu(of, false); else submit_blocks(of, jobs, false);
                             t_sub += tick() - ts;
                         }
                     }
@@ -663,7 +744,8 @@ int main(int argc, char **argv) {
                 g_times.router_format += tick() - tf - t_sub;
             }
             for (size_t f = 0; f < outs.size(); ++f)
-                if (file_owner[f] == w) submit_blocks(outs[f], jobs, true);
+                if (file_owner[f] == w) { if (opt.gpu_bgzf) submit_blocks_gpu(outs[f], true); else submit_blocks(outs[f], jobs, true); }
+            if (opt.gpu_bgzf) gpu_stage.to_gpu.push(GpuBlock{});   // this router is done
         });
 
     // ---- stage B (this thread): chunk assembly, barcode SoA packing, GPU pipeline -------------------
@@ -859,7 +941,12 @@ int main(int argc, char **argv) {
     info("Finished reading input FASTQs.");
     for (size_t w = 0; w < n_workers; ++w) wq[w]->push(nullptr);
     for (auto &t : workers) t.join();
-    for (size_t c = 0; c < n_comp; ++c) jobs[c]->push(CompressJob{});
+    if (opt.gpu_bgzf) {
+        gpu_stage_thread.join();   // sends the writers their end markers
+        info("GPU BGZF stage: %llu blocks in %llu launches.", (unsigned long long)gpu_stage.blocks(), (unsigned long long)gpu_stage.launches());
+    } else {
+        for (size_t c = 0; c < n_comp; ++c) jobs[c]->push(CompressJob{});
+    }
     for (auto &t : compressors) t.join();
     for (OutFile &of : outs) {   // every block is on disk: terminate the BGZF streams
         if (!of.ready.empty() || of.next_write != of.next_submit) die("internal error: unwritten blocks in " + of.path);

@@ -148,8 +148,13 @@ def make_inputs(tmp, n, gz, block=1_000_000, repeat_first_block=False):
     return paths, meta, w
 
 
-def scope_e(n, threads, gz, tmp, expect_counts=None, extra_args=(), repeat_first_block=False):
-    paths, meta, w = make_inputs(tmp, n, gz, repeat_first_block=repeat_first_block)
+def scope_e(n, threads, gz, tmp, expect_counts=None, extra_args=(), repeat_first_block=False, reuse_inputs=False):
+    if reuse_inputs:   # a second run over the files of the previous scope_e() call in the same directory
+        ext = ".gz" if gz else ""
+        paths = [os.path.join(tmp, x + ext) for x in ("R1.fastq", "I1.fastq", "I2.fastq", "R2.fastq")]
+        meta = os.path.join(tmp, "meta.tsv")
+    else:
+        paths, meta, w = make_inputs(tmp, n, gz, repeat_first_block=repeat_first_block)
     in_bytes = sum(os.path.getsize(f) for f in paths)
     out = os.path.join(tmp, "out")
     exe = os.path.join(ROOT, "fqtk_amd", "bin", "fqtk")
@@ -172,6 +177,7 @@ def scope_e(n, threads, gz, tmp, expect_counts=None, extra_args=(), repeat_first
     return {"what": "fqtk_amd/bin/fqtk demux, files -> files (gunzip/parse -> GPU match -> BGZF), "
                     "as Demux::execute demux.rs:881-1001",
             "workload": "cfg3 shape: R1 150T, I1 8B, I2 8B, R2 150T; 384 samples", "templates": n, "threads": threads,
+            "extra_args": list(extra_args),
             "gz_inputs": gz, "seconds": round(dt, 3), "M_templates_per_s": round(n / dt / 1e6, 3),
             "seconds_is": "wall clock of the whole process: start-up, GPU bring-up, demux, flush, exit",
             "M_input_records_per_s": round(4 * n / dt / 1e6, 3),
