@@ -168,12 +168,16 @@ def effective_cpus() -> int:
     return n
 
 
+MATCHER_KERNEL_SOURCES = ("match_kernels.hip.h", "memo_kernels.hip.h", "lds_memo_kernels.hip.h", "memo_hash.hpp",
+                          "lds_memo_plan.hpp", "direct_memo_plan.hpp", "fqtk_match.hip")
+
+
 def kernel_sources_digest() -> str:
+    """Digest of the files that define the matcher's kernels, their tables and their launch shapes."""
     h = hashlib.sha1()
     d = os.path.join(ROOT, "fqtk_amd", "csrc")
-    for f in sorted(os.listdir(d)):
-        if f.endswith((".h", ".hpp", ".hip")):
-            h.update(open(os.path.join(d, f), "rb").read())
+    for f in MATCHER_KERNEL_SOURCES:
+        h.update(open(os.path.join(d, f), "rb").read())
     return h.hexdigest()
 
 

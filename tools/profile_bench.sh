@@ -27,11 +27,10 @@ for d,c in (("fetch","FETCH_SIZE"),("write","WRITE_SIZE")):
 out["hbm_read_bytes_corrected"]=out["FETCH_SIZE_KB_per_launch"]*1024*2
 out["hbm_write_bytes"]=out["WRITE_SIZE_KB_per_launch"]*1024
 out["traffic_bytes_per_launch"]=out["hbm_read_bytes_corrected"]+out["hbm_write_bytes"]
-import hashlib, os
-h=hashlib.sha1(); d="$R/fqtk_amd/csrc"
-for f in sorted(os.listdir(d)):
-    if f.endswith((".h",".hpp",".hip")): h.update(open(os.path.join(d,f),"rb").read())
-out["kernel_sources_sha1"]=h.hexdigest()   # bench.py reports this traffic only for the kernels it was measured on
+import sys
+sys.path.insert(0, "$R")
+import bench
+out["kernel_sources_sha1"]=bench.kernel_sources_digest()   # bench.py reports this traffic only for the kernels it was measured on
 json.dump(out, open(f"{O}/pmc_traffic.json","w"), indent=1)
 print(out)
 PY
