@@ -4,7 +4,8 @@
 // (gz-aware, 1 MiB buffer; /root/reference/src/bin/commands/demux.rs:844-849) and seq_io's
 // fastq::Reader (demux.rs:16-17,289-294,891): four-line records, `head` = line 1 without '@'.
 // Three byte sources behind one interface, chosen by looking at the file (not at its name):
-//   plain text      read(2) straight into the piece buffer
+//   plain text      a regular file is memory-mapped and parsed where it lies (records are offsets into the
+//                   mapping: no copy at all); anything else (a pipe) is read(2) into piece buffers
 //   gzip            zlib inflate (gzread: single- and multi-member streams); one stream cannot be split
 //   BGZF            independent <= 64 KiB members ('BC' extra field): a group of blocks is inflated IN PARALLEL
 //                   by a few helper threads (libdeflate through dlopen, zlib's inflate if it is absent)
@@ -15,6 +16,8 @@
 #pragma once
 #include <dlfcn.h>
 #include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
 #include <unistd.h>
 #include <zlib.h>
 
@@ -41,15 +44,17 @@ struct FastqRec {
 };
 
 struct RecBatch {
-    std::vector<char> data;
+    std::vector<char> data;          // the batch's bytes ... unless `mapped` points into a memory-mapped input
+    const char *mapped = nullptr;
     std::vector<FastqRec> recs;
     // filled by the demux reader threads (not by the parser): reads shorter than the read structure needs,
     // and this input's fixed-length sample-barcode segments, packed side by side (one row per record)
     std::vector<uint8_t> too_short, bc;
     size_t n_short = 0;
-    const char *head(size_t i) const { return data.data() + recs[i].head_off; }
-    const char *seq(size_t i) const { return data.data() + recs[i].seq_off; }
-    const char *qual(size_t i) const { return data.data() + recs[i].qual_off; }
+    const char *base() const { return mapped ? mapped : data.data(); }
+    const char *head(size_t i) const { return base() + recs[i].head_off; }
+    const char *seq(size_t i) const { return base() + recs[i].seq_off; }
+    const char *qual(size_t i) const { return base() + recs[i].qual_off; }
 };
 
 // libdeflate's decompressor, bound at run time (the image ships libdeflate.so.0 without its header).
@@ -117,6 +122,7 @@ class FastqSource {
         for (auto &t : helpers_) if (t.joinable()) t.join();
         if (gz_) gzclose(gz_);
         if (fd_ >= 0) ::close(fd_);
+        // a mapping stays for the life of the process: record batches point into it
     }
     // inflate_helpers: extra threads that inflate BGZF blocks next to the producer (ignored for other kinds)
     bool open(const std::string &path, std::string *err, unsigned inflate_helpers = 2) {
@@ -139,6 +145,17 @@ class FastqSource {
             gzbuffer(gz_, 1 << 20);
         }
         n_helpers_ = kind_ == Kind::Bgzf ? inflate_helpers : 0;
+        if (kind_ == Kind::Plain && !std::getenv("FQTK_NO_MMAP")) {
+            struct stat st;
+            if (fstat(fd_, &st) == 0 && S_ISREG(st.st_mode) && st.st_size > 0) {
+                void *m = mmap(nullptr, (size_t)st.st_size, PROT_READ, MAP_PRIVATE, fd_, 0);
+                if (m != MAP_FAILED) {
+                    map_ = static_cast<const char *>(m);
+                    map_size_ = (size_t)st.st_size;
+                    madvise(m, map_size_, MADV_SEQUENTIAL);
+                }
+            }
+        }
         return true;
     }
     Kind kind() const { return kind_; }
@@ -149,6 +166,7 @@ class FastqSource {
     // record is four (offset, length) pairs into that vector -- no per-record copy.  Bytes read past the
     // last record of this batch (at most one piece) are carried into the next batch.
     bool next_batch(size_t max_records, RecBatch *out, std::string *err) {
+        if (map_) return next_batch_mapped(max_records, out, err);
         if (!producer_.joinable()) start();
         out->recs.clear();
         out->recs.reserve(std::min<size_t>(max_records, 1u << 20));
@@ -225,6 +243,71 @@ class FastqSource {
     }
 
   private:
+    // Plain regular file: the records of a batch are located in the mapping itself.
+    bool next_batch_mapped(size_t max_records, RecBatch *out, std::string *err) {
+        out->recs.clear();
+        out->recs.reserve(std::min<size_t>(max_records, 1u << 20));
+        out->data.clear();
+        const char *base = map_ + map_pos_;
+        const size_t avail = map_size_ - map_pos_;
+        out->mapped = base;
+        size_t pos = 0;
+        while (out->recs.size() < max_records && pos < avail) {
+            size_t lo[4], len[4], p = pos;
+            int got = 0;
+            while (got < 4) {
+                const char *nl = p < avail ? (const char *)memchr(base + p, '\n', avail - p) : nullptr;
+                if (!nl) break;
+                lo[got] = p;
+                len[got] = (size_t)(nl - (base + p));
+                p += len[got] + 1;
+                ++got;
+            }
+            if (got < 4) {
+                if (got == 3 && p < avail) {   // final line without '\n'
+                    lo[3] = p;
+                    len[3] = avail - p;
+                    p = avail;
+                } else {
+                    for (size_t q = pos; q < avail; ++q)
+                        if (base[q] != '\n' && base[q] != '\r') {
+                            *err = "Unexpected error parsing FASTQs: truncated record at end of " + path_;
+                            return false;
+                        }
+                    pos = avail;
+                    break;
+                }
+            }
+            for (int k = 0; k < 4; ++k)
+                if (len[k] > 0 && base[lo[k] + len[k] - 1] == '\r') --len[k];
+            if (len[0] == 0 || base[lo[0]] != '@') {
+                *err = "Unexpected error parsing FASTQs: expected '@' at record " + std::to_string(nrec_) + " of " + path_;
+                return false;
+            }
+            if (len[2] == 0 || base[lo[2]] != '+') {
+                *err = "Unexpected error parsing FASTQs: expected '+' at record " + std::to_string(nrec_) + " of " + path_;
+                return false;
+            }
+            if (len[1] != len[3]) {
+                *err = "Unexpected error parsing FASTQs: sequence and quality lengths differ at record " +
+                       std::to_string(nrec_) + " of " + path_;
+                return false;
+            }
+            if (p > 0xFFFFFFFFull) { *err = "Unexpected error parsing FASTQs: batch larger than 4 GiB in " + path_; return false; }
+            FastqRec r;
+            r.head_off = (uint32_t)lo[0] + 1;
+            r.head_len = (uint32_t)len[0] - 1;
+            r.seq_off = (uint32_t)lo[1];
+            r.seq_len = (uint32_t)len[1];
+            r.qual_off = (uint32_t)lo[3];
+            out->recs.push_back(r);
+            pos = p;
+            ++nrec_;
+        }
+        map_pos_ += pos;
+        return true;
+    }
+
     static constexpr size_t kPiece = 4u << 20;
     struct Piece { std::vector<char> data; std::string error; bool eof = false; };
 
@@ -391,6 +474,8 @@ class FastqSource {
     }
 
     Kind kind_ = Kind::Plain;
+    const char *map_ = nullptr;
+    size_t map_size_ = 0, map_pos_ = 0;
     gzFile gz_ = nullptr;
     int fd_ = -1;
     std::string path_;

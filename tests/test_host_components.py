@@ -240,8 +240,14 @@ def test_large_inputs_plain_gzip_multimember_and_bgzf_block_parallel_agree(tmp_p
     bg = tmp_path / "big.bgzf.fastq.gz"
     blob = H.bgzf(text, 1)
     bg.write_bytes(blob)
-    want = H.fastq_digest(plain)
+    want = H.fastq_digest(plain)                       # regular file: memory-mapped, parsed in place
     assert want[0] == n and want[2] == 0
+    os.environ["FQTK_NO_MMAP"] = "1"                   # the read(2) + producer-thread path a pipe would take
+    try:
+        assert H.fastq_digest(plain) == want and H.fastq_digest(plain, batch=777) == want
+    finally:
+        del os.environ["FQTK_NO_MMAP"]
+    assert H.fastq_digest(plain, batch=777) == want
     assert H.fastq_digest(gz)[:2] == want[:2] and H.fastq_digest(gz)[2] == 1
     assert H.fastq_digest(multi)[:2] == want[:2]
     for helpers in (0, 1, 3):
