@@ -28,7 +28,9 @@ def test_bench_line_carries_scopes_create_time_cpu_rows_and_the_full_parity_gate
                     "--e2e-templates", "200000", "--e2e-threads", "8"]))
     assert d["n_gpus"] == 1 and d["unit"] == "M reads/s" and d["value"] > 0
     assert "bit-exact" in d["config"]["parity"] and "count vector of all 3000000 reads" in d["config"]["parity"]
-    assert set(d["scopes"]) == {"K", "B", "E"}
+    assert set(d["scopes"]) == {"K", "B", "E", "E_gpu_bgzf"}
+    assert d["scopes"]["E_gpu_bgzf"]["metrics_vs_oracle"] == "per-sample counts identical"
+    assert d["scopes"]["E_gpu_bgzf"]["extra_args"] == ["--gpu-bgzf"]
     assert d["scopes"]["B"]["M_reads_per_s"] > 0 and d["scopes"]["B"]["GB_per_s_over_pcie"] > 0
     assert d["scopes"]["E"]["templates"] == 200000 and d["scopes"]["E"]["metrics_vs_oracle"] == "per-sample counts identical"
     assert d["create_ms"] > 0

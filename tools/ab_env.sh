@@ -4,7 +4,7 @@
 set -e
 cd "$(dirname "$0")/.."
 cp fqtk_amd/lib/libfqtk_match.so /tmp/libfqtk_match.prod.so
-hipcc --offload-arch=gfx950 -O3 -std=c++17 -shared -fPIC -Iinclude -DFQTK_DEV_ABLATE -o fqtk_amd/lib/libfqtk_match.so fqtk_amd/csrc/fqtk_match.hip
+hipcc --offload-arch=gfx950 -O3 -std=c++17 -shared -fPIC -Iinclude -DFQTK_DEV_ABLATE -o fqtk_amd/lib/libfqtk_match.so fqtk_amd/csrc/fqtk_match.hip fqtk_amd/csrc/fqtk_bgzf.hip
 for rep in 1 2; do for c in ${CONFIGS:-5}; do for v in $VALUES; do
 env $VAR=$v python bench.py --config $c --steps 5 --warmup 1 --cpu-seconds 0 --no-verify --no-scopes "$@" 2>/dev/null | grep "^{" | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.readline()); print('cfg$c $VAR=$v', d['value'], d['roofline']['kernel_ms'])"
 done; done; done

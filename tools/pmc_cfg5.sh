@@ -8,7 +8,7 @@ O=$R/gpurun_out/$TAG
 mkdir -p $O
 cd $R
 cp fqtk_amd/lib/libfqtk_match.so /tmp/libfqtk_match.prod.so
-hipcc --offload-arch=gfx950 -O3 -std=c++17 -shared -fPIC -Iinclude -DFQTK_DEV_ABLATE -o fqtk_amd/lib/libfqtk_match.so fqtk_amd/csrc/fqtk_match.hip || exit 1
+hipcc --offload-arch=gfx950 -O3 -std=c++17 -shared -fPIC -Iinclude -DFQTK_DEV_ABLATE -o fqtk_amd/lib/libfqtk_match.so fqtk_amd/csrc/fqtk_match.hip fqtk_amd/csrc/fqtk_bgzf.hip || exit 1
 cd /tmp && export TMPDIR=/tmp
 B="python $R/bench.py --config 5 --steps 3 --warmup 1 --cpu-seconds 0 --no-verify --no-scopes"
 for nd in 0 1; do
