@@ -144,6 +144,10 @@ struct fqtk_matcher {
     mutable std::vector<const void *> ldsm_big_lds_ok;   // kernels already allowed > 64 KiB LDS on this device
     int memo_kind_wanted = 0;                  // 0 = best available, 1 = force the HBM/L2 table (tests, A/B)
     size_t ldsm_lds_bytes = 0;                 // image + LUT (histogram added at launch)
+    // worklist of the memo kernels' non-canonical reads (second pass: the scan kernel over the listed reads)
+    mutable uint32_t *d_work = nullptr;
+    mutable uint32_t *d_work_n = nullptr;
+    mutable uint64_t work_cap = 0;
     int use_cache = 1;                       // BarcodeMatcher.use_cache (barcode_matching.rs:41-42)
     Slot slots[kNumSlots];
 };
@@ -228,7 +232,7 @@ int launch_memo_vec(const fqtk_matcher *m, fqtk::MemoParams Q, hipStream_t strea
     // cfg 3 table pinned (16-byte rows) 148.0 / 141.6 / 139.4 (spills) / 178.0 / 91.2;
     // cfg 2 table pinned (8-byte rows) 236.4 / 203.0 / 248.2 / 234.1 / 182.9.
     const int direct = (KW == 1 && Q.direct) ? m->direct_bytes : 0;
-    int R = (vec > 0 && !P.lens) ? 2 : 1;
+    int R = (vec > 0 && vec != 5 && !P.lens) ? 2 : 1;   // 20-byte rows: two reads per lane would spill
     int abl = 0;
     bool pf = vec == 1 || vec == 2;
 #ifdef FQTK_DEV_ABLATE
@@ -318,7 +322,7 @@ int launch_memo_vec(const fqtk_matcher *m, fqtk::MemoParams Q, hipStream_t strea
         HIP_TRY(hipGetLastError());
         return FQTK_OK;
     }
-    if (!P.lens && vec > 0 && (R != 2 || pf != (vec <= 2))) {   // A/B of reads per lane and of the pipeline
+    if (!P.lens && vec > 0 && (R != (vec == 5 ? 1 : 2) || pf != (vec <= 2))) {   // A/B of reads per lane and of the pipeline
 #define FQTK_X(RR, D) FQTK_MEMO_PACKED(RR, 0, D, false)
 #define FQTK_Y(RR, D) FQTK_MEMO_PACKED(RR, 0, D, true)
         if (R == 4) FQTK_MEMO_BY_FORM(FQTK_X, 4);
@@ -344,11 +348,11 @@ int launch_memo_vec(const fqtk_matcher *m, fqtk::MemoParams Q, hipStream_t strea
         else FQTK_MEMO_LAUNCH_P(1, 2, 0, false, D, true);
         if (direct == 2) { FQTK_X(2) } else if (direct == 4) { FQTK_X(4) } else { FQTK_X(0) }
 #undef FQTK_X
-    } else if (vec > 0) {               // 12- / 16- / 20-byte rows: two reads per lane, plain loop
+    } else if (vec > 0) {               // 12- / 16-byte rows: two reads per lane (20-byte rows: one), plain loop
 #define FQTK_X(D)                                                       \
         if (vec == 3) FQTK_MEMO_LAUNCH_P(3, 2, 0, false, D, false);     \
         else if (vec == 4) FQTK_MEMO_LAUNCH_P(4, 2, 0, false, D, false);\
-        else FQTK_MEMO_LAUNCH_P(5, 2, 0, false, D, false);
+        else FQTK_MEMO_LAUNCH_P(5, 1, 0, false, D, false);
         if (direct == 2) { FQTK_X(2) } else if (direct == 4) { FQTK_X(4) } else { FQTK_X(0) }
 #undef FQTK_X
     } else {               // generic load paths: one read per lane
@@ -487,7 +491,52 @@ int launch_lds_memo(const fqtk_matcher *m, fqtk::LdsMemoParams Q, hipStream_t st
     return FQTK_OK;
 }
 
-int launch(const fqtk_matcher *m, const fqtk::MatchParams &P, hipStream_t stream) {
+// Second pass of a memo launch: the scan kernel over the reads the memo kernels listed (non-canonical bytes).
+int launch_second_pass(const fqtk_matcher *m, const fqtk::MatchParams &P0, hipStream_t stream) {
+    fqtk::MatchParams P = P0;
+    P.index = m->d_work;
+    P.index_n = m->d_work_n;
+    P.work = nullptr;
+    P.work_n = nullptr;
+    const uint32_t grid = (uint32_t)m->num_cus * 8;   // the kernel reads the list length itself; an empty list costs one launch
+    const size_t shmem = 256 * sizeof(uint32_t) + ((P.counts && P.lds_hist) ? (size_t)(P.S + 1) * sizeof(uint32_t) : 0);
+    const uintptr_t base = reinterpret_cast<uintptr_t>(P.obs);
+    if (P.stride % 4 == 0 && base % 4 == 0 && P.stride >= ((P.L + 3) / 4) * 4)
+        hipLaunchKernelGGL((fqtk::match_kernel<1, 1, -1, true>), dim3(grid), dim3(fqtk::kBlock), shmem, stream, P);
+    else
+        hipLaunchKernelGGL((fqtk::match_kernel<1, 1, 0, true>), dim3(grid), dim3(fqtk::kBlock), shmem, stream, P);
+    HIP_TRY(hipGetLastError());
+    return FQTK_OK;
+}
+
+int launch_memo(const fqtk_matcher *m, const fqtk::MatchParams &P, hipStream_t stream);
+
+int launch(const fqtk_matcher *m, const fqtk::MatchParams &P0, hipStream_t stream) {
+    const bool memo = m->use_cache && P0.stride >= P0.L && ((m->d_ldsm && m->memo_kind_wanted != 1) || m->d_memo);
+    if (!memo || P0.n > 0xFFFFFFFFull) return launch_memo(m, P0, stream);
+    // Memo launch with a worklist for the reads that are not in the memo (IUPAC / junk bytes in the READ): room
+    // for one read in sixteen (the rest, if any, is scanned in place by its wave); grown on demand, per matcher.
+    uint64_t want = std::max<uint64_t>(4096, P0.n / 16);
+    if (const char *cap = std::getenv("FQTK_WORKLIST_CAP")) want = (uint64_t)std::max(0l, std::atol(cap));   // test knob: force overflows
+    if (want > m->work_cap || !m->d_work_n) {
+        if (m->d_work) { HIP_TRY(hipStreamSynchronize(stream)); HIP_TRY(hipFree(m->d_work)); m->d_work = nullptr; }
+        if (!m->d_work_n) HIP_TRY(hipMalloc(reinterpret_cast<void **>(&m->d_work_n), sizeof(uint32_t)));
+        if (want) HIP_TRY(hipMalloc(reinterpret_cast<void **>(&m->d_work), want * sizeof(uint32_t)));
+        m->work_cap = want;
+    }
+    fqtk::MatchParams P = P0;
+    if (m->work_cap) {
+        P.work = m->d_work;
+        P.work_n = m->d_work_n;
+        P.work_cap = (uint32_t)std::min<uint64_t>(m->work_cap, 0xFFFFFFFFull);
+        HIP_TRY(hipMemsetAsync(m->d_work_n, 0, sizeof(uint32_t), stream));
+    }
+    const int rc = launch_memo(m, P, stream);
+    if (rc != FQTK_OK || !P.work) return rc;
+    return launch_second_pass(m, P, stream);
+}
+
+int launch_memo(const fqtk_matcher *m, const fqtk::MatchParams &P, hipStream_t stream) {
     // Rows shorter than a barcode (only legal with obs_len, check_batch_args): every read is shorter
     // than L, so every result is None (barcode_matching.rs:167-169) -- and no kernel below may read L
     // bytes from rows that do not hold them.
@@ -557,6 +606,11 @@ fqtk::MatchParams make_params(const fqtk_matcher *m, const void *d_obs, uint32_t
     P.nocall_limit = m->max_mm + m->max_ns;
     P.lds_hist = (m->S + 1 <= fqtk::kMaxLdsHist) ? 1u : 0u;
     P.scan_tab_lds = 0;   // the memo launchers turn it on when the table fits their LDS budget
+    P.work = nullptr;     // launch() attaches the worklist for the memo kernels
+    P.work_n = nullptr;
+    P.work_cap = 0;
+    P.index = nullptr;
+    P.index_n = nullptr;
     return P;
 }
 
@@ -1066,6 +1120,8 @@ void fqtk_matcher_destroy(fqtk_matcher *m) {
     }
     if (m->d_memo) (void)hipFree(m->d_memo);
     if (m->d_hot) (void)hipFree(m->d_hot);
+    if (m->d_work) (void)hipFree(m->d_work);
+    if (m->d_work_n) (void)hipFree(m->d_work_n);
     if (m->d_direct) (void)hipFree(m->d_direct);
     if (m->d_hot2) (void)hipFree(m->d_hot2);
     if (m->d_ldsm) (void)hipFree(m->d_ldsm);

@@ -243,6 +243,7 @@ void lds_memo_kernel(const LdsMemoParams Q) {
                 // '.' no-calls were looked up under N's key already: only IUPAC / junk bytes need the scan
                 const uint32_t really = (live[r] && bflag[r]) ? noncanonical_beyond_dots<NWD>(words[r], kc, kv) : 0u;
                 uint64_t todo = __builtin_amdgcn_uicmp(really, 0u, 33);
+                todo = defer_to_second_pass(P, todo, really != 0u, t * tile + local[r], res[r]);   // normally all of them
                 if (todo) {
                     Planes<1> mine;
                     encode_planes<1>(words[r], nwords, L, lds_lut, mine);
@@ -260,7 +261,7 @@ void lds_memo_kernel(const LdsMemoParams Q) {
         if (P.counts) {
 #pragma unroll
             for (int r = 0; r < R; ++r) {
-                if (!live[r]) continue;
+                if (!live[r] || res[r] == kMemoDeferred) continue;
                 const uint32_t bin = min(res[r] & 0xFFFFu, P.S);   // None (0xFFFF) -> bin S
                 if (hist_on) lds_atomic_inc(hist_base_b + bin * 4u);
                 else atomicAdd(&P.counts[bin], 1ull);

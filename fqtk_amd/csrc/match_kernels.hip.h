@@ -47,6 +47,14 @@ struct MatchParams {
     uint32_t nocall_limit;       // max_mismatches + max_ns_in_barcodes (barcode_matching.rs:171)
     uint32_t lds_hist;           // 1: histogram in LDS, 0: global atomics
     uint32_t scan_tab_lds;       // memo kernels: 1 = the wave scan of non-canonical reads finds the table in LDS
+    // Non-canonical reads (IUPAC / junk bytes in the READ) are not in the memo.  The memo kernels append their
+    // indices to `work` (work_n counts, also past work_cap: the overflow is scanned in place by its wave) and a
+    // second pass -- this scan kernel over the listed reads only, one lane per read -- resolves them.
+    uint32_t *work;              // [work_cap] read indices, or nullptr
+    uint32_t *work_n;
+    uint32_t work_cap;
+    const uint32_t *index;       // scan kernel, second pass: read j is obs row index[j], j < min(*index_n, work_cap)
+    const uint32_t *index_n;
 };
 
 __device__ __forceinline__ uint32_t med3_u32(uint32_t a, uint32_t b, uint32_t c) {
@@ -234,7 +242,8 @@ __global__ __launch_bounds__(256) void none_kernel(const MatchParams P) {
 
 // The kernel.  NW = 32-base words per plane (L <= 32*NW), R = reads per lane (amortises the scalar
 // table loads), VEC = load path (see load_words).
-template <int NW, int R, int VEC>
+// INDEXED: the second pass over the memo kernels' worklist (see MatchParams::work).
+template <int NW, int R, int VEC, bool INDEXED = false>
 __global__ __launch_bounds__(kBlock) void match_kernel(const MatchParams P) {
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
     uint32_t *lds_lut = smem;          // 256 entries
@@ -250,15 +259,20 @@ __global__ __launch_bounds__(kBlock) void match_kernel(const MatchParams P) {
     const uint32_t nwords = (P.L + 3u) >> 2;
     const const_u32x4_ptr tab = (const_u32x4_ptr)(uintptr_t)P.table;
     const uint64_t tile = (uint64_t)kBlock * R;
-    const uint64_t ntiles = (P.n + tile - 1) / tile;
+    uint64_t n_items = P.n;
+    if constexpr (INDEXED) { const uint32_t c = *P.index_n; n_items = c < P.work_cap ? c : P.work_cap; }
+    const uint64_t ntiles = (n_items + tile - 1) / tile;
 
     for (uint64_t t = blockIdx.x; t < ntiles; t += gridDim.x) {
         Planes<NW> o[R];
         bool live[R];
+        uint64_t row[R];   // obs / out row of the r-th read of this lane
 #pragma unroll
         for (int r = 0; r < R; ++r) {
-            const uint64_t i = t * tile + (uint64_t)r * kBlock + tid;
-            live[r] = i < P.n;
+            uint64_t i = t * tile + (uint64_t)r * kBlock + tid;
+            live[r] = i < n_items;
+            if constexpr (INDEXED) i = live[r] ? P.index[i] : 0;
+            row[r] = i;
             uint32_t words[NW * 8];
 #pragma unroll
             for (int w = 0; w < NW * 8; ++w) words[w] = 0;
@@ -298,7 +312,7 @@ __global__ __launch_bounds__(kBlock) void match_kernel(const MatchParams P) {
 #pragma unroll
         for (int r = 0; r < R; ++r) {
             if (!live[r]) continue;
-            const uint64_t i = t * tile + (uint64_t)r * kBlock + tid;
+            const uint64_t i = row[r];
             const uint32_t bm = best[r] >> 16;
             const uint32_t nm = second[r] >> 16;
             bool none = bm > P.max_mm || (nm - bm) < P.delta;

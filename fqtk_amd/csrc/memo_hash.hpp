@@ -19,6 +19,9 @@ FQTK_HD constexpr uint32_t memo_nibble_shift(uint32_t base) {   // bit offset of
     return base >= 16u ? 4u * (base - 16u) : 4u * (((base & 3u) << 1) | ((base & 7u) >> 2));
 }
 constexpr uint32_t kMemoEmpty = 0xFFFFFFFFu;
+// Placeholder a memo kernel writes for a read it handed to the second pass (index 0xFFFE is no sample: at most
+// 65534 of them); the second pass, next in the stream, overwrites it with the read's result.
+constexpr uint32_t kMemoDeferred = 0xFFFFFFFEu;
 
 #ifndef FQTK_HOT_BYTES
 #define FQTK_HOT_BYTES 65536

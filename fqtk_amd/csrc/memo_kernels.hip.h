@@ -179,6 +179,28 @@ __device__ __forceinline__ uint32_t noncanonical_beyond_dots(const uint32_t (&wo
     return bad;
 }
 
+// Hands the lanes in `flagged` (a wave-wide mask; `mine` = this lane is one of them) over to the second pass:
+// one atomic per wave reserves their slots in the worklist, each lane writes its read index.  Returns the lanes
+// that did NOT fit (worklist full / absent): the caller scans those in place.
+__device__ __forceinline__ uint64_t defer_to_second_pass(const MatchParams &P, uint64_t flagged, bool mine, uint64_t read_index,
+                                                         uint32_t &res) {
+    bool deferred = false;
+    if (!P.work || !flagged) return flagged;
+    const uint32_t lane = __lane_id();
+    const uint32_t cnt = (uint32_t)__popcll((unsigned long long)flagged);
+    const int leader = __ffsll((unsigned long long)flagged) - 1;
+    uint32_t base = 0;
+    if ((int)lane == leader) base = atomicAdd(P.work_n, cnt);
+    base = __shfl(base, leader);
+    const uint32_t rank = (uint32_t)__popcll((unsigned long long)(flagged & ((1ull << lane) - 1ull)));
+    if (mine && base + rank < P.work_cap) {
+        P.work[base + rank] = (uint32_t)read_index;
+        deferred = true;
+        res = kMemoDeferred;   // the second pass writes the result and counts it
+    }
+    return __ballot(mine && !deferred);
+}
+
 // LENS: the batch carries obs_len (variable-length '+B' structures): the memo serves the reads of length
 // exactly L, the others follow the length rules of barcode_matching.rs:165-172.  A separate instantiation,
 // so that the fixed-length kernels carry none of it.
@@ -397,6 +419,7 @@ void memo_kernel(const MemoParams Q) {
             if (__ballot(bad[r])) {   // wave-uniform
                 const bool really = bad[r] && noncanonical_beyond_dots<NWD>(words[r], kc, kv) != 0;
                 uint64_t todo = __ballot(really);
+                todo = defer_to_second_pass(P, todo, really, t * tile + local[r], res[r]);   // normally all of them
                 if (todo) {
                     Planes<1> mine;
                     encode_planes<1>(words[r], nwords, L, lds_lut, mine);
@@ -422,7 +445,7 @@ void memo_kernel(const MemoParams Q) {
                     if (len > L) overlong_read(P, i, len);
                 }
             }
-            if (P.counts && !(ABL & 4)) {
+            if (P.counts && !(ABL & 4) && res[r] != kMemoDeferred) {
                 const uint32_t idx = res[r] & 0xFFFFu;
                 const uint32_t bin = idx == kNoMatch ? P.S : idx;
                 if (P.lds_hist) atomicAdd(&lds_hist[bin], 1u);

@@ -204,6 +204,27 @@ def test_memo_path_handles_non_canonical_reads_in_every_lane_position():
     _compare(w.barcodes, 2, 1, obs)
 
 
+@pytest.mark.parametrize("cap", ["0", "5", "100", None])
+def test_second_pass_worklist_and_its_overflow(cap, monkeypatch):
+    """The memo kernels list the reads with IUPAC / junk bytes and the scan kernel resolves them in a second
+    pass; what does not fit in the list is scanned in place by its wave.  A tiny (or absent) list forces the
+    overflow path; results and counts must not depend on where a read was resolved."""
+    if cap is not None:
+        monkeypatch.setenv("FQTK_WORKLIST_CAP", cap)
+    rng = np.random.default_rng(11)
+    for k, n in ((3, 20000), (2, 9000), (5, 9000)):
+        w = synth.Workload(synth.CONFIGS[k])
+        cfg = w.cfg
+        L = len(w.barcodes[0])
+        obs = w.fill_host(0, n).copy()
+        rows = rng.choice(n, n // 5, replace=False)                       # 20 % of the reads: more than the default list holds
+        obs[rows, rng.integers(0, L, rows.size)] = rng.choice(np.frombuffer(b"RYKM#x", dtype=np.uint8), rows.size)
+        obs[rng.integers(0, n, 500), rng.integers(0, L, 500)] = ord(".")  # '.' reads stay with the memo
+        _compare(w.barcodes, cfg.max_mismatches, cfg.min_mismatch_delta, obs)
+        lens = np.where(rng.random(n) < 0.9, L, rng.integers(0, L + 1, size=n)).astype(np.uint32)
+        _compare(w.barcodes, cfg.max_mismatches, cfg.min_mismatch_delta, obs, lens)
+
+
 # ------------------------------------------------------------------------------------------------
 # seeded random parity vs the oracle
 # ------------------------------------------------------------------------------------------------
