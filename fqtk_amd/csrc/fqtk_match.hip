@@ -14,6 +14,7 @@
 #include <cstring>
 #include <new>
 #include <string>
+#include <deque>
 #include <vector>
 
 #include "../../include/fqtk_match.h"
@@ -82,6 +83,19 @@ struct ErrCtx {
     bool device = false;
 };
 
+// Worklist of the memo kernels' non-canonical reads (MatchParams::work): one per stream batches run on.
+struct Worklist {
+    uint32_t *d_list = nullptr;   // [segments][cap] read indices
+    uint32_t *d_fill = nullptr;   // [segments] entries used; zero between launches
+    uint32_t cap = 0;
+    void release() {
+        if (d_list) (void)hipFree(d_list);
+        if (d_fill) (void)hipFree(d_fill);
+        d_list = d_fill = nullptr;
+        cap = 0;
+    }
+};
+
 struct Slot {
     hipStream_t stream = nullptr;
     uint8_t *d_obs = nullptr;
@@ -92,6 +106,7 @@ struct Slot {
     size_t out_cap = 0;  // elements
     bool busy = false;
     ErrCtx ctx;          // the chunk in flight on this slot
+    Worklist work;
 };
 
 // Pipeline slots 0..FQTK_MAX_SLOTS-1 belong to the caller (enqueue/wait); two more are private to the
@@ -144,10 +159,7 @@ struct fqtk_matcher {
     mutable std::vector<const void *> ldsm_big_lds_ok;   // kernels already allowed > 64 KiB LDS on this device
     int memo_kind_wanted = 0;                  // 0 = best available, 1 = force the HBM/L2 table (tests, A/B)
     size_t ldsm_lds_bytes = 0;                 // image + LUT (histogram added at launch)
-    // worklist of the memo kernels' non-canonical reads (second pass: the scan kernel over the listed reads)
-    mutable uint32_t *d_work = nullptr;
-    mutable uint32_t *d_work_n = nullptr;
-    mutable uint64_t work_cap = 0;
+    std::deque<std::pair<hipStream_t, Worklist>> stream_work;   // worklists of the *_device entry point, by caller stream
     int use_cache = 1;                       // BarcodeMatcher.use_cache (barcode_matching.rs:41-42)
     Slot slots[kNumSlots];
 };
@@ -492,13 +504,8 @@ int launch_lds_memo(const fqtk_matcher *m, fqtk::LdsMemoParams Q, hipStream_t st
 }
 
 // Second pass of a memo launch: the scan kernel over the reads the memo kernels listed (non-canonical bytes).
-int launch_second_pass(const fqtk_matcher *m, const fqtk::MatchParams &P0, hipStream_t stream) {
-    fqtk::MatchParams P = P0;
-    P.index = m->d_work;
-    P.index_n = m->d_work_n;
-    P.work = nullptr;
-    P.work_n = nullptr;
-    const uint32_t grid = (uint32_t)m->num_cus * 8;   // the kernel reads the list length itself; an empty list costs one launch
+int launch_second_pass(const fqtk_matcher *m, const fqtk::MatchParams &P, hipStream_t stream) {
+    const uint32_t grid = (uint32_t)m->num_cus * 8;   // a workgroup takes whole segments; empty ones cost it one scalar load
     const size_t shmem = 256 * sizeof(uint32_t) + ((P.counts && P.lds_hist) ? (size_t)(P.S + 1) * sizeof(uint32_t) : 0);
     const uintptr_t base = reinterpret_cast<uintptr_t>(P.obs);
     if (P.stride % 4 == 0 && base % 4 == 0 && P.stride >= ((P.L + 3) / 4) * 4)
@@ -511,29 +518,50 @@ int launch_second_pass(const fqtk_matcher *m, const fqtk::MatchParams &P0, hipSt
 
 int launch_memo(const fqtk_matcher *m, const fqtk::MatchParams &P, hipStream_t stream);
 
-int launch(const fqtk_matcher *m, const fqtk::MatchParams &P0, hipStream_t stream) {
+// One batch: the memo kernel (or the scan, or the all-None fill) and, behind a memo kernel, the second pass.
+// `wl` = the worklist of the stream the batch runs on (batches on different streams may overlap).
+int launch(const fqtk_matcher *m, const fqtk::MatchParams &P0, hipStream_t stream, Worklist &wl) {
     const bool memo = m->use_cache && P0.stride >= P0.L && ((m->d_ldsm && m->memo_kind_wanted != 1) || m->d_memo);
     if (!memo || P0.n > 0xFFFFFFFFull) return launch_memo(m, P0, stream);
-    // Memo launch with a worklist for the reads that are not in the memo (IUPAC / junk bytes in the READ): room
-    // for one read in sixteen (the rest, if any, is scanned in place by its wave); grown on demand, per matcher.
-    uint64_t want = std::max<uint64_t>(4096, P0.n / 16);
-    if (const char *cap = std::getenv("FQTK_WORKLIST_CAP")) want = (uint64_t)std::max(0l, std::atol(cap));   // test knob: force overflows
-    if (want > m->work_cap || !m->d_work_n) {
-        if (m->d_work) { HIP_TRY(hipStreamSynchronize(stream)); HIP_TRY(hipFree(m->d_work)); m->d_work = nullptr; }
-        if (!m->d_work_n) HIP_TRY(hipMalloc(reinterpret_cast<void **>(&m->d_work_n), sizeof(uint32_t)));
-        if (want) HIP_TRY(hipMalloc(reinterpret_cast<void **>(&m->d_work), want * sizeof(uint32_t)));
-        m->work_cap = want;
+    // One segment per wave the chip can hold (the memo grids never exceed that); room for one read in eight
+    // overall (what does not fit is scanned in place by its wave); grown on demand.
+    const uint32_t segs = (uint32_t)m->num_cus * 32u;
+    uint64_t want = std::max<uint64_t>(64, (P0.n / 8 + segs - 1) / segs);
+    if (const char *cap = std::getenv("FQTK_WORKLIST_CAP")) want = (uint64_t)std::max(0l, std::atol(cap));   // test knob: entries per segment
+    if (want > wl.cap || !wl.d_fill) {
+        if (wl.d_list) { HIP_TRY(hipStreamSynchronize(stream)); HIP_TRY(hipFree(wl.d_list)); wl.d_list = nullptr; }
+        if (!wl.d_fill) {
+            HIP_TRY(hipMalloc(reinterpret_cast<void **>(&wl.d_fill), segs * sizeof(uint32_t)));
+            HIP_TRY(hipMemsetAsync(wl.d_fill, 0, segs * sizeof(uint32_t), stream));   // the second pass keeps it zero from here on
+        }
+        if (want) HIP_TRY(hipMalloc(reinterpret_cast<void **>(&wl.d_list), (size_t)segs * want * sizeof(uint32_t)));
+        wl.cap = (uint32_t)want;
     }
     fqtk::MatchParams P = P0;
-    if (m->work_cap) {
-        P.work = m->d_work;
-        P.work_n = m->d_work_n;
-        P.work_cap = (uint32_t)std::min<uint64_t>(m->work_cap, 0xFFFFFFFFull);
-        HIP_TRY(hipMemsetAsync(m->d_work_n, 0, sizeof(uint32_t), stream));
+    if (want && wl.cap) {
+        P.work = wl.d_list;
+        P.work_n = wl.d_fill;
+        P.work_cap = wl.cap;
+        P.work_segs = segs;
     }
     const int rc = launch_memo(m, P, stream);
-    if (rc != FQTK_OK || !P.work) return rc;
+    if (rc != FQTK_OK || !P.work_segs) return rc;
     return launch_second_pass(m, P, stream);
+}
+
+// The worklist of a caller's stream (the *_device entry point).  A handful of streams at most in practice;
+// past 16 the table is dropped (after the device has drained) and starts over.
+int worklist_of_stream(fqtk_matcher *m, hipStream_t stream, Worklist **out) {
+    for (auto &e : m->stream_work)
+        if (e.first == stream) { *out = &e.second; return FQTK_OK; }
+    if (m->stream_work.size() >= 16) {
+        HIP_TRY(hipDeviceSynchronize());
+        for (auto &e : m->stream_work) e.second.release();
+        m->stream_work.clear();
+    }
+    m->stream_work.emplace_back(stream, Worklist{});
+    *out = &m->stream_work.back().second;
+    return FQTK_OK;
 }
 
 int launch_memo(const fqtk_matcher *m, const fqtk::MatchParams &P, hipStream_t stream) {
@@ -609,8 +637,7 @@ fqtk::MatchParams make_params(const fqtk_matcher *m, const void *d_obs, uint32_t
     P.work = nullptr;     // launch() attaches the worklist for the memo kernels
     P.work_n = nullptr;
     P.work_cap = 0;
-    P.index = nullptr;
-    P.index_n = nullptr;
+    P.work_segs = 0;
     return P;
 }
 
@@ -1117,11 +1144,11 @@ void fqtk_matcher_destroy(fqtk_matcher *m) {
         if (s.d_obs) (void)hipFree(s.d_obs);
         if (s.d_len) (void)hipFree(s.d_len);
         if (s.d_out) (void)hipFree(s.d_out);
+        s.work.release();
     }
     if (m->d_memo) (void)hipFree(m->d_memo);
     if (m->d_hot) (void)hipFree(m->d_hot);
-    if (m->d_work) (void)hipFree(m->d_work);
-    if (m->d_work_n) (void)hipFree(m->d_work_n);
+    for (auto &e : m->stream_work) e.second.release();
     if (m->d_direct) (void)hipFree(m->d_direct);
     if (m->d_hot2) (void)hipFree(m->d_hot2);
     if (m->d_ldsm) (void)hipFree(m->d_ldsm);
@@ -1180,7 +1207,9 @@ int fqtk_matcher_assign_batch_device(fqtk_matcher *m, const void *d_obs, uint32_
     HIP_TRY(hipSetDevice(m->device));
     const fqtk::MatchParams P = make_params(m, d_obs, stride, d_obs_len, n, d_out, d_counts, kDeviceErrWord);
     m->device_ctx = ErrCtx{static_cast<const uint8_t *>(d_obs), static_cast<const uint32_t *>(d_obs_len), stride, n, true};
-    return launch(m, P, static_cast<hipStream_t>(hip_stream));
+    Worklist *wl = nullptr;
+    if ((rc = worklist_of_stream(m, static_cast<hipStream_t>(hip_stream), &wl)) != FQTK_OK) return rc;
+    return launch(m, P, static_cast<hipStream_t>(hip_stream), *wl);
 }
 
 int fqtk_matcher_poll_error(fqtk_matcher *m, void *hip_stream, uint64_t *read_index) {
@@ -1218,7 +1247,7 @@ int enqueue_impl(fqtk_matcher *m, int slot, const uint8_t *obs, uint32_t stride,
     const fqtk::MatchParams P =
         make_params(m, s.d_obs, stride, obs_len ? s.d_len : nullptr, n, s.d_out, d_counts_target, slot);
     s.ctx = ErrCtx{obs, obs_len, stride, n, false};
-    rc = launch(m, P, s.stream);
+    rc = launch(m, P, s.stream, s.work);
     if (rc != FQTK_OK) return rc;
     HIP_TRY(hipMemcpyAsync(out, s.d_out, (size_t)n * sizeof(fqtk_match_t), hipMemcpyDeviceToHost, s.stream));
     s.busy = true;

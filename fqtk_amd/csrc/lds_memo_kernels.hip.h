@@ -162,6 +162,9 @@ void lds_memo_kernel(const LdsMemoParams Q) {
         }
     };
 
+    // this wave's segment of the second pass's worklist, and how much of it is used
+    const uint32_t work_seg = blockIdx.x * (kLdsBlock / 64u) + (uint32_t)__builtin_amdgcn_readfirstlane((int)(tid >> 6));   // wave-uniform: SGPRs
+    uint32_t work_fill = 0;
     // Looks one tile up: res[r] = the result word of the tile's r-th read; also feeds the LDS histogram.
     auto compute = [&](uint64_t t, uint32_t (&words)[R][8], const bool (&live)[R], uint32_t (&res)[R]) {
         uint32_t bflag[R];
@@ -243,7 +246,7 @@ void lds_memo_kernel(const LdsMemoParams Q) {
                 // '.' no-calls were looked up under N's key already: only IUPAC / junk bytes need the scan
                 const uint32_t really = (live[r] && bflag[r]) ? noncanonical_beyond_dots<NWD>(words[r], kc, kv) : 0u;
                 uint64_t todo = __builtin_amdgcn_uicmp(really, 0u, 33);
-                todo = defer_to_second_pass(P, todo, really != 0u, t * tile + local[r], res[r]);   // normally all of them
+                todo = defer_to_second_pass(P, work_seg, work_fill, todo, really != 0u, t * tile + local[r], res[r]);   // normally all of them
                 if (todo) {
                     Planes<1> mine;
                     encode_planes<1>(words[r], nwords, L, lds_lut, mine);
@@ -354,6 +357,7 @@ void lds_memo_kernel(const LdsMemoParams Q) {
         compute(t, words, live, res);
         store_any(t, res, live);
     }
+    publish_worklist_fill(P, work_seg, work_fill);
 
     if (P.counts && P.lds_hist) {
         __syncthreads();

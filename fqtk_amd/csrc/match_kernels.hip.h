@@ -47,14 +47,15 @@ struct MatchParams {
     uint32_t nocall_limit;       // max_mismatches + max_ns_in_barcodes (barcode_matching.rs:171)
     uint32_t lds_hist;           // 1: histogram in LDS, 0: global atomics
     uint32_t scan_tab_lds;       // memo kernels: 1 = the wave scan of non-canonical reads finds the table in LDS
-    // Non-canonical reads (IUPAC / junk bytes in the READ) are not in the memo.  The memo kernels append their
-    // indices to `work` (work_n counts, also past work_cap: the overflow is scanned in place by its wave) and a
-    // second pass -- this scan kernel over the listed reads only, one lane per read -- resolves them.
-    uint32_t *work;              // [work_cap] read indices, or nullptr
-    uint32_t *work_n;
-    uint32_t work_cap;
-    const uint32_t *index;       // scan kernel, second pass: read j is obs row index[j], j < min(*index_n, work_cap)
-    const uint32_t *index_n;
+    // Non-canonical reads (IUPAC / junk bytes in the READ) are not in the memo.  Every wave of a memo kernel owns
+    // one segment of `work` and appends the indices of its such reads there -- no atomics: one counter on one
+    // address serialises in L2 at ~8 ns per wave that has anything to add, 25 x the kernel's own time at 1 % of
+    // reads -- and what does not fit is scanned in place by the wave.  A second pass, this scan kernel over the
+    // listed reads only (one lane per read), resolves them and zeroes the fill counts again.
+    uint32_t *work;              // [work_segs][work_cap] read indices
+    uint32_t *work_n;            // [work_segs] entries filled; all zero between launches
+    uint32_t work_cap;           // entries per segment
+    uint32_t work_segs;          // 0: no list (every such read is scanned in place)
 };
 
 __device__ __forceinline__ uint32_t med3_u32(uint32_t a, uint32_t b, uint32_t c) {
@@ -259,11 +260,21 @@ __global__ __launch_bounds__(kBlock) void match_kernel(const MatchParams P) {
     const uint32_t nwords = (P.L + 3u) >> 2;
     const const_u32x4_ptr tab = (const_u32x4_ptr)(uintptr_t)P.table;
     const uint64_t tile = (uint64_t)kBlock * R;
+    // INDEXED: a workgroup takes whole segments of the worklist, one after the other; else one pass over the batch
+    for (uint32_t seg = INDEXED ? blockIdx.x : 0; seg < (INDEXED ? P.work_segs : 1u); seg += INDEXED ? gridDim.x : 1u) {
     uint64_t n_items = P.n;
-    if constexpr (INDEXED) { const uint32_t c = *P.index_n; n_items = c < P.work_cap ? c : P.work_cap; }
+    const uint32_t *list = nullptr;
+    if constexpr (INDEXED) {
+        const uint32_t c = P.work_n[seg];
+        n_items = c < P.work_cap ? c : P.work_cap;
+        list = P.work + (uint64_t)seg * P.work_cap;
+        if (n_items == 0) continue;   // workgroup-uniform
+        __syncthreads();              // every lane has read the count ...
+        if (tid == 0) P.work_n[seg] = 0;   // ... so it can go back to zero for the next launch
+    }
     const uint64_t ntiles = (n_items + tile - 1) / tile;
 
-    for (uint64_t t = blockIdx.x; t < ntiles; t += gridDim.x) {
+    for (uint64_t t = INDEXED ? 0 : blockIdx.x; t < ntiles; t += INDEXED ? 1 : gridDim.x) {
         Planes<NW> o[R];
         bool live[R];
         uint64_t row[R];   // obs / out row of the r-th read of this lane
@@ -271,7 +282,7 @@ __global__ __launch_bounds__(kBlock) void match_kernel(const MatchParams P) {
         for (int r = 0; r < R; ++r) {
             uint64_t i = t * tile + (uint64_t)r * kBlock + tid;
             live[r] = i < n_items;
-            if constexpr (INDEXED) i = live[r] ? P.index[i] : 0;
+            if constexpr (INDEXED) i = live[r] ? list[i] : 0;
             row[r] = i;
             uint32_t words[NW * 8];
 #pragma unroll
@@ -334,6 +345,7 @@ __global__ __launch_bounds__(kBlock) void match_kernel(const MatchParams P) {
                 else atomicAdd(&P.counts[bin], 1ull);
             }
         }
+    }
     }
 
     if (P.counts && P.lds_hist) {

@@ -180,25 +180,24 @@ __device__ __forceinline__ uint32_t noncanonical_beyond_dots(const uint32_t (&wo
 }
 
 // Hands the lanes in `flagged` (a wave-wide mask; `mine` = this lane is one of them) over to the second pass:
-// one atomic per wave reserves their slots in the worklist, each lane writes its read index.  Returns the lanes
-// that did NOT fit (worklist full / absent): the caller scans those in place.
-__device__ __forceinline__ uint64_t defer_to_second_pass(const MatchParams &P, uint64_t flagged, bool mine, uint64_t read_index,
-                                                         uint32_t &res) {
-    bool deferred = false;
-    if (!P.work || !flagged) return flagged;
-    const uint32_t lane = __lane_id();
-    const uint32_t cnt = (uint32_t)__popcll((unsigned long long)flagged);
-    const int leader = __ffsll((unsigned long long)flagged) - 1;
-    uint32_t base = 0;
-    if ((int)lane == leader) base = atomicAdd(P.work_n, cnt);
-    base = __shfl(base, leader);
-    const uint32_t rank = (uint32_t)__popcll((unsigned long long)(flagged & ((1ull << lane) - 1ull)));
-    if (mine && base + rank < P.work_cap) {
-        P.work[base + rank] = (uint32_t)read_index;
-        deferred = true;
+// each writes its read index into the wave's own segment of the worklist (`fill` = entries used so far,
+// wave-uniform) and gets the placeholder result.  Returns the lanes that did NOT fit (segment full / no list):
+// the caller scans those in place.
+__device__ __forceinline__ uint64_t defer_to_second_pass(const MatchParams &P, uint32_t seg, uint32_t &fill, uint64_t flagged,
+                                                         bool mine, uint64_t read_index, uint32_t &res) {
+    if (seg >= P.work_segs || !flagged) return flagged;
+    const uint32_t at = fill + (uint32_t)__popcll((unsigned long long)(flagged & ((1ull << __lane_id()) - 1ull)));
+    const bool fits = mine && at < P.work_cap;
+    if (fits) {
+        P.work[(uint64_t)seg * P.work_cap + at] = (uint32_t)read_index;
         res = kMemoDeferred;   // the second pass writes the result and counts it
     }
-    return __ballot(mine && !deferred);
+    fill = (uint32_t)__builtin_amdgcn_readfirstlane((int)min(fill + (uint32_t)__popcll((unsigned long long)flagged), P.work_cap));
+    return __ballot(mine && !fits);
+}
+// The wave's fill count goes out once, at the end of the kernel.
+__device__ __forceinline__ void publish_worklist_fill(const MatchParams &P, uint32_t seg, uint32_t fill) {
+    if (fill && __lane_id() == 0) P.work_n[seg] = fill;
 }
 
 // LENS: the batch carries obs_len (variable-length '+B' structures): the memo serves the reads of length
@@ -298,6 +297,9 @@ void memo_kernel(const MemoParams Q) {
         }
     };
 
+    // this wave's segment of the second pass's worklist, and how much of it is used
+    const uint32_t work_seg = blockIdx.x * (kMemoBlock / 64u) + (uint32_t)__builtin_amdgcn_readfirstlane((int)(tid >> 6));   // wave-uniform: SGPRs
+    uint32_t work_fill = 0;
     // Looks one tile up: res[r] = the result word of the tile's r-th read; also feeds the histogram.
     auto lookup = [&](uint64_t t, uint32_t (&words)[R][8], const bool (&live)[R], uint32_t (&res)[R]) {
         uint32_t lo[R], hi[R], ext[R], didx[R];
@@ -419,7 +421,7 @@ void memo_kernel(const MemoParams Q) {
             if (__ballot(bad[r])) {   // wave-uniform
                 const bool really = bad[r] && noncanonical_beyond_dots<NWD>(words[r], kc, kv) != 0;
                 uint64_t todo = __ballot(really);
-                todo = defer_to_second_pass(P, todo, really, t * tile + local[r], res[r]);   // normally all of them
+                todo = defer_to_second_pass(P, work_seg, work_fill, todo, really, t * tile + local[r], res[r]);   // normally all of them
                 if (todo) {
                     Planes<1> mine;
                     encode_planes<1>(words[r], nwords, L, lds_lut, mine);
@@ -540,6 +542,7 @@ void memo_kernel(const MemoParams Q) {
         lookup(t, words, live, res);
         store_any(t, res, live);
     }
+    publish_worklist_fill(P, work_seg, work_fill);
 
     if (P.counts && P.lds_hist) {
         __syncthreads();

@@ -204,7 +204,7 @@ def test_memo_path_handles_non_canonical_reads_in_every_lane_position():
     _compare(w.barcodes, 2, 1, obs)
 
 
-@pytest.mark.parametrize("cap", ["0", "5", "100", None])
+@pytest.mark.parametrize("cap", ["0", "1", "7", None])
 def test_second_pass_worklist_and_its_overflow(cap, monkeypatch):
     """The memo kernels list the reads with IUPAC / junk bytes and the scan kernel resolves them in a second
     pass; what does not fit in the list is scanned in place by its wave.  A tiny (or absent) list forces the
