@@ -383,7 +383,7 @@ int launch_memo_vec(const fqtk_matcher *m, fqtk::MemoParams Q, hipStream_t strea
 }
 
 template <int KW, bool POW2>
-int launch_lds_memo(const fqtk_matcher *m, fqtk::LdsMemoParams Q, hipStream_t stream) {
+int launch_lds_memo(const fqtk_matcher *m, fqtk::LdsMemoParams Q, hipStream_t stream, bool second_pass = false) {
     const fqtk::MatchParams &P = Q.m;
     const uintptr_t base = reinterpret_cast<uintptr_t>(P.obs);
     const uint32_t nwords = (P.L + 3) / 4;
@@ -416,19 +416,21 @@ int launch_lds_memo(const fqtk_matcher *m, fqtk::LdsMemoParams Q, hipStream_t st
 #ifdef FQTK_DEV_ABLATE
     if (const char *rr = std::getenv("FQTK_MEMO_R")) R = std::atoi(rr);
 #endif
-    if (P.lens) R = 1;
+    if (P.lens || second_pass) R = 1;
     const uint64_t tile = (uint64_t)fqtk::kLdsBlock * R;
     const uint64_t ntiles = (P.n + tile - 1) / tile;
     if (ntiles == 0) return FQTK_OK;
     // workgroups per CU: LDS-limited, and never more than 2 x 1024 lanes
     const uint32_t per_cu = (uint32_t)std::max<size_t>(1, std::min<size_t>(2048 / fqtk::kLdsBlock, fqtk::kLdsMemoMaxBytes / (shmem + 1024)));
-    const uint32_t grid = (uint32_t)std::min<uint64_t>(ntiles, (uint64_t)m->num_cus * per_cu);
+    // (the second pass: every wave the chip holds takes the worklist segments it owns, most of them empty)
+    const uint32_t grid = second_pass ? (uint32_t)m->num_cus * per_cu : (uint32_t)std::min<uint64_t>(ntiles, (uint64_t)m->num_cus * per_cu);
 #define FQTK_LDSM_LAUNCH(V, RR) FQTK_LDSM_LAUNCH_L(V, RR, false)
 #define FQTK_LDSM_LAUNCH_L(V, RR, LENS) FQTK_LDSM_LAUNCH_P(V, RR, LENS, false)
-#define FQTK_LDSM_LAUNCH_P(V, RR, LENS, PF)                                                                \
+#define FQTK_LDSM_LAUNCH_P(V, RR, LENS, PF) FQTK_LDSM_LAUNCH_I(V, RR, LENS, PF, false)
+#define FQTK_LDSM_LAUNCH_I(V, RR, LENS, PF, IDX)                                                           \
     do {                                                                                                   \
         if constexpr ((V) <= 0 || KW == ((V) == 5 ? 3 : ((V) >= 3 ? 2 : 1))) {                             \
-            auto kern = fqtk::lds_memo_kernel<V, KW, RR, POW2, LENS, PF>;                                  \
+            auto kern = fqtk::lds_memo_kernel<V, KW, RR, POW2, LENS, PF, IDX>;                             \
             /* > 64 KiB of dynamic LDS must be allowed per kernel AND per device: remembered per matcher */ \
             const void *fn = reinterpret_cast<const void *>(kern);                                         \
             if (shmem > 64 * 1024 &&                                                                       \
@@ -449,7 +451,10 @@ int launch_lds_memo(const fqtk_matcher *m, fqtk::LdsMemoParams Q, hipStream_t st
         return FQTK_OK;
     }
 #endif
-    if (P.lens) {   // variable-length batch: the LENS instantiations, one read per lane
+    if (second_pass) {   // rows gathered through the worklist: the generic load paths
+        if (vec != 0) FQTK_LDSM_LAUNCH_I(-1, 1, false, false, true);
+        else FQTK_LDSM_LAUNCH_I(0, 1, false, false, true);
+    } else if (P.lens) {   // variable-length batch: the LENS instantiations, one read per lane
         switch (vec) {
             case 5: FQTK_LDSM_LAUNCH_L(5, 1, true); break;
             case 4: FQTK_LDSM_LAUNCH_L(4, 1, true); break;
@@ -499,12 +504,29 @@ int launch_lds_memo(const fqtk_matcher *m, fqtk::LdsMemoParams Q, hipStream_t st
 #undef FQTK_LDSM_LAUNCH
 #undef FQTK_LDSM_LAUNCH_L
 #undef FQTK_LDSM_LAUNCH_P
+#undef FQTK_LDSM_LAUNCH_I
     HIP_TRY(hipGetLastError());
     return FQTK_OK;
 }
 
-// Second pass of a memo launch: the scan kernel over the reads the memo kernels listed (non-canonical bytes).
-int launch_second_pass(const fqtk_matcher *m, const fqtk::MatchParams &P, hipStream_t stream) {
+// Second pass of a memo launch, over the reads the memo kernel listed (a byte other than A C G T N . in them).
+// LDS form (plain A/C/G/T samples by construction): the memo again, with the reads' ambiguity codes spelled as N.
+// Table form: the scan kernel, one lane per listed read.
+int launch_second_pass(const fqtk_matcher *m, const fqtk::MatchParams &P0, hipStream_t stream) {
+    if (m->d_ldsm && m->memo_kind_wanted != 1) {
+        fqtk::LdsMemoParams Q = m->ldsm;
+        Q.m = P0;
+        Q.m.lens = nullptr;   // only reads of length L are ever listed
+        switch (m->ldsm_kw * 2 + (m->ldsm_pow2 ? 1 : 0)) {
+            case 3: return launch_lds_memo<1, true>(m, Q, stream, true);
+            case 2: return launch_lds_memo<1, false>(m, Q, stream, true);
+            case 5: return launch_lds_memo<2, true>(m, Q, stream, true);
+            case 4: return launch_lds_memo<2, false>(m, Q, stream, true);
+            case 7: return launch_lds_memo<3, true>(m, Q, stream, true);
+            default: return launch_lds_memo<3, false>(m, Q, stream, true);
+        }
+    }
+    const fqtk::MatchParams &P = P0;
     const uint32_t grid = (uint32_t)m->num_cus * 8;   // a workgroup takes whole segments; empty ones cost it one scalar load
     const size_t shmem = 256 * sizeof(uint32_t) + ((P.counts && P.lds_hist) ? (size_t)(P.S + 1) * sizeof(uint32_t) : 0);
     const uintptr_t base = reinterpret_cast<uintptr_t>(P.obs);

@@ -73,9 +73,15 @@ __device__ __forceinline__ uint32_t lane_select(uint64_t mask, uint32_t a, uint3
 // looked up, so a wave always has a load in flight while it computes.  With R = 1 this is the stream shape
 // the memory system likes best (tools/hbm_stream.hip: one 1-KiB request per wave at a time, 256 tiles = a
 // 4-MiB window sweeping the buffer) without the compute latency serialised behind every load.
-template <int VEC, int KW, int R, bool POW2, bool LENS = false, bool PF = false>   // LENS: see memo_kernel
+// INDEXED: the second pass.  The first pass (any instantiation without it) lists the reads that carry a byte other
+// than A C G T N . and gives them a placeholder result; this one takes the listed reads -- each wave the segments
+// of the worklist it owns, 64 reads at a time -- spells their ambiguity codes as N (spell_ambiguity_codes_as_n:
+// this form exists for plain A/C/G/T samples only) and looks them up like any other read.  What is left
+// non-canonical then (bytes of no IUPAC meaning) is scanned in place by its wave.
+template <int VEC, int KW, int R, bool POW2, bool LENS = false, bool PF = false, bool INDEXED = false>   // LENS: see memo_kernel
 __global__ __launch_bounds__(kLdsBlock) __attribute__((amdgpu_waves_per_eu(4, 8)))
 void lds_memo_kernel(const LdsMemoParams Q) {
+    static_assert(!INDEXED || (R == 1 && VEC <= 0 && !LENS && !PF), "the second pass gathers single rows");
     const MatchParams &P = Q.m;
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
     // LDS: [entry table | sample keys | spread LUT (fallback scan) | histogram]; the entry table sits
@@ -246,7 +252,8 @@ void lds_memo_kernel(const LdsMemoParams Q) {
                 // '.' no-calls were looked up under N's key already: only IUPAC / junk bytes need the scan
                 const uint32_t really = (live[r] && bflag[r]) ? noncanonical_beyond_dots<NWD>(words[r], kc, kv) : 0u;
                 uint64_t todo = __builtin_amdgcn_uicmp(really, 0u, 33);
-                todo = defer_to_second_pass(P, work_seg, work_fill, todo, really != 0u, t * tile + local[r], res[r]);   // normally all of them
+                if constexpr (!INDEXED)
+                    todo = defer_to_second_pass(P, work_seg, work_fill, todo, really != 0u, t * tile + local[r], res[r]);   // normally all of them
                 if (todo) {
                     Planes<1> mine;
                     encode_planes<1>(words[r], nwords, L, lds_lut, mine);
@@ -283,11 +290,35 @@ void lds_memo_kernel(const LdsMemoParams Q) {
             if (live[r]) FQTK_STREAM_STORE(res[r], &P.out[t * tile + local[r]]);
     };
 
-    const uint64_t full_tiles = (VEC >= 1) ? P.n / tile : 0;
+    if constexpr (INDEXED) {
+        const uint32_t lane = tid & 63u;
+        const uint32_t waves = gridDim.x * (kLdsBlock / 64u);
+        for (uint32_t seg = work_seg; seg < P.work_segs; seg += waves) {   // wave-private: no barrier in here
+            const uint32_t filled = P.work_n[seg];
+            const uint32_t cnt = filled < P.work_cap ? filled : P.work_cap;
+            if (cnt == 0) continue;
+            const uint32_t *list = P.work + (uint64_t)seg * P.work_cap;
+            for (uint32_t base = 0; base < cnt; base += 64u) {
+                uint32_t words[R][8], res[R];
+                bool live[R];
+                live[0] = base + lane < cnt;
+                const uint64_t row = live[0] ? list[base + lane] : 0;
+#pragma unroll
+                for (int w = 0; w < 8; ++w) words[0][w] = 0x41414141u;
+                if (live[0]) load_words<1, VEC>(P, row, nwords, words[0]);
+                spell_ambiguity_codes_as_n<NWD>(words[0]);
+                compute(0, words, live, res);
+                if (live[0]) FQTK_STREAM_STORE(res[0], &P.out[row]);
+            }
+            if (lane == 0) P.work_n[seg] = 0;   // all zero again for the next launch
+        }
+    }
+    const uint64_t full_tiles = (VEC >= 1 && !INDEXED) ? P.n / tile : 0;
     bool all_live[R];
 #pragma unroll
     for (int r = 0; r < R; ++r) all_live[r] = true;
-    if constexpr (PF && VEC >= 1) {
+    if constexpr (INDEXED) {
+    } else if constexpr (PF && VEC >= 1) {
         // Software pipeline, one tile deep on both streams.  gfx950 counts loads AND stores in vmcnt and
         // they complete out of order with respect to each other, so "wait for my loads" also waits for every
         // store issued since: the plain loop (load, look up, store) pays a store acknowledgement plus a load
@@ -350,14 +381,14 @@ void lds_memo_kernel(const LdsMemoParams Q) {
         }
     }
     // whatever is left (the ragged last tile; every tile on the generic load paths)
-    for (uint64_t t = full_tiles + (blockIdx.x + gridDim.x - full_tiles % gridDim.x) % gridDim.x; t < ntiles; t += gridDim.x) {
+    for (uint64_t t = full_tiles + (blockIdx.x + gridDim.x - full_tiles % gridDim.x) % gridDim.x; t < (INDEXED ? 0 : ntiles); t += gridDim.x) {
         uint32_t words[R][8], res[R];
         bool live[R];
         load_any(t, words, live);
         compute(t, words, live, res);
         store_any(t, res, live);
     }
-    publish_worklist_fill(P, work_seg, work_fill);
+    if constexpr (!INDEXED) publish_worklist_fill(P, work_seg, work_fill);
 
     if (P.counts && P.lds_hist) {
         __syncthreads();

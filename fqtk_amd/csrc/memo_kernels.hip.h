@@ -179,6 +179,40 @@ __device__ __forceinline__ uint32_t noncanonical_beyond_dots(const uint32_t (&wo
     return bad;
 }
 
+// Plain-A/C/G/T sample tables only (no sample base covers two bases): an observed base mismatches an expected
+// one iff observed_mask & ~expected_mask != 0 (bitenc.rs:432-459), so against single-base samples EVERY observed
+// code of two or more bases -- M R W S Y K V H D B as much as N -- mismatches every sample, and 'U' is 'T'
+// (mod.rs:26-46).  The no-call prefilter (barcode_matching.rs:171) cannot tell them apart either: with no N in
+// any sample it passes reads of <= max_mismatches no-calls, and a read of k such bases is k mismatches from
+// every sample anyway (None, like the prefilter's answer).  So such a read has the memo entry of the read with
+// those bases spelled 'N' (and 'U' spelled 'T'): this rewrites the words that way, '.' included.  Bytes of no
+// IUPAC meaning (mask 0: they MATCH everything) are left as they are and stay non-canonical.
+template <int NWD>
+__device__ __forceinline__ void spell_ambiguity_codes_as_n(uint32_t (&words)[8]) {
+    // replacement letter by (byte & 0x1F), 0 = not an IUPAC code; four 8-entry pools for v_perm_b32
+    constexpr uint32_t p0lo = 0x434E4100u, p0hi = 0x4700004Eu;   // @ A B C | D E F G
+    constexpr uint32_t p1lo = 0x4E00004Eu, p1hi = 0x004E4E00u;   // H I J K | L M N O
+    constexpr uint32_t p2lo = 0x4E4E0000u, p2hi = 0x4E4E5454u;   // P Q R S | T U V W
+    constexpr uint32_t p3lo = 0x00004E00u, p3hi = 0x00000000u;   // X Y Z [ | \ ] ^ _
+#pragma unroll
+    for (int w = 0; w < NWD; ++w) {
+        const uint32_t x = words[w];
+        const uint32_t t = x ^ 0x2E2E2E2Eu;
+        const uint32_t dot = (~(((t & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | t | 0x7F7F7F7Fu)) >> 7;   // 1 in every byte that is '.'
+        const uint32_t sel = x & 0x07070707u;
+        const uint32_t t0 = __builtin_amdgcn_perm(p0hi, p0lo, sel), t1 = __builtin_amdgcn_perm(p1hi, p1lo, sel);
+        const uint32_t t2 = __builtin_amdgcn_perm(p2hi, p2lo, sel), t3 = __builtin_amdgcn_perm(p3hi, p3lo, sel);
+        const uint32_t m3 = ((x >> 3) & 0x01010101u) * 0xFFu, m4 = ((x >> 4) & 0x01010101u) * 0xFFu;
+        const uint32_t t01 = (t0 & ~m3) | (t1 & m3), t23 = (t2 & ~m3) | (t3 & m3);
+        uint32_t rep = (t01 & ~m4) | (t23 & m4);
+        const uint32_t z = (x & 0xC0C0C0C0u) ^ 0x40404040u;                      // zero in every byte 0x40..0x7F
+        const uint32_t letter = ~(((z >> 6) | (z >> 7)) & 0x01010101u) & 0x01010101u;
+        rep = (rep & (letter * 0xFFu)) | (dot * 0x4Eu);                          // '.' -> 'N'
+        const uint32_t have = ((rep >> 6) & 0x01010101u) * 0xFFu;                // every replacement letter has bit 6
+        words[w] = (rep & have) | (x & ~have);
+    }
+}
+
 // Hands the lanes in `flagged` (a wave-wide mask; `mine` = this lane is one of them) over to the second pass:
 // each writes its read index into the wave's own segment of the worklist (`fill` = entries used so far,
 // wave-uniform) and gets the placeholder result.  Returns the lanes that did NOT fit (segment full / no list):

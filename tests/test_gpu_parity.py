@@ -220,6 +220,9 @@ def test_second_pass_worklist_and_its_overflow(cap, monkeypatch):
         rows = rng.choice(n, n // 5, replace=False)                       # 20 % of the reads: more than the default list holds
         obs[rows, rng.integers(0, L, rows.size)] = rng.choice(np.frombuffer(b"RYKM#x", dtype=np.uint8), rows.size)
         obs[rng.integers(0, n, 500), rng.integers(0, L, 500)] = ord(".")  # '.' reads stay with the memo
+        for j in range(L):                                                # every byte value at every position,
+            obs[256 * j:256 * (j + 1), j] = np.arange(256, dtype=np.uint8)   # alone and next to another odd byte
+            obs[256 * j + 128:256 * (j + 1), (j + 5) % L] = rng.choice(np.frombuffer(b"Nn.RUu#", dtype=np.uint8), 128)
         _compare(w.barcodes, cfg.max_mismatches, cfg.min_mismatch_delta, obs)
         lens = np.where(rng.random(n) < 0.9, L, rng.integers(0, L + 1, size=n)).astype(np.uint32)
         _compare(w.barcodes, cfg.max_mismatches, cfg.min_mismatch_delta, obs, lens)
