@@ -452,8 +452,8 @@ int launch_lds_memo(const fqtk_matcher *m, fqtk::LdsMemoParams Q, hipStream_t st
     }
 #endif
     if (second_pass) {   // rows gathered through the worklist: the generic load paths
-        if (vec != 0) FQTK_LDSM_LAUNCH_I(-1, 1, false, false, true);
-        else FQTK_LDSM_LAUNCH_I(0, 1, false, false, true);
+        if (vec != 0) FQTK_LDSM_LAUNCH_I(-1, 4, false, false, true);
+        else FQTK_LDSM_LAUNCH_I(0, 4, false, false, true);
     } else if (P.lens) {   // variable-length batch: the LENS instantiations, one read per lane
         switch (vec) {
             case 5: FQTK_LDSM_LAUNCH_L(5, 1, true); break;
@@ -545,10 +545,11 @@ int launch_memo(const fqtk_matcher *m, const fqtk::MatchParams &P, hipStream_t s
 int launch(const fqtk_matcher *m, const fqtk::MatchParams &P0, hipStream_t stream, Worklist &wl) {
     const bool memo = m->use_cache && P0.stride >= P0.L && ((m->d_ldsm && m->memo_kind_wanted != 1) || m->d_memo);
     if (!memo || P0.n > 0xFFFFFFFFull) return launch_memo(m, P0, stream);
-    // One segment per wave the chip can hold (the memo grids never exceed that); room for one read in eight
-    // overall (what does not fit is scanned in place by its wave); grown on demand.
+    // One segment per wave the chip can hold (the memo grids never exceed that; the LDS form may run half as many
+    // waves); room for one read in four overall, i.e. at least one in eight of any wave's reads -- what does not
+    // fit is scanned in place by its wave.  Grown on demand.
     const uint32_t segs = (uint32_t)m->num_cus * 32u;
-    uint64_t want = std::max<uint64_t>(64, (P0.n / 8 + segs - 1) / segs);
+    uint64_t want = std::max<uint64_t>(64, (P0.n / 4 + segs - 1) / segs);
     if (const char *cap = std::getenv("FQTK_WORKLIST_CAP")) want = (uint64_t)std::max(0l, std::atol(cap));   // test knob: entries per segment
     if (want > wl.cap || !wl.d_fill) {
         if (wl.d_list) { HIP_TRY(hipStreamSynchronize(stream)); HIP_TRY(hipFree(wl.d_list)); wl.d_list = nullptr; }

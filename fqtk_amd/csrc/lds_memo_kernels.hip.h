@@ -81,7 +81,7 @@ __device__ __forceinline__ uint32_t lane_select(uint64_t mask, uint32_t a, uint3
 template <int VEC, int KW, int R, bool POW2, bool LENS = false, bool PF = false, bool INDEXED = false>   // LENS: see memo_kernel
 __global__ __launch_bounds__(kLdsBlock) __attribute__((amdgpu_waves_per_eu(4, 8)))
 void lds_memo_kernel(const LdsMemoParams Q) {
-    static_assert(!INDEXED || (R == 1 && VEC <= 0 && !LENS && !PF), "the second pass gathers single rows");
+    static_assert(!INDEXED || (VEC <= 0 && !LENS && !PF), "the second pass gathers single rows");
     const MatchParams &P = Q.m;
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
     // LDS: [entry table | sample keys | spread LUT (fallback scan) | histogram]; the entry table sits
@@ -298,17 +298,30 @@ void lds_memo_kernel(const LdsMemoParams Q) {
             const uint32_t cnt = filled < P.work_cap ? filled : P.work_cap;
             if (cnt == 0) continue;
             const uint32_t *list = P.work + (uint64_t)seg * P.work_cap;
-            for (uint32_t base = 0; base < cnt; base += 64u) {
+            // R reads per lane: a wave's iteration is a chain of three dependent memory round trips (list entry,
+            // row, result store) and the R of them overlap
+            for (uint32_t base = 0; base < cnt; base += 64u * R) {
                 uint32_t words[R][8], res[R];
                 bool live[R];
-                live[0] = base + lane < cnt;
-                const uint64_t row = live[0] ? list[base + lane] : 0;
+                uint64_t row[R];
 #pragma unroll
-                for (int w = 0; w < 8; ++w) words[0][w] = 0x41414141u;
-                if (live[0]) load_words<1, VEC>(P, row, nwords, words[0]);
-                spell_ambiguity_codes_as_n<NWD>(words[0]);
+                for (int r = 0; r < R; ++r) {
+                    const uint32_t j = base + (uint32_t)r * 64u + lane;
+                    live[r] = j < cnt;
+                    row[r] = live[r] ? list[j] : 0;
+                }
+#pragma unroll
+                for (int r = 0; r < R; ++r) {
+#pragma unroll
+                    for (int w = 0; w < 8; ++w) words[r][w] = 0x41414141u;
+                    if (live[r]) load_words<1, VEC>(P, row[r], nwords, words[r]);
+                }
+#pragma unroll
+                for (int r = 0; r < R; ++r) spell_ambiguity_codes_as_n<NWD>(words[r]);
                 compute(0, words, live, res);
-                if (live[0]) FQTK_STREAM_STORE(res[0], &P.out[row]);
+#pragma unroll
+                for (int r = 0; r < R; ++r)
+                    if (live[r]) FQTK_STREAM_STORE(res[r], &P.out[row[r]]);
             }
             if (lane == 0) P.work_n[seg] = 0;   // all zero again for the next launch
         }
