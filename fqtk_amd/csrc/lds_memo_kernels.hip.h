@@ -38,6 +38,11 @@ namespace fqtk {
 #define FQTK_LDS_BLOCK 1024
 #endif
 constexpr int kLdsBlock = FQTK_LDS_BLOCK;
+// Developer ablations of the look-up (tools/ab_ldsm_ablate.sh), compile-time: 1 = no table look-up at all (the
+// result is a fold of the key), 2 = no histogram, 4 = the first candidate is taken unverified.  0 in the product.
+#ifndef FQTK_LDSM_ABL
+#define FQTK_LDSM_ABL 0
+#endif
 struct LdsMemoParams {
     MatchParams m;
     const uint32_t *image;    // [n_slots] entries, then (S + 1) sample keys of key_stride words each
@@ -88,6 +93,12 @@ void lds_memo_kernel(const LdsMemoParams Q) {
     // at byte 0 so a masked hash is used as the ds_read address as is
     constexpr int KS = KW == 3 ? 4 : KW;                      // key stride in dwords (b128 reads for KW 3)
     const uint32_t tid = threadIdx.x;
+    if constexpr (INDEXED) {   // nothing listed for this workgroup's waves (the usual case): leave before staging anything
+        uint32_t any = 0;
+        for (uint32_t seg = blockIdx.x * (kLdsBlock / 64u) + (tid >> 6); seg < P.work_segs; seg += gridDim.x * (kLdsBlock / 64u))
+            any |= P.work_n[seg];
+        if (!__syncthreads_or((int)any)) return;
+    }
     for (uint32_t w = tid; w < Q.image_words; w += kLdsBlock) smem[w] = Q.image[w];
     uint32_t *lds_lut = smem + Q.image_words;
     uint32_t *lds_hist = lds_lut + 256;
@@ -200,6 +211,7 @@ void lds_memo_kernel(const LdsMemoParams Q) {
 #pragma unroll
         for (int r = 0; r < R; ++r) {
             encode_nibbles<NWD, (VEC >= 1), false>(words[r], kc, kv, lo[r], hi[r], ext[r], bflag[r]);
+            if constexpr ((FQTK_LDSM_ABL & 1) != 0) { res[r] = (lo[r] ^ (KW >= 2 ? hi[r] : 0u)) | 0xFFFFu; continue; }
             uint32_t h1, h2, h3, fps;
             memo_hash3(lo[r], KW >= 2 ? hi[r] : 0u, KW >= 3 ? ext[r] : 0u, Q.salt, h1, h2, h3, fps);
             (void)h3;
@@ -212,7 +224,8 @@ void lds_memo_kernel(const LdsMemoParams Q) {
             const uint64_t M2 = __builtin_amdgcn_uicmp((e2 ^ fps) & fp_mask, 0u, 32);
             const uint64_t M3 = __builtin_amdgcn_uicmp((e3 ^ fps) & fp_mask, 0u, 32);
             // the first fingerprint match in probe order (e3 if none: it then cannot verify either) ...
-            uint32_t v = verify(r, lane_select(M1, e1, lane_select(M2, e2, e3)));
+            uint32_t v = (FQTK_LDSM_ABL & 4) ? (lane_select(M1, e1, lane_select(M2, e2, e3)) & res_mask)
+                                             : verify(r, lane_select(M1, e1, lane_select(M2, e2, e3)));
             // ... and, rarely (two entries among the three slots share the fingerprint: ~0.1 % of lanes),
             // the later matches
             const uint64_t multi = (M1 & (M2 | M3)) | (M2 & M3);
@@ -268,7 +281,7 @@ void lds_memo_kernel(const LdsMemoParams Q) {
             }
         }
         // ---- per-sample counts ---------------------------------------------------------------------
-        if (P.counts) {
+        if (P.counts && !(FQTK_LDSM_ABL & 2)) {
 #pragma unroll
             for (int r = 0; r < R; ++r) {
                 if (!live[r] || res[r] == kMemoDeferred) continue;
