@@ -97,7 +97,14 @@ void lds_memo_kernel(const LdsMemoParams Q) {
         uint32_t any = 0;
         for (uint32_t seg = blockIdx.x * (kLdsBlock / 64u) + (tid >> 6); seg < P.work_segs; seg += gridDim.x * (kLdsBlock / 64u))
             any |= P.work_n[seg];
-        if (!__syncthreads_or((int)any)) return;
+        // (no __syncthreads_or: it brings static LDS with it, and the table may need all of the dynamic 160 KiB)
+        if (tid == 0) smem[0] = 0;
+        __syncthreads();
+        if (any) smem[0] = 1;
+        __syncthreads();
+        const bool listed = smem[0] != 0;
+        __syncthreads();
+        if (!listed) return;
     }
     for (uint32_t w = tid; w < Q.image_words; w += kLdsBlock) smem[w] = Q.image[w];
     uint32_t *lds_lut = smem + Q.image_words;
