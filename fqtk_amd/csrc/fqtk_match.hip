@@ -273,7 +273,11 @@ int launch_memo_vec(const fqtk_matcher *m, fqtk::MemoParams Q, hipStream_t strea
     const uint64_t tile = (uint64_t)fqtk::kMemoBlock * R;
     const uint64_t ntiles = (P.n + tile - 1) / tile;
     if (ntiles == 0) return FQTK_OK;
-    const uint32_t grid = (uint32_t)std::min<uint64_t>(ntiles, (uint64_t)m->num_cus * (2048 / fqtk::kMemoBlock));
+    uint32_t per_cu = 2048 / fqtk::kMemoBlock;
+#ifdef FQTK_DEV_ABLATE
+    if (const char *pc = std::getenv("FQTK_MEMO_PER_CU")) per_cu = (uint32_t)std::atoi(pc);   // occupancy experiments
+#endif
+    const uint32_t grid = (uint32_t)std::min<uint64_t>(ntiles, (uint64_t)m->num_cus * per_cu);
     // One launch; the `if constexpr` drops the (load width, key width, form) combinations that cannot occur:
     // the packed vector paths imply the key width (stride 16 B -> 2 key words, 12 B -> 1 or 2, 8/4 B -> 1, 20 B -> 3)
     // and the direct form exists for one-word keys only.
