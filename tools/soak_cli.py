@@ -68,8 +68,10 @@ def one(rng, it, tmp):
     if L == 0 or L > 40:
         return "skipped-degenerate"
     barcodes = set()
+    sample_alphabet = list("ACGT") if rng.random() < 0.7 else list("ACGTACGTACGTNRYKMSWBDHV")   # 30 %: IUPAC-degenerate tables
+    read_noise = "ACGTN" if rng.random() < 0.5 else "ACGTNACGTNn.RYKMuX#"                        # 50 %: odd bytes in the reads
     while len(barcodes) < S:
-        barcodes.add("".join(nprng.choice(list("ACGT"), size=L)))
+        barcodes.add("".join(nprng.choice(sample_alphabet, size=L)))
         if len(barcodes) < S and 4 ** L <= len(barcodes):
             break
     barcodes = sorted(barcodes)
@@ -79,7 +81,7 @@ def one(rng, it, tmp):
     short_any = False
     for t in range(n):
         src = barcodes[nprng.integers(0, S)] if nprng.random() < 0.85 else "".join(nprng.choice(list("ACGTN"), size=L))
-        src = "".join(c if nprng.random() > 0.03 else "ACGTN"[nprng.integers(0, 5)] for c in src)
+        src = "".join(c if nprng.random() > 0.03 else read_noise[nprng.integers(0, len(read_noise))] for c in src)
         pos = 0
         for i, p in enumerate(parsed):
             s = ""
