@@ -35,6 +35,8 @@
 #include <thread>
 #include <vector>
 
+#include "fast_inflate.hpp"
+
 namespace fqtk_host {
 
 struct FastqRec {
@@ -121,6 +123,7 @@ class FastqSource {
         if (producer_.joinable()) producer_.join();
         for (auto &t : helpers_) if (t.joinable()) t.join();
         if (gz_) gzclose(gz_);
+        if (gz_map_) munmap(const_cast<uint8_t *>(gz_map_), gz_map_size_);   // compressed bytes: nothing points into them
         if (fd_ >= 0) ::close(fd_);
         // a mapping stays for the life of the process: record batches point into it
     }
@@ -138,7 +141,21 @@ class FastqSource {
                 hdr[14] == 2 && hdr[15] == 0)
                 kind_ = Kind::Bgzf;
         }
-        if (kind_ == Kind::Gzip) {
+        if (kind_ == Kind::Gzip && !std::getenv("FQTK_ZLIB_INFLATE")) {
+            // a regular file: map it and decode with the streaming decoder of fast_inflate.hpp (2x zlib's inflate)
+            struct stat st;
+            if (fstat(fd_, &st) == 0 && S_ISREG(st.st_mode) && st.st_size > 0) {
+                void *m = mmap(nullptr, (size_t)st.st_size, PROT_READ, MAP_PRIVATE, fd_, 0);
+                if (m != MAP_FAILED) {
+                    gz_map_ = static_cast<const uint8_t *>(m);
+                    gz_map_size_ = (size_t)st.st_size;
+                    madvise(m, gz_map_size_, MADV_SEQUENTIAL);
+                    fast_.reset(new FastInflate());
+                    fast_->open(gz_map_, gz_map_size_, &FastqSource::crc32_fn);
+                }
+            }
+        }
+        if (kind_ == Kind::Gzip && !fast_) {   // pipes and the like: zlib's gzread
             gz_ = gzdopen(fd_, "rb");
             if (!gz_) { *err = "Error opening input files for reading: " + path; return false; }
             fd_ = -1;               // owned by gz_ now
@@ -370,6 +387,18 @@ class FastqSource {
         return true;
     }
     bool produce_gzip(Piece &pc) {
+        if (fast_) {
+            const uint8_t *p = nullptr;
+            size_t n = 0;
+            std::string e;
+            if (!fast_->next(&p, &n, &e)) {
+                pc.error = "Unexpected error parsing FASTQs: " + e + " in " + path_;
+                return false;
+            }
+            if (n == 0) { pc.eof = true; return false; }
+            pc.data.assign(reinterpret_cast<const char *>(p), reinterpret_cast<const char *>(p) + n);
+            return true;
+        }
         pc.data.resize(kPiece);
         const int n = gzread(gz_, pc.data.data(), (unsigned)kPiece);
         if (n < 0) {
@@ -477,6 +506,29 @@ class FastqSource {
     const char *map_ = nullptr;
     size_t map_size_ = 0, map_pos_ = 0;
     gzFile gz_ = nullptr;
+    const uint8_t *gz_map_ = nullptr;       // single-stream gzip, regular file: decoded by fast_
+    size_t gz_map_size_ = 0;
+    std::unique_ptr<FastInflate> fast_;
+    // CRC-32 for the gzip trailers: libdeflate's (PCLMUL) when the library is there, zlib's otherwise
+    static uint32_t crc32_fn(uint32_t seed, const void *p, size_t n) {
+        using Fn = uint32_t (*)(uint32_t, const void *, size_t);
+        static const Fn fast = [] {
+            if (std::getenv("FQTK_NO_LIBDEFLATE")) return (Fn) nullptr;
+            void *h = dlopen("libdeflate.so.0", RTLD_NOW | RTLD_LOCAL);
+            if (!h) h = dlopen("libdeflate.so", RTLD_NOW | RTLD_LOCAL);
+            return h ? reinterpret_cast<Fn>(dlsym(h, "libdeflate_crc32")) : (Fn) nullptr;
+        }();
+        if (fast) return fast(seed, p, n);
+        uLong c = seed;
+        const Bytef *b = static_cast<const Bytef *>(p);
+        while (n) {   // zlib takes 32-bit lengths
+            const uInt k = n > (1u << 30) ? (1u << 30) : (uInt)n;
+            c = ::crc32(c, b, k);
+            b += k;
+            n -= k;
+        }
+        return (uint32_t)c;
+    }
     int fd_ = -1;
     std::string path_;
     std::vector<char> carry_;

@@ -119,6 +119,26 @@ int64_t fqtk_host_fastq_digest(const char *path, uint64_t batch, uint32_t inflat
     return n;
 }
 
+// Decodes a gzip file held in memory with the streaming decoder of fast_inflate.hpp (tests: against zlib).
+// Returns the decoded length (also when it exceeds cap: then only cap bytes were stored), -1 on a corrupt stream.
+int64_t fqtk_host_gunzip(const uint8_t *in, size_t n, uint8_t *out, size_t cap, char *err, size_t errcap) {
+    std::unique_ptr<FastInflate> z(new FastInflate());
+    z->open(in, n, [](uint32_t seed, const void *p, size_t k) -> uint32_t {
+        return (uint32_t)::crc32(seed, static_cast<const Bytef *>(p), (uInt)k);
+    });
+    int64_t total = 0;
+    std::string e;
+    for (;;) {
+        const uint8_t *p = nullptr;
+        size_t k = 0;
+        if (!z->next(&p, &k, &e)) { put(e, err, errcap); return -1; }
+        if (k == 0) break;
+        if ((size_t)total < cap) std::memcpy(out + total, p, std::min(k, cap - (size_t)total));
+        total += (int64_t)k;
+    }
+    return total;
+}
+
 // BGZF-compresses a whole buffer (blocks of kBgzfBlockSize + EOF marker).
 int fqtk_host_bgzf(const uint8_t *in, size_t n, int level, uint8_t *out, size_t cap, size_t *out_len) {
     std::vector<uint8_t> o;

@@ -78,6 +78,21 @@ def fastq_digest(path, batch=50_000, helpers=2):
     return int(n), int(dig.value), int(kind.value)
 
 
+def gunzip(data: bytes, cap=None) -> bytes:
+    """A gzip file in memory through the streaming decoder of fast_inflate.hpp; ValueError on a corrupt stream."""
+    import numpy as np
+    cap = (len(data) * 40 + (1 << 20)) if cap is None else cap
+    out = np.empty(cap, dtype=np.uint8)
+    err = C.create_string_buffer(256)
+    fn = lib().fqtk_host_gunzip
+    fn.restype = C.c_int64
+    n = fn(data, C.c_size_t(len(data)), out.ctypes.data_as(C.c_void_p), C.c_size_t(cap), err, C.c_size_t(256))
+    if n < 0:
+        raise ValueError(err.value.decode())
+    assert n <= cap, "test buffer too small"
+    return out[:n].tobytes()
+
+
 def bgzf(data: bytes, level=5) -> bytes:
     cap = len(data) + len(data) // 8 + 65536
     out = (C.c_uint8 * cap)()

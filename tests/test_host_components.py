@@ -262,3 +262,102 @@ def test_large_inputs_plain_gzip_multimember_and_bgzf_block_parallel_agree(tmp_p
     (tmp_path / "cut.gz").write_bytes(blob[:len(blob) // 2])
     with pytest.raises(ValueError):
         H.fastq_digest(tmp_path / "cut.gz")
+
+
+# ---- the streaming inflate of single-stream gzip inputs (fast_inflate.hpp) against zlib --------------
+def _gz(data, level=6, strategy=zlib.Z_DEFAULT_STRATEGY, wbits=31, memlevel=8):
+    c = zlib.compressobj(level, zlib.DEFLATED, wbits, memlevel, strategy)
+    return c.compress(data) + c.flush()
+
+
+def _fastq_like(n, seed):
+    import numpy as np
+    rng = np.random.default_rng(seed)
+    recs = []
+    for i in range(n):
+        L = int(rng.integers(30, 160))
+        seq = "".join(rng.choice(list("ACGTN"), size=L, p=[0.24, 0.24, 0.24, 0.24, 0.04]))
+        qual = "".join(rng.choice(list("FFFFFF:,#"), size=L))
+        recs.append(f"@inst:7:FC:1:{1000 + i % 97}:{rng.integers(1, 30000)}:{rng.integers(1, 30000)} 1:N:0:ACGT\n{seq}\n+\n{qual}\n")
+    return "".join(recs).encode()
+
+
+@pytest.mark.parametrize("level", [0, 1, 2, 4, 6, 9])
+@pytest.mark.parametrize("strategy", [zlib.Z_DEFAULT_STRATEGY, zlib.Z_FILTERED, zlib.Z_HUFFMAN_ONLY, zlib.Z_RLE, zlib.Z_FIXED])
+def test_gunzip_every_level_and_strategy(level, strategy):
+    """Stored, fixed and dynamic blocks, long and short codes, long runs (distance 1), far matches."""
+    import numpy as np
+    rng = np.random.default_rng(level * 10 + strategy)
+    parts = [_fastq_like(3000, 5), bytes(rng.integers(0, 256, 70000, dtype=np.uint8)), b"A" * 100000,
+             bytes(rng.integers(0, 4, 50000, dtype=np.uint8)), b"abcdefg" * 9000, _fastq_like(500, 6) * 3]
+    data = b"".join(parts)
+    assert H.gunzip(_gz(data, level, strategy)) == data
+
+
+def test_gunzip_spans_many_pieces_and_windows():
+    """12 MB of output: three 4 MiB pieces, matches that reach back across piece boundaries."""
+    data = _fastq_like(40000, 1)
+    data = data * (12_000_000 // len(data) + 1)
+    for level in (1, 6):
+        assert H.gunzip(_gz(data, level)) == data
+
+
+def test_gunzip_headers_members_and_tiny_streams():
+    data = _fastq_like(200, 2)
+    one = gzip.compress(data, mtime=0)
+    assert H.gunzip(one) == data
+    assert H.gunzip(one + gzip.compress(b"") + one) == data + data            # concatenated members, an empty one
+    assert H.gunzip(gzip.compress(b"")) == b""
+    assert H.gunzip(gzip.compress(b"x")) == b"x"
+    # FEXTRA + FNAME + FCOMMENT + FHCRC set by hand
+    raw = zlib.compressobj(6, zlib.DEFLATED, -15)
+    body = raw.compress(data) + raw.flush()
+    hdr = bytes([0x1f, 0x8b, 8, 4 | 8 | 16 | 2, 0, 0, 0, 0, 0, 3]) + struct.pack("<H", 5) + b"extra" + b"name\0" + b"comment\0"
+    hdr += struct.pack("<H", zlib.crc32(hdr) & 0xFFFF)
+    trailer = struct.pack("<II", zlib.crc32(data), len(data) & 0xFFFFFFFF)
+    assert H.gunzip(hdr + body + trailer) == data
+    assert H.gunzip(one + b"\0" * 100) == data                                # trailing padding is ignored, as gzread does
+    for memlevel in (1, 9):                                                    # small / large symbol buffers: block sizes
+        assert H.gunzip(_gz(data * 20, 6, memlevel=memlevel)) == data * 20
+    for wbits in (25, 28):                                                     # 512-byte and 4-KiB windows
+        assert H.gunzip(_gz(data, 9, wbits=wbits)) == data
+
+
+def test_gunzip_rejects_corrupt_and_truncated_streams_without_crashing():
+    import numpy as np
+    data = _fastq_like(3000, 3)
+    good = _gz(data, 6)
+    with pytest.raises(ValueError):
+        H.gunzip(good[:-1])                                                    # trailer cut
+    with pytest.raises(ValueError):
+        H.gunzip(good[:len(good) // 2])                                        # stream cut
+    bad = bytearray(good)
+    bad[-5] ^= 1                                                               # CRC
+    with pytest.raises(ValueError):
+        H.gunzip(bytes(bad))
+    rng = np.random.default_rng(4)
+    survived = 0
+    for _ in range(300):                                                       # random damage: an error or (rarely) the
+        b = bytearray(good)                                                    # CRC catches it; never a crash
+        for _ in range(int(rng.integers(1, 4))):
+            b[int(rng.integers(10, len(b)))] = int(rng.integers(0, 256))
+        cut = int(rng.integers(20, len(b) + 1)) if rng.random() < 0.3 else len(b)
+        try:
+            out = H.gunzip(bytes(b[:cut]), cap=len(data) * 4 + (1 << 20))
+            survived += out == data
+        except (ValueError, AssertionError):
+            pass
+    assert survived <= 300
+
+
+def test_single_stream_gzip_input_through_the_reader_uses_the_fast_decoder(tmp_path, monkeypatch):
+    data = _fastq_like(30000, 8)
+    p = tmp_path / "x.fq.gz"
+    p.write_bytes(_gz(data, 6))
+    plain = tmp_path / "x.fq"
+    plain.write_bytes(data)
+    want = H.fastq_digest(plain)
+    got = H.fastq_digest(p)
+    assert got[2] == 1 and got[:2] == want[:2]
+    monkeypatch.setenv("FQTK_ZLIB_INFLATE", "1")                               # zlib's gzread path stays available
+    assert H.fastq_digest(p)[:2] == want[:2]
