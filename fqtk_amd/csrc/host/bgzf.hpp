@@ -15,6 +15,8 @@
 #include <string>
 #include <vector>
 
+#include "env.hpp"
+
 namespace fqtk_host {
 
 constexpr size_t kBgzfBlockSize = 65280;   // uncompressed payload per block (as the bgzf crate)
@@ -95,7 +97,7 @@ class BlockCompressor {
         uint32_t (*crc32)(uint32_t, const void *, size_t) = nullptr;
         static LibDeflate load() {
             LibDeflate l;
-            if (std::getenv("FQTK_NO_LIBDEFLATE")) return l;
+            if (env_on("FQTK_NO_LIBDEFLATE")) return l;
             void *h = dlopen("libdeflate.so.0", RTLD_NOW | RTLD_LOCAL);
             if (!h) h = dlopen("libdeflate.so", RTLD_NOW | RTLD_LOCAL);
             if (!h) return l;
@@ -120,7 +122,7 @@ class BlockCompressor {
 class BgzfCrc {
   public:
     BgzfCrc() {
-        if (std::getenv("FQTK_NO_LIBDEFLATE")) return;
+        if (env_on("FQTK_NO_LIBDEFLATE")) return;
         void *h = dlopen("libdeflate.so.0", RTLD_NOW | RTLD_LOCAL);
         if (!h) h = dlopen("libdeflate.so", RTLD_NOW | RTLD_LOCAL);
         if (h) fn_ = reinterpret_cast<uint32_t (*)(uint32_t, const void *, size_t)>(dlsym(h, "libdeflate_crc32"));

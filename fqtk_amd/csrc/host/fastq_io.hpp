@@ -35,6 +35,8 @@
 #include <thread>
 #include <vector>
 
+#include "env.hpp"
+
 #include "fast_inflate.hpp"
 
 namespace fqtk_host {
@@ -68,7 +70,7 @@ struct LibInflate {
     static const LibInflate &get() {
         static const LibInflate l = [] {
             LibInflate x;
-            if (std::getenv("FQTK_NO_LIBDEFLATE")) return x;
+            if (env_on("FQTK_NO_LIBDEFLATE")) return x;
             void *h = dlopen("libdeflate.so.0", RTLD_NOW | RTLD_LOCAL);
             if (!h) h = dlopen("libdeflate.so", RTLD_NOW | RTLD_LOCAL);
             if (!h) return x;
@@ -141,7 +143,7 @@ class FastqSource {
                 hdr[14] == 2 && hdr[15] == 0)
                 kind_ = Kind::Bgzf;
         }
-        if (kind_ == Kind::Gzip && !std::getenv("FQTK_ZLIB_INFLATE")) {
+        if (kind_ == Kind::Gzip && !env_on("FQTK_ZLIB_INFLATE")) {
             // a regular file: map it and decode with the streaming decoder of fast_inflate.hpp (2x zlib's inflate)
             struct stat st;
             if (fstat(fd_, &st) == 0 && S_ISREG(st.st_mode) && st.st_size > 0) {
@@ -162,7 +164,7 @@ class FastqSource {
             gzbuffer(gz_, 1 << 20);
         }
         n_helpers_ = kind_ == Kind::Bgzf ? inflate_helpers : 0;
-        if (kind_ == Kind::Plain && !std::getenv("FQTK_NO_MMAP")) {
+        if (kind_ == Kind::Plain && !env_on("FQTK_NO_MMAP")) {
             struct stat st;
             if (fstat(fd_, &st) == 0 && S_ISREG(st.st_mode) && st.st_size > 0) {
                 void *m = mmap(nullptr, (size_t)st.st_size, PROT_READ, MAP_PRIVATE, fd_, 0);
@@ -513,7 +515,7 @@ class FastqSource {
     static uint32_t crc32_fn(uint32_t seed, const void *p, size_t n) {
         using Fn = uint32_t (*)(uint32_t, const void *, size_t);
         static const Fn fast = [] {
-            if (std::getenv("FQTK_NO_LIBDEFLATE")) return (Fn) nullptr;
+            if (env_on("FQTK_NO_LIBDEFLATE")) return (Fn) nullptr;
             void *h = dlopen("libdeflate.so.0", RTLD_NOW | RTLD_LOCAL);
             if (!h) h = dlopen("libdeflate.so", RTLD_NOW | RTLD_LOCAL);
             return h ? reinterpret_cast<Fn>(dlsym(h, "libdeflate_crc32")) : (Fn) nullptr;
