@@ -554,7 +554,8 @@ int launch(const fqtk_matcher *m, const fqtk::MatchParams &P0, hipStream_t strea
     // fit is scanned in place by its wave.  Grown on demand.
     const uint32_t segs = (uint32_t)m->num_cus * 32u;
     uint64_t want = std::max<uint64_t>(64, (P0.n / 4 + segs - 1) / segs);
-    if (const char *cap = std::getenv("FQTK_WORKLIST_CAP")) want = (uint64_t)std::max(0l, std::atol(cap));   // test knob: entries per segment
+    if (const char *cap = std::getenv("FQTK_WORKLIST_CAP"))   // test knob: entries per segment (0: no list, no second pass)
+        if (*cap) want = (uint64_t)std::max(0l, std::atol(cap));
     if (want > wl.cap || !wl.d_fill) {
         if (wl.d_list) { HIP_TRY(hipStreamSynchronize(stream)); HIP_TRY(hipFree(wl.d_list)); wl.d_list = nullptr; }
         if (!wl.d_fill) {

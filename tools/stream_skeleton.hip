@@ -76,6 +76,52 @@ __global__ __launch_bounds__(1024) void kskel(const uint8_t *in, uint8_t *out, u
     if (tid == 0) { stamps[2 * blockIdx.x] = t0; stamps[2 * blockIdx.x + 1] = wall_clock64(); }
 }
 
+// Wider stores: every lane loads R 16-byte rows (wave-contiguous: a wave's r-th load covers 1 KiB) and stores ONE
+// vector of R dwords -- as if the R results had been transposed across the wave -- so a wave's store covers
+// R x 256 contiguous bytes instead of 256.  No work; does the memory system like the wider write bursts?
+template <int R>
+__global__ __launch_bounds__(1024) void kwide(const uint8_t *in, uint8_t *out, uint64_t n) {
+    const uint32_t tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const uint64_t tile = 1024ull * R, nt = n / tile;
+    const u32x4 *src = reinterpret_cast<const u32x4 *>(in);
+    for (uint64_t t = blockIdx.x; t < nt; t += gridDim.x) {
+        const uint64_t base = t * tile + (uint64_t)wave * 64 * R;
+        uint32_t x[R];
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const u32x4 v = __builtin_nontemporal_load(src + base + r * 64 + lane);
+            x[r] = v.x ^ v.y ^ v.z ^ v.w;
+        }
+        uint32_t *dst = reinterpret_cast<uint32_t *>(out) + base + (uint64_t)lane * R;
+        if constexpr (R == 4) {
+            u32x4 o = {x[0], x[1], x[2], x[3]};
+            __builtin_nontemporal_store(o, reinterpret_cast<u32x4 *>(dst));
+        } else if constexpr (R == 2) {
+            typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+            u32x2 o = {x[0], x[1]};
+            __builtin_nontemporal_store(o, reinterpret_cast<u32x2 *>(dst));
+        } else {
+            __builtin_nontemporal_store(x[0], dst);
+        }
+    }
+}
+template <int R>
+void run_wide(const uint8_t *in, uint8_t *out, uint64_t n, int grid) {
+    hipEvent_t a, b;
+    hipEventCreate(&a);
+    hipEventCreate(&b);
+    for (int w = 0; w < 2; ++w) hipLaunchKernelGGL(kwide<R>, dim3(grid), dim3(1024), 0, 0, in, out, n);
+    hipEventRecord(a);
+    const int reps = 10;
+    for (int w = 0; w < reps; ++w) hipLaunchKernelGGL(kwide<R>, dim3(grid), dim3(1024), 0, 0, in, out, n);
+    hipEventRecord(b);
+    hipEventSynchronize(b);
+    float ms = 0;
+    hipEventElapsedTime(&ms, a, b);
+    ms /= reps;
+    printf("%d rows per lane, one %2d-byte store per lane, %d workgroups: %.3f ms  %.0f GB/s\n", R, 4 * R, grid, ms, n * 20.0 / ms / 1e6);
+}
+
 template <int C, bool PF>
 void run(const uint8_t *in, uint8_t *out, uint64_t n, int grid, uint32_t lds_words, uint64_t *d_stamps) {
     auto kern = kskel<C, PF>;
@@ -120,6 +166,13 @@ int main() {
     run<4, false>(in, out, n, cus, big, d_stamps);
     run<4, true>(in, out, n, cus, big, d_stamps);
     run<8, true>(in, out, n, cus, big, d_stamps);
+    printf("-- wider stores (no LDS, no work)\n");
+    run_wide<1>(in, out, n, cus);
+    run_wide<2>(in, out, n, cus);
+    run_wide<4>(in, out, n, cus);
+    run_wide<1>(in, out, n, 2 * cus);
+    run_wide<2>(in, out, n, 2 * cus);
+    run_wide<4>(in, out, n, 2 * cus);
     printf("-- two workgroups per CU (64 KB each)\n");
     run<0, false>(in, out, n, 2 * cus, 16384, d_stamps);
     run<2, false>(in, out, n, 2 * cus, 16384, d_stamps);
