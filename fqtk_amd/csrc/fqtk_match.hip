@@ -160,6 +160,8 @@ struct fqtk_matcher {
     int memo_kind_wanted = 0;                  // 0 = best available, 1 = force the HBM/L2 table (tests, A/B)
     size_t ldsm_lds_bytes = 0;                 // image + LUT (histogram added at launch)
     std::deque<std::pair<hipStream_t, Worklist>> stream_work;   // worklists of the *_device entry point, by caller stream
+    volatile uint32_t *h_seen = nullptr;     // page-locked: set by a memo kernel that met an IUPAC / junk byte in a read
+    uint32_t *d_seen = nullptr;              // the same word, device address
     int use_cache = 1;                       // BarcodeMatcher.use_cache (barcode_matching.rs:41-42)
     Slot slots[kNumSlots];
 };
@@ -549,6 +551,14 @@ int launch_memo(const fqtk_matcher *m, const fqtk::MatchParams &P, hipStream_t s
 int launch(const fqtk_matcher *m, const fqtk::MatchParams &P0, hipStream_t stream, Worklist &wl) {
     const bool memo = m->use_cache && P0.stride >= P0.L && ((m->d_ldsm && m->memo_kind_wanted != 1) || m->d_memo);
     if (!memo || P0.n > 0xFFFFFFFFull) return launch_memo(m, P0, stream);
+    // The list and the second launch only once a read with an IUPAC / junk byte has been met (MatchParams::seen);
+    // FQTK_SECOND_PASS=always / never pins it (tests, A/B runs).
+    bool listed = m->h_seen && m->h_seen[0] != 0;
+    if (const char *sp = std::getenv("FQTK_SECOND_PASS")) {
+        if (!std::strcmp(sp, "always")) listed = true;
+        else if (!std::strcmp(sp, "never")) listed = false;
+    }
+    if (!listed) return launch_memo(m, P0, stream);
     // One segment per wave the chip can hold (the memo grids never exceed that; the LDS form may run half as many
     // waves); room for one read in four overall, i.e. at least one in eight of any wave's reads -- what does not
     // fit is scanned in place by its wave.  Grown on demand.
@@ -666,6 +676,7 @@ fqtk::MatchParams make_params(const fqtk_matcher *m, const void *d_obs, uint32_t
     P.work_n = nullptr;
     P.work_cap = 0;
     P.work_segs = 0;
+    P.seen = m->d_seen;
     return P;
 }
 
@@ -1149,6 +1160,13 @@ int fqtk_matcher_create(const char *const *barcodes, uint32_t n_samples, uint32_
     HIP_TRY_C(hipMemset(m->d_counts_sync, 0, (size_t)(n_samples + 1) * sizeof(unsigned long long)));
     HIP_TRY_C(hipHostMalloc(reinterpret_cast<void **>(&m->h_err), kErrBytes, hipHostMallocDefault));
     std::memset(m->h_err, 0xFF, kErrBytes);
+    {
+        void *seen = nullptr;
+        HIP_TRY_C(hipHostMalloc(&seen, sizeof(uint32_t), hipHostMallocMapped));
+        m->h_seen = static_cast<volatile uint32_t *>(seen);
+        m->h_seen[0] = 0;
+        HIP_TRY_C(hipHostGetDevicePointer(reinterpret_cast<void **>(&m->d_seen), seen, 0));
+    }
     // The pipeline slots use NON-BLOCKING streams, which do not order against the legacy NULL stream the
     // initialisation above ran on: make it all visible before any slot stream touches these buffers.
     HIP_TRY_C(hipDeviceSynchronize());
@@ -1186,6 +1204,7 @@ void fqtk_matcher_destroy(fqtk_matcher *m) {
     if (m->d_counts) (void)hipFree(m->d_counts);
     if (m->d_counts_sync) (void)hipFree(m->d_counts_sync);
     if (m->h_err) (void)hipHostFree(m->h_err);
+    if (m->h_seen) (void)hipHostFree(const_cast<uint32_t *>(m->h_seen));
     delete m;
 }
 

@@ -56,6 +56,10 @@ struct MatchParams {
     uint32_t *work_n;            // [work_segs] entries filled; all zero between launches
     uint32_t work_cap;           // entries per segment
     uint32_t work_segs;          // 0: no list (every such read is scanned in place)
+    // Launches carry the list (and are followed by the second pass) only once such a read has been seen: a
+    // list-less memo kernel that meets one sets this word in page-locked host memory, and the host attaches
+    // the list from its next launch on -- inputs without such bytes never pay for the second launch.
+    uint32_t *seen;
 };
 
 __device__ __forceinline__ uint32_t med3_u32(uint32_t a, uint32_t b, uint32_t c) {

@@ -219,7 +219,14 @@ __device__ __forceinline__ void spell_ambiguity_codes_as_n(uint32_t (&words)[8])
 // the caller scans those in place.
 __device__ __forceinline__ uint64_t defer_to_second_pass(const MatchParams &P, uint32_t seg, uint32_t &fill, uint64_t flagged,
                                                          bool mine, uint64_t read_index, uint32_t &res) {
-    if (seg >= P.work_segs || !flagged) return flagged;
+    if (!flagged) return flagged;
+    if (seg >= P.work_segs) {   // launched without a list (no such read seen so far): tell the host, once per wave
+        if (!fill) {
+            fill = 1;
+            if (P.seen && __lane_id() == 0) *P.seen = 1u;   // page-locked host memory
+        }
+        return flagged;
+    }
     const uint32_t at = fill + (uint32_t)__popcll((unsigned long long)(flagged & ((1ull << __lane_id()) - 1ull)));
     const bool fits = mine && at < P.work_cap;
     if (fits) {
@@ -231,7 +238,7 @@ __device__ __forceinline__ uint64_t defer_to_second_pass(const MatchParams &P, u
 }
 // The wave's fill count goes out once, at the end of the kernel.
 __device__ __forceinline__ void publish_worklist_fill(const MatchParams &P, uint32_t seg, uint32_t fill) {
-    if (fill && __lane_id() == 0) P.work_n[seg] = fill;
+    if (fill && seg < P.work_segs && __lane_id() == 0) P.work_n[seg] = fill;
 }
 
 // LENS: the batch carries obs_len (variable-length '+B' structures): the memo serves the reads of length

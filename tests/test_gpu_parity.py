@@ -204,12 +204,15 @@ def test_memo_path_handles_non_canonical_reads_in_every_lane_position():
     _compare(w.barcodes, 2, 1, obs)
 
 
-@pytest.mark.parametrize("cap", ["0", "1", "7", None])
+@pytest.mark.parametrize("cap", ["0", "1", "7", None, "never"])
 def test_second_pass_worklist_and_its_overflow(cap, monkeypatch):
-    """The memo kernels list the reads with IUPAC / junk bytes and the scan kernel resolves them in a second
-    pass; what does not fit in the list is scanned in place by its wave.  A tiny (or absent) list forces the
-    overflow path; results and counts must not depend on where a read was resolved."""
-    if cap is not None:
+    """The memo kernels list the reads with IUPAC / junk bytes and a second kernel resolves them (LDS form: the
+    memo again with ambiguity codes spelled as N; table form: the scan); what does not fit in the list is scanned
+    in place by its wave.  A tiny (or absent) list forces the overflow path; results and counts must not depend
+    on where a read was resolved.  (A fresh matcher launches without the list until it has met such a read:
+    FQTK_SECOND_PASS=always pins the list on.)"""
+    monkeypatch.setenv("FQTK_SECOND_PASS", "never" if cap == "never" else "always")
+    if cap not in (None, "never"):
         monkeypatch.setenv("FQTK_WORKLIST_CAP", cap)
     rng = np.random.default_rng(11)
     for k, n in ((3, 20000), (2, 9000), (5, 9000)):
@@ -228,6 +231,27 @@ def test_second_pass_worklist_and_its_overflow(cap, monkeypatch):
         _compare(w.barcodes, cfg.max_mismatches, cfg.min_mismatch_delta, obs, lens)
 
 
+def test_second_pass_switches_itself_on_after_the_first_such_read():
+    """Default policy: no list and no second launch until a kernel has met an IUPAC / junk byte in a read; every
+    batch is right whichever way it ran, on the synchronous path and on the pipeline slots."""
+    rng = np.random.default_rng(12)
+    for k in (3, 5):
+        w = synth.Workload(synth.CONFIGS[k])
+        cfg = w.cfg
+        L = len(w.barcodes[0])
+        lit = O.RefLiteral(w.barcodes, cfg.max_mismatches, cfg.min_mismatch_delta, True)
+        gm = BarcodeMatcher(w.barcodes, cfg.max_mismatches, cfg.min_mismatch_delta)
+        for step in range(4):
+            obs = w.fill_host(step * 30000, 30000).copy()
+            if step >= 1:                                  # the first batch is clean, the others carry odd bytes
+                rows = rng.choice(30000, 900, replace=False)
+                obs[rows, rng.integers(0, L, rows.size)] = rng.choice(np.frombuffer(b"RYKMu#", dtype=np.uint8), rows.size)
+            i, b, nx, c = lit.assign_batch(np.ascontiguousarray(obs[:, :L]))
+            got, counts = gm.assign_batch(obs)
+            assert np.array_equal(got["idx"], i) and np.array_equal(got["best"], b) and np.array_equal(got["next"], nx), (k, step)
+            assert np.array_equal(counts, c), (k, step)
+
+
 # ------------------------------------------------------------------------------------------------
 # seeded random parity vs the oracle
 # ------------------------------------------------------------------------------------------------
@@ -236,7 +260,9 @@ SAMPLE_ALPHABET = list("ACGTACGTACGTNMRWSYKVHDBn.")
 
 
 @pytest.mark.parametrize("seed", range(int(__import__("os").environ.get("FQTK_SOAK_SEEDS", "16"))))
-def test_random_tables_and_reads(seed):
+def test_random_tables_and_reads(seed, monkeypatch):
+    if seed % 2 == 0:                                   # odd bytes in the reads: half the seeds through the second pass
+        monkeypatch.setenv("FQTK_SECOND_PASS", "always")
     rng = np.random.default_rng(99 + seed)
     S = int(rng.choice([1, 2, 3, 4, 5, 7, 16, 33, 100]))
     L = int(rng.choice([1, 3, 7, 8, 9, 12, 16, 17, 24, 32, 33, 40, 64, 65, 100, 128]))
@@ -264,10 +290,12 @@ def test_random_tables_and_reads(seed):
 
 
 @pytest.mark.parametrize("seed", range(int(__import__("os").environ.get("FQTK_SOAK_SEEDS", "16"))))
-def test_random_plain_tables_lds_form(seed):
+def test_random_plain_tables_lds_form(seed, monkeypatch):
     """Random plain-A/C/G/T tables with max_mismatches <= 1 -- the shape the LDS-resident memo is built
     for -- over random S, L, delta, strides and read noise (lower case, N, '.', IUPAC and junk bytes in
     the READS, which take the in-kernel fallback)."""
+    if seed % 2 == 0:
+        monkeypatch.setenv("FQTK_SECOND_PASS", "always")
     rng = np.random.default_rng(7000 + seed)
     L = int(rng.integers(1, 21))
     S = int(rng.choice([2, 3, 5, 16, 24, 96, 200, 384, 500]))
