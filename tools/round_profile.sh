@@ -18,10 +18,16 @@ print(json.dumps({'config': d['config']['workload'][:5].strip(), 'obs_len': d['c
 for a in "--config 3" "--config 2" "--config 4" "--config 5" "--config 1" "--config 3 --table" "--config 2 --table"; do python tools/full_parity.py $a 2>/dev/null | tail -1 >> $O/full_parity.jsonl; done
 python tools/bgzf_bench.py > $O/bgzf_kernel.json 2>/dev/null
 for v in "--threads 16" "--threads 16 --extra=--gpu-bgzf" "--threads 8" "--threads 8 --extra=--gpu-bgzf" "--threads 32" "--threads 32 --extra=--gpu-bgzf"; do python tools/scope_bench.py --skip-b --templates 16000000 --repeat-block $v >> $O/scope_E.jsonl 2>> $O/scope_E.err; done
-python tools/scope_bench.py --skip-b --templates 4000000 --repeat-block --threads 16 --gz >> $O/scope_E.jsonl 2>> $O/scope_E.err
+for v in "" "--extra=--gpu-bgzf"; do python tools/scope_bench.py --skip-b --templates 16000000 --repeat-block --threads 16 --gz $v >> $O/scope_E_gz.jsonl 2>> $O/scope_E.err; done
+FQTK_ZLIB_INFLATE=1 python tools/scope_bench.py --skip-b --templates 16000000 --repeat-block --threads 16 --gz >> $O/scope_E_gz_zlib.jsonl 2>> $O/scope_E.err
 python tools/scope_bench.py --skip-b --templates 8000000 --repeat-block --threads 16 --bgzf >> $O/scope_E.jsonl 2>> $O/scope_E.err
 python tools/scope_bench.py --skip-b --templates 8000000 --repeat-block --threads 16 --bgzf --extra=--gpu-bgzf >> $O/scope_E.jsonl 2>> $O/scope_E.err
 FQTK_SOAK_SEEDS=${SOAK:-300} python -m pytest tests/test_gpu_parity.py -m gpu -q -k "random" > $O/soak.log 2>&1; tail -2 $O/soak.log
+python tools/soak_cli.py --iters ${SOAK_CLI:-60} --seed 11 > $O/soak_cli.log 2>&1; tail -1 $O/soak_cli.log
+hipcc --offload-arch=gfx950 -O3 tools/stream_skeleton.hip -o /tmp/stream_skeleton 2>/dev/null && /tmp/stream_skeleton > $O/stream_skeleton.txt 2>&1
+FQTK_SYNTH_PIUPAC=0.00063 python tools/kernel_times.py $O/kt_iupac1 -- --steps 10 --warmup 2 --cpu-seconds 0 --parity windows --no-scopes > $O/kernel_times_iupac1pct.csv 2>&1
+bash tools/ab_ldsm_ablate.sh > $O/ab_ldsm_ablate.txt 2>&1
+bash tools/pmc_insts.sh > $O/pmc_insts_cfg3.txt 2>&1
 bash tools/pmc_cfg5.sh ${TAG}_pmc5 > $O/pmc5.log 2>&1
 bash tools/pmc_memo.sh ${TAG}_pmc > $O/pmc_memo.log 2>&1; tail -30 $O/pmc_memo.log
 ls $O
