@@ -152,7 +152,9 @@ int fqtk_matcher_assign_batch(fqtk_matcher *m, const uint8_t *obs, uint32_t stri
  * used when reads are already resident in HBM.  d_counts: NULL or S+1 uint64 accumulated with
  * atomics.  Length errors are latched in the handle; collect them with fqtk_matcher_poll_error().
  * d_obs_len[i] <= stride is the caller's contract here (device memory is not inspected on the host);
- * the kernels clamp every access to the read's row regardless. */
+ * the kernels clamp every access to the read's row regardless.
+ * Device memory the handle may add behind this call: once a read with an IUPAC / junk byte has been met, a
+ * worklist of up to n bytes per stream in use (n / 4 read indices; grown on demand, freed with the handle). */
 int fqtk_matcher_assign_batch_device(fqtk_matcher *m, const void *d_obs, uint32_t stride,
                                      const void *d_obs_len, uint64_t n, void *d_out, void *d_counts,
                                      void *hip_stream);
