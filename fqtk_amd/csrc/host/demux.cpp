@@ -689,6 +689,7 @@ int main(int argc, char **argv) {
             std::vector<std::vector<Owned>> owned(S + 1);
             bool have_plan = false;
             std::vector<std::string_view> bsegs, msegs;
+            std::vector<uint32_t> mine;
             for (;;) {
                 const uint64_t tw = tick();
                 std::shared_ptr<Chunk> ch = wq[w]->pop();
@@ -706,10 +707,34 @@ int main(int argc, char **argv) {
                 if (!ch) break;
                 uint64_t t_sub = 0;
                 const RecBatch &b0 = *ch->batches[0];   // header of the FIRST input (combine_readsets, demux.rs:126-139)
+                // This router's templates of the chunk, in input order.  Their records were last touched by the
+                // reader threads on other cores and a chunk (~100 MB) outlives the caches: each record would start
+                // with a miss to DRAM.  Knowing the list up front, the lines of the record a few templates ahead
+                // are requested while this one is formatted.
+                mine.clear();
                 for (size_t i = 0; i < ch->n; ++i) {
                     if (ch->skip[i]) continue;
                     const size_t s = ch->res[i].idx == FQTK_NO_MATCH ? S : ch->res[i].idx;
-                    if (owned[s].empty()) continue;
+                    if (!owned[s].empty()) mine.push_back((uint32_t)i);
+                }
+                auto prefetch_template = [&](size_t i) {
+                    for (size_t b = 0; b < ch->batches.size(); ++b) {
+                        const RecBatch &rb = *ch->batches[b];
+                        const FastqRec &r = rb.recs[i];
+                        const char *base = rb.base();
+                        __builtin_prefetch(base + r.head_off);
+                        for (uint32_t off = 0; off < r.seq_len; off += 64) {
+                            __builtin_prefetch(base + r.seq_off + off);
+                            __builtin_prefetch(base + r.qual_off + off);
+                        }
+                    }
+                };
+                constexpr size_t kAhead = 6;
+                for (size_t q = 0; q < std::min(kAhead, mine.size()); ++q) prefetch_template(mine[q]);
+                for (size_t q = 0; q < mine.size(); ++q) {
+                    if (q + kAhead < mine.size()) prefetch_template(mine[q + kAhead]);
+                    const size_t i = mine[q];
+                    const size_t s = ch->res[i].idx == FQTK_NO_MATCH ? S : ch->res[i].idx;
                     auto span = [&](const SegRef &r, std::string_view *bases, std::string_view *quals) {
                         const RecBatch &b = *ch->batches[r.input];
                         size_t lo, hi;
