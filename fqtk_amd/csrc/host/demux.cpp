@@ -270,7 +270,7 @@ struct OutFile {
 
 struct StageTimes {   // FQTK_TIMING=1: where the host threads spend their time (seconds, summed over threads)
     std::atomic<uint64_t> router_wait{0}, router_format{0}, router_submit{0}, comp_wait{0}, comp_deflate{0}, comp_write{0};
-    std::atomic<uint64_t> submit_calls{0}, submit_cut{0}, submit_push{0};
+    std::atomic<uint64_t> submit_calls{0}, submit_cut{0}, submit_push{0}, submit_slab{0};
     std::atomic<uint64_t> main_wait{0}, main_gpu_wait{0}, main_handoff{0}, reader_parse{0}, reader_push{0};
 };
 StageTimes g_times;
@@ -356,6 +356,7 @@ void submit_blocks_gpu(OutFile &of, bool final) {
         b.file = &of;
         b.seq = of.next_submit++;
         b.in_slab = g_gpu_stage->in_pool.get();
+        if (g_timing) g_times.submit_slab += tick() - ta;
         b.n = (uint32_t)n;
         std::memcpy(g_gpu_stage->in_slab(b.in_slab), of.buf.data(), n);
         b.crc = crc32(of.buf.data(), n);
@@ -988,12 +989,12 @@ int main(int argc, char **argv) {
         uint64_t fw = 0;
         for (auto &q : jobs) fw += q->full_waits;
         if (g_timing)
-            if (g_timing)
             info("main thread: waiting for readers %.2f s, for the GPU %.2f s, handing chunks to routers %.2f s | readers: parse %.2f s, push %.2f s",
                  g_times.main_wait / 1e9, g_times.main_gpu_wait / 1e9, g_times.main_handoff / 1e9, g_times.reader_parse / 1e9, g_times.reader_push / 1e9);
         if (g_timing)
-            info("submit: %llu blocks, cut %.2f s, push %.2f s, %llu pushes found their queue full", (unsigned long long)g_times.submit_calls.load(),
-                 g_times.submit_cut / 1e9, g_times.submit_push / 1e9, (unsigned long long)fw);
+            info("submit: %llu blocks, cut %.2f s (of it waiting for a free slab %.2f s), push %.2f s, %llu pushes found their queue full",
+                 (unsigned long long)g_times.submit_calls.load(), g_times.submit_cut / 1e9, g_times.submit_slab / 1e9, g_times.submit_push / 1e9,
+                 (unsigned long long)fw);
     }
     if (skipped == 0) info("No records were skipped.");
     else info("%llu records were skipped due to Too few bases", (unsigned long long)skipped);

@@ -171,7 +171,7 @@ def scope_e(n, threads, gz, tmp, expect_counts=None, extra_args=(), repeat_first
         assert np.array_equal(got, expect_counts), "demux-metrics.txt differs from the oracle's per-sample counts"
     out_files = os.listdir(out)
     out_bytes = sum(os.path.getsize(os.path.join(out, f)) for f in out_files)
-    stage = [ln.split("fqtk] ", 1)[1] for ln in r.stderr.splitlines() if "thread-seconds" in ln or "main thread" in ln]
+    stage = [ln.split("fqtk] ", 1)[1] for ln in r.stderr.splitlines() if "thread-seconds" in ln or "main thread" in ln or "submit:" in ln]
     timeline = [ln.strip() for ln in r.stderr.splitlines() if "INFO fqtk" in ln and "demultiplexed" not in ln
                 and "thread-seconds" not in ln and "main thread" not in ln and "submit:" not in ln]
     return {"what": "fqtk_amd/bin/fqtk demux, files -> files (gunzip/parse -> GPU match -> BGZF), "
