@@ -13,39 +13,61 @@
 namespace fqtk {
 namespace bgzf {
 
+#ifdef FQTK_BGZF_PHASE_TIMES
+// Developer build (tools/bgzf_phases.sh): 100 MHz ticks spent in each phase, summed over all blocks by lane 0.
+__device__ unsigned long long g_phase_ticks[12];
+#define FQTK_PHASE_MARK(k) do { if (lane == 0) { const uint64_t now = wall_clock64(); atomicAdd(&g_phase_ticks[k], (unsigned long long)(now - t_mark)); t_mark = now; } } while (0)
+#else
+#define FQTK_PHASE_MARK(k) do { } while (0)
+#endif
+
 __global__ __launch_bounds__(kLanes) void deflate_kernel(const fqtk_bgzf_block *blocks, uint32_t n_blocks,
                                                          uint32_t *out_len, uint32_t *tok_all) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem_raw[];
     Shared &S = *reinterpret_cast<Shared *>(smem_raw);
     const int lane = (int)threadIdx.x;
     uint32_t *tok = tok_all + (size_t)blockIdx.x * kTokensPerBlock;   // token scratch of this workgroup
+#ifdef FQTK_BGZF_PHASE_TIMES
+    uint64_t t_mark = wall_clock64();
+#endif
     for (uint32_t j = blockIdx.x; j < n_blocks; j += gridDim.x) {
         const uint8_t *in = blocks[j].in;
         uint8_t *out = blocks[j].out;
         const uint32_t n = blocks[j].n_in;
         phase_load(S, lane, in, n);
         __syncthreads();
+        FQTK_PHASE_MARK(0);
         phase_index(S, lane, n);
         __syncthreads();
+        FQTK_PHASE_MARK(1);
         phase_literal_costs(S, lane, n);
         __syncthreads();
+        FQTK_PHASE_MARK(2);
         phase_lz(S, lane, n, tok);
         __syncthreads();
+        FQTK_PHASE_MARK(3);
         phase_clear_out(S, lane);
         __syncthreads();
+        FQTK_PHASE_MARK(4);
         if (lane == 0) phase_codes_and_header(S);
         __syncthreads();
+        FQTK_PHASE_MARK(5);
         phase_count_bits(S, lane, tok);
         __syncthreads();
+        FQTK_PHASE_MARK(6);
         if (lane == 0) phase_offsets(S, n);
         __syncthreads();
+        FQTK_PHASE_MARK(7);
         phase_emit(S, lane, tok);
         __syncthreads();
+        FQTK_PHASE_MARK(8);
         const uint32_t bytes = phase_store(S, lane, in, n, out);
         if (lane == 0) out_len[j] = bytes;
         __syncthreads();   // S is reused by the next block
+        FQTK_PHASE_MARK(9);
     }
 }
+#undef FQTK_PHASE_MARK
 
 }  // namespace bgzf
 }  // namespace fqtk
@@ -69,6 +91,12 @@ struct fqtk_bgzf {
 };
 
 extern "C" {
+
+#ifdef FQTK_BGZF_PHASE_TIMES
+int fqtk_bgzf_dev_phase_ticks(unsigned long long *out12) {
+    return hipMemcpyFromSymbol(out12, HIP_SYMBOL(fqtk::bgzf::g_phase_ticks), 12 * sizeof(unsigned long long)) == hipSuccess ? 0 : 1;
+}
+#endif
 
 const char *fqtk_bgzf_last_error(void) { return g_bgzf_error.c_str(); }
 

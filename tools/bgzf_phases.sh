@@ -1,0 +1,21 @@
+#!/bin/bash
+# Developer tool: where the BGZF compressor kernel spends its time, phase by phase (dev build with timestamps).
+cd "$(dirname "$0")/.."
+cp fqtk_amd/lib/libfqtk_match.so /tmp/libfqtk_match.prod.so
+hipcc --offload-arch=gfx950 -O3 -std=c++17 -shared -fPIC -Iinclude -DFQTK_BGZF_PHASE_TIMES -o fqtk_amd/lib/libfqtk_match.so fqtk_amd/csrc/fqtk_match.hip fqtk_amd/csrc/fqtk_bgzf.hip || exit 1
+python - <<'PY'
+import ctypes as C, json, subprocess, sys
+sys.path.insert(0, ".")
+import runpy
+from fqtk_amd import _lib
+lib = _lib.load()
+sys.argv = ["bgzf_bench.py"]
+runpy.run_path("tools/bgzf_bench.py", run_name="__main__")
+t = (C.c_ulonglong * 12)()
+assert lib.fqtk_bgzf_dev_phase_ticks(t) == 0
+names = ["load", "index", "literal costs", "lz", "clear", "codes + header (one lane)", "count bits", "offsets (one lane)", "emit", "store"]
+tot = sum(t[:10])
+for k, nme in enumerate(names):
+    print(f"{nme:28s} {100.0 * t[k] / tot:5.1f} %")
+PY
+cp /tmp/libfqtk_match.prod.so fqtk_amd/lib/libfqtk_match.so
