@@ -213,6 +213,24 @@ FQTK_HD inline uint32_t load_le32(const uint8_t *p) {
     return (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((uint32_t)p[3] << 24);
 }
 FQTK_HD inline uint32_t hash4(uint32_t x) { return (x * 2654435761u) >> (32 - kHashBits); }
+// Four bytes at any byte offset of the block buffer.  Device: two aligned LDS words and one v_alignbyte_b32
+// instead of four byte reads (the word after the last payload byte exists: the buffer is 64 KiB, a block 65 280 B).
+FQTK_HD inline uint32_t buf_le32(const uint32_t *words, uint32_t pos) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_alignbyte(words[(pos >> 2) + 1], words[pos >> 2], pos & 3u);
+#else
+    return load_le32(reinterpret_cast<const uint8_t *>(words) + pos);
+#endif
+}
+FQTK_HD inline uint32_t ctz32(uint32_t x) {   // x != 0
+#if defined(__HIP_DEVICE_COMPILE__)
+    return (uint32_t)__builtin_ctz(x);
+#else
+    uint32_t k = 0;
+    while (!(x & 1u)) { x >>= 1; ++k; }
+    return k;
+#endif
+}
 
 // P0: clear the shared state, bring the block in.  `in` may be device or (pinned, device-visible) host memory.
 FQTK_HD inline void phase_load(Shared &S, int lane, const uint8_t *in, uint32_t n) {
@@ -245,7 +263,7 @@ FQTK_HD inline void phase_index(Shared &S, int lane, uint32_t n) {
     const uint32_t hi = lo + kChunk < n ? lo + kChunk : n;
     for (uint32_t p = lo; p < hi; ++p) FQTK_BGZF_ADD(&S.byte_cnt[b[p]], 1u);
     for (uint32_t p = lo; p < hi && p + 4 <= n; ++p) {
-        uint32_t *w = &S.tminmax[region_slot(p, hash4(load_le32(b + p)))];
+        uint32_t *w = &S.tminmax[region_slot(p, hash4(buf_le32(S.buf, p)))];
         uint32_t old = *w;
         for (;;) {
             const uint32_t mn = (old & 0xFFFFu) < p ? (old & 0xFFFFu) : p;
@@ -294,9 +312,8 @@ FQTK_HD inline void lz_begin(Shared &S, int lane, uint32_t n, LzLane &st) {
     st.nt = 0;
     st.last_dist = 0;
     // the private table starts with the slice before this one (the neighbour's bytes, read-only here)
-    const uint8_t *b = reinterpret_cast<const uint8_t *>(S.buf);
     for (uint32_t q = st.p >= kChunk ? st.p - kChunk : 0u; q < st.p && q + 4 <= n; ++q)
-        S.near_tab[((hash4(load_le32(b + q)) >> 5) & (kNearSlots - 1u)) * kLanes + (uint32_t)lane] = (uint16_t)q;
+        S.near_tab[((hash4(buf_le32(S.buf, q)) >> 5) & (kNearSlots - 1u)) * kLanes + (uint32_t)lane] = (uint16_t)q;
 }
 // one token; false when the slice is done
 FQTK_HD inline bool lz_step(Shared &S, int lane, uint32_t n, uint32_t *tok, LzLane &st) {
@@ -305,7 +322,7 @@ FQTK_HD inline bool lz_step(Shared &S, int lane, uint32_t n, uint32_t *tok, LzLa
     const uint32_t p = st.p;
     uint32_t mlen = 0, mdist = 0, msave = 0;
     if (p + 4 <= n) {
-        const uint32_t w = load_le32(b + p);
+        const uint32_t w = buf_le32(S.buf, p);
         const uint32_t h = hash4(w);
         const uint32_t near_slot = ((h >> 5) & (kNearSlots - 1u)) * kLanes + (uint32_t)lane;
         const uint32_t own = S.tminmax[region_slot(p, h)] & 0xFFFFu;
@@ -317,18 +334,42 @@ FQTK_HD inline bool lz_step(Shared &S, int lane, uint32_t n, uint32_t *tok, LzLa
         cand[4] = p >= 16384u ? (S.tminmax[region_slot(p - 16384u, h)] >> 16) : 0u;
         S.near_tab[near_slot] = (uint16_t)p;
         const uint32_t maxl = st.end - p < 258u ? st.end - p : 258u;       // a match never leaves the lane's slice
+        // length of every candidate that starts with the same four bytes, compared four bytes at a time
+        uint32_t len_c[5], lmax = 0;
         for (int c = 0; c < 5; ++c) {
+            len_c[c] = 0;
             if (cand[c] == 0u) continue;
             const uint32_t q = cand[c] - 1;
-            if (q >= p || p - q > 32768u || load_le32(b + q) != w) continue;
+            if (q >= p || p - q > 32768u || buf_le32(S.buf, q) != w) continue;
             uint32_t l = 4;
-            while (l < maxl && b[q + l] == b[p + l]) ++l;
+            while (l < maxl) {
+                const uint32_t x = buf_le32(S.buf, q + l) ^ buf_le32(S.buf, p + l);
+                if (x) { l += ctz32(x) >> 3; break; }
+                l += 4;
+            }
             if (l > maxl) l = maxl;
             if (l < (uint32_t)kMinMatch) continue;
-            uint32_t lit = 0;
-            for (uint32_t k = 0; k < l; ++k) lit += S.lit_cost[b[p + k]];
-            const uint32_t cost = match_cost(l, p - q);
-            if (lit > cost && lit - cost > msave) { msave = lit - cost; mlen = l; mdist = p - q; }
+            len_c[c] = l;
+            if (l > lmax) lmax = l;
+        }
+        // what the covered bytes would cost as literals: ONE pass up to the longest candidate, the running sum
+        // picked up at each candidate's length
+        uint32_t lit_c[5] = {0, 0, 0, 0, 0}, cum = 0;
+        for (uint32_t k = 0; k < lmax; k += 4) {
+            const uint32_t w4 = buf_le32(S.buf, p + k);
+            const uint32_t s1 = cum + S.lit_cost[w4 & 255u], s2 = s1 + S.lit_cost[(w4 >> 8) & 255u];
+            const uint32_t s3 = s2 + S.lit_cost[(w4 >> 16) & 255u], s4 = s3 + S.lit_cost[w4 >> 24];
+            for (int c = 0; c < 5; ++c) {
+                const uint32_t d = len_c[c] - k;   // (wraps for shorter candidates: not in 1..4)
+                if (d - 1u < 4u) lit_c[c] = d == 1 ? s1 : (d == 2 ? s2 : (d == 3 ? s3 : s4));
+            }
+            cum = s4;
+        }
+        for (int c = 0; c < 5; ++c) {
+            if (!len_c[c]) continue;
+            const uint32_t dist = p - (cand[c] - 1);
+            const uint32_t cost = match_cost(len_c[c], dist);
+            if (lit_c[c] > cost && lit_c[c] - cost > msave) { msave = lit_c[c] - cost; mlen = len_c[c]; mdist = dist; }
         }
     }
     if (mlen) {
@@ -340,7 +381,7 @@ FQTK_HD inline bool lz_step(Shared &S, int lane, uint32_t n, uint32_t *tok, LzLa
         tok[st.nt * kLanes + (uint32_t)lane] = match_token(mlen, mdist);
         st.last_dist = mdist;
         for (uint32_t q = p + 1; q < p + mlen && q + 4 <= n; ++q)         // the positions skipped are recent history too
-            S.near_tab[((hash4(load_le32(b + q)) >> 5) & (kNearSlots - 1u)) * kLanes + (uint32_t)lane] = (uint16_t)q;
+            S.near_tab[((hash4(buf_le32(S.buf, q)) >> 5) & (kNearSlots - 1u)) * kLanes + (uint32_t)lane] = (uint16_t)q;
         st.p = p + mlen;
     } else {
         FQTK_BGZF_ADD(&S.freq_ll[b[p]], 1u);
