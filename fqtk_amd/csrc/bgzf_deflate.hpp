@@ -58,6 +58,7 @@ struct Shared {
     uint16_t near_tab[kNearSlots * kLanes];  // [slot][lane]: every lane's private table of recent positions
     uint32_t byte_cnt[256];                  // P1a: how often each byte value occurs in the block
     uint8_t lit_cost[256];                   // estimated cost of a literal, in half-bits (from byte_cnt)
+    uint32_t lit_total;                      // sum of them over the block's bytes (for the average)
     uint32_t freq_ll[288], freq_d[32];
     uint16_t code_ll[288], code_d[32];    // bit-reversed canonical codes (appended LSB first)
     uint8_t len_ll[288], len_d[32];
@@ -76,11 +77,7 @@ struct Shared {
 };
 
 // ---- symbol arithmetic (RFC 1951 3.2.5), computed rather than tabulated -------------------------------------
-FQTK_HD inline int floor_log2(uint32_t x) {   // x >= 1
-    int r = 0;
-    while (x >>= 1) ++r;
-    return r;
-}
+FQTK_HD inline int floor_log2(uint32_t x) { return 31 - __builtin_clz(x); }   // x >= 1
 // length 3..258 -> literal/length symbol 257..285, number of extra bits and their value
 FQTK_HD inline void length_symbol(uint32_t len, uint32_t &sym, uint32_t &nextra, uint32_t &extra) {
     const uint32_t l = len - 3;
@@ -239,6 +236,7 @@ FQTK_HD inline void phase_load(Shared &S, int lane, const uint8_t *in, uint32_t 
     for (uint32_t i = (uint32_t)lane; i < 288; i += kLanes) S.freq_ll[i] = 0;
     if (lane < 32) S.freq_d[lane] = 0;
     S.byte_cnt[lane] = 0;
+    if (lane == 0) S.lit_total = 0;
     uint8_t *b = reinterpret_cast<uint8_t *>(S.buf);
     if ((reinterpret_cast<uintptr_t>(in) & 15u) == 0) {
         const uint32_t n16 = n >> 4;
@@ -295,6 +293,7 @@ FQTK_HD inline void phase_literal_costs(Shared &S, int lane, uint32_t n) {   // 
         if (cost > 30u) cost = 30u;
     }
     S.lit_cost[lane] = (uint8_t)cost;
+    if (c) FQTK_BGZF_ADD(&S.lit_total, c * cost);
 }
 FQTK_HD inline uint32_t match_cost(uint32_t len, uint32_t dist) {   // half-bits: length code + distance code + extras
     uint32_t sym, ne_l, ne_d, ev;
@@ -305,12 +304,13 @@ FQTK_HD inline uint32_t match_cost(uint32_t len, uint32_t dist) {   // half-bits
 
 // P1b: greedy LZ77 over this lane's slice; tokens to tok[t * kLanes + lane].  Deterministic: reads the tables
 // of P1a and the lane's own state only.
-struct LzLane { uint32_t p, end, nt, last_dist; };
+struct LzLane { uint32_t p, end, nt, last_dist, avg16; };   // avg16: the block's average literal cost, half-bits x 16
 FQTK_HD inline void lz_begin(Shared &S, int lane, uint32_t n, LzLane &st) {
     st.p = (uint32_t)lane * kChunk;
     st.end = st.p + kChunk < n ? st.p + kChunk : n;
     st.nt = 0;
     st.last_dist = 0;
+    st.avg16 = n ? (uint32_t)(((uint64_t)S.lit_total << 4) / n) : 0u;
     // the private table starts with the slice before this one (the neighbour's bytes, read-only here)
     for (uint32_t q = st.p >= kChunk ? st.p - kChunk : 0u; q < st.p && q + 4 <= n; ++q)
         S.near_tab[((hash4(buf_le32(S.buf, q)) >> 5) & (kNearSlots - 1u)) * kLanes + (uint32_t)lane] = (uint16_t)q;
@@ -334,42 +334,43 @@ FQTK_HD inline bool lz_step(Shared &S, int lane, uint32_t n, uint32_t *tok, LzLa
         cand[4] = p >= 16384u ? (S.tminmax[region_slot(p - 16384u, h)] >> 16) : 0u;
         S.near_tab[near_slot] = (uint16_t)p;
         const uint32_t maxl = st.end - p < 258u ? st.end - p : 258u;       // a match never leaves the lane's slice
-        // length of every candidate that starts with the same four bytes, compared four bytes at a time
-        uint32_t len_c[5], lmax = 0;
+        // Which candidates start with the same four bytes: all five are read before any is looked at (one wave
+        // per SIMD: every dependent LDS round trip is paid in full, so the reads go out together).
+        uint32_t qpos[5], first[5];
         for (int c = 0; c < 5; ++c) {
-            len_c[c] = 0;
-            if (cand[c] == 0u) continue;
-            const uint32_t q = cand[c] - 1;
-            if (q >= p || p - q > 32768u || buf_le32(S.buf, q) != w) continue;
+            const uint32_t q = cand[c] - 1u;                               // 0xFFFFFFFF for "none"
+            const bool in_reach = cand[c] != 0u && q < p && p - q <= 32768u;
+            qpos[c] = in_reach ? q : p;                                    // p itself: reads fine, never accepted
+            first[c] = buf_le32(S.buf, qpos[c]);
+        }
+        // what the bytes cost as literals: exactly for the first eight, the block's average beyond (every long
+        // match pays for itself many times over; the estimate only ranks long candidates among themselves)
+        const uint32_t w4 = buf_le32(S.buf, p + 4);
+        uint32_t lit8[9];
+        lit8[0] = 0;
+        for (int k = 0; k < 4; ++k) lit8[k + 1] = lit8[k] + S.lit_cost[(w >> (8 * k)) & 255u];
+        for (int k = 0; k < 4; ++k) lit8[k + 5] = lit8[k + 4] + S.lit_cost[(w4 >> (8 * k)) & 255u];
+        for (int c = 0; c < 5; ++c) {
+            const uint32_t q = qpos[c];
+            if (q == p || first[c] != w) continue;
+            // sixteen bytes per round: the eight word pairs are independent reads
             uint32_t l = 4;
             while (l < maxl) {
-                const uint32_t x = buf_le32(S.buf, q + l) ^ buf_le32(S.buf, p + l);
-                if (x) { l += ctz32(x) >> 3; break; }
-                l += 4;
+                const uint32_t x0 = buf_le32(S.buf, q + l) ^ buf_le32(S.buf, p + l);
+                const uint32_t x1 = buf_le32(S.buf, q + l + 4) ^ buf_le32(S.buf, p + l + 4);
+                const uint32_t x2 = buf_le32(S.buf, q + l + 8) ^ buf_le32(S.buf, p + l + 8);
+                const uint32_t x3 = buf_le32(S.buf, q + l + 12) ^ buf_le32(S.buf, p + l + 12);
+                if (x0 | x1 | x2 | x3) {
+                    l += x0 ? ctz32(x0) >> 3 : (x1 ? 4 + (ctz32(x1) >> 3) : (x2 ? 8 + (ctz32(x2) >> 3) : 12 + (ctz32(x3) >> 3)));
+                    break;
+                }
+                l += 16;
             }
             if (l > maxl) l = maxl;
             if (l < (uint32_t)kMinMatch) continue;
-            len_c[c] = l;
-            if (l > lmax) lmax = l;
-        }
-        // what the covered bytes would cost as literals: ONE pass up to the longest candidate, the running sum
-        // picked up at each candidate's length
-        uint32_t lit_c[5] = {0, 0, 0, 0, 0}, cum = 0;
-        for (uint32_t k = 0; k < lmax; k += 4) {
-            const uint32_t w4 = buf_le32(S.buf, p + k);
-            const uint32_t s1 = cum + S.lit_cost[w4 & 255u], s2 = s1 + S.lit_cost[(w4 >> 8) & 255u];
-            const uint32_t s3 = s2 + S.lit_cost[(w4 >> 16) & 255u], s4 = s3 + S.lit_cost[w4 >> 24];
-            for (int c = 0; c < 5; ++c) {
-                const uint32_t d = len_c[c] - k;   // (wraps for shorter candidates: not in 1..4)
-                if (d - 1u < 4u) lit_c[c] = d == 1 ? s1 : (d == 2 ? s2 : (d == 3 ? s3 : s4));
-            }
-            cum = s4;
-        }
-        for (int c = 0; c < 5; ++c) {
-            if (!len_c[c]) continue;
-            const uint32_t dist = p - (cand[c] - 1);
-            const uint32_t cost = match_cost(len_c[c], dist);
-            if (lit_c[c] > cost && lit_c[c] - cost > msave) { msave = lit_c[c] - cost; mlen = len_c[c]; mdist = dist; }
+            const uint32_t lit = l == 4 ? lit8[4] : (l == 5 ? lit8[5] : (l == 6 ? lit8[6] : (l == 7 ? lit8[7] : lit8[8] + (((l - 8) * st.avg16) >> 4))));
+            const uint32_t cost = match_cost(l, p - q);
+            if (lit > cost && lit - cost > msave) { msave = lit - cost; mlen = l; mdist = p - q; }
         }
     }
     if (mlen) {
@@ -380,8 +381,12 @@ FQTK_HD inline bool lz_step(Shared &S, int lane, uint32_t n, uint32_t *tok, LzLa
         FQTK_BGZF_ADD(&S.freq_d[sym], 1u);
         tok[st.nt * kLanes + (uint32_t)lane] = match_token(mlen, mdist);
         st.last_dist = mdist;
-        for (uint32_t q = p + 1; q < p + mlen && q + 4 <= n; ++q)         // the positions skipped are recent history too
+        // the positions skipped are recent history too: the first sixteen and the last eight of them (a long
+        // match is a run or a copied line; its middle adds nothing the ends do not)
+        for (uint32_t q = p + 1; q < p + mlen && q + 4 <= n; ++q) {
+            if (q == p + 17 && p + mlen > q + 8) q = p + mlen - 8;
             S.near_tab[((hash4(buf_le32(S.buf, q)) >> 5) & (kNearSlots - 1u)) * kLanes + (uint32_t)lane] = (uint16_t)q;
+        }
         st.p = p + mlen;
     } else {
         FQTK_BGZF_ADD(&S.freq_ll[b[p]], 1u);
