@@ -350,9 +350,15 @@ FQTK_HD inline bool lz_step(Shared &S, int lane, uint32_t n, uint32_t *tok, LzLa
         lit8[0] = 0;
         for (int k = 0; k < 4; ++k) lit8[k + 1] = lit8[k] + S.lit_cost[(w >> (8 * k)) & 255u];
         for (int k = 0; k < 4; ++k) lit8[k + 5] = lit8[k + 4] + S.lit_cost[(w4 >> (8 * k)) & 255u];
+        uint32_t full_dist_bits = 99;   // extra bits of the distance of a candidate that already ran to maxl
         for (int c = 0; c < 5; ++c) {
             const uint32_t q = qpos[c];
             if (q == p || first[c] != w) continue;
+            {   // nothing is longer than maxl: against such a match only a cheaper distance could still win
+                uint32_t dsym, dne, dev;
+                dist_symbol(p - q, dsym, dne, dev);
+                if (dne >= full_dist_bits) continue;
+            }
             // sixteen bytes per round: the eight word pairs are independent reads
             uint32_t l = 4;
             while (l < maxl) {
@@ -371,6 +377,11 @@ FQTK_HD inline bool lz_step(Shared &S, int lane, uint32_t n, uint32_t *tok, LzLa
             const uint32_t lit = l == 4 ? lit8[4] : (l == 5 ? lit8[5] : (l == 6 ? lit8[6] : (l == 7 ? lit8[7] : lit8[8] + (((l - 8) * st.avg16) >> 4))));
             const uint32_t cost = match_cost(l, p - q);
             if (lit > cost && lit - cost > msave) { msave = lit - cost; mlen = l; mdist = p - q; }
+            if (l == maxl) {
+                uint32_t dsym, dne, dev;
+                dist_symbol(p - q, dsym, dne, dev);
+                if (dne < full_dist_bits) full_dist_bits = dne;
+            }
         }
     }
     if (mlen) {
@@ -382,10 +393,27 @@ FQTK_HD inline bool lz_step(Shared &S, int lane, uint32_t n, uint32_t *tok, LzLa
         tok[st.nt * kLanes + (uint32_t)lane] = match_token(mlen, mdist);
         st.last_dist = mdist;
         // the positions skipped are recent history too: the first sixteen and the last eight of them (a long
-        // match is a run or a copied line; its middle adds nothing the ends do not)
-        for (uint32_t q = p + 1; q < p + mlen && q + 4 <= n; ++q) {
-            if (q == p + 17 && p + mlen > q + 8) q = p + mlen - 8;
-            S.near_tab[((hash4(buf_le32(S.buf, q)) >> 5) & (kNearSlots - 1u)) * kLanes + (uint32_t)lane] = (uint16_t)q;
+        // match is a run or a copied line; its middle adds nothing the ends do not).  Each group is read as one
+        // run of words and hashed from registers.
+        auto insert_run = [&](uint32_t from, uint32_t count) {   // positions from .. from + count - 1, count <= 16
+            uint32_t v[6];
+            const uint32_t i0 = from >> 2, sh = from & 3u;
+            for (int j = 0; j < 5; ++j) v[j] = buf_le32(S.buf, (i0 + (uint32_t)j) * 4u + sh);   // v = the bytes from `from` on
+            v[5] = 0;
+            for (uint32_t k = 0; k < 16; ++k) {
+                if (k >= count || from + k + 4 > n) break;
+                const uint32_t lo = v[k >> 2], hi = v[(k >> 2) + 1];
+                const uint32_t x = (k & 3u) ? (lo >> (8 * (k & 3u))) | (hi << (32 - 8 * (k & 3u))) : lo;
+                S.near_tab[((hash4(x) >> 5) & (kNearSlots - 1u)) * kLanes + (uint32_t)lane] = (uint16_t)(from + k);
+            }
+        };
+        if (mlen > 1) {
+            const uint32_t skipped = mlen - 1;           // positions p + 1 .. p + mlen - 1
+            insert_run(p + 1, skipped < 16u ? skipped : 16u);
+            if (skipped > 16u) {
+                const uint32_t tail = skipped - 16u < 8u ? skipped - 16u : 8u;
+                insert_run(p + mlen - tail, tail);
+            }
         }
         st.p = p + mlen;
     } else {
