@@ -316,7 +316,19 @@ FQTK_HD inline void lz_begin(Shared &S, int lane, uint32_t n, LzLane &st) {
         S.near_tab[((hash4(buf_le32(S.buf, q)) >> 5) & (kNearSlots - 1u)) * kLanes + (uint32_t)lane] = (uint16_t)q;
 }
 // one token; false when the slice is done
-FQTK_HD inline bool lz_step(Shared &S, int lane, uint32_t n, uint32_t *tok, LzLane &st) {
+#if defined(FQTK_BGZF_PHASE_TIMES) && defined(__HIPCC__)
+__device__ unsigned long long g_lz_cycles[8];   // setup, candidate reads + literal costs, extension, token + inserts, steps
+#endif
+#if defined(FQTK_BGZF_PHASE_TIMES) && defined(__HIP_DEVICE_COMPILE__)
+#define FQTK_LZ_MARK(k) do { const uint64_t now_ = __builtin_readcyclecounter(); lz_acc[k] += now_ - lz_t; lz_t = now_; } while (0)
+#else
+#define FQTK_LZ_MARK(k) do { } while (0)
+#endif
+FQTK_HD inline bool lz_step(Shared &S, int lane, uint32_t n, uint32_t *tok, LzLane &st
+#if defined(FQTK_BGZF_PHASE_TIMES) && defined(__HIP_DEVICE_COMPILE__)
+                            , uint64_t (&lz_acc)[5], uint64_t &lz_t
+#endif
+) {
     if (st.p >= st.end) return false;
     const uint8_t *b = reinterpret_cast<const uint8_t *>(S.buf);
     const uint32_t p = st.p;
@@ -334,6 +346,7 @@ FQTK_HD inline bool lz_step(Shared &S, int lane, uint32_t n, uint32_t *tok, LzLa
         cand[4] = p >= 16384u ? (S.tminmax[region_slot(p - 16384u, h)] >> 16) : 0u;
         S.near_tab[near_slot] = (uint16_t)p;
         const uint32_t maxl = st.end - p < 258u ? st.end - p : 258u;       // a match never leaves the lane's slice
+        FQTK_LZ_MARK(0);
         // Which candidates start with the same four bytes: all five are read before any is looked at (one wave
         // per SIMD: every dependent LDS round trip is paid in full, so the reads go out together).
         uint32_t qpos[5], first[5];
@@ -350,6 +363,7 @@ FQTK_HD inline bool lz_step(Shared &S, int lane, uint32_t n, uint32_t *tok, LzLa
         lit8[0] = 0;
         for (int k = 0; k < 4; ++k) lit8[k + 1] = lit8[k] + S.lit_cost[(w >> (8 * k)) & 255u];
         for (int k = 0; k < 4; ++k) lit8[k + 5] = lit8[k + 4] + S.lit_cost[(w4 >> (8 * k)) & 255u];
+        FQTK_LZ_MARK(1);
         uint32_t full_dist_bits = 99;   // extra bits of the distance of a candidate that already ran to maxl
         for (int c = 0; c < 5; ++c) {
             const uint32_t q = qpos[c];
@@ -384,6 +398,7 @@ FQTK_HD inline bool lz_step(Shared &S, int lane, uint32_t n, uint32_t *tok, LzLa
             }
         }
     }
+    FQTK_LZ_MARK(2);
     if (mlen) {
         uint32_t sym, ne, ev;
         length_symbol(mlen, sym, ne, ev);
@@ -422,12 +437,26 @@ FQTK_HD inline bool lz_step(Shared &S, int lane, uint32_t n, uint32_t *tok, LzLa
         st.p = p + 1;
     }
     ++st.nt;
+    FQTK_LZ_MARK(3);
     return true;
 }
 FQTK_HD inline void phase_lz(Shared &S, int lane, uint32_t n, uint32_t *tok) {
     LzLane st;
+#if defined(FQTK_BGZF_PHASE_TIMES) && defined(__HIP_DEVICE_COMPILE__)
+    uint64_t lz_acc[5] = {0, 0, 0, 0, 0}, lz_t = __builtin_readcyclecounter();
+    lz_begin(S, lane, n, st);
+    { const uint64_t now_ = __builtin_readcyclecounter(); lz_acc[4] += now_ - lz_t; lz_t = now_; }
+    uint64_t steps = 0;
+    while (lz_step(S, lane, n, tok, st, lz_acc, lz_t)) { ++steps; }
+    if ((lane & 63) == 0) {
+        for (int k = 0; k < 5; ++k) atomicAdd(&g_lz_cycles[k], (unsigned long long)lz_acc[k]);
+        atomicAdd(&g_lz_cycles[5], (unsigned long long)steps);
+        atomicAdd(&g_lz_cycles[6], 1ull);
+    }
+#else
     lz_begin(S, lane, n, st);
     while (lz_step(S, lane, n, tok, st)) {}
+#endif
     S.ntok[lane] = st.nt;
 }
 

@@ -96,6 +96,9 @@ extern "C" {
 int fqtk_bgzf_dev_phase_ticks(unsigned long long *out12) {
     return hipMemcpyFromSymbol(out12, HIP_SYMBOL(fqtk::bgzf::g_phase_ticks), 12 * sizeof(unsigned long long)) == hipSuccess ? 0 : 1;
 }
+int fqtk_bgzf_dev_lz_cycles(unsigned long long *out8) {
+    return hipMemcpyFromSymbol(out8, HIP_SYMBOL(fqtk::bgzf::g_lz_cycles), 8 * sizeof(unsigned long long)) == hipSuccess ? 0 : 1;
+}
 #endif
 
 const char *fqtk_bgzf_last_error(void) { return g_bgzf_error.c_str(); }

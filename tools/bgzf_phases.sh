@@ -17,5 +17,10 @@ names = ["load", "index", "literal costs", "lz", "clear", "codes + header (one l
 tot = sum(t[:10])
 for k, nme in enumerate(names):
     print(f"{nme:28s} {100.0 * t[k] / tot:5.1f} %")
+z = (C.c_ulonglong * 8)()
+assert lib.fqtk_bgzf_dev_lz_cycles(z) == 0
+waves = max(z[6], 1)
+print(f"lz, per wave (lane 0 of each wave): {z[5] / waves:.0f} steps; cycles per step: table reads {z[0] / max(z[5],1):.0f}, candidate reads + literal costs {z[1] / max(z[5],1):.0f}, "
+      f"match extension {z[2] / max(z[5],1):.0f}, token + history inserts {z[3] / max(z[5],1):.0f}; history preload {z[4] / waves:.0f} cycles per wave")
 PY
 cp /tmp/libfqtk_match.prod.so fqtk_amd/lib/libfqtk_match.so
