@@ -317,7 +317,7 @@ FQTK_HD inline void lz_begin(Shared &S, int lane, uint32_t n, LzLane &st) {
 }
 // one token; false when the slice is done
 #if defined(FQTK_BGZF_PHASE_TIMES) && defined(__HIPCC__)
-__device__ unsigned long long g_lz_cycles[8];   // setup, candidate reads + literal costs, extension, token + inserts, steps
+__device__ unsigned long long g_lz_cycles[10];   // setup, candidate reads + literal costs, extension, token + inserts, steps
 #endif
 #if defined(FQTK_BGZF_PHASE_TIMES) && defined(__HIP_DEVICE_COMPILE__)
 #define FQTK_LZ_MARK(k) do { const uint64_t now_ = __builtin_readcyclecounter(); lz_acc[k] += now_ - lz_t; lz_t = now_; } while (0)
@@ -326,7 +326,7 @@ __device__ unsigned long long g_lz_cycles[8];   // setup, candidate reads + lite
 #endif
 FQTK_HD inline bool lz_step(Shared &S, int lane, uint32_t n, uint32_t *tok, LzLane &st
 #if defined(FQTK_BGZF_PHASE_TIMES) && defined(__HIP_DEVICE_COMPILE__)
-                            , uint64_t (&lz_acc)[5], uint64_t &lz_t
+                            , uint64_t (&lz_acc)[8], uint64_t &lz_t
 #endif
 ) {
     if (st.p >= st.end) return false;
@@ -407,6 +407,7 @@ FQTK_HD inline bool lz_step(Shared &S, int lane, uint32_t n, uint32_t *tok, LzLa
         FQTK_BGZF_ADD(&S.freq_d[sym], 1u);
         tok[st.nt * kLanes + (uint32_t)lane] = match_token(mlen, mdist);
         st.last_dist = mdist;
+        FQTK_LZ_MARK(5);
         // the positions skipped are recent history too: the first sixteen and the last eight of them (a long
         // match is a run or a copied line; its middle adds nothing the ends do not).  Each group is read as one
         // run of words and hashed from registers.
@@ -431,10 +432,12 @@ FQTK_HD inline bool lz_step(Shared &S, int lane, uint32_t n, uint32_t *tok, LzLa
             }
         }
         st.p = p + mlen;
+        FQTK_LZ_MARK(6);
     } else {
         FQTK_BGZF_ADD(&S.freq_ll[b[p]], 1u);
         tok[st.nt * kLanes + (uint32_t)lane] = b[p];
         st.p = p + 1;
+        FQTK_LZ_MARK(7);
     }
     ++st.nt;
     FQTK_LZ_MARK(3);
@@ -443,15 +446,15 @@ FQTK_HD inline bool lz_step(Shared &S, int lane, uint32_t n, uint32_t *tok, LzLa
 FQTK_HD inline void phase_lz(Shared &S, int lane, uint32_t n, uint32_t *tok) {
     LzLane st;
 #if defined(FQTK_BGZF_PHASE_TIMES) && defined(__HIP_DEVICE_COMPILE__)
-    uint64_t lz_acc[5] = {0, 0, 0, 0, 0}, lz_t = __builtin_readcyclecounter();
+    uint64_t lz_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, lz_t = __builtin_readcyclecounter();
     lz_begin(S, lane, n, st);
     { const uint64_t now_ = __builtin_readcyclecounter(); lz_acc[4] += now_ - lz_t; lz_t = now_; }
     uint64_t steps = 0;
     while (lz_step(S, lane, n, tok, st, lz_acc, lz_t)) { ++steps; }
     if ((lane & 63) == 0) {
-        for (int k = 0; k < 5; ++k) atomicAdd(&g_lz_cycles[k], (unsigned long long)lz_acc[k]);
-        atomicAdd(&g_lz_cycles[5], (unsigned long long)steps);
-        atomicAdd(&g_lz_cycles[6], 1ull);
+        for (int k = 0; k < 8; ++k) atomicAdd(&g_lz_cycles[k], (unsigned long long)lz_acc[k]);
+        atomicAdd(&g_lz_cycles[8], (unsigned long long)steps);
+        atomicAdd(&g_lz_cycles[9], 1ull);
     }
 #else
     lz_begin(S, lane, n, st);

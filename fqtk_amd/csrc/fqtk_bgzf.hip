@@ -96,8 +96,8 @@ extern "C" {
 int fqtk_bgzf_dev_phase_ticks(unsigned long long *out12) {
     return hipMemcpyFromSymbol(out12, HIP_SYMBOL(fqtk::bgzf::g_phase_ticks), 12 * sizeof(unsigned long long)) == hipSuccess ? 0 : 1;
 }
-int fqtk_bgzf_dev_lz_cycles(unsigned long long *out8) {
-    return hipMemcpyFromSymbol(out8, HIP_SYMBOL(fqtk::bgzf::g_lz_cycles), 8 * sizeof(unsigned long long)) == hipSuccess ? 0 : 1;
+int fqtk_bgzf_dev_lz_cycles(unsigned long long *out10) {
+    return hipMemcpyFromSymbol(out10, HIP_SYMBOL(fqtk::bgzf::g_lz_cycles), 10 * sizeof(unsigned long long)) == hipSuccess ? 0 : 1;
 }
 #endif
 

@@ -17,10 +17,11 @@ names = ["load", "index", "literal costs", "lz", "clear", "codes + header (one l
 tot = sum(t[:10])
 for k, nme in enumerate(names):
     print(f"{nme:28s} {100.0 * t[k] / tot:5.1f} %")
-z = (C.c_ulonglong * 8)()
+z = (C.c_ulonglong * 10)()
 assert lib.fqtk_bgzf_dev_lz_cycles(z) == 0
-waves = max(z[6], 1)
-print(f"lz, per wave (lane 0 of each wave): {z[5] / waves:.0f} steps; cycles per step: table reads {z[0] / max(z[5],1):.0f}, candidate reads + literal costs {z[1] / max(z[5],1):.0f}, "
-      f"match extension {z[2] / max(z[5],1):.0f}, token + history inserts {z[3] / max(z[5],1):.0f}; history preload {z[4] / waves:.0f} cycles per wave")
+waves, steps = max(z[9], 1), max(z[8], 1)
+print(f"lz, per wave: {steps / waves:.0f} steps; history preload {z[4] / waves:.0f} cycles; cycles per step: table reads {z[0] / steps:.0f}, "
+      f"candidate reads + literal costs {z[1] / steps:.0f}, match extension {z[2] / steps:.0f}, match token {z[5] / steps:.0f}, "
+      f"history inserts {z[6] / steps:.0f}, literal token {z[7] / steps:.0f}, rest {z[3] / steps:.0f}")
 PY
 cp /tmp/libfqtk_match.prod.so fqtk_amd/lib/libfqtk_match.so
