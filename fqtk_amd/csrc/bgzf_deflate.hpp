@@ -344,6 +344,9 @@ __device__ unsigned long long g_lz_cycles[10];   // setup, candidate reads + lit
 #else
 #define FQTK_LZ_MARK(k) do { } while (0)
 #endif
+#ifndef FQTK_BGZF_ABL
+#define FQTK_BGZF_ABL 0   // developer ablations of the LZ phase (tools/bgzf_phases.sh); 0 in the product
+#endif
 FQTK_HD inline bool lz_step(Shared &S, int lane, uint32_t n, uint32_t *tok, LzLane &st
 #if defined(FQTK_BGZF_PHASE_TIMES) && defined(__HIP_DEVICE_COMPILE__)
                             , uint64_t (&lz_acc)[8], uint64_t &lz_t
@@ -365,7 +368,8 @@ FQTK_HD inline bool lz_step(Shared &S, int lane, uint32_t n, uint32_t *tok, LzLa
         cand[3] = own == 0xFFFFu ? 0u : own + 1u;
         cand[4] = p >= 16384u ? (S.tminmax[region_slot(p - 16384u, h)] >> 16) : 0u;
         S.near_tab[near_slot] = (uint16_t)p;
-        const uint32_t maxl = st.end - p < 258u ? st.end - p : 258u;       // a match never leaves the lane's slice
+        uint32_t maxl = st.end - p < 258u ? st.end - p : 258u;       // a match never leaves the lane's slice
+        if ((FQTK_BGZF_ABL & 8) && maxl > 8u) maxl = 8u;
         FQTK_LZ_MARK(0);
         // Which candidates start with the same four bytes: all five are read before any is looked at (one wave
         // per SIMD: every dependent LDS round trip is paid in full, so the reads go out together).
@@ -425,7 +429,7 @@ FQTK_HD inline bool lz_step(Shared &S, int lane, uint32_t n, uint32_t *tok, LzLa
         FQTK_BGZF_ADD(&S.freq_ll[sym], 1u);
         dist_symbol(mdist, sym, ne, ev);
         FQTK_BGZF_ADD(&S.freq_d[sym], 1u);
-        tok[st.nt * kLanes + (uint32_t)lane] = match_token(mlen, mdist);
+        if (!(FQTK_BGZF_ABL & 2)) tok[st.nt * kLanes + (uint32_t)lane] = match_token(mlen, mdist);
         st.last_dist = mdist;
         FQTK_LZ_MARK(5);
         // the positions skipped are recent history too: the first sixteen and the last eight of them (a long
@@ -443,7 +447,7 @@ FQTK_HD inline bool lz_step(Shared &S, int lane, uint32_t n, uint32_t *tok, LzLa
                 S.near_tab[((hash4(x) >> 5) & (kNearSlots - 1u)) * kLanes + (uint32_t)lane] = (uint16_t)(from + k);
             }
         };
-        if (mlen > 1) {
+        if (mlen > 1 && !(FQTK_BGZF_ABL & 4)) {
             const uint32_t skipped = mlen - 1;           // positions p + 1 .. p + mlen - 1
             insert_run(p + 1, skipped < 16u ? skipped : 16u);
             if (skipped > 16u) {

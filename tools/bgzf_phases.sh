@@ -2,7 +2,7 @@
 # Developer tool: where the BGZF compressor kernel spends its time, phase by phase (dev build with timestamps).
 cd "$(dirname "$0")/.."
 cp fqtk_amd/lib/libfqtk_match.so /tmp/libfqtk_match.prod.so
-hipcc --offload-arch=gfx950 -O3 -std=c++17 -shared -fPIC -Iinclude -DFQTK_BGZF_PHASE_TIMES -o fqtk_amd/lib/libfqtk_match.so fqtk_amd/csrc/fqtk_match.hip fqtk_amd/csrc/fqtk_bgzf.hip || exit 1
+hipcc --offload-arch=gfx950 -O3 -std=c++17 -shared -fPIC -Iinclude -DFQTK_BGZF_PHASE_TIMES $EXTRA_DEFS -o fqtk_amd/lib/libfqtk_match.so fqtk_amd/csrc/fqtk_match.hip fqtk_amd/csrc/fqtk_bgzf.hip || exit 1
 python - <<'PY'
 import ctypes as C, json, subprocess, sys
 sys.path.insert(0, ".")
