@@ -41,11 +41,11 @@
 namespace fqtk {
 namespace bgzf {
 
-constexpr int kLanes = 256;
+constexpr int kLanes = 512;
 constexpr uint32_t kMaxIn = 65280;        // uncompressed payload of a BGZF block (as the bgzf crate cuts them)
-constexpr uint32_t kChunk = 256;          // bytes parsed by one lane: 255 lanes x 256 = 65 280
+constexpr uint32_t kChunk = 128;          // bytes parsed by one lane: 510 lanes x 128 = 65 280
 constexpr uint32_t kHashBits = 11;        // per region; 4 regions x 2048 entries x {min, max}
-constexpr uint32_t kNearSlots = 64;       // per lane: direct-mapped table of its recent positions (local repeats)
+constexpr uint32_t kNearSlots = 32;       // per lane: direct-mapped table of its recent positions (local repeats)
 constexpr uint32_t kOutStride = 65536;    // bytes reserved per block in the output arena (stored worst case: n + 5)
 constexpr uint32_t kTokensPerBlock = kLanes * kChunk;   // token scratch, u32 each, [t][lane]
 constexpr int kNumLitLen = 286, kNumDist = 30, kNumCl = 19;
@@ -117,26 +117,6 @@ FQTK_HD inline uint32_t match_token(uint32_t len, uint32_t dist) { return 0x8000
 #define FQTK_BGZF_ADD(ptr, v) (*(ptr) += (v))
 #define FQTK_BGZF_CAS(ptr, expect, v) (*(ptr) == (expect) ? (*(ptr) = (v), (expect)) : *(ptr))
 #endif
-// counts[sym] += 1 from every calling lane.  FASTQ text is a handful of byte values, so the lanes of a wave mostly
-// hit the same few counters, and same-address LDS atomics run one lane at a time (measured: 3 400 cycles per
-// 64-lane literal step).  Device: one atomic per DISTINCT value among the calling lanes of the wave.
-FQTK_HD inline void histogram_add(uint32_t *counts, uint32_t sym) {
-#if defined(__HIP_DEVICE_COMPILE__)
-    uint64_t todo = __ballot(1);   // the lanes that called
-    while (todo) {
-        const uint32_t v = (uint32_t)__builtin_amdgcn_readfirstlane((int)sym);   // the first active lane's value
-        const uint64_t same = __ballot(sym == v);
-        if (sym == v) {
-            if (__lane_id() == (unsigned)(__ffsll((unsigned long long)same) - 1)) atomicAdd(&counts[v], (uint32_t)__popcll((unsigned long long)same));
-            return;
-        }
-        todo &= ~same;
-    }
-#else
-    counts[sym] += 1u;
-#endif
-}
-
 struct BitWriter {
     uint32_t *words;
     uint64_t acc;      // pending bits, aligned to the 32-bit word `word`
@@ -255,7 +235,7 @@ FQTK_HD inline void phase_load(Shared &S, int lane, const uint8_t *in, uint32_t 
     for (uint32_t i = 0; i < kNearSlots; ++i) S.near_tab[i * kLanes + (uint32_t)lane] = 0xFFFFu;
     for (uint32_t i = (uint32_t)lane; i < 288; i += kLanes) S.freq_ll[i] = 0;
     if (lane < 32) S.freq_d[lane] = 0;
-    S.byte_cnt[lane] = 0;
+    if (lane < 256) S.byte_cnt[lane] = 0;
     if (lane == 0) S.lit_total = 0;
     uint8_t *b = reinterpret_cast<uint8_t *>(S.buf);
     if ((reinterpret_cast<uintptr_t>(in) & 15u) == 0) {
@@ -279,7 +259,7 @@ FQTK_HD inline void phase_index(Shared &S, int lane, uint32_t n) {
     const uint8_t *b = reinterpret_cast<const uint8_t *>(S.buf);
     const uint32_t lo = (uint32_t)lane * kChunk;
     const uint32_t hi = lo + kChunk < n ? lo + kChunk : n;
-    for (uint32_t p = lo; p < hi; ++p) histogram_add(S.byte_cnt, b[p]);
+    for (uint32_t p = lo; p < hi; ++p) FQTK_BGZF_ADD(&S.byte_cnt[b[p]], 1u);
     for (uint32_t p = lo; p < hi && p + 4 <= n; ++p) {
         uint32_t *w = &S.tminmax[region_slot(p, hash4(buf_le32(S.buf, p)))];
         uint32_t old = *w;
@@ -304,6 +284,7 @@ FQTK_HD inline uint32_t log2_halfbits(uint32_t x) {   // ~ 2 * log2(x), x >= 1
     return 2u * (uint32_t)m + (m > 0 ? ((x >> (m - 1)) & 1u) : 0u);
 }
 FQTK_HD inline void phase_literal_costs(Shared &S, int lane, uint32_t n) {   // lane = byte value
+    if (lane >= 256) return;
     const uint32_t c = S.byte_cnt[lane];
     uint32_t cost = 30;
     if (c) {
@@ -458,8 +439,8 @@ FQTK_HD inline bool lz_step(Shared &S, int lane, uint32_t n, uint32_t *tok, LzLa
         st.p = p + mlen;
         FQTK_LZ_MARK(6);
     } else {
-        histogram_add(S.freq_ll, b[p]);
-        tok[st.nt * kLanes + (uint32_t)lane] = b[p];
+        if (!(FQTK_BGZF_ABL & 1)) FQTK_BGZF_ADD(&S.freq_ll[b[p]], 1u);
+        if (!(FQTK_BGZF_ABL & 2)) tok[st.nt * kLanes + (uint32_t)lane] = b[p];
         st.p = p + 1;
         FQTK_LZ_MARK(7);
     }

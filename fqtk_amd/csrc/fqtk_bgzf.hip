@@ -21,7 +21,8 @@ __device__ unsigned long long g_phase_ticks[12];
 #define FQTK_PHASE_MARK(k) do { } while (0)
 #endif
 
-__global__ __launch_bounds__(kLanes) void deflate_kernel(const fqtk_bgzf_block *blocks, uint32_t n_blocks,
+__global__ __launch_bounds__(kLanes) __attribute__((amdgpu_waves_per_eu(2, 2)))   // one workgroup per CU (LDS): registers are free
+void deflate_kernel(const fqtk_bgzf_block *blocks, uint32_t n_blocks,
                                                          uint32_t *out_len, uint32_t *tok_all) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem_raw[];
     Shared &S = *reinterpret_cast<Shared *>(smem_raw);
