@@ -355,6 +355,9 @@ FQTK_HD inline bool lz_step(Shared &S, int lane, uint32_t n, uint32_t *tok, LzLa
         // Which candidates start with the same four bytes: all five are read before any is looked at (one wave
         // per SIMD: every dependent LDS round trip is paid in full, so the reads go out together).
         uint32_t qpos[5], first[5];
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
         for (int c = 0; c < 5; ++c) {
             const uint32_t q = cand[c] - 1u;                               // 0xFFFFFFFF for "none"
             const bool in_reach = cand[c] != 0u && q < p && p - q <= 32768u;
@@ -366,10 +369,19 @@ FQTK_HD inline bool lz_step(Shared &S, int lane, uint32_t n, uint32_t *tok, LzLa
         const uint32_t w4 = buf_le32(S.buf, p + 4);
         uint32_t lit8[9];
         lit8[0] = 0;
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
         for (int k = 0; k < 4; ++k) lit8[k + 1] = lit8[k] + S.lit_cost[(w >> (8 * k)) & 255u];
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
         for (int k = 0; k < 4; ++k) lit8[k + 5] = lit8[k + 4] + S.lit_cost[(w4 >> (8 * k)) & 255u];
         FQTK_LZ_MARK(1);
         uint32_t full_dist_bits = 99;   // extra bits of the distance of a candidate that already ran to maxl
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
         for (int c = 0; c < 5; ++c) {
             const uint32_t q = qpos[c];
             if (q == p || first[c] != w) continue;
@@ -419,13 +431,19 @@ FQTK_HD inline bool lz_step(Shared &S, int lane, uint32_t n, uint32_t *tok, LzLa
         auto insert_run = [&](uint32_t from, uint32_t count) {   // positions from .. from + count - 1, count <= 16
             uint32_t v[6];
             const uint32_t i0 = from >> 2, sh = from & 3u;
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
             for (int j = 0; j < 5; ++j) v[j] = buf_le32(S.buf, (i0 + (uint32_t)j) * 4u + sh);   // v = the bytes from `from` on
             v[5] = 0;
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
             for (uint32_t k = 0; k < 16; ++k) {
-                if (k >= count || from + k + 4 > n) break;
                 const uint32_t lo = v[k >> 2], hi = v[(k >> 2) + 1];
                 const uint32_t x = (k & 3u) ? (lo >> (8 * (k & 3u))) | (hi << (32 - 8 * (k & 3u))) : lo;
-                S.near_tab[((hash4(x) >> 5) & (kNearSlots - 1u)) * kLanes + (uint32_t)lane] = (uint16_t)(from + k);
+                if (k < count && from + k + 4 <= n)   // (no break: the loop must unroll for v[] to stay in registers)
+                    S.near_tab[((hash4(x) >> 5) & (kNearSlots - 1u)) * kLanes + (uint32_t)lane] = (uint16_t)(from + k);
             }
         };
         if (mlen > 1 && !(FQTK_BGZF_ABL & 4)) {
