@@ -49,6 +49,7 @@ constexpr uint32_t kNearSlots = 32;       // per lane: direct-mapped table of it
 constexpr uint32_t kOutStride = 65536;    // bytes reserved per block in the output arena (stored worst case: n + 5)
 constexpr uint32_t kTokensPerBlock = kLanes * kChunk;   // token scratch, u32 each, [t][lane]
 constexpr int kNumLitLen = 286, kNumDist = 30, kNumCl = 19;
+constexpr int kCands = 3;                 // match candidates looked at per position
 constexpr int kMinMatch = 4;              // shorter matches cost more bits than their literals on FASTQ
 
 // Everything a block's workgroup shares.  LDS on the device (~141 KiB: one workgroup per CU), heap in the CPU tests.
@@ -305,12 +306,11 @@ FQTK_HD inline uint32_t match_cost(uint32_t len, uint32_t dist) {   // half-bits
 
 // P1b: greedy LZ77 over this lane's slice; tokens to tok[t * kLanes + lane].  Deterministic: reads the tables
 // of P1a and the lane's own state only.
-struct LzLane { uint32_t p, end, nt, last_dist, avg16; };   // avg16: the block's average literal cost, half-bits x 16
+struct LzLane { uint32_t p, end, nt, avg16; };   // avg16: the block's average literal cost, half-bits x 16
 FQTK_HD inline void lz_begin(Shared &S, int lane, uint32_t n, LzLane &st) {
     st.p = (uint32_t)lane * kChunk;
     st.end = st.p + kChunk < n ? st.p + kChunk : n;
     st.nt = 0;
-    st.last_dist = 0;
     st.avg16 = n ? (uint32_t)(((uint64_t)S.lit_total << 4) / n) : 0u;
     // the private table starts with the slice before this one (the neighbour's bytes, read-only here)
     for (uint32_t q = st.p >= kChunk ? st.p - kChunk : 0u; q < st.p && q + 4 <= n; ++q)
@@ -342,23 +342,29 @@ FQTK_HD inline bool lz_step(Shared &S, int lane, uint32_t n, uint32_t *tok, LzLa
         const uint32_t h = hash4(w);
         const uint32_t near_slot = ((h >> 5) & (kNearSlots - 1u)) * kLanes + (uint32_t)lane;
         const uint32_t own = S.tminmax[region_slot(p, h)] & 0xFFFFu;
-        uint32_t cand[5];                                                  // position + 1; 0 = none
+        // Three candidates (position + 1; 0 = none).  Two more were tried and bought nothing on FASTQ text
+        // (tools/bgzf_ratio.py): the previous match's distance and distance 1 -- the lane's own table already
+        // holds the position a run or a repeat comes from.  What each of the three is worth: without the lane's
+        // table the output grows by 0.1-1.2 %, without the region's earliest occurrence by 6-9 %, without the
+        // previous region's latest by 1-2 %.
+        uint32_t cand[kCands];
         cand[0] = (uint32_t)S.near_tab[near_slot] + 1u;                    // 0xFFFF + 1 = 0x10000: fails q < p below
-        cand[1] = st.last_dist && p >= st.last_dist ? p - st.last_dist + 1 : 0u;
-        cand[2] = p;                                                       // distance 1
-        cand[3] = own == 0xFFFFu ? 0u : own + 1u;
-        cand[4] = p >= 16384u ? (S.tminmax[region_slot(p - 16384u, h)] >> 16) : 0u;
+        cand[1] = own == 0xFFFFu ? 0u : own + 1u;
+        cand[2] = p >= 16384u ? (S.tminmax[region_slot(p - 16384u, h)] >> 16) : 0u;
         S.near_tab[near_slot] = (uint16_t)p;
+#ifdef FQTK_BGZF_DROP   // developer study (tools/bgzf_ratio.py): candidates switched off by bit mask
+        for (int c = 0; c < kCands; ++c) if ((FQTK_BGZF_DROP >> c) & 1) cand[c] = 0;
+#endif
         uint32_t maxl = st.end - p < 258u ? st.end - p : 258u;       // a match never leaves the lane's slice
         if ((FQTK_BGZF_ABL & 8) && maxl > 8u) maxl = 8u;
         FQTK_LZ_MARK(0);
         // Which candidates start with the same four bytes: all five are read before any is looked at (one wave
         // per SIMD: every dependent LDS round trip is paid in full, so the reads go out together).
-        uint32_t qpos[5], first[5];
+        uint32_t qpos[kCands], first[kCands];
 #if defined(__HIP_DEVICE_COMPILE__)
 #pragma unroll
 #endif
-        for (int c = 0; c < 5; ++c) {
+        for (int c = 0; c < kCands; ++c) {
             const uint32_t q = cand[c] - 1u;                               // 0xFFFFFFFF for "none"
             const bool in_reach = cand[c] != 0u && q < p && p - q <= 32768u;
             qpos[c] = in_reach ? q : p;                                    // p itself: reads fine, never accepted
@@ -382,7 +388,7 @@ FQTK_HD inline bool lz_step(Shared &S, int lane, uint32_t n, uint32_t *tok, LzLa
 #if defined(__HIP_DEVICE_COMPILE__)
 #pragma unroll
 #endif
-        for (int c = 0; c < 5; ++c) {
+        for (int c = 0; c < kCands; ++c) {
             const uint32_t q = qpos[c];
             if (q == p || first[c] != w) continue;
             {   // nothing is longer than maxl: against such a match only a cheaper distance could still win
@@ -423,7 +429,6 @@ FQTK_HD inline bool lz_step(Shared &S, int lane, uint32_t n, uint32_t *tok, LzLa
         dist_symbol(mdist, sym, ne, ev);
         FQTK_BGZF_ADD(&S.freq_d[sym], 1u);
         if (!(FQTK_BGZF_ABL & 2)) tok[st.nt * kLanes + (uint32_t)lane] = match_token(mlen, mdist);
-        st.last_dist = mdist;
         FQTK_LZ_MARK(5);
         // the positions skipped are recent history too: the first sixteen and the last eight of them (a long
         // match is a run or a copied line; its middle adds nothing the ends do not).  Each group is read as one
