@@ -60,6 +60,7 @@ struct Shared {
     uint32_t byte_cnt[256];                  // P1a: how often each byte value occurs in the block
     uint8_t lit_cost[256];                   // estimated cost of a literal, in half-bits (from byte_cnt)
     uint32_t lit_total;                      // sum of them over the block's bytes (for the average)
+    uint32_t m_ll;                           // used literal/length symbols (S.sorted holds them in order after P2a)
     uint32_t freq_ll[288], freq_d[32];
     uint16_t code_ll[288], code_d[32];    // bit-reversed canonical codes (appended LSB first)
     uint8_t len_ll[288], len_d[32];
@@ -141,10 +142,11 @@ struct BitWriter {
 // ---- Huffman code lengths ---------------------------------------------------------------------------------------
 // counts[0..n) -> len[0..n) (0 = unused symbol), no code longer than max_bits, Kraft sum exactly 1 (inflate
 // implementations reject incomplete literal/length sets).  At least two symbols get a code (as zlib does).
-FQTK_HD inline void huffman_lengths(Shared &S, const uint32_t *counts, int n, int max_bits, uint8_t *len) {
+// presorted_m >= 0: S.sorted[0..presorted_m) already holds the used symbols ascending by (count, symbol).
+FQTK_HD inline void huffman_lengths(Shared &S, const uint32_t *counts, int n, int max_bits, uint8_t *len, int presorted_m = -1) {
     for (int i = 0; i < n; ++i) len[i] = 0;
-    int m = 0;
-    for (int i = 0; i < n; ++i) {   // insertion sort of the used symbols by (count, symbol)
+    int m = presorted_m < 0 ? 0 : presorted_m;
+    for (int i = 0; presorted_m < 0 && i < n; ++i) {   // insertion sort of the used symbols by (count, symbol)
         if (!counts[i]) continue;
         int j = m++;
         while (j > 0 && counts[S.sorted[j - 1]] > counts[i]) { S.sorted[j] = S.sorted[j - 1]; --j; }
@@ -237,7 +239,7 @@ FQTK_HD inline void phase_load(Shared &S, int lane, const uint8_t *in, uint32_t 
     for (uint32_t i = (uint32_t)lane; i < 288; i += kLanes) S.freq_ll[i] = 0;
     if (lane < 32) S.freq_d[lane] = 0;
     if (lane < 256) S.byte_cnt[lane] = 0;
-    if (lane == 0) S.lit_total = 0;
+    if (lane == 0) { S.lit_total = 0; S.m_ll = 0; }
     uint8_t *b = reinterpret_cast<uint8_t *>(S.buf);
     if ((reinterpret_cast<uintptr_t>(in) & 15u) == 0) {
         const uint32_t n16 = n >> 4;
@@ -304,6 +306,27 @@ FQTK_HD inline uint32_t match_cost(uint32_t len, uint32_t dist) {   // half-bits
     return 2u * (7u + 5u + ne_l + ne_d);
 }
 
+// Positions from .. from + count - 1 (count <= 16) go into the lane's private table: read as one run of words,
+// hashed from registers.
+FQTK_HD inline void near_insert_run(Shared &S, int lane, uint32_t n, uint32_t from, uint32_t count) {
+    uint32_t v[6];
+    const uint32_t i0 = from >> 2, sh = from & 3u;
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+    for (int j = 0; j < 5; ++j) v[j] = buf_le32(S.buf, (i0 + (uint32_t)j) * 4u + sh);   // v = the bytes from `from` on
+    v[5] = 0;
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+    for (uint32_t k = 0; k < 16; ++k) {
+        const uint32_t lo = v[k >> 2], hi = v[(k >> 2) + 1];
+        const uint32_t x = (k & 3u) ? (lo >> (8 * (k & 3u))) | (hi << (32 - 8 * (k & 3u))) : lo;
+        if (k < count && from + k + 4 <= n)   // (no break: the loop must unroll for v[] to stay in registers)
+            S.near_tab[((hash4(x) >> 5) & (kNearSlots - 1u)) * kLanes + (uint32_t)lane] = (uint16_t)(from + k);
+    }
+}
+
 // P1b: greedy LZ77 over this lane's slice; tokens to tok[t * kLanes + lane].  Deterministic: reads the tables
 // of P1a and the lane's own state only.
 struct LzLane { uint32_t p, end, nt, avg16; };   // avg16: the block's average literal cost, half-bits x 16
@@ -313,8 +336,9 @@ FQTK_HD inline void lz_begin(Shared &S, int lane, uint32_t n, LzLane &st) {
     st.nt = 0;
     st.avg16 = n ? (uint32_t)(((uint64_t)S.lit_total << 4) / n) : 0u;
     // the private table starts with the slice before this one (the neighbour's bytes, read-only here)
-    for (uint32_t q = st.p >= kChunk ? st.p - kChunk : 0u; q < st.p && q + 4 <= n; ++q)
-        S.near_tab[((hash4(buf_le32(S.buf, q)) >> 5) & (kNearSlots - 1u)) * kLanes + (uint32_t)lane] = (uint16_t)q;
+    static_assert(kChunk % 16 == 0, "history preload in runs of 16");
+    if (st.p >= kChunk)
+        for (uint32_t q = st.p - kChunk; q < st.p; q += 16) near_insert_run(S, lane, n, q, 16);
 }
 // one token; false when the slice is done
 #if defined(FQTK_BGZF_PHASE_TIMES) && defined(__HIPCC__)
@@ -433,30 +457,12 @@ FQTK_HD inline bool lz_step(Shared &S, int lane, uint32_t n, uint32_t *tok, LzLa
         // the positions skipped are recent history too: the first sixteen and the last eight of them (a long
         // match is a run or a copied line; its middle adds nothing the ends do not).  Each group is read as one
         // run of words and hashed from registers.
-        auto insert_run = [&](uint32_t from, uint32_t count) {   // positions from .. from + count - 1, count <= 16
-            uint32_t v[6];
-            const uint32_t i0 = from >> 2, sh = from & 3u;
-#if defined(__HIP_DEVICE_COMPILE__)
-#pragma unroll
-#endif
-            for (int j = 0; j < 5; ++j) v[j] = buf_le32(S.buf, (i0 + (uint32_t)j) * 4u + sh);   // v = the bytes from `from` on
-            v[5] = 0;
-#if defined(__HIP_DEVICE_COMPILE__)
-#pragma unroll
-#endif
-            for (uint32_t k = 0; k < 16; ++k) {
-                const uint32_t lo = v[k >> 2], hi = v[(k >> 2) + 1];
-                const uint32_t x = (k & 3u) ? (lo >> (8 * (k & 3u))) | (hi << (32 - 8 * (k & 3u))) : lo;
-                if (k < count && from + k + 4 <= n)   // (no break: the loop must unroll for v[] to stay in registers)
-                    S.near_tab[((hash4(x) >> 5) & (kNearSlots - 1u)) * kLanes + (uint32_t)lane] = (uint16_t)(from + k);
-            }
-        };
         if (mlen > 1 && !(FQTK_BGZF_ABL & 4)) {
             const uint32_t skipped = mlen - 1;           // positions p + 1 .. p + mlen - 1
-            insert_run(p + 1, skipped < 16u ? skipped : 16u);
+            near_insert_run(S, lane, n, p + 1, skipped < 16u ? skipped : 16u);
             if (skipped > 16u) {
                 const uint32_t tail = skipped - 16u < 8u ? skipped - 16u : 8u;
-                insert_run(p + mlen - tail, tail);
+                near_insert_run(S, lane, n, p + mlen - tail, tail);
             }
         }
         st.p = p + mlen;
@@ -492,14 +498,31 @@ FQTK_HD inline void phase_lz(Shared &S, int lane, uint32_t n, uint32_t *tok) {
 }
 
 // P2a (all lanes): the input copy is no longer needed: the same LDS becomes the (zeroed) output image
+// ... and the used literal/length symbols are put in order for the code builder: every lane ranks one symbol
+// among all of them (a one-lane insertion sort of ~80 symbols was a fifth of the kernel's time).
 FQTK_HD inline void phase_clear_out(Shared &S, int lane) {
     for (uint32_t i = (uint32_t)lane; i < kOutStride / 4; i += kLanes) S.buf[i] = 0;
+    static_assert(kLanes >= kNumLitLen, "one lane per literal/length symbol");
+    if (lane == 0) S.freq_ll[256] = 1;   // end of block (read through count_of below: no barrier needed)
+    auto count_of = [&](int sym) -> uint32_t { return sym == 256 ? 1u : S.freq_ll[sym]; };
+    if (lane < kNumLitLen) {
+        const uint32_t c = count_of(lane);
+        if (c) {
+            uint32_t rank = 0;
+            for (int j = 0; j < kNumLitLen; ++j) {
+                const uint32_t cj = count_of(j);
+                rank += (cj != 0u && (cj < c || (cj == c && j < lane))) ? 1u : 0u;
+            }
+            S.sorted[rank] = (uint16_t)lane;
+            FQTK_BGZF_ADD(&S.m_ll, 1u);
+        }
+    }
 }
 
 // P2b (one lane): both codes, the code-length code, the block header (BFINAL = 1, BTYPE = 2)
 FQTK_HD inline void phase_codes_and_header(Shared &S) {
     S.freq_ll[256] = 1;   // end of block
-    huffman_lengths(S, S.freq_ll, kNumLitLen, 15, S.len_ll);
+    huffman_lengths(S, S.freq_ll, kNumLitLen, 15, S.len_ll, (int)S.m_ll);
     huffman_lengths(S, S.freq_d, kNumDist, 15, S.len_d);
     canonical_codes(S.len_ll, kNumLitLen, 15, S.code_ll);
     canonical_codes(S.len_d, kNumDist, 15, S.code_d);
