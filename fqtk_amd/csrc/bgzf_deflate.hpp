@@ -73,6 +73,7 @@ struct Shared {
     uint16_t parent[576];
     uint8_t depth[576];
     uint8_t cl_sym[320], cl_extra[320];   // run-length coded code lengths
+    uint32_t bl_count[17], next_code[17]; // (indexed by run-time values: private arrays would live in scratch memory)
     uint32_t freq_cl[kNumCl];
     uint16_t code_cl[kNumCl];
     uint8_t len_cl[kNumCl];
@@ -99,10 +100,14 @@ FQTK_HD inline void dist_symbol(uint32_t dist, uint32_t &sym, uint32_t &nextra, 
     nextra = (uint32_t)(m - 1);
     extra = d & ((1u << (m - 1)) - 1u);
 }
-FQTK_HD inline uint32_t reverse_bits(uint32_t code, int len) {
+FQTK_HD inline uint32_t reverse_bits(uint32_t code, int len) {   // len >= 1
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_bitreverse32(code) >> (32 - len);
+#else
     uint32_t r = 0;
     for (int i = 0; i < len; ++i) { r = (r << 1) | (code & 1u); code >>= 1; }
     return r;
+#endif
 }
 
 // token: literal = the byte; match = bit 31 | (len - 3) << 16 | (dist - 1)
@@ -176,7 +181,7 @@ FQTK_HD inline void huffman_lengths(Shared &S, const uint32_t *counts, int n, in
     }
     // lengths per depth, zlib's overflow rule for the limit (trees.c gen_bitlen), then the longest codes go to
     // the rarest symbols
-    uint32_t bl_count[17];
+    uint32_t *bl_count = S.bl_count;
     for (int b = 0; b <= 16; ++b) bl_count[b] = 0;
     int overflow = 0;
     for (int i = 0; i < m; ++i) {
@@ -198,8 +203,8 @@ FQTK_HD inline void huffman_lengths(Shared &S, const uint32_t *counts, int n, in
 }
 
 // canonical codes (RFC 1951 3.2.2), stored bit-reversed
-FQTK_HD inline void canonical_codes(const uint8_t *len, int n, int max_bits, uint16_t *code) {
-    uint32_t bl_count[17], next_code[17];
+FQTK_HD inline void canonical_codes(Shared &S, const uint8_t *len, int n, int max_bits, uint16_t *code) {
+    uint32_t *bl_count = S.bl_count, *next_code = S.next_code;
     for (int b = 0; b <= 16; ++b) bl_count[b] = 0;
     for (int i = 0; i < n; ++i) ++bl_count[len[i]];
     bl_count[0] = 0;
@@ -524,8 +529,8 @@ FQTK_HD inline void phase_codes_and_header(Shared &S) {
     S.freq_ll[256] = 1;   // end of block
     huffman_lengths(S, S.freq_ll, kNumLitLen, 15, S.len_ll, (int)S.m_ll);
     huffman_lengths(S, S.freq_d, kNumDist, 15, S.len_d);
-    canonical_codes(S.len_ll, kNumLitLen, 15, S.code_ll);
-    canonical_codes(S.len_d, kNumDist, 15, S.code_d);
+    canonical_codes(S, S.len_ll, kNumLitLen, 15, S.code_ll);
+    canonical_codes(S, S.len_d, kNumDist, 15, S.code_d);
     int hlit = kNumLitLen, hdist = kNumDist;
     while (hlit > 257 && S.len_ll[hlit - 1] == 0) --hlit;
     while (hdist > 1 && S.len_d[hdist - 1] == 0) --hdist;
@@ -551,7 +556,7 @@ FQTK_HD inline void phase_codes_and_header(Shared &S) {
     }
     for (int k = 0; k < nsym; ++k) ++S.freq_cl[S.cl_sym[k]];
     huffman_lengths(S, S.freq_cl, kNumCl, 7, S.len_cl);
-    canonical_codes(S.len_cl, kNumCl, 7, S.code_cl);
+    canonical_codes(S, S.len_cl, kNumCl, 7, S.code_cl);
     const uint8_t order[kNumCl] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
     int hclen = kNumCl;
     while (hclen > 4 && S.len_cl[order[hclen - 1]] == 0) --hclen;
