@@ -41,11 +41,14 @@
 namespace fqtk {
 namespace bgzf {
 
-constexpr int kLanes = 512;
+#ifndef FQTK_BGZF_LANES
+#define FQTK_BGZF_LANES 512   // (overridable for studies: tools/bgzf_ratio.py -DFQTK_BGZF_LANES=256)
+#endif
+constexpr int kLanes = FQTK_BGZF_LANES;
 constexpr uint32_t kMaxIn = 65280;        // uncompressed payload of a BGZF block (as the bgzf crate cuts them)
-constexpr uint32_t kChunk = 128;          // bytes parsed by one lane: 510 lanes x 128 = 65 280
+constexpr uint32_t kChunk = 65536 / kLanes;          // bytes parsed by one lane: 510 lanes x 128 = 65 280
 constexpr uint32_t kHashBits = 11;        // per region; 4 regions x 2048 entries x {min, max}
-constexpr uint32_t kNearSlots = 32;       // per lane: direct-mapped table of its recent positions (local repeats)
+constexpr uint32_t kNearSlots = 16384 / kLanes;       // per lane: direct-mapped table of its recent positions (local repeats)
 constexpr uint32_t kOutStride = 65536;    // bytes reserved per block in the output arena (stored worst case: n + 5)
 constexpr uint32_t kTokensPerBlock = kLanes * kChunk;   // token scratch, u32 each, [t][lane]
 constexpr int kNumLitLen = 286, kNumDist = 30, kNumCl = 19;
@@ -507,20 +510,18 @@ FQTK_HD inline void phase_lz(Shared &S, int lane, uint32_t n, uint32_t *tok) {
 // among all of them (a one-lane insertion sort of ~80 symbols was a fifth of the kernel's time).
 FQTK_HD inline void phase_clear_out(Shared &S, int lane) {
     for (uint32_t i = (uint32_t)lane; i < kOutStride / 4; i += kLanes) S.buf[i] = 0;
-    static_assert(kLanes >= kNumLitLen, "one lane per literal/length symbol");
     if (lane == 0) S.freq_ll[256] = 1;   // end of block (read through count_of below: no barrier needed)
     auto count_of = [&](int sym) -> uint32_t { return sym == 256 ? 1u : S.freq_ll[sym]; };
-    if (lane < kNumLitLen) {
-        const uint32_t c = count_of(lane);
-        if (c) {
-            uint32_t rank = 0;
-            for (int j = 0; j < kNumLitLen; ++j) {
-                const uint32_t cj = count_of(j);
-                rank += (cj != 0u && (cj < c || (cj == c && j < lane))) ? 1u : 0u;
-            }
-            S.sorted[rank] = (uint16_t)lane;
-            FQTK_BGZF_ADD(&S.m_ll, 1u);
+    for (int sym = lane; sym < kNumLitLen; sym += kLanes) {
+        const uint32_t c = count_of(sym);
+        if (!c) continue;
+        uint32_t rank = 0;
+        for (int j = 0; j < kNumLitLen; ++j) {
+            const uint32_t cj = count_of(j);
+            rank += (cj != 0u && (cj < c || (cj == c && j < sym))) ? 1u : 0u;
         }
+        S.sorted[rank] = (uint16_t)sym;
+        FQTK_BGZF_ADD(&S.m_ll, 1u);
     }
 }
 
