@@ -177,20 +177,20 @@ FQTK_HD inline void huffman_lengths(Shared &S, const uint32_t *counts, int n, in
         ++made;
     }
     const int root = made - 1;
-    S.depth[root] = 0;
-    for (int v = root - 1; v >= 0; --v) {
-        const uint32_t d = (uint32_t)S.depth[S.parent[v]] + 1u;
-        S.depth[v] = (uint8_t)(d > 255u ? 255u : d);
-    }
-    // lengths per depth, zlib's overflow rule for the limit (trees.c gen_bitlen), then the longest codes go to
-    // the rarest symbols
+    // Depths top-down with zlib's rule for the length limit (trees.c gen_bitlen): a node deeper than max_bits is put
+    // AT max_bits -- its children then see that depth -- and every such node, INTERNAL ones included, counts as one
+    // overflow; the repair loop below then moves leaves down until the code is complete again.  (Counting only the
+    // leaves beyond the limit, as this did before, leaves the code over-subscribed by one when an internal node
+    // sits at the limit: inflate rejects the block.)
     uint32_t *bl_count = S.bl_count;
     for (int b = 0; b <= 16; ++b) bl_count[b] = 0;
     int overflow = 0;
-    for (int i = 0; i < m; ++i) {
-        int bits = S.depth[i];
+    S.depth[root] = 0;
+    for (int v = root - 1; v >= 0; --v) {
+        int bits = (int)S.depth[S.parent[v]] + 1;
         if (bits > max_bits) { bits = max_bits; ++overflow; }
-        ++bl_count[bits];
+        S.depth[v] = (uint8_t)bits;
+        if (v < m) ++bl_count[bits];   // a leaf
     }
     while (overflow > 0) {
         int bits = max_bits - 1;
@@ -374,10 +374,11 @@ FQTK_HD inline bool lz_step(Shared &S, int lane, uint32_t n, uint32_t *tok, LzLa
         const uint32_t h = hash4(w);
         const uint32_t near_slot = ((h >> 5) & (kNearSlots - 1u)) * kLanes + (uint32_t)lane;
         const uint32_t own = S.tminmax[region_slot(p, h)] & 0xFFFFu;
-        // Three candidates (position + 1; 0 = none).  Two more were tried and bought nothing on FASTQ text
-        // (tools/bgzf_ratio.py): the previous match's distance and distance 1 -- the lane's own table already
-        // holds the position a run or a repeat comes from.  What each of the three is worth: without the lane's
-        // table the output grows by 0.1-1.2 %, without the region's earliest occurrence by 6-9 %, without the
+        // Three candidates (position + 1; 0 = none).  Three more were tried and dropped (tools/bgzf_ratio.py): the
+        // previous match's distance and distance 1 bought nothing -- the lane's own table already holds the position
+        // a run or a repeat comes from -- and "the same place one record back" bought 0.2-0.7 % (records are
+        // rarely equally long).  What each of the three is worth on Illumina-style records: without the lane's
+        // table the output grows by 0.1-8 %, without the region's earliest occurrence by 6-9 %, without the
         // previous region's latest by 1-2 %.
         uint32_t cand[kCands];
         cand[0] = (uint32_t)S.near_tab[near_slot] + 1u;                    // 0xFFFF + 1 = 0x10000: fails q < p below

@@ -237,6 +237,16 @@ int fqtk_host_direct_memo(uint32_t S, uint32_t L, uint64_t n_ents, const uint32_
 // lockstep != 0: the LZ phase advances all lanes one token at a time, round robin, instead of lane after lane --
 // the algorithm is built so that the interleaving cannot matter (min / max tables, lane-private parse state), and
 // the tests check that both orders give identical bytes.
+// The code builder of the BGZF compressor alone (tests: complete, length-limited codes for any counts).
+int fqtk_host_huffman_lengths(const uint32_t *counts, int n, int max_bits, uint8_t *len) {
+    using namespace fqtk::bgzf;
+    if (n < 2 || n > 288 || max_bits < 1 || max_bits > 15) return -1;
+    std::vector<uint8_t> mem(sizeof(Shared));
+    Shared &S = *reinterpret_cast<Shared *>(mem.data());
+    huffman_lengths(S, counts, n, max_bits, len);
+    return 0;
+}
+
 int64_t fqtk_host_bgzf_deflate_emulated(const uint8_t *in, uint32_t n, uint8_t *out, size_t cap, int *stored, int lockstep) {
     using namespace fqtk::bgzf;
     if (n == 0 || n > kMaxIn || cap < kOutStride) return -1;

@@ -96,3 +96,58 @@ def test_output_is_a_single_final_dynamic_block():
     d = zlib.decompressobj(-15)
     d.decompress(payload)
     assert d.eof and d.unused_data == b""
+
+
+def _huffman_lengths(counts, max_bits):
+    n = len(counts)
+    arr = (C.c_uint32 * n)(*[int(c) for c in counts])
+    out = (C.c_uint8 * n)()
+    assert hostlib.lib().fqtk_host_huffman_lengths(arr, n, max_bits, out) == 0
+    return list(out)
+
+
+def test_length_limited_codes_are_complete_for_any_counts():
+    """The code builder under its length limit (15 bits; 7 for the code-length code): Fibonacci-like counts make
+    trees far deeper than the limit, and the repaired code must still be COMPLETE (Kraft sum exactly 1) -- inflate
+    rejects an over-subscribed literal/length set.  Regression: the overflow rule once counted only leaves."""
+    from fractions import Fraction
+    rng = np.random.default_rng(3)
+    cases = []
+    fib = [1, 1]
+    while len(fib) < 40:
+        fib.append(fib[-1] + fib[-2])
+    for n, max_bits in ((286, 15), (30, 15), (19, 7)):
+        k = min(n, 40)
+        cases.append((fib[:k] + [0] * (n - k), max_bits))                       # deepest possible tree
+        cases.append(([0] * (n - k) + fib[:k][::-1], max_bits))
+        cases.append(([1] * n, max_bits))
+        cases.append(([0] * (n - 1) + [7], max_bits))                             # one symbol: still two codes
+        cases.append(([0] * n, max_bits))
+        for _ in range(300):
+            c = (rng.pareto(0.7, size=n) * 3).astype(np.int64)                    # heavy-tailed, many zeros
+            c[rng.random(n) < rng.random()] = 0
+            cases.append((np.minimum(c, 1 << 20).tolist(), max_bits))
+            g = (2.0 ** rng.integers(0, 22, size=n)).astype(np.int64)             # geometric spread: deep trees
+            g[rng.random(n) < 0.5] = 0
+            cases.append((g.tolist(), max_bits))
+    for counts, max_bits in cases:
+        lens = _huffman_lengths(counts, max_bits)
+        used = [l for l in lens if l]
+        assert len(used) >= 2 and max(used) <= max_bits, (counts, lens)
+        assert sum(Fraction(1, 1 << l) for l in used) == 1, (counts, lens)
+        for c, l in zip(counts, lens):
+            assert (l != 0) or c == 0 or sum(1 for x in counts if x) < 2
+            if c:
+                assert l != 0
+
+
+def test_block_with_a_very_deep_literal_tree_inflates():
+    """Byte counts 1, 1, 2, 3, 5, 8, ... in one block: the literal code hits the 15-bit limit."""
+    fib = [1, 1]
+    while sum(fib) < 60000:
+        fib.append(fib[-1] + fib[-2])
+    rng = np.random.default_rng(5)
+    data = np.concatenate([np.full(c, 33 + i, dtype=np.uint8) for i, c in enumerate(fib)])
+    rng.shuffle(data)
+    data = data.tobytes()[:65280]
+    roundtrip(data)

@@ -19,10 +19,14 @@ def fastq_text(n_records, rng, qual):
     acgt = np.frombuffer(b"ACGT", dtype=np.uint8)
     q = np.frombuffer(qual, dtype=np.uint8)
     recs = []
-    for i in range(n_records):
+    x = 1000
+    for i in range(n_records):   # as a sequencer writes them: tile by tile, x ascending within a tile, y anywhere
         qs = q[rng.integers(0, len(q), 150)].tobytes()
-        recs.append(b"@A00123:45:HXXXXXXXX:1:%04d:%05d:%05d 1:N:0:ACGTACGT+TTGCAATG\n%s\n+\n%s\n" % (
-            1101 + i % 40, rng.integers(1000, 30000), rng.integers(1000, 30000), acgt[rng.integers(0, 4, 150)].tobytes(), qs))
+        x += int(rng.integers(0, 12))
+        if x > 30000:
+            x = 1000
+        recs.append(b"@A00123:45:HXXXXXXXX:1:%04d:%d:%d 1:N:0:ACGTACGT+TTGCAATG\n%s\n+\n%s\n" % (
+            1101 + i // 2500, x, rng.integers(1000, 30000), acgt[rng.integers(0, 4, 150)].tobytes(), qs))
     return b"".join(recs)
 
 
