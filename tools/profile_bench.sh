@@ -32,6 +32,10 @@ sys.path.insert(0, "$R")
 import bench
 out["kernel_sources_sha1"]=bench.kernel_sources_digest()   # bench.py reports this traffic only for the kernels it was measured on
 json.dump(out, open(f"{O}/pmc_traffic.json","w"), indent=1)
+# the form bench.py reads as roofline.traffic (copy to profiles/pmc_traffic.json)
+json.dump({"cfg3": {"reads_per_launch": 400000000, "kernel_prefix": "fqtk::lds_memo_kernel",
+                    "traffic_bytes_per_launch": out["traffic_bytes_per_launch"], "kernel_sources_sha1": out["kernel_sources_sha1"],
+                    "source": "tools/profile_bench.sh"}}, open(f"{O}/pmc_traffic_for_bench.json","w"), indent=1)
 print(out)
 PY
 cat $O/stats/bench_kernel_stats.csv | head -4 | cut -c1-200
