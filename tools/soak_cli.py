@@ -43,6 +43,9 @@ def read_fq(path):
     return [(lines[i][1:], lines[i + 1], lines[i + 3]) for i in range(0, len(lines), 4)]
 
 
+EXTRA = []   # extra fqtk demux arguments of this run
+
+
 def one(rng, it, tmp):
     n_inputs = rng.randint(1, 4)
     kinds_pool = ["T", "B", "M", "C", "S"]
@@ -114,6 +117,7 @@ def one(rng, it, tmp):
            "-d", str(delta), "-t", str(rng.randint(5, 16)), "--chunk-reads", str(rng.choice([1, 7, 100, 1000, 5000, 262144]))]
     if skip_ok:
         cmd += ["-S", "too-few-bases"]
+    cmd += EXTRA
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=300)
     # expected
     minlen = [sum((l if l is not None else 1) for (_, l, _) in p) for p in parsed]
@@ -169,7 +173,9 @@ if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--iters", type=int, default=40)
     ap.add_argument("--seed", type=int, default=1)
+    ap.add_argument("--gpu-bgzf", action="store_true", help="every run with --gpu-bgzf (output blocks compressed on the GPU)")
     a = ap.parse_args()
+    EXTRA[:] = ["--gpu-bgzf"] if a.gpu_bgzf else []
     rng = random.Random(a.seed)
     tmp = tempfile.mkdtemp(prefix="fqtk_soak_", dir="/tmp")
     tally = {}
