@@ -97,3 +97,46 @@ def test_many_blocks_more_than_workgroups_resident():
     finally:
         a.free()
         lib.fqtk_bgzf_destroy(z)
+
+
+def test_skewed_alphabets_and_deep_code_trees_on_the_gpu():
+    """Blocks built to stress the code builder and the parser: Fibonacci byte counts (code trees far deeper than
+    the 15-bit limit; a once over-subscribed code was found this way), geometric counts, a few symbols only, long
+    runs with rare interruptions, periodic text at every period up to 40 -- each must inflate and equal the CPU run."""
+    lib = _lib.load()
+    z = C.c_void_p()
+    assert lib.fqtk_bgzf_create(0, C.byref(z)) == 0, lib.fqtk_bgzf_last_error()
+    rng = np.random.default_rng(17)
+    blocks = []
+    fib = [1, 1]
+    while sum(fib) < 64000:
+        fib.append(fib[-1] + fib[-2])
+    for base in (33, 65, 128):
+        d = np.concatenate([np.full(c, (base + i) % 256, dtype=np.uint8) for i, c in enumerate(fib)])
+        rng.shuffle(d)
+        blocks.append(d.tobytes()[:MAX_IN])
+        blocks.append(np.sort(d).tobytes()[:MAX_IN])                                          # the same counts as long runs
+    for k in (2, 3, 5, 17, 40, 120, 256):
+        p = 0.5 ** np.arange(k)
+        blocks.append(rng.choice(k, size=MAX_IN, p=p / p.sum()).astype(np.uint8).tobytes())   # geometric counts
+        blocks.append(rng.integers(0, k, size=int(rng.integers(1, MAX_IN)), dtype=np.uint8).tobytes())
+    for period in range(1, 41):
+        unit = bytes(rng.integers(65, 91, period, dtype=np.uint8))
+        n = int(rng.integers(period, MAX_IN))
+        blocks.append((unit * (n // period + 1))[:n])
+    run = np.full(MAX_IN, ord("F"), dtype=np.uint8)
+    run[rng.integers(0, MAX_IN, 300)] = rng.integers(33, 75, 300, dtype=np.uint8)
+    blocks.append(run.tobytes())
+    a = Arena(lib, len(blocks))
+    try:
+        a.load(blocks)
+        assert lib.fqtk_bgzf_deflate_enqueue(z, 0, a.pdesc, len(blocks), a.plen) == 0, lib.fqtk_bgzf_last_error()
+        assert lib.fqtk_bgzf_wait(z, 0) == 0
+        for i, b in enumerate(blocks):
+            p = a.payload(i)
+            d = zlib.decompressobj(-15)
+            assert d.decompress(p) == b and d.eof and d.unused_data == b"", (i, len(b))
+            assert p == cpu_deflate(b)[0], (i, len(b))
+    finally:
+        a.free()
+        lib.fqtk_bgzf_destroy(z)
