@@ -1,21 +1,21 @@
-// bgzf_deflate.hpp -- DEFLATE block compressor for BGZF output, written for one 256-lane workgroup per block.
+// bgzf_deflate.hpp -- DEFLATE block compressor for BGZF output, written for one 512-lane workgroup per block.
 //
 // SURVEY.md section 8(f) row 3 (output side).  End to end `fqtk demux` is bound by BGZF compression on the
 // host (the reference: pooled-writer -> bgzf -> libdeflater, /root/reference/src/bin/commands/demux.rs:755-798)
 // while the GPU matcher idles.  This is the MI355X form of that stage: every <= 65 280-byte block becomes one
-// dynamic-Huffman DEFLATE block (RFC 1951), produced by 256 lanes:
+// dynamic-Huffman DEFLATE block (RFC 1951), produced by 512 lanes:
 //   P0  the block is copied into LDS, the LZ hash table and the histograms are cleared
-//   P1a every lane counts the bytes of its 256-byte slice (-> estimated literal costs) and enters all its
+//   P1a every lane counts the bytes of its 128-byte slice (-> estimated literal costs) and enters all its
 //       positions into a shared table keyed by (16 KiB region of the block, hash of 4 bytes) holding the SMALLEST
 //       and the LARGEST position seen -- min / max, so the table does not depend on how the lanes interleave and
 //       the output is deterministic
-//   P1b LZ77: every lane parses its slice greedily; candidates for a position are the largest entry of the
-//       region before it (always behind it and inside the 32 KiB window), the smallest entry of its own region,
-//       the distance of its previous match, and distance 1; each is verified byte by byte and must pay for
-//       itself (estimated literal bits saved > bits of the match); tokens go to a global scratch, symbol
-//       counts to LDS
-//   P2  one lane builds the two Huffman codes (two-queue construction on the sorted counts, zlib's overflow
-//       rule for the 15-bit limit), the code-length code, and writes the block header
+//   P1b LZ77: every lane parses its slice greedily; candidates for a position are its own small table of recent
+//       positions, the smallest entry of its own region and the largest entry of the region before it (always
+//       behind it and inside the 32 KiB window); each is verified 16 bytes per round and must pay for itself
+//       (estimated literal bits saved > bits of the match); tokens go to a global scratch, symbol counts to LDS
+//   P2  all lanes rank the used literal/length symbols; one lane builds the two Huffman codes (two-queue
+//       construction on the sorted counts, zlib's overflow rule for the 15-bit limit), the code-length code, and
+//       writes the block header
 //   P3  every lane adds up the bits of its tokens; exclusive prefix sum -> its bit offset; if the result would
 //       not be smaller than the input, the block is emitted STORED instead
 //   P4  every lane ORs its tokens' bits into the output image (LDS), the end-of-block code follows
@@ -23,7 +23,7 @@
 // The compressed bytes are unpinned by the reference's tests (they compare decompressed content only,
 // demux.rs:1069-1076); parity here = any inflate implementation returns the input bytes.
 //
-// Plain C++17, no HIP: compiles under hipcc for the device (bgzf_kernel.hip.h runs the phases with barriers
+// Plain C++17 with a few device-only fast paths: compiles under hipcc for the device (fqtk_bgzf.hip runs the phases with barriers
 // in between) and under g++ for the CPU test-suite, which runs the SAME phase functions lane by lane through
 // libfqtk_host.so and inflates the result with zlib.
 #pragma once

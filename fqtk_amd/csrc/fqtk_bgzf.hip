@@ -1,6 +1,6 @@
 // fqtk_bgzf.hip -- device side and C ABI (include/fqtk_bgzf.h) of the BGZF block compressor.
 // The algorithm lives in bgzf_deflate.hpp (phase functions shared with the CPU test-suite); this file runs
-// the phases of one block on one 256-lane workgroup with barriers in between.
+// the phases of one block on one 512-lane workgroup with barriers in between.
 #include <hip/hip_runtime.h>
 
 #include <new>

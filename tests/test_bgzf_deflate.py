@@ -14,7 +14,7 @@ MAX_IN = 65280
 
 
 def deflate(data: bytes, lockstep: int = 1):
-    """lockstep=1: the 256 lanes advance token by token, round robin (the GPU's interleaving, approximately);
+    """lockstep=1: the lanes advance token by token, round robin (the GPU's interleaving, approximately);
     lockstep=0: lane after lane."""
     lib = hostlib.lib()
     fn = lib.fqtk_host_bgzf_deflate_emulated

@@ -1,7 +1,7 @@
 """The BGZF block compressor on the GPU (include/fqtk_bgzf.h), through the C ABI with page-locked host buffers the
 kernel reads and writes directly: every payload must inflate (zlib) to its input AND be byte-identical to what the
 same phase functions produce lane by lane on the CPU (tests/test_bgzf_deflate.py) -- the algorithm is built to be
-independent of how the 256 lanes interleave (min / max tables, lane-private parse state)."""
+independent of how the lanes interleave (min / max tables, lane-private parse state)."""
 import ctypes as C
 import zlib
 
