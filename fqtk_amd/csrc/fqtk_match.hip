@@ -406,7 +406,20 @@ int launch_lds_memo(const fqtk_matcher *m, fqtk::LdsMemoParams Q, hipStream_t st
         }
     }
     size_t shmem = m->ldsm_lds_bytes;
-    if (P.counts && P.lds_hist) shmem += (size_t)(P.S + 1) * sizeof(uint32_t);
+    Q.hist_shift = 0;
+    if (P.counts && P.lds_hist) {
+        // copies of the histogram: as many as fit 4 KiB (8 at most) without costing a workgroup per CU
+        const size_t one = (size_t)(P.S + 1) * sizeof(uint32_t);
+        const bool two_now = 2 * (shmem + one + 1024) <= fqtk::kLdsMemoMaxBytes;
+        while (Q.hist_shift < 3 && (one << (Q.hist_shift + 1)) <= 4096 &&
+               shmem + (one << (Q.hist_shift + 1)) <= fqtk::kLdsMemoMaxBytes &&
+               (!two_now || 2 * (shmem + (one << (Q.hist_shift + 1)) + 1024) <= fqtk::kLdsMemoMaxBytes))
+            ++Q.hist_shift;
+#ifdef FQTK_DEV_ABLATE
+        if (const char *hs = std::getenv("FQTK_LDSM_HIST_SHIFT")) Q.hist_shift = (uint32_t)std::atoi(hs);
+#endif
+        shmem += one << Q.hist_shift;
+    }
     if (shmem > fqtk::kLdsMemoMaxBytes) return fail(FQTK_EINVAL, "lds memo: table does not fit LDS");
     {   // the expected-barcode planes next to it, for the wave scan of non-canonical reads -- when there is room
         // and it does not cost a workgroup per CU

@@ -52,6 +52,9 @@ struct LdsMemoParams {
     uint32_t image_words;     // dwords to stage into LDS
     uint32_t skey_off_b;      // byte offset of the sample keys inside LDS
     uint32_t salt;            // hash salt the builder settled on
+    uint32_t hist_shift;      // the LDS histogram holds 1 << hist_shift copies of every bin (lane & mask picks one):
+                              // with few samples the lanes of a wave pile up on a few counters, and same-address
+                              // LDS atomics of one instruction run one after the other
 };
 
 // Raw LDS accesses by BYTE ADDRESS.  The kernel has no static LDS, so its dynamic LDS starts at address
@@ -111,10 +114,11 @@ void lds_memo_kernel(const LdsMemoParams Q) {
     uint32_t *lds_hist = lds_lut + 256;
     if (tid < 256) lds_lut[tid] = P.lut[tid];
     const uint32_t bins = P.S + 1;
+    const uint32_t hist_words = bins << Q.hist_shift;
     // [S][1][4] planes for the wave scan of non-canonical reads, 16-byte aligned behind the histogram
-    uint32_t *lds_tab = P.scan_tab_lds ? smem + ((Q.image_words + 256u + ((P.counts && P.lds_hist) ? bins : 0u) + 3u) & ~3u) : nullptr;
+    uint32_t *lds_tab = P.scan_tab_lds ? smem + ((Q.image_words + 256u + ((P.counts && P.lds_hist) ? hist_words : 0u) + 3u) & ~3u) : nullptr;
     if (P.counts && P.lds_hist)
-        for (uint32_t b = tid; b < bins; b += kLdsBlock) lds_hist[b] = 0;
+        for (uint32_t b = tid; b < hist_words; b += kLdsBlock) lds_hist[b] = 0;
     if (lds_tab)
         for (uint32_t w = tid; w < P.S * 4u; w += kLdsBlock) lds_tab[w] = P.table[w];
     __syncthreads();
@@ -151,7 +155,10 @@ void lds_memo_kernel(const LdsMemoParams Q) {
         out_off[r] = local[r] * 4u;
     }
     const uint32_t hist_on = (P.counts && P.lds_hist) ? 1u : 0u;
-    const uint32_t hist_base_b = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint32_t *)lds_hist;
+    // this lane's copy of bin b: byte address hist_base_b + (b << (hist_shift + 2))
+    const uint32_t hist_base_b = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint32_t *)lds_hist +
+                                 ((tid & ((1u << Q.hist_shift) - 1u)) << 2);
+    const uint32_t hist_bin_shift = Q.hist_shift + 2u;
 
     // The packed vector loads of one full tile (every read exists, the rows are VEC dwords).
     auto load_full = [&](uint64_t t, uint32_t (&words)[R][8]) {
@@ -293,7 +300,7 @@ void lds_memo_kernel(const LdsMemoParams Q) {
             for (int r = 0; r < R; ++r) {
                 if (!live[r] || res[r] == kMemoDeferred) continue;
                 const uint32_t bin = min(res[r] & 0xFFFFu, P.S);   // None (0xFFFF) -> bin S
-                if (hist_on) lds_atomic_inc(hist_base_b + bin * 4u);
+                if (hist_on) lds_atomic_inc(hist_base_b + (bin << hist_bin_shift));
                 else atomicAdd(&P.counts[bin], 1ull);
             }
         }
@@ -426,7 +433,8 @@ void lds_memo_kernel(const LdsMemoParams Q) {
     if (P.counts && P.lds_hist) {
         __syncthreads();
         for (uint32_t b = tid; b < bins; b += kLdsBlock) {
-            const uint32_t c = lds_hist[b];
+            uint32_t c = 0;
+            for (uint32_t k = 0; k < (1u << Q.hist_shift); ++k) c += lds_hist[(b << Q.hist_shift) + k];
             if (c) atomicAdd(&P.counts[b], (unsigned long long)c);
         }
     }
