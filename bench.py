@@ -293,7 +293,8 @@ def main() -> int:
 
     for _ in range(args.warmup):
         step()
-    torch.cuda.synchronize()
+        torch.cuda.synchronize()   # (untimed) a matcher adapts between batches -- the worklist for reads with IUPAC /
+                                   # junk bytes is attached once one has been seen -- so warm-up steps run one at a time
     d_counts.zero_()
 
     # ---- timed region: EXACTLY K steps, barrier + synchronize on both sides ------------------------
