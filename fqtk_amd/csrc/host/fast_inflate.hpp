@@ -415,8 +415,23 @@ class FastInflate {
     }
 
     // ---- the loop ---------------------------------------------------------------------------------------------
-    // Decodes symbols of the current block until `stop` is reached or the block ends.
+    // Decodes symbols of the current block until `stop` is reached or the block ends.  Two copies of the loop: the
+    // one for CPUs with BMI2 lets the compiler use shrx / shlx / bzhi for the variable shifts and masks (x86's
+    // shift-by-CL costs three micro-ops); picked once per process.
     bool decode(uint8_t *base, uint8_t *&op_ref, uint8_t *stop, std::string *err) {
+#if defined(__x86_64__) && defined(__GNUC__)
+        static const bool bmi2 = __builtin_cpu_supports("bmi2") && !env_flag_off_bmi2();
+        if (bmi2) return decode_bmi2(base, op_ref, stop, err);
+#endif
+        return decode_loop(base, op_ref, stop, err);
+    }
+    static bool env_flag_off_bmi2() { const char *v = std::getenv("FQTK_NO_BMI2"); return v && *v && !(v[0] == '0' && v[1] == 0); }
+#if defined(__x86_64__) && defined(__GNUC__)
+    __attribute__((target("bmi2"))) bool decode_bmi2(uint8_t *base, uint8_t *&op_ref, uint8_t *stop, std::string *err) {
+        return decode_loop(base, op_ref, stop, err);
+    }
+#endif
+    __attribute__((always_inline)) inline bool decode_loop(uint8_t *base, uint8_t *&op_ref, uint8_t *stop, std::string *err) {
         uint8_t *op = op_ref;
         uint64_t bb = bb_;
         unsigned bc = bc_;
