@@ -464,10 +464,26 @@ int main(int argc, char **argv) {
     for (const std::string &in : opt.inputs)
         if (access(in.c_str(), F_OK) != 0) problems.push_back("Provided input file \"" + in + "\" doesn't exist");
     std::vector<std::unique_ptr<FastqSource>> sources;
-    for (const std::string &in : opt.inputs) {
+    // Single-stream gzip inputs are decoded by several threads each (parallel_gunzip.hpp): three quarters of the usable
+    // CPUs, shared out by file size (the index reads of a run are a fifth of its bytes), at most 8 per file.
+    std::vector<unsigned> gz_threads(opt.inputs.size(), 1);
+    {
+        std::vector<uint64_t> sz(opt.inputs.size(), 0);
+        uint64_t total = 0;
+        for (size_t i = 0; i < opt.inputs.size(); ++i) {
+            struct stat st;
+            if (stat(opt.inputs[i].c_str(), &st) == 0 && S_ISREG(st.st_mode)) sz[i] = (uint64_t)st.st_size;
+            total += sz[i];
+        }
+        const unsigned pool = std::max(2u, usable_cpus() * 3 / 4);
+        for (size_t i = 0; i < opt.inputs.size(); ++i)
+            if (total) gz_threads[i] = (unsigned)std::min<uint64_t>(8, std::max<uint64_t>(1, (pool * sz[i] + total / 2) / total));
+    }
+    for (size_t i_in = 0; i_in < opt.inputs.size(); ++i_in) {
+        const std::string &in = opt.inputs[i_in];
         auto src = std::make_unique<FastqSource>();
         std::string err;
-        if (access(in.c_str(), F_OK) == 0 && !src->open(in, &err)) problems.push_back("Error opening input files for reading: " + err);
+        if (access(in.c_str(), F_OK) == 0 && !src->open(in, &err, 2, gz_threads[i_in])) problems.push_back("Error opening input files for reading: " + err);
         sources.push_back(std::move(src));
     }
     if (opt.threads < 5) problems.push_back("Threads provided " + std::to_string(opt.threads) + " was too low! Must be 5 or more.");

@@ -35,6 +35,8 @@ class FastInflate {
 
     // `data` must stay valid (a mapping) until the last next().
     void open(const uint8_t *data, size_t n, CrcFn crc) {
+        data_ = data;
+        data_end_ = data + n;
         in_end_ = data + n;
         ip_ = data;
         crc_fn_ = crc;
@@ -61,7 +63,9 @@ class FastInflate {
             uint8_t *op = piece;
             uint8_t *const stop = piece + kPiece;   // a symbol that starts before it may run kSlack bytes past
             bool member_done = false;
-            while (op < stop && state_ != State::Done && !member_done) {
+            bool block_done = false;
+            while (op < stop && state_ != State::Done && !member_done && !block_done) {
+                const State before = state_;
                 switch (state_) {
                     case State::Header:
                         if (!parse_header(err)) return false;
@@ -89,6 +93,8 @@ class FastInflate {
                     case State::Done:
                         break;
                 }
+                if (stop_at_block_end_ && (before == State::Codes || before == State::Stored) && state_ == State::BlockStart)
+                    block_done = true;
             }
             const size_t got = (size_t)(op - piece);
             if (got) {
@@ -98,8 +104,10 @@ class FastInflate {
             hist_ += got;
             if (member_done) {
                 if (!check_trailer(err)) return false;
-                if (got == 0) continue;   // nothing in hand: on to the next member, or the end
+                if (got == 0 && !stop_at_block_end_) continue;   // nothing in hand: on to the next member, or the end
             }
+            if (got == 0 && block_done) { *out = piece; *n = 0; at_boundary_ = true; return true; }
+            at_boundary_ = block_done || member_done;
             *out = piece;
             *n = got;
             return true;
@@ -108,7 +116,7 @@ class FastInflate {
 
     static constexpr size_t kPiece = 4u << 20;
 
-  private:
+  protected:   // (parallel_gunzip.hpp builds its speculative decoder on these)
     static constexpr size_t kWindow = 32768, kSlack = 258 + 64;
     static constexpr int kLitBits = 11, kDistBits = 8;
     // table entry: bits 0-7 code bits to consume | bits 8-12 extra-bit count (or second-level index bits)
@@ -130,6 +138,7 @@ class FastInflate {
         const size_t left = (size_t)(in_end_ - ip_);
         std::memset(tail_, 0, sizeof tail_);
         std::memcpy(tail_, ip_, left);
+        tail_origin_ = ip_;
         ip_ = tail_;
         in_end_ = tail_ + left;
         tail_active_ = true;
@@ -166,6 +175,24 @@ class FastInflate {
         guard_tail();
         if (tail_active_ && ip_ > in_end_ + 8) return fail(err, "stream runs past the end of the file");
         refill();
+        return true;
+    }
+
+    // Position of the next unconsumed bit, in bits from the start of the mapping.
+    uint64_t bit_pos() const {
+        const uint8_t *real = tail_active_ ? tail_origin_ + (ip_ - tail_) : ip_;
+        return (uint64_t)(real - data_) * 8u - bc_;
+    }
+    // Continue at bit `pos` of the mapping (a block boundary).
+    bool seek_bit(uint64_t pos, std::string *err) {
+        ip_ = data_ + (pos >> 3);
+        in_end_ = data_end_;
+        tail_active_ = false;
+        bb_ = 0;
+        bc_ = 0;
+        if (ip_ > data_end_) return fail(err, "position past the end of the file");
+        if (!safe_refill(err)) return false;
+        take((unsigned)(pos & 7u));
         return true;
     }
 
@@ -536,6 +563,10 @@ class FastInflate {
     static constexpr uint32_t kLitCap = (1u << kLitBits) + 2048, kDistCap = (1u << kDistBits) + 1024;
 
     const uint8_t *in_end_ = nullptr, *ip_ = nullptr;
+    const uint8_t *data_ = nullptr, *data_end_ = nullptr;   // the whole mapping
+    const uint8_t *tail_origin_ = nullptr;                   // where tail_[0] sits in the mapping
+    bool at_boundary_ = false;                               // the last next() ended exactly at a block / member end
+    bool stop_at_block_end_ = false;                         // next() hands back control after every block
     CrcFn crc_fn_ = nullptr;
     std::vector<uint8_t> obuf_;
     size_t hist_ = 0;          // bytes of obuf_ that hold output already handed out (<= window after the slide)

@@ -38,6 +38,7 @@
 #include "env.hpp"
 
 #include "fast_inflate.hpp"
+#include "parallel_gunzip.hpp"
 
 namespace fqtk_host {
 
@@ -130,7 +131,8 @@ class FastqSource {
         // a mapping stays for the life of the process: record batches point into it
     }
     // inflate_helpers: extra threads that inflate BGZF blocks next to the producer (ignored for other kinds)
-    bool open(const std::string &path, std::string *err, unsigned inflate_helpers = 2) {
+    // gz_threads: decoders for a single-stream gzip input (0 = decide here; 1 = the sequential decoder)
+    bool open(const std::string &path, std::string *err, unsigned inflate_helpers = 2, unsigned gz_threads = 0) {
         path_ = path;
         fd_ = ::open(path.c_str(), O_RDONLY);
         if (fd_ < 0) { *err = "Error opening input files for reading: " + path; return false; }
@@ -152,12 +154,23 @@ class FastqSource {
                     gz_map_ = static_cast<const uint8_t *>(m);
                     gz_map_size_ = (size_t)st.st_size;
                     madvise(m, gz_map_size_, MADV_SEQUENTIAL);
-                    fast_.reset(new FastInflate());
-                    fast_->open(gz_map_, gz_map_size_, &FastqSource::crc32_fn);
+                    // Large files: several decoders side by side (parallel_gunzip.hpp); the caller shares the CPUs out
+                    // among its inputs (demux.cpp), FQTK_GZ_THREADS overrides (1: the sequential decoder).
+                    unsigned t = gz_threads ? gz_threads : std::min(8u, std::max(2u, usable_cpus() * 3 / 8));
+                    if (const char *g = std::getenv("FQTK_GZ_THREADS")) if (*g) t = (unsigned)std::atoi(g);
+                    size_t chunk = ParallelGunzip::kChunk;   // (FQTK_GZ_CHUNK: tests cross many chunk boundaries in small files)
+                    if (const char *g = std::getenv("FQTK_GZ_CHUNK")) if (*g) chunk = (size_t)std::atol(g);
+                    if (t >= 2 && gz_map_size_ >= 32 * chunk) {   // 64 MiB by default: below that the sequential decoder is done in 0.2 s
+                        pgz_.reset(new ParallelGunzip());
+                        pgz_->open(gz_map_, gz_map_size_, &FastqSource::crc32_fn, t, chunk);
+                    } else {
+                        fast_.reset(new FastInflate());
+                        fast_->open(gz_map_, gz_map_size_, &FastqSource::crc32_fn);
+                    }
                 }
             }
         }
-        if (kind_ == Kind::Gzip && !fast_) {   // pipes and the like: zlib's gzread
+        if (kind_ == Kind::Gzip && !fast_ && !pgz_) {   // pipes and the like: zlib's gzread
             gz_ = gzdopen(fd_, "rb");
             if (!gz_) { *err = "Error opening input files for reading: " + path; return false; }
             fd_ = -1;               // owned by gz_ now
@@ -389,11 +402,11 @@ class FastqSource {
         return true;
     }
     bool produce_gzip(Piece &pc) {
-        if (fast_) {
+        if (fast_ || pgz_) {
             const uint8_t *p = nullptr;
             size_t n = 0;
             std::string e;
-            if (!fast_->next(&p, &n, &e)) {
+            if (!(pgz_ ? pgz_->next(&p, &n, &e) : fast_->next(&p, &n, &e))) {
                 pc.error = "Unexpected error parsing FASTQs: " + e + " in " + path_;
                 return false;
             }
@@ -511,6 +524,7 @@ class FastqSource {
     const uint8_t *gz_map_ = nullptr;       // single-stream gzip, regular file: decoded by fast_
     size_t gz_map_size_ = 0;
     std::unique_ptr<FastInflate> fast_;
+    std::unique_ptr<ParallelGunzip> pgz_;
     // CRC-32 for the gzip trailers: libdeflate's (PCLMUL) when the library is there, zlib's otherwise
     static uint32_t crc32_fn(uint32_t seed, const void *p, size_t n) {
         using Fn = uint32_t (*)(uint32_t, const void *, size_t);

@@ -8,6 +8,7 @@
 
 #include "bgzf.hpp"
 #include "fastq_io.hpp"
+#include "parallel_gunzip.hpp"
 #include "header.hpp"
 #include "metrics.hpp"
 #include "read_structure.hpp"
@@ -136,6 +137,28 @@ int64_t fqtk_host_gunzip(const uint8_t *in, size_t n, uint8_t *out, size_t cap, 
         if ((size_t)total < cap) std::memcpy(out + total, p, std::min(k, cap - (size_t)total));
         total += (int64_t)k;
     }
+    return total;
+}
+
+// The same through parallel_gunzip.hpp (`threads` speculative decoders); stats[0] = stretches decoded in parallel,
+// stats[1] = stretches that fell back (partly) to the sequential decoder.
+int64_t fqtk_host_gunzip_parallel(const uint8_t *in, size_t n, uint8_t *out, size_t cap, unsigned threads, size_t chunk, uint64_t *stats,
+                                  char *err, size_t errcap) {
+    std::unique_ptr<ParallelGunzip> z(new ParallelGunzip());
+    z->open(in, n, [](uint32_t seed, const void *p, size_t k) -> uint32_t {
+        return (uint32_t)::crc32(seed, static_cast<const Bytef *>(p), (uInt)k);
+    }, threads, chunk ? chunk : ParallelGunzip::kChunk);
+    int64_t total = 0;
+    std::string e;
+    for (;;) {
+        const uint8_t *p = nullptr;
+        size_t k = 0;
+        if (!z->next(&p, &k, &e)) { put(e, err, errcap); return -1; }
+        if (k == 0) break;
+        if ((size_t)total < cap) std::memcpy(out + total, p, std::min(k, cap - (size_t)total));
+        total += (int64_t)k;
+    }
+    if (stats) { stats[0] = z->rounds(); stats[1] = z->fallbacks(); }
     return total;
 }
 

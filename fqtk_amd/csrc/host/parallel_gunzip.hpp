@@ -1,0 +1,383 @@
+// parallel_gunzip.hpp -- one gzip stream decoded by several threads.
+//
+// SURVEY 8(f) row 3 asks for a reader POOL; a BGZF file gives one for free (independent blocks, fastq_io.hpp), a plain
+// `.fastq.gz` does not: it is one serial bit stream whose every match may reach 32 KiB back.  The way around it
+// (the idea behind pugz / rapidgzip, rebuilt here on fast_inflate.hpp's tables):
+//   * cut the next stretch of the compressed file into chunks; for every chunk but the first, SEARCH for a place where
+//     a DEFLATE block starts (a bit offset whose dynamic-Huffman header parses into two complete codes -- a one-in-
+//     many-millions accident otherwise);
+//   * decode all chunks at once, each from its start to the next chunk's start.  A chunk does not know the 32 KiB
+//     before it, so it decodes into 16-bit symbols: a byte, or "the byte at position j of the unknown window";
+//     copies of such symbols copy the reference;
+//   * afterwards the windows are handed down the line (the last 32 KiB of chunk k, resolved, are chunk k+1's) and
+//     every chunk is resolved to bytes, again in parallel.
+// Nothing here is trusted on probability: a chunk's output is used only if the chunk BEFORE it -- itself accepted,
+// starting from the sequential decoder's exact position -- ended on exactly the bit this chunk started at, at a
+// block boundary.  Then that bit IS a block start of the one true parse, and the chunk decoded what a sequential
+// decoder would have.  Anything else (no start found, a false start, an error) discards the rest of the stretch and
+// the sequential decoder carries on from the last accepted bit.  CRC32 and ISIZE of every member are still checked.
+#pragma once
+#include <algorithm>
+#include <chrono>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "fast_inflate.hpp"
+
+namespace fqtk_host {
+
+// One speculative chunk: DEFLATE blocks from a bit position, unknown window, into 16-bit symbols.
+class SpecInflate : public FastInflate {
+  public:
+    struct Task {
+        uint64_t start_bit = 0, stop_bit = 0;   // decode until the first block boundary at or after stop_bit
+        std::vector<uint16_t> sym;              // < 256: the byte; else 256 + index into the 32 KiB before the chunk
+        size_t n_sym = 0;
+        uint64_t end_bit = 0;
+        bool final_block = false, error = false;
+        double seconds = 0;                     // (how long run() took)
+    };
+
+    void attach(const uint8_t *data, size_t n) { open(data, n, nullptr); }
+
+    // First bit position in [from, limit) where a non-final dynamic-Huffman block header parses; ~0 if none.
+    uint64_t find_block_start(uint64_t from, uint64_t limit) {
+        const uint64_t last = (uint64_t)(data_end_ - data_) * 8u;
+        if (limit + 1024 > last) limit = last > 1024 ? last - 1024 : 0;   // a header needs room; the file's end is sequential anyway
+        std::string scratch;
+        for (uint64_t t = from; t < limit; ++t) {
+            const uint64_t b = peek(t);
+            // BFINAL = 0, BTYPE = 2 (binary 10, LSB first: bits 1-2 = 0, 1), HLIT <= 29, HDIST <= 29
+            if ((b & 7u) != 4u) continue;
+            if (((b >> 3) & 31u) > 29u || ((b >> 8) & 31u) > 29u) continue;
+            const unsigned hclen = (unsigned)((b >> 13) & 15u) + 4u;
+            // the code-length code must be complete: sum of 2^(7 - len) over its used symbols == 2^7
+            unsigned kraft = 0;
+            const uint64_t c0 = b >> 17, c1 = peek(t + 17 + 39);   // 3-bit fields 0..12 (b holds 57 bits) and 13..18
+            for (unsigned k = 0; k < hclen; ++k) {
+                const unsigned l = (unsigned)(((k < 13 ? c0 >> (3 * k) : c1 >> (3 * (k - 13)))) & 7u);
+                if (l) kraft += 128u >> l;
+            }
+            if (kraft != 128u) continue;
+            // the full header: both length sets decode and give complete codes
+            if (!seek_bit(t, &scratch)) continue;
+            state_ = State::BlockStart;
+            if (start_block(&scratch) && state_ == State::Codes && !final_block_) return t;
+        }
+        return ~0ull;
+    }
+
+    void run(Task &tk) {
+        const auto t0 = std::chrono::steady_clock::now();
+        struct Stamp { Task &t; std::chrono::steady_clock::time_point t0; ~Stamp() { t.seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(); } } stamp{tk, t0};
+        std::string err;
+        tk.n_sym = 0;
+        tk.error = tk.final_block = false;
+        if (tk.sym.size() < (1u << 20)) tk.sym.resize(1u << 20);
+        if (!seek_bit(tk.start_bit, &err)) { tk.error = true; return; }
+        for (;;) {
+            state_ = State::BlockStart;
+            if (!start_block(&err)) { tk.error = true; return; }
+            if (state_ == State::Stored) {
+                if (in_end_ - ip_ < (ptrdiff_t)stored_left_) { tk.error = true; return; }
+                reserve(tk, stored_left_);
+                for (size_t i = 0; i < stored_left_; ++i) tk.sym[tk.n_sym + i] = ip_[i];
+                tk.n_sym += stored_left_;
+                ip_ += stored_left_;
+                stored_left_ = 0;
+            } else if (state_ == State::Codes) {
+                if (!decode_symbols(tk)) { tk.error = true; return; }
+            }
+            if (final_block_) {
+                tk.final_block = true;
+                tk.end_bit = bit_pos();
+                return;
+            }
+            const uint64_t at = bit_pos();
+            if (at >= tk.stop_bit) { tk.end_bit = at; return; }
+        }
+    }
+
+    // 16-bit symbols -> bytes, given the 32 KiB that preceded the chunk (window[32767] = the byte right before it).
+    static void resolve(const uint16_t *sym, size_t n, const uint8_t *window, uint8_t *out) {
+        uint8_t tab[256 + 32768];   // one look-up per symbol, no branch
+        for (int b = 0; b < 256; ++b) tab[b] = (uint8_t)b;
+        std::memcpy(tab + 256, window, 32768);
+        size_t i = 0;
+        for (; i + 4 <= n; i += 4) {
+            out[i] = tab[sym[i]];
+            out[i + 1] = tab[sym[i + 1]];
+            out[i + 2] = tab[sym[i + 2]];
+            out[i + 3] = tab[sym[i + 3]];
+        }
+        for (; i < n; ++i) out[i] = tab[sym[i]];
+    }
+
+  private:
+    uint64_t peek(uint64_t bit) const {   // 57+ bits starting at `bit` (callers stay 1 KiB clear of the file's end)
+        return load64(data_ + (bit >> 3)) >> (bit & 7u);
+    }
+    static void reserve(Task &tk, size_t more) {
+        if (tk.n_sym + more + 600 > tk.sym.size()) tk.sym.resize(std::max(tk.sym.size() * 2, tk.n_sym + more + 600));
+    }
+
+    // One block's symbols (fast_inflate.hpp's loop, 16-bit output, references into the unknown window).
+    bool decode_symbols(Task &tk) {
+        uint64_t bb = bb_;
+        unsigned bc = bc_;
+        const uint8_t *ip = ip_;
+        const uint32_t *const lit = lit_, *const dist = dist_;
+        bool ok = true, eob = false;
+        const uint8_t *in_limit = tail_active_ ? in_end_ + 8 : in_end_ - kTailAt;
+        size_t o = tk.n_sym;
+        uint16_t *out = tk.sym.data();
+        size_t cap = tk.sym.size();
+#define FQTK_REFILL() do { bb |= load64(ip) << bc; ip += (63 - bc) >> 3; bc |= 56; } while (0)
+#define FQTK_DROP(n) do { bb >>= (n); bc -= (n); } while (0)
+#define FQTK_PUT16(e) do { out[o] = (uint16_t)(((e) >> 16) & 0xFFu); out[o + 1] = (uint16_t)((e) >> 24); o += ((e) >> 8) & 3u; FQTK_DROP((e) & 0xFF); } while (0)
+        while (!eob) {
+            if (o + 600 > cap) {
+                tk.n_sym = o;
+                reserve(tk, 1u << 20);
+                out = tk.sym.data();
+                cap = tk.sym.size();
+            }
+            if (ip > in_limit) {
+                if (tail_active_) { ok = false; break; }
+                ip_ = ip;
+                guard_tail();
+                ip = ip_;
+                in_limit = in_end_ + 8;
+            }
+            FQTK_REFILL();
+            uint32_t e = lit[bb & ((1u << kLitBits) - 1)];
+            if (e & kLit) {   // up to three look-ups of one or two literals on one refill, as in fast_inflate.hpp
+                FQTK_PUT16(e);
+                e = lit[bb & ((1u << kLitBits) - 1)];
+                if (e & kLit) {
+                    FQTK_PUT16(e);
+                    e = lit[bb & ((1u << kLitBits) - 1)];
+                    if (e & kLit) {
+                        FQTK_PUT16(e);
+                        continue;
+                    }
+                }
+                FQTK_REFILL();
+            }
+            if (e & kSub) {
+                FQTK_DROP(kLitBits);
+                e = lit[(e >> 16) + (bb & ((1u << ((e >> 8) & 31u)) - 1))];
+                if (e & kLit) {
+                    FQTK_PUT16(e);
+                    continue;
+                }
+            }
+            if ((e & 0xFF) == 0) { ok = false; break; }
+            FQTK_DROP(e & 0xFF);
+            if (e & kEob) { eob = true; break; }
+            const unsigned lx = (e >> 8) & 31u;
+            const uint32_t len = (e >> 16) + (uint32_t)(bb & ((1ull << lx) - 1));
+            FQTK_DROP(lx);
+            uint32_t d = dist[bb & ((1u << kDistBits) - 1)];
+            if (d & kSub) {
+                FQTK_DROP(kDistBits);
+                d = dist[(d >> 16) + (bb & ((1u << ((d >> 8) & 31u)) - 1))];
+            }
+            if ((d & 0xFF) == 0) { ok = false; break; }
+            FQTK_DROP(d & 0xFF);
+            const unsigned dx = (d >> 8) & 31u;
+            const uint32_t distance = (d >> 16) + (uint32_t)(bb & ((1ull << dx) - 1));
+            FQTK_DROP(dx);
+            if (distance > o + 32768u) { ok = false; break; }
+            if (distance <= o) {
+                const uint16_t *src = out + o - distance;
+                if (distance >= 8) {   // eight symbols (16 bytes) at a time; may write up to 7 symbols past the match
+                    uint16_t *dst = out + o, *const end = dst + len;
+                    do {
+                        std::memcpy(dst, src, 16);
+                        dst += 8;
+                        src += 8;
+                    } while (dst < end);
+                } else {
+                    for (uint32_t i = 0; i < len; ++i) out[o + i] = src[i];
+                }
+            } else {
+                // (part of) the source lies before the chunk: position 32768 + (o - distance) + i of the window
+                const int64_t s0 = (int64_t)o - (int64_t)distance;
+                for (uint32_t i = 0; i < len; ++i) {
+                    const int64_t sp = s0 + i;
+                    out[o + i] = sp >= 0 ? out[sp] : (uint16_t)(256 + 32768 + sp);
+                }
+            }
+            o += len;
+        }
+#undef FQTK_REFILL
+#undef FQTK_DROP
+#undef FQTK_PUT16
+        tk.n_sym = o;
+        bb_ = bb;
+        bc_ = bc;
+        ip_ = ip;
+        if (!ok || overrun()) return false;
+        return true;
+    }
+};
+
+class ParallelGunzip : public FastInflate {
+  public:
+    // threads: decoders working side by side (>= 2; 1 would be the sequential decoder with extra steps)
+    // chunk: compressed bytes per decoder and stretch (2 MiB; tests use small ones to cross many boundaries)
+    void open(const uint8_t *data, size_t n, CrcFn crc, unsigned threads, size_t chunk = kChunk) {
+        FastInflate::open(data, n, crc);
+        chunk_ = std::max<size_t>(chunk, 4096);
+        stop_at_block_end_ = true;
+        threads_ = std::max(2u, threads);
+        workers_.resize(threads_);
+        for (auto &w : workers_) w.attach(data, n);
+        tasks_.assign(threads_, SpecInflate::Task{});
+        resolved_.assign(threads_, std::vector<uint8_t>());
+        emit_chunk_ = emit_off_ = n_ready_ = 0;
+        rounds_ = fallbacks_ = 0;
+    }
+
+    bool next(const uint8_t **out, size_t *n, std::string *err) {
+        for (;;) {
+            if (emit_chunk_ < n_ready_) {   // pieces of the last stretch, in order
+                const std::vector<uint8_t> &r = resolved_[emit_chunk_];
+                const size_t take_n = std::min(kPiece, r.size() - emit_off_);
+                *out = r.data() + emit_off_;
+                *n = take_n;
+                emit_off_ += take_n;
+                if (emit_off_ == r.size()) { ++emit_chunk_; emit_off_ = 0; }
+                if (take_n) return true;
+                continue;
+            }
+            if (state_ == State::Done) { *n = 0; return true; }
+            if (state_ == State::BlockStart && (size_t)(data_end_ - data_) - (size_t)(bit_pos() >> 3) > 3 * chunk_) {
+                if (!stretch(err)) return false;
+                if (n_ready_) continue;
+            }
+            // sequential: one block (or the header / trailer work between members)
+            size_t got = 0;
+            if (!FastInflate::next(out, &got, err)) return false;
+            if (got) { *n = got; return true; }
+            if (state_ == State::Done) { *n = 0; return true; }
+        }
+    }
+    uint64_t rounds() const { return rounds_; }
+    uint64_t fallbacks() const { return fallbacks_; }
+    const double *seconds() const { return seconds_; }   // find starts, decode, resolve, CRC
+
+    static constexpr size_t kChunk = 2u << 20;   // compressed bytes per chunk
+
+  private:
+    // Decodes the next threads_ chunks side by side; leaves their bytes in resolved_[0 .. n_ready_) and this
+    // (sequential) decoder positioned behind the last accepted one.  n_ready_ == 0: nothing accepted.
+    bool stretch(std::string *err) {
+        auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+        double t_mark = now();
+        auto lap = [&](int k) { const double t = now(); seconds_[k] += t - t_mark; t_mark = t; };
+        ++rounds_;
+        emit_chunk_ = emit_off_ = n_ready_ = 0;
+        const uint64_t p0 = bit_pos();
+        const uint64_t file_bits = (uint64_t)(data_end_ - data_) * 8u;
+        const unsigned K = threads_;
+        std::vector<uint64_t> starts(K, ~0ull);
+        starts[0] = p0;
+        {   // where the other chunks can start
+            std::vector<std::thread> th;
+            for (unsigned k = 1; k < K; ++k)
+                th.emplace_back([&, k] {
+                    const uint64_t from = ((p0 >> 3) + (uint64_t)k * chunk_) * 8u;
+                    if (from + 8 * chunk_ / 2 < file_bits) starts[k] = workers_[k].find_block_start(from, from + 8 * chunk_ / 2);
+                });
+            for (auto &t : th) t.join();
+        }
+        lap(0);
+        std::vector<unsigned> order;   // chunks that have a start, in file order
+        for (unsigned k = 0; k < K; ++k)
+            if (starts[k] != ~0ull) order.push_back(k);
+        const uint64_t stretch_end = std::min<uint64_t>(file_bits, ((p0 >> 3) + (uint64_t)K * chunk_) * 8u);
+        {
+            std::vector<std::thread> th;
+            for (size_t j = 0; j < order.size(); ++j) {
+                SpecInflate::Task &tk = tasks_[order[j]];
+                tk.start_bit = starts[order[j]];
+                tk.stop_bit = j + 1 < order.size() ? starts[order[j + 1]] : stretch_end;
+                th.emplace_back([&, j] { workers_[order[j]].run(tasks_[order[j]]); });
+            }
+            for (auto &t : th) t.join();
+        }
+        if (std::getenv("FQTK_PG_DEBUG"))
+            for (size_t j = 0; j < order.size(); ++j)
+                std::fprintf(stderr, "chunk %zu: %.1f ms, %zu symbols, error %d\n", j, tasks_[order[j]].seconds * 1e3, tasks_[order[j]].n_sym, (int)tasks_[order[j]].error);
+        lap(1);
+        // the chain of trust: chunk j+1 counts only if chunk j ended exactly where it starts
+        size_t accepted = 0;
+        for (size_t j = 0; j < order.size(); ++j) {
+            const SpecInflate::Task &tk = tasks_[order[j]];
+            if (tk.error) break;
+            ++accepted;
+            if (tk.final_block || j + 1 == order.size() || tk.end_bit != starts[order[j + 1]]) break;
+        }
+        if (accepted == 0) {   // the stream is damaged right here (or ends): the sequential decoder will say how
+            ++fallbacks_;
+            return true;
+        }
+        if (accepted < order.size()) ++fallbacks_;
+        // windows down the line, then every chunk to bytes
+        std::vector<std::vector<uint8_t>> windows(accepted + 1, std::vector<uint8_t>(32768, 0));
+        {
+            const size_t have = std::min<size_t>(hist_, 32768);
+            std::memcpy(windows[0].data() + 32768 - have, obuf_.data() + hist_ - have, have);
+        }
+        for (size_t j = 0; j < accepted; ++j) {   // the last 32 KiB of chunk j, resolved = the window of chunk j + 1
+            const SpecInflate::Task &tk = tasks_[order[j]];
+            const size_t tail = std::min<size_t>(tk.n_sym, 32768);
+            std::vector<uint8_t> &w = windows[j + 1];
+            if (tail < 32768) std::memcpy(w.data(), windows[j].data() + tail, 32768 - tail);
+            SpecInflate::resolve(tk.sym.data() + tk.n_sym - tail, tail, windows[j].data(), w.data() + 32768 - tail);
+        }
+        {
+            std::vector<std::thread> th;
+            for (size_t j = 0; j < accepted; ++j)
+                th.emplace_back([&, j] {
+                    const SpecInflate::Task &tk = tasks_[order[j]];
+                    resolved_[j].resize(tk.n_sym);
+                    SpecInflate::resolve(tk.sym.data(), tk.n_sym, windows[j].data(), resolved_[j].data());
+                });
+            for (auto &t : th) t.join();
+        }
+        lap(2);
+        for (size_t j = 0; j < accepted; ++j) {
+            crc_ = crc_fn_(crc_, resolved_[j].data(), resolved_[j].size());
+            isize_ += (uint32_t)resolved_[j].size();
+        }
+        lap(3);
+        n_ready_ = accepted;
+        // carry on behind the last accepted chunk, with its window as history
+        const SpecInflate::Task &last = tasks_[order[accepted - 1]];
+        std::memcpy(obuf_.data(), windows[accepted].data(), 32768);
+        hist_ = 32768;
+        if (!seek_bit(last.end_bit, err)) return false;
+        final_block_ = last.final_block;
+        state_ = last.final_block ? State::Trailer : State::BlockStart;
+        return true;
+    }
+
+    unsigned threads_ = 2;
+    size_t chunk_ = kChunk;
+    std::vector<SpecInflate> workers_;
+    std::vector<SpecInflate::Task> tasks_;
+    std::vector<std::vector<uint8_t>> resolved_;
+    size_t emit_chunk_ = 0, emit_off_ = 0, n_ready_ = 0;
+    uint64_t rounds_ = 0, fallbacks_ = 0;
+    double seconds_[4] = {0, 0, 0, 0};
+};
+
+}  // namespace fqtk_host

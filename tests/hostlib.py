@@ -93,6 +93,22 @@ def gunzip(data: bytes, cap=None) -> bytes:
     return out[:n].tobytes()
 
 
+def gunzip_parallel(data: bytes, threads=4, cap=None, chunk=0):
+    """The same through parallel_gunzip.hpp; returns (bytes, stretches decoded in parallel, stretches that fell back)."""
+    import numpy as np
+    cap = (len(data) * 40 + (1 << 20)) if cap is None else cap
+    out = np.empty(cap, dtype=np.uint8)
+    err = C.create_string_buffer(256)
+    stats = (C.c_uint64 * 2)()
+    fn = lib().fqtk_host_gunzip_parallel
+    fn.restype = C.c_int64
+    n = fn(data, C.c_size_t(len(data)), out.ctypes.data_as(C.c_void_p), C.c_size_t(cap), C.c_uint(threads), C.c_size_t(chunk), stats, err, C.c_size_t(256))
+    if n < 0:
+        raise ValueError(err.value.decode())
+    assert n <= cap, "test buffer too small"
+    return out[:n].tobytes(), int(stats[0]), int(stats[1])
+
+
 def bgzf(data: bytes, level=5) -> bytes:
     cap = len(data) + len(data) // 8 + 65536
     out = (C.c_uint8 * cap)()

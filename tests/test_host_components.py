@@ -361,3 +361,62 @@ def test_single_stream_gzip_input_through_the_reader_uses_the_fast_decoder(tmp_p
     assert got[2] == 1 and got[:2] == want[:2]
     monkeypatch.setenv("FQTK_ZLIB_INFLATE", "1")                               # zlib's gzread path stays available
     assert H.fastq_digest(p)[:2] == want[:2]
+
+
+# ---- one gzip stream decoded by several threads (parallel_gunzip.hpp) against zlib ------------------------
+@pytest.mark.parametrize("level,strategy", [(1, zlib.Z_DEFAULT_STRATEGY), (6, zlib.Z_DEFAULT_STRATEGY), (9, zlib.Z_DEFAULT_STRATEGY),
+                                            (6, zlib.Z_FILTERED), (6, zlib.Z_RLE), (6, zlib.Z_HUFFMAN_ONLY), (6, zlib.Z_FIXED), (0, zlib.Z_DEFAULT_STRATEGY)])
+@pytest.mark.parametrize("threads,chunk", [(2, 65536), (5, 30000), (8, 200000)])
+def test_parallel_gunzip_every_level_and_strategy(level, strategy, threads, chunk):
+    """Small chunks, so that a few MB cross hundreds of chunk boundaries: every accepted chunk must have been decoded
+    exactly (chain of block starts), everything else must fall back to the sequential decoder -- same bytes either way.
+    Fixed-Huffman and stored streams have no dynamic block to find: the whole file falls back."""
+    import numpy as np
+    rng = np.random.default_rng(level * 7 + strategy)
+    data = _fastq_like(9000, 11) + bytes(rng.integers(0, 4, 200000, dtype=np.uint8)) + b"A" * 300000 + _fastq_like(4000, 12)
+    out, rounds, fallbacks = H.gunzip_parallel(_gz(data, level, strategy), threads=threads, chunk=chunk, cap=len(data) + 1000)
+    assert out == data
+    if level >= 1 and strategy in (zlib.Z_DEFAULT_STRATEGY, zlib.Z_FILTERED):
+        assert rounds >= (1 if chunk >= 200000 else 4) and fallbacks < rounds          # the parallel path really ran
+
+
+def test_parallel_gunzip_members_windows_and_damage():
+    import numpy as np
+    data = _fastq_like(20000, 13)
+    one = _gz(data, 6)
+    many = one + gzip.compress(b"") + _gz(data[:100000], 1) + one                # members end inside stretches
+    want = data + data[:100000] + data
+    for threads, chunk in ((3, 50000), (6, 20000)):
+        out, rounds, _ = H.gunzip_parallel(many, threads=threads, chunk=chunk, cap=len(want) + 1000)
+        assert out == want and rounds > 3
+    far = bytes(np.random.default_rng(1).integers(0, 256, 30000, dtype=np.uint8))
+    data2 = (far + _fastq_like(300, 14)) * 40                                     # matches that reach ~32 KiB back, across chunks
+    out, rounds, _ = H.gunzip_parallel(_gz(data2, 9), threads=4, chunk=40000, cap=len(data2) + 1000)
+    assert out == data2 and rounds > 1
+    rng = np.random.default_rng(2)
+    for _ in range(60):                                                           # damage: an error, never a crash, never wrong bytes accepted silently
+        b = bytearray(one)
+        for _ in range(int(rng.integers(1, 4))):
+            b[int(rng.integers(10, len(b)))] = int(rng.integers(0, 256))
+        cut = int(rng.integers(20, len(b) + 1)) if rng.random() < 0.3 else len(b)
+        try:
+            out, _, _ = H.gunzip_parallel(bytes(b[:cut]), threads=4, chunk=30000, cap=len(data) * 3)
+            assert out == data                                                    # (only if the damage missed everything that matters)
+        except ValueError:
+            pass
+
+
+def test_reader_decodes_a_gzip_input_with_several_threads(tmp_path, monkeypatch):
+    data = _fastq_like(40000, 15)
+    p = tmp_path / "y.fq.gz"
+    p.write_bytes(_gz(data, 6))
+    plain = tmp_path / "y.fq"
+    plain.write_bytes(data)
+    want = H.fastq_digest(plain)
+    monkeypatch.setenv("FQTK_GZ_CHUNK", "30000")            # 3 MB of gzip = a hundred chunks
+    for threads in ("2", "5"):
+        monkeypatch.setenv("FQTK_GZ_THREADS", threads)
+        got = H.fastq_digest(p, batch=7777)
+        assert got[2] == 1 and got[:2] == want[:2]
+    monkeypatch.setenv("FQTK_GZ_THREADS", "1")              # the sequential decoder
+    assert H.fastq_digest(p)[:2] == want[:2]
