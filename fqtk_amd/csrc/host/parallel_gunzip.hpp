@@ -42,6 +42,9 @@ class SpecInflate : public FastInflate {
         bool final_block = false, error = false;
         double seconds = 0;                     // (how long run() took)
     };
+    // A chunk of highly compressible data could expand a thousandfold: past this many symbols it is given up (the
+    // stretch then ends before it and the sequential decoder, which works in 4 MiB pieces, takes over for a while).
+    static constexpr size_t kMaxSymbols = 48u << 20;
 
     void attach(const uint8_t *data, size_t n) { open(data, n, nullptr); }
 
@@ -84,7 +87,7 @@ class SpecInflate : public FastInflate {
             state_ = State::BlockStart;
             if (!start_block(&err)) { tk.error = true; return; }
             if (state_ == State::Stored) {
-                if (in_end_ - ip_ < (ptrdiff_t)stored_left_) { tk.error = true; return; }
+                if (in_end_ - ip_ < (ptrdiff_t)stored_left_ || tk.n_sym > kMaxSymbols) { tk.error = true; return; }
                 reserve(tk, stored_left_);
                 for (size_t i = 0; i < stored_left_; ++i) tk.sym[tk.n_sym + i] = ip_[i];
                 tk.n_sym += stored_left_;
@@ -142,6 +145,7 @@ class SpecInflate : public FastInflate {
 #define FQTK_PUT16(e) do { out[o] = (uint16_t)(((e) >> 16) & 0xFFu); out[o + 1] = (uint16_t)((e) >> 24); o += ((e) >> 8) & 3u; FQTK_DROP((e) & 0xFF); } while (0)
         while (!eob) {
             if (o + 600 > cap) {
+                if (o > kMaxSymbols) { ok = false; break; }
                 tk.n_sym = o;
                 reserve(tk, 1u << 20);
                 out = tk.sym.data();
@@ -242,7 +246,7 @@ class ParallelGunzip : public FastInflate {
         tasks_.assign(threads_, SpecInflate::Task{});
         resolved_.assign(threads_, std::vector<uint8_t>());
         emit_chunk_ = emit_off_ = n_ready_ = 0;
-        rounds_ = fallbacks_ = 0;
+        rounds_ = fallbacks_ = cooldown_bit_ = 0;
     }
 
     bool next(const uint8_t **out, size_t *n, std::string *err) {
@@ -258,7 +262,8 @@ class ParallelGunzip : public FastInflate {
                 continue;
             }
             if (state_ == State::Done) { *n = 0; return true; }
-            if (state_ == State::BlockStart && (size_t)(data_end_ - data_) - (size_t)(bit_pos() >> 3) > 3 * chunk_) {
+            if (state_ == State::BlockStart && bit_pos() >= cooldown_bit_ &&
+                (size_t)(data_end_ - data_) - (size_t)(bit_pos() >> 3) > 3 * chunk_) {
                 if (!stretch(err)) return false;
                 if (n_ready_) continue;
             }
@@ -325,11 +330,13 @@ class ParallelGunzip : public FastInflate {
             ++accepted;
             if (tk.final_block || j + 1 == order.size() || tk.end_bit != starts[order[j + 1]]) break;
         }
-        if (accepted == 0) {   // the stream is damaged right here (or ends): the sequential decoder will say how
+        if (accepted < order.size()) {
+            // something did not line up (no start where one was believed, a chunk that expands beyond reason, damage):
+            // sequential for the next few chunks' worth before speculating again
             ++fallbacks_;
-            return true;
+            cooldown_bit_ = p0 + 8ull * 4 * chunk_;
         }
-        if (accepted < order.size()) ++fallbacks_;
+        if (accepted == 0) return true;   // the sequential decoder goes on from here (and reports damage, if that is what it was)
         // windows down the line, then every chunk to bytes
         std::vector<std::vector<uint8_t>> windows(accepted + 1, std::vector<uint8_t>(32768, 0));
         {
@@ -376,7 +383,7 @@ class ParallelGunzip : public FastInflate {
     std::vector<SpecInflate::Task> tasks_;
     std::vector<std::vector<uint8_t>> resolved_;
     size_t emit_chunk_ = 0, emit_off_ = 0, n_ready_ = 0;
-    uint64_t rounds_ = 0, fallbacks_ = 0;
+    uint64_t rounds_ = 0, fallbacks_ = 0, cooldown_bit_ = 0;
     double seconds_[4] = {0, 0, 0, 0};
 };
 
