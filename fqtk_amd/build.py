@@ -45,7 +45,7 @@ def build_host(force: bool = False, verbose: bool = False) -> None:
     shim = os.path.join(LIBDIR, "libfqtk_host.so")
     src = os.path.join(HOST, "host_capi.cpp")
     if force or _stale(shim, [src] + deps):
-        cmd = [CXX, "-O2", "-std=c++17", "-shared", "-fPIC", "-Wall", "-o", shim, src, "-lz", "-ldl"]
+        cmd = [CXX, "-O2", "-std=c++17", "-shared", "-fPIC", "-Wall", "-pthread", "-o", shim, src, "-lz", "-ldl"]
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.run(cmd, check=True)

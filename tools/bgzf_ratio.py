@@ -33,7 +33,7 @@ def fastq_text(n_records, rng, qual):
 def main():
     flags = [a for a in sys.argv[1:] if a.startswith("-D")]
     so = os.path.join(tempfile.mkdtemp(), "libshim.so")
-    subprocess.check_call(["g++", "-O2", "-std=c++17", "-shared", "-fPIC", *flags, "-o", so,
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-shared", "-fPIC", "-pthread", *flags, "-o", so,
                            os.path.join(ROOT, "fqtk_amd/csrc/host/host_capi.cpp"), "-lz", "-ldl"])
     lib = C.CDLL(so)
     fn = lib.fqtk_host_bgzf_deflate_emulated
