@@ -358,13 +358,16 @@ class FastqSource {
         d.insert(d.end(), pc.data.begin(), pc.data.end());
         {
             std::lock_guard<std::mutex> lk(mu_);
-            if (spare_.size() < 8) spare_.push_back(std::move(pc.data));   // piece buffers go round
+            if (spare_.size() < (pgz_ ? 40u : 8u)) spare_.push_back(std::move(pc.data));   // piece buffers go round
         }
         return true;
     }
     void push(Piece &&pc) {
         std::unique_lock<std::mutex> lk(mu_);
-        cv_space_.wait(lk, [&] { return q_.size() < 4 || stop_; });
+        // (a parallel gzip decoder delivers a whole stretch -- a dozen pieces -- at once and then computes the next one:
+        //  the queue must hold a stretch, or parser and decoder take turns instead of overlapping)
+        const size_t depth = pgz_ ? 32 : 4;
+        cv_space_.wait(lk, [&] { return q_.size() < depth || stop_; });
         if (stop_) return;
         q_.push_back(std::move(pc));
         cv_data_.notify_one();
