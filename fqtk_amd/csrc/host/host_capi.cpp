@@ -162,6 +162,26 @@ int64_t fqtk_host_gunzip_parallel(const uint8_t *in, size_t n, uint8_t *out, siz
     return total;
 }
 
+// Reads a FASTQ file through the reader (decode + parse, nothing else) and returns the number of records; *bytes =
+// sequence + quality + header bytes seen.  For timing the input side alone (tools/reader_bench.py).
+int64_t fqtk_host_fastq_count(const char *path, uint64_t batch, uint32_t inflate_helpers, uint32_t gz_threads, uint64_t *bytes,
+                              char *err, size_t errcap) {
+    FastqSource src;
+    std::string e;
+    if (!src.open(path, &e, inflate_helpers, gz_threads)) { put(e, err, errcap); return -1; }
+    int64_t n = 0;
+    uint64_t b = 0;
+    for (;;) {
+        RecBatch rb;
+        if (!src.next_batch((size_t)batch, &rb, &e)) { put(e, err, errcap); return -1; }
+        if (rb.recs.empty()) break;
+        n += (int64_t)rb.recs.size();
+        for (const FastqRec &r : rb.recs) b += r.head_len + 2u * r.seq_len;
+    }
+    if (bytes) *bytes = b;
+    return n;
+}
+
 // BGZF-compresses a whole buffer (blocks of kBgzfBlockSize + EOF marker).
 int fqtk_host_bgzf(const uint8_t *in, size_t n, int level, uint8_t *out, size_t cap, size_t *out_len) {
     std::vector<uint8_t> o;
