@@ -405,6 +405,7 @@ class FastqSource {
         return true;
     }
     bool produce_gzip(Piece &pc) {
+        if (pgz_ && pgz_->take_chunk(pc.data)) return true;   // a whole chunk of a decoded stretch, by swap
         if (fast_ || pgz_) {
             const uint8_t *p = nullptr;
             size_t n = 0;

@@ -27,6 +27,8 @@
 #include <thread>
 #include <vector>
 
+#include <zlib.h>   // crc32_combine
+
 #include "fast_inflate.hpp"
 
 namespace fqtk_host {
@@ -244,7 +246,8 @@ class ParallelGunzip : public FastInflate {
         workers_.resize(threads_);
         for (auto &w : workers_) w.attach(data, n);
         tasks_.assign(threads_, SpecInflate::Task{});
-        resolved_.assign(threads_, std::vector<uint8_t>());
+        resolved_.assign(threads_, std::vector<char>());
+        chunk_crc_.assign(threads_, 0);
         emit_chunk_ = emit_off_ = n_ready_ = 0;
         rounds_ = fallbacks_ = cooldown_bit_ = 0;
     }
@@ -252,9 +255,9 @@ class ParallelGunzip : public FastInflate {
     bool next(const uint8_t **out, size_t *n, std::string *err) {
         for (;;) {
             if (emit_chunk_ < n_ready_) {   // pieces of the last stretch, in order
-                const std::vector<uint8_t> &r = resolved_[emit_chunk_];
+                const std::vector<char> &r = resolved_[emit_chunk_];
                 const size_t take_n = std::min(kPiece, r.size() - emit_off_);
-                *out = r.data() + emit_off_;
+                *out = reinterpret_cast<const uint8_t *>(r.data()) + emit_off_;
                 *n = take_n;
                 emit_off_ += take_n;
                 if (emit_off_ == r.size()) { ++emit_chunk_; emit_off_ = 0; }
@@ -273,6 +276,13 @@ class ParallelGunzip : public FastInflate {
             if (got) { *n = got; return true; }
             if (state_ == State::Done) { *n = 0; return true; }
         }
+    }
+    // A whole decoded chunk by swap instead of by copy, when one is next in line (out's old buffer is reused here).
+    bool take_chunk(std::vector<char> &out) {
+        if (emit_chunk_ >= n_ready_ || emit_off_ != 0 || resolved_[emit_chunk_].empty()) return false;
+        out.swap(resolved_[emit_chunk_]);
+        ++emit_chunk_;
+        return true;
     }
     uint64_t rounds() const { return rounds_; }
     uint64_t fallbacks() const { return fallbacks_; }
@@ -356,13 +366,14 @@ class ParallelGunzip : public FastInflate {
                 th.emplace_back([&, j] {
                     const SpecInflate::Task &tk = tasks_[order[j]];
                     resolved_[j].resize(tk.n_sym);
-                    SpecInflate::resolve(tk.sym.data(), tk.n_sym, windows[j].data(), resolved_[j].data());
+                    SpecInflate::resolve(tk.sym.data(), tk.n_sym, windows[j].data(), reinterpret_cast<uint8_t *>(resolved_[j].data()));
+                    chunk_crc_[j] = crc_fn_(0, resolved_[j].data(), resolved_[j].size());   // folded into the member's CRC below
                 });
             for (auto &t : th) t.join();
         }
         lap(2);
         for (size_t j = 0; j < accepted; ++j) {
-            crc_ = crc_fn_(crc_, resolved_[j].data(), resolved_[j].size());
+            crc_ = (uint32_t)crc32_combine(crc_, chunk_crc_[j], (z_off_t)resolved_[j].size());
             isize_ += (uint32_t)resolved_[j].size();
         }
         lap(3);
@@ -381,7 +392,8 @@ class ParallelGunzip : public FastInflate {
     size_t chunk_ = kChunk;
     std::vector<SpecInflate> workers_;
     std::vector<SpecInflate::Task> tasks_;
-    std::vector<std::vector<uint8_t>> resolved_;
+    std::vector<std::vector<char>> resolved_;
+    std::vector<uint32_t> chunk_crc_;
     size_t emit_chunk_ = 0, emit_off_ = 0, n_ready_ = 0;
     uint64_t rounds_ = 0, fallbacks_ = 0, cooldown_bit_ = 0;
     double seconds_[4] = {0, 0, 0, 0};
