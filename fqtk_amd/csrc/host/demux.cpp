@@ -748,7 +748,7 @@ int main(int argc, char **argv) {
                     for (size_t b = 0; b < ch->batches.size(); ++b) {
                         const RecBatch &rb = *ch->batches[b];
                         const FastqRec &r = rb.recs[i];
-                        const char *base = rb.base();
+                        const char *base = rb.rec_base(i);
                         __builtin_prefetch(base + r.head_off);
                         for (uint32_t off = 0; off < r.seq_len; off += 64) {
                             __builtin_prefetch(base + r.seq_off + off);

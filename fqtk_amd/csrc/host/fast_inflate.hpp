@@ -23,10 +23,24 @@
 #include <cstdint>
 #include <cstdlib>
 #include <cstring>
+#include <memory>
+#include <new>
 #include <string>
+#include <type_traits>
+#include <utility>
 #include <vector>
 
 namespace fqtk_host {
+
+// A byte vector whose resize() does not zero what it adds (buffers that are about to be overwritten anyway).
+template <typename T>
+struct DefaultInitAllocator : std::allocator<T> {
+    template <typename U> struct rebind { using other = DefaultInitAllocator<U>; };
+    using std::allocator<T>::allocator;
+    template <typename U> void construct(U *p) noexcept(std::is_nothrow_default_constructible<U>::value) { ::new (static_cast<void *>(p)) U; }
+    template <typename U, typename... A> void construct(U *p, A &&...a) { ::new (static_cast<void *>(p)) U(std::forward<A>(a)...); }
+};
+using ByteVec = std::vector<char, DefaultInitAllocator<char>>;
 
 class FastInflate {
   public:

@@ -46,20 +46,24 @@ struct FastqRec {
     uint32_t head_off, head_len;   // header without the leading '@'
     uint32_t seq_off, seq_len;
     uint32_t qual_off;             // qual_len == seq_len
+    uint32_t buf = 0;              // which of the batch's buffers the offsets are in (decoded inputs)
 };
 
+// The bytes of a batch are NOT copied together.  A mapped plain file: `mapped` points into the mapping.  Anything that
+// is decoded or read in pieces: the batch holds (shares) the pieces its records lie in -- a record never straddles
+// two of them, the reader moves the few hundred bytes of a straddling record in front of the next piece.
 struct RecBatch {
-    std::vector<char> data;          // the batch's bytes ... unless `mapped` points into a memory-mapped input
+    std::vector<std::shared_ptr<ByteVec>> bufs;
     const char *mapped = nullptr;
     std::vector<FastqRec> recs;
     // filled by the demux reader threads (not by the parser): reads shorter than the read structure needs,
     // and this input's fixed-length sample-barcode segments, packed side by side (one row per record)
     std::vector<uint8_t> too_short, bc;
     size_t n_short = 0;
-    const char *base() const { return mapped ? mapped : data.data(); }
-    const char *head(size_t i) const { return base() + recs[i].head_off; }
-    const char *seq(size_t i) const { return base() + recs[i].seq_off; }
-    const char *qual(size_t i) const { return base() + recs[i].qual_off; }
+    const char *rec_base(size_t i) const { return mapped ? mapped : bufs[recs[i].buf]->data(); }
+    const char *head(size_t i) const { return rec_base(i) + recs[i].head_off; }
+    const char *seq(size_t i) const { return rec_base(i) + recs[i].seq_off; }
+    const char *qual(size_t i) const { return rec_base(i) + recs[i].qual_off; }
 };
 
 // libdeflate's decompressor, bound at run time (the image ships libdeflate.so.0 without its header).
@@ -162,7 +166,7 @@ class FastqSource {
                     if (const char *g = std::getenv("FQTK_GZ_CHUNK")) if (*g) chunk = (size_t)std::atol(g);
                     if (t >= 2 && gz_map_size_ >= 32 * chunk) {   // 64 MiB by default: below that the sequential decoder is done in 0.2 s
                         pgz_.reset(new ParallelGunzip());
-                        pgz_->open(gz_map_, gz_map_size_, &FastqSource::crc32_fn, t, chunk);
+                        pgz_->open(gz_map_, gz_map_size_, &FastqSource::crc32_fn, t, chunk, kHead);
                     } else {
                         fast_.reset(new FastInflate());
                         fast_->open(gz_map_, gz_map_size_, &FastqSource::crc32_fn);
@@ -202,52 +206,51 @@ class FastqSource {
         if (!producer_.joinable()) start();
         out->recs.clear();
         out->recs.reserve(std::min<size_t>(max_records, 1u << 20));
-        std::vector<char> &d = out->data;
-        d.clear();
-        d.reserve(cap_hint_);           // batches of one input are alike: no regrowth copies after the first
-        d.insert(d.end(), carry_.begin(), carry_.end());   // bytes already read that belong to this batch
-        size_t pos = 0;                 // first unparsed byte
-        carry_.clear();
+        out->bufs.clear();
+        out->mapped = nullptr;
+        int cur_idx = -1;   // index of cur_ in out->bufs (-1: not referenced by this batch yet)
         while (out->recs.size() < max_records) {
-            // four complete lines starting at pos?
-            size_t lo[4], len[4], p = pos;
+            // four complete lines in what is left of the current piece?
+            size_t lo[4], len[4], p = cur_pos_;
             int got = 0;
-            while (got < 4) {
-                const char *nl = p < d.size() ? (const char *)memchr(d.data() + p, '\n', d.size() - p) : nullptr;
+            const char *base = cur_ ? cur_->data() : nullptr;
+            while (got < 4 && p < cur_end_) {
+                const char *nl = (const char *)memchr(base + p, '\n', cur_end_ - p);
                 if (!nl) break;
                 lo[got] = p;
-                len[got] = (size_t)(nl - (d.data() + p));
+                len[got] = (size_t)(nl - (base + p));
                 p += len[got] + 1;
                 ++got;
             }
             if (got < 4) {
-                if (!eof_) {            // need more bytes: append one piece to the batch
-                    if (!fill(d, err)) return false;
+                if (!eof_) {   // the record continues in the next piece: its beginning moves in front of that piece
+                    if (!next_piece(err)) return false;
+                    cur_idx = -1;
                     continue;
                 }
-                if (got == 3 && p < d.size()) {   // final line without '\n'
+                if (got == 3 && p < cur_end_) {   // final line without '\n'
                     lo[3] = p;
-                    len[3] = d.size() - p;
-                    p = d.size();
+                    len[3] = cur_end_ - p;
+                    p = cur_end_;
                     got = 4;
                 } else {
                     // EOF: anything left must be blank
-                    for (size_t q = pos; q < d.size(); ++q)
-                        if (d[q] != '\n' && d[q] != '\r') {
+                    for (size_t q = cur_pos_; q < cur_end_; ++q)
+                        if (base[q] != '\n' && base[q] != '\r') {
                             *err = "Unexpected error parsing FASTQs: truncated record at end of " + path_;
                             return false;
                         }
-                    pos = d.size();
+                    cur_pos_ = cur_end_;
                     break;
                 }
             }
             for (int k = 0; k < 4; ++k)
-                if (len[k] > 0 && d[lo[k] + len[k] - 1] == '\r') --len[k];
-            if (len[0] == 0 || d[lo[0]] != '@') {
+                if (len[k] > 0 && base[lo[k] + len[k] - 1] == '\r') --len[k];
+            if (len[0] == 0 || base[lo[0]] != '@') {
                 *err = "Unexpected error parsing FASTQs: expected '@' at record " + std::to_string(nrec_) + " of " + path_;
                 return false;
             }
-            if (len[2] == 0 || d[lo[2]] != '+') {
+            if (len[2] == 0 || base[lo[2]] != '+') {
                 *err = "Unexpected error parsing FASTQs: expected '+' at record " + std::to_string(nrec_) + " of " + path_;
                 return false;
             }
@@ -256,30 +259,32 @@ class FastqSource {
                        std::to_string(nrec_) + " of " + path_;
                 return false;
             }
-            if (p > 0xFFFFFFFFull) { *err = "Unexpected error parsing FASTQs: batch larger than 4 GiB in " + path_; return false; }
+            if (p > 0xFFFFFFFFull) { *err = "Unexpected error parsing FASTQs: piece larger than 4 GiB in " + path_; return false; }
+            if (cur_idx < 0) {
+                cur_idx = (int)out->bufs.size();
+                out->bufs.push_back(cur_);
+            }
             FastqRec r;
             r.head_off = (uint32_t)lo[0] + 1;
             r.head_len = (uint32_t)len[0] - 1;
             r.seq_off = (uint32_t)lo[1];
             r.seq_len = (uint32_t)len[1];
             r.qual_off = (uint32_t)lo[3];
+            r.buf = (uint32_t)cur_idx;
             out->recs.push_back(r);
-            pos = p;
+            cur_pos_ = p;
             ++nrec_;
         }
-        // what was read beyond this batch's last record starts the next batch
-        carry_.assign(d.begin() + (std::ptrdiff_t)pos, d.end());
-        cap_hint_ = std::max(cap_hint_, d.size() + (8u << 20));
-        d.resize(pos);
         return true;
     }
+
 
   private:
     // Plain regular file: the records of a batch are located in the mapping itself.
     bool next_batch_mapped(size_t max_records, RecBatch *out, std::string *err) {
         out->recs.clear();
         out->recs.reserve(std::min<size_t>(max_records, 1u << 20));
-        out->data.clear();
+        out->bufs.clear();
         const char *base = map_ + map_pos_;
         const size_t avail = map_size_ - map_pos_;
         out->mapped = base;
@@ -341,10 +346,13 @@ class FastqSource {
     }
 
     static constexpr size_t kPiece = 4u << 20;
-    struct Piece { std::vector<char> data; std::string error; bool eof = false; };
+    static constexpr size_t kHead = 65536;   // free bytes in front of every piece (a straddling record's beginning goes there)
+    struct Piece { std::shared_ptr<ByteVec> buf; size_t head = 0, len = 0; std::string error; bool eof = false; };
 
     // consumer side: next piece from the producer's queue
-    bool fill(std::vector<char> &d, std::string *err) {
+    // Makes the next piece current.  The unparsed rest of the current one (the beginning of a record) is moved in
+    // front of it -- into the head room every piece comes with, or, if a record is longer than that, into a copy.
+    bool next_piece(std::string *err) {
         Piece pc;
         {
             std::unique_lock<std::mutex> lk(mu_);
@@ -355,10 +363,21 @@ class FastqSource {
         cv_space_.notify_one();
         if (!pc.error.empty()) { *err = pc.error; return false; }
         if (pc.eof) { eof_ = true; return true; }
-        d.insert(d.end(), pc.data.begin(), pc.data.end());
-        {
-            std::lock_guard<std::mutex> lk(mu_);
-            if (spare_.size() < (pgz_ ? 40u : 8u)) spare_.push_back(std::move(pc.data));   // piece buffers go round
+        if (pc.len == 0) return true;   // (a BGZF round that only read more input)
+        const size_t rest = cur_ ? cur_end_ - cur_pos_ : 0;
+        if (rest <= pc.head) {
+            if (rest) std::memcpy(pc.buf->data() + pc.head - rest, cur_->data() + cur_pos_, rest);
+            cur_pos_ = pc.head - rest;
+            cur_end_ = pc.head + pc.len;
+            cur_ = std::move(pc.buf);
+        } else {
+            auto joined = std::make_shared<ByteVec>();
+            joined->resize(rest + pc.len);
+            std::memcpy(joined->data(), cur_->data() + cur_pos_, rest);
+            std::memcpy(joined->data() + rest, pc.buf->data() + pc.head, pc.len);
+            cur_pos_ = 0;
+            cur_end_ = rest + pc.len;
+            cur_ = std::move(joined);
         }
         return true;
     }
@@ -372,19 +391,11 @@ class FastqSource {
         q_.push_back(std::move(pc));
         cv_data_.notify_one();
     }
-    std::vector<char> buffer() {
-        std::lock_guard<std::mutex> lk(mu_);
-        if (spare_.empty()) return {};
-        std::vector<char> b = std::move(spare_.back());
-        spare_.pop_back();
-        return b;
-    }
     void start() {
         for (unsigned h = 0; h < n_helpers_; ++h) helpers_.emplace_back([this] { helper_loop(); });
         producer_ = std::thread([this] {
             for (;;) {
                 Piece pc;
-                pc.data = buffer();
                 bool more = kind_ == Kind::Plain ? produce_plain(pc) : (kind_ == Kind::Gzip ? produce_gzip(pc) : produce_bgzf(pc));
                 const bool last = !more || !pc.error.empty() || pc.eof;
                 push(std::move(pc));
@@ -396,16 +407,30 @@ class FastqSource {
             }
         });
     }
+    static void fresh(Piece &pc, size_t room) {
+        pc.buf = std::make_shared<ByteVec>();
+        pc.buf->resize(kHead + room);
+        pc.head = kHead;
+        pc.len = 0;
+    }
     bool produce_plain(Piece &pc) {
-        pc.data.resize(kPiece);
-        const ssize_t n = ::read(fd_, pc.data.data(), kPiece);
+        fresh(pc, kPiece);
+        const ssize_t n = ::read(fd_, pc.buf->data() + kHead, kPiece);
         if (n < 0) { pc.error = "Unexpected error parsing FASTQs: read failed in " + path_; return false; }
         if (n == 0) { pc.eof = true; return false; }
-        pc.data.resize((size_t)n);
+        pc.len = (size_t)n;
         return true;
     }
     bool produce_gzip(Piece &pc) {
-        if (pgz_ && pgz_->take_chunk(pc.data)) return true;   // a whole chunk of a decoded stretch, by swap
+        if (pgz_) {   // a whole chunk of a decoded stretch, by swap
+            auto v = std::make_shared<ByteVec>();
+            if (pgz_->take_chunk(*v)) {
+                pc.head = kHead;
+                pc.len = v->size() - kHead;
+                pc.buf = std::move(v);
+                return true;
+            }
+        }
         if (fast_ || pgz_) {
             const uint8_t *p = nullptr;
             size_t n = 0;
@@ -415,18 +440,20 @@ class FastqSource {
                 return false;
             }
             if (n == 0) { pc.eof = true; return false; }
-            pc.data.assign(reinterpret_cast<const char *>(p), reinterpret_cast<const char *>(p) + n);
+            fresh(pc, n);
+            std::memcpy(pc.buf->data() + kHead, p, n);
+            pc.len = n;
             return true;
         }
-        pc.data.resize(kPiece);
-        const int n = gzread(gz_, pc.data.data(), (unsigned)kPiece);
+        fresh(pc, kPiece);
+        const int n = gzread(gz_, pc.buf->data() + kHead, (unsigned)kPiece);
         if (n < 0) {
             int e = 0;
             pc.error = std::string("Unexpected error parsing FASTQs: ") + gzerror(gz_, &e) + " in " + path_;
             return false;
         }
         if (n == 0) { pc.eof = true; return false; }
-        pc.data.resize((size_t)n);
+        pc.len = (size_t)n;
         return true;
     }
     // ---- BGZF: read a group of whole members, inflate them in parallel into one piece --------------------
@@ -469,11 +496,12 @@ class FastqSource {
             return true;   // a member larger than what is buffered: read more next round (empty piece)
         }
         cpos_ = p;
-        pc.data.resize(out_total);
+        fresh(pc, out_total);
+        pc.len = out_total;
         // fan the blocks out: helpers and this thread claim them one by one
         {
             std::lock_guard<std::mutex> lk(mu_);
-            job_out_ = reinterpret_cast<uint8_t *>(pc.data.data());
+            job_out_ = reinterpret_cast<uint8_t *>(pc.buf->data() + kHead);
             job_next_.store(0);
             job_done_ = 0;
             job_failed_ = false;
@@ -551,8 +579,8 @@ class FastqSource {
     }
     int fd_ = -1;
     std::string path_;
-    std::vector<char> carry_;
-    size_t cap_hint_ = 8u << 20;
+    std::shared_ptr<ByteVec> cur_;          // the piece being parsed (decoded inputs), its unparsed range
+    size_t cur_pos_ = 0, cur_end_ = 0;
     bool eof_ = false;
     uint64_t nrec_ = 0;
     // producer / consumer
@@ -560,7 +588,6 @@ class FastqSource {
     std::mutex mu_;
     std::condition_variable cv_data_, cv_space_, cv_work_, cv_done_;
     std::deque<Piece> q_;
-    std::vector<std::vector<char>> spare_;
     bool stop_ = false;
     // BGZF group state
     unsigned n_helpers_ = 0;

@@ -238,15 +238,18 @@ class ParallelGunzip : public FastInflate {
   public:
     // threads: decoders working side by side (>= 2; 1 would be the sequential decoder with extra steps)
     // chunk: compressed bytes per decoder and stretch (2 MiB; tests use small ones to cross many boundaries)
-    void open(const uint8_t *data, size_t n, CrcFn crc, unsigned threads, size_t chunk = kChunk) {
+    // head: bytes left free in front of every decoded chunk handed out by take_chunk() (room for the reader to put the
+    // tail of the record that straddles two chunks)
+    void open(const uint8_t *data, size_t n, CrcFn crc, unsigned threads, size_t chunk = kChunk, size_t head = 0) {
         FastInflate::open(data, n, crc);
+        head_ = head;
         chunk_ = std::max<size_t>(chunk, 4096);
         stop_at_block_end_ = true;
         threads_ = std::max(2u, threads);
         workers_.resize(threads_);
         for (auto &w : workers_) w.attach(data, n);
         tasks_.assign(threads_, SpecInflate::Task{});
-        resolved_.assign(threads_, std::vector<char>());
+        resolved_.assign(threads_, ByteVec());
         chunk_crc_.assign(threads_, 0);
         emit_chunk_ = emit_off_ = n_ready_ = 0;
         rounds_ = fallbacks_ = cooldown_bit_ = 0;
@@ -255,12 +258,13 @@ class ParallelGunzip : public FastInflate {
     bool next(const uint8_t **out, size_t *n, std::string *err) {
         for (;;) {
             if (emit_chunk_ < n_ready_) {   // pieces of the last stretch, in order
-                const std::vector<char> &r = resolved_[emit_chunk_];
-                const size_t take_n = std::min(kPiece, r.size() - emit_off_);
-                *out = reinterpret_cast<const uint8_t *>(r.data()) + emit_off_;
+                const ByteVec &r = resolved_[emit_chunk_];
+                const size_t have = r.size() - head_;
+                const size_t take_n = std::min(kPiece, have - emit_off_);
+                *out = reinterpret_cast<const uint8_t *>(r.data()) + head_ + emit_off_;
                 *n = take_n;
                 emit_off_ += take_n;
-                if (emit_off_ == r.size()) { ++emit_chunk_; emit_off_ = 0; }
+                if (emit_off_ == have) { ++emit_chunk_; emit_off_ = 0; }
                 if (take_n) return true;
                 continue;
             }
@@ -278,8 +282,9 @@ class ParallelGunzip : public FastInflate {
         }
     }
     // A whole decoded chunk by swap instead of by copy, when one is next in line (out's old buffer is reused here).
-    bool take_chunk(std::vector<char> &out) {
-        if (emit_chunk_ >= n_ready_ || emit_off_ != 0 || resolved_[emit_chunk_].empty()) return false;
+    // (the chunk's bytes start at offset head of `out`)
+    bool take_chunk(ByteVec &out) {
+        if (emit_chunk_ >= n_ready_ || emit_off_ != 0 || resolved_[emit_chunk_].size() <= head_) return false;
         out.swap(resolved_[emit_chunk_]);
         ++emit_chunk_;
         return true;
@@ -365,16 +370,16 @@ class ParallelGunzip : public FastInflate {
             for (size_t j = 0; j < accepted; ++j)
                 th.emplace_back([&, j] {
                     const SpecInflate::Task &tk = tasks_[order[j]];
-                    resolved_[j].resize(tk.n_sym);
-                    SpecInflate::resolve(tk.sym.data(), tk.n_sym, windows[j].data(), reinterpret_cast<uint8_t *>(resolved_[j].data()));
-                    chunk_crc_[j] = crc_fn_(0, resolved_[j].data(), resolved_[j].size());   // folded into the member's CRC below
+                    resolved_[j].resize(head_ + tk.n_sym);
+                    SpecInflate::resolve(tk.sym.data(), tk.n_sym, windows[j].data(), reinterpret_cast<uint8_t *>(resolved_[j].data()) + head_);
+                    chunk_crc_[j] = crc_fn_(0, resolved_[j].data() + head_, tk.n_sym);   // folded into the member's CRC below
                 });
             for (auto &t : th) t.join();
         }
         lap(2);
         for (size_t j = 0; j < accepted; ++j) {
-            crc_ = (uint32_t)crc32_combine(crc_, chunk_crc_[j], (z_off_t)resolved_[j].size());
-            isize_ += (uint32_t)resolved_[j].size();
+            crc_ = (uint32_t)crc32_combine(crc_, chunk_crc_[j], (z_off_t)(resolved_[j].size() - head_));
+            isize_ += (uint32_t)(resolved_[j].size() - head_);
         }
         lap(3);
         n_ready_ = accepted;
@@ -392,7 +397,8 @@ class ParallelGunzip : public FastInflate {
     size_t chunk_ = kChunk;
     std::vector<SpecInflate> workers_;
     std::vector<SpecInflate::Task> tasks_;
-    std::vector<std::vector<char>> resolved_;
+    std::vector<ByteVec> resolved_;
+    size_t head_ = 0;
     std::vector<uint32_t> chunk_crc_;
     size_t emit_chunk_ = 0, emit_off_ = 0, n_ready_ = 0;
     uint64_t rounds_ = 0, fallbacks_ = 0, cooldown_bit_ = 0;
