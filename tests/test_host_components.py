@@ -420,3 +420,32 @@ def test_reader_decodes_a_gzip_input_with_several_threads(tmp_path, monkeypatch)
         assert got[2] == 1 and got[:2] == want[:2]
     monkeypatch.setenv("FQTK_GZ_THREADS", "1")              # the sequential decoder
     assert H.fastq_digest(p)[:2] == want[:2]
+
+
+def test_records_longer_than_a_piece_s_head_room(tmp_path, monkeypatch):
+    """Reads of 70-300 kb: a record that straddles two pieces is longer than the 64 KiB of head room, so the reader
+    joins the two pieces instead (and a record can span several 4 MiB pieces of a BGZF or gzip input)."""
+    import numpy as np
+    rng = np.random.default_rng(21)
+    recs = []
+    for i in range(120):
+        L = int(rng.integers(70_000, 300_000))
+        seq = rng.choice(np.frombuffer(b"ACGT", dtype=np.uint8), L).tobytes()
+        recs.append(b"@long%d some comment\n" % i + seq + b"\n+\n" + b"F" * L + b"\n")
+    data = b"".join(recs)
+    plain = tmp_path / "l.fq"
+    plain.write_bytes(data)
+    want = H.fastq_digest(plain, batch=7)
+    assert want[0] == 120
+    monkeypatch.setenv("FQTK_NO_MMAP", "1")
+    assert H.fastq_digest(plain, batch=7)[:2] == want[:2]
+    monkeypatch.delenv("FQTK_NO_MMAP")
+    gz = tmp_path / "l.fq.gz"
+    gz.write_bytes(_gz(data, 6))
+    assert H.fastq_digest(gz, batch=5)[:2] == want[:2]
+    monkeypatch.setenv("FQTK_GZ_CHUNK", "50000")
+    monkeypatch.setenv("FQTK_GZ_THREADS", "3")
+    assert H.fastq_digest(gz, batch=11)[:2] == want[:2]
+    bg = tmp_path / "l.bgzf.fq.gz"
+    bg.write_bytes(H.bgzf(data))
+    assert H.fastq_digest(bg, batch=3)[:2] == want[:2]
