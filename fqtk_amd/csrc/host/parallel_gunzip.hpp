@@ -236,6 +236,10 @@ class SpecInflate : public FastInflate {
 
 class ParallelGunzip : public FastInflate {
   public:
+    ~ParallelGunzip() {
+        for (Stage &st : stages_)
+            if (st.driver.joinable()) st.driver.join();
+    }
     // threads: decoders working side by side (>= 2; 1 would be the sequential decoder with extra steps)
     // chunk: compressed bytes per decoder and stretch (2 MiB; tests use small ones to cross many boundaries)
     // head: bytes left free in front of every decoded chunk handed out by take_chunk() (room for the reader to put the
@@ -246,9 +250,14 @@ class ParallelGunzip : public FastInflate {
         chunk_ = std::max<size_t>(chunk, 4096);
         stop_at_block_end_ = true;
         threads_ = std::max(2u, threads);
-        workers_.resize(threads_);
-        for (auto &w : workers_) w.attach(data, n);
-        tasks_.assign(threads_, SpecInflate::Task{});
+        for (Stage &st : stages_) {
+            if (st.driver.joinable()) st.driver.join();
+            st.launched = false;
+            st.workers.resize(threads_);
+            for (auto &w : st.workers) w.attach(data, n);
+            st.tasks.assign(threads_, SpecInflate::Task{});
+        }
+        which_ = 0;
         resolved_.assign(threads_, ByteVec());
         chunk_crc_.assign(threads_, 0);
         emit_chunk_ = emit_off_ = n_ready_ = 0;
@@ -269,8 +278,7 @@ class ParallelGunzip : public FastInflate {
                 continue;
             }
             if (state_ == State::Done) { *n = 0; return true; }
-            if (state_ == State::BlockStart && bit_pos() >= cooldown_bit_ &&
-                (size_t)(data_end_ - data_) - (size_t)(bit_pos() >> 3) > 3 * chunk_) {
+            if (state_ == State::BlockStart && worth_a_stretch(bit_pos())) {
                 if (!stretch(err)) return false;
                 if (n_ready_) continue;
             }
@@ -291,11 +299,60 @@ class ParallelGunzip : public FastInflate {
     }
     uint64_t rounds() const { return rounds_; }
     uint64_t fallbacks() const { return fallbacks_; }
-    const double *seconds() const { return seconds_; }   // find starts, decode, resolve, CRC
+    const double *seconds() const { return seconds_; }   // waiting for the decoders, resolving, CRC
 
     static constexpr size_t kChunk = 2u << 20;   // compressed bytes per chunk
 
   private:
+    // One stretch in flight: where its chunks start and what they decoded.  Two of them take turns, so that the
+    // decoders of the NEXT stretch already run (from the bit this one ended on, known as soon as its chunks have been
+    // checked) while this one is resolved, checksummed and handed out.
+    struct Stage {
+        std::vector<SpecInflate> workers;
+        std::vector<SpecInflate::Task> tasks;
+        std::vector<uint64_t> starts;
+        std::vector<unsigned> order;   // chunks that have a start, in file order
+        uint64_t p0 = 0;
+        bool launched = false;
+        std::thread driver;            // finds the starts, then runs the decoders, and ends
+    };
+
+    bool worth_a_stretch(uint64_t pos) const {
+        return pos >= cooldown_bit_ && (size_t)(data_end_ - data_) - (size_t)(pos >> 3) > 3 * chunk_;
+    }
+
+    void launch(Stage &st, uint64_t p0) {
+        st.p0 = p0;
+        st.launched = true;
+        st.driver = std::thread([this, &st, p0] {
+            const uint64_t file_bits = (uint64_t)(data_end_ - data_) * 8u;
+            const unsigned K = threads_;
+            st.starts.assign(K, ~0ull);
+            st.starts[0] = p0;
+            {   // where the other chunks can start
+                std::vector<std::thread> th;
+                for (unsigned k = 1; k < K; ++k)
+                    th.emplace_back([&, k] {
+                        const uint64_t from = ((p0 >> 3) + (uint64_t)k * chunk_) * 8u;
+                        if (from + 8 * chunk_ / 2 < file_bits) st.starts[k] = st.workers[k].find_block_start(from, from + 8 * chunk_ / 2);
+                    });
+                for (auto &t : th) t.join();
+            }
+            st.order.clear();
+            for (unsigned k = 0; k < K; ++k)
+                if (st.starts[k] != ~0ull) st.order.push_back(k);
+            const uint64_t stretch_end = std::min<uint64_t>(file_bits, ((p0 >> 3) + (uint64_t)K * chunk_) * 8u);
+            std::vector<std::thread> th;
+            for (size_t j = 0; j < st.order.size(); ++j) {
+                SpecInflate::Task &tk = st.tasks[st.order[j]];
+                tk.start_bit = st.starts[st.order[j]];
+                tk.stop_bit = j + 1 < st.order.size() ? st.starts[st.order[j + 1]] : stretch_end;
+                th.emplace_back([&st, j] { st.workers[st.order[j]].run(st.tasks[st.order[j]]); });
+            }
+            for (auto &t : th) t.join();
+        });
+    }
+
     // Decodes the next threads_ chunks side by side; leaves their bytes in resolved_[0 .. n_ready_) and this
     // (sequential) decoder positioned behind the last accepted one.  n_ready_ == 0: nothing accepted.
     bool stretch(std::string *err) {
@@ -305,45 +362,27 @@ class ParallelGunzip : public FastInflate {
         ++rounds_;
         emit_chunk_ = emit_off_ = n_ready_ = 0;
         const uint64_t p0 = bit_pos();
-        const uint64_t file_bits = (uint64_t)(data_end_ - data_) * 8u;
-        const unsigned K = threads_;
-        std::vector<uint64_t> starts(K, ~0ull);
-        starts[0] = p0;
-        {   // where the other chunks can start
-            std::vector<std::thread> th;
-            for (unsigned k = 1; k < K; ++k)
-                th.emplace_back([&, k] {
-                    const uint64_t from = ((p0 >> 3) + (uint64_t)k * chunk_) * 8u;
-                    if (from + 8 * chunk_ / 2 < file_bits) starts[k] = workers_[k].find_block_start(from, from + 8 * chunk_ / 2);
-                });
-            for (auto &t : th) t.join();
+        Stage &st = stages_[which_];
+        if (st.launched && st.p0 != p0) {   // started for a position we did not arrive at (a sequential interlude): void
+            st.driver.join();
+            st.launched = false;
         }
-        lap(0);
-        std::vector<unsigned> order;   // chunks that have a start, in file order
-        for (unsigned k = 0; k < K; ++k)
-            if (starts[k] != ~0ull) order.push_back(k);
-        const uint64_t stretch_end = std::min<uint64_t>(file_bits, ((p0 >> 3) + (uint64_t)K * chunk_) * 8u);
-        {
-            std::vector<std::thread> th;
-            for (size_t j = 0; j < order.size(); ++j) {
-                SpecInflate::Task &tk = tasks_[order[j]];
-                tk.start_bit = starts[order[j]];
-                tk.stop_bit = j + 1 < order.size() ? starts[order[j + 1]] : stretch_end;
-                th.emplace_back([&, j] { workers_[order[j]].run(tasks_[order[j]]); });
-            }
-            for (auto &t : th) t.join();
-        }
+        if (!st.launched) launch(st, p0);
+        st.driver.join();
+        st.launched = false;
+        const std::vector<unsigned> &order = st.order;
+        const std::vector<SpecInflate::Task> &tasks = st.tasks;
         if (std::getenv("FQTK_PG_DEBUG"))
             for (size_t j = 0; j < order.size(); ++j)
-                std::fprintf(stderr, "chunk %zu: %.1f ms, %zu symbols, error %d\n", j, tasks_[order[j]].seconds * 1e3, tasks_[order[j]].n_sym, (int)tasks_[order[j]].error);
-        lap(1);
+                std::fprintf(stderr, "chunk %zu: %.1f ms, %zu symbols, error %d\n", j, tasks[order[j]].seconds * 1e3, tasks[order[j]].n_sym, (int)tasks[order[j]].error);
+        lap(0);
         // the chain of trust: chunk j+1 counts only if chunk j ended exactly where it starts
         size_t accepted = 0;
         for (size_t j = 0; j < order.size(); ++j) {
-            const SpecInflate::Task &tk = tasks_[order[j]];
+            const SpecInflate::Task &tk = tasks[order[j]];
             if (tk.error) break;
             ++accepted;
-            if (tk.final_block || j + 1 == order.size() || tk.end_bit != starts[order[j + 1]]) break;
+            if (tk.final_block || j + 1 == order.size() || tk.end_bit != st.starts[order[j + 1]]) break;
         }
         if (accepted < order.size()) {
             // something did not line up (no start where one was believed, a chunk that expands beyond reason, damage):
@@ -352,6 +391,9 @@ class ParallelGunzip : public FastInflate {
             cooldown_bit_ = p0 + 8ull * 4 * chunk_;
         }
         if (accepted == 0) return true;   // the sequential decoder goes on from here (and reports damage, if that is what it was)
+        const SpecInflate::Task &last = tasks[order[accepted - 1]];
+        // the next stretch starts decoding now, from the bit this one ended on
+        if (accepted == order.size() && !last.final_block && worth_a_stretch(last.end_bit)) launch(stages_[which_ ^ 1], last.end_bit);
         // windows down the line, then every chunk to bytes
         std::vector<std::vector<uint8_t>> windows(accepted + 1, std::vector<uint8_t>(32768, 0));
         {
@@ -359,7 +401,7 @@ class ParallelGunzip : public FastInflate {
             std::memcpy(windows[0].data() + 32768 - have, obuf_.data() + hist_ - have, have);
         }
         for (size_t j = 0; j < accepted; ++j) {   // the last 32 KiB of chunk j, resolved = the window of chunk j + 1
-            const SpecInflate::Task &tk = tasks_[order[j]];
+            const SpecInflate::Task &tk = tasks[order[j]];
             const size_t tail = std::min<size_t>(tk.n_sym, 32768);
             std::vector<uint8_t> &w = windows[j + 1];
             if (tail < 32768) std::memcpy(w.data(), windows[j].data() + tail, 32768 - tail);
@@ -369,34 +411,34 @@ class ParallelGunzip : public FastInflate {
             std::vector<std::thread> th;
             for (size_t j = 0; j < accepted; ++j)
                 th.emplace_back([&, j] {
-                    const SpecInflate::Task &tk = tasks_[order[j]];
+                    const SpecInflate::Task &tk = tasks[order[j]];
                     resolved_[j].resize(head_ + tk.n_sym);
                     SpecInflate::resolve(tk.sym.data(), tk.n_sym, windows[j].data(), reinterpret_cast<uint8_t *>(resolved_[j].data()) + head_);
                     chunk_crc_[j] = crc_fn_(0, resolved_[j].data() + head_, tk.n_sym);   // folded into the member's CRC below
                 });
             for (auto &t : th) t.join();
         }
-        lap(2);
+        lap(1);
         for (size_t j = 0; j < accepted; ++j) {
             crc_ = (uint32_t)crc32_combine(crc_, chunk_crc_[j], (z_off_t)(resolved_[j].size() - head_));
             isize_ += (uint32_t)(resolved_[j].size() - head_);
         }
-        lap(3);
+        lap(2);
         n_ready_ = accepted;
         // carry on behind the last accepted chunk, with its window as history
-        const SpecInflate::Task &last = tasks_[order[accepted - 1]];
         std::memcpy(obuf_.data(), windows[accepted].data(), 32768);
         hist_ = 32768;
         if (!seek_bit(last.end_bit, err)) return false;
         final_block_ = last.final_block;
         state_ = last.final_block ? State::Trailer : State::BlockStart;
+        which_ ^= 1;
         return true;
     }
 
     unsigned threads_ = 2;
     size_t chunk_ = kChunk;
-    std::vector<SpecInflate> workers_;
-    std::vector<SpecInflate::Task> tasks_;
+    Stage stages_[2];
+    int which_ = 0;
     std::vector<ByteVec> resolved_;
     size_t head_ = 0;
     std::vector<uint32_t> chunk_crc_;
