@@ -1030,14 +1030,22 @@ int main(int argc, char **argv) {
     bool distinct = true;
     for (size_t a = 0; a < G; ++a)
         for (size_t b = 0; b < a; ++b) distinct = distinct && opt.devices[a] != opt.devices[b];
+    bool reduced = false;
     if (G > 1 && distinct) {
-        // the one collective of the path: per-device count vectors summed with RCCL over xGMI
-        if (fqtk_matchers_allreduce_counts(matchers.data(), (int)G, 0, counts.data()) != FQTK_OK) die(fqtk_last_error());
-        info("Per-sample counts all-reduced over %zu devices (RCCL).", G);
-    } else {
-        for (fqtk_matcher *mt : matchers)   // one device (or the same one repeated): fqtk_matcher_counts ADDS into `counts`
-            if (fqtk_matcher_counts(mt, counts.data()) != FQTK_OK) die(fqtk_last_error());
+        // the one collective of the path: per-device count vectors summed with RCCL over xGMI.  A box
+        // without librccl, or a failing collective, must not cost a finished run its outputs: the accumulators are
+        // only reset on success, so the host-side sum below still sees them.
+        if (fqtk_matchers_allreduce_counts(matchers.data(), (int)G, 0, counts.data()) == FQTK_OK) {
+            reduced = true;
+            info("Per-sample counts all-reduced over %zu devices (RCCL).", G);
+        } else {
+            info("RCCL all-reduce of the per-sample counts unavailable (%s): summing the per-device counts on the host.", fqtk_last_error());
+            std::fill(counts.begin(), counts.end(), 0);
+        }
     }
+    if (!reduced)
+        for (fqtk_matcher *mt : matchers)   // fqtk_matcher_counts ADDS into `counts`
+            if (fqtk_matcher_counts(mt, counts.data()) != FQTK_OK) die(fqtk_last_error());
     uint64_t sum = 0;
     for (uint64_t c : counts) sum += c;
     if (sum != total_templates) die("internal error: device counts do not add up to the number of templates");

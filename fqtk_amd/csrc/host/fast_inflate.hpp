@@ -48,13 +48,13 @@ class FastInflate {
     using CrcFn = uint32_t (*)(uint32_t, const void *, size_t);
 
     // `data` must stay valid (a mapping) until the last next().
-    void open(const uint8_t *data, size_t n, CrcFn crc) {
+    void open(const uint8_t *data, size_t n, CrcFn crc, bool with_output = true) {
         data_ = data;
         data_end_ = data + n;
         in_end_ = data + n;
         ip_ = data;
         crc_fn_ = crc;
-        obuf_.assign(kWindow + kPiece + kSlack, 0);
+        if (with_output) obuf_.assign(kWindow + kPiece + kSlack, 0);
         hist_ = 0;
         state_ = State::Header;
         bb_ = 0;
@@ -147,14 +147,18 @@ class FastInflate {
     // ---- bit input ------------------------------------------------------------------------------------------
     // The last bytes of the file are decoded from a zero-padded copy, so that the 8-byte refill never reads past
     // the mapping; `ip_` then points into tail_.
+    // The bit buffer may still hold up to 7 bytes fetched before `ip_` (align_to_byte() hands them back), so the
+    // copy keeps kTailBack bytes of history in front of the switch point.
     void guard_tail() {
         if (tail_active_ || in_end_ - ip_ >= (ptrdiff_t)kTailAt) return;
         const size_t left = (size_t)(in_end_ - ip_);
+        const size_t have = (size_t)(ip_ - data_);
+        const size_t back = have < kTailBack ? have : kTailBack;
         std::memset(tail_, 0, sizeof tail_);
-        std::memcpy(tail_, ip_, left);
-        tail_origin_ = ip_;
-        ip_ = tail_;
-        in_end_ = tail_ + left;
+        std::memcpy(tail_ + kTailBack - back, ip_ - back, left + back);
+        tail_origin_off_ = (ptrdiff_t)(ip_ - data_) - (ptrdiff_t)kTailBack;   // where tail_[0] sits in the mapping
+        ip_ = tail_ + kTailBack;
+        in_end_ = tail_ + kTailBack + left;
         tail_active_ = true;
     }
     static uint64_t load64(const uint8_t *p) {
@@ -194,8 +198,8 @@ class FastInflate {
 
     // Position of the next unconsumed bit, in bits from the start of the mapping.
     uint64_t bit_pos() const {
-        const uint8_t *real = tail_active_ ? tail_origin_ + (ip_ - tail_) : ip_;
-        return (uint64_t)(real - data_) * 8u - bc_;
+        const ptrdiff_t off = tail_active_ ? tail_origin_off_ + (ip_ - tail_) : ip_ - data_;
+        return (uint64_t)off * 8u - bc_;
     }
     // Continue at bit `pos` of the mapping (a block boundary).
     bool seek_bit(uint64_t pos, std::string *err) {
@@ -573,12 +577,12 @@ class FastInflate {
         return true;
     }
 
-    static constexpr size_t kTailAt = 64;
+    static constexpr size_t kTailAt = 64, kTailBack = 8;
     static constexpr uint32_t kLitCap = (1u << kLitBits) + 2048, kDistCap = (1u << kDistBits) + 1024;
 
     const uint8_t *in_end_ = nullptr, *ip_ = nullptr;
     const uint8_t *data_ = nullptr, *data_end_ = nullptr;   // the whole mapping
-    const uint8_t *tail_origin_ = nullptr;                   // where tail_[0] sits in the mapping
+    ptrdiff_t tail_origin_off_ = 0;                          // offset of tail_[0] in the mapping (may be negative)
     bool at_boundary_ = false;                               // the last next() ended exactly at a block / member end
     bool stop_at_block_end_ = false;                         // next() hands back control after every block
     CrcFn crc_fn_ = nullptr;
@@ -591,7 +595,7 @@ class FastInflate {
     size_t stored_left_ = 0;
     uint32_t crc_ = 0, isize_ = 0;
     uint64_t members_ = 0;
-    uint8_t tail_[kTailAt + 64];
+    uint8_t tail_[kTailBack + kTailAt + 64];
     uint32_t lit_[kLitCap], dist_[kDistCap];
 };
 

@@ -130,6 +130,8 @@ class FastqSource {
         if (producer_.joinable()) producer_.join();
         for (auto &t : helpers_) if (t.joinable()) t.join();
         if (gz_) gzclose(gz_);
+        pgz_.reset();   // their decoder threads read the mapping: gone before it is
+        fast_.reset();
         if (gz_map_) munmap(const_cast<uint8_t *>(gz_map_), gz_map_size_);   // compressed bytes: nothing points into them
         if (fd_ >= 0) ::close(fd_);
         // a mapping stays for the life of the process: record batches point into it
@@ -396,7 +398,7 @@ class FastqSource {
         producer_ = std::thread([this] {
             for (;;) {
                 Piece pc;
-                bool more = kind_ == Kind::Plain ? produce_plain(pc) : (kind_ == Kind::Gzip ? produce_gzip(pc) : produce_bgzf(pc));
+                bool more = kind_ == Kind::Plain ? produce_plain(pc) : (kind_ == Kind::Gzip || streaming_ ? produce_gzip(pc) : produce_bgzf(pc));
                 const bool last = !more || !pc.error.empty() || pc.eof;
                 push(std::move(pc));
                 {
@@ -457,11 +459,12 @@ class FastqSource {
         return true;
     }
     // ---- BGZF: read a group of whole members, inflate them in parallel into one piece --------------------
-    struct Block { size_t in_off, in_len, out_off, out_len; };
+    struct Block { size_t in_off, in_len, out_off, out_len; uint32_t crc; };
     bool produce_bgzf(Piece &pc) {
         // top the compressed buffer up, then cut it at member boundaries (header: 18 bytes, BSIZE at 16)
         if (!craw_eof_ && craw_.size() - cpos_ < kPiece) {
             craw_.erase(craw_.begin(), craw_.begin() + (std::ptrdiff_t)cpos_);
+            craw_file_off_ += cpos_;
             cpos_ = 0;
             const size_t old = craw_.size();
             craw_.resize(old + kPiece);
@@ -474,7 +477,13 @@ class FastqSource {
         size_t p = cpos_, out_total = 0;
         while (p + 18 <= craw_.size() && out_total < kPiece) {
             const uint8_t *h = craw_.data() + p;
-            if (h[0] != 0x1f || h[1] != 0x8b || h[12] != 'B' || h[13] != 'C') {
+            if (h[0] != 0x1f || h[1] != 0x8b || h[2] != 8 || !(h[3] & 4) || h[10] != 6 || h[11] != 0 || h[12] != 'B' || h[13] != 'C') {
+                if (h[0] == 0x1f && h[1] == 0x8b) {
+                    // an ordinary gzip member behind the BGZF ones (gzread and the reference's reader take the file as
+                    // one multi-member stream): what was cut so far goes out, the rest through the streaming decoder
+                    if (blocks_.empty()) return switch_to_stream(p, pc);
+                    break;
+                }
                 pc.error = "Unexpected error parsing FASTQs: not a BGZF member at compressed offset in " + path_;
                 return false;
             }
@@ -483,7 +492,9 @@ class FastqSource {
             if (p + bsize > craw_.size()) break;
             const uint8_t *t = h + bsize - 4;
             const size_t isize = (size_t)t[0] | ((size_t)t[1] << 8) | ((size_t)t[2] << 16) | ((size_t)t[3] << 24);
-            blocks_.push_back(Block{p + 18, bsize - 26, out_total, isize});
+            if (isize > 65536) { pc.error = "Unexpected error parsing FASTQs: BGZF member larger than 64 KiB in " + path_; return false; }
+            const uint32_t crc = (uint32_t)t[-4] | ((uint32_t)t[-3] << 8) | ((uint32_t)t[-2] << 16) | ((uint32_t)t[-1] << 24);
+            blocks_.push_back(Block{p + 18, bsize - 26, out_total, isize, crc});
             out_total += isize;
             p += bsize;
         }
@@ -518,6 +529,25 @@ class FastqSource {
         }
         return true;
     }
+    // BGZF members followed by an ordinary gzip member at craw_[p]: map the file and decode from there on with the
+    // streaming decoder (produce_gzip's path).
+    bool switch_to_stream(size_t p, Piece &pc) {
+        const size_t abs = craw_file_off_ + p;
+        struct stat st;
+        void *m = MAP_FAILED;
+        if (fstat(fd_, &st) == 0 && S_ISREG(st.st_mode) && (size_t)st.st_size > abs)
+            m = mmap(nullptr, (size_t)st.st_size, PROT_READ, MAP_PRIVATE, fd_, 0);
+        if (m == MAP_FAILED) {
+            pc.error = "Unexpected error parsing FASTQs: not a BGZF member at compressed offset in " + path_;
+            return false;
+        }
+        gz_map_ = static_cast<const uint8_t *>(m);
+        gz_map_size_ = (size_t)st.st_size;
+        fast_.reset(new FastInflate());
+        fast_->open(gz_map_ + abs, gz_map_size_ - abs, &FastqSource::crc32_fn);
+        streaming_ = true;
+        return produce_gzip(pc);
+    }
     void work(BlockInflater &inf) {
         size_t done = 0;
         bool failed = false;
@@ -525,7 +555,9 @@ class FastqSource {
             const size_t i = job_next_.fetch_add(1);
             if (i >= job_size_.load()) break;
             const Block &b = blocks_[i];
-            if (!inf.inflate_block(craw_.data() + b.in_off, b.in_len, job_out_ + b.out_off, b.out_len)) failed = true;
+            if (!inf.inflate_block(craw_.data() + b.in_off, b.in_len, job_out_ + b.out_off, b.out_len) ||
+                crc32_fn(0, job_out_ + b.out_off, b.out_len) != b.crc)
+                failed = true;
             ++done;
         }
         if (done || failed) {
@@ -593,8 +625,9 @@ class FastqSource {
     unsigned n_helpers_ = 0;
     std::vector<std::thread> helpers_;
     std::vector<uint8_t> craw_;
-    size_t cpos_ = 0;
+    size_t cpos_ = 0, craw_file_off_ = 0;   // craw_[0] is byte craw_file_off_ of the file
     bool craw_eof_ = false;
+    bool streaming_ = false;                // an ordinary gzip member followed the BGZF ones: fast_ decodes the rest
     std::vector<Block> blocks_;
     BlockInflater own_inflater_;
     uint8_t *job_out_ = nullptr;

@@ -29,6 +29,8 @@
 
 #include <zlib.h>   // crc32_combine
 
+#include "env.hpp"
+
 #include "fast_inflate.hpp"
 
 namespace fqtk_host {
@@ -48,7 +50,8 @@ class SpecInflate : public FastInflate {
     // stretch then ends before it and the sequential decoder, which works in 4 MiB pieces, takes over for a while).
     static constexpr size_t kMaxSymbols = 48u << 20;
 
-    void attach(const uint8_t *data, size_t n) { open(data, n, nullptr); }
+    // (a speculative decoder writes 16-bit symbols into its task, never into obuf_: no 4 MiB output buffer per worker)
+    void attach(const uint8_t *data, size_t n) { open(data, n, nullptr, /*with_output=*/false); }
 
     // First bit position in [from, limit) where a non-final dynamic-Huffman block header parses; ~0 if none.
     uint64_t find_block_start(uint64_t from, uint64_t limit) {
@@ -372,7 +375,7 @@ class ParallelGunzip : public FastInflate {
         st.launched = false;
         const std::vector<unsigned> &order = st.order;
         const std::vector<SpecInflate::Task> &tasks = st.tasks;
-        if (std::getenv("FQTK_PG_DEBUG"))
+        if (env_on("FQTK_PG_DEBUG"))
             for (size_t j = 0; j < order.size(); ++j)
                 std::fprintf(stderr, "chunk %zu: %.1f ms, %zu symbols, error %d\n", j, tasks[order[j]].seconds * 1e3, tasks[order[j]].n_sym, (int)tasks[order[j]].error);
         lap(0);

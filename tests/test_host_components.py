@@ -449,3 +449,106 @@ def test_records_longer_than_a_piece_s_head_room(tmp_path, monkeypatch):
     bg = tmp_path / "l.bgzf.fq.gz"
     bg.write_bytes(H.bgzf(data))
     assert H.fastq_digest(bg, batch=3)[:2] == want[:2]
+
+
+# ---- members / stored blocks that end inside the decoder's last 64 bytes ------------------------
+def test_gunzip_small_members_and_stored_blocks_near_the_end_of_the_file():
+    """The decoder switches to a padded copy of the file's last 64 bytes; its bit buffer may still hold bytes from
+    before the switch.  A trailer or a stored-block header right behind the switch point used to be read from the
+    wrong place ('CRC mismatch' on valid files)."""
+    import numpy as np
+    rng = np.random.default_rng(11)
+    big = (b"ACGTACGTTTGA" * 420)[:5000]
+    for tail_len in list(range(0, 40)) + [60, 100, 200]:
+        tail = bytes(rng.choice(list(b"ACGT"), tail_len).astype(np.uint8))
+        for lvl in (1, 6, 9):
+            m1, m2 = _gz(big, lvl), _gz(tail, lvl)
+            assert 18 <= len(m2) <= 250
+            want = big + tail
+            assert H.gunzip(m1 + m2) == want
+            assert H.gunzip(m1 + m2 + m2) == want + tail
+            got, _, _ = H.gunzip_parallel(m1 + m2, threads=3, chunk=20_000)
+            assert got == want
+    # stored blocks (level 0) whose headers land near the end
+    for n in (0, 1, 5, 30, 50, 58, 59, 60, 61, 70):
+        d = bytes(rng.integers(0, 256, n, dtype=np.uint8))
+        assert H.gunzip(_gz(big, 6) + _gz(d, 0)) == big + d
+        # a deflate stream that ends with an empty stored block (Z_SYNC_FLUSH) then the final block
+        c = zlib.compressobj(6, zlib.DEFLATED, 31)
+        body = c.compress(big) + c.flush(zlib.Z_SYNC_FLUSH) + c.compress(d) + c.flush(zlib.Z_FULL_FLUSH) + c.flush()
+        assert H.gunzip(body) == big + d
+
+
+def test_gunzip_fuzz_against_zlib_many_member_shapes():
+    import numpy as np
+    rng = np.random.default_rng(5)
+    for _ in range(60):
+        members, want = [], b""
+        for _ in range(int(rng.integers(1, 5))):
+            n = int(rng.choice([0, 1, 7, 40, 300, 5000, 70_000]))
+            d = bytes(rng.choice(list(b"ACGTN\n@+I"), n).astype(np.uint8))
+            members.append(_gz(d, int(rng.integers(0, 10))))
+            want += d
+        blob = b"".join(members)
+        assert H.gunzip(blob) == want
+        assert zlib.decompressobj(31).decompress(members[0]) == want[:len(zlib.decompress(members[0], 31))]
+
+
+def _bgzf_members(data, level=6, block=60_000):
+    out = []
+    for i in range(0, max(len(data), 1), block):
+        d = data[i:i + block]
+        c = zlib.compressobj(level, zlib.DEFLATED, -15)
+        body = c.compress(d) + c.flush()
+        bsize = 18 + len(body) + 8
+        out.append(bytes([0x1f, 0x8b, 8, 4, 0, 0, 0, 0, 0, 0xff, 6, 0, 0x42, 0x43, 2, 0]) + struct.pack("<H", bsize - 1) +
+                   body + struct.pack("<II", zlib.crc32(d), len(d)))
+    return out
+
+
+def test_bgzf_reader_checks_crc_and_isize_and_takes_a_plain_member_behind_bgzf_ones(tmp_path):
+    text = b"".join(b"@r%d\nACGTACGTAC\n+\nIIIIIIIIII\n" % i for i in range(20_000))
+    members = _bgzf_members(text)
+    eof = bytes.fromhex("1f8b08040000000000ff0600424302001b0003000000000000000000")
+    good = tmp_path / "good.fq.gz"
+    good.write_bytes(b"".join(members) + eof)
+    n, dig, kind = H.fastq_digest(good)
+    assert (n, kind) == (20_000, 2)
+    # a forged CRC field is an error (python's gzip and the reference's flate2 reader reject the same file)
+    m = bytearray(members[1])
+    m[-8] ^= 0x55
+    bad = tmp_path / "badcrc.fq.gz"
+    bad.write_bytes(members[0] + bytes(m) + b"".join(members[2:]) + eof)
+    with pytest.raises(ValueError, match="corrupt BGZF block"):
+        H.fastq_digest(bad)
+    with pytest.raises(Exception):
+        gzip.decompress(bad.read_bytes())
+    # ISIZE beyond what a BGZF member may hold: an error, not a 4 GiB allocation
+    m = bytearray(members[1])
+    m[-4:] = struct.pack("<I", 0xFFFFFFF0)
+    bad.write_bytes(members[0] + bytes(m) + eof)
+    with pytest.raises(ValueError, match="64 KiB"):
+        H.fastq_digest(bad)
+    # BGZF members followed by an ordinary gzip member: one multi-member stream to gzread and to the reference
+    more = b"".join(b"@s%d\nTTTTGGGGCC\n+\nIIIIIIIIII\n" % i for i in range(3000))
+    mixed = tmp_path / "mixed.fq.gz"
+    mixed.write_bytes(b"".join(members) + gzip.compress(more, mtime=0))
+    plain = tmp_path / "all.fq"
+    plain.write_bytes(text + more)
+    assert gzip.decompress(mixed.read_bytes()) == text + more
+    n2, dig2, kind2 = H.fastq_digest(mixed)
+    n3, dig3, _ = H.fastq_digest(plain)
+    assert (n2, dig2, kind2) == (n3, dig3, 2) and n2 == 23_000
+
+
+def test_reader_teardown_after_a_parse_error_mid_file_with_parallel_decoders(tmp_path, monkeypatch):
+    """The decoder threads read the mapping of the compressed file: it must outlive them."""
+    recs = [b"@r%d\nACGTACGTACGTACGTACGT\n+\nIIIIIIIIIIIIIIIIIIII\n" % i for i in range(120_000)]
+    recs[60_000] = b"@broken\nACGT\n+\nII\n"
+    p = tmp_path / "broken.fq.gz"
+    p.write_bytes(gzip.compress(b"".join(recs), 1, mtime=0))
+    monkeypatch.setenv("FQTK_GZ_THREADS", "4")
+    monkeypatch.setenv("FQTK_GZ_CHUNK", "65536")
+    for _ in range(5):
+        with pytest.raises(ValueError, match="lengths differ"):
+            H.fastq_digest(p, batch=1000)
