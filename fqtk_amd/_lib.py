@@ -23,6 +23,27 @@ class fqtk_bgzf_block(C.Structure):   # include/fqtk_bgzf.h
 FQTK_BGZF_MAX_IN, FQTK_BGZF_OUT_STRIDE, FQTK_BGZF_SLOTS = 65280, 65536, 4
 
 
+# include/fqtk_demux.h
+class fqtk_demux_segment(C.Structure):
+    _fields_ = [("offset", C.c_uint32), ("length", C.c_int32), ("kind", C.c_char)]
+
+
+class fqtk_demux_config(C.Structure):
+    _fields_ = [("n_inputs", C.c_uint32), ("n_segments", C.POINTER(C.c_uint32)),
+                ("segments", C.POINTER(fqtk_demux_segment)), ("want", C.c_uint8 * 4),
+                ("skip_too_few_bases", C.c_int), ("max_chunk_templates", C.c_uint32), ("carry_blocks", C.c_int),
+                ("compression_level", C.c_int)]
+
+
+class fqtk_demux_result(C.Structure):
+    _fields_ = [("bytes", C.c_void_p), ("file_off", C.POINTER(C.c_uint64)), ("n_files", C.c_uint64),
+                ("n_blocks", C.c_uint64), ("n_templates", C.c_uint32), ("n_skipped", C.c_uint32), ("error", C.c_int),
+                ("error_input", C.c_uint32), ("error_template", C.c_uint32), ("error_detail", C.c_uint32)]
+
+
+FQTK_DEMUX_SLOTS, FQTK_DEMUX_STAGES = 3, 8
+
+
 _lib = None
 _hip_preloaded = False
 
@@ -85,6 +106,16 @@ SIGNATURES = [
     ("fqtk_bgzf_destroy", None, [C.c_void_p]),
     ("fqtk_bgzf_deflate_enqueue", C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_uint32, C.c_void_p]),
     ("fqtk_bgzf_wait", C.c_int, [C.c_void_p, C.c_int]),
+    # include/fqtk_demux.h
+    ("fqtk_demuxer_create", C.c_int, [C.c_void_p, C.POINTER(fqtk_demux_config), C.POINTER(C.c_void_p)]),
+    ("fqtk_demuxer_destroy", None, [C.c_void_p]),
+    ("fqtk_demuxer_files_per_sample", C.c_uint32, [C.c_void_p]),
+    ("fqtk_demuxer_submit", C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_uint64), C.c_uint32]),
+    ("fqtk_demuxer_collect", C.c_int, [C.c_void_p, C.c_int, C.POINTER(fqtk_demux_result)]),
+    ("fqtk_demuxer_flush", C.c_int, [C.c_void_p, C.POINTER(fqtk_demux_result)]),
+    ("fqtk_demuxer_counts", C.c_int, [C.c_void_p, C.c_void_p]),
+    ("fqtk_demuxer_stage_seconds", C.c_int, [C.c_void_p, C.POINTER(C.c_double)]),
+    ("fqtk_demuxer_stage_name", C.c_char_p, [C.c_int]),
 ]
 
 

@@ -80,6 +80,13 @@ struct Shared {
     uint32_t freq_cl[kNumCl];
     uint16_t code_cl[kNumCl];
     uint8_t len_cl[kNumCl];
+    // CRC-32 of the block's bytes (the BGZF trailer): byte table, x^(8 * kChunk * j) and x^(8 * r) mod the CRC polynomial
+    // (built once per workgroup by crc_tables(), they survive the blocks), the lanes' partial values
+    uint32_t crc_tab[256];
+    uint32_t crc_pow_chunk[kLanes];
+    uint32_t crc_pow_byte[kChunk + 1];
+    uint32_t crc_part[kLanes];
+    uint32_t crc;
 };
 
 // ---- symbol arithmetic (RFC 1951 3.2.5), computed rather than tabulated -------------------------------------
@@ -214,6 +221,62 @@ FQTK_HD inline void canonical_codes(Shared &S, const uint8_t *len, int n, int ma
     uint32_t c = 0;
     for (int b = 1; b <= max_bits; ++b) { c = (c + bl_count[b - 1]) << 1; next_code[b] = c; }
     for (int i = 0; i < n; ++i) code[i] = len[i] ? (uint16_t)reverse_bits(next_code[len[i]]++, len[i]) : 0;
+}
+
+// ---- CRC-32 of the block (RFC 1952 8.; the reflected polynomial 0xEDB88320) ---------------------------------------------
+// Every lane takes the CRC of its own slice; CRC(A || B) = CRC(A) * x^(8 |B|) + CRC(B) over GF(2) modulo the polynomial,
+// so the slices' values, each multiplied by x^(8 * bytes behind it), XOR to the CRC of the block.  Polynomials are held
+// the way the CRC register holds them: bit 31 is the coefficient of x^0.
+FQTK_HD inline uint32_t crc_gf_mul(uint32_t a, uint32_t b) {
+    uint32_t p = 0;
+    for (int i = 0; i < 32; ++i) {
+        if (a & 0x80000000u) p ^= b;
+        a <<= 1;
+        b = (b & 1u) ? (b >> 1) ^ 0xEDB88320u : (b >> 1);   // b * x
+    }
+    return p;
+}
+FQTK_HD inline uint32_t crc_x_pow(uint32_t nbits) {   // x^nbits
+    uint32_t r = 0x80000000u, base = 0x40000000u;
+    for (uint32_t e = nbits; e; e >>= 1) {
+        if (e & 1u) r = crc_gf_mul(r, base);
+        base = crc_gf_mul(base, base);
+    }
+    return r;
+}
+// once per workgroup (all lanes; a barrier must follow)
+FQTK_HD inline void crc_tables(Shared &S, int lane) {
+    if (lane < 256) {
+        uint32_t c = (uint32_t)lane;
+        for (int k = 0; k < 8; ++k) c = (c & 1u) ? (c >> 1) ^ 0xEDB88320u : (c >> 1);
+        S.crc_tab[lane] = c;
+    }
+    S.crc_pow_chunk[lane] = crc_x_pow(8u * kChunk * (uint32_t)lane);
+    for (uint32_t r = (uint32_t)lane; r <= kChunk; r += kLanes) S.crc_pow_byte[r] = crc_x_pow(8u * r);
+}
+// after phase_load (the block is in S.buf); a barrier, then phase_crc_fold by one lane
+FQTK_HD inline void phase_crc(Shared &S, int lane, uint32_t n) {
+    const uint8_t *b = reinterpret_cast<const uint8_t *>(S.buf);
+    const uint32_t lo = (uint32_t)lane * kChunk;
+    uint32_t part = 0;
+    if (lo < n) {
+        const uint32_t hi = lo + kChunk < n ? lo + kChunk : n;
+        uint32_t c = 0xFFFFFFFFu;
+        for (uint32_t p = lo; p < hi; ++p) c = S.crc_tab[(c ^ b[p]) & 0xFFu] ^ (c >> 8);
+        c = ~c;
+        if (hi < n) {   // bytes behind this slice: whole slices of the lanes between it and the last one, then the last one's
+            const uint32_t last = (n - 1u) / kChunk;
+            c = crc_gf_mul(c, S.crc_pow_chunk[last - 1u - (uint32_t)lane]);
+            c = crc_gf_mul(c, S.crc_pow_byte[n - last * kChunk]);
+        }
+        part = c;
+    }
+    S.crc_part[lane] = part;
+}
+FQTK_HD inline void phase_crc_fold(Shared &S) {
+    uint32_t c = 0;
+    for (int l = 0; l < kLanes; ++l) c ^= S.crc_part[l];
+    S.crc = c;
 }
 
 // ---- the phases ----------------------------------------------------------------------------------------------------

@@ -1,0 +1,634 @@
+// demux_kernels.hip.h -- gfx950 kernels of the record pipeline (include/fqtk_demux.h): FASTQ text in HBM ->
+// line index -> records -> barcode rows -> [matcher] -> placement of every output record by stable per-file prefix
+// sums -> records copied into 65 280-byte blocks -> [DEFLATE kernel] -> BGZF members packed per output file.
+//
+// All of it is byte / integer work bound by HBM or by latency, none of it is a contraction: no MFMA.  One wavefront is
+// 64 lanes; where lanes cooperate on one record they do so as a wave (k_format), otherwise one lane owns one template.
+// Reference semantics: ReadSetIterator::next /root/reference/src/bin/commands/demux.rs:285-343 (records, too-few-bases),
+// ReadSet::sample_barcode_sequence :121-123 (barcode rows), SampleWriters::write :396-415 + write_header_internal
+// :171-267 (record text; stated once in record_format.hpp), DemuxMetric counting :970-974 (the count column).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/fqtk_demux.h"
+#include "../../include/fqtk_bgzf.h"
+#include "record_format.hpp"
+
+namespace fqtk {
+namespace demux {
+
+constexpr uint32_t kBlock = FQTK_BGZF_MAX_IN;   // uncompressed bytes of a BGZF block (as the bgzf crate cuts them)
+constexpr uint32_t kSlab = 65536;               // bytes a block occupies in HBM
+constexpr uint32_t kTile = 1024;                // templates ranked together (one workgroup)
+constexpr uint32_t kRankGroup = 2;              // output files ranked per pass over a tile (LDS: 4 KiB each + 4 KiB of keys)
+constexpr uint32_t kLineTile = 4096;            // bytes of text per workgroup of the line index (256 lanes x 16 B)
+constexpr uint32_t kMaxSegs = 24;               // sample- / molecular-barcode segments over all inputs
+constexpr uint32_t kPersist = 3;                // persistent slabs per output file, used in rotation (see FileState)
+constexpr unsigned long long kNoError = ~0ull;
+
+struct RecView { uint32_t head_off, head_len, seq_off, seq_len, qual_off; };   // head: after the '@'
+
+// What the kernels need to know of the run (kernel argument: lives in SGPRs / the scalar cache).
+struct DevConfig {
+    uint32_t n_inputs, n_b, n_m, n_files;     // n_files: output files per sample
+    uint32_t n_samples, barcode_len;
+    uint32_t fixed_bc_len, variable_bc;       // sample-barcode layout: sum of the fixed B segments; a '+B' exists
+    uint32_t skip_short, use_lens;
+    uint32_t min_len[FQTK_DEMUX_MAX_INPUTS];
+    fmt::SegPos bseg[kMaxSegs], mseg[kMaxSegs];
+    fmt::FileSeg fseg[FQTK_DEMUX_MAX_FILES];
+};
+
+struct TextSet {
+    const uint8_t *text[FQTK_DEMUX_MAX_INPUTS];
+    uint32_t len[FQTK_DEMUX_MAX_INPUTS];
+    uint32_t *tile_cnt[FQTK_DEMUX_MAX_INPUTS];   // newlines per 4 KiB tile, then their exclusive prefix sum
+    uint32_t *ls[FQTK_DEMUX_MAX_INPUTS];         // line starts: ls[k] = offset of line k; 4N + 1 entries
+    RecView *rec[FQTK_DEMUX_MAX_INPUTS];
+};
+
+// Device-side status of one chunk (copied to page-locked memory at the end of the chunk).
+struct ChunkStatus {
+    unsigned long long err_key;       // lowest (template << 24 | stage << 20 | input << 8 | kind), ~0 = none
+    unsigned long long matcher_err;   // the matcher's latched length error (read index), ~0 = none
+    unsigned long long total_bytes;   // packed BGZF members
+    uint32_t n_lines[FQTK_DEMUX_MAX_INPUTS];
+    uint32_t n_blocks, n_skipped, max_bc_len, pad;
+};
+__device__ inline void report(ChunkStatus *st, uint32_t t, uint32_t stage, uint32_t input, uint32_t kind) {
+    atomicMin(&st->err_key, ((unsigned long long)t << 24) | ((unsigned long long)stage << 20) | ((unsigned long long)input << 8) | kind);
+}
+
+// the line index did not come out as 4 lines per template: k_records wrote nothing, nothing downstream may run
+__device__ inline bool no_records(const ChunkStatus *st) {
+    const unsigned long long e = st->err_key;
+    return e != kNoError && (e >> 20) == 0 && (e & 0xFFu) == FQTK_DEMUX_ERR_LINES;
+}
+
+// Per output file (column c = sample * n_files + f), kept across chunks.
+// A file's open (partly filled) block lives in one of kPersist slabs of its own; when a chunk closes it, the next open
+// block starts in the next slab of the rotation -- so the compressor may still be reading the closed one (and the one
+// closed a chunk earlier) while the next chunk is being formatted.
+struct FileState {
+    uint32_t rem;   // bytes in the file's open block
+    uint32_t par;   // which persistent slab holds it
+};
+__host__ __device__ inline uint32_t next_slab(uint32_t par) { return par + 1u == kPersist ? 0u : par + 1u; }
+// Per output file, for one chunk.
+struct FileChunk {
+    uint32_t rem;        // open bytes when the chunk started
+    uint32_t nb;         // blocks this chunk closes (65 280 bytes each)
+    uint32_t n_emit;     // blocks it hands to the compressor: nb, + 1 when the open rest is flushed
+    uint32_t blk_base;   // index of its first block in the chunk's block list
+    uint32_t slab_base;  // first of its nb - 1 chunk slabs
+    uint32_t par;        // persistent slab of the block open at the start (the next open one: next_slab(par))
+    uint32_t new_rem;    // open bytes after the chunk (before a flush empties them)
+    uint32_t pad;
+};
+
+// Where byte `q` (counted from the start of the block that was open when the chunk began) of file `c` lives.
+__device__ inline uint8_t *file_byte(const FileChunk &fc, uint32_t c, uint32_t q, uint8_t *persist, uint8_t *slabs) {
+    const uint32_t kth = q / kBlock, r = q - kth * kBlock;
+    uint8_t *base;
+    if (kth == 0) base = persist + ((size_t)c * kPersist + fc.par) * kSlab;
+    else if (kth < fc.nb) base = slabs + (size_t)(fc.slab_base + kth - 1) * kSlab;
+    else base = persist + ((size_t)c * kPersist + next_slab(fc.par)) * kSlab;
+    return base + r;
+}
+__device__ inline uint8_t *block_base(const FileChunk &fc, uint32_t c, uint32_t kth, uint8_t *persist, uint8_t *slabs) {
+    if (kth == 0) return persist + ((size_t)c * kPersist + fc.par) * kSlab;
+    if (kth < fc.nb) return slabs + (size_t)(fc.slab_base + kth - 1) * kSlab;
+    return persist + ((size_t)c * kPersist + next_slab(fc.par)) * kSlab;
+}
+
+// ---- line index -----------------------------------------------------------------------------------------------------
+// 0x80 in every byte of w that is '\n' (exact: no borrow across bytes)
+__device__ inline uint32_t newline_mask(uint32_t w) {
+    const uint32_t x = w ^ 0x0A0A0A0Au;
+    const uint32_t t = (x & 0x7F7F7F7Fu) + 0x7F7F7F7Fu;
+    return ~(t | x | 0x7F7F7F7Fu);
+}
+// the 16 bytes of lane `lane` of tile `tile`, bytes at or past `len` read as zeros
+__device__ inline uint4 tile_bytes(const uint8_t *text, uint32_t len, uint32_t tile, uint32_t lane) {
+    const uint32_t off = tile * kLineTile + lane * 16u;
+    uint4 v = make_uint4(0, 0, 0, 0);
+    if (off + 16u <= len) {
+        v = *reinterpret_cast<const uint4 *>(text + off);
+    } else if (off < len) {
+        uint32_t w[4] = {0, 0, 0, 0};
+        for (uint32_t k = 0; off + k < len; ++k) w[k >> 2] |= (uint32_t)text[off + k] << (8 * (k & 3u));
+        v = make_uint4(w[0], w[1], w[2], w[3]);
+    }
+    return v;
+}
+__device__ inline uint32_t lane_newlines(const uint4 &v, uint32_t *m) {
+    m[0] = newline_mask(v.x); m[1] = newline_mask(v.y); m[2] = newline_mask(v.z); m[3] = newline_mask(v.w);
+    return (uint32_t)(__popc(m[0]) + __popc(m[1]) + __popc(m[2]) + __popc(m[3]));
+}
+__device__ inline uint32_t block_sum_256(uint32_t v, uint32_t *sh /* 8 words */) {
+    for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d);
+    if ((threadIdx.x & 63u) == 0) sh[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return sh[0] + sh[1] + sh[2] + sh[3];
+}
+
+__global__ __launch_bounds__(256) void k_count_lines(TextSet T) {
+    __shared__ uint32_t sh[8];
+    const uint32_t in = blockIdx.y, tile = blockIdx.x;
+    if ((uint64_t)tile * kLineTile >= T.len[in]) return;
+    uint32_t m[4];
+    const uint32_t c = lane_newlines(tile_bytes(T.text[in], T.len[in], tile, threadIdx.x), m);
+    const uint32_t tot = block_sum_256(c, sh);
+    if (threadIdx.x == 0) T.tile_cnt[in][tile] = tot;
+}
+
+// exclusive prefix sum of an input's tile counts, in place; the total = its number of lines
+__global__ __launch_bounds__(1024) void k_scan_tiles(TextSet T, ChunkStatus *st) {
+    __shared__ uint32_t sh[1024];
+    __shared__ uint32_t carry;
+    const uint32_t in = blockIdx.x;
+    const uint32_t n_tiles = (T.len[in] + kLineTile - 1) / kLineTile;
+    uint32_t *a = T.tile_cnt[in];
+    if (threadIdx.x == 0) carry = 0;
+    __syncthreads();
+    for (uint32_t base = 0; base < n_tiles; base += 1024) {
+        const uint32_t i = base + threadIdx.x;
+        const uint32_t v = i < n_tiles ? a[i] : 0;
+        sh[threadIdx.x] = v;
+        __syncthreads();
+        for (uint32_t d = 1; d < 1024; d <<= 1) {
+            const uint32_t add = threadIdx.x >= d ? sh[threadIdx.x - d] : 0;
+            __syncthreads();
+            sh[threadIdx.x] += add;
+            __syncthreads();
+        }
+        const uint32_t incl = sh[threadIdx.x], c0 = carry;
+        if (i < n_tiles) a[i] = c0 + incl - v;
+        __syncthreads();
+        if (threadIdx.x == 1023) carry = c0 + incl;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) st->n_lines[in] = carry;
+}
+
+// ls[k + 1] = offset of the byte after newline k (k < max_lines)
+__global__ __launch_bounds__(256) void k_line_starts(TextSet T, uint32_t max_lines) {
+    __shared__ uint32_t sh[256];
+    const uint32_t in = blockIdx.y, tile = blockIdx.x;
+    if ((uint64_t)tile * kLineTile >= T.len[in]) return;
+    uint32_t m[4];
+    const uint32_t c = lane_newlines(tile_bytes(T.text[in], T.len[in], tile, threadIdx.x), m);
+    sh[threadIdx.x] = c;
+    __syncthreads();
+    for (uint32_t d = 1; d < 256; d <<= 1) {
+        const uint32_t add = threadIdx.x >= d ? sh[threadIdx.x - d] : 0;
+        __syncthreads();
+        sh[threadIdx.x] += add;
+        __syncthreads();
+    }
+    uint32_t k = T.tile_cnt[in][tile] + sh[threadIdx.x] - c;
+    uint32_t *ls = T.ls[in];
+    if (tile == 0 && threadIdx.x == 0) ls[0] = 0;
+    const uint32_t off = tile * kLineTile + threadIdx.x * 16u;
+    for (int w = 0; w < 4; ++w) {
+        uint32_t mm = m[w];
+        while (mm) {
+            const uint32_t bit = (uint32_t)__ffs((int)mm) - 1u;   // 7, 15, 23 or 31
+            mm &= mm - 1u;
+            if (k < max_lines) ls[k + 1] = off + (uint32_t)w * 4u + (bit >> 3) + 1u;
+            ++k;
+        }
+    }
+}
+
+// ---- records ----------------------------------------------------------------------------------------------------------
+// One lane per template: the four lines of its record in every input (seq_io's checks: '@', '+', equal lengths; a
+// trailing '\r' is not part of a line), the too-few-bases rule (demux.rs:298-313), the length of its sample barcode.
+__global__ __launch_bounds__(256) void k_records(TextSet T, DevConfig C, uint32_t n, uint8_t *skip, uint32_t *bc_len,
+                                                 ChunkStatus *st) {
+    for (uint32_t i = 0; i < C.n_inputs; ++i)
+        if (st->n_lines[i] != 4u * n) {   // the index is not the one the later kernels expect: nothing is touched
+            if (blockIdx.x == 0 && threadIdx.x == 0) report(st, 0, 0, i, FQTK_DEMUX_ERR_LINES);
+            return;
+        }
+    const uint32_t t = blockIdx.x * 256u + threadIdx.x;
+    if (t >= n) return;
+    bool too_short = false;
+    for (uint32_t i = 0; i < C.n_inputs; ++i) {
+        const uint8_t *x = T.text[i];
+        const uint32_t *ls = T.ls[i] + 4u * t;
+        const uint32_t s0 = ls[0], s1 = ls[1], s2 = ls[2], s3 = ls[3], s4 = ls[4];
+        auto line_len = [&](uint32_t a, uint32_t b) {   // [a, b - 1) without the newline, without a trailing '\r'
+            uint32_t l = b - 1u - a;
+            if (l && x[a + l - 1u] == '\r') --l;
+            return l;
+        };
+        const uint32_t hl = line_len(s0, s1), ql = line_len(s3, s4), pl = line_len(s2, s3);
+        uint32_t sl = line_len(s1, s2);
+        if (hl == 0 || x[s0] != '@') report(st, t, 0, i, FQTK_DEMUX_ERR_NO_AT);
+        else if (pl == 0 || x[s2] != '+') report(st, t, 0, i, FQTK_DEMUX_ERR_NO_PLUS);
+        else if (sl != ql) report(st, t, 0, i, FQTK_DEMUX_ERR_QUAL_LEN);
+        if (ql < sl) sl = ql;   // (an error anyway; keeps every later access inside both lines)
+        RecView r;
+        r.head_off = s0 + 1u;
+        r.head_len = hl ? hl - 1u : 0u;
+        r.seq_off = s1;
+        r.seq_len = sl;
+        r.qual_off = s3;
+        T.rec[i][t] = r;
+        if (sl < C.min_len[i]) {
+            too_short = true;
+            if (!C.skip_short) report(st, t, 1, i, FQTK_DEMUX_ERR_TOO_SHORT);
+        }
+    }
+    skip[t] = too_short ? 1 : 0;
+    if (too_short) atomicAdd(&st->n_skipped, 1u);
+    uint32_t bl = 0;
+    if (!too_short)
+        for (uint32_t b = 0; b < C.n_b; ++b) {
+            uint32_t lo, hi;
+            fmt::segment_span(C.bseg[b].offset, C.bseg[b].length, T.rec[C.bseg[b].input][t].seq_len, &lo, &hi);
+            bl += hi - lo;
+        }
+    bc_len[t] = bl;
+    if (C.variable_bc) atomicMax(&st->max_bc_len, bl);
+}
+
+// The sample barcode of every template = its B segments side by side (demux.rs:121-123), one row of `stride` bytes.
+// A dropped template gets an empty row (length 0: shorter than any barcode -> no match, no length error).
+__global__ __launch_bounds__(256) void k_extract(TextSet T, DevConfig C, uint32_t n, uint32_t stride, const uint8_t *skip,
+                                                 const uint32_t *bc_len, uint8_t *obs, uint32_t *lens, const ChunkStatus *st) {
+    if (no_records(st)) return;
+    const uint32_t t = blockIdx.x * 256u + threadIdx.x;
+    if (t >= n) return;
+    uint8_t *row = obs + (size_t)t * stride;
+    uint32_t w = 0;
+    if (!skip[t])
+        for (uint32_t b = 0; b < C.n_b; ++b) {
+            const RecView r = T.rec[C.bseg[b].input][t];
+            uint32_t lo, hi;
+            fmt::segment_span(C.bseg[b].offset, C.bseg[b].length, r.seq_len, &lo, &hi);
+            const uint8_t *src = T.text[C.bseg[b].input] + r.seq_off;
+            for (uint32_t k = lo; k < hi && w < stride; ++k) row[w++] = src[k];
+        }
+    for (uint32_t k = w; k < stride; ++k) row[k] = 0;
+    if (lens) lens[t] = skip[t] ? 0u : bc_len[t];
+}
+
+// ---- placement ----------------------------------------------------------------------------------------------------------
+// Every output file is a byte stream in input order (the reference writes templates one after another).  A template's
+// record lands at (bytes of earlier templates of the same sample) in each of that sample's files: a prefix sum keyed by
+// sample, stable in the template order.  Per tile of 1024 templates each lane adds up the lengths of the lanes before
+// it that share its sample (an O(tile) loop over LDS: ~6 k lane-operations per template, nothing next to the text
+// traffic) and the tile's total per (sample, file) goes into a [tiles x columns] matrix whose columns are then summed
+// down the tiles (k_column_scan).  Column layout: sample * (n_files + 1) + f, the last one counts templates.
+struct TemplatePlan {
+    fmt::HeaderPlan h;
+    uint32_t base_len;   // bytes of a record of this template with a one-digit read number and an empty segment
+};
+
+__device__ inline uint32_t digits_of(uint32_t v) { uint32_t n = 1; while (v >= 10u) { v /= 10u; ++n; } return n; }
+
+__global__ __launch_bounds__(1024) void k_plan_rank(TextSet T, DevConfig C, uint32_t n, const uint32_t *res, const uint8_t *skip,
+                                                    TemplatePlan *plans, uint32_t *rec_off /* [n_files][n] */,
+                                                    uint32_t *tile_tot /* [tiles][cols] */, ChunkStatus *st) {
+    if (no_records(st)) return;
+    __shared__ uint32_t s_key[kTile];
+    __shared__ uint32_t s_len[kRankGroup][kTile];
+    const uint32_t i = threadIdx.x, tile = blockIdx.x, t = tile * kTile + i;
+    const uint32_t cps = C.n_files + 1u, cols = (C.n_samples + 1u) * cps;
+    uint32_t key = 0xFFFFFFFFu;
+    TemplatePlan tp;
+    tp.base_len = 0;
+    if (t < n && !skip[t]) {
+        const uint32_t idx = res[t] & 0xFFFFu;
+        key = idx == FQTK_NO_MATCH ? C.n_samples : idx;
+        const RecView r0 = T.rec[0][t];
+        tp.h = fmt::plan_header(T.text[0] + r0.head_off, r0.head_len, C.n_m != 0);
+        if (tp.h.err) report(st, t, 3, 0, tp.h.err);
+        // everything of the record but the read number's extra digits and the segment itself
+        uint32_t bl = 0, ml = 0;
+        for (uint32_t b = 0; b < C.n_b; ++b) {
+            uint32_t lo, hi;
+            fmt::segment_span(C.bseg[b].offset, C.bseg[b].length, T.rec[C.bseg[b].input][t].seq_len, &lo, &hi);
+            bl += hi - lo;
+        }
+        for (uint32_t b = 0; b < C.n_m; ++b) {
+            uint32_t lo, hi;
+            fmt::segment_span(C.mseg[b].offset, C.mseg[b].length, T.rec[C.mseg[b].input][t].seq_len, &lo, &hi);
+            ml += hi - lo;
+        }
+        uint32_t len = 1u + tp.h.name_len + 1u;                          // '@' name ' '
+        if (C.n_m) len += 1u + ml + (C.n_m - 1u);                        // sep M1+M2..
+        if (tp.h.kind == 0) len += 1u + 5u;                              // "1:N:0:"
+        else if (tp.h.kind == 1) len += tp.h.copy_len + (tp.h.tail ? 1u : 0u);
+        else len += 1u + 1u + tp.h.copy_len + (tp.h.tail ? 1u : 0u);    // "1:" rest [+]
+        if (C.n_b) len += bl + (C.n_b - 1u);
+        len += 6u;                                                       // "\n" "\n+\n" "\n"
+        tp.base_len = len;
+        plans[t] = tp;
+    }
+    s_key[i] = key;
+    uint32_t cnt_before = 0, cnt_tot = 0;
+    for (uint32_t f0 = 0; f0 < C.n_files; f0 += kRankGroup) {
+        const uint32_t g = C.n_files - f0 < kRankGroup ? C.n_files - f0 : kRankGroup;
+        __syncthreads();
+        uint32_t mine[kRankGroup] = {0, 0};
+        if (key != 0xFFFFFFFFu) {
+#pragma unroll
+            for (uint32_t f = 0; f < kRankGroup; ++f) {
+                if (f >= g) continue;
+                const fmt::FileSeg fs = C.fseg[f0 + f];
+                uint32_t lo, hi;
+                fmt::segment_span(fs.offset, fs.length, T.rec[fs.input][t].seq_len, &lo, &hi);
+                mine[f] = tp.base_len + (tp.h.kind != 1 ? digits_of(fs.read_num) - 1u : 0u) + 2u * (hi - lo);
+            }
+        }
+#pragma unroll
+        for (uint32_t f = 0; f < kRankGroup; ++f) s_len[f][i] = mine[f];
+        __syncthreads();
+        uint32_t before[kRankGroup] = {0, 0}, tot[kRankGroup] = {0, 0};
+        cnt_before = 0;
+        cnt_tot = 0;
+        if (key != 0xFFFFFFFFu)
+            for (uint32_t j = 0; j < kTile; ++j) {
+                if (s_key[j] != key) continue;
+                const bool b4 = j < i;
+                cnt_tot += 1u;
+                cnt_before += b4 ? 1u : 0u;
+#pragma unroll
+                for (uint32_t f = 0; f < kRankGroup; ++f) {
+                    const uint32_t l = s_len[f][j];
+                    tot[f] += l;
+                    before[f] += b4 ? l : 0u;
+                }
+            }
+        if (key != 0xFFFFFFFFu) {
+            const bool last = cnt_before + 1u == cnt_tot;
+#pragma unroll
+            for (uint32_t f = 0; f < kRankGroup; ++f) {
+                if (f >= g) continue;
+                rec_off[(size_t)(f0 + f) * n + t] = before[f];
+                if (last) tile_tot[(size_t)tile * cols + key * cps + f0 + f] = tot[f];
+            }
+        }
+    }
+    if (C.n_files == 0) {   // (no output files: the templates are still counted)
+        __syncthreads();
+        cnt_before = 0;
+        cnt_tot = 0;
+        if (key != 0xFFFFFFFFu)
+            for (uint32_t j = 0; j < kTile; ++j) if (s_key[j] == key) { ++cnt_tot; cnt_before += j < i ? 1u : 0u; }
+    }
+    if (key != 0xFFFFFFFFu && cnt_before + 1u == cnt_tot) tile_tot[(size_t)tile * cols + key * cps + C.n_files] = cnt_tot;
+}
+
+// exclusive prefix sum down the tiles of every column, in place; the column totals of the chunk
+__global__ __launch_bounds__(256) void k_column_scan(uint32_t *tile_tot, uint32_t n_tiles, uint32_t cols, uint32_t *chunk_tot) {
+    const uint32_t c = blockIdx.x * 256u + threadIdx.x;
+    if (c >= cols) return;
+    uint32_t run = 0;
+    for (uint32_t tl = 0; tl < n_tiles; ++tl) {
+        const uint32_t v = tile_tot[(size_t)tl * cols + c];
+        tile_tot[(size_t)tl * cols + c] = run;
+        run += v;
+    }
+    chunk_tot[c] = run;
+}
+
+// One workgroup: what every file closes in this chunk, where its blocks go, and the per-sample counts.
+__global__ __launch_bounds__(1024) void k_layout(DevConfig C, const uint32_t *chunk_tot, FileState *fs, FileChunk *fc,
+                                                 unsigned long long *counts, uint32_t flush, ChunkStatus *st) {
+    __shared__ uint32_t sh_a[1024], sh_b[1024];
+    __shared__ uint32_t carry_a, carry_b;
+    const uint32_t cps = C.n_files + 1u, n_cols = (C.n_samples + 1u) * C.n_files;
+    if (threadIdx.x == 0) { carry_a = 0; carry_b = 0; }
+    __syncthreads();
+    for (uint32_t base = 0; base < n_cols; base += 1024) {
+        const uint32_t c = base + threadIdx.x;
+        FileChunk x;
+        x.rem = x.nb = x.n_emit = x.blk_base = x.slab_base = x.par = x.new_rem = x.pad = 0;
+        uint32_t n_slabs = 0;
+        if (c < n_cols) {
+            const uint32_t s = c / C.n_files, f = c - s * C.n_files;
+            const uint32_t bytes = chunk_tot ? chunk_tot[s * cps + f] : 0u;
+            const FileState cur = fs[c];
+            const unsigned long long end = (unsigned long long)cur.rem + bytes;
+            x.rem = cur.rem;
+            x.par = cur.par;
+            x.nb = (uint32_t)(end / kBlock);
+            x.new_rem = (uint32_t)(end - (unsigned long long)x.nb * kBlock);
+            x.n_emit = x.nb + ((flush && x.new_rem) ? 1u : 0u);
+            n_slabs = x.nb ? x.nb - 1u : 0u;
+            FileState nx;
+            nx.rem = flush ? 0u : x.new_rem;
+            // the block open after the chunk sits in the other slab once a block was closed; a flush hands it to the
+            // compressor, and the (empty) block after it starts in the slab that is free by then
+            nx.par = x.nb ? next_slab(cur.par) : cur.par;
+            if (flush && x.new_rem) nx.par = next_slab(nx.par);
+            fs[c] = nx;
+        }
+        sh_a[threadIdx.x] = x.n_emit;
+        sh_b[threadIdx.x] = n_slabs;
+        __syncthreads();
+        for (uint32_t d = 1; d < 1024; d <<= 1) {
+            const uint32_t a = threadIdx.x >= d ? sh_a[threadIdx.x - d] : 0, b = threadIdx.x >= d ? sh_b[threadIdx.x - d] : 0;
+            __syncthreads();
+            sh_a[threadIdx.x] += a;
+            sh_b[threadIdx.x] += b;
+            __syncthreads();
+        }
+        const uint32_t ca = carry_a, cb = carry_b;
+        if (c < n_cols) {
+            x.blk_base = ca + sh_a[threadIdx.x] - x.n_emit;
+            x.slab_base = cb + sh_b[threadIdx.x] - n_slabs;
+            fc[c] = x;
+        }
+        __syncthreads();
+        if (threadIdx.x == 1023) { carry_a = ca + sh_a[1023]; carry_b = cb + sh_b[1023]; }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        st->n_blocks = carry_a;
+        FileChunk end;   // sentinel: fc[n_cols].blk_base = number of blocks
+        end.rem = end.nb = end.n_emit = end.slab_base = end.par = end.new_rem = end.pad = 0;
+        end.blk_base = carry_a;
+        fc[n_cols] = end;
+    }
+    if (chunk_tot)
+        for (uint32_t s = threadIdx.x; s <= C.n_samples; s += 1024) counts[s] += chunk_tot[s * cps + C.n_files];
+}
+
+// Block descriptors for the compressor: block j of the chunk belongs to the file whose [blk_base, blk_base + n_emit)
+// holds j.
+__global__ __launch_bounds__(256) void k_descs(DevConfig C, const FileChunk *fc, uint8_t *persist, uint8_t *slabs, uint8_t *out_slabs,
+                                               fqtk_bgzf_block *desc, uint32_t *blk_file, const ChunkStatus *st) {
+    const uint32_t j = blockIdx.x * 256u + threadIdx.x;
+    if (j >= st->n_blocks) return;
+    const uint32_t n_cols = (C.n_samples + 1u) * C.n_files;
+    uint32_t lo = 0, hi = n_cols;   // last column with blk_base <= j (columns without blocks share their successor's base)
+    while (hi - lo > 1u) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (fc[mid].blk_base <= j) lo = mid; else hi = mid;
+    }
+    const FileChunk x = fc[lo];
+    const uint32_t k = j - x.blk_base;
+    fqtk_bgzf_block d;
+    d.in = block_base(x, lo, k, persist, slabs);
+    d.out = out_slabs + (size_t)j * kSlab;
+    d.n_in = k < x.nb ? kBlock : x.new_rem;
+    d.reserved = 0;
+    desc[j] = d;
+    blk_file[j] = lo;
+}
+
+// ---- formatting -----------------------------------------------------------------------------------------------------------
+// One wavefront per template: lane 0 lists the pieces of the record (record_format.hpp), all 64 lanes copy them,
+// for every output file of the template's sample.  Bytes go straight into the file's blocks.
+constexpr int kFormatWaves = 4;
+struct WaveScratch {
+    fmt::Piece pc[fmt::kMaxPieces];
+    fmt::Span b[kMaxSegs], m[kMaxSegs];
+    uint32_t n_pieces, total;
+};
+
+__global__ __launch_bounds__(64 * kFormatWaves) void k_format(TextSet T, DevConfig C, uint32_t n, const uint32_t *res, const uint8_t *skip,
+                                                               const TemplatePlan *plans, const uint32_t *rec_off, const uint32_t *tile_tot,
+                                                               const FileChunk *fc, uint8_t *persist, uint8_t *slabs, const ChunkStatus *st) {
+    if (st->err_key != kNoError) return;
+    __shared__ WaveScratch scratch[kFormatWaves];
+    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+    const uint32_t t = blockIdx.x * kFormatWaves + wave;
+    if (t >= n || skip[t]) return;
+    WaveScratch &W = scratch[wave];
+    const uint32_t idx = res[t] & 0xFFFFu;
+    const uint32_t s = idx == FQTK_NO_MATCH ? C.n_samples : idx;
+    const uint32_t cps = C.n_files + 1u, cols = (C.n_samples + 1u) * cps, tile = t / kTile;
+    const TemplatePlan tp = plans[t];
+    const RecView r0 = T.rec[0][t];
+    if (lane == 0) {
+        for (uint32_t b = 0; b < C.n_b; ++b) {
+            const RecView r = T.rec[C.bseg[b].input][t];
+            uint32_t lo, hi;
+            fmt::segment_span(C.bseg[b].offset, C.bseg[b].length, r.seq_len, &lo, &hi);
+            W.b[b] = fmt::Span{C.bseg[b].input, r.seq_off + lo, hi - lo};
+        }
+        for (uint32_t b = 0; b < C.n_m; ++b) {
+            const RecView r = T.rec[C.mseg[b].input][t];
+            uint32_t lo, hi;
+            fmt::segment_span(C.mseg[b].offset, C.mseg[b].length, r.seq_len, &lo, &hi);
+            W.m[b] = fmt::Span{C.mseg[b].input, r.seq_off + lo, hi - lo};
+        }
+    }
+    for (uint32_t f = 0; f < C.n_files; ++f) {
+        const uint32_t c = s * C.n_files + f;
+        if (lane == 0) {
+            const fmt::FileSeg fsg = C.fseg[f];
+            const RecView r = T.rec[fsg.input][t];
+            uint32_t lo, hi;
+            fmt::segment_span(fsg.offset, fsg.length, r.seq_len, &lo, &hi);
+            fmt::PieceSink sink(W.pc);
+            fmt::emit_record(sink, tp.h, r0.head_off, fsg.read_num, W.b, C.n_b, W.m, C.n_m,
+                             fmt::Span{fsg.input, r.seq_off + lo, hi - lo}, fmt::Span{fsg.input, r.qual_off + lo, hi - lo});
+            W.n_pieces = sink.n;
+        }
+        __builtin_amdgcn_wave_barrier();
+        __threadfence_block();
+        const FileChunk x = fc[c];
+        uint32_t q = x.rem + tile_tot[(size_t)tile * cols + s * cps + f] + rec_off[(size_t)f * n + t];
+        const uint32_t np = W.n_pieces;
+        for (uint32_t p = 0; p < np; ++p) {
+            const fmt::Piece pc = W.pc[p];
+            if (pc.is_lit) {
+                if (lane < pc.len) *file_byte(x, c, q + lane, persist, slabs) = (uint8_t)(pc.lit >> (8u * lane));
+            } else {
+                const uint8_t *src = T.text[pc.input] + pc.off;
+                for (uint32_t k = lane; k < pc.len; k += 64u) *file_byte(x, c, q + k, persist, slabs) = src[k];
+            }
+            q += pc.len;
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+// ---- packing ------------------------------------------------------------------------------------------------------------
+// BGZF member = 18-byte header (BSIZE), DEFLATE payload, CRC-32 and length of the uncompressed block.
+// pos[j] = byte offset of member j in the packed result; file_off[c] = offset of file c's first member.
+__global__ __launch_bounds__(1024) void k_pack_scan(DevConfig C, const FileChunk *fc, const uint32_t *out_len, unsigned long long *pos,
+                                                    unsigned long long *file_off, ChunkStatus *st) {
+    __shared__ unsigned long long sh[1024];
+    __shared__ unsigned long long carry;
+    const uint32_t nblk = st->n_blocks;
+    if (threadIdx.x == 0) carry = 0;
+    __syncthreads();
+    for (uint32_t base = 0; base < nblk; base += 1024) {
+        const uint32_t j = base + threadIdx.x;
+        const unsigned long long v = j < nblk ? 26ull + out_len[j] : 0ull;
+        sh[threadIdx.x] = v;
+        __syncthreads();
+        for (uint32_t d = 1; d < 1024; d <<= 1) {
+            const unsigned long long a = threadIdx.x >= d ? sh[threadIdx.x - d] : 0ull;
+            __syncthreads();
+            sh[threadIdx.x] += a;
+            __syncthreads();
+        }
+        const unsigned long long c0 = carry;
+        if (j < nblk) pos[j] = c0 + sh[threadIdx.x] - v;
+        __syncthreads();
+        if (threadIdx.x == 1023) carry = c0 + sh[1023];
+        __syncthreads();
+    }
+    const unsigned long long total = carry;
+    if (threadIdx.x == 0) { st->total_bytes = total; pos[nblk] = total; }
+    __syncthreads();
+    const uint32_t n_cols = (C.n_samples + 1u) * C.n_files;
+    for (uint32_t c = threadIdx.x; c <= n_cols; c += 1024) {
+        const uint32_t b = fc[c].blk_base;
+        file_off[c] = b < nblk ? pos[b] : total;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_pack_copy(const fqtk_bgzf_block *desc, const uint32_t *out_len, const uint32_t *crc,
+                                                   const unsigned long long *pos, uint8_t *packed, const ChunkStatus *st) {
+    for (uint32_t j = blockIdx.x; j < st->n_blocks; j += gridDim.x) {
+        const uint32_t len = out_len[j], total = 26u + len, bsize1 = total - 1u;
+        const uint8_t *payload = desc[j].out;
+        const uint32_t c = crc[j], isz = desc[j].n_in;
+        uint8_t *dst = packed + pos[j];
+        auto member_byte = [&](uint32_t x) -> uint8_t {
+            if (x >= 18u && x < 18u + len) return payload[x - 18u];
+            switch (x) {
+                case 0: return 0x1f; case 1: return 0x8b; case 2: return 8; case 3: return 4;
+                case 9: return 0xff; case 10: return 6; case 12: return 'B'; case 13: return 'C'; case 14: return 2;
+                case 16: return (uint8_t)(bsize1 & 0xFFu); case 17: return (uint8_t)(bsize1 >> 8);
+                default: break;
+            }
+            if (x < 18u) return 0;
+            const uint32_t y = x - 18u - len;   // trailer
+            return y < 4u ? (uint8_t)(c >> (8u * y)) : (uint8_t)(isz >> (8u * (y - 4u)));
+        };
+        // whole aligned words of the destination, single bytes at its ragged ends
+        const uint32_t mis = (uint32_t)(reinterpret_cast<uintptr_t>(dst) & 3u);
+        const uint32_t head = mis ? 4u - mis : 0u;
+        for (uint32_t x = threadIdx.x; x < head && x < total; x += 256u) dst[x] = member_byte(x);
+        const uint32_t words = total > head ? (total - head) >> 2 : 0u;
+        uint32_t *dw = reinterpret_cast<uint32_t *>(dst + head);
+        for (uint32_t w = threadIdx.x; w < words; w += 256u) {
+            const uint32_t x = head + 4u * w;
+            uint32_t v;
+            if (x >= 18u && x + 4u <= 18u + len) {
+                const uint8_t *p = payload + (x - 18u);
+                v = (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((uint32_t)p[3] << 24);
+            } else {
+                v = (uint32_t)member_byte(x) | ((uint32_t)member_byte(x + 1) << 8) | ((uint32_t)member_byte(x + 2) << 16) |
+                    ((uint32_t)member_byte(x + 3) << 24);
+            }
+            dw[w] = v;
+        }
+        for (uint32_t x = head + 4u * words + threadIdx.x; x < total; x += 256u) dst[x] = member_byte(x);
+    }
+}
+
+}  // namespace demux
+}  // namespace fqtk

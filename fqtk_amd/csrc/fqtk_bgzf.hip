@@ -9,6 +9,7 @@
 #include "../../include/fqtk_bgzf.h"
 #include "../../include/fqtk_match.h"
 #include "bgzf_deflate.hpp"
+#include "bgzf_internal.hpp"
 
 namespace fqtk {
 namespace bgzf {
@@ -22,8 +23,8 @@ __device__ unsigned long long g_phase_ticks[12];
 #endif
 
 __global__ __launch_bounds__(kLanes) __attribute__((amdgpu_waves_per_eu(2, 2)))   // one workgroup per CU (LDS): registers are free
-void deflate_kernel(const fqtk_bgzf_block *blocks, uint32_t n_blocks,
-                                                         uint32_t *out_len, uint32_t *tok_all) {
+void deflate_kernel(const fqtk_bgzf_block *blocks, uint32_t n_blocks, const uint32_t *n_blocks_dev,
+                                                         uint32_t *out_len, uint32_t *crc_out, uint32_t *tok_all) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem_raw[];
     Shared &S = *reinterpret_cast<Shared *>(smem_raw);
     const int lane = (int)threadIdx.x;
@@ -31,12 +32,28 @@ void deflate_kernel(const fqtk_bgzf_block *blocks, uint32_t n_blocks,
 #ifdef FQTK_BGZF_PHASE_TIMES
     uint64_t t_mark = wall_clock64();
 #endif
+    if (n_blocks_dev) n_blocks = *n_blocks_dev;   // (the record pipeline learns the count on the device)
+    if (blockIdx.x >= n_blocks) return;
+    if (crc_out) {
+        crc_tables(S, lane);
+        __syncthreads();
+    }
     for (uint32_t j = blockIdx.x; j < n_blocks; j += gridDim.x) {
         const uint8_t *in = blocks[j].in;
         uint8_t *out = blocks[j].out;
         const uint32_t n = blocks[j].n_in;
         phase_load(S, lane, in, n);
         __syncthreads();
+        if (crc_out) {
+            phase_crc(S, lane, n);
+            __syncthreads();
+            if (lane < 64) {   // the first wave folds the lanes' values (phase_crc_fold is the one-lane form of the CPU tests)
+                uint32_t c = 0;
+                for (int k = 0; k < kLanes / 64; ++k) c ^= S.crc_part[lane + 64 * k];
+                for (int d = 32; d >= 1; d >>= 1) c ^= (uint32_t)__shfl_xor((int)c, d);
+                if (lane == 0) crc_out[j] = c;
+            }
+        }
         FQTK_PHASE_MARK(0);
         phase_index(S, lane, n);
         __syncthreads();
@@ -70,6 +87,21 @@ void deflate_kernel(const fqtk_bgzf_block *blocks, uint32_t n_blocks,
 }
 #undef FQTK_PHASE_MARK
 
+}  // namespace bgzf
+}  // namespace fqtk
+
+namespace fqtk {
+namespace bgzf {
+size_t deflate_token_bytes_per_group() { return (size_t)kTokensPerBlock * sizeof(uint32_t); }
+hipError_t deflate_prepare() {
+    return hipFuncSetAttribute(reinterpret_cast<const void *>(deflate_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(Shared));
+}
+hipError_t deflate_launch(hipStream_t stream, uint32_t groups, const fqtk_bgzf_block *blocks, const uint32_t *n_blocks_dev,
+                          uint32_t *out_len, uint32_t *crc, uint32_t *tok, int level) {
+    (void)level;
+    hipLaunchKernelGGL(deflate_kernel, dim3(groups), dim3(kLanes), sizeof(Shared), stream, blocks, 0u, n_blocks_dev, out_len, crc, tok);
+    return hipGetLastError();
+}
 }  // namespace bgzf
 }  // namespace fqtk
 
@@ -154,7 +186,7 @@ int fqtk_bgzf_deflate_enqueue(fqtk_bgzf *z, int slot, const fqtk_bgzf_block *blo
     BGZF_TRY(hipSetDevice(z->device));
     const uint32_t grid = n < (uint32_t)z->num_cus ? n : (uint32_t)z->num_cus;   // one workgroup per CU (107 KiB of LDS each)
     hipLaunchKernelGGL(fqtk::bgzf::deflate_kernel, dim3(grid), dim3(fqtk::bgzf::kLanes), sizeof(fqtk::bgzf::Shared),
-                       z->streams[slot], blocks, n, out_len, z->d_tok[slot]);
+                       z->streams[slot], blocks, n, (const uint32_t *)nullptr, out_len, (uint32_t *)nullptr, z->d_tok[slot]);
     BGZF_TRY(hipGetLastError());
     z->busy[slot] = true;
     return FQTK_OK;

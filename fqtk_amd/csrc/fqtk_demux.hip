@@ -1,0 +1,486 @@
+// fqtk_demux.hip -- C ABI (include/fqtk_demux.h) of the record pipeline: host side of demux_kernels.hip.h.
+//
+// One chunk = the raw FASTQ text of n templates from every input.  Two HIP streams carry it:
+//   stream A   H2D wait -> line index -> records -> barcode rows -> matcher -> placement -> formatting
+//   stream B   DEFLATE + CRC of the chunk's blocks -> packing into BGZF members -> status to the host
+// B(k) waits for A(k); A(k) waits for B(k - 2) (a file's persistent slabs rotate over three, demux_kernels.hip.h), so
+// the compressor -- the longest kernel by far -- works on chunk k while chunk k + 1 is indexed, matched and formatted.
+// A copy stream moves the text in, another the packed members out.  Three chunks may be in flight (slots).
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "../../include/fqtk_demux.h"
+#include "bgzf_internal.hpp"
+#include "demux_kernels.hip.h"
+#include "matcher_internal.hpp"
+
+namespace {
+using namespace fqtk::demux;
+using fqtk::internal::set_error;
+
+#define DX_TRY(expr)                                                                                   \
+    do {                                                                                               \
+        hipError_t _e = (expr);                                                                        \
+        if (_e != hipSuccess) return set_error(FQTK_EHIP, std::string(#expr) + ": " + hipGetErrorString(_e)); \
+    } while (0)
+
+template <typename T>
+struct DevBuf {   // grow-only device buffer
+    T *p = nullptr;
+    size_t cap = 0;   // elements
+    int ensure(size_t want) {
+        if (want <= cap) return FQTK_OK;
+        if (p) { DX_TRY(hipFree(p)); p = nullptr; cap = 0; }
+        const size_t n = want + want / 8 + 64;
+        DX_TRY(hipMalloc(reinterpret_cast<void **>(&p), n * sizeof(T)));
+        cap = n;
+        return FQTK_OK;
+    }
+    void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+};
+template <typename T>
+struct PinBuf {   // grow-only page-locked host buffer
+    T *p = nullptr;
+    size_t cap = 0;
+    int ensure(size_t want) {
+        if (want <= cap) return FQTK_OK;
+        if (p) { DX_TRY(hipHostFree(p)); p = nullptr; cap = 0; }
+        const size_t n = want + want / 4 + 64;
+        DX_TRY(hipHostMalloc(reinterpret_cast<void **>(&p), n * sizeof(T), hipHostMallocDefault));
+        cap = n;
+        return FQTK_OK;
+    }
+    void release() { if (p) (void)hipHostFree(p); p = nullptr; cap = 0; }
+};
+
+constexpr int kStageEvents = 8;   // a0 a1 a2 a3 a4 (stream A), b0 b1 b2 (stream B)
+
+struct Slot {
+    DevBuf<uint8_t> text[FQTK_DEMUX_MAX_INPUTS];
+    DevBuf<uint32_t> tile_cnt[FQTK_DEMUX_MAX_INPUTS], ls[FQTK_DEMUX_MAX_INPUTS];
+    DevBuf<RecView> rec[FQTK_DEMUX_MAX_INPUTS];
+    DevBuf<uint8_t> skip, obs, slabs, out_slabs, packed;
+    DevBuf<uint32_t> bc_len, lens, res, rec_off, tile_tot, chunk_tot, blk_file, out_len, crc;
+    DevBuf<TemplatePlan> plans;
+    DevBuf<FileChunk> fc;
+    DevBuf<fqtk_bgzf_block> desc;
+    DevBuf<unsigned long long> pos, file_off;
+    ChunkStatus *d_status = nullptr;
+    ChunkStatus *h_status = nullptr;       // page-locked
+    PinBuf<unsigned long long> h_file_off;
+    PinBuf<uint8_t> h_packed;
+    hipEvent_t ev_h2d0 = nullptr, ev_h2d1 = nullptr, ev_fmt = nullptr, ev_status = nullptr, ev_d2h0 = nullptr, ev_d2h1 = nullptr;
+    hipEvent_t ev[kStageEvents] = {};
+    bool busy = false, flush_only = false;
+    uint32_t n = 0, stride = 0;
+    size_t max_blocks = 0;
+};
+
+}  // namespace
+
+struct fqtk_demuxer {
+    fqtk_matcher *m = nullptr;
+    int device = 0, num_cus = 256;
+    DevConfig C{};
+    uint32_t n_cols = 0, cols = 0;   // output files; columns of the placement matrix
+    uint32_t max_chunk = 0;
+    bool carry = true;
+    int level = 5;
+    hipStream_t s_in = nullptr, s_a = nullptr, s_b = nullptr, s_out = nullptr;
+    uint8_t *d_persist = nullptr;
+    FileState *d_fs = nullptr;
+    unsigned long long *d_counts = nullptr;
+    uint32_t *d_tok = nullptr;
+    Slot slots[FQTK_DEMUX_SLOTS];
+    uint64_t chunk_no = 0;              // chunks submitted
+    int slot_of_chunk[2] = {-1, -1};    // slots of the last two chunks submitted (A(k) waits for B(k - 2))
+    double stage_s[FQTK_DEMUX_STAGES] = {};
+};
+
+namespace {
+
+int alloc_slot_fixed(fqtk_demuxer *d, Slot &s) {
+    DX_TRY(hipMalloc(reinterpret_cast<void **>(&s.d_status), sizeof(ChunkStatus)));
+    DX_TRY(hipHostMalloc(reinterpret_cast<void **>(&s.h_status), sizeof(ChunkStatus), hipHostMallocDefault));
+    for (hipEvent_t *e : {&s.ev_h2d0, &s.ev_h2d1, &s.ev_fmt, &s.ev_status, &s.ev_d2h0, &s.ev_d2h1}) DX_TRY(hipEventCreate(e));
+    for (int k = 0; k < kStageEvents; ++k) DX_TRY(hipEventCreate(&s.ev[k]));
+    int rc;
+    if ((rc = s.fc.ensure((size_t)d->n_cols + 1)) != FQTK_OK) return rc;
+    if ((rc = s.file_off.ensure((size_t)d->n_cols + 1)) != FQTK_OK) return rc;
+    if ((rc = s.h_file_off.ensure((size_t)d->n_cols + 1)) != FQTK_OK) return rc;
+    if ((rc = s.chunk_tot.ensure(d->cols)) != FQTK_OK) return rc;
+    return FQTK_OK;
+}
+
+// buffers whose size follows the number of blocks a chunk can produce
+int ensure_blocks(Slot &s, size_t max_blocks) {
+    int rc;
+    if ((rc = s.slabs.ensure(max_blocks * kSlab)) != FQTK_OK) return rc;
+    if ((rc = s.out_slabs.ensure(max_blocks * kSlab)) != FQTK_OK) return rc;
+    if ((rc = s.packed.ensure(max_blocks * kSlab)) != FQTK_OK) return rc;
+    if ((rc = s.desc.ensure(max_blocks)) != FQTK_OK) return rc;
+    if ((rc = s.blk_file.ensure(max_blocks)) != FQTK_OK) return rc;
+    if ((rc = s.out_len.ensure(max_blocks)) != FQTK_OK) return rc;
+    if ((rc = s.crc.ensure(max_blocks)) != FQTK_OK) return rc;
+    if ((rc = s.pos.ensure(max_blocks + 1)) != FQTK_OK) return rc;
+    s.max_blocks = max_blocks;
+    return FQTK_OK;
+}
+
+// stream B: compress the chunk's blocks, pack them, bring the status home
+int enqueue_compress(fqtk_demuxer *d, Slot &s) {
+    DX_TRY(hipEventRecord(s.ev[5], d->s_b));
+    DX_TRY(fqtk::bgzf::deflate_launch(d->s_b, (uint32_t)d->num_cus, s.desc.p, &s.d_status->n_blocks, s.out_len.p, s.crc.p, d->d_tok, d->level));
+    DX_TRY(hipEventRecord(s.ev[6], d->s_b));
+    hipLaunchKernelGGL(k_pack_scan, dim3(1), dim3(1024), 0, d->s_b, d->C, s.fc.p, s.out_len.p, s.pos.p, s.file_off.p, s.d_status);
+    DX_TRY(hipGetLastError());
+    hipLaunchKernelGGL(k_pack_copy, dim3((uint32_t)d->num_cus * 4), dim3(256), 0, d->s_b, s.desc.p, s.out_len.p, s.crc.p, s.pos.p, s.packed.p, s.d_status);
+    DX_TRY(hipGetLastError());
+    DX_TRY(hipMemcpyAsync(s.h_status, s.d_status, sizeof(ChunkStatus), hipMemcpyDeviceToHost, d->s_b));
+    DX_TRY(hipMemcpyAsync(s.h_file_off.p, s.file_off.p, ((size_t)d->n_cols + 1) * sizeof(unsigned long long), hipMemcpyDeviceToHost, d->s_b));
+    DX_TRY(hipEventRecord(s.ev[7], d->s_b));
+    DX_TRY(hipEventRecord(s.ev_status, d->s_b));
+    return FQTK_OK;
+}
+
+void add_elapsed(double *acc, hipEvent_t a, hipEvent_t b) {
+    float ms = 0;
+    if (hipEventElapsedTime(&ms, a, b) == hipSuccess) *acc += ms * 1e-3;
+    else (void)hipGetLastError();
+}
+
+int fill_result(fqtk_demuxer *d, Slot &s, fqtk_demux_result *res) {
+    std::memset(res, 0, sizeof *res);
+    DX_TRY(hipEventSynchronize(s.ev_status));
+    const ChunkStatus &st = *s.h_status;
+    res->n_files = d->n_cols;
+    res->n_templates = s.n;
+    res->n_skipped = st.n_skipped;
+    if (!s.flush_only) {
+        add_elapsed(&d->stage_s[0], s.ev_h2d0, s.ev_h2d1);
+        for (int k = 0; k < 4; ++k) add_elapsed(&d->stage_s[1 + k], s.ev[k], s.ev[k + 1]);
+    }
+    add_elapsed(&d->stage_s[5], s.ev[5], s.ev[6]);
+    add_elapsed(&d->stage_s[6], s.ev[6], s.ev[7]);
+    if (st.matcher_err != kNoError && (st.err_key == kNoError || (st.err_key >> 24) > st.matcher_err ||
+                                       ((st.err_key >> 24) == st.matcher_err && ((st.err_key >> 20) & 15u) > 2u))) {
+        // the matcher's length error comes first in template order (stage 2: after the records, before the headers)
+        res->error = FQTK_DEMUX_ERR_BARCODE_LEN;
+        res->error_template = (uint32_t)st.matcher_err;
+        fqtk::internal::word_device_length_error(d->m, s.obs.p, s.lens.p, s.stride, s.n, st.matcher_err);
+        return FQTK_OK;
+    }
+    if (st.err_key != kNoError) {
+        res->error = (int)(st.err_key & 0xFFu);
+        res->error_input = (uint32_t)((st.err_key >> 8) & 0xFFFu);
+        res->error_template = (uint32_t)(st.err_key >> 24);
+        if (((st.err_key >> 20) & 15u) == 3u) { res->error_detail = (uint32_t)res->error; res->error = FQTK_DEMUX_ERR_HEADER; }
+        return FQTK_OK;
+    }
+    if (st.n_blocks > s.max_blocks) return set_error(FQTK_EINVAL, "internal error: more blocks than the chunk's bound");
+    int rc;
+    if ((rc = s.h_packed.ensure((size_t)st.total_bytes + 16)) != FQTK_OK) return rc;
+    DX_TRY(hipEventRecord(s.ev_d2h0, d->s_out));
+    if (st.total_bytes) DX_TRY(hipMemcpyAsync(s.h_packed.p, s.packed.p, (size_t)st.total_bytes, hipMemcpyDeviceToHost, d->s_out));
+    DX_TRY(hipEventRecord(s.ev_d2h1, d->s_out));
+    DX_TRY(hipEventSynchronize(s.ev_d2h1));
+    add_elapsed(&d->stage_s[7], s.ev_d2h0, s.ev_d2h1);
+    res->bytes = s.h_packed.p;
+    res->file_off = reinterpret_cast<const uint64_t *>(s.h_file_off.p);
+    res->n_blocks = st.n_blocks;
+    return FQTK_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int fqtk_demuxer_create(fqtk_matcher *m, const fqtk_demux_config *cfg, fqtk_demuxer **out) {
+    if (!out) return set_error(FQTK_EINVAL, "out is NULL");
+    *out = nullptr;
+    if (!m || !cfg || !cfg->n_segments || !cfg->segments) return set_error(FQTK_EINVAL, "matcher / configuration is NULL");
+    if (cfg->n_inputs == 0 || cfg->n_inputs > FQTK_DEMUX_MAX_INPUTS)
+        return set_error(FQTK_EINVAL, "between 1 and " + std::to_string(FQTK_DEMUX_MAX_INPUTS) + " inputs are supported by the GPU record pipeline");
+    if (cfg->max_chunk_templates == 0 || cfg->max_chunk_templates > (1u << 22)) return set_error(FQTK_EINVAL, "max_chunk_templates must be 1 .. 4194304");
+    fqtk_demuxer *d = new (std::nothrow) fqtk_demuxer();
+    if (!d) return set_error(FQTK_ENOMEM, "out of host memory");
+    d->m = m;
+    d->device = fqtk_matcher_device(m);
+    d->carry = cfg->carry_blocks != 0;
+    d->level = cfg->compression_level;
+    d->max_chunk = cfg->max_chunk_templates;
+    DevConfig &C = d->C;
+    std::memset(&C, 0, sizeof C);
+    C.n_inputs = cfg->n_inputs;
+    C.n_samples = fqtk_matcher_n_samples(m);
+    C.barcode_len = fqtk_matcher_barcode_len(m);
+    C.skip_short = cfg->skip_too_few_bases ? 1u : 0u;
+    // segments by type in (input, position) order: demux.rs:100-118 filter the combined read set's segments in place
+    static const char kKinds[4] = {'T', 'B', 'M', 'C'};
+    size_t at = 0;
+    uint32_t per_type[4] = {0, 0, 0, 0};
+    std::vector<fqtk::fmt::FileSeg> by_type[4];
+    for (uint32_t i = 0; i < cfg->n_inputs; ++i) {
+        uint32_t min_len = 0;
+        for (uint32_t k = 0; k < cfg->n_segments[i]; ++k, ++at) {
+            const fqtk_demux_segment &sg = cfg->segments[at];
+            min_len += sg.length >= 0 ? (uint32_t)sg.length : 1u;   // demux.rs:298
+            if (sg.length < 0 && k + 1 != cfg->n_segments[i]) { delete d; return set_error(FQTK_EINVAL, "only the last segment of a read structure may be '+'"); }
+            int ty = -1;
+            for (int q = 0; q < 4; ++q) if (sg.kind == kKinds[q]) ty = q;
+            if (ty < 0) { if (sg.kind == 'S') continue; delete d; return set_error(FQTK_EINVAL, "unknown segment kind"); }
+            by_type[ty].push_back(fqtk::fmt::FileSeg{i, sg.offset, sg.length, ++per_type[ty]});
+        }
+        C.min_len[i] = min_len;
+    }
+    if (by_type[1].size() > kMaxSegs || by_type[2].size() > kMaxSegs) { delete d; return set_error(FQTK_EINVAL, "more than 24 sample- or molecular-barcode segments"); }
+    for (const auto &b : by_type[1]) {
+        C.bseg[C.n_b++] = fqtk::fmt::SegPos{b.input, b.offset, b.length};
+        if (b.length >= 0) C.fixed_bc_len += (uint32_t)b.length; else C.variable_bc = 1;
+    }
+    for (const auto &b : by_type[2]) C.mseg[C.n_m++] = fqtk::fmt::SegPos{b.input, b.offset, b.length};
+    if (fqtk::fmt::max_pieces(C.n_b, C.n_m) > (uint32_t)fqtk::fmt::kMaxPieces) { delete d; return set_error(FQTK_EINVAL, "too many barcode segments for one record"); }
+    for (int ty = 0; ty < 4; ++ty) {
+        if (!cfg->want[ty]) continue;
+        for (const auto &f : by_type[ty]) {
+            if (C.n_files == FQTK_DEMUX_MAX_FILES) { delete d; return set_error(FQTK_EINVAL, "more than " + std::to_string(FQTK_DEMUX_MAX_FILES) + " output files per sample"); }
+            C.fseg[C.n_files++] = f;
+        }
+    }
+    // the lengths travel with the rows whenever a row may not be exactly one barcode long (fqtk_match.h: obs_len)
+    C.use_lens = (C.variable_bc || C.fixed_bc_len != C.barcode_len || C.skip_short) ? 1u : 0u;
+    d->n_cols = (C.n_samples + 1u) * C.n_files;
+    d->cols = (C.n_samples + 1u) * (C.n_files + 1u);
+
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) { (void)hipGetLastError(); delete d; return set_error(FQTK_ENODEV, "no HIP device available (the record pipeline has no CPU fallback)"); }
+    auto bail = [&](int rc) { fqtk_demuxer_destroy(d); return rc; };
+#define DX_OR_BAIL(expr) do { hipError_t _e = (expr); if (_e != hipSuccess) return bail(set_error(FQTK_EHIP, std::string(#expr) + ": " + hipGetErrorString(_e))); } while (0)
+    DX_OR_BAIL(hipSetDevice(d->device));
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, d->device) == hipSuccess && prop.multiProcessorCount > 0) d->num_cus = prop.multiProcessorCount;
+    DX_OR_BAIL(fqtk::bgzf::deflate_prepare());
+    for (hipStream_t *st : {&d->s_in, &d->s_a, &d->s_b, &d->s_out}) DX_OR_BAIL(hipStreamCreateWithFlags(st, hipStreamNonBlocking));
+    const size_t persist_bytes = (size_t)std::max<uint32_t>(d->n_cols, 1) * kPersist * kSlab;
+    DX_OR_BAIL(hipMalloc(reinterpret_cast<void **>(&d->d_persist), persist_bytes));
+    DX_OR_BAIL(hipMalloc(reinterpret_cast<void **>(&d->d_fs), (size_t)std::max<uint32_t>(d->n_cols, 1) * sizeof(FileState)));
+    DX_OR_BAIL(hipMemset(d->d_fs, 0, (size_t)std::max<uint32_t>(d->n_cols, 1) * sizeof(FileState)));
+    DX_OR_BAIL(hipMalloc(reinterpret_cast<void **>(&d->d_counts), ((size_t)C.n_samples + 1) * sizeof(unsigned long long)));
+    DX_OR_BAIL(hipMemset(d->d_counts, 0, ((size_t)C.n_samples + 1) * sizeof(unsigned long long)));
+    DX_OR_BAIL(hipMalloc(reinterpret_cast<void **>(&d->d_tok), (size_t)d->num_cus * fqtk::bgzf::deflate_token_bytes_per_group()));
+#undef DX_OR_BAIL
+    for (Slot &s : d->slots) {
+        const int rc = alloc_slot_fixed(d, s);
+        if (rc != FQTK_OK) return bail(rc);
+    }
+    *out = d;
+    return FQTK_OK;
+}
+
+void fqtk_demuxer_destroy(fqtk_demuxer *d) {
+    if (!d) return;
+    (void)hipSetDevice(d->device);
+    for (hipStream_t st : {d->s_in, d->s_a, d->s_b, d->s_out}) if (st) (void)hipStreamSynchronize(st);
+    for (Slot &s : d->slots) {
+        for (int i = 0; i < FQTK_DEMUX_MAX_INPUTS; ++i) { s.text[i].release(); s.tile_cnt[i].release(); s.ls[i].release(); s.rec[i].release(); }
+        s.skip.release(); s.obs.release(); s.slabs.release(); s.out_slabs.release(); s.packed.release();
+        s.bc_len.release(); s.lens.release(); s.res.release(); s.rec_off.release(); s.tile_tot.release(); s.chunk_tot.release();
+        s.blk_file.release(); s.out_len.release(); s.crc.release(); s.plans.release(); s.fc.release(); s.desc.release();
+        s.pos.release(); s.file_off.release(); s.h_file_off.release(); s.h_packed.release();
+        if (s.d_status) (void)hipFree(s.d_status);
+        if (s.h_status) (void)hipHostFree(s.h_status);
+        for (hipEvent_t e : {s.ev_h2d0, s.ev_h2d1, s.ev_fmt, s.ev_status, s.ev_d2h0, s.ev_d2h1}) if (e) (void)hipEventDestroy(e);
+        for (hipEvent_t e : s.ev) if (e) (void)hipEventDestroy(e);
+    }
+    if (d->d_persist) (void)hipFree(d->d_persist);
+    if (d->d_fs) (void)hipFree(d->d_fs);
+    if (d->d_counts) (void)hipFree(d->d_counts);
+    if (d->d_tok) (void)hipFree(d->d_tok);
+    for (hipStream_t st : {d->s_in, d->s_a, d->s_b, d->s_out}) if (st) (void)hipStreamDestroy(st);
+    delete d;
+}
+
+uint32_t fqtk_demuxer_files_per_sample(const fqtk_demuxer *d) { return d ? d->C.n_files : 0; }
+
+int fqtk_demuxer_submit(fqtk_demuxer *d, int slot, const uint8_t *const *text, const uint64_t *text_len, uint32_t n) {
+    if (!d || !text || !text_len) return set_error(FQTK_EINVAL, "NULL argument");
+    if (slot < 0 || slot >= FQTK_DEMUX_SLOTS) return set_error(FQTK_EINVAL, "slot out of range");
+    Slot &s = d->slots[slot];
+    if (s.busy) return set_error(FQTK_EINVAL, "slot is busy: call fqtk_demuxer_collect() first");
+    if (n == 0 || n > d->max_chunk) return set_error(FQTK_EINVAL, "n_templates must be 1 .. max_chunk_templates");
+    const DevConfig &C = d->C;
+    uint64_t sum_text = 0, seg_text = 0;
+    for (uint32_t i = 0; i < C.n_inputs; ++i) {
+        if (!text[i] || text_len[i] == 0 || text_len[i] >= (1ull << 31)) return set_error(FQTK_EINVAL, "an input's text is empty or 2 GiB or more: use smaller chunks");
+        sum_text += text_len[i];
+    }
+    for (uint32_t f = 0; f < C.n_files; ++f) seg_text += text_len[C.fseg[f].input];
+    DX_TRY(hipSetDevice(d->device));
+    int rc;
+    // bound of the chunk's output: every file gets the first input's header, all barcode segments and its own
+    // segment's bases and qualities (all of them parts of the text), plus a few bytes per record
+    const uint64_t out_bound = (uint64_t)C.n_files * (sum_text + 32ull * n) + seg_text;
+    const size_t max_blocks = (size_t)(out_bound / kBlock) + (size_t)d->n_cols + 2;
+    if ((rc = ensure_blocks(s, max_blocks)) != FQTK_OK) return rc;
+    TextSet T;
+    std::memset(&T, 0, sizeof T);
+    uint32_t max_tiles = 0;
+    for (uint32_t i = 0; i < C.n_inputs; ++i) {
+        const uint32_t tiles = (uint32_t)((text_len[i] + kLineTile - 1) / kLineTile);
+        max_tiles = std::max(max_tiles, tiles);
+        if ((rc = s.text[i].ensure((size_t)text_len[i] + 64)) != FQTK_OK) return rc;
+        if ((rc = s.tile_cnt[i].ensure(tiles)) != FQTK_OK) return rc;
+        if ((rc = s.ls[i].ensure(4 * (size_t)n + 2)) != FQTK_OK) return rc;
+        if ((rc = s.rec[i].ensure(n)) != FQTK_OK) return rc;
+        T.text[i] = s.text[i].p;
+        T.len[i] = (uint32_t)text_len[i];
+        T.tile_cnt[i] = s.tile_cnt[i].p;
+        T.ls[i] = s.ls[i].p;
+        T.rec[i] = s.rec[i].p;
+    }
+    const uint32_t n_tiles = (n + kTile - 1) / kTile;
+    if ((rc = s.skip.ensure(n)) != FQTK_OK) return rc;
+    if ((rc = s.bc_len.ensure(n)) != FQTK_OK) return rc;
+    if ((rc = s.lens.ensure(n)) != FQTK_OK) return rc;
+    if ((rc = s.res.ensure(n)) != FQTK_OK) return rc;
+    if ((rc = s.plans.ensure(n)) != FQTK_OK) return rc;
+    if ((rc = s.rec_off.ensure((size_t)std::max<uint32_t>(C.n_files, 1) * n)) != FQTK_OK) return rc;
+    if ((rc = s.tile_tot.ensure((size_t)n_tiles * d->cols)) != FQTK_OK) return rc;
+
+    // text in (copy stream)
+    DX_TRY(hipEventRecord(s.ev_h2d0, d->s_in));
+    for (uint32_t i = 0; i < C.n_inputs; ++i)
+        DX_TRY(hipMemcpyAsync(s.text[i].p, text[i], (size_t)text_len[i], hipMemcpyHostToDevice, d->s_in));
+    DX_TRY(hipEventRecord(s.ev_h2d1, d->s_in));
+
+    // stream A
+    hipStream_t A = d->s_a;
+    DX_TRY(hipStreamWaitEvent(A, s.ev_h2d1, 0));
+    if (d->slot_of_chunk[0] >= 0) DX_TRY(hipStreamWaitEvent(A, d->slots[d->slot_of_chunk[0]].ev_status, 0));   // B(k - 2): the persistent slabs it read
+    ChunkStatus init;
+    std::memset(&init, 0, sizeof init);
+    init.err_key = kNoError;
+    init.matcher_err = kNoError;
+    *s.h_status = init;
+    DX_TRY(hipMemcpyAsync(s.d_status, s.h_status, sizeof init, hipMemcpyHostToDevice, A));
+    DX_TRY(hipEventRecord(s.ev[0], A));
+    hipLaunchKernelGGL(k_count_lines, dim3(max_tiles, C.n_inputs), dim3(256), 0, A, T);
+    DX_TRY(hipGetLastError());
+    hipLaunchKernelGGL(k_scan_tiles, dim3(C.n_inputs), dim3(1024), 0, A, T, s.d_status);
+    DX_TRY(hipGetLastError());
+    hipLaunchKernelGGL(k_line_starts, dim3(max_tiles, C.n_inputs), dim3(256), 0, A, T, 4u * n);
+    DX_TRY(hipGetLastError());
+    const uint32_t g256 = (n + 255u) / 256u;
+    hipLaunchKernelGGL(k_records, dim3(g256), dim3(256), 0, A, T, C, n, s.skip.p, s.bc_len.p, s.d_status);
+    DX_TRY(hipGetLastError());
+    uint32_t stride = (C.fixed_bc_len + 3u) / 4u * 4u;
+    if (C.variable_bc) {   // a '+B' segment: the longest barcode of the chunk decides the row width (one host round trip)
+        uint32_t mx = 0;
+        DX_TRY(hipMemcpyAsync(&mx, &s.d_status->max_bc_len, sizeof mx, hipMemcpyDeviceToHost, A));
+        DX_TRY(hipStreamSynchronize(A));
+        stride = (std::max(mx, C.fixed_bc_len) + 3u) / 4u * 4u;
+    }
+    if (stride == 0) stride = 4;
+    s.stride = stride;
+    if ((rc = s.obs.ensure((size_t)n * stride + 64)) != FQTK_OK) return rc;
+    hipLaunchKernelGGL(k_extract, dim3(g256), dim3(256), 0, A, T, C, n, stride, s.skip.p, s.bc_len.p, s.obs.p, C.use_lens ? s.lens.p : (uint32_t *)nullptr, s.d_status);
+    DX_TRY(hipGetLastError());
+    DX_TRY(hipEventRecord(s.ev[1], A));
+    if ((rc = fqtk_matcher_assign_batch_device(d->m, s.obs.p, stride, C.use_lens ? s.lens.p : nullptr, n, s.res.p, nullptr, A)) != FQTK_OK) return rc;
+    if ((rc = fqtk::internal::take_device_error(d->m, A, &s.d_status->matcher_err)) != FQTK_OK) return rc;
+    DX_TRY(hipEventRecord(s.ev[2], A));
+    DX_TRY(hipMemsetAsync(s.tile_tot.p, 0, (size_t)n_tiles * d->cols * sizeof(uint32_t), A));
+    hipLaunchKernelGGL(k_plan_rank, dim3(n_tiles), dim3(kTile), 0, A, T, C, n, s.res.p, s.skip.p, s.plans.p, s.rec_off.p, s.tile_tot.p, s.d_status);
+    DX_TRY(hipGetLastError());
+    hipLaunchKernelGGL(k_column_scan, dim3((d->cols + 255u) / 256u), dim3(256), 0, A, s.tile_tot.p, n_tiles, d->cols, s.chunk_tot.p);
+    DX_TRY(hipGetLastError());
+    hipLaunchKernelGGL(k_layout, dim3(1), dim3(1024), 0, A, C, s.chunk_tot.p, d->d_fs, s.fc.p, d->d_counts, d->carry ? 0u : 1u, s.d_status);
+    DX_TRY(hipGetLastError());
+    hipLaunchKernelGGL(k_descs, dim3((uint32_t)((max_blocks + 255) / 256)), dim3(256), 0, A, C, s.fc.p, d->d_persist, s.slabs.p, s.out_slabs.p, s.desc.p, s.blk_file.p, s.d_status);
+    DX_TRY(hipGetLastError());
+    DX_TRY(hipEventRecord(s.ev[3], A));
+    hipLaunchKernelGGL(k_format, dim3((n + kFormatWaves - 1) / kFormatWaves), dim3(64 * kFormatWaves), 0, A, T, C, n, s.res.p, s.skip.p, s.plans.p,
+                       s.rec_off.p, s.tile_tot.p, s.fc.p, d->d_persist, s.slabs.p, s.d_status);
+    DX_TRY(hipGetLastError());
+    DX_TRY(hipEventRecord(s.ev[4], A));
+    DX_TRY(hipEventRecord(s.ev_fmt, A));
+    // stream B
+    DX_TRY(hipStreamWaitEvent(d->s_b, s.ev_fmt, 0));
+    if ((rc = enqueue_compress(d, s)) != FQTK_OK) return rc;
+    s.busy = true;
+    s.flush_only = false;
+    s.n = n;
+    d->slot_of_chunk[0] = d->slot_of_chunk[1];
+    d->slot_of_chunk[1] = slot;
+    ++d->chunk_no;
+    return FQTK_OK;
+}
+
+int fqtk_demuxer_collect(fqtk_demuxer *d, int slot, fqtk_demux_result *res) {
+    if (!d || !res) return set_error(FQTK_EINVAL, "NULL argument");
+    if (slot < 0 || slot >= FQTK_DEMUX_SLOTS) return set_error(FQTK_EINVAL, "slot out of range");
+    Slot &s = d->slots[slot];
+    if (!s.busy) return set_error(FQTK_EINVAL, "nothing was submitted on this slot");
+    DX_TRY(hipSetDevice(d->device));
+    const int rc = fill_result(d, s, res);
+    s.busy = false;
+    return rc;
+}
+
+int fqtk_demuxer_flush(fqtk_demuxer *d, fqtk_demux_result *res) {
+    if (!d || !res) return set_error(FQTK_EINVAL, "NULL argument");
+    for (Slot &s : d->slots) if (s.busy) return set_error(FQTK_EINVAL, "collect every chunk before the flush");
+    DX_TRY(hipSetDevice(d->device));
+    for (hipStream_t st : {d->s_a, d->s_b}) DX_TRY(hipStreamSynchronize(st));
+    Slot &s = d->slots[0];
+    int rc;
+    const size_t max_blocks = (size_t)d->n_cols + 2;
+    if (s.max_blocks < max_blocks && (rc = ensure_blocks(s, max_blocks)) != FQTK_OK) return rc;
+    hipStream_t A = d->s_a;
+    ChunkStatus init;
+    std::memset(&init, 0, sizeof init);
+    init.err_key = kNoError;
+    init.matcher_err = kNoError;
+    *s.h_status = init;
+    DX_TRY(hipMemcpyAsync(s.d_status, s.h_status, sizeof init, hipMemcpyHostToDevice, A));
+    hipLaunchKernelGGL(k_layout, dim3(1), dim3(1024), 0, A, d->C, (const uint32_t *)nullptr, d->d_fs, s.fc.p, d->d_counts, 1u, s.d_status);
+    DX_TRY(hipGetLastError());
+    hipLaunchKernelGGL(k_descs, dim3((uint32_t)((max_blocks + 255) / 256)), dim3(256), 0, A, d->C, s.fc.p, d->d_persist, s.slabs.p, s.out_slabs.p, s.desc.p, s.blk_file.p, s.d_status);
+    DX_TRY(hipGetLastError());
+    DX_TRY(hipEventRecord(s.ev_fmt, A));
+    DX_TRY(hipStreamWaitEvent(d->s_b, s.ev_fmt, 0));
+    if ((rc = enqueue_compress(d, s)) != FQTK_OK) return rc;
+    s.flush_only = true;
+    s.n = 0;
+    rc = fill_result(d, s, res);
+    s.flush_only = false;
+    return rc;
+}
+
+int fqtk_demuxer_counts(fqtk_demuxer *d, uint64_t *counts) {
+    if (!d || !counts) return set_error(FQTK_EINVAL, "NULL argument");
+    DX_TRY(hipSetDevice(d->device));
+    DX_TRY(hipStreamSynchronize(d->s_a));
+    std::vector<unsigned long long> h((size_t)d->C.n_samples + 1);
+    DX_TRY(hipMemcpy(h.data(), d->d_counts, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    for (size_t i = 0; i < h.size(); ++i) counts[i] += (uint64_t)h[i];
+    return FQTK_OK;
+}
+
+int fqtk_demuxer_stage_seconds(fqtk_demuxer *d, double *seconds) {
+    if (!d || !seconds) return set_error(FQTK_EINVAL, "NULL argument");
+    for (int k = 0; k < FQTK_DEMUX_STAGES; ++k) seconds[k] = d->stage_s[k];
+    return FQTK_OK;
+}
+
+const char *fqtk_demuxer_stage_name(int stage) {
+    static const char *kNames[FQTK_DEMUX_STAGES] = {"h2d", "index", "match", "place", "format", "deflate", "pack", "d2h"};
+    return stage >= 0 && stage < FQTK_DEMUX_STAGES ? kNames[stage] : "";
+}
+
+}  // extern "C"

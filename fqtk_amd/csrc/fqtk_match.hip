@@ -720,18 +720,9 @@ bool decode_like_reference(const uint8_t *read, uint32_t len, std::string *out) 
     return true;
 }
 
-// Reads + clears one latched error word.  Stream must be idle for the value to be final.  On an error
-// the message is the reference's own sentence (barcode_matching.rs:95-107: assign_internal compares
-// with sample 0 first, so that is the sample it names), followed by the read's index in its batch.
-int collect_error(fqtk_matcher *m, hipStream_t stream, int err_word, const ErrCtx &ctx, uint64_t *read_index) {
-    unsigned long long *d_err = m->d_err + err_word, *h_err = m->h_err + err_word;
-    HIP_TRY(hipMemcpyAsync(h_err, d_err, sizeof(unsigned long long), hipMemcpyDeviceToHost, stream));
-    HIP_TRY(hipStreamSynchronize(stream));
-    const unsigned long long e = *h_err;
-    if (e == ~0ull) return FQTK_OK;
-    HIP_TRY(hipMemsetAsync(d_err, 0xFF, sizeof(unsigned long long), stream));
-    HIP_TRY(hipStreamSynchronize(stream));
-    if (read_index) *read_index = (uint64_t)e;
+// The reference's panic sentence for read `e` of a batch (barcode_matching.rs:95-107: assign_internal compares with
+// sample 0 first, so that is the sample it names), followed by the read's index in its batch.  Returns FQTK_ELEN.
+int word_length_error(fqtk_matcher *m, const ErrCtx &ctx, unsigned long long e) {
     std::string msg;
     std::vector<uint8_t> read;
     uint32_t len = 0;
@@ -764,6 +755,20 @@ int collect_error(fqtk_matcher *m, hipStream_t stream, int err_word, const ErrCt
     return fail(FQTK_ELEN, msg);
 }
 
+// Reads + clears one latched error word.  Stream must be idle for the value to be final.  On an error
+// the message is the reference's own sentence (barcode_matching.rs:95-107: assign_internal compares
+// with sample 0 first, so that is the sample it names), followed by the read's index in its batch.
+int collect_error(fqtk_matcher *m, hipStream_t stream, int err_word, const ErrCtx &ctx, uint64_t *read_index) {
+    unsigned long long *d_err = m->d_err + err_word, *h_err = m->h_err + err_word;
+    HIP_TRY(hipMemcpyAsync(h_err, d_err, sizeof(unsigned long long), hipMemcpyDeviceToHost, stream));
+    HIP_TRY(hipStreamSynchronize(stream));
+    const unsigned long long e = *h_err;
+    if (e == ~0ull) return FQTK_OK;
+    HIP_TRY(hipMemsetAsync(d_err, 0xFF, sizeof(unsigned long long), stream));
+    HIP_TRY(hipStreamSynchronize(stream));
+    if (read_index) *read_index = (uint64_t)e;
+    return word_length_error(m, ctx, e);
+}
 
 // ---- complete-memo construction (see memo_kernels.hip.h) -----------------------------------------
 constexpr uint64_t kMemoCandidateBudget = 6000000;   // strings scanned at create time, at most
@@ -1529,3 +1534,22 @@ int fqtk_matchers_allreduce_counts(fqtk_matcher *const *ms, int n, int force_col
 }
 
 }  // extern "C"
+
+// ---- internal to libfqtk_match.so (matcher_internal.hpp): the record pipeline of fqtk_demux.hip ----------------------
+namespace fqtk {
+namespace internal {
+int set_error(int code, const std::string &msg) { return fail(code, msg); }
+
+int take_device_error(fqtk_matcher *m, hipStream_t stream, unsigned long long *d_dst) {
+    unsigned long long *w = m->d_err + kDeviceErrWord;
+    HIP_TRY(hipMemcpyAsync(d_dst, w, sizeof(unsigned long long), hipMemcpyDeviceToDevice, stream));
+    HIP_TRY(hipMemsetAsync(w, 0xFF, sizeof(unsigned long long), stream));
+    return FQTK_OK;
+}
+
+int word_device_length_error(fqtk_matcher *m, const uint8_t *d_obs, const uint32_t *d_lens, uint32_t stride, uint64_t n, uint64_t index) {
+    (void)hipSetDevice(m->device);
+    return word_length_error(m, ErrCtx{d_obs, d_lens, stride, n, true}, index);
+}
+}  // namespace internal
+}  // namespace fqtk

@@ -117,6 +117,45 @@ class BlockInflater {
     void *d_ = nullptr;
 };
 
+// Number of '\n' in [p, p + n): 32 bytes per step where the CPU has AVX2 (the record pipeline cuts its inputs by this
+// count alone: a FASTQ record is four lines).
+inline size_t count_newlines_scalar(const char *p, size_t n) {
+    size_t c = 0;
+    for (size_t i = 0; i < n; ++i) c += p[i] == '\n';
+    return c;
+}
+#if defined(__x86_64__) && defined(__GNUC__)
+__attribute__((target("avx2,popcnt"))) inline size_t count_newlines_avx2(const char *p, size_t n) {
+    typedef char v32 __attribute__((vector_size(32), aligned(1)));
+    const v32 nl = {'\n', '\n', '\n', '\n', '\n', '\n', '\n', '\n', '\n', '\n', '\n', '\n', '\n', '\n', '\n', '\n',
+                    '\n', '\n', '\n', '\n', '\n', '\n', '\n', '\n', '\n', '\n', '\n', '\n', '\n', '\n', '\n', '\n'};
+    size_t c = 0, i = 0;
+    for (; i + 128 <= n; i += 128) {
+        const v32 a = *reinterpret_cast<const v32 *>(p + i) == nl, b = *reinterpret_cast<const v32 *>(p + i + 32) == nl;
+        const v32 d = *reinterpret_cast<const v32 *>(p + i + 64) == nl, e = *reinterpret_cast<const v32 *>(p + i + 96) == nl;
+        c += (size_t)__builtin_popcount((unsigned)__builtin_ia32_pmovmskb256(a)) + (size_t)__builtin_popcount((unsigned)__builtin_ia32_pmovmskb256(b)) +
+             (size_t)__builtin_popcount((unsigned)__builtin_ia32_pmovmskb256(d)) + (size_t)__builtin_popcount((unsigned)__builtin_ia32_pmovmskb256(e));
+    }
+    for (; i < n; ++i) c += p[i] == '\n';
+    return c;
+}
+#endif
+inline size_t count_newlines(const char *p, size_t n) {
+#if defined(__x86_64__) && defined(__GNUC__)
+    static const bool avx2 = __builtin_cpu_supports("avx2") && __builtin_cpu_supports("popcnt");
+    if (avx2) return count_newlines_avx2(p, n);
+#endif
+    return count_newlines_scalar(p, n);
+}
+
+// Destination of FastqSource::next_raw: a buffer the caller can enlarge (page-locked memory in `fqtk demux`).
+struct RawBuffer {
+    char *data = nullptr;
+    size_t cap = 0;
+    virtual bool grow(size_t want, size_t keep) = 0;   // cap >= want afterwards, the first `keep` bytes preserved
+    virtual ~RawBuffer() = default;
+};
+
 class FastqSource {
   public:
     enum class Kind { Plain, Gzip, Bgzf };
@@ -280,8 +319,88 @@ class FastqSource {
         return true;
     }
 
+    // The text of up to max_records records, uninterpreted, copied to dst: *n_records records in *n_bytes bytes, the
+    // last byte a newline.  Four lines are a record (seq_io's reader knows no multi-line FASTQ either): the cut is found
+    // by counting newlines; what the lines hold is checked where the text is used (the GPU record pipeline).  At the
+    // end of the input fewer records come back, then none; up to three trailing blank lines are dropped, as the
+    // parsing reader drops them.  Do not mix with next_batch() on one source.
+    bool next_raw(size_t max_records, RawBuffer *dst, size_t *n_records, size_t *n_bytes, std::string *err) {
+        if (!map_ && !producer_.joinable()) start();
+        size_t w = 0, lines = 0;
+        const size_t target = 4 * max_records;
+        auto room = [&](size_t want) { return want <= dst->cap || dst->grow(want + want / 4 + 65536, w); };
+        bool eof = false;
+        while (lines < target) {
+            const char *p = nullptr;
+            size_t avail = 0;
+            if (!raw_window(&p, &avail, &eof, err)) return false;
+            if (eof) break;
+            size_t take = std::min<size_t>(avail, 256u << 10);
+            size_t c = count_newlines(p, take);
+            if (lines + c >= target) {   // the cut lies in this block: right behind its (target - lines)-th newline
+                const char *q = p;
+                for (size_t need = target - lines; need; --need) q = static_cast<const char *>(std::memchr(q, '\n', (size_t)(p + take - q))) + 1;
+                take = (size_t)(q - p);
+                c = target - lines;
+            }
+            if (!room(w + take + 1)) { *err = "out of page-locked memory"; return false; }
+            std::memcpy(dst->data + w, p, take);
+            w += take;
+            lines += c;
+            raw_consume(take);
+        }
+        if (lines < target) {   // end of the input
+            if (w && dst->data[w - 1] != '\n') { dst->data[w++] = '\n'; ++lines; }   // final line without '\n' (room was kept)
+            size_t extra = lines % 4;
+            while (extra) {   // lines beyond the last whole record: blank, or the file is cut short
+                size_t e = w - 1;                      // the newline that ends the last line
+                size_t b = e;
+                while (b > 0 && dst->data[b - 1] != '\n') --b;
+                for (size_t q = b; q < e; ++q)
+                    if (dst->data[q] != '\r') { *err = "Unexpected error parsing FASTQs: truncated record at end of " + path_; return false; }
+                w = b;
+                --lines;
+                --extra;
+            }
+        }
+        *n_records = lines / 4;
+        *n_bytes = w;
+        nrec_ += lines / 4;
+        return true;
+    }
+    uint64_t records_read() const { return nrec_; }
 
   private:
+    // next_raw's view of the input: the unread rest of the mapping, or of the current piece of a decoded / piped input.
+    bool raw_window(const char **p, size_t *avail, bool *eof, std::string *err) {
+        if (map_) {
+            *p = map_ + map_pos_;
+            *avail = map_size_ - map_pos_;
+            *eof = *avail == 0;
+            return true;
+        }
+        while (cur_pos_ == cur_end_ && !eof_) {
+            Piece pc;
+            {
+                std::unique_lock<std::mutex> lk(mu_);
+                cv_data_.wait(lk, [&] { return !q_.empty(); });
+                pc = std::move(q_.front());
+                q_.pop_front();
+            }
+            cv_space_.notify_one();
+            if (!pc.error.empty()) { *err = pc.error; return false; }
+            if (pc.eof) { eof_ = true; break; }
+            cur_ = std::move(pc.buf);
+            cur_pos_ = pc.head;
+            cur_end_ = pc.head + pc.len;
+        }
+        *eof = cur_pos_ == cur_end_;
+        *p = cur_ ? cur_->data() + cur_pos_ : nullptr;
+        *avail = cur_end_ - cur_pos_;
+        return true;
+    }
+    void raw_consume(size_t n) { if (map_) map_pos_ += n; else cur_pos_ += n; }
+
     // Plain regular file: the records of a batch are located in the mapping itself.
     bool next_batch_mapped(size_t max_records, RecBatch *out, std::string *err) {
         out->recs.clear();

@@ -16,6 +16,7 @@
 #include "../lds_memo_plan.hpp"
 #include "../direct_memo_plan.hpp"
 #include "../bgzf_deflate.hpp"
+#include "../record_format.hpp"
 
 using namespace fqtk_host;
 
@@ -318,5 +319,83 @@ int64_t fqtk_host_bgzf_deflate_emulated(const uint8_t *in, uint32_t n, uint8_t *
     for (int l = 0; l < kLanes; ++l) bytes = phase_store(S, l, in, n, out);
     if (stored) *stored = (int)S.stored;
     return (int64_t)bytes;
+}
+
+// CRC-32 of a block the way the BGZF kernel takes it (csrc/bgzf_deflate.hpp: every lane its slice, values folded).
+uint32_t fqtk_host_bgzf_crc_emulated(const uint8_t *in, uint32_t n) {
+    using namespace fqtk::bgzf;
+    if (n == 0 || n > kMaxIn) return 0;
+    std::vector<uint8_t> mem(sizeof(Shared));
+    Shared &S = *reinterpret_cast<Shared *>(mem.data());
+    for (int l = 0; l < kLanes; ++l) crc_tables(S, l);
+    for (int l = 0; l < kLanes; ++l) phase_load(S, l, in, n);
+    for (int l = 0; l < kLanes; ++l) phase_crc(S, l, n);
+    phase_crc_fold(S);
+    return S.crc;
+}
+
+// One output record the way the GPU record pipeline states it (csrc/record_format.hpp: header plan + pieces), built
+// from strings: `header` is the first input's header, bsegs / msegs the sample / molecular barcode segments, bases and
+// quals the segment the file takes.  Returns the record's length (also what the sizing sink says), -1 - HeaderError for
+// a header the reference rejects, -100 when out is too small or the two sinks disagree.
+int64_t fqtk_host_format_record(const char *header, uint32_t read_num, const char *const *bsegs, uint32_t nb,
+                                const char *const *msegs, uint32_t nm, const char *bases, const char *quals, char *out, size_t cap) {
+    using namespace fqtk::fmt;
+    // one "text" per input: input 0 = header, then the segments
+    std::vector<std::string> texts;
+    texts.emplace_back(header);
+    std::vector<Span> b, m;
+    for (uint32_t i = 0; i < nb; ++i) { texts.emplace_back(bsegs[i]); b.push_back(Span{(uint32_t)texts.size() - 1, 0, (uint32_t)texts.back().size()}); }
+    for (uint32_t i = 0; i < nm; ++i) { texts.emplace_back(msegs[i]); m.push_back(Span{(uint32_t)texts.size() - 1, 0, (uint32_t)texts.back().size()}); }
+    texts.emplace_back(bases);
+    const Span sb{(uint32_t)texts.size() - 1, 0, (uint32_t)texts.back().size()};
+    texts.emplace_back(quals);
+    const Span sq{(uint32_t)texts.size() - 1, 0, (uint32_t)texts.back().size()};
+    const HeaderPlan p = plan_header(reinterpret_cast<const uint8_t *>(texts[0].data()), (uint32_t)texts[0].size(), nm != 0);
+    if (p.err) return -1 - (int64_t)p.err;
+    LenSink ls;
+    emit_record(ls, p, 0, read_num, b.data(), nb, m.data(), nm, sb, sq);
+    std::vector<Piece> pcs(kMaxPieces);
+    if (max_pieces(nb, nm) > (uint32_t)kMaxPieces) return -100;
+    PieceSink ps(pcs.data());
+    emit_record(ps, p, 0, read_num, b.data(), nb, m.data(), nm, sb, sq);
+    std::string rec;
+    for (uint32_t k = 0; k < ps.n; ++k) {
+        const Piece &pc = pcs[k];
+        if (pc.is_lit) for (uint32_t j = 0; j < pc.len; ++j) rec.push_back((char)(pc.lit >> (8 * j)));
+        else rec.append(texts[pc.input], pc.off, pc.len);
+    }
+    if (rec.size() != ls.n || rec.size() > cap || ps.n > max_pieces(nb, nm)) return -100;
+    std::memcpy(out, rec.data(), rec.size());
+    return (int64_t)rec.size();
+}
+
+// FastqSource::next_raw over a whole file in calls of `batch` records: the concatenated text goes to out (cap bytes),
+// the number of records of every call to counts (max_calls).  Returns the number of calls made, -1 on an error.
+namespace {
+struct HeapRaw : fqtk_host::RawBuffer {
+    std::vector<char> v;
+    bool grow(size_t want, size_t keep) override { (void)keep; v.resize(want); data = v.data(); cap = v.size(); return true; }
+};
+}  // namespace
+int64_t fqtk_host_read_raw(const char *path, uint64_t batch, char *out, size_t cap, size_t *out_len, uint64_t *counts, size_t max_calls,
+                           char *err, size_t errcap) {
+    FastqSource src;
+    std::string e;
+    if (!src.open(path, &e)) { put(e, err, errcap); return -1; }
+    HeapRaw buf;
+    buf.grow(4096, 0);   // small on purpose: the tests make it grow
+    size_t w = 0, calls = 0;
+    for (;;) {
+        size_t n = 0, bytes = 0;
+        if (!src.next_raw((size_t)batch, &buf, &n, &bytes, &e)) { put(e, err, errcap); return -1; }
+        if (n == 0) break;
+        if (w + bytes > cap || calls >= max_calls) { put("test buffer too small", err, errcap); return -1; }
+        std::memcpy(out + w, buf.data, bytes);
+        w += bytes;
+        counts[calls++] = n;
+    }
+    *out_len = w;
+    return (int64_t)calls;
 }
 }  // extern "C"

@@ -1,0 +1,200 @@
+// record_format.hpp -- the demultiplexed FASTQ record, as a list of pieces.
+//
+// SURVEY.md section 8(f) row 2.  The reference formats every output record on the host, one at a time:
+// ReadSet::write_header_internal (/root/reference/src/bin/commands/demux.rs:171-267) rewrites the header and
+// SampleWriters::write (:396-415) appends "\n<bases>\n+\n<quals>\n".  On the MI355X path the record is formatted
+// where the matcher's result already is -- in HBM -- so this file states the record ONCE, as an ordered list of
+// pieces (a span of some input's text, or up to eight literal bytes), for both users:
+//   * the device: a sizing pass adds the piece lengths up (the prefix sums over them place every record in its
+//     output file), the formatting pass copies the pieces with all 64 lanes of a wavefront (demux_kernels.hip.h);
+//   * the CPU test-suite, which runs the same functions through libfqtk_host.so against host/header.hpp and the
+//     reference's own header vectors (demux.rs:2084-2196).
+// Plain C++17, no allocation, no library calls: compiles under hipcc for the device and under g++.
+#pragma once
+#include <stdint.h>
+
+#if defined(__HIPCC__)
+#define FQTK_HD __host__ __device__
+#else
+#ifndef FQTK_HD
+#define FQTK_HD
+#endif
+#endif
+
+namespace fqtk {
+namespace fmt {
+
+// Why a record cannot be formatted (the reference returns an error / panics at the same places).
+enum HeaderError : uint8_t {
+    kHeaderOk = 0,
+    kTooManyNameSegments = 1,   // "Can't handle read name with more than 8 segments"   demux.rs:197-199
+    kEmptyComment = 2,          // comment present but empty: the reference unwraps chars.last()    :225
+    kCommentNot4Segments = 3,   // more than three ':' in the comment                                 :234
+    kMalformedComment = 4,      // nothing left of the comment after its first field                 :252
+};
+
+// What write_header_internal decides from the input header alone (the header of the FIRST input, :126-139).
+struct HeaderPlan {
+    uint32_t name_len;    // bytes before the first space (the whole header when there is none)
+    uint32_t copy_off;    // part of the comment that is copied: all of it (kind 1) or what follows its first ':' (kind 2)
+    uint32_t copy_len;
+    uint8_t kind;         // 0: no comment -> "<n>:N:0:"   1: fewer than 3 colons -> comment as it is   2: "<n>:" + rest
+    uint8_t tail;         // byte appended after the copied part (':' or '+'), 0 = none
+    uint8_t msep;         // what joins the name and the first molecular barcode: ':' or '+' (8th name field = a UMI)
+    uint8_t err;          // HeaderError
+};
+
+FQTK_HD inline HeaderPlan plan_header(const uint8_t *h, uint32_t len, bool have_molecular) {
+    HeaderPlan p;
+    p.name_len = len;
+    p.copy_off = 0;
+    p.copy_len = 0;
+    p.kind = 0;
+    p.tail = 0;
+    p.msep = ':';
+    p.err = kHeaderOk;
+    uint32_t sp = len;
+    for (uint32_t i = 0; i < len; ++i)
+        if (h[i] == ' ') { sp = i; break; }
+    p.name_len = sp;
+    if (have_molecular) {   // demux.rs:188-211
+        uint32_t colons = 0;
+        for (uint32_t i = 0; i < sp; ++i) colons += h[i] == ':';
+        if (colons > 7) { p.err = kTooManyNameSegments; return p; }
+        p.msep = colons == 7 ? '+' : ':';
+    }
+    if (sp == len) return p;   // no comment: "<n>:N:0:"
+    const uint32_t c0 = sp + 1, clen = len - c0;
+    if (clen == 0) { p.err = kEmptyComment; return p; }
+    uint32_t colons = 0, first = clen;
+    for (uint32_t i = 0; i < clen; ++i)
+        if (h[c0 + i] == ':') { if (first == clen) first = i; ++colons; }
+    const uint8_t last = h[len - 1];
+    if (colons < 3) {   // demux.rs:227-232
+        p.kind = 1;
+        p.copy_off = c0;
+        p.copy_len = clen;
+        p.tail = last != ':' ? ':' : 0;
+        return p;
+    }
+    if (colons != 3) { p.err = kCommentNot4Segments; return p; }
+    // Illumina can place a "0" in the index position of unmatched FASTQs: a trailing digit goes (demux.rs:241-246)
+    const uint32_t drop = (last >= '0' && last <= '9') ? 1u : 0u;
+    p.kind = 2;
+    p.copy_off = c0 + first + 1;
+    p.copy_len = clen - (first + 1) - drop;
+    if (p.copy_len == 0) { p.err = kMalformedComment; return p; }
+    p.tail = h[p.copy_off + p.copy_len - 1] != ':' ? '+' : 0;
+    return p;
+}
+
+// A span of an input's text.
+struct Span { uint32_t input, off, len; };
+
+// What one output file takes from a template: which segment, and the read number its header carries.
+struct FileSeg { uint32_t input; uint32_t offset; int32_t length; uint32_t read_num; };
+// A segment of a read structure by position: [offset, offset + length), length < 0 = to the end of the read.
+struct SegPos { uint32_t input; uint32_t offset; int32_t length; };
+
+FQTK_HD inline void segment_span(uint32_t offset, int32_t length, uint32_t read_len, uint32_t *lo, uint32_t *hi) {
+    uint32_t e = length >= 0 ? offset + (uint32_t)length : read_len;
+    if (e > read_len) e = read_len;
+    *hi = e;
+    *lo = offset > e ? e : offset;
+}
+
+FQTK_HD inline uint32_t decimal_digits(uint32_t v, uint8_t *out /* >= 10 bytes */) {
+    uint8_t tmp[10];
+    uint32_t n = 0;
+    do { tmp[n++] = (uint8_t)('0' + v % 10u); v /= 10u; } while (v);
+    for (uint32_t i = 0; i < n; ++i) out[i] = tmp[n - 1 - i];
+    return n;
+}
+
+// Emits the record of one output file as pieces, in order.  Sink: lit(byte), span(input, off, len).
+// `head`: the first input's header (input 0, bytes [head_off, head_off + head_len) of its text, without '@').
+template <typename Sink>
+FQTK_HD inline void emit_record(Sink &s, const HeaderPlan &p, uint32_t head_off, uint32_t read_num,
+                                const Span *bsegs, uint32_t nb, const Span *msegs, uint32_t nm,
+                                const Span &bases, const Span &quals) {
+    s.lit('@');
+    s.span(0, head_off, p.name_len);
+    if (nm) {
+        s.lit(p.msep);
+        for (uint32_t i = 0; i < nm; ++i) {
+            if (i) s.lit('+');
+            s.span(msegs[i].input, msegs[i].off, msegs[i].len);
+        }
+    }
+    s.lit(' ');
+    if (p.kind != 1) {
+        uint8_t d[10];
+        const uint32_t nd = decimal_digits(read_num, d);
+        for (uint32_t i = 0; i < nd; ++i) s.lit(d[i]);
+        s.lit(':');
+        if (p.kind == 0) { s.lit('N'); s.lit(':'); s.lit('0'); s.lit(':'); }
+    }
+    if (p.kind != 0) {
+        s.span(0, head_off + p.copy_off, p.copy_len);
+        if (p.tail) s.lit(p.tail);
+    }
+    for (uint32_t i = 0; i < nb; ++i) {
+        if (i) s.lit('+');
+        s.span(bsegs[i].input, bsegs[i].off, bsegs[i].len);
+    }
+    s.lit('\n');
+    s.span(bases.input, bases.off, bases.len);
+    s.lit('\n');
+    s.lit('+');
+    s.lit('\n');
+    s.span(quals.input, quals.off, quals.len);
+    s.lit('\n');
+}
+
+// Sizing sink.
+struct LenSink {
+    uint32_t n = 0;
+    FQTK_HD void lit(uint8_t) { ++n; }
+    FQTK_HD void span(uint32_t, uint32_t, uint32_t len) { n += len; }
+};
+
+// Piece list: spans as they are, runs of literals packed eight to a piece.
+constexpr int kMaxPieces = 64;
+struct Piece {
+    uint64_t lit;        // literal bytes, first byte lowest (is_lit)
+    uint32_t off, len;   // span: offset in its input's text
+    uint16_t input;
+    uint16_t is_lit;
+};
+struct PieceSink {
+    Piece *pc;
+    uint32_t n = 0;
+    FQTK_HD explicit PieceSink(Piece *p) : pc(p) {}
+    FQTK_HD void lit(uint8_t b) {
+        if (n && pc[n - 1].is_lit && pc[n - 1].len < 8) {
+            pc[n - 1].lit |= (uint64_t)b << (8 * pc[n - 1].len);
+            ++pc[n - 1].len;
+            return;
+        }
+        pc[n].lit = b;
+        pc[n].off = 0;
+        pc[n].len = 1;
+        pc[n].input = 0;
+        pc[n].is_lit = 1;
+        ++n;
+    }
+    FQTK_HD void span(uint32_t input, uint32_t off, uint32_t len) {
+        if (!len) return;
+        pc[n].lit = 0;
+        pc[n].off = off;
+        pc[n].len = len;
+        pc[n].input = (uint16_t)input;
+        pc[n].is_lit = 0;
+        ++n;
+    }
+};
+// Upper bound of the pieces of one record (every literal its own run at worst between spans).
+FQTK_HD inline uint32_t max_pieces(uint32_t nb, uint32_t nm) { return 2u * (nb + nm) + 14u; }
+
+}  // namespace fmt
+}  // namespace fqtk

@@ -1,0 +1,122 @@
+/*
+ * fqtk_demux.h -- C ABI of the MI355X record pipeline of `fqtk demux` (part of libfqtk_match.so).
+ *
+ * The rows either side of the barcode matcher, moved onto the device so that the text of a
+ * template crosses PCIe once in and its compressed records once out:
+ *
+ *   reference (host, one template at a time)                           here (device, one chunk of templates at a time)
+ *   ------------------------------------------------------------------ -------------------------------------------------
+ *   seq_io fastq::Reader + ReadSetIterator::next   demux.rs:285-343    line index + record validation + segment extraction
+ *   ReadSet::sample_barcode_sequence               demux.rs:121-123    barcode rows packed for the matcher (fqtk_match.h)
+ *   BarcodeMatcher::assign                         demux.rs:968        fqtk_matcher_assign_batch_device
+ *   DemuxMetric counting                           demux.rs:970-974    per-sample counts (a column of the placement sums)
+ *   ReadSet::write_header_internal                 demux.rs:171-267    header plan + record pieces (csrc/record_format.hpp)
+ *   SampleWriters::write                           demux.rs:396-415    records placed by stable per-file prefix sums,
+ *                                                                      copied into 65 280-byte blocks in HBM, input order kept
+ *   pooled-writer BgzfCompressor (libdeflater)     demux.rs:755-798    fqtk::bgzf::deflate_kernel + CRC-32 on those blocks,
+ *                                                                      whole BGZF members packed per output file
+ *
+ * The caller (csrc/host/demux.cpp) keeps what is I/O: it reads / gunzips each input, cuts it after the same number of
+ * records in every input (a record is four lines: counting '\n' is all the host does with the text), hands the raw text
+ * over, and appends the returned bytes to the output files.  File f of sample s (s == n_samples: unmatched) is column
+ * s * files_per_sample + f; the files of a sample are ordered as demux.rs:674-688 orders them: by output type in the
+ * order T, B, M, C (the requested ones), and within a type by position of the segment in the read structures.
+ *
+ * Plain pointers and sizes; status codes of fqtk_match.h; no CPU fallback (FQTK_ENODEV without a GPU).
+ * A handle is not thread-safe: one thread submits, the same or another single thread collects, in slot order.
+ */
+#ifndef FQTK_DEMUX_H
+#define FQTK_DEMUX_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#include "fqtk_match.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FQTK_DEMUX_SLOTS 3        /* chunks in flight */
+#define FQTK_DEMUX_MAX_INPUTS 16
+#define FQTK_DEMUX_MAX_FILES 32   /* output files per sample */
+
+/* One segment of a read structure (`read-structure` crate: <length|+><T|B|M|C|S>); offset = sum of the lengths before it. */
+typedef struct fqtk_demux_segment {
+    uint32_t offset;
+    int32_t length; /* -1: '+', the rest of the read (last segment only) */
+    char kind;      /* 'T' 'B' 'M' 'C' 'S' */
+} fqtk_demux_segment;
+
+typedef struct fqtk_demux_config {
+    uint32_t n_inputs;
+    const uint32_t *n_segments;         /* per input */
+    const fqtk_demux_segment *segments; /* all inputs' segments, input after input */
+    uint8_t want[4];                    /* which segment types get output files: T, B, M, C (demux.rs:608-612) */
+    int skip_too_few_bases;             /* -S too-few-bases: such templates are dropped and counted (demux.rs:300-306),
+                                           otherwise the first one is an error (:307-313) */
+    uint32_t max_chunk_templates;       /* largest n_templates of a submit (buffers are sized by it) */
+    int carry_blocks;                   /* 1: a file's partly filled block waits for the next chunk (one device);
+                                           0: every chunk ends all its blocks (chunks of one run spread over devices) */
+    int compression_level;              /* --compression-level (demux.rs:641-643): parse effort of the DEFLATE kernel */
+} fqtk_demux_config;
+
+typedef struct fqtk_demuxer fqtk_demuxer;
+
+/* Why a chunk failed (status FQTK_EINVAL from collect unless said otherwise); `template_index` is the lowest
+ * offending template of the chunk, `input` the input file it was found in. */
+#define FQTK_DEMUX_OK 0
+#define FQTK_DEMUX_ERR_NO_AT 1        /* record does not start with '@' */
+#define FQTK_DEMUX_ERR_NO_PLUS 2      /* third line does not start with '+' */
+#define FQTK_DEMUX_ERR_QUAL_LEN 3     /* sequence and quality lengths differ */
+#define FQTK_DEMUX_ERR_LINES 4        /* the text does not hold 4 * n_templates lines */
+#define FQTK_DEMUX_ERR_TOO_SHORT 5    /* read shorter than its read structure needs (no -S too-few-bases) */
+#define FQTK_DEMUX_ERR_BARCODE_LEN 6  /* FQTK_ELEN of the matcher: fqtk_last_error() is the reference's panic text */
+#define FQTK_DEMUX_ERR_HEADER 7       /* write_header_internal's errors; `detail` = fqtk::fmt::HeaderError */
+
+typedef struct fqtk_demux_result {
+    const uint8_t *bytes;      /* whole BGZF members, the files' runs one after another (valid until the slot is reused) */
+    const uint64_t *file_off;  /* n_files + 1 offsets into bytes: file c's members are bytes[file_off[c] .. file_off[c+1]) */
+    uint64_t n_files;
+    uint64_t n_blocks;         /* BGZF members in this result */
+    uint32_t n_templates;      /* templates of the chunk (0 for a flush) */
+    uint32_t n_skipped;        /* of them dropped for too few bases */
+    int error;                 /* FQTK_DEMUX_ERR_* */
+    uint32_t error_input, error_template, error_detail;
+} fqtk_demux_result;
+
+/* The matcher decides device and sample count; it must outlive the demuxer and is used by it (do not enqueue on it
+ * from elsewhere meanwhile).  FQTK_EINVAL: no sample-barcode... (any configuration the reference accepts is accepted;
+ * more than FQTK_DEMUX_MAX_INPUTS inputs, more than FQTK_DEMUX_MAX_FILES files per sample or more than 24 barcode
+ * segments are not). */
+int fqtk_demuxer_create(fqtk_matcher *m, const fqtk_demux_config *cfg, fqtk_demuxer **out);
+void fqtk_demuxer_destroy(fqtk_demuxer *d);
+
+uint32_t fqtk_demuxer_files_per_sample(const fqtk_demuxer *d);
+
+/* Enqueues one chunk on `slot` (0..FQTK_DEMUX_SLOTS-1, used round robin) and returns at once: text[i] is input i's
+ * FASTQ text of exactly n_templates records (text_len[i] bytes ending with '\n'; page-locked memory from
+ * fqtk_pinned_alloc for an asynchronous copy) and must stay valid until the slot's collect(). */
+int fqtk_demuxer_submit(fqtk_demuxer *d, int slot, const uint8_t *const *text, const uint64_t *text_len,
+                        uint32_t n_templates);
+
+/* Waits for the chunk on `slot`.  FQTK_OK with res->error == 0: res holds the members to append to the files.
+ * res->error != 0: nothing of the chunk was written into the result; the run cannot continue. */
+int fqtk_demuxer_collect(fqtk_demuxer *d, int slot, fqtk_demux_result *res);
+
+/* After the last chunk has been collected: ends every partly filled block (carry_blocks) and returns those members
+ * the same way (the 28-byte BGZF EOF marker is the caller's to write). */
+int fqtk_demuxer_flush(fqtk_demuxer *d, fqtk_demux_result *res);
+
+/* Adds the per-sample template counts (n_samples + 1, unmatched last) of all collected chunks into counts. */
+int fqtk_demuxer_counts(fqtk_demuxer *d, uint64_t *counts);
+
+/* Seconds of device time per stage, summed over the chunks collected so far (names: fqtk_demuxer_stage_name). */
+#define FQTK_DEMUX_STAGES 8
+int fqtk_demuxer_stage_seconds(fqtk_demuxer *d, double *seconds /* FQTK_DEMUX_STAGES */);
+const char *fqtk_demuxer_stage_name(int stage);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FQTK_DEMUX_H */
