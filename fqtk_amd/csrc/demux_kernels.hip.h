@@ -319,13 +319,7 @@ __global__ __launch_bounds__(1024) void k_plan_rank(TextSet T, DevConfig C, uint
             fmt::segment_span(C.mseg[b].offset, C.mseg[b].length, T.rec[C.mseg[b].input][t].seq_len, &lo, &hi);
             ml += hi - lo;
         }
-        uint32_t len = 1u + tp.h.name_len + 1u;                          // '@' name ' '
-        if (C.n_m) len += 1u + ml + (C.n_m - 1u);                        // sep M1+M2..
-        if (tp.h.kind == 0) len += 1u + 5u;                              // "1:N:0:"
-        else if (tp.h.kind == 1) len += tp.h.copy_len + (tp.h.tail ? 1u : 0u);
-        else len += 1u + 1u + tp.h.copy_len + (tp.h.tail ? 1u : 0u);    // "1:" rest [+]
-        if (C.n_b) len += bl + (C.n_b - 1u);
-        len += 6u;                                                       // "\n" "\n+\n" "\n"
+        const uint32_t len = fmt::record_len(tp.h, 1u, bl, C.n_b, ml, C.n_m, 0u);
         tp.base_len = len;
         plans[t] = tp;
     }

@@ -365,6 +365,11 @@ int64_t fqtk_host_format_record(const char *header, uint32_t read_num, const cha
         if (pc.is_lit) for (uint32_t j = 0; j < pc.len; ++j) rec.push_back((char)(pc.lit >> (8 * j)));
         else rec.append(texts[pc.input], pc.off, pc.len);
     }
+    uint32_t bl = 0, ml = 0, digits = 0;
+    for (const Span &x : b) bl += x.len;
+    for (const Span &x : m) ml += x.len;
+    for (uint32_t v = read_num; digits == 0 || v; v /= 10) ++digits;
+    if (record_len(p, digits, bl, nb, ml, nm, sb.len) != ls.n) return -100;
     if (rec.size() != ls.n || rec.size() > cap || ps.n > max_pieces(nb, nm)) return -100;
     std::memcpy(out, rec.data(), rec.size());
     return (int64_t)rec.size();

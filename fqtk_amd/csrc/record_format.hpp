@@ -151,6 +151,19 @@ FQTK_HD inline void emit_record(Sink &s, const HeaderPlan &p, uint32_t head_off,
     s.lit('\n');
 }
 
+// Length of that record from sums alone (the placement kernel sizes every record of a chunk before any is written):
+// `digits` of the read number, `bl` / `ml` bases in the nb sample / nm molecular barcode segments, `seg` bases in the
+// file's own segment.  Checked against the sizing sink in the CPU tests.
+FQTK_HD inline uint32_t record_len(const HeaderPlan &p, uint32_t digits, uint32_t bl, uint32_t nb, uint32_t ml, uint32_t nm, uint32_t seg) {
+    uint32_t len = 1u + p.name_len + 1u;                                    // '@' name ' '
+    if (nm) len += 1u + ml + (nm - 1u);                                     // sep M1+M2..
+    if (p.kind == 0) len += digits + 5u;                                    // "<n>:N:0:"
+    else if (p.kind == 1) len += p.copy_len + (p.tail ? 1u : 0u);           // the comment as it is [:]
+    else len += digits + 1u + p.copy_len + (p.tail ? 1u : 0u);              // "<n>:" rest [+]
+    if (nb) len += bl + (nb - 1u);                                          // B1+B2..
+    return len + 5u + 2u * seg;                                             // "\n" bases "\n+\n" quals "\n"
+}
+
 // Sizing sink.
 struct LenSink {
     uint32_t n = 0;

@@ -1,0 +1,270 @@
+"""GPU parity of the record pipeline (include/fqtk_demux.h) through the C ABI: FASTQ text in, BGZF members out, compared
+record for record with the reference's semantics restated on the host -- assignments from the oracle
+(oracle/ref_literal.c), headers from host/header.hpp (write_header_internal, demux.rs:171-267), records as
+SampleWriters::write lays them out (:396-415), file order as demux.rs:674-688."""
+import gzip
+import zlib
+
+import numpy as np
+import pytest
+
+from fqtk_amd import BarcodeMatcher
+from fqtk_amd.demux import Demuxer, DemuxChunkError, parse_read_structure
+from oracle import oracle as O
+from tests import hostlib as H
+
+pytestmark = pytest.mark.gpu
+
+
+def _span(seg, read_len):
+    off, length, _ = seg
+    hi = min(off + length, read_len) if length >= 0 else read_len
+    return min(off, hi), hi
+
+
+def expected_files(barcodes, mm, delta, structures, output_types, templates, skip_short=False):
+    """templates: list of per-input (header, bases, quals).  Returns (files[(S+1)*F] as bytes, counts, skipped)."""
+    segs = [parse_read_structure(r) for r in structures]
+    by = {k: [(i, s) for i, ss in enumerate(segs) for s in ss if s[2] == k] for k in "TBMC"}
+    file_segs = [(k, j, i, s) for k in "TBMC" if k in output_types for j, (i, s) in enumerate(by[k])]
+    F, S = len(file_segs), len(barcodes)
+    files = [bytearray() for _ in range((S + 1) * F)]
+    lit = O.RefLiteral(barcodes, mm, delta, True)
+    counts = np.zeros(S + 1, dtype=np.uint64)
+    skipped = 0
+    min_len = [sum(l if l >= 0 else 1 for _, l, _ in ss) for ss in segs]
+    for tpl in templates:
+        if any(len(tpl[i][1]) < min_len[i] for i in range(len(segs))):
+            assert skip_short
+            skipped += 1
+            continue
+        def seg_text(i, s, what):
+            lo, hi = _span(s, len(tpl[i][1]))
+            return tpl[i][what][lo:hi]
+        bsegs = [seg_text(i, s, 1) for i, s in by["B"]]
+        msegs = [seg_text(i, s, 1) for i, s in by["M"]]
+        bc = "".join(bsegs).encode()
+        L = len(barcodes[0])
+        if len(bc) == L:
+            obs = np.frombuffer(bc, dtype=np.uint8).reshape(1, L)
+            idx, _, _, _ = lit.assign_batch(obs)
+            s_idx = int(idx[0])
+            s_idx = S if s_idx == 0xFFFF else s_idx
+        else:
+            assert len(bc) < L, "longer barcodes are the matcher's length error: not part of these cases"
+            s_idx = S
+        counts[s_idx] += 1
+        for f, (k, j, i, s) in enumerate(file_segs):
+            head = H.write_header(j + 1, tpl[0][0], bsegs, msegs)
+            files[s_idx * F + f] += (head + "\n" + seg_text(i, s, 1) + "\n+\n" + seg_text(i, s, 2) + "\n").encode()
+    return [bytes(f) for f in files], counts, skipped
+
+
+def make_templates(rng, n, barcodes, structures, header_kind=0, junk=0.0, short_every=0):
+    segs = [parse_read_structure(r) for r in structures]
+    out = []
+    # where the sample barcode segments are, to plant real barcodes
+    bpos = [(i, s) for i, ss in enumerate(segs) for s in ss if s[2] == "B"]
+    for t in range(n):
+        tpl = []
+        bc = barcodes[int(rng.integers(0, len(barcodes)))] if rng.random() < 0.85 else "".join(rng.choice(list("ACGT"), len(barcodes[0])))
+        bc = list(bc)
+        if rng.random() < 0.2:
+            bc[int(rng.integers(0, len(bc)))] = "ACGTN"[int(rng.integers(0, 5))]
+        bc = "".join(bc)
+        taken = 0
+        reads = []
+        for i, ss in enumerate(segs):
+            fixed = sum(l for _, l, _ in ss if l >= 0)
+            var = any(l < 0 for _, l, _ in ss)
+            rl = fixed + (int(rng.integers(1, 40)) if var else int(rng.integers(0, 3)))
+            if short_every and t % short_every == short_every - 1 and i == len(segs) - 1:
+                rl = max(0, fixed - 1)
+            reads.append(list(rng.choice(list("ACGT"), rl)))
+        for i, s in bpos:
+            lo, hi = _span(s, len(reads[i]))
+            if s[1] < 0:
+                hi = min(hi, lo + len(bc) - taken)
+                reads[i] = reads[i][:hi]
+            for k in range(lo, hi):
+                if taken < len(bc):
+                    reads[i][k] = bc[taken]
+                    taken += 1
+        for i in range(len(segs)):
+            bases = "".join(reads[i])
+            quals = "".join(rng.choice(list("#5?FI"), len(bases)))
+            if header_kind == 0:
+                head = f"inst:1:fc:{1 + t % 4}:{t}:{int(rng.integers(0, 99999))}:{t * 7} {i + 1}:N:0:{'ACGT' if t % 3 else '0'}"
+            elif header_kind == 1:
+                head = f"q{t}"
+            elif header_kind == 2:
+                head = f"r{t} some comment" if t % 2 else f"r{t} a:b:"
+            else:
+                head = f"a:b:c:d:e:f:g:UMI{t} 1:Y:18:" if t % 2 else f"x{t}:y 2:N:0:7"
+            tpl.append((head, bases, quals))
+        out.append(tpl)
+    return out
+
+
+def texts_of(templates, lo, hi, n_inputs, crlf=False):
+    nl = "\r\n" if crlf else "\n"
+    return [("".join(f"@{t[i][0]}{nl}{t[i][1]}{nl}+{nl}{t[i][2]}{nl}" for t in templates[lo:hi])).encode() for i in range(n_inputs)]
+
+
+def run_case(barcodes, mm, delta, structures, output_types, templates, chunk, skip_short=False, carry=True, crlf=False, in_flight=3):
+    m = BarcodeMatcher(barcodes, mm, delta, device=0)
+    d = Demuxer(m, structures, output_types, skip_too_few_bases=skip_short, max_chunk_templates=max(chunk, 1), carry_blocks=carry)
+    chunks = [(texts_of(templates, lo, min(lo + chunk, len(templates)), len(structures), crlf), min(chunk, len(templates) - lo))
+              for lo in range(0, len(templates), chunk)]
+    got = d.run(chunks, in_flight=in_flight)
+    want, counts, skipped = expected_files(barcodes, mm, delta, structures, output_types, templates, skip_short)
+    assert len(got) == len(want)
+    for c, (g, w) in enumerate(zip(got, want)):
+        assert gzip.decompress(g) == w, f"file column {c}"
+    assert np.array_equal(d.counts(), counts)
+    assert d.skipped == skipped
+    return d, got
+
+
+BARCODES8 = ["AAAAAAAA", "CCCCCCCC", "GGGGGGGG", "TTTTTTTT", "ACGTACGT", "TGCATGCA", "AACCGGTT", "GATTACAG"]
+
+
+@pytest.mark.parametrize("structures, types", [
+    (["8B20T"], "T"), (["8B+T"], "T"), (["4B4M+T", "4B+T"], "TBM"), (["+T", "+T", "8B"], "T"),
+    (["+T", "+T", "4B", "4B"], "TB"), (["3M2S3B10T5C", "5B+T"], "TBMC"), (["8B"], "B"), (["+T", "8B"], "TB"),
+])
+@pytest.mark.parametrize("header_kind", [0, 1, 2, 3])
+def test_small_runs_of_every_structure_and_header_shape(structures, types, header_kind):
+    rng = np.random.default_rng(zlib.crc32(repr((structures, types, header_kind)).encode()))
+    tpl = make_templates(rng, 700, BARCODES8, structures, header_kind)
+    run_case(BARCODES8, 1, 2, structures, types, tpl, chunk=256)
+
+
+def test_blocks_fill_carry_over_chunks_and_are_flushed_at_the_end():
+    rng = np.random.default_rng(1)
+    structures = ["8B+T", "+T"]
+    tpl = make_templates(rng, 9000, BARCODES8[:3], structures)      # ~1 MB per file: many full blocks, partial ones carried
+    d, got = run_case(BARCODES8[:3], 1, 2, structures, "T", tpl, chunk=1000)
+    # whole blocks of 65280 bytes except the last one of every file
+    for g in got:
+        sizes = []
+        p = 0
+        while p < len(g):
+            bsize = int.from_bytes(g[p + 16:p + 18], "little") + 1
+            sizes.append(int.from_bytes(g[p + bsize - 4:p + bsize], "little"))
+            p += bsize
+        assert sizes[-1] == 0 and all(s == 65280 for s in sizes[:-2])
+    run_case(BARCODES8[:3], 1, 2, structures, "T", tpl, chunk=1000, carry=False)      # every chunk ends its blocks
+    run_case(BARCODES8[:3], 1, 2, structures, "T", tpl, chunk=9000)                   # one chunk
+
+
+def test_chunk_sizes_around_the_tile_and_one_template_chunks():
+    rng = np.random.default_rng(2)
+    structures = ["8B10T"]
+    tpl = make_templates(rng, 2100, BARCODES8, structures, header_kind=1)
+    for chunk in (1, 1023, 1024, 1025, 2100):
+        if chunk == 1:
+            run_case(BARCODES8, 1, 2, structures, "T", tpl[:40], chunk=1)
+        else:
+            run_case(BARCODES8, 1, 2, structures, "T", tpl, chunk=chunk)
+
+
+def test_crlf_input_and_too_few_bases_skipping():
+    rng = np.random.default_rng(4)
+    structures = ["8B12T", "6T"]
+    tpl = make_templates(rng, 1500, BARCODES8, structures, short_every=7)
+    run_case(BARCODES8, 1, 2, structures, "T", tpl, chunk=400, skip_short=True)
+    run_case(BARCODES8, 1, 2, structures, "T", make_templates(rng, 500, BARCODES8, structures), chunk=200, crlf=True)
+    with pytest.raises(DemuxChunkError) as e:
+        run_case(BARCODES8, 1, 2, structures, "T", tpl, chunk=400, skip_short=False)
+    assert e.value.kind == 5 and e.value.template == 6 and e.value.input_index == 1
+
+
+def test_malformed_text_is_reported_with_its_first_template():
+    rng = np.random.default_rng(5)
+    structures = ["8B12T"]
+    tpl = make_templates(rng, 300, BARCODES8, structures, header_kind=1)
+    m = BarcodeMatcher(BARCODES8, 1, 2, device=0)
+    d = Demuxer(m, structures, "T", max_chunk_templates=300)
+    good = texts_of(tpl, 0, 300, 1)[0]
+    lines = good.split(b"\n")
+    for line_no, kind in ((4 * 17, 1), (4 * 33 + 2, 2)):
+        bad = list(lines)
+        bad[line_no] = b"x" + bad[line_no][1:]
+        d.submit(0, [b"\n".join(bad)], 300)
+        with pytest.raises(DemuxChunkError) as e:
+            d.collect(0)
+        assert (e.value.kind, e.value.template) == (kind, line_no // 4)
+    bad = list(lines)
+    bad[4 * 50 + 3] = bad[4 * 50 + 3] + b"I"
+    d.submit(0, [b"\n".join(bad)], 300)
+    with pytest.raises(DemuxChunkError) as e:
+        d.collect(0)
+    assert (e.value.kind, e.value.template) == (3, 50)
+    d.submit(0, [good], 299)                      # one record more than announced
+    with pytest.raises(DemuxChunkError) as e:
+        d.collect(0)
+    assert e.value.kind == 4
+    # header errors of write_header_internal
+    tpl2 = [list(t) for t in tpl]
+    tpl2[77][0] = ("q77 1:N:0:A:B", tpl2[77][0][1], tpl2[77][0][2])
+    d.submit(0, texts_of(tpl2, 0, 300, 1), 300)
+    with pytest.raises(DemuxChunkError) as e:
+        d.collect(0)
+    assert (e.value.kind, e.value.template, e.value.detail) == (7, 77, 3)
+
+
+def test_barcode_longer_than_expected_is_the_reference_panic():
+    structures = ["+B"]
+    m = BarcodeMatcher(BARCODES8, 1, 2, device=0)
+    d = Demuxer(m, structures, "B", max_chunk_templates=16)
+    text = b"@a\nAAAAAAAA\n+\nIIIIIIII\n@b\nAAAAAAAAC\n+\nIIIIIIIII\n"
+    d.submit(0, [text], 2)
+    with pytest.raises(DemuxChunkError) as e:
+        d.collect(0)
+    assert e.value.kind == 6 and e.value.template == 1 and "length (9) differs from expected barcode (AAAAAAAA) length (8)" in e.value.message
+
+
+def test_a_million_templates_cfg3_shape_counts_and_streams():
+    """cfg 3's shape (dual index 8+8, 384 samples) at a size where every file closes many blocks in every chunk."""
+    from fqtk_amd import synth
+    cfg = synth.CONFIGS[3]
+    w = synth.Workload(cfg)
+    n = 200_000
+    obs = w.fill_host(0, n)                                        # n x 16 barcode bytes
+    rng = np.random.default_rng(6)
+    r1 = rng.choice(np.frombuffer(b"ACGT", dtype=np.uint8), (n, 60))
+    def fastq(name_fn, bases):
+        parts = []
+        for t in range(n):
+            b = bases[t].tobytes().decode()
+            parts.append(f"@{name_fn(t)}\n{b}\n+\n{'I' * len(b)}\n")
+        return "".join(parts).encode()
+    name = lambda t: f"inst:1:fc:1:{t}:5:7 1:N:0:0"
+    texts = [fastq(name, r1), fastq(name, obs[:, :8]), fastq(name, obs[:, 8:16])]
+    m = BarcodeMatcher(w.barcodes, cfg.max_mismatches, cfg.min_mismatch_delta, device=0)
+    d = Demuxer(m, ["+T", "8B", "8B"], "T", max_chunk_templates=n)
+    # chunks of 65536 templates cut at record boundaries
+    def cut(text, lo, hi):
+        lines = text.split(b"\n")
+        return b"\n".join(lines[4 * lo:4 * hi]) + b"\n"
+    chunks = [([cut(t, lo, min(lo + 65536, n)) for t in texts], min(65536, n - lo)) for lo in range(0, n, 65536)]
+    got = d.run(chunks)
+    lit = O.RefLiteral(w.barcodes, cfg.max_mismatches, cfg.min_mismatch_delta, True)
+    idx, _, _, counts = lit.assign_batch(obs)
+    assert np.array_equal(d.counts(), counts)
+    S = cfg.n_samples
+    sample_of = np.where(idx == 0xFFFF, S, idx).astype(np.int64)
+    total = 0
+    for s in range(S + 1):
+        text = gzip.decompress(got[s]).decode()
+        recs = text.split("\n")[:-1]
+        assert len(recs) == 4 * int(counts[s])
+        ts = np.nonzero(sample_of == s)[0]
+        for k in (0, len(ts) // 2, len(ts) - 1) if len(ts) else ():
+            t = int(ts[k])
+            bc = obs[t, :8].tobytes().decode() + "+" + obs[t, 8:16].tobytes().decode()
+            assert recs[4 * k] == f"@inst:1:fc:1:{t}:5:7 1:N:0:{bc}" and recs[4 * k + 1] == r1[t].tobytes().decode()
+        total += len(recs) // 4
+    assert total == n
+    print("stage seconds:", d.stage_seconds())
