@@ -432,6 +432,29 @@ int fqtk_demuxer_collect(fqtk_demuxer *d, int slot, fqtk_demux_result *res) {
     return rc;
 }
 
+int fqtk_demuxer_text_done(fqtk_demuxer *d, int slot) {
+    if (!d) return set_error(FQTK_EINVAL, "NULL argument");
+    if (slot < 0 || slot >= FQTK_DEMUX_SLOTS) return set_error(FQTK_EINVAL, "slot out of range");
+    DX_TRY(hipSetDevice(d->device));
+    DX_TRY(hipEventSynchronize(d->slots[slot].ev_h2d1));
+    return FQTK_OK;
+}
+
+int fqtk_demuxer_record_text(fqtk_demuxer *d, int slot, uint32_t input, uint32_t t, char *header, size_t cap, uint32_t *n_bases) {
+    if (!d || !header || cap == 0) return set_error(FQTK_EINVAL, "NULL argument");
+    if (slot < 0 || slot >= FQTK_DEMUX_SLOTS || input >= d->C.n_inputs) return set_error(FQTK_EINVAL, "slot / input out of range");
+    Slot &s = d->slots[slot];
+    if (t >= s.n) return set_error(FQTK_EINVAL, "template index out of range");
+    DX_TRY(hipSetDevice(d->device));
+    RecView r;
+    DX_TRY(hipMemcpy(&r, s.rec[input].p + t, sizeof r, hipMemcpyDeviceToHost));
+    const size_t n = std::min<size_t>(r.head_len, cap - 1);
+    if (n) DX_TRY(hipMemcpy(header, s.text[input].p + r.head_off, n, hipMemcpyDeviceToHost));
+    header[n] = 0;
+    if (n_bases) *n_bases = r.seq_len;
+    return FQTK_OK;
+}
+
 int fqtk_demuxer_flush(fqtk_demuxer *d, fqtk_demux_result *res) {
     if (!d || !res) return set_error(FQTK_EINVAL, "NULL argument");
     for (Slot &s : d->slots) if (s.busy) return set_error(FQTK_EINVAL, "collect every chunk before the flush");

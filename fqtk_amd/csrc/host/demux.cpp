@@ -13,6 +13,7 @@
 //   * routing/compression is partitioned BY SAMPLE across worker threads (each output file has one
 //     owner, no locks, input order preserved per file as in the sequential reference loop).
 // All matching goes through libfqtk_match.so; there is no CPU matching path here.
+#include <fcntl.h>
 #include <sys/resource.h>
 #include <malloc.h>
 #include <sys/stat.h>
@@ -34,10 +35,10 @@
 #include <thread>
 #include <vector>
 
+#include "../../../include/fqtk_demux.h"
 #include "../../../include/fqtk_match.h"
 #include "bgzf.hpp"
 #include "fastq_io.hpp"
-#include "gpu_bgzf_stage.hpp"
 #include "header.hpp"
 #include "metrics.hpp"
 #include "read_structure.hpp"
@@ -90,7 +91,8 @@ struct Options {
     int device = 0;
     std::vector<int> devices;        // --devices a,b,..: chunk k goes to devices[k mod G]
     unsigned long chunk_reads = 1ul << 17;
-    bool gpu_bgzf = false;           // --gpu-bgzf: DEFLATE the output blocks on the GPU (additive flag)
+    bool chunk_given = false;
+    bool host_output = false;        // --host-output: format and compress the records on the host (the reference's way)
 };
 
 const char *kUsage =
@@ -110,9 +112,11 @@ const char *kUsage =
     "      --device <N>                            GPU to use [default: 0] (additive flag)\n"
     "      --devices <A,B,..>                      several GPUs: chunk k is matched on devices[k mod G] (additive flag)\n"
     "      --chunk-reads <N>                       templates per GPU chunk [default: 131072] (additive flag)\n"
-    "      --gpu-bgzf                              compress the output BGZF blocks on the GPU instead of with the\n"
-    "                                              libdeflate thread pool (additive flag; --compression-level does\n"
-    "                                              not apply: ~7 % larger files than level 5 on FASTQ text)\n";
+    "      --host-output                           parse, format and BGZF-compress the records on the host CPUs (as the\n"
+    "                                              reference does) instead of on the GPU, which is the default: there the\n"
+    "                                              inputs' text goes to the device, records are formatted and DEFLATE-compressed\n"
+    "                                              in HBM and whole BGZF members come back (additive flag; alias --no-gpu-bgzf;\n"
+    "                                              --gpu-bgzf is accepted and means the default)\n";
 
 bool parse_ulong(const std::string &s, unsigned long *out) {
     if (s.empty()) return false;
@@ -196,8 +200,9 @@ Options parse_args(int argc, char **argv) {
                 p = q + 1;
             }
         }
-        else if (a == "--chunk-reads") num(&o.chunk_reads);
-        else if (a == "--gpu-bgzf") o.gpu_bgzf = true;
+        else if (a == "--chunk-reads") { num(&o.chunk_reads); o.chunk_given = true; }
+        else if (a == "--gpu-bgzf") o.host_output = false;
+        else if (a == "--host-output" || a == "--no-gpu-bgzf") o.host_output = true;
         else if (a == "--help" || a == "-h") { std::fputs(kUsage, stdout); std::exit(0); }
         else die("unexpected argument '" + a + "' found\n\n" + kUsage);
     }
@@ -345,56 +350,6 @@ void submit_blocks(OutFile &of, JobQueues &jobs, bool final) {
     }
 }
 
-// --gpu-bgzf: the cut block goes into a slab of the page-locked arena instead (the kernel reads it from there),
-// with the CRC32 the BGZF trailer needs.
-GpuBgzfStage *g_gpu_stage = nullptr;
-void submit_blocks_gpu(OutFile &of, bool final) {
-    static const BgzfCrc crc32;
-    while (of.buf.size() >= kBgzfBlockSize || (final && !of.buf.empty())) {
-        const uint64_t ta = tick();
-        const size_t n = std::min(kBgzfBlockSize, of.buf.size());
-        GpuBlock b;
-        b.file = &of;
-        b.seq = of.next_submit++;
-        b.in_slab = g_gpu_stage->in_pool.get();
-        if (g_timing) g_times.submit_slab += tick() - ta;
-        b.n = (uint32_t)n;
-        std::memcpy(g_gpu_stage->in_slab(b.in_slab), of.buf.data(), n);
-        b.crc = crc32(of.buf.data(), n);
-        of.buf.erase(0, n);
-        const uint64_t tb = tick();
-        g_gpu_stage->to_gpu.push(b);
-        if (g_timing) { g_times.submit_calls += 1; g_times.submit_cut += tb - ta; g_times.submit_push += tick() - tb; }
-    }
-}
-
-// writer side of --gpu-bgzf: payload -> BGZF member, written in sequence order
-void write_gpu_block(const GpuBlock &b) {
-    OutFile &of = *static_cast<OutFile *>(b.file);
-    const uint64_t t0 = tick();
-    const size_t bsize = 18 + (size_t)b.out_len + 8;
-    if (bsize > 65536) die("BGZF block overflow");
-    std::vector<uint8_t> member(bsize);
-    const uint8_t hdr[18] = {0x1f, 0x8b, 0x08, 0x04, 0, 0, 0, 0, 0, 0xff, 0x06, 0, 0x42, 0x43, 0x02, 0,
-                             (uint8_t)((bsize - 1) & 0xff), (uint8_t)((bsize - 1) >> 8)};
-    std::memcpy(member.data(), hdr, 18);
-    std::memcpy(member.data() + 18, g_gpu_stage->out_slab(b.out_slab), b.out_len);
-    uint8_t *t = member.data() + 18 + b.out_len;
-    t[0] = b.crc & 0xff; t[1] = (b.crc >> 8) & 0xff; t[2] = (b.crc >> 16) & 0xff; t[3] = (b.crc >> 24) & 0xff;
-    t[4] = b.n & 0xff; t[5] = (b.n >> 8) & 0xff; t[6] = (b.n >> 16) & 0xff; t[7] = (b.n >> 24) & 0xff;
-    g_gpu_stage->out_pool.put(b.out_slab);
-    g_gpu_stage->in_pool.put(b.in_slab);
-    const uint64_t t1 = tick();
-    g_times.comp_deflate += t1 - t0;
-    std::lock_guard<std::mutex> lk(of.mu);
-    of.ready.emplace(b.seq, std::move(member));
-    for (auto it = of.ready.begin(); it != of.ready.end() && it->first == of.next_write; it = of.ready.erase(it)) {
-        if (std::fwrite(it->second.data(), 1, it->second.size(), of.f) != it->second.size()) die("write failed: " + of.path);
-        ++of.next_write;
-    }
-    g_times.comp_write += tick() - t1;
-}
-
 // Pool side: compress one block, then write it -- and any successors already waiting -- in order.
 void compress_and_write(CompressJob &j, BlockCompressor &bc) {
     std::vector<uint8_t> comp;
@@ -411,6 +366,340 @@ void compress_and_write(CompressJob &j, BlockCompressor &bc) {
         ++of.next_write;
     }
     g_times.comp_write += tick() - t1;
+}
+
+
+// ---- the GPU record pipeline (include/fqtk_demux.h): the default output path ------------------------------------------
+// The host keeps what is I/O: a reader thread per input copies the text of the next `chunk` records into page-locked
+// memory (decompressing if need be; a record is four lines, so it only counts newlines), this thread hands the chunks
+// to the device -- where the records are indexed, matched, formatted into per-file 65 280-byte blocks and DEFLATE-
+// compressed -- and a collector appends the BGZF members that come back to the output files.
+struct PinnedRaw : RawBuffer {
+    ~PinnedRaw() override { if (data) fqtk_pinned_free(data); }
+    bool grow(size_t want, size_t keep) override {
+        void *p = nullptr;
+        if (fqtk_pinned_alloc(want, &p) != FQTK_OK) return false;
+        if (keep) std::memcpy(p, data, keep);
+        if (data) fqtk_pinned_free(data);
+        data = static_cast<char *>(p);
+        cap = want;
+        return true;
+    }
+};
+struct RawChunk { PinnedRaw *buf = nullptr; size_t n = 0, bytes = 0; std::string error; };
+
+void write_all(int fd, const uint8_t *p, size_t n, const std::string &path) {
+    while (n) {
+        const ssize_t w = ::write(fd, p, n);
+        if (w < 0) { if (errno == EINTR) continue; die("write failed: " + path + ": " + std::strerror(errno)); }
+        p += w;
+        n -= (size_t)w;
+    }
+}
+
+// Which configurations the device pipeline takes (the limits of include/fqtk_demux.h); anything else is formatted on the host.
+bool gpu_output_supported(const Plan &plan, std::string *why) {
+    if (plan.rs.size() > FQTK_DEMUX_MAX_INPUTS) { *why = "more than " + std::to_string(FQTK_DEMUX_MAX_INPUTS) + " inputs"; return false; }
+    if (plan.files_per_sample > FQTK_DEMUX_MAX_FILES) { *why = "more than " + std::to_string(FQTK_DEMUX_MAX_FILES) + " output files per sample"; return false; }
+    if (plan.by_type[1].size() > 24 || plan.by_type[2].size() > 24) { *why = "more than 24 barcode segments"; return false; }
+    return true;
+}
+
+[[noreturn]] void run_gpu_output(const Options &opt, const Plan &plan, const std::vector<Sample> &samples,
+                                 std::vector<std::unique_ptr<FastqSource>> &sources, bool skip_few) {
+    const size_t n_inputs = plan.rs.size(), S = samples.size(), G = opt.devices.size();
+    const size_t chunk = std::max<unsigned long>(1, opt.chunk_given ? opt.chunk_reads : 262144ul);
+    const uint32_t L = (uint32_t)samples[0].barcode.size();
+
+    // ---- devices: matcher + record pipeline each (their bring-up overlaps the first reads and the file creation)
+    std::vector<fqtk_matcher *> matchers(G, nullptr);
+    std::vector<fqtk_demuxer *> demuxers(G, nullptr);
+    std::vector<const char *> bc, ids;
+    for (const Sample &s : samples) { bc.push_back(s.barcode.c_str()); ids.push_back(s.sample_id.c_str()); }
+    std::vector<uint32_t> n_segments;
+    std::vector<fqtk_demux_segment> segments;
+    for (const ReadStructure &r : plan.rs) {
+        n_segments.push_back((uint32_t)r.segments.size());
+        for (const ReadSegment &g : r.segments)
+            segments.push_back(fqtk_demux_segment{(uint32_t)g.offset, g.has_length() ? (int32_t)g.length : -1, (char)g.kind});
+    }
+    std::thread gpu_init([&] {
+        for (size_t g = 0; g < G; ++g) {
+            if (fqtk_matcher_create(bc.data(), (uint32_t)S, L, (uint8_t)opt.max_mismatches, (uint8_t)opt.min_mismatch_delta, opt.devices[g], &matchers[g]) != FQTK_OK)
+                die(std::string("cannot create the GPU barcode matcher: ") + fqtk_last_error());
+            fqtk_matcher_set_sample_ids(matchers[g], ids.data());
+            fqtk_demux_config cfg;
+            std::memset(&cfg, 0, sizeof cfg);
+            cfg.n_inputs = (uint32_t)n_inputs;
+            cfg.n_segments = n_segments.data();
+            cfg.segments = segments.data();
+            for (int k = 0; k < 4; ++k) cfg.want[k] = plan.want[k] ? 1 : 0;
+            cfg.skip_too_few_bases = skip_few ? 1 : 0;
+            cfg.max_chunk_templates = (uint32_t)std::min<size_t>(chunk, 1u << 22);
+            cfg.carry_blocks = G == 1 ? 1 : 0;   // several devices take the chunks in turn: a file's stream must not wait on any of them
+            cfg.compression_level = (int)opt.compression_level;
+            if (fqtk_demuxer_create(matchers[g], &cfg, &demuxers[g]) != FQTK_OK) die(std::string("cannot set up the GPU record pipeline: ") + fqtk_last_error());
+            info("GPU barcode matcher and record pipeline ready on device %d (%llu memo entries).", opt.devices[g],
+                 (unsigned long long)fqtk_matcher_memo_entries(matchers[g]));
+        }
+    });
+
+    // ---- readers
+    constexpr size_t kRing = 3;
+    std::vector<std::unique_ptr<BoundedQueue<RawChunk>>> rq;
+    std::vector<std::unique_ptr<BoundedQueue<PinnedRaw *>>> free_bufs;
+    std::vector<std::vector<std::unique_ptr<PinnedRaw>>> rings(n_inputs);
+    for (size_t i = 0; i < n_inputs; ++i) {
+        rq.push_back(std::make_unique<BoundedQueue<RawChunk>>(kRing));
+        free_bufs.push_back(std::make_unique<BoundedQueue<PinnedRaw *>>(kRing));
+        for (size_t k = 0; k < kRing; ++k) {
+            rings[i].push_back(std::make_unique<PinnedRaw>());
+            free_bufs[i]->push(rings[i].back().get());
+        }
+    }
+    std::vector<std::thread> readers;
+    for (size_t i = 0; i < n_inputs; ++i)
+        readers.emplace_back([&, i] {
+            for (;;) {
+                RawChunk c;
+                c.buf = free_bufs[i]->pop();
+                const uint64_t t0 = tick();
+                if (c.buf->cap == 0) {   // first use: sized by what the input's first lines look like, so that it need not grow
+                    const size_t want = sources[i]->estimate_raw_bytes(std::min<size_t>(chunk, 1u << 22));
+                    if (want && !c.buf->grow(want, 0)) die(std::string("cannot allocate page-locked memory: ") + fqtk_last_error());
+                }
+                const bool ok = sources[i]->next_raw(std::min<size_t>(chunk, 1u << 22), c.buf, &c.n, &c.bytes, &c.error);
+                g_times.reader_parse += tick() - t0;
+                if (!ok && c.error.empty()) c.error = "read failed";
+                const bool last = !ok || c.n == 0;
+                const uint64_t t1 = tick();
+                rq[i]->push(std::move(c));
+                g_times.reader_push += tick() - t1;
+                if (last) return;
+            }
+        });
+
+    // ---- output files (demux.rs:674-688), raw descriptors: whole BGZF members are appended as they come back
+    const size_t F = plan.files_per_sample, n_outs = (S + 1) * F;
+    {
+        rlimit rl;
+        if (getrlimit(RLIMIT_NOFILE, &rl) == 0 && rl.rlim_cur < n_outs + 64) {
+            rl.rlim_cur = std::min<rlim_t>(rl.rlim_max, n_outs + 64);
+            setrlimit(RLIMIT_NOFILE, &rl);
+        }
+    }
+    std::vector<int> fds(n_outs, -1);
+    std::vector<std::string> paths(n_outs);
+    for (size_t s = 0; s <= S; ++s) {
+        const std::string &prefix = s < S ? samples[s].sample_id : opt.unmatched_prefix;
+        for (int k = 0; k < 4; ++k) {
+            if (!plan.want[k]) continue;
+            for (size_t j = 0; j < plan.by_type[k].size(); ++j) {
+                const size_t c = s * F + plan.file_base[k] + j;
+                paths[c] = opt.output + "/" + prefix + "." + kCodes[k] + std::to_string(j + 1) + ".fq.gz";
+                fds[c] = ::open(paths[c].c_str(), O_WRONLY | O_CREAT | O_TRUNC | O_CLOEXEC, 0666);
+                if (fds[c] < 0) die("cannot create " + paths[c] + ": " + std::strerror(errno));
+                std::lock_guard<std::mutex> lk(g_created_mu);
+                g_created.push_back(paths[c]);
+            }
+        }
+    }
+    info("Created sample and %s writers.", opt.unmatched_prefix.c_str());
+    gpu_init.join();
+    const double t_ready = now_s();
+
+    // ---- writers: file c belongs to writer c mod W
+    const size_t W = std::min<size_t>(4, std::max<size_t>(1, std::min<size_t>(opt.threads, usable_cpus()) / 4));
+    std::mutex wmu;
+    std::condition_variable wcv_go, wcv_done;
+    const fqtk_demux_result *wres = nullptr;
+    uint64_t wgen = 0;
+    size_t wpending = 0;
+    bool wstop = false;
+    std::vector<std::thread> writers;
+    for (size_t w = 0; w < W; ++w)
+        writers.emplace_back([&, w] {
+            uint64_t seen = 0;
+            for (;;) {
+                const fqtk_demux_result *r;
+                {
+                    std::unique_lock<std::mutex> lk(wmu);
+                    wcv_go.wait(lk, [&] { return wstop || wgen != seen; });
+                    if (wgen == seen) return;
+                    seen = wgen;
+                    r = wres;
+                }
+                const uint64_t t0 = tick();
+                for (size_t c = w; c < n_outs; c += W) {
+                    const uint64_t lo = r->file_off[c], hi = r->file_off[c + 1];
+                    if (hi > lo) write_all(fds[c], r->bytes + lo, (size_t)(hi - lo), paths[c]);
+                }
+                g_times.comp_write += tick() - t0;
+                {
+                    std::lock_guard<std::mutex> lk(wmu);
+                    --wpending;
+                }
+                wcv_done.notify_all();
+            }
+        });
+    auto write_result = [&](const fqtk_demux_result &r) {
+        if (r.n_blocks == 0) return;
+        std::unique_lock<std::mutex> lk(wmu);
+        wres = &r;
+        wpending = W;
+        ++wgen;
+        wcv_go.notify_all();
+        wcv_done.wait(lk, [&] { return wpending == 0; });
+    };
+
+    // ---- collector: chunks in order
+    struct Flight { uint64_t k = 0; int dev = 0, slot = 0; uint32_t n = 0; uint64_t first_record = 0; bool end = false; };
+    BoundedQueue<Flight> flights(G * FQTK_DEMUX_SLOTS + 1);
+    std::mutex dmu;
+    std::condition_variable dcv;
+    uint64_t chunks_done = 0, blocks_total = 0, skipped = 0;
+    auto chunk_error = [&](const Flight &f, const fqtk_demux_result &r) {
+        const uint64_t rec = f.first_record + r.error_template;
+        const std::string &path = opt.inputs[std::min<size_t>(r.error_input, n_inputs - 1)];
+        char head[4096];
+        uint32_t n_bases = 0;
+        switch (r.error) {
+            case FQTK_DEMUX_ERR_NO_AT: die("Unexpected error parsing FASTQs: expected '@' at record " + std::to_string(rec) + " of " + path);
+            case FQTK_DEMUX_ERR_NO_PLUS: die("Unexpected error parsing FASTQs: expected '+' at record " + std::to_string(rec) + " of " + path);
+            case FQTK_DEMUX_ERR_QUAL_LEN: die("Unexpected error parsing FASTQs: sequence and quality lengths differ at record " + std::to_string(rec) + " of " + path);
+            case FQTK_DEMUX_ERR_TOO_SHORT:
+                if (fqtk_demuxer_record_text(demuxers[f.dev], f.slot, r.error_input, r.error_template, head, sizeof head, &n_bases) != FQTK_OK) die(fqtk_last_error());
+                die("Read " + std::string(head) + " had too few bases to demux " + std::to_string(n_bases) + " vs. " +
+                    std::to_string(plan.rs[r.error_input].min_length()) + " needed in read structure " + plan.rs[r.error_input].to_string() + ".");
+            case FQTK_DEMUX_ERR_BARCODE_LEN: die(fqtk_last_error());   // the reference's panic sentence (barcode_matching.rs:95-107)
+            case FQTK_DEMUX_ERR_HEADER: {
+                if (fqtk_demuxer_record_text(demuxers[f.dev], f.slot, 0, r.error_template, head, sizeof head, &n_bases) != FQTK_OK) die(fqtk_last_error());
+                static const char *const kWhat[5] = {"", "Can't handle read name with more than 8 segments: ", "Empty comment in FASTQ header: ",
+                                                     "Comment in did not have 4 segments: ", "Malformed comment in FASTQ header: "};
+                die(std::string(kWhat[std::min<uint32_t>(r.error_detail, 4)]) + head);
+            }
+            default: die("internal error: the device did not find four lines per record in a chunk of " + path);
+        }
+    };
+    std::thread collector([&] {
+        for (;;) {
+            const Flight f = flights.pop();
+            if (f.end) return;
+            fqtk_demux_result r;
+            const uint64_t t0 = tick();
+            if (fqtk_demuxer_collect(demuxers[f.dev], f.slot, &r) != FQTK_OK) die(std::string("GPU record pipeline: ") + fqtk_last_error());
+            g_times.main_gpu_wait += tick() - t0;
+            if (r.error) chunk_error(f, r);
+            write_result(r);
+            blocks_total += r.n_blocks;
+            skipped += r.n_skipped;
+            {
+                std::lock_guard<std::mutex> lk(dmu);
+                ++chunks_done;
+            }
+            dcv.notify_all();
+        }
+    });
+
+    // ---- this thread: chunks to the devices, chunk k on device k mod G
+    uint64_t k = 0, records = 0, next_log = 1000000;
+    double t_first = 0;
+    std::vector<const uint8_t *> text(n_inputs);
+    std::vector<uint64_t> text_len(n_inputs);
+    for (;; ++k) {
+        std::vector<RawChunk> in(n_inputs);
+        for (size_t i = 0; i < n_inputs; ++i) {
+            const uint64_t tw = tick();
+            in[i] = rq[i]->pop();
+            g_times.main_wait += tick() - tw;
+            if (!in[i].error.empty()) die(in[i].error);
+        }
+        const size_t n = in[0].n;
+        for (size_t i = 0; i < n_inputs; ++i)
+            if (in[i].n != n) die("FASTQ sources out of sync at records: input " + opt.inputs[in[i].n < n ? i : 0] + " ended after a different number of records");
+        if (n == 0) break;
+        {   // a slot is free again once its chunk has been collected and written
+            std::unique_lock<std::mutex> lk(dmu);
+            dcv.wait(lk, [&] { return k - chunks_done < G * FQTK_DEMUX_SLOTS; });
+        }
+        const int dev = (int)(k % G), slot = (int)((k / G) % FQTK_DEMUX_SLOTS);
+        for (size_t i = 0; i < n_inputs; ++i) { text[i] = reinterpret_cast<const uint8_t *>(in[i].buf->data); text_len[i] = in[i].bytes; }
+        if (k == 0) t_first = now_s();
+        const uint64_t th = tick();
+        if (fqtk_demuxer_submit(demuxers[dev], slot, text.data(), text_len.data(), (uint32_t)n) != FQTK_OK) die(std::string("GPU record pipeline: ") + fqtk_last_error());
+        Flight f;
+        f.k = k; f.dev = dev; f.slot = slot; f.n = (uint32_t)n; f.first_record = records;
+        flights.push(f);
+        if (fqtk_demuxer_text_done(demuxers[dev], slot) != FQTK_OK) die(std::string("GPU record pipeline: ") + fqtk_last_error());
+        g_times.main_handoff += tick() - th;
+        for (size_t i = 0; i < n_inputs; ++i) free_bufs[i]->push(in[i].buf);
+        records += n;
+        while (records >= next_log) { info("demultiplexed %llu records", (unsigned long long)next_log); next_log += 1000000; }
+    }
+    for (auto &t : readers) t.join();
+    info("Finished reading input FASTQs.");
+    { Flight e; e.end = true; flights.push(e); }
+    collector.join();
+    for (size_t g = 0; g < G; ++g) {   // what is left in the files' open blocks
+        fqtk_demux_result r;
+        if (fqtk_demuxer_flush(demuxers[g], &r) != FQTK_OK) die(std::string("GPU record pipeline: ") + fqtk_last_error());
+        write_result(r);
+        blocks_total += r.n_blocks;
+    }
+    {
+        std::lock_guard<std::mutex> lk(wmu);
+        wstop = true;
+    }
+    wcv_go.notify_all();
+    for (auto &t : writers) t.join();
+    for (size_t c = 0; c < n_outs; ++c) {
+        if (fds[c] < 0) continue;
+        write_all(fds[c], kBgzfEof, sizeof kBgzfEof, paths[c]);
+        if (::close(fds[c]) != 0) die("close failed: " + paths[c]);
+    }
+    const double t_done = now_s();
+    info("Output FASTQ writing complete.");
+    info("GPU record pipeline: %llu templates in %llu chunks, %llu BGZF blocks; %.3f s from the first chunk to the last byte written (%.2f M templates/s), devices ready at %.3f s.",
+         (unsigned long long)records, (unsigned long long)k, (unsigned long long)blocks_total, t_done - t_first,
+         t_done > t_first ? records / (t_done - t_first) / 1e6 : 0.0, t_ready);
+    if (g_timing) {
+        for (size_t g = 0; g < G; ++g) {
+            double st[FQTK_DEMUX_STAGES];
+            fqtk_demuxer_stage_seconds(demuxers[g], st);
+            std::string line;
+            for (int q = 0; q < FQTK_DEMUX_STAGES; ++q) line += std::string(q ? ", " : "") + fqtk_demuxer_stage_name(q) + " " + std::to_string(st[q]);
+            info("device %d stage seconds: %s", opt.devices[g], line.c_str());
+        }
+        info("host thread-seconds: readers fill %.2f push %.2f | this thread: waiting for readers %.2f, submit + text copy %.2f | collector waiting for the GPU %.2f | writers %.2f",
+             g_times.reader_parse / 1e9, g_times.reader_push / 1e9, g_times.main_wait / 1e9, g_times.main_handoff / 1e9, g_times.main_gpu_wait / 1e9, g_times.comp_write / 1e9);
+    }
+    if (skipped == 0) info("No records were skipped.");
+    else info("%llu records were skipped due to Too few bases", (unsigned long long)skipped);
+
+    // ---- metrics (demux.rs:994-998): the per-sample counts are a column of the device's placement sums
+    std::vector<uint64_t> counts(S + 1, 0);
+    for (size_t g = 0; g < G; ++g)
+        if (fqtk_demuxer_counts(demuxers[g], counts.data()) != FQTK_OK) die(fqtk_last_error());
+    uint64_t sum = 0;
+    for (uint64_t c : counts) sum += c;
+    if (sum != records - skipped) die("internal error: device counts do not add up to the number of templates");
+    std::vector<DemuxMetric> rows(S);
+    for (size_t s = 0; s < S; ++s) {
+        rows[s].sample_id = samples[s].sample_id;
+        rows[s].barcode = samples[s].barcode;
+        rows[s].templates = counts[s];
+    }
+    DemuxMetric unmatched;
+    unmatched.sample_id = opt.unmatched_prefix;
+    unmatched.barcode = ".";
+    unmatched.templates = counts[S];
+    update_metrics(rows, unmatched);
+    rows.push_back(unmatched);
+    std::string err;
+    if (!write_metrics_tsv(opt.output + "/demux-metrics.txt", rows, &err)) die(err);
+    std::fflush(stdout);
+    std::fflush(stderr);
+    std::_Exit(0);
 }
 
 }  // namespace
@@ -537,10 +826,14 @@ int main(int argc, char **argv) {
     // One matcher (replicated table) per device; chunk k is matched on device k mod G.  Templates are
     // independent, so there is no data-path exchange; the per-device counts are reduced at the end.
     if (opt.devices.empty()) opt.devices.push_back(opt.device);
+    if (!opt.host_output && !env_on("FQTK_HOST_OUTPUT")) {
+        std::string why;
+        if (gpu_output_supported(plan, &why)) run_gpu_output(opt, plan, samples, sources, skip_few);   // does not return
+        info("The GPU record pipeline does not take this configuration (%s): records are formatted and compressed on the host.", why.c_str());
+    }
     const size_t G = opt.devices.size();
     std::vector<fqtk_matcher *> matchers(G, nullptr);
     const uint32_t L = (uint32_t)samples[0].barcode.size();
-    GpuBgzfStage gpu_stage;
     std::thread gpu_init([&] {
         for (size_t g = 0; g < G; ++g) {
             if (fqtk_matcher_create(bc.data(), (uint32_t)S, L, (uint8_t)opt.max_mismatches, (uint8_t)opt.min_mismatch_delta,
@@ -551,12 +844,6 @@ int main(int argc, char **argv) {
             fqtk_matcher_set_sample_ids(matchers[g], ids.data());
             info("GPU barcode matcher ready on device %d (%llu memo entries).", opt.devices[g],
                  (unsigned long long)fqtk_matcher_memo_entries(matchers[g]));
-        }
-        if (opt.gpu_bgzf) {   // 2048 + 2048 slabs of 64 KiB: 256 MiB of page-locked memory the kernel works in directly
-            std::string err;
-            if (!gpu_stage.init(opt.devices[0], 2048, &err)) die("cannot set up the GPU BGZF compressor: " + err);
-            g_gpu_stage = &gpu_stage;
-            info("GPU BGZF compressor ready on device %d.", opt.devices[0]);
         }
     });
 
@@ -660,9 +947,7 @@ int main(int argc, char **argv) {
     const size_t n_threads_c = std::min<size_t>(std::max<size_t>(2, opt.threads - 1), std::max<size_t>(4, usable_cpus()));
     // Formatting a template costs ~1.15 us of router time, compressing its ~680 bytes at level 5 ~5.2 us of
     // libdeflate time (measured, FQTK_TIMING, 16 M dual-index templates): two routers feed seven compressors.
-    // With --gpu-bgzf the compressors only wrap and write what the GPU produced: three routers per writer.
-    const size_t n_workers = opt.gpu_bgzf ? std::max<size_t>(1, (n_threads_c * 3) / 4)
-                                          : std::max<size_t>(1, (n_threads_c * 2 + 4) / 9);   // routers
+    const size_t n_workers = std::max<size_t>(1, (n_threads_c * 2 + 4) / 9);   // routers
     const size_t n_comp = std::max<size_t>(1, n_threads_c - n_workers);     // compressors / writers
     // Output files fill in lock-step (samples are hit in proportion, so hundreds of files reach a full
     // 64 KiB block within the same few chunks): the queue must absorb such a burst or the routers stall
@@ -672,24 +957,7 @@ int main(int argc, char **argv) {
     for (size_t c = 0; c < n_comp; ++c)
         jobs.push_back(std::make_unique<BoundedQueue<CompressJob>>(std::max<size_t>(64, 8192 / n_comp)));   // <= 512 MiB of blocks in flight
     std::vector<std::thread> compressors;
-    std::thread gpu_stage_thread;
-    if (opt.gpu_bgzf) {
-        gpu_stage_thread = std::thread([&] {
-            std::string err;
-            if (!gpu_stage.run(n_workers, n_comp, &err)) die("GPU BGZF stage: " + err);
-        });
-        for (size_t c = 0; c < n_comp; ++c)
-            compressors.emplace_back([&] {
-                for (;;) {
-                    const uint64_t t0 = tick();
-                    const GpuBlock b = gpu_stage.to_writers.pop();
-                    g_times.comp_wait += tick() - t0;
-                    if (!b.file) break;
-                    write_gpu_block(b);
-                }
-            });
-    }
-    for (size_t c = 0; c < (opt.gpu_bgzf ? 0 : n_comp); ++c)
+    for (size_t c = 0; c < n_comp; ++c)
         compressors.emplace_back([&, c] {
             BlockCompressor bc((int)opt.compression_level);
             for (;;) {
@@ -787,7 +1055,7 @@ int main(int argc, char **argv) {
                         of.buf.push_back('\n');
                         if (of.buf.size() >= kBgzfBlockSize) {
                             const uint64_t ts = tick();
-                            if (opt.gpu_bgzf) submit_blocks_gpu(of, false); else submit_blocks(of, jobs, false);
+                            submit_blocks(of, jobs, false);
                             t_sub += tick() - ts;
                         }
                     }
@@ -796,8 +1064,7 @@ int main(int argc, char **argv) {
                 g_times.router_format += tick() - tf - t_sub;
             }
             for (size_t f = 0; f < outs.size(); ++f)
-                if (file_owner[f] == w) { if (opt.gpu_bgzf) submit_blocks_gpu(outs[f], true); else submit_blocks(outs[f], jobs, true); }
-            if (opt.gpu_bgzf) gpu_stage.to_gpu.push(GpuBlock{});   // this router is done
+                if (file_owner[f] == w) submit_blocks(outs[f], jobs, true);
         });
 
     // ---- stage B (this thread): chunk assembly, barcode SoA packing, GPU pipeline -------------------
@@ -993,12 +1260,7 @@ int main(int argc, char **argv) {
     info("Finished reading input FASTQs.");
     for (size_t w = 0; w < n_workers; ++w) wq[w]->push(nullptr);
     for (auto &t : workers) t.join();
-    if (opt.gpu_bgzf) {
-        gpu_stage_thread.join();   // sends the writers their end markers
-        info("GPU BGZF stage: %llu blocks in %llu launches.", (unsigned long long)gpu_stage.blocks(), (unsigned long long)gpu_stage.launches());
-    } else {
-        for (size_t c = 0; c < n_comp; ++c) jobs[c]->push(CompressJob{});
-    }
+    for (size_t c = 0; c < n_comp; ++c) jobs[c]->push(CompressJob{});
     for (auto &t : compressors) t.join();
     for (OutFile &of : outs) {   // every block is on disk: terminate the BGZF streams
         if (!of.ready.empty() || of.next_write != of.next_submit) die("internal error: unwritten blocks in " + of.path);

@@ -328,7 +328,7 @@ class FastqSource {
         if (!map_ && !producer_.joinable()) start();
         size_t w = 0, lines = 0;
         const size_t target = 4 * max_records;
-        auto room = [&](size_t want) { return want <= dst->cap || dst->grow(want + want / 4 + 65536, w); };
+        auto room = [&](size_t want) { return want <= dst->cap || dst->grow(std::max(want + 65536, dst->cap + dst->cap / 2), w); };
         bool eof = false;
         while (lines < target) {
             const char *p = nullptr;
@@ -369,6 +369,22 @@ class FastqSource {
         return true;
     }
     uint64_t records_read() const { return nrec_; }
+    // Bytes next_raw will want for max_records records, judged by the lines of the first MiB at hand (0: nothing to go by).
+    size_t estimate_raw_bytes(size_t max_records) {
+        if (!map_ && !producer_.joinable()) start();
+        const char *p = nullptr;
+        size_t avail = 0;
+        bool eof = false;
+        std::string err;
+        if (!raw_window(&p, &avail, &eof, &err) || eof || avail == 0) return 0;
+        const size_t look = std::min<size_t>(avail, 1u << 20);
+        const size_t lines = count_newlines(p, look);
+        if (lines < 4) return 0;
+        const double per_record = 4.0 * (double)look / (double)lines;
+        size_t want = (size_t)(per_record * 1.08 * (double)max_records) + 65536;
+        if (map_) want = std::min(want, map_size_ - map_pos_ + 65536);
+        return want;
+    }
 
   private:
     // next_raw's view of the input: the unread rest of the mapping, or of the current piece of a decoded / piped input.

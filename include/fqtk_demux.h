@@ -100,9 +100,19 @@ uint32_t fqtk_demuxer_files_per_sample(const fqtk_demuxer *d);
 int fqtk_demuxer_submit(fqtk_demuxer *d, int slot, const uint8_t *const *text, const uint64_t *text_len,
                         uint32_t n_templates);
 
+/* Blocks until the text of the chunk on `slot` has been copied to the device: the caller's buffers may be reused
+ * (the chunk itself is still in flight). */
+int fqtk_demuxer_text_done(fqtk_demuxer *d, int slot);
+
 /* Waits for the chunk on `slot`.  FQTK_OK with res->error == 0: res holds the members to append to the files.
  * res->error != 0: nothing of the chunk was written into the result; the run cannot continue. */
 int fqtk_demuxer_collect(fqtk_demuxer *d, int slot, fqtk_demux_result *res);
+
+/* For wording an error: header (without '@', at most cap - 1 bytes, NUL-terminated) and number of bases of template
+ * `template_index` in input `input` of the chunk last collected on `slot` (its text is still in device memory until
+ * the slot's next submit). */
+int fqtk_demuxer_record_text(fqtk_demuxer *d, int slot, uint32_t input, uint32_t template_index, char *header, size_t cap,
+                             uint32_t *n_bases);
 
 /* After the last chunk has been collected: ends every partly filled block (carry_blocks) and returns those members
  * the same way (the 28-byte BGZF EOF marker is the caller's to write). */

@@ -20,6 +20,17 @@ def _ok(r):
     return r
 
 
+@pytest.fixture(autouse=True, params=["device", "host"])
+def output_path(request, monkeypatch):
+    """Every test runs twice: with the records formatted and compressed on the device (the default: the GPU record
+    pipeline of include/fqtk_demux.h) and on the host (--host-output, the reference's division of labour)."""
+    if request.param == "host":
+        monkeypatch.setenv("FQTK_HOST_OUTPUT", "1")
+    else:
+        monkeypatch.delenv("FQTK_HOST_OUTPUT", raising=False)
+    return request.param
+
+
 def test_validate_inputs_can_succeed(tmp_path):   # demux.rs:1104-1135
     inputs = [H.fastq_file(tmp_path, "read1", "ex", ["GATTACA"]), H.fastq_file(tmp_path, "read2", "ex", ["TAGGATTA"]),
               H.fastq_file(tmp_path, "index1", "ex", ["GAT"]), H.fastq_file(tmp_path, "index2", "ex", ["TGGG"])]
@@ -181,7 +192,7 @@ def test_late_fatal_error_removes_every_partial_output(tmp_path):
     assert "removed" in r.stderr and not list((tmp_path / "output").glob("*.fq.gz"))
 
 
-def test_chunk_round_robin_over_devices_keeps_order_and_counts(tmp_path):
+def test_chunk_round_robin_over_devices_keeps_order_and_counts(tmp_path, output_path):
     """SURVEY 8e in the CLI: chunk k is matched on devices[k mod G] (table replicated, counts summed).
     The GPU box has one device, so the list repeats it -- the routing logic is what is under test:
     outputs must be byte-identical (after decompression) to the single-device run."""
@@ -206,7 +217,7 @@ def test_chunk_round_robin_over_devices_keeps_order_and_counts(tmp_path):
     for tag, extra in runs:
         out = tmp_path / tag
         r = _ok(H.run_demux([fq], ["8B10T"], meta, out, threads=6, extra=extra))
-        if tag == "distinct":
+        if tag == "distinct" and output_path == "host":   # (the record pipeline's counts are summed on the host)
             assert "all-reduced" in r.stderr
         outs.append(out)
     names = [f"S{i}" for i in range(cfg.n_samples)] + ["unmatched"]
@@ -291,9 +302,9 @@ def test_cfg5_shape_1536_iupac_samples_inline_barcode_plus_template(tmp_path):
         assert H.read_fastq(out / f"{name}.R1.fq.gz") == exp
 
 
-def test_gpu_bgzf_outputs_are_valid_bgzf_with_identical_content(tmp_path):
-    """--gpu-bgzf: the output blocks are DEFLATE-compressed by the GPU kernel (include/fqtk_bgzf.h) instead of the
-    libdeflate pool.  Same records in the same order in every file (the reference's tests compare decompressed
+def test_device_and_host_outputs_are_valid_bgzf_with_identical_content(tmp_path, monkeypatch):
+    """By default the records are formatted and DEFLATE-compressed on the device (include/fqtk_demux.h), with
+    --host-output by the host's router / libdeflate threads.  Same records in the same order in every file (the reference's tests compare decompressed
     content, demux.rs:1069-1093), same metrics, and every file is well-formed BGZF: members with the BC field, BSIZE,
     CRC32 and ISIZE that check out, and the EOF marker."""
     import gzip
@@ -312,11 +323,11 @@ def test_gpu_bgzf_outputs_are_valid_bgzf_with_identical_content(tmp_path):
     with open(meta, "w") as fh:
         fh.write("sample_id\tbarcode\n" + "".join(f"S{i}\t{b}\n" for i, b in enumerate(w.barcodes)))
     outs = []
-    for tag, extra in (("cpu", []), ("gpu", ["--gpu-bgzf"])):
+    monkeypatch.delenv("FQTK_HOST_OUTPUT", raising=False)
+    for tag, extra in (("cpu", ["--host-output"]), ("gpu", ["--gpu-bgzf"])):
         out = tmp_path / tag
         r = _ok(H.run_demux([fq], ["8B60T"], meta, out, threads=8, extra=extra + ["--chunk-reads", "7000"]))
-        if tag == "gpu":
-            assert "GPU BGZF stage:" in r.stderr
+        assert ("GPU record pipeline:" in r.stderr) == (tag == "gpu")
         outs.append(out)
     names = [f"S{i}" for i in range(cfg.n_samples)] + ["unmatched"]
     total = 0
