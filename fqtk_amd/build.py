@@ -60,21 +60,42 @@ def build_host(force: bool = False, verbose: bool = False) -> None:
 
 
 def build(force: bool = False, verbose: bool = False) -> None:
+    """Every .hip source is compiled to its own object (side by side: the three of libfqtk_match.so take a minute
+    one after another), then linked.  FQTK_EXTRA_DEFS="-DX=1 ..." adds defines (developer A/B builds)."""
+    from concurrent.futures import ThreadPoolExecutor
     os.makedirs(LIBDIR, exist_ok=True)
+    objdir = os.path.join(LIBDIR, "obj")
+    os.makedirs(objdir, exist_ok=True)
+    extra_defs = os.environ.get("FQTK_EXTRA_DEFS", "").split()
+    stamp = os.path.join(objdir, "defs.txt")
+    if (open(stamp).read() if os.path.exists(stamp) else "") != " ".join(extra_defs):
+        force = True
     deps_common = (glob.glob(os.path.join(CSRC, "*.h")) + glob.glob(os.path.join(CSRC, "*.hpp")) +
                    glob.glob(os.path.join(INCLUDE, "*.h")))
+    jobs, links = [], []
     for name, (srcs, extra) in TARGETS.items():
         srcs_abs = [os.path.join(CSRC, s) for s in srcs]
         if not all(os.path.exists(s) for s in srcs_abs):
             continue
-        out = os.path.join(LIBDIR, name)
-        if not force and not _stale(out, srcs_abs + deps_common):
-            continue
-        cmd = [HIPCC, f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-shared", "-fPIC",
-               "-I", INCLUDE, "-o", out] + extra + srcs_abs
+        objs = []
+        for src in srcs_abs:
+            obj = os.path.join(objdir, os.path.basename(src) + ".o")
+            objs.append(obj)
+            if force or _stale(obj, [src] + deps_common):
+                jobs.append([HIPCC, f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-I", INCLUDE, "-c", "-o", obj] + extra + extra_defs + [src])
+        links.append((os.path.join(LIBDIR, name), objs))
+
+    def run(cmd):
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.run(cmd, check=True)
+
+    with ThreadPoolExecutor(max(1, len(jobs))) as ex:
+        list(ex.map(run, jobs))
+    for out, objs in links:
+        if force or _stale(out, objs):
+            run([HIPCC, f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", out] + objs)
+    open(stamp, "w").write(" ".join(extra_defs))
     build_host(force=force, verbose=verbose)
 
 

@@ -1,11 +1,11 @@
-// bgzf_deflate.hpp -- DEFLATE block compressor for BGZF output, written for one 512-lane workgroup per block.
+// bgzf_deflate.hpp -- DEFLATE block compressor for BGZF output, written for one 1024-lane workgroup per block.
 //
 // SURVEY.md section 8(f) row 3 (output side).  End to end `fqtk demux` is bound by BGZF compression on the
 // host (the reference: pooled-writer -> bgzf -> libdeflater, /root/reference/src/bin/commands/demux.rs:755-798)
 // while the GPU matcher idles.  This is the MI355X form of that stage: every <= 65 280-byte block becomes one
-// dynamic-Huffman DEFLATE block (RFC 1951), produced by 512 lanes:
+// dynamic-Huffman DEFLATE block (RFC 1951), produced by 1024 lanes (16 wavefronts: four per SIMD hide each other's LDS latencies):
 //   P0  the block is copied into LDS, the LZ hash table and the histograms are cleared
-//   P1a every lane counts the bytes of its 128-byte slice (-> estimated literal costs) and enters all its
+//   P1a every lane counts the bytes of its 64-byte slice (-> estimated literal costs) and enters all its
 //       positions into a shared table keyed by (16 KiB region of the block, hash of 4 bytes) holding the SMALLEST
 //       and the LARGEST position seen -- min / max, so the table does not depend on how the lanes interleave and
 //       the output is deterministic
@@ -42,11 +42,11 @@ namespace fqtk {
 namespace bgzf {
 
 #ifndef FQTK_BGZF_LANES
-#define FQTK_BGZF_LANES 512   // (overridable for studies: tools/bgzf_ratio.py -DFQTK_BGZF_LANES=256)
+#define FQTK_BGZF_LANES 1024   // (overridable for studies: tools/ab_bgzf.sh, tools/bgzf_ratio.py -DFQTK_BGZF_LANES=512)
 #endif
 constexpr int kLanes = FQTK_BGZF_LANES;
 constexpr uint32_t kMaxIn = 65280;        // uncompressed payload of a BGZF block (as the bgzf crate cuts them)
-constexpr uint32_t kChunk = 65536 / kLanes;          // bytes parsed by one lane: 510 lanes x 128 = 65 280
+constexpr uint32_t kChunk = 65536 / kLanes;          // bytes parsed by one lane: 1020 lanes x 64 = 65 280
 constexpr uint32_t kHashBits = 11;        // per region; 4 regions x 2048 entries x {min, max}
 constexpr uint32_t kNearSlots = 16384 / kLanes;       // per lane: direct-mapped table of its recent positions (local repeats)
 constexpr uint32_t kOutStride = 65536;    // bytes reserved per block in the output arena (stored worst case: n + 5)
@@ -70,13 +70,27 @@ struct Shared {
     uint32_t lane_bits[kLanes];           // bits of a lane's tokens, then their exclusive prefix sum
     uint32_t ntok[kLanes];
     uint32_t header_bits, total_bits, stored;
-    // scratch of the code builder (one lane)
+    // scratch of the code builders: the literal/length code and the distance code are built side by side by two lanes
+    // (of different wavefronts), each with its own scratch; the code-length code reuses the first set afterwards
     uint16_t sorted[288];                 // used symbols, ascending by (count, symbol)
     uint32_t weight[576];                 // leaves then internal nodes
     uint16_t parent[576];
     uint8_t depth[576];
-    uint8_t cl_sym[320], cl_extra[320];   // run-length coded code lengths
     uint32_t bl_count[17], next_code[17]; // (indexed by run-time values: private arrays would live in scratch memory)
+    uint16_t sorted_d[32];
+    uint32_t weight_d[64];
+    uint16_t parent_d[64];
+    uint8_t depth_d[64];
+    uint32_t bl_count_d[17];
+    uint32_t m_d;                         // used distance symbols
+    uint32_t hlit, hdist;                 // lengths transmitted: literal/length 257.., distance 1..
+    // run-length coding of the hlit + hdist code lengths (RFC 1951 3.2.7), one lane per run
+    uint8_t cl_sym[320], cl_extra[320];   // the coded sequence
+    uint16_t run_syms[320];               // per position: symbols its run emits (0: not the start of a run)
+    uint16_t run_len[320];
+    uint32_t n_cl;                        // length of the coded sequence
+    uint32_t fixed_header_bits;           // block header up to and including the code-length code's lengths
+    uint32_t wave_tot[kLanes / 64 + 1];   // prefix sum of the lanes' bit counts: totals per wavefront
     uint32_t freq_cl[kNumCl];
     uint16_t code_cl[kNumCl];
     uint8_t len_cl[kNumCl];
@@ -129,7 +143,9 @@ FQTK_HD inline uint32_t match_token(uint32_t len, uint32_t dist) { return 0x8000
 #define FQTK_BGZF_OR(ptr, v) atomicOr((ptr), (v))
 #define FQTK_BGZF_ADD(ptr, v) atomicAdd((ptr), (v))
 #define FQTK_BGZF_CAS(ptr, expect, v) atomicCAS((ptr), (expect), (v))
+#define FQTK_BGZF_MAX(ptr, v) atomicMax((ptr), (v))
 #else
+#define FQTK_BGZF_MAX(ptr, v) (*(ptr) = *(ptr) > (v) ? *(ptr) : (v))
 #define FQTK_BGZF_OR(ptr, v) (*(ptr) |= (v))
 #define FQTK_BGZF_ADD(ptr, v) (*(ptr) += (v))
 #define FQTK_BGZF_CAS(ptr, expect, v) (*(ptr) == (expect) ? (*(ptr) = (v), (expect)) : *(ptr))
@@ -158,29 +174,34 @@ struct BitWriter {
 // counts[0..n) -> len[0..n) (0 = unused symbol), no code longer than max_bits, Kraft sum exactly 1 (inflate
 // implementations reject incomplete literal/length sets).  At least two symbols get a code (as zlib does).
 // presorted_m >= 0: S.sorted[0..presorted_m) already holds the used symbols ascending by (count, symbol).
-FQTK_HD inline void huffman_lengths(Shared &S, const uint32_t *counts, int n, int max_bits, uint8_t *len, int presorted_m = -1) {
-    for (int i = 0; i < n; ++i) len[i] = 0;
+struct HuffScratch { uint16_t *sorted; uint32_t *weight; uint16_t *parent; uint8_t *depth; uint32_t *bl_count; };
+FQTK_HD inline HuffScratch huff_scratch_ll(Shared &S) { return HuffScratch{S.sorted, S.weight, S.parent, S.depth, S.bl_count}; }
+FQTK_HD inline HuffScratch huff_scratch_d(Shared &S) { return HuffScratch{S.sorted_d, S.weight_d, S.parent_d, S.depth_d, S.bl_count_d}; }
+// len_cleared: len[0..n) is all zero already (the workgroup cleared it).  On return W.bl_count[b] = number of codes of b bits.
+FQTK_HD inline void huffman_lengths(const HuffScratch &W, const uint32_t *counts, int n, int max_bits, uint8_t *len, int presorted_m = -1, bool len_cleared = false) {
+    for (int i = 0; !len_cleared && i < n; ++i) len[i] = 0;
+    for (int b = 0; b <= 16; ++b) W.bl_count[b] = 0;
     int m = presorted_m < 0 ? 0 : presorted_m;
     for (int i = 0; presorted_m < 0 && i < n; ++i) {   // insertion sort of the used symbols by (count, symbol)
         if (!counts[i]) continue;
         int j = m++;
-        while (j > 0 && counts[S.sorted[j - 1]] > counts[i]) { S.sorted[j] = S.sorted[j - 1]; --j; }
-        S.sorted[j] = (uint16_t)i;
+        while (j > 0 && counts[W.sorted[j - 1]] > counts[i]) { W.sorted[j] = W.sorted[j - 1]; --j; }
+        W.sorted[j] = (uint16_t)i;
     }
-    if (m == 0) { len[0] = 1; len[1] = 1; return; }
-    if (m == 1) { len[S.sorted[0]] = 1; len[S.sorted[0] == 0 ? 1 : 0] = 1; return; }
+    if (m == 0) { len[0] = 1; len[1] = 1; W.bl_count[1] = 2; return; }
+    if (m == 1) { len[W.sorted[0]] = 1; len[W.sorted[0] == 0 ? 1 : 0] = 1; W.bl_count[1] = 2; return; }
     // two-queue construction: leaves 0..m-1 in ascending order, internal nodes m.. in creation (= ascending) order
-    for (int i = 0; i < m; ++i) S.weight[i] = counts[S.sorted[i]];
+    for (int i = 0; i < m; ++i) W.weight[i] = counts[W.sorted[i]];
     int li = 0, ii = m, made = m;
     for (int k = 0; k < m - 1; ++k) {
         int pick[2];
         for (int t = 0; t < 2; ++t) {
-            if (li < m && (ii >= made || S.weight[li] <= S.weight[ii])) pick[t] = li++;
+            if (li < m && (ii >= made || W.weight[li] <= W.weight[ii])) pick[t] = li++;
             else pick[t] = ii++;
         }
-        S.weight[made] = S.weight[pick[0]] + S.weight[pick[1]];
-        S.parent[pick[0]] = (uint16_t)made;
-        S.parent[pick[1]] = (uint16_t)made;
+        W.weight[made] = W.weight[pick[0]] + W.weight[pick[1]];
+        W.parent[pick[0]] = (uint16_t)made;
+        W.parent[pick[1]] = (uint16_t)made;
         ++made;
     }
     const int root = made - 1;
@@ -189,14 +210,13 @@ FQTK_HD inline void huffman_lengths(Shared &S, const uint32_t *counts, int n, in
     // overflow; the repair loop below then moves leaves down until the code is complete again.  (Counting only the
     // leaves beyond the limit, as this did before, leaves the code over-subscribed by one when an internal node
     // sits at the limit: inflate rejects the block.)
-    uint32_t *bl_count = S.bl_count;
-    for (int b = 0; b <= 16; ++b) bl_count[b] = 0;
+    uint32_t *bl_count = W.bl_count;
     int overflow = 0;
-    S.depth[root] = 0;
+    W.depth[root] = 0;
     for (int v = root - 1; v >= 0; --v) {
-        int bits = (int)S.depth[S.parent[v]] + 1;
+        int bits = (int)W.depth[W.parent[v]] + 1;
         if (bits > max_bits) { bits = max_bits; ++overflow; }
-        S.depth[v] = (uint8_t)bits;
+        W.depth[v] = (uint8_t)bits;
         if (v < m) ++bl_count[bits];   // a leaf
     }
     while (overflow > 0) {
@@ -209,11 +229,22 @@ FQTK_HD inline void huffman_lengths(Shared &S, const uint32_t *counts, int n, in
     }
     int idx = 0;   // sorted[] ascends by count: rarest first
     for (int bits = max_bits; bits >= 1; --bits)
-        for (uint32_t c = bl_count[bits]; c > 0; --c) len[S.sorted[idx++]] = (uint8_t)bits;
+        for (uint32_t c = bl_count[bits]; c > 0; --c) len[W.sorted[idx++]] = (uint8_t)bits;
 }
 
-// canonical codes (RFC 1951 3.2.2), stored bit-reversed
-FQTK_HD inline void canonical_codes(Shared &S, const uint8_t *len, int n, int max_bits, uint16_t *code) {
+// canonical codes (RFC 1951 3.2.2), stored bit-reversed.  All lanes, one symbol each: the code of a symbol is the
+// first code of its length (from the counts per length) plus the number of lower symbols of the same length.
+FQTK_HD inline uint16_t canonical_code_of(const uint8_t *len, int sym, const uint32_t *bl_count, int max_bits) {
+    const int l = len[sym];
+    if (!l) return 0;
+    uint32_t c = 0;
+    for (int b = 1; b <= l && b <= max_bits; ++b) c = (c + (b > 1 ? bl_count[b - 1] : 0u)) << 1;
+    uint32_t rank = 0;
+    for (int j = 0; j < sym; ++j) rank += len[j] == l ? 1u : 0u;
+    return (uint16_t)reverse_bits(c + rank, l);
+}
+// the same for a whole set by one lane (the 19-symbol code-length code)
+FQTK_HD inline void canonical_codes(Shared &S, const uint8_t *len, int n, int max_bits, uint16_t *code) {   // one lane
     uint32_t *bl_count = S.bl_count, *next_code = S.next_code;
     for (int b = 0; b <= 16; ++b) bl_count[b] = 0;
     for (int i = 0; i < n; ++i) ++bl_count[len[i]];
@@ -310,7 +341,7 @@ FQTK_HD inline void phase_load(Shared &S, int lane, const uint8_t *in, uint32_t 
     for (uint32_t i = (uint32_t)lane; i < 288; i += kLanes) S.freq_ll[i] = 0;
     if (lane < 32) S.freq_d[lane] = 0;
     if (lane < 256) S.byte_cnt[lane] = 0;
-    if (lane == 0) { S.lit_total = 0; S.m_ll = 0; }
+    if (lane == 0) { S.lit_total = 0; S.m_ll = 0; S.m_d = 0; S.n_cl = 0; S.hlit = 257; S.hdist = 1; }
     uint8_t *b = reinterpret_cast<uint8_t *>(S.buf);
     if ((reinterpret_cast<uintptr_t>(in) & 15u) == 0) {
         const uint32_t n16 = n >> 4;
@@ -574,6 +605,9 @@ FQTK_HD inline void phase_lz(Shared &S, int lane, uint32_t n, uint32_t *tok) {
 // among all of them (a one-lane insertion sort of ~80 symbols was a fifth of the kernel's time).
 FQTK_HD inline void phase_clear_out(Shared &S, int lane) {
     for (uint32_t i = (uint32_t)lane; i < kOutStride / 4; i += kLanes) S.buf[i] = 0;
+    for (uint32_t i = (uint32_t)lane; i < 288; i += kLanes) S.len_ll[i] = 0;
+    if (lane < 32) S.len_d[lane] = 0;
+    if (lane < kNumCl) S.freq_cl[lane] = 0;
     if (lane == 0) S.freq_ll[256] = 1;   // end of block (read through count_of below: no barrier needed)
     auto count_of = [&](int sym) -> uint32_t { return sym == 256 ? 1u : S.freq_ll[sym]; };
     for (int sym = lane; sym < kNumLitLen; sym += kLanes) {
@@ -587,40 +621,90 @@ FQTK_HD inline void phase_clear_out(Shared &S, int lane) {
         S.sorted[rank] = (uint16_t)sym;
         FQTK_BGZF_ADD(&S.m_ll, 1u);
     }
+    // the distance symbols likewise, by lanes of another wavefront
+    const int d = lane - (kLanes >= 128 ? 64 : 0);
+    if (d >= 0 && d < kNumDist) {
+        const uint32_t c = S.freq_d[d];
+        if (c) {
+            uint32_t rank = 0;
+            for (int j = 0; j < kNumDist; ++j) {
+                const uint32_t cj = S.freq_d[j];
+                rank += (cj != 0u && (cj < c || (cj == c && j < d))) ? 1u : 0u;
+            }
+            S.sorted_d[rank] = (uint16_t)d;
+            FQTK_BGZF_ADD(&S.m_d, 1u);
+        }
+    }
 }
 
-// P2b (one lane): both codes, the code-length code, the block header (BFINAL = 1, BTYPE = 2)
-FQTK_HD inline void phase_codes_and_header(Shared &S) {
-    S.freq_ll[256] = 1;   // end of block
-    huffman_lengths(S, S.freq_ll, kNumLitLen, 15, S.len_ll, (int)S.m_ll);
-    huffman_lengths(S, S.freq_d, kNumDist, 15, S.len_d);
-    canonical_codes(S, S.len_ll, kNumLitLen, 15, S.code_ll);
-    canonical_codes(S, S.len_d, kNumDist, 15, S.code_d);
-    int hlit = kNumLitLen, hdist = kNumDist;
-    while (hlit > 257 && S.len_ll[hlit - 1] == 0) --hlit;
-    while (hdist > 1 && S.len_d[hdist - 1] == 0) --hdist;
-    // run-length code the hlit + hdist lengths (RFC 1951 3.2.7: 16 = repeat previous 3-6, 17 = 3-10 zeros, 18 = 11-138 zeros)
-    for (int i = 0; i < kNumCl; ++i) S.freq_cl[i] = 0;
-    const int total = hlit + hdist;
-    int nsym = 0, i = 0;
-    while (i < total) {
-        const uint8_t v = i < hlit ? S.len_ll[i] : S.len_d[i - hlit];
-        int run = 1;
-        while (i + run < total && (i + run < hlit ? S.len_ll[i + run] : S.len_d[i + run - hlit]) == v) ++run;
-        int left = run;
-        if (v == 0) {
-            while (left >= 11) { const int r = left < 138 ? left : 138; S.cl_sym[nsym] = 18; S.cl_extra[nsym++] = (uint8_t)(r - 11); left -= r; }
-            if (left >= 3) { S.cl_sym[nsym] = 17; S.cl_extra[nsym++] = (uint8_t)(left - 3); left = 0; }
-            while (left-- > 0) { S.cl_sym[nsym] = 0; S.cl_extra[nsym++] = 0; }
-        } else {
-            S.cl_sym[nsym] = v; S.cl_extra[nsym++] = 0; --left;     // the length itself, then repeats of it
-            while (left >= 3) { const int r = left < 6 ? left : 6; S.cl_sym[nsym] = 16; S.cl_extra[nsym++] = (uint8_t)(r - 3); left -= r; }
-            while (left-- > 0) { S.cl_sym[nsym] = v; S.cl_extra[nsym++] = 0; }
-        }
-        i += run;
+// P2b (two lanes): the code lengths of both codes -- the serial part: the two-queue tree construction and the depth pass
+FQTK_HD inline void phase_code_lengths(Shared &S, int lane) {
+    if (lane == 0) {
+        S.freq_ll[256] = 1;   // end of block
+        huffman_lengths(huff_scratch_ll(S), S.freq_ll, kNumLitLen, 15, S.len_ll, (int)S.m_ll, true);
+    } else if (lane == (kLanes >= 128 ? 64 : 1)) {
+        huffman_lengths(huff_scratch_d(S), S.freq_d, kNumDist, 15, S.len_d, (int)S.m_d, true);
     }
-    for (int k = 0; k < nsym; ++k) ++S.freq_cl[S.cl_sym[k]];
-    huffman_lengths(S, S.freq_cl, kNumCl, 7, S.len_cl);
+}
+// P2c (all lanes): canonical codes, one symbol per lane; how many lengths of each set are transmitted
+FQTK_HD inline void phase_codes(Shared &S, int lane) {
+    if (lane < kNumLitLen) {
+        S.code_ll[lane] = canonical_code_of(S.len_ll, lane, S.bl_count, 15);
+        if (lane >= 257 && S.len_ll[lane]) FQTK_BGZF_MAX(&S.hlit, (uint32_t)lane + 1u);
+    }
+    const int d = lane - (kLanes >= 512 ? 320 : 0);
+    if (d >= 0 && d < kNumDist) {
+        S.code_d[d] = canonical_code_of(S.len_d, d, S.bl_count_d, 15);
+        if (S.len_d[d]) FQTK_BGZF_MAX(&S.hdist, (uint32_t)d + 1u);
+    }
+}
+// Run-length coding of the hlit + hdist lengths (RFC 1951 3.2.7: 16 = repeat the previous length 3-6 times, 17 = 3-10
+// zeros, 18 = 11-138 zeros).  A run of equal lengths is coded by the lane of its first position.
+FQTK_HD inline uint32_t cl_length_at(const Shared &S, uint32_t i) { return i < S.hlit ? S.len_ll[i] : S.len_d[i - S.hlit]; }
+// symbols a run of r lengths of value v is coded with; out != nullptr: they are written (symbol, extra-bit value)
+FQTK_HD inline uint32_t cl_code_run(uint32_t v, uint32_t r, uint8_t *sym, uint8_t *extra) {
+    uint32_t n = 0, left = r;
+    auto put = [&](uint32_t sy, uint32_t ex) { if (sym) { sym[n] = (uint8_t)sy; extra[n] = (uint8_t)ex; } ++n; };
+    if (v == 0) {
+        while (left >= 11) { const uint32_t t = left < 138 ? left : 138; put(18, t - 11); left -= t; }
+        if (left >= 3) { put(17, left - 3); left = 0; }
+        while (left-- > 0) put(0, 0);
+    } else {
+        put(v, 0);
+        --left;     // the length itself, then repeats of it
+        while (left >= 3) { const uint32_t t = left < 6 ? left : 6; put(16, t - 3); left -= t; }
+        while (left-- > 0) put(v, 0);
+    }
+    return n;
+}
+// P2d (all lanes): the runs
+FQTK_HD inline void phase_cl_runs(Shared &S, int lane) {
+    const uint32_t total = S.hlit + S.hdist;
+    for (uint32_t i = (uint32_t)lane; i < total; i += kLanes) {
+        const uint32_t v = cl_length_at(S, i);
+        if (i && cl_length_at(S, i - 1) == v) { S.run_syms[i] = 0; continue; }
+        uint32_t r = 1;
+        while (i + r < total && cl_length_at(S, i + r) == v) ++r;
+        S.run_len[i] = (uint16_t)r;
+        S.run_syms[i] = (uint16_t)cl_code_run(v, r, nullptr, nullptr);
+    }
+}
+// P2e (all lanes): every run's symbols go to their place in the coded sequence; symbol counts for the code-length code
+FQTK_HD inline void phase_cl_emit(Shared &S, int lane) {
+    const uint32_t total = S.hlit + S.hdist;
+    for (uint32_t i = (uint32_t)lane; i < total; i += kLanes) {
+        const uint32_t n = S.run_syms[i];
+        if (!n) continue;
+        uint32_t off = 0;
+        for (uint32_t j = 0; j < i; ++j) off += S.run_syms[j];
+        cl_code_run(cl_length_at(S, i), S.run_len[i], S.cl_sym + off, S.cl_extra + off);
+        for (uint32_t k = 0; k < n; ++k) FQTK_BGZF_ADD(&S.freq_cl[S.cl_sym[off + k]], 1u);
+        FQTK_BGZF_ADD(&S.n_cl, n);
+    }
+}
+// P2f (one lane): the code-length code and the fixed part of the block header (BFINAL = 1, BTYPE = 2)
+FQTK_HD inline void phase_cl_code(Shared &S) {
+    huffman_lengths(huff_scratch_ll(S), S.freq_cl, kNumCl, 7, S.len_cl);
     canonical_codes(S, S.len_cl, kNumCl, 7, S.code_cl);
     const uint8_t order[kNumCl] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
     int hclen = kNumCl;
@@ -629,19 +713,33 @@ FQTK_HD inline void phase_codes_and_header(Shared &S) {
     w.start(S.buf, 0);
     w.put(1, 1);                        // BFINAL
     w.put(2, 2);                        // BTYPE = dynamic Huffman
-    w.put((uint32_t)(hlit - 257), 5);
-    w.put((uint32_t)(hdist - 1), 5);
+    w.put(S.hlit - 257u, 5);
+    w.put(S.hdist - 1u, 5);
     w.put((uint32_t)(hclen - 4), 4);
     for (int k = 0; k < hclen; ++k) w.put(S.len_cl[order[k]], 3);
-    for (int k = 0; k < nsym; ++k) {
-        const int s = S.cl_sym[k];
+    w.finish();
+    S.fixed_header_bits = w.bitpos();
+}
+FQTK_HD inline uint32_t cl_symbol_bits(const Shared &S, uint32_t k) {
+    const uint32_t s = S.cl_sym[k];
+    return S.len_cl[s] + (s == 16 ? 2u : (s == 17 ? 3u : (s == 18 ? 7u : 0u)));
+}
+// P2g (all lanes): the coded lengths, one symbol per lane
+FQTK_HD inline void phase_cl_bits(Shared &S, int lane) {
+    const uint32_t n = S.n_cl;
+    for (uint32_t k = (uint32_t)lane; k < n; k += kLanes) {
+        uint32_t pos = S.fixed_header_bits;
+        for (uint32_t j = 0; j < k; ++j) pos += cl_symbol_bits(S, j);
+        const uint32_t s = S.cl_sym[k];
+        BitWriter w;
+        w.start(S.buf, pos);
         w.put(S.code_cl[s], S.len_cl[s]);
         if (s == 16) w.put(S.cl_extra[k], 2);
         else if (s == 17) w.put(S.cl_extra[k], 3);
         else if (s == 18) w.put(S.cl_extra[k], 7);
+        w.finish();
+        if (k + 1 == n) S.header_bits = w.bitpos();
     }
-    w.finish();
-    S.header_bits = w.bitpos();
 }
 
 // P3a (all lanes): bits this lane's tokens will take

@@ -1,6 +1,6 @@
 // fqtk_bgzf.hip -- device side and C ABI (include/fqtk_bgzf.h) of the BGZF block compressor.
 // The algorithm lives in bgzf_deflate.hpp (phase functions shared with the CPU test-suite); this file runs
-// the phases of one block on one 512-lane workgroup with barriers in between.
+// the phases of one block on one 1024-lane workgroup with barriers in between.
 #include <hip/hip_runtime.h>
 
 #include <new>
@@ -16,13 +16,13 @@ namespace bgzf {
 
 #ifdef FQTK_BGZF_PHASE_TIMES
 // Developer build (tools/bgzf_phases.sh): 100 MHz ticks spent in each phase, summed over all blocks by lane 0.
-__device__ unsigned long long g_phase_ticks[12];
+__device__ unsigned long long g_phase_ticks[12];   // [10] = the parallel part of the code construction
 #define FQTK_PHASE_MARK(k) do { if (lane == 0) { const uint64_t now = wall_clock64(); atomicAdd(&g_phase_ticks[k], (unsigned long long)(now - t_mark)); t_mark = now; } } while (0)
 #else
 #define FQTK_PHASE_MARK(k) do { } while (0)
 #endif
 
-__global__ __launch_bounds__(kLanes) __attribute__((amdgpu_waves_per_eu(2, 2)))   // one workgroup per CU (LDS): registers are free
+__global__ __launch_bounds__(kLanes) __attribute__((amdgpu_waves_per_eu(kLanes / 256, kLanes / 256)))   // one workgroup per CU (LDS): registers are free
 void deflate_kernel(const fqtk_bgzf_block *blocks, uint32_t n_blocks, const uint32_t *n_blocks_dev,
                                                          uint32_t *out_len, uint32_t *crc_out, uint32_t *tok_all) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem_raw[];
@@ -67,13 +67,39 @@ void deflate_kernel(const fqtk_bgzf_block *blocks, uint32_t n_blocks, const uint
         phase_clear_out(S, lane);
         __syncthreads();
         FQTK_PHASE_MARK(4);
-        if (lane == 0) phase_codes_and_header(S);
+        phase_code_lengths(S, lane);        // two lanes: the serial part of the code construction
         __syncthreads();
         FQTK_PHASE_MARK(5);
+        phase_codes(S, lane);
+        __syncthreads();
+        phase_cl_runs(S, lane);
+        __syncthreads();
+        phase_cl_emit(S, lane);
+        __syncthreads();
+        if (lane == 0) phase_cl_code(S);
+        __syncthreads();
+        phase_cl_bits(S, lane);
+        FQTK_PHASE_MARK(10);
         phase_count_bits(S, lane, tok);
         __syncthreads();
         FQTK_PHASE_MARK(6);
-        if (lane == 0) phase_offsets(S, n);
+        {   // exclusive prefix sum of the lanes' bit counts (phase_offsets is the one-lane form of the CPU tests)
+            const uint32_t mine = S.lane_bits[lane];
+            uint32_t incl = mine;
+            for (int d = 1; d < 64; d <<= 1) {
+                const uint32_t up = (uint32_t)__shfl_up((int)incl, d);
+                if ((lane & 63) >= d) incl += up;
+            }
+            if ((lane & 63) == 63) S.wave_tot[lane >> 6] = incl;
+            __syncthreads();
+            uint32_t before = S.header_bits;
+            for (int w = 0; w < (lane >> 6); ++w) before += S.wave_tot[w];
+            S.lane_bits[lane] = before + incl - mine;
+            if (lane == kLanes - 1) {
+                S.total_bits = before + incl + S.len_ll[256];
+                S.stored = ((S.total_bits + 7) >> 3) >= n + 5 ? 1u : 0u;
+            }
+        }
         __syncthreads();
         FQTK_PHASE_MARK(7);
         phase_emit(S, lane, tok);

@@ -287,7 +287,7 @@ int fqtk_host_huffman_lengths(const uint32_t *counts, int n, int max_bits, uint8
     if (n < 2 || n > 288 || max_bits < 1 || max_bits > 15) return -1;
     std::vector<uint8_t> mem(sizeof(Shared));
     Shared &S = *reinterpret_cast<Shared *>(mem.data());
-    huffman_lengths(S, counts, n, max_bits, len);
+    huffman_lengths(huff_scratch_ll(S), counts, n, max_bits, len);
     return 0;
 }
 
@@ -311,7 +311,12 @@ int64_t fqtk_host_bgzf_deflate_emulated(const uint8_t *in, uint32_t n, uint8_t *
     } else
     for (int l = 0; l < kLanes; ++l) phase_lz(S, l, n, tok.data());
     for (int l = 0; l < kLanes; ++l) phase_clear_out(S, l);
-    phase_codes_and_header(S);
+    for (int l = 0; l < kLanes; ++l) phase_code_lengths(S, l);
+    for (int l = 0; l < kLanes; ++l) phase_codes(S, l);
+    for (int l = 0; l < kLanes; ++l) phase_cl_runs(S, l);
+    for (int l = 0; l < kLanes; ++l) phase_cl_emit(S, l);
+    phase_cl_code(S);
+    for (int l = 0; l < kLanes; ++l) phase_cl_bits(S, l);
     for (int l = 0; l < kLanes; ++l) phase_count_bits(S, l, tok.data());
     phase_offsets(S, n);
     for (int l = 0; l < kLanes; ++l) phase_emit(S, l, tok.data());

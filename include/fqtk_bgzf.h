@@ -4,7 +4,7 @@
  * The reference writes every output FASTQ through pooled-writer's BgzfCompressor
  * (/root/reference/src/bin/commands/demux.rs:755-798): independent gzip members of <= 64 KiB carrying the 'BC'
  * extra field.  End to end that compression is what bounds `fqtk demux` on the host while the GPU that does the
- * matching idles; this entry point moves the DEFLATE step of each block onto the device.  One 512-lane workgroup
+ * matching idles; this entry point moves the DEFLATE step of each block onto the device.  One 1024-lane workgroup
  * per block produces ONE dynamic-Huffman DEFLATE block (or a stored block when the data does not compress);
  * the caller wraps it into a BGZF member (18-byte header, payload, CRC32 and ISIZE of the INPUT) and keeps
  * computing the CRC on the host.  Compressed bytes are unpinned by the reference's tests (decompressed content

@@ -2,7 +2,8 @@
 # Developer tool: where the BGZF compressor kernel spends its time, phase by phase (dev build with timestamps).
 cd "$(dirname "$0")/.."
 cp fqtk_amd/lib/libfqtk_match.so /tmp/libfqtk_match.prod.so
-hipcc --offload-arch=gfx950 -O3 -std=c++17 -shared -fPIC -Iinclude -DFQTK_BGZF_PHASE_TIMES $EXTRA_DEFS -o fqtk_amd/lib/libfqtk_match.so fqtk_amd/csrc/fqtk_match.hip fqtk_amd/csrc/fqtk_bgzf.hip || exit 1
+hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Iinclude -c -DFQTK_BGZF_PHASE_TIMES $EXTRA_DEFS -o /tmp/bgzf_ph.o fqtk_amd/csrc/fqtk_bgzf.hip || exit 1
+hipcc --offload-arch=gfx950 -shared -fPIC -o fqtk_amd/lib/libfqtk_match.so fqtk_amd/lib/obj/fqtk_match.hip.o fqtk_amd/lib/obj/fqtk_demux.hip.o /tmp/bgzf_ph.o || exit 1
 python - <<'PY'
 import ctypes as C, json, subprocess, sys
 sys.path.insert(0, ".")
@@ -13,8 +14,8 @@ sys.argv = ["bgzf_bench.py"]
 runpy.run_path("tools/bgzf_bench.py", run_name="__main__")
 t = (C.c_ulonglong * 12)()
 assert lib.fqtk_bgzf_dev_phase_ticks(t) == 0
-names = ["load", "index", "literal costs", "lz", "clear", "codes + header (one lane)", "count bits", "offsets (one lane)", "emit", "store"]
-tot = sum(t[:10])
+names = ["load", "index", "literal costs", "lz", "clear + rank", "code lengths (two lanes)", "count bits", "offsets", "emit", "store", "codes + header (all lanes, 19-symbol code by one)"]
+tot = sum(t[:11])
 for k, nme in enumerate(names):
     print(f"{nme:28s} {100.0 * t[k] / tot:5.1f} %")
 z = (C.c_ulonglong * 10)()

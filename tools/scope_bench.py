@@ -171,14 +171,19 @@ def scope_e(n, threads, gz, tmp, expect_counts=None, extra_args=(), repeat_first
         assert np.array_equal(got, expect_counts), "demux-metrics.txt differs from the oracle's per-sample counts"
     out_files = os.listdir(out)
     out_bytes = sum(os.path.getsize(os.path.join(out, f)) for f in out_files)
-    stage = [ln.split("fqtk] ", 1)[1] for ln in r.stderr.splitlines() if "thread-seconds" in ln or "main thread" in ln or "submit:" in ln]
-    timeline = [ln.strip() for ln in r.stderr.splitlines() if "INFO fqtk" in ln and "demultiplexed" not in ln
-                and "thread-seconds" not in ln and "main thread" not in ln and "submit:" not in ln]
+    is_stage = lambda ln: "thread-seconds" in ln or "main thread" in ln or "submit:" in ln or "stage seconds" in ln
+    stage = [ln.split("fqtk] ", 1)[1] for ln in r.stderr.splitlines() if is_stage(ln)]
+    timeline = [ln.strip() for ln in r.stderr.splitlines() if "INFO fqtk" in ln and "demultiplexed" not in ln and not is_stage(ln)]
+    steady = None   # the record pipeline's own clock: first chunk submitted -> last byte written
+    for ln in r.stderr.splitlines():
+        if "GPU record pipeline:" in ln and "M templates/s" in ln:
+            steady = float(ln.split("(")[1].split(" M templates/s")[0])
     return {"what": "fqtk_amd/bin/fqtk demux, files -> files (gunzip/parse -> GPU match -> BGZF), "
                     "as Demux::execute demux.rs:881-1001",
             "workload": "cfg3 shape: R1 150T, I1 8B, I2 8B, R2 150T; 384 samples", "templates": n, "threads": threads,
             "extra_args": list(extra_args),
             "gz_inputs": gz, "seconds": round(dt, 3), "M_templates_per_s": round(n / dt / 1e6, 3),
+            "M_templates_per_s_steady": steady,
             "seconds_is": "wall clock of the whole process: start-up, GPU bring-up, demux, flush, exit",
             "M_input_records_per_s": round(4 * n / dt / 1e6, 3),
             "input_MB": round(in_bytes / 1e6, 1), "output_MB": round(out_bytes / 1e6, 1), "output_files": len(out_files),
