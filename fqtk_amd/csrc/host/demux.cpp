@@ -428,6 +428,7 @@ bool gpu_output_supported(const Plan &plan, std::string *why) {
             if (fqtk_matcher_create(bc.data(), (uint32_t)S, L, (uint8_t)opt.max_mismatches, (uint8_t)opt.min_mismatch_delta, opt.devices[g], &matchers[g]) != FQTK_OK)
                 die(std::string("cannot create the GPU barcode matcher: ") + fqtk_last_error());
             fqtk_matcher_set_sample_ids(matchers[g], ids.data());
+            if (g_timing) info("(timing) matcher on device %d created.", opt.devices[g]);
             fqtk_demux_config cfg;
             std::memset(&cfg, 0, sizeof cfg);
             cfg.n_inputs = (uint32_t)n_inputs;
@@ -454,7 +455,9 @@ bool gpu_output_supported(const Plan &plan, std::string *why) {
         free_bufs.push_back(std::make_unique<BoundedQueue<PinnedRaw *>>(kRing));
         for (size_t k = 0; k < kRing; ++k) {
             rings[i].push_back(std::make_unique<PinnedRaw>());
-            free_bufs[i]->push(rings[i].back().get());
+            // two to begin with: page-locking memory goes through the HIP runtime, where the device bring-up is busy
+            // (a dozen 90 MB allocations queued up in front of the matcher's own calls); the third joins when it is done
+            if (k < 2) free_bufs[i]->push(rings[i].back().get());
         }
     }
     std::vector<std::thread> readers;
@@ -467,6 +470,7 @@ bool gpu_output_supported(const Plan &plan, std::string *why) {
                 if (c.buf->cap == 0) {   // first use: sized by what the input's first lines look like, so that it need not grow
                     const size_t want = sources[i]->estimate_raw_bytes(std::min<size_t>(chunk, 1u << 22));
                     if (want && !c.buf->grow(want, 0)) die(std::string("cannot allocate page-locked memory: ") + fqtk_last_error());
+                    if (g_timing) info("(timing) input %zu: %zu MB of page-locked memory ready.", i, want >> 20);
                 }
                 const bool ok = sources[i]->next_raw(std::min<size_t>(chunk, 1u << 22), c.buf, &c.n, &c.bytes, &c.error);
                 g_times.reader_parse += tick() - t0;
@@ -507,6 +511,8 @@ bool gpu_output_supported(const Plan &plan, std::string *why) {
     info("Created sample and %s writers.", opt.unmatched_prefix.c_str());
     gpu_init.join();
     const double t_ready = now_s();
+    for (size_t i = 0; i < n_inputs; ++i)
+        for (size_t k = 2; k < kRing; ++k) free_bufs[i]->push(rings[i][k].get());
 
     // ---- writers: file c belongs to writer c mod W
     const size_t W = std::min<size_t>(4, std::max<size_t>(1, std::min<size_t>(opt.threads, usable_cpus()) / 4));
@@ -826,6 +832,19 @@ int main(int argc, char **argv) {
     // One matcher (replicated table) per device; chunk k is matched on device k mod G.  Templates are
     // independent, so there is no data-path exchange; the per-device counts are reduced at the end.
     if (opt.devices.empty()) opt.devices.push_back(opt.device);
+    {
+        // Room for every output file in the descriptor table NOW, while this is the only thread: the kernel grows the
+        // table of a multi-threaded process behind an RCU grace period per doubling (expand_fdtable), which on these
+        // hosts made creating 771 files next to the device bring-up take 0.5 s instead of 2 ms -- and held the HIP
+        // runtime's own open() calls up as long.
+        const size_t want = (samples.size() + 1) * plan.files_per_sample + 256;
+        rlimit rl;
+        if (getrlimit(RLIMIT_NOFILE, &rl) == 0) {
+            if (rl.rlim_cur < want) { rl.rlim_cur = std::min<rlim_t>(rl.rlim_max, want); setrlimit(RLIMIT_NOFILE, &rl); }
+            const int top = (int)std::min<rlim_t>(rl.rlim_cur, want) - 1;
+            if (top > 2 && dup2(2, top) == top) ::close(top);
+        }
+    }
     if (!opt.host_output && !env_on("FQTK_HOST_OUTPUT")) {
         std::string why;
         if (gpu_output_supported(plan, &why)) run_gpu_output(opt, plan, samples, sources, skip_few);   // does not return
