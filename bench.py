@@ -210,7 +210,7 @@ def main() -> int:
                     help="full: first 50 M triples + count vector of all reads (default at 1 rank); windows: 3 x 100 k")
     ap.add_argument("--no-verify", action="store_true", help="same as --parity none")
     ap.add_argument("--no-scopes", action="store_true", help="skip scopes B and E")
-    ap.add_argument("--e2e-templates", type=int, default=16_000_000,
+    ap.add_argument("--e2e-templates", type=int, default=64_000_000,
                     help="templates of the scope E run (multiples of 1 M above 1 M: the first 1 M templates repeated)")
     ap.add_argument("--e2e-threads", type=int, default=0, help="--threads of the scope E run (default: the usable CPUs, at most 32)")
     ap.add_argument("--e2e-gz", action="store_true", help="gzip the scope E inputs (single-stream gunzip per file)")
@@ -437,13 +437,22 @@ def main() -> int:
                                                     for lo in range(0, uniq, 250_000)])
                     expect = sum((r[1] for r in res), np.zeros(385, dtype=np.uint64)) * np.uint64(n_e // uniq)
                 e_threads = args.e2e_threads or max(5, min(32, host_cores))
+                # E: the default run -- text to the device, whole BGZF members back (include/fqtk_demux.h)
                 scopes["E"] = scope_bench.scope_e(n_e, e_threads, args.e2e_gz, tmp, expect, repeat_first_block=rep)
                 scopes["E"]["host_cpus_usable"] = host_cores
-                shutil.rmtree(os.path.join(tmp, "out"), ignore_errors=True)
-                # the same run with the output blocks compressed on the GPU (include/fqtk_bgzf.h) instead of by libdeflate
-                scopes["E_gpu_bgzf"] = scope_bench.scope_e(n_e, e_threads, args.e2e_gz, tmp, expect, extra_args=("--gpu-bgzf",),
-                                                           repeat_first_block=rep, reuse_inputs=True)
-                scopes["E_gpu_bgzf"]["host_cpus_usable"] = host_cores
+                if rep and not args.e2e_gz and n_e >= 4_000_000 and n_e % 4_000_000 == 0:
+                    # a quarter of the same inputs for the two slower rows: the reference's division of labour
+                    # (--host-output: host threads parse, format and libdeflate-compress) and single-stream gzip inputs
+                    paths = [os.path.join(tmp, x) for x in ("R1.fastq", "I1.fastq", "I2.fastq", "R2.fastq")]
+                    meta = os.path.join(tmp, "meta.tsv")
+                    sub = scope_bench.prefix_inputs(tmp, paths, 1, 4)
+                    exp4 = None if expect is None else expect // np.uint64(4)
+                    scopes["E_host"] = scope_bench.scope_e(n_e // 4, e_threads, False, tmp, exp4, extra_args=("--host-output",), inputs=(sub, meta))
+                    scopes["E_host"]["host_cpus_usable"] = host_cores
+                    gz = scope_bench.gzip_single_stream(sub)
+                    scopes["E_gz"] = scope_bench.scope_e(n_e // 4, e_threads, True, tmp, exp4, inputs=(gz, meta))
+                    scopes["E_gz"]["host_cpus_usable"] = host_cores
+                    scopes["E_gz"]["gz_inputs"] = "one gzip member per file (level 1), decoded by several host threads per file"
             finally:
                 shutil.rmtree(tmp, ignore_errors=True)
             out["scopes"] = scopes

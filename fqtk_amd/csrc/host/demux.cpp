@@ -83,6 +83,13 @@ std::atomic<bool> g_dying{false};
     std::_Exit(1);
 }
 
+// (end of a run: what it cost the host)
+void report_footprint(size_t n_files) {
+    rusage ru;
+    if (getrusage(RUSAGE_SELF, &ru) == 0)
+        info("Host footprint: peak resident set %.1f MB, %zu output files open at once.", ru.ru_maxrss / 1024.0, n_files);
+}
+
 struct Options {
     std::vector<std::string> inputs, read_structures, skip_reasons;
     std::vector<char> output_types{'T'};
@@ -681,6 +688,7 @@ bool gpu_output_supported(const Plan &plan, std::string *why) {
     }
     if (skipped == 0) info("No records were skipped.");
     else info("%llu records were skipped due to Too few bases", (unsigned long long)skipped);
+    report_footprint(n_outs);
 
     // ---- metrics (demux.rs:994-998): the per-sample counts are a column of the device's placement sums
     std::vector<uint64_t> counts(S + 1, 0);
@@ -1305,6 +1313,7 @@ int main(int argc, char **argv) {
     }
     if (skipped == 0) info("No records were skipped.");
     else info("%llu records were skipped due to Too few bases", (unsigned long long)skipped);
+    report_footprint(n_outs);
 
     // ---- metrics (demux.rs:994-998): counts come from the device-side per-sample histogram --------
     std::vector<uint64_t> counts(S + 1, 0);

@@ -25,14 +25,16 @@ def _line(r):
 @pytest.mark.gpu
 def test_bench_line_carries_scopes_create_time_cpu_rows_and_the_full_parity_gate():
     d = _line(_run(["--reads", "3000000", "--steps", "3", "--warmup", "1", "--cpu-seconds", "1",
-                    "--e2e-templates", "200000", "--e2e-threads", "8"]))
+                    "--e2e-templates", "4000000", "--e2e-threads", "8"]))
     assert d["n_gpus"] == 1 and d["unit"] == "M reads/s" and d["value"] > 0
     assert "bit-exact" in d["config"]["parity"] and "count vector of all 3000000 reads" in d["config"]["parity"]
-    assert set(d["scopes"]) == {"K", "B", "E", "E_gpu_bgzf"}
-    assert d["scopes"]["E_gpu_bgzf"]["metrics_vs_oracle"] == "per-sample counts identical"
-    assert d["scopes"]["E_gpu_bgzf"]["extra_args"] == ["--gpu-bgzf"]
+    assert set(d["scopes"]) == {"K", "B", "E", "E_host", "E_gz"}
+    for k, n in (("E", 4000000), ("E_host", 1000000), ("E_gz", 1000000)):   # device output (default), host output, gzip inputs
+        assert d["scopes"][k]["templates"] == n and d["scopes"][k]["metrics_vs_oracle"] == "per-sample counts identical"
+        assert d["scopes"][k]["peak_rss_MB"] > 0 and d["scopes"][k]["output_files"] == 771
+    assert d["scopes"]["E"]["M_templates_per_s_steady"] > 0 and d["scopes"]["E_gz"]["M_templates_per_s_steady"] > 0
+    assert d["scopes"]["E_host"]["extra_args"] == ["--host-output"] and d["scopes"]["E_gz"]["gz_inputs"]
     assert d["scopes"]["B"]["M_reads_per_s"] > 0 and d["scopes"]["B"]["GB_per_s_over_pcie"] > 0
-    assert d["scopes"]["E"]["templates"] == 200000 and d["scopes"]["E"]["metrics_vs_oracle"] == "per-sample counts identical"
     assert d["create_ms"] > 0
     cb = d["cpu_baseline"]
     assert cb["cores"] == 1 and cb["kind"] == "port" and cb["value"] > 0

@@ -148,15 +148,72 @@ def make_inputs(tmp, n, gz, block=1_000_000, repeat_first_block=False):
     return paths, meta, w
 
 
-def scope_e(n, threads, gz, tmp, expect_counts=None, extra_args=(), repeat_first_block=False, reuse_inputs=False):
-    if reuse_inputs:   # a second run over the files of the previous scope_e() call in the same directory
+def prefix_inputs(tmp, paths, frac_num, frac_den, sub="sub"):
+    """The first frac_num / frac_den of every (fixed-width-record, plain) input, copied next to it."""
+    d = os.path.join(tmp, sub)
+    os.makedirs(d, exist_ok=True)
+    out = []
+    for p in paths:
+        size = os.path.getsize(p) * frac_num // frac_den
+        q = os.path.join(d, os.path.basename(p))
+        with open(p, "rb") as fi, open(q, "wb") as fo:
+            left = size
+            while left:
+                b = fi.read(min(left, 64 << 20))
+                fo.write(b)
+                left -= len(b)
+        out.append(q)
+    return out
+
+
+def _gzip_repeated(args):
+    path, block_bytes = args
+    import zlib as _z
+    size = os.path.getsize(path)
+    assert size % block_bytes == 0
+    with open(path, "rb") as fh:
+        block = fh.read(block_bytes)
+    c = _z.compressobj(1, _z.DEFLATED, -15)
+    body = c.compress(block) + c.flush(_z.Z_FULL_FLUSH)      # whole deflate blocks, byte-aligned, window reset: repeatable
+    reps = size // block_bytes
+    crc = 0
+    for _ in range(reps):
+        crc = _z.crc32(block, crc)
+    with open(path + ".gz", "wb") as fo:
+        fo.write(bytes([0x1f, 0x8b, 8, 0, 0, 0, 0, 0, 0, 3]))
+        for _ in range(reps):
+            fo.write(body)
+        fo.write(bytes([0x03, 0x00]))                                # final empty block (fixed Huffman, end of block)
+        fo.write(crc.to_bytes(4, "little") + (size & 0xFFFFFFFF).to_bytes(4, "little"))
+    return path + ".gz"
+
+
+def gzip_single_stream(paths, block_records=1_000_000):
+    """path -> path.gz: ONE gzip member per file (one serial DEFLATE stream, level 1, what `gzip -1` / bcl2fastq write)
+    of a file that repeats its first block_records records: the block is compressed once and its deflate blocks are
+    repeated inside the stream, which takes seconds instead of the minute `gzip -1` needs for 12 GB."""
+    from concurrent.futures import ProcessPoolExecutor
+    jobs = []
+    for p in paths:
+        with open(p, "rb") as fh:
+            head = fh.read(1 << 16)
+        rec = head.index(b"\n", head.index(b"\n", head.index(b"\n", head.index(b"\n") + 1) + 1) + 1) + 1   # fixed-width records
+        jobs.append((p, rec * block_records))
+    with ProcessPoolExecutor(4) as ex:
+        return list(ex.map(_gzip_repeated, jobs))
+
+
+def scope_e(n, threads, gz, tmp, expect_counts=None, extra_args=(), repeat_first_block=False, reuse_inputs=False, inputs=None, out_name="out"):
+    if inputs is not None:   # (paths, meta) made by the caller
+        paths, meta = inputs
+    elif reuse_inputs:   # a second run over the files of the previous scope_e() call in the same directory
         ext = ".gz" if gz else ""
         paths = [os.path.join(tmp, x + ext) for x in ("R1.fastq", "I1.fastq", "I2.fastq", "R2.fastq")]
         meta = os.path.join(tmp, "meta.tsv")
     else:
         paths, meta, w = make_inputs(tmp, n, gz, repeat_first_block=repeat_first_block)
     in_bytes = sum(os.path.getsize(f) for f in paths)
-    out = os.path.join(tmp, "out")
+    out = os.path.join(tmp, out_name)
     exe = os.path.join(ROOT, "fqtk_amd", "bin", "fqtk")
     cmd = [exe, "demux", "-i", *paths, "-r", "150T", "8B", "8B", "150T", "-s", meta, "-o", out, "-t", str(threads),
            *extra_args]
@@ -171,6 +228,10 @@ def scope_e(n, threads, gz, tmp, expect_counts=None, extra_args=(), repeat_first
         assert np.array_equal(got, expect_counts), "demux-metrics.txt differs from the oracle's per-sample counts"
     out_files = os.listdir(out)
     out_bytes = sum(os.path.getsize(os.path.join(out, f)) for f in out_files)
+    peak_rss_mb = None
+    for ln in r.stderr.splitlines():
+        if "peak resident set" in ln:
+            peak_rss_mb = float(ln.split("peak resident set ")[1].split(" MB")[0])
     is_stage = lambda ln: "thread-seconds" in ln or "main thread" in ln or "submit:" in ln or "stage seconds" in ln
     stage = [ln.split("fqtk] ", 1)[1] for ln in r.stderr.splitlines() if is_stage(ln)]
     timeline = [ln.strip() for ln in r.stderr.splitlines() if "INFO fqtk" in ln and "demultiplexed" not in ln and not is_stage(ln)]
@@ -178,8 +239,11 @@ def scope_e(n, threads, gz, tmp, expect_counts=None, extra_args=(), repeat_first
     for ln in r.stderr.splitlines():
         if "GPU record pipeline:" in ln and "M templates/s" in ln:
             steady = float(ln.split("(")[1].split(" M templates/s")[0])
-    return {"what": "fqtk_amd/bin/fqtk demux, files -> files (gunzip/parse -> GPU match -> BGZF), "
-                    "as Demux::execute demux.rs:881-1001",
+    shutil.rmtree(out, ignore_errors=True)
+    return {"what": "fqtk_amd/bin/fqtk demux, files -> files, as Demux::execute demux.rs:881-1001" +
+                    (": records parsed, formatted and BGZF-compressed by the host threads, barcodes matched on the GPU"
+                     if "--host-output" in extra_args else
+                     ": text -> GPU (records indexed, matched, formatted, DEFLATE-compressed in HBM) -> BGZF members appended"),
             "workload": "cfg3 shape: R1 150T, I1 8B, I2 8B, R2 150T; 384 samples", "templates": n, "threads": threads,
             "extra_args": list(extra_args),
             "gz_inputs": gz, "seconds": round(dt, 3), "M_templates_per_s": round(n / dt / 1e6, 3),
@@ -187,8 +251,11 @@ def scope_e(n, threads, gz, tmp, expect_counts=None, extra_args=(), repeat_first
             "seconds_is": "wall clock of the whole process: start-up, GPU bring-up, demux, flush, exit",
             "M_input_records_per_s": round(4 * n / dt / 1e6, 3),
             "input_MB": round(in_bytes / 1e6, 1), "output_MB": round(out_bytes / 1e6, 1), "output_files": len(out_files),
+            "peak_rss_MB": peak_rss_mb,
             "files_on": tmp, "host_cores": os.cpu_count(),
             "metrics_vs_oracle": None if expect_counts is None else "per-sample counts identical", "stages": stage,
+            "steady_is": "fqtk's own clock from the first chunk handed to the device to the last output byte written "
+                         "(without process start, device bring-up and exit)",
             "timeline": timeline}
 
 
