@@ -246,7 +246,7 @@ int launch_memo_vec(const fqtk_matcher *m, fqtk::MemoParams Q, hipStream_t strea
     // cfg 3 table pinned (16-byte rows) 148.0 / 141.6 / 139.4 (spills) / 178.0 / 91.2;
     // cfg 2 table pinned (8-byte rows) 236.4 / 203.0 / 248.2 / 234.1 / 182.9.
     const int direct = (KW == 1 && Q.direct) ? m->direct_bytes : 0;
-    int R = (vec > 0 && vec != 5 && !P.lens) ? 2 : 1;   // 20-byte rows: two reads per lane would spill
+    int R = (vec > 0 && vec != 5) ? 2 : 1;   // 20-byte rows: two reads per lane would spill
     int abl = 0;
     bool pf = vec == 1 || vec == 2;
 #ifdef FQTK_DEV_ABLATE
@@ -356,8 +356,18 @@ int launch_memo_vec(const fqtk_matcher *m, fqtk::MemoParams Q, hipStream_t strea
 #endif
     (void)abl;
     (void)pf;
-    if (P.lens) {          // variable-length batch: one read per lane on every load path (the LENS instantiations)
-#define FQTK_X(D) FQTK_MEMO_ALL_VEC(1, 0, true, D, false)
+    if (P.lens) {          // variable-length batch (the LENS instantiations): the shapes of the fixed-length batches --
+                           // the length word is loaded with the row -- and one read per lane on the generic load paths
+#define FQTK_X(D)                                                       \
+        switch (vec) {                                                  \
+            case 5: FQTK_MEMO_LAUNCH_P(5, 1, 0, true, D, false); break; \
+            case 4: FQTK_MEMO_LAUNCH_P(4, 2, 0, true, D, false); break; \
+            case 3: FQTK_MEMO_LAUNCH_P(3, 2, 0, true, D, false); break; \
+            case 2: FQTK_MEMO_LAUNCH_P(2, 2, 0, true, D, true); break;  \
+            case 1: FQTK_MEMO_LAUNCH_P(1, 2, 0, true, D, true); break;  \
+            case -1: FQTK_MEMO_LAUNCH_P(-1, 1, 0, true, D, false); break; \
+            default: FQTK_MEMO_LAUNCH_P(0, 1, 0, true, D, false); break;  \
+        }
         if (direct == 2) { FQTK_X(2) } else if (direct == 4) { FQTK_X(4) } else { FQTK_X(0) }
 #undef FQTK_X
     } else if (vec == 1 || vec == 2) {  // 4- / 8-byte rows: two reads per lane, pipelined
@@ -435,7 +445,7 @@ int launch_lds_memo(const fqtk_matcher *m, fqtk::LdsMemoParams Q, hipStream_t st
 #ifdef FQTK_DEV_ABLATE
     if (const char *rr = std::getenv("FQTK_MEMO_R")) R = std::atoi(rr);
 #endif
-    if (P.lens || second_pass) R = 1;
+    if ((P.lens && vec <= 0) || second_pass) R = 1;
     const uint64_t tile = (uint64_t)fqtk::kLdsBlock * R;
     const uint64_t ntiles = (P.n + tile - 1) / tile;
     if (ntiles == 0) return FQTK_OK;
@@ -473,13 +483,14 @@ int launch_lds_memo(const fqtk_matcher *m, fqtk::LdsMemoParams Q, hipStream_t st
     if (second_pass) {   // rows gathered through the worklist: the generic load paths
         if (vec != 0) FQTK_LDSM_LAUNCH_I(-1, 4, false, false, true);
         else FQTK_LDSM_LAUNCH_I(0, 4, false, false, true);
-    } else if (P.lens) {   // variable-length batch: the LENS instantiations, one read per lane
+    } else if (P.lens) {   // variable-length batch (the LENS instantiations): packed rows take the pipelined loop at the
+                           // fixed-length shapes (the length word is loaded with the row), the generic paths one read per lane
         switch (vec) {
-            case 5: FQTK_LDSM_LAUNCH_L(5, 1, true); break;
-            case 4: FQTK_LDSM_LAUNCH_L(4, 1, true); break;
-            case 3: FQTK_LDSM_LAUNCH_L(3, 1, true); break;
-            case 2: FQTK_LDSM_LAUNCH_L(2, 1, true); break;
-            case 1: FQTK_LDSM_LAUNCH_L(1, 1, true); break;
+            case 5: FQTK_LDSM_LAUNCH_P(5, 1, true, true); break;
+            case 4: FQTK_LDSM_LAUNCH_P(4, 1, true, true); break;
+            case 3: FQTK_LDSM_LAUNCH_P(3, 1, true, true); break;
+            case 2: FQTK_LDSM_LAUNCH_P(2, 2, true, true); break;
+            case 1: FQTK_LDSM_LAUNCH_P(1, 4, true, true); break;
             case -1: FQTK_LDSM_LAUNCH_L(-1, 1, true); break;
             default: FQTK_LDSM_LAUNCH_L(0, 1, true); break;
         }

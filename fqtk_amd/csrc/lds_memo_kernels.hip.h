@@ -179,6 +179,9 @@ void lds_memo_kernel(const LdsMemoParams Q) {
             } else {
                 words[r][0] = FQTK_STREAM_LOAD(reinterpret_cast<const uint32_t *>(src));
             }
+            // a variable-length batch: the read's length travels with its row (word 7 of the buffer is free: keys
+            // have five words at most), in the same group of loads -- so these batches take the pipelined loop too
+            if constexpr (LENS) words[r][7] = FQTK_STREAM_LOAD(P.lens + t * tile + local[r]);
         }
     };
     // Any tile through the generic path (ragged last tile, unaligned strides): bounds-checked loads.
@@ -190,6 +193,7 @@ void lds_memo_kernel(const LdsMemoParams Q) {
 #pragma unroll
             for (int w = 0; w < 8; ++w) words[r][w] = 0x41414141u;   // dead lanes look like "AAAA"
             if (live[r]) load_words<1, VEC>(P, i, nwords, words[r]);
+            if constexpr (LENS) words[r][7] = live[r] ? P.lens[i] : L;
         }
     };
 
@@ -260,12 +264,11 @@ void lds_memo_kernel(const LdsMemoParams Q) {
 #pragma unroll
             for (int r = 0; r < R; ++r) {
                 if (!live[r]) continue;
-                const uint64_t i = t * tile + local[r];
-                const uint32_t len = P.lens[i];
+                const uint32_t len = words[r][7];
                 if (len != L) {
                     res[r] = kMemoEmpty;
                     bflag[r] = 0;
-                    if (len > L) overlong_read(P, i, len);
+                    if (len > L) overlong_read(P, t * tile + local[r], len);
                 }
             }
         }
@@ -373,6 +376,10 @@ void lds_memo_kernel(const LdsMemoParams Q) {
             for (int r = 0; r < R; ++r)
 #pragma unroll
                 for (int k = 0; k < NWD; ++k) asm volatile("" : "+v"(w[r][k]) : : "memory");
+            if constexpr (LENS) {
+#pragma unroll
+                for (int r = 0; r < R; ++r) asm volatile("" : "+v"(w[r][7]) : : "memory");
+            }
         };
         auto computed = [&](uint32_t (&v)[R]) {     // the results exist now (their gathers / LDS reads were waited for HERE)
 #pragma unroll

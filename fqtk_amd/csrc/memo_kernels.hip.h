@@ -324,6 +324,9 @@ void memo_kernel(const MemoParams Q) {
             } else {
                 words[r][0] = FQTK_STREAM_LOAD(reinterpret_cast<const uint32_t *>(src));
             }
+            // a variable-length batch: the read's length travels with its row, in word 7 of the buffer (keys have
+            // five words at most) -- loaded in the same group, so these batches run the same loops as the others
+            if constexpr (LENS) words[r][7] = FQTK_STREAM_LOAD(P.lens + t * tile + local[r]);
         }
     };
     // Any tile through the generic path (ragged last tile, unaligned strides): bounds-checked loads.
@@ -335,6 +338,7 @@ void memo_kernel(const MemoParams Q) {
 #pragma unroll
             for (int w = 0; w < 8; ++w) words[r][w] = 0x41414141u;   // dead lanes look like "AAAA"
             if (live[r]) load_words<1, VEC>(P, i, nwords, words[r]);
+            if constexpr (LENS) words[r][7] = live[r] ? P.lens[i] : L;
         }
     };
 
@@ -351,7 +355,7 @@ void memo_kernel(const MemoParams Q) {
             uint32_t b, lo_unf, c2;
             encode_nibbles<NWD, (VEC >= 1 && !(ABL & 2)), FOLD>(words[r], kc, kv, lo[r], hi[r], ext[r], b, lo_unf, c2);
             bad[r] = b != 0 && live[r];
-            if constexpr (LENS) { if (live[r]) bad[r] = bad[r] && P.lens[t * tile + local[r]] == L; }
+            if constexpr (LENS) bad[r] = bad[r] && words[r][7] == L;
             if constexpr (DIRECT) {
                 didx[r] = memo_direct_index(lo_unf, c2);
                 has_n[r] = memo_nocall_bits(lo_unf, c2) != 0;
@@ -481,11 +485,10 @@ void memo_kernel(const MemoParams Q) {
         for (int r = 0; r < R; ++r) {
             if (!live[r]) continue;
             if constexpr (LENS) {   // the memo served the reads of length L
-                const uint64_t i = t * tile + local[r];
-                const uint32_t len = P.lens[i];
+                const uint32_t len = words[r][7];
                 if (len != L) {   // shorter -> None (barcode_matching.rs:167-169); longer -> None or the panic
                     res[r] = kMemoEmpty;
-                    if (len > L) overlong_read(P, i, len);
+                    if (len > L) overlong_read(P, t * tile + local[r], len);
                 }
             }
             if (P.counts && !(ABL & 4) && res[r] != kMemoDeferred) {
@@ -528,6 +531,10 @@ void memo_kernel(const MemoParams Q) {
             for (int r = 0; r < R; ++r)
 #pragma unroll
                 for (int k = 0; k < NWD; ++k) asm volatile("" : "+v"(w[r][k]) : : "memory");
+            if constexpr (LENS) {
+#pragma unroll
+                for (int r = 0; r < R; ++r) asm volatile("" : "+v"(w[r][7]) : : "memory");
+            }
         };
         auto computed = [&](uint32_t (&v)[R]) {     // the results exist now (their gathers / LDS reads were waited for HERE)
 #pragma unroll
