@@ -55,9 +55,18 @@ constexpr int kNumLitLen = 286, kNumDist = 30, kNumCl = 19;
 constexpr int kCands = 3;                 // match candidates looked at per position
 constexpr int kMinMatch = 4;              // shorter matches cost more bits than their literals on FASTQ
 
+// The input block in LDS is SKEWED: logical word w lives at w + (w >> 4), one pad word per 64 bytes.  Every lane parses
+// its own 64-byte slice, so at any moment the lanes of a wave touch addresses 64 bytes apart -- 16 words: two LDS
+// banks for the whole wave, a 32-way conflict on every access (measured with rocprofv3: SQ_LDS_BANK_CONFLICT a
+// third of the kernel's cycles).  With the pad word the stride is 17 words and consecutive lanes use consecutive banks.
+constexpr uint32_t kBufWords = kOutStride / 4 + kOutStride / 64 + 16;
+FQTK_HD inline uint32_t buf_word(uint32_t w) { return w + (w >> 4); }
+// one byte of the (skewed) input block
+FQTK_HD inline uint32_t buf_byte(const uint32_t *words, uint32_t pos) { return (words[buf_word(pos >> 2)] >> (8 * (pos & 3u))) & 0xFFu; }
+
 // Everything a block's workgroup shares.  LDS on the device (~141 KiB: one workgroup per CU), heap in the CPU tests.
 struct Shared {
-    uint32_t buf[kOutStride / 4];         // P0-P1: the input bytes.  P2-P5: the output bit stream.
+    uint32_t buf[kBufWords];              // P0-P1: the input bytes, skewed (buf_word).  P2-P5: the output bit stream, linear.
     uint32_t tminmax[4u << kHashBits];      // per (region, hash): smallest position in the low half, largest in the high half
     uint16_t near_tab[kNearSlots * kLanes];  // [slot][lane]: every lane's private table of recent positions
     uint32_t byte_cnt[256];                  // P1a: how often each byte value occurs in the block
@@ -99,8 +108,7 @@ struct Shared {
     uint32_t crc_tab[256];
     uint32_t crc_pow_chunk[kLanes];
     uint32_t crc_pow_byte[kChunk + 1];
-    uint32_t crc_part[kLanes];
-    uint32_t crc;
+    uint32_t crc;                         // (the lanes' partial values wait in lane_bits, which is free that early)
 };
 
 // ---- symbol arithmetic (RFC 1951 3.2.5), computed rather than tabulated -------------------------------------
@@ -287,13 +295,12 @@ FQTK_HD inline void crc_tables(Shared &S, int lane) {
 }
 // after phase_load (the block is in S.buf); a barrier, then phase_crc_fold by one lane
 FQTK_HD inline void phase_crc(Shared &S, int lane, uint32_t n) {
-    const uint8_t *b = reinterpret_cast<const uint8_t *>(S.buf);
     const uint32_t lo = (uint32_t)lane * kChunk;
     uint32_t part = 0;
     if (lo < n) {
         const uint32_t hi = lo + kChunk < n ? lo + kChunk : n;
         uint32_t c = 0xFFFFFFFFu;
-        for (uint32_t p = lo; p < hi; ++p) c = S.crc_tab[(c ^ b[p]) & 0xFFu] ^ (c >> 8);
+        for (uint32_t p = lo; p < hi; ++p) c = S.crc_tab[(c ^ buf_byte(S.buf, p)) & 0xFFu] ^ (c >> 8);
         c = ~c;
         if (hi < n) {   // bytes behind this slice: whole slices of the lanes between it and the last one, then the last one's
             const uint32_t last = (n - 1u) / kChunk;
@@ -302,11 +309,11 @@ FQTK_HD inline void phase_crc(Shared &S, int lane, uint32_t n) {
         }
         part = c;
     }
-    S.crc_part[lane] = part;
+    S.lane_bits[lane] = part;
 }
 FQTK_HD inline void phase_crc_fold(Shared &S) {
     uint32_t c = 0;
-    for (int l = 0; l < kLanes; ++l) c ^= S.crc_part[l];
+    for (int l = 0; l < kLanes; ++l) c ^= S.lane_bits[l];
     S.crc = c;
 }
 
@@ -318,10 +325,12 @@ FQTK_HD inline uint32_t hash4(uint32_t x) { return (x * 2654435761u) >> (32 - kH
 // Four bytes at any byte offset of the block buffer.  Device: two aligned LDS words and one v_alignbyte_b32
 // instead of four byte reads (the word after the last payload byte exists: the buffer is 64 KiB, a block 65 280 B).
 FQTK_HD inline uint32_t buf_le32(const uint32_t *words, uint32_t pos) {
+    const uint32_t w = pos >> 2;
 #if defined(__HIP_DEVICE_COMPILE__)
-    return __builtin_amdgcn_alignbyte(words[(pos >> 2) + 1], words[pos >> 2], pos & 3u);
+    return __builtin_amdgcn_alignbyte(words[buf_word(w + 1)], words[buf_word(w)], pos & 3u);
 #else
-    return load_le32(reinterpret_cast<const uint8_t *>(words) + pos);
+    const uint64_t two = (uint64_t)words[buf_word(w)] | ((uint64_t)words[buf_word(w + 1)] << 32);
+    return (uint32_t)(two >> (8 * (pos & 3u)));
 #endif
 }
 FQTK_HD inline uint32_t ctz32(uint32_t x) {   // x != 0
@@ -342,17 +351,31 @@ FQTK_HD inline void phase_load(Shared &S, int lane, const uint8_t *in, uint32_t 
     if (lane < 32) S.freq_d[lane] = 0;
     if (lane < 256) S.byte_cnt[lane] = 0;
     if (lane == 0) { S.lit_total = 0; S.m_ll = 0; S.m_d = 0; S.n_cl = 0; S.hlit = 257; S.hdist = 1; }
-    uint8_t *b = reinterpret_cast<uint8_t *>(S.buf);
-    if ((reinterpret_cast<uintptr_t>(in) & 15u) == 0) {
-        const uint32_t n16 = n >> 4;
-        for (uint32_t i = (uint32_t)lane; i < n16; i += kLanes) {
-            const uint32_t *src = reinterpret_cast<const uint32_t *>(in) + 4 * i;
-            uint32_t *dst = S.buf + 4 * i;
-            dst[0] = src[0]; dst[1] = src[1]; dst[2] = src[2]; dst[3] = src[3];
+    if ((reinterpret_cast<uintptr_t>(in) & 3u) == 0) {
+        const uint32_t nw = n >> 2;
+        if ((reinterpret_cast<uintptr_t>(in) & 15u) == 0) {
+            const uint32_t n16 = n >> 4;
+            for (uint32_t i = (uint32_t)lane; i < n16; i += kLanes) {   // four words of one 64-byte group: one skew
+                const uint32_t *src = reinterpret_cast<const uint32_t *>(in) + 4 * i;
+                uint32_t *dst = S.buf + buf_word(4 * i);
+                dst[0] = src[0]; dst[1] = src[1]; dst[2] = src[2]; dst[3] = src[3];
+            }
+            for (uint32_t i = (n16 << 2) + (uint32_t)lane; i < nw; i += kLanes) S.buf[buf_word(i)] = reinterpret_cast<const uint32_t *>(in)[i];
+        } else {
+            for (uint32_t i = (uint32_t)lane; i < nw; i += kLanes) S.buf[buf_word(i)] = reinterpret_cast<const uint32_t *>(in)[i];
         }
-        for (uint32_t i = (n16 << 4) + (uint32_t)lane; i < n; i += kLanes) b[i] = in[i];
-    } else {
-        for (uint32_t i = (uint32_t)lane; i < n; i += kLanes) b[i] = in[i];
+        if (lane == 0 && (n & 3u)) {   // the ragged last word
+            uint32_t v = 0;
+            for (uint32_t k = 0; k < (n & 3u); ++k) v |= (uint32_t)in[(nw << 2) + k] << (8 * k);
+            S.buf[buf_word(nw)] = v;
+        }
+    } else {   // (a source that is not word-aligned: whole words assembled from bytes)
+        const uint32_t nw = (n + 3u) >> 2;
+        for (uint32_t i = (uint32_t)lane; i < nw; i += kLanes) {
+            uint32_t v = 0;
+            for (uint32_t k = 0; k < 4 && 4 * i + k < n; ++k) v |= (uint32_t)in[4 * i + k] << (8 * k);
+            S.buf[buf_word(i)] = v;
+        }
     }
 }
 
@@ -361,10 +384,9 @@ FQTK_HD inline void phase_load(Shared &S, int lane, const uint8_t *in, uint32_t 
 // order-independent, so the table -- and with it the whole output -- does not depend on how the lanes interleave.
 FQTK_HD inline uint32_t region_slot(uint32_t p, uint32_t h) { return ((p >> 14) << kHashBits) | h; }
 FQTK_HD inline void phase_index(Shared &S, int lane, uint32_t n) {
-    const uint8_t *b = reinterpret_cast<const uint8_t *>(S.buf);
     const uint32_t lo = (uint32_t)lane * kChunk;
     const uint32_t hi = lo + kChunk < n ? lo + kChunk : n;
-    for (uint32_t p = lo; p < hi; ++p) FQTK_BGZF_ADD(&S.byte_cnt[b[p]], 1u);
+    for (uint32_t p = lo; p < hi; ++p) FQTK_BGZF_ADD(&S.byte_cnt[buf_byte(S.buf, p)], 1u);
     for (uint32_t p = lo; p < hi && p + 4 <= n; ++p) {
         uint32_t *w = &S.tminmax[region_slot(p, hash4(buf_le32(S.buf, p)))];
         uint32_t old = *w;
@@ -460,7 +482,6 @@ FQTK_HD inline bool lz_step(Shared &S, int lane, uint32_t n, uint32_t *tok, LzLa
 #endif
 ) {
     if (st.p >= st.end) return false;
-    const uint8_t *b = reinterpret_cast<const uint8_t *>(S.buf);
     const uint32_t p = st.p;
     uint32_t mlen = 0, mdist = 0, msave = 0;
     if (p + 4 <= n) {
@@ -487,7 +508,7 @@ FQTK_HD inline bool lz_step(Shared &S, int lane, uint32_t n, uint32_t *tok, LzLa
         FQTK_LZ_MARK(0);
         // Which candidates start with the same four bytes: all five are read before any is looked at (one wave
         // per SIMD: every dependent LDS round trip is paid in full, so the reads go out together).
-        uint32_t qpos[kCands], first[kCands];
+        uint32_t qpos[kCands], first[kCands], second[kCands];
 #if defined(__HIP_DEVICE_COMPILE__)
 #pragma unroll
 #endif
@@ -496,6 +517,7 @@ FQTK_HD inline bool lz_step(Shared &S, int lane, uint32_t n, uint32_t *tok, LzLa
             const bool in_reach = cand[c] != 0u && q < p && p - q <= 32768u;
             qpos[c] = in_reach ? q : p;                                    // p itself: reads fine, never accepted
             first[c] = buf_le32(S.buf, qpos[c]);
+            second[c] = buf_le32(S.buf, qpos[c] + 4u);
         }
         // what the bytes cost as literals: exactly for the first eight, the block's average beyond (every long
         // match pays for itself many times over; the estimate only ranks long candidates among themselves)
@@ -523,18 +545,26 @@ FQTK_HD inline bool lz_step(Shared &S, int lane, uint32_t n, uint32_t *tok, LzLa
                 dist_symbol(p - q, dsym, dne, dev);
                 if (dne >= full_dist_bits) continue;
             }
-            // sixteen bytes per round: the eight word pairs are independent reads
-            uint32_t l = 4;
-            while (l < maxl) {
-                const uint32_t x0 = buf_le32(S.buf, q + l) ^ buf_le32(S.buf, p + l);
-                const uint32_t x1 = buf_le32(S.buf, q + l + 4) ^ buf_le32(S.buf, p + l + 4);
-                const uint32_t x2 = buf_le32(S.buf, q + l + 8) ^ buf_le32(S.buf, p + l + 8);
-                const uint32_t x3 = buf_le32(S.buf, q + l + 12) ^ buf_le32(S.buf, p + l + 12);
-                if (x0 | x1 | x2 | x3) {
-                    l += x0 ? ctz32(x0) >> 3 : (x1 ? 4 + (ctz32(x1) >> 3) : (x2 ? 8 + (ctz32(x2) >> 3) : 12 + (ctz32(x3) >> 3)));
-                    break;
+            // Bytes 4-7 were fetched with the first four (no loop, no further round trip): in sequence lines nearly every
+            // position finds an earlier copy of its four bases and nearly none of them runs to eight, so the loop below
+            // -- sixteen bytes per round, the eight word pairs independent reads -- is left to the matches that do.
+            uint32_t l;
+            const uint32_t x4 = second[c] ^ w4;
+            if (x4) {
+                l = 4u + (ctz32(x4) >> 3);
+            } else {
+                l = 8;
+                while (l < maxl) {
+                    const uint32_t x0 = buf_le32(S.buf, q + l) ^ buf_le32(S.buf, p + l);
+                    const uint32_t x1 = buf_le32(S.buf, q + l + 4) ^ buf_le32(S.buf, p + l + 4);
+                    const uint32_t x2 = buf_le32(S.buf, q + l + 8) ^ buf_le32(S.buf, p + l + 8);
+                    const uint32_t x3 = buf_le32(S.buf, q + l + 12) ^ buf_le32(S.buf, p + l + 12);
+                    if (x0 | x1 | x2 | x3) {
+                        l += x0 ? ctz32(x0) >> 3 : (x1 ? 4 + (ctz32(x1) >> 3) : (x2 ? 8 + (ctz32(x2) >> 3) : 12 + (ctz32(x3) >> 3)));
+                        break;
+                    }
+                    l += 16;
                 }
-                l += 16;
             }
             if (l > maxl) l = maxl;
             if (l < (uint32_t)kMinMatch) continue;
@@ -571,8 +601,9 @@ FQTK_HD inline bool lz_step(Shared &S, int lane, uint32_t n, uint32_t *tok, LzLa
         st.p = p + mlen;
         FQTK_LZ_MARK(6);
     } else {
-        if (!(FQTK_BGZF_ABL & 1)) FQTK_BGZF_ADD(&S.freq_ll[b[p]], 1u);
-        if (!(FQTK_BGZF_ABL & 2)) tok[st.nt * kLanes + (uint32_t)lane] = b[p];
+        const uint32_t lit = buf_byte(S.buf, p);
+        if (!(FQTK_BGZF_ABL & 1)) FQTK_BGZF_ADD(&S.freq_ll[lit], 1u);
+        if (!(FQTK_BGZF_ABL & 2)) tok[st.nt * kLanes + (uint32_t)lane] = lit;
         st.p = p + 1;
         FQTK_LZ_MARK(7);
     }

@@ -49,7 +49,7 @@ void deflate_kernel(const fqtk_bgzf_block *blocks, uint32_t n_blocks, const uint
             __syncthreads();
             if (lane < 64) {   // the first wave folds the lanes' values (phase_crc_fold is the one-lane form of the CPU tests)
                 uint32_t c = 0;
-                for (int k = 0; k < kLanes / 64; ++k) c ^= S.crc_part[lane + 64 * k];
+                for (int k = 0; k < kLanes / 64; ++k) c ^= S.lane_bits[lane + 64 * k];
                 for (int d = 32; d >= 1; d >>= 1) c ^= (uint32_t)__shfl_xor((int)c, d);
                 if (lane == 0) crc_out[j] = c;
             }
