@@ -318,6 +318,31 @@ def main() -> int:
     kernel_ms = ev0.elapsed_time(ev1) / args.steps  # HIP events around the K launches, per launch
     matcher.poll_error(stream)
 
+    # ---- several ranks: the same K steps once more over 1 / world of the batch -- what every rank does when the
+    #      config's N reads are SPLIT over the ranks (BASELINE config 3's wording: 400 M reads over 1 -> 8 GPUs); the
+    #      line's `value` stays the weak-scaling one (every rank a full batch) unless --scaling strong was asked for
+    strong = None
+    if use_dist and args.scaling == "weak":
+        ns = max(1, (args.reads or cfg.n_reads) // world)
+        d_counts_s = torch.zeros_like(d_counts)
+        dist.barrier()
+        torch.cuda.synchronize()
+        ts = time.perf_counter()
+        for _ in range(args.steps):
+            matcher.assign_batch_device(d_obs.data_ptr(), cfg.stride, ns, d_out.data_ptr(), d_counts_s.data_ptr(),
+                                        d_lens=d_lens.data_ptr() if d_lens is not None else 0, stream=stream)
+        allreduce_counts(d_counts_s.clone())
+        torch.cuda.synchronize()
+        dist.barrier()
+        es = torch.tensor([time.perf_counter() - ts], dtype=torch.float64, device=dev)
+        dist.all_reduce(es, op=dist.ReduceOp.MAX)
+        strong = {"value": round(ns * world * args.steps / float(es.item()) / 1e6, 2), "unit": "M reads/s",
+                  "ms_per_step": round(float(es.item()) / args.steps * 1e3, 4), "reads_per_gpu_per_step": ns,
+                  "reads_per_step_whole_job": ns * world,
+                  "what": "strong scaling: the config's reads split over the ranks (each rank: the first 1/world of its resident "
+                          "batch), barrier + synchronize on both sides, max over ranks, RCCL all-reduce of the counts included"}
+        matcher.poll_error(stream)
+
     per_rank_kernel_ms = [round(kernel_ms, 4)]
     if use_dist:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
@@ -382,6 +407,7 @@ def main() -> int:
             "ms_per_step": round(elapsed / args.steps * 1e3, 4),
             "higher_is_better": True,
             "scaling": args.scaling,
+            **({"strong_scaling": strong} if strong is not None else {}),
             "vs_baseline": None,
             "dtype": "u8",
             "data": "synthetic",

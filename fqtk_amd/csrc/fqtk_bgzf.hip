@@ -24,7 +24,7 @@ __device__ unsigned long long g_phase_ticks[12];   // [10] = the parallel part o
 
 __global__ __launch_bounds__(kLanes) __attribute__((amdgpu_waves_per_eu(kLanes / 256, kLanes / 256)))   // one workgroup per CU (LDS): registers are free
 void deflate_kernel(const fqtk_bgzf_block *blocks, uint32_t n_blocks, const uint32_t *n_blocks_dev,
-                                                         uint32_t *out_len, uint32_t *crc_out, uint32_t *tok_all) {
+                                                         uint32_t *out_len, uint32_t *crc_out, uint32_t *tok_all, uint32_t level) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem_raw[];
     Shared &S = *reinterpret_cast<Shared *>(smem_raw);
     const int lane = (int)threadIdx.x;
@@ -55,6 +55,14 @@ void deflate_kernel(const fqtk_bgzf_block *blocks, uint32_t n_blocks, const uint
             }
         }
         FQTK_PHASE_MARK(0);
+        if (level == 0) {   // --compression-level 0: stored blocks (RFC 1951 3.2.4), as libdeflate's level 0
+            if (lane == 0) S.stored = 1u;
+            __syncthreads();
+            const uint32_t raw = phase_store(S, lane, in, n, out);
+            if (lane == 0) out_len[j] = raw;
+            __syncthreads();
+            continue;
+        }
         phase_index(S, lane, n);
         __syncthreads();
         FQTK_PHASE_MARK(1);
@@ -124,8 +132,8 @@ hipError_t deflate_prepare() {
 }
 hipError_t deflate_launch(hipStream_t stream, uint32_t groups, const fqtk_bgzf_block *blocks, const uint32_t *n_blocks_dev,
                           uint32_t *out_len, uint32_t *crc, uint32_t *tok, int level) {
-    (void)level;
-    hipLaunchKernelGGL(deflate_kernel, dim3(groups), dim3(kLanes), sizeof(Shared), stream, blocks, 0u, n_blocks_dev, out_len, crc, tok);
+    hipLaunchKernelGGL(deflate_kernel, dim3(groups), dim3(kLanes), sizeof(Shared), stream, blocks, 0u, n_blocks_dev, out_len, crc, tok,
+                       level <= 0 ? 0u : (uint32_t)level);
     return hipGetLastError();
 }
 }  // namespace bgzf
@@ -212,7 +220,7 @@ int fqtk_bgzf_deflate_enqueue(fqtk_bgzf *z, int slot, const fqtk_bgzf_block *blo
     BGZF_TRY(hipSetDevice(z->device));
     const uint32_t grid = n < (uint32_t)z->num_cus ? n : (uint32_t)z->num_cus;   // one workgroup per CU (107 KiB of LDS each)
     hipLaunchKernelGGL(fqtk::bgzf::deflate_kernel, dim3(grid), dim3(fqtk::bgzf::kLanes), sizeof(fqtk::bgzf::Shared),
-                       z->streams[slot], blocks, n, (const uint32_t *)nullptr, out_len, (uint32_t *)nullptr, z->d_tok[slot]);
+                       z->streams[slot], blocks, n, (const uint32_t *)nullptr, out_len, (uint32_t *)nullptr, z->d_tok[slot], 5u);
     BGZF_TRY(hipGetLastError());
     z->busy[slot] = true;
     return FQTK_OK;

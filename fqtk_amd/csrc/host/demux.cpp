@@ -38,6 +38,7 @@
 #include "../../../include/fqtk_demux.h"
 #include "../../../include/fqtk_match.h"
 #include "bgzf.hpp"
+#include "chunk_schedule.hpp"
 #include "fastq_io.hpp"
 #include "header.hpp"
 #include "metrics.hpp"
@@ -627,6 +628,9 @@ bool gpu_output_supported(const Plan &plan, std::string *why) {
     // ---- this thread: chunks to the devices, chunk k on device k mod G
     uint64_t k = 0, records = 0, next_log = 1000000;
     double t_first = 0;
+    ChunkSchedule schedule;
+    schedule.devices = G;
+    schedule.slots = FQTK_DEMUX_SLOTS;
     std::vector<const uint8_t *> text(n_inputs);
     std::vector<uint64_t> text_len(n_inputs);
     for (;; ++k) {
@@ -643,9 +647,9 @@ bool gpu_output_supported(const Plan &plan, std::string *why) {
         if (n == 0) break;
         {   // a slot is free again once its chunk has been collected and written
             std::unique_lock<std::mutex> lk(dmu);
-            dcv.wait(lk, [&] { return k - chunks_done < G * FQTK_DEMUX_SLOTS; });
+            dcv.wait(lk, [&] { return schedule.may_submit(k, chunks_done); });
         }
-        const int dev = (int)(k % G), slot = (int)((k / G) % FQTK_DEMUX_SLOTS);
+        const int dev = schedule.device_of(k), slot = schedule.slot_of(k);
         for (size_t i = 0; i < n_inputs; ++i) { text[i] = reinterpret_cast<const uint8_t *>(in[i].buf->data); text_len[i] = in[i].bytes; }
         if (k == 0) t_first = now_s();
         const uint64_t th = tick();

@@ -7,6 +7,7 @@
 #include <vector>
 
 #include "bgzf.hpp"
+#include "chunk_schedule.hpp"
 #include "fastq_io.hpp"
 #include "parallel_gunzip.hpp"
 #include "header.hpp"
@@ -407,5 +408,46 @@ int64_t fqtk_host_read_raw(const char *path, uint64_t batch, char *out, size_t c
     }
     *out_len = w;
     return (int64_t)calls;
+}
+
+// Drives ChunkSchedule the way `fqtk demux` does -- one submitter, chunks collected in order, completions arriving
+// whenever `order` says (order[i] != 0: try to collect one chunk before the next submit) -- and checks what the
+// pipeline relies on.  Returns 0, or the number of the first rule broken:
+//   1 a (device, slot) pair was handed a chunk while its previous one was still outstanding
+//   2 a device did not receive its chunks in ascending order
+//   3 more than devices * slots chunks were outstanding
+//   4 not every chunk was submitted and collected
+int fqtk_host_chunk_schedule_check(uint64_t devices, uint64_t slots, uint64_t n_chunks, const uint8_t *order, size_t n_order) {
+    ChunkSchedule sc;
+    sc.devices = (size_t)devices;
+    sc.slots = (size_t)slots;
+    std::vector<int64_t> busy(devices * slots, -1), last_on_device(devices, -1);
+    uint64_t next = 0, done = 0;
+    size_t at = 0;
+    auto collect_one = [&]() {
+        if (done == next) return;
+        const size_t cell = (size_t)sc.device_of(done) * slots + (size_t)sc.slot_of(done);
+        busy[cell] = -1;
+        ++done;
+    };
+    auto submit = [&]() -> int {
+        const int d = sc.device_of(next), sl = sc.slot_of(next);
+        const size_t cell = (size_t)d * slots + (size_t)sl;
+        if (busy[cell] >= 0) return 1;
+        if (last_on_device[d] >= (int64_t)next) return 2;
+        busy[cell] = (int64_t)next;
+        last_on_device[d] = (int64_t)next;
+        ++next;
+        return next - done > devices * slots ? 3 : 0;
+    };
+    while (done < n_chunks) {
+        const bool want_collect = at < n_order ? order[at++] != 0 : true;
+        const bool can_submit = next < n_chunks && sc.may_submit(next, done);
+        if (can_submit && !want_collect) { if (int rc = submit()) return rc; }
+        else if (done < next) collect_one();
+        else if (can_submit) { if (int rc = submit()) return rc; }
+        else return 4;   // nothing outstanding and nothing may be submitted: stuck
+    }
+    return (next == n_chunks && done == n_chunks) ? 0 : 4;
 }
 }  // extern "C"

@@ -350,3 +350,55 @@ def test_device_and_host_outputs_are_valid_bgzf_with_identical_content(tmp_path,
         assert text == gzip.decompress(raw)
     assert total == n
     assert open(outs[0] / "demux-metrics.txt").read() == open(outs[1] / "demux-metrics.txt").read()
+
+
+def test_compression_level_zero_writes_stored_blocks(tmp_path, output_path):
+    """--compression-level 0 (demux.rs:641-643 hands the level to libdeflate, whose level 0 stores): valid BGZF whose
+    members are stored DEFLATE blocks, on the device as on the host."""
+    import struct
+    meta = H.metadata_file(tmp_path, FOUR)
+    reads = [S1 + "ACGT" * 25] * 3000
+    fq = H.fastq_file(tmp_path, "ex", "ex", reads)
+    out = tmp_path / "output"
+    _ok(H.run_demux([fq], ["17B100T"], meta, out, compression_level=0))
+    got = H.read_fastq(out / "Sample0000.R1.fq.gz")
+    assert got == [(f"ex_{i} 1:N:0:" + S1, "ACGT" * 25, ";" * 100) for i in range(3000)]
+    raw = open(out / "Sample0000.R1.fq.gz", "rb").read()
+    plain = sum(len(h) + 1 + 100 + 3 + 100 + 2 for h, _, _ in got)
+    assert plain < len(raw) < plain + 40 * (plain // 65280 + 2)
+    assert raw[18] & 7 == 1                                          # BFINAL = 1, BTYPE = 00: stored
+
+
+def test_two_hundred_million_templates_through_771_files(tmp_path, output_path):
+    """The pipeline at the size of a real run: cfg 3's shape, 192 M templates (the first 1 M repeated; 149 GB of plain
+    FASTQ on RAM-backed scratch), 771 output files.  The metrics file must carry 192 x the first block's per-sample
+    counts (oracle) and the host footprint stays that of a few chunks in flight."""
+    import shutil
+    import sys
+    if output_path == "host":
+        pytest.skip("the device output path is what scales to this size in a test's time budget")
+    need = 200 << 30
+    if shutil.disk_usage("/dev/shm").free < need or (os.sysconf("SC_PHYS_PAGES") * os.sysconf("SC_PAGE_SIZE")) < 2 * need:
+        pytest.skip("needs 200 GB of RAM-backed scratch")
+    try:
+        if int(open("/sys/fs/cgroup/memory.max").read()) < need + (40 << 30):
+            pytest.skip("memory cgroup too small for 150 GB of inputs on /dev/shm")
+    except (OSError, ValueError):
+        pass
+    sys.path.insert(0, os.path.join(H.ROOT, "tools"))
+    import scope_bench
+    from fqtk_amd import synth
+    from oracle import oracle as O
+    n = 192_000_000
+    tmp = scope_bench.scratch_dir(n * 1000)
+    try:
+        cfg = synth.CONFIGS[3]
+        w = synth.Workload(cfg)
+        lit = O.RefLiteral(w.barcodes, cfg.max_mismatches, cfg.min_mismatch_delta, True)
+        bcs = w.fill_host(0, 1_000_000)
+        idx, _, _, counts = lit.assign_batch(bcs)
+        e = scope_bench.scope_e(n, 16, False, tmp, counts * np.uint64(192), repeat_first_block=True, out_name="out_keep")
+        assert e["output_files"] == 771 and e["peak_rss_MB"] < 8000, e
+        print("192 M templates:", {k: e[k] for k in ("seconds", "M_templates_per_s", "M_templates_per_s_steady", "output_MB", "peak_rss_MB")})
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)

@@ -132,3 +132,20 @@ def test_product_package_never_touches_the_oracle():
                 continue   # prose in a comment
             offenders.append((os.path.relpath(path, root), line))
     assert offenders == []
+
+
+def test_chunk_schedule_keeps_slots_exclusive_and_devices_in_order():
+    """SURVEY 8e without a GPU: chunk k -> device k mod G, slot (k / G) mod S, at most G * S chunks outstanding, collected in
+    order -- under any interleaving of submits and completions no (device, slot) pair is handed a second chunk early."""
+    import ctypes as C
+    import numpy as np
+    from tests import hostlib as H
+    fn = H.lib().fqtk_host_chunk_schedule_check
+    rng = np.random.default_rng(8)
+    for devices in (1, 2, 3, 4, 8):
+        for slots in (1, 2, 3):
+            for n_chunks in (0, 1, devices * slots, 1000):
+                for p in (0.0, 0.3, 0.7, 1.0):
+                    order = (rng.random(4 * n_chunks + 8) < p).astype(np.uint8)
+                    rc = fn(C.c_uint64(devices), C.c_uint64(slots), C.c_uint64(n_chunks), order.ctypes.data_as(C.c_void_p), C.c_size_t(order.size))
+                    assert rc == 0, (devices, slots, n_chunks, p, rc)
