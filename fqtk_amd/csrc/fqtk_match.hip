@@ -85,9 +85,9 @@ struct ErrCtx {
 
 // Worklist of the memo kernels' non-canonical reads (MatchParams::work): one per stream batches run on.
 struct Worklist {
-    uint32_t *d_list = nullptr;   // [segments][cap] read indices
+    uint32_t *d_list = nullptr;   // [segments][cap] entries of `ew` dwords: read index + row
     uint32_t *d_fill = nullptr;   // [segments] entries used; zero between launches
-    uint32_t cap = 0;
+    uint32_t cap = 0, ew = 1;
     void release() {
         if (d_list) (void)hipFree(d_list);
         if (d_fill) (void)hipFree(d_fill);
@@ -590,13 +590,17 @@ int launch(const fqtk_matcher *m, const fqtk::MatchParams &P0, hipStream_t strea
     uint64_t want = std::max<uint64_t>(64, (P0.n / 4 + segs - 1) / segs);
     if (const char *cap = std::getenv("FQTK_WORKLIST_CAP"))   // test knob: entries per segment (0: no list, no second pass)
         if (*cap) want = (uint64_t)std::max(0l, std::atol(cap));
-    if (want > wl.cap || !wl.d_fill) {
+    // rows of at most eight dwords travel with their index (MatchParams::work_rw)
+    const uint32_t rw = (P0.stride % 4 == 0 && P0.stride <= 32 && reinterpret_cast<uintptr_t>(P0.obs) % 4 == 0) ? P0.stride / 4 : 0;
+    if (want > wl.cap || !wl.d_fill || 1u + rw > wl.ew) {
         if (wl.d_list) { HIP_TRY(hipStreamSynchronize(stream)); HIP_TRY(hipFree(wl.d_list)); wl.d_list = nullptr; }
         if (!wl.d_fill) {
             HIP_TRY(hipMalloc(reinterpret_cast<void **>(&wl.d_fill), segs * sizeof(uint32_t)));
             HIP_TRY(hipMemsetAsync(wl.d_fill, 0, segs * sizeof(uint32_t), stream));   // the second pass keeps it zero from here on
         }
-        if (want) HIP_TRY(hipMalloc(reinterpret_cast<void **>(&wl.d_list), (size_t)segs * want * sizeof(uint32_t)));
+        wl.ew = std::max(wl.ew, 1u + rw);
+        want = std::max<uint64_t>(want, wl.cap);
+        if (want) HIP_TRY(hipMalloc(reinterpret_cast<void **>(&wl.d_list), (size_t)segs * want * wl.ew * sizeof(uint32_t)));
         wl.cap = (uint32_t)want;
     }
     fqtk::MatchParams P = P0;
@@ -605,6 +609,7 @@ int launch(const fqtk_matcher *m, const fqtk::MatchParams &P0, hipStream_t strea
         P.work_n = wl.d_fill;
         P.work_cap = wl.cap;
         P.work_segs = segs;
+        P.work_rw = rw;
     }
     const int rc = launch_memo(m, P, stream);
     if (rc != FQTK_OK || !P.work_segs) return rc;
@@ -700,6 +705,7 @@ fqtk::MatchParams make_params(const fqtk_matcher *m, const void *d_obs, uint32_t
     P.work_n = nullptr;
     P.work_cap = 0;
     P.work_segs = 0;
+    P.work_rw = 0;
     P.seen = m->d_seen;
     return P;
 }

@@ -283,7 +283,7 @@ void lds_memo_kernel(const LdsMemoParams Q) {
                 const uint32_t really = (live[r] && bflag[r]) ? noncanonical_beyond_dots<NWD>(words[r], kc, kv) : 0u;
                 uint64_t todo = __builtin_amdgcn_uicmp(really, 0u, 33);
                 if constexpr (!INDEXED)
-                    todo = defer_to_second_pass(P, work_seg, work_fill, todo, really != 0u, t * tile + local[r], res[r]);   // normally all of them
+                    todo = defer_to_second_pass(P, work_seg, work_fill, todo, really != 0u, t * tile + local[r], res[r], words[r]);   // normally all of them
                 if (todo) {
                     Planes<1> mine;
                     encode_planes<1>(words[r], nwords, L, lds_lut, mine);
@@ -327,9 +327,10 @@ void lds_memo_kernel(const LdsMemoParams Q) {
             const uint32_t filled = P.work_n[seg];
             const uint32_t cnt = filled < P.work_cap ? filled : P.work_cap;
             if (cnt == 0) continue;
-            const uint32_t *list = P.work + (uint64_t)seg * P.work_cap;
-            // R reads per lane: a wave's iteration is a chain of three dependent memory round trips (list entry,
-            // row, result store) and the R of them overlap
+            const uint32_t ew = 1u + P.work_rw;   // an entry: the read's index, then (work_rw dwords of) its row
+            const uint32_t *list = P.work + (uint64_t)seg * P.work_cap * ew;
+            // R reads per lane: a wave's iteration is a chain of dependent memory round trips (list entry [, row], result
+            // store) and the R of them overlap
             for (uint32_t base = 0; base < cnt; base += 64u * R) {
                 uint32_t words[R][8], res[R];
                 bool live[R];
@@ -338,13 +339,19 @@ void lds_memo_kernel(const LdsMemoParams Q) {
                 for (int r = 0; r < R; ++r) {
                     const uint32_t j = base + (uint32_t)r * 64u + lane;
                     live[r] = j < cnt;
-                    row[r] = live[r] ? list[j] : 0;
-                }
-#pragma unroll
-                for (int r = 0; r < R; ++r) {
+                    row[r] = live[r] ? list[(uint64_t)j * ew] : 0;
 #pragma unroll
                     for (int w = 0; w < 8; ++w) words[r][w] = 0x41414141u;
-                    if (live[r]) load_words<1, VEC>(P, row[r], nwords, words[r]);
+                    if (P.work_rw && live[r]) {   // wave-uniform: the rows stream in with the indices
+#pragma unroll
+                        for (int w = 0; w < 8; ++w)
+                            if ((uint32_t)w < P.work_rw && (uint32_t)w < nwords) words[r][w] = list[(uint64_t)j * ew + 1u + (uint32_t)w];
+                    }
+                }
+                if (!P.work_rw) {
+#pragma unroll
+                    for (int r = 0; r < R; ++r)
+                        if (live[r]) load_words<1, VEC>(P, row[r], nwords, words[r]);
                 }
 #pragma unroll
                 for (int r = 0; r < R; ++r) spell_ambiguity_codes_as_n<NWD>(words[r]);

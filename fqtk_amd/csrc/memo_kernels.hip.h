@@ -218,7 +218,7 @@ __device__ __forceinline__ void spell_ambiguity_codes_as_n(uint32_t (&words)[8])
 // wave-uniform) and gets the placeholder result.  Returns the lanes that did NOT fit (segment full / no list):
 // the caller scans those in place.
 __device__ __forceinline__ uint64_t defer_to_second_pass(const MatchParams &P, uint32_t seg, uint32_t &fill, uint64_t flagged,
-                                                         bool mine, uint64_t read_index, uint32_t &res) {
+                                                         bool mine, uint64_t read_index, uint32_t &res, const uint32_t (&row)[8]) {
     if (!flagged) return flagged;
     if (seg >= P.work_segs) {   // launched without a list (no such read seen so far): tell the host, once per wave
         if (!fill) {
@@ -230,7 +230,11 @@ __device__ __forceinline__ uint64_t defer_to_second_pass(const MatchParams &P, u
     const uint32_t at = fill + (uint32_t)__popcll((unsigned long long)(flagged & ((1ull << __lane_id()) - 1ull)));
     const bool fits = mine && at < P.work_cap;
     if (fits) {
-        P.work[(uint64_t)seg * P.work_cap + at] = (uint32_t)read_index;
+        uint32_t *entry = P.work + ((uint64_t)seg * P.work_cap + at) * (1u + P.work_rw);
+        entry[0] = (uint32_t)read_index;
+#pragma unroll
+        for (int w = 0; w < 8; ++w)   // the row goes along (wave-uniform count; the words are in registers already)
+            if ((uint32_t)w < P.work_rw) entry[1 + w] = row[w];
         res = kMemoDeferred;   // the second pass writes the result and counts it
     }
     fill = (uint32_t)__builtin_amdgcn_readfirstlane((int)min(fill + (uint32_t)__popcll((unsigned long long)flagged), P.work_cap));
@@ -466,7 +470,7 @@ void memo_kernel(const MemoParams Q) {
             if (__ballot(bad[r])) {   // wave-uniform
                 const bool really = bad[r] && noncanonical_beyond_dots<NWD>(words[r], kc, kv) != 0;
                 uint64_t todo = __ballot(really);
-                todo = defer_to_second_pass(P, work_seg, work_fill, todo, really, t * tile + local[r], res[r]);   // normally all of them
+                todo = defer_to_second_pass(P, work_seg, work_fill, todo, really, t * tile + local[r], res[r], words[r]);   // normally all of them
                 if (todo) {
                     Planes<1> mine;
                     encode_planes<1>(words[r], nwords, L, lds_lut, mine);

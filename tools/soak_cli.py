@@ -173,9 +173,9 @@ if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--iters", type=int, default=40)
     ap.add_argument("--seed", type=int, default=1)
-    ap.add_argument("--gpu-bgzf", action="store_true", help="every run with --gpu-bgzf (output blocks compressed on the GPU)")
+    ap.add_argument("--host-output", action="store_true", help="every run with --host-output (records formatted and compressed by the host threads; default: on the device)")
     a = ap.parse_args()
-    EXTRA[:] = ["--gpu-bgzf"] if a.gpu_bgzf else []
+    EXTRA[:] = ["--host-output"] if a.host_output else []
     rng = random.Random(a.seed)
     tmp = tempfile.mkdtemp(prefix="fqtk_soak_", dir="/tmp")
     tally = {}
