@@ -533,8 +533,9 @@ bool gpu_output_supported(const Plan &plan, std::string *why) {
         for (size_t k = 2; k < kRing; ++k) free_bufs[i]->push(rings[i][k].get());
 
     // ---- writers: file c belongs to writer c mod W
-    // (two: appending ~3 GB/s of members is half a CPU each; four took cycles from the readers -- 64 M templates: 27 -> 31 M/s)
-    const size_t W = std::min<size_t>(2, std::max<size_t>(1, std::min<size_t>(opt.threads, usable_cpus()) / 4));
+    // (same box, 64 M templates, tools/ab_writers.sh: one or two writers 24 M templates/s, four 31: 87 k write() calls a second)
+    size_t W = std::min<size_t>(4, std::max<size_t>(1, std::min<size_t>(opt.threads, usable_cpus()) / 4));
+    if (const char *w = std::getenv("FQTK_WRITERS")) if (*w) W = std::max(1, std::atoi(w));   // (A/B runs)
     std::mutex wmu;
     std::condition_variable wcv_go, wcv_done;
     const fqtk_demux_result *wres = nullptr;

@@ -343,9 +343,15 @@ void lds_memo_kernel(const LdsMemoParams Q) {
 #pragma unroll
                     for (int w = 0; w < 8; ++w) words[r][w] = 0x41414141u;
                     if (P.work_rw && live[r]) {   // wave-uniform: the rows stream in with the indices
+                        const uint32_t *e = list + (uint64_t)j * ew + 1u;
+                        if (P.work_rw == 4) {
+                            const u32x4v v = *reinterpret_cast<const u32x4v *>(e);
+                            words[r][0] = v.x; words[r][1] = v.y; words[r][2] = v.z; words[r][3] = v.w;
+                        } else {
 #pragma unroll
-                        for (int w = 0; w < 8; ++w)
-                            if ((uint32_t)w < P.work_rw && (uint32_t)w < nwords) words[r][w] = list[(uint64_t)j * ew + 1u + (uint32_t)w];
+                            for (int w = 0; w < 8; ++w)
+                                if ((uint32_t)w < P.work_rw && (uint32_t)w < nwords) words[r][w] = e[w];
+                        }
                     }
                 }
                 if (!P.work_rw) {

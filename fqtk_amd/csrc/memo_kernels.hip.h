@@ -232,9 +232,17 @@ __device__ __forceinline__ uint64_t defer_to_second_pass(const MatchParams &P, u
     if (fits) {
         uint32_t *entry = P.work + ((uint64_t)seg * P.work_cap + at) * (1u + P.work_rw);
         entry[0] = (uint32_t)read_index;
+        // the row goes along (wave-uniform count; the words are in registers already): as few store instructions as
+        // the width allows -- every one of them sits in the pipelined loop's vmcnt window
+        if (P.work_rw == 4) {
+            *reinterpret_cast<u32x4v *>(entry + 1) = u32x4v{row[0], row[1], row[2], row[3]};
+        } else if (P.work_rw == 2) {
+            *reinterpret_cast<u32x2v *>(entry + 1) = u32x2v{row[0], row[1]};
+        } else {
 #pragma unroll
-        for (int w = 0; w < 8; ++w)   // the row goes along (wave-uniform count; the words are in registers already)
-            if ((uint32_t)w < P.work_rw) entry[1 + w] = row[w];
+            for (int w = 0; w < 8; ++w)
+                if ((uint32_t)w < P.work_rw) entry[1 + w] = row[w];
+        }
         res = kMemoDeferred;   // the second pass writes the result and counts it
     }
     fill = (uint32_t)__builtin_amdgcn_readfirstlane((int)min(fill + (uint32_t)__popcll((unsigned long long)flagged), P.work_cap));
