@@ -452,6 +452,8 @@ def main() -> int:
             torch.cuda.empty_cache()
             scopes["B"] = scope_bench.scope_b(args.config, matcher=matcher, workload=workload,
                                               n_chunk=min(8_000_000, max(job_reads // 4, 1)))
+            scopes["B_packed"] = scope_bench.scope_b_packed(args.config, matcher=matcher, workload=workload,
+                                                            n_chunk=min(8_000_000, max(job_reads // 4, 1)))
             tmp = scope_bench.scratch_dir(args.e2e_templates * 900)
             try:
                 expect = None

@@ -97,6 +97,11 @@ SIGNATURES = [
     ("fqtk_pinned_free", C.c_int, [C.c_void_p]),
     ("fqtk_matcher_enqueue", C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_uint32, C.c_void_p,
                                        C.c_uint64, C.c_void_p]),
+    ("fqtk_packed_stride", C.c_uint32, [C.c_uint32]),
+    ("fqtk_pack_barcodes", C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint64, C.c_void_p, C.c_uint32, C.c_void_p,
+                                     C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64)]),
+    ("fqtk_matcher_enqueue_packed", C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_uint32, C.c_uint64, C.c_void_p,
+                                              C.c_void_p, C.c_uint64, C.c_void_p]),
     ("fqtk_matcher_wait", C.c_int, [C.c_void_p, C.c_int]),
     ("fqtk_matcher_counts", C.c_int, [C.c_void_p, C.c_void_p]),
     ("fqtk_matchers_allreduce_counts", C.c_int, [C.POINTER(C.c_void_p), C.c_int, C.c_int, C.c_void_p]),

@@ -153,6 +153,39 @@ class BarcodeMatcher:
                                                    out.ctypes.data, cnt.ctypes.data if counts else None))
         return out, cnt
 
+    # ---- packed input: 4 bits per base over PCIe (fqtk_pack_barcodes / fqtk_matcher_enqueue_packed) ----------
+    def pack(self, obs: np.ndarray):
+        """obs: uint8 [n, stride >= barcode_len] ASCII rows -> (packed uint8 [n, packed_stride], exc_index u32[k], exc_rows u8[k, L])."""
+        obs = np.ascontiguousarray(obs, dtype=np.uint8)
+        n, stride = obs.shape
+        L = self.barcode_len
+        ps = int(self._lib.fqtk_packed_stride(L))
+        packed = np.empty((n, ps), dtype=np.uint8)
+        exc_index = np.empty(max(n, 1), dtype=np.uint32)
+        exc_rows = np.empty((max(n, 1), L), dtype=np.uint8)
+        n_exc = C.c_uint64(0)
+        _check(self._lib.fqtk_pack_barcodes(obs.ctypes.data, stride, L, n, packed.ctypes.data, ps, exc_index.ctypes.data,
+                                            exc_rows.ctypes.data, n, C.byref(n_exc)))
+        k = int(n_exc.value)
+        return packed, exc_index[:k].copy(), exc_rows[:k].copy()
+
+    def assign_batch_packed(self, packed: np.ndarray, exc_index: np.ndarray, exc_rows: np.ndarray, slot: int = 0):
+        """The packed entry, synchronously: returns (matches, counts of this call)."""
+        packed = np.ascontiguousarray(packed, dtype=np.uint8)
+        exc_index = np.ascontiguousarray(exc_index, dtype=np.uint32)
+        exc_rows = np.ascontiguousarray(exc_rows, dtype=np.uint8)
+        n, ps = packed.shape
+        out = np.empty(n, dtype=MATCH_DTYPE)
+        scratch = np.zeros(self.n_samples + 1, dtype=np.uint64)
+        _check(self._lib.fqtk_matcher_counts(self._h, scratch.ctypes.data))          # start from an empty accumulator
+        _check(self._lib.fqtk_matcher_enqueue_packed(self._h, slot, packed.ctypes.data, ps, n,
+                                                     exc_index.ctypes.data if exc_index.size else None,
+                                                     exc_rows.ctypes.data if exc_index.size else None, exc_index.size, out.ctypes.data))
+        _check(self._lib.fqtk_matcher_wait(self._h, slot))
+        cnt = np.zeros(self.n_samples + 1, dtype=np.uint64)
+        _check(self._lib.fqtk_matcher_counts(self._h, cnt.ctypes.data))
+        return out, cnt
+
     def assign_batch_device(self, d_obs: int, stride: int, n: int, d_out: int, d_counts: int = 0,
                             d_lens: int = 0, stream: int = 0) -> None:
         """Zero-copy form: raw device pointers (e.g. torch tensor .data_ptr()) and a hipStream_t

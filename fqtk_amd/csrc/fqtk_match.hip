@@ -104,6 +104,12 @@ struct Slot {
     size_t len_cap = 0;  // elements
     uint32_t *d_out = nullptr;
     size_t out_cap = 0;  // elements
+    uint8_t *d_packed = nullptr;     // fqtk_matcher_enqueue_packed: the 4-bit rows as they arrive, the exceptions' indices and rows
+    size_t packed_cap = 0;
+    uint32_t *d_exc_index = nullptr;
+    size_t exc_index_cap = 0;
+    uint8_t *d_exc_rows = nullptr;
+    size_t exc_rows_cap = 0;
     bool busy = false;
     ErrCtx ctx;          // the chunk in flight on this slot
     Worklist work;
@@ -1089,7 +1095,7 @@ extern "C" {
 
 const char *fqtk_last_error(void) { return g_last_error.c_str(); }
 
-int fqtk_abi_version(void) { return 3; }
+int fqtk_abi_version(void) { return 4; }
 
 int fqtk_device_count(int *n_devices) {
     if (!n_devices) return fail(FQTK_EINVAL, "n_devices is NULL");
@@ -1225,6 +1231,9 @@ void fqtk_matcher_destroy(fqtk_matcher *m) {
         if (s.d_obs) (void)hipFree(s.d_obs);
         if (s.d_len) (void)hipFree(s.d_len);
         if (s.d_out) (void)hipFree(s.d_out);
+        if (s.d_packed) (void)hipFree(s.d_packed);
+        if (s.d_exc_index) (void)hipFree(s.d_exc_index);
+        if (s.d_exc_rows) (void)hipFree(s.d_exc_rows);
         s.work.release();
     }
     if (m->d_memo) (void)hipFree(m->d_memo);
@@ -1347,6 +1356,127 @@ int wait_impl(fqtk_matcher *m, int slot) {
     return collect_error(m, s.stream, slot, s.ctx, nullptr);   // this slot's own error word
 }
 }  // namespace
+
+// ---- packed input (include/fqtk_match.h: fqtk_pack_barcodes / fqtk_matcher_enqueue_packed) -----------------------------
+// Over PCIe a barcode costs its ASCII bytes; 4 bits per base halve that (cfg 3: 8 + 4 instead of 16 + 4 bytes per read).
+// The packed rows are turned back into ASCII rows in HBM -- 100x the link's bandwidth -- and the matcher's kernels run
+// on those unchanged, so every path (LDS / table / direct memo, second pass, scan, counts) is the one the ASCII entry
+// takes and results are identical by construction.
+namespace fqtk {
+__global__ __launch_bounds__(256) void unpack_kernel(const uint8_t *packed, uint32_t ps, uint32_t L, uint64_t n, uint8_t *obs, uint32_t stride) {
+    const uint64_t i = (uint64_t)blockIdx.x * 256u + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t *src = reinterpret_cast<const uint32_t *>(packed + i * ps);
+    uint32_t *dst = reinterpret_cast<uint32_t *>(obs + i * stride);
+    const uint32_t out_words = stride >> 2;
+    for (uint32_t w = 0; w < out_words; ++w) {
+        const uint32_t sw = w >> 1;
+        const uint32_t x = sw < (ps >> 2) ? (src[sw] >> (16u * (w & 1u))) & 0xFFFFu : 0u;   // the four nibbles of bases 4w .. 4w + 3
+        const uint32_t c = (x & 0xFu) | ((x & 0xF0u) << 4) | ((x & 0xF00u) << 8) | ((x & 0xF000u) << 12);
+        uint32_t chars = __builtin_amdgcn_perm(kCodePoolHi, kCodePoolLo, c & 0x07070707u);
+        const int rem = (int)L - 4 * (int)w;                                                           // pad bytes are zero
+        if (rem < 4) chars &= rem <= 0 ? 0u : ((1u << (8 * rem)) - 1u);
+        dst[w] = chars;
+    }
+}
+__global__ __launch_bounds__(256) void patch_rows_kernel(const uint32_t *index, const uint8_t *rows, uint32_t rows_stride, uint64_t n_exc,
+                                                         uint64_t n, uint32_t L, uint8_t *obs, uint32_t stride) {
+    const uint64_t j = (uint64_t)blockIdx.x * 256u + threadIdx.x;
+    if (j >= n_exc) return;
+    const uint64_t i = index[j];
+    if (i >= n) return;
+    for (uint32_t k = 0; k < L; ++k) obs[i * stride + k] = rows[j * rows_stride + k];
+}
+}  // namespace fqtk
+
+namespace {
+// code of a base in a packed row (A 0, C 1, T 2, G 3, no-call 7), 0xFF for a byte the packed form cannot carry
+struct PackLut {
+    uint8_t code[256];
+    PackLut() {
+        std::memset(code, 0xFF, sizeof code);
+        const char *b = "ACTG";
+        for (int k = 0; k < 4; ++k) { code[(uint8_t)b[k]] = (uint8_t)k; code[(uint8_t)(b[k] | 0x20)] = (uint8_t)k; }
+        code[(uint8_t)'N'] = code[(uint8_t)'n'] = code[(uint8_t)'.'] = 7;   // the no-calls (mod.rs:85-87)
+    }
+};
+const PackLut kPackLut;
+}  // namespace
+
+extern "C" {
+
+uint32_t fqtk_packed_stride(uint32_t barcode_len) { return (((barcode_len + 1u) / 2u) + 3u) & ~3u; }
+
+int fqtk_pack_barcodes(const uint8_t *obs, uint32_t stride, uint32_t barcode_len, uint64_t n, uint8_t *packed, uint32_t packed_stride,
+                       uint32_t *exc_index, uint8_t *exc_rows, uint64_t exc_cap, uint64_t *n_exc) {
+    if (!obs || !packed || !n_exc) return fail(FQTK_EINVAL, "NULL argument");
+    if (barcode_len == 0 || barcode_len > FQTK_MAX_BARCODE_LEN || stride < barcode_len) return fail(FQTK_EINVAL, "stride < barcode_len, or barcode_len out of range");
+    if (packed_stride < fqtk_packed_stride(barcode_len)) return fail(FQTK_EINVAL, "packed_stride smaller than fqtk_packed_stride(barcode_len)");
+    if (n > 0xFFFFFFFFull) return fail(FQTK_EINVAL, "at most 2^32 - 1 reads per call");
+    uint64_t ne = 0;
+    const uint8_t *lut = kPackLut.code;
+    for (uint64_t i = 0; i < n; ++i) {
+        const uint8_t *r = obs + i * stride;
+        uint8_t *o = packed + i * packed_stride;
+        uint32_t bad = 0;
+        uint32_t k = 0;
+        for (; k + 1 < barcode_len; k += 2) {
+            const uint32_t a = lut[r[k]], b = lut[r[k + 1]];
+            bad |= a | b;
+            o[k >> 1] = (uint8_t)((a & 7u) | ((b & 7u) << 4));
+        }
+        if (k < barcode_len) { const uint32_t a = lut[r[k]]; bad |= a; o[k >> 1] = (uint8_t)(a & 7u); k += 2; }
+        for (uint32_t j = k >> 1; j < packed_stride; ++j) o[j] = 0;
+        if (bad & 0x80u) {   // an IUPAC code / other byte: the read travels as ASCII beside the packed rows
+            if (ne >= exc_cap || !exc_index || !exc_rows) return fail(FQTK_ENOMEM, "more reads with bytes outside A C G T N . than exc_cap");
+            exc_index[ne] = (uint32_t)i;
+            std::memcpy(exc_rows + ne * barcode_len, r, barcode_len);
+            ++ne;
+        }
+    }
+    *n_exc = ne;
+    return FQTK_OK;
+}
+
+int fqtk_matcher_enqueue_packed(fqtk_matcher *m, int slot, const uint8_t *packed, uint32_t packed_stride, uint64_t n,
+                                const uint32_t *exc_index, const uint8_t *exc_rows, uint64_t n_exc, fqtk_match_t *out) {
+    if (!m) return fail(FQTK_EINVAL, "matcher is NULL");
+    if (slot < 0 || slot >= FQTK_MAX_SLOTS) return fail(FQTK_EINVAL, "slot out of range");
+    if (n == 0) return FQTK_OK;
+    if (!packed || !out || (n_exc && (!exc_index || !exc_rows))) return fail(FQTK_EINVAL, "NULL argument");
+    if (packed_stride < fqtk_packed_stride(m->L) || packed_stride % 4) return fail(FQTK_EINVAL, "packed_stride must be a multiple of 4 and at least fqtk_packed_stride(barcode_len)");
+    if (n > 0xFFFFFFFFull) return fail(FQTK_EINVAL, "at most 2^32 - 1 reads per chunk");
+    HIP_TRY(hipSetDevice(m->device));
+    int rc = ensure_slot(m, slot);
+    if (rc != FQTK_OK) return rc;
+    Slot &s = m->slots[slot];
+    if (s.busy) return fail(FQTK_EINVAL, "slot is busy: call fqtk_matcher_wait() first");
+    const uint32_t stride = (m->L + 3u) & ~3u;
+    if ((rc = ensure_cap(s.d_packed, s.packed_cap, (size_t)n * packed_stride + 16)) != FQTK_OK) return rc;
+    if ((rc = ensure_cap(s.d_obs, s.obs_cap, (size_t)n * stride + 16)) != FQTK_OK) return rc;
+    if ((rc = ensure_cap(s.d_out, s.out_cap, (size_t)n)) != FQTK_OK) return rc;
+    HIP_TRY(hipMemcpyAsync(s.d_packed, packed, (size_t)n * packed_stride, hipMemcpyHostToDevice, s.stream));
+    hipLaunchKernelGGL(fqtk::unpack_kernel, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, s.stream, s.d_packed, packed_stride, m->L, n, s.d_obs, stride);
+    HIP_TRY(hipGetLastError());
+    if (n_exc) {
+        if ((rc = ensure_cap(s.d_exc_index, s.exc_index_cap, (size_t)n_exc)) != FQTK_OK) return rc;
+        if ((rc = ensure_cap(s.d_exc_rows, s.exc_rows_cap, (size_t)n_exc * m->L)) != FQTK_OK) return rc;
+        HIP_TRY(hipMemcpyAsync(s.d_exc_index, exc_index, (size_t)n_exc * sizeof(uint32_t), hipMemcpyHostToDevice, s.stream));
+        HIP_TRY(hipMemcpyAsync(s.d_exc_rows, exc_rows, (size_t)n_exc * m->L, hipMemcpyHostToDevice, s.stream));
+        hipLaunchKernelGGL(fqtk::patch_rows_kernel, dim3((uint32_t)((n_exc + 255) / 256)), dim3(256), 0, s.stream, s.d_exc_index, s.d_exc_rows,
+                           m->L, n_exc, n, m->L, s.d_obs, stride);
+        HIP_TRY(hipGetLastError());
+    }
+    const fqtk::MatchParams P = make_params(m, s.d_obs, stride, nullptr, n, s.d_out, m->d_counts, slot);
+    s.ctx = ErrCtx{nullptr, nullptr, stride, n, false};   // (every row is exactly one barcode long: no length error can arise)
+    rc = launch(m, P, s.stream, s.work);
+    if (rc != FQTK_OK) return rc;
+    HIP_TRY(hipMemcpyAsync(out, s.d_out, (size_t)n * sizeof(fqtk_match_t), hipMemcpyDeviceToHost, s.stream));
+    s.busy = true;
+    return FQTK_OK;
+}
+
+}  // extern "C"
 
 extern "C" {
 

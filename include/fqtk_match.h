@@ -181,6 +181,28 @@ int fqtk_pinned_free(void *p);
  * Per-sample counts are accumulated on the device; read them with fqtk_matcher_counts(). */
 int fqtk_matcher_enqueue(fqtk_matcher *m, int slot, const uint8_t *obs, uint32_t stride,
                          const uint32_t *obs_len, uint64_t n, fqtk_match_t *out);
+/* ---- packed input: 4 bits per base over PCIe instead of 8 ------------------------------------------------------
+ * A packed row holds base k of the barcode in nibble k (byte k / 2, low nibble first); codes A 0, C 1, T 2, G 3 and 7
+ * for the no-calls N, n and '.' (mod.rs:85-87) -- lower case like upper case, as the reference's encode() treats it
+ * (mod.rs:49-61).  Rows are fqtk_packed_stride(barcode_len) bytes apart (the nibbles rounded up to 4 bytes: 8 + 8
+ * bases -> 8 bytes).  A read with any other byte (an IUPAC code, junk) cannot be carried in 4 bits: the packer lists it
+ * as an EXCEPTION -- its index and its barcode_len ASCII bytes -- and the enqueue call puts those rows back in place on
+ * the device, so results are those of the ASCII entry points for every input.
+ *
+ * fqtk_pack_barcodes: host-side packer (plain CPU code: one table look-up per base; run it in the threads that produce
+ * the barcodes).  obs: n x stride ASCII rows as for fqtk_matcher_enqueue; exc_index / exc_rows: room for exc_cap
+ * exceptions (exc_cap * barcode_len bytes of rows), *n_exc = how many there are; FQTK_ENOMEM if they do not fit. */
+uint32_t fqtk_packed_stride(uint32_t barcode_len);
+int fqtk_pack_barcodes(const uint8_t *obs, uint32_t stride, uint32_t barcode_len, uint64_t n, uint8_t *packed,
+                       uint32_t packed_stride, uint32_t *exc_index, uint8_t *exc_rows, uint64_t exc_cap, uint64_t *n_exc);
+/* fqtk_matcher_enqueue for packed rows (every read exactly barcode_len bases: no obs_len form): async H2D of the packed
+ * rows and the exceptions, unpack to ASCII rows in HBM, the same kernels as every other entry point, async D2H into
+ * `out`; fqtk_matcher_wait(slot) completes it, counts accumulate as for fqtk_matcher_enqueue.  Replaces one `assign`
+ * per template (demux.rs:968) like fqtk_matcher_enqueue does, at 8 + 4 instead of 16 + 4 bytes per read over the link
+ * for 8 + 8-base dual indexes. */
+int fqtk_matcher_enqueue_packed(fqtk_matcher *m, int slot, const uint8_t *packed, uint32_t packed_stride, uint64_t n,
+                                const uint32_t *exc_index, const uint8_t *exc_rows, uint64_t n_exc, fqtk_match_t *out);
+
 /* Blocks until the chunk on `slot` is complete; FQTK_ELEN as for assign_batch.  Every slot latches its
  * own error: the status belongs to the chunk that was enqueued on THIS slot. */
 int fqtk_matcher_wait(fqtk_matcher *m, int slot);

@@ -52,7 +52,7 @@ def test_match_struct_is_4_bytes_little_endian_layout():
 
 def test_abi_version_and_device_count_do_not_need_a_gpu():
     lib = _lib.load()
-    assert lib.fqtk_abi_version() == 3
+    assert lib.fqtk_abi_version() == 4
     n = C.c_int(-1)
     assert lib.fqtk_device_count(C.byref(n)) == _lib.FQTK_OK
     assert n.value >= 0
@@ -87,3 +87,36 @@ def test_no_cpu_fallback_without_a_device():
         pytest.skip("a GPU is present")
     rc, _, msg = _create(["ACGT", "TTTT"])
     assert rc == _lib.FQTK_ENODEV and "no CPU fallback" in msg
+
+
+def test_packer_lays_nibbles_out_as_documented_and_lists_exceptions():
+    """fqtk_pack_barcodes is plain host code: base k in nibble k, A 0 C 1 T 2 G 3, no-calls 7, either case; a read with
+    any other byte is an exception (index + ASCII row)."""
+    import numpy as np
+    lib = _lib.load()
+    for L in (1, 7, 8, 10, 16, 17, 20):
+        ps = lib.fqtk_packed_stride(L)
+        assert ps % 4 == 0 and ps >= (L + 1) // 2
+        rng = np.random.default_rng(L)
+        n = 500
+        rows = rng.choice(np.frombuffer(b"ACGTNacgtn.", dtype=np.uint8), (n, L + 3))
+        bad = rng.choice(n, 20, replace=False)
+        for i in bad:
+            rows[i, int(rng.integers(0, L))] = int(rng.choice(np.frombuffer(b"RYKMSWBDHVU*x\0", dtype=np.uint8)))
+        packed = np.zeros((n, ps), dtype=np.uint8)
+        exc_i = np.zeros(n, dtype=np.uint32)
+        exc_r = np.zeros((n, L), dtype=np.uint8)
+        k = C.c_uint64(0)
+        assert lib.fqtk_pack_barcodes(rows.ctypes.data, L + 3, L, n, packed.ctypes.data, ps, exc_i.ctypes.data, exc_r.ctypes.data, n, C.byref(k)) == 0
+        assert sorted(exc_i[:k.value].tolist()) == sorted(bad.tolist())
+        code = {ord("A"): 0, ord("C"): 1, ord("T"): 2, ord("G"): 3, ord("N"): 7, ord("."): 7}
+        for i in range(n):
+            if i in set(bad.tolist()):
+                j = exc_i[:k.value].tolist().index(i)
+                assert bytes(exc_r[j]) == bytes(rows[i, :L])
+                continue
+            for b in range(L):
+                nib = (int(packed[i, b // 2]) >> (4 * (b & 1))) & 0xF
+                assert nib == code[int(rows[i, b]) & 0xDF if rows[i, b] != ord(".") else ord(".")], (L, i, b)
+        # no room for the exceptions is an error, not an overflow
+        assert lib.fqtk_pack_barcodes(rows.ctypes.data, L + 3, L, n, packed.ctypes.data, ps, exc_i.ctypes.data, exc_r.ctypes.data, 3, C.byref(k)) == _lib.FQTK_ENOMEM

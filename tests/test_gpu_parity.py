@@ -819,3 +819,35 @@ def test_full_size_parity_of_every_baseline_config():
         assert r.returncode == 0, r.stderr[-2000:]
         d = json.loads(r.stdout.strip().splitlines()[-1])
         assert d["mismatching_reads"] == 0 and d["counts_equal"], d
+
+
+@pytest.mark.parametrize("k", [1, 2, 3, 4, 5])
+def test_packed_entry_equals_the_ascii_entry_and_the_oracle_on_every_config(k):
+    """fqtk_pack_barcodes + fqtk_matcher_enqueue_packed (4 bits per base over PCIe): triples and counts equal those of
+    fqtk_matcher_assign_batch and of the oracle, reads with IUPAC / junk bytes included (they travel as exceptions)."""
+    cfg = synth.CONFIGS[k]
+    w = synth.Workload(cfg)
+    n = {1: 100_000, 2: 200_000, 3: 200_000, 4: 100_000, 5: 60_000}[k]
+    obs = w.fill_host(0, n).copy()
+    rng = np.random.default_rng(40 + k)
+    L = cfg.barcode_len
+    for i in rng.choice(n, 300, replace=False):                         # IUPAC codes, lower case, dots, junk
+        obs[i, int(rng.integers(0, L))] = int(rng.choice(np.frombuffer(b"RYKMSWBDHVUnacgt.*\0", dtype=np.uint8)))
+    m = BarcodeMatcher(w.barcodes, cfg.max_mismatches, cfg.min_mismatch_delta, device=0)
+    packed, exc_index, exc_rows = m.pack(obs)
+    assert packed.shape[1] == {8: 4, 10: 8, 16: 8}[L] and 0 < exc_index.size <= 300
+    got_p, counts_p = m.assign_batch_packed(packed, exc_index, exc_rows)
+    got_a, counts_a = m.assign_batch(obs)
+    assert np.array_equal(got_p.view(np.uint32), got_a.view(np.uint32)) and np.array_equal(counts_p, counts_a)
+    lit = O.RefLiteral(w.barcodes, cfg.max_mismatches, cfg.min_mismatch_delta, True)
+    i, b, nx, c = lit.assign_batch(np.ascontiguousarray(obs[:, :L]))
+    assert np.array_equal(got_p["idx"], i) and np.array_equal(got_p["best"], b) and np.array_equal(got_p["next"], nx)
+    assert np.array_equal(counts_p, c)
+    # no exceptions at all, and two chunks in flight on two slots
+    clean = w.fill_host(n, 50_000)
+    p2, e2, r2 = m.pack(clean)
+    if k != 5:
+        assert e2.size == 0
+    got2, _ = m.assign_batch_packed(p2, e2, r2, slot=1)
+    ref2, _ = m.assign_batch(clean)
+    assert np.array_equal(got2.view(np.uint32), ref2.view(np.uint32))

@@ -68,6 +68,64 @@ def scope_b(cfg_id=3, n_chunk=8_000_000, chunks=12, matcher=None, workload=None)
             "GB_per_s_over_pcie": round(reads * (cfg.stride + 4) / dt / 1e9, 2)}
 
 
+def scope_b_packed(cfg_id=3, n_chunk=8_000_000, chunks=12, matcher=None, workload=None):
+    """Scope B with 4 bits per base over the link (fqtk_pack_barcodes + fqtk_matcher_enqueue_packed): the rows are packed
+    once on the host (outside the timed region, as scope B's ASCII rows are filled outside it); the packer's own rate on
+    one host thread is reported beside."""
+    cfg = synth.CONFIGS[cfg_id]
+    w = workload or synth.Workload(cfg)
+    lib = _lib.load()
+    m = matcher or BarcodeMatcher(w.barcodes, cfg.max_mismatches, cfg.min_mismatch_delta)
+    ps = int(lib.fqtk_packed_stride(cfg.barcode_len))
+    bufs = []
+    pack_s = 0.0
+    for s in range(2):
+        pp, pr = C.c_void_p(), C.c_void_p()
+        assert lib.fqtk_pinned_alloc(n_chunk * ps, C.byref(pp)) == 0, _lib.last_error()
+        assert lib.fqtk_pinned_alloc(n_chunk * 4, C.byref(pr)) == 0, _lib.last_error()
+        host = w.fill_host(s * n_chunk, n_chunk)
+        exc_i = np.empty(1 << 16, dtype=np.uint32)
+        exc_r = np.empty((1 << 16, cfg.barcode_len), dtype=np.uint8)
+        k = C.c_uint64(0)
+        t0 = time.perf_counter()
+        assert lib.fqtk_pack_barcodes(host.ctypes.data, cfg.stride, cfg.barcode_len, n_chunk, pp, ps, exc_i.ctypes.data,
+                                      exc_r.ctypes.data, 1 << 16, C.byref(k)) == 0, _lib.last_error()
+        pack_s += time.perf_counter() - t0
+        bufs.append((pp, pr, exc_i[:k.value].copy(), exc_r[:k.value].copy()))
+    def enqueue(s):
+        pp, pr, ei, er = bufs[s]
+        return lib.fqtk_matcher_enqueue_packed(m.handle, s, pp, ps, n_chunk, ei.ctypes.data if ei.size else None,
+                                               er.ctypes.data if ei.size else None, ei.size, pr)
+    try:
+        for s in range(2):
+            assert enqueue(s) == 0, _lib.last_error()
+        for s in range(2):
+            assert lib.fqtk_matcher_wait(m.handle, s) == 0
+        t0 = time.perf_counter()
+        for c in range(chunks):
+            s = c % 2
+            if c >= 2:
+                assert lib.fqtk_matcher_wait(m.handle, s) == 0
+            assert enqueue(s) == 0
+        for s in range(2):
+            assert lib.fqtk_matcher_wait(m.handle, s) == 0
+        dt = time.perf_counter() - t0
+        got = np.ctypeslib.as_array(C.cast(bufs[1][1], C.POINTER(C.c_uint32)), (n_chunk,))[:100_000].copy()
+        ref, _ = m.assign_batch(w.fill_host(n_chunk, 100_000), counts=False)
+        assert np.array_equal(got, ref.view(np.uint32)), "packed scope B results differ from the synchronous ASCII path"
+        scratch = np.zeros(cfg.n_samples + 1, dtype=np.uint64)
+        lib.fqtk_matcher_counts(m.handle, scratch.ctypes.data)
+    finally:
+        for pp, pr, _, _ in bufs:
+            lib.fqtk_pinned_free(pp)
+            lib.fqtk_pinned_free(pr)
+    reads = n_chunk * chunks
+    return {"what": "fqtk_matcher_enqueue_packed/wait on 2 pinned slots: 4-bit packed host barcodes -> host results, PCIe inclusive",
+            "workload": cfg.name, "reads": reads, "chunk_reads": n_chunk, "packed_bytes_per_read": ps, "seconds": round(dt, 4),
+            "M_reads_per_s": round(reads / dt / 1e6, 1), "GB_per_s_over_pcie": round(reads * (ps + 4) / dt / 1e9, 2),
+            "host_packer_M_reads_per_s_1_thread": round(2 * n_chunk / pack_s / 1e6, 1)}
+
+
 def fixed_fastq(path, start, n, seqs, read_no, append):
     """n records with fixed-width fields, built as one numpy byte matrix; names carry start + row."""
     L = seqs.shape[1]
