@@ -265,6 +265,9 @@ int fqtk_demuxer_create(fqtk_matcher *m, const fqtk_demux_config *cfg, fqtk_demu
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, d->device) == hipSuccess && prop.multiProcessorCount > 0) d->num_cus = prop.multiProcessorCount;
     DX_OR_BAIL(fqtk::bgzf::deflate_prepare());
+    if (kFormatWaves * format_wave_bytes(C.n_inputs) > 48 * 1024)   // (many inputs: the record views of 64 templates per wave need more than the default LDS)
+        DX_OR_BAIL(hipFuncSetAttribute(reinterpret_cast<const void *>(k_format), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       (int)(kFormatWaves * format_wave_bytes(C.n_inputs))));
     for (hipStream_t *st : {&d->s_in, &d->s_a, &d->s_b, &d->s_out}) DX_OR_BAIL(hipStreamCreateWithFlags(st, hipStreamNonBlocking));
     const size_t persist_bytes = (size_t)std::max<uint32_t>(d->n_cols, 1) * kPersist * kSlab;
     DX_OR_BAIL(hipMalloc(reinterpret_cast<void **>(&d->d_persist), persist_bytes));
@@ -404,7 +407,7 @@ int fqtk_demuxer_submit(fqtk_demuxer *d, int slot, const uint8_t *const *text, c
     hipLaunchKernelGGL(k_descs, dim3((uint32_t)((max_blocks + 255) / 256)), dim3(256), 0, A, C, s.fc.p, d->d_persist, s.slabs.p, s.out_slabs.p, s.desc.p, s.blk_file.p, s.d_status);
     DX_TRY(hipGetLastError());
     DX_TRY(hipEventRecord(s.ev[3], A));
-    hipLaunchKernelGGL(k_format, dim3((n + kFormatWaves - 1) / kFormatWaves), dim3(64 * kFormatWaves), 0, A, T, C, n, s.res.p, s.skip.p, s.plans.p,
+    hipLaunchKernelGGL(k_format, dim3((n + kFormatGroup * kFormatWaves - 1) / (kFormatGroup * kFormatWaves)), dim3(64 * kFormatWaves), kFormatWaves * format_wave_bytes(C.n_inputs), A, T, C, n, s.res.p, s.skip.p, s.plans.p,
                        s.rec_off.p, s.tile_tot.p, s.fc.p, d->d_persist, s.slabs.p, s.d_status);
     DX_TRY(hipGetLastError());
     DX_TRY(hipEventRecord(s.ev[4], A));

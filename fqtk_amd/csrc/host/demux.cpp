@@ -406,6 +406,39 @@ struct PinnedRaw : RawBuffer {
 };
 struct RawChunk { PinnedRaw *buf = nullptr; size_t n = 0, bytes = 0; std::string error; };
 
+// A second pair of hands for one memcpy: a large plain input is copied into page-locked memory by two threads at once
+// (one thread moves ~10 GB/s out of the page cache; the two 150-base files of a run need twice that to keep the device fed).
+class CopyHelper {
+  public:
+    CopyHelper() : th_([this] { run(); }) {}
+    ~CopyHelper() { { std::lock_guard<std::mutex> lk(mu_); stop_ = true; } cv_.notify_all(); th_.join(); }
+    void start(char *dst, const char *src, size_t n) {
+        { std::lock_guard<std::mutex> lk(mu_); dst_ = dst; src_ = src; n_ = n; busy_ = true; }
+        cv_.notify_all();
+    }
+    void wait() { std::unique_lock<std::mutex> lk(mu_); cv_.wait(lk, [&] { return !busy_; }); }
+  private:
+    void run() {
+        for (;;) {
+            std::unique_lock<std::mutex> lk(mu_);
+            cv_.wait(lk, [&] { return stop_ || busy_; });
+            if (stop_) return;
+            lk.unlock();
+            std::memcpy(dst_, src_, n_);
+            lk.lock();
+            busy_ = false;
+            cv_.notify_all();
+        }
+    }
+    std::mutex mu_;
+    std::condition_variable cv_;
+    char *dst_ = nullptr;
+    const char *src_ = nullptr;
+    size_t n_ = 0;
+    bool busy_ = false, stop_ = false;
+    std::thread th_;
+};
+
 void write_all(int fd, const uint8_t *p, size_t n, const std::string &path) {
     while (n) {
         const ssize_t w = ::write(fd, p, n);
@@ -479,7 +512,55 @@ bool gpu_output_supported(const Plan &plan, std::string *why) {
         }
     }
     std::vector<std::thread> readers;
-    for (size_t i = 0; i < n_inputs; ++i)
+    // A large plain (mapped) input: one thread only COUNTS newlines to cut the chunks, a second one copies every cut into
+    // page-locked memory together with a helper, while the next cut is being counted.  Everything else (small files,
+    // gzip / BGZF / pipes): one thread that decodes, counts and copies (FastqSource::next_raw).
+    std::vector<std::unique_ptr<BoundedQueue<std::pair<FastqSource::RawCut, std::string>>>> cuts(n_inputs);
+    std::vector<std::unique_ptr<CopyHelper>> helpers(n_inputs);
+    const bool split_ok = usable_cpus() >= 12 && !env_on("FQTK_NO_SPLIT_READERS");
+    for (size_t i = 0; i < n_inputs; ++i) {
+        if (split_ok && sources[i]->mapped() && sources[i]->mapped_size() >= (1ull << 30)) {
+            cuts[i] = std::make_unique<BoundedQueue<std::pair<FastqSource::RawCut, std::string>>>(2);
+            helpers[i] = std::make_unique<CopyHelper>();
+            readers.emplace_back([&, i] {   // the cutter
+                for (;;) {
+                    std::pair<FastqSource::RawCut, std::string> c;
+                    const uint64_t t0 = tick();
+                    const bool ok = sources[i]->next_cut(std::min<size_t>(chunk, 1u << 22), &c.first, &c.second);
+                    g_times.reader_parse += tick() - t0;
+                    if (!ok && c.second.empty()) c.second = "read failed";
+                    const bool last = !ok || c.first.n_records == 0;
+                    cuts[i]->push(std::move(c));
+                    if (last) return;
+                }
+            });
+            readers.emplace_back([&, i] {   // the copier
+                for (;;) {
+                    auto c = cuts[i]->pop();
+                    RawChunk out;
+                    out.error = c.second;
+                    out.n = c.first.n_records;
+                    out.bytes = c.first.bytes + (c.first.add_newline ? 1 : 0);
+                    const bool last = !out.error.empty() || out.n == 0;
+                    if (!last) {
+                        out.buf = free_bufs[i]->pop();
+                        const uint64_t t0 = tick();
+                        if (out.buf->cap < out.bytes + 1 && !out.buf->grow(out.bytes + out.bytes / 16 + 65536, 0)) die(std::string("cannot allocate page-locked memory: ") + fqtk_last_error());
+                        const size_t half = (c.first.bytes / 2) & ~(size_t)63;
+                        helpers[i]->start(out.buf->data + half, c.first.p + half, c.first.bytes - half);
+                        std::memcpy(out.buf->data, c.first.p, half);
+                        helpers[i]->wait();
+                        if (c.first.add_newline) out.buf->data[c.first.bytes] = '\n';
+                        g_times.reader_push += tick() - t0;   // (the copy: reported as "push")
+                    } else {
+                        out.buf = nullptr;
+                    }
+                    rq[i]->push(std::move(out));
+                    if (last) return;
+                }
+            });
+            continue;
+        }
         readers.emplace_back([&, i] {
             for (;;) {
                 RawChunk c;
@@ -500,6 +581,7 @@ bool gpu_output_supported(const Plan &plan, std::string *why) {
                 if (last) return;
             }
         });
+    }
 
     // ---- output files (demux.rs:674-688), raw descriptors: whole BGZF members are appended as they come back
     const size_t F = plan.files_per_sample, n_outs = (S + 1) * F;

@@ -450,4 +450,28 @@ int fqtk_host_chunk_schedule_check(uint64_t devices, uint64_t slots, uint64_t n_
     }
     return (next == n_chunks && done == n_chunks) ? 0 : 4;
 }
+
+// FastqSource::next_cut over a whole plain (mapped) file: the same contract as fqtk_host_read_raw, the text taken
+// from the cuts (+ the newline a cut asks for).  Returns the number of cuts, -1 on an error, -2 if the file is not mapped.
+int64_t fqtk_host_read_cuts(const char *path, uint64_t batch, char *out, size_t cap, size_t *out_len, uint64_t *counts, size_t max_calls,
+                            char *err, size_t errcap) {
+    FastqSource src;
+    std::string e;
+    if (!src.open(path, &e)) { put(e, err, errcap); return -1; }
+    if (!src.mapped()) return -2;
+    size_t w = 0, calls = 0;
+    for (;;) {
+        FastqSource::RawCut c;
+        if (!src.next_cut((size_t)batch, &c, &e, 1u << 20)) { put(e, err, errcap); return -1; }
+        if (c.n_records == 0) break;
+        const size_t bytes = c.bytes + (c.add_newline ? 1 : 0);
+        if (w + bytes > cap || calls >= max_calls) { put("test buffer too small", err, errcap); return -1; }
+        std::memcpy(out + w, c.p, c.bytes);
+        if (c.add_newline) out[w + c.bytes] = '\n';
+        w += bytes;
+        counts[calls++] = c.n_records;
+    }
+    *out_len = w;
+    return (int64_t)calls;
+}
 }  // extern "C"

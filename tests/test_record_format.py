@@ -90,8 +90,8 @@ def test_random_headers_agree_with_write_header():
     assert agree > 1000 and errors > 100
 
 
-def read_raw(path, batch):
-    fn = H.lib().fqtk_host_read_raw
+def read_raw(path, batch, cuts=False):
+    fn = H.lib().fqtk_host_read_cuts if cuts else H.lib().fqtk_host_read_raw
     fn.restype = C.c_int64
     cap = 64 << 20
     out = np.empty(cap, dtype=np.uint8)
@@ -135,6 +135,22 @@ def test_next_raw_cuts_every_kind_of_input_by_counting_lines(tmp_path, monkeypat
         read_raw(tmp_path / "e.fq", 1000)
     (tmp_path / "f.fq").write_bytes(b"")
     assert read_raw(tmp_path / "f.fq", 10) == (b"", [])
+
+
+def test_next_cut_hands_out_the_same_chunks_without_copying(tmp_path):
+    """A large plain input is cut by a thread that only counts newlines (FastqSource::next_cut) and copied by others."""
+    recs = [b"@r%d c\n%s\n+\n%s\n" % (i, b"ACGT" * (1 + i % 30), b"IIII" * (1 + i % 30)) for i in range(20_000)]
+    text = b"".join(recs)
+    for name, data in (("a.fq", text), ("b.fq", text[:-1]), ("c.fq", text + b"\n\r\n")):
+        p = tmp_path / name
+        p.write_bytes(data)
+        for batch in (1, 999, 20_000, 30_000):
+            if batch == 1 and name != "a.fq":
+                continue
+            assert read_raw(p, batch, cuts=True) == read_raw(p, batch) and read_raw(p, batch, cuts=True)[0] == text
+    (tmp_path / "d.fq").write_bytes(text + b"@cut\nAC\n")
+    with pytest.raises(ValueError, match="truncated record"):
+        read_raw(tmp_path / "d.fq", 1000, cuts=True)
 
 
 def test_count_newlines_every_alignment_and_length():
