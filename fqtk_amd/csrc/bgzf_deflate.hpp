@@ -109,6 +109,7 @@ struct Shared {
     uint32_t crc_pow_chunk[kLanes];
     uint32_t crc_pow_byte[kChunk + 1];
     uint32_t crc;                         // (the lanes' partial values wait in lane_bits, which is free that early)
+    uint32_t effort;                      // parse effort of the block (from --compression-level): 0 fast, 1 default
 };
 
 // ---- symbol arithmetic (RFC 1951 3.2.5), computed rather than tabulated -------------------------------------
@@ -343,6 +344,10 @@ FQTK_HD inline uint32_t ctz32(uint32_t x) {   // x != 0
 #endif
 }
 
+// --compression-level (demux.rs:641-643) -> parse effort: 1-3 two match candidates per position (output +1.0-1.6 %), 4 and
+// up three (the default is 5); level 0 does not come here (stored blocks).
+FQTK_HD inline uint32_t effort_of_level(uint32_t level) { return level <= 3u ? 0u : 1u; }
+
 // P0: clear the shared state, bring the block in.  `in` may be device or (pinned, device-visible) host memory.
 FQTK_HD inline void phase_load(Shared &S, int lane, const uint8_t *in, uint32_t n) {
     for (uint32_t i = (uint32_t)lane; i < (4u << kHashBits); i += kLanes) S.tminmax[i] = 0x0000FFFFu;   // min = none (0xFFFF), max = none (0)
@@ -476,14 +481,10 @@ __device__ unsigned long long g_lz_cycles[10];   // setup, candidate reads + lit
 #ifndef FQTK_BGZF_ABL
 #define FQTK_BGZF_ABL 0   // developer ablations of the LZ phase (tools/bgzf_phases.sh); 0 in the product
 #endif
-FQTK_HD inline bool lz_step(Shared &S, int lane, uint32_t n, uint32_t *tok, LzLane &st
-#if defined(FQTK_BGZF_PHASE_TIMES) && defined(__HIP_DEVICE_COMPILE__)
-                            , uint64_t (&lz_acc)[8], uint64_t &lz_t
-#endif
-) {
-    if (st.p >= st.end) return false;
-    const uint32_t p = st.p;
-    uint32_t mlen = 0, mdist = 0, msave = 0;
+// The best match at position p of this lane's slice: length, distance and the half-bits it saves (0 = none).  Enters p
+// into the lane's table of recent positions.  S.effort: 0 = two candidates, 1 = three (see below).
+FQTK_HD inline void lz_find(Shared &S, int lane, uint32_t n, uint32_t p, const LzLane &st, uint32_t &mlen, uint32_t &mdist, uint32_t &msave) {
+    mlen = mdist = msave = 0;
     if (p + 4 <= n) {
         const uint32_t w = buf_le32(S.buf, p);
         const uint32_t h = hash4(w);
@@ -500,13 +501,13 @@ FQTK_HD inline bool lz_step(Shared &S, int lane, uint32_t n, uint32_t *tok, LzLa
         cand[1] = own == 0xFFFFu ? 0u : own + 1u;
         cand[2] = p >= 16384u ? (S.tminmax[region_slot(p - 16384u, h)] >> 16) : 0u;
         S.near_tab[near_slot] = (uint16_t)p;
+        if (S.effort == 0) cand[2] = 0;   // --compression-level 1-3: without the previous region's latest occurrence (+1-2 % output)
 #ifdef FQTK_BGZF_DROP   // developer study (tools/bgzf_ratio.py): candidates switched off by bit mask
         for (int c = 0; c < kCands; ++c) if ((FQTK_BGZF_DROP >> c) & 1) cand[c] = 0;
 #endif
         uint32_t maxl = st.end - p < 258u ? st.end - p : 258u;       // a match never leaves the lane's slice
         if ((FQTK_BGZF_ABL & 8) && maxl > 8u) maxl = 8u;
-        FQTK_LZ_MARK(0);
-        // Which candidates start with the same four bytes: all five are read before any is looked at (one wave
+                // Which candidates start with the same four bytes: all five are read before any is looked at (one wave
         // per SIMD: every dependent LDS round trip is paid in full, so the reads go out together).
         uint32_t qpos[kCands], first[kCands], second[kCands];
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -532,12 +533,12 @@ FQTK_HD inline bool lz_step(Shared &S, int lane, uint32_t n, uint32_t *tok, LzLa
 #pragma unroll
 #endif
         for (int k = 0; k < 4; ++k) lit8[k + 5] = lit8[k + 4] + S.lit_cost[(w4 >> (8 * k)) & 255u];
-        FQTK_LZ_MARK(1);
         uint32_t full_dist_bits = 99;   // extra bits of the distance of a candidate that already ran to maxl
 #if defined(__HIP_DEVICE_COMPILE__)
 #pragma unroll
 #endif
         for (int c = 0; c < kCands; ++c) {
+            if (c == 2 && S.effort == 0) continue;   // (workgroup-uniform)
             const uint32_t q = qpos[c];
             if (q == p || first[c] != w) continue;
             {   // nothing is longer than maxl: against such a match only a cheaper distance could still win
@@ -578,6 +579,19 @@ FQTK_HD inline bool lz_step(Shared &S, int lane, uint32_t n, uint32_t *tok, LzLa
             }
         }
     }
+}
+
+FQTK_HD inline bool lz_step(Shared &S, int lane, uint32_t n, uint32_t *tok, LzLane &st
+#if defined(FQTK_BGZF_PHASE_TIMES) && defined(__HIP_DEVICE_COMPILE__)
+                            , uint64_t (&lz_acc)[8], uint64_t &lz_t
+#endif
+) {
+    if (st.p >= st.end) return false;
+    const uint32_t p = st.p;
+    uint32_t mlen, mdist, msave;
+    lz_find(S, lane, n, p, st, mlen, mdist, msave);
+    // (A lazy step -- take the literal when the next position holds a longer match that saves more, zlib's levels 4-9 -- was
+    //  measured on the CPU run of these phases: 0.0 % / -0.4 % of the output on varied / binned qualities.  Not kept.)
     FQTK_LZ_MARK(2);
     if (mlen) {
         uint32_t sym, ne, ev;

@@ -34,10 +34,9 @@ void deflate_kernel(const fqtk_bgzf_block *blocks, uint32_t n_blocks, const uint
 #endif
     if (n_blocks_dev) n_blocks = *n_blocks_dev;   // (the record pipeline learns the count on the device)
     if (blockIdx.x >= n_blocks) return;
-    if (crc_out) {
-        crc_tables(S, lane);
-        __syncthreads();
-    }
+    if (lane == 0) S.effort = effort_of_level(level);
+    if (crc_out) crc_tables(S, lane);
+    __syncthreads();
     for (uint32_t j = blockIdx.x; j < n_blocks; j += gridDim.x) {
         const uint8_t *in = blocks[j].in;
         uint8_t *out = blocks[j].out;

@@ -459,7 +459,16 @@ bool gpu_output_supported(const Plan &plan, std::string *why) {
 [[noreturn]] void run_gpu_output(const Options &opt, const Plan &plan, const std::vector<Sample> &samples,
                                  std::vector<std::unique_ptr<FastqSource>> &sources, bool skip_few) {
     const size_t n_inputs = plan.rs.size(), S = samples.size(), G = opt.devices.size();
-    const size_t chunk = std::max<unsigned long>(1, opt.chunk_given ? opt.chunk_reads : 262144ul);
+    size_t chunk = std::max<unsigned long>(1, opt.chunk_given ? opt.chunk_reads : 262144ul);
+    {   // a chunk's text must stay below 2 GiB per input (32-bit offsets on the device): long reads get smaller chunks
+        size_t per_record = 0;
+        for (auto &src : sources) per_record = std::max(per_record, src->estimate_raw_bytes(1024) / 1024);
+        const size_t fit = per_record ? std::max<size_t>(1, (768ull << 20) / per_record) : chunk;
+        if (fit < chunk) {
+            info("Records of about %zu bytes: %zu templates per chunk instead of %zu.", per_record, fit, chunk);
+            chunk = fit;
+        }
+    }
     const uint32_t L = (uint32_t)samples[0].barcode.size();
 
     // ---- devices: matcher + record pipeline each (their bring-up overlaps the first reads and the file creation)
@@ -890,7 +899,8 @@ int main(int argc, char **argv) {
         const std::string &in = opt.inputs[i_in];
         auto src = std::make_unique<FastqSource>();
         std::string err;
-        if (access(in.c_str(), F_OK) == 0 && !src->open(in, &err, 2, gz_threads[i_in])) problems.push_back("Error opening input files for reading: " + err);
+        // (BGZF inputs: the same share of the CPUs as helpers that inflate blocks side by side; unused for other kinds)
+        if (access(in.c_str(), F_OK) == 0 && !src->open(in, &err, std::max(2u, gz_threads[i_in]), gz_threads[i_in])) problems.push_back("Error opening input files for reading: " + err);
         sources.push_back(std::move(src));
     }
     if (opt.threads < 5) problems.push_back("Threads provided " + std::to_string(opt.threads) + " was too low! Must be 5 or more.");

@@ -292,11 +292,16 @@ int fqtk_host_huffman_lengths(const uint32_t *counts, int n, int max_bits, uint8
     return 0;
 }
 
+int64_t fqtk_host_bgzf_deflate_level(const uint8_t *in, uint32_t n, uint8_t *out, size_t cap, int *stored, int lockstep, int level);
 int64_t fqtk_host_bgzf_deflate_emulated(const uint8_t *in, uint32_t n, uint8_t *out, size_t cap, int *stored, int lockstep) {
+    return fqtk_host_bgzf_deflate_level(in, n, out, cap, stored, lockstep, 5);
+}
+int64_t fqtk_host_bgzf_deflate_level(const uint8_t *in, uint32_t n, uint8_t *out, size_t cap, int *stored, int lockstep, int level) {
     using namespace fqtk::bgzf;
-    if (n == 0 || n > kMaxIn || cap < kOutStride) return -1;
+    if (n == 0 || n > kMaxIn || cap < kOutStride || level < 1) return -1;
     std::vector<uint8_t> mem(sizeof(Shared));
     Shared &S = *reinterpret_cast<Shared *>(mem.data());
+    S.effort = effort_of_level((uint32_t)level);
     std::vector<uint32_t> tok(kTokensPerBlock);
     for (int l = 0; l < kLanes; ++l) phase_load(S, l, in, n);
     for (int l = 0; l < kLanes; ++l) phase_index(S, l, n);

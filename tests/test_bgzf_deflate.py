@@ -151,3 +151,33 @@ def test_block_with_a_very_deep_literal_tree_inflates():
     rng.shuffle(data)
     data = data.tobytes()[:65280]
     roundtrip(data)
+
+
+def test_fast_effort_of_low_compression_levels_round_trips_and_is_at_most_a_little_larger():
+    """--compression-level 1-3 parse with two match candidates per position instead of three (csrc/bgzf_deflate.hpp:
+    effort_of_level): the payload must inflate to the input and stay within a few per cent of the default's."""
+    import ctypes as C
+    import zlib
+    import numpy as np
+    from tests import hostlib as H
+    fn = H.lib().fqtk_host_bgzf_deflate_level
+    fn.restype = C.c_int64
+    rng = np.random.default_rng(21)
+    recs = []
+    for i in range(400):
+        recs.append(b"@A00123:45:HXXXXXXXX:1:1101:%d:%d 1:N:0:ACGTACGT+TTGCAATG\n%s\n+\n%s\n" % (
+            1000 + 7 * i, int(rng.integers(1000, 30000)), bytes(rng.choice(list(b"ACGT"), 150).astype(np.uint8)),
+            bytes(rng.choice(list(b"FFFFFFFF:,#"), 150).astype(np.uint8))))
+    text = b"".join(recs)
+    out = (C.c_uint8 * 70000)()
+    sizes = {}
+    for level in (1, 3, 4, 5, 9, 12):
+        tot = 0
+        for o in range(0, len(text) - 65280, 65280):
+            b = text[o:o + 65280]
+            n = fn(b, C.c_uint32(len(b)), out, C.c_size_t(70000), None, 0, level)
+            assert n > 0 and zlib.decompress(bytes(out[:n]), -15) == b
+            tot += n
+        sizes[level] = tot
+    assert sizes[1] == sizes[3] and sizes[4] == sizes[5] == sizes[9] == sizes[12]
+    assert sizes[5] <= sizes[1] <= sizes[5] * 1.04

@@ -369,6 +369,18 @@ def test_compression_level_zero_writes_stored_blocks(tmp_path, output_path):
     assert raw[18] & 7 == 1                                          # BFINAL = 1, BTYPE = 00: stored
 
 
+@pytest.mark.parametrize("level", [1, 9])
+def test_other_compression_levels_give_the_same_records(tmp_path, output_path, level):
+    """--compression-level (demux.rs:641-643): any level, the same records; on the device 1-3 parse faster, 4+ as the default."""
+    meta = H.metadata_file(tmp_path, FOUR)
+    reads = [FOUR[i % 4] + "ACGT" * 25 for i in range(4000)]
+    fq = H.fastq_file(tmp_path, "ex", "ex", reads)
+    out = tmp_path / "output"
+    _ok(H.run_demux([fq], ["17B100T"], meta, out, compression_level=level))
+    for s in range(4):
+        assert H.read_fastq(out / f"Sample000{s}.R1.fq.gz") == [(f"ex_{i} 1:N:0:" + FOUR[s], "ACGT" * 25, ";" * 100) for i in range(s, 4000, 4)]
+
+
 def test_two_hundred_million_templates_through_771_files(tmp_path, output_path):
     """The pipeline at the size of a real run: cfg 3's shape, 192 M templates (the first 1 M repeated; 149 GB of plain
     FASTQ on RAM-backed scratch), 771 output files.  The metrics file must carry 192 x the first block's per-sample
