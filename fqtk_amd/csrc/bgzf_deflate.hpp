@@ -391,6 +391,9 @@ FQTK_HD inline uint32_t region_slot(uint32_t p, uint32_t h) { return ((p >> 14) 
 FQTK_HD inline void phase_index(Shared &S, int lane, uint32_t n) {
     const uint32_t lo = (uint32_t)lane * kChunk;
     const uint32_t hi = lo + kChunk < n ? lo + kChunk : n;
+    // (the four bases are nearly half of FASTQ text and 64 lanes of a wave hammer their four counters -- yet counting them
+    //  in a packed register per lane and adding once per slice was SLOWER, 36.6 against 38.4 GB/s, tools/ab_bgzf.sh:
+    //  same-address LDS atomics are cheap, the extra selects are not)
     for (uint32_t p = lo; p < hi; ++p) FQTK_BGZF_ADD(&S.byte_cnt[buf_byte(S.buf, p)], 1u);
     for (uint32_t p = lo; p < hi && p + 4 <= n; ++p) {
         uint32_t *w = &S.tminmax[region_slot(p, hash4(buf_le32(S.buf, p)))];
@@ -458,11 +461,12 @@ FQTK_HD inline void near_insert_run(Shared &S, int lane, uint32_t n, uint32_t fr
 
 // P1b: greedy LZ77 over this lane's slice; tokens to tok[t * kLanes + lane].  Deterministic: reads the tables
 // of P1a and the lane's own state only.
-struct LzLane { uint32_t p, end, nt, avg16; };   // avg16: the block's average literal cost, half-bits x 16
+struct LzLane { uint32_t p, end, nt, avg16, effort; };   // avg16: the block's average literal cost, half-bits x 16
 FQTK_HD inline void lz_begin(Shared &S, int lane, uint32_t n, LzLane &st) {
     st.p = (uint32_t)lane * kChunk;
     st.end = st.p + kChunk < n ? st.p + kChunk : n;
     st.nt = 0;
+    st.effort = S.effort;
     st.avg16 = n ? (uint32_t)(((uint64_t)S.lit_total << 4) / n) : 0u;
     // the private table starts with the slice before this one (the neighbour's bytes, read-only here)
     static_assert(kChunk % 16 == 0, "history preload in runs of 16");
@@ -501,7 +505,7 @@ FQTK_HD inline void lz_find(Shared &S, int lane, uint32_t n, uint32_t p, const L
         cand[1] = own == 0xFFFFu ? 0u : own + 1u;
         cand[2] = p >= 16384u ? (S.tminmax[region_slot(p - 16384u, h)] >> 16) : 0u;
         S.near_tab[near_slot] = (uint16_t)p;
-        if (S.effort == 0) cand[2] = 0;   // --compression-level 1-3: without the previous region's latest occurrence (+1-2 % output)
+        if (st.effort == 0) cand[2] = 0;   // --compression-level 1-3: without the previous region's latest occurrence (+1-2 % output)
 #ifdef FQTK_BGZF_DROP   // developer study (tools/bgzf_ratio.py): candidates switched off by bit mask
         for (int c = 0; c < kCands; ++c) if ((FQTK_BGZF_DROP >> c) & 1) cand[c] = 0;
 #endif
@@ -538,7 +542,7 @@ FQTK_HD inline void lz_find(Shared &S, int lane, uint32_t n, uint32_t p, const L
 #pragma unroll
 #endif
         for (int c = 0; c < kCands; ++c) {
-            if (c == 2 && S.effort == 0) continue;   // (workgroup-uniform)
+            if (c == 2 && st.effort == 0) continue;   // (workgroup-uniform)
             const uint32_t q = qpos[c];
             if (q == p || first[c] != w) continue;
             {   // nothing is longer than maxl: against such a match only a cheaper distance could still win

@@ -83,13 +83,13 @@ void deflate_kernel(const fqtk_bgzf_block *blocks, uint32_t n_blocks, const uint
         __syncthreads();
         phase_cl_emit(S, lane);
         __syncthreads();
-        if (lane == 0) phase_cl_code(S);
-        __syncthreads();
-        phase_cl_bits(S, lane);
-        FQTK_PHASE_MARK(10);
-        phase_count_bits(S, lane, tok);
+        if (lane == 0) phase_cl_code(S);        // one lane builds the 19-symbol code ...
+        phase_count_bits(S, lane, tok);         // ... while all lanes add up the bits of their tokens (needs the two big codes only)
         __syncthreads();
         FQTK_PHASE_MARK(6);
+        phase_cl_bits(S, lane);
+        __syncthreads();
+        FQTK_PHASE_MARK(10);
         {   // exclusive prefix sum of the lanes' bit counts (phase_offsets is the one-lane form of the CPU tests)
             const uint32_t mine = S.lane_bits[lane];
             uint32_t incl = mine;
