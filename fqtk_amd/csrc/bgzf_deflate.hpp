@@ -27,6 +27,7 @@
 // in between) and under g++ for the CPU test-suite, which runs the SAME phase functions lane by lane through
 // libfqtk_host.so and inflates the result with zlib.
 #pragma once
+#include <stddef.h>
 #include <stdint.h>
 #include <string.h>
 
@@ -50,7 +51,8 @@ constexpr uint32_t kChunk = 65536 / kLanes;          // bytes parsed by one lane
 constexpr uint32_t kHashBits = 11;        // per region; 4 regions x 2048 entries x {min, max}
 constexpr uint32_t kNearSlots = 16384 / kLanes;       // per lane: direct-mapped table of its recent positions (local repeats)
 constexpr uint32_t kOutStride = 65536;    // bytes reserved per block in the output arena (stored worst case: n + 5)
-constexpr uint32_t kTokensPerBlock = kLanes * kChunk;   // token scratch, u32 each, [t][lane]
+constexpr uint32_t kMaxMatchesPerLane = kChunk / 4;     // kMinMatch bytes each at least
+constexpr uint32_t kTokensPerBlock = kLanes * kMaxMatchesPerLane;   // match scratch (global, L2-resident), u32 each, [m][lane]
 constexpr int kNumLitLen = 286, kNumDist = 30, kNumCl = 19;
 constexpr int kCands = 3;                 // match candidates looked at per position
 constexpr int kMinMatch = 4;              // shorter matches cost more bits than their literals on FASTQ
@@ -66,7 +68,8 @@ FQTK_HD inline uint32_t buf_byte(const uint32_t *words, uint32_t pos) { return (
 
 // Everything a block's workgroup shares.  LDS on the device (~141 KiB: one workgroup per CU), heap in the CPU tests.
 struct Shared {
-    uint32_t buf[kBufWords];              // P0-P1: the input bytes, skewed (buf_word).  P2-P5: the output bit stream, linear.
+    uint32_t buf[kBufWords];              // the input bytes, skewed (buf_word), from P0 to the end (literals are read from here)
+    // P0-P1: the two match tables.  P2-P5: the same 64 KiB, as one array, hold the output bit stream (out_image()).
     uint32_t tminmax[4u << kHashBits];      // per (region, hash): smallest position in the low half, largest in the high half
     uint16_t near_tab[kNearSlots * kLanes];  // [slot][lane]: every lane's private table of recent positions
     uint32_t byte_cnt[256];                  // P1a: how often each byte value occurs in the block
@@ -77,7 +80,7 @@ struct Shared {
     uint16_t code_ll[288], code_d[32];    // bit-reversed canonical codes (appended LSB first)
     uint8_t len_ll[288], len_d[32];
     uint32_t lane_bits[kLanes];           // bits of a lane's tokens, then their exclusive prefix sum
-    uint32_t ntok[kLanes];
+    uint32_t ntok[kLanes];                // matches of the lane's slice (the literals between them are not stored anywhere)
     uint32_t header_bits, total_bits, stored;
     // scratch of the code builders: the literal/length code and the distance code are built side by side by two lanes
     // (of different wavefronts), each with its own scratch; the code-length code reuses the first set afterwards
@@ -112,6 +115,14 @@ struct Shared {
     uint32_t effort;                      // parse effort of the block (from --compression-level): 0 fast, 1 default
 };
 
+// The output bit stream lives where the match tables were: they are dead once the LZ phase is over, and the input stays
+// intact to the end -- so a token stream need not be written out: a lane's tokens are its MATCHES (a few per slice, in a
+// small global scratch) and, between them, the bytes of its slice.  (Tokens used to go to a 64 MB global scratch, one dword
+// per token, written once and read twice: 9x the kernel's input in HBM traffic, rocprofv3 FETCH_SIZE / WRITE_SIZE.)
+static_assert(offsetof(Shared, near_tab) == offsetof(Shared, tminmax) + sizeof(uint32_t) * (4u << kHashBits), "the two tables are one 64 KiB array");
+static_assert(sizeof(uint32_t) * (4u << kHashBits) + sizeof(uint16_t) * kNearSlots * kLanes >= kOutStride, "the output image fits the tables' place");
+FQTK_HD inline uint32_t *out_image(Shared &S) { return S.tminmax; }
+
 // ---- symbol arithmetic (RFC 1951 3.2.5), computed rather than tabulated -------------------------------------
 FQTK_HD inline int floor_log2(uint32_t x) { return 31 - __builtin_clz(x); }   // x >= 1
 // length 3..258 -> literal/length symbol 257..285, number of extra bits and their value
@@ -143,8 +154,9 @@ FQTK_HD inline uint32_t reverse_bits(uint32_t code, int len) {   // len >= 1
 #endif
 }
 
-// token: literal = the byte; match = bit 31 | (len - 3) << 16 | (dist - 1)
-FQTK_HD inline uint32_t match_token(uint32_t len, uint32_t dist) { return 0x80000000u | ((len - 3) << 16) | (dist - 1); }
+// a match of a lane: offset of its first byte in the lane's slice << 24 | (len - 3) << 16 | (dist - 1)
+FQTK_HD inline uint32_t match_token(uint32_t len, uint32_t dist, uint32_t slice_off) { return (slice_off << 24) | ((len - 3) << 16) | (dist - 1); }
+static_assert(kChunk <= 256, "a match's offset in its slice has 8 bits");
 
 // ---- append bits to the output image -------------------------------------------------------------------------
 // The image is zero before P2; several lanes may touch one word, so words are ORed in (atomic on the device).
@@ -603,7 +615,8 @@ FQTK_HD inline bool lz_step(Shared &S, int lane, uint32_t n, uint32_t *tok, LzLa
         FQTK_BGZF_ADD(&S.freq_ll[sym], 1u);
         dist_symbol(mdist, sym, ne, ev);
         FQTK_BGZF_ADD(&S.freq_d[sym], 1u);
-        if (!(FQTK_BGZF_ABL & 2)) tok[st.nt * kLanes + (uint32_t)lane] = match_token(mlen, mdist);
+        if (!(FQTK_BGZF_ABL & 2)) tok[st.nt * kLanes + (uint32_t)lane] = match_token(mlen, mdist, p - (uint32_t)lane * kChunk);
+        ++st.nt;
         FQTK_LZ_MARK(5);
         // the positions skipped are recent history too: the first sixteen and the last eight of them (a long
         // match is a run or a copied line; its middle adds nothing the ends do not).  Each group is read as one
@@ -621,11 +634,9 @@ FQTK_HD inline bool lz_step(Shared &S, int lane, uint32_t n, uint32_t *tok, LzLa
     } else {
         const uint32_t lit = buf_byte(S.buf, p);
         if (!(FQTK_BGZF_ABL & 1)) FQTK_BGZF_ADD(&S.freq_ll[lit], 1u);
-        if (!(FQTK_BGZF_ABL & 2)) tok[st.nt * kLanes + (uint32_t)lane] = lit;
         st.p = p + 1;
         FQTK_LZ_MARK(7);
     }
-    ++st.nt;
     FQTK_LZ_MARK(3);
     return true;
 }
@@ -653,7 +664,8 @@ FQTK_HD inline void phase_lz(Shared &S, int lane, uint32_t n, uint32_t *tok) {
 // ... and the used literal/length symbols are put in order for the code builder: every lane ranks one symbol
 // among all of them (a one-lane insertion sort of ~80 symbols was a fifth of the kernel's time).
 FQTK_HD inline void phase_clear_out(Shared &S, int lane) {
-    for (uint32_t i = (uint32_t)lane; i < kOutStride / 4; i += kLanes) S.buf[i] = 0;
+    uint32_t *image = out_image(S);
+    for (uint32_t i = (uint32_t)lane; i < kOutStride / 4; i += kLanes) image[i] = 0;
     for (uint32_t i = (uint32_t)lane; i < 288; i += kLanes) S.len_ll[i] = 0;
     if (lane < 32) S.len_d[lane] = 0;
     if (lane < kNumCl) S.freq_cl[lane] = 0;
@@ -759,7 +771,7 @@ FQTK_HD inline void phase_cl_code(Shared &S) {
     int hclen = kNumCl;
     while (hclen > 4 && S.len_cl[order[hclen - 1]] == 0) --hclen;
     BitWriter w;
-    w.start(S.buf, 0);
+    w.start(out_image(S), 0);
     w.put(1, 1);                        // BFINAL
     w.put(2, 2);                        // BTYPE = dynamic Huffman
     w.put(S.hlit - 257u, 5);
@@ -781,7 +793,7 @@ FQTK_HD inline void phase_cl_bits(Shared &S, int lane) {
         for (uint32_t j = 0; j < k; ++j) pos += cl_symbol_bits(S, j);
         const uint32_t s = S.cl_sym[k];
         BitWriter w;
-        w.start(S.buf, pos);
+        w.start(out_image(S), pos);
         w.put(S.code_cl[s], S.len_cl[s]);
         if (s == 16) w.put(S.cl_extra[k], 2);
         else if (s == 17) w.put(S.cl_extra[k], 3);
@@ -791,22 +803,42 @@ FQTK_HD inline void phase_cl_bits(Shared &S, int lane) {
     }
 }
 
-// P3a (all lanes): bits this lane's tokens will take
-FQTK_HD inline void phase_count_bits(Shared &S, int lane, const uint32_t *tok) {
-    uint32_t bits = 0;
-    const uint32_t nt = S.ntok[lane];
-    for (uint32_t t = 0; t < nt; ++t) {
-        const uint32_t k = tok[t * kLanes + (uint32_t)lane];
-        if (k & 0x80000000u) {
-            uint32_t sym, ne, ev;
-            length_symbol(((k >> 16) & 0xFFu) + 3, sym, ne, ev);
-            bits += S.len_ll[sym] + ne;
-            dist_symbol((k & 0x7FFFu) + 1, sym, ne, ev);
-            bits += S.len_d[sym] + ne;
+// A lane's tokens in order: the matches of its slice (global scratch, [m][lane]) and the literal bytes between them.
+// visit(literal byte) / visit(len, dist).
+template <typename OnLit, typename OnMatch>
+FQTK_HD inline void walk_tokens(Shared &S, int lane, uint32_t n, const uint32_t *tok, OnLit on_lit, OnMatch on_match) {
+    const uint32_t lo = (uint32_t)lane * kChunk;
+    const uint32_t hi = lo + kChunk < n ? lo + kChunk : n;
+    const uint32_t nm = S.ntok[lane];
+    uint32_t m = 0, next = nm ? tok[(uint32_t)lane] : 0u;
+    uint32_t next_pos = nm ? lo + (next >> 24) : 0xFFFFFFFFu;
+    for (uint32_t p = lo; p < hi;) {
+        if (p == next_pos) {
+            const uint32_t len = ((next >> 16) & 0xFFu) + 3u;
+            on_match(len, (next & 0x7FFFu) + 1u);
+            p += len;
+            ++m;
+            next = m < nm ? tok[m * kLanes + (uint32_t)lane] : 0u;
+            next_pos = m < nm ? lo + (next >> 24) : 0xFFFFFFFFu;
         } else {
-            bits += S.len_ll[k];
+            on_lit(buf_byte(S.buf, p));
+            ++p;
         }
     }
+}
+
+// P3a (all lanes): bits this lane's tokens will take
+FQTK_HD inline void phase_count_bits(Shared &S, int lane, uint32_t n, const uint32_t *tok) {
+    uint32_t bits = 0;
+    walk_tokens(S, lane, n, tok,
+                [&](uint32_t lit) { bits += S.len_ll[lit]; },
+                [&](uint32_t len, uint32_t dist) {
+                    uint32_t sym, ne, ev;
+                    length_symbol(len, sym, ne, ev);
+                    bits += S.len_ll[sym] + ne;
+                    dist_symbol(dist, sym, ne, ev);
+                    bits += S.len_d[sym] + ne;
+                });
     S.lane_bits[lane] = bits;
 }
 // P3b (one lane): exclusive prefix sum, total size, stored-block decision
@@ -818,29 +850,25 @@ FQTK_HD inline void phase_offsets(Shared &S, uint32_t n) {
 }
 
 // P4 (all lanes): the tokens' bits; lane 0 also appends the end-of-block code
-FQTK_HD inline void phase_emit(Shared &S, int lane, const uint32_t *tok) {
+FQTK_HD inline void phase_emit(Shared &S, int lane, uint32_t n, const uint32_t *tok) {
     if (S.stored) return;
     BitWriter w;
-    w.start(S.buf, S.lane_bits[lane]);
-    const uint32_t nt = S.ntok[lane];
-    for (uint32_t t = 0; t < nt; ++t) {
-        const uint32_t k = tok[t * kLanes + (uint32_t)lane];
-        if (k & 0x80000000u) {
-            uint32_t sym, ne, ev;
-            length_symbol(((k >> 16) & 0xFFu) + 3, sym, ne, ev);
-            w.put(S.code_ll[sym], S.len_ll[sym]);
-            if (ne) w.put(ev, ne);
-            dist_symbol((k & 0x7FFFu) + 1, sym, ne, ev);
-            w.put(S.code_d[sym], S.len_d[sym]);
-            if (ne) w.put(ev, ne);
-        } else {
-            w.put(S.code_ll[k], S.len_ll[k]);
-        }
-    }
+    w.start(out_image(S), S.lane_bits[lane]);
+    walk_tokens(S, lane, n, tok,
+                [&](uint32_t lit) { w.put(S.code_ll[lit], S.len_ll[lit]); },
+                [&](uint32_t len, uint32_t dist) {
+                    uint32_t sym, ne, ev;
+                    length_symbol(len, sym, ne, ev);
+                    w.put(S.code_ll[sym], S.len_ll[sym]);
+                    if (ne) w.put(ev, ne);
+                    dist_symbol(dist, sym, ne, ev);
+                    w.put(S.code_d[sym], S.len_d[sym]);
+                    if (ne) w.put(ev, ne);
+                });
     w.finish();
     if (lane == 0) {
         BitWriter e;
-        e.start(S.buf, S.total_bits - S.len_ll[256]);
+        e.start(out_image(S), S.total_bits - S.len_ll[256]);
         e.put(S.code_ll[256], S.len_ll[256]);
         e.finish();
     }
@@ -860,7 +888,8 @@ FQTK_HD inline uint32_t phase_store(Shared &S, int lane, const uint8_t *in, uint
     const uint32_t bytes = (S.total_bits + 7) >> 3;
     const uint32_t words = (bytes + 3) >> 2;              // out is 4-byte aligned and kOutStride long
     uint32_t *o = reinterpret_cast<uint32_t *>(out);
-    for (uint32_t i = (uint32_t)lane; i < words; i += kLanes) o[i] = S.buf[i];
+    const uint32_t *image = out_image(S);
+    for (uint32_t i = (uint32_t)lane; i < words; i += kLanes) o[i] = image[i];
     return bytes;
 }
 

@@ -393,7 +393,7 @@ __global__ __launch_bounds__(256) void k_column_scan(uint32_t *tile_tot, uint32_
 
 // One workgroup: what every file closes in this chunk, where its blocks go, and the per-sample counts.
 __global__ __launch_bounds__(1024) void k_layout(DevConfig C, const uint32_t *chunk_tot, FileState *fs, FileChunk *fc,
-                                                 unsigned long long *counts, uint32_t flush, ChunkStatus *st) {
+                                                 unsigned long long *counts, uint32_t flush, uint32_t max_blocks, ChunkStatus *st) {
     __shared__ uint32_t sh_a[1024], sh_b[1024];
     __shared__ uint32_t carry_a, carry_b;
     const uint32_t cps = C.n_files + 1u, n_cols = (C.n_samples + 1u) * C.n_files;
@@ -444,6 +444,9 @@ __global__ __launch_bounds__(1024) void k_layout(DevConfig C, const uint32_t *ch
         __syncthreads();
     }
     if (threadIdx.x == 0) {
+        // (the host sized the slabs and descriptors for max_blocks: more than that cannot be -- its bound covers every byte
+        //  a record can hold -- but nothing downstream may run past the buffers if it ever were)
+        if (carry_a > max_blocks) { report(st, 0, 4, 0, FQTK_DEMUX_ERR_LINES); carry_a = 0; }
         st->n_blocks = carry_a;
         FileChunk end;   // sentinel: fc[n_cols].blk_base = number of blocks
         end.rem = end.nb = end.n_emit = end.slab_base = end.par = end.new_rem = end.pad = 0;

@@ -84,7 +84,7 @@ void deflate_kernel(const fqtk_bgzf_block *blocks, uint32_t n_blocks, const uint
         phase_cl_emit(S, lane);
         __syncthreads();
         if (lane == 0) phase_cl_code(S);        // one lane builds the 19-symbol code ...
-        phase_count_bits(S, lane, tok);         // ... while all lanes add up the bits of their tokens (needs the two big codes only)
+        phase_count_bits(S, lane, n, tok);      // ... while all lanes add up the bits of their tokens (needs the two big codes only)
         __syncthreads();
         FQTK_PHASE_MARK(6);
         phase_cl_bits(S, lane);
@@ -109,7 +109,7 @@ void deflate_kernel(const fqtk_bgzf_block *blocks, uint32_t n_blocks, const uint
         }
         __syncthreads();
         FQTK_PHASE_MARK(7);
-        phase_emit(S, lane, tok);
+        phase_emit(S, lane, n, tok);
         __syncthreads();
         FQTK_PHASE_MARK(8);
         const uint32_t bytes = phase_store(S, lane, in, n, out);

@@ -182,7 +182,7 @@ int fill_result(fqtk_demuxer *d, Slot &s, fqtk_demux_result *res) {
         if (((st.err_key >> 20) & 15u) == 3u) { res->error_detail = (uint32_t)res->error; res->error = FQTK_DEMUX_ERR_HEADER; }
         return FQTK_OK;
     }
-    if (st.n_blocks > s.max_blocks) return set_error(FQTK_EINVAL, "internal error: more blocks than the chunk's bound");
+    if (st.err_key == kNoError && st.n_blocks > s.max_blocks) return set_error(FQTK_EINVAL, "internal error: more blocks than the chunk's bound");
     int rc;
     if ((rc = s.h_packed.ensure((size_t)st.total_bytes + 16)) != FQTK_OK) return rc;
     DX_TRY(hipEventRecord(s.ev_d2h0, d->s_out));
@@ -327,7 +327,8 @@ int fqtk_demuxer_submit(fqtk_demuxer *d, int slot, const uint8_t *const *text, c
     int rc;
     // bound of the chunk's output: every file gets the first input's header, all barcode segments and its own
     // segment's bases and qualities (all of them parts of the text), plus a few bytes per record
-    const uint64_t out_bound = (uint64_t)C.n_files * (sum_text + 32ull * n) + seg_text;
+    // (per record: '@', ' ', up to 10 digits, ':', "N:0:" or a tail byte, the separators of the barcode segments, 5 line bytes)
+    const uint64_t out_bound = (uint64_t)C.n_files * (sum_text + (32ull + C.n_b + C.n_m) * n) + seg_text;
     const size_t max_blocks = (size_t)(out_bound / kBlock) + (size_t)d->n_cols + 2;
     if ((rc = ensure_blocks(s, max_blocks)) != FQTK_OK) return rc;
     TextSet T;
@@ -402,7 +403,7 @@ int fqtk_demuxer_submit(fqtk_demuxer *d, int slot, const uint8_t *const *text, c
     DX_TRY(hipGetLastError());
     hipLaunchKernelGGL(k_column_scan, dim3((d->cols + 255u) / 256u), dim3(256), 0, A, s.tile_tot.p, n_tiles, d->cols, s.chunk_tot.p);
     DX_TRY(hipGetLastError());
-    hipLaunchKernelGGL(k_layout, dim3(1), dim3(1024), 0, A, C, s.chunk_tot.p, d->d_fs, s.fc.p, d->d_counts, d->carry ? 0u : 1u, s.d_status);
+    hipLaunchKernelGGL(k_layout, dim3(1), dim3(1024), 0, A, C, s.chunk_tot.p, d->d_fs, s.fc.p, d->d_counts, d->carry ? 0u : 1u, (uint32_t)max_blocks, s.d_status);
     DX_TRY(hipGetLastError());
     hipLaunchKernelGGL(k_descs, dim3((uint32_t)((max_blocks + 255) / 256)), dim3(256), 0, A, C, s.fc.p, d->d_persist, s.slabs.p, s.out_slabs.p, s.desc.p, s.blk_file.p, s.d_status);
     DX_TRY(hipGetLastError());
@@ -474,7 +475,7 @@ int fqtk_demuxer_flush(fqtk_demuxer *d, fqtk_demux_result *res) {
     init.matcher_err = kNoError;
     *s.h_status = init;
     DX_TRY(hipMemcpyAsync(s.d_status, s.h_status, sizeof init, hipMemcpyHostToDevice, A));
-    hipLaunchKernelGGL(k_layout, dim3(1), dim3(1024), 0, A, d->C, (const uint32_t *)nullptr, d->d_fs, s.fc.p, d->d_counts, 1u, s.d_status);
+    hipLaunchKernelGGL(k_layout, dim3(1), dim3(1024), 0, A, d->C, (const uint32_t *)nullptr, d->d_fs, s.fc.p, d->d_counts, 1u, (uint32_t)s.max_blocks, s.d_status);
     DX_TRY(hipGetLastError());
     hipLaunchKernelGGL(k_descs, dim3((uint32_t)((max_blocks + 255) / 256)), dim3(256), 0, A, d->C, s.fc.p, d->d_persist, s.slabs.p, s.out_slabs.p, s.desc.p, s.blk_file.p, s.d_status);
     DX_TRY(hipGetLastError());

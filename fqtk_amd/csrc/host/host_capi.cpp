@@ -323,9 +323,9 @@ int64_t fqtk_host_bgzf_deflate_level(const uint8_t *in, uint32_t n, uint8_t *out
     for (int l = 0; l < kLanes; ++l) phase_cl_emit(S, l);
     phase_cl_code(S);
     for (int l = 0; l < kLanes; ++l) phase_cl_bits(S, l);
-    for (int l = 0; l < kLanes; ++l) phase_count_bits(S, l, tok.data());
+    for (int l = 0; l < kLanes; ++l) phase_count_bits(S, l, n, tok.data());
     phase_offsets(S, n);
-    for (int l = 0; l < kLanes; ++l) phase_emit(S, l, tok.data());
+    for (int l = 0; l < kLanes; ++l) phase_emit(S, l, n, tok.data());
     uint32_t bytes = 0;
     for (int l = 0; l < kLanes; ++l) bytes = phase_store(S, l, in, n, out);
     if (stored) *stored = (int)S.stored;
