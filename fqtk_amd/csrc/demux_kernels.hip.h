@@ -500,21 +500,33 @@ __host__ __device__ inline size_t format_wave_bytes(uint32_t n_inputs) { return 
 struct GatherSink {
     const TextSet &T;
     uint32_t run = 0;          // bytes of the record offered so far (wave-uniform)
+    uint64_t plit = 0;         // literal bytes not offered yet (wave-uniform): runs of literals go out eight at a time,
+    uint32_t nlit = 0;         // one round of compares per run instead of one per byte
     uint32_t pos[8];           // this lane's byte positions in the record (0xFFFFFFFF: none)
     const uint8_t *src[8];     // where each comes from (nullptr: a literal, in val)
     uint32_t val[8];
     __device__ explicit GatherSink(const TextSet &t) : T(t) {}
-    __device__ void lit(uint8_t b) {
+    __device__ void flush() {
+        if (!nlit) return;
 #pragma unroll
-        for (int j = 0; j < 8; ++j)
-            if (pos[j] == run) { src[j] = nullptr; val[j] = b; }
-        ++run;
+        for (int j = 0; j < 8; ++j) {
+            const uint32_t k = pos[j] - run;   // (positions before the run wrap around to huge values)
+            if (k < nlit) { src[j] = nullptr; val[j] = (uint32_t)(plit >> (8u * k)) & 0xFFu; }
+        }
+        run += nlit;
+        plit = 0;
+        nlit = 0;
+    }
+    __device__ void lit(uint8_t b) {
+        plit |= (uint64_t)b << (8u * nlit);
+        if (++nlit == 8u) flush();
     }
     __device__ void span(uint32_t input, uint32_t off, uint32_t len) {
+        flush();
         const uint8_t *base = T.text[input] + off;
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-            const uint32_t k = pos[j] - run;   // (positions before the piece wrap around to huge values)
+            const uint32_t k = pos[j] - run;
             if (k < len) src[j] = base + k;
         }
         run += len;
@@ -616,6 +628,7 @@ __global__ __launch_bounds__(64 * kFormatWaves) void k_format(TextSet T, DevConf
                 }
                 fmt::emit_record(sink, h, head_off, fsg.read_num, W.b, C.n_b, W.m, C.n_m,
                                  fmt::Span{fsg.input, r.seq_off + lo, hi - lo}, fmt::Span{fsg.input, r.qual_off + lo, hi - lo});
+                sink.flush();
                 uint32_t byte[8];
 #pragma unroll
                 for (int j = 0; j < 8; ++j) byte[j] = sink.src[j] ? (uint32_t)*sink.src[j] : sink.val[j];   // all loads, then ...
