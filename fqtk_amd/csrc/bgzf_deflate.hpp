@@ -408,7 +408,8 @@ FQTK_HD inline void phase_index(Shared &S, int lane, uint32_t n) {
     //  same-address LDS atomics are cheap, the extra selects are not)
     for (uint32_t p = lo; p < hi; ++p) FQTK_BGZF_ADD(&S.byte_cnt[buf_byte(S.buf, p)], 1u);
     for (uint32_t p = lo; p < hi && p + 4 <= n; ++p) {
-        uint32_t *w = &S.tminmax[region_slot(p, hash4(buf_le32(S.buf, p)))];
+        const uint32_t x = buf_le32(S.buf, p);
+        uint32_t *w = &S.tminmax[region_slot(p, hash4(x))];
         uint32_t old = *w;
         for (;;) {
             const uint32_t mn = (old & 0xFFFFu) < p ? (old & 0xFFFFu) : p;
@@ -452,6 +453,13 @@ FQTK_HD inline uint32_t match_cost(uint32_t len, uint32_t dist) {   // half-bits
 
 // Positions from .. from + count - 1 (count <= 16) go into the lane's private table: read as one run of words,
 // hashed from registers.
+#ifndef FQTK_BGZF_INS_HEAD
+#define FQTK_BGZF_INS_HEAD 4    // positions behind a match's first byte that enter the lane's table ...
+#endif
+#ifndef FQTK_BGZF_INS_TAIL
+#define FQTK_BGZF_INS_TAIL 4    // ... and before its end (tools/ab_bgzf.sh, tools/bgzf_ratio.py: 16 + 8 gave the same output, 5 % slower)
+#endif
+template <int MAXK = 16>
 FQTK_HD inline void near_insert_run(Shared &S, int lane, uint32_t n, uint32_t from, uint32_t count) {
     uint32_t v[6];
     const uint32_t i0 = from >> 2, sh = from & 3u;
@@ -463,7 +471,7 @@ FQTK_HD inline void near_insert_run(Shared &S, int lane, uint32_t n, uint32_t fr
 #if defined(__HIP_DEVICE_COMPILE__)
 #pragma unroll
 #endif
-    for (uint32_t k = 0; k < 16; ++k) {
+    for (uint32_t k = 0; k < (uint32_t)MAXK; ++k) {
         const uint32_t lo = v[k >> 2], hi = v[(k >> 2) + 1];
         const uint32_t x = (k & 3u) ? (lo >> (8 * (k & 3u))) | (hi << (32 - 8 * (k & 3u))) : lo;
         if (k < count && from + k + 4 <= n)   // (no break: the loop must unroll for v[] to stay in registers)
@@ -482,8 +490,12 @@ FQTK_HD inline void lz_begin(Shared &S, int lane, uint32_t n, LzLane &st) {
     st.avg16 = n ? (uint32_t)(((uint64_t)S.lit_total << 4) / n) : 0u;
     // the private table starts with the slice before this one (the neighbour's bytes, read-only here)
     static_assert(kChunk % 16 == 0, "history preload in runs of 16");
+#ifndef FQTK_BGZF_PRELOAD
+#define FQTK_BGZF_PRELOAD kChunk
+#endif
+    constexpr uint32_t kPreload = FQTK_BGZF_PRELOAD;
     if (st.p >= kChunk)
-        for (uint32_t q = st.p - kChunk; q < st.p; q += 16) near_insert_run(S, lane, n, q, 16);
+        for (uint32_t q = st.p - kPreload; q < st.p; q += 16) near_insert_run(S, lane, n, q, 16);
 }
 // one token; false when the slice is done
 #if defined(FQTK_BGZF_PHASE_TIMES) && defined(__HIPCC__)
@@ -549,7 +561,6 @@ FQTK_HD inline void lz_find(Shared &S, int lane, uint32_t n, uint32_t p, const L
 #pragma unroll
 #endif
         for (int k = 0; k < 4; ++k) lit8[k + 5] = lit8[k + 4] + S.lit_cost[(w4 >> (8 * k)) & 255u];
-        uint32_t full_dist_bits = 99;   // extra bits of the distance of a candidate that already ran to maxl
 #if defined(__HIP_DEVICE_COMPILE__)
 #pragma unroll
 #endif
@@ -557,11 +568,6 @@ FQTK_HD inline void lz_find(Shared &S, int lane, uint32_t n, uint32_t p, const L
             if (c == 2 && st.effort == 0) continue;   // (workgroup-uniform)
             const uint32_t q = qpos[c];
             if (q == p || first[c] != w) continue;
-            {   // nothing is longer than maxl: against such a match only a cheaper distance could still win
-                uint32_t dsym, dne, dev;
-                dist_symbol(p - q, dsym, dne, dev);
-                if (dne >= full_dist_bits) continue;
-            }
             // Bytes 4-7 were fetched with the first four (no loop, no further round trip): in sequence lines nearly every
             // position finds an earlier copy of its four bases and nearly none of them runs to eight, so the loop below
             // -- sixteen bytes per round, the eight word pairs independent reads -- is left to the matches that do.
@@ -588,11 +594,6 @@ FQTK_HD inline void lz_find(Shared &S, int lane, uint32_t n, uint32_t p, const L
             const uint32_t lit = l == 4 ? lit8[4] : (l == 5 ? lit8[5] : (l == 6 ? lit8[6] : (l == 7 ? lit8[7] : lit8[8] + (((l - 8) * st.avg16) >> 4))));
             const uint32_t cost = match_cost(l, p - q);
             if (lit > cost && lit - cost > msave) { msave = lit - cost; mlen = l; mdist = p - q; }
-            if (l == maxl) {
-                uint32_t dsym, dne, dev;
-                dist_symbol(p - q, dsym, dne, dev);
-                if (dne < full_dist_bits) full_dist_bits = dne;
-            }
         }
     }
 }
@@ -618,15 +619,16 @@ FQTK_HD inline bool lz_step(Shared &S, int lane, uint32_t n, uint32_t *tok, LzLa
         if (!(FQTK_BGZF_ABL & 2)) tok[st.nt * kLanes + (uint32_t)lane] = match_token(mlen, mdist, p - (uint32_t)lane * kChunk);
         ++st.nt;
         FQTK_LZ_MARK(5);
-        // the positions skipped are recent history too: the first sixteen and the last eight of them (a long
+        // the positions skipped are recent history too: the first four and the last four of them (a long
         // match is a run or a copied line; its middle adds nothing the ends do not).  Each group is read as one
         // run of words and hashed from registers.
         if (mlen > 1 && !(FQTK_BGZF_ABL & 4)) {
             const uint32_t skipped = mlen - 1;           // positions p + 1 .. p + mlen - 1
-            near_insert_run(S, lane, n, p + 1, skipped < 16u ? skipped : 16u);
-            if (skipped > 16u) {
-                const uint32_t tail = skipped - 16u < 8u ? skipped - 16u : 8u;
-                near_insert_run(S, lane, n, p + mlen - tail, tail);
+            constexpr uint32_t kHead = FQTK_BGZF_INS_HEAD, kTail = FQTK_BGZF_INS_TAIL;
+            near_insert_run<(int)kHead>(S, lane, n, p + 1, skipped < kHead ? skipped : kHead);
+            if (kTail && skipped > kHead) {
+                const uint32_t tail = skipped - kHead < kTail ? skipped - kHead : kTail;
+                near_insert_run<(int)(kTail ? kTail : 1)>(S, lane, n, p + mlen - tail, tail);
             }
         }
         st.p = p + mlen;

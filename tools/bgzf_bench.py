@@ -32,11 +32,12 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--blocks", type=int, default=4096)
     ap.add_argument("--reps", type=int, default=5)
+    ap.add_argument("--const-qual", action="store_true", help="every quality 'I' (scope E's synthetic records: long runs)")
     a = ap.parse_args()
     import torch
     lib = _lib.load()
     rng = np.random.default_rng(1)
-    text = fastq_text(4000, rng)
+    text = fastq_text(4000, rng, b"I") if a.const_qual else fastq_text(4000, rng)
     uniq = [text[o:o + 65280] for o in range(0, len(text) - 65280, 65280)]
     n = a.blocks
     host_in = np.zeros((n, 65536), dtype=np.uint8)
