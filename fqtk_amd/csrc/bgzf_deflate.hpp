@@ -48,7 +48,11 @@ namespace bgzf {
 constexpr int kLanes = FQTK_BGZF_LANES;
 constexpr uint32_t kMaxIn = 65280;        // uncompressed payload of a BGZF block (as the bgzf crate cuts them)
 constexpr uint32_t kChunk = 65536 / kLanes;          // bytes parsed by one lane: 1020 lanes x 64 = 65 280
-constexpr uint32_t kHashBits = 11;        // per region; 4 regions x 2048 entries x {min, max}
+#ifndef FQTK_BGZF_REGION_SHIFT
+#define FQTK_BGZF_REGION_SHIFT 11   // (tools/bgzf_ratio.py: 14 -> 11 takes 1.3 % off records with binned qualities, costs nothing)
+#endif
+constexpr uint32_t kRegionShift = FQTK_BGZF_REGION_SHIFT, kRegion = 1u << kRegionShift, kRegions = 65536u >> kRegionShift;
+constexpr uint32_t kHashBits = kRegionShift - 3;        // per region: 32 regions x 256 entries x {min, max} = 32 KiB
 constexpr uint32_t kNearSlots = 16384 / kLanes;       // per lane: direct-mapped table of its recent positions (local repeats)
 constexpr uint32_t kOutStride = 65536;    // bytes reserved per block in the output arena (stored worst case: n + 5)
 constexpr uint32_t kMaxMatchesPerLane = kChunk / 4;     // kMinMatch bytes each at least
@@ -66,11 +70,11 @@ FQTK_HD inline uint32_t buf_word(uint32_t w) { return w + (w >> 4); }
 // one byte of the (skewed) input block
 FQTK_HD inline uint32_t buf_byte(const uint32_t *words, uint32_t pos) { return (words[buf_word(pos >> 2)] >> (8 * (pos & 3u))) & 0xFFu; }
 
-// Everything a block's workgroup shares.  LDS on the device (~141 KiB: one workgroup per CU), heap in the CPU tests.
+// Everything a block's workgroup shares.  LDS on the device (158 KiB of the CU's 160: one workgroup per CU), heap in the CPU tests.
 struct Shared {
     uint32_t buf[kBufWords];              // the input bytes, skewed (buf_word), from P0 to the end (literals are read from here)
     // P0-P1: the two match tables.  P2-P5: the same 64 KiB, as one array, hold the output bit stream (out_image()).
-    uint32_t tminmax[4u << kHashBits];      // per (region, hash): smallest position in the low half, largest in the high half
+    uint32_t tminmax[kRegions << kHashBits];      // per (region, hash): smallest position in the low half, largest in the high half
     uint16_t near_tab[kNearSlots * kLanes];  // [slot][lane]: every lane's private table of recent positions
     uint32_t byte_cnt[256];                  // P1a: how often each byte value occurs in the block
     uint8_t lit_cost[256];                   // estimated cost of a literal, in half-bits (from byte_cnt)
@@ -80,7 +84,8 @@ struct Shared {
     uint16_t code_ll[288], code_d[32];    // bit-reversed canonical codes (appended LSB first)
     uint8_t len_ll[288], len_d[32];
     uint32_t lane_bits[kLanes];           // bits of a lane's tokens, then their exclusive prefix sum
-    uint32_t ntok[kLanes];                // matches of the lane's slice (the literals between them are not stored anywhere)
+    uint16_t ntok[kLanes];                // matches of the lane's slice (the literals between them are not stored anywhere); << 8: the first that counts
+    uint32_t span[kLanes];                // P1b: where the lane's last match ends; from P1c: the bytes the lane codes, [low half, high half)
     uint32_t header_bits, total_bits, stored;
     // scratch of the code builders: the literal/length code and the distance code are built side by side by two lanes
     // (of different wavefronts), each with its own scratch; the code-length code reuses the first set afterwards
@@ -119,8 +124,9 @@ struct Shared {
 // intact to the end -- so a token stream need not be written out: a lane's tokens are its MATCHES (a few per slice, in a
 // small global scratch) and, between them, the bytes of its slice.  (Tokens used to go to a 64 MB global scratch, one dword
 // per token, written once and read twice: 9x the kernel's input in HBM traffic, rocprofv3 FETCH_SIZE / WRITE_SIZE.)
-static_assert(offsetof(Shared, near_tab) == offsetof(Shared, tminmax) + sizeof(uint32_t) * (4u << kHashBits), "the two tables are one 64 KiB array");
-static_assert(sizeof(uint32_t) * (4u << kHashBits) + sizeof(uint16_t) * kNearSlots * kLanes >= kOutStride, "the output image fits the tables' place");
+static_assert(offsetof(Shared, near_tab) == offsetof(Shared, tminmax) + sizeof(uint32_t) * (kRegions << kHashBits), "the two tables are one 64 KiB array");
+static_assert(sizeof(uint32_t) * (kRegions << kHashBits) + sizeof(uint16_t) * kNearSlots * kLanes >= kOutStride, "the output image fits the tables' place");
+static_assert(sizeof(Shared) <= 160 * 1024, "one workgroup's LDS");
 FQTK_HD inline uint32_t *out_image(Shared &S) { return S.tminmax; }
 
 // ---- symbol arithmetic (RFC 1951 3.2.5), computed rather than tabulated -------------------------------------
@@ -154,9 +160,15 @@ FQTK_HD inline uint32_t reverse_bits(uint32_t code, int len) {   // len >= 1
 #endif
 }
 
-// a match of a lane: offset of its first byte in the lane's slice << 24 | (len - 3) << 16 | (dist - 1)
-FQTK_HD inline uint32_t match_token(uint32_t len, uint32_t dist, uint32_t slice_off) { return (slice_off << 24) | ((len - 3) << 16) | (dist - 1); }
-static_assert(kChunk <= 256, "a match's offset in its slice has 8 bits");
+// a match of a lane: offset of its first byte from the start of the lane's slice (9 bits: low eight << 24, ninth << 15)
+// | (len - 3) << 16 | (dist - 1).  The offset passes the slice's end when the match was cut at its front (phase_reach).
+FQTK_HD inline uint32_t match_token(uint32_t len, uint32_t dist, uint32_t slice_off) {
+    return ((slice_off & 0xFFu) << 24) | ((slice_off >> 8) << 15) | ((len - 3) << 16) | (dist - 1);
+}
+FQTK_HD inline uint32_t token_off(uint32_t t) { return (t >> 24) | ((t >> 7) & 0x100u); }
+FQTK_HD inline uint32_t token_len(uint32_t t) { return ((t >> 16) & 0xFFu) + 3u; }
+FQTK_HD inline uint32_t token_dist(uint32_t t) { return (t & 0x7FFFu) + 1u; }
+static_assert(kChunk + 258 <= 512, "a match's offset from its slice's start has 9 bits");
 
 // ---- append bits to the output image -------------------------------------------------------------------------
 // The image is zero before P2; several lanes may touch one word, so words are ORed in (atomic on the device).
@@ -335,6 +347,7 @@ FQTK_HD inline uint32_t load_le32(const uint8_t *p) {
     return (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((uint32_t)p[3] << 24);
 }
 FQTK_HD inline uint32_t hash4(uint32_t x) { return (x * 2654435761u) >> (32 - kHashBits); }
+FQTK_HD inline uint32_t near_of(uint32_t h) { return (h >> (kHashBits - 6)) & (kNearSlots - 1u); }
 // Four bytes at any byte offset of the block buffer.  Device: two aligned LDS words and one v_alignbyte_b32
 // instead of four byte reads (the word after the last payload byte exists: the buffer is 64 KiB, a block 65 280 B).
 FQTK_HD inline uint32_t buf_le32(const uint32_t *words, uint32_t pos) {
@@ -344,6 +357,23 @@ FQTK_HD inline uint32_t buf_le32(const uint32_t *words, uint32_t pos) {
 #else
     const uint64_t two = (uint64_t)words[buf_word(w)] | ((uint64_t)words[buf_word(w + 1)] << 32);
     return (uint32_t)(two >> (8 * (pos & 3u)));
+#endif
+}
+// NW dwords from byte `pos` on: NW + 1 aligned words and a funnel shift each (two reads per dword the buf_le32 way; the LZ
+// phase is bound by LDS reads whose banks collide -- the lanes stand at unrelated offsets of their slices)
+template <int NW>
+FQTK_HD inline void buf_run(const uint32_t *words, uint32_t pos, uint32_t (&out)[NW]) {
+    const uint32_t w = pos >> 2, sh = pos & 3u;
+    uint32_t a[NW + 1];
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+    for (int i = 0; i <= NW; ++i) a[i] = words[buf_word(w + (uint32_t)i)];
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+    for (int i = 0; i < NW; ++i) out[i] = __builtin_amdgcn_alignbyte(a[i + 1], a[i], sh);
+#else
+    for (int i = 0; i < NW; ++i) out[i] = (uint32_t)(((uint64_t)a[i] | ((uint64_t)a[i + 1] << 32)) >> (8 * sh));
 #endif
 }
 FQTK_HD inline uint32_t ctz32(uint32_t x) {   // x != 0
@@ -362,7 +392,7 @@ FQTK_HD inline uint32_t effort_of_level(uint32_t level) { return level <= 3u ? 0
 
 // P0: clear the shared state, bring the block in.  `in` may be device or (pinned, device-visible) host memory.
 FQTK_HD inline void phase_load(Shared &S, int lane, const uint8_t *in, uint32_t n) {
-    for (uint32_t i = (uint32_t)lane; i < (4u << kHashBits); i += kLanes) S.tminmax[i] = 0x0000FFFFu;   // min = none (0xFFFF), max = none (0)
+    for (uint32_t i = (uint32_t)lane; i < (kRegions << kHashBits); i += kLanes) S.tminmax[i] = 0x0000FFFFu;   // min = none (0xFFFF), max = none (0)
     for (uint32_t i = 0; i < kNearSlots; ++i) S.near_tab[i * kLanes + (uint32_t)lane] = 0xFFFFu;
     for (uint32_t i = (uint32_t)lane; i < 288; i += kLanes) S.freq_ll[i] = 0;
     if (lane < 32) S.freq_d[lane] = 0;
@@ -399,26 +429,43 @@ FQTK_HD inline void phase_load(Shared &S, int lane, const uint8_t *in, uint32_t 
 // P1a: every position of this lane's slice into the (region, hash) table.  One word holds the smallest position
 // (low half, 0xFFFF = none) and the largest position + 1 (high half, 0 = none) of its bucket; min and max are
 // order-independent, so the table -- and with it the whole output -- does not depend on how the lanes interleave.
-FQTK_HD inline uint32_t region_slot(uint32_t p, uint32_t h) { return ((p >> 14) << kHashBits) | h; }
+FQTK_HD inline uint32_t region_slot(uint32_t p, uint32_t h) { return ((p >> kRegionShift) << kHashBits) | h; }
 FQTK_HD inline void phase_index(Shared &S, int lane, uint32_t n) {
     const uint32_t lo = (uint32_t)lane * kChunk;
     const uint32_t hi = lo + kChunk < n ? lo + kChunk : n;
     // (the four bases are nearly half of FASTQ text and 64 lanes of a wave hammer their four counters -- yet counting them
     //  in a packed register per lane and adding once per slice was SLOWER, 36.6 against 38.4 GB/s, tools/ab_bgzf.sh:
     //  same-address LDS atomics are cheap, the extra selects are not)
-    for (uint32_t p = lo; p < hi; ++p) FQTK_BGZF_ADD(&S.byte_cnt[buf_byte(S.buf, p)], 1u);
-    for (uint32_t p = lo; p < hi && p + 4 <= n; ++p) {
-        const uint32_t x = buf_le32(S.buf, p);
-        uint32_t *w = &S.tminmax[region_slot(p, hash4(x))];
-        uint32_t old = *w;
-        for (;;) {
-            const uint32_t mn = (old & 0xFFFFu) < p ? (old & 0xFFFFu) : p;
-            const uint32_t mx = (old >> 16) > p + 1 ? (old >> 16) : p + 1;
-            const uint32_t want = (mx << 16) | mn;
-            if (want == old) break;
-            const uint32_t seen = FQTK_BGZF_CAS(w, old, want);
-            if (seen == old) break;
-            old = seen;
+    // the slice is read once, a run of five aligned words per sixteen positions (it begins on a word: no shifts by a variable);
+    // a read per byte and two per position made this phase wait for LDS like the LZ phase does
+    for (uint32_t g = lo; g < hi; g += 16u) {
+        uint32_t v[5];
+        const uint32_t w0 = g >> 2;
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+        for (int i = 0; i < 5; ++i) v[i] = S.buf[buf_word(w0 + (uint32_t)i)];
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+        for (uint32_t k = 0; k < 16u; ++k) {
+            const uint32_t p = g + k;
+            const uint32_t lo32 = v[k >> 2], hi32 = v[(k >> 2) + 1];
+            const uint32_t x = (k & 3u) ? (lo32 >> (8 * (k & 3u))) | (hi32 << (32 - 8 * (k & 3u))) : lo32;
+            if (p < hi) FQTK_BGZF_ADD(&S.byte_cnt[x & 0xFFu], 1u);
+            if (p < hi && p + 4 <= n) {
+                uint32_t *w = &S.tminmax[region_slot(p, hash4(x))];
+                uint32_t old = *w;
+                for (;;) {
+                    const uint32_t mn = (old & 0xFFFFu) < p ? (old & 0xFFFFu) : p;
+                    const uint32_t mx = (old >> 16) > p + 1 ? (old >> 16) : p + 1;
+                    const uint32_t want = (mx << 16) | mn;
+                    if (want == old) break;
+                    const uint32_t seen = FQTK_BGZF_CAS(w, old, want);
+                    if (seen == old) break;
+                    old = seen;
+                }
+            }
         }
     }
 }
@@ -438,7 +485,10 @@ FQTK_HD inline void phase_literal_costs(Shared &S, int lane, uint32_t n) {   // 
     if (c) {
         const uint32_t a = log2_halfbits(n), b = log2_halfbits(c);
         cost = a > b ? a - b : 0u;
-        if (cost < 2u) cost = 2u;
+#ifndef FQTK_BGZF_MINLIT
+#define FQTK_BGZF_MINLIT 4u   // two bits: the frequent quality value of binned records shares the short codes with the four bases (2u: +3 % output)
+#endif
+        if (cost < FQTK_BGZF_MINLIT) cost = FQTK_BGZF_MINLIT;
         if (cost > 30u) cost = 30u;
     }
     S.lit_cost[lane] = (uint8_t)cost;
@@ -475,7 +525,7 @@ FQTK_HD inline void near_insert_run(Shared &S, int lane, uint32_t n, uint32_t fr
         const uint32_t lo = v[k >> 2], hi = v[(k >> 2) + 1];
         const uint32_t x = (k & 3u) ? (lo >> (8 * (k & 3u))) | (hi << (32 - 8 * (k & 3u))) : lo;
         if (k < count && from + k + 4 <= n)   // (no break: the loop must unroll for v[] to stay in registers)
-            S.near_tab[((hash4(x) >> 5) & (kNearSlots - 1u)) * kLanes + (uint32_t)lane] = (uint16_t)(from + k);
+            S.near_tab[(near_of(hash4(x))) * kLanes + (uint32_t)lane] = (uint16_t)(from + k);
     }
 }
 
@@ -511,12 +561,16 @@ __device__ unsigned long long g_lz_cycles[10];   // setup, candidate reads + lit
 #endif
 // The best match at position p of this lane's slice: length, distance and the half-bits it saves (0 = none).  Enters p
 // into the lane's table of recent positions.  S.effort: 0 = two candidates, 1 = three (see below).
-FQTK_HD inline void lz_find(Shared &S, int lane, uint32_t n, uint32_t p, const LzLane &st, uint32_t &mlen, uint32_t &mdist, uint32_t &msave) {
+FQTK_HD inline void lz_find(Shared &S, int lane, uint32_t n, uint32_t p, const LzLane &st, uint32_t &mlen, uint32_t &mdist, uint32_t &msave, uint32_t &byte0) {
     mlen = mdist = msave = 0;
+    if (p + 4 > n) byte0 = buf_byte(S.buf, p);
     if (p + 4 <= n) {
-        const uint32_t w = buf_le32(S.buf, p);
+        uint32_t here[2];
+        buf_run<2>(S.buf, p, here);
+        const uint32_t w = here[0], w4 = here[1];
+        byte0 = w & 0xFFu;
         const uint32_t h = hash4(w);
-        const uint32_t near_slot = ((h >> 5) & (kNearSlots - 1u)) * kLanes + (uint32_t)lane;
+        const uint32_t near_slot = near_of(h) * kLanes + (uint32_t)lane;
         const uint32_t own = S.tminmax[region_slot(p, h)] & 0xFFFFu;
         // Three candidates (position + 1; 0 = none).  Three more were tried and dropped (tools/bgzf_ratio.py): the
         // previous match's distance and distance 1 bought nothing -- the lane's own table already holds the position
@@ -527,13 +581,18 @@ FQTK_HD inline void lz_find(Shared &S, int lane, uint32_t n, uint32_t p, const L
         uint32_t cand[kCands];
         cand[0] = (uint32_t)S.near_tab[near_slot] + 1u;                    // 0xFFFF + 1 = 0x10000: fails q < p below
         cand[1] = own == 0xFFFFu ? 0u : own + 1u;
-        cand[2] = p >= 16384u ? (S.tminmax[region_slot(p - 16384u, h)] >> 16) : 0u;
+        cand[2] = p >= kRegion ? (S.tminmax[region_slot(p - kRegion, h)] >> 16) : 0u;
         S.near_tab[near_slot] = (uint16_t)p;
-        if (st.effort == 0) cand[2] = 0;   // --compression-level 1-3: without the previous region's latest occurrence (+1-2 % output)
 #ifdef FQTK_BGZF_DROP   // developer study (tools/bgzf_ratio.py): candidates switched off by bit mask
         for (int c = 0; c < kCands; ++c) if ((FQTK_BGZF_DROP >> c) & 1) cand[c] = 0;
 #endif
-        uint32_t maxl = st.end - p < 258u ? st.end - p : 258u;       // a match never leaves the lane's slice
+#ifdef FQTK_BGZF_NO_REACH   // (study: matches cut at the slice's end, as before phase_reach existed)
+        uint32_t maxl = st.end - p < 258u ? st.end - p : 258u;
+#else
+        // a match may run past the end of the lane's slice: phase_reach (--compression-level 1-3: it may not; 7 % faster)
+        uint32_t maxl = st.effort ? n - p : st.end - p;
+        maxl = maxl < 258u ? maxl : 258u;
+#endif
         if ((FQTK_BGZF_ABL & 8) && maxl > 8u) maxl = 8u;
                 // Which candidates start with the same four bytes: all five are read before any is looked at (one wave
         // per SIMD: every dependent LDS round trip is paid in full, so the reads go out together).
@@ -545,12 +604,13 @@ FQTK_HD inline void lz_find(Shared &S, int lane, uint32_t n, uint32_t p, const L
             const uint32_t q = cand[c] - 1u;                               // 0xFFFFFFFF for "none"
             const bool in_reach = cand[c] != 0u && q < p && p - q <= 32768u;
             qpos[c] = in_reach ? q : p;                                    // p itself: reads fine, never accepted
-            first[c] = buf_le32(S.buf, qpos[c]);
-            second[c] = buf_le32(S.buf, qpos[c] + 4u);
+            uint32_t there[2];
+            buf_run<2>(S.buf, qpos[c], there);
+            first[c] = there[0];
+            second[c] = there[1];
         }
         // what the bytes cost as literals: exactly for the first eight, the block's average beyond (every long
         // match pays for itself many times over; the estimate only ranks long candidates among themselves)
-        const uint32_t w4 = buf_le32(S.buf, p + 4);
         uint32_t lit8[9];
         lit8[0] = 0;
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -565,7 +625,6 @@ FQTK_HD inline void lz_find(Shared &S, int lane, uint32_t n, uint32_t p, const L
 #pragma unroll
 #endif
         for (int c = 0; c < kCands; ++c) {
-            if (c == 2 && st.effort == 0) continue;   // (workgroup-uniform)
             const uint32_t q = qpos[c];
             if (q == p || first[c] != w) continue;
             // Bytes 4-7 were fetched with the first four (no loop, no further round trip): in sequence lines nearly every
@@ -578,10 +637,10 @@ FQTK_HD inline void lz_find(Shared &S, int lane, uint32_t n, uint32_t p, const L
             } else {
                 l = 8;
                 while (l < maxl) {
-                    const uint32_t x0 = buf_le32(S.buf, q + l) ^ buf_le32(S.buf, p + l);
-                    const uint32_t x1 = buf_le32(S.buf, q + l + 4) ^ buf_le32(S.buf, p + l + 4);
-                    const uint32_t x2 = buf_le32(S.buf, q + l + 8) ^ buf_le32(S.buf, p + l + 8);
-                    const uint32_t x3 = buf_le32(S.buf, q + l + 12) ^ buf_le32(S.buf, p + l + 12);
+                    uint32_t a[4], b[4];
+                    buf_run<4>(S.buf, q + l, a);
+                    buf_run<4>(S.buf, p + l, b);
+                    const uint32_t x0 = a[0] ^ b[0], x1 = a[1] ^ b[1], x2 = a[2] ^ b[2], x3 = a[3] ^ b[3];
                     if (x0 | x1 | x2 | x3) {
                         l += x0 ? ctz32(x0) >> 3 : (x1 ? 4 + (ctz32(x1) >> 3) : (x2 ? 8 + (ctz32(x2) >> 3) : 12 + (ctz32(x3) >> 3)));
                         break;
@@ -605,8 +664,8 @@ FQTK_HD inline bool lz_step(Shared &S, int lane, uint32_t n, uint32_t *tok, LzLa
 ) {
     if (st.p >= st.end) return false;
     const uint32_t p = st.p;
-    uint32_t mlen, mdist, msave;
-    lz_find(S, lane, n, p, st, mlen, mdist, msave);
+    uint32_t mlen, mdist, msave, lit;
+    lz_find(S, lane, n, p, st, mlen, mdist, msave, lit);
     // (A lazy step -- take the literal when the next position holds a longer match that saves more, zlib's levels 4-9 -- was
     //  measured on the CPU run of these phases: 0.0 % / -0.4 % of the output on varied / binned qualities.  Not kept.)
     FQTK_LZ_MARK(2);
@@ -634,13 +693,16 @@ FQTK_HD inline bool lz_step(Shared &S, int lane, uint32_t n, uint32_t *tok, LzLa
         st.p = p + mlen;
         FQTK_LZ_MARK(6);
     } else {
-        const uint32_t lit = buf_byte(S.buf, p);
         if (!(FQTK_BGZF_ABL & 1)) FQTK_BGZF_ADD(&S.freq_ll[lit], 1u);
         st.p = p + 1;
         FQTK_LZ_MARK(7);
     }
     FQTK_LZ_MARK(3);
     return true;
+}
+FQTK_HD inline void lz_end(Shared &S, int lane, const LzLane &st) {
+    S.ntok[lane] = (uint16_t)st.nt;
+    S.span[lane] = st.p;   // >= the slice's end when the last match ran on (a lane without bytes: its slice's start)
 }
 FQTK_HD inline void phase_lz(Shared &S, int lane, uint32_t n, uint32_t *tok) {
     LzLane st;
@@ -659,7 +721,64 @@ FQTK_HD inline void phase_lz(Shared &S, int lane, uint32_t n, uint32_t *tok) {
     lz_begin(S, lane, n, st);
     while (lz_step(S, lane, n, tok, st)) {}
 #endif
-    S.ntok[lane] = st.nt;
+    lz_end(S, lane, st);
+}
+
+// P1c (all lanes): who codes which bytes.  Every lane parsed its whole slice from the slice's first byte on, and the last
+// match of a slice was allowed to run on into the next ones (cutting every match at a 64-byte boundary cost 2-4 % of the
+// output: a header line, a run of equal qualities became two or three matches).  So a lane's bytes begin where the
+// matches of the lanes before it end -- the largest of at most five values, a match being at most 258 bytes long -- and
+// what its own parse said about the bytes before that point is taken back: literals and whole matches leave the
+// symbol counts, a match that straddles the point is cut at its front (shorter than three bytes: its rest become
+// literals).  Nothing is parsed again, and no lane waits for another: the ends are those of the first parse, which
+// stay valid however a match is cut at its front.
+constexpr int kReachLanes = (int)((257u + kChunk - 1u) / kChunk);
+FQTK_HD inline void count_match(Shared &S, uint32_t len, uint32_t dist, uint32_t by) {
+    uint32_t sym, ne, ev;
+    length_symbol(len, sym, ne, ev);
+    FQTK_BGZF_ADD(&S.freq_ll[sym], by);
+    dist_symbol(dist, sym, ne, ev);
+    FQTK_BGZF_ADD(&S.freq_d[sym], by);
+}
+FQTK_HD inline void phase_reach(Shared &S, int lane, uint32_t *tok, uint32_t *span_out) {
+    const uint32_t lo = (uint32_t)lane * kChunk;
+    const uint32_t reach = S.span[lane];
+    uint32_t start = lo;
+    for (int i = 1; i <= kReachLanes; ++i)
+        if (lane >= i) { const uint32_t r = S.span[lane - i]; start = r > start ? r : start; }
+    const uint32_t nm = S.ntok[lane];
+    uint32_t first = 0;
+    if (start > lo) {
+        const uint32_t stop = start < reach ? start : reach;
+        uint32_t m = 0, next = nm ? tok[(uint32_t)lane] : 0u;
+        uint32_t next_pos = nm ? lo + token_off(next) : 0xFFFFFFFFu;
+        for (uint32_t p = lo; p < stop;) {
+            if (p == next_pos) {
+                const uint32_t len = token_len(next), dist = token_dist(next);
+                count_match(S, len, dist, 0xFFFFFFFFu);   // - 1
+                first = m + 1;
+                if (p + len > start) {   // (then start < reach: this lane keeps the match's rest)
+                    const uint32_t rest = p + len - start;
+                    if (rest >= 3u) {
+                        tok[m * kLanes + (uint32_t)lane] = match_token(rest, dist, start - lo);
+                        count_match(S, rest, dist, 1u);
+                        first = m;
+                    } else {
+                        for (uint32_t k = 0; k < rest; ++k) FQTK_BGZF_ADD(&S.freq_ll[buf_byte(S.buf, start + k)], 1u);
+                    }
+                }
+                p += len;
+                ++m;
+                next = m < nm ? tok[m * kLanes + (uint32_t)lane] : 0u;
+                next_pos = m < nm ? lo + token_off(next) : 0xFFFFFFFFu;
+            } else {
+                FQTK_BGZF_ADD(&S.freq_ll[buf_byte(S.buf, p)], 0xFFFFFFFFu);
+                ++p;
+            }
+        }
+    }
+    *span_out = (start < reach ? start : reach) | (reach << 16);   // (nothing left: an empty range)
+    S.ntok[lane] = (uint16_t)(nm | (first << 8));
 }
 
 // P2a (all lanes): the input copy is no longer needed: the same LDS becomes the (zeroed) output image
@@ -810,20 +929,23 @@ FQTK_HD inline void phase_cl_bits(Shared &S, int lane) {
 template <typename OnLit, typename OnMatch>
 FQTK_HD inline void walk_tokens(Shared &S, int lane, uint32_t n, const uint32_t *tok, OnLit on_lit, OnMatch on_match) {
     const uint32_t lo = (uint32_t)lane * kChunk;
-    const uint32_t hi = lo + kChunk < n ? lo + kChunk : n;
-    const uint32_t nm = S.ntok[lane];
-    uint32_t m = 0, next = nm ? tok[(uint32_t)lane] : 0u;
-    uint32_t next_pos = nm ? lo + (next >> 24) : 0xFFFFFFFFu;
-    for (uint32_t p = lo; p < hi;) {
+    const uint32_t span = S.span[lane], hi = span >> 16;
+    const uint32_t nm = S.ntok[lane] & 0xFFu;
+    uint32_t m = S.ntok[lane] >> 8, next = m < nm ? tok[m * kLanes + (uint32_t)lane] : 0u;
+    uint32_t next_pos = m < nm ? lo + token_off(next) : 0xFFFFFFFFu;
+    (void)n;
+    uint32_t have = 0xFFFFFFFFu, word = 0;
+    for (uint32_t p = span & 0xFFFFu; p < hi;) {
         if (p == next_pos) {
-            const uint32_t len = ((next >> 16) & 0xFFu) + 3u;
-            on_match(len, (next & 0x7FFFu) + 1u);
+            const uint32_t len = token_len(next);
+            on_match(len, token_dist(next));
             p += len;
             ++m;
             next = m < nm ? tok[m * kLanes + (uint32_t)lane] : 0u;
-            next_pos = m < nm ? lo + (next >> 24) : 0xFFFFFFFFu;
+            next_pos = m < nm ? lo + token_off(next) : 0xFFFFFFFFu;
         } else {
-            on_lit(buf_byte(S.buf, p));
+            if ((p >> 2) != have) { have = p >> 2; word = S.buf[buf_word(have)]; }   // one read per four literals
+            on_lit((word >> (8 * (p & 3u))) & 0xFFu);
             ++p;
         }
     }

@@ -70,6 +70,13 @@ void deflate_kernel(const fqtk_bgzf_block *blocks, uint32_t n_blocks, const uint
         FQTK_PHASE_MARK(2);
         phase_lz(S, lane, n, tok);
         __syncthreads();
+        {
+            uint32_t span;
+            phase_reach(S, lane, tok, &span);
+            __syncthreads();   // every lane has read its neighbours' ends
+            S.span[lane] = span;
+        }
+        __syncthreads();
         FQTK_PHASE_MARK(3);
         phase_clear_out(S, lane);
         __syncthreads();

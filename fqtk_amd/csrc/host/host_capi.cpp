@@ -313,9 +313,14 @@ int64_t fqtk_host_bgzf_deflate_level(const uint8_t *in, uint32_t n, uint8_t *out
             any = false;
             for (int l = 0; l < kLanes; ++l) any = lz_step(S, l, n, tok.data(), st[l]) || any;
         }
-        for (int l = 0; l < kLanes; ++l) S.ntok[l] = st[l].nt;
+        for (int l = 0; l < kLanes; ++l) lz_end(S, l, st[l]);
     } else
     for (int l = 0; l < kLanes; ++l) phase_lz(S, l, n, tok.data());
+    {   // (every lane reads its neighbours' ends before any span is replaced: a barrier on the device)
+        std::vector<uint32_t> span(kLanes);
+        for (int l = 0; l < kLanes; ++l) phase_reach(S, l, tok.data(), &span[l]);
+        for (int l = 0; l < kLanes; ++l) S.span[l] = span[l];
+    }
     for (int l = 0; l < kLanes; ++l) phase_clear_out(S, l);
     for (int l = 0; l < kLanes; ++l) phase_code_lengths(S, l);
     for (int l = 0; l < kLanes; ++l) phase_codes(S, l);

@@ -181,3 +181,33 @@ def test_fast_effort_of_low_compression_levels_round_trips_and_is_at_most_a_litt
         sizes[level] = tot
     assert sizes[1] == sizes[3] and sizes[4] == sizes[5] == sizes[9] == sizes[12]
     assert sizes[5] <= sizes[1] <= sizes[5] * 1.04
+
+
+def test_matches_that_run_past_their_slice_and_the_lanes_they_cover():
+    """bgzf_deflate.hpp phase_reach: the last match of a 64-byte slice runs on (up to 258 bytes: five slices), the lanes
+    behind it start where it ends -- whole slices covered, matches cut at their front, rests of one or two bytes."""
+    rng = np.random.default_rng(11)
+    cases = [b"A" * MAX_IN, b"A" * 700, b"AB" * 3000, b"ABC" * 1000 + b"x" + b"ABC" * 1000]
+    # runs of every length around the slice and the match maximum, at every phase of the 64-byte grid
+    for run in (60, 63, 64, 65, 66, 67, 127, 128, 129, 256, 257, 258, 259, 260, 261, 262, 320, 515, 516, 517, 518):
+        for lead in (0, 1, 2, 3, 61, 62, 63):
+            filler = bytes(rng.integers(33, 127, 200, dtype=np.uint8))
+            cases.append(filler[:lead] + b"Q" * run + filler + b"Q" * run + filler[:77] + b"Q" * (run + 3))
+    # a repeated line of every length: matches at distance = line length straddle the grid at every offset
+    for line_len in (5, 37, 63, 64, 65, 100, 193, 257, 258, 259, 300):
+        line = bytes(rng.integers(65, 91, line_len - 1, dtype=np.uint8)) + b"\n"
+        cases.append(line * (4000 // line_len))
+    # lines that differ in one or two bytes at random places: matches end and restart within a few bytes of each other
+    for _ in range(12):
+        line = bytearray(rng.integers(65, 91, int(rng.integers(40, 400)), dtype=np.uint8))
+        text = bytearray()
+        while len(text) < 20000:
+            for _k in range(int(rng.integers(1, 4))):
+                line[int(rng.integers(0, len(line)))] = int(rng.integers(65, 91))
+            text += line + b"\n"
+        cases.append(bytes(text))
+    for data in cases:
+        n, stored = roundtrip(data[:MAX_IN])
+        assert not stored
+    # and they do what they are for: a 150-byte run of one quality value is one match, not three (0.157 without them)
+    assert roundtrip(fastq_text(176, rng)[:MAX_IN])[0] / MAX_IN < 0.145

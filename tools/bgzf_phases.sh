@@ -10,7 +10,8 @@ sys.path.insert(0, ".")
 import runpy
 from fqtk_amd import _lib
 lib = _lib.load()
-sys.argv = ["bgzf_bench.py"]
+import os
+sys.argv = ["bgzf_bench.py"] + os.environ.get("BENCH_ARGS", "").split()
 runpy.run_path("tools/bgzf_bench.py", run_name="__main__")
 t = (C.c_ulonglong * 12)()
 assert lib.fqtk_bgzf_dev_phase_ticks(t) == 0
