@@ -229,12 +229,7 @@ __device__ __forceinline__ uint64_t defer_to_second_pass(const MatchParams &P, u
     }
     const uint32_t at = fill + (uint32_t)__popcll((unsigned long long)(flagged & ((1ull << __lane_id()) - 1ull)));
     const bool fits = mine && at < P.work_cap;
-#ifdef FQTK_DEFER_ABL   // developer study (tools/cliff_ablate.sh): 1 = mark the read, store nothing (listed reads come out wrong)
-    if (fits && FQTK_DEFER_ABL == 1) res = kMemoDeferred;
-    if (fits && FQTK_DEFER_ABL != 1) {
-#else
     if (fits) {
-#endif
         uint32_t *entry = P.work + ((uint64_t)seg * P.work_cap + at) * (1u + P.work_rw);
         entry[0] = (uint32_t)read_index;
         // the row goes along (wave-uniform count; the words are in registers already): as few store instructions as
