@@ -525,12 +525,26 @@ bool gpu_output_supported(const Plan &plan, std::string *why) {
     // page-locked memory together with a helper, while the next cut is being counted.  Everything else (small files,
     // gzip / BGZF / pipes): one thread that decodes, counts and copies (FastqSource::next_raw).
     std::vector<std::unique_ptr<BoundedQueue<std::pair<FastqSource::RawCut, std::string>>>> cuts(n_inputs);
-    std::vector<std::unique_ptr<CopyHelper>> helpers(n_inputs);
+    std::vector<std::vector<std::unique_ptr<CopyHelper>>> helpers(n_inputs);
     const bool split_ok = usable_cpus() >= 12 && !env_on("FQTK_NO_SPLIT_READERS");
+    // helpers per large input: one with --threads 16 (the fixed threads -- readers, writers, this one, the collector -- take 13
+    // of them on a four-file run), more when --threads and the machine leave room
+    size_t n_large = 0;
+    for (size_t i = 0; i < n_inputs; ++i) n_large += split_ok && sources[i]->mapped() && sources[i]->mapped_size() >= (1ull << 30);
+    size_t n_helpers = 1;
+    if (n_large) {
+        const size_t have = std::min<size_t>(opt.threads, usable_cpus()), fixed = n_inputs + 2 * n_large + 4 + 3;
+        n_helpers = std::min<size_t>(3, std::max<size_t>(1, have > fixed ? (have - fixed) / n_large : 1));
+    }
+    // ... and a second thread that counts newlines for the cutter (of the fixed threads the writers, the collector and the
+    // unmapper mostly wait)
+    const bool count_assist = n_large && std::min<size_t>(opt.threads, usable_cpus()) >= 16 && !env_on("FQTK_NO_COUNT_ASSISTANT");
+    if (const char *e = std::getenv("FQTK_COPY_HELPERS")) n_helpers = std::min<size_t>(8, std::max<size_t>(1, (size_t)std::atoi(e)));
     for (size_t i = 0; i < n_inputs; ++i) {
         if (split_ok && sources[i]->mapped() && sources[i]->mapped_size() >= (1ull << 30)) {
             cuts[i] = std::make_unique<BoundedQueue<std::pair<FastqSource::RawCut, std::string>>>(2);
-            helpers[i] = std::make_unique<CopyHelper>();
+            for (size_t h = 0; h < n_helpers; ++h) helpers[i].push_back(std::make_unique<CopyHelper>());
+            if (count_assist) sources[i]->attach_count_assistant();
             readers.emplace_back([&, i] {   // the cutter
                 for (;;) {
                     std::pair<FastqSource::RawCut, std::string> c;
@@ -555,10 +569,13 @@ bool gpu_output_supported(const Plan &plan, std::string *why) {
                         out.buf = free_bufs[i]->pop();
                         const uint64_t t0 = tick();
                         if (out.buf->cap < out.bytes + 1 && !out.buf->grow(out.bytes + out.bytes / 16 + 65536, 0)) die(std::string("cannot allocate page-locked memory: ") + fqtk_last_error());
-                        const size_t half = (c.first.bytes / 2) & ~(size_t)63;
-                        helpers[i]->start(out.buf->data + half, c.first.p + half, c.first.bytes - half);
-                        std::memcpy(out.buf->data, c.first.p, half);
-                        helpers[i]->wait();
+                        const size_t parts = helpers[i].size() + 1, part = (c.first.bytes / parts) & ~(size_t)63;
+                        for (size_t h = 0; h < helpers[i].size(); ++h) {
+                            const size_t from = part * (h + 1), upto = h + 2 == parts ? c.first.bytes : part * (h + 2);
+                            helpers[i][h]->start(out.buf->data + from, c.first.p + from, upto - from);
+                        }
+                        std::memcpy(out.buf->data, c.first.p, part);
+                        for (auto &h : helpers[i]) h->wait();
                         if (c.first.add_newline) out.buf->data[c.first.bytes] = '\n';
                         g_times.reader_push += tick() - t0;   // (the copy: reported as "push")
                     } else {

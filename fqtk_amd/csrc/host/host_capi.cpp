@@ -463,12 +463,24 @@ int fqtk_host_chunk_schedule_check(uint64_t devices, uint64_t slots, uint64_t n_
 
 // FastqSource::next_cut over a whole plain (mapped) file: the same contract as fqtk_host_read_raw, the text taken
 // from the cuts (+ the newline a cut asks for).  Returns the number of cuts, -1 on an error, -2 if the file is not mapped.
+static int64_t read_cuts(const char *path, uint64_t batch, char *out, size_t cap, size_t *out_len, uint64_t *counts, size_t max_calls,
+                         char *err, size_t errcap, bool assistant);
 int64_t fqtk_host_read_cuts(const char *path, uint64_t batch, char *out, size_t cap, size_t *out_len, uint64_t *counts, size_t max_calls,
                             char *err, size_t errcap) {
+    return read_cuts(path, batch, out, cap, out_len, counts, max_calls, err, errcap, false);
+}
+// ... with a second thread counting the later steps of every cut (FastqSource::attach_count_assistant)
+int64_t fqtk_host_read_cuts_assisted(const char *path, uint64_t batch, char *out, size_t cap, size_t *out_len, uint64_t *counts, size_t max_calls,
+                                     char *err, size_t errcap) {
+    return read_cuts(path, batch, out, cap, out_len, counts, max_calls, err, errcap, true);
+}
+static int64_t read_cuts(const char *path, uint64_t batch, char *out, size_t cap, size_t *out_len, uint64_t *counts, size_t max_calls,
+                         char *err, size_t errcap, bool assistant) {
     FastqSource src;
     std::string e;
     if (!src.open(path, &e)) { put(e, err, errcap); return -1; }
     if (!src.mapped()) return -2;
+    if (assistant) src.attach_count_assistant();
     size_t w = 0, calls = 0;
     for (;;) {
         FastqSource::RawCut c;

@@ -183,10 +183,9 @@ def test_fast_effort_of_low_compression_levels_round_trips_and_is_at_most_a_litt
     assert sizes[5] <= sizes[1] <= sizes[5] * 1.04
 
 
-def test_matches_that_run_past_their_slice_and_the_lanes_they_cover():
-    """bgzf_deflate.hpp phase_reach: the last match of a 64-byte slice runs on (up to 258 bytes: five slices), the lanes
-    behind it start where it ends -- whole slices covered, matches cut at their front, rests of one or two bytes."""
-    rng = np.random.default_rng(11)
+def reach_cases(rng):
+    """Inputs for bgzf_deflate.hpp phase_reach: the last match of a 64-byte slice runs on (up to 258 bytes: five slices), the
+    lanes behind it start where it ends -- whole slices covered, matches cut at their front, rests of one or two bytes."""
     cases = [b"A" * MAX_IN, b"A" * 700, b"AB" * 3000, b"ABC" * 1000 + b"x" + b"ABC" * 1000]
     # runs of every length around the slice and the match maximum, at every phase of the 64-byte grid
     for run in (60, 63, 64, 65, 66, 67, 127, 128, 129, 256, 257, 258, 259, 260, 261, 262, 320, 515, 516, 517, 518):
@@ -206,8 +205,13 @@ def test_matches_that_run_past_their_slice_and_the_lanes_they_cover():
                 line[int(rng.integers(0, len(line)))] = int(rng.integers(65, 91))
             text += line + b"\n"
         cases.append(bytes(text))
-    for data in cases:
-        n, stored = roundtrip(data[:MAX_IN])
+    return [c[:MAX_IN] for c in cases]
+
+
+def test_matches_that_run_past_their_slice_and_the_lanes_they_cover():
+    rng = np.random.default_rng(11)
+    for data in reach_cases(rng):
+        n, stored = roundtrip(data)
         assert not stored
     # and they do what they are for: a 150-byte run of one quality value is one match, not three (0.157 without them)
     assert roundtrip(fastq_text(176, rng)[:MAX_IN])[0] / MAX_IN < 0.145

@@ -11,7 +11,7 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 from fqtk_amd import _lib  # noqa: E402
-from tests.test_bgzf_deflate import MAX_IN, deflate as cpu_deflate, fastq_text  # noqa: E402
+from tests.test_bgzf_deflate import MAX_IN, deflate as cpu_deflate, fastq_text, reach_cases  # noqa: E402
 
 
 class Arena:
@@ -127,6 +127,28 @@ def test_skewed_alphabets_and_deep_code_trees_on_the_gpu():
     run = np.full(MAX_IN, ord("F"), dtype=np.uint8)
     run[rng.integers(0, MAX_IN, 300)] = rng.integers(33, 75, 300, dtype=np.uint8)
     blocks.append(run.tobytes())
+    a = Arena(lib, len(blocks))
+    try:
+        a.load(blocks)
+        assert lib.fqtk_bgzf_deflate_enqueue(z, 0, a.pdesc, len(blocks), a.plen) == 0, lib.fqtk_bgzf_last_error()
+        assert lib.fqtk_bgzf_wait(z, 0) == 0
+        for i, b in enumerate(blocks):
+            p = a.payload(i)
+            d = zlib.decompressobj(-15)
+            assert d.decompress(p) == b and d.eof and d.unused_data == b"", (i, len(b))
+            assert p == cpu_deflate(b)[0], (i, len(b))
+    finally:
+        a.free()
+        lib.fqtk_bgzf_destroy(z)
+
+
+def test_matches_past_their_slice_on_the_gpu():
+    """phase_reach (matches that run on over the next lanes' slices): the crafted runs, repeated lines and nearly equal lines
+    of the CPU test, bit-exact against the CPU run of the same phases."""
+    lib = _lib.load()
+    z = C.c_void_p()
+    assert lib.fqtk_bgzf_create(0, C.byref(z)) == 0, lib.fqtk_bgzf_last_error()
+    blocks = reach_cases(np.random.default_rng(11))
     a = Arena(lib, len(blocks))
     try:
         a.load(blocks)

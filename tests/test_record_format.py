@@ -91,7 +91,7 @@ def test_random_headers_agree_with_write_header():
 
 
 def read_raw(path, batch, cuts=False):
-    fn = H.lib().fqtk_host_read_cuts if cuts else H.lib().fqtk_host_read_raw
+    fn = {False: H.lib().fqtk_host_read_raw, True: H.lib().fqtk_host_read_cuts, "assisted": H.lib().fqtk_host_read_cuts_assisted}[cuts]
     fn.restype = C.c_int64
     cap = 64 << 20
     out = np.empty(cap, dtype=np.uint8)
@@ -151,6 +151,25 @@ def test_next_cut_hands_out_the_same_chunks_without_copying(tmp_path):
     (tmp_path / "d.fq").write_bytes(text + b"@cut\nAC\n")
     with pytest.raises(ValueError, match="truncated record"):
         read_raw(tmp_path / "d.fq", 1000, cuts=True)
+
+
+def test_a_second_thread_counting_for_the_cutter_changes_nothing(tmp_path):
+    """FastqSource::attach_count_assistant: the later 256 KiB steps of a cut are counted by a second thread (it guesses the
+    cut's length from the last one): cuts of 4-40 MB whose lengths drift up and down, so the guess overshoots and falls short."""
+    rng = np.random.default_rng(5)
+    recs = []
+    for i in range(120_000):
+        n = 40 + 25 * ((i // 9000) % 7) + int(rng.integers(0, 9))   # record lengths drift in bands
+        recs.append(b"@r%d\n%s\n+\n%s\n" % (i, b"A" * n, b"I" * n))
+    text = b"".join(recs)
+    assert 24 << 20 < len(text) < 60 << 20
+    for name, data in (("a.fq", text), ("b.fq", text[:-1])):
+        p = tmp_path / name
+        p.write_bytes(data)
+        for batch in (11_000, 25_000, 50_001, 200_000):
+            plain = read_raw(p, batch, cuts=True)
+            assert read_raw(p, batch, cuts="assisted") == plain and plain[0] == text
+            assert plain[1] == [batch] * (120_000 // batch) + ([120_000 % batch] if 120_000 % batch else [])
 
 
 def test_count_newlines_every_alignment_and_length():
