@@ -52,8 +52,9 @@ constexpr uint32_t kChunk = 65536 / kLanes;          // bytes parsed by one lane
 #define FQTK_BGZF_REGION_SHIFT 11   // (tools/bgzf_ratio.py: 14 -> 11 takes 1.3 % off records with binned qualities, costs nothing)
 #endif
 constexpr uint32_t kRegionShift = FQTK_BGZF_REGION_SHIFT, kRegion = 1u << kRegionShift, kRegions = 65536u >> kRegionShift;
-constexpr uint32_t kHashBits = kRegionShift - 3;        // per region: 32 regions x 256 entries x {min, max} = 32 KiB
+constexpr uint32_t kHashBits = kRegionShift - 3;        // per region: 32 regions x 256 buckets x {earliest, latest} = 32 KiB
 constexpr uint32_t kNearSlots = 16384 / kLanes;       // per lane: direct-mapped table of its recent positions (local repeats)
+static_assert(kRegionShift <= 11, "a position's offset in its region has 11 bits (+ 5 check bits = half a word)");
 constexpr uint32_t kOutStride = 65536;    // bytes reserved per block in the output arena (stored worst case: n + 5)
 constexpr uint32_t kMaxMatchesPerLane = kChunk / 4;     // kMinMatch bytes each at least
 constexpr uint32_t kTokensPerBlock = kLanes * kMaxMatchesPerLane;   // match scratch (global, L2-resident), u32 each, [m][lane]
@@ -74,8 +75,8 @@ FQTK_HD inline uint32_t buf_byte(const uint32_t *words, uint32_t pos) { return (
 struct Shared {
     uint32_t buf[kBufWords];              // the input bytes, skewed (buf_word), from P0 to the end (literals are read from here)
     // P0-P1: the two match tables.  P2-P5: the same 64 KiB, as one array, hold the output bit stream (out_image()).
-    uint32_t tminmax[kRegions << kHashBits];      // per (region, hash): smallest position in the low half, largest in the high half
-    uint16_t near_tab[kNearSlots * kLanes];  // [slot][lane]: every lane's private table of recent positions
+    uint32_t tminmax[(kRegions + 1u) << kHashBits];   // per (hash bucket, region; region_slot): the earliest position in the low half, the latest in the high half (region_entry)
+    uint16_t near_tab[kNearSlots * kLanes];    // [slot][lane]: every lane's private table of recent positions (near_entry)
     uint32_t byte_cnt[256];                  // P1a: how often each byte value occurs in the block
     uint8_t lit_cost[256];                   // estimated cost of a literal, in half-bits (from byte_cnt)
     uint32_t lit_total;                      // sum of them over the block's bytes (for the average)
@@ -124,8 +125,8 @@ struct Shared {
 // intact to the end -- so a token stream need not be written out: a lane's tokens are its MATCHES (a few per slice, in a
 // small global scratch) and, between them, the bytes of its slice.  (Tokens used to go to a 64 MB global scratch, one dword
 // per token, written once and read twice: 9x the kernel's input in HBM traffic, rocprofv3 FETCH_SIZE / WRITE_SIZE.)
-static_assert(offsetof(Shared, near_tab) == offsetof(Shared, tminmax) + sizeof(uint32_t) * (kRegions << kHashBits), "the two tables are one 64 KiB array");
-static_assert(sizeof(uint32_t) * (kRegions << kHashBits) + sizeof(uint16_t) * kNearSlots * kLanes >= kOutStride, "the output image fits the tables' place");
+static_assert(offsetof(Shared, near_tab) == offsetof(Shared, tminmax) + sizeof(uint32_t) * ((kRegions + 1u) << kHashBits), "the two tables are one 64 KiB array");
+static_assert(sizeof(uint32_t) * ((kRegions + 1u) << kHashBits) + sizeof(uint16_t) * kNearSlots * kLanes >= kOutStride, "the output image fits the tables' place");
 static_assert(sizeof(Shared) <= 160 * 1024, "one workgroup's LDS");
 FQTK_HD inline uint32_t *out_image(Shared &S) { return S.tminmax; }
 
@@ -346,8 +347,30 @@ FQTK_HD inline void phase_crc_fold(Shared &S) {
 FQTK_HD inline uint32_t load_le32(const uint8_t *p) {
     return (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((uint32_t)p[3] << 24);
 }
-FQTK_HD inline uint32_t hash4(uint32_t x) { return (x * 2654435761u) >> (32 - kHashBits); }
-FQTK_HD inline uint32_t near_of(uint32_t h) { return (h >> (kHashBits - 6)) & (kNearSlots - 1u); }
+// The hash of a position's gram: bucket = the top kHashBits bits, slot of the lane's own table = the bits below them,
+// check = sixteen bits further down.  A CHEAP position -- its next four bytes cost at most kCheap4 half-bits as literals:
+// sequence lines, a run of the frequent quality value -- is known by its next EIGHT bytes: a match of four to seven such
+// bytes never pays for its distance code, yet nearly every position of a sequence line finds an earlier copy of its four
+// bases, and reading and comparing those candidates was most of the LZ phase's time (tools/ab_bgzf.sh: 45 GB/s with the
+// three candidates, 102 GB/s with none).  The check bits travel with every table entry, so a candidate's bytes are only
+// read when its gram (almost certainly) is the position's own.
+#ifndef FQTK_BGZF_CHEAP4
+#define FQTK_BGZF_CHEAP4 28u
+#endif
+constexpr uint32_t kCheap4 = FQTK_BGZF_CHEAP4;
+FQTK_HD inline uint32_t gram_hash(uint32_t w, uint32_t w4, bool cheap) {
+    const uint32_t x = cheap ? (w ^ (w4 * 0x85EBCA6Bu) ^ 0x5BD1E995u) : w;
+    return x * 2654435761u;
+}
+// Entries are half words: the region table's = offset in the 2 KiB region << 5 | 5 check bits (none: 0xFFFF as an earliest,
+// 0 as a latest entry -- the two grams that would look like that are not entered), the lane's own table's = distance from
+// 64 bytes before the lane's slice << 7 | 7 check bits (a lane's table holds the slice before its own, its own, and the
+// 257 bytes a match may run on: 9 bits; none: 0xFFFF, a position no look-up can be behind).
+static_assert(kHashBits + 4u + 7u <= 32u && kChunk + kChunk + 258u <= 512u, "bucket / slot / check bits; 9-bit distances");
+FQTK_HD inline uint32_t bucket_of(uint32_t h) { return h >> (32 - kHashBits); }
+FQTK_HD inline uint32_t near_of(uint32_t h) { return (h >> (32 - kHashBits - 4)) & (kNearSlots - 1u); }
+FQTK_HD inline uint32_t region_entry(uint32_t p, uint32_t h) { return ((p & (kRegion - 1u)) << 5) | ((h >> 8) & 0x1Fu); }
+FQTK_HD inline uint32_t near_entry(uint32_t p, int lane, uint32_t h) { return ((p + kChunk - (uint32_t)lane * kChunk) << 7) | ((h >> 8) & 0x7Fu); }
 // Four bytes at any byte offset of the block buffer.  Device: two aligned LDS words and one v_alignbyte_b32
 // instead of four byte reads (the word after the last payload byte exists: the buffer is 64 KiB, a block 65 280 B).
 FQTK_HD inline uint32_t buf_le32(const uint32_t *words, uint32_t pos) {
@@ -392,7 +415,7 @@ FQTK_HD inline uint32_t effort_of_level(uint32_t level) { return level <= 3u ? 0
 
 // P0: clear the shared state, bring the block in.  `in` may be device or (pinned, device-visible) host memory.
 FQTK_HD inline void phase_load(Shared &S, int lane, const uint8_t *in, uint32_t n) {
-    for (uint32_t i = (uint32_t)lane; i < (kRegions << kHashBits); i += kLanes) S.tminmax[i] = 0x0000FFFFu;   // min = none (0xFFFF), max = none (0)
+    for (uint32_t i = (uint32_t)lane; i < ((kRegions + 1u) << kHashBits); i += kLanes) S.tminmax[i] = 0x0000FFFFu;   // earliest = none (0xFFFF), latest = none (0)
     for (uint32_t i = 0; i < kNearSlots; ++i) S.near_tab[i * kLanes + (uint32_t)lane] = 0xFFFFu;
     for (uint32_t i = (uint32_t)lane; i < 288; i += kLanes) S.freq_ll[i] = 0;
     if (lane < 32) S.freq_d[lane] = 0;
@@ -426,48 +449,88 @@ FQTK_HD inline void phase_load(Shared &S, int lane, const uint8_t *in, uint32_t 
     }
 }
 
-// P1a: every position of this lane's slice into the (region, hash) table.  One word holds the smallest position
-// (low half, 0xFFFF = none) and the largest position + 1 (high half, 0 = none) of its bucket; min and max are
-// order-independent, so the table -- and with it the whole output -- does not depend on how the lanes interleave.
-FQTK_HD inline uint32_t region_slot(uint32_t p, uint32_t h) { return ((p >> kRegionShift) << kHashBits) | h; }
-FQTK_HD inline void phase_index(Shared &S, int lane, uint32_t n) {
+// P1a: how often each byte value occurs in the block (-> what a literal costs, phase_literal_costs).  The slice is read
+// once, as aligned words.  (The four bases are nearly half of FASTQ text and 64 lanes of a wave hammer their four counters
+// -- yet counting them in a packed register per lane and adding once per slice was SLOWER, 36.6 against 38.4 GB/s,
+// tools/ab_bgzf.sh: same-address LDS atomics are cheap, the extra selects are not.)
+FQTK_HD inline void phase_count(Shared &S, int lane, uint32_t n) {
     const uint32_t lo = (uint32_t)lane * kChunk;
     const uint32_t hi = lo + kChunk < n ? lo + kChunk : n;
-    // (the four bases are nearly half of FASTQ text and 64 lanes of a wave hammer their four counters -- yet counting them
-    //  in a packed register per lane and adding once per slice was SLOWER, 36.6 against 38.4 GB/s, tools/ab_bgzf.sh:
-    //  same-address LDS atomics are cheap, the extra selects are not)
-    // the slice is read once, a run of five aligned words per sixteen positions (it begins on a word: no shifts by a variable);
-    // a read per byte and two per position made this phase wait for LDS like the LZ phase does
     for (uint32_t g = lo; g < hi; g += 16u) {
-        uint32_t v[5];
-        const uint32_t w0 = g >> 2;
+        uint32_t v[4];
 #if defined(__HIP_DEVICE_COMPILE__)
 #pragma unroll
 #endif
-        for (int i = 0; i < 5; ++i) v[i] = S.buf[buf_word(w0 + (uint32_t)i)];
+        for (int i = 0; i < 4; ++i) v[i] = S.buf[buf_word((g >> 2) + (uint32_t)i)];
 #if defined(__HIP_DEVICE_COMPILE__)
 #pragma unroll
 #endif
-        for (uint32_t k = 0; k < 16u; ++k) {
-            const uint32_t p = g + k;
-            const uint32_t lo32 = v[k >> 2], hi32 = v[(k >> 2) + 1];
-            const uint32_t x = (k & 3u) ? (lo32 >> (8 * (k & 3u))) | (hi32 << (32 - 8 * (k & 3u))) : lo32;
-            if (p < hi) FQTK_BGZF_ADD(&S.byte_cnt[x & 0xFFu], 1u);
-            if (p < hi && p + 4 <= n) {
-                uint32_t *w = &S.tminmax[region_slot(p, hash4(x))];
-                uint32_t old = *w;
-                for (;;) {
-                    const uint32_t mn = (old & 0xFFFFu) < p ? (old & 0xFFFFu) : p;
-                    const uint32_t mx = (old >> 16) > p + 1 ? (old >> 16) : p + 1;
-                    const uint32_t want = (mx << 16) | mn;
-                    if (want == old) break;
-                    const uint32_t seen = FQTK_BGZF_CAS(w, old, want);
-                    if (seen == old) break;
-                    old = seen;
-                }
-            }
+        for (uint32_t k = 0; k < 16u; ++k)
+            if (g + k < hi) FQTK_BGZF_ADD(&S.byte_cnt[(v[k >> 2] >> (8 * (k & 3u))) & 0xFFu], 1u);
+    }
+}
+
+// The grams of positions from .. from + count - 1 (count <= MAXK): fn(position, gram_hash, is it a cheap position).  The bytes come in as one run of
+// aligned words, the literal costs that decide between the four-byte and the eight-byte gram one read per byte.
+template <int MAXK, typename Fn>
+FQTK_HD inline void for_grams(Shared &S, uint32_t n, uint32_t from, uint32_t count, Fn fn) {
+    constexpr int NW = (MAXK + 7 + 3) / 4;
+    uint32_t d[NW];
+    buf_run<NW>(S.buf, from, d);
+    uint32_t c[MAXK + 3];
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+    for (int j = 0; j < MAXK + 3; ++j) c[j] = S.lit_cost[(d[j >> 2] >> (8 * (j & 3))) & 0xFFu];
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+    for (int k = 0; k < MAXK; ++k) {
+        const int k4 = k + 4;
+        const uint32_t w = (k & 3) ? (d[k >> 2] >> (8 * (k & 3))) | (d[(k >> 2) + 1] << (32 - 8 * (k & 3))) : d[k >> 2];
+        const uint32_t w4 = (k4 & 3) ? (d[k4 >> 2] >> (8 * (k4 & 3))) | (d[(k4 >> 2) + 1] << (32 - 8 * (k4 & 3))) : d[k4 >> 2];
+        const uint32_t p = from + (uint32_t)k;
+        if ((uint32_t)k < count && p + 4 <= n) {   // (no break: the loop must unroll for d[] and c[] to stay in registers)
+            const bool cheap = c[k] + c[k + 1] + c[k + 2] + c[k + 3] <= kCheap4 && p + 8 <= n;
+            fn(p, gram_hash(w, w4, cheap), cheap);
         }
     }
+}
+
+// P1b: every position of this lane's slice into the (region, hash bucket) table.  A bucket keeps the earliest and the latest
+// of its positions, each with the check bits of its gram, position in the high half: one atomic min and one atomic max per
+// position, and both are order-independent -- so the table, and with it the whole output, does not depend on how the lanes
+// interleave.
+// Word of (region of p, bucket): the regions of a bucket side by side, so that the two entries a look-up wants -- its own
+// region's and the one before -- are neighbours (one ds_read2_b32); kRegions + 1 words per bucket, or every lane of a
+// wavefront (they stand in one or two regions) would hit the same bank.
+FQTK_HD inline uint32_t region_slot(uint32_t p, uint32_t bucket) { return bucket * (kRegions + 1u) + 1u + (p >> kRegionShift); }
+// The same grams go into the NEXT lane's own table (its history begins with the slice before its own: this lane's), and
+// which positions are cheap comes back as a bit mask -- the LZ phase then hashes a position without a look at the
+// literal costs (one dependent LDS round trip less per step).
+FQTK_HD inline uint64_t phase_index(Shared &S, int lane, uint32_t n) {
+    const uint32_t lo = (uint32_t)lane * kChunk;
+    const uint32_t hi = lo + kChunk < n ? lo + kChunk : n;
+    uint64_t cheap_mask = 0;
+    for (uint32_t g = lo; g < hi; g += 16u)
+        for_grams<16>(S, n, g, hi - g < 16u ? hi - g : 16u, [&](uint32_t p, uint32_t h, bool cheap) {
+            if (cheap) cheap_mask |= 1ull << (p - lo);
+            if (lane + 1 < kLanes) S.near_tab[near_of(h) * kLanes + (uint32_t)lane + 1u] = (uint16_t)near_entry(p, lane + 1, h);
+            const uint32_t v = region_entry(p, h);
+            if (v == 0u || v == 0xFFFFu) return;   // (would read as "none")
+            uint32_t *e = &S.tminmax[region_slot(p, bucket_of(h))];
+            uint32_t old = *e;
+            for (;;) {
+                const uint32_t mn = (old & 0xFFFFu) < v ? (old & 0xFFFFu) : v;
+                const uint32_t mx = (old >> 16) > v ? (old >> 16) : v;
+                const uint32_t want = (mx << 16) | mn;
+                if (want == old) break;
+                const uint32_t seen = FQTK_BGZF_CAS(e, old, want);
+                if (seen == old) break;
+                old = seen;
+            }
+        });
+    return cheap_mask;
 }
 
 // What a literal will cost after Huffman coding, roughly: -log2 of the byte's share of the block, in half-bits
@@ -504,48 +567,30 @@ FQTK_HD inline uint32_t match_cost(uint32_t len, uint32_t dist) {   // half-bits
 // Positions from .. from + count - 1 (count <= 16) go into the lane's private table: read as one run of words,
 // hashed from registers.
 #ifndef FQTK_BGZF_INS_HEAD
-#define FQTK_BGZF_INS_HEAD 4    // positions behind a match's first byte that enter the lane's table ...
+#define FQTK_BGZF_INS_HEAD 1    // positions behind a match's first byte that enter the lane's table ...
 #endif
 #ifndef FQTK_BGZF_INS_TAIL
-#define FQTK_BGZF_INS_TAIL 4    // ... and before its end (tools/ab_bgzf.sh, tools/bgzf_ratio.py: 16 + 8 gave the same output, 5 % slower)
-#endif
+#define FQTK_BGZF_INS_TAIL 2    // ... and before its end (tools/bgzf_ratio.py: none +1.4 % output on binned qualities, 1 + 2 +0.05 %, 4 + 4 and
+#endif                          //     16 + 8 the same as 1 + 4; tools/ab_bgzf.sh: none is 13 % faster than 4 + 4)
 template <int MAXK = 16>
 FQTK_HD inline void near_insert_run(Shared &S, int lane, uint32_t n, uint32_t from, uint32_t count) {
-    uint32_t v[6];
-    const uint32_t i0 = from >> 2, sh = from & 3u;
-#if defined(__HIP_DEVICE_COMPILE__)
-#pragma unroll
-#endif
-    for (int j = 0; j < 5; ++j) v[j] = buf_le32(S.buf, (i0 + (uint32_t)j) * 4u + sh);   // v = the bytes from `from` on
-    v[5] = 0;
-#if defined(__HIP_DEVICE_COMPILE__)
-#pragma unroll
-#endif
-    for (uint32_t k = 0; k < (uint32_t)MAXK; ++k) {
-        const uint32_t lo = v[k >> 2], hi = v[(k >> 2) + 1];
-        const uint32_t x = (k & 3u) ? (lo >> (8 * (k & 3u))) | (hi << (32 - 8 * (k & 3u))) : lo;
-        if (k < count && from + k + 4 <= n)   // (no break: the loop must unroll for v[] to stay in registers)
-            S.near_tab[(near_of(hash4(x))) * kLanes + (uint32_t)lane] = (uint16_t)(from + k);
-    }
+    for_grams<MAXK>(S, n, from, count, [&](uint32_t p, uint32_t h, bool) {
+        S.near_tab[near_of(h) * kLanes + (uint32_t)lane] = (uint16_t)near_entry(p, lane, h);
+    });
 }
 
 // P1b: greedy LZ77 over this lane's slice; tokens to tok[t * kLanes + lane].  Deterministic: reads the tables
 // of P1a and the lane's own state only.
-struct LzLane { uint32_t p, end, nt, avg16, effort; };   // avg16: the block's average literal cost, half-bits x 16
-FQTK_HD inline void lz_begin(Shared &S, int lane, uint32_t n, LzLane &st) {
+struct LzLane { uint32_t p, end, nt, avg16, effort; uint64_t cheap; };   // avg16: the block's average literal cost, half-bits x 16; cheap: phase_index's mask
+FQTK_HD inline void lz_begin(Shared &S, int lane, uint32_t n, LzLane &st, uint64_t cheap_mask) {
+    st.cheap = cheap_mask;
     st.p = (uint32_t)lane * kChunk;
     st.end = st.p + kChunk < n ? st.p + kChunk : n;
     st.nt = 0;
     st.effort = S.effort;
     st.avg16 = n ? (uint32_t)(((uint64_t)S.lit_total << 4) / n) : 0u;
-    // the private table starts with the slice before this one (the neighbour's bytes, read-only here)
-    static_assert(kChunk % 16 == 0, "history preload in runs of 16");
-#ifndef FQTK_BGZF_PRELOAD
-#define FQTK_BGZF_PRELOAD kChunk
-#endif
-    constexpr uint32_t kPreload = FQTK_BGZF_PRELOAD;
-    if (st.p >= kChunk)
-        for (uint32_t q = st.p - kPreload; q < st.p; q += 16) near_insert_run(S, lane, n, q, 16);
+    // (the lane's own table already holds the slice before this one: phase_index of the lane before)
+    (void)S;
 }
 // one token; false when the slice is done
 #if defined(FQTK_BGZF_PHASE_TIMES) && defined(__HIPCC__)
@@ -559,104 +604,147 @@ __device__ unsigned long long g_lz_cycles[10];   // setup, candidate reads + lit
 #ifndef FQTK_BGZF_ABL
 #define FQTK_BGZF_ABL 0   // developer ablations of the LZ phase (tools/bgzf_phases.sh); 0 in the product
 #endif
-// The best match at position p of this lane's slice: length, distance and the half-bits it saves (0 = none).  Enters p
-// into the lane's table of recent positions.  S.effort: 0 = two candidates, 1 = three (see below).
-FQTK_HD inline void lz_find(Shared &S, int lane, uint32_t n, uint32_t p, const LzLane &st, uint32_t &mlen, uint32_t &mdist, uint32_t &msave, uint32_t &byte0) {
-    mlen = mdist = msave = 0;
-    if (p + 4 > n) byte0 = buf_byte(S.buf, p);
-    if (p + 4 <= n) {
-        uint32_t here[2];
-        buf_run<2>(S.buf, p, here);
-        const uint32_t w = here[0], w4 = here[1];
-        byte0 = w & 0xFFu;
-        const uint32_t h = hash4(w);
-        const uint32_t near_slot = near_of(h) * kLanes + (uint32_t)lane;
-        const uint32_t own = S.tminmax[region_slot(p, h)] & 0xFFFFu;
-        // Three candidates (position + 1; 0 = none).  Three more were tried and dropped (tools/bgzf_ratio.py): the
-        // previous match's distance and distance 1 bought nothing -- the lane's own table already holds the position
-        // a run or a repeat comes from -- and "the same place one record back" bought 0.2-0.7 % (records are
-        // rarely equally long).  What each of the three is worth on Illumina-style records: without the lane's
-        // table the output grows by 0.1-8 %, without the region's earliest occurrence by 6-9 %, without the
-        // previous region's latest by 1-2 %.
-        uint32_t cand[kCands];
-        cand[0] = (uint32_t)S.near_tab[near_slot] + 1u;                    // 0xFFFF + 1 = 0x10000: fails q < p below
-        cand[1] = own == 0xFFFFu ? 0u : own + 1u;
-        cand[2] = p >= kRegion ? (S.tminmax[region_slot(p - kRegion, h)] >> 16) : 0u;
-        S.near_tab[near_slot] = (uint16_t)p;
+// A position's look-up comes in three parts, so that a step can have the look-ups of TWO positions in flight (lz_step):
+// the table entries of its gram (lz_probe), the candidates they stand for (lz_candidates), and -- only when there is one --
+// the comparison of the bytes (lz_match).
+struct LzProbe { uint32_t near_slot, mine_near, mine, e_near, e_min, e_max; };
+FQTK_HD inline void lz_probe(Shared &S, int lane, uint32_t p, const LzLane &st, uint32_t w, uint32_t w4, LzProbe &pr) {
+    const bool cheap = ((st.cheap >> (p - (uint32_t)lane * kChunk)) & 1ull) != 0;   // (what for_grams found: literal costs and p + 8 <= n)
+    const uint32_t h = gram_hash(w, w4, cheap);
+    pr.near_slot = near_of(h) * kLanes + (uint32_t)lane;
+    pr.mine_near = near_entry(p, lane, h);
+    pr.mine = region_entry(p, h);
+    pr.e_near = S.near_tab[pr.near_slot];
+    const uint32_t *e = &S.tminmax[region_slot(p, bucket_of(h))];
+    pr.e_min = e[0] & 0xFFFFu;
+    pr.e_max = e[-1] >> 16;   // (the word before region 0's is never written: "none")
+}
+// Three candidates: the lane's own table, the region's earliest entry of the bucket, the previous region's latest -- each
+// only if its check bits are the gram's.  Three more were tried and dropped (tools/bgzf_ratio.py): the previous match's
+// distance and distance 1 bought nothing -- the lane's own table already holds the position a run or a repeat comes
+// from -- and "the same place one record back" bought 0.2-0.7 % (records are rarely equally long).  What each of the
+// three is worth on Illumina-style records: without the lane's table the output grows by 0.1-8 %, without the region's
+// earliest occurrence by 6-9 %, without the previous region's latest by 1-2 %.
+FQTK_HD inline bool lz_candidates(int lane, uint32_t p, const LzProbe &pr, uint32_t (&qpos)[kCands]) {
+    uint32_t cand[kCands];
+    // (position + 1 of an entry whose check bits are the gram's; "none" entries fail the q < p test below or are 0 here)
+    cand[0] = ((pr.e_near ^ pr.mine_near) & 0x7Fu) == 0u ? (pr.e_near >> 7) + (uint32_t)lane * kChunk - kChunk + 1u : 0u;
+    cand[1] = ((pr.e_min ^ pr.mine) & 0x1Fu) == 0u ? (p & ~(kRegion - 1u)) + (pr.e_min >> 5) + 1u : 0u;
+    cand[2] = (pr.e_max != 0u && ((pr.e_max ^ pr.mine) & 0x1Fu) == 0u) ? ((p - kRegion) & ~(kRegion - 1u)) + (pr.e_max >> 5) + 1u : 0u;
 #ifdef FQTK_BGZF_DROP   // developer study (tools/bgzf_ratio.py): candidates switched off by bit mask
-        for (int c = 0; c < kCands; ++c) if ((FQTK_BGZF_DROP >> c) & 1) cand[c] = 0;
+    for (int c = 0; c < kCands; ++c) if ((FQTK_BGZF_DROP >> c) & 1) cand[c] = 0;
 #endif
+    bool any = false;
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+    for (int c = 0; c < kCands; ++c) {
+        const uint32_t q = cand[c] - 1u;                               // 0xFFFFFFFF for "none"
+        const bool in_reach = cand[c] != 0u && q < p && p - q <= 32768u;
+        qpos[c] = in_reach ? q : p;                                    // p itself: reads fine, never accepted
+        any = any || in_reach;
+    }
+    return any;
+}
+// The best of the candidates at position p: length and distance (0 = none pays for itself).
+FQTK_HD inline void lz_match(Shared &S, uint32_t n, uint32_t p, const LzLane &st, uint32_t w, uint32_t w4, const uint32_t (&qpos)[kCands],
+                             uint32_t &mlen, uint32_t &mdist) {
+    uint32_t msave = 0;
+    mlen = mdist = 0;
 #ifdef FQTK_BGZF_NO_REACH   // (study: matches cut at the slice's end, as before phase_reach existed)
-        uint32_t maxl = st.end - p < 258u ? st.end - p : 258u;
+    uint32_t maxl = st.end - p < 258u ? st.end - p : 258u;
 #else
-        // a match may run past the end of the lane's slice: phase_reach (--compression-level 1-3: it may not; 7 % faster)
-        uint32_t maxl = st.effort ? n - p : st.end - p;
-        maxl = maxl < 258u ? maxl : 258u;
+    // a match may run past the end of the lane's slice: phase_reach (--compression-level 1-3: it may not; 7 % faster)
+    uint32_t maxl = st.effort ? n - p : st.end - p;
+    maxl = maxl < 258u ? maxl : 258u;
 #endif
-        if ((FQTK_BGZF_ABL & 8) && maxl > 8u) maxl = 8u;
-                // Which candidates start with the same four bytes: all five are read before any is looked at (one wave
-        // per SIMD: every dependent LDS round trip is paid in full, so the reads go out together).
-        uint32_t qpos[kCands], first[kCands], second[kCands];
+    if ((FQTK_BGZF_ABL & 8) && maxl > 8u) maxl = 8u;
+    // the candidates' first eight bytes: all are read before any is looked at (every dependent LDS round trip is paid
+    // in full, so the reads go out together)
+    uint32_t first[kCands], second[kCands];
 #if defined(__HIP_DEVICE_COMPILE__)
 #pragma unroll
 #endif
-        for (int c = 0; c < kCands; ++c) {
-            const uint32_t q = cand[c] - 1u;                               // 0xFFFFFFFF for "none"
-            const bool in_reach = cand[c] != 0u && q < p && p - q <= 32768u;
-            qpos[c] = in_reach ? q : p;                                    // p itself: reads fine, never accepted
-            uint32_t there[2];
-            buf_run<2>(S.buf, qpos[c], there);
-            first[c] = there[0];
-            second[c] = there[1];
-        }
-        // what the bytes cost as literals: exactly for the first eight, the block's average beyond (every long
-        // match pays for itself many times over; the estimate only ranks long candidates among themselves)
-        uint32_t lit8[9];
-        lit8[0] = 0;
+    for (int c = 0; c < kCands; ++c) {
+        uint32_t there[2];
+        buf_run<2>(S.buf, qpos[c], there);
+        first[c] = there[0];
+        second[c] = there[1];
+    }
+    // what the bytes cost as literals: exactly for the first eight, the block's average beyond (every long match pays for
+    // itself many times over; the estimate only ranks long candidates among themselves)
+    uint32_t lit8[9];
+    lit8[0] = 0;
 #if defined(__HIP_DEVICE_COMPILE__)
 #pragma unroll
 #endif
-        for (int k = 0; k < 4; ++k) lit8[k + 1] = lit8[k] + S.lit_cost[(w >> (8 * k)) & 255u];
+    for (int k = 0; k < 4; ++k) lit8[k + 1] = lit8[k] + S.lit_cost[(w >> (8 * k)) & 255u];
 #if defined(__HIP_DEVICE_COMPILE__)
 #pragma unroll
 #endif
-        for (int k = 0; k < 4; ++k) lit8[k + 5] = lit8[k + 4] + S.lit_cost[(w4 >> (8 * k)) & 255u];
+    for (int k = 0; k < 4; ++k) lit8[k + 5] = lit8[k + 4] + S.lit_cost[(w4 >> (8 * k)) & 255u];
 #if defined(__HIP_DEVICE_COMPILE__)
 #pragma unroll
 #endif
-        for (int c = 0; c < kCands; ++c) {
-            const uint32_t q = qpos[c];
-            if (q == p || first[c] != w) continue;
-            // Bytes 4-7 were fetched with the first four (no loop, no further round trip): in sequence lines nearly every
-            // position finds an earlier copy of its four bases and nearly none of them runs to eight, so the loop below
-            // -- sixteen bytes per round, the eight word pairs independent reads -- is left to the matches that do.
-            uint32_t l;
-            const uint32_t x4 = second[c] ^ w4;
-            if (x4) {
-                l = 4u + (ctz32(x4) >> 3);
-            } else {
-                l = 8;
-                while (l < maxl) {
-                    uint32_t a[4], b[4];
-                    buf_run<4>(S.buf, q + l, a);
-                    buf_run<4>(S.buf, p + l, b);
-                    const uint32_t x0 = a[0] ^ b[0], x1 = a[1] ^ b[1], x2 = a[2] ^ b[2], x3 = a[3] ^ b[3];
-                    if (x0 | x1 | x2 | x3) {
-                        l += x0 ? ctz32(x0) >> 3 : (x1 ? 4 + (ctz32(x1) >> 3) : (x2 ? 8 + (ctz32(x2) >> 3) : 12 + (ctz32(x3) >> 3)));
-                        break;
-                    }
-                    l += 16;
+    for (int c = 0; c < kCands; ++c) {
+        const uint32_t q = qpos[c];
+        if (q == p || first[c] != w) continue;
+        // Bytes 4-7 were fetched with the first four (no loop, no further round trip); the loop below -- sixteen bytes per
+        // round, each side a run of aligned words -- is left to the matches that reach eight.
+        uint32_t l;
+        const uint32_t x4 = second[c] ^ w4;
+        if (x4) {
+            l = 4u + (ctz32(x4) >> 3);
+        } else {
+            l = 8;
+            while (l < maxl) {
+                uint32_t a[4], b[4];
+                buf_run<4>(S.buf, q + l, a);
+                buf_run<4>(S.buf, p + l, b);
+                const uint32_t x0 = a[0] ^ b[0], x1 = a[1] ^ b[1], x2 = a[2] ^ b[2], x3 = a[3] ^ b[3];
+                if (x0 | x1 | x2 | x3) {
+                    l += x0 ? ctz32(x0) >> 3 : (x1 ? 4 + (ctz32(x1) >> 3) : (x2 ? 8 + (ctz32(x2) >> 3) : 12 + (ctz32(x3) >> 3)));
+                    break;
                 }
+                l += 16;
             }
-            if (l > maxl) l = maxl;
-            if (l < (uint32_t)kMinMatch) continue;
-            const uint32_t lit = l == 4 ? lit8[4] : (l == 5 ? lit8[5] : (l == 6 ? lit8[6] : (l == 7 ? lit8[7] : lit8[8] + (((l - 8) * st.avg16) >> 4))));
-            const uint32_t cost = match_cost(l, p - q);
-            if (lit > cost && lit - cost > msave) { msave = lit - cost; mlen = l; mdist = p - q; }
         }
+        if (l > maxl) l = maxl;
+        if (l < (uint32_t)kMinMatch) continue;
+        const uint32_t lit = l == 4 ? lit8[4] : (l == 5 ? lit8[5] : (l == 6 ? lit8[6] : (l == 7 ? lit8[7] : lit8[8] + (((l - 8) * st.avg16) >> 4))));
+        const uint32_t cost = match_cost(l, p - q);
+        if (lit > cost && lit - cost > msave) { msave = lit - cost; mlen = l; mdist = p - q; }
     }
 }
 
+// A match at p is taken: its symbols counted, its token stored, the positions it skips entered into the lane's table.
+FQTK_HD inline void lz_take(Shared &S, int lane, uint32_t n, uint32_t *tok, LzLane &st, uint32_t p, uint32_t mlen, uint32_t mdist) {
+    uint32_t sym, ne, ev;
+    length_symbol(mlen, sym, ne, ev);
+    FQTK_BGZF_ADD(&S.freq_ll[sym], 1u);
+    dist_symbol(mdist, sym, ne, ev);
+    FQTK_BGZF_ADD(&S.freq_d[sym], 1u);
+    if (!(FQTK_BGZF_ABL & 2)) tok[st.nt * kLanes + (uint32_t)lane] = match_token(mlen, mdist, p - (uint32_t)lane * kChunk);
+    ++st.nt;
+    // the positions skipped are recent history too: the first four and the last four of them (a long match is a run or a
+    // copied line; its middle adds nothing the ends do not).  Each group is read as one run of words and hashed from registers.
+    if (mlen > 1 && !(FQTK_BGZF_ABL & 4)) {
+        const uint32_t skipped = mlen - 1;           // positions p + 1 .. p + mlen - 1
+        constexpr uint32_t kHead = FQTK_BGZF_INS_HEAD, kTail = FQTK_BGZF_INS_TAIL;
+        near_insert_run<(int)kHead>(S, lane, n, p + 1, skipped < kHead ? skipped : kHead);
+        if (kTail && skipped > kHead) {
+            const uint32_t tail = skipped - kHead < kTail ? skipped - kHead : kTail;
+            near_insert_run<(int)(kTail ? kTail : 1)>(S, lane, n, p + mlen - tail, tail);
+        }
+    }
+    st.p = p + mlen;
+}
+
+// One step: the token at st.p and, when that is a literal, the token behind it -- the table look-ups of both positions are
+// issued together (in a sequence line nearly every position is a literal, and a wave's step is a chain of dependent LDS
+// round trips: two positions per chain instead of one).  The second position's look-up is the one it would have had in a
+// step of its own: it sees the first position in the lane's table when both share a slot, and when the first position
+// starts a match, the second is among the positions the match enters into the table anyway.  False when the slice is done.
 FQTK_HD inline bool lz_step(Shared &S, int lane, uint32_t n, uint32_t *tok, LzLane &st
 #if defined(FQTK_BGZF_PHASE_TIMES) && defined(__HIP_DEVICE_COMPILE__)
                             , uint64_t (&lz_acc)[8], uint64_t &lz_t
@@ -664,51 +752,58 @@ FQTK_HD inline bool lz_step(Shared &S, int lane, uint32_t n, uint32_t *tok, LzLa
 ) {
     if (st.p >= st.end) return false;
     const uint32_t p = st.p;
-    uint32_t mlen, mdist, msave, lit;
-    lz_find(S, lane, n, p, st, mlen, mdist, msave, lit);
+    if (p + 4 > n) {   // the block's last three bytes: literals
+        if (!(FQTK_BGZF_ABL & 1)) FQTK_BGZF_ADD(&S.freq_ll[buf_byte(S.buf, p)], 1u);
+        st.p = p + 1;
+        return true;
+    }
+    const bool two = p + 1 < st.end && p + 5 <= n;
+    uint32_t r[3];
+    buf_run<3>(S.buf, p, r);
+    const uint32_t wa = r[0], wa4 = r[1], wb = (r[0] >> 8) | (r[1] << 24), wb4 = (r[1] >> 8) | (r[2] << 24);
+    LzProbe a, b;
+    lz_probe(S, lane, p, st, wa, wa4, a);
+    if (two) {
+        lz_probe(S, lane, p + 1, st, wb, wb4, b);
+        if (b.near_slot == a.near_slot) b.e_near = a.mine_near;   // (a run: the position before is the candidate)
+    }
+    S.near_tab[a.near_slot] = (uint16_t)a.mine_near;
+    if (two) S.near_tab[b.near_slot] = (uint16_t)b.mine_near;
+    uint32_t qpos[kCands], mlen = 0, mdist = 0;
     // (A lazy step -- take the literal when the next position holds a longer match that saves more, zlib's levels 4-9 -- was
     //  measured on the CPU run of these phases: 0.0 % / -0.4 % of the output on varied / binned qualities.  Not kept.)
+    if (lz_candidates(lane, p, a, qpos)) lz_match(S, n, p, st, wa, wa4, qpos, mlen, mdist);
     FQTK_LZ_MARK(2);
     if (mlen) {
-        uint32_t sym, ne, ev;
-        length_symbol(mlen, sym, ne, ev);
-        FQTK_BGZF_ADD(&S.freq_ll[sym], 1u);
-        dist_symbol(mdist, sym, ne, ev);
-        FQTK_BGZF_ADD(&S.freq_d[sym], 1u);
-        if (!(FQTK_BGZF_ABL & 2)) tok[st.nt * kLanes + (uint32_t)lane] = match_token(mlen, mdist, p - (uint32_t)lane * kChunk);
-        ++st.nt;
-        FQTK_LZ_MARK(5);
-        // the positions skipped are recent history too: the first four and the last four of them (a long
-        // match is a run or a copied line; its middle adds nothing the ends do not).  Each group is read as one
-        // run of words and hashed from registers.
-        if (mlen > 1 && !(FQTK_BGZF_ABL & 4)) {
-            const uint32_t skipped = mlen - 1;           // positions p + 1 .. p + mlen - 1
-            constexpr uint32_t kHead = FQTK_BGZF_INS_HEAD, kTail = FQTK_BGZF_INS_TAIL;
-            near_insert_run<(int)kHead>(S, lane, n, p + 1, skipped < kHead ? skipped : kHead);
-            if (kTail && skipped > kHead) {
-                const uint32_t tail = skipped - kHead < kTail ? skipped - kHead : kTail;
-                near_insert_run<(int)(kTail ? kTail : 1)>(S, lane, n, p + mlen - tail, tail);
-            }
-        }
-        st.p = p + mlen;
+        lz_take(S, lane, n, tok, st, p, mlen, mdist);
         FQTK_LZ_MARK(6);
-    } else {
-        if (!(FQTK_BGZF_ABL & 1)) FQTK_BGZF_ADD(&S.freq_ll[lit], 1u);
-        st.p = p + 1;
-        FQTK_LZ_MARK(7);
+        return true;
     }
-    FQTK_LZ_MARK(3);
+    if (!(FQTK_BGZF_ABL & 1)) FQTK_BGZF_ADD(&S.freq_ll[wa & 0xFFu], 1u);
+    st.p = p + 1;
+    FQTK_LZ_MARK(7);
+    if (!two) return true;
+    if (lz_candidates(lane, p + 1, b, qpos)) lz_match(S, n, p + 1, st, wb, wb4, qpos, mlen, mdist);
+    FQTK_LZ_MARK(2);
+    if (mlen) {
+        lz_take(S, lane, n, tok, st, p + 1, mlen, mdist);
+        FQTK_LZ_MARK(6);
+        return true;
+    }
+    if (!(FQTK_BGZF_ABL & 1)) FQTK_BGZF_ADD(&S.freq_ll[wb & 0xFFu], 1u);
+    st.p = p + 2;
+    FQTK_LZ_MARK(7);
     return true;
 }
 FQTK_HD inline void lz_end(Shared &S, int lane, const LzLane &st) {
     S.ntok[lane] = (uint16_t)st.nt;
     S.span[lane] = st.p;   // >= the slice's end when the last match ran on (a lane without bytes: its slice's start)
 }
-FQTK_HD inline void phase_lz(Shared &S, int lane, uint32_t n, uint32_t *tok) {
+FQTK_HD inline void phase_lz(Shared &S, int lane, uint32_t n, uint32_t *tok, uint64_t cheap_mask) {
     LzLane st;
 #if defined(FQTK_BGZF_PHASE_TIMES) && defined(__HIP_DEVICE_COMPILE__)
     uint64_t lz_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, lz_t = __builtin_readcyclecounter();
-    lz_begin(S, lane, n, st);
+    lz_begin(S, lane, n, st, cheap_mask);
     { const uint64_t now_ = __builtin_readcyclecounter(); lz_acc[4] += now_ - lz_t; lz_t = now_; }
     uint64_t steps = 0;
     while (lz_step(S, lane, n, tok, st, lz_acc, lz_t)) { ++steps; }
@@ -718,7 +813,7 @@ FQTK_HD inline void phase_lz(Shared &S, int lane, uint32_t n, uint32_t *tok) {
         atomicAdd(&g_lz_cycles[9], 1ull);
     }
 #else
-    lz_begin(S, lane, n, st);
+    lz_begin(S, lane, n, st, cheap_mask);
     while (lz_step(S, lane, n, tok, st)) {}
 #endif
     lz_end(S, lane, st);

@@ -62,13 +62,15 @@ void deflate_kernel(const fqtk_bgzf_block *blocks, uint32_t n_blocks, const uint
             __syncthreads();
             continue;
         }
-        phase_index(S, lane, n);
+        phase_count(S, lane, n);
         __syncthreads();
-        FQTK_PHASE_MARK(1);
         phase_literal_costs(S, lane, n);
         __syncthreads();
         FQTK_PHASE_MARK(2);
-        phase_lz(S, lane, n, tok);
+        const uint64_t cheap_mask = phase_index(S, lane, n);
+        __syncthreads();
+        FQTK_PHASE_MARK(1);
+        phase_lz(S, lane, n, tok, cheap_mask);
         __syncthreads();
         {
             uint32_t span;

@@ -304,18 +304,20 @@ int64_t fqtk_host_bgzf_deflate_level(const uint8_t *in, uint32_t n, uint8_t *out
     S.effort = effort_of_level((uint32_t)level);
     std::vector<uint32_t> tok(kTokensPerBlock);
     for (int l = 0; l < kLanes; ++l) phase_load(S, l, in, n);
-    for (int l = 0; l < kLanes; ++l) phase_index(S, l, n);
+    for (int l = 0; l < kLanes; ++l) phase_count(S, l, n);
     for (int l = 0; l < kLanes; ++l) phase_literal_costs(S, l, n);
+    std::vector<uint64_t> cheap(kLanes);
+    for (int l = 0; l < kLanes; ++l) cheap[l] = phase_index(S, l, n);
     if (lockstep) {
         std::vector<LzLane> st(kLanes);
-        for (int l = 0; l < kLanes; ++l) lz_begin(S, l, n, st[l]);
+        for (int l = 0; l < kLanes; ++l) lz_begin(S, l, n, st[l], cheap[l]);
         for (bool any = true; any;) {
             any = false;
             for (int l = 0; l < kLanes; ++l) any = lz_step(S, l, n, tok.data(), st[l]) || any;
         }
         for (int l = 0; l < kLanes; ++l) lz_end(S, l, st[l]);
     } else
-    for (int l = 0; l < kLanes; ++l) phase_lz(S, l, n, tok.data());
+    for (int l = 0; l < kLanes; ++l) phase_lz(S, l, n, tok.data(), cheap[l]);
     {   // (every lane reads its neighbours' ends before any span is replaced: a barrier on the device)
         std::vector<uint32_t> span(kLanes);
         for (int l = 0; l < kLanes; ++l) phase_reach(S, l, tok.data(), &span[l]);
