@@ -596,7 +596,7 @@ FQTK_HD inline void lz_begin(Shared &S, int lane, uint32_t n, LzLane &st, uint64
 #if defined(FQTK_BGZF_PHASE_TIMES) && defined(__HIPCC__)
 __device__ unsigned long long g_lz_cycles[10];   // setup, candidate reads + literal costs, extension, token + inserts, steps
 #endif
-#if defined(FQTK_BGZF_PHASE_TIMES) && defined(__HIP_DEVICE_COMPILE__)
+#if defined(FQTK_BGZF_LZ_TIMES) && defined(__HIP_DEVICE_COMPILE__)   // (marks inside the LZ loop: they slow it down a lot)
 #define FQTK_LZ_MARK(k) do { const uint64_t now_ = __builtin_readcyclecounter(); lz_acc[k] += now_ - lz_t; lz_t = now_; } while (0)
 #else
 #define FQTK_LZ_MARK(k) do { } while (0)
@@ -659,18 +659,26 @@ FQTK_HD inline void lz_match(Shared &S, uint32_t n, uint32_t p, const LzLane &st
     maxl = maxl < 258u ? maxl : 258u;
 #endif
     if ((FQTK_BGZF_ABL & 8) && maxl > 8u) maxl = 8u;
-    // the candidates' first eight bytes: all are read before any is looked at (every dependent LDS round trip is paid
-    // in full, so the reads go out together)
+    // The candidates' first four bytes, all read before any is looked at (every dependent LDS round trip is paid in full, so
+    // the reads go out together).  Five check bits let one entry in thirty through whose gram is another: among the 64
+    // lanes of a wavefront there is nearly always one, and it leaves here -- before the literal costs, the second four
+    // bytes and the arithmetic below are paid for by the whole wavefront.
     uint32_t first[kCands], second[kCands];
+    bool real = false;
 #if defined(__HIP_DEVICE_COMPILE__)
 #pragma unroll
 #endif
     for (int c = 0; c < kCands; ++c) {
-        uint32_t there[2];
-        buf_run<2>(S.buf, qpos[c], there);
+        uint32_t there[1];
+        buf_run<1>(S.buf, qpos[c], there);
         first[c] = there[0];
-        second[c] = there[1];
+        real = real || (qpos[c] != p && first[c] == w);
     }
+    if (!real || (FQTK_BGZF_ABL & 32)) return;
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+    for (int c = 0; c < kCands; ++c) second[c] = buf_le32(S.buf, qpos[c] + 4u);
     // what the bytes cost as literals: exactly for the first eight, the block's average beyond (every long match pays for
     // itself many times over; the estimate only ranks long candidates among themselves)
     uint32_t lit8[9];
@@ -717,13 +725,8 @@ FQTK_HD inline void lz_match(Shared &S, uint32_t n, uint32_t p, const LzLane &st
     }
 }
 
-// A match at p is taken: its symbols counted, its token stored, the positions it skips entered into the lane's table.
+// A match at p is taken: its token stored (phase_reach counts its symbols), the positions it skips entered into the lane's table.
 FQTK_HD inline void lz_take(Shared &S, int lane, uint32_t n, uint32_t *tok, LzLane &st, uint32_t p, uint32_t mlen, uint32_t mdist) {
-    uint32_t sym, ne, ev;
-    length_symbol(mlen, sym, ne, ev);
-    FQTK_BGZF_ADD(&S.freq_ll[sym], 1u);
-    dist_symbol(mdist, sym, ne, ev);
-    FQTK_BGZF_ADD(&S.freq_d[sym], 1u);
     if (!(FQTK_BGZF_ABL & 2)) tok[st.nt * kLanes + (uint32_t)lane] = match_token(mlen, mdist, p - (uint32_t)lane * kChunk);
     ++st.nt;
     // the positions skipped are recent history too: the first four and the last four of them (a long match is a run or a
@@ -746,7 +749,7 @@ FQTK_HD inline void lz_take(Shared &S, int lane, uint32_t n, uint32_t *tok, LzLa
 // step of its own: it sees the first position in the lane's table when both share a slot, and when the first position
 // starts a match, the second is among the positions the match enters into the table anyway.  False when the slice is done.
 FQTK_HD inline bool lz_step(Shared &S, int lane, uint32_t n, uint32_t *tok, LzLane &st
-#if defined(FQTK_BGZF_PHASE_TIMES) && defined(__HIP_DEVICE_COMPILE__)
+#if defined(FQTK_BGZF_LZ_TIMES) && defined(__HIP_DEVICE_COMPILE__)   // (marks inside the LZ loop: they slow it down a lot)
                             , uint64_t (&lz_acc)[8], uint64_t &lz_t
 #endif
 ) {
@@ -772,7 +775,10 @@ FQTK_HD inline bool lz_step(Shared &S, int lane, uint32_t n, uint32_t *tok, LzLa
     uint32_t qpos[kCands], mlen = 0, mdist = 0;
     // (A lazy step -- take the literal when the next position holds a longer match that saves more, zlib's levels 4-9 -- was
     //  measured on the CPU run of these phases: 0.0 % / -0.4 % of the output on varied / binned qualities.  Not kept.)
-    if (lz_candidates(lane, p, a, qpos)) lz_match(S, n, p, st, wa, wa4, qpos, mlen, mdist);
+    if (lz_candidates(lane, p, a, qpos)) {
+        if (FQTK_BGZF_ABL & 16) st.avg16 += qpos[0] + qpos[1] + qpos[2]; else   // (ablation: the candidates are worked out, nothing is compared)
+        lz_match(S, n, p, st, wa, wa4, qpos, mlen, mdist);
+    }
     FQTK_LZ_MARK(2);
     if (mlen) {
         lz_take(S, lane, n, tok, st, p, mlen, mdist);
@@ -783,7 +789,10 @@ FQTK_HD inline bool lz_step(Shared &S, int lane, uint32_t n, uint32_t *tok, LzLa
     st.p = p + 1;
     FQTK_LZ_MARK(7);
     if (!two) return true;
-    if (lz_candidates(lane, p + 1, b, qpos)) lz_match(S, n, p + 1, st, wb, wb4, qpos, mlen, mdist);
+    if (lz_candidates(lane, p + 1, b, qpos)) {
+        if (FQTK_BGZF_ABL & 16) st.avg16 += qpos[0] + qpos[1] + qpos[2]; else
+        lz_match(S, n, p + 1, st, wb, wb4, qpos, mlen, mdist);
+    }
     FQTK_LZ_MARK(2);
     if (mlen) {
         lz_take(S, lane, n, tok, st, p + 1, mlen, mdist);
@@ -797,11 +806,11 @@ FQTK_HD inline bool lz_step(Shared &S, int lane, uint32_t n, uint32_t *tok, LzLa
 }
 FQTK_HD inline void lz_end(Shared &S, int lane, const LzLane &st) {
     S.ntok[lane] = (uint16_t)st.nt;
-    S.span[lane] = st.p;   // >= the slice's end when the last match ran on (a lane without bytes: its slice's start)
+    S.span[lane] = (FQTK_BGZF_ABL & 16) ? st.p + (st.avg16 & 0u) : st.p;   // >= the slice's end when the last match ran on (a lane without bytes: its slice's start)
 }
 FQTK_HD inline void phase_lz(Shared &S, int lane, uint32_t n, uint32_t *tok, uint64_t cheap_mask) {
     LzLane st;
-#if defined(FQTK_BGZF_PHASE_TIMES) && defined(__HIP_DEVICE_COMPILE__)
+#if defined(FQTK_BGZF_LZ_TIMES) && defined(__HIP_DEVICE_COMPILE__)   // (marks inside the LZ loop: they slow it down a lot)
     uint64_t lz_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, lz_t = __builtin_readcyclecounter();
     lz_begin(S, lane, n, st, cheap_mask);
     { const uint64_t now_ = __builtin_readcyclecounter(); lz_acc[4] += now_ - lz_t; lz_t = now_; }
@@ -823,9 +832,9 @@ FQTK_HD inline void phase_lz(Shared &S, int lane, uint32_t n, uint32_t *tok, uin
 // match of a slice was allowed to run on into the next ones (cutting every match at a 64-byte boundary cost 2-4 % of the
 // output: a header line, a run of equal qualities became two or three matches).  So a lane's bytes begin where the
 // matches of the lanes before it end -- the largest of at most five values, a match being at most 258 bytes long -- and
-// what its own parse said about the bytes before that point is taken back: literals and whole matches leave the
-// symbol counts, a match that straddles the point is cut at its front (shorter than three bytes: its rest become
-// literals).  Nothing is parsed again, and no lane waits for another: the ends are those of the first parse, which
+// what its own parse said about the bytes before that point is taken back: literals leave the symbol counts (matches are
+// counted here in the first place), a match that straddles the point is cut at its front (shorter than three bytes: its
+// rest become literals).  Nothing is parsed again, and no lane waits for another: the ends are those of the first parse, which
 // stay valid however a match is cut at its front.
 constexpr int kReachLanes = (int)((257u + kChunk - 1u) / kChunk);
 FQTK_HD inline void count_match(Shared &S, uint32_t len, uint32_t dist, uint32_t by) {
@@ -842,7 +851,7 @@ FQTK_HD inline void phase_reach(Shared &S, int lane, uint32_t *tok, uint32_t *sp
     for (int i = 1; i <= kReachLanes; ++i)
         if (lane >= i) { const uint32_t r = S.span[lane - i]; start = r > start ? r : start; }
     const uint32_t nm = S.ntok[lane];
-    uint32_t first = 0;
+    uint32_t first = 0, cut = 0;
     if (start > lo) {
         const uint32_t stop = start < reach ? start : reach;
         uint32_t m = 0, next = nm ? tok[(uint32_t)lane] : 0u;
@@ -850,7 +859,6 @@ FQTK_HD inline void phase_reach(Shared &S, int lane, uint32_t *tok, uint32_t *sp
         for (uint32_t p = lo; p < stop;) {
             if (p == next_pos) {
                 const uint32_t len = token_len(next), dist = token_dist(next);
-                count_match(S, len, dist, 0xFFFFFFFFu);   // - 1
                 first = m + 1;
                 if (p + len > start) {   // (then start < reach: this lane keeps the match's rest)
                     const uint32_t rest = p + len - start;
@@ -858,6 +866,7 @@ FQTK_HD inline void phase_reach(Shared &S, int lane, uint32_t *tok, uint32_t *sp
                         tok[m * kLanes + (uint32_t)lane] = match_token(rest, dist, start - lo);
                         count_match(S, rest, dist, 1u);
                         first = m;
+                        cut = 1;
                     } else {
                         for (uint32_t k = 0; k < rest; ++k) FQTK_BGZF_ADD(&S.freq_ll[buf_byte(S.buf, start + k)], 1u);
                     }
@@ -871,6 +880,20 @@ FQTK_HD inline void phase_reach(Shared &S, int lane, uint32_t *tok, uint32_t *sp
                 ++p;
             }
         }
+    }
+    // The symbols of the matches that stay are counted here, all lanes side by side, four tokens per round trip -- not where
+    // a match is taken: there the other lanes of the wavefront, busy with literals, paid for the arithmetic every time.
+    for (uint32_t m0 = first + cut; m0 < nm; m0 += 4u) {
+        uint32_t t[4];
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+        for (uint32_t k = 0; k < 4u; ++k) t[k] = m0 + k < nm ? tok[(m0 + k) * kLanes + (uint32_t)lane] : 0u;
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+        for (uint32_t k = 0; k < 4u; ++k)
+            if (m0 + k < nm) count_match(S, token_len(t[k]), token_dist(t[k]), 1u);
     }
     *span_out = (start < reach ? start : reach) | (reach << 16);   // (nothing left: an empty range)
     S.ntok[lane] = (uint16_t)(nm | (first << 8));
@@ -1030,19 +1053,35 @@ FQTK_HD inline void walk_tokens(Shared &S, int lane, uint32_t n, const uint32_t 
     uint32_t next_pos = m < nm ? lo + token_off(next) : 0xFFFFFFFFu;
     (void)n;
     uint32_t have = 0xFFFFFFFFu, word = 0;
-    for (uint32_t p = span & 0xFFFFu; p < hi;) {
-        if (p == next_pos) {
-            const uint32_t len = token_len(next);
-            on_match(len, token_dist(next));
-            p += len;
-            ++m;
-            next = m < nm ? tok[m * kLanes + (uint32_t)lane] : 0u;
-            next_pos = m < nm ? lo + token_off(next) : 0xFFFFFFFFu;
-        } else {
-            if ((p >> 2) != have) { have = p >> 2; word = S.buf[buf_word(have)]; }   // one read per four literals
+    // Token-major: the literals up to the lane's next match in an inner loop of their own, then the match.  (With one loop
+    // over the positions, a wavefront ran the match's arithmetic in nearly every round -- some lane is at a match -- while
+    // most lanes only had a literal to do: the rounds of 64 lanes are as many as the slowest lane's, and each then costs
+    // the literal path only.)
+    uint32_t p = span & 0xFFFFu;
+    for (;;) {
+        const uint32_t lim = next_pos < hi ? next_pos : hi;
+        for (; p < lim && (p & 3u); ++p) {   // up to a word boundary
+            if ((p >> 2) != have) { have = p >> 2; word = S.buf[buf_word(have)]; }
             on_lit((word >> (8 * (p & 3u))) & 0xFFu);
-            ++p;
         }
+        for (; p + 4u <= lim; p += 4u) {     // whole words: the four table look-ups of a round go out together
+            const uint32_t four = S.buf[buf_word(p >> 2)];
+            on_lit(four & 0xFFu);
+            on_lit((four >> 8) & 0xFFu);
+            on_lit((four >> 16) & 0xFFu);
+            on_lit(four >> 24);
+        }
+        for (; p < lim; ++p) {
+            if ((p >> 2) != have) { have = p >> 2; word = S.buf[buf_word(have)]; }
+            on_lit((word >> (8 * (p & 3u))) & 0xFFu);
+        }
+        if (p >= hi) break;
+        const uint32_t len = token_len(next);
+        on_match(len, token_dist(next));
+        p += len;
+        ++m;
+        next = m < nm ? tok[m * kLanes + (uint32_t)lane] : 0u;
+        next_pos = m < nm ? lo + token_off(next) : 0xFFFFFFFFu;
     }
 }
 
