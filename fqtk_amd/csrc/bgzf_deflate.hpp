@@ -646,24 +646,11 @@ FQTK_HD inline bool lz_candidates(int lane, uint32_t p, const LzProbe &pr, uint3
     }
     return any;
 }
-// The best of the candidates at position p: length and distance (0 = none pays for itself).
-FQTK_HD inline void lz_match(Shared &S, uint32_t n, uint32_t p, const LzLane &st, uint32_t w, uint32_t w4, const uint32_t (&qpos)[kCands],
-                             uint32_t &mlen, uint32_t &mdist) {
-    uint32_t msave = 0;
-    mlen = mdist = 0;
-#ifdef FQTK_BGZF_NO_REACH   // (study: matches cut at the slice's end, as before phase_reach existed)
-    uint32_t maxl = st.end - p < 258u ? st.end - p : 258u;
-#else
-    // a match may run past the end of the lane's slice: phase_reach (--compression-level 1-3: it may not; 7 % faster)
-    uint32_t maxl = st.effort ? n - p : st.end - p;
-    maxl = maxl < 258u ? maxl : 258u;
-#endif
-    if ((FQTK_BGZF_ABL & 8) && maxl > 8u) maxl = 8u;
-    // The candidates' first four bytes, all read before any is looked at (every dependent LDS round trip is paid in full, so
-    // the reads go out together).  Five check bits let one entry in thirty through whose gram is another: among the 64
-    // lanes of a wavefront there is nearly always one, and it leaves here -- before the literal costs, the second four
-    // bytes and the arithmetic below are paid for by the whole wavefront.
-    uint32_t first[kCands], second[kCands];
+// The candidates' first four bytes, all read before any is looked at (every dependent LDS round trip is paid in full, so the
+// reads go out together); true when one of them is the position's own.  Five check bits let one entry in thirty through
+// whose gram is another: among the 64 lanes of a wavefront there is nearly always one, and it is turned away here -- before
+// the literal costs, the second four bytes and the arithmetic of lz_rest are paid for by the whole wavefront.
+FQTK_HD inline bool lz_first(Shared &S, uint32_t p, uint32_t w, const uint32_t (&qpos)[kCands], uint32_t (&first)[kCands]) {
     bool real = false;
 #if defined(__HIP_DEVICE_COMPILE__)
 #pragma unroll
@@ -674,7 +661,22 @@ FQTK_HD inline void lz_match(Shared &S, uint32_t n, uint32_t p, const LzLane &st
         first[c] = there[0];
         real = real || (qpos[c] != p && first[c] == w);
     }
-    if (!real || (FQTK_BGZF_ABL & 32)) return;
+    return real && !(FQTK_BGZF_ABL & 32);
+}
+// The best of the candidates at position p: length and distance (0 = none pays for itself).
+FQTK_HD inline void lz_rest(Shared &S, uint32_t n, uint32_t p, const LzLane &st, uint32_t w, uint32_t w4, const uint32_t (&qpos)[kCands],
+                            const uint32_t (&first)[kCands], uint32_t &mlen, uint32_t &mdist) {
+    uint32_t msave = 0;
+    mlen = mdist = 0;
+#ifdef FQTK_BGZF_NO_REACH   // (study: matches cut at the slice's end, as before phase_reach existed)
+    uint32_t maxl = st.end - p < 258u ? st.end - p : 258u;
+#else
+    // a match may run past the end of the lane's slice: phase_reach (--compression-level 1-3: it may not; 7 % faster)
+    uint32_t maxl = st.effort ? n - p : st.end - p;
+    maxl = maxl < 258u ? maxl : 258u;
+#endif
+    if ((FQTK_BGZF_ABL & 8) && maxl > 8u) maxl = 8u;
+    uint32_t second[kCands];
 #if defined(__HIP_DEVICE_COMPILE__)
 #pragma unroll
 #endif
@@ -723,6 +725,13 @@ FQTK_HD inline void lz_match(Shared &S, uint32_t n, uint32_t p, const LzLane &st
         const uint32_t cost = match_cost(l, p - q);
         if (lit > cost && lit - cost > msave) { msave = lit - cost; mlen = l; mdist = p - q; }
     }
+}
+
+FQTK_HD inline void lz_match(Shared &S, uint32_t n, uint32_t p, const LzLane &st, uint32_t w, uint32_t w4, const uint32_t (&qpos)[kCands],
+                             uint32_t &mlen, uint32_t &mdist) {
+    uint32_t first[kCands];
+    mlen = mdist = 0;
+    if (lz_first(S, p, w, qpos, first)) lz_rest(S, n, p, st, w, w4, qpos, first, mlen, mdist);
 }
 
 // A match at p is taken: its token stored (phase_reach counts its symbols), the positions it skips entered into the lane's table.
@@ -823,6 +832,9 @@ FQTK_HD inline void phase_lz(Shared &S, int lane, uint32_t n, uint32_t *tok, uin
     }
 #else
     lz_begin(S, lane, n, st, cheap_mask);
+    // (Token-major instead -- an inner loop over literals until the lane has a real candidate, then the match code run by all
+    //  lanes that got that far together -- was measured: 40 instead of 55 GB/s.  The lanes' literal runs do not line up, and
+    //  every round waits for the longest.)
     while (lz_step(S, lane, n, tok, st)) {}
 #endif
     lz_end(S, lane, st);

@@ -27,10 +27,13 @@ def deflate(data: bytes, lockstep: int = 1):
 
 
 def roundtrip(data: bytes):
-    for lockstep in (0, 1):
+    payloads = []
+    for lockstep in (0, 1):   # lane after lane, and all lanes step by step (the tables must not care)
         payload, stored = deflate(data, lockstep)
         assert zlib.decompress(payload, -15) == data
         assert len(payload) <= len(data) + 5
+        payloads.append(payload)
+    assert payloads[0] == payloads[1]
     return len(payload), stored
 
 
