@@ -22,6 +22,129 @@ __device__ unsigned long long g_phase_ticks[12];   // [10] = the parallel part o
 #define FQTK_PHASE_MARK(k) do { } while (0)
 #endif
 
+// The 19-symbol code-length code and the fixed part of the block header, by the 64 lanes of ONE wavefront: phase_cl_code's
+// algorithm (bgzf_deflate.hpp: huffman_lengths + canonical_codes, the one-lane form the CPU tests run) with the tree in
+// registers -- node k's weight, parent and depth live in lane k of a VGPR and are read and written with v_readlane /
+// v_writelane under wave-uniform control flow.  The one-lane form is a chain of ~600 dependent LDS round trips (insertion
+// sort, two queues, depths, codes, header bits): 52 us of a block's 305 while 1023 lanes waited (tools/bgzf_phases.sh).
+__device__ inline uint32_t rdl(uint32_t v, uint32_t l) { return (uint32_t)__builtin_amdgcn_readlane((int)v, (int)l); }
+__device__ inline uint32_t wrl(uint32_t val, uint32_t l, uint32_t old) { return __lane_id() == l ? val : old; }   // (v_writelane_b32 by a select: l is wave-uniform)
+__device__ void phase_cl_code_wave(Shared &S, int lane) {   // lane = 0 .. 63 of the first wavefront
+    constexpr uint32_t kMax = 7;
+    const uint32_t cnt = lane < kNumCl ? S.freq_cl[lane] : 0u;
+    const uint64_t used = __ballot(cnt != 0u);
+    const uint32_t m = (uint32_t)__popcll(used);
+    // rank among the used symbols by (count, symbol); sym_of = the symbol of this lane's RANK
+    uint32_t rank = 0;
+    for (uint32_t j = 0; j < (uint32_t)kNumCl; ++j) {
+        const uint32_t cj = rdl(cnt, j);
+        if (cj != 0u && (cj < cnt || (cj == cnt && j < (uint32_t)lane))) ++rank;
+    }
+    uint32_t bl = 0;         // lane b: number of codes of b bits
+    uint32_t len = 0;        // lane s < 19: code length of symbol s
+    if (m == 0u) {
+        len = lane < 2 ? 1u : 0u;
+        bl = lane == 1 ? 2u : 0u;
+    } else if (m == 1u) {
+        const uint32_t s0 = (uint32_t)__ffsll((unsigned long long)used) - 1u;
+        len = ((uint32_t)lane == s0 || (uint32_t)lane == (s0 == 0u ? 1u : 0u)) ? 1u : 0u;
+        bl = lane == 1 ? 2u : 0u;
+    } else {
+        // leaves 0 .. m-1 in ascending order: lane r gets the weight of the leaf of rank r (a push through LDS: ds_permute)
+        const uint32_t to = cnt != 0u ? rank : 63u;   // (unused symbols all push to lane 63: never a node, 2 m - 1 <= 37)
+        uint32_t wv = (uint32_t)__builtin_amdgcn_ds_permute((int)(to << 2), (int)cnt);
+        uint32_t sym_of = (uint32_t)__builtin_amdgcn_ds_permute((int)(to << 2), lane);
+        uint32_t pv = 0, dv = 0;
+        uint32_t li = 0, ii = m, made = m;
+        for (uint32_t k = 0; k + 1u < m; ++k) {
+            uint32_t pick[2];
+            for (int t = 0; t < 2; ++t) {
+                const uint32_t wl = li < m ? rdl(wv, li) : 0u, wi = ii < made ? rdl(wv, ii) : 0u;
+                if (li < m && (ii >= made || wl <= wi)) pick[t] = li++;
+                else pick[t] = ii++;
+            }
+            wv = wrl(rdl(wv, pick[0]) + rdl(wv, pick[1]), made, wv);
+            pv = wrl(made, pick[0], pv);
+            pv = wrl(made, pick[1], pv);
+            ++made;
+        }
+        const uint32_t root = made - 1u;
+        uint32_t overflow = 0;
+        for (uint32_t v = root; v-- > 0u;) {   // depths top-down with zlib's rule for the length limit (huffman_lengths)
+            uint32_t bits = rdl(dv, rdl(pv, v)) + 1u;
+            if (bits > kMax) { bits = kMax; ++overflow; }
+            dv = wrl(bits, v, dv);
+            if (v < m) bl = wrl(rdl(bl, bits) + 1u, bits, bl);
+        }
+        while ((int)overflow > 0) {
+            uint32_t bits = kMax - 1u;
+            while (rdl(bl, bits) == 0u) --bits;
+            bl = wrl(rdl(bl, bits) - 1u, bits, bl);
+            bl = wrl(rdl(bl, bits + 1u) + 2u, bits + 1u, bl);
+            bl = wrl(rdl(bl, kMax) - 1u, kMax, bl);
+            overflow -= 2u;
+        }
+        // the leaf of rank r (rarest first) gets the longest length still to be given out
+        uint32_t mine = 0, before = 0;
+        for (uint32_t bits = kMax; bits >= 1u; --bits) {
+            const uint32_t c = rdl(bl, bits);
+            if (mine == 0u && (uint32_t)lane < before + c) mine = bits;
+            before += c;
+        }
+        if ((uint32_t)lane >= m) mine = 0;
+        // back to symbol order: lane r pushes its length to lane sym_of
+        len = (uint32_t)__builtin_amdgcn_ds_permute((int)(((uint32_t)lane < m ? sym_of : 63u) << 2), (int)mine);
+        if (lane >= kNumCl) len = 0;
+    }
+    if (lane < kNumCl) S.len_cl[lane] = (uint8_t)len;
+    if (lane <= 16) S.bl_count[lane] = lane == 0 ? 0u : bl;
+    // canonical code of symbol `lane`: first code of its length + number of lower symbols of the same length
+    uint32_t first_code = 0;
+    {
+        uint32_t c = 0;
+        for (uint32_t b = 1; b <= kMax; ++b) {
+            c = (c + (b > 1u ? rdl(bl, b - 1u) : 0u)) << 1;
+            if (b == len) first_code = c;
+        }
+    }
+    uint32_t lower = 0;
+    for (uint32_t j = 0; j < (uint32_t)kNumCl; ++j) {
+        const uint32_t lj = rdl(len, j);
+        if (j < (uint32_t)lane && lj == len) ++lower;
+    }
+    if (lane < kNumCl) S.code_cl[lane] = len ? (uint16_t)reverse_bits(first_code + lower, (int)len) : (uint16_t)0;
+    // header: BFINAL, BTYPE = 2, HLIT, HDIST, HCLEN, then the code lengths in RFC 1951's order, three bits each
+    uint32_t my_sym = 0;
+    switch (lane) {
+        case 0: my_sym = 16; break; case 1: my_sym = 17; break; case 2: my_sym = 18; break; case 3: my_sym = 0; break;
+        case 4: my_sym = 8; break; case 5: my_sym = 7; break; case 6: my_sym = 9; break; case 7: my_sym = 6; break;
+        case 8: my_sym = 10; break; case 9: my_sym = 5; break; case 10: my_sym = 11; break; case 11: my_sym = 4; break;
+        case 12: my_sym = 12; break; case 13: my_sym = 3; break; case 14: my_sym = 13; break; case 15: my_sym = 2; break;
+        case 16: my_sym = 14; break; case 17: my_sym = 1; break; case 18: my_sym = 15; break; default: my_sym = 0; break;
+    }
+    const uint32_t my_len = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(my_sym << 2), (int)len);   // pull: len of symbol my_sym
+    const uint64_t nz = __ballot(lane < kNumCl && my_len != 0u);
+    uint32_t hclen = nz ? 64u - (uint32_t)__builtin_clzll((unsigned long long)nz) : 0u;
+    if (hclen < 4u) hclen = 4u;
+    if (lane == 0) {
+        BitWriter w;
+        w.start(out_image(S), 0);
+        w.put(1, 1);
+        w.put(2, 2);
+        w.put(S.hlit - 257u, 5);
+        w.put(S.hdist - 1u, 5);
+        w.put(hclen - 4u, 4);
+        w.finish();
+        S.fixed_header_bits = 17u + 3u * hclen;
+    }
+    if ((uint32_t)lane < hclen) {
+        BitWriter w;
+        w.start(out_image(S), 17u + 3u * (uint32_t)lane);
+        w.put(my_len, 3);
+        w.finish();
+    }
+}
+
 __global__ __launch_bounds__(kLanes) __attribute__((amdgpu_waves_per_eu(kLanes / 256, kLanes / 256)))   // one workgroup per CU (LDS): registers are free
 void deflate_kernel(const fqtk_bgzf_block *blocks, uint32_t n_blocks, const uint32_t *n_blocks_dev,
                                                          uint32_t *out_len, uint32_t *crc_out, uint32_t *tok_all, uint32_t level) {
@@ -41,6 +164,8 @@ void deflate_kernel(const fqtk_bgzf_block *blocks, uint32_t n_blocks, const uint
         const uint8_t *in = blocks[j].in;
         uint8_t *out = blocks[j].out;
         const uint32_t n = blocks[j].n_in;
+        // (Fetching the next block into registers while this one is coded -- before the emit phase, or before the code
+        //  construction -- moved the ~10 us of a block's read from this phase into that one: the kernel ran no faster.)
         phase_load(S, lane, in, n);
         __syncthreads();
         if (crc_out) {
@@ -92,7 +217,7 @@ void deflate_kernel(const fqtk_bgzf_block *blocks, uint32_t n_blocks, const uint
         __syncthreads();
         phase_cl_emit(S, lane);
         __syncthreads();
-        if (lane == 0) phase_cl_code(S);        // one lane builds the 19-symbol code ...
+        if (lane < 64) phase_cl_code_wave(S, lane);   // the first wavefront builds the 19-symbol code ...
         phase_count_bits(S, lane, n, tok);      // ... while all lanes add up the bits of their tokens (needs the two big codes only)
         __syncthreads();
         FQTK_PHASE_MARK(6);
