@@ -454,6 +454,10 @@ def main() -> int:
                                               n_chunk=min(8_000_000, max(job_reads // 4, 1)))
             scopes["B_packed"] = scope_bench.scope_b_packed(args.config, matcher=matcher, workload=workload,
                                                             n_chunk=min(8_000_000, max(job_reads // 4, 1)))
+            import bgzf_bench   # (tools/)
+            scopes["bgzf_kernel"] = bgzf_bench.measure(blocks=2048, reps=3, where_list=("hbm",))
+            scopes["bgzf_kernel"]["what"] = ("fqtk::bgzf::deflate_kernel alone: 2048 BGZF blocks of Illumina-style text in HBM -> DEFLATE payloads + CRC-32 in HBM "
+                                             "(the compressor of scope E's output path, BgzfCompressor demux.rs:755-798); ratio = output / input")
             tmp = scope_bench.scratch_dir(args.e2e_templates * 900)
             try:
                 expect = None

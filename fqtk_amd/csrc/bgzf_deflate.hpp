@@ -409,8 +409,8 @@ FQTK_HD inline uint32_t ctz32(uint32_t x) {   // x != 0
 #endif
 }
 
-// --compression-level (demux.rs:641-643) -> parse effort: 1-3 two match candidates per position (output +1.0-1.6 %), 4 and
-// up three (the default is 5); level 0 does not come here (stored blocks).
+// --compression-level (demux.rs:641-643) -> parse effort: 1-3 every match is cut at its lane's slice (7 % faster, output
+// +2-5 %), 4 and up a slice's last match runs on (phase_reach; the default is 5); level 0 does not come here (stored blocks).
 FQTK_HD inline uint32_t effort_of_level(uint32_t level) { return level <= 3u ? 0u : 1u; }
 
 // P0: clear the shared state, bring the block in.  `in` may be device or (pinned, device-visible) host memory.

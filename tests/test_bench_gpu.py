@@ -28,7 +28,8 @@ def test_bench_line_carries_scopes_create_time_cpu_rows_and_the_full_parity_gate
                     "--e2e-templates", "4000000", "--e2e-threads", "8"]))
     assert d["n_gpus"] == 1 and d["unit"] == "M reads/s" and d["value"] > 0
     assert "bit-exact" in d["config"]["parity"] and "count vector of all 3000000 reads" in d["config"]["parity"]
-    assert set(d["scopes"]) == {"K", "B", "B_packed", "E", "E_host", "E_gz"}
+    assert set(d["scopes"]) == {"K", "B", "B_packed", "bgzf_kernel", "E", "E_host", "E_gz"}
+    assert d["scopes"]["bgzf_kernel"]["hbm"]["GB_per_s_in"] > 5 and 0.2 < d["scopes"]["bgzf_kernel"]["hbm"]["ratio"] < 0.5
     assert d["scopes"]["B_packed"]["M_reads_per_s"] > 0 and d["scopes"]["B_packed"]["packed_bytes_per_read"] == 8
     for k, n in (("E", 4000000), ("E_host", 1000000), ("E_gz", 1000000)):   # device output (default), host output, gzip inputs
         assert d["scopes"][k]["templates"] == n and d["scopes"][k]["metrics_vs_oracle"] == "per-sample counts identical"

@@ -34,12 +34,18 @@ def main():
     ap.add_argument("--reps", type=int, default=5)
     ap.add_argument("--const-qual", action="store_true", help="every quality 'I' (scope E's synthetic records: long runs)")
     a = ap.parse_args()
+    print(json.dumps(measure(a.blocks, a.reps, a.const_qual)))
+
+
+def measure(blocks=4096, reps=5, const_qual=False, where_list=("hbm", "pinned_host")):
+    """GB/s of input and output / input of fqtk::bgzf::deflate_kernel over `blocks` 65 280-byte blocks of Illumina-style text
+    (also bench.py's scopes.bgzf_kernel)."""
     import torch
     lib = _lib.load()
     rng = np.random.default_rng(1)
-    text = fastq_text(4000, rng, b"I") if a.const_qual else fastq_text(4000, rng)
+    text = fastq_text(4000, rng, b"I") if const_qual else fastq_text(4000, rng)
     uniq = [text[o:o + 65280] for o in range(0, len(text) - 65280, 65280)]
-    n = a.blocks
+    n = blocks
     host_in = np.zeros((n, 65536), dtype=np.uint8)
     for i in range(n):
         b = uniq[i % len(uniq)]
@@ -47,7 +53,7 @@ def main():
     z = C.c_void_p()
     assert lib.fqtk_bgzf_create(0, C.byref(z)) == 0
     out = {"blocks": n, "block_bytes": 65280}
-    for where in ("hbm", "pinned_host"):
+    for where in where_list:
         if where == "hbm":
             d_in = torch.from_numpy(host_in).cuda()
             d_out = torch.zeros((n, 65536), dtype=torch.uint8, device="cuda")
@@ -73,7 +79,7 @@ def main():
             desc_host[:, 2] = 65280
             C.memmove(p_desc, desc_host.ctypes.data, desc_host.nbytes)
         times = []
-        for rep in range(a.reps + 1):
+        for rep in range(reps + 1):
             t0 = time.perf_counter()
             assert lib.fqtk_bgzf_deflate_enqueue(z, 0, p_desc, n, p_len) == 0
             assert lib.fqtk_bgzf_wait(z, 0) == 0
@@ -93,7 +99,8 @@ def main():
     for b in uniq[:20]:
         cpu.append(len(zlib.compress(b, 5)))
     out["zlib_level5_1core_GB_per_s"] = round(20 * 65280 / (time.perf_counter() - t0) / 1e9, 3)
-    print(json.dumps(out))
+    lib.fqtk_bgzf_destroy(z)
+    return out
 
 
 if __name__ == "__main__":
