@@ -128,6 +128,7 @@ struct Shared {
 static_assert(offsetof(Shared, near_tab) == offsetof(Shared, tminmax) + sizeof(uint32_t) * ((kRegions + 1u) << kHashBits), "the two tables are one 64 KiB array");
 static_assert(sizeof(uint32_t) * ((kRegions + 1u) << kHashBits) + sizeof(uint16_t) * kNearSlots * kLanes >= kOutStride, "the output image fits the tables' place");
 static_assert(sizeof(Shared) <= 160 * 1024, "one workgroup's LDS");
+static_assert(offsetof(Shared, run_syms) % 4 == 0 && offsetof(Shared, len_ll) % 4 == 0 && offsetof(Shared, len_d) % 4 == 0, "code lengths are read four at a time (canonical_code_of)");
 FQTK_HD inline uint32_t *out_image(Shared &S) { return S.tminmax; }
 
 // ---- symbol arithmetic (RFC 1951 3.2.5), computed rather than tabulated -------------------------------------
@@ -273,8 +274,23 @@ FQTK_HD inline uint16_t canonical_code_of(const uint8_t *len, int sym, const uin
     if (!l) return 0;
     uint32_t c = 0;
     for (int b = 1; b <= l && b <= max_bits; ++b) c = (c + (b > 1 ? bl_count[b - 1] : 0u)) << 1;
+    // how many lower symbols have the same length: four lengths per read, compared as one word, eight reads in flight -- a byte per round trip made this loop, up to 285 rounds on one lane's
+    // latency, a tenth of a block's time
+    const uint32_t *words = reinterpret_cast<const uint32_t *>(len);   // (len_ll / len_d / len_cl begin on a word: static_assert below)
+    const uint32_t same = (uint32_t)l * 0x01010101u;
+    const int full = sym >> 2;
     uint32_t rank = 0;
-    for (int j = 0; j < sym; ++j) rank += len[j] == l ? 1u : 0u;
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll 8
+#endif
+    for (int q = 0; q < full; ++q) {
+        const uint32_t y = words[q] ^ same;   // (every byte < 16: adding 0x7F sets a byte's top bit iff it is not zero, without a carry)
+        rank += 4u - (uint32_t)__builtin_popcount((y + 0x7F7F7F7Fu) & 0x80808080u);
+    }
+    if (sym & 3) {
+        const uint32_t y = (words[full] ^ same) | (0x01010101u << (8 * (sym & 3)));   // (the symbol itself and those above it do not count)
+        rank += 4u - (uint32_t)__builtin_popcount((y + 0x7F7F7F7Fu) & 0x80808080u);
+    }
     return (uint16_t)reverse_bits(c + rank, l);
 }
 // the same for a whole set by one lane (the 19-symbol code-length code)
@@ -926,6 +942,9 @@ FQTK_HD inline void phase_clear_out(Shared &S, int lane) {
         const uint32_t c = count_of(sym);
         if (!c) continue;
         uint32_t rank = 0;
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll 8   // (eight reads in flight: a read per round trip made these 286 rounds 14 us of a block's 290)
+#endif
         for (int j = 0; j < kNumLitLen; ++j) {
             const uint32_t cj = count_of(j);
             rank += (cj != 0u && (cj < c || (cj == c && j < sym))) ? 1u : 0u;
@@ -939,6 +958,9 @@ FQTK_HD inline void phase_clear_out(Shared &S, int lane) {
         const uint32_t c = S.freq_d[d];
         if (c) {
             uint32_t rank = 0;
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll 10
+#endif
             for (int j = 0; j < kNumDist; ++j) {
                 const uint32_t cj = S.freq_d[j];
                 rank += (cj != 0u && (cj < c || (cj == c && j < d))) ? 1u : 0u;
@@ -995,8 +1017,23 @@ FQTK_HD inline void phase_cl_runs(Shared &S, int lane) {
     for (uint32_t i = (uint32_t)lane; i < total; i += kLanes) {
         const uint32_t v = cl_length_at(S, i);
         if (i && cl_length_at(S, i - 1) == v) { S.run_syms[i] = 0; continue; }
+        // the run's length, eight lengths per round trip (a run of unused symbols is up to 138+ long, and a lane that walks it
+        // one read at a time holds up the whole workgroup)
         uint32_t r = 1;
-        while (i + r < total && cl_length_at(S, i + r) == v) ++r;
+        for (;;) {
+            uint32_t vals[8];
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+            for (uint32_t k = 0; k < 8u; ++k) vals[k] = i + r + k < total ? cl_length_at(S, i + r + k) : 0xFFFFFFFFu;
+            uint32_t k = 0;
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+            for (uint32_t q = 0; q < 8u; ++q) k += (k == q && vals[q] == v) ? 1u : 0u;
+            r += k;
+            if (k < 8u) break;
+        }
         S.run_len[i] = (uint16_t)r;
         S.run_syms[i] = (uint16_t)cl_code_run(v, r, nullptr, nullptr);
     }
@@ -1007,8 +1044,13 @@ FQTK_HD inline void phase_cl_emit(Shared &S, int lane) {
     for (uint32_t i = (uint32_t)lane; i < total; i += kLanes) {
         const uint32_t n = S.run_syms[i];
         if (!n) continue;
-        uint32_t off = 0;
-        for (uint32_t j = 0; j < i; ++j) off += S.run_syms[j];
+        uint32_t off = 0;   // symbols of the runs before this one: two counts per read, eight reads in flight
+        const uint32_t *pairs = reinterpret_cast<const uint32_t *>(S.run_syms);
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll 8
+#endif
+        for (uint32_t j = 0; j < (i >> 1); ++j) { const uint32_t two = pairs[j]; off += (two & 0xFFFFu) + (two >> 16); }
+        if (i & 1u) off += S.run_syms[i - 1u];
         cl_code_run(cl_length_at(S, i), S.run_len[i], S.cl_sym + off, S.cl_extra + off);
         for (uint32_t k = 0; k < n; ++k) FQTK_BGZF_ADD(&S.freq_cl[S.cl_sym[off + k]], 1u);
         FQTK_BGZF_ADD(&S.n_cl, n);
@@ -1041,6 +1083,9 @@ FQTK_HD inline void phase_cl_bits(Shared &S, int lane) {
     const uint32_t n = S.n_cl;
     for (uint32_t k = (uint32_t)lane; k < n; k += kLanes) {
         uint32_t pos = S.fixed_header_bits;
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll 8
+#endif
         for (uint32_t j = 0; j < k; ++j) pos += cl_symbol_bits(S, j);
         const uint32_t s = S.cl_sym[k];
         BitWriter w;

@@ -213,6 +213,7 @@ void deflate_kernel(const fqtk_bgzf_block *blocks, uint32_t n_blocks, const uint
         FQTK_PHASE_MARK(5);
         phase_codes(S, lane);
         __syncthreads();
+        FQTK_PHASE_MARK(11);
         phase_cl_runs(S, lane);
         __syncthreads();
         phase_cl_emit(S, lane);

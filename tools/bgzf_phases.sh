@@ -15,8 +15,8 @@ sys.argv = ["bgzf_bench.py"] + os.environ.get("BENCH_ARGS", "").split()
 runpy.run_path("tools/bgzf_bench.py", run_name="__main__")
 t = (C.c_ulonglong * 12)()
 assert lib.fqtk_bgzf_dev_phase_ticks(t) == 0
-names = ["load", "index", "literal costs", "lz", "clear + rank", "code lengths (two lanes)", "count bits", "offsets", "emit", "store", "codes + header (all lanes, 19-symbol code by one)"]
-tot = sum(t[:11])
+names = ["load", "index", "count + literal costs", "lz + reach", "clear + rank", "code lengths (two lanes)", "code-length runs + 19-symbol code || count bits", "offsets", "emit", "store", "header bits", "canonical codes"]
+tot = sum(t[:12])
 for k, nme in enumerate(names):
     print(f"{nme:28s} {100.0 * t[k] / tot:5.1f} %")
 z = (C.c_ulonglong * 10)()
