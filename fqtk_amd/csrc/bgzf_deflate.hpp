@@ -950,6 +950,7 @@ FQTK_HD inline void phase_clear_out(Shared &S, int lane) {
             rank += (cj != 0u && (cj < c || (cj == c && j < sym))) ? 1u : 0u;
         }
         S.sorted[rank] = (uint16_t)sym;
+        S.weight[rank] = c;   // (the leaves of the code builder, in its order)
         FQTK_BGZF_ADD(&S.m_ll, 1u);
     }
     // the distance symbols likewise, by lanes of another wavefront
@@ -966,6 +967,7 @@ FQTK_HD inline void phase_clear_out(Shared &S, int lane) {
                 rank += (cj != 0u && (cj < c || (cj == c && j < d))) ? 1u : 0u;
             }
             S.sorted_d[rank] = (uint16_t)d;
+            S.weight_d[rank] = c;
             FQTK_BGZF_ADD(&S.m_d, 1u);
         }
     }

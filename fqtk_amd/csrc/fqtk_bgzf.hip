@@ -22,6 +22,74 @@ __device__ unsigned long long g_phase_ticks[12];   // [10] = the parallel part o
 #define FQTK_PHASE_MARK(k) do { } while (0)
 #endif
 
+// The code lengths of the two big codes (huffman_lengths of bgzf_deflate.hpp, the one-lane form the CPU tests run), in four
+// steps with the serial part cut down to what is serial: (a) the two-queue tree construction by one lane per code -- the
+// four queue heads it can need are read together, one LDS round trip per merge instead of four or five; (b) every node's
+// depth by a lane of its own, walking up the parents (zlib's length limit puts a node deeper than max_bits AT max_bits and
+// its children see that: the depth is min(true depth, max_bits), and every node below the limit is one overflow);
+// (c) the repair of an over-subscribed code by one lane; (d) every leaf's length by a lane of its own.
+struct CodeJob { const uint16_t *sorted; uint32_t *weight; uint16_t *parent; uint32_t *bl_count; uint8_t *len; uint32_t m; uint32_t *overflow; };
+__device__ inline CodeJob code_job(Shared &S, int which) {
+    return which == 0 ? CodeJob{S.sorted, S.weight, S.parent, S.bl_count, S.len_ll, S.m_ll, &S.next_code[0]}
+                      : CodeJob{S.sorted_d, S.weight_d, S.parent_d, S.bl_count_d, S.len_d, S.m_d, &S.next_code[1]};
+}
+__device__ void code_tree(const CodeJob &J) {   // (a): one lane
+    for (int b = 0; b <= 16; ++b) J.bl_count[b] = 0;
+    *J.overflow = 0;
+    const uint32_t m = J.m;
+    if (m == 0u) { J.len[0] = 1; J.len[1] = 1; J.bl_count[1] = 2; return; }
+    if (m == 1u) { J.len[J.sorted[0]] = 1; J.len[J.sorted[0] == 0 ? 1 : 0] = 1; J.bl_count[1] = 2; return; }
+    constexpr uint32_t kInf = 0xFFFFFFFFu;
+    uint32_t li = 0, ii = m, made = m;
+    for (uint32_t k = 0; k + 1u < m; ++k) {
+        // the two smallest of the leaf queue's and the internal queue's first two (a leaf wins a tie, as in huffman_lengths)
+        uint32_t wl0 = li < m ? J.weight[li] : kInf, wl1 = li + 1u < m ? J.weight[li + 1u] : kInf;
+        uint32_t wi0 = ii < made ? J.weight[ii] : kInf, wi1 = ii + 1u < made ? J.weight[ii + 1u] : kInf;
+        uint32_t pick[2], w[2];
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            if (li < m && wl0 <= wi0) { pick[t] = li++; w[t] = wl0; wl0 = wl1; }
+            else { pick[t] = ii++; w[t] = wi0; wi0 = wi1; }
+        }
+        J.weight[made] = w[0] + w[1];
+        J.parent[pick[0]] = (uint16_t)made;
+        J.parent[pick[1]] = (uint16_t)made;
+        ++made;
+    }
+}
+__device__ void code_depth(const CodeJob &J, uint32_t v, uint32_t max_bits) {   // (b): node v < root
+    const uint32_t m = J.m;
+    if (m < 2u) return;
+    const uint32_t root = 2u * m - 2u;
+    if (v >= root) return;
+    uint32_t depth = 0;
+    for (uint32_t x = v; x != root; x = J.parent[x]) ++depth;
+    if (depth > max_bits) atomicAdd(J.overflow, 1u);
+    if (v < m) atomicAdd(&J.bl_count[depth > max_bits ? max_bits : depth], 1u);
+}
+__device__ void code_repair(const CodeJob &J, uint32_t max_bits) {   // (c): one lane
+    if (J.m < 2u) return;
+    int overflow = (int)*J.overflow;
+    while (overflow > 0) {
+        uint32_t bits = max_bits - 1u;
+        while (J.bl_count[bits] == 0u) --bits;
+        --J.bl_count[bits];
+        J.bl_count[bits + 1u] += 2u;
+        --J.bl_count[max_bits];
+        overflow -= 2;
+    }
+}
+__device__ void code_assign(const CodeJob &J, uint32_t r, uint32_t max_bits) {   // (d): the leaf of rank r (rarest first)
+    if (J.m < 2u || r >= J.m) return;
+    uint32_t before = 0, mine = 0;
+    for (uint32_t bits = max_bits; bits >= 1u; --bits) {
+        const uint32_t c = J.bl_count[bits];
+        if (mine == 0u && r < before + c) mine = bits;
+        before += c;
+    }
+    J.len[J.sorted[r]] = (uint8_t)mine;
+}
+
 // The 19-symbol code-length code and the fixed part of the block header, by the 64 lanes of ONE wavefront: phase_cl_code's
 // algorithm (bgzf_deflate.hpp: huffman_lengths + canonical_codes, the one-lane form the CPU tests run) with the tree in
 // registers -- node k's weight, parent and depth live in lane k of a VGPR and are read and written with v_readlane /
@@ -208,7 +276,21 @@ void deflate_kernel(const fqtk_bgzf_block *blocks, uint32_t n_blocks, const uint
         phase_clear_out(S, lane);
         __syncthreads();
         FQTK_PHASE_MARK(4);
-        phase_code_lengths(S, lane);        // two lanes: the serial part of the code construction
+        {   // the two big codes' lengths (the one-lane form: phase_code_lengths)
+            constexpr int kDistLane0 = 640;   // distance-code nodes and leaves: lanes 640 .. 703
+            static_assert(kLanes >= 704 && 2 * kNumLitLen - 2 <= kDistLane0 && 2 * kNumDist - 2 <= 64, "a lane per node of both trees");
+            if (lane == 0) { S.freq_ll[256] = 1; code_tree(code_job(S, 0)); }
+            else if (lane == 64) code_tree(code_job(S, 1));
+            __syncthreads();
+            if (lane < kDistLane0) code_depth(code_job(S, 0), (uint32_t)lane, 15u);
+            else if (lane < kDistLane0 + 64) code_depth(code_job(S, 1), (uint32_t)(lane - kDistLane0), 15u);
+            __syncthreads();
+            if (lane == 0) code_repair(code_job(S, 0), 15u);
+            else if (lane == 64) code_repair(code_job(S, 1), 15u);
+            __syncthreads();
+            if (lane < kDistLane0) code_assign(code_job(S, 0), (uint32_t)lane, 15u);
+            else if (lane < kDistLane0 + 64) code_assign(code_job(S, 1), (uint32_t)(lane - kDistLane0), 15u);
+        }
         __syncthreads();
         FQTK_PHASE_MARK(5);
         phase_codes(S, lane);
