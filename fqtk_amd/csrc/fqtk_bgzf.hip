@@ -233,7 +233,8 @@ void deflate_kernel(const fqtk_bgzf_block *blocks, uint32_t n_blocks, const uint
         uint8_t *out = blocks[j].out;
         const uint32_t n = blocks[j].n_in;
         // (Fetching the next block into registers while this one is coded -- before the emit phase, or before the code
-        //  construction -- moved the ~10 us of a block's read from this phase into that one: the kernel ran no faster.)
+        //  construction, with barriers there that wait for LDS only -- moved the ~14 us of a block's read from this phase
+        //  into that one three times out of three: the kernel ran no faster.)
         phase_load(S, lane, in, n);
         __syncthreads();
         if (crc_out) {
