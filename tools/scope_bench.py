@@ -42,15 +42,17 @@ def scope_b(cfg_id=3, n_chunk=8_000_000, chunks=12, matcher=None, workload=None)
             assert lib.fqtk_matcher_enqueue(m.handle, s, bufs[s][0], cfg.stride, None, n_chunk, bufs[s][1]) == 0
         for s in range(2):
             assert lib.fqtk_matcher_wait(m.handle, s) == 0
-        t0 = time.perf_counter()
-        for c in range(chunks):
-            s = c % 2
-            if c >= 2:
+        dt = float("inf")
+        for _rep in range(3):   # (a pass is 20-30 ms: the best of three, a hiccup of the host costs a third of one)
+            t0 = time.perf_counter()
+            for c in range(chunks):
+                s = c % 2
+                if c >= 2:
+                    assert lib.fqtk_matcher_wait(m.handle, s) == 0
+                assert lib.fqtk_matcher_enqueue(m.handle, s, bufs[s][0], cfg.stride, None, n_chunk, bufs[s][1]) == 0
+            for s in range(2):
                 assert lib.fqtk_matcher_wait(m.handle, s) == 0
-            assert lib.fqtk_matcher_enqueue(m.handle, s, bufs[s][0], cfg.stride, None, n_chunk, bufs[s][1]) == 0
-        for s in range(2):
-            assert lib.fqtk_matcher_wait(m.handle, s) == 0
-        dt = time.perf_counter() - t0
+            dt = min(dt, time.perf_counter() - t0)
         # the results that came back are the matcher's: spot-check one slot against the sync path
         got = np.ctypeslib.as_array(C.cast(bufs[1][1], C.POINTER(C.c_uint32)), (n_chunk,))[:100_000].copy()
         ref, _ = m.assign_batch(w.fill_host(n_chunk, 100_000), counts=False)
@@ -101,15 +103,17 @@ def scope_b_packed(cfg_id=3, n_chunk=8_000_000, chunks=12, matcher=None, workloa
             assert enqueue(s) == 0, _lib.last_error()
         for s in range(2):
             assert lib.fqtk_matcher_wait(m.handle, s) == 0
-        t0 = time.perf_counter()
-        for c in range(chunks):
-            s = c % 2
-            if c >= 2:
+        dt = float("inf")
+        for _rep in range(3):
+            t0 = time.perf_counter()
+            for c in range(chunks):
+                s = c % 2
+                if c >= 2:
+                    assert lib.fqtk_matcher_wait(m.handle, s) == 0
+                assert enqueue(s) == 0
+            for s in range(2):
                 assert lib.fqtk_matcher_wait(m.handle, s) == 0
-            assert enqueue(s) == 0
-        for s in range(2):
-            assert lib.fqtk_matcher_wait(m.handle, s) == 0
-        dt = time.perf_counter() - t0
+            dt = min(dt, time.perf_counter() - t0)
         got = np.ctypeslib.as_array(C.cast(bufs[1][1], C.POINTER(C.c_uint32)), (n_chunk,))[:100_000].copy()
         ref, _ = m.assign_batch(w.fill_host(n_chunk, 100_000), counts=False)
         assert np.array_equal(got, ref.view(np.uint32)), "packed scope B results differ from the synchronous ASCII path"
@@ -121,7 +125,7 @@ def scope_b_packed(cfg_id=3, n_chunk=8_000_000, chunks=12, matcher=None, workloa
             lib.fqtk_pinned_free(pr)
     reads = n_chunk * chunks
     return {"what": "fqtk_matcher_enqueue_packed/wait on 2 pinned slots: 4-bit packed host barcodes -> host results, PCIe inclusive",
-            "workload": cfg.name, "reads": reads, "chunk_reads": n_chunk, "packed_bytes_per_read": ps, "seconds": round(dt, 4),
+            "workload": cfg.name, "reads": reads, "chunk_reads": n_chunk, "packed_bytes_per_read": ps, "seconds": round(dt, 4), "passes": 3,
             "M_reads_per_s": round(reads / dt / 1e6, 1), "GB_per_s_over_pcie": round(reads * (ps + 4) / dt / 1e9, 2),
             "host_packer_M_reads_per_s_1_thread": round(2 * n_chunk / pack_s / 1e6, 1)}
 
