@@ -415,6 +415,14 @@ FQTK_HD inline void buf_run(const uint32_t *words, uint32_t pos, uint32_t (&out)
     for (int i = 0; i < NW; ++i) out[i] = (uint32_t)(((uint64_t)a[i] | ((uint64_t)a[i + 1] << 32)) >> (8 * sh));
 #endif
 }
+// four bytes from byte `o` (0 .. 3) of the eight in (lo, hi)
+FQTK_HD inline uint32_t bytes_at(uint32_t lo, uint32_t hi, uint32_t o) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_alignbyte(hi, lo, o);
+#else
+    return (uint32_t)(((uint64_t)lo | ((uint64_t)hi << 32)) >> (8 * o));
+#endif
+}
 FQTK_HD inline uint32_t ctz32(uint32_t x) {   // x != 0
 #if defined(__HIP_DEVICE_COMPILE__)
     return (uint32_t)__builtin_ctz(x);
@@ -580,26 +588,12 @@ FQTK_HD inline uint32_t match_cost(uint32_t len, uint32_t dist) {   // half-bits
     return 2u * (7u + 5u + ne_l + ne_d);
 }
 
-// Positions from .. from + count - 1 (count <= 16) go into the lane's private table: read as one run of words,
-// hashed from registers.
-#ifndef FQTK_BGZF_INS_HEAD
-#define FQTK_BGZF_INS_HEAD 1    // positions behind a match's first byte that enter the lane's table ...
-#endif
-#ifndef FQTK_BGZF_INS_TAIL
-#define FQTK_BGZF_INS_TAIL 2    // ... and before its end (tools/bgzf_ratio.py: none +1.4 % output on binned qualities, 1 + 2 +0.05 %, 4 + 4 and
-#endif                          //     16 + 8 the same as 1 + 4; tools/ab_bgzf.sh: none is 13 % faster than 4 + 4)
-template <int MAXK = 16>
-FQTK_HD inline void near_insert_run(Shared &S, int lane, uint32_t n, uint32_t from, uint32_t count) {
-    for_grams<MAXK>(S, n, from, count, [&](uint32_t p, uint32_t h, bool) {
-        S.near_tab[near_of(h) * kLanes + (uint32_t)lane] = (uint16_t)near_entry(p, lane, h);
-    });
-}
-
 // P1b: greedy LZ77 over this lane's slice; tokens to tok[t * kLanes + lane].  Deterministic: reads the tables
 // of P1a and the lane's own state only.
-struct LzLane { uint32_t p, end, nt, avg16, effort; uint64_t cheap; };   // avg16: the block's average literal cost, half-bits x 16; cheap: phase_index's mask
+struct LzLane { uint32_t p, end, nt, avg16, effort, pending; uint64_t cheap; };   // avg16: the block's average literal cost, half-bits x 16; cheap: phase_index's mask
 FQTK_HD inline void lz_begin(Shared &S, int lane, uint32_t n, LzLane &st, uint64_t cheap_mask) {
     st.cheap = cheap_mask;
+    st.pending = 0;
     st.p = (uint32_t)lane * kChunk;
     st.end = st.p + kChunk < n ? st.p + kChunk : n;
     st.nt = 0;
@@ -750,21 +744,17 @@ FQTK_HD inline void lz_match(Shared &S, uint32_t n, uint32_t p, const LzLane &st
     if (lz_first(S, p, w, qpos, first)) lz_rest(S, n, p, st, w, w4, qpos, first, mlen, mdist);
 }
 
-// A match at p is taken: its token stored (phase_reach counts its symbols), the positions it skips entered into the lane's table.
+// A match at p is taken: its token stored (phase_reach counts its symbols).  The last two positions it skips are recent
+// history too (a long match is a run or a copied line: its end is where the next one starts from) -- they enter the lane's
+// table at the start of the lane's next step, which reads their bytes anyway (tools/bgzf_ratio.py: no positions +1.4 % output
+// on binned qualities, the last two +0.05 %, four at each end as much as sixteen and eight; hashed here, at once, they cost
+// 7 % of the kernel's time: two more chains of dependent LDS round trips per match).
 FQTK_HD inline void lz_take(Shared &S, int lane, uint32_t n, uint32_t *tok, LzLane &st, uint32_t p, uint32_t mlen, uint32_t mdist) {
+    (void)S;
+    (void)n;
     if (!(FQTK_BGZF_ABL & 2)) tok[st.nt * kLanes + (uint32_t)lane] = match_token(mlen, mdist, p - (uint32_t)lane * kChunk);
     ++st.nt;
-    // the positions skipped are recent history too: the first four and the last four of them (a long match is a run or a
-    // copied line; its middle adds nothing the ends do not).  Each group is read as one run of words and hashed from registers.
-    if (mlen > 1 && !(FQTK_BGZF_ABL & 4)) {
-        const uint32_t skipped = mlen - 1;           // positions p + 1 .. p + mlen - 1
-        constexpr uint32_t kHead = FQTK_BGZF_INS_HEAD, kTail = FQTK_BGZF_INS_TAIL;
-        near_insert_run<(int)kHead>(S, lane, n, p + 1, skipped < kHead ? skipped : kHead);
-        if (kTail && skipped > kHead) {
-            const uint32_t tail = skipped - kHead < kTail ? skipped - kHead : kTail;
-            near_insert_run<(int)(kTail ? kTail : 1)>(S, lane, n, p + mlen - tail, tail);
-        }
-    }
+    st.pending = (FQTK_BGZF_ABL & 4) ? 0u : 2u;   // (a match is at least four bytes long: three positions skipped)
     st.p = p + mlen;
 }
 
@@ -786,9 +776,25 @@ FQTK_HD inline bool lz_step(Shared &S, int lane, uint32_t n, uint32_t *tok, LzLa
         return true;
     }
     const bool two = p + 1 < st.end && p + 5 <= n;
+    // twelve bytes from two positions back: the grams of p and p + 1, and of the two positions before p when the lane's last
+    // match left them to be entered into its table (they lie in the lane's slice: their class is in the mask)
+    const uint32_t back = p >= 2u ? 2u : 0u;
     uint32_t r[3];
-    buf_run<3>(S.buf, p, r);
-    const uint32_t wa = r[0], wa4 = r[1], wb = (r[0] >> 8) | (r[1] << 24), wb4 = (r[1] >> 8) | (r[2] << 24);
+    buf_run<3>(S.buf, p - back, r);
+    const uint32_t wa = bytes_at(r[0], r[1], back), wa4 = bytes_at(r[1], r[2], back);
+    const uint32_t wb = bytes_at(r[0], r[1], back + 1u), wb4 = bytes_at(r[1], r[2], back + 1u);
+    if (st.pending) {
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+        for (uint32_t o = 0; o < 2u; ++o) {   // p - 2, then p - 1: the later one wins a shared slot
+            const uint32_t q = p - 2u + o;
+            const bool cheap = ((st.cheap >> (q - (uint32_t)lane * kChunk)) & 1ull) != 0;
+            const uint32_t h = gram_hash(bytes_at(r[0], r[1], o), bytes_at(r[1], r[2], o), cheap);
+            S.near_tab[near_of(h) * kLanes + (uint32_t)lane] = (uint16_t)near_entry(q, lane, h);
+        }
+        st.pending = 0;
+    }
     LzProbe a, b;
     lz_probe(S, lane, p, st, wa, wa4, a);
     if (two) {
