@@ -533,7 +533,10 @@ struct GatherSink {
     }
 };
 
-__global__ __launch_bounds__(64 * kFormatWaves) void k_format(TextSet T, DevConfig C, uint32_t n, const uint32_t *res, const uint8_t *skip,
+#ifndef FQTK_FORMAT_WAVES_PER_EU
+#define FQTK_FORMAT_WAVES_PER_EU 5   // (tools/ab_format.sh: the stage takes 0.183 s of a 64 M-template run at 4, 0.176 at 5, 0.185 at 6, 0.243 at 8: spills)
+#endif
+__global__ __launch_bounds__(64 * kFormatWaves) __attribute__((amdgpu_waves_per_eu(FQTK_FORMAT_WAVES_PER_EU, 8))) void k_format(TextSet T, DevConfig C, uint32_t n, const uint32_t *res, const uint8_t *skip,
                                                                const TemplatePlan *plans, const uint32_t *rec_off, const uint32_t *tile_tot,
                                                                const FileChunk *fc, uint8_t *persist, uint8_t *slabs, const ChunkStatus *st) {
     if (st->err_key != kNoError) return;
