@@ -129,7 +129,7 @@ const char *kUsage =
     "  -S, --skip-reasons <REASON>...              too-few-bases\n"
     "      --device <N>                            GPU to use [default: 0] (additive flag)\n"
     "      --devices <A,B,..>                      several GPUs: chunk k is matched on devices[k mod G] (additive flag)\n"
-    "      --chunk-reads <N>                       templates per GPU chunk [default: 131072] (additive flag)\n"
+    "      --chunk-reads <N>                       templates per GPU chunk [default: 262144; 131072 with --host-output] (additive flag)\n"
     "      --host-output                           parse, format and BGZF-compress the records on the host CPUs (as the\n"
     "                                              reference does) instead of on the GPU, which is the default: there the\n"
     "                                              inputs' text goes to the device, records are formatted and DEFLATE-compressed\n"
