@@ -309,20 +309,19 @@ void memo_kernel(const MemoParams Q) {
     const uint32_t hot2_mask = (1u << Q.hot2_bits) - 1u;
     // lane -> read inside a tile is WAVE-CONTIGUOUS (a wave's R loads cover 64 R consecutive reads), and a full
     // tile is addressed as "uniform 64-bit base + loop-invariant 32-bit lane offset" (as in the LDS form)
-    uint32_t local[R], in_off[R], out_off[R];
+    // (ONE lane offset per stream: read r of a lane sits r * 64 rows behind read 0, which goes into the uniform part of
+    // the address -- the compiler keeps every loop-invariant lane offset as a 64-bit register pair.)
+    uint32_t local[R];
 #pragma unroll
-    for (int r = 0; r < R; ++r) {
-        local[r] = (tid >> 6) * (64u * R) + (uint32_t)r * 64u + (tid & 63u);
-        in_off[r] = local[r] * P.stride;
-        out_off[r] = local[r] * 4u;
-    }
+    for (int r = 0; r < R; ++r) local[r] = (tid >> 6) * (64u * R) + (uint32_t)r * 64u + (tid & 63u);
+    const uint32_t in_off0 = local[0] * P.stride, out_off0 = local[0] * 4u;
 
     // The packed vector loads of one full tile (every read exists, the rows are VEC dwords).
     auto load_full = [&](uint64_t t, uint32_t (&words)[R][8]) {
         const uint8_t *tile_in = P.obs + t * tile * (uint64_t)P.stride;   // wave-uniform
 #pragma unroll
         for (int r = 0; r < R; ++r) {
-            const uint8_t *src = tile_in + in_off[r];
+            const uint8_t *src = (tile_in + (uint32_t)r * 64u * P.stride) + in_off0;
             if constexpr (VEC == 4) {
                 const u32x4v v = FQTK_STREAM_LOAD(reinterpret_cast<const u32x4v *>(src));
                 words[r][0] = v.x; words[r][1] = v.y; words[r][2] = v.z; words[r][3] = v.w;
@@ -382,6 +381,19 @@ void memo_kernel(const MemoParams Q) {
 #pragma unroll
         for (int r = 0; r < R; ++r)
             memo_hash2(lo[r], KW >= 2 ? hi[r] : 0u, KW >= 3 ? ext[r] : 0u, Q.mask, s1[r], s2[r]);
+        // Hash-table form: every load of the tile's probe phase is UNCONDITIONAL, and the loads of one phase are issued
+        // together and waited for once (`arrived`): lanes that need nothing read the table's first bytes (one line for
+        // the whole wave).  A load inside a lane-masked branch is followed by its own s_waitcnt before the next read's
+        // branch can start -- the probe phase of a two-read tile paid up to six LDS / L2 round trips back to back
+        // (round 3, tools/ab_libs_cfg5.sh, same box: cfg 3 with the table form pinned 172.9 -> 198.1 G reads/s).
+        auto arrived2 = [&](u32x2v (&v)[R]) {
+#pragma unroll
+            for (int r = 0; r < R; ++r) { asm volatile("" : "+v"(v[r].x), "+v"(v[r].y) : : "memory"); }
+        };
+        auto arrived4 = [&](u32x4v (&v)[R]) {
+#pragma unroll
+            for (int r = 0; r < R; ++r) { asm volatile("" : "+v"(v[r].x), "+v"(v[r].y), "+v"(v[r].z), "+v"(v[r].w) : : "memory"); }
+        };
         bool hit[R];
 #pragma unroll
         for (int r = 0; r < R; ++r) { hit[r] = false; res[r] = kMemoEmpty; }
@@ -403,70 +415,119 @@ void memo_kernel(const MemoParams Q) {
                 }
             }
         } else if (Q.hot_mask && !(ABL & 16)) {   // wave-uniform
+            if constexpr (KW >= 2) {
+                u32x4v h1[R], h2[R];
 #pragma unroll
-            for (int r = 0; r < R; ++r) {
-                const uint32_t a1 = s1[r] & Q.hot_mask, a2 = s2[r] & Q.hot_mask;
-                if constexpr (KW >= 2) {
-                    const uint4 h1 = reinterpret_cast<const uint4 *>(lds_hot)[a1];
-                    const uint4 h2 = reinterpret_cast<const uint4 *>(lds_hot)[a2];
-                    const bool m1 = h1.x == lo[r] && h1.y == hi[r] && (KW < 3 || (h1.w >> 16) == ext[r]);
-                    const bool m2 = h2.x == lo[r] && h2.y == hi[r] && (KW < 3 || (h2.w >> 16) == ext[r]);
-                    hit[r] = m1 || m2;
-                    res[r] = m1 ? h1.z : (m2 ? h2.z : kMemoEmpty);
-                } else {
-                    const uint2 h1 = reinterpret_cast<const uint2 *>(lds_hot)[a1];
-                    const uint2 h2 = reinterpret_cast<const uint2 *>(lds_hot)[a2];
-                    const bool m1 = h1.x == lo[r], m2 = h2.x == lo[r];
-                    hit[r] = m1 || m2;
-                    res[r] = m1 ? h1.y : (m2 ? h2.y : kMemoEmpty);
+                for (int r = 0; r < R; ++r) {
+                    h1[r] = reinterpret_cast<const u32x4v *>(lds_hot)[s1[r] & Q.hot_mask];
+                    h2[r] = reinterpret_cast<const u32x4v *>(lds_hot)[s2[r] & Q.hot_mask];
+                }
+                arrived4(h1);
+                arrived4(h2);
+#pragma unroll
+                for (int r = 0; r < R; ++r) {
+                    const bool m1 = h1[r].x == lo[r] && h1[r].y == hi[r] && (KW < 3 || (h1[r].w >> 16) == ext[r]);
+                    const bool m2 = h2[r].x == lo[r] && h2[r].y == hi[r] && (KW < 3 || (h2[r].w >> 16) == ext[r]);
+                    hit[r] = m1 | m2;
+                    res[r] = m1 ? h1[r].z : (m2 ? h2[r].z : kMemoEmpty);
+                }
+            } else {
+                u32x2v h1[R], h2[R];
+#pragma unroll
+                for (int r = 0; r < R; ++r) {
+                    h1[r] = reinterpret_cast<const u32x2v *>(lds_hot)[s1[r] & Q.hot_mask];
+                    h2[r] = reinterpret_cast<const u32x2v *>(lds_hot)[s2[r] & Q.hot_mask];
+                }
+                arrived2(h1);
+                arrived2(h2);
+#pragma unroll
+                for (int r = 0; r < R; ++r) {
+                    const bool m1 = h1[r].x == lo[r], m2 = h2[r].x == lo[r];
+                    hit[r] = m1 | m2;
+                    res[r] = m1 ? h1[r].y : (m2 ? h2[r].y : kMemoEmpty);
                 }
             }
         }
         if constexpr (ABL & 1) {
 #pragma unroll
             for (int r = 0; r < R; ++r) res[r] = (s1[r] ^ s2[r]) | 0xFFFFu;
-        } else {
-            // Direct form: one 2/4-byte gather settles every no-call-free read that missed the LDS cache.
-            // (Non-canonical lanes probe too -- harmless, see below -- so a '.' read is already right.)
-            if constexpr (DIRECT != 0) {
+        } else if constexpr (DIRECT != 0) {
+            // Direct form: one 2/4-byte gather settles every no-call-free read that missed the LDS cache, lanes that
+            // hit masked off.  (Non-canonical lanes probe too -- harmless, see below -- so a '.' read is already right.)
+            // Measured with the batched, unconditional shape of the hash-table form below (every lane one 8-byte gather,
+            // the N reads' two slots in the same batch, one wait; tools/ab_libs_cfg5.sh, same box): cfg 5 172 instead of
+            // 185 G reads/s whatever the loop shape, lane-masked or not -- this form is bound by bytes in flight per
+            // wave, not by the number of waits, and the extra registers and selects cost more than the waits saved.
 #pragma unroll
-                for (int r = 0; r < R; ++r) {
-                    if (!hit[r] && !has_n[r]) {
-                        if constexpr (DIRECT == 2) res[r] = memo_direct_unpack16(reinterpret_cast<const uint16_t *>(Q.direct)[didx[r]], Q.d_ib, Q.d_bb);
-                        else res[r] = reinterpret_cast<const uint32_t *>(Q.direct)[didx[r]];
-                    }
+            for (int r = 0; r < R; ++r) {
+                if (!hit[r] && !has_n[r]) {
+                    if constexpr (DIRECT == 2) res[r] = memo_direct_unpack16(reinterpret_cast<const uint16_t *>(Q.direct)[didx[r]], Q.d_ib, Q.d_bb);
+                    else res[r] = reinterpret_cast<const uint32_t *>(Q.direct)[didx[r]];
                 }
             }
-            // Global table, two-choice placement with a per-slot SPILL bit: the builder keeps a key in
-            // its first slot whenever it can and marks a slot whose would-be owner lives in its second
-            // slot.  So one gather settles ~90 % of the probing lanes (hit, or miss with spill = 0);
-            // only the rest issue the second, dependent gather -- with almost every lane masked off.
+            // reads with an N: the cuckoo table (first slot; the second only where the SPILL bit says so)
             bool again[R];
 #pragma unroll
             for (int r = 0; r < R; ++r) {
                 again[r] = false;
                 if (!hit[r] && has_n[r] && !(ABL & 256)) {
-                    if constexpr (KW >= 2) {
-                        const uint4 e = reinterpret_cast<const uint4 *>(Q.slots)[g1[r]];
-                        if (e.x == lo[r] && e.y == hi[r] && (KW < 3 || (e.w >> 16) == ext[r])) res[r] = e.z;
-                        else again[r] = (e.w & 1u) != 0;
-                    } else {
-                        const uint2 e = reinterpret_cast<const uint2 *>(Q.slots)[g1[r]];
-                        if ((e.x & 0x7FFFFFFFu) == lo[r]) res[r] = e.y;
-                        else again[r] = (e.x >> 31) != 0;
-                    }
+                    const uint2 e = reinterpret_cast<const uint2 *>(Q.slots)[g1[r]];
+                    if ((e.x & 0x7FFFFFFFu) == lo[r]) res[r] = e.y;
+                    else again[r] = (e.x >> 31) != 0;
                 }
             }
 #pragma unroll
             for (int r = 0; r < R; ++r) {
                 if (again[r] && !(ABL & 64)) {
-                    if constexpr (KW >= 2) {
-                        const uint4 e = reinterpret_cast<const uint4 *>(Q.slots)[g2[r]];
-                        if (e.x == lo[r] && e.y == hi[r] && (KW < 3 || (e.w >> 16) == ext[r])) res[r] = e.z;
-                    } else {
-                        const uint2 e = reinterpret_cast<const uint2 *>(Q.slots)[g2[r]];
-                        if ((e.x & 0x7FFFFFFFu) == lo[r]) res[r] = e.y;
-                    }
+                    const uint2 e = reinterpret_cast<const uint2 *>(Q.slots)[g2[r]];
+                    if ((e.x & 0x7FFFFFFFu) == lo[r]) res[r] = e.y;
+                }
+            }
+        } else {
+            // Global table, two-choice placement with a per-slot SPILL bit: the builder keeps a key in
+            // its first slot whenever it can and marks a slot whose would-be owner lives in its second
+            // slot.  So one gather settles ~90 % of the probing lanes (hit, or miss with spill = 0);
+            // only the rest issue the second, dependent gather -- with almost every lane reading slot 0.
+            bool again[R], any_again = false;
+            if constexpr (KW >= 2) {
+                u32x4v e[R];
+#pragma unroll
+                for (int r = 0; r < R; ++r) e[r] = reinterpret_cast<const u32x4v *>(Q.slots)[hit[r] ? 0u : g1[r]];
+                arrived4(e);
+#pragma unroll
+                for (int r = 0; r < R; ++r) {
+                    const bool k = e[r].x == lo[r] && e[r].y == hi[r] && (KW < 3 || (e[r].w >> 16) == ext[r]);
+                    if (!hit[r] && k) res[r] = e[r].z;
+                    again[r] = !hit[r] && !k && (e[r].w & 1u) != 0 && !(ABL & 64);
+                    any_again |= again[r];
+                }
+                if (__ballot(any_again)) {   // wave-uniform
+#pragma unroll
+                    for (int r = 0; r < R; ++r) e[r] = reinterpret_cast<const u32x4v *>(Q.slots)[again[r] ? g2[r] : 0u];
+                    arrived4(e);
+#pragma unroll
+                    for (int r = 0; r < R; ++r)
+                        if (again[r] && e[r].x == lo[r] && e[r].y == hi[r] && (KW < 3 || (e[r].w >> 16) == ext[r])) res[r] = e[r].z;
+                }
+            } else {
+                u32x2v e[R];
+#pragma unroll
+                for (int r = 0; r < R; ++r) e[r] = reinterpret_cast<const u32x2v *>(Q.slots)[hit[r] ? 0u : g1[r]];
+                arrived2(e);
+#pragma unroll
+                for (int r = 0; r < R; ++r) {
+                    const bool k = (e[r].x & 0x7FFFFFFFu) == lo[r];
+                    if (!hit[r] && k) res[r] = e[r].y;
+                    again[r] = !hit[r] && !k && (e[r].x >> 31) != 0 && !(ABL & 64);
+                    any_again |= again[r];
+                }
+                if (__ballot(any_again)) {   // wave-uniform
+#pragma unroll
+                    for (int r = 0; r < R; ++r) e[r] = reinterpret_cast<const u32x2v *>(Q.slots)[again[r] ? g2[r] : 0u];
+                    arrived2(e);
+#pragma unroll
+                    for (int r = 0; r < R; ++r)
+                        if (again[r] && (e[r].x & 0x7FFFFFFFu) == lo[r]) res[r] = e[r].y;
                 }
             }
         }
@@ -516,7 +577,7 @@ void memo_kernel(const MemoParams Q) {
         if constexpr (ABL & 8) { if (res[0] == 0x12345u) P.out[t * tile + local[0]] = res[0]; return; }
         uint8_t *tile_out = reinterpret_cast<uint8_t *>(P.out + t * tile);   // wave-uniform
 #pragma unroll
-        for (int r = 0; r < R; ++r) FQTK_STREAM_STORE(res[r], reinterpret_cast<uint32_t *>(tile_out + out_off[r]));
+        for (int r = 0; r < R; ++r) FQTK_STREAM_STORE(res[r], reinterpret_cast<uint32_t *>((tile_out + r * 256) + out_off0));
     };
     auto store_any = [&](uint64_t t, const uint32_t (&res)[R], const bool (&live)[R]) {
 #pragma unroll
