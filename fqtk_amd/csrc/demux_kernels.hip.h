@@ -35,6 +35,7 @@ struct DevConfig {
     uint32_t n_samples, barcode_len;
     uint32_t fixed_bc_len, variable_bc;       // sample-barcode layout: sum of the fixed B segments; a '+B' exists
     uint32_t skip_short, use_lens;
+    uint32_t no_carry;                        // every chunk ends its blocks (several devices): nothing lives in the persistent slabs
     uint32_t min_len[FQTK_DEMUX_MAX_INPUTS];
     fmt::SegPos bseg[kMaxSegs], mseg[kMaxSegs];
     fmt::FileSeg fseg[FQTK_DEMUX_MAX_FILES];
@@ -50,14 +51,23 @@ struct TextSet {
 
 // Device-side status of one chunk (copied to page-locked memory at the end of the chunk).
 struct ChunkStatus {
-    unsigned long long err_key;       // lowest (template << 24 | stage << 20 | input << 8 | kind), ~0 = none
+    unsigned long long err_key;       // lowest (template << 24 | class << 20 | input << 9 | stage << 8 | kind), ~0 = none
     unsigned long long matcher_err;   // the matcher's latched length error (read index), ~0 = none
     unsigned long long total_bytes;   // packed BGZF members
     uint32_t n_lines[FQTK_DEMUX_MAX_INPUTS];
     uint32_t n_blocks, n_skipped, max_bc_len, pad;
 };
+// Order of the errors of ONE template = the order the reference meets them in: its per-input iterators are zipped
+// (demux.rs:285-343, 946-951), so input 0's record is parsed AND length-checked before input 1's is looked at -- for the
+// record-level stages (0 = malformed record, 1 = too few bases) the input ranks above the stage (class 0); the
+// matcher's length error (class 2, kept in matcher_err) and the header errors (class 3) follow, then the internal ones.
+__device__ inline unsigned long long error_key(uint32_t t, uint32_t stage, uint32_t input, uint32_t kind) {
+    const uint32_t cls = stage <= 1u ? 0u : stage;
+    return ((unsigned long long)t << 24) | ((unsigned long long)cls << 20) | ((unsigned long long)input << 9) |
+           ((unsigned long long)(stage <= 1u ? stage : 0u) << 8) | kind;
+}
 __device__ inline void report(ChunkStatus *st, uint32_t t, uint32_t stage, uint32_t input, uint32_t kind) {
-    atomicMin(&st->err_key, ((unsigned long long)t << 24) | ((unsigned long long)stage << 20) | ((unsigned long long)input << 8) | kind);
+    atomicMin(&st->err_key, error_key(t, stage, input, kind));
 }
 
 // the line index did not come out as 4 lines per template: k_records wrote nothing, nothing downstream may run
@@ -84,19 +94,21 @@ struct FileChunk {
     uint32_t slab_base;  // first of its nb - 1 chunk slabs
     uint32_t par;        // persistent slab of the block open at the start (the next open one: next_slab(par))
     uint32_t new_rem;    // open bytes after the chunk (before a flush empties them)
-    uint32_t pad;
+    uint32_t chunk_only; // DevConfig::no_carry: all n_emit blocks live in the chunk's own slabs, slab_base + k
 };
 
 // Where byte `q` (counted from the start of the block that was open when the chunk began) of file `c` lives.
 __device__ inline uint8_t *file_byte(const FileChunk &fc, uint32_t c, uint32_t q, uint8_t *persist, uint8_t *slabs) {
     const uint32_t kth = q / kBlock, r = q - kth * kBlock;
     uint8_t *base;
-    if (kth == 0) base = persist + ((size_t)c * kPersist + fc.par) * kSlab;
+    if (fc.chunk_only) base = slabs + (size_t)(fc.slab_base + kth) * kSlab;
+    else if (kth == 0) base = persist + ((size_t)c * kPersist + fc.par) * kSlab;
     else if (kth < fc.nb) base = slabs + (size_t)(fc.slab_base + kth - 1) * kSlab;
     else base = persist + ((size_t)c * kPersist + next_slab(fc.par)) * kSlab;
     return base + r;
 }
 __device__ inline uint8_t *block_base(const FileChunk &fc, uint32_t c, uint32_t kth, uint8_t *persist, uint8_t *slabs) {
+    if (fc.chunk_only) return slabs + (size_t)(fc.slab_base + kth) * kSlab;
     if (kth == 0) return persist + ((size_t)c * kPersist + fc.par) * kSlab;
     if (kth < fc.nb) return slabs + (size_t)(fc.slab_base + kth - 1) * kSlab;
     return persist + ((size_t)c * kPersist + next_slab(fc.par)) * kSlab;
@@ -402,7 +414,8 @@ __global__ __launch_bounds__(1024) void k_layout(DevConfig C, const uint32_t *ch
     for (uint32_t base = 0; base < n_cols; base += 1024) {
         const uint32_t c = base + threadIdx.x;
         FileChunk x;
-        x.rem = x.nb = x.n_emit = x.blk_base = x.slab_base = x.par = x.new_rem = x.pad = 0;
+        x.rem = x.nb = x.n_emit = x.blk_base = x.slab_base = x.par = x.new_rem = 0;
+        x.chunk_only = C.no_carry;
         uint32_t n_slabs = 0;
         if (c < n_cols) {
             const uint32_t s = c / C.n_files, f = c - s * C.n_files;
@@ -414,7 +427,10 @@ __global__ __launch_bounds__(1024) void k_layout(DevConfig C, const uint32_t *ch
             x.nb = (uint32_t)(end / kBlock);
             x.new_rem = (uint32_t)(end - (unsigned long long)x.nb * kBlock);
             x.n_emit = x.nb + ((flush && x.new_rem) ? 1u : 0u);
-            n_slabs = x.nb ? x.nb - 1u : 0u;
+            // (no_carry: a file's persistent slabs would be written by chunk k + 1 while the compressor still reads chunk
+            //  k's blocks from them -- two slabs per chunk against a rotation of three, ADVICE r03 -- and nothing has to
+            //  persist when every chunk is flushed: the blocks live with the chunk)
+            n_slabs = C.no_carry ? x.n_emit : (x.nb ? x.nb - 1u : 0u);
             FileState nx;
             nx.rem = flush ? 0u : x.new_rem;
             // the block open after the chunk sits in the other slab once a block was closed; a flush hands it to the
@@ -449,7 +465,7 @@ __global__ __launch_bounds__(1024) void k_layout(DevConfig C, const uint32_t *ch
         if (carry_a > max_blocks) { report(st, 0, 4, 0, FQTK_DEMUX_ERR_LINES); carry_a = 0; }
         st->n_blocks = carry_a;
         FileChunk end;   // sentinel: fc[n_cols].blk_base = number of blocks
-        end.rem = end.nb = end.n_emit = end.slab_base = end.par = end.new_rem = end.pad = 0;
+        end.rem = end.nb = end.n_emit = end.slab_base = end.par = end.new_rem = end.chunk_only = 0;
         end.blk_base = carry_a;
         fc[n_cols] = end;
     }
@@ -495,7 +511,7 @@ constexpr int kFormatWaves = 4;
 constexpr uint32_t kFormatGroup = 16;
 struct WaveScratch { fmt::Span b[kMaxSegs], m[kMaxSegs]; };
 // dynamic LDS per wave: WaveScratch, then RecView rec[n_inputs][kFormatGroup]
-__host__ __device__ inline size_t format_wave_bytes(uint32_t n_inputs) { return (sizeof(WaveScratch) + (size_t)n_inputs * kFormatGroup * sizeof(RecView) + 15u) & ~(size_t)15u; }
+__host__ __device__ constexpr size_t format_wave_bytes(uint32_t n_inputs) { return (sizeof(WaveScratch) + (size_t)n_inputs * kFormatGroup * sizeof(RecView) + 15u) & ~(size_t)15u; }
 
 struct GatherSink {
     const TextSet &T;
@@ -595,7 +611,8 @@ __global__ __launch_bounds__(64 * kFormatWaves) __attribute__((amdgpu_waves_per_
             const uint32_t c = (uint32_t)__builtin_amdgcn_readlane((int)s, i) * C.n_files + f;
             const uint32_t q = (uint32_t)__builtin_amdgcn_readlane((int)my_q, i);
             FileChunk x;
-            x.rem = x.n_emit = x.blk_base = x.new_rem = x.pad = 0;
+            x.rem = x.n_emit = x.blk_base = x.new_rem = 0;
+            x.chunk_only = C.no_carry;
             x.nb = (uint32_t)__builtin_amdgcn_readlane((int)my_nb, i);
             x.slab_base = (uint32_t)__builtin_amdgcn_readlane((int)my_slab, i);
             x.par = (uint32_t)__builtin_amdgcn_readlane((int)my_par, i);

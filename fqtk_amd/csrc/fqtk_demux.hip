@@ -3,7 +3,8 @@
 // One chunk = the raw FASTQ text of n templates from every input.  Two HIP streams carry it:
 //   stream A   H2D wait -> line index -> records -> barcode rows -> matcher -> placement -> formatting
 //   stream B   DEFLATE + CRC of the chunk's blocks -> packing into BGZF members -> status to the host
-// B(k) waits for A(k); A(k) waits for B(k - 2) (a file's persistent slabs rotate over three, demux_kernels.hip.h), so
+// B(k) waits for A(k); A(k) waits for B(k - 2) (a file's persistent slabs rotate over three, demux_kernels.hip.h; with
+// carry_blocks = 0 every block lives in its chunk's own slabs and A(k) waits for nothing), so
 // the compressor -- the longest kernel by far -- works on chunk k while chunk k + 1 is indexed, matched and formatted.
 // A copy stream moves the text in, another the packed members out.  Three chunks may be in flight (slots).
 #include <hip/hip_runtime.h>
@@ -177,7 +178,7 @@ int fill_result(fqtk_demuxer *d, Slot &s, fqtk_demux_result *res) {
     }
     if (st.err_key != kNoError) {
         res->error = (int)(st.err_key & 0xFFu);
-        res->error_input = (uint32_t)((st.err_key >> 8) & 0xFFFu);
+        res->error_input = (uint32_t)((st.err_key >> 9) & 0x7FFu);
         res->error_template = (uint32_t)(st.err_key >> 24);
         if (((st.err_key >> 20) & 15u) == 3u) { res->error_detail = (uint32_t)res->error; res->error = FQTK_DEMUX_ERR_HEADER; }
         return FQTK_OK;
@@ -220,6 +221,7 @@ int fqtk_demuxer_create(fqtk_matcher *m, const fqtk_demux_config *cfg, fqtk_demu
     C.n_samples = fqtk_matcher_n_samples(m);
     C.barcode_len = fqtk_matcher_barcode_len(m);
     C.skip_short = cfg->skip_too_few_bases ? 1u : 0u;
+    C.no_carry = d->carry ? 0u : 1u;
     // segments by type in (input, position) order: demux.rs:100-118 filter the combined read set's segments in place
     static const char kKinds[4] = {'T', 'B', 'M', 'C'};
     size_t at = 0;
@@ -265,9 +267,7 @@ int fqtk_demuxer_create(fqtk_matcher *m, const fqtk_demux_config *cfg, fqtk_demu
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, d->device) == hipSuccess && prop.multiProcessorCount > 0) d->num_cus = prop.multiProcessorCount;
     DX_OR_BAIL(fqtk::bgzf::deflate_prepare());
-    if (kFormatWaves * format_wave_bytes(C.n_inputs) > 48 * 1024)   // (many inputs: the record views of 64 templates per wave need more than the default LDS)
-        DX_OR_BAIL(hipFuncSetAttribute(reinterpret_cast<const void *>(k_format), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       (int)(kFormatWaves * format_wave_bytes(C.n_inputs))));
+    static_assert(kFormatWaves * format_wave_bytes(FQTK_DEMUX_MAX_INPUTS) <= 48 * 1024, "k_format: the record views of a group per wave fit the default LDS");
     for (hipStream_t *st : {&d->s_in, &d->s_a, &d->s_b, &d->s_out}) DX_OR_BAIL(hipStreamCreateWithFlags(st, hipStreamNonBlocking));
     const size_t persist_bytes = (size_t)std::max<uint32_t>(d->n_cols, 1) * kPersist * kSlab;
     DX_OR_BAIL(hipMalloc(reinterpret_cast<void **>(&d->d_persist), persist_bytes));
@@ -323,6 +323,14 @@ int fqtk_demuxer_submit(fqtk_demuxer *d, int slot, const uint8_t *const *text, c
         sum_text += text_len[i];
     }
     for (uint32_t f = 0; f < C.n_files; ++f) seg_text += text_len[C.fseg[f].input];
+    // placement is 32-bit arithmetic per output file (rec_off, tile_tot, chunk_tot, a record's place q): a file's bytes of
+    // one chunk -- at most every input's text once more its own segment's, plus the per-record bytes below -- must fit
+    {
+        uint64_t max_text = 0;
+        for (uint32_t i = 0; i < C.n_inputs; ++i) max_text = std::max<uint64_t>(max_text, text_len[i]);
+        if (sum_text + max_text + (32ull + C.n_b + C.n_m) * n + kBlock >= (1ull << 32))
+            return set_error(FQTK_EINVAL, "the chunk's text adds up to 4 GiB or more per output file: use smaller chunks");
+    }
     DX_TRY(hipSetDevice(d->device));
     int rc;
     // bound of the chunk's output: every file gets the first input's header, all barcode segments and its own
@@ -365,7 +373,7 @@ int fqtk_demuxer_submit(fqtk_demuxer *d, int slot, const uint8_t *const *text, c
     // stream A
     hipStream_t A = d->s_a;
     DX_TRY(hipStreamWaitEvent(A, s.ev_h2d1, 0));
-    if (d->slot_of_chunk[0] >= 0) DX_TRY(hipStreamWaitEvent(A, d->slots[d->slot_of_chunk[0]].ev_status, 0));   // B(k - 2): the persistent slabs it read
+    if (d->carry && d->slot_of_chunk[0] >= 0) DX_TRY(hipStreamWaitEvent(A, d->slots[d->slot_of_chunk[0]].ev_status, 0));   // B(k - 2): the persistent slabs it read
     ChunkStatus init;
     std::memset(&init, 0, sizeof init);
     init.err_key = kNoError;

@@ -576,6 +576,7 @@ bool gpu_output_supported(const Plan &plan, std::string *why) {
                         }
                         std::memcpy(out.buf->data, c.first.p, part);
                         for (auto &h : helpers[i]) h->wait();
+                        sources[i]->release_cut(c.first);   // only now may the cutter unmap it (fastq_io.hpp)
                         if (c.first.add_newline) out.buf->data[c.first.bytes] = '\n';
                         g_times.reader_push += tick() - t0;   // (the copy: reported as "push")
                     } else {

@@ -396,15 +396,21 @@ class FastqSource {
     uint64_t records_read() const { return nrec_; }
     // A plain mapped file can be cut WITHOUT being copied: next_cut only counts newlines (twice the speed of counting and
     // copying) and hands out the range; whoever copies it (several threads, `fqtk demux`) does so while the next cut is
-    // being counted.  The range stays mapped until `lag` more bytes have been consumed behind it.
+    // being counted.  The range stays mapped until its consumer hands it back with release_cut(): however far the cutter
+    // runs ahead of the copiers (queues between them, cuts of any size), nothing below the last released cut's end is
+    // unmapped -- a distance in bytes cannot promise that (four cuts of more than 256 MiB outran a 1 GiB lag).
     struct RawCut { const char *p = nullptr; size_t bytes = 0, n_records = 0; bool add_newline = false; };
+    // Cuts are released in the order they were handed out (one copier per source).
+    void release_cut(const RawCut &c) { cut_released_.store((size_t)(c.p - map_) + c.bytes, std::memory_order_release); }
     bool mapped() const { return map_ != nullptr; }
     size_t mapped_size() const { return map_size_; }
     // A second thread may count the later steps of a cut while this one counts the first ones (the counts of whole 256 KiB
     // steps do not depend on where the cut will fall): one thread counts ~15 GB/s out of the page cache, and the device
     // takes the two 150-base files of a run faster than that.
+    void set_cut_unmap_step(size_t bytes) { cut_unmap_step_ = std::max<size_t>(4096, bytes / 4096 * 4096); }
+    size_t cut_unmapped_bytes() const { return map_unmapped_; }
     void attach_count_assistant() { if (!assistant_) assistant_ = std::make_unique<CountAssistant>(); }
-    bool next_cut(size_t max_records, RawCut *c, std::string *err, size_t lag = 1u << 30) {
+    bool next_cut(size_t max_records, RawCut *c, std::string *err) {
         const char *base = map_ + map_pos_;
         const size_t avail = map_size_ - map_pos_, target = 4 * max_records;
         constexpr size_t kCutStep = 256u << 10;
@@ -453,12 +459,12 @@ class FastqSource {
         c->add_newline = add_nl;
         nrec_ += lines / 4;
         map_pos_ += w;
-        if (map_pos_ > lag + (128u << 20) && map_pos_ - lag - map_unmapped_ >= (128u << 20)) {   // unmap far behind the copiers
-            const size_t upto = (map_pos_ - lag) / (64u << 20) * (64u << 20);
-            if (upto > map_unmapped_) {
-                Unmapper::get().push(const_cast<char *>(map_) + map_unmapped_, upto - map_unmapped_);
-                map_unmapped_ = upto;
-            }
+        // unmap what the copiers have handed back, in steps of kCutUnmapStep, whole pages only
+        const size_t released = cut_released_.load(std::memory_order_acquire);
+        if (released >= map_unmapped_ + 2 * cut_unmap_step_) {
+            const size_t upto = released / cut_unmap_step_ * cut_unmap_step_;
+            Unmapper::get().push(const_cast<char *>(map_) + map_unmapped_, upto - map_unmapped_);
+            map_unmapped_ = upto;
         }
         return true;
     }
@@ -519,6 +525,8 @@ class FastqSource {
         }
     }
     size_t map_unmapped_ = 0;
+    std::atomic<size_t> cut_released_{0};   // end offset of the last cut its consumer is done with
+    size_t cut_unmap_step_ = 64u << 20;     // (tests shrink it: set_cut_unmap_step)
     size_t last_cut_bytes_ = 0;
     class CountAssistant {
       public:

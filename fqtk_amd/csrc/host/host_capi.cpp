@@ -466,7 +466,7 @@ int fqtk_host_chunk_schedule_check(uint64_t devices, uint64_t slots, uint64_t n_
 // FastqSource::next_cut over a whole plain (mapped) file: the same contract as fqtk_host_read_raw, the text taken
 // from the cuts (+ the newline a cut asks for).  Returns the number of cuts, -1 on an error, -2 if the file is not mapped.
 static int64_t read_cuts(const char *path, uint64_t batch, char *out, size_t cap, size_t *out_len, uint64_t *counts, size_t max_calls,
-                         char *err, size_t errcap, bool assistant);
+                         char *err, size_t errcap, bool assistant, size_t hold = 0, size_t unmap_step = 0, size_t *unmapped = nullptr);
 int64_t fqtk_host_read_cuts(const char *path, uint64_t batch, char *out, size_t cap, size_t *out_len, uint64_t *counts, size_t max_calls,
                             char *err, size_t errcap) {
     return read_cuts(path, batch, out, cap, out_len, counts, max_calls, err, errcap, false);
@@ -476,25 +476,45 @@ int64_t fqtk_host_read_cuts_assisted(const char *path, uint64_t batch, char *out
                                      char *err, size_t errcap) {
     return read_cuts(path, batch, out, cap, out_len, counts, max_calls, err, errcap, true);
 }
+// ... with the consumer `hold` cuts behind the cutter (the copier of `fqtk demux` behind its queue) and the consumed
+// input unmapped in steps of `unmap_step` bytes: a cut must stay readable until release_cut() hands it back.
+// *unmapped = bytes the source had unmapped when the last cut was taken.
+int64_t fqtk_host_read_cuts_held(const char *path, uint64_t batch, uint64_t hold, uint64_t unmap_step, char *out, size_t cap, size_t *out_len,
+                                 uint64_t *counts, size_t max_calls, size_t *unmapped, char *err, size_t errcap) {
+    return read_cuts(path, batch, out, cap, out_len, counts, max_calls, err, errcap, false, (size_t)hold, (size_t)unmap_step, unmapped);
+}
 static int64_t read_cuts(const char *path, uint64_t batch, char *out, size_t cap, size_t *out_len, uint64_t *counts, size_t max_calls,
-                         char *err, size_t errcap, bool assistant) {
+                         char *err, size_t errcap, bool assistant, size_t hold, size_t unmap_step, size_t *unmapped) {
     FastqSource src;
     std::string e;
     if (!src.open(path, &e)) { put(e, err, errcap); return -1; }
     if (!src.mapped()) return -2;
     if (assistant) src.attach_count_assistant();
+    if (unmap_step) src.set_cut_unmap_step(unmap_step);
     size_t w = 0, calls = 0;
-    for (;;) {
-        FastqSource::RawCut c;
-        if (!src.next_cut((size_t)batch, &c, &e, 1u << 20)) { put(e, err, errcap); return -1; }
-        if (c.n_records == 0) break;
+    std::deque<FastqSource::RawCut> held;
+    auto consume = [&]() -> bool {   // copy the oldest cut, then hand it back
+        const FastqSource::RawCut c = held.front();
+        held.pop_front();
         const size_t bytes = c.bytes + (c.add_newline ? 1 : 0);
-        if (w + bytes > cap || calls >= max_calls) { put("test buffer too small", err, errcap); return -1; }
+        if (w + bytes > cap || calls >= max_calls) { put("test buffer too small", err, errcap); return false; }
         std::memcpy(out + w, c.p, c.bytes);
         if (c.add_newline) out[w + c.bytes] = '\n';
+        src.release_cut(c);
         w += bytes;
         counts[calls++] = c.n_records;
+        return true;
+    };
+    for (;;) {
+        FastqSource::RawCut c;
+        if (!src.next_cut((size_t)batch, &c, &e)) { put(e, err, errcap); return -1; }
+        if (c.n_records == 0) break;
+        held.push_back(c);
+        if (held.size() > hold && !consume()) return -1;
     }
+    if (unmapped) *unmapped = src.cut_unmapped_bytes();
+    if (unmap_step) usleep(20000);   // let the unmapper thread get to what was queued: a cut unmapped too early must fault HERE
+    while (!held.empty()) if (!consume()) return -1;
     *out_len = w;
     return (int64_t)calls;
 }

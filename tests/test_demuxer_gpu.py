@@ -180,6 +180,65 @@ def test_crlf_input_and_too_few_bases_skipping():
     assert e.value.kind == 5 and e.value.template == 6 and e.value.input_index == 1
 
 
+def test_chunks_that_end_their_blocks_keep_three_in_flight():
+    """carry_blocks = 0 (`--devices a,b,..`): every chunk closes at least one block AND flushes a rest per file -- two slabs
+    per file and chunk.  They used to come out of the file's three persistent slabs, which the formatter of chunk k + 1
+    overwrote while the compressor still read chunk k's; now such blocks live in the chunk's own slabs and
+    three chunks overlap without waiting for each other."""
+    rng = np.random.default_rng(11)
+    structures = ["8B+T", "+T"]
+    bcs = BARCODES8[:3]
+    segs = 24_000
+    tpl = make_templates(rng, segs, bcs, structures, header_kind=1)
+    # long second reads: ~5 blocks per file and chunk, so that DEFLATE (stream B) runs far behind formatting (stream A)
+    tpl = [[t[0], (t[1][0], t[1][1] * 12, t[1][2] * 12)] for t in tpl]
+    for in_flight in (3, 1):
+        d, got = run_case(bcs, 1, 2, structures, "T", tpl, chunk=6000, carry=False, in_flight=in_flight)
+    sizes = []
+    g = got[1]
+    p = 0
+    while p < len(g):
+        bsize = int.from_bytes(g[p + 16:p + 18], "little") + 1
+        sizes.append(int.from_bytes(g[p + bsize - 4:p + bsize], "little"))
+        p += bsize
+    assert sizes.count(65280) >= 8 and sum(1 for x in sizes if 0 < x < 65280) == 4   # one flushed rest per chunk
+
+
+def test_errors_of_one_template_come_in_the_reference_order():
+    """The reference zips its per-input iterators (demux.rs:285-343, 946-951): input 0's record is parsed and
+    length-checked before input 1's is looked at.  So for a template broken in several inputs the LOWER input's error is
+    the fatal one, whatever its stage (a parse error in input 1 used to outrank too-few-bases in input 0)."""
+    structures = ["8B12T", "6T"]
+    m = BarcodeMatcher(BARCODES8, 1, 2, device=0)
+    d = Demuxer(m, structures, "T", max_chunk_templates=8)
+    def texts(r0, r1):
+        a = b"".join(b"@t%d\n%s\n+\n%s\n" % (k, b"ACGTACGT" + b"A" * 12, b"I" * 20) for k in range(8)).split(b"\n")
+        b = b"".join(b"@t%d\n%s\n+\n%s\n" % (k, b"ACGTAC", b"IIIIII") for k in range(8)).split(b"\n")
+        r0(a)
+        r1(b)
+        return [b"\n".join(a), b"\n".join(b)]
+    def short(lines, t, n):
+        lines[4 * t + 1] = lines[4 * t + 1][:n]
+        lines[4 * t + 3] = lines[4 * t + 3][:n]
+    def no_at(lines, t):
+        lines[4 * t] = b"x" + lines[4 * t][1:]
+    # input 0 too short, input 1 malformed, same template: the reference panics on input 0's length
+    d.submit(0, texts(lambda a: short(a, 5, 10), lambda b: no_at(b, 5)), 8)
+    with pytest.raises(DemuxChunkError) as e:
+        d.collect(0)
+    assert (e.value.kind, e.value.template, e.value.input_index) == (5, 5, 0)
+    # the other way round: input 0's parse error
+    d.submit(0, texts(lambda a: no_at(a, 5), lambda b: short(b, 5, 3)), 8)
+    with pytest.raises(DemuxChunkError) as e:
+        d.collect(0)
+    assert (e.value.kind, e.value.template, e.value.input_index) == (1, 5, 0)
+    # an earlier template always wins, whatever the input
+    d.submit(0, texts(lambda a: short(a, 5, 10), lambda b: no_at(b, 4)), 8)
+    with pytest.raises(DemuxChunkError) as e:
+        d.collect(0)
+    assert (e.value.kind, e.value.template, e.value.input_index) == (1, 4, 1)
+
+
 def test_malformed_text_is_reported_with_its_first_template():
     rng = np.random.default_rng(5)
     structures = ["8B12T"]

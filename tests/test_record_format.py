@@ -153,6 +153,32 @@ def test_next_cut_hands_out_the_same_chunks_without_copying(tmp_path):
         read_raw(tmp_path / "d.fq", 1000, cuts=True)
 
 
+def test_a_cut_stays_mapped_until_its_copier_hands_it_back(tmp_path):
+    """the cutter unmapped everything a fixed distance behind it, but the copier of `fqtk demux` may be four cuts
+    behind (one in hand, two queued, one just finished) and a cut may be hundreds of MiB.  Unmapping now follows
+    release_cut(): the consumer here stays `hold` cuts behind while the source unmaps in 64 KiB steps; with the old rule
+    the copies below would read unmapped pages."""
+    fn = H.lib().fqtk_host_read_cuts_held
+    fn.restype = C.c_int64
+    recs = [b"@r%d c\n%s\n+\n%s\n" % (i, b"ACGT" * (1 + i % 30), b"IIII" * (1 + i % 30)) for i in range(60_000)]
+    text = b"".join(recs)
+    p = tmp_path / "a.fq"
+    p.write_bytes(text)
+    for batch, hold in ((1000, 4), (5000, 3), (700, 9), (60_000, 2)):
+        cap = len(text) + 16
+        out = np.empty(cap, dtype=np.uint8)
+        counts = (C.c_uint64 * 1000)()
+        n_out, unmapped = C.c_size_t(), C.c_size_t()
+        err = C.create_string_buffer(512)
+        n = fn(str(p).encode(), C.c_uint64(batch), C.c_uint64(hold), C.c_uint64(65536), out.ctypes.data_as(C.c_void_p), C.c_size_t(cap),
+               C.byref(n_out), counts, C.c_size_t(1000), C.byref(unmapped), err, C.c_size_t(512))
+        assert n >= 0, err.value
+        assert out[: n_out.value].tobytes() == text and sum(counts[i] for i in range(n)) == 60_000
+        if n > hold + 3:   # something was unmapped behind the consumer, and never past what it had handed back
+            held_bytes = sum(len(b"".join(recs[k * batch:(k + 1) * batch])) for k in range(n - hold, n))
+            assert 0 < unmapped.value <= len(text) - held_bytes + 65536
+
+
 def test_a_second_thread_counting_for_the_cutter_changes_nothing(tmp_path):
     """FastqSource::attach_count_assistant: the later 256 KiB steps of a cut are counted by a second thread (it guesses the
     cut's length from the last one): cuts of 4-40 MB whose lengths drift up and down, so the guess overshoots and falls short."""
