@@ -19,6 +19,16 @@
 
 #include "../../include/fqtk_match.h"
 #include "match_kernels.hip.h"
+#ifdef FQTK_DEV_TIMING
+namespace fqtk { __device__ unsigned long long g_dev_phase[16]; }
+// developer builds: cycles per phase summed over the waves of every launch since the last call ([15] = waves), then zeroed
+extern "C" int fqtk_dev_phase_cycles(unsigned long long *out16) {
+    if (hipDeviceSynchronize() != hipSuccess) return 1;
+    if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(fqtk::g_dev_phase), 16 * sizeof(unsigned long long)) != hipSuccess) return 1;
+    unsigned long long zero[16] = {};
+    return hipMemcpyToSymbol(HIP_SYMBOL(fqtk::g_dev_phase), zero, sizeof zero) == hipSuccess ? 0 : 1;
+}
+#endif
 #include "lds_memo_kernels.hip.h"
 #include "lds_memo_plan.hpp"
 #include "direct_memo_plan.hpp"

@@ -66,6 +66,42 @@ struct MatchParams {
     uint32_t *seen;
 };
 
+// Developer-only phase clock (tools/phase_times.sh builds with -DFQTK_DEV_TIMING): where a wave's cycles go inside one
+// iteration of a streaming loop.  mark(k) WAITS for everything the wave has issued (vector memory, LDS, scalar memory),
+// reads the shader clock and books the cycles since the previous mark under phase k -- so a phase's number is its
+// exposed latency plus its share of the SIMD, and the marks change the schedule (nothing overlaps across a mark): the
+// sums say where time can be won, not what the product loop takes.  Wave-uniform: lives in SGPRs.  No-op in the product.
+#ifdef FQTK_DEV_TIMING
+extern __device__ unsigned long long g_dev_phase[16];
+struct PhaseClock {
+    unsigned long long t, acc[8];
+    __device__ __forceinline__ void start() {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) acc[k] = 0;
+        t = __builtin_readcyclecounter();
+    }
+    __device__ __forceinline__ void mark(int k) {
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        const unsigned long long n = __builtin_readcyclecounter();
+        acc[k] += n - t;
+        t = n;
+    }
+    __device__ __forceinline__ void publish() {
+        if (__lane_id() == 0) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) atomicAdd(&g_dev_phase[k], acc[k]);
+            atomicAdd(&g_dev_phase[15], 1ull);
+        }
+    }
+};
+#else
+struct PhaseClock {
+    __device__ __forceinline__ void start() {}
+    __device__ __forceinline__ void mark(int) {}
+    __device__ __forceinline__ void publish() {}
+};
+#endif
+
 __device__ __forceinline__ uint32_t med3_u32(uint32_t a, uint32_t b, uint32_t c) {
     uint32_t d;
     asm("v_med3_u32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));

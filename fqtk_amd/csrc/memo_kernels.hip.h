@@ -356,6 +356,8 @@ void memo_kernel(const MemoParams Q) {
     // this wave's segment of the second pass's worklist, and how much of it is used
     const uint32_t work_seg = blockIdx.x * (kMemoBlock / 64u) + (uint32_t)__builtin_amdgcn_readfirstlane((int)(tid >> 6));   // wave-uniform: SGPRs
     uint32_t work_fill = 0;
+    PhaseClock clk;   // (developer builds only)
+    clk.start();
     // Looks one tile up: res[r] = the result word of the tile's r-th read; also feeds the histogram.
     auto lookup = [&](uint64_t t, uint32_t (&words)[R][8], const bool (&live)[R], uint32_t (&res)[R]) {
         uint32_t lo[R], hi[R], ext[R], didx[R];
@@ -397,6 +399,7 @@ void memo_kernel(const MemoParams Q) {
         bool hit[R];
 #pragma unroll
         for (int r = 0; r < R; ++r) { hit[r] = false; res[r] = kMemoEmpty; }
+        clk.mark(1);   // encode + hashes
         uint32_t g1[R], g2[R];   // global-table slots (ABL 32: folded into a 4 KB corner = L1-resident)
 #pragma unroll
         for (int r = 0; r < R; ++r) { g1[r] = (ABL & 32) ? (s1[r] & 0xFFu) : s1[r]; g2[r] = (ABL & 32) ? (s2[r] & 0xFFu) : ((ABL & 128) ? (s1[r] ^ 1u) : s2[r]); }
@@ -448,6 +451,7 @@ void memo_kernel(const MemoParams Q) {
                 }
             }
         }
+        clk.mark(2);   // LDS cache / hot table
         if constexpr (ABL & 1) {
 #pragma unroll
             for (int r = 0; r < R; ++r) res[r] = (s1[r] ^ s2[r]) | 0xFFFFu;
@@ -465,6 +469,7 @@ void memo_kernel(const MemoParams Q) {
                     else res[r] = reinterpret_cast<const uint32_t *>(Q.direct)[didx[r]];
                 }
             }
+            clk.mark(3);   // direct gather
             // reads with an N: the cuckoo table (first slot; the second only where the SPILL bit says so)
             bool again[R];
 #pragma unroll
@@ -531,6 +536,7 @@ void memo_kernel(const MemoParams Q) {
                 }
             }
         }
+        clk.mark(4);   // cuckoo table (direct form: the reads with an N; hash form: every read that missed the hot table)
         // ---- rare: non-canonical reads -> wave-cooperative exhaustive scan.  Every lane was looked up
         //      above under its 4-bit key; '.' has N's code, so a read whose only non-canonical bytes are
         //      '.' no-calls already holds its answer -- only IUPAC / junk bytes need the scan. ----------
@@ -571,6 +577,7 @@ void memo_kernel(const MemoParams Q) {
                 else atomicAdd(&P.counts[bin], 1ull);
             }
         }
+        clk.mark(5);   // non-canonical reads, length rules, histogram
     };
     // The result stream of one tile.
     auto store_full = [&](uint64_t t, const uint32_t (&res)[R]) {
@@ -651,8 +658,10 @@ void memo_kernel(const MemoParams Q) {
         for (uint64_t t = blockIdx.x; t < full_tiles; t += gridDim.x) {
             uint32_t words[R][8], res[R];
             load_full(t, words);
+            clk.mark(0);   // the row stream
             lookup(t, words, all_live, res);
             store_full(t, res);
+            clk.mark(6);   // the result stream
         }
     }
     // whatever is left (the ragged last tile; every tile on the generic load paths)
@@ -664,6 +673,8 @@ void memo_kernel(const MemoParams Q) {
         store_any(t, res, live);
     }
     publish_worklist_fill(P, work_seg, work_fill);
+    clk.mark(7);
+    clk.publish();
 
     if (P.counts && P.lds_hist) {
         __syncthreads();
