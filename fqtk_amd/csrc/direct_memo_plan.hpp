@@ -4,8 +4,11 @@
 // replays the kernel's lookup.
 //
 // Input: the distinct Some entries of the memo that carry NO no-call -- unfolded key words (lo = bases 0-7,
-// hi = bases 8-9 as memo_key_of(fold = false) builds them) and the result word.  Output: the flat result
-// array indexed by memo_direct_index(), and the LDS cache of its exact-match entries.
+// hi = bases 8-9 as memo_key_of(fold = false) builds them) and the result word -- plus the strings that ARE a
+// spelling of some sample barcode but resolve to None (two samples admit them: min_mismatch_delta), which the
+// array already answers (absent = None) and the LDS cache should too: they are as popular as any exact match.
+// Output: the flat result array indexed by memo_direct_index(), the LDS cache of the exact-match strings, and
+// (plan_nbuckets) the bucketed cuckoo table of the entries WITH a no-call.
 #pragma once
 #include <stdint.h>
 
@@ -24,7 +27,7 @@ struct DirectMemoPlan {
     std::vector<uint16_t> table16;
     std::vector<uint32_t> table32;
     std::vector<uint32_t> hot2;      // (2 << hot2_bits) slots, empty when no cache was built
-    uint32_t hot2_bits = 0;
+    uint32_t hot2_bits = 0, nbits = 0;   // log2(buckets); bits of the index (memo_direct_index_bits)
     uint64_t hot2_wanted = 0, hot2_placed = 0;
 };
 
@@ -34,12 +37,10 @@ inline uint32_t direct_memo_lookup(const DirectMemoPlan &p, uint32_t lo_unf, uin
     const uint32_t didx = memo_direct_index(lo_unf, c2);
     if (from_cache) *from_cache = false;
     if (!p.hot2.empty()) {
-        const uint32_t mask = (1u << p.hot2_bits) - 1u;
-        const uint32_t key[2] = {didx, memo_hot2_rot(didx)};
         for (uint32_t w = 0; w < 2; ++w)
             for (uint32_t s = 0; s < 2; ++s) {
-                const uint32_t e = p.hot2[(size_t)(key[w] & mask) * 2 + s];
-                if ((e >> 16) == memo_hot2_want(key[w], p.hot2_bits, w)) {
+                const uint32_t e = p.hot2[(size_t)memo_hot2_bucket(didx, p.hot2_bits, p.nbits, w) * 2 + s];
+                if ((e >> 16) == memo_hot2_want(didx, p.hot2_bits, p.nbits, w)) {
                     if (from_cache) *from_cache = true;
                     return memo_direct_unpack16(e & 0xFFFFu, p.ib, p.bb);
                 }
@@ -48,10 +49,12 @@ inline uint32_t direct_memo_lookup(const DirectMemoPlan &p, uint32_t lo_unf, uin
     return p.entry_bytes == 2 ? memo_direct_unpack16(p.table16[didx], p.ib, p.bb) : p.table32[didx];
 }
 
-inline DirectMemoPlan plan_direct_memo(uint32_t S, uint32_t L, const std::vector<DirectEntry> &ents) {
+inline DirectMemoPlan plan_direct_memo(uint32_t S, uint32_t L, const std::vector<DirectEntry> &ents,
+                                       const std::vector<DirectEntry> &exact_none = {}) {
     DirectMemoPlan plan;
     if (L == 0 || L > kDirectMaxLen) return plan;
     const uint32_t n_dir = memo_direct_entries(L);
+    plan.nbits = memo_direct_index_bits(L);
     uint32_t max_best = 0, max_next = 0;
     for (const DirectEntry &e : ents) {
         max_best = std::max(max_best, (e.val >> 16) & 0xFFu);
@@ -80,14 +83,15 @@ inline DirectMemoPlan plan_direct_memo(uint32_t S, uint32_t L, const std::vector
     for (const DirectEntry &e : ents)
         if (((e.val >> 16) & 0xFFu) == 0) hot.push_back({memo_direct_index(e.lo, e.hi), e.val});
     std::stable_sort(hot.begin(), hot.end(), [](const Hot &a, const Hot &b) { return (a.val & 0xFFFFu) < (b.val & 0xFFFFu); });
+    // ... then the exact spellings that are None (val = kMemoEmpty; packed: 0xFFFF): placed after every Some entry
+    for (const DirectEntry &e : exact_none) hot.push_back({memo_direct_index(e.lo, e.hi), kMemoEmpty});
     plan.hot2_wanted = hot.size();
     if (hot.empty()) return plan;
-    uint32_t B = 6;                               // >= 6: the tag (20 - B bits) must stay below bit 14 of a slot's upper half
-    while (B < kHot2MaxBucketBits && (double)(2ull << B) * 0.8 < (double)hot.size()) ++B;
-    const uint32_t mask = (1u << B) - 1u;
+    uint32_t B = 6;                               // >= 6: the tag (nbits - B bits) must stay below bit 14 of a slot's upper half
+    while (B < kHot2MaxBucketBits && B < plan.nbits && (double)(2ull << B) * 0.8 < (double)hot.size()) ++B;
     std::vector<int64_t> owner((size_t)2 << B, -1);
     std::vector<uint8_t> which((size_t)2 << B, 0);
-    auto bucket_of = [&](size_t i, uint32_t w) { return (w ? memo_hot2_rot(hot[i].didx) : hot[i].didx) & mask; };
+    auto bucket_of = [&](size_t i, uint32_t w) { return memo_hot2_bucket(hot[i].didx, B, plan.nbits, w); };
     uint64_t rng = 0x9E3779B97F4A7C15ull;
     for (size_t i = 0; i < hot.size(); ++i) {
         int64_t cur = (int64_t)i;
@@ -110,9 +114,90 @@ inline DirectMemoPlan plan_direct_memo(uint32_t S, uint32_t L, const std::vector
     for (size_t slot = 0; slot < owner.size(); ++slot) {
         if (owner[slot] < 0) continue;
         const Hot &h = hot[(size_t)owner[slot]];
-        const uint32_t key20 = which[slot] ? memo_hot2_rot(h.didx) : h.didx;
-        plan.hot2[slot] = memo_direct_pack16(h.val, ib, bb) | (memo_hot2_want(key20, B, which[slot]) << 16);
+        plan.hot2[slot] = (h.val == kMemoEmpty ? 0xFFFFu : memo_direct_pack16(h.val, ib, bb)) | (memo_hot2_want(h.didx, B, plan.nbits, which[slot]) << 16);
         ++plan.hot2_placed;
+    }
+    return plan;
+}
+
+// ---- the entries WITH a no-call: two-choice cuckoo over BUCKETS of two slots ------------------------------------
+// A bucket is one aligned 16-byte line {key0 | spill << 31, val0, key1, val1} (one-word folded keys, memo_key_of):
+// the kernel fetches a read's FIRST bucket (memo_hash2's s1) with its other gathers, finds the key in either slot,
+// and only where the bucket's SPILL bit says that one of its would-be owners lives in its second bucket (s2) does a
+// wave go round once more.  Empty slots: key 0x7FFFFFFF (no folded key has bit 23 set), val None.
+struct NBucketPlan {
+    std::vector<uint32_t> words;   // 4 per bucket
+    uint32_t mask = 0;             // buckets - 1
+    uint64_t second = 0;           // keys living in their second bucket
+    bool ok = false;
+};
+struct NKey { uint32_t lo, val; };   // folded 4-bit key, result
+
+inline uint32_t nbucket_lookup(const NBucketPlan &p, uint32_t lo) {
+    const uint32_t sh = memo_nbucket_shift(p.mask), s1 = memo_nbucket1(lo, sh), s2 = memo_nbucket2(lo, sh);
+    const uint32_t *b = &p.words[(size_t)s1 * 4];
+    if ((b[0] & 0x7FFFFFFFu) == lo) return b[1];
+    if ((b[2] & 0x7FFFFFFFu) == lo) return b[3];
+    if (!(b[0] >> 31)) return kMemoEmpty;
+    b = &p.words[(size_t)s2 * 4];
+    if ((b[0] & 0x7FFFFFFFu) == lo) return b[1];
+    if ((b[2] & 0x7FFFFFFFu) == lo) return b[3];
+    return kMemoEmpty;
+}
+
+inline NBucketPlan plan_nbuckets(const std::vector<NKey> &keys, uint32_t min_buckets = 64) {
+    NBucketPlan plan;
+    uint64_t nb = min_buckets;
+    while (nb * 2 * 0.6 < (double)keys.size()) nb <<= 1;   // load <= 0.6 of the slots
+    for (int attempt = 0; attempt < 6 && nb <= (1u << 24); ++attempt, nb <<= 1) {
+        const uint32_t mask = (uint32_t)(nb - 1);
+        std::vector<int64_t> owner(nb * 2, -1);
+        auto buckets_of = [&](int64_t k, uint32_t &a1, uint32_t &a2) { a1 = memo_nbucket1(keys[(size_t)k].lo, memo_nbucket_shift(mask)); a2 = memo_nbucket2(keys[(size_t)k].lo, memo_nbucket_shift(mask)); };
+        auto free_slot = [&](uint32_t b) -> int64_t { return owner[(size_t)b * 2] < 0 ? (int64_t)b * 2 : (owner[(size_t)b * 2 + 1] < 0 ? (int64_t)b * 2 + 1 : -1); };
+        bool ok = true;
+        uint64_t rng = 0x9E3779B97F4A7C15ull;
+        for (size_t i = 0; i < keys.size() && ok; ++i) {
+            int64_t cur = (int64_t)i;
+            for (int kick = 0;; ++kick) {
+                uint32_t a1, a2;
+                buckets_of(cur, a1, a2);
+                int64_t at = free_slot(a1);
+                if (at < 0) at = free_slot(a2);
+                if (at >= 0) { owner[(size_t)at] = cur; break; }
+                if (kick == 1000) { ok = false; break; }
+                rng = rng * 6364136223846793005ull + 1442695040888963407ull;
+                const size_t victim = (size_t)(((rng >> 33) & 1 ? a1 : a2)) * 2 + ((rng >> 34) & 1);
+                std::swap(cur, owner[victim]);
+            }
+        }
+        if (!ok) continue;
+        for (bool moved = true; moved;) {   // back into the first bucket wherever it has room by now
+            moved = false;
+            for (size_t p = 0; p < owner.size(); ++p) {
+                if (owner[p] < 0) continue;
+                uint32_t a1, a2;
+                buckets_of(owner[p], a1, a2);
+                if (a1 == (uint32_t)(p / 2)) continue;
+                const int64_t at = free_slot(a1);
+                if (at >= 0) { owner[(size_t)at] = owner[p]; owner[p] = -1; moved = true; }
+            }
+        }
+        plan.words.assign(nb * 4, 0u);
+        for (size_t b = 0; b < nb; ++b) { plan.words[b * 4] = plan.words[b * 4 + 2] = 0x7FFFFFFFu; plan.words[b * 4 + 1] = plan.words[b * 4 + 3] = kMemoEmpty; }
+        plan.second = 0;
+        for (size_t p = 0; p < owner.size(); ++p) {
+            if (owner[p] < 0) continue;
+            const NKey &k = keys[(size_t)owner[p]];
+            uint32_t a1, a2;
+            buckets_of(owner[p], a1, a2);
+            uint32_t *w = &plan.words[(p / 2) * 4 + (p & 1) * 2];
+            w[0] = (w[0] & 0x80000000u) | k.lo;
+            w[1] = k.val;
+            if (a1 != (uint32_t)(p / 2)) { plan.words[(size_t)a1 * 4] |= 0x80000000u; ++plan.second; }
+        }
+        plan.mask = mask;
+        plan.ok = true;
+        return plan;
     }
     return plan;
 }

@@ -160,7 +160,7 @@ struct fqtk_matcher {
     void *d_direct = nullptr;
     int direct_bytes = 0;                      // 0 = not built, 2 = packed 16-bit entries, 4 = result words
     uint32_t *d_hot2 = nullptr;
-    uint32_t hot2_bits = 0;
+    uint32_t hot2_bits = 0, direct_nbits = 0;
     uint32_t direct_ib = 0, direct_bb = 0;     // 16-bit entry layout
     uint64_t hot2_placed = 0, hot2_wanted = 0;
     uint64_t memo_entries = 0;
@@ -255,6 +255,9 @@ int launch_memo_vec(const fqtk_matcher *m, fqtk::MemoParams Q, hipStream_t strea
         }
     }
     // Two reads per lane on the packed vector paths, one on the generic ones and for variable-length batches.
+    // Round 4, the direct form with its gathers batched (cfg 5, 12-byte rows; tools/_g4.sh-style A/B, one box, G reads/s):
+    // R=2 plain 217-226 (the product shape) / R=2 pipelined 201 (36 bytes of scratch) / one 1024-lane workgroup per CU at
+    // 128 VGPRs, pipelined, R=2 207-212, R=4 212-216: the kernel is bound by VALU issue, not by loads in flight.
     // 4- and 8-byte rows run their full tiles software-pipelined one tile deep; wider rows would spill 28-60
     // bytes per lane out of the 64 VGPRs that keep 8 waves per SIMD (hipcc -Rpass-analysis=kernel-resource-usage)
     // and take the plain loop.  Measured on MI355X (tools/ab_table.sh, G reads/s, R=1 pipelined / R=1 plain /
@@ -681,6 +684,7 @@ int launch_memo(const fqtk_matcher *m, const fqtk::MatchParams &P, hipStream_t s
         Q.direct = m->d_direct;
         Q.hot2 = m->d_hot2;
         Q.hot2_bits = m->hot2_bits;
+        Q.d_nbits = m->direct_nbits;
         Q.d_ib = m->direct_ib;
         Q.d_bb = m->direct_bb;
         switch (m->memo_kw) {
@@ -824,17 +828,19 @@ uint64_t count_candidates(const uint8_t *e, uint32_t L, uint32_t max_mm, uint64_
     return tot > (double)cap ? cap + 1 : (uint64_t)tot;
 }
 
+// `exact` gets one byte per string: 1 = it is a spelling of this very barcode (no mismatch used)
 void enumerate_candidates(const uint8_t *e, uint32_t L, uint32_t budget, uint32_t pos, char *cur,
-                          std::vector<char> &out) {
+                          std::vector<char> &out, std::vector<uint8_t> &exact, uint32_t used = 0) {
     if (pos == L) {
         out.insert(out.end(), cur, cur + L);
+        exact.push_back(used == 0 ? 1 : 0);
         return;
     }
     for (int c = 0; c < 5; ++c) {
         const bool mis = (kCanonNib[c] & ~e[pos] & 0xF) != 0;
         if (mis && budget == 0) continue;
         cur[pos] = kCanonChr[c];
-        enumerate_candidates(e, L, budget - (mis ? 1u : 0u), pos + 1, cur, out);
+        enumerate_candidates(e, L, budget - (mis ? 1u : 0u), pos + 1, cur, out, exact, used + (mis ? 1u : 0u));
     }
 }
 
@@ -888,7 +894,8 @@ struct Entry { uint32_t lo, hi, ext, val; uint64_t ci; };   // one Some entry of
 
 // Direct-indexed form of the memo for barcodes of <= 10 bases: planned on the host (direct_memo_plan.hpp),
 // uploaded here.
-int build_direct(fqtk_matcher *m, const std::vector<char> &cand, const std::vector<Entry> &ents) {
+int build_direct(fqtk_matcher *m, const std::vector<char> &cand, const std::vector<Entry> &ents,
+                 const std::vector<uint8_t> &exact, const std::vector<fqtk_match_t> &res) {
 #ifdef FQTK_DEV_ABLATE
     if (env_flag("FQTK_NO_DIRECT")) return FQTK_OK;
 #endif
@@ -902,8 +909,28 @@ int build_direct(fqtk_matcher *m, const std::vector<char> &cand, const std::vect
         d.val = e.val;
         dir.push_back(d);
     }
-    const fqtk::DirectMemoPlan plan = fqtk::plan_direct_memo(m->S, m->L, dir);
+    // spellings of a sample barcode that resolve to None (another sample admits them too): as popular as any exact
+    // match, and the LDS cache may as well say so (the array's answer for them is the absent entry)
+    std::vector<fqtk::DirectEntry> exact_none;
+    {
+        std::vector<uint32_t> seen;
+        for (uint64_t i = 0; i < exact.size(); ++i) {
+            if (!exact[i] || res[i].idx != FQTK_NO_MATCH) continue;
+            const char *q = cand.data() + i * m->L;
+            if (std::memchr(q, 'N', m->L)) continue;
+            fqtk::DirectEntry d;
+            uint32_t ext;
+            memo_key_of(q, m->L, d.lo, d.hi, ext, false);
+            d.val = fqtk::kMemoEmpty;
+            exact_none.push_back(d);
+        }
+        std::sort(exact_none.begin(), exact_none.end(), [](const fqtk::DirectEntry &a, const fqtk::DirectEntry &b) { return a.hi != b.hi ? a.hi < b.hi : a.lo < b.lo; });
+        exact_none.erase(std::unique(exact_none.begin(), exact_none.end(), [](const fqtk::DirectEntry &a, const fqtk::DirectEntry &b) { return a.lo == b.lo && a.hi == b.hi; }), exact_none.end());
+    }
+    const fqtk::DirectMemoPlan plan = fqtk::plan_direct_memo(m->S, m->L, dir, exact_none);
     if (!plan.entry_bytes) return FQTK_OK;
+    for (const fqtk::DirectEntry &d : exact_none)
+        if (fqtk::direct_memo_lookup(plan, d.lo, d.hi) != fqtk::kMemoEmpty) return fail(FQTK_EINVAL, "direct memo: self-check failed (None spelling)");
     for (const fqtk::DirectEntry &d : dir)   // self-check: the kernel's lookup returns every stored entry
         if (fqtk::direct_memo_lookup(plan, d.lo, d.hi) != d.val) return fail(FQTK_EINVAL, "direct memo: self-check failed");
     const void *src = plan.entry_bytes == 2 ? (const void *)plan.table16.data() : (const void *)plan.table32.data();
@@ -918,6 +945,7 @@ int build_direct(fqtk_matcher *m, const std::vector<char> &cand, const std::vect
     m->direct_ib = plan.ib;
     m->direct_bb = plan.bb;
     m->hot2_bits = plan.hot2_bits;
+    m->direct_nbits = plan.nbits;
     m->hot2_placed = plan.hot2_placed;
     m->hot2_wanted = plan.hot2_wanted;
     return FQTK_OK;
@@ -932,7 +960,9 @@ int build_memo(fqtk_matcher *m, const std::vector<std::vector<uint8_t>> &enc) {
     std::vector<char> cand;
     cand.reserve((size_t)total * m->L);
     std::vector<char> cur(m->L);
-    for (uint32_t s = 0; s < m->S; ++s) enumerate_candidates(enc[s].data(), m->L, m->max_mm, 0, cur.data(), cand);
+    std::vector<uint8_t> exact;   // per candidate: it spells the barcode it was enumerated from
+    exact.reserve((size_t)total);
+    for (uint32_t s = 0; s < m->S; ++s) enumerate_candidates(enc[s].data(), m->L, m->max_mm, 0, cur.data(), cand, exact);
     const uint64_t nc = cand.size() / m->L;
     m->memo_candidates = nc;
     std::vector<fqtk_match_t> res(nc);
@@ -975,13 +1005,40 @@ int build_memo(fqtk_matcher *m, const std::vector<std::vector<uint8_t>> &enc) {
     if (env_flag("FQTK_FORCE_DIRECT")) want_direct = m->L <= fqtk::kDirectMaxLen;
 #endif
     if (want_direct) {
-        int rc = build_direct(m, cand, ents);
+        int rc = build_direct(m, cand, ents, exact, res);
         if (rc != FQTK_OK) return rc;
         if (m->d_direct) {
-            std::vector<Entry> with_n;
+            // the entries with a no-call: buckets of two slots (direct_memo_plan.hpp), probed with the tile's other gathers
+            std::vector<fqtk::NKey> with_n;
             for (const Entry &e : ents)
-                if (std::memchr(cand.data() + e.ci * m->L, 'N', m->L)) with_n.push_back(e);
-            ents.swap(with_n);
+                if (std::memchr(cand.data() + e.ci * m->L, 'N', m->L)) with_n.push_back(fqtk::NKey{e.lo, e.val});
+            const fqtk::NBucketPlan nb = fqtk::plan_nbuckets(with_n);
+            bool good = nb.ok;
+            for (size_t i = 0; i < with_n.size() && good; ++i) good = fqtk::nbucket_lookup(nb, with_n[i].lo) == with_n[i].val;
+            if (!good) {   // (placement kept failing: drop the direct form, the hash table below serves every read)
+                (void)hipFree(m->d_direct); m->d_direct = nullptr;
+                if (m->d_hot2) { (void)hipFree(m->d_hot2); m->d_hot2 = nullptr; }
+                m->direct_bytes = 0;
+            } else {
+                void *d = nullptr;
+                HIP_TRY(hipMalloc(&d, nb.words.size() * sizeof(uint32_t)));
+                HIP_TRY(hipMemcpy(d, nb.words.data(), nb.words.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+                HIP_TRY(hipDeviceSynchronize());
+                {
+                    std::vector<fqtk::LdsEntry> le(all_ents.size());
+                    for (size_t i = 0; i < all_ents.size(); ++i) {
+                        memo_key_of(cand.data() + all_ents[i].ci * m->L, m->L, le[i].k[0], le[i].k[1], le[i].k[2], false);
+                        le[i].val = all_ents[i].val;
+                    }
+                    rc = build_lds_memo(m, le, enc);
+                    if (rc != FQTK_OK) { (void)hipFree(d); return rc; }
+                }
+                m->memo_second_slot = nb.second;
+                m->memo_mask = nb.mask;
+                m->memo_entries = all_ents.size();
+                m->d_memo = d;   // last: enables the memo path
+                return FQTK_OK;
+            }
         }
     }
     // two-choice (cuckoo) placement with random-walk eviction; grow on the (unlikely) failure

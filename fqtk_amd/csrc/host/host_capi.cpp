@@ -276,6 +276,20 @@ int fqtk_host_direct_memo(uint32_t S, uint32_t L, uint64_t n_ents, const uint32_
     return 0;
 }
 
+// The direct form's table of the entries WITH a no-call (csrc/direct_memo_plan.hpp: plan_nbuckets): planned from n
+// (folded key, result) pairs, then the kernel's lookup replayed for n_q keys.  meta = {ok, buckets, keys in their second bucket}.
+int fqtk_host_nbuckets(uint64_t n, const uint32_t *lo, const uint32_t *vals, uint64_t n_q, const uint32_t *q, uint32_t *out, uint32_t *meta) {
+    std::vector<fqtk::NKey> keys(n);
+    for (uint64_t i = 0; i < n; ++i) keys[i] = fqtk::NKey{lo[i], vals[i]};
+    const fqtk::NBucketPlan p = fqtk::plan_nbuckets(keys);
+    meta[0] = p.ok ? 1u : 0u;
+    meta[1] = p.ok ? p.mask + 1u : 0u;
+    meta[2] = (uint32_t)p.second;
+    if (!p.ok) return 0;
+    for (uint64_t i = 0; i < n_q; ++i) out[i] = fqtk::nbucket_lookup(p, q[i]);
+    return 0;
+}
+
 // The GPU BGZF compressor's phase functions (csrc/bgzf_deflate.hpp) run lane by lane on the CPU -- the same
 // code the HIP kernel runs with barriers in between.  Test infrastructure: lets the CPU suite inflate what
 // the algorithm produces (zlib) without a GPU.  Returns the DEFLATE payload size, or -1 on a bad argument.

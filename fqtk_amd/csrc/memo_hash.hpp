@@ -100,20 +100,47 @@ FQTK_HD inline uint32_t memo_direct_unpack16(uint32_t e, uint32_t ib, uint32_t b
     const uint32_t idx = e & ((1u << ib) - 1u), best = (e >> ib) & ((1u << bb) - 1u), next = e >> (ib + bb);
     return e == 0xFFFFu ? kMemoEmpty : (idx | (best << 16) | (next << 24));
 }
+// The kernel's form: the layout as three wave-uniform words (mask of idx, shift | width of best, shift of next) and NO
+// branch -- everything is computed and None is one compare + select at the end (hipcc turned the ?: above into a
+// lane-masked branch with its scalar operands reloaded from spilled SGPRs inside).
+struct DirectLayout { uint32_t idx_mask, ib, bb_mask, nsh; };
+FQTK_HD inline DirectLayout memo_direct_layout(uint32_t ib, uint32_t bb) { return DirectLayout{(1u << ib) - 1u, ib, (1u << bb) - 1u, ib + bb}; }
+FQTK_HD inline uint32_t memo_direct_unpack16(uint32_t e, const DirectLayout &d) {
+    const uint32_t lowhalf = (e & d.idx_mask) | (((e >> d.ib) & d.bb_mask) << 16);
+    const uint32_t v = ((e >> d.nsh) << 24) | lowhalf;
+    return e == 0xFFFFu ? kMemoEmpty : v;
+}
 FQTK_HD inline uint32_t memo_direct_pack16(uint32_t val, uint32_t ib, uint32_t bb) {   // val = idx | best << 16 | next << 24
     return (val & 0xFFFFu) | (((val >> 16) & 0xFFu) << ib) | ((val >> 24) << (ib + bb));
 }
 // LDS cache of the direct table's EXACT-match entries (the bulk of real reads): two-choice cuckoo over
 // buckets of two 4-byte slots, so one ds_read_b64 fetches a bucket.  A slot is [which : 1 | tag | val16]:
-// the bucket index is a slice of the (rotated) 20-bit read index and the tag is the rest of it, so a tag
-// match is an EXACT key match without storing the key.  Choice 0 buckets by the low bits of the index,
-// choice 1 by the low bits of the index rotated by 10 (the two tags cover disjoint bases).
-FQTK_HD inline uint32_t memo_hot2_rot(uint32_t didx) { return ((didx >> 10) | (didx << 10)) & 0xFFFFFu; }
-FQTK_HD inline uint32_t memo_hot2_want(uint32_t key20, uint32_t bucket_bits, uint32_t which) {
-    return (key20 >> bucket_bits) | (which << 15);   // upper half-word of a matching slot (tag <= 14 bits)
+// the bucket index is a slice of the read's index and the tag is the REST of it, so a tag match is an EXACT
+// key match without storing the key.  Choice 0 buckets by the low B bits of the index (tag = the bits above),
+// choice 1 by its top B bits (tag = the bits below): two shifts and two masks per read, no rotation.
+// nbits = bits of the index (memo_direct_index_bits(L)); 6 <= B <= nbits, nbits - B <= 14 (the tag sits below `which`).
+FQTK_HD constexpr uint32_t memo_direct_index_bits(uint32_t L) { return L <= 8 ? 16u : (L == 9 ? 18u : 20u); }
+FQTK_HD inline uint32_t memo_hot2_bucket(uint32_t didx, uint32_t B, uint32_t nbits, uint32_t which) {
+    return which ? didx >> (nbits - B) : didx & ((1u << B) - 1u);
+}
+FQTK_HD inline uint32_t memo_hot2_want(uint32_t didx, uint32_t B, uint32_t nbits, uint32_t which) {
+    return which ? ((didx & ((1u << (nbits - B)) - 1u)) | 0x8000u) : didx >> B;   // upper half-word of a matching slot
 }
 constexpr uint32_t kHot2MaxBucketBits = 13;           // 8192 buckets x 8 B = 64 KiB
 
+// Direct form, the entries WITH a no-call (direct_memo_plan.hpp: buckets of two slots), keyed by the folded 4-bit key
+// `lo` (which says WHERE the no-calls are; the 2-bit index alone does not -- an N reads as G there, and a string with k
+// G's would put k keys on one index).  Four VALU operations for the first bucket; the second choice is only computed by
+// the rare wave that needs it.
+// `shift` = 32 - log2(buckets) (>= 6 bucket bits): the TOP bits of two 24-bit multiplies over the low and the high 24 bits
+// of the key -- every base reaches them, whatever the table's size.
+FQTK_HD inline uint32_t memo_nbucket1(uint32_t lo, uint32_t shift) { return (mul24(lo, 0x9E3779u) + mul24(lo >> 8, 0x85EBCBu)) >> shift; }
+FQTK_HD inline uint32_t memo_nbucket2(uint32_t lo, uint32_t shift) { return (mul24(lo, 0xC2B2AFu) + mul24(lo >> 8, 0xA54FF5u) + 0x7F4A7C15u) >> shift; }
+FQTK_HD inline uint32_t memo_nbucket_shift(uint32_t mask) {   // mask = buckets - 1
+    uint32_t b = 0;
+    while (mask >> b) ++b;
+    return 32u - b;
+}
 
 // ---- LDS-resident compact memo (lds_memo_kernels.hip.h, lds_memo_plan.hpp) ---------------------------
 constexpr uint32_t kLdsMemoMaxBytes = 160u * 1024u;   // LDS per CU = per workgroup limit on gfx950

@@ -30,6 +30,7 @@ namespace fqtk {
 struct MemoParams {
     MatchParams m;
     const void *slots;        // KW=1: uint2 {lo | spill << 31, val}.  KW>=2: uint4 {lo, hi, val, spill | ext << 16}
+                              // direct form: BUCKETS of two one-word-key slots, uint4 {lo0 | spill << 31, val0, lo1, val1} (mask = buckets - 1)
     const uint32_t *hot;      // hot subset (exact matches) in the same slot format, copied to LDS
     uint32_t mask;            // n_slots - 1
     uint32_t hot_mask;        // hot slots - 1 (0 = no hot table)
@@ -37,6 +38,7 @@ struct MemoParams {
     const void *direct;       // [memo_direct_entries(L)] uint16 (packed) or uint32 results, indexed by the read itself
     const uint32_t *hot2;     // [2 << hot2_bits] LDS cache of the exact-match entries (two-slot buckets), or NULL
     uint32_t hot2_bits;       // log2(buckets)
+    uint32_t d_nbits;         // bits of the read's index (memo_direct_index_bits(L))
     uint32_t d_ib, d_bb;      // 16-bit entries: bits of idx and of best (memo_direct_unpack16)
 };
 
@@ -377,17 +379,11 @@ void memo_kernel(const MemoParams Q) {
                 has_n[r] = true;   // every read takes the cuckoo table
             }
         }
-        // ---- probe: both candidate slots of every read are known up front.  Empty slots carry
-        //      key = ~0 (no real key has a nibble's top bit set) and val = None. ---------------------
-        uint32_t s1[R], s2[R];
-#pragma unroll
-        for (int r = 0; r < R; ++r)
-            memo_hash2(lo[r], KW >= 2 ? hi[r] : 0u, KW >= 3 ? ext[r] : 0u, Q.mask, s1[r], s2[r]);
-        // Hash-table form: every load of the tile's probe phase is UNCONDITIONAL, and the loads of one phase are issued
-        // together and waited for once (`arrived`): lanes that need nothing read the table's first bytes (one line for
-        // the whole wave).  A load inside a lane-masked branch is followed by its own s_waitcnt before the next read's
-        // branch can start -- the probe phase of a two-read tile paid up to six LDS / L2 round trips back to back
-        // (round 3, tools/ab_libs_cfg5.sh, same box: cfg 3 with the table form pinned 172.9 -> 198.1 G reads/s).
+        // Every load of a tile's probe phase is UNCONDITIONAL, and the loads of one phase are issued together and waited for
+        // once (`arrived`): lanes that need nothing read the table's first bytes (one line for the whole wave).  A load
+        // inside a lane-masked branch is followed by its own s_waitcnt before the next read's branch can start -- the probe
+        // phase of a two-read tile paid up to six LDS / L2 round trips back to back (round 3, tools/ab_libs_cfg5.sh, same
+        // box: cfg 3 with the table form pinned 172.9 -> 198.1 G reads/s).
         auto arrived2 = [&](u32x2v (&v)[R]) {
 #pragma unroll
             for (int r = 0; r < R; ++r) { asm volatile("" : "+v"(v[r].x), "+v"(v[r].y) : : "memory"); }
@@ -397,142 +393,181 @@ void memo_kernel(const MemoParams Q) {
             for (int r = 0; r < R; ++r) { asm volatile("" : "+v"(v[r].x), "+v"(v[r].y), "+v"(v[r].z), "+v"(v[r].w) : : "memory"); }
         };
         bool hit[R];
-#pragma unroll
-        for (int r = 0; r < R; ++r) { hit[r] = false; res[r] = kMemoEmpty; }
-        clk.mark(1);   // encode + hashes
-        uint32_t g1[R], g2[R];   // global-table slots (ABL 32: folded into a 4 KB corner = L1-resident)
-#pragma unroll
-        for (int r = 0; r < R; ++r) { g1[r] = (ABL & 32) ? (s1[r] & 0xFFu) : s1[r]; g2[r] = (ABL & 32) ? (s2[r] & 0xFFu) : ((ABL & 128) ? (s1[r] ^ 1u) : s2[r]); }
         if constexpr (DIRECT != 0) {
+            // ======== direct-indexed form (L <= 10) ========================================================================
+            // Per tile: the LDS cache of the exact spellings (both buckets of every read, one wait), then ONE batch of
+            // global look-ups behind one wait -- the flat array at the read's own index (2 / 4 bytes) and, for a read with an
+            // N, one 16-byte bucket of the N table.  Every load is unconditional: a lane that needs nothing reads entry 0 /
+            // bucket 0 (one request for all such lanes of the wave).  Round 4, tools/phase_times.sh + tools/pmc_table2.sh:
+            // the lane-masked shape paid up to 2 R + 2 R dependent L2 round trips per tile here; batching them took cfg 5
+            // from 187 to 205 G reads/s and left the kernel bound by VALU issue (71 % busy), so this path is also written
+            // for few instructions: cheap bucket arithmetic (two shifts, two masks), the 16-bit value picked first and
+            // unpacked once, a four-operation hash for the N table.
+#pragma unroll
+            for (int r = 0; r < R; ++r) { hit[r] = false; res[r] = kMemoEmpty; }
+            clk.mark(1);   // encode
+            const uint32_t hb = Q.hot2_bits, hs = Q.d_nbits - Q.hot2_bits;   // wave-uniform
+            const uint32_t nsh = 32u - (uint32_t)__builtin_popcount(Q.mask);   // memo_nbucket_shift
+            const DirectLayout lay = memo_direct_layout(Q.d_ib, Q.d_bb);
+            uint32_t e16[R];
+#pragma unroll
+            for (int r = 0; r < R; ++r) e16[r] = 0xFFFFu;
             if (Q.hot2 && !(ABL & 16)) {   // wave-uniform
+                u32x2v b1[R], b2[R];
 #pragma unroll
                 for (int r = 0; r < R; ++r) {
-                    const uint32_t p = didx[r], q = memo_hot2_rot(didx[r]);
-                    const u32x2v b1 = reinterpret_cast<const u32x2v *>(lds_hot)[p & hot2_mask];
-                    const u32x2v b2 = reinterpret_cast<const u32x2v *>(lds_hot)[q & hot2_mask];
-                    const uint32_t w1 = memo_hot2_want(p, Q.hot2_bits, 0), w2 = memo_hot2_want(q, Q.hot2_bits, 1);
-                    const bool m0 = (b1.x >> 16) == w1, m1 = (b1.y >> 16) == w1, m2 = (b2.x >> 16) == w2, m3 = (b2.y >> 16) == w2;
-                    const uint32_t e = m0 ? b1.x : (m1 ? b1.y : (m2 ? b2.x : b2.y));
+                    b1[r] = reinterpret_cast<const u32x2v *>(lds_hot)[didx[r] & hot2_mask];
+                    b2[r] = reinterpret_cast<const u32x2v *>(lds_hot)[didx[r] >> hs];
+                }
+                arrived2(b1);
+                arrived2(b2);
+#pragma unroll
+                for (int r = 0; r < R; ++r) {
+                    const uint32_t w1 = didx[r] >> hb, w2 = (didx[r] & ((1u << hs) - 1u)) | 0x8000u;
+                    const bool m0 = (b1[r].x >> 16) == w1, m1 = (b1[r].y >> 16) == w1, m2 = (b2[r].x >> 16) == w2, m3 = (b2[r].y >> 16) == w2;
+                    e16[r] = m0 ? b1[r].x : (m1 ? b1[r].y : (m2 ? b2[r].x : b2[r].y));
                     hit[r] = (m0 || m1 || m2 || m3) && !has_n[r];   // an N aliases G in the 2-bit index: never trust it
-                    if (hit[r]) res[r] = memo_direct_unpack16(e & 0xFFFFu, Q.d_ib, Q.d_bb);   // the cache exists for 16-bit entries only
                 }
             }
-        } else if (Q.hot_mask && !(ABL & 16)) {   // wave-uniform
-            if constexpr (KW >= 2) {
-                u32x4v h1[R], h2[R];
-#pragma unroll
-                for (int r = 0; r < R; ++r) {
-                    h1[r] = reinterpret_cast<const u32x4v *>(lds_hot)[s1[r] & Q.hot_mask];
-                    h2[r] = reinterpret_cast<const u32x4v *>(lds_hot)[s2[r] & Q.hot_mask];
-                }
-                arrived4(h1);
-                arrived4(h2);
-#pragma unroll
-                for (int r = 0; r < R; ++r) {
-                    const bool m1 = h1[r].x == lo[r] && h1[r].y == hi[r] && (KW < 3 || (h1[r].w >> 16) == ext[r]);
-                    const bool m2 = h2[r].x == lo[r] && h2[r].y == hi[r] && (KW < 3 || (h2[r].w >> 16) == ext[r]);
-                    hit[r] = m1 | m2;
-                    res[r] = m1 ? h1[r].z : (m2 ? h2[r].z : kMemoEmpty);
-                }
-            } else {
-                u32x2v h1[R], h2[R];
-#pragma unroll
-                for (int r = 0; r < R; ++r) {
-                    h1[r] = reinterpret_cast<const u32x2v *>(lds_hot)[s1[r] & Q.hot_mask];
-                    h2[r] = reinterpret_cast<const u32x2v *>(lds_hot)[s2[r] & Q.hot_mask];
-                }
-                arrived2(h1);
-                arrived2(h2);
-#pragma unroll
-                for (int r = 0; r < R; ++r) {
-                    const bool m1 = h1[r].x == lo[r], m2 = h2[r].x == lo[r];
-                    hit[r] = m1 | m2;
-                    res[r] = m1 ? h1[r].y : (m2 ? h2[r].y : kMemoEmpty);
-                }
-            }
-        }
-        clk.mark(2);   // LDS cache / hot table
-        if constexpr (ABL & 1) {
-#pragma unroll
-            for (int r = 0; r < R; ++r) res[r] = (s1[r] ^ s2[r]) | 0xFFFFu;
-        } else if constexpr (DIRECT != 0) {
-            // Direct form: one 2/4-byte gather settles every no-call-free read that missed the LDS cache, lanes that
-            // hit masked off.  (Non-canonical lanes probe too -- harmless, see below -- so a '.' read is already right.)
-            // Measured with the batched, unconditional shape of the hash-table form below (every lane one 8-byte gather,
-            // the N reads' two slots in the same batch, one wait; tools/ab_libs_cfg5.sh, same box): cfg 5 172 instead of
-            // 185 G reads/s whatever the loop shape, lane-masked or not -- this form is bound by bytes in flight per
-            // wave, not by the number of waits, and the extra registers and selects cost more than the waits saved.
+            clk.mark(2);   // LDS cache
+            uint32_t dv[R];
+            u32x4v nb[R];
+            const uint8_t *dbase = reinterpret_cast<const uint8_t *>(Q.direct), *nbase = reinterpret_cast<const uint8_t *>(Q.slots);
 #pragma unroll
             for (int r = 0; r < R; ++r) {
-                if (!hit[r] && !has_n[r]) {
-                    if constexpr (DIRECT == 2) res[r] = memo_direct_unpack16(reinterpret_cast<const uint16_t *>(Q.direct)[didx[r]], Q.d_ib, Q.d_bb);
-                    else res[r] = reinterpret_cast<const uint32_t *>(Q.direct)[didx[r]];
-                }
-            }
-            clk.mark(3);   // direct gather
-            // reads with an N: the cuckoo table (first slot; the second only where the SPILL bit says so)
-            bool again[R];
-#pragma unroll
-            for (int r = 0; r < R; ++r) {
-                again[r] = false;
-                if (!hit[r] && has_n[r] && !(ABL & 256)) {
-                    const uint2 e = reinterpret_cast<const uint2 *>(Q.slots)[g1[r]];
-                    if ((e.x & 0x7FFFFFFFu) == lo[r]) res[r] = e.y;
-                    else again[r] = (e.x >> 31) != 0;
-                }
+                const uint32_t di = ((hit[r] || has_n[r]) && !(ABL & 1)) ? 0u : didx[r];
+                if constexpr (DIRECT == 2) dv[r] = *reinterpret_cast<const uint16_t *>(dbase + (di << 1));   // 32-bit offsets from a uniform base
+                else dv[r] = *reinterpret_cast<const uint32_t *>(dbase + (di << 2));
             }
 #pragma unroll
             for (int r = 0; r < R; ++r) {
-                if (again[r] && !(ABL & 64)) {
-                    const uint2 e = reinterpret_cast<const uint2 *>(Q.slots)[g2[r]];
-                    if ((e.x & 0x7FFFFFFFu) == lo[r]) res[r] = e.y;
+                const uint32_t bi = (has_n[r] && !(ABL & 256)) ? memo_nbucket1(lo[r], nsh) : 0u;
+                nb[r] = *reinterpret_cast<const u32x4v *>(nbase + (bi << 4));
+            }
+#pragma unroll
+            for (int r = 0; r < R; ++r) { asm volatile("" : "+v"(dv[r]) : : "memory"); }
+            arrived4(nb);
+            clk.mark(3);   // the tile's gathers
+            bool again[R], any_again = false;
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                const bool k0 = (nb[r].x & 0x7FFFFFFFu) == lo[r], k1 = (nb[r].z & 0x7FFFFFFFu) == lo[r];
+                const uint32_t nres = k0 ? nb[r].y : (k1 ? nb[r].w : kMemoEmpty);
+                uint32_t dres;
+                if constexpr (DIRECT == 2) dres = memo_direct_unpack16(hit[r] ? (e16[r] & 0xFFFFu) : dv[r], lay);   // picked first, unpacked once
+                else dres = dv[r];
+                res[r] = has_n[r] ? ((ABL & 256) ? kMemoEmpty : nres) : dres;
+                again[r] = has_n[r] && !k0 && !k1 && (nb[r].x >> 31) != 0 && !(ABL & (64 | 256));
+                any_again |= again[r];
+            }
+            if (__ballot(any_again)) {   // wave-uniform, rare: some first bucket was full when the table was built
+#pragma unroll
+                for (int r = 0; r < R; ++r) nb[r] = *reinterpret_cast<const u32x4v *>(nbase + ((again[r] ? memo_nbucket2(lo[r], nsh) : 0u) << 4));
+                arrived4(nb);
+#pragma unroll
+                for (int r = 0; r < R; ++r) {
+                    const bool k0 = (nb[r].x & 0x7FFFFFFFu) == lo[r], k1 = (nb[r].z & 0x7FFFFFFFu) == lo[r];
+                    if (again[r] && (k0 || k1)) res[r] = k0 ? nb[r].y : nb[r].w;
                 }
             }
         } else {
-            // Global table, two-choice placement with a per-slot SPILL bit: the builder keeps a key in
-            // its first slot whenever it can and marks a slot whose would-be owner lives in its second
-            // slot.  So one gather settles ~90 % of the probing lanes (hit, or miss with spill = 0);
-            // only the rest issue the second, dependent gather -- with almost every lane reading slot 0.
-            bool again[R], any_again = false;
-            if constexpr (KW >= 2) {
-                u32x4v e[R];
+            // ======== hash-table form ======================================================================================
+            // ---- probe: both candidate slots of every read are known up front.  Empty slots carry
+            //      key = ~0 (no real key has a nibble's top bit set) and val = None. ---------------------
+            uint32_t s1[R], s2[R];
 #pragma unroll
-                for (int r = 0; r < R; ++r) e[r] = reinterpret_cast<const u32x4v *>(Q.slots)[hit[r] ? 0u : g1[r]];
-                arrived4(e);
+            for (int r = 0; r < R; ++r)
+                memo_hash2(lo[r], KW >= 2 ? hi[r] : 0u, KW >= 3 ? ext[r] : 0u, Q.mask, s1[r], s2[r]);
 #pragma unroll
-                for (int r = 0; r < R; ++r) {
-                    const bool k = e[r].x == lo[r] && e[r].y == hi[r] && (KW < 3 || (e[r].w >> 16) == ext[r]);
-                    if (!hit[r] && k) res[r] = e[r].z;
-                    again[r] = !hit[r] && !k && (e[r].w & 1u) != 0 && !(ABL & 64);
-                    any_again |= again[r];
+            for (int r = 0; r < R; ++r) { hit[r] = false; res[r] = kMemoEmpty; }
+            clk.mark(1);   // encode + hashes
+            uint32_t g1[R], g2[R];   // global-table slots (ABL 32: folded into a 4 KB corner = L1-resident)
+#pragma unroll
+            for (int r = 0; r < R; ++r) { g1[r] = (ABL & 32) ? (s1[r] & 0xFFu) : s1[r]; g2[r] = (ABL & 32) ? (s2[r] & 0xFFu) : ((ABL & 128) ? (s1[r] ^ 1u) : s2[r]); }
+            if (Q.hot_mask && !(ABL & 16)) {   // wave-uniform
+                if constexpr (KW >= 2) {
+                    u32x4v h1[R], h2[R];
+#pragma unroll
+                    for (int r = 0; r < R; ++r) {
+                        h1[r] = reinterpret_cast<const u32x4v *>(lds_hot)[s1[r] & Q.hot_mask];
+                        h2[r] = reinterpret_cast<const u32x4v *>(lds_hot)[s2[r] & Q.hot_mask];
+                    }
+                    arrived4(h1);
+                    arrived4(h2);
+#pragma unroll
+                    for (int r = 0; r < R; ++r) {
+                        const bool m1 = h1[r].x == lo[r] && h1[r].y == hi[r] && (KW < 3 || (h1[r].w >> 16) == ext[r]);
+                        const bool m2 = h2[r].x == lo[r] && h2[r].y == hi[r] && (KW < 3 || (h2[r].w >> 16) == ext[r]);
+                        hit[r] = m1 | m2;
+                        res[r] = m1 ? h1[r].z : (m2 ? h2[r].z : kMemoEmpty);
+                    }
+                } else {
+                    u32x2v h1[R], h2[R];
+#pragma unroll
+                    for (int r = 0; r < R; ++r) {
+                        h1[r] = reinterpret_cast<const u32x2v *>(lds_hot)[s1[r] & Q.hot_mask];
+                        h2[r] = reinterpret_cast<const u32x2v *>(lds_hot)[s2[r] & Q.hot_mask];
+                    }
+                    arrived2(h1);
+                    arrived2(h2);
+#pragma unroll
+                    for (int r = 0; r < R; ++r) {
+                        const bool m1 = h1[r].x == lo[r], m2 = h2[r].x == lo[r];
+                        hit[r] = m1 | m2;
+                        res[r] = m1 ? h1[r].y : (m2 ? h2[r].y : kMemoEmpty);
+                    }
                 }
-                if (__ballot(any_again)) {   // wave-uniform
+            }
+            clk.mark(2);   // LDS cache / hot table
+            if constexpr (ABL & 1) {
 #pragma unroll
-                    for (int r = 0; r < R; ++r) e[r] = reinterpret_cast<const u32x4v *>(Q.slots)[again[r] ? g2[r] : 0u];
+                for (int r = 0; r < R; ++r) res[r] = (s1[r] ^ s2[r]) | 0xFFFFu;
+            } else {
+                // Global table, two-choice placement with a per-slot SPILL bit: the builder keeps a key in
+                // its first slot whenever it can and marks a slot whose would-be owner lives in its second
+                // slot.  So one gather settles ~90 % of the probing lanes (hit, or miss with spill = 0);
+                // only the rest issue the second, dependent gather -- with almost every lane reading slot 0.
+                bool again[R], any_again = false;
+                if constexpr (KW >= 2) {
+                    u32x4v e[R];
+#pragma unroll
+                    for (int r = 0; r < R; ++r) e[r] = reinterpret_cast<const u32x4v *>(Q.slots)[hit[r] ? 0u : g1[r]];
                     arrived4(e);
 #pragma unroll
-                    for (int r = 0; r < R; ++r)
-                        if (again[r] && e[r].x == lo[r] && e[r].y == hi[r] && (KW < 3 || (e[r].w >> 16) == ext[r])) res[r] = e[r].z;
-                }
-            } else {
-                u32x2v e[R];
+                    for (int r = 0; r < R; ++r) {
+                        const bool k = e[r].x == lo[r] && e[r].y == hi[r] && (KW < 3 || (e[r].w >> 16) == ext[r]);
+                        if (!hit[r] && k) res[r] = e[r].z;
+                        again[r] = !hit[r] && !k && (e[r].w & 1u) != 0 && !(ABL & 64);
+                        any_again |= again[r];
+                    }
+                    if (__ballot(any_again)) {   // wave-uniform
 #pragma unroll
-                for (int r = 0; r < R; ++r) e[r] = reinterpret_cast<const u32x2v *>(Q.slots)[hit[r] ? 0u : g1[r]];
-                arrived2(e);
+                        for (int r = 0; r < R; ++r) e[r] = reinterpret_cast<const u32x4v *>(Q.slots)[again[r] ? g2[r] : 0u];
+                        arrived4(e);
 #pragma unroll
-                for (int r = 0; r < R; ++r) {
-                    const bool k = (e[r].x & 0x7FFFFFFFu) == lo[r];
-                    if (!hit[r] && k) res[r] = e[r].y;
-                    again[r] = !hit[r] && !k && (e[r].x >> 31) != 0 && !(ABL & 64);
-                    any_again |= again[r];
-                }
-                if (__ballot(any_again)) {   // wave-uniform
+                        for (int r = 0; r < R; ++r)
+                            if (again[r] && e[r].x == lo[r] && e[r].y == hi[r] && (KW < 3 || (e[r].w >> 16) == ext[r])) res[r] = e[r].z;
+                    }
+                } else {
+                    u32x2v e[R];
 #pragma unroll
-                    for (int r = 0; r < R; ++r) e[r] = reinterpret_cast<const u32x2v *>(Q.slots)[again[r] ? g2[r] : 0u];
+                    for (int r = 0; r < R; ++r) e[r] = reinterpret_cast<const u32x2v *>(Q.slots)[hit[r] ? 0u : g1[r]];
                     arrived2(e);
 #pragma unroll
-                    for (int r = 0; r < R; ++r)
-                        if (again[r] && (e[r].x & 0x7FFFFFFFu) == lo[r]) res[r] = e[r].y;
+                    for (int r = 0; r < R; ++r) {
+                        const bool k = (e[r].x & 0x7FFFFFFFu) == lo[r];
+                        if (!hit[r] && k) res[r] = e[r].y;
+                        again[r] = !hit[r] && !k && (e[r].x >> 31) != 0 && !(ABL & 64);
+                        any_again |= again[r];
+                    }
+                    if (__ballot(any_again)) {   // wave-uniform
+#pragma unroll
+                        for (int r = 0; r < R; ++r) e[r] = reinterpret_cast<const u32x2v *>(Q.slots)[again[r] ? g2[r] : 0u];
+                        arrived2(e);
+#pragma unroll
+                        for (int r = 0; r < R; ++r)
+                            if (again[r] && (e[r].x & 0x7FFFFFFFu) == lo[r]) res[r] = e[r].y;
+                    }
                 }
             }
         }
@@ -593,6 +628,7 @@ void memo_kernel(const MemoParams Q) {
     };
 
     const uint64_t full_tiles = (VEC >= 1) ? P.n / tile : 0;
+    const uint32_t grid = gridDim.x;   // (read once: inside the loops hipcc reloaded it from the dispatch packet every tile)
     bool all_live[R];
 #pragma unroll
     for (int r = 0; r < R; ++r) all_live[r] = true;
@@ -655,7 +691,7 @@ void memo_kernel(const MemoParams Q) {
             store_full(t_held, held);
         }
     } else {
-        for (uint64_t t = blockIdx.x; t < full_tiles; t += gridDim.x) {
+        for (uint64_t t = blockIdx.x; t < full_tiles; t += grid) {
             uint32_t words[R][8], res[R];
             load_full(t, words);
             clk.mark(0);   // the row stream

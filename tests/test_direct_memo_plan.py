@@ -119,3 +119,62 @@ def test_tables_too_wide_for_16_bit_entries_fall_back_to_result_words_without_a_
     meta, out, cached, want, _, _ = _plan_and_probe(barcodes, 0, 1, probe)
     assert meta[0] == 4 and meta[4] == 0 and not cached.any()
     assert np.array_equal(out, want)
+
+
+def _fold(keys):
+    """memo_key_of(fold = true) for L <= 10: bases 8-9 ride in the spare bits of lo's nibbles (memo_hash.hpp: kFoldMul)."""
+    lo, hi = keys[:, 0].astype(np.uint64), keys[:, 1].astype(np.uint64)
+    x = (hi & 7) | (((hi >> 8) & 7) << 8)
+    mul = (1 << 3) | (1 << 6) | (1 << 17)
+    return (lo | ((x * mul) & 0x08088888)).astype(np.uint32)
+
+
+@pytest.mark.parametrize("case", ["cfg5", "g_rich"])
+def test_reads_with_a_no_call_find_their_entry_in_one_bucket_of_two_slots(case):
+    """The direct form's N table (plan_nbuckets): a read's first 16-byte bucket holds its key in either slot, or the
+    bucket's SPILL bit sends it to the second choice.  Keys are the folded 4-bit keys, so strings that differ only in
+    WHERE their N sits -- one 2-bit index, an N reads as G there -- are told apart (g_rich: barcodes of eight G's)."""
+    rng = np.random.default_rng(3)
+    if case == "cfg5":
+        cfg = synth.CONFIGS[5]
+        barcodes, mm, delta = synth.make_barcodes(cfg), cfg.max_mismatches, cfg.min_mismatch_delta
+    else:
+        barcodes, mm, delta = sorted({"GGGGGGGG" + a + b for a in "ACGT" for b in "ACGT"} | {"ACGTACGTAC", "TTTTTTTTTT"}), 2, 1
+    exact = _neighbours_iupac(barcodes, 0)
+    cands = [exact]
+    for k in range(mm):   # one more base spelled N per round
+        nxt = []
+        for c in cands[-1][: 40_000]:
+            for p in range(c.size):
+                if c[p] != ord("N"):
+                    d = c.copy()
+                    d[p] = ord("N")
+                    nxt.append(d)
+        cands.append(np.unique(np.stack(nxt), axis=0))
+    cand = np.concatenate(cands[1:])
+    lit = O.RefLiteral(barcodes, mm, delta, True)
+    idx, best, nxt, _ = lit.assign_batch(cand)
+    some = idx != O.NONE_IDX
+    assert some.sum() > 100
+    lo = _fold(_keys(cand))
+    assert len(np.unique(lo)) == len(lo)                       # the folded key identifies the string
+    vals = _word(idx, best, nxt)
+    # absent keys: random strings with an N somewhere that are not stored
+    L = len(barcodes[0])
+    rnd = np.frombuffer(b"ACGT", dtype=np.uint8)[rng.integers(0, 4, size=(30_000, L))].copy()
+    rnd[np.arange(30_000), rng.integers(0, L, 30_000)] = ord("N")
+    i2, b2, n2, _ = lit.assign_batch(rnd)
+    q = np.concatenate([lo, _fold(_keys(rnd))]).astype(np.uint32)
+    want = np.concatenate([np.where(some, vals, NONE), _word(i2, b2, n2)]).astype(np.uint32)
+    out = np.zeros(len(q), dtype=np.uint32)
+    meta = np.zeros(3, dtype=np.uint32)
+    klo, kv = np.ascontiguousarray(lo[some]), np.ascontiguousarray(vals[some])
+    assert hostlib.lib().fqtk_host_nbuckets(C.c_uint64(len(klo)), klo.ctypes.data_as(C.c_void_p), kv.ctypes.data_as(C.c_void_p),
+                                            C.c_uint64(len(q)), q.ctypes.data_as(C.c_void_p), out.ctypes.data_as(C.c_void_p),
+                                            meta.ctypes.data_as(C.c_void_p)) == 0
+    assert meta[0] == 1 and meta[1] * 2 * 0.6 >= len(klo) * 0.5
+    # a random N read absent from the table may still resolve (within mm of a sample): only strings the table was built from count
+    stored = set(klo.tolist())
+    mask = np.array([int(x) in stored or w == NONE for x, w in zip(q.tolist(), want.tolist())])
+    assert np.array_equal(out[mask], want[mask]) and mask[: len(lo)].all()
+    assert meta[2] <= 0.2 * len(klo)                          # nearly every key sits in its first bucket

@@ -27,9 +27,11 @@ __global__ __launch_bounds__(1024) void k(const uint8_t *tab, uint32_t *out, int
             if (MODE == 1) { v[u] = 0; if ((lane & 3u) == 0) v[u] = reinterpret_cast<const uint16_t *>(tab)[idx]; }
             if (MODE == 2) v[u] = reinterpret_cast<const uint16_t *>(tab)[(lane & 3u) == 0 ? idx : 0u];
             if (MODE == 3) v[u] = reinterpret_cast<const uint16_t *>(tab)[__builtin_amdgcn_readfirstlane(idx)];
-            if (MODE == 4) v[u] = reinterpret_cast<const uint32_t *>(tab)[((gw * 8u + u) & 1023u) * 64u + lane];
-            if (MODE == 5) { const u32x4v q = reinterpret_cast<const u32x4v *>(tab)[((gw * 8u + u) & 255u) * 64u + lane]; v[u] = q.x ^ q.y ^ q.z ^ q.w; }
-            if (MODE == 6) { const u32x3s q = reinterpret_cast<const u32x3s *>(tab)[((gw * 8u + u) & 255u) * 64u + lane]; v[u] = q.x ^ q.y ^ q.z; }
+            const uint32_t wu = __builtin_amdgcn_readfirstlane(idx);   // a wave-uniform random row of the table
+            if (MODE == 4) v[u] = reinterpret_cast<const uint32_t *>(tab)[(wu & 0x3FFFu) * 64u + lane];
+            if (MODE == 5) { const u32x4v q = reinterpret_cast<const u32x4v *>(tab)[(wu & 0xFFFu) * 64u + lane]; v[u] = q.x ^ q.y ^ q.z ^ q.w; }
+            if (MODE == 6) { const u32x3s q = reinterpret_cast<const u32x3s *>(tab)[(wu & 0xFFFu) * 64u + lane]; v[u] = q.x ^ q.y ^ q.z; }
+            if (MODE == 9) { const uint2 q = reinterpret_cast<const uint2 *>(tab)[(wu & 0x1FFFu) * 64u + lane]; v[u] = q.x ^ q.y; }
             if (MODE == 7) { const u32x4v q = reinterpret_cast<const u32x4v *>(tab)[idx >> 3]; v[u] = q.x ^ q.y ^ q.z ^ q.w; }
             if (MODE == 8) { v[u] = 0; if (lane == 0) v[u] = reinterpret_cast<const uint16_t *>(tab)[idx]; }
         }
@@ -42,8 +44,9 @@ __global__ __launch_bounds__(1024) void k(const uint8_t *tab, uint32_t *out, int
 }
 
 template <int MODE>
-void run(const char *name, const uint8_t *tab, uint32_t *out, unsigned long long *cyc, int cus) {
-    const int blocks = cus * 2, iters = 400;
+void run(const char *name, const uint8_t *tab, uint32_t *out, unsigned long long *cyc, int cus, int blocks = 0) {
+    const int iters = 400;
+    if (!blocks) blocks = cus * 2;
     hipEvent_t e0, e1;
     hipEventCreate(&e0);
     hipEventCreate(&e1);
@@ -57,9 +60,8 @@ void run(const char *name, const uint8_t *tab, uint32_t *out, unsigned long long
     hipEventElapsedTime(&ms, e0, e1);
     unsigned long long c = 0;
     hipMemcpy(&c, cyc, 8, hipMemcpyDeviceToHost);
-    const double instr_per_cu = 32.0 * iters * 8;   // wave-instructions per CU
-    printf("%-58s %7.3f ms  %6.1f M wave-instr/s/CU  %6.1f shader cycles per instruction and CU (clock %.2f GHz)\n", name, ms,
-           instr_per_cu / ms / 1e3, (double)c / instr_per_cu, (double)c / ms / 1e6);
+    const double instr = 16.0 * blocks * iters * 8;   // wave-instructions
+    printf("%-58s %4d workgroups  %7.3f ms  %7.2f G wave-instr/s on the chip  %6.1f M per workgroup\n", name, blocks, ms, instr / ms / 1e6, instr / blocks / ms / 1e3);
 }
 
 int main() {
@@ -81,6 +83,10 @@ int main() {
     run<4>("dword, coalesced, L2-resident", tab, out, cyc, cus);
     run<6>("dwordx3 at 12-byte stride, L2-resident", tab, out, cyc, cus);
     run<5>("dwordx4, coalesced, L2-resident", tab, out, cyc, cus);
+    run<9>("dwordx2, coalesced, L2-resident", tab, out, cyc, cus);
     run<7>("16-byte gather, 2 MiB table, 64 lanes", tab, out, cyc, cus);
+    for (int b : {cus, cus / 2, cus / 4, cus / 8, 8, 1}) run<0>("2-byte gather, 64 lanes", tab, out, cyc, cus, b);
+    for (int b : {cus, cus / 8}) run<5>("dwordx4 coalesced", tab, out, cyc, cus, b);
+    for (int b : {cus, cus / 8}) run<6>("dwordx3 at 12-byte stride", tab, out, cyc, cus, b);
     return 0;
 }
