@@ -108,6 +108,11 @@ class BarcodeMatcher:
         """Entries of the precomputed complete memo (0 = exhaustive scan only)."""
         return int(self._lib.fqtk_matcher_memo_entries(self._h))
 
+    @property
+    def memo_candidates(self) -> int:
+        """Strings enumerated and scanned on the device to build the memo (0 when no memo was built)."""
+        return int(self._lib.fqtk_matcher_memo_candidates(self._h))
+
     MEMO_NONE, MEMO_TABLE, MEMO_LDS = 0, 1, 2
 
     @property

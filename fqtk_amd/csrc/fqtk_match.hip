@@ -8,6 +8,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <array>
 #include <atomic>
 #include <cstdio>
 #include <cstdlib>
@@ -252,6 +253,9 @@ int launch_memo_vec(const fqtk_matcher *m, fqtk::MemoParams Q, hipStream_t strea
             else if (sw == 1) vec = 1;
             else if (sw == 3) vec = 3;
             else if (sw == 5) vec = 5;
+            else if (sw == 6 && base % 8 == 0) vec = 6;
+            else if (sw == 7) vec = 7;
+            else if (sw == 8 && base % 16 == 0) vec = 8;
         }
     }
     // Two reads per lane on the packed vector paths, one on the generic ones and for variable-length batches.
@@ -265,7 +269,7 @@ int launch_memo_vec(const fqtk_matcher *m, fqtk::MemoParams Q, hipStream_t strea
     // cfg 3 table pinned (16-byte rows) 148.0 / 141.6 / 139.4 (spills) / 178.0 / 91.2;
     // cfg 2 table pinned (8-byte rows) 236.4 / 203.0 / 248.2 / 234.1 / 182.9.
     const int direct = (KW == 1 && Q.direct) ? m->direct_bytes : 0;
-    int R = (vec > 0 && vec != 5) ? 2 : 1;   // 20-byte rows: two reads per lane would spill
+    int R = (vec > 0 && vec < 5) ? 2 : 1;   // rows of 20 bytes and more: two reads per lane would spill
     int abl = 0;
     bool pf = vec == 1 || vec == 2;
 #ifdef FQTK_DEV_ABLATE
@@ -279,7 +283,7 @@ int launch_memo_vec(const fqtk_matcher *m, fqtk::MemoParams Q, hipStream_t strea
 #endif
     size_t shmem = 256 * sizeof(uint32_t);
     if (direct) shmem += Q.hot2 ? ((size_t)8 << Q.hot2_bits) : 0;
-    else if (Q.hot_mask) shmem += (size_t)(Q.hot_mask + 1) * (KW >= 2 ? 16 : 8);
+    else if (Q.hot_mask) shmem += (size_t)(Q.hot_mask + 1) * (KW == 4 ? 32 : (KW >= 2 ? 16 : 8));
     if (P.counts && P.lds_hist) shmem += (size_t)(P.S + 1) * sizeof(uint32_t);
     {   // the expected-barcode planes for the wave scan of non-canonical reads, while two workgroups still fit a CU
         const size_t with_tab = ((shmem + 15) & ~(size_t)15) + (size_t)P.S * 16;
@@ -300,11 +304,12 @@ int launch_memo_vec(const fqtk_matcher *m, fqtk::MemoParams Q, hipStream_t strea
 #endif
     const uint32_t grid = (uint32_t)std::min<uint64_t>(ntiles, (uint64_t)m->num_cus * per_cu);
     // One launch; the `if constexpr` drops the (load width, key width, form) combinations that cannot occur:
-    // the packed vector paths imply the key width (stride 16 B -> 2 key words, 12 B -> 1 or 2, 8/4 B -> 1, 20 B -> 3)
-    // and the direct form exists for one-word keys only.
+    // the packed vector paths imply the key width (stride 16 B -> 2 key words, 12 B -> 1 or 2, 8/4 B -> 1, 20 / 24 B -> 3,
+    // 28 / 32 B -> 4) and the direct form exists for one-word keys only.
 #define FQTK_MEMO_LAUNCH_P(V, RR, A, LENS, D, PFV)                                                         \
     do {                                                                                                   \
-        if constexpr (((V) <= 0 || ((V) == 3 && KW <= 2) || KW == ((V) == 5 ? 3 : ((V) == 4 ? 2 : 1))) && \
+        if constexpr (((V) <= 0 || ((V) == 3 && KW <= 2) ||                                                \
+                       KW == ((V) >= 7 ? 4 : ((V) >= 5 ? 3 : ((V) == 4 ? 2 : 1)))) &&                      \
                       ((D) == 0 || (KW == 1 && (V) <= 3))) {                                               \
             auto kern = fqtk::memo_kernel<V, KW, RR, A, LENS, D, PFV>;                                     \
             const void *fn = reinterpret_cast<const void *>(kern);                                         \
@@ -321,6 +326,9 @@ int launch_memo_vec(const fqtk_matcher *m, fqtk::MemoParams Q, hipStream_t strea
     // every load path of one (reads per lane, ablation, lens, form, pipelined) combination
 #define FQTK_MEMO_ALL_VEC(RR, A, LENS, D, PFV)                          \
     switch (vec) {                                                      \
+        case 8: FQTK_MEMO_LAUNCH_P(8, RR, A, LENS, D, PFV); break;      \
+        case 7: FQTK_MEMO_LAUNCH_P(7, RR, A, LENS, D, PFV); break;      \
+        case 6: FQTK_MEMO_LAUNCH_P(6, RR, A, LENS, D, PFV); break;      \
         case 5: FQTK_MEMO_LAUNCH_P(5, RR, A, LENS, D, PFV); break;      \
         case 4: FQTK_MEMO_LAUNCH_P(4, RR, A, LENS, D, PFV); break;      \
         case 3: FQTK_MEMO_LAUNCH_P(3, RR, A, LENS, D, PFV); break;      \
@@ -332,6 +340,9 @@ int launch_memo_vec(const fqtk_matcher *m, fqtk::MemoParams Q, hipStream_t strea
     // packed paths only (vec > 0)
 #define FQTK_MEMO_PACKED(RR, A, D, PFV)                                 \
     switch (vec) {                                                      \
+        case 8: FQTK_MEMO_LAUNCH_P(8, RR, A, false, D, PFV); break;     \
+        case 7: FQTK_MEMO_LAUNCH_P(7, RR, A, false, D, PFV); break;     \
+        case 6: FQTK_MEMO_LAUNCH_P(6, RR, A, false, D, PFV); break;     \
         case 5: FQTK_MEMO_LAUNCH_P(5, RR, A, false, D, PFV); break;     \
         case 4: FQTK_MEMO_LAUNCH_P(4, RR, A, false, D, PFV); break;     \
         case 3: FQTK_MEMO_LAUNCH_P(3, RR, A, false, D, PFV); break;     \
@@ -359,7 +370,7 @@ int launch_memo_vec(const fqtk_matcher *m, fqtk::MemoParams Q, hipStream_t strea
         HIP_TRY(hipGetLastError());
         return FQTK_OK;
     }
-    if (!P.lens && vec > 0 && (R != (vec == 5 ? 1 : 2) || pf != (vec <= 2))) {   // A/B of reads per lane and of the pipeline
+    if (!P.lens && vec > 0 && (R != (vec >= 5 ? 1 : 2) || pf != (vec <= 2))) {   // A/B of reads per lane and of the pipeline
 #define FQTK_X(RR, D) FQTK_MEMO_PACKED(RR, 0, D, false)
 #define FQTK_Y(RR, D) FQTK_MEMO_PACKED(RR, 0, D, true)
         if (R == 4) FQTK_MEMO_BY_FORM(FQTK_X, 4);
@@ -379,6 +390,9 @@ int launch_memo_vec(const fqtk_matcher *m, fqtk::MemoParams Q, hipStream_t strea
                            // the length word is loaded with the row -- and one read per lane on the generic load paths
 #define FQTK_X(D)                                                       \
         switch (vec) {                                                  \
+            case 8: FQTK_MEMO_LAUNCH_P(8, 1, 0, true, D, false); break; \
+            case 7: FQTK_MEMO_LAUNCH_P(7, 1, 0, true, D, false); break; \
+            case 6: FQTK_MEMO_LAUNCH_P(6, 1, 0, true, D, false); break; \
             case 5: FQTK_MEMO_LAUNCH_P(5, 1, 0, true, D, false); break; \
             case 4: FQTK_MEMO_LAUNCH_P(4, 2, 0, true, D, false); break; \
             case 3: FQTK_MEMO_LAUNCH_P(3, 2, 0, true, D, false); break; \
@@ -395,11 +409,14 @@ int launch_memo_vec(const fqtk_matcher *m, fqtk::MemoParams Q, hipStream_t strea
         else FQTK_MEMO_LAUNCH_P(1, 2, 0, false, D, true);
         if (direct == 2) { FQTK_X(2) } else if (direct == 4) { FQTK_X(4) } else { FQTK_X(0) }
 #undef FQTK_X
-    } else if (vec > 0) {               // 12- / 16-byte rows: two reads per lane (20-byte rows: one), plain loop
+    } else if (vec > 0) {               // 12- / 16-byte rows: two reads per lane (wider rows: one), plain loop
 #define FQTK_X(D)                                                       \
         if (vec == 3) FQTK_MEMO_LAUNCH_P(3, 2, 0, false, D, false);     \
         else if (vec == 4) FQTK_MEMO_LAUNCH_P(4, 2, 0, false, D, false);\
-        else FQTK_MEMO_LAUNCH_P(5, 1, 0, false, D, false);
+        else if (vec == 5) FQTK_MEMO_LAUNCH_P(5, 1, 0, false, D, false);\
+        else if (vec == 6) FQTK_MEMO_LAUNCH_P(6, 1, 0, false, D, false);\
+        else if (vec == 7) FQTK_MEMO_LAUNCH_P(7, 1, 0, false, D, false);\
+        else FQTK_MEMO_LAUNCH_P(8, 1, 0, false, D, false);
         if (direct == 2) { FQTK_X(2) } else if (direct == 4) { FQTK_X(4) } else { FQTK_X(0) }
 #undef FQTK_X
     } else {               // generic load paths: one read per lane
@@ -432,6 +449,9 @@ int launch_lds_memo(const fqtk_matcher *m, fqtk::LdsMemoParams Q, hipStream_t st
             else if (sw == 1) vec = 1;
             else if (sw == 3) vec = 3;
             else if (sw == 5) vec = 5;
+            else if (sw == 6 && base % 8 == 0) vec = 6;
+            else if (sw == 7) vec = 7;
+            else if (sw == 8 && base % 16 == 0) vec = 8;
         }
     }
     size_t shmem = m->ldsm_lds_bytes;
@@ -477,7 +497,7 @@ int launch_lds_memo(const fqtk_matcher *m, fqtk::LdsMemoParams Q, hipStream_t st
 #define FQTK_LDSM_LAUNCH_P(V, RR, LENS, PF) FQTK_LDSM_LAUNCH_I(V, RR, LENS, PF, false)
 #define FQTK_LDSM_LAUNCH_I(V, RR, LENS, PF, IDX)                                                           \
     do {                                                                                                   \
-        if constexpr ((V) <= 0 || KW == ((V) == 5 ? 3 : ((V) >= 3 ? 2 : 1))) {                             \
+        if constexpr ((V) <= 0 || KW == ((V) >= 7 ? 4 : ((V) >= 5 ? 3 : ((V) >= 3 ? 2 : 1)))) {           \
             auto kern = fqtk::lds_memo_kernel<V, KW, RR, POW2, LENS, PF, IDX>;                             \
             /* > 64 KiB of dynamic LDS must be allowed per kernel AND per device: remembered per matcher */ \
             const void *fn = reinterpret_cast<const void *>(kern);                                         \
@@ -505,6 +525,9 @@ int launch_lds_memo(const fqtk_matcher *m, fqtk::LdsMemoParams Q, hipStream_t st
     } else if (P.lens) {   // variable-length batch (the LENS instantiations): packed rows take the pipelined loop at the
                            // fixed-length shapes (the length word is loaded with the row), the generic paths one read per lane
         switch (vec) {
+            case 8: FQTK_LDSM_LAUNCH_P(8, 1, true, true); break;
+            case 7: FQTK_LDSM_LAUNCH_P(7, 1, true, true); break;
+            case 6: FQTK_LDSM_LAUNCH_P(6, 1, true, true); break;
             case 5: FQTK_LDSM_LAUNCH_P(5, 1, true, true); break;
             case 4: FQTK_LDSM_LAUNCH_P(4, 1, true, true); break;
             case 3: FQTK_LDSM_LAUNCH_P(3, 1, true, true); break;
@@ -538,6 +561,9 @@ int launch_lds_memo(const fqtk_matcher *m, fqtk::LdsMemoParams Q, hipStream_t st
         } else
 #endif
         switch (vec) {
+            case 8: FQTK_LDSM_LAUNCH_P(8, 1, false, true); break;
+            case 7: FQTK_LDSM_LAUNCH_P(7, 1, false, true); break;
+            case 6: FQTK_LDSM_LAUNCH_P(6, 1, false, true); break;
             case 5: FQTK_LDSM_LAUNCH_P(5, 1, false, true); break;
             case 4: FQTK_LDSM_LAUNCH_P(4, 1, false, true); break;
             case 3: FQTK_LDSM_LAUNCH_P(3, 1, false, true); break;
@@ -572,7 +598,9 @@ int launch_second_pass(const fqtk_matcher *m, const fqtk::MatchParams &P0, hipSt
             case 5: return launch_lds_memo<2, true>(m, Q, stream, true);
             case 4: return launch_lds_memo<2, false>(m, Q, stream, true);
             case 7: return launch_lds_memo<3, true>(m, Q, stream, true);
-            default: return launch_lds_memo<3, false>(m, Q, stream, true);
+            case 6: return launch_lds_memo<3, false>(m, Q, stream, true);
+            case 9: return launch_lds_memo<4, true>(m, Q, stream, true);
+            default: return launch_lds_memo<4, false>(m, Q, stream, true);
         }
     }
     const fqtk::MatchParams &P = P0;
@@ -671,7 +699,9 @@ int launch_memo(const fqtk_matcher *m, const fqtk::MatchParams &P, hipStream_t s
             case 5: return launch_lds_memo<2, true>(m, Q, stream);
             case 4: return launch_lds_memo<2, false>(m, Q, stream);
             case 7: return launch_lds_memo<3, true>(m, Q, stream);
-            default: return launch_lds_memo<3, false>(m, Q, stream);
+            case 6: return launch_lds_memo<3, false>(m, Q, stream);
+            case 9: return launch_lds_memo<4, true>(m, Q, stream);
+            default: return launch_lds_memo<4, false>(m, Q, stream);
         }
     }
     if (m->use_cache && m->d_memo) {
@@ -690,7 +720,8 @@ int launch_memo(const fqtk_matcher *m, const fqtk::MatchParams &P, hipStream_t s
         switch (m->memo_kw) {
             case 1: return launch_memo_vec<1>(m, Q, stream);
             case 2: return launch_memo_vec<2>(m, Q, stream);
-            default: return launch_memo_vec<3>(m, Q, stream);
+            case 3: return launch_memo_vec<3>(m, Q, stream);
+            default: return launch_memo_vec<4>(m, Q, stream);
         }
     }
     switch (m->NW) {
@@ -808,7 +839,11 @@ int collect_error(fqtk_matcher *m, hipStream_t stream, int err_word, const ErrCt
 }
 
 // ---- complete-memo construction (see memo_kernels.hip.h) -----------------------------------------
-constexpr uint64_t kMemoCandidateBudget = 6000000;   // strings scanned at create time, at most
+// Strings enumerated and scanned at create time, at most.  They are streamed through the scan kernel in chunks, so the
+// bound is on the TABLE they leave behind (16-byte slots at load <= 0.5; a quarter of the strings are Some entries in
+// the worst case seen) and on create time (~1 s of host work per 10 M strings), not on host memory.
+constexpr uint64_t kMemoCandidateBudget = 24000000;
+constexpr uint64_t kMemoScanChunk = 4000000;
 const uint8_t kCanonNib[5] = {1, 2, 4, 8, 15};
 const char kCanonChr[5] = {'A', 'C', 'G', 'T', 'N'};
 
@@ -844,21 +879,15 @@ void enumerate_candidates(const uint8_t *e, uint32_t L, uint32_t budget, uint32_
     }
 }
 
-// 4 bits per base at memo_nibble_shift(k) of {lo, hi, ext}: the same key the kernels' encode_nibbles builds
-void memo_key_of(const char *q, uint32_t L, uint32_t &lo, uint32_t &hi, uint32_t &ext, bool fold = true) {
-    lo = hi = ext = 0;
-    for (uint32_t k = 0; k < L; ++k) {
-        const uint32_t c = fqtk::memo_code_of(q[k]);
-        const uint32_t sh = fqtk::memo_nibble_shift(k);
-        if (k < 8) lo |= c << sh;
-        else if (k < 16) hi |= c << sh;
-        else ext |= c << sh;
-    }
-    if (fold && fqtk::memo_key_words(L) == 1 && L > 8) {   // bases 8-9 ride in lo's spare bits (kFoldMul)
-        const uint32_t x = (hi & 7u) | (((hi >> 8) & 7u) << 8);   // c[2] as the kernel sees it: codes in bytes 0, 1
-        lo |= (x * fqtk::kFoldMul) & fqtk::kFoldMask;
-        hi = 0;
-    }
+// 4 bits per base at memo_nibble_shift(k) of word k >> 3: the key the kernels' encode_nibbles builds, never folded
+void memo_key_of(const char *q, uint32_t L, uint32_t (&k)[4]) {
+    k[0] = k[1] = k[2] = k[3] = 0;
+    for (uint32_t i = 0; i < L; ++i) k[i >> 3] |= fqtk::memo_code_of(q[i]) << fqtk::memo_nibble_shift(i);
+}
+// the one-word key of a barcode of <= 10 bases: bases 8-9 ride in lo's spare bits (kFoldMul)
+uint32_t memo_folded(const uint32_t (&k)[4]) {
+    const uint32_t x = (k[1] & 7u) | (((k[1] >> 8) & 7u) << 8);   // c[2] as the kernel sees it: codes in bytes 0, 1
+    return k[0] | ((x * fqtk::kFoldMul) & fqtk::kFoldMask);
 }
 
 // ---- LDS-resident compact memo (lds_memo_kernels.hip.h; planned on the host by lds_memo_plan.hpp) ----
@@ -890,49 +919,30 @@ int build_lds_memo(fqtk_matcher *m, const std::vector<fqtk::LdsEntry> &ents,
     return FQTK_OK;
 }
 
-struct Entry { uint32_t lo, hi, ext, val; uint64_t ci; };   // one Some entry of the memo; ci = its candidate string
+// One Some entry of the memo: the unfolded key of its string, the result word, whether the string carries a no-call.
+struct Entry { uint32_t k[4]; uint32_t val; bool has_n; };
+inline bool key_less(const uint32_t (&a)[4], const uint32_t (&b)[4]) {
+    for (int w = 3; w >= 0; --w) if (a[w] != b[w]) return a[w] < b[w];
+    return false;
+}
+inline bool key_equal(const uint32_t (&a)[4], const uint32_t (&b)[4]) { return a[0] == b[0] && a[1] == b[1] && a[2] == b[2] && a[3] == b[3]; }
 
 // Direct-indexed form of the memo for barcodes of <= 10 bases: planned on the host (direct_memo_plan.hpp),
-// uploaded here.
-int build_direct(fqtk_matcher *m, const std::vector<char> &cand, const std::vector<Entry> &ents,
-                 const std::vector<uint8_t> &exact, const std::vector<fqtk_match_t> &res) {
+// uploaded here.  exact_none: spellings of a sample barcode that resolve to None (another sample admits them too) --
+// as popular as any exact match, and the LDS cache may as well say so (the array's answer for them is the absent entry).
+int build_direct(fqtk_matcher *m, const std::vector<Entry> &ents, const std::vector<fqtk::DirectEntry> &exact_none) {
 #ifdef FQTK_DEV_ABLATE
     if (env_flag("FQTK_NO_DIRECT")) return FQTK_OK;
 #endif
     std::vector<fqtk::DirectEntry> dir;
-    for (const Entry &e : ents) {
-        const char *q = cand.data() + e.ci * m->L;
-        if (std::memchr(q, 'N', m->L)) continue;
-        fqtk::DirectEntry d;
-        uint32_t ext;
-        memo_key_of(q, m->L, d.lo, d.hi, ext, false);
-        d.val = e.val;
-        dir.push_back(d);
-    }
-    // spellings of a sample barcode that resolve to None (another sample admits them too): as popular as any exact
-    // match, and the LDS cache may as well say so (the array's answer for them is the absent entry)
-    std::vector<fqtk::DirectEntry> exact_none;
-    {
-        std::vector<uint32_t> seen;
-        for (uint64_t i = 0; i < exact.size(); ++i) {
-            if (!exact[i] || res[i].idx != FQTK_NO_MATCH) continue;
-            const char *q = cand.data() + i * m->L;
-            if (std::memchr(q, 'N', m->L)) continue;
-            fqtk::DirectEntry d;
-            uint32_t ext;
-            memo_key_of(q, m->L, d.lo, d.hi, ext, false);
-            d.val = fqtk::kMemoEmpty;
-            exact_none.push_back(d);
-        }
-        std::sort(exact_none.begin(), exact_none.end(), [](const fqtk::DirectEntry &a, const fqtk::DirectEntry &b) { return a.hi != b.hi ? a.hi < b.hi : a.lo < b.lo; });
-        exact_none.erase(std::unique(exact_none.begin(), exact_none.end(), [](const fqtk::DirectEntry &a, const fqtk::DirectEntry &b) { return a.lo == b.lo && a.hi == b.hi; }), exact_none.end());
-    }
+    for (const Entry &e : ents)
+        if (!e.has_n) dir.push_back(fqtk::DirectEntry{e.k[0], e.k[1], e.val});
     const fqtk::DirectMemoPlan plan = fqtk::plan_direct_memo(m->S, m->L, dir, exact_none);
     if (!plan.entry_bytes) return FQTK_OK;
-    for (const fqtk::DirectEntry &d : exact_none)
-        if (fqtk::direct_memo_lookup(plan, d.lo, d.hi) != fqtk::kMemoEmpty) return fail(FQTK_EINVAL, "direct memo: self-check failed (None spelling)");
     for (const fqtk::DirectEntry &d : dir)   // self-check: the kernel's lookup returns every stored entry
         if (fqtk::direct_memo_lookup(plan, d.lo, d.hi) != d.val) return fail(FQTK_EINVAL, "direct memo: self-check failed");
+    for (const fqtk::DirectEntry &d : exact_none)
+        if (fqtk::direct_memo_lookup(plan, d.lo, d.hi) != fqtk::kMemoEmpty) return fail(FQTK_EINVAL, "direct memo: self-check failed (None spelling)");
     const void *src = plan.entry_bytes == 2 ? (const void *)plan.table16.data() : (const void *)plan.table32.data();
     const size_t bytes = plan.entry_bytes == 2 ? plan.table16.size() * 2 : plan.table32.size() * 4;
     HIP_TRY(hipMalloc(&m->d_direct, bytes));
@@ -951,99 +961,133 @@ int build_direct(fqtk_matcher *m, const std::vector<char> &cand, const std::vect
     return FQTK_OK;
 }
 
+// Slot image of the hash-table form by key width (MemoParams::slots): words per slot, and one slot written.
+inline size_t slot_words(int kw) { return kw == 1 ? 2 : (kw == 4 ? 8 : 4); }
+inline void write_slot(uint32_t *w, int kw, const uint32_t *key /* folded for kw 1; NULL = empty */, uint32_t val, bool spill) {
+    const uint32_t sp = spill ? 1u : 0u;
+    switch (kw) {
+        case 1: w[0] = (key ? key[0] : 0x7FFFFFFFu) | (sp << 31); w[1] = key ? val : fqtk::kMemoEmpty; break;
+        case 2: w[0] = key ? key[0] : ~0u; w[1] = key ? key[1] : ~0u; w[2] = key ? val : fqtk::kMemoEmpty; w[3] = sp; break;
+        case 3: w[0] = key ? key[0] : ~0u; w[1] = key ? key[1] : ~0u; w[2] = key ? key[2] : ~0u;
+                w[3] = (key ? val : 0x7FFFFFFFu) | (sp << 31); break;   // (a result word never has bit 31: next <= 32)
+        default: for (int j = 0; j < 4; ++j) w[j] = key ? key[j] : ~0u;
+                 w[4] = key ? val : fqtk::kMemoEmpty; w[5] = sp; w[6] = w[7] = 0; break;
+    }
+}
+
 int build_memo(fqtk_matcher *m, const std::vector<std::vector<uint8_t>> &enc) {
     if (m->L > fqtk::kMemoMaxLen) return FQTK_OK;
     uint64_t total = 0;
     for (uint32_t s = 0; s < m->S && total <= kMemoCandidateBudget; ++s)
         total += count_candidates(enc[s].data(), m->L, m->max_mm, kMemoCandidateBudget);
     if (total > kMemoCandidateBudget) return FQTK_OK;   // over budget: exhaustive scan only
-    std::vector<char> cand;
-    cand.reserve((size_t)total * m->L);
-    std::vector<char> cur(m->L);
-    std::vector<uint8_t> exact;   // per candidate: it spells the barcode it was enumerated from
-    exact.reserve((size_t)total);
-    for (uint32_t s = 0; s < m->S; ++s) enumerate_candidates(enc[s].data(), m->L, m->max_mm, 0, cur.data(), cand, exact);
-    const uint64_t nc = cand.size() / m->L;
-    m->memo_candidates = nc;
-    std::vector<fqtk_match_t> res(nc);
-    if (nc) {
-        int rc = fqtk_matcher_assign_batch(m, reinterpret_cast<const uint8_t *>(cand.data()), m->L, nullptr, nc,
-                                           res.data(), nullptr);   // d_memo is still NULL: scan kernel
+    m->memo_kw = fqtk::memo_key_words(m->L);
+    const int kw = m->memo_kw;
+    const bool direct_len = m->L <= fqtk::kDirectMaxLen;
+    // ---- enumerate every canonical string within max_mismatches of a sample, scan them on the device in chunks
+    //      (d_memo is still NULL: the scan kernel), keep the Some results (and, for the direct form, the exact
+    //      spellings that are None)
+    std::vector<Entry> ents;
+    std::vector<fqtk::DirectEntry> exact_none;
+    {
+        std::vector<char> cand, cur(m->L);
+        std::vector<uint8_t> exact;
+        std::vector<fqtk_match_t> res;
+        uint64_t nc_total = 0;
+        auto flush = [&]() -> int {
+            const uint64_t nc = cand.size() / m->L;
+            if (!nc) return FQTK_OK;
+            res.resize(nc);
+            const int rc = fqtk_matcher_assign_batch(m, reinterpret_cast<const uint8_t *>(cand.data()), m->L, nullptr, nc, res.data(), nullptr);
+            if (rc != FQTK_OK) return rc;
+            for (uint64_t i = 0; i < nc; ++i) {
+                const char *q = cand.data() + i * m->L;
+                if (res[i].idx != FQTK_NO_MATCH) {
+                    Entry e;
+                    memo_key_of(q, m->L, e.k);
+                    std::memcpy(&e.val, &res[i], 4);
+                    e.has_n = std::memchr(q, 'N', m->L) != nullptr;
+                    ents.push_back(e);
+                } else if (direct_len && exact[i] && !std::memchr(q, 'N', m->L)) {
+                    uint32_t k[4];
+                    memo_key_of(q, m->L, k);
+                    exact_none.push_back(fqtk::DirectEntry{k[0], k[1], fqtk::kMemoEmpty});
+                }
+            }
+            nc_total += nc;
+            cand.clear();
+            exact.clear();
+            return FQTK_OK;
+        };
+        cand.reserve((size_t)std::min<uint64_t>(total, kMemoScanChunk + 65536) * m->L);
+        for (uint32_t s = 0; s < m->S; ++s) {
+            enumerate_candidates(enc[s].data(), m->L, m->max_mm, 0, cur.data(), cand, exact);
+            if (cand.size() / m->L >= kMemoScanChunk) { const int rc = flush(); if (rc != FQTK_OK) return rc; }
+        }
+        { const int rc = flush(); if (rc != FQTK_OK) return rc; }
+        m->memo_candidates = nc_total;
+    }
+    // distinct Some entries (a string can neighbour several samples)
+    std::sort(ents.begin(), ents.end(), [](const Entry &a, const Entry &b) { return key_less(a.k, b.k); });
+    ents.erase(std::unique(ents.begin(), ents.end(), [](const Entry &a, const Entry &b) { return key_equal(a.k, b.k); }), ents.end());
+    std::sort(exact_none.begin(), exact_none.end(), [](const fqtk::DirectEntry &a, const fqtk::DirectEntry &b) { return a.hi != b.hi ? a.hi < b.hi : a.lo < b.lo; });
+    exact_none.erase(std::unique(exact_none.begin(), exact_none.end(), [](const fqtk::DirectEntry &a, const fqtk::DirectEntry &b) { return a.lo == b.lo && a.hi == b.hi; }), exact_none.end());
+    const uint64_t entries = ents.size();
+    // ---- LDS-resident form (plain A/C/G/T samples, <= 1 mismatch, fits one CU's LDS): sees every entry
+    {
+        std::vector<fqtk::LdsEntry> le(ents.size());
+        for (size_t i = 0; i < ents.size(); ++i) { std::memcpy(le[i].k, ents[i].k, sizeof le[i].k); le[i].val = ents[i].val; }
+        const int rc = build_lds_memo(m, le, enc);
         if (rc != FQTK_OK) return rc;
     }
-    uint64_t n_some = 0;
-    for (uint64_t i = 0; i < nc; ++i) n_some += res[i].idx != FQTK_NO_MATCH;
-    m->memo_kw = fqtk::memo_key_words(m->L);
-    const bool wide = m->memo_kw >= 2;
-    const size_t wps = wide ? 4 : 2;   // words per slot
-    // distinct Some entries (a string can neighbour several samples)
-    std::vector<Entry> ents;
-    ents.reserve(n_some);
-    for (uint64_t i = 0; i < nc; ++i) {
-        if (res[i].idx == FQTK_NO_MATCH) continue;
-        Entry e;
-        memo_key_of(cand.data() + i * m->L, m->L, e.lo, e.hi, e.ext);
-        std::memcpy(&e.val, &res[i], 4);
-        e.ci = i;
-        ents.push_back(e);
-    }
-    std::sort(ents.begin(), ents.end(), [](const Entry &a, const Entry &b) {
-        return a.ext != b.ext ? a.ext < b.ext : (a.hi != b.hi ? a.hi < b.hi : a.lo < b.lo);
-    });
-    ents.erase(std::unique(ents.begin(), ents.end(),
-                           [](const Entry &a, const Entry &b) { return a.lo == b.lo && a.hi == b.hi && a.ext == b.ext; }),
-               ents.end());
-    const std::vector<Entry> all_ents = ents;   // the LDS form and the entry count see every entry
     // ---- direct-indexed form (L <= 10): entries without a no-call go to a flat array indexed by the read
-    //      itself; the cuckoo table below keeps only the entries WITH one -------------------------------
+    //      itself; the entries WITH one go to buckets of two slots (direct_memo_plan.hpp) ---------------
     // Measured on MI355X (tools/ab_direct.sh, G reads/s, direct / hash table only): it pays where the hash
     // table is big or most non-exact reads are unmatched -- cfg 5 (1536 IUPAC x 10) 177.5 / 149.3, 1536 x 10 plain
     // 215.9 / 207.7, 1536 x 8 227.2 / 203.2 -- and costs a little where the old LDS hot table already held every
     // exact match of a small table -- cfg 2 pinned (96 x 8) 243.3 / 276.2, 96 x 8 with two mismatches 257.5 / 276.3.
-    bool want_direct = m->L <= fqtk::kDirectMaxLen && (m->L >= 9 || m->S >= 512);
+    bool want_direct = direct_len && (m->L >= 9 || m->S >= 512);
 #ifdef FQTK_DEV_ABLATE
-    if (env_flag("FQTK_FORCE_DIRECT")) want_direct = m->L <= fqtk::kDirectMaxLen;
+    if (env_flag("FQTK_FORCE_DIRECT")) want_direct = direct_len;
 #endif
     if (want_direct) {
-        int rc = build_direct(m, cand, ents, exact, res);
+        int rc = build_direct(m, ents, exact_none);
         if (rc != FQTK_OK) return rc;
         if (m->d_direct) {
-            // the entries with a no-call: buckets of two slots (direct_memo_plan.hpp), probed with the tile's other gathers
             std::vector<fqtk::NKey> with_n;
             for (const Entry &e : ents)
-                if (std::memchr(cand.data() + e.ci * m->L, 'N', m->L)) with_n.push_back(fqtk::NKey{e.lo, e.val});
+                if (e.has_n) with_n.push_back(fqtk::NKey{memo_folded(e.k), e.val});
             const fqtk::NBucketPlan nb = fqtk::plan_nbuckets(with_n);
             bool good = nb.ok;
             for (size_t i = 0; i < with_n.size() && good; ++i) good = fqtk::nbucket_lookup(nb, with_n[i].lo) == with_n[i].val;
-            if (!good) {   // (placement kept failing: drop the direct form, the hash table below serves every read)
-                (void)hipFree(m->d_direct); m->d_direct = nullptr;
-                if (m->d_hot2) { (void)hipFree(m->d_hot2); m->d_hot2 = nullptr; }
-                m->direct_bytes = 0;
-            } else {
+            if (good) {
                 void *d = nullptr;
                 HIP_TRY(hipMalloc(&d, nb.words.size() * sizeof(uint32_t)));
                 HIP_TRY(hipMemcpy(d, nb.words.data(), nb.words.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
                 HIP_TRY(hipDeviceSynchronize());
-                {
-                    std::vector<fqtk::LdsEntry> le(all_ents.size());
-                    for (size_t i = 0; i < all_ents.size(); ++i) {
-                        memo_key_of(cand.data() + all_ents[i].ci * m->L, m->L, le[i].k[0], le[i].k[1], le[i].k[2], false);
-                        le[i].val = all_ents[i].val;
-                    }
-                    rc = build_lds_memo(m, le, enc);
-                    if (rc != FQTK_OK) { (void)hipFree(d); return rc; }
-                }
                 m->memo_second_slot = nb.second;
                 m->memo_mask = nb.mask;
-                m->memo_entries = all_ents.size();
+                m->memo_entries = entries;
                 m->d_memo = d;   // last: enables the memo path
                 return FQTK_OK;
             }
+            // (placement kept failing: drop the direct form, the hash table below serves every read)
+            (void)hipFree(m->d_direct); m->d_direct = nullptr;
+            if (m->d_hot2) { (void)hipFree(m->d_hot2); m->d_hot2 = nullptr; }
+            m->direct_bytes = 0;
         }
     }
-    // two-choice (cuckoo) placement with random-walk eviction; grow on the (unlikely) failure
+    // ---- hash-table form: two-choice (cuckoo) placement with random-walk eviction; grow on the (unlikely) failure.
+    //      Keys as the kernel hashes them: folded to one word for L <= 10, else the unfolded words.
+    const size_t wps = slot_words(kw);
+    std::vector<std::array<uint32_t, 4>> keys(ents.size());
+    for (size_t i = 0; i < ents.size(); ++i) {
+        if (kw == 1) keys[i] = {memo_folded(ents[i].k), 0u, 0u, 0u};
+        else keys[i] = {ents[i].k[0], ents[i].k[1], ents[i].k[2], ents[i].k[3]};
+    }
+    auto slots_of = [&](size_t i, uint32_t mask, uint32_t &a1, uint32_t &a2) { fqtk::memo_hash2(keys[i][0], keys[i][1], keys[i][2], keys[i][3], mask, a1, a2); };
     uint64_t nslots = 1024;
-    uint64_t slot_factor = 4;
+    uint64_t slot_factor = ents.size() > (1u << 20) ? 2 : 4;   // small tables sparse (fewer second probes), big ones at load <= 0.5
 #ifdef FQTK_DEV_ABLATE
     if (const char *sf = std::getenv("FQTK_MEMO_SLOT_FACTOR")) slot_factor = (uint64_t)std::atoi(sf);
 #endif
@@ -1051,22 +1095,22 @@ int build_memo(fqtk_matcher *m, const std::vector<std::vector<uint8_t>> &enc) {
     std::vector<uint32_t> slots;
     uint32_t mask = 0;
     for (int attempt = 0;; ++attempt) {
-        if (attempt == 6) return FQTK_OK;   // placement keeps failing: no memo, every read takes the scan kernel
+        if (attempt == 6 || nslots * wps * 4 >= (1ull << 32)) return FQTK_OK;   // placement keeps failing / past the kernel's
+                                                                              // 32-bit slot offsets: no memo, the scan kernel
         mask = (uint32_t)(nslots - 1);
-        slots.assign(nslots * wps, 0xFFFFFFFFu);
         std::vector<int64_t> owner(nslots, -1);
         bool ok = true;
         uint64_t rng = 0x9E3779B97F4A7C15ull;
         for (size_t i = 0; i < ents.size() && ok; ++i) {
             int64_t cur = (int64_t)i;
             uint32_t a1, a2;
-            fqtk::memo_hash2(ents[cur].lo, ents[cur].hi, ents[cur].ext, mask, a1, a2);
+            slots_of((size_t)cur, mask, a1, a2);
             uint32_t pos = owner[a1] < 0 ? a1 : a2;
             for (int kick = 0;; ++kick) {
                 if (owner[pos] < 0) { owner[pos] = cur; break; }
                 if (kick == 1000) { ok = false; break; }
                 std::swap(cur, owner[pos]);   // evict the occupant, re-home it
-                fqtk::memo_hash2(ents[cur].lo, ents[cur].hi, ents[cur].ext, mask, a1, a2);
+                slots_of((size_t)cur, mask, a1, a2);
                 rng = rng * 6364136223846793005ull + 1442695040888963407ull;
                 pos = (a1 == pos) ? a2 : ((a2 == pos) ? a1 : ((rng >> 33) & 1 ? a1 : a2));
                 if (a1 == a2 && owner[pos] >= 0 && kick > 8) { ok = false; break; }
@@ -1080,7 +1124,7 @@ int build_memo(fqtk_matcher *m, const std::vector<std::vector<uint8_t>> &enc) {
             for (uint64_t p = 0; p < nslots; ++p) {
                 if (owner[p] < 0) continue;
                 uint32_t a1, a2;
-                fqtk::memo_hash2(ents[owner[p]].lo, ents[owner[p]].hi, ents[owner[p]].ext, mask, a1, a2);
+                slots_of((size_t)owner[p], mask, a1, a2);
                 if (a1 != p && owner[a1] < 0) { owner[a1] = owner[p]; owner[p] = -1; moved = true; }
             }
         }
@@ -1089,55 +1133,41 @@ int build_memo(fqtk_matcher *m, const std::vector<std::vector<uint8_t>> &enc) {
         for (uint64_t p = 0; p < nslots; ++p) {
             if (owner[p] < 0) continue;
             uint32_t a1, a2;
-            fqtk::memo_hash2(ents[owner[p]].lo, ents[owner[p]].hi, ents[owner[p]].ext, mask, a1, a2);
+            slots_of((size_t)owner[p], mask, a1, a2);
             if (a1 != p) { spill[a1] = 1; ++n_second; }
         }
         m->memo_second_slot = n_second;
-        for (uint64_t p = 0; p < nslots; ++p) {
-            uint32_t *w = &slots[p * wps];
-            if (wide) w[3] = spill[p]; else w[0] = 0x7FFFFFFFu | ((uint32_t)spill[p] << 31);
-            if (owner[p] < 0) continue;
-            const Entry &e = ents[owner[p]];
-            if (wide) { w[0] = e.lo; w[1] = e.hi; w[2] = e.val; w[3] = spill[p] | (e.ext << 16); }
-            else { w[0] = e.lo | ((uint32_t)spill[p] << 31); w[1] = e.val; }
-        }
+        slots.assign(nslots * wps, 0u);
+        for (uint64_t p = 0; p < nslots; ++p)
+            write_slot(&slots[p * wps], kw, owner[p] < 0 ? nullptr : keys[(size_t)owner[p]].data(),
+                       owner[p] < 0 ? 0u : ents[(size_t)owner[p]].val, spill[p] != 0);
         break;
-    }
-    const uint64_t entries = all_ents.size();
-    {
-        std::vector<fqtk::LdsEntry> le(all_ents.size());
-        for (size_t i = 0; i < all_ents.size(); ++i) {
-            memo_key_of(cand.data() + all_ents[i].ci * m->L, m->L, le[i].k[0], le[i].k[1], le[i].k[2], false);
-            le[i].val = all_ents[i].val;
-        }
-        int rc = build_lds_memo(m, le, enc);
-        if (rc != FQTK_OK) return rc;
     }
     // hot table for LDS: 0-mismatch entries, two-choice without eviction (it is only a cache: an
     // entry that finds both of its slots taken is simply served by the global table)
     {
-        const uint32_t slot_bytes = wide ? 16 : 8;
+        const uint32_t slot_bytes = (uint32_t)wps * 4;
         uint32_t hot_slots = fqtk::kHotBytes / slot_bytes;
         uint64_t n_hot = 0;
         for (const Entry &e : ents) n_hot += ((e.val >> 16) & 0xFFu) == 0;
         while (hot_slots > 64 && hot_slots / 2 >= n_hot * 2) hot_slots >>= 1;
-        if (n_hot && !m->d_direct) {
+        if (n_hot) {
             const uint32_t hmask = hot_slots - 1;
-            std::vector<uint32_t> hot((size_t)hot_slots * wps, 0xFFFFFFFFu);
-            std::vector<Entry> order;
-            for (const Entry &e : ents) if (((e.val >> 16) & 0xFFu) == 0) order.push_back(e);
-            std::sort(order.begin(), order.end(), [](const Entry &a, const Entry &b) {
-                return (a.val & 0xFFFFu) < (b.val & 0xFFFFu);   // low sample index first
+            std::vector<uint32_t> hot((size_t)hot_slots * wps, 0u);
+            std::vector<uint8_t> used(hot_slots, 0);
+            for (uint32_t p = 0; p < hot_slots; ++p) write_slot(&hot[(size_t)p * wps], kw, nullptr, 0u, false);
+            std::vector<size_t> order;
+            for (size_t i = 0; i < ents.size(); ++i) if (((ents[i].val >> 16) & 0xFFu) == 0) order.push_back(i);
+            std::stable_sort(order.begin(), order.end(), [&](size_t a, size_t b) {
+                return (ents[a].val & 0xFFFFu) < (ents[b].val & 0xFFFFu);   // low sample index first
             });
-            for (const Entry &e : order) {
+            for (size_t i : order) {
                 uint32_t a1, a2;
-                fqtk::memo_hash2(e.lo, e.hi, e.ext, mask, a1, a2);
+                slots_of(i, mask, a1, a2);
                 for (uint32_t a : {a1 & hmask, a2 & hmask}) {
-                    uint32_t *w = &hot[(size_t)a * wps];
-                    const uint32_t v = wide ? w[2] : w[1];
-                    if (v != fqtk::kMemoEmpty) continue;
-                    w[0] = e.lo;
-                    if (wide) { w[1] = e.hi; w[2] = e.val; w[3] = e.ext << 16; } else { w[1] = e.val; }
+                    if (used[a]) continue;
+                    used[a] = 1;
+                    write_slot(&hot[(size_t)a * wps], kw, keys[i].data(), ents[i].val, false);
                     break;
                 }
             }

@@ -222,7 +222,7 @@ int64_t fqtk_host_load_samples(const char *path, char *err, size_t errcap) {
 }
 
 
-// Plans the LDS-resident memo from `n_ents` (key[3], val) entries and the S x L encoded sample barcodes.
+// Plans the LDS-resident memo from `n_ents` (key[4], val) entries and the S x L encoded sample barcodes.
 // meta = {ok, n_slots, slot_mask_b, idx_bits, skey_off_b, salt, kw, key_stride, pow2, image_words}.
 // Returns 0 (also when the memo is not of the LDS shape: meta[0] = 0), -2 if `image` is too small.
 int fqtk_host_plan_lds_memo(uint32_t S, uint32_t L, const uint8_t *enc, uint64_t n_ents, const uint32_t *keys,
@@ -232,7 +232,7 @@ int fqtk_host_plan_lds_memo(uint32_t S, uint32_t L, const uint8_t *enc, uint64_t
     for (uint32_t s = 0; s < S; ++s) std::memcpy(e[s].data(), enc + (size_t)s * L, L);
     std::vector<fqtk::LdsEntry> ents(n_ents);
     for (uint64_t i = 0; i < n_ents; ++i) {
-        for (int w = 0; w < 3; ++w) ents[i].k[w] = keys[3 * i + w];
+        for (int w = 0; w < 4; ++w) ents[i].k[w] = keys[4 * i + w];
         ents[i].val = vals[i];
     }
     const fqtk::LdsMemoPlan p = fqtk::plan_lds_memo(S, L, ents, e, salt_offset, salt_trials);
@@ -252,7 +252,7 @@ void fqtk_host_lds_memo_lookup(const uint32_t *image, const uint32_t *meta, uint
     p.image.assign(image, image + meta[9]);
     p.n_slots = meta[1]; p.slot_mask_b = meta[2]; p.idx_bits = meta[3]; p.skey_off_b = meta[4];
     p.salt = meta[5]; p.kw = (int)meta[6]; p.key_stride = (int)meta[7]; p.pow2 = meta[8] != 0;
-    for (uint64_t i = 0; i < n; ++i) out[i] = fqtk::lds_memo_lookup(p, keys + 3 * i);
+    for (uint64_t i = 0; i < n; ++i) out[i] = fqtk::lds_memo_lookup(p, keys + 4 * i);
 }
 
 // Plans the direct-indexed memo (csrc/direct_memo_plan.hpp) from n_ents no-call-free entries given as

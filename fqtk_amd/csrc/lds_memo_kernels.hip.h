@@ -94,7 +94,7 @@ void lds_memo_kernel(const LdsMemoParams Q) {
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
     // LDS: [entry table | sample keys | spread LUT (fallback scan) | histogram]; the entry table sits
     // at byte 0 so a masked hash is used as the ds_read address as is
-    constexpr int KS = KW == 3 ? 4 : KW;                      // key stride in dwords (b128 reads for KW 3)
+    constexpr int KS = KW >= 3 ? 4 : KW;                      // key stride in dwords (b128 reads for KW 3 and 4)
     const uint32_t tid = threadIdx.x;
     if constexpr (INDEXED) {   // nothing listed for this workgroup's waves (the usual case): leave before staging anything
         uint32_t any = 0;
@@ -126,7 +126,7 @@ void lds_memo_kernel(const LdsMemoParams Q) {
 
     const uint32_t L = P.L;
     const uint32_t nwords = (L + 3u) >> 2;
-    constexpr int NWD = VEC >= 1 ? VEC : (KW == 1 ? 2 : (KW == 2 ? 4 : 5));
+    constexpr int NWD = VEC >= 1 ? VEC : 2 * KW;
     static_assert(NWD <= 2 * KW, "key too narrow for the load width");
     uint32_t kc[NWD], kv[NWD];
 #pragma unroll
@@ -161,7 +161,7 @@ void lds_memo_kernel(const LdsMemoParams Q) {
     const uint32_t hist_bin_shift = Q.hist_shift + 2u;
 
     // The packed vector loads of one full tile (every read exists, the rows are VEC dwords).
-    auto load_full = [&](uint64_t t, uint32_t (&words)[R][8]) {
+    auto load_full = [&](uint64_t t, uint32_t (&words)[R][kRowWords]) {
         const uint8_t *tile_in = P.obs + t * tile * (uint64_t)P.stride;   // wave-uniform
 #pragma unroll
         for (int r = 0; r < R; ++r) {
@@ -169,31 +169,43 @@ void lds_memo_kernel(const LdsMemoParams Q) {
             if constexpr (VEC == 4) {
                 const u32x4v v = FQTK_STREAM_LOAD(reinterpret_cast<const u32x4v *>(src));
                 words[r][0] = v.x; words[r][1] = v.y; words[r][2] = v.z; words[r][3] = v.w;
-            } else if constexpr (VEC == 3 || VEC == 5) {   // 12- / 20-byte rows are only 4-byte aligned: dword pieces,
+            } else if constexpr (VEC == 3 || VEC == 5 || VEC == 7) {   // 12- / 20- / 28-byte rows are only 4-byte aligned: dword pieces,
                 const uint32_t *s32 = reinterpret_cast<const uint32_t *>(src);   // non-temporal like the rest of the stream
 #pragma unroll
                 for (int w = 0; w < VEC; ++w) words[r][w] = FQTK_STREAM_LOAD(s32 + w);
             } else if constexpr (VEC == 2) {
                 const u32x2v v = FQTK_STREAM_LOAD(reinterpret_cast<const u32x2v *>(src));
                 words[r][0] = v.x; words[r][1] = v.y;
+            } else if constexpr (VEC == 6) {   // 24-byte rows (12 + 12 dual index): three 8-byte pieces
+#pragma unroll
+                for (int w = 0; w < 3; ++w) {
+                    const u32x2v v = FQTK_STREAM_LOAD(reinterpret_cast<const u32x2v *>(src) + w);
+                    words[r][2 * w] = v.x; words[r][2 * w + 1] = v.y;
+                }
+            } else if constexpr (VEC == 8) {   // 32-byte rows: two 16-byte pieces
+#pragma unroll
+                for (int w = 0; w < 2; ++w) {
+                    const u32x4v v = FQTK_STREAM_LOAD(reinterpret_cast<const u32x4v *>(src) + w);
+                    words[r][4 * w] = v.x; words[r][4 * w + 1] = v.y; words[r][4 * w + 2] = v.z; words[r][4 * w + 3] = v.w;
+                }
             } else {
                 words[r][0] = FQTK_STREAM_LOAD(reinterpret_cast<const uint32_t *>(src));
             }
-            // a variable-length batch: the read's length travels with its row (word 7 of the buffer is free: keys
-            // have five words at most), in the same group of loads -- so these batches take the pipelined loop too
-            if constexpr (LENS) words[r][7] = FQTK_STREAM_LOAD(P.lens + t * tile + local[r]);
+            // a variable-length batch: the read's length travels with its row (the buffer's last word), in the same
+            // group of loads -- so these batches take the pipelined loop too
+            if constexpr (LENS) words[r][kLenWord] = FQTK_STREAM_LOAD(P.lens + t * tile + local[r]);
         }
     };
     // Any tile through the generic path (ragged last tile, unaligned strides): bounds-checked loads.
-    auto load_any = [&](uint64_t t, uint32_t (&words)[R][8], bool (&live)[R]) {
+    auto load_any = [&](uint64_t t, uint32_t (&words)[R][kRowWords], bool (&live)[R]) {
 #pragma unroll
         for (int r = 0; r < R; ++r) {
             const uint64_t i = t * tile + local[r];
             live[r] = i < P.n;
 #pragma unroll
             for (int w = 0; w < 8; ++w) words[r][w] = 0x41414141u;   // dead lanes look like "AAAA"
-            if (live[r]) load_words<1, VEC>(P, i, nwords, words[r]);
-            if constexpr (LENS) words[r][7] = live[r] ? P.lens[i] : L;
+            if (live[r]) load_words<1, VEC, kRowWords>(P, i, nwords, words[r]);
+            if constexpr (LENS) words[r][kLenWord] = live[r] ? P.lens[i] : L;
         }
     };
 
@@ -201,11 +213,11 @@ void lds_memo_kernel(const LdsMemoParams Q) {
     const uint32_t work_seg = blockIdx.x * (kLdsBlock / 64u) + (uint32_t)__builtin_amdgcn_readfirstlane((int)(tid >> 6));   // wave-uniform: SGPRs
     uint32_t work_fill = 0;
     // Looks one tile up: res[r] = the result word of the tile's r-th read; also feeds the LDS histogram.
-    auto compute = [&](uint64_t t, uint32_t (&words)[R][8], const bool (&live)[R], uint32_t (&res)[R]) {
+    auto compute = [&](uint64_t t, uint32_t (&words)[R][kRowWords], const bool (&live)[R], uint32_t (&res)[R]) {
         uint32_t bflag[R];
         // One read at a time: hash, three entry reads, select, verify; the rare extra verification
         // rounds sit behind wave-uniform branches.
-        uint32_t lo[R], hi[R], ext[R];
+        uint32_t key[R][4];
         // candidate -> exact check against the sample's own key: key ^ sample_key == xnib << 4*pos
         auto verify = [&](int r, uint32_t e) -> uint32_t {
             const uint32_t ka = Q.skey_off_b + (e & idx_mask) * (KS * 4u);
@@ -213,25 +225,26 @@ void lds_memo_kernel(const LdsMemoParams Q) {
             const uint32_t tsh = xnib << ((e >> 18) & 28u);        // the differing nibble, in its word
             uint32_t diff;
             if constexpr (KW == 1) {
-                diff = lo[r] ^ lds_word(ka) ^ tsh;
+                diff = key[r][0] ^ lds_word(ka) ^ tsh;
             } else if constexpr (KW == 2) {
                 const u32x2v sk = *reinterpret_cast<lds_u2 *>((uintptr_t)ka);
                 const bool w1 = (e & (1u << 23)) != 0;
-                diff = (lo[r] ^ sk.x ^ (w1 ? 0u : tsh)) | (hi[r] ^ sk.y ^ (w1 ? tsh : 0u));
-            } else {
+                diff = (key[r][0] ^ sk.x ^ (w1 ? 0u : tsh)) | (key[r][1] ^ sk.y ^ (w1 ? tsh : 0u));
+            } else {   // the differing nibble's word: bit 23 = pos bit 3, bit 29 = pos bit 4
                 const u32x4v sk = *reinterpret_cast<lds_u4 *>((uintptr_t)ka);
                 const bool w1 = (e & (1u << 23)) != 0, w2 = (e & (1u << 29)) != 0;
-                diff = (lo[r] ^ sk.x ^ ((w1 || w2) ? 0u : tsh)) | (hi[r] ^ sk.y ^ (w1 ? tsh : 0u)) |
-                       (ext[r] ^ sk.z ^ (w2 ? tsh : 0u));
+                diff = (key[r][0] ^ sk.x ^ ((w1 || w2) ? 0u : tsh)) | (key[r][1] ^ sk.y ^ ((w1 && !w2) ? tsh : 0u)) |
+                       (key[r][2] ^ sk.z ^ ((w2 && !w1) ? tsh : 0u));
+                if constexpr (KW == 4) diff |= key[r][3] ^ sk.w ^ ((w1 && w2) ? tsh : 0u);
             }
             return diff == 0 ? (e & res_mask) : kMemoEmpty;
         };
 #pragma unroll
         for (int r = 0; r < R; ++r) {
-            encode_nibbles<NWD, (VEC >= 1), false>(words[r], kc, kv, lo[r], hi[r], ext[r], bflag[r]);
-            if constexpr ((FQTK_LDSM_ABL & 1) != 0) { res[r] = (lo[r] ^ (KW >= 2 ? hi[r] : 0u)) | 0xFFFFu; continue; }
+            encode_nibbles<NWD, (VEC >= 1), false>(words[r], kc, kv, key[r], bflag[r]);
+            if constexpr ((FQTK_LDSM_ABL & 1) != 0) { res[r] = (key[r][0] ^ (KW >= 2 ? key[r][1] : 0u)) | 0xFFFFu; continue; }
             uint32_t h1, h2, h3, fps;
-            memo_hash3(lo[r], KW >= 2 ? hi[r] : 0u, KW >= 3 ? ext[r] : 0u, Q.salt, h1, h2, h3, fps);
+            memo_hash3(key[r][0], KW >= 2 ? key[r][1] : 0u, KW >= 3 ? key[r][2] : 0u, KW >= 4 ? key[r][3] : 0u, Q.salt, h1, h2, h3, fps);
             (void)h3;
             uint32_t a1, a2, a3;
             lds_slots(POW2, h1, h2, Q.slot_mask_b, Q.n_slots, a1, a2, a3);
@@ -264,7 +277,7 @@ void lds_memo_kernel(const LdsMemoParams Q) {
 #pragma unroll
             for (int r = 0; r < R; ++r) {
                 if (!live[r]) continue;
-                const uint32_t len = words[r][7];
+                const uint32_t len = words[r][kLenWord];
                 if (len != L) {
                     res[r] = kMemoEmpty;
                     bflag[r] = 0;
@@ -332,7 +345,7 @@ void lds_memo_kernel(const LdsMemoParams Q) {
             // R reads per lane: a wave's iteration is a chain of dependent memory round trips (list entry [, row], result
             // store) and the R of them overlap
             for (uint32_t base = 0; base < cnt; base += 64u * R) {
-                uint32_t words[R][8], res[R];
+                uint32_t words[R][kRowWords], res[R];
                 bool live[R];
                 uint64_t row[R];
 #pragma unroll
@@ -357,7 +370,7 @@ void lds_memo_kernel(const LdsMemoParams Q) {
                 if (!P.work_rw) {
 #pragma unroll
                     for (int r = 0; r < R; ++r)
-                        if (live[r]) load_words<1, VEC>(P, row[r], nwords, words[r]);
+                        if (live[r]) load_words<1, VEC, kRowWords>(P, row[r], nwords, words[r]);
                 }
 #pragma unroll
                 for (int r = 0; r < R; ++r) spell_ambiguity_codes_as_n<NWD>(words[r]);
@@ -383,15 +396,15 @@ void lds_memo_kernel(const LdsMemoParams Q) {
         // then issues the next tile's loads and the previous tile's stores, which fly during the look-up.
         // Two word buffers used alternately (no register rotation); the prefetch is unconditional -- past the
         // end it re-reads the last full tile and the words are never used -- so that it cannot sit in a branch.
-        uint32_t wa[R][8], wb[R][8], held[R];
-        auto landed = [&](uint32_t (&w)[R][8]) {   // the words are in registers; nothing below moves above this point
+        uint32_t wa[R][kRowWords], wb[R][kRowWords], held[R];
+        auto landed = [&](uint32_t (&w)[R][kRowWords]) {   // the words are in registers; nothing below moves above this point
 #pragma unroll
             for (int r = 0; r < R; ++r)
 #pragma unroll
                 for (int k = 0; k < NWD; ++k) asm volatile("" : "+v"(w[r][k]) : : "memory");
             if constexpr (LENS) {
 #pragma unroll
-                for (int r = 0; r < R; ++r) asm volatile("" : "+v"(w[r][7]) : : "memory");
+                for (int r = 0; r < R; ++r) asm volatile("" : "+v"(w[r][kLenWord]) : : "memory");
             }
         };
         auto computed = [&](uint32_t (&v)[R]) {     // the results exist now (their gathers / LDS reads were waited for HERE)
@@ -434,7 +447,7 @@ void lds_memo_kernel(const LdsMemoParams Q) {
         }
     } else {
         for (uint64_t t = blockIdx.x; t < full_tiles; t += gridDim.x) {
-            uint32_t words[R][8], res[R];
+            uint32_t words[R][kRowWords], res[R];
             load_full(t, words);
             compute(t, words, all_live, res);
             store_full(t, res);
@@ -442,7 +455,7 @@ void lds_memo_kernel(const LdsMemoParams Q) {
     }
     // whatever is left (the ragged last tile; every tile on the generic load paths)
     for (uint64_t t = full_tiles + (blockIdx.x + gridDim.x - full_tiles % gridDim.x) % gridDim.x; t < (INDEXED ? 0 : ntiles); t += gridDim.x) {
-        uint32_t words[R][8], res[R];
+        uint32_t words[R][kRowWords], res[R];
         bool live[R];
         load_any(t, words, live);
         compute(t, words, live, res);

@@ -16,7 +16,7 @@
 
 namespace fqtk {
 
-struct LdsEntry { uint32_t k[3]; uint32_t val; };
+struct LdsEntry { uint32_t k[4]; uint32_t val; };
 
 struct LdsMemoPlan {
     bool ok = false;
@@ -27,17 +27,17 @@ struct LdsMemoPlan {
     uint32_t idx_bits = 0;
     uint32_t skey_off_b = 0;
     uint32_t salt = 0;
-    int kw = 0;                    // key words: 1 (L <= 8), 2 (L <= 16), 3 (L <= 20) -- never folded
-    int key_stride = 0;            // dwords per sample key (4 for kw = 3)
+    int kw = 0;                    // key words: 1 (L <= 8), 2 (L <= 16), 3 (L <= 24), 4 (L <= 32) -- never folded
+    int key_stride = 0;            // dwords per sample key (4 for kw = 3 and 4)
     uint64_t multi_score = 0;      // (exact-match keys with > 1 fingerprint match) << 32 | all such keys
 };
 
 // The kernel's lookup, for the builder's self-check and for tests: returns the result word or kMemoEmpty.
 // A candidate whose fingerprint agrees is VERIFIED against its sample's key; candidates are tried in
 // probe order until one verifies (the kernel does the same, the later rounds behind wave-uniform branches).
-inline uint32_t lds_memo_lookup(const LdsMemoPlan &p, const uint32_t key[3]) {
+inline uint32_t lds_memo_lookup(const LdsMemoPlan &p, const uint32_t key[4]) {
     uint32_t h[3], fps;
-    memo_hash3(key[0], key[1], key[2], p.salt, h[0], h[1], h[2], fps);
+    memo_hash3(key[0], key[1], key[2], key[3], p.salt, h[0], h[1], h[2], fps);
     const uint32_t fp_mask = lds_fp_mask(p.idx_bits, p.kw);
     uint32_t a[3];
     lds_slots(p.pow2, h[0], h[1], p.slot_mask_b, p.n_slots, a[0], a[1], a[2]);
@@ -62,12 +62,12 @@ inline LdsMemoPlan plan_lds_memo(uint32_t S, uint32_t L, const std::vector<LdsEn
     uint32_t idx_bits = 1;
     while ((1u << idx_bits) < S + 1) ++idx_bits;
     if (idx_bits > kLdsMaxIdxBits) return plan;
-    const int kw = L <= 8 ? 1 : (L <= 16 ? 2 : 3);
-    const int ks = kw == 3 ? 4 : kw;
+    const int kw = L <= 8 ? 1 : (L <= 16 ? 2 : (L <= 24 ? 3 : 4));
+    const int ks = kw >= 3 ? 4 : kw;
     // sample keys; only plain A/C/G/T samples have one (an IUPAC / N sample matches several strings)
     std::vector<uint32_t> skeys((size_t)(S + 1) * ks, 0xFFFFFFFFu);   // row S = "no sample": equals no key
     for (uint32_t s = 0; s < S; ++s) {
-        uint32_t k[3] = {0, 0, 0};
+        uint32_t k[4] = {0, 0, 0, 0};
         for (uint32_t i = 0; i < L; ++i) {
             const uint8_t nib = enc[s][i];
             if (nib != 1 && nib != 2 && nib != 4 && nib != 8) return plan;
@@ -82,7 +82,7 @@ inline LdsMemoPlan plan_lds_memo(uint32_t S, uint32_t L, const std::vector<LdsEn
         const uint32_t idx = ents[i].val & 0xFFFFu, best = (ents[i].val >> 16) & 0xFFu, next = ents[i].val >> 24;
         if (idx >= S || next > 31 || best > 1) return plan;
         uint32_t pos = 0, xnib = 0, ndiff = 0;
-        for (uint32_t b = 0; b < 24; ++b) {
+        for (uint32_t b = 0; b < 32; ++b) {
             const uint32_t w = b >> 3;
             const uint32_t sk = w < (uint32_t)kw ? skeys[(size_t)idx * ks + w] : 0u;
             const uint32_t x = ((ents[i].k[w] ^ sk) >> (4 * (b & 7))) & 0xFu;
@@ -123,7 +123,7 @@ inline LdsMemoPlan plan_lds_memo(uint32_t S, uint32_t L, const std::vector<LdsEn
         const uint32_t salt = 0x51ED27u * (uint32_t)(attempt + 1 + salt_offset);
         owner.assign(nslots, -1);
         for (size_t i = 0; i < ents.size(); ++i)
-            memo_hash3(ents[i].k[0], ents[i].k[1], ents[i].k[2], salt, h[3 * i], h[3 * i + 1], h[3 * i + 2], fps[i]);
+            memo_hash3(ents[i].k[0], ents[i].k[1], ents[i].k[2], ents[i].k[3], salt, h[3 * i], h[3 * i + 1], h[3 * i + 2], fps[i]);
         auto slot_of = [&](size_t i, int c) {
             uint32_t a[3];
             lds_slots(pow2, h[3 * i], h[3 * i + 1], mask_b, (uint32_t)nslots, a[0], a[1], a[2]);

@@ -170,10 +170,11 @@ typedef uint32_t u32x2v __attribute__((ext_vector_type(2)));
 #endif
 
 // Load the first ceil(L/4) dwords of read `i`.  VEC = stride in dwords when the fast, aligned vector
-// path applies (1,2,3,4,5), 0 = generic byte path (any stride / alignment).
-template <int NW, int VEC>
+// path applies (1 .. 8), 0 = generic byte path (any stride / alignment).
+template <int NW, int VEC, int N>
 __device__ __forceinline__ void load_words(const MatchParams &P, uint64_t i, uint32_t nwords,
-                                           uint32_t (&words)[NW * 8]) {
+                                           uint32_t (&words)[N]) {
+    static_assert(N >= NW * 8, "row buffer too small");
     const uint8_t *src = P.obs + i * (uint64_t)P.stride;
     if constexpr (VEC == 4) {
         const u32x4v v = FQTK_STREAM_LOAD(reinterpret_cast<const u32x4v *>(src));
@@ -189,6 +190,17 @@ __device__ __forceinline__ void load_words(const MatchParams &P, uint64_t i, uin
     } else if constexpr (VEC == 5) {   // 20-byte reads (10+10 dual index): rows are only 4-byte aligned
         const uint32_t *s32 = reinterpret_cast<const uint32_t *>(src);
         words[0] = s32[0]; words[1] = s32[1]; words[2] = s32[2]; words[3] = s32[3]; words[4] = s32[4];
+    } else if constexpr (VEC == 6) {   // 24-byte rows (12 + 12): 8-byte aligned
+        const u32x2v *s64 = reinterpret_cast<const u32x2v *>(src);
+        const u32x2v a = s64[0], b = s64[1], c = s64[2];
+        words[0] = a.x; words[1] = a.y; words[2] = b.x; words[3] = b.y; words[4] = c.x; words[5] = c.y;
+    } else if constexpr (VEC == 7) {
+        const uint32_t *s32 = reinterpret_cast<const uint32_t *>(src);
+#pragma unroll
+        for (int w = 0; w < 7; ++w) words[w] = s32[w];
+    } else if constexpr (VEC == 8) {   // 32-byte rows: 16-byte aligned
+        const u32x4v a = reinterpret_cast<const u32x4v *>(src)[0], b = reinterpret_cast<const u32x4v *>(src)[1];
+        words[0] = a.x; words[1] = a.y; words[2] = a.z; words[3] = a.w; words[4] = b.x; words[5] = b.y; words[6] = b.z; words[7] = b.w;
     } else if constexpr (VEC == -1) {   // stride % 4 == 0, base 4-aligned, any length
 #pragma unroll
         for (int w = 0; w < NW * 8; ++w)
@@ -341,7 +353,7 @@ __global__ __launch_bounds__(kBlock) void match_kernel(const MatchParams P) {
                     for (int w = 0; w < 8; ++w)
                         if ((uint32_t)w < P.work_rw && (uint32_t)w < nwords) words[w] = entry[1 + w];
                 }
-            } else if (live[r]) load_words<NW, VEC>(P, i, nwords, words);
+            } else if (live[r]) load_words<NW, VEC, NW * 8>(P, i, nwords, words);
             encode_planes<NW>(words, nwords, P.L, lds_lut, o[r]);
         }
 

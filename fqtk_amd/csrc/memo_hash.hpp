@@ -11,12 +11,14 @@
 
 namespace fqtk {
 
-constexpr uint32_t kMemoMaxLen = 20;       // 4 bits/base: lo = bases 0-7, hi = 8-15, ext = 16-19
+constexpr uint32_t kMemoMaxLen = 32;       // 4 bits/base, eight bases per key word: lo = bases 0-7, hi = 8-15, ext = 16-23, ext2 = 24-31
+constexpr int kMemoMaxKeyWords = 4;
 // Inside a key word, byte k holds base k in its low nibble and base 4+k in its high nibble: the kernel
-// packs two 4-base input words with ONE v_lshl_or_b32 (codes_hi << 4 | codes_lo).
-// The third word (bases 16-19) keeps its 4 nibbles contiguous: it has to fit 16 bits of a table slot.
-FQTK_HD constexpr uint32_t memo_nibble_shift(uint32_t base) {   // bit offset of `base` inside its key word
-    return base >= 16u ? 4u * (base - 16u) : 4u * (((base & 3u) << 1) | ((base & 7u) >> 2));
+// packs two 4-base input words with ONE v_lshl_or_b32 (codes_hi << 4 | codes_lo).  The same in every word.
+// (The reference's cache has no length limit at all -- barcode_matching.rs:174-181 keys an AHashMap by the raw bytes --
+// 32 bases cover 16 + 16 dual indices; longer barcodes take the exhaustive scan.)
+FQTK_HD constexpr uint32_t memo_nibble_shift(uint32_t base) {   // bit offset of `base` inside its key word (base >> 3)
+    return 4u * (((base & 3u) << 1) | ((base & 7u) >> 2));
 }
 constexpr uint32_t kMemoEmpty = 0xFFFFFFFFu;
 // Placeholder a memo kernel writes for a read it handed to the second pass (index 0xFFFE is no sample: at most
@@ -29,8 +31,8 @@ constexpr uint32_t kMemoDeferred = 0xFFFFFFFEu;
 constexpr uint32_t kHotBytes = FQTK_HOT_BYTES;   // LDS budget of the hot table per workgroup
 
 // Key words: 1 (L <= 10: bases 8-9 are folded into the spare top bits of lo's nibbles, see kFoldMul),
-// 2 (L <= 16), 3 (L <= 20).
-FQTK_HD constexpr int memo_key_words(uint32_t L) { return L <= 10 ? 1 : (L <= 16 ? 2 : 3); }
+// 2 (L <= 16), 3 (L <= 24), 4 (L <= 32).
+FQTK_HD constexpr int memo_key_words(uint32_t L) { return L <= 10 ? 1 : (L <= 16 ? 2 : (L <= 24 ? 3 : 4)); }
 // Fold of the third word's codes x = code8 | code9 << 8 into bits {3,7,19} / {11,15,27} of lo: the three
 // shifted copies of x (<< 3, << 6, << 17) have disjoint supports, so one 24-bit multiply and one AND
 // deposit the six bits with no carries; bit 31 stays free for the slot's SPILL flag.
@@ -50,7 +52,8 @@ inline uint32_t memo_code_of(char ch) {   // host mirror (the builder only sees 
 // Two-choice (cuckoo) placement: a key lives in slot h1 or slot h2, nowhere else, so a lookup is two
 // INDEPENDENT loads issued back to back -- no probe loop, no divergence, one memory round trip.
 // 24-bit multiplies only: v_mul_u32_u24 / v_mad_u32_u24 issue at the full VALU rate on gfx950, while
-// v_mul_lo_u32 is quarter rate.  The 80-bit key is cut into four <=24-bit limbs.
+// v_mul_lo_u32 is quarter rate.  The key is cut into <= 24-bit limbs, one multiply each (the limbs of absent key words
+// are compile-time zeros in the kernels: their multiplies fold away).
 FQTK_HD inline uint32_t mul24(uint32_t a, uint32_t b) {
 #if defined(__HIP_DEVICE_COMPILE__)
     return __umul24(a, b);
@@ -58,19 +61,40 @@ FQTK_HD inline uint32_t mul24(uint32_t a, uint32_t b) {
     return (a & 0xFFFFFFu) * (b & 0xFFFFFFu);
 #endif
 }
-FQTK_HD inline void memo_hash2(uint32_t lo, uint32_t hi, uint32_t ext, uint32_t mask,
-                                           uint32_t &s1, uint32_t &s2) {
-    const uint32_t a = lo;                         // mul24 reads bits 0..23: bases 0-5
-    const uint32_t b = (lo >> 24) | (hi << 8);     // bases 6-7 and 8-11
-    const uint32_t c = (hi >> 16) | (ext << 16);   // bases 12-15 and 16-17
-    const uint32_t d = ext >> 8;                   // bases 18-19
-    uint32_t h = mul24(a, 0x9E3779u) + mul24(b, 0x85EBCBu) + mul24(c, 0xC2B2AFu) + mul24(d, 0xA54FF5u);
+FQTK_HD inline uint32_t memo_limb_sum(uint32_t lo, uint32_t hi, uint32_t ext, uint32_t ext2) {
+    const uint32_t a = lo;                         // mul24 reads bits 0..23
+    const uint32_t b = (lo >> 24) | (hi << 8);
+    const uint32_t c = (hi >> 16) | (ext << 16);
+    const uint32_t d = ext >> 8;
+    const uint32_t e = ext2;
+    const uint32_t f = ext2 >> 24;
+    return mul24(a, 0x9E3779u) + mul24(b, 0x85EBCBu) + mul24(c, 0xC2B2AFu) + mul24(d, 0xA54FF5u) + mul24(e, 0xB5297Au) + mul24(f, 0x68E31Du);
+}
+// The same limbs under a second set of odd multipliers: the two slots of a key come from two INDEPENDENT 32-bit sums.
+// (Until round 4 the second slot was a function of the first sum alone: keys whose sums collide then share BOTH slots,
+// the sums being linear in the limbs such collisions are systematic among millions of one- and two-substitution
+// neighbours, and three of them made every placement fail whatever the table's size -- 384 x 24 bases with two
+// mismatches, 1.7 M keys.)
+FQTK_HD inline uint32_t memo_limb_sum2(uint32_t lo, uint32_t hi, uint32_t ext, uint32_t ext2) {
+    const uint32_t a = lo;
+    const uint32_t b = (lo >> 24) | (hi << 8);
+    const uint32_t c = (hi >> 16) | (ext << 16);
+    const uint32_t d = ext >> 8;
+    const uint32_t e = ext2;
+    const uint32_t f = ext2 >> 24;
+    return mul24(a, 0xD6E8FFu) + mul24(b, 0x2C1B3Du) + mul24(c, 0x7F4A7Du) + mul24(d, 0x51ED27u) + mul24(e, 0xC4CEB9u) + mul24(f, 0x3243F7u);
+}
+FQTK_HD inline void memo_hash2(uint32_t lo, uint32_t hi, uint32_t ext, uint32_t ext2, uint32_t mask,
+                               uint32_t &s1, uint32_t &s2) {
+    uint32_t h = memo_limb_sum(lo, hi, ext, ext2);
     h ^= h >> 15;
     h = mul24(h, 0x2C1B3Du) + (h >> 9);
     h ^= h >> 13;
     s1 = h & mask;
-    uint32_t g = mul24(h >> 7, 0xD6E8FFu) + h;
+    uint32_t g = memo_limb_sum2(lo, hi, ext, ext2);
     g ^= g >> 14;
+    g = mul24(g, 0x9E3779u) + (g >> 10);
+    g ^= g >> 12;
     s2 = g & mask;
 }
 
@@ -146,7 +170,7 @@ FQTK_HD inline uint32_t memo_nbucket_shift(uint32_t mask) {   // mask = buckets 
 constexpr uint32_t kLdsMemoMaxBytes = 160u * 1024u;   // LDS per CU = per workgroup limit on gfx950
 // Entry dword.  The result bits sit where fqtk_match_t wants them, so "entry & res_mask" IS the result:
 //   [0, IB) idx | [IB, 16) fingerprint | 16 best | 17-19 xnib | 20-23 pos (nibble index; bit 23 = hi word)
-//   | 24-28 next | 29 pos bit 4 (ext word; 3-word keys only, else fingerprint) | 30-31 fingerprint
+//   | 24-28 next | 29 pos bit 4 (ext / ext2 words; keys of 3 and 4 words only, else fingerprint) | 30-31 fingerprint
 constexpr uint32_t kLdsMaxIdxBits = 12;               // leaves >= 6 fingerprint bits
 FQTK_HD constexpr uint32_t lds_fp_mask(uint32_t idx_bits, int kw) {
     return (kw >= 3 ? 0xC0000000u : 0xE0000000u) | (0xFFFFu & ~((1u << idx_bits) - 1u));
@@ -163,16 +187,12 @@ FQTK_HD constexpr uint32_t lds_entry_pos(uint32_t e, int kw) { return ((e >> 20)
 // two keys that share a slot share those bits -- so it is taken from g[16..31], which no slot index
 // reads (slot 2 uses g[2..16]): one v_perm_b32 moves g's upper half under the entry's fingerprint
 // fields (bits IB..15 <- g[16+IB..31], bits 29..31 <- g[21..23]).
-FQTK_HD inline void memo_hash3(uint32_t lo, uint32_t hi, uint32_t ext, uint32_t salt,
+FQTK_HD inline void memo_hash3(uint32_t lo, uint32_t hi, uint32_t ext, uint32_t ext2, uint32_t salt,
                                uint32_t &h1, uint32_t &h2, uint32_t &h3, uint32_t &fp_src) {
-    const uint32_t a = lo;
-    const uint32_t b = (lo >> 24) | (hi << 8);
-    const uint32_t c = (hi >> 16) | (ext << 16);
-    const uint32_t d = ext >> 8;
     // one multiply-add per 24-bit limb, one xor-shift to bring the well-mixed top bits down, one more
     // multiply for the second word: 3-choice cuckoo at load 0.76 does not need more (the planner
     // verifies every placement and falls back to the table form if a build ever failed)
-    uint32_t h = mul24(a, 0x9E3779u) + mul24(b, 0x85EBCBu) + mul24(c, 0xC2B2AFu) + mul24(d, 0xA54FF5u) + salt;
+    uint32_t h = memo_limb_sum(lo, hi, ext, ext2) + salt;
     h ^= h >> 15;
     uint32_t g = mul24(h >> 7, 0xD6E8FFu) + h;
     g ^= g >> 14;

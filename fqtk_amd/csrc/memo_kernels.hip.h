@@ -27,9 +27,15 @@
 
 namespace fqtk {
 
+// A read's row in registers: up to eight dwords of barcode (32 bases) and, for a variable-length batch, its length.
+constexpr int kRowWords = 9;
+constexpr int kLenWord = 8;
+
 struct MemoParams {
     MatchParams m;
-    const void *slots;        // KW=1: uint2 {lo | spill << 31, val}.  KW>=2: uint4 {lo, hi, val, spill | ext << 16}
+    const void *slots;        // KW=1: uint2 {lo | spill << 31, val}.  KW=2: uint4 {lo, hi, val, spill}.  KW=3: uint4 {lo, hi, ext,
+                              // val | spill << 31} (a result word never has bit 31: next <= 32).  KW=4: two uint4 {lo, hi, ext, ext2}
+                              // {val, spill, -, -}, one 32-byte line
                               // direct form: BUCKETS of two one-word-key slots, uint4 {lo0 | spill << 31, val0, lo1, val1} (mask = buckets - 1)
     const uint32_t *hot;      // hot subset (exact matches) in the same slot format, copied to LDS
     uint32_t mask;            // n_slots - 1
@@ -51,11 +57,11 @@ struct MemoParams {
 // down to the real bases of a word (pad positions encode as 'A' = 0 = absent); FULL says all words but
 // the last are complete, so only the last one needs its masks from SGPRs.
 template <int NWD, bool FULL, bool FOLD>
-__device__ __forceinline__ void encode_nibbles(const uint32_t (&words)[8], const uint32_t (&kc)[NWD],
-                                               const uint32_t (&kv)[NWD], uint32_t &lo, uint32_t &hi,
-                                               uint32_t &ext, uint32_t &bad, uint32_t &lo_unf, uint32_t &c2) {
+__device__ __forceinline__ void encode_nibbles(const uint32_t (&words)[kRowWords], const uint32_t (&kc)[NWD],
+                                               const uint32_t (&kv)[NWD], uint32_t (&key)[4], uint32_t &bad, uint32_t &lo_unf, uint32_t &c2) {
     static_assert(!FOLD || NWD == 3, "the fold is for the 9-10 base keys only");
-    uint32_t c[6] = {0, 0, 0, 0, 0, 0};
+    static_assert(NWD >= 1 && NWD <= 8, "at most 32 bases");
+    uint32_t c[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     bad = 0;
 #pragma unroll
     for (int w = 0; w < NWD; ++w) {
@@ -64,24 +70,24 @@ __device__ __forceinline__ void encode_nibbles(const uint32_t (&words)[8], const
         const uint32_t e = __builtin_amdgcn_perm(kCodePoolHi, kCodePoolLo, c[w]);
         bad |= (words[w] ^ e) & (full ? 0xDFDFDFDFu : kv[w]);
     }
-    lo = NWD >= 2 ? ((c[1] << 4) | c[0]) : c[0];
-    lo_unf = lo;    // bases 0-7 before the fold, and the codes of bases 8.. : what memo_direct_index reads
+    key[0] = NWD >= 2 ? ((c[1] << 4) | c[0]) : c[0];
+    lo_unf = key[0];    // bases 0-7 before the fold, and the codes of bases 8.. : what memo_direct_index reads
     c2 = c[2];
     if constexpr (FOLD) {   // L <= 10: kc[2] leaves only codes 8 and 9 in c[2]
-        lo |= mul24(c[2], kFoldMul) & kFoldMask;
-        hi = ext = 0;
+        key[0] |= mul24(c[2], kFoldMul) & kFoldMask;
+        key[1] = key[2] = key[3] = 0;
         return;
     }
-    hi = NWD >= 4 ? ((c[3] << 4) | c[2]) : (NWD == 3 ? c[2] : 0u);
-    ext = NWD >= 5 ? __builtin_amdgcn_perm(0u, c[4] | (c[4] >> 4), 0x0C0C0200u) : 0u;   // 4 contiguous nibbles
+    key[1] = NWD >= 4 ? ((c[3] << 4) | c[2]) : (NWD == 3 ? c[2] : 0u);
+    key[2] = NWD >= 6 ? ((c[5] << 4) | c[4]) : (NWD == 5 ? c[4] : 0u);
+    key[3] = NWD >= 8 ? ((c[7] << 4) | c[6]) : (NWD == 7 ? c[6] : 0u);
 }
 
 template <int NWD, bool FULL, bool FOLD>
-__device__ __forceinline__ void encode_nibbles(const uint32_t (&words)[8], const uint32_t (&kc)[NWD],
-                                               const uint32_t (&kv)[NWD], uint32_t &lo, uint32_t &hi,
-                                               uint32_t &ext, uint32_t &bad) {
+__device__ __forceinline__ void encode_nibbles(const uint32_t (&words)[kRowWords], const uint32_t (&kc)[NWD],
+                                               const uint32_t (&kv)[NWD], uint32_t (&key)[4], uint32_t &bad) {
     uint32_t lo_unf, c2;
-    encode_nibbles<NWD, FULL, FOLD>(words, kc, kv, lo, hi, ext, bad, lo_unf, c2);
+    encode_nibbles<NWD, FULL, FOLD>(words, kc, kv, key, bad, lo_unf, c2);
 }
 
 // (best, second) packed keys -> result word (barcode_matching.rs:150-159).
@@ -166,7 +172,7 @@ constexpr int kMemoBlock = FQTK_MEMO_BLOCK;
 // the same 4-bit key code.  So a read whose only offence is '.' was ALREADY looked up under the right key;
 // this exact test (rare branch only) keeps such reads out of the wave-cooperative scan.
 template <int NWD>
-__device__ __forceinline__ uint32_t noncanonical_beyond_dots(const uint32_t (&words)[8], const uint32_t (&kc)[NWD],
+__device__ __forceinline__ uint32_t noncanonical_beyond_dots(const uint32_t (&words)[kRowWords], const uint32_t (&kc)[NWD],
                                                              const uint32_t (&kv)[NWD]) {
     uint32_t bad = 0;
 #pragma unroll
@@ -190,7 +196,7 @@ __device__ __forceinline__ uint32_t noncanonical_beyond_dots(const uint32_t (&wo
 // those bases spelled 'N' (and 'U' spelled 'T'): this rewrites the words that way, '.' included.  Bytes of no
 // IUPAC meaning (mask 0: they MATCH everything) are left as they are and stay non-canonical.
 template <int NWD>
-__device__ __forceinline__ void spell_ambiguity_codes_as_n(uint32_t (&words)[8]) {
+__device__ __forceinline__ void spell_ambiguity_codes_as_n(uint32_t (&words)[kRowWords]) {
     // replacement letter by (byte & 0x1F), 0 = not an IUPAC code; four 8-entry pools for v_perm_b32
     constexpr uint32_t p0lo = 0x434E4100u, p0hi = 0x4700004Eu;   // @ A B C | D E F G
     constexpr uint32_t p1lo = 0x4E00004Eu, p1hi = 0x004E4E00u;   // H I J K | L M N O
@@ -220,7 +226,7 @@ __device__ __forceinline__ void spell_ambiguity_codes_as_n(uint32_t (&words)[8])
 // wave-uniform) and gets the placeholder result.  Returns the lanes that did NOT fit (segment full / no list):
 // the caller scans those in place.
 __device__ __forceinline__ uint64_t defer_to_second_pass(const MatchParams &P, uint32_t seg, uint32_t &fill, uint64_t flagged,
-                                                         bool mine, uint64_t read_index, uint32_t &res, const uint32_t (&row)[8]) {
+                                                         bool mine, uint64_t read_index, uint32_t &res, const uint32_t (&row)[kRowWords]) {
     if (!flagged) return flagged;
     if (seg >= P.work_segs) {   // launched without a list (no such read seen so far): tell the host, once per wave
         if (!fill) {
@@ -275,7 +281,7 @@ void memo_kernel(const MemoParams Q) {
     // real data) live in LDS, so most lanes never touch the global table; the rest probe it with
     // the hit lanes masked off, which shrinks the gather traffic by the hit rate.
     const uint32_t hot_words = DIRECT ? (Q.hot2 ? (2u << Q.hot2_bits) : 0u)
-                                      : (Q.hot_mask ? (Q.hot_mask + 1) * (KW >= 2 ? 4u : 2u) : 0u);
+                                      : (Q.hot_mask ? (Q.hot_mask + 1) * (KW == 4 ? 8u : (KW >= 2 ? 4u : 2u)) : 0u);
     uint32_t *lds_hot = smem + 256;
     uint32_t *lds_hist = lds_hot + hot_words;
     const uint32_t bins = P.S + 1;
@@ -295,7 +301,7 @@ void memo_kernel(const MemoParams Q) {
     const uint32_t L = P.L;
     const uint32_t nwords = (L + 3u) >> 2;
     // words encoded per read: exactly the packed stride on the vector paths, the key's capacity else
-    constexpr int NWD = VEC >= 1 ? VEC : (KW == 1 ? 3 : (KW == 2 ? 4 : 5));
+    constexpr int NWD = VEC >= 1 ? VEC : (KW == 1 ? 3 : 2 * KW);
     constexpr bool FOLD = KW == 1 && NWD == 3;
     static_assert(NWD <= 2 * KW || FOLD, "key too narrow for the load width");
     uint32_t kc[NWD], kv[NWD];   // code / validation masks of the real bases (< L) per word; wave-uniform
@@ -319,7 +325,7 @@ void memo_kernel(const MemoParams Q) {
     const uint32_t in_off0 = local[0] * P.stride, out_off0 = local[0] * 4u;
 
     // The packed vector loads of one full tile (every read exists, the rows are VEC dwords).
-    auto load_full = [&](uint64_t t, uint32_t (&words)[R][8]) {
+    auto load_full = [&](uint64_t t, uint32_t (&words)[R][kRowWords]) {
         const uint8_t *tile_in = P.obs + t * tile * (uint64_t)P.stride;   // wave-uniform
 #pragma unroll
         for (int r = 0; r < R; ++r) {
@@ -327,31 +333,43 @@ void memo_kernel(const MemoParams Q) {
             if constexpr (VEC == 4) {
                 const u32x4v v = FQTK_STREAM_LOAD(reinterpret_cast<const u32x4v *>(src));
                 words[r][0] = v.x; words[r][1] = v.y; words[r][2] = v.z; words[r][3] = v.w;
-            } else if constexpr (VEC == 3 || VEC == 5) {   // 12- / 20-byte rows are only 4-byte aligned: dword pieces,
+            } else if constexpr (VEC == 3 || VEC == 5 || VEC == 7) {   // 12- / 20- / 28-byte rows are only 4-byte aligned: dword pieces,
                 const uint32_t *s32 = reinterpret_cast<const uint32_t *>(src);   // non-temporal like the rest of the stream
 #pragma unroll
                 for (int w = 0; w < VEC; ++w) words[r][w] = FQTK_STREAM_LOAD(s32 + w);
             } else if constexpr (VEC == 2) {
                 const u32x2v v = FQTK_STREAM_LOAD(reinterpret_cast<const u32x2v *>(src));
                 words[r][0] = v.x; words[r][1] = v.y;
+            } else if constexpr (VEC == 6) {   // 24-byte rows (12 + 12 dual index): three 8-byte pieces
+#pragma unroll
+                for (int w = 0; w < 3; ++w) {
+                    const u32x2v v = FQTK_STREAM_LOAD(reinterpret_cast<const u32x2v *>(src) + w);
+                    words[r][2 * w] = v.x; words[r][2 * w + 1] = v.y;
+                }
+            } else if constexpr (VEC == 8) {   // 32-byte rows: two 16-byte pieces
+#pragma unroll
+                for (int w = 0; w < 2; ++w) {
+                    const u32x4v v = FQTK_STREAM_LOAD(reinterpret_cast<const u32x4v *>(src) + w);
+                    words[r][4 * w] = v.x; words[r][4 * w + 1] = v.y; words[r][4 * w + 2] = v.z; words[r][4 * w + 3] = v.w;
+                }
             } else {
                 words[r][0] = FQTK_STREAM_LOAD(reinterpret_cast<const uint32_t *>(src));
             }
-            // a variable-length batch: the read's length travels with its row, in word 7 of the buffer (keys have
-            // five words at most) -- loaded in the same group, so these batches run the same loops as the others
-            if constexpr (LENS) words[r][7] = FQTK_STREAM_LOAD(P.lens + t * tile + local[r]);
+            // a variable-length batch: the read's length travels with its row, in the buffer's last word -- loaded in
+            // the same group, so these batches run the same loops as the others
+            if constexpr (LENS) words[r][kLenWord] = FQTK_STREAM_LOAD(P.lens + t * tile + local[r]);
         }
     };
     // Any tile through the generic path (ragged last tile, unaligned strides): bounds-checked loads.
-    auto load_any = [&](uint64_t t, uint32_t (&words)[R][8], bool (&live)[R]) {
+    auto load_any = [&](uint64_t t, uint32_t (&words)[R][kRowWords], bool (&live)[R]) {
 #pragma unroll
         for (int r = 0; r < R; ++r) {
             const uint64_t i = t * tile + local[r];
             live[r] = i < P.n;
 #pragma unroll
             for (int w = 0; w < 8; ++w) words[r][w] = 0x41414141u;   // dead lanes look like "AAAA"
-            if (live[r]) load_words<1, VEC>(P, i, nwords, words[r]);
-            if constexpr (LENS) words[r][7] = live[r] ? P.lens[i] : L;
+            if (live[r]) load_words<1, VEC, kRowWords>(P, i, nwords, words[r]);
+            if constexpr (LENS) words[r][kLenWord] = live[r] ? P.lens[i] : L;
         }
     };
 
@@ -361,16 +379,16 @@ void memo_kernel(const MemoParams Q) {
     PhaseClock clk;   // (developer builds only)
     clk.start();
     // Looks one tile up: res[r] = the result word of the tile's r-th read; also feeds the histogram.
-    auto lookup = [&](uint64_t t, uint32_t (&words)[R][8], const bool (&live)[R], uint32_t (&res)[R]) {
-        uint32_t lo[R], hi[R], ext[R], didx[R];
+    auto lookup = [&](uint64_t t, uint32_t (&words)[R][kRowWords], const bool (&live)[R], uint32_t (&res)[R]) {
+        uint32_t key[R][4], didx[R];
         bool bad[R], has_n[R];
         // ---- ASCII -> 4-bit codes (SWAR, see encode_nibbles); `bad` = some base is not A C G T N ----
 #pragma unroll
         for (int r = 0; r < R; ++r) {
             uint32_t b, lo_unf, c2;
-            encode_nibbles<NWD, (VEC >= 1 && !(ABL & 2)), FOLD>(words[r], kc, kv, lo[r], hi[r], ext[r], b, lo_unf, c2);
+            encode_nibbles<NWD, (VEC >= 1 && !(ABL & 2)), FOLD>(words[r], kc, kv, key[r], b, lo_unf, c2);
             bad[r] = b != 0 && live[r];
-            if constexpr (LENS) bad[r] = bad[r] && words[r][7] == L;
+            if constexpr (LENS) bad[r] = bad[r] && words[r][kLenWord] == L;
             if constexpr (DIRECT) {
                 didx[r] = memo_direct_index(lo_unf, c2);
                 has_n[r] = memo_nocall_bits(lo_unf, c2) != 0;
@@ -441,7 +459,7 @@ void memo_kernel(const MemoParams Q) {
             }
 #pragma unroll
             for (int r = 0; r < R; ++r) {
-                const uint32_t bi = (has_n[r] && !(ABL & 256)) ? memo_nbucket1(lo[r], nsh) : 0u;
+                const uint32_t bi = (has_n[r] && !(ABL & 256)) ? memo_nbucket1(key[r][0], nsh) : 0u;
                 nb[r] = *reinterpret_cast<const u32x4v *>(nbase + (bi << 4));
             }
 #pragma unroll
@@ -451,7 +469,7 @@ void memo_kernel(const MemoParams Q) {
             bool again[R], any_again = false;
 #pragma unroll
             for (int r = 0; r < R; ++r) {
-                const bool k0 = (nb[r].x & 0x7FFFFFFFu) == lo[r], k1 = (nb[r].z & 0x7FFFFFFFu) == lo[r];
+                const bool k0 = (nb[r].x & 0x7FFFFFFFu) == key[r][0], k1 = (nb[r].z & 0x7FFFFFFFu) == key[r][0];
                 const uint32_t nres = k0 ? nb[r].y : (k1 ? nb[r].w : kMemoEmpty);
                 uint32_t dres;
                 if constexpr (DIRECT == 2) dres = memo_direct_unpack16(hit[r] ? (e16[r] & 0xFFFFu) : dv[r], lay);   // picked first, unpacked once
@@ -462,11 +480,11 @@ void memo_kernel(const MemoParams Q) {
             }
             if (__ballot(any_again)) {   // wave-uniform, rare: some first bucket was full when the table was built
 #pragma unroll
-                for (int r = 0; r < R; ++r) nb[r] = *reinterpret_cast<const u32x4v *>(nbase + ((again[r] ? memo_nbucket2(lo[r], nsh) : 0u) << 4));
+                for (int r = 0; r < R; ++r) nb[r] = *reinterpret_cast<const u32x4v *>(nbase + ((again[r] ? memo_nbucket2(key[r][0], nsh) : 0u) << 4));
                 arrived4(nb);
 #pragma unroll
                 for (int r = 0; r < R; ++r) {
-                    const bool k0 = (nb[r].x & 0x7FFFFFFFu) == lo[r], k1 = (nb[r].z & 0x7FFFFFFFu) == lo[r];
+                    const bool k0 = (nb[r].x & 0x7FFFFFFFu) == key[r][0], k1 = (nb[r].z & 0x7FFFFFFFu) == key[r][0];
                     if (again[r] && (k0 || k1)) res[r] = k0 ? nb[r].y : nb[r].w;
                 }
             }
@@ -477,31 +495,88 @@ void memo_kernel(const MemoParams Q) {
             uint32_t s1[R], s2[R];
 #pragma unroll
             for (int r = 0; r < R; ++r)
-                memo_hash2(lo[r], KW >= 2 ? hi[r] : 0u, KW >= 3 ? ext[r] : 0u, Q.mask, s1[r], s2[r]);
+                memo_hash2(key[r][0], KW >= 2 ? key[r][1] : 0u, KW >= 3 ? key[r][2] : 0u, KW >= 4 ? key[r][3] : 0u, Q.mask, s1[r], s2[r]);
 #pragma unroll
             for (int r = 0; r < R; ++r) { hit[r] = false; res[r] = kMemoEmpty; }
             clk.mark(1);   // encode + hashes
             uint32_t g1[R], g2[R];   // global-table slots (ABL 32: folded into a 4 KB corner = L1-resident)
 #pragma unroll
             for (int r = 0; r < R; ++r) { g1[r] = (ABL & 32) ? (s1[r] & 0xFFu) : s1[r]; g2[r] = (ABL & 32) ? (s2[r] & 0xFFu) : ((ABL & 128) ? (s1[r] ^ 1u) : s2[r]); }
-            if (Q.hot_mask && !(ABL & 16)) {   // wave-uniform
-                if constexpr (KW >= 2) {
-                    u32x4v h1[R], h2[R];
+            if constexpr (KW >= 2) {
+                // A slot by key width (MemoParams::slots): k = the key quad (KW 2 / 3: the whole 16-byte slot), m = the
+                // second quad of a four-word key's 32-byte slot.  Global slots are addressed as a 32-bit byte offset from
+                // the table's (uniform) base: no 64-bit lane arithmetic (the builder keeps tables under 4 GiB).
+                constexpr uint32_t kSlotShift = KW == 4 ? 5u : 4u;
+                auto slot_hit = [&](const u32x4v &k, int r) {
+                    return k.x == key[r][0] && k.y == key[r][1] && (KW < 3 || k.z == key[r][2]) && (KW < 4 || k.w == key[r][3]);
+                };
+                auto slot_val = [&](const u32x4v &k, const u32x4v &m) { return KW == 2 ? k.z : (KW == 3 ? (k.w & 0x7FFFFFFFu) : m.x); };
+                auto slot_spill = [&](const u32x4v &k, const u32x4v &m) { return KW == 2 ? (k.w & 1u) != 0 : (KW == 3 ? (k.w >> 31) != 0 : (m.y & 1u) != 0); };
+                const uint8_t *gbase = reinterpret_cast<const uint8_t *>(Q.slots);
+                if (Q.hot_mask && !(ABL & 16)) {   // wave-uniform: the LDS hot table (0-mismatch entries), same slot format
+                    const uint8_t *hbase = reinterpret_cast<const uint8_t *>(lds_hot);
+                    u32x4v h1[R], h2[R], n1[R], n2[R];
 #pragma unroll
                     for (int r = 0; r < R; ++r) {
-                        h1[r] = reinterpret_cast<const u32x4v *>(lds_hot)[s1[r] & Q.hot_mask];
-                        h2[r] = reinterpret_cast<const u32x4v *>(lds_hot)[s2[r] & Q.hot_mask];
+                        h1[r] = *reinterpret_cast<const u32x4v *>(hbase + ((s1[r] & Q.hot_mask) << kSlotShift));
+                        h2[r] = *reinterpret_cast<const u32x4v *>(hbase + ((s2[r] & Q.hot_mask) << kSlotShift));
+                        if constexpr (KW == 4) {
+                            n1[r] = *reinterpret_cast<const u32x4v *>(hbase + ((s1[r] & Q.hot_mask) << kSlotShift) + 16);
+                            n2[r] = *reinterpret_cast<const u32x4v *>(hbase + ((s2[r] & Q.hot_mask) << kSlotShift) + 16);
+                        } else { n1[r] = h1[r]; n2[r] = h2[r]; }
                     }
                     arrived4(h1);
                     arrived4(h2);
+                    if constexpr (KW == 4) { arrived4(n1); arrived4(n2); }
 #pragma unroll
                     for (int r = 0; r < R; ++r) {
-                        const bool m1 = h1[r].x == lo[r] && h1[r].y == hi[r] && (KW < 3 || (h1[r].w >> 16) == ext[r]);
-                        const bool m2 = h2[r].x == lo[r] && h2[r].y == hi[r] && (KW < 3 || (h2[r].w >> 16) == ext[r]);
+                        const bool m1 = slot_hit(h1[r], r), m2 = slot_hit(h2[r], r);
                         hit[r] = m1 | m2;
-                        res[r] = m1 ? h1[r].z : (m2 ? h2[r].z : kMemoEmpty);
+                        res[r] = m1 ? slot_val(h1[r], n1[r]) : (m2 ? slot_val(h2[r], n2[r]) : kMemoEmpty);
                     }
+                }
+                clk.mark(2);   // LDS hot table
+                if constexpr (ABL & 1) {
+#pragma unroll
+                    for (int r = 0; r < R; ++r) res[r] = (s1[r] ^ s2[r]) | 0xFFFFu;
                 } else {
+                    // Global table, two-choice placement with a per-slot SPILL bit: the builder keeps a key in
+                    // its first slot whenever it can and marks a slot whose would-be owner lives in its second
+                    // slot.  So one gather settles ~90 % of the probing lanes (hit, or miss with spill = 0);
+                    // only the rest issue the second, dependent gather -- with almost every lane reading slot 0.
+                    bool again[R], any_again = false;
+                    u32x4v e[R], f[R];
+#pragma unroll
+                    for (int r = 0; r < R; ++r) {
+                        const uint32_t off = (hit[r] ? 0u : g1[r]) << kSlotShift;
+                        e[r] = *reinterpret_cast<const u32x4v *>(gbase + off);
+                        if constexpr (KW == 4) f[r] = *reinterpret_cast<const u32x4v *>(gbase + off + 16); else f[r] = e[r];
+                    }
+                    arrived4(e);
+                    if constexpr (KW == 4) arrived4(f);
+#pragma unroll
+                    for (int r = 0; r < R; ++r) {
+                        const bool k = slot_hit(e[r], r);
+                        if (!hit[r] && k) res[r] = slot_val(e[r], f[r]);
+                        again[r] = !hit[r] && !k && slot_spill(e[r], f[r]) && !(ABL & 64);
+                        any_again |= again[r];
+                    }
+                    if (__ballot(any_again)) {   // wave-uniform
+#pragma unroll
+                        for (int r = 0; r < R; ++r) {
+                            const uint32_t off = (again[r] ? g2[r] : 0u) << kSlotShift;
+                            e[r] = *reinterpret_cast<const u32x4v *>(gbase + off);
+                            if constexpr (KW == 4) f[r] = *reinterpret_cast<const u32x4v *>(gbase + off + 16); else f[r] = e[r];
+                        }
+                        arrived4(e);
+                        if constexpr (KW == 4) arrived4(f);
+#pragma unroll
+                        for (int r = 0; r < R; ++r)
+                            if (again[r] && slot_hit(e[r], r)) res[r] = slot_val(e[r], f[r]);
+                    }
+                }
+            } else {
+                if (Q.hot_mask && !(ABL & 16)) {   // wave-uniform
                     u32x2v h1[R], h2[R];
 #pragma unroll
                     for (int r = 0; r < R; ++r) {
@@ -512,50 +587,24 @@ void memo_kernel(const MemoParams Q) {
                     arrived2(h2);
 #pragma unroll
                     for (int r = 0; r < R; ++r) {
-                        const bool m1 = h1[r].x == lo[r], m2 = h2[r].x == lo[r];
+                        const bool m1 = h1[r].x == key[r][0], m2 = h2[r].x == key[r][0];
                         hit[r] = m1 | m2;
                         res[r] = m1 ? h1[r].y : (m2 ? h2[r].y : kMemoEmpty);
                     }
                 }
-            }
-            clk.mark(2);   // LDS cache / hot table
-            if constexpr (ABL & 1) {
+                clk.mark(2);   // LDS hot table
+                if constexpr (ABL & 1) {
 #pragma unroll
-                for (int r = 0; r < R; ++r) res[r] = (s1[r] ^ s2[r]) | 0xFFFFu;
-            } else {
-                // Global table, two-choice placement with a per-slot SPILL bit: the builder keeps a key in
-                // its first slot whenever it can and marks a slot whose would-be owner lives in its second
-                // slot.  So one gather settles ~90 % of the probing lanes (hit, or miss with spill = 0);
-                // only the rest issue the second, dependent gather -- with almost every lane reading slot 0.
-                bool again[R], any_again = false;
-                if constexpr (KW >= 2) {
-                    u32x4v e[R];
-#pragma unroll
-                    for (int r = 0; r < R; ++r) e[r] = reinterpret_cast<const u32x4v *>(Q.slots)[hit[r] ? 0u : g1[r]];
-                    arrived4(e);
-#pragma unroll
-                    for (int r = 0; r < R; ++r) {
-                        const bool k = e[r].x == lo[r] && e[r].y == hi[r] && (KW < 3 || (e[r].w >> 16) == ext[r]);
-                        if (!hit[r] && k) res[r] = e[r].z;
-                        again[r] = !hit[r] && !k && (e[r].w & 1u) != 0 && !(ABL & 64);
-                        any_again |= again[r];
-                    }
-                    if (__ballot(any_again)) {   // wave-uniform
-#pragma unroll
-                        for (int r = 0; r < R; ++r) e[r] = reinterpret_cast<const u32x4v *>(Q.slots)[again[r] ? g2[r] : 0u];
-                        arrived4(e);
-#pragma unroll
-                        for (int r = 0; r < R; ++r)
-                            if (again[r] && e[r].x == lo[r] && e[r].y == hi[r] && (KW < 3 || (e[r].w >> 16) == ext[r])) res[r] = e[r].z;
-                    }
+                    for (int r = 0; r < R; ++r) res[r] = (s1[r] ^ s2[r]) | 0xFFFFu;
                 } else {
+                    bool again[R], any_again = false;
                     u32x2v e[R];
 #pragma unroll
                     for (int r = 0; r < R; ++r) e[r] = reinterpret_cast<const u32x2v *>(Q.slots)[hit[r] ? 0u : g1[r]];
                     arrived2(e);
 #pragma unroll
                     for (int r = 0; r < R; ++r) {
-                        const bool k = (e[r].x & 0x7FFFFFFFu) == lo[r];
+                        const bool k = (e[r].x & 0x7FFFFFFFu) == key[r][0];
                         if (!hit[r] && k) res[r] = e[r].y;
                         again[r] = !hit[r] && !k && (e[r].x >> 31) != 0 && !(ABL & 64);
                         any_again |= again[r];
@@ -566,7 +615,7 @@ void memo_kernel(const MemoParams Q) {
                         arrived2(e);
 #pragma unroll
                         for (int r = 0; r < R; ++r)
-                            if (again[r] && (e[r].x & 0x7FFFFFFFu) == lo[r]) res[r] = e[r].y;
+                            if (again[r] && (e[r].x & 0x7FFFFFFFu) == key[r][0]) res[r] = e[r].y;
                     }
                 }
             }
@@ -599,7 +648,7 @@ void memo_kernel(const MemoParams Q) {
         for (int r = 0; r < R; ++r) {
             if (!live[r]) continue;
             if constexpr (LENS) {   // the memo served the reads of length L
-                const uint32_t len = words[r][7];
+                const uint32_t len = words[r][kLenWord];
                 if (len != L) {   // shorter -> None (barcode_matching.rs:167-169); longer -> None or the panic
                     res[r] = kMemoEmpty;
                     if (len > L) overlong_read(P, t * tile + local[r], len);
@@ -641,15 +690,15 @@ void memo_kernel(const MemoParams Q) {
         // then issues the next tile's loads and the previous tile's stores, which fly during the look-up.
         // Two word buffers used alternately (no register rotation); the prefetch is unconditional -- past the
         // end it re-reads the last full tile and the words are never used -- so that it cannot sit in a branch.
-        uint32_t wa[R][8], wb[R][8], held[R];
-        auto landed = [&](uint32_t (&w)[R][8]) {   // the words are in registers; nothing below moves above this point
+        uint32_t wa[R][kRowWords], wb[R][kRowWords], held[R];
+        auto landed = [&](uint32_t (&w)[R][kRowWords]) {   // the words are in registers; nothing below moves above this point
 #pragma unroll
             for (int r = 0; r < R; ++r)
 #pragma unroll
                 for (int k = 0; k < NWD; ++k) asm volatile("" : "+v"(w[r][k]) : : "memory");
             if constexpr (LENS) {
 #pragma unroll
-                for (int r = 0; r < R; ++r) asm volatile("" : "+v"(w[r][7]) : : "memory");
+                for (int r = 0; r < R; ++r) asm volatile("" : "+v"(w[r][kLenWord]) : : "memory");
             }
         };
         auto computed = [&](uint32_t (&v)[R]) {     // the results exist now (their gathers / LDS reads were waited for HERE)
@@ -692,7 +741,7 @@ void memo_kernel(const MemoParams Q) {
         }
     } else {
         for (uint64_t t = blockIdx.x; t < full_tiles; t += grid) {
-            uint32_t words[R][8], res[R];
+            uint32_t words[R][kRowWords], res[R];
             load_full(t, words);
             clk.mark(0);   // the row stream
             lookup(t, words, all_live, res);
@@ -702,7 +751,7 @@ void memo_kernel(const MemoParams Q) {
     }
     // whatever is left (the ragged last tile; every tile on the generic load paths)
     for (uint64_t t = full_tiles + (blockIdx.x + gridDim.x - full_tiles % gridDim.x) % gridDim.x; t < ntiles; t += gridDim.x) {
-        uint32_t words[R][8], res[R];
+        uint32_t words[R][kRowWords], res[R];
         bool live[R];
         load_any(t, words, live);
         lookup(t, words, live, res);

@@ -140,7 +140,8 @@ def test_memo_table_is_built_when_it_should_be():
     # every canonical string within 1 mismatch of a sample: 1 + 16*4 per sample; all are Some here
     # because the table has pairwise distance >= 3
     assert m.memo_entries == 384 * (1 + 16 * 4)
-    assert BarcodeMatcher(["A" * 21, "C" * 21], 1, 2).memo_entries == 0      # L > 20: scan only
+    assert BarcodeMatcher(["A" * 21, "C" * 21], 1, 2).memo_entries == 2 * (1 + 21 * 4)   # (until round 4: L > 20 was scan only)
+    assert BarcodeMatcher(["A" * 33, "C" * 33], 1, 2).memo_entries == 0      # L > 32: scan only
     assert BarcodeMatcher(w.barcodes, 6, 2).memo_entries == 0                # over the build budget
     assert BarcodeMatcher(["NNNNNNN"], 0, 2).memo_entries == 5 ** 7          # catch-all barcode
 
@@ -157,7 +158,10 @@ def test_memo_kind_selection():
     assert M(["ACGTACGN", "TTTTGGGG"], 1, 1).memo_kind == M.MEMO_TABLE                 # N in a sample
     assert M(["ACGTACGT"], 1, 1).memo_kind == M.MEMO_TABLE                             # S = 1: next = 255
     assert M(["ACGTACGT", "TTTTGGGG"], 1, 1, use_cache=False).memo_kind == M.MEMO_NONE
-    assert M(["A" * 24, "C" * 24], 1, 1).memo_kind == M.MEMO_NONE                      # L > 20
+    assert M(["A" * 24, "C" * 24], 1, 1).memo_kind == M.MEMO_LDS                       # three key words
+    assert M(["ACGT" * 8, "CCGT" * 8], 1, 1).memo_kind == M.MEMO_LDS                   # four
+    assert M(["A" * 32, "C" * 32], 1, 1).memo_kind == M.MEMO_TABLE                     # next = 32 does not fit the entry's 5 bits
+    assert M(["A" * 33, "C" * 33], 1, 1).memo_kind == M.MEMO_NONE                      # L > 32
     m = M(["ACGTACGT", "TTTTGGGG"], 1, 1)
     assert m.memo_kind == M.MEMO_LDS
     m.memo_kind = M.MEMO_TABLE
@@ -516,13 +520,14 @@ def test_limits_are_rejected_at_create():
 
 
 def test_longest_memo_key_and_longer_barcodes():
-    """L = 20 is the longest barcode the memo covers (80-bit key: lo, hi, ext); L = 21..128 are scan-only."""
+    """L = 32 is the longest barcode the memo covers (128-bit key: lo, hi, ext, ext2; 16 + 16 dual indices); L = 33..128
+    are scan-only.  (The reference's cache has no length limit: barcode_matching.rs:174-181.)"""
     rng = np.random.default_rng(12)
     acgt = np.frombuffer(b"ACGTN", dtype=np.uint8)
-    for L in (19, 20, 21, 31, 32, 33, 96, 128):
+    for L in (19, 20, 21, 24, 25, 31, 32, 33, 96, 128):
         bcs = ["".join(rng.choice(list("ACGT"), size=L)) for _ in range(40)]
         m = BarcodeMatcher(bcs, 1, 1)
-        assert (m.memo_entries > 0) == (L <= 20)
+        assert (m.memo_entries > 0) == (L <= 32)
         n = 3000
         src = rng.integers(0, 40, size=n)
         obs = np.stack([np.frombuffer(bcs[i].encode(), dtype=np.uint8) for i in src]).copy()
@@ -532,11 +537,11 @@ def test_longest_memo_key_and_longer_barcodes():
         _compare(bcs, 2, 1, obs[:500])
 
 
-@pytest.mark.parametrize("L", range(1, 22))
+@pytest.mark.parametrize("L", range(1, 34))
 def test_every_memo_key_width_and_load_path(L):
     """Every barcode length the memo covers (and one it does not), on every load path: the packed
-    stride (vector loads for L <= 16), a dword-padded stride and an odd stride.  L <= 8 is one key word,
-    9-10 the folded single word, 11-16 two words, 17-20 three; reads include lower case, N, '.', U and
+    stride (vector loads), a dword-padded stride and an odd stride.  L <= 8 is one key word,
+    9-10 the folded single word, 11-16 two words, 17-24 three, 25-32 four; reads include lower case, N, '.', U and
     IUPAC/junk bytes (the wave-cooperative fallback) and pad bytes that must be ignored."""
     rng = np.random.default_rng(500 + L)
     S = min(48, 4 ** L // 2) or 1
@@ -545,7 +550,7 @@ def test_every_memo_key_width_and_load_path(L):
         seen.add("".join(rng.choice(list("ACGT"), size=L)))
     bcs = sorted(seen)
     m = BarcodeMatcher(bcs, 1, 1)
-    assert (m.memo_entries > 0) == (L <= 20)
+    assert (m.memo_entries > 0) == (L <= 32)
     n = 4099
     noise = np.frombuffer(b"ACGTNacgtn.URY#", dtype=np.uint8)
     for stride in sorted({(L + 3) // 4 * 4, (L + 3) // 4 * 4 + 4, L | 1, L + 2}):
@@ -564,9 +569,9 @@ def test_every_memo_key_width_and_load_path(L):
 
 def test_memo_keys_do_not_alias_near_identical_reads():
     """Reads that differ from a sample in exactly one base at every position and to every other
-    canonical base (and N): each must resolve to its own memo entry, for all four key layouts."""
-    for L in (8, 10, 16, 20):
-        bcs = ["ACGT" * 5, "TGCA" * 5, "GGGGGCCCCCAAAAATTTTT", "ATATATATATCGCGCGCGCG"]
+    canonical base (and N): each must resolve to its own memo entry, for all five key layouts."""
+    for L in (8, 10, 16, 20, 24, 29, 32):
+        bcs = ["ACGT" * 8, "TGCA" * 8, "GGGGGCCCCCAAAAATTTTTGGGGGCCCCCAA", "ATATATATATCGCGCGCGCGATATATCGCGCG"]
         bcs = [b[:L] for b in bcs]
         rows = []
         for b in bcs:
@@ -578,6 +583,37 @@ def test_memo_keys_do_not_alias_near_identical_reads():
         obs = np.frombuffer("".join(rows).encode(), dtype=np.uint8).reshape(-1, L)
         for mm, delta in ((1, 1), (2, 1), (2, 2), (0, 1)):
             _compare(bcs, mm, delta, obs)
+
+
+def test_dual_index_12_plus_12_and_a_memo_of_millions_of_strings():
+    """12 + 12 dual indices (L = 24) used to fall to the scan; with --max-mismatches 2 the memo of such a
+    plate is 1.7 M strings, and cfg 3 with three mismatches enumerates 14.5 M -- streamed through the scan kernel in
+    chunks at create time (the old budget was 6 M strings held in host memory at once)."""
+    rng = np.random.default_rng(24)
+    seen = set()
+    while len(seen) < 384:
+        seen.add("".join(rng.choice(list("ACGT"), size=24)))
+    bcs = sorted(seen)
+    acgtn = np.frombuffer(b"ACGTN", dtype=np.uint8)
+    n = 30_000
+    obs = np.stack([np.frombuffer(b.encode(), dtype=np.uint8) for b in bcs])[rng.integers(0, 384, n)].copy()
+    flip = rng.random(obs.shape) < 0.03
+    obs[flip] = acgtn[rng.integers(0, 5, int(flip.sum()))]
+    obs[rng.random(n) < 0.1] = acgtn[rng.integers(0, 4, 24)]
+    for mm, delta in ((1, 2), (2, 2)):
+        m = BarcodeMatcher(bcs, mm, delta)
+        assert m.memo_entries > 0 and m.memo_candidates == 384 * (1 + 24 * 4 + (mm == 2) * 276 * 16)
+        _compare(bcs, mm, delta, obs)
+    w = synth.Workload(synth.CONFIGS[3])
+    m = BarcodeMatcher(w.barcodes, 3, 2)
+    assert m.memo_candidates == 384 * (1 + 16 * 4 + 120 * 16 + 560 * 64) and m.memo_entries > 1_000_000
+    o16 = w.fill_host(0, 20_000)
+    flip = rng.random(o16.shape) < 0.08
+    o16 = o16.copy()
+    o16[flip] = acgtn[rng.integers(0, 5, int(flip.sum()))]
+    got, counts = m.assign_batch(o16)
+    i, b, nx, c = O.RefLiteral(w.barcodes, 3, 2, True).assign_batch(o16)
+    assert np.array_equal(got["idx"], i) and np.array_equal(got["best"], b) and np.array_equal(got["next"], nx) and np.array_equal(counts, c)
 
 
 def test_device_entry_point_with_misaligned_and_padded_buffers():

@@ -14,12 +14,12 @@ NONE = 0xFFFFFFFF
 
 
 def _keys(strings: np.ndarray) -> np.ndarray:
-    """uint8 [n, L] ASCII -> uint32 [n, 3] unfolded 4-bit keys (code = bits 1..2 of the byte, N = 7)."""
+    """uint8 [n, L] ASCII -> uint32 [n, 4] unfolded 4-bit keys (code = bits 1..2 of the byte, N = 7), eight bases a word."""
     n, L = strings.shape
     code = ((strings.astype(np.uint32) >> 1) & 7)
-    keys = np.zeros((n, 3), dtype=np.uint32)
+    keys = np.zeros((n, 4), dtype=np.uint32)
     for k in range(L):   # memo_hash.hpp memo_nibble_shift: byte k&3 of the word, high nibble for bases 4-7
-        keys[:, k >> 3] |= code[:, k] << np.uint32(4 * (k - 16) if k >= 16 else 4 * (((k & 3) << 1) | ((k & 7) >> 2)))
+        keys[:, k >> 3] |= code[:, k] << np.uint32(4 * (((k & 3) << 1) | ((k & 7) >> 2)))
     return keys
 
 
@@ -98,12 +98,12 @@ def test_shapes_the_lds_form_does_not_cover():
     assert np.array_equal(_lookup(meta, image, keys), vals)
 
 
-@pytest.mark.parametrize("L", [5, 8, 9, 12, 16, 17, 20])
+@pytest.mark.parametrize("L", [5, 8, 9, 12, 16, 17, 20, 21, 24, 25, 28, 31, 32])
 def test_all_key_widths(L):
     rng = np.random.default_rng(L)
     barcodes = sorted({"".join(rng.choice(list("ACGT"), size=L)) for _ in range(60)})
     meta, image, cand, keys, vals = _plan(barcodes, 1, 1)
-    assert meta[0] == 1 and meta[6] == (1 if L <= 8 else 2 if L <= 16 else 3)
+    assert meta[0] == 1 and meta[6] == (1 if L <= 8 else 2 if L <= 16 else 3 if L <= 24 else 4)
     assert np.array_equal(_lookup(meta, image, keys), vals)
     rnd = np.frombuffer(b"ACGTN", dtype=np.uint8)[rng.integers(0, 5, size=(5000, L))]
     idx, best, nxt, _ = O.RefLiteral(barcodes, 1, 1, True).assign_batch(rnd)
