@@ -344,6 +344,7 @@ def main() -> int:
         matcher.poll_error(stream)
 
     per_rank_kernel_ms = [round(kernel_ms, 4)]
+    per_rank_reads = [n]
     if use_dist:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -352,6 +353,11 @@ def main() -> int:
         km[rank] = kernel_ms
         dist.all_reduce(km)
         per_rank_kernel_ms = [round(float(x), 4) for x in km.tolist()]
+        nr = torch.zeros(world, dtype=torch.int64, device=dev)
+        nr[rank] = n
+        dist.all_reduce(nr)
+        per_rank_reads = [int(x) for x in nr.tolist()]   # an N > 1 record checks itself: sum == reads_per_step_whole_job
+        assert sum(per_rank_reads) == job_reads
 
     # ---- correctness gates outside the timed region -------------------------------------------------
     counts_host = d_counts.cpu().numpy()
@@ -396,12 +402,15 @@ def main() -> int:
     out = None
     if rank == 0:
         value = job_reads * args.steps / elapsed / 1e6
-        achieved = n * cfg.bytes_per_read / (kernel_ms * 1e-3) / 1e9
+        bytes_per_read = cfg.bytes_per_read + (4 if args.lens else 0)   # an obs_len batch reads one more dword per read
+        achieved = n * bytes_per_read / (kernel_ms * 1e-3) / 1e9
         out = {
             "metric": "M reads/sec demuxed (bit-exact assigns)",
             "value": round(value, 2),
             "unit": "M reads/s",
             "n_gpus": world,
+            "rccl_ranks": dist.get_world_size() if use_dist else 1,   # the process group the counts were all-reduced over
+            "reads_per_step_per_rank": per_rank_reads,
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 4),
@@ -439,10 +448,10 @@ def main() -> int:
                 "frac": round(achieved / HBM_PEAK_GBPS, 5),
                 "traffic": pmc_traffic(args.config, n, kernel_name),
                 "traffic_unit": "bytes per launch (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, profiles/)",
-                "algorithmic_bytes_per_launch": n * (cfg.bytes_per_read + (4 if args.lens else 0)),
+                "algorithmic_bytes_per_launch": n * bytes_per_read,
                 "kernel_ms": round(kernel_ms, 4),
                 "kernel_ms_per_rank": per_rank_kernel_ms,
-                "algorithmic_bytes_per_read": cfg.bytes_per_read,
+                "algorithmic_bytes_per_read": bytes_per_read,
             },
         }
         if world == 1 and not args.no_scopes:

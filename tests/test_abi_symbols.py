@@ -120,3 +120,41 @@ def test_packer_lays_nibbles_out_as_documented_and_lists_exceptions():
                 assert nib == code[int(rows[i, b]) & 0xDF if rows[i, b] != ord(".") else ord(".")], (L, i, b)
         # no room for the exceptions is an error, not an overflow
         assert lib.fqtk_pack_barcodes(rows.ctypes.data, L + 3, L, n, packed.ctypes.data, ps, exc_i.ctypes.data, exc_r.ctypes.data, 3, C.byref(k)) == _lib.FQTK_ENOMEM
+
+
+def test_pack_barcodes_simd_blocks_equal_the_table_lookup_per_base():
+    """fqtk_pack_barcodes is host code (no GPU needed): 4 bits per base, code = bits 1..3 of the byte for A C G T N in either
+    case and '.', anything else sends the row along as an exception.  The SSSE3 block path (16 / 8 bases at a time) must
+    agree with the per-base definition on every length, stride and byte value."""
+    import numpy as np
+    lib = _lib.load()
+    rng = np.random.default_rng(7)
+    alphabet = np.frombuffer(b"ACGTNacgtn.", dtype=np.uint8)
+    code = np.full(256, 0xFF, dtype=np.uint8)
+    for ch, c in zip(b"ACTG", range(4)):
+        code[ch] = code[ch | 0x20] = c
+    code[ord("N")] = code[ord("n")] = code[ord(".")] = 7
+    for L in list(range(1, 34)) + [40, 64, 128]:
+        for stride in (L, L + 3, (L + 3) // 4 * 4):
+            n = 300
+            obs = alphabet[rng.integers(0, alphabet.size, size=(n, stride))].copy()
+            dirty = rng.random(n) < 0.2                       # rows with an IUPAC code / junk byte somewhere in the barcode
+            for i in np.nonzero(dirty)[0]:
+                obs[i, rng.integers(0, L)] = rng.choice(np.frombuffer(b"RYKMSWBDHVU#\x00\xff\xdf-", dtype=np.uint8))
+            if stride > L:
+                obs[:, L:] = rng.integers(0, 256, size=(n, stride - L))   # pad bytes are not part of the barcode
+            ps = int(lib.fqtk_packed_stride(L))
+            packed = np.full((n, ps), 0xAA, dtype=np.uint8)
+            ei = np.zeros(n, dtype=np.uint32)
+            er = np.zeros((n, L), dtype=np.uint8)
+            k = C.c_uint64(0)
+            assert lib.fqtk_pack_barcodes(obs.ctypes.data, stride, L, n, packed.ctypes.data, ps, ei.ctypes.data, er.ctypes.data, n, C.byref(k)) == 0
+            c = code[obs[:, :L]]
+            bad = (c == 0xFF).any(axis=1)
+            want_exc = np.nonzero(bad)[0]
+            assert k.value == len(want_exc) and np.array_equal(ei[:k.value], want_exc) and np.array_equal(er[:k.value], obs[want_exc, :L])
+            nib = np.zeros((n, 2 * ps), dtype=np.uint8)
+            nib[:, :L] = c & 7
+            want = nib[:, 0::2] | (nib[:, 1::2] << 4)
+            ok = ~bad                                          # (an exception row's packed bytes are not read by the device)
+            assert np.array_equal(packed[ok], want[ok]), (L, stride)
