@@ -1502,41 +1502,107 @@ struct PackLut {
 };
 const PackLut kPackLut;
 
+// One row: the bases from `k` on, a table look-up per base (the tail of a row behind the SIMD blocks; every base elsewhere).
+inline void pack_row_tail(const uint8_t *r, uint32_t k, uint32_t barcode_len, uint8_t *o, uint32_t packed_stride, uint32_t *bad) {
+    const uint8_t *lut = kPackLut.code;
+    for (; k + 1 < barcode_len; k += 2) {
+        const uint32_t a = lut[r[k]], b = lut[r[k + 1]];
+        *bad |= a | b;
+        o[k >> 1] = (uint8_t)((a & 7u) | ((b & 7u) << 4));
+    }
+    if (k < barcode_len) { const uint32_t a = lut[r[k]]; *bad |= a; o[k >> 1] = (uint8_t)(a & 7u); k += 2; }
+    for (uint32_t j = k >> 1; j < packed_stride; ++j) o[j] = 0;
+}
+// Returns false when there are more exception rows than exc_cap.
+inline bool pack_exception(const uint8_t *r, uint64_t i, uint32_t barcode_len, uint32_t *exc_index, uint8_t *exc_rows, uint64_t exc_cap, uint64_t *ne) {
+    if (*ne >= exc_cap || !exc_index || !exc_rows) return false;
+    exc_index[*ne] = (uint32_t)i;
+    std::memcpy(exc_rows + *ne * barcode_len, r, barcode_len);
+    ++*ne;
+    return true;
+}
+bool pack_rows_scalar(const uint8_t *obs, uint32_t stride, uint32_t barcode_len, uint64_t n, uint8_t *packed, uint32_t packed_stride,
+                      uint32_t *exc_index, uint8_t *exc_rows, uint64_t exc_cap, uint64_t *ne) {
+    for (uint64_t i = 0; i < n; ++i) {
+        const uint8_t *r = obs + i * stride;
+        uint32_t bad = 0;
+        pack_row_tail(r, 0, barcode_len, packed + i * packed_stride, packed_stride, &bad);
+        if ((bad & 0x80u) && !pack_exception(r, i, barcode_len, exc_index, exc_rows, exc_cap, ne)) return false;
+    }
+    return true;
+}
 #if defined(__x86_64__)
-// The packer's inner loop on 16 (then 8) bases at a time: code = bits 1..3 of the byte, one pshufb maps a code back to the
-// letter it stands for ('A' 'C' 'T' 'G' . . . 'N': fqtk::kCodePool) -- the byte is canonical iff it equals that letter in
-// either case, or is '.', the legacy no-call, which has N's code -- and one pmaddubsw puts two codes into a byte.
-// Returns the bases consumed (a multiple of 8); *bad gets bit 7 set if some byte was not A C G T N . (any case).
-// One table look-up per base did 143 M reads/s per host thread (round 3); a link that takes 4.4 G packed reads/s needs
-// the packer at memory speed.
-__attribute__((target("ssse3"))) uint32_t pack_blocks_ssse3(const uint8_t *r, uint32_t L, uint8_t *o, uint32_t *bad) {
+// The same on 16 (then 8) bases at a time: code = bits 1..3 of the byte, one pshufb maps a code back to the letter it
+// stands for ('A' 'C' 'T' 'G' . . . 'N': fqtk::kCodePool) -- the byte is canonical iff it equals that letter in either case,
+// or is '.', the legacy no-call, which has N's code -- and one pmaddubsw puts two codes into a byte.  The whole row loop
+// lives in this function so that the constants stay in registers (a per-row call re-made them: 150 M reads/s).
+// One table look-up per base did 143 M reads/s per host thread (round 3).
+__attribute__((target("ssse3"))) bool pack_rows_ssse3(const uint8_t *obs, uint32_t stride, uint32_t barcode_len, uint64_t n, uint8_t *packed,
+                                                      uint32_t packed_stride, uint32_t *exc_index, uint8_t *exc_rows, uint64_t exc_cap, uint64_t *ne) {
     const __m128i pool = _mm_setr_epi8(0x41, 0x43, 0x54, 0x47, (char)0xFF, (char)0xFF, (char)0xFF, 0x4E, 0x41, 0x43, 0x54, 0x47, (char)0xFF, (char)0xFF, (char)0xFF, 0x4E);
     const __m128i seven = _mm_set1_epi8(7), upper = _mm_set1_epi8((char)0xDF), dotc = _mm_set1_epi8(0x2E), pair = _mm_set1_epi16(0x1001);
-    __m128i flagged = _mm_setzero_si128();
-    uint32_t k = 0;
-    for (; k + 16 <= L; k += 16) {
-        const __m128i v = _mm_loadu_si128(reinterpret_cast<const __m128i *>(r + k));
-        const __m128i c = _mm_and_si128(_mm_srli_epi16(v, 1), seven);
-        const __m128i e = _mm_shuffle_epi8(pool, c);
-        const __m128i off = _mm_andnot_si128(_mm_cmpeq_epi8(v, dotc), _mm_and_si128(_mm_xor_si128(v, e), upper));
-        flagged = _mm_or_si128(flagged, off);
-        const __m128i two = _mm_maddubs_epi16(c, pair);                 // code[2j] + 16 * code[2j + 1] in every 16-bit lane
-        _mm_storel_epi64(reinterpret_cast<__m128i *>(o + (k >> 1)), _mm_packus_epi16(two, two));
+    const __m128i zero = _mm_setzero_si128();
+    for (uint64_t i = 0; i < n; ++i) {
+        const uint8_t *r = obs + i * stride;
+        uint8_t *o = packed + i * packed_stride;
+        __m128i flagged = zero;
+        uint32_t k = 0;
+        for (; k + 16 <= barcode_len; k += 16) {
+            const __m128i v = _mm_loadu_si128(reinterpret_cast<const __m128i *>(r + k));
+            const __m128i c = _mm_and_si128(_mm_srli_epi16(v, 1), seven);
+            const __m128i e = _mm_shuffle_epi8(pool, c);
+            flagged = _mm_or_si128(flagged, _mm_andnot_si128(_mm_cmpeq_epi8(v, dotc), _mm_and_si128(_mm_xor_si128(v, e), upper)));
+            const __m128i two = _mm_maddubs_epi16(c, pair);             // code[2j] + 16 * code[2j + 1] in every 16-bit lane
+            _mm_storel_epi64(reinterpret_cast<__m128i *>(o + (k >> 1)), _mm_packus_epi16(two, two));
+        }
+        if (k + 8 <= barcode_len) {
+            const __m128i v = _mm_loadl_epi64(reinterpret_cast<const __m128i *>(r + k));
+            const __m128i c = _mm_and_si128(_mm_srli_epi16(v, 1), seven);
+            const __m128i e = _mm_shuffle_epi8(pool, c);
+            const __m128i off = _mm_andnot_si128(_mm_cmpeq_epi8(v, dotc), _mm_and_si128(_mm_xor_si128(v, e), upper));
+            flagged = _mm_or_si128(flagged, _mm_move_epi64(off));       // (the upper half holds zeros' "mismatch" with 'A')
+            const __m128i two = _mm_maddubs_epi16(c, pair);
+            const uint32_t w = (uint32_t)_mm_cvtsi128_si32(_mm_packus_epi16(two, two));
+            std::memcpy(o + (k >> 1), &w, 4);
+            k += 8;
+        }
+        uint32_t bad = _mm_movemask_epi8(_mm_cmpeq_epi8(flagged, zero)) != 0xFFFF ? 0x80u : 0u;
+        pack_row_tail(r, k, barcode_len, o, packed_stride, &bad);
+        if ((bad & 0x80u) && !pack_exception(r, i, barcode_len, exc_index, exc_rows, exc_cap, ne)) return false;
     }
-    if (k + 8 <= L) {
-        const __m128i v = _mm_loadl_epi64(reinterpret_cast<const __m128i *>(r + k));
-        const __m128i c = _mm_and_si128(_mm_srli_epi16(v, 1), seven);
-        const __m128i e = _mm_shuffle_epi8(pool, c);
-        __m128i off = _mm_andnot_si128(_mm_cmpeq_epi8(v, dotc), _mm_and_si128(_mm_xor_si128(v, e), upper));
-        off = _mm_move_epi64(off);                                      // (the upper half holds zeros' "mismatch" with 'A')
-        flagged = _mm_or_si128(flagged, off);
-        const __m128i two = _mm_maddubs_epi16(c, pair);
-        const uint32_t w = (uint32_t)_mm_cvtsi128_si32(_mm_packus_epi16(two, two));
-        std::memcpy(o + (k >> 1), &w, 4);
-        k += 8;
+    return true;
+}
+// The common case -- rows of exactly 16 bases, back to back (8 + 8 dual indices) -- two rows per step in one 256-bit
+// register: the buffer is one stream, 32 bytes in, 16 out.
+__attribute__((target("avx2"))) bool pack_rows16_avx2(const uint8_t *obs, uint64_t n, uint8_t *packed, uint32_t *exc_index, uint8_t *exc_rows,
+                                                      uint64_t exc_cap, uint64_t *ne) {
+    const __m256i pool = _mm256_setr_epi8(0x41, 0x43, 0x54, 0x47, (char)0xFF, (char)0xFF, (char)0xFF, 0x4E, 0x41, 0x43, 0x54, 0x47, (char)0xFF, (char)0xFF, (char)0xFF, 0x4E,
+                                          0x41, 0x43, 0x54, 0x47, (char)0xFF, (char)0xFF, (char)0xFF, 0x4E, 0x41, 0x43, 0x54, 0x47, (char)0xFF, (char)0xFF, (char)0xFF, 0x4E);
+    const __m256i seven = _mm256_set1_epi8(7), upper = _mm256_set1_epi8((char)0xDF), dotc = _mm256_set1_epi8(0x2E), pair = _mm256_set1_epi16(0x1001);
+    const __m256i zero = _mm256_setzero_si256();
+    uint64_t i = 0;
+    for (; i + 2 <= n; i += 2) {
+        const __m256i v = _mm256_loadu_si256(reinterpret_cast<const __m256i *>(obs + i * 16));
+        const __m256i c = _mm256_and_si256(_mm256_srli_epi16(v, 1), seven);
+        const __m256i e = _mm256_shuffle_epi8(pool, c);
+        const __m256i off = _mm256_andnot_si256(_mm256_cmpeq_epi8(v, dotc), _mm256_and_si256(_mm256_xor_si256(v, e), upper));
+        const __m256i two = _mm256_maddubs_epi16(c, pair);
+        const __m256i pk = _mm256_permute4x64_epi64(_mm256_packus_epi16(two, two), 0x08);   // quadwords 0 and 2: the two rows
+        _mm_storeu_si128(reinterpret_cast<__m128i *>(packed + i * 8), _mm256_castsi256_si128(pk));
+        const uint32_t clean = (uint32_t)_mm256_movemask_epi8(_mm256_cmpeq_epi8(off, zero));
+        if (clean != 0xFFFFFFFFu) {
+            if ((clean & 0xFFFFu) != 0xFFFFu && !pack_exception(obs + i * 16, i, 16, exc_index, exc_rows, exc_cap, ne)) return false;
+            if ((clean >> 16) != 0xFFFFu && !pack_exception(obs + (i + 1) * 16, i + 1, 16, exc_index, exc_rows, exc_cap, ne)) return false;
+        }
     }
-    if (_mm_movemask_epi8(_mm_cmpeq_epi8(flagged, _mm_setzero_si128())) != 0xFFFF) *bad |= 0x80u;
-    return k;
+    if (i < n) {
+        uint64_t ne1 = 0;
+        uint32_t idx1 = 0;
+        uint8_t row1[16];
+        if (!pack_rows_ssse3(obs + i * 16, 16, 16, 1, packed + i * 8, 8, &idx1, row1, 1, &ne1)) return false;
+        if (ne1 && !pack_exception(obs + i * 16, i, 16, exc_index, exc_rows, exc_cap, ne)) return false;
+    }
+    return true;
 }
 #endif
 }  // namespace
@@ -1552,34 +1618,14 @@ int fqtk_pack_barcodes(const uint8_t *obs, uint32_t stride, uint32_t barcode_len
     if (packed_stride < fqtk_packed_stride(barcode_len)) return fail(FQTK_EINVAL, "packed_stride smaller than fqtk_packed_stride(barcode_len)");
     if (n > 0xFFFFFFFFull) return fail(FQTK_EINVAL, "at most 2^32 - 1 reads per call");
     uint64_t ne = 0;
-    const uint8_t *lut = kPackLut.code;
+    bool ok;
 #if defined(__x86_64__)
-    const bool simd = __builtin_cpu_supports("ssse3");
-#else
-    const bool simd = false;
+    if (barcode_len == 16 && stride == 16 && packed_stride == 8 && __builtin_cpu_supports("avx2")) ok = pack_rows16_avx2(obs, n, packed, exc_index, exc_rows, exc_cap, &ne);
+    else if (__builtin_cpu_supports("ssse3")) ok = pack_rows_ssse3(obs, stride, barcode_len, n, packed, packed_stride, exc_index, exc_rows, exc_cap, &ne);
+    else
 #endif
-    for (uint64_t i = 0; i < n; ++i) {
-        const uint8_t *r = obs + i * stride;
-        uint8_t *o = packed + i * packed_stride;
-        uint32_t bad = 0;
-        uint32_t k = 0;
-#if defined(__x86_64__)
-        if (simd) k = pack_blocks_ssse3(r, barcode_len, o, &bad);   // whole 16- and 8-base blocks, 16 bases per ~10 instructions
-#endif
-        for (; k + 1 < barcode_len; k += 2) {
-            const uint32_t a = lut[r[k]], b = lut[r[k + 1]];
-            bad |= a | b;
-            o[k >> 1] = (uint8_t)((a & 7u) | ((b & 7u) << 4));
-        }
-        if (k < barcode_len) { const uint32_t a = lut[r[k]]; bad |= a; o[k >> 1] = (uint8_t)(a & 7u); k += 2; }
-        for (uint32_t j = k >> 1; j < packed_stride; ++j) o[j] = 0;
-        if (bad & 0x80u) {   // an IUPAC code / other byte: the read travels as ASCII beside the packed rows
-            if (ne >= exc_cap || !exc_index || !exc_rows) return fail(FQTK_ENOMEM, "more reads with bytes outside A C G T N . than exc_cap");
-            exc_index[ne] = (uint32_t)i;
-            std::memcpy(exc_rows + ne * barcode_len, r, barcode_len);
-            ++ne;
-        }
-    }
+        ok = pack_rows_scalar(obs, stride, barcode_len, n, packed, packed_stride, exc_index, exc_rows, exc_cap, &ne);
+    if (!ok) return fail(FQTK_ENOMEM, "more reads with bytes outside A C G T N . than exc_cap");
     *n_exc = ne;
     return FQTK_OK;
 }
