@@ -2,6 +2,7 @@
 
     python -m fqtk_amd.build            # build if stale
     python -m fqtk_amd.build --force
+    python -m fqtk_amd.build --sanitize=address   # ASan + UBSan build of the host side (also: --sanitize=thread)
 """
 from __future__ import annotations
 
@@ -35,6 +36,38 @@ def _stale(out: str, deps) -> bool:
 HOST = os.path.join(CSRC, "host")
 BINDIR = os.path.join(HERE, "bin")
 CXX = os.environ.get("CXX", "g++")
+
+
+SANITIZERS = {"address": ["-fsanitize=address,undefined", "-fno-sanitize-recover=undefined"], "thread": ["-fsanitize=thread"]}
+
+
+def sanitized_paths(kind: str):
+    """(shim, binary) of a sanitizer build: fqtk_amd/lib/san_<kind>/libfqtk_host.so, fqtk_amd/bin/fqtk.<kind>."""
+    return os.path.join(LIBDIR, f"san_{kind}", "libfqtk_host.so"), os.path.join(BINDIR, f"fqtk.{kind}")
+
+
+def build_sanitized(kind: str, force: bool = False, verbose: bool = False) -> None:
+    """ASan + UBSan or TSan builds of the host side: the ctypes shim the CPU tests load under
+    LD_PRELOAD=libasan/libtsan (tests/test_sanitizers.py) and the `fqtk` binary (its threads -- cutters, count assistants,
+    copy helpers, collector, writers, unmapper, gunzip decoders -- run under TSan on a GPU box: tools/soak_cli.py --exe)."""
+    flags = SANITIZERS[kind]
+    shim, exe = sanitized_paths(kind)
+    os.makedirs(os.path.dirname(shim), exist_ok=True)
+    os.makedirs(BINDIR, exist_ok=True)
+    deps = (glob.glob(os.path.join(HOST, "*.hpp")) + glob.glob(os.path.join(INCLUDE, "*.h")) + glob.glob(os.path.join(CSRC, "*.hpp")))
+    common = [CXX, "-O1", "-g", "-fno-omit-frame-pointer", "-std=c++17", "-Wall", "-pthread"] + flags
+    src = os.path.join(HOST, "host_capi.cpp")
+    if force or _stale(shim, [src] + deps):
+        cmd = common + ["-shared", "-fPIC", "-o", shim, src, "-lz", "-ldl"]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.run(cmd, check=True)
+    src = os.path.join(HOST, "demux.cpp")
+    if os.path.exists(os.path.join(LIBDIR, "libfqtk_match.so")) and (force or _stale(exe, [src] + deps)):
+        cmd = common + ["-o", exe, src, "-L", LIBDIR, "-lfqtk_match", "-lz", "-ldl", "-Wl,-rpath,$ORIGIN/../lib", "-Wl,-rpath,/opt/rocm/lib"]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.run(cmd, check=True)
 
 
 def build_host(force: bool = False, verbose: bool = False) -> None:
@@ -100,4 +133,12 @@ def build(force: bool = False, verbose: bool = False) -> None:
 
 
 if __name__ == "__main__":
-    build(force="--force" in sys.argv, verbose=True)
+    kinds = [a.split("=", 1)[1] for a in sys.argv[1:] if a.startswith("--sanitize=")]
+    for k in kinds:
+        if k not in SANITIZERS:
+            sys.exit(f"--sanitize={k}: one of {sorted(SANITIZERS)}")
+    if kinds:
+        for k in kinds:
+            build_sanitized(k, force="--force" in sys.argv, verbose=True)
+    else:
+        build(force="--force" in sys.argv, verbose=True)

@@ -38,6 +38,7 @@
 #include "../../../include/fqtk_demux.h"
 #include "../../../include/fqtk_match.h"
 #include "bgzf.hpp"
+#include "chunk_dispatch.hpp"
 #include "chunk_schedule.hpp"
 #include "fastq_io.hpp"
 #include "header.hpp"
@@ -506,7 +507,9 @@ bool gpu_output_supported(const Plan &plan, std::string *why) {
     });
 
     // ---- readers
-    constexpr size_t kRing = 3;
+    // page-locked staging per input: one buffer being filled, one waiting, and one per device whose H2D copy may still be
+    // reading it (fqtk_demuxer_text_done)
+    const size_t kRing = 2 + G;
     std::vector<std::unique_ptr<BoundedQueue<RawChunk>>> rq;
     std::vector<std::unique_ptr<BoundedQueue<PinnedRaw *>>> free_bufs;
     std::vector<std::vector<std::unique_ptr<PinnedRaw>>> rings(n_inputs);
@@ -688,11 +691,9 @@ bool gpu_output_supported(const Plan &plan, std::string *why) {
     };
 
     // ---- collector: chunks in order
-    struct Flight { uint64_t k = 0; int dev = 0, slot = 0; uint32_t n = 0; uint64_t first_record = 0; bool end = false; };
-    BoundedQueue<Flight> flights(G * FQTK_DEMUX_SLOTS + 1);
-    std::mutex dmu;
-    std::condition_variable dcv;
-    uint64_t chunks_done = 0, blocks_total = 0, skipped = 0;
+    // Every device has its own submit thread, one collector takes the chunks back in order: chunk_dispatch.hpp.
+    struct Flight { int dev = 0, slot = 0; uint32_t n = 0; uint64_t first_record = 0; };
+    uint64_t blocks_total = 0, skipped = 0;
     auto chunk_error = [&](const Flight &f, const fqtk_demux_result &r) {
         const uint64_t rec = f.first_record + r.error_template;
         const std::string &path = opt.inputs[std::min<size_t>(r.error_input, n_inputs - 1)];
@@ -716,68 +717,59 @@ bool gpu_output_supported(const Plan &plan, std::string *why) {
             default: die("internal error: the device did not find four lines per record in a chunk of " + path);
         }
     };
-    std::thread collector([&] {
-        for (;;) {
-            const Flight f = flights.pop();
-            if (f.end) return;
-            fqtk_demux_result r;
-            const uint64_t t0 = tick();
-            if (fqtk_demuxer_collect(demuxers[f.dev], f.slot, &r) != FQTK_OK) die(std::string("GPU record pipeline: ") + fqtk_last_error());
-            g_times.main_gpu_wait += tick() - t0;
-            if (r.error) chunk_error(f, r);
-            write_result(r);
-            blocks_total += r.n_blocks;
-            skipped += r.n_skipped;
-            {
-                std::lock_guard<std::mutex> lk(dmu);
-                ++chunks_done;
-            }
-            dcv.notify_all();
-        }
-    });
-
-    // ---- this thread: chunks to the devices, chunk k on device k mod G
-    uint64_t k = 0, records = 0, next_log = 1000000;
+    // ---- this thread: cuts the stream of chunks, chunk k to device k mod G; every device's own thread submits its chunks
+    struct Job { size_t n = 0; uint64_t first_record = 0; std::vector<RawChunk> in; };
+    std::atomic<bool> first_submit{false};
     double t_first = 0;
-    ChunkSchedule schedule;
-    schedule.devices = G;
-    schedule.slots = FQTK_DEMUX_SLOTS;
-    std::vector<const uint8_t *> text(n_inputs);
-    std::vector<uint64_t> text_len(n_inputs);
+    auto submit_chunk = [&](int g, int slot, uint64_t, Job &j) -> Flight {
+        std::vector<const uint8_t *> text(n_inputs);
+        std::vector<uint64_t> text_len(n_inputs);
+        for (size_t i = 0; i < n_inputs; ++i) { text[i] = reinterpret_cast<const uint8_t *>(j.in[i].buf->data); text_len[i] = j.in[i].bytes; }
+        const uint64_t th = tick();
+        if (fqtk_demuxer_submit(demuxers[g], slot, text.data(), text_len.data(), (uint32_t)j.n) != FQTK_OK) die(std::string("GPU record pipeline: ") + fqtk_last_error());
+        // (the chunk counts as submitted only once its text has left the host buffers: they go back to the readers here)
+        if (fqtk_demuxer_text_done(demuxers[g], slot) != FQTK_OK) die(std::string("GPU record pipeline: ") + fqtk_last_error());
+        g_times.main_handoff += tick() - th;
+        for (size_t i = 0; i < n_inputs; ++i) free_bufs[i]->push(j.in[i].buf);
+        Flight f;
+        f.dev = g; f.slot = slot; f.n = (uint32_t)j.n; f.first_record = j.first_record;
+        return f;
+    };
+    auto collect_chunk = [&](int g, int slot, uint64_t, Flight &f) {
+        fqtk_demux_result r;
+        const uint64_t t0 = tick();
+        if (fqtk_demuxer_collect(demuxers[g], slot, &r) != FQTK_OK) die(std::string("GPU record pipeline: ") + fqtk_last_error());
+        g_times.main_gpu_wait += tick() - t0;
+        if (r.error) chunk_error(f, r);
+        write_result(r);
+        blocks_total += r.n_blocks;
+        skipped += r.n_skipped;
+    };
+    ChunkDispatcher<Job, Flight> dispatch(G, FQTK_DEMUX_SLOTS, submit_chunk, collect_chunk);
+    uint64_t k = 0, records = 0, next_log = 1000000;
     for (;; ++k) {
-        std::vector<RawChunk> in(n_inputs);
+        Job j;
+        j.in.resize(n_inputs);
         for (size_t i = 0; i < n_inputs; ++i) {
             const uint64_t tw = tick();
-            in[i] = rq[i]->pop();
+            j.in[i] = rq[i]->pop();
             g_times.main_wait += tick() - tw;
-            if (!in[i].error.empty()) die(in[i].error);
+            if (!j.in[i].error.empty()) die(j.in[i].error);
         }
-        const size_t n = in[0].n;
+        const size_t n = j.in[0].n;
         for (size_t i = 0; i < n_inputs; ++i)
-            if (in[i].n != n) die("FASTQ sources out of sync at records: input " + opt.inputs[in[i].n < n ? i : 0] + " ended after a different number of records");
+            if (j.in[i].n != n) die("FASTQ sources out of sync at records: input " + opt.inputs[j.in[i].n < n ? i : 0] + " ended after a different number of records");
         if (n == 0) break;
-        {   // a slot is free again once its chunk has been collected and written
-            std::unique_lock<std::mutex> lk(dmu);
-            dcv.wait(lk, [&] { return schedule.may_submit(k, chunks_done); });
-        }
-        const int dev = schedule.device_of(k), slot = schedule.slot_of(k);
-        for (size_t i = 0; i < n_inputs; ++i) { text[i] = reinterpret_cast<const uint8_t *>(in[i].buf->data); text_len[i] = in[i].bytes; }
-        if (k == 0) t_first = now_s();
-        const uint64_t th = tick();
-        if (fqtk_demuxer_submit(demuxers[dev], slot, text.data(), text_len.data(), (uint32_t)n) != FQTK_OK) die(std::string("GPU record pipeline: ") + fqtk_last_error());
-        Flight f;
-        f.k = k; f.dev = dev; f.slot = slot; f.n = (uint32_t)n; f.first_record = records;
-        flights.push(f);
-        if (fqtk_demuxer_text_done(demuxers[dev], slot) != FQTK_OK) die(std::string("GPU record pipeline: ") + fqtk_last_error());
-        g_times.main_handoff += tick() - th;
-        for (size_t i = 0; i < n_inputs; ++i) free_bufs[i]->push(in[i].buf);
+        if (!first_submit.exchange(true)) t_first = now_s();
+        j.n = n;
+        j.first_record = records;
+        dispatch.push(std::move(j));   // blocks while G x slots chunks are outstanding
         records += n;
         while (records >= next_log) { info("demultiplexed %llu records", (unsigned long long)next_log); next_log += 1000000; }
     }
     for (auto &t : readers) t.join();
     info("Finished reading input FASTQs.");
-    { Flight e; e.end = true; flights.push(e); }
-    collector.join();
+    dispatch.finish();
     for (size_t g = 0; g < G; ++g) {   // what is left in the files' open blocks
         fqtk_demux_result r;
         if (fqtk_demuxer_flush(demuxers[g], &r) != FQTK_OK) die(std::string("GPU record pipeline: ") + fqtk_last_error());

@@ -2,11 +2,15 @@
 // through ctypes (no GPU needed): read structures, header rewriting, FASTQ parsing, BGZF, metrics, and
 // the host-side planners of the LDS-resident memo (csrc/lds_memo_plan.hpp) and of the direct-indexed memo
 // (csrc/direct_memo_plan.hpp).
+#include <chrono>
 #include <cstring>
+#include <mutex>
+#include <thread>
 #include <string>
 #include <vector>
 
 #include "bgzf.hpp"
+#include "chunk_dispatch.hpp"
 #include "chunk_schedule.hpp"
 #include "fastq_io.hpp"
 #include "parallel_gunzip.hpp"
@@ -475,6 +479,73 @@ int fqtk_host_chunk_schedule_check(uint64_t devices, uint64_t slots, uint64_t n_
         else return 4;   // nothing outstanding and nothing may be submitted: stuck
     }
     return (next == n_chunks && done == n_chunks) ? 0 : 4;
+}
+
+// The threads of `fqtk demux --devices a,b,..` (chunk_dispatch.hpp) over a FAKE device: submits and collects take random
+// times (microseconds drawn from `seed`), every device's chunks are submitted by its own thread, one collector takes them
+// back.  Returns 0, or the first rule broken:
+//   1 a (device, slot) pair was handed a chunk while its previous one was still outstanding
+//   2 a device did not receive its chunks in ascending order, or a chunk went to the wrong device / slot
+//   3 chunks were not collected in order 0, 1, 2, ..
+//   4 not every chunk was submitted and collected exactly once, or its payload / meta did not come through
+//   5 two submits ran on one device at the same time (a device has ONE submit thread)
+// *overlap = 1 if submits on two different devices were ever in progress at the same time (the point of the exercise).
+int fqtk_host_chunk_dispatch_check(uint64_t devices, uint64_t slots, uint64_t n_chunks, uint64_t seed, int *overlap) {
+    struct Job { uint64_t payload; };
+    struct Meta { uint64_t payload = 0, k = 0; };
+    std::mutex mu;
+    std::vector<int64_t> busy(devices * slots, -1), last_on_device(devices, -1);
+    std::vector<int> in_submit(devices, 0);
+    std::vector<uint8_t> submitted(n_chunks, 0), collected(n_chunks, 0);
+    int broken = 0, saw_overlap = 0;
+    uint64_t next_collect = 0;
+    auto rnd = [seed](uint64_t k, uint64_t salt) { uint64_t x = (k + 1) * 0x9E3779B97F4A7C15ull ^ (seed + salt) * 0xBF58476D1CE4E5B9ull; x ^= x >> 29; x *= 0x94D049BB133111EBull; return (x >> 40) % 300; };
+    auto flag = [&](int rule) { if (!broken) broken = rule; };
+    {
+        ChunkDispatcher<Job, Meta> d((size_t)devices, (size_t)slots,
+            [&](int dev, int slot, uint64_t k, Job &j) {
+                {
+                    std::lock_guard<std::mutex> lk(mu);
+                    if ((uint64_t)dev != k % devices || (uint64_t)slot != (k / devices) % slots) flag(2);
+                    const size_t cell = (size_t)dev * slots + (size_t)slot;
+                    if (busy[cell] >= 0) flag(1);
+                    busy[cell] = (int64_t)k;
+                    if (last_on_device[dev] >= (int64_t)k) flag(2);
+                    last_on_device[dev] = (int64_t)k;
+                    if (in_submit[dev]++) flag(5);
+                    for (uint64_t o = 0; o < devices; ++o) if ((int)o != dev && in_submit[o]) saw_overlap = 1;
+                    if (k < n_chunks && submitted[k]++) flag(4);
+                }
+                std::this_thread::sleep_for(std::chrono::microseconds(rnd(k, 1)));
+                {
+                    std::lock_guard<std::mutex> lk(mu);
+                    --in_submit[dev];
+                }
+                Meta m;
+                m.payload = j.payload;
+                m.k = k;
+                return m;
+            },
+            [&](int dev, int slot, uint64_t k, Meta &m) {
+                std::this_thread::sleep_for(std::chrono::microseconds(rnd(k, 2)));
+                std::lock_guard<std::mutex> lk(mu);
+                if (k != next_collect++) flag(3);
+                if (m.k != k || m.payload != k * 7 + 1) flag(4);
+                const size_t cell = (size_t)dev * slots + (size_t)slot;
+                if (busy[cell] != (int64_t)k) flag(1);
+                busy[cell] = -1;
+                if (k < n_chunks && collected[k]++) flag(4);
+            });
+        for (uint64_t k = 0; k < n_chunks; ++k) {
+            if (rnd(k, 3) < 30) std::this_thread::sleep_for(std::chrono::microseconds(rnd(k, 4)));   // a reader that stalls now and then
+            d.push(Job{k * 7 + 1});
+        }
+        d.finish();
+    }
+    for (uint64_t k = 0; k < n_chunks; ++k) if (submitted[k] != 1 || collected[k] != 1) flag(4);
+    if (next_collect != n_chunks) flag(4);
+    if (overlap) *overlap = saw_overlap;
+    return broken;
 }
 
 // FastqSource::next_cut over a whole plain (mapped) file: the same contract as fqtk_host_read_raw, the text taken

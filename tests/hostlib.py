@@ -5,7 +5,8 @@ import os
 import subprocess
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-LIB = os.path.join(ROOT, "fqtk_amd", "lib", "libfqtk_host.so")
+# FQTK_HOST_LIB: a sanitizer build of the same shim (python -m fqtk_amd.build --sanitize=address|thread; tests/test_sanitizers.py)
+LIB = os.environ.get("FQTK_HOST_LIB") or os.path.join(ROOT, "fqtk_amd", "lib", "libfqtk_host.so")
 EXE = os.path.join(ROOT, "fqtk_amd", "bin", "fqtk")
 
 _lib = None

@@ -149,3 +149,18 @@ def test_chunk_schedule_keeps_slots_exclusive_and_devices_in_order():
                     order = (rng.random(4 * n_chunks + 8) < p).astype(np.uint8)
                     rc = fn(C.c_uint64(devices), C.c_uint64(slots), C.c_uint64(n_chunks), order.ctypes.data_as(C.c_void_p), C.c_size_t(order.size))
                     assert rc == 0, (devices, slots, n_chunks, p, rc)
+
+
+def test_every_device_has_its_own_submit_thread_and_chunks_come_back_in_order():
+    """`fqtk demux --devices a,b,..` (csrc/host/chunk_dispatch.hpp) over a fake device whose submits and collects take random
+    times: every device's chunks are submitted by that device's own thread (never two at once on one device, two devices'
+    submits DO overlap), a (device, slot) pair gets its next chunk only after the previous one was collected, the
+    collector sees 0, 1, 2, .. -- the order every output file is written in (demux.rs:945-977)."""
+    import ctypes as C
+    from tests import hostlib as H
+    fn = H.lib().fqtk_host_chunk_dispatch_check
+    for devices, slots, n, seed in ((1, 3, 200, 1), (2, 3, 400, 2), (3, 2, 300, 3), (8, 3, 600, 4), (4, 1, 100, 5), (2, 3, 1, 6), (3, 3, 0, 7)):
+        overlap = C.c_int(0)
+        assert fn(C.c_uint64(devices), C.c_uint64(slots), C.c_uint64(n), C.c_uint64(seed), C.byref(overlap)) == 0, (devices, slots, n)
+        if devices > 1 and n >= 100:
+            assert overlap.value == 1, "the devices' submits never overlapped"

@@ -118,7 +118,11 @@ def one(rng, it, tmp):
     if skip_ok:
         cmd += ["-S", "too-few-bases"]
     cmd += EXTRA
-    r = subprocess.run(cmd, capture_output=True, text=True, timeout=300)
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+    for mark in ("WARNING: ThreadSanitizer", "ERROR: AddressSanitizer", "runtime error:"):   # (a sanitizer build: --exe)
+        if mark in r.stderr:
+            at = r.stderr.index(mark)
+            raise AssertionError("sanitizer report from " + " ".join(cmd) + "\n" + r.stderr[at:at + 4000])
     # expected
     minlen = [sum((l if l is not None else 1) for (_, l, _) in p) for p in parsed]
     skipped = [any(len(reads[i][t]) < minlen[i] for i in range(n_inputs)) for t in range(n)]
@@ -173,8 +177,12 @@ if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--iters", type=int, default=40)
     ap.add_argument("--seed", type=int, default=1)
+    ap.add_argument("--exe", default="", help="another build of the binary, e.g. fqtk_amd/bin/fqtk.thread (python -m fqtk_amd.build --sanitize=thread): "
+                                              "its stderr is scanned for sanitizer reports")
     ap.add_argument("--host-output", action="store_true", help="every run with --host-output (records formatted and compressed by the host threads; default: on the device)")
     a = ap.parse_args()
+    if a.exe:
+        EXE = os.path.abspath(a.exe)
     EXTRA[:] = ["--host-output"] if a.host_output else []
     rng = random.Random(a.seed)
     tmp = tempfile.mkdtemp(prefix="fqtk_soak_", dir="/tmp")
