@@ -499,58 +499,31 @@ __global__ __launch_bounds__(256) void k_descs(DevConfig C, const FileChunk *fc,
 // ---- formatting -----------------------------------------------------------------------------------------------------------
 // One wavefront per kFormatGroup consecutive templates.  First the lanes fetch what the group's templates need (plan,
 // sample, the record views of all inputs -> LDS, per output file the record's place): the dependent look-ups of the whole
-// group in one round trip.  Then the wave takes the records one by one, and NO lane works alone: the record is stated as
-// in record_format.hpp (emit_record), but the sink is a GATHER -- every lane holds eight byte positions of the record (two
-// aligned dwords of the file's block) and every piece the record is made of is offered to all lanes at once: a lane
-// whose position falls inside takes the source address (or the literal byte).  The pieces' bounds are wave-uniform, so
-// this is ~4 VALU operations per piece and position with no divergence, no LDS table and no barrier; then all loads go
-// out together, and the two dwords are stored (the ragged first and last dwords of a record byte by byte).
-// (Before: lane 0 listed the pieces into LDS and the lanes copied piece after piece -- a serial section of several
-// hundred instructions plus one dependent memory round trip per piece, 0.8 ms per chunk for 0.4 GB of traffic.)
+// group in one round trip.  Then the wave takes the records one by one:
+//   1. the record's SLOT TABLE (record_format.hpp: record_slot) -- lane s works out slot s in closed form from the plan,
+//      a wave prefix sum places the slots, the table goes to LDS (start, source, kind per slot; <= 62 slots);
+//   2. the body: every lane takes whole dwords of the file's block that lie inside ONE slot -- a binary search over the
+//      slot starts (six LDS reads), two aligned dwords of the source and one v_alignbyte -- 256 bytes per pass;
+//   3. the seams: lane j takes the dword that holds the first byte of slot j (and two more lanes the record's first and
+//      last dword), byte by byte -- literals, slot boundaries and the ragged ends of the record, ONE pass per record.
+// ~250 wave-instructions per 360-byte record.  Round 3 offered every piece of the record to all 64 lanes x 8 byte positions
+// each (a gather sink: no serial lane, no table, but ~1 200 wave-instructions per record, 108 VGPRs: 740 us per chunk of
+// 262 144 templates, the second-largest device stage of a run); before that one lane listed the pieces (805 us).
 constexpr int kFormatWaves = 4;
 constexpr uint32_t kFormatGroup = 16;
-struct WaveScratch { fmt::Span b[kMaxSegs], m[kMaxSegs]; };
-// dynamic LDS per wave: WaveScratch, then RecView rec[n_inputs][kFormatGroup]
-__host__ __device__ constexpr size_t format_wave_bytes(uint32_t n_inputs) { return (sizeof(WaveScratch) + (size_t)n_inputs * kFormatGroup * sizeof(RecView) + 15u) & ~(size_t)15u; }
-
-struct GatherSink {
-    const TextSet &T;
-    uint32_t run = 0;          // bytes of the record offered so far (wave-uniform)
-    uint64_t plit = 0;         // literal bytes not offered yet (wave-uniform): runs of literals go out eight at a time,
-    uint32_t nlit = 0;         // one round of compares per run instead of one per byte
-    uint32_t pos[8];           // this lane's byte positions in the record (0xFFFFFFFF: none)
-    const uint8_t *src[8];     // where each comes from (nullptr: a literal, in val)
-    uint32_t val[8];
-    __device__ explicit GatherSink(const TextSet &t) : T(t) {}
-    __device__ void flush() {
-        if (!nlit) return;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const uint32_t k = pos[j] - run;   // (positions before the run wrap around to huge values)
-            if (k < nlit) { src[j] = nullptr; val[j] = (uint32_t)(plit >> (8u * k)) & 0xFFu; }
-        }
-        run += nlit;
-        plit = 0;
-        nlit = 0;
-    }
-    __device__ void lit(uint8_t b) {
-        plit |= (uint64_t)b << (8u * nlit);
-        if (++nlit == 8u) flush();
-    }
-    __device__ void span(uint32_t input, uint32_t off, uint32_t len) {
-        flush();
-        const uint8_t *base = T.text[input] + off;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const uint32_t k = pos[j] - run;
-            if (k < len) src[j] = base + k;
-        }
-        run += len;
-    }
+constexpr uint32_t kFormatSlots = 64;   // record_slots(nb, nm) + 6 <= 64: a lane per slot, six more for the seams (fqtk_demuxer_create)
+struct WaveScratch {
+    fmt::Span b[kMaxSegs], m[kMaxSegs];
+    uint32_t start[kFormatSlots + 1];   // byte offset of every slot in the record; [n_slots] = the record's length
+    uint32_t src[kFormatSlots];         // span: offset in its input's text; literal: the bytes
+    uint32_t info[kFormatSlots];        // input | kind << 16
 };
+// dynamic LDS: the inputs' text pointers (one copy per workgroup), then per wave: WaveScratch, RecView rec[n_inputs][kFormatGroup]
+__host__ __device__ constexpr size_t format_wave_bytes(uint32_t n_inputs) { return (sizeof(WaveScratch) + (size_t)n_inputs * kFormatGroup * sizeof(RecView) + 15u) & ~(size_t)15u; }
+__host__ __device__ constexpr size_t format_block_bytes(uint32_t n_inputs) { return FQTK_DEMUX_MAX_INPUTS * sizeof(uint64_t) + kFormatWaves * format_wave_bytes(n_inputs); }
 
 #ifndef FQTK_FORMAT_WAVES_PER_EU
-#define FQTK_FORMAT_WAVES_PER_EU 5   // (tools/ab_format.sh: the stage takes 0.183 s of a 64 M-template run at 4, 0.176 at 5, 0.185 at 6, 0.243 at 8: spills)
+#define FQTK_FORMAT_WAVES_PER_EU 8
 #endif
 __global__ __launch_bounds__(64 * kFormatWaves) __attribute__((amdgpu_waves_per_eu(FQTK_FORMAT_WAVES_PER_EU, 8))) void k_format(TextSet T, DevConfig C, uint32_t n, const uint32_t *res, const uint8_t *skip,
                                                                const TemplatePlan *plans, const uint32_t *rec_off, const uint32_t *tile_tot,
@@ -558,7 +531,11 @@ __global__ __launch_bounds__(64 * kFormatWaves) __attribute__((amdgpu_waves_per_
     if (st->err_key != kNoError) return;
     extern __shared__ __attribute__((aligned(16))) uint8_t fmt_lds[];
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
-    uint8_t *mine_lds = fmt_lds + (size_t)wave * format_wave_bytes(C.n_inputs);
+    // the inputs' text pointers where a lane can index them by a slot's input
+    const uint8_t **text_of = reinterpret_cast<const uint8_t **>(fmt_lds);
+    if (threadIdx.x < C.n_inputs) text_of[threadIdx.x] = T.text[threadIdx.x];
+    __syncthreads();
+    uint8_t *mine_lds = fmt_lds + FQTK_DEMUX_MAX_INPUTS * sizeof(uint64_t) + (size_t)wave * format_wave_bytes(C.n_inputs);
     WaveScratch &W = *reinterpret_cast<WaveScratch *>(mine_lds);
     RecView *recs = reinterpret_cast<RecView *>(mine_lds + sizeof(WaveScratch));   // [input][template of the group]
     const uint32_t t0 = (blockIdx.x * kFormatWaves + wave) * kFormatGroup;
@@ -585,7 +562,7 @@ __global__ __launch_bounds__(64 * kFormatWaves) __attribute__((amdgpu_waves_per_
     if (!live) return;
     const uint32_t plan_w0 = tp.h.name_len, plan_w1 = tp.h.copy_off, plan_w2 = tp.h.copy_len;
     const uint32_t plan_w3 = (uint32_t)tp.h.kind | ((uint32_t)tp.h.tail << 8) | ((uint32_t)tp.h.msep << 16);
-    const uint32_t plan_w4 = tp.base_len;
+    const uint32_t n_slots = fmt::record_slots(C.n_b, C.n_m);
     for (uint32_t f = 0; f < C.n_files; ++f) {
         uint32_t my_q = 0, my_nb = 0, my_slab = 0, my_par = 0;   // where this lane's record of file f goes
         if (valid) {
@@ -596,6 +573,9 @@ __global__ __launch_bounds__(64 * kFormatWaves) __attribute__((amdgpu_waves_per_
             my_par = x.par;
         }
         const fmt::FileSeg fsg = C.fseg[f];
+        // "<n>:" and "<n>:N:0:" of this file (wave-uniform; which one a record takes depends on its header)
+        uint32_t num0[4], num2[4];
+        const uint32_t num0_len = fmt::number_literal(fsg.read_num, 0, num0), num2_len = fmt::number_literal(fsg.read_num, 2, num2);
         for (uint64_t todo = live; todo;) {
             const int i = __ffsll((unsigned long long)todo) - 1;   // wave-uniform
             todo &= todo - 1;
@@ -635,40 +615,144 @@ __global__ __launch_bounds__(64 * kFormatWaves) __attribute__((amdgpu_waves_per_
             uint32_t lo, hi;
             fmt::segment_span(fsg.offset, fsg.length, r.seq_len, &lo, &hi);
             const uint32_t head_off = recs[(uint32_t)i].head_off;
-            const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)plan_w4, i) + (h.kind != 1 ? digits_of(fsg.read_num) - 1u : 0u) + 2u * (hi - lo);
-            const uint32_t a = q & 3u, span = a + total;   // the record from the aligned start of its first dword
-            for (uint32_t g0 = 0; g0 < span; g0 += 64u * 8u) {
-                GatherSink sink(T);
+            const bool number0 = h.kind == 0;
+            // ---- 1. the slot table: lane s = slot s ----------------------------------------------------------------------
+            fmt::Slot z;
+            z.len = 0; z.kind = fmt::kLiteral; z.input = 0; z.off = 0; z.lit = 0;
+            if (lane < n_slots)
+                z = fmt::record_slot(lane, h, head_off, number0 ? num0_len : num2_len, W.b, C.n_b, W.m, C.n_m,
+                                     fmt::Span{fsg.input, r.seq_off + lo, hi - lo}, fmt::Span{fsg.input, r.qual_off + lo, hi - lo});
+            uint32_t incl = z.len;   // inclusive prefix sum over the lanes
 #pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    const uint32_t g = g0 + ((uint32_t)(j >> 2) * 64u + lane) * 4u + (uint32_t)(j & 3);   // counted from the aligned start
-                    sink.pos[j] = (g >= a && g < span) ? g - a : 0xFFFFFFFFu;
-                    sink.src[j] = nullptr;
-                    sink.val[j] = 0;
-                }
-                fmt::emit_record(sink, h, head_off, fsg.read_num, W.b, C.n_b, W.m, C.n_m,
-                                 fmt::Span{fsg.input, r.seq_off + lo, hi - lo}, fmt::Span{fsg.input, r.qual_off + lo, hi - lo});
-                sink.flush();
-                uint32_t byte[8];
+            for (int d = 1; d < 64; d <<= 1) {
+                const uint32_t up = __shfl_up(incl, d);
+                if (lane >= (uint32_t)d) incl += up;
+            }
+            const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+            W.start[lane] = incl - z.len;
+            if (lane == 63) W.start[64] = total;
+            W.src[lane] = z.kind == fmt::kSpan ? z.off : z.lit;
+            W.info[lane] = z.input | (z.kind << 16);
+            __builtin_amdgcn_wave_barrier();
+            __threadfence_block();
+            // One byte of the record: slot p holds record position rq.
+            auto byte_of = [&](uint32_t p, uint32_t rq) -> uint32_t {
+                const uint32_t inf = W.info[p], k = rq - W.start[p], sv = W.src[p];
+                if ((inf >> 16) == fmt::kSpan) return text_of[inf & 0xFFFFu][sv + k];
+                if ((inf >> 16) == fmt::kLiteral) return (sv >> (8u * k)) & 0xFFu;
+                const uint32_t w = number0 ? (k < 4 ? num0[0] : (k < 8 ? num0[1] : (k < 12 ? num0[2] : num0[3])))
+                                           : (k < 4 ? num2[0] : (k < 8 ? num2[1] : (k < 12 ? num2[2] : num2[3])));
+                return (w >> (8u * (k & 3u))) & 0xFFu;
+            };
+            // the last slot that starts at or before rq (rq < total): empty slots share their successor's start and lose
+            auto slot_at = [&](uint32_t rq) -> uint32_t {
+                uint32_t p = 0;
 #pragma unroll
-                for (int j = 0; j < 8; ++j) byte[j] = sink.src[j] ? (uint32_t)*sink.src[j] : sink.val[j];   // all loads, then ...
+                for (uint32_t step = 32; step; step >>= 1)
+                    if (p + step < kFormatSlots && W.start[p + step] <= rq) p += step;
+                return p;
+            };
+            const uint32_t a = q & 3u;                    // the record starts `a` bytes into a dword of its block
+            // Where a byte of the record goes: the record begins in block q / kBlock of its file's chunk and may run on into
+            // the next one (both bases are wave-uniform; records longer than a block take file_byte's general arithmetic).
+            const uint32_t kth0 = q / kBlock, in0 = q - kth0 * kBlock;
+            uint8_t *const base0 = block_base(x, c, kth0, persist, slabs), *const base1 = block_base(x, c, kth0 + 1u, persist, slabs);
+            const bool two_blocks_at_most = in0 + total <= 2u * kBlock;
+            auto dst_of = [&](uint32_t pos /* bytes from the dword-aligned start of the record's first dword */) -> uint8_t * {
+                const uint32_t o = in0 - a + pos;   // offset inside block kth0
+                if (two_blocks_at_most) return o < kBlock ? base0 + o : base1 + (o - kBlock);
+                return file_byte(x, c, q - a + pos, persist, slabs);
+            };
+            const uint32_t n_dw = (a + total + 3u) >> 2;  // dwords of the block it touches
+            // A wave's record is a chain of dependent round trips (slot look-ups in LDS, then the text in HBM): the look-ups
+            // and loads of TWO body passes (512 bytes: a whole record of 150-base reads) and of the seams are worked out and
+            // issued together, branch-free -- a lane with nothing to do reads the first input's first bytes -- and only then
+            // anything is stored.  (Taken one after another they cost ~10 us per record: three HBM round trips.)
+            const uint8_t *safe = text_of[0];
+            // ---- 2. the body: dwords that lie inside one slot ---------------------------------------------------------------
+            auto body_plan = [&](uint32_t d, bool &ok, const uint32_t *&aw, uint32_t &mis, uint32_t &p_out, uint32_t &rq_out) {
+                const uint32_t rq = 4u * d - a;           // record position of the dword's first byte (wraps for d = 0, a > 0)
+                const bool inside = d < n_dw && 4u * d >= a && rq + 4u <= total;
+                const uint32_t p = slot_at(inside ? rq : 0u);
+                const uint32_t inf = W.info[p];
+                ok = inside && rq + 4u <= W.start[p + 1] && (inf >> 16) == fmt::kSpan;   // (literals and the digits: the seams)
+                const uint8_t *sp = ok ? text_of[inf & 0xFFFFu] + W.src[p] + (rq - W.start[p]) : safe;
+                mis = (uint32_t)(reinterpret_cast<uintptr_t>(sp) & 3u);
+                aw = reinterpret_cast<const uint32_t *>(sp - mis);
+                p_out = p;
+                rq_out = rq;
+            };
+            auto body_word = [&](bool, uint32_t w0, uint32_t w1, uint32_t mis, uint32_t, uint32_t) -> uint32_t {
+                return __builtin_amdgcn_alignbyte(w1, w0, mis);   // (every text buffer has 64 bytes of slack behind it)
+            };
+            bool ok0, ok1;
+            const uint32_t *aw0, *aw1;
+            uint32_t mis0, mis1, bp0, bp1, brq0, brq1;
+            body_plan(lane, ok0, aw0, mis0, bp0, brq0);
+            body_plan(64u + lane, ok1, aw1, mis1, bp1, brq1);
+            // ---- 3. the seams: the dword of every slot's first byte, the record's first and last dword ----------------------
+            uint32_t rq0 = 0xFFFFFFFFu;                   // a record position inside the dword this lane takes
+            const uint32_t num_slot = 4u + 2u * C.n_m, num_start = W.start[num_slot], num_len = W.start[num_slot + 1u] - num_start;
+            if (lane < n_slots) { if (z.len) rq0 = incl - z.len; }
+            else if (lane == n_slots) rq0 = 0;
+            else if (lane == n_slots + 1u) rq0 = total - 1u;
+            else if (lane < n_slots + 6u) {               // the inner dwords of "<n>:N:0:" (<= 15 bytes: four more dwords at most)
+                const uint32_t off = 4u * (lane - n_slots - 1u);
+                if (off < num_len) rq0 = num_start + off;
+            }
+            const bool seam = rq0 != 0xFFFFFFFFu && total != 0u;
+            const uint32_t sd = seam ? (a + rq0) >> 2 : 0u;
+            const uint8_t *sbyte[4];
+            uint32_t slit[4], shave = 0;
+            {
+                uint32_t p = slot_at(seam && 4u * sd >= a ? 4u * sd - a : 0u);
 #pragma unroll
-                for (int j2 = 0; j2 < 2; ++j2) {                                                            // ... the stores
-                    const uint32_t gb = g0 + ((uint32_t)j2 * 64u + lane) * 4u;
-                    uint32_t have = 0, word = 0;
-#pragma unroll
-                    for (int k = 0; k < 4; ++k)
-                        if (sink.pos[4 * j2 + k] != 0xFFFFFFFFu) { have |= 1u << k; word |= byte[4 * j2 + k] << (8 * k); }
-                    if (!have) continue;
-                    uint8_t *dst = file_byte(x, c, q - a + gb, persist, slabs);
-                    if (have == 15u) {
-                        *reinterpret_cast<uint32_t *>(dst) = word;
-                    } else {
-#pragma unroll
-                        for (int k = 0; k < 4; ++k)
-                            if (have & (1u << k)) dst[k] = (uint8_t)(word >> (8 * k));
+                for (uint32_t k = 0; k < 4u; ++k) {
+                    const uint32_t pos = 4u * sd + k;
+                    const bool in = seam && pos >= a && pos - a < total;
+                    const uint32_t rq = in ? pos - a : 0u;
+                    while (in && p + 1u < kFormatSlots && W.start[p + 1] <= rq) ++p;
+                    const uint32_t inf = W.info[p], kk = rq - W.start[p], sv = W.src[p];
+                    const bool span = in && (inf >> 16) == fmt::kSpan;
+                    sbyte[k] = span ? text_of[inf & 0xFFFFu] + sv + kk : safe;
+                    uint32_t lit = (sv >> (8u * (kk & 3u))) & 0xFFu;
+                    if ((inf >> 16) == fmt::kNumber) {
+                        const uint32_t w = number0 ? (kk < 4 ? num0[0] : (kk < 8 ? num0[1] : (kk < 12 ? num0[2] : num0[3])))
+                                                   : (kk < 4 ? num2[0] : (kk < 8 ? num2[1] : (kk < 12 ? num2[2] : num2[3])));
+                        lit = (w >> (8u * (kk & 3u))) & 0xFFu;
                     }
+                    slit[k] = span ? 0x100u : lit;        // 0x100: the byte comes from the text
+                    if (in) shave |= 1u << k;
                 }
+            }
+            // every load of the record, then the stores
+            const uint32_t w00 = aw0[0], w01 = aw0[1], w10 = aw1[0], w11 = aw1[1];
+            uint32_t sb[4];
+#pragma unroll
+            for (uint32_t k = 0; k < 4u; ++k) sb[k] = *sbyte[k];
+            if (ok0) *reinterpret_cast<uint32_t *>(dst_of(4u * lane)) = body_word(ok0, w00, w01, mis0, bp0, brq0);
+            if (ok1) *reinterpret_cast<uint32_t *>(dst_of(4u * (64u + lane))) = body_word(ok1, w10, w11, mis1, bp1, brq1);
+            if (shave) {
+                uint32_t word = 0;
+#pragma unroll
+                for (uint32_t k = 0; k < 4u; ++k) word |= ((slit[k] & 0x100u) ? sb[k] : slit[k]) << (8u * k);
+                uint8_t *dst = dst_of(4u * sd);
+                if (shave == 15u) {
+                    *reinterpret_cast<uint32_t *>(dst) = word;
+                } else {
+#pragma unroll
+                    for (uint32_t k = 0; k < 4u; ++k)
+                        if (shave & (1u << k)) dst[k] = (uint8_t)(word >> (8u * k));
+                }
+            }
+            // records of more than 512 bytes (long reads): the rest of the body, 256 bytes per pass
+            for (uint32_t d0 = 128u; d0 < n_dw; d0 += 64u) {
+                bool ok;
+                const uint32_t *aw;
+                uint32_t mis, bp, brq;
+                body_plan(d0 + lane, ok, aw, mis, bp, brq);
+                const uint32_t w0 = aw[0], w1 = aw[1];
+                if (ok) *reinterpret_cast<uint32_t *>(dst_of(4u * (d0 + lane))) = body_word(ok, w0, w1, mis, bp, brq);
             }
             __builtin_amdgcn_wave_barrier();
         }

@@ -246,7 +246,10 @@ int fqtk_demuxer_create(fqtk_matcher *m, const fqtk_demux_config *cfg, fqtk_demu
         if (b.length >= 0) C.fixed_bc_len += (uint32_t)b.length; else C.variable_bc = 1;
     }
     for (const auto &b : by_type[2]) C.mseg[C.n_m++] = fqtk::fmt::SegPos{b.input, b.offset, b.length};
-    if (fqtk::fmt::max_pieces(C.n_b, C.n_m) > (uint32_t)fqtk::fmt::kMaxPieces) { delete d; return set_error(FQTK_EINVAL, "too many barcode segments for one record"); }
+    if (fqtk::fmt::max_pieces(C.n_b, C.n_m) > (uint32_t)fqtk::fmt::kMaxPieces || fqtk::fmt::record_slots(C.n_b, C.n_m) + 6u > kFormatSlots) {
+        delete d;
+        return set_error(FQTK_EINVAL, "too many barcode segments for one record (sample + molecular: at most 23)");
+    }
     for (int ty = 0; ty < 4; ++ty) {
         if (!cfg->want[ty]) continue;
         for (const auto &f : by_type[ty]) {
@@ -267,7 +270,7 @@ int fqtk_demuxer_create(fqtk_matcher *m, const fqtk_demux_config *cfg, fqtk_demu
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, d->device) == hipSuccess && prop.multiProcessorCount > 0) d->num_cus = prop.multiProcessorCount;
     DX_OR_BAIL(fqtk::bgzf::deflate_prepare());
-    static_assert(kFormatWaves * format_wave_bytes(FQTK_DEMUX_MAX_INPUTS) <= 48 * 1024, "k_format: the record views of a group per wave fit the default LDS");
+    static_assert(format_block_bytes(FQTK_DEMUX_MAX_INPUTS) <= 48 * 1024, "k_format: slot tables and record views of a group per wave fit the default LDS");
     for (hipStream_t *st : {&d->s_in, &d->s_a, &d->s_b, &d->s_out}) DX_OR_BAIL(hipStreamCreateWithFlags(st, hipStreamNonBlocking));
     const size_t persist_bytes = (size_t)std::max<uint32_t>(d->n_cols, 1) * kPersist * kSlab;
     DX_OR_BAIL(hipMalloc(reinterpret_cast<void **>(&d->d_persist), persist_bytes));
@@ -416,7 +419,7 @@ int fqtk_demuxer_submit(fqtk_demuxer *d, int slot, const uint8_t *const *text, c
     hipLaunchKernelGGL(k_descs, dim3((uint32_t)((max_blocks + 255) / 256)), dim3(256), 0, A, C, s.fc.p, d->d_persist, s.slabs.p, s.out_slabs.p, s.desc.p, s.blk_file.p, s.d_status);
     DX_TRY(hipGetLastError());
     DX_TRY(hipEventRecord(s.ev[3], A));
-    hipLaunchKernelGGL(k_format, dim3((n + kFormatGroup * kFormatWaves - 1) / (kFormatGroup * kFormatWaves)), dim3(64 * kFormatWaves), kFormatWaves * format_wave_bytes(C.n_inputs), A, T, C, n, s.res.p, s.skip.p, s.plans.p,
+    hipLaunchKernelGGL(k_format, dim3((n + kFormatGroup * kFormatWaves - 1) / (kFormatGroup * kFormatWaves)), dim3(64 * kFormatWaves), format_block_bytes(C.n_inputs), A, T, C, n, s.res.p, s.skip.p, s.plans.p,
                        s.rec_off.p, s.tile_tot.p, s.fc.p, d->d_persist, s.slabs.p, s.d_status);
     DX_TRY(hipGetLastError());
     DX_TRY(hipEventRecord(s.ev[4], A));

@@ -453,7 +453,7 @@ void write_all(int fd, const uint8_t *p, size_t n, const std::string &path) {
 bool gpu_output_supported(const Plan &plan, std::string *why) {
     if (plan.rs.size() > FQTK_DEMUX_MAX_INPUTS) { *why = "more than " + std::to_string(FQTK_DEMUX_MAX_INPUTS) + " inputs"; return false; }
     if (plan.files_per_sample > FQTK_DEMUX_MAX_FILES) { *why = "more than " + std::to_string(FQTK_DEMUX_MAX_FILES) + " output files per sample"; return false; }
-    if (plan.by_type[1].size() > 24 || plan.by_type[2].size() > 24) { *why = "more than 24 barcode segments"; return false; }
+    if (plan.by_type[1].size() + plan.by_type[2].size() > 23) { *why = "more than 23 sample / molecular barcode segments"; return false; }
     return true;
 }
 

@@ -407,6 +407,18 @@ int64_t fqtk_host_format_record(const char *header, uint32_t read_num, const cha
     for (uint32_t v = read_num; digits == 0 || v; v /= 10) ++digits;
     if (record_len(p, digits, bl, nb, ml, nm, sb.len) != ls.n) return -100;
     if (rec.size() != ls.n || rec.size() > cap || ps.n > max_pieces(nb, nm)) return -100;
+    {   // the slot table k_format's lanes work from must spell the same bytes
+        uint32_t numw[4];
+        const uint32_t num_len = number_literal(read_num, p.kind, numw);
+        std::string rec2;
+        for (uint32_t sidx = 0; sidx < record_slots(nb, nm); ++sidx) {
+            const Slot z = record_slot(sidx, p, 0, num_len, b.data(), nb, m.data(), nm, sb, sq);
+            if (z.kind == kSpan) rec2.append(texts[z.input], z.off, z.len);
+            else if (z.kind == kLiteral) for (uint32_t j = 0; j < z.len; ++j) rec2.push_back((char)(z.lit >> (8 * j)));
+            else for (uint32_t j = 0; j < z.len; ++j) rec2.push_back((char)(numw[j >> 2] >> (8 * (j & 3))));
+        }
+        if (rec2 != rec) return -101;
+    }
     std::memcpy(out, rec.data(), rec.size());
     return (int64_t)rec.size();
 }

@@ -151,6 +151,55 @@ FQTK_HD inline void emit_record(Sink &s, const HeaderPlan &p, uint32_t head_off,
     s.lit('\n');
 }
 
+// The same record as a TABLE OF SLOTS in fixed positions (empty ones have length 0), so that slot s can be worked out on
+// its own -- by lane s of a wavefront, all slots at once (k_format) -- where emit_record walks the record from its start:
+//   0 '@' | 1 name | 2 msep | 3 + 2i ['+'] , 4 + 2i molecular segment i | b1 ' ' | b1+1 "<n>:" or "<n>:N:0:" | b1+2 copied
+//   part of the comment | b1+3 tail | b2 + 2i ['+'] , b2 + 2i + 1 sample segment i | b3 '\n' | bases | "\n+\n" | quals | '\n'
+// with b1 = 3 + 2 nm, b2 = b1 + 4, b3 = b2 + 2 nb.  A literal slot holds up to four bytes in `lit`; the number slot (kNumber)
+// refers to the caller's digits (they depend on the file, not on the template).  Checked against emit_record byte for byte
+// in the CPU tests (fqtk_host_format_record).
+enum SlotKind : uint32_t { kSpan = 0, kLiteral = 1, kNumber = 2 };
+struct Slot { uint32_t len, kind, input, off, lit; };
+FQTK_HD inline uint32_t record_slots(uint32_t nb, uint32_t nm) { return 12u + 2u * (nb + nm); }
+// "<n>:" (kind 2) / "<n>:N:0:" (kind 0) / nothing (kind 1) as up to 16 bytes in four words; returns the length
+FQTK_HD inline uint32_t number_literal(uint32_t read_num, uint32_t header_kind, uint32_t (&w)[4]) {
+    w[0] = w[1] = w[2] = w[3] = 0;
+    if (header_kind == 1) return 0;
+    uint8_t d[16];
+    uint32_t n = decimal_digits(read_num, d);
+    d[n++] = ':';
+    if (header_kind == 0) { d[n++] = 'N'; d[n++] = ':'; d[n++] = '0'; d[n++] = ':'; }
+    for (uint32_t i = 0; i < n; ++i) w[i >> 2] |= (uint32_t)d[i] << (8 * (i & 3u));
+    return n;
+}
+FQTK_HD inline Slot record_slot(uint32_t s, const HeaderPlan &p, uint32_t head_off, uint32_t number_len,
+                                const Span *bsegs, uint32_t nb, const Span *msegs, uint32_t nm, const Span &bases, const Span &quals) {
+    Slot z;
+    z.len = 0; z.kind = kLiteral; z.input = 0; z.off = 0; z.lit = 0;
+    auto lit1 = [&](uint32_t byte, bool on) { z.kind = kLiteral; z.lit = byte; z.len = on ? 1u : 0u; };
+    auto span = [&](uint32_t input, uint32_t off, uint32_t len) { z.kind = kSpan; z.input = input; z.off = off; z.len = len; };
+    const uint32_t b1 = 3u + 2u * nm, b2 = b1 + 4u, b3 = b2 + 2u * nb;
+    if (s == 0) lit1('@', true);
+    else if (s == 1) span(0, head_off, p.name_len);
+    else if (s == 2) lit1(p.msep, nm != 0);
+    else if (s < b1) {
+        const uint32_t i = (s - 3u) >> 1;
+        if (((s - 3u) & 1u) == 0) lit1('+', i != 0); else span(msegs[i].input, msegs[i].off, msegs[i].len);
+    } else if (s == b1) lit1(' ', true);
+    else if (s == b1 + 1u) { z.kind = kNumber; z.len = p.kind != 1 ? number_len : 0u; }
+    else if (s == b1 + 2u) span(0, head_off + p.copy_off, p.kind != 0 ? p.copy_len : 0u);
+    else if (s == b1 + 3u) lit1(p.tail, p.kind != 0 && p.tail != 0);
+    else if (s < b3) {
+        const uint32_t i = (s - b2) >> 1;
+        if (((s - b2) & 1u) == 0) lit1('+', i != 0); else span(bsegs[i].input, bsegs[i].off, bsegs[i].len);
+    } else if (s == b3) lit1('\n', true);
+    else if (s == b3 + 1u) span(bases.input, bases.off, bases.len);
+    else if (s == b3 + 2u) { z.kind = kLiteral; z.lit = (uint32_t)'\n' | ((uint32_t)'+' << 8) | ((uint32_t)'\n' << 16); z.len = 3; }
+    else if (s == b3 + 3u) span(quals.input, quals.off, quals.len);
+    else if (s == b3 + 4u) lit1('\n', true);
+    return z;
+}
+
 // Length of that record from sums alone (the placement kernel sizes every record of a chunk before any is written):
 // `digits` of the read number, `bl` / `ml` bases in the nb sample / nm molecular barcode segments, `seg` bases in the
 // file's own segment.  Checked against the sizing sink in the CPU tests.

@@ -1,0 +1,7 @@
+cp fqtk_amd/lib/libfqtk_match.so /tmp/prod.so
+for w in 8 5 4; do
+cp fqtk_amd/lib/variants/fmt$w/libfqtk_match.so fqtk_amd/lib/libfqtk_match.so
+python tools/scope_bench.py --skip-b --templates 16000000 --threads 16 --repeat-block --extra "--compression-level 0" 2>/dev/null | tail -1 | python -c "
+import json,sys; d=json.loads(sys.stdin.read())['E']; print('level 0, waves $w: E', d['seconds'], d['M_templates_per_s'], d['M_templates_per_s_steady'], d['stages'][0])"
+done
+cp /tmp/prod.so fqtk_amd/lib/libfqtk_match.so
