@@ -1146,14 +1146,14 @@ int build_memo(fqtk_matcher *m, const std::vector<std::vector<uint8_t>> &enc) {
                        owner[p] < 0 ? 0u : ents[(size_t)owner[p]].val, spill[p] != 0);
         break;
     }
-    // hot table for LDS: 0-mismatch entries, two-choice without eviction (it is only a cache: an
-    // entry that finds both of its slots taken is simply served by the global table)
+    // hot table for LDS: 0-mismatch entries in the low bits of their FIRST slot's number (it is only a cache: an entry
+    // that finds the slot taken -- low sample index first -- is simply served by the global table)
     {
         const uint32_t slot_bytes = (uint32_t)wps * 4;
         uint32_t hot_slots = fqtk::kHotBytes / slot_bytes;
         uint64_t n_hot = 0;
         for (const Entry &e : ents) n_hot += ((e.val >> 16) & 0xFFu) == 0;
-        while (hot_slots > 64 && hot_slots / 2 >= n_hot * 2) hot_slots >>= 1;
+        while (hot_slots > 64 && hot_slots / 2 >= n_hot * 8) hot_slots >>= 1;   // single choice: an eighth full at most while LDS allows
         if (n_hot) {
             const uint32_t hmask = hot_slots - 1;
             std::vector<uint32_t> hot((size_t)hot_slots * wps, 0u);
@@ -1167,12 +1167,10 @@ int build_memo(fqtk_matcher *m, const std::vector<std::vector<uint8_t>> &enc) {
             for (size_t i : order) {
                 uint32_t a1, a2;
                 slots_of(i, mask, a1, a2);
-                for (uint32_t a : {a1 & hmask, a2 & hmask}) {
-                    if (used[a]) continue;
-                    used[a] = 1;
-                    write_slot(&hot[(size_t)a * wps], kw, keys[i].data(), ents[i].val, false);
-                    break;
-                }
+                const uint32_t a = a1 & hmask;
+                if (used[a]) continue;
+                used[a] = 1;
+                write_slot(&hot[(size_t)a * wps], kw, keys[i].data(), ents[i].val, false);
             }
             HIP_TRY(hipMalloc(reinterpret_cast<void **>(&m->d_hot), hot.size() * sizeof(uint32_t)));
             HIP_TRY(hipMemcpy(m->d_hot, hot.data(), hot.size() * sizeof(uint32_t), hipMemcpyHostToDevice));

@@ -84,18 +84,25 @@ FQTK_HD inline uint32_t memo_limb_sum2(uint32_t lo, uint32_t hi, uint32_t ext, u
     const uint32_t f = ext2 >> 24;
     return mul24(a, 0xD6E8FFu) + mul24(b, 0x2C1B3Du) + mul24(c, 0x7F4A7Du) + mul24(d, 0x51ED27u) + mul24(e, 0xC4CEB9u) + mul24(f, 0x3243F7u);
 }
-FQTK_HD inline void memo_hash2(uint32_t lo, uint32_t hi, uint32_t ext, uint32_t ext2, uint32_t mask,
-                               uint32_t &s1, uint32_t &s2) {
+FQTK_HD inline uint32_t memo_slot1(uint32_t lo, uint32_t hi, uint32_t ext, uint32_t ext2, uint32_t mask) {
     uint32_t h = memo_limb_sum(lo, hi, ext, ext2);
     h ^= h >> 15;
     h = mul24(h, 0x2C1B3Du) + (h >> 9);
     h ^= h >> 13;
-    s1 = h & mask;
+    return h & mask;
+}
+// (the kernels work this one out only in the rare wave that needs a second probe)
+FQTK_HD inline uint32_t memo_slot2(uint32_t lo, uint32_t hi, uint32_t ext, uint32_t ext2, uint32_t mask) {
     uint32_t g = memo_limb_sum2(lo, hi, ext, ext2);
     g ^= g >> 14;
     g = mul24(g, 0x9E3779u) + (g >> 10);
     g ^= g >> 12;
-    s2 = g & mask;
+    return g & mask;
+}
+FQTK_HD inline void memo_hash2(uint32_t lo, uint32_t hi, uint32_t ext, uint32_t ext2, uint32_t mask,
+                               uint32_t &s1, uint32_t &s2) {
+    s1 = memo_slot1(lo, hi, ext, ext2, mask);
+    s2 = memo_slot2(lo, hi, ext, ext2, mask);
 }
 
 // ---- direct-indexed memo for short barcodes (table form, L <= kDirectMaxLen) ----------------------------

@@ -492,16 +492,23 @@ void memo_kernel(const MemoParams Q) {
             // ======== hash-table form ======================================================================================
             // ---- probe: both candidate slots of every read are known up front.  Empty slots carry
             //      key = ~0 (no real key has a nibble's top bit set) and val = None. ---------------------
-            uint32_t s1[R], s2[R];
+            // The FIRST slot only: the second comes from an independent hash of its own (memo_slot2) that only the rare wave
+            // with a spilled key works out, and the LDS hot table is single-choice (the few exact-match entries that lose
+            // their slot to another are served by the global table): a dozen VALU operations and one LDS read fewer per read.
+            uint32_t s1[R];
 #pragma unroll
             for (int r = 0; r < R; ++r)
-                memo_hash2(key[r][0], KW >= 2 ? key[r][1] : 0u, KW >= 3 ? key[r][2] : 0u, KW >= 4 ? key[r][3] : 0u, Q.mask, s1[r], s2[r]);
+                s1[r] = memo_slot1(key[r][0], KW >= 2 ? key[r][1] : 0u, KW >= 3 ? key[r][2] : 0u, KW >= 4 ? key[r][3] : 0u, Q.mask);
+            auto second_slot = [&](int r) {
+                const uint32_t s2 = memo_slot2(key[r][0], KW >= 2 ? key[r][1] : 0u, KW >= 3 ? key[r][2] : 0u, KW >= 4 ? key[r][3] : 0u, Q.mask);
+                return (ABL & 32) ? (s2 & 0xFFu) : ((ABL & 128) ? (s1[r] ^ 1u) : s2);
+            };
 #pragma unroll
             for (int r = 0; r < R; ++r) { hit[r] = false; res[r] = kMemoEmpty; }
             clk.mark(1);   // encode + hashes
-            uint32_t g1[R], g2[R];   // global-table slots (ABL 32: folded into a 4 KB corner = L1-resident)
+            uint32_t g1[R];   // global-table slots (ABL 32: folded into a 4 KB corner = L1-resident)
 #pragma unroll
-            for (int r = 0; r < R; ++r) { g1[r] = (ABL & 32) ? (s1[r] & 0xFFu) : s1[r]; g2[r] = (ABL & 32) ? (s2[r] & 0xFFu) : ((ABL & 128) ? (s1[r] ^ 1u) : s2[r]); }
+            for (int r = 0; r < R; ++r) g1[r] = (ABL & 32) ? (s1[r] & 0xFFu) : s1[r];
             if constexpr (KW >= 2) {
                 // A slot by key width (MemoParams::slots): k = the key quad (KW 2 / 3: the whole 16-byte slot), m = the
                 // second quad of a four-word key's 32-byte slot.  Global slots are addressed as a 32-bit byte offset from
@@ -515,30 +522,25 @@ void memo_kernel(const MemoParams Q) {
                 const uint8_t *gbase = reinterpret_cast<const uint8_t *>(Q.slots);
                 if (Q.hot_mask && !(ABL & 16)) {   // wave-uniform: the LDS hot table (0-mismatch entries), same slot format
                     const uint8_t *hbase = reinterpret_cast<const uint8_t *>(lds_hot);
-                    u32x4v h1[R], h2[R], n1[R], n2[R];
+                    u32x4v h1[R], n1[R];
 #pragma unroll
                     for (int r = 0; r < R; ++r) {
                         h1[r] = *reinterpret_cast<const u32x4v *>(hbase + ((s1[r] & Q.hot_mask) << kSlotShift));
-                        h2[r] = *reinterpret_cast<const u32x4v *>(hbase + ((s2[r] & Q.hot_mask) << kSlotShift));
-                        if constexpr (KW == 4) {
-                            n1[r] = *reinterpret_cast<const u32x4v *>(hbase + ((s1[r] & Q.hot_mask) << kSlotShift) + 16);
-                            n2[r] = *reinterpret_cast<const u32x4v *>(hbase + ((s2[r] & Q.hot_mask) << kSlotShift) + 16);
-                        } else { n1[r] = h1[r]; n2[r] = h2[r]; }
+                        if constexpr (KW == 4) n1[r] = *reinterpret_cast<const u32x4v *>(hbase + ((s1[r] & Q.hot_mask) << kSlotShift) + 16);
+                        else n1[r] = h1[r];
                     }
                     arrived4(h1);
-                    arrived4(h2);
-                    if constexpr (KW == 4) { arrived4(n1); arrived4(n2); }
+                    if constexpr (KW == 4) arrived4(n1);
 #pragma unroll
                     for (int r = 0; r < R; ++r) {
-                        const bool m1 = slot_hit(h1[r], r), m2 = slot_hit(h2[r], r);
-                        hit[r] = m1 | m2;
-                        res[r] = m1 ? slot_val(h1[r], n1[r]) : (m2 ? slot_val(h2[r], n2[r]) : kMemoEmpty);
+                        hit[r] = slot_hit(h1[r], r);
+                        res[r] = hit[r] ? slot_val(h1[r], n1[r]) : kMemoEmpty;
                     }
                 }
                 clk.mark(2);   // LDS hot table
                 if constexpr (ABL & 1) {
 #pragma unroll
-                    for (int r = 0; r < R; ++r) res[r] = (s1[r] ^ s2[r]) | 0xFFFFu;
+                    for (int r = 0; r < R; ++r) res[r] = s1[r] | 0xFFFFu;
                 } else {
                     // Global table, two-choice placement with a per-slot SPILL bit: the builder keeps a key in
                     // its first slot whenever it can and marks a slot whose would-be owner lives in its second
@@ -564,7 +566,7 @@ void memo_kernel(const MemoParams Q) {
                     if (__ballot(any_again)) {   // wave-uniform
 #pragma unroll
                         for (int r = 0; r < R; ++r) {
-                            const uint32_t off = (again[r] ? g2[r] : 0u) << kSlotShift;
+                            const uint32_t off = (again[r] ? second_slot(r) : 0u) << kSlotShift;
                             e[r] = *reinterpret_cast<const u32x4v *>(gbase + off);
                             if constexpr (KW == 4) f[r] = *reinterpret_cast<const u32x4v *>(gbase + off + 16); else f[r] = e[r];
                         }
@@ -577,25 +579,20 @@ void memo_kernel(const MemoParams Q) {
                 }
             } else {
                 if (Q.hot_mask && !(ABL & 16)) {   // wave-uniform
-                    u32x2v h1[R], h2[R];
+                    u32x2v h1[R];
 #pragma unroll
-                    for (int r = 0; r < R; ++r) {
-                        h1[r] = reinterpret_cast<const u32x2v *>(lds_hot)[s1[r] & Q.hot_mask];
-                        h2[r] = reinterpret_cast<const u32x2v *>(lds_hot)[s2[r] & Q.hot_mask];
-                    }
+                    for (int r = 0; r < R; ++r) h1[r] = reinterpret_cast<const u32x2v *>(lds_hot)[s1[r] & Q.hot_mask];
                     arrived2(h1);
-                    arrived2(h2);
 #pragma unroll
                     for (int r = 0; r < R; ++r) {
-                        const bool m1 = h1[r].x == key[r][0], m2 = h2[r].x == key[r][0];
-                        hit[r] = m1 | m2;
-                        res[r] = m1 ? h1[r].y : (m2 ? h2[r].y : kMemoEmpty);
+                        hit[r] = h1[r].x == key[r][0];
+                        res[r] = hit[r] ? h1[r].y : kMemoEmpty;
                     }
                 }
                 clk.mark(2);   // LDS hot table
                 if constexpr (ABL & 1) {
 #pragma unroll
-                    for (int r = 0; r < R; ++r) res[r] = (s1[r] ^ s2[r]) | 0xFFFFu;
+                    for (int r = 0; r < R; ++r) res[r] = s1[r] | 0xFFFFu;
                 } else {
                     bool again[R], any_again = false;
                     u32x2v e[R];
@@ -611,7 +608,7 @@ void memo_kernel(const MemoParams Q) {
                     }
                     if (__ballot(any_again)) {   // wave-uniform
 #pragma unroll
-                        for (int r = 0; r < R; ++r) e[r] = reinterpret_cast<const u32x2v *>(Q.slots)[again[r] ? g2[r] : 0u];
+                        for (int r = 0; r < R; ++r) e[r] = reinterpret_cast<const u32x2v *>(Q.slots)[again[r] ? second_slot(r) : 0u];
                         arrived2(e);
 #pragma unroll
                         for (int r = 0; r < R; ++r)
