@@ -23,6 +23,14 @@ class fqtk_bgzf_block(C.Structure):   # include/fqtk_bgzf.h
 FQTK_BGZF_MAX_IN, FQTK_BGZF_OUT_STRIDE, FQTK_BGZF_SLOTS = 65280, 65536, 4
 
 
+class fqtk_inflate_member(C.Structure):   # include/fqtk_inflate.h
+    _fields_ = [("payload_off", C.c_uint64), ("out_off", C.c_uint64), ("payload_len", C.c_uint32), ("isize", C.c_uint32),
+                ("crc", C.c_uint32), ("reserved", C.c_uint32)]
+
+
+FQTK_INFLATE_SLOTS, FQTK_INFLATE_MAX_ISIZE, FQTK_INFLATE_ERR_CRC = 4, 65536, 10
+
+
 # include/fqtk_demux.h
 class fqtk_demux_segment(C.Structure):
     _fields_ = [("offset", C.c_uint32), ("length", C.c_int32), ("kind", C.c_char)]
@@ -111,6 +119,12 @@ SIGNATURES = [
     ("fqtk_bgzf_destroy", None, [C.c_void_p]),
     ("fqtk_bgzf_deflate_enqueue", C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_uint32, C.c_void_p]),
     ("fqtk_bgzf_wait", C.c_int, [C.c_void_p, C.c_int]),
+    # include/fqtk_inflate.h
+    ("fqtk_inflate_last_error", C.c_char_p, []),
+    ("fqtk_inflate_create", C.c_int, [C.c_int, C.POINTER(C.c_void_p)]),
+    ("fqtk_inflate_destroy", None, [C.c_void_p]),
+    ("fqtk_inflate_enqueue", C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]),
+    ("fqtk_inflate_wait", C.c_int, [C.c_void_p, C.c_int]),
     # include/fqtk_demux.h
     ("fqtk_demuxer_create", C.c_int, [C.c_void_p, C.POINTER(fqtk_demux_config), C.POINTER(C.c_void_p)]),
     ("fqtk_demuxer_destroy", None, [C.c_void_p]),

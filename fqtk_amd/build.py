@@ -21,7 +21,7 @@ ARCH = "gfx950"
 
 # name -> (sources, extra flags)
 TARGETS = {
-    "libfqtk_match.so": (["fqtk_match.hip", "fqtk_bgzf.hip", "fqtk_demux.hip"], []),
+    "libfqtk_match.so": (["fqtk_match.hip", "fqtk_bgzf.hip", "fqtk_inflate.hip", "fqtk_demux.hip"], []),
     "libfqtk_synth.so": (["synth.hip"], []),
 }
 

@@ -1,0 +1,521 @@
+// bgzf_inflate.hpp -- DEFLATE decoder for BGZF input members, written for ONE 64-lane wavefront per member.
+//
+// SURVEY.md section 8(f) row 3 (input side).  The reference opens every input through a gz-aware reader
+// (/root/reference/src/bin/commands/demux.rs:844-849: fgoxide `Io` -> flate2) and inflates on the host; real FASTQs are
+// compressed, so the host's inflate rate bounds the whole run while PCIe carries four to five times the bytes it needs to.
+// BGZF members (RFC 1952 members of <= 64 KiB with the 'BC' extra field; what bgzip, htslib and fqtk itself write) are
+// independent DEFLATE streams: one wavefront takes one member, thousands are in flight.
+//
+// A DEFLATE stream is serial -- where a code starts is known only when the one before it has been decoded -- so one lane
+// per stream would leave 63 idle and a wave would crawl through its member at one dependent LDS look-up per symbol.  The wave
+// decodes SPECULATIVELY instead: lane i decodes the whole token (literal, or length + distance with their extra bits, or
+// end-of-block) that WOULD start at bit `base + i`, all 64 at once, one table look-up each; the true tokens are then the
+// chain 0 -> 0 + bits[0] -> ... walked with v_readlane on the scalar unit (~10 cycles a step, no memory), which also
+// gives the position of the next window.  The lanes on the chain hold real tokens: a wave prefix sum of their output
+// lengths places them, literal lanes store their byte, matches are copied by all 64 lanes together.  Codes longer than the
+// table's index bits (rare symbols) are resolved canonically (puff-style: lengths' limits compared side by side, no
+// second-level tables to build) only when the chain reaches one.
+//
+// The output goes straight to HBM: a match reads what earlier lanes wrote, which the CU's L1 / the L2 serve; a
+// workgroup-scope fence is placed only where a match reaches into bytes whose stores may still be in flight.
+//
+// Parity: zlib inflates the same members to the same bytes (tests/test_bgzf_inflate.py: every level and strategy, stored /
+// fixed / dynamic blocks, corrupted streams, CRC and ISIZE mismatches).  Written from RFC 1951 / RFC 1952.
+//
+// One source for two builds: the device (fqtk_bgzf.hip instantiates inflate_member<DeviceWave>) and the CPU test-suite,
+// where host/wave_emu.hpp runs the SAME function as 64 cooperatively scheduled fibers whose cross-lane operations
+// (ballot, readlane, scan, barrier) are real exchanges -- slow (a few MB/s) but the decoder's logic, not a restatement of it.
+#pragma once
+#include <stddef.h>
+#include <stdint.h>
+
+#if defined(__HIPCC__)
+#define FQTK_HD __host__ __device__
+#else
+#ifndef FQTK_HD
+#define FQTK_HD
+#endif
+#endif
+
+#if defined(__clang__)
+#define FQTK_UNROLL _Pragma("unroll")
+#else
+#define FQTK_UNROLL
+#endif
+
+namespace fqtk {
+namespace inflate {
+
+constexpr int kLitBits = 10, kDistBits = 8;
+constexpr uint32_t kRingWords = 256;   // 1 KiB of the compressed stream in LDS (dword d of the stream at ring[d & 255])
+
+// status of a member (written to status[member]; 0 = fine)
+enum : uint32_t {
+    kOk = 0,
+    kErrBlockType = 1,      // reserved block type 3
+    kErrStoredLen = 2,      // LEN != ~NLEN
+    kErrCodeLengths = 3,    // bad code-length code / repeat without a previous length / repeat past the end / no EOB code
+    kErrOverSubscribed = 4, // a Huffman code that is over-subscribed, or incomplete where RFC 1951 / zlib do not allow it
+    kErrBadCode = 5,        // a bit pattern that is no code of the block's Huffman code (or symbols 286, 287, 30, 31)
+    kErrDistance = 6,       // distance reaches before the start of the member's output
+    kErrOutput = 7,         // more output than ISIZE says
+    kErrTruncated = 8,      // the stream runs past the member's payload
+    kErrLength = 9,         // fewer bytes than ISIZE says
+    kErrCrc = 10,           // CRC-32 of the output differs from the trailer's (set by the check kernel)
+    kErrHeader = 11,        // not a gzip member / unsupported flags (set by whoever parses the header)
+};
+
+FQTK_HD inline uint32_t brev32(uint32_t x) {
+#if defined(__clang__)
+    return __builtin_bitreverse32(x);
+#else
+    x = ((x >> 1) & 0x55555555u) | ((x & 0x55555555u) << 1);
+    x = ((x >> 2) & 0x33333333u) | ((x & 0x33333333u) << 2);
+    x = ((x >> 4) & 0x0F0F0F0Fu) | ((x & 0x0F0F0F0Fu) << 4);
+    return __builtin_bswap32(x);
+#endif
+}
+
+// table entry: bits 0-3 code length (0: no such code), 4-7 extra bits, 8-9 kind, 16-31 literal byte / base value
+enum : uint32_t { kLit = 0, kLen = 1, kEob = 2, kLong = 3 };
+FQTK_HD inline uint32_t make_entry(uint32_t codelen, uint32_t extra, uint32_t kind, uint32_t value) {
+    return codelen | (extra << 4) | (kind << 8) | (value << 16);
+}
+// literal/length symbol -> entry (RFC 1951 3.2.5, computed: no constant tables on the device); 0 for 286, 287
+FQTK_HD inline uint32_t litlen_entry(uint32_t sym, uint32_t codelen) {
+    if (sym < 256u) return make_entry(codelen, 0, kLit, sym);
+    if (sym == 256u) return make_entry(codelen, 0, kEob, 0);
+    if (sym >= 286u) return 0u;
+    const uint32_t i = sym - 257u;
+    if (i < 8u) return make_entry(codelen, 0, kLen, 3u + i);
+    if (i == 28u) return make_entry(codelen, 0, kLen, 258u);
+    const uint32_t e = (i >> 2) - 1u;
+    return make_entry(codelen, e, kLen, 3u + ((4u + (i & 3u)) << e));
+}
+FQTK_HD inline uint32_t dist_entry(uint32_t sym, uint32_t codelen) {
+    if (sym >= 30u) return 0u;
+    if (sym < 4u) return make_entry(codelen, 0, kLit, 1u + sym);
+    const uint32_t e = (sym >> 1) - 1u;
+    return make_entry(codelen, e, kLit, 1u + ((2u + (sym & 1u)) << e));
+}
+
+// A canonical Huffman code (RFC 1951 3.2.2) the way the slow path and the table builder read it.  Code words are taken
+// left-aligned in 15 bits (first bit of the code = bit 14): codes of increasing length are increasing numbers, so the
+// length of the code in front of `rev` is 1 + the number of lengths whose (left-aligned, exclusive) limit rev has reached.
+struct Canon {
+    uint32_t limit[16];    // [l]: (first code of length l + number of codes of length l) << (15 - l); limit[0] = 0
+    uint32_t first[16];    // [l]: first code of length l, left-aligned
+    uint16_t offs[16];     // [l]: index in perm of the first symbol of length l
+    uint16_t cnt[16];
+};
+
+// Everything a member's wavefront shares (LDS on the device: ~8.5 KiB, 16 wavefronts per CU).
+struct Shared {
+    uint32_t ring[kRingWords];
+    uint32_t lit[1u << kLitBits];
+    uint32_t dist[1u << kDistBits];
+    Canon cl, cd;              // literal/length code, distance code
+    uint16_t perm_l[288 + 32]; // symbols ordered by (code length, symbol)
+    uint16_t perm_d[32];
+    uint8_t lens[320 + 8];     // the block's code lengths: hlit literal/length ones, then hdist distance ones
+    uint32_t cl_tab[128];      // the code-length code: 7 index bits -> symbol << 16 | length (0: no such code)
+    uint32_t run[16];          // scratch of the builders
+};
+
+struct MemberArgs {
+    const uint32_t *in_words;  // 4-byte aligned address at or before the first byte of the DEFLATE payload
+    uint32_t first_bit;        // bit offset of the payload from in_words (0, 8, 16 or 24)
+    uint32_t payload_bits;     // length of the payload in bits (the trailer follows)
+    uint32_t readable_words;   // dwords that may be read from in_words (the caller's buffer ends there; past it reads as 0)
+    uint8_t *out;              // isize bytes
+    uint32_t isize;            // ISIZE of the member's trailer
+};
+
+// ---- the wave -------------------------------------------------------------------------------------------------------
+// W provides: lane() 0..63; ballot(bool) -> uint64; readlane(uint32 v, uint32 l) (l the same in all lanes);
+// uniform(uint32 v) (a value known to be the same in all lanes: the device keeps it in a scalar register);
+// scan_incl(uint32 v) inclusive prefix sum over the lanes; barrier() (LDS written before is visible to
+// all lanes after); fence_global() (global stores issued by any lane before are visible to the loads of all lanes after);
+// atomic_inc_lds(uint16*/uint32*).
+
+template <class W>
+FQTK_HD inline uint32_t peek32(W &w, const Shared &S, uint32_t bit) {   // 32 bits of the stream from `bit`
+    const uint32_t d = bit >> 5, s = bit & 31u;
+    const uint64_t v = (uint64_t)S.ring[d & (kRingWords - 1u)] | ((uint64_t)S.ring[(d + 1u) & (kRingWords - 1u)] << 32);
+    return (uint32_t)(v >> s);
+}
+
+// The ring: dwords [.., filled) of the stream are in LDS, every lane holds dword filled + lane in `pref` (requested one
+// refill ahead, so its latency hides behind ~250 bytes of decoding).
+template <class W>
+struct Ring {
+    uint32_t filled;   // uniform
+    uint32_t pref;     // per lane
+    FQTK_HD inline uint32_t load(W &w, const MemberArgs &a, uint32_t d) const { return d < a.readable_words ? a.in_words[d] : 0u; }
+    FQTK_HD inline void reset(W &w, const MemberArgs &a, uint32_t bit) {
+        filled = (bit >> 5) & ~63u;
+        pref = load(w, a, filled + w.lane());
+    }
+    // after this, dwords up to (bit >> 5) + 7 are in the ring
+    FQTK_HD inline void ensure(W &w, Shared &S, const MemberArgs &a, uint32_t bit) {
+        const uint32_t need = (bit >> 5) + 8u;
+        if (filled >= need) return;
+        w.barrier();   // (reads of the ring issued before the overwrite)
+        while (filled < need) {
+            S.ring[(filled + w.lane()) & (kRingWords - 1u)] = pref;
+            filled += 64u;
+            pref = load(w, a, filled + w.lane());
+        }
+        w.barrier();
+    }
+};
+
+// Builds the canonical description of a code from lens[0..n) and its fast table (2^P entries).  Returns an error code.
+template <class W, bool kLitLen>
+FQTK_HD inline uint32_t build_code(W &w, Shared &S, const uint8_t *lens, uint32_t n) {
+    constexpr uint32_t P = kLitLen ? kLitBits : kDistBits;
+    Canon &C = kLitLen ? S.cl : S.cd;
+    uint16_t *perm = kLitLen ? S.perm_l : S.perm_d;
+    uint32_t *tab = kLitLen ? S.lit : S.dist;
+    const uint32_t lane = w.lane();
+    // (1) how many codes of each length, and each symbol's rank among the symbols of its length (in symbol order)
+    uint32_t total[16];
+FQTK_UNROLL
+    for (int l = 0; l < 16; ++l) total[l] = 0;
+    uint32_t my_rank[5], my_len[5];
+FQTK_UNROLL
+    for (uint32_t p = 0; p < 5u; ++p) {
+        const uint32_t s = p * 64u + lane;
+        const uint32_t len = (kLitLen || p == 0u) && s < n ? (uint32_t)lens[s] : 0u;
+        my_len[p] = len;
+        my_rank[p] = 0;
+        if (!kLitLen && p > 0u) continue;
+FQTK_UNROLL
+        for (uint32_t l = 1; l < 16u; ++l) {
+            const uint64_t m = w.ballot(len == l);
+            if (len == l) my_rank[p] = total[l] + (uint32_t)__builtin_popcountll(m & ((1ull << lane) - 1ull));
+            total[l] += (uint32_t)__builtin_popcountll(m);
+        }
+    }
+    // (2) the canonical numbers (the same in every lane)
+    uint32_t first = 0, offs = 0, used = 0, maxlen = 0;
+    int32_t left = 1;
+    bool over = false;
+    uint32_t my_offs[5];
+FQTK_UNROLL
+    for (uint32_t p = 0; p < 5u; ++p) my_offs[p] = 0;
+    if (lane == 0u) { C.limit[0] = 0; C.first[0] = 0; C.offs[0] = 0; C.cnt[0] = 0; }
+FQTK_UNROLL
+    for (uint32_t l = 1; l < 16u; ++l) {
+        const uint32_t c = total[l];
+        left = (left << 1) - (int32_t)c;
+        if (left < 0) over = true;
+        if (c) maxlen = l;
+        used += c;
+        if (lane == 0u) {
+            C.first[l] = first << (15u - l);
+            C.limit[l] = (first + c) << (15u - l);
+            C.offs[l] = (uint16_t)offs;
+            C.cnt[l] = (uint16_t)c;
+        }
+FQTK_UNROLL
+        for (uint32_t p = 0; p < 5u; ++p)
+            if (my_len[p] == l) my_offs[p] = offs;
+        offs += c;
+        first = (first + c) << 1;
+    }
+    if (over) return kErrOverSubscribed;
+    // incomplete codes: legal only as "at most one code, of one bit" (a block with one distance code, or none)
+    if (left > 0 && !(used <= 1u && maxlen <= 1u)) return kErrOverSubscribed;
+FQTK_UNROLL
+    for (uint32_t p = 0; p < 5u; ++p)
+        if (my_len[p]) perm[my_offs[p] + my_rank[p]] = (uint16_t)(p * 64u + lane);
+    w.barrier();
+    // (3) the fast table, entry by entry: what code stands in front of these P bits?
+    uint32_t lim[16];
+FQTK_UNROLL
+    for (int l = 1; l < 16; ++l) lim[l] = w.uniform(C.limit[l]);
+    for (uint32_t idx = lane; idx < (1u << P); idx += 64u) {
+        const uint32_t rev = brev32(idx) >> 17;   // the P index bits, first bit at bit 14; the bits behind them: 0
+        uint32_t len = 1;
+FQTK_UNROLL
+        for (int l = 1; l < 15; ++l) len += rev >= lim[l] ? 1u : 0u;
+        uint32_t e;
+        if (rev >= lim[15]) {
+            // past the last code: no code starts with these bits -- unless a longer code does (bits behind the index are 0 here,
+            // so a code of more than P bits whose first P bits are these compares below its limit; reaching here means none does)
+            e = 0u;
+        } else if (len > P) {
+            e = make_entry(0, 0, kLong, 0) | 1u;   // code length unknown yet (non-zero marks "a code exists")
+        } else {
+            const uint32_t sym = perm[C.offs[len] + ((rev - C.first[len]) >> (15u - len))];
+            e = kLitLen ? litlen_entry(sym, len) : dist_entry(sym, len);
+        }
+        tab[idx] = e;
+    }
+    w.barrier();
+    return kOk;
+}
+
+// The code in front of `rev` (15 stream bits, first bit at bit 14): symbol and length, canonically.  false: no such code.
+FQTK_HD inline bool canon_decode(const Canon &C, const uint16_t *perm, uint32_t rev, uint32_t *sym, uint32_t *len_out) {
+    uint32_t len = 1;
+FQTK_UNROLL
+    for (int l = 1; l < 15; ++l) len += rev >= C.limit[l] ? 1u : 0u;
+    if (rev >= C.limit[15]) return false;
+    *sym = perm[C.offs[len] + ((rev - C.first[len]) >> (15u - len))];
+    *len_out = len;
+    return true;
+}
+
+// One speculative token: what stands at the start of `bits` (64 stream bits)?
+struct Token {
+    uint32_t nbits;    // bits of the whole token
+    uint32_t outlen;   // bytes it produces
+    uint32_t value;    // literal byte, or the distance
+    uint32_t flags;    // kTok*
+};
+enum : uint32_t { kTokMatch = 1, kTokEob = 2, kTokSlow = 4, kTokBad = 8 };
+
+template <bool kSlow>
+FQTK_HD inline Token decode_token(const Shared &S, uint64_t bits) {
+    Token t;
+    t.nbits = 1; t.outlen = 0; t.value = 0; t.flags = 0;
+    uint32_t e = S.lit[(uint32_t)bits & ((1u << kLitBits) - 1u)];
+    if (((e >> 8) & 3u) == kLong) {
+        if (!kSlow) { t.flags = kTokSlow; return t; }
+        uint32_t sym, len;
+        if (!canon_decode(S.cl, S.perm_l, brev32((uint32_t)bits) >> 17, &sym, &len)) { t.flags = kTokBad; return t; }
+        e = litlen_entry(sym, len);
+    }
+    const uint32_t cl = e & 15u;
+    if (cl == 0u) { t.flags = kTokBad; return t; }
+    const uint32_t kind = (e >> 8) & 3u;
+    if (kind == kLit) { t.nbits = cl; t.outlen = 1; t.value = e >> 16; return t; }
+    if (kind == kEob) { t.nbits = cl; t.flags = kTokEob; return t; }
+    const uint32_t ne = (e >> 4) & 15u;
+    const uint32_t len = (e >> 16) + ((uint32_t)(bits >> cl) & ((1u << ne) - 1u));
+    const uint32_t u = cl + ne;   // <= 20
+    const uint32_t dbits = (uint32_t)(bits >> u);
+    uint32_t de = S.dist[dbits & ((1u << kDistBits) - 1u)];
+    if (((de >> 8) & 3u) == kLong) {
+        if (!kSlow) { t.flags = kTokSlow; return t; }
+        uint32_t sym, dl;
+        if (!canon_decode(S.cd, S.perm_d, brev32(dbits) >> 17, &sym, &dl)) { t.flags = kTokBad; return t; }
+        de = dist_entry(sym, dl);
+    }
+    const uint32_t dcl = de & 15u;
+    if (dcl == 0u) { t.flags = kTokBad; return t; }
+    const uint32_t dne = (de >> 4) & 15u;
+    t.value = (de >> 16) + ((uint32_t)(bits >> (u + dcl)) & ((1u << dne) - 1u));
+    t.nbits = u + dcl + dne;   // <= 48
+    t.outlen = len;
+    t.flags = kTokMatch;
+    return t;
+}
+
+// Decodes one member.  Returns its status (the same in all lanes); *out_bytes = bytes written.
+template <class W>
+FQTK_HD inline uint32_t inflate_member(W &w, Shared &S, const MemberArgs &a) {
+    const uint32_t lane = w.lane();
+    Ring<W> ring;
+    uint32_t bit = a.first_bit;                    // uniform: next unread bit of the stream
+    const uint32_t end_bit = a.first_bit + a.payload_bits;
+    uint32_t out_pos = 0;                          // uniform
+    uint32_t safe = 0;                             // output below this is visible to every lane's loads
+    ring.reset(w, a, bit);
+    for (;;) {
+        // ---- block header (RFC 1951 3.2.3): the same work in every lane
+        ring.ensure(w, S, a, bit);
+        const uint32_t h = w.uniform(peek32(w, S, bit));
+        const uint32_t final_block = h & 1u, type = (h >> 1) & 3u;
+        bit += 3u;
+        if (type == 3u) return kErrBlockType;
+        if (type == 0u) {
+            bit = (bit + 7u) & ~7u;
+            ring.ensure(w, S, a, bit);
+            const uint32_t ll = w.uniform(peek32(w, S, bit));
+            const uint32_t len = ll & 0xFFFFu, nlen = ll >> 16;
+            if ((len ^ 0xFFFFu) != nlen) return kErrStoredLen;
+            bit += 32u;
+            if (bit + 8u * len > end_bit) return kErrTruncated;
+            if (out_pos + len > a.isize) return kErrOutput;
+            const uint8_t *src = reinterpret_cast<const uint8_t *>(a.in_words) + (bit >> 3);
+            for (uint32_t k = lane; k < len; k += 64u) a.out[out_pos + k] = src[k];
+            out_pos += len;
+            bit += 8u * len;
+            ring.reset(w, a, bit);
+        } else {
+            uint32_t hlit, hdist;
+            if (type == 1u) {
+                hlit = 288u; hdist = 32u;
+                for (uint32_t s = lane; s < 320u; s += 64u) S.lens[s] = (uint8_t)(s < 144u ? 8u : s < 256u ? 9u : s < 280u ? 7u : s < 288u ? 8u : 5u);
+                w.barrier();
+            } else {
+                ring.ensure(w, S, a, bit);
+                const uint32_t hh = w.uniform(peek32(w, S, bit));
+                hlit = (hh & 31u) + 257u; hdist = ((hh >> 5) & 31u) + 1u;
+                const uint32_t hclen = ((hh >> 10) & 15u) + 4u;
+                bit += 14u;
+                if (hlit > 286u || hdist > 30u) return kErrCodeLengths;
+                // the code-length code's 19 lengths: lane k takes the k-th (3 bits each, in the order of RFC 1951 3.2.7)
+                ring.ensure(w, S, a, bit + 64u);
+                uint32_t my_cl_len = 0;   // lane s: length of code-length symbol s
+                // position of symbol s in the transmitted order 16 17 18 0 8 7 9 6 10 5 11 4 12 3 13 2 14 1 15
+                uint32_t pos_of = 19u;
+                if (lane < 19u) {
+                    const uint32_t s = lane;
+                    if (s >= 16u) pos_of = s - 16u;
+                    else if (s == 0u) pos_of = 3u;
+                    else if (s >= 8u) pos_of = 4u + 2u * (s - 8u);          // 8 -> 4, 9 -> 6, 10 -> 8, ... 15 -> 18
+                    else pos_of = 5u + 2u * (7u - s);                      // 7 -> 5, 6 -> 7, ... 1 -> 17
+                }
+                if (pos_of < hclen) my_cl_len = peek32(w, S, bit + 3u * pos_of) & 7u;
+                bit += 3u * hclen;
+                // its canonical code (<= 7 bits, 19 symbols) and a 128-entry table, by the wave
+                uint32_t ctot[8];
+FQTK_UNROLL
+                for (int l = 0; l < 8; ++l) ctot[l] = 0;
+                uint32_t my_rank = 0;
+FQTK_UNROLL
+                for (uint32_t l = 1; l < 8u; ++l) {
+                    const uint64_t m = w.ballot(my_cl_len == l);
+                    if (my_cl_len == l) my_rank = (uint32_t)__builtin_popcountll(m & ((1ull << lane) - 1ull));
+                    ctot[l] = (uint32_t)__builtin_popcountll(m);
+                }
+                uint32_t code = 0, my_code = 0;
+                int32_t left = 1;
+                bool over = false;
+FQTK_UNROLL
+                for (uint32_t l = 1; l < 8u; ++l) {
+                    left = (left << 1) - (int32_t)ctot[l];
+                    if (left < 0) over = true;
+                    if (my_cl_len == l) my_code = code + my_rank;
+                    code = (code + ctot[l]) << 1;
+                }
+                if (over) return kErrCodeLengths;
+                S.cl_tab[lane] = 0u;
+                S.cl_tab[lane + 64u] = 0u;
+                w.barrier();
+                if (my_cl_len) {
+                    const uint32_t rev = brev32(my_code) >> (32u - my_cl_len);
+                    for (uint32_t k = rev; k < 128u; k += 1u << my_cl_len) S.cl_tab[k] = (lane << 16) | my_cl_len;
+                }
+                w.barrier();
+                // the hlit + hdist code lengths, run-length coded: a serial chain, every lane follows it
+                const uint32_t total = hlit + hdist;
+                uint32_t i = 0, prev = 0;
+                while (i < total) {
+                    ring.ensure(w, S, a, bit);
+                    const uint32_t b = w.uniform(peek32(w, S, bit));
+                    const uint32_t e = w.uniform(S.cl_tab[b & 127u]);
+                    const uint32_t l = e & 0xFFu;
+                    if (l == 0u) return kErrCodeLengths;
+                    const uint32_t sym = e >> 16;
+                    bit += l;
+                    const uint32_t x = b >> l;
+                    if (sym < 16u) {
+                        if (lane == 0u) S.lens[i] = (uint8_t)sym;
+                        prev = sym;
+                        ++i;
+                    } else {
+                        uint32_t rep, v = 0;
+                        if (sym == 16u) {
+                            if (i == 0u) return kErrCodeLengths;
+                            v = prev; rep = 3u + (x & 3u); bit += 2u;
+                        } else if (sym == 17u) {
+                            rep = 3u + (x & 7u); bit += 3u;
+                        } else {
+                            rep = 11u + (x & 127u); bit += 7u;
+                        }
+                        if (i + rep > total) return kErrCodeLengths;
+                        for (uint32_t k = lane; k < rep; k += 64u) S.lens[i + k] = (uint8_t)v;
+                        prev = v;
+                        i += rep;
+                    }
+                }
+                w.barrier();
+                if (w.uniform(S.lens[256]) == 0u) return kErrCodeLengths;
+            }
+            if (bit > end_bit) return kErrTruncated;
+            uint32_t err = build_code<W, true>(w, S, S.lens, hlit);
+            if (err) return err;
+            err = build_code<W, false>(w, S, S.lens + hlit, hdist);
+            if (err) return err;
+
+            // ---- the block's tokens, 64 bit positions at a time
+            for (;;) {
+                ring.ensure(w, S, a, bit + 128u);
+                const uint32_t b = bit + lane, d = b >> 5, s = b & 31u;
+                const uint32_t d0 = S.ring[d & (kRingWords - 1u)], d1 = S.ring[(d + 1u) & (kRingWords - 1u)], d2 = S.ring[(d + 2u) & (kRingWords - 1u)];
+                const uint64_t lo = (uint64_t)d0 | ((uint64_t)d1 << 32);
+                const uint64_t bits = s ? (lo >> s) | ((uint64_t)d2 << (64u - s)) : lo;
+                Token t = decode_token<false>(S, bits);
+                uint64_t slow = w.ballot((t.flags & kTokSlow) != 0u);
+                // the chain of real tokens
+                uint32_t meta = t.nbits | (t.flags << 8);
+                uint64_t chain = 0;
+                uint32_t cur = 0;
+                bool eob = false;
+                uint32_t bad = 0;
+                while (cur < 64u) {
+                    uint32_t m = w.readlane(meta, cur);
+                    if ((m >> 8) & kTokSlow) {
+                        // a long code on the chain: every lane that met one resolves it now (rare)
+                        if ((slow >> lane) & 1ull) {
+                            t = decode_token<true>(S, bits);
+                            meta = t.nbits | (t.flags << 8);
+                        }
+                        slow = 0;
+                        m = w.readlane(meta, cur);
+                    }
+                    if ((m >> 8) & kTokBad) { bad = kErrBadCode; break; }
+                    chain |= 1ull << cur;
+                    cur += m & 0xFFu;
+                    if ((m >> 8) & kTokEob) { eob = true; break; }
+                }
+                if (bad) return bad;
+                const bool mine = ((chain >> lane) & 1ull) != 0ull;
+                const uint32_t my_out = mine ? t.outlen : 0u;
+                const uint32_t incl = w.scan_incl(my_out);
+                const uint32_t my_pos = out_pos + incl - my_out;
+                const uint32_t produced = w.readlane(incl, 63u);
+                if (out_pos + produced > a.isize) return kErrOutput;
+                if (mine && my_out == 1u && !(t.flags & kTokMatch)) a.out[my_pos] = (uint8_t)t.value;
+                uint64_t matches = w.ballot(mine && (t.flags & kTokMatch) != 0u);
+                while (matches) {
+                    const uint32_t l = (uint32_t)__builtin_ctzll(matches);
+                    matches &= matches - 1ull;
+                    const uint32_t len = w.readlane(t.outlen, l), dist = w.readlane(t.value, l), pos = w.readlane(my_pos, l);
+                    if (dist > pos) return kErrDistance;
+                    const uint32_t src = pos - dist;
+                    if (src + (len < dist ? len : dist) > safe) {
+                        w.fence_global();
+                        safe = pos;
+                    }
+                    if (dist >= len) {
+                        for (uint32_t k = lane; k < len; k += 64u) a.out[pos + k] = a.out[src + k];
+                    } else {
+                        // the source repeats with period dist: byte k is source byte k mod dist (k < 258, exact with 20 bits)
+                        const uint32_t inv = ((1u << 20) + dist - 1u) / dist;
+                        for (uint32_t k = lane; k < len; k += 64u) {
+                            const uint32_t q = (k * inv) >> 20;
+                            a.out[pos + k] = a.out[src + (k - q * dist)];
+                        }
+                    }
+                }
+                out_pos += produced;
+                bit += cur;
+                if (eob) break;
+                if (bit > end_bit) return kErrTruncated;
+            }
+        }
+        if (bit > end_bit) return kErrTruncated;
+        if (final_block) break;
+    }
+    if (out_pos != a.isize) return kErrLength;
+    return kOk;
+}
+
+}  // namespace inflate
+}  // namespace fqtk

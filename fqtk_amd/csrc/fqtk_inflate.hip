@@ -1,0 +1,228 @@
+// fqtk_inflate.hip -- device side and C ABI (include/fqtk_inflate.h) of the BGZF member decoder.
+// The algorithm lives in bgzf_inflate.hpp (one function, shared with the CPU test-suite's wave emulator); this file gives
+// it a real wavefront, adds the per-member check (CRC-32 of the text against the trailer, newline count) and the handle.
+#include <hip/hip_runtime.h>
+
+#include <new>
+#include <string>
+
+#include "../../include/fqtk_inflate.h"
+#include "../../include/fqtk_match.h"
+#include "bgzf_deflate.hpp"   // crc_gf_mul / crc_x_pow
+#include "bgzf_inflate.hpp"
+#include "inflate_internal.hpp"
+
+namespace fqtk {
+namespace inflate {
+
+// The W of bgzf_inflate.hpp on gfx950: a workgroup is ONE wavefront, so a barrier is an LDS wait and wave-uniform values
+// live in scalar registers (readfirstlane tells the compiler so).
+struct DeviceWave {
+    __device__ inline uint32_t lane() const { return threadIdx.x; }
+    __device__ inline uint64_t ballot(bool p) const { return __ballot(p); }
+    __device__ inline uint32_t readlane(uint32_t v, uint32_t l) const {
+        return (uint32_t)__builtin_amdgcn_readlane((int)v, (int)__builtin_amdgcn_readfirstlane((int)l));
+    }
+    __device__ inline uint32_t uniform(uint32_t v) const { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
+    // inclusive prefix sum over the 64 lanes in registers (DPP): within rows of 16 by shifts, then the rows' totals
+    // (row_bcast:15 into rows 1 and 3, row_bcast:31 into rows 2 and 3)
+    __device__ inline uint32_t scan_incl(uint32_t v) const {
+        v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xF, 0xF, false);   // row_shr:1
+        v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xF, 0xF, false);   // row_shr:2
+        v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xF, 0xF, false);   // row_shr:4
+        v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xF, 0xF, false);   // row_shr:8
+        v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xA, 0xF, false);   // row_bcast:15
+        v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xC, 0xF, false);   // row_bcast:31
+        return v;
+    }
+    __device__ inline void barrier() const { __syncthreads(); }
+    __device__ inline void fence_global() const { __threadfence_block(); }
+};
+
+__global__ __launch_bounds__(64) void inflate_kernel(const uint8_t *in, uint64_t in_len, const fqtk_inflate_member *members, uint32_t n,
+                                                      uint8_t *out, uint32_t *status) {
+    __shared__ Shared S;
+    const uint32_t j = blockIdx.x;
+    if (j >= n) return;
+    const fqtk_inflate_member m = members[j];
+    uint32_t st;
+    if (m.isize > FQTK_INFLATE_MAX_ISIZE || m.payload_off > in_len || (uint64_t)m.payload_len > in_len - m.payload_off) {
+        st = kErrTruncated;
+    } else {
+        MemberArgs a;
+        const uint64_t base = m.payload_off & ~(uint64_t)3;
+        a.in_words = reinterpret_cast<const uint32_t *>(in + base);
+        a.first_bit = 8u * (uint32_t)(m.payload_off & 3u);
+        a.payload_bits = 8u * m.payload_len;
+        const uint64_t words_left = (in_len - base) / 4u;   // whole dwords of the caller's buffer from `base` on
+        a.readable_words = words_left > 0x7FFFFFFFull ? 0x7FFFFFFFu : (uint32_t)words_left;
+        a.out = out + m.out_off;
+        a.isize = m.isize;
+        DeviceWave w;
+        st = inflate_member(w, S, a);
+    }
+    if (threadIdx.x == 0) status[j] = st;
+}
+
+// CRC-32 of every member's text (RFC 1952 8.) and its number of newlines, one workgroup of 256 lanes per member.  The
+// text is brought into LDS in whole, coalesced dwords (from the 4-byte boundary at or before its first byte), cut into 256
+// slices of kSlice bytes laid kSlice / 4 + 1 dwords apart (lane k's dword j sits in bank 3 k + j: no conflicts); lane k
+// takes slice k byte by byte, and the slices' values -- each multiplied by x^(8 * bytes behind it) -- XOR to the member's CRC
+// (bgzf_deflate.hpp: crc_gf_mul; the powers come from a table made once per handle).
+constexpr uint32_t kSlice = 264, kSliceWords = kSlice / 4, kSliceStride = kSliceWords + 1;   // 256 x 264 >= 3 + 65 536
+__global__ __launch_bounds__(256) void member_check_kernel(const fqtk_inflate_member *members, uint32_t n, const uint8_t *out,
+                                                           uint32_t *status, uint32_t *lines, const uint32_t *crc_pow) {
+    extern __shared__ uint32_t lds[];
+    uint32_t *tab = lds, *part = lds + 256, *cnt = lds + 260, *text = lds + 264;
+    const uint32_t j = blockIdx.x, lane = threadIdx.x;
+    if (j >= n) return;
+    {
+        uint32_t c = lane;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) c = (c & 1u) ? (c >> 1) ^ 0xEDB88320u : (c >> 1);
+        tab[lane] = c;
+    }
+    const fqtk_inflate_member m = members[j];
+    const uint32_t st = status[j];
+    uint32_t mine = 0, nl = 0;
+    const bool live = st == kOk && m.isize != 0u;
+    const uint32_t a = (uint32_t)(m.out_off & 3u), end = a + m.isize;   // the text is bytes [a, end) of the aligned stream
+    if (live) {
+        const uint32_t *src = reinterpret_cast<const uint32_t *>(out + (m.out_off & ~(uint64_t)3));
+        const uint32_t words = (end + 3u) / 4u;
+        for (uint32_t i = lane; i < words; i += 256u) text[(i / kSliceWords) * kSliceStride + i % kSliceWords] = src[i];
+    }
+    __syncthreads();
+    if (live) {
+        const uint32_t lo0 = lane * kSlice, lo = lo0 < a ? a : lo0;
+        if (lo < end && lo0 + kSlice > a) {
+            const uint32_t hi = lo0 + kSlice < end ? lo0 + kSlice : end;
+            const uint32_t *row = text + lane * kSliceStride;
+            uint32_t c = 0xFFFFFFFFu;
+            for (uint32_t q = lo; q < hi; ++q) {
+                const uint32_t b = (row[(q - lo0) >> 2] >> (8u * (q & 3u))) & 0xFFu;
+                nl += b == 0x0Au ? 1u : 0u;
+                c = tab[(c ^ b) & 0xFFu] ^ (c >> 8);
+            }
+            c = ~c;
+            if (hi < end) {   // whole slices between this one and the last, then the last one's bytes
+                const uint32_t last = (end - 1u) / kSlice;
+                c = bgzf::crc_gf_mul(c, crc_pow[last - 1u - lane]);
+                c = bgzf::crc_gf_mul(c, crc_pow[256u + (end - last * kSlice)]);
+            }
+            mine = c;
+        }
+    }
+    for (int d = 32; d >= 1; d >>= 1) { mine ^= __shfl_xor(mine, d); nl += __shfl_xor(nl, d); }
+    if ((lane & 63u) == 0u) { part[lane >> 6] = mine; cnt[lane >> 6] = nl; }
+    __syncthreads();
+    if (lane == 0) {
+        const uint32_t crc = part[0] ^ part[1] ^ part[2] ^ part[3];
+        lines[j] = cnt[0] + cnt[1] + cnt[2] + cnt[3];
+        if (st == kOk && crc != m.crc) status[j] = kErrCrc;
+    }
+}
+constexpr size_t kCheckLds = (264 + 256 * kSliceStride) * sizeof(uint32_t);
+
+void crc_pow_table(uint32_t *pow) {
+    for (uint32_t k = 0; k < 256u; ++k) pow[k] = bgzf::crc_x_pow(8u * kSlice * k);
+    for (uint32_t r = 0; r <= kSlice; ++r) pow[256u + r] = bgzf::crc_x_pow(8u * r);
+}
+
+hipError_t inflate_launch(hipStream_t stream, const uint8_t *in, uint64_t in_len, const fqtk_inflate_member *members, uint32_t n,
+                          uint8_t *out, uint32_t *status, uint32_t *lines, const uint32_t *crc_pow_dev) {
+    if (n == 0) return hipSuccess;
+    static const hipError_t prepared = hipFuncSetAttribute(reinterpret_cast<const void *>(member_check_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kCheckLds);
+    if (prepared != hipSuccess) return prepared;
+    hipLaunchKernelGGL(inflate_kernel, dim3(n), dim3(64), 0, stream, in, in_len, members, n, out, status);
+    hipLaunchKernelGGL(member_check_kernel, dim3(n), dim3(256), kCheckLds, stream, members, n, (const uint8_t *)out, status, lines, crc_pow_dev);
+    return hipGetLastError();
+}
+
+}  // namespace inflate
+}  // namespace fqtk
+
+namespace {
+thread_local std::string g_inflate_error;
+int ifail(int code, const std::string &msg) { g_inflate_error = msg; return code; }
+#define INFLATE_TRY(expr)                                                                    \
+    do {                                                                                     \
+        hipError_t _e = (expr);                                                              \
+        if (_e != hipSuccess) return ifail(FQTK_EHIP, std::string(#expr) + ": " + hipGetErrorString(_e)); \
+    } while (0)
+}  // namespace
+
+struct fqtk_inflate {
+    int device = 0;
+    hipStream_t streams[FQTK_INFLATE_SLOTS] = {};
+    uint32_t *d_pow = nullptr;
+    bool busy[FQTK_INFLATE_SLOTS] = {};
+};
+
+extern "C" {
+
+const char *fqtk_inflate_last_error(void) { return g_inflate_error.c_str(); }
+
+int fqtk_inflate_create(int device, fqtk_inflate **out) {
+    if (!out) return ifail(FQTK_EINVAL, "out is NULL");
+    *out = nullptr;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
+        (void)hipGetLastError();
+        return ifail(FQTK_ENODEV, "no HIP device available (the BGZF decoder has no CPU fallback)");
+    }
+    if (device < 0 || device >= ndev) return ifail(FQTK_ENODEV, "device index out of range");
+    INFLATE_TRY(hipSetDevice(device));
+    fqtk_inflate *z = new (std::nothrow) fqtk_inflate();
+    if (!z) return ifail(FQTK_ENOMEM, "out of host memory");
+    z->device = device;
+    uint32_t pow[fqtk::inflate::kCrcPowWords];
+    fqtk::inflate::crc_pow_table(pow);
+    if (hipMalloc(reinterpret_cast<void **>(&z->d_pow), sizeof pow) != hipSuccess ||
+        hipMemcpy(z->d_pow, pow, sizeof pow, hipMemcpyHostToDevice) != hipSuccess) {
+        fqtk_inflate_destroy(z);
+        return ifail(FQTK_EHIP, "cannot allocate the BGZF decoder's tables");
+    }
+    for (int s = 0; s < FQTK_INFLATE_SLOTS; ++s)
+        if (hipStreamCreateWithFlags(&z->streams[s], hipStreamNonBlocking) != hipSuccess) {
+            fqtk_inflate_destroy(z);
+            return ifail(FQTK_EHIP, "cannot create the BGZF decoder's streams");
+        }
+    *out = z;
+    return FQTK_OK;
+}
+
+void fqtk_inflate_destroy(fqtk_inflate *z) {
+    if (!z) return;
+    (void)hipSetDevice(z->device);
+    for (int s = 0; s < FQTK_INFLATE_SLOTS; ++s)
+        if (z->streams[s]) { (void)hipStreamSynchronize(z->streams[s]); (void)hipStreamDestroy(z->streams[s]); }
+    if (z->d_pow) (void)hipFree(z->d_pow);
+    delete z;
+}
+
+int fqtk_inflate_enqueue(fqtk_inflate *z, int slot, const uint8_t *in, uint64_t in_len, const fqtk_inflate_member *members,
+                         uint32_t n, uint8_t *out, uint32_t *status, uint32_t *lines) {
+    if (!z) return ifail(FQTK_EINVAL, "decoder is NULL");
+    if (slot < 0 || slot >= FQTK_INFLATE_SLOTS) return ifail(FQTK_EINVAL, "slot out of range");
+    if (z->busy[slot]) return ifail(FQTK_EINVAL, "slot is busy: call fqtk_inflate_wait() first");
+    if (n == 0) return FQTK_OK;
+    if (!in || !members || !out || !status || !lines) return ifail(FQTK_EINVAL, "in / members / out / status / lines is NULL");
+    if ((uintptr_t)in & 3u) return ifail(FQTK_EINVAL, "in must be 4-byte aligned");
+    INFLATE_TRY(hipSetDevice(z->device));
+    INFLATE_TRY(fqtk::inflate::inflate_launch(z->streams[slot], in, in_len, members, n, out, status, lines, z->d_pow));
+    z->busy[slot] = true;
+    return FQTK_OK;
+}
+
+int fqtk_inflate_wait(fqtk_inflate *z, int slot) {
+    if (!z) return ifail(FQTK_EINVAL, "decoder is NULL");
+    if (slot < 0 || slot >= FQTK_INFLATE_SLOTS) return ifail(FQTK_EINVAL, "slot out of range");
+    if (!z->busy[slot]) return FQTK_OK;
+    INFLATE_TRY(hipSetDevice(z->device));
+    INFLATE_TRY(hipStreamSynchronize(z->streams[slot]));
+    z->busy[slot] = false;
+    return FQTK_OK;
+}
+
+}  // extern "C"

@@ -21,6 +21,8 @@
 #include "../lds_memo_plan.hpp"
 #include "../direct_memo_plan.hpp"
 #include "../bgzf_deflate.hpp"
+#include "../bgzf_inflate.hpp"
+#include "wave_emu.hpp"
 #include "../record_format.hpp"
 
 using namespace fqtk_host;
@@ -368,6 +370,32 @@ uint32_t fqtk_host_bgzf_crc_emulated(const uint8_t *in, uint32_t n) {
     for (int l = 0; l < kLanes; ++l) phase_crc(S, l, n);
     phase_crc_fold(S);
     return S.crc;
+}
+
+// A raw DEFLATE stream decoded by the BGZF input kernel's own code (csrc/bgzf_inflate.hpp: inflate_member, one wavefront per
+// member), run on the CPU as 64 fibers (wave_emu.hpp).  `misalign` (0..3) puts the payload that many bytes behind a 4-byte
+// boundary, as a member's payload lies in a file.  Returns the member's status (fqtk::inflate::kOk = 0, kErr*).
+int fqtk_host_bgzf_inflate_emulated(const uint8_t *payload, uint32_t payload_len, uint32_t isize, uint8_t *out, uint32_t misalign) {
+    using namespace fqtk::inflate;
+    misalign &= 3u;
+    const uint32_t words = (misalign + payload_len + 3u) / 4u;
+    std::vector<uint32_t> buf(words + 1u, 0xA5A5A5A5u);   // what lies behind the payload is not zero
+    std::memcpy(reinterpret_cast<uint8_t *>(buf.data()) + misalign, payload, payload_len);
+    std::vector<uint8_t> mem(sizeof(Shared));
+    Shared &S = *reinterpret_cast<Shared *>(mem.data());
+    MemberArgs a;
+    a.in_words = buf.data();
+    a.first_bit = 8u * misalign;
+    a.payload_bits = 8u * payload_len;
+    a.readable_words = words;
+    a.out = out;
+    a.isize = isize;
+    uint32_t status[64];
+    fqtk_host::WaveEmu wave;
+    wave.run([&](fqtk_host::WaveEmu &w) { status[w.lane()] = inflate_member(w, S, a); });
+    for (int l = 1; l < 64; ++l)
+        if (status[l] != status[0]) return -1;   // the status is wave-uniform by construction
+    return (int)status[0];
 }
 
 // One output record the way the GPU record pipeline states it (csrc/record_format.hpp: header plan + pieces), built

@@ -1,0 +1,212 @@
+"""The BGZF member decoder (include/fqtk_inflate.h, csrc/bgzf_inflate.hpp).
+
+CPU part: the decoder's own function (inflate_member, written for one 64-lane wavefront) run as 64 fibers by
+csrc/host/wave_emu.hpp against zlib -- every level and strategy, stored / fixed / dynamic blocks, several blocks per
+member, codes longer than the fast tables' index bits, payloads at every byte alignment, corrupted streams (an error, or
+exactly zlib's bytes -- never a crash, never a write past ISIZE).
+GPU part: the same members through the C ABI; text, per-member status, newline counts and the CRC check."""
+import ctypes as C
+import os
+import struct
+import zlib
+
+import numpy as np
+import pytest
+
+from fqtk_amd import _lib
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HOST = os.path.join(ROOT, "fqtk_amd", "lib", "libfqtk_host.so")
+
+
+def _emu():
+    lib = C.CDLL(HOST)
+    f = lib.fqtk_host_bgzf_inflate_emulated
+    f.argtypes = [C.c_char_p, C.c_uint32, C.c_uint32, C.c_char_p, C.c_uint32]
+    f.restype = C.c_int
+    return f
+
+
+def raw_deflate(data, level=6, strategy=0):
+    c = zlib.compressobj(level, zlib.DEFLATED, -15, 8, strategy)
+    return c.compress(data) + c.flush()
+
+
+def emulated(payload, isize, misalign=0):
+    out = C.create_string_buffer(isize + 64)
+    guard = b"\xEE" * 64
+    C.memmove(C.addressof(out) + isize, guard, 64)
+    st = _emu()(payload, len(payload), isize, out, misalign)
+    assert out.raw[isize:] == guard                      # nothing is written past ISIZE, whatever the stream says
+    return st, out.raw[:isize]
+
+
+def fastq_text(n, rng, qual=b"FFFFFFFFFF:,#IIJJ<<AA"):
+    acgt = np.frombuffer(b"ACGT", dtype=np.uint8)
+    q = np.frombuffer(qual, dtype=np.uint8)
+    recs = []
+    for i in range(n):
+        L = int(rng.choice([36, 100, 150]))
+        recs.append(b"@inst:1:FC:1:%07d:%d 1:N:0:ACGTACGT+TTGCAATG\n%s\n+\n%s\n" % (
+            i, int(rng.integers(0, 99999)), acgt[rng.integers(0, 4, L)].tobytes(), q[rng.integers(0, len(q), L)].tobytes()))
+    return b"".join(recs)
+
+
+def members_of_cases(rng):
+    """(text, payload) pairs that cover the decoder's paths."""
+    geom = bytes(rng.choice(256, 30000, p=np.array([2.0 ** (-i / 9) for i in range(256)]) / sum(2.0 ** (-i / 9) for i in range(256))).astype(np.uint8))
+    texts = [b"", b"a", b"hello hello hello hello", b"a" * 1000, bytes(range(256)) * 4, fastq_text(30, rng), fastq_text(400, rng)[:65280],
+             bytes(rng.integers(0, 256, 20000, dtype=np.uint8)), geom, (b"ACGT" * 17000)[:65536], b"\n" * 5000 + b"x"]
+    out = []
+    for t in texts:
+        for level, strategy in ((0, 0), (1, 0), (6, 0), (9, 0), (6, 1), (6, 2), (6, 3), (6, 4)):
+            out.append((t, raw_deflate(t, level, strategy)))
+    # several blocks in one member: stored, dynamic and fixed ones mixed
+    c = zlib.compressobj(6, zlib.DEFLATED, -15)
+    parts = [fastq_text(30, rng), bytes(rng.integers(0, 256, 500, dtype=np.uint8)), b"abc" * 50, fastq_text(10, rng)]
+    comp = b"".join(c.compress(p) + c.flush(zlib.Z_FULL_FLUSH) for p in parts) + c.flush()
+    out.append((b"".join(parts), comp))
+    return out
+
+
+def test_emulated_wavefront_inflates_what_zlib_wrote():
+    rng = np.random.default_rng(3)
+    cases = members_of_cases(rng)
+    # (the emulator runs ~50 KB/s: the big cases once, the small ones at every alignment)
+    for k, (text, payload) in enumerate(cases):
+        for mis in ((0, 1, 2, 3) if len(text) < 3000 else (k & 3,)):
+            st, got = emulated(payload, len(text), mis)
+            assert st == 0 and got == text, (k, len(text), mis, st)
+
+
+def test_emulated_wavefront_rejects_what_zlib_rejects():
+    rng = np.random.default_rng(4)
+    text = fastq_text(25, rng)
+    payload = raw_deflate(text)
+    errors = 0
+    for bit in range(0, len(payload) * 8, 29):
+        bad = bytearray(payload)
+        bad[bit >> 3] ^= 1 << (bit & 7)
+        st, got = emulated(bytes(bad), len(text))
+        d = zlib.decompressobj(-15)
+        try:
+            ref = d.decompress(bytes(bad))
+            zok = d.eof
+        except zlib.error:
+            ref, zok = None, False
+        if st == 0:
+            assert zok and ref == got, bit                # accepted: then zlib accepts it too, with the same bytes
+        else:
+            errors += 1
+            assert not (zok and len(ref) == len(text) and d.unused_data == b""), (bit, st)   # rejected: zlib does not return ISIZE bytes cleanly
+    assert errors > 50
+    assert emulated(payload, len(text) - 1)[0] == 7      # more text than ISIZE
+    assert emulated(payload, len(text) + 1)[0] == 9      # less text than ISIZE
+    assert emulated(payload[:-3], len(text))[0] in (7, 8)  # truncated payload (what lies behind it decodes to too much, or to nothing)
+    assert emulated(b"\x07", 0)[0] == 1                  # reserved block type
+    assert emulated(b"\x01\x05\x00\x00\x00", 5)[0] == 2  # stored block whose NLEN is not ~LEN
+
+
+# ---- GPU ----------------------------------------------------------------------------------------------------------------
+def bgzf_member(text, level=6):
+    payload = raw_deflate(text, level)
+    bsize = 18 + len(payload) + 8 - 1
+    head = b"\x1f\x8b\x08\x04\0\0\0\0\0\xff\x06\0BC\x02\0" + struct.pack("<H", bsize)
+    return head + payload + struct.pack("<II", zlib.crc32(text), len(text))
+
+
+class Batch:
+    """Members laid out back to back the way a BGZF file holds them, in page-locked memory."""
+
+    def __init__(self, lib, items):
+        self.lib = lib
+        file_bytes = bytearray()
+        desc = []
+        out_off = 0
+        for text, payload, crc in items:
+            start = len(file_bytes) + 18
+            file_bytes += b"\x1f\x8b\x08\x04\0\0\0\0\0\xff\x06\0BC\x02\0" + struct.pack("<H", min(18 + len(payload) + 7, 65535)) + payload + struct.pack("<II", crc, len(text))
+            desc.append((start, out_off, len(payload), len(text), crc))
+            out_off += len(text)
+        self.n, self.total = len(items), out_off
+        self.in_len = len(file_bytes)
+        self.ptrs = [C.c_void_p() for _ in range(5)]
+        sizes = [self.in_len + 8, max(out_off, 1) + 64, self.n * C.sizeof(_lib.fqtk_inflate_member), self.n * 4, self.n * 4]
+        for p, s in zip(self.ptrs, sizes):
+            assert lib.fqtk_pinned_alloc(s, C.byref(p)) == 0
+        self.pin, self.pout, self.pdesc, self.pstat, self.plines = self.ptrs
+        C.memmove(self.pin.value, bytes(file_bytes), self.in_len)
+        C.memset(self.pout.value, 0xEE, sizes[1])
+        self.desc = (_lib.fqtk_inflate_member * self.n).from_address(self.pdesc.value)
+        for i, (a, b, c, d, e) in enumerate(desc):
+            self.desc[i].payload_off, self.desc[i].out_off, self.desc[i].payload_len, self.desc[i].isize, self.desc[i].crc = a, b, c, d, e
+        self.status = (C.c_uint32 * self.n).from_address(self.pstat.value)
+        self.lines = (C.c_uint32 * self.n).from_address(self.plines.value)
+
+    def text(self, i):
+        return C.string_at(self.pout.value + self.desc[i].out_off, self.desc[i].isize)
+
+    def free(self):
+        for p in self.ptrs:
+            self.lib.fqtk_pinned_free(p)
+
+
+@pytest.mark.gpu
+def test_members_inflate_on_the_gpu_to_what_zlib_returns():
+    lib = _lib.load()
+    z = C.c_void_p()
+    assert lib.fqtk_inflate_create(0, C.byref(z)) == 0, lib.fqtk_inflate_last_error()
+    rng = np.random.default_rng(3)
+    cases = members_of_cases(rng)
+    big = fastq_text(30000, rng)
+    cases += [(big[o:o + 65280], raw_deflate(big[o:o + 65280], 1 + (o // 65280) % 9)) for o in range(0, len(big), 65280)]
+    items = [(t, p, zlib.crc32(t)) for t, p in cases]
+    b = Batch(lib, items)
+    try:
+        for slot in (0, 1):
+            C.memset(b.pout.value, 0xEE, b.total + 64)
+            assert lib.fqtk_inflate_enqueue(z, slot, b.pin, b.in_len, b.pdesc, b.n, b.pout, b.pstat, b.plines) == 0, lib.fqtk_inflate_last_error()
+            assert lib.fqtk_inflate_wait(z, slot) == 0, lib.fqtk_inflate_last_error()
+            for i, (t, _, _) in enumerate(items):
+                assert b.status[i] == 0, (i, b.status[i], len(t))
+                assert b.text(i) == t, (i, len(t))
+                assert b.lines[i] == t.count(b"\n"), i
+            assert C.string_at(b.pout.value + b.total, 64) == b"\xEE" * 64
+        assert lib.fqtk_inflate_enqueue(z, 2, b.pin, b.in_len, b.pdesc, b.n, b.pout, b.pstat, b.plines) == 0
+        assert lib.fqtk_inflate_enqueue(z, 2, b.pin, b.in_len, b.pdesc, b.n, b.pout, b.pstat, b.plines) == _lib.FQTK_EINVAL
+        assert lib.fqtk_inflate_wait(z, 2) == 0
+        assert lib.fqtk_inflate_enqueue(z, 7, b.pin, b.in_len, b.pdesc, b.n, b.pout, b.pstat, b.plines) == _lib.FQTK_EINVAL
+    finally:
+        b.free()
+        lib.fqtk_inflate_destroy(z)
+
+
+@pytest.mark.gpu
+def test_gpu_decoder_reports_bad_members_and_leaves_the_others_alone():
+    lib = _lib.load()
+    z = C.c_void_p()
+    assert lib.fqtk_inflate_create(0, C.byref(z)) == 0
+    rng = np.random.default_rng(5)
+    text = fastq_text(200, rng)
+    payload = raw_deflate(text)
+    good = (text, payload, zlib.crc32(text))
+    items = [good, (text, payload, zlib.crc32(text) ^ 1), good, (text, payload[:-5], zlib.crc32(text)), good]
+    flipped = []
+    for bit in range(40, len(payload) * 8, 997):
+        bad = bytearray(payload)
+        bad[bit >> 3] ^= 1 << (bit & 7)
+        flipped.append(bytes(bad))
+        items.append((text, bytes(bad), zlib.crc32(text)))
+    items.append(good)
+    b = Batch(lib, items)
+    try:
+        assert lib.fqtk_inflate_enqueue(z, 0, b.pin, b.in_len, b.pdesc, b.n, b.pout, b.pstat, b.plines) == 0
+        assert lib.fqtk_inflate_wait(z, 0) == 0
+        assert [b.status[i] for i in (0, 1, 2, 4)] == [0, _lib.FQTK_INFLATE_ERR_CRC, 0, 0] and b.status[3] in (7, 8)
+        for i in (0, 2, 4, b.n - 1):
+            assert b.status[i] == 0 and b.text(i) == text and b.lines[i] == text.count(b"\n")
+        for k, bad in enumerate(flipped):
+            assert b.status[5 + k] != 0, k               # a flipped bit: the stream breaks, or the CRC does
+    finally:
+        b.free()
+        lib.fqtk_inflate_destroy(z)
