@@ -46,7 +46,8 @@ class fqtk_demux_config(C.Structure):
 class fqtk_demux_result(C.Structure):
     _fields_ = [("bytes", C.c_void_p), ("file_off", C.POINTER(C.c_uint64)), ("n_files", C.c_uint64),
                 ("n_blocks", C.c_uint64), ("n_templates", C.c_uint32), ("n_skipped", C.c_uint32), ("error", C.c_int),
-                ("error_input", C.c_uint32), ("error_template", C.c_uint32), ("error_detail", C.c_uint32)]
+                ("error_input", C.c_uint32), ("error_template", C.c_uint32), ("error_detail", C.c_uint32),
+                ("text_end", C.POINTER(C.c_uint64))]
 
 
 FQTK_DEMUX_SLOTS, FQTK_DEMUX_STAGES = 3, 8
@@ -137,6 +138,10 @@ SIGNATURES = [
     ("fqtk_demuxer_counts", C.c_int, [C.c_void_p, C.c_void_p]),
     ("fqtk_demuxer_stage_seconds", C.c_int, [C.c_void_p, C.POINTER(C.c_double)]),
     ("fqtk_demuxer_stage_name", C.c_char_p, [C.c_int]),
+    ("fqtk_demuxer_feed", C.c_int, [C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint32, C.c_int, C.POINTER(C.c_uint64)]),
+    ("fqtk_demuxer_submit_fed", C.c_int, [C.c_void_p, C.c_int, C.c_uint32]),
+    ("fqtk_demuxer_fed_tail", C.c_int, [C.c_void_p, C.c_uint32, C.c_uint64, C.c_void_p, C.c_size_t, C.POINTER(C.c_uint64)]),
+    ("fqtk_demuxer_inflate_seconds", C.c_int, [C.c_void_p, C.POINTER(C.c_double)]),
 ]
 
 

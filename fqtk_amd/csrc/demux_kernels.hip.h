@@ -47,6 +47,13 @@ struct TextSet {
     uint32_t *tile_cnt[FQTK_DEMUX_MAX_INPUTS];   // newlines per 4 KiB tile, then their exclusive prefix sum
     uint32_t *ls[FQTK_DEMUX_MAX_INPUTS];         // line starts: ls[k] = offset of line k; 4N + 1 entries
     RecView *rec[FQTK_DEMUX_MAX_INPUTS];
+    // A chunk cut out of text that is already on the device (BGZF inputs inflated there: fqtk_demuxer_submit_fed) is a
+    // WINDOW of whole members around the chunk's records: text[i] is 16-byte aligned, its first lead[i] (< 16) bytes belong
+    // to something else and read as zeros, the chunk's first line is line first_line[i] of the window and lines behind its
+    // last one are ignored.  Text handed over by the host: lead = first_line = 0, and the window holds exactly 4 n lines.
+    uint32_t lead[FQTK_DEMUX_MAX_INPUTS];
+    uint32_t first_line[FQTK_DEMUX_MAX_INPUTS];
+    uint32_t window;   // 1: windows (at least first_line + 4 n lines each)
 };
 
 // Device-side status of one chunk (copied to page-locked memory at the end of the chunk).
@@ -55,6 +62,7 @@ struct ChunkStatus {
     unsigned long long matcher_err;   // the matcher's latched length error (read index), ~0 = none
     unsigned long long total_bytes;   // packed BGZF members
     uint32_t n_lines[FQTK_DEMUX_MAX_INPUTS];
+    uint32_t end_off[FQTK_DEMUX_MAX_INPUTS];   // offset in the input's text of the byte behind the chunk's last record
     uint32_t n_blocks, n_skipped, max_bc_len, pad;
 };
 // Order of the errors of ONE template = the order the reference meets them in: its per-input iterators are zipped
@@ -122,10 +130,14 @@ __device__ inline uint32_t newline_mask(uint32_t w) {
     return ~(t | x | 0x7F7F7F7Fu);
 }
 // the 16 bytes of lane `lane` of tile `tile`, bytes at or past `len` read as zeros
-__device__ inline uint4 tile_bytes(const uint8_t *text, uint32_t len, uint32_t tile, uint32_t lane) {
+__device__ inline uint4 tile_bytes(const uint8_t *text, uint32_t len, uint32_t tile, uint32_t lane, uint32_t lead = 0) {
     const uint32_t off = tile * kLineTile + lane * 16u;
     uint4 v = make_uint4(0, 0, 0, 0);
-    if (off + 16u <= len) {
+    if (off < lead) {   // (lead < 16: the first lane of the first tile) the window's first bytes are not its own
+        uint32_t w[4] = {0, 0, 0, 0};
+        for (uint32_t k = lead; k < 16u && off + k < len; ++k) w[k >> 2] |= (uint32_t)text[off + k] << (8 * (k & 3u));
+        v = make_uint4(w[0], w[1], w[2], w[3]);
+    } else if (off + 16u <= len) {
         v = *reinterpret_cast<const uint4 *>(text + off);
     } else if (off < len) {
         uint32_t w[4] = {0, 0, 0, 0};
@@ -150,7 +162,7 @@ __global__ __launch_bounds__(256) void k_count_lines(TextSet T) {
     const uint32_t in = blockIdx.y, tile = blockIdx.x;
     if ((uint64_t)tile * kLineTile >= T.len[in]) return;
     uint32_t m[4];
-    const uint32_t c = lane_newlines(tile_bytes(T.text[in], T.len[in], tile, threadIdx.x), m);
+    const uint32_t c = lane_newlines(tile_bytes(T.text[in], T.len[in], tile, threadIdx.x, T.lead[in]), m);
     const uint32_t tot = block_sum_256(c, sh);
     if (threadIdx.x == 0) T.tile_cnt[in][tile] = tot;
 }
@@ -190,7 +202,7 @@ __global__ __launch_bounds__(256) void k_line_starts(TextSet T, uint32_t max_lin
     const uint32_t in = blockIdx.y, tile = blockIdx.x;
     if ((uint64_t)tile * kLineTile >= T.len[in]) return;
     uint32_t m[4];
-    const uint32_t c = lane_newlines(tile_bytes(T.text[in], T.len[in], tile, threadIdx.x), m);
+    const uint32_t c = lane_newlines(tile_bytes(T.text[in], T.len[in], tile, threadIdx.x, T.lead[in]), m);
     sh[threadIdx.x] = c;
     __syncthreads();
     for (uint32_t d = 1; d < 256; d <<= 1) {
@@ -199,16 +211,19 @@ __global__ __launch_bounds__(256) void k_line_starts(TextSet T, uint32_t max_lin
         sh[threadIdx.x] += add;
         __syncthreads();
     }
+    // newline number k of the window ends the chunk's line k - first_line (the window's lines before first_line and
+    // behind the chunk's last one belong to other chunks)
+    const uint32_t first = T.first_line[in];
     uint32_t k = T.tile_cnt[in][tile] + sh[threadIdx.x] - c;
     uint32_t *ls = T.ls[in];
-    if (tile == 0 && threadIdx.x == 0) ls[0] = 0;
+    if (tile == 0 && threadIdx.x == 0 && first == 0u) ls[0] = T.lead[in];
     const uint32_t off = tile * kLineTile + threadIdx.x * 16u;
     for (int w = 0; w < 4; ++w) {
         uint32_t mm = m[w];
         while (mm) {
             const uint32_t bit = (uint32_t)__ffs((int)mm) - 1u;   // 7, 15, 23 or 31
             mm &= mm - 1u;
-            if (k < max_lines) ls[k + 1] = off + (uint32_t)w * 4u + (bit >> 3) + 1u;
+            if (k + 1u >= first && k + 1u - first <= max_lines) ls[k + 1u - first] = off + (uint32_t)w * 4u + (bit >> 3) + 1u;
             ++k;
         }
     }
@@ -220,12 +235,14 @@ __global__ __launch_bounds__(256) void k_line_starts(TextSet T, uint32_t max_lin
 __global__ __launch_bounds__(256) void k_records(TextSet T, DevConfig C, uint32_t n, uint8_t *skip, uint32_t *bc_len,
                                                  ChunkStatus *st) {
     for (uint32_t i = 0; i < C.n_inputs; ++i)
-        if (st->n_lines[i] != 4u * n) {   // the index is not the one the later kernels expect: nothing is touched
+        if (T.window ? st->n_lines[i] < T.first_line[i] + 4u * n : st->n_lines[i] != 4u * n) {   // the index is not the one the later kernels expect: nothing is touched
             if (blockIdx.x == 0 && threadIdx.x == 0) report(st, 0, 0, i, FQTK_DEMUX_ERR_LINES);
             return;
         }
     const uint32_t t = blockIdx.x * 256u + threadIdx.x;
     if (t >= n) return;
+    if (t == n - 1u)
+        for (uint32_t i = 0; i < C.n_inputs; ++i) st->end_off[i] = T.ls[i][4u * n];
     bool too_short = false;
     for (uint32_t i = 0; i < C.n_inputs; ++i) {
         const uint8_t *x = T.text[i];

@@ -10,7 +10,11 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
+#include <cstdlib>
 #include <cstring>
+#include <deque>
+#include <mutex>
 #include <new>
 #include <string>
 #include <vector>
@@ -18,6 +22,7 @@
 #include "../../include/fqtk_demux.h"
 #include "bgzf_internal.hpp"
 #include "demux_kernels.hip.h"
+#include "inflate_internal.hpp"
 #include "matcher_internal.hpp"
 
 namespace {
@@ -79,8 +84,41 @@ struct Slot {
     hipEvent_t ev[kStageEvents] = {};
     bool busy = false, flush_only = false;
     uint32_t n = 0, stride = 0;
+    uint64_t win_pos[FQTK_DEMUX_MAX_INPUTS] = {};           // fed text: position of text_base in the input's whole text
+    uint64_t text_end[FQTK_DEMUX_MAX_INPUTS] = {};          // ... and of the byte behind the chunk's last record
+    bool fed = false;
+    const uint8_t *text_base[FQTK_DEMUX_MAX_INPUTS] = {};   // where the chunk's record views point (the slot's own copy, or a window of fed text)
     size_t max_blocks = 0;
 };
+
+
+// ---- BGZF inputs inflated on the device (fqtk_demuxer_feed / fqtk_demuxer_submit_fed) ------------------------------------
+// The text of an input lives in one of two arenas; members are appended at `tail`.  When the arena is full the part no
+// chunk has consumed yet moves to the front of the other arena (after every chunk submitted so far has been formatted:
+// their record views point into the arenas) and the feed goes on there.
+struct FedMember { uint64_t off; uint32_t isize, lines; uint64_t lines_before, pos; };   // off: in the current arena; pos: in the input's text
+struct FedInput {
+    std::mutex mu;                      // one feeder thread per input + the submit thread
+    DevBuf<uint8_t> arena[2], comp;
+    DevBuf<fqtk_inflate_member> d_members;
+    DevBuf<uint32_t> d_status, d_lines;
+    PinBuf<uint32_t> h_status, h_lines;
+    PinBuf<fqtk_inflate_member> h_members;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev_moved = nullptr;      // behind the copy of the last change of arena (chunks cut afterwards wait for it)
+    bool moved = false;
+    int cur = 0;
+    uint64_t tail = 0;                  // bytes of arena[cur] in use
+    std::deque<FedMember> members;      // not yet consumed in full, in file order
+    uint64_t lines_total = 0;           // newlines fed so far
+    uint64_t lines_consumed = 0;        // lines taken by chunks so far
+    uint64_t members_fed = 0;
+    uint64_t text_total = 0;            // bytes of text fed so far
+    bool ended = false;
+};
+constexpr uint64_t kFedSlack = 256;     // bytes kept free behind the text (the check kernel and the line index read whole dwords / 16 bytes)
+
+__global__ void k_put_newline(uint8_t *p) { *p = 0x0A; }
 
 }  // namespace
 
@@ -101,6 +139,14 @@ struct fqtk_demuxer {
     uint64_t chunk_no = 0;              // chunks submitted
     int slot_of_chunk[2] = {-1, -1};    // slots of the last two chunks submitted (A(k) waits for B(k - 2))
     double stage_s[FQTK_DEMUX_STAGES] = {};
+    // device-side inflate of BGZF inputs
+    FedInput *fed = nullptr;            // n_inputs of them, made by the first feed
+    std::mutex fed_mu;                  // one submit_fed at a time (taken BEFORE an input's mutex, never after)
+    std::mutex init_mu, stat_mu;
+    std::atomic<uint64_t> chunks_submitted{0};
+    uint32_t *d_crc_pow = nullptr;
+    hipEvent_t ev_last_fmt = nullptr;   // ev_fmt of the latest chunk submitted (recorded again on stream A)
+    double inflate_s = 0;
 };
 
 namespace {
@@ -191,6 +237,10 @@ int fill_result(fqtk_demuxer *d, Slot &s, fqtk_demux_result *res) {
     DX_TRY(hipEventRecord(s.ev_d2h1, d->s_out));
     DX_TRY(hipEventSynchronize(s.ev_d2h1));
     add_elapsed(&d->stage_s[7], s.ev_d2h0, s.ev_d2h1);
+    if (s.fed && !s.flush_only) {
+        for (uint32_t i = 0; i < d->C.n_inputs; ++i) s.text_end[i] = s.win_pos[i] + st.end_off[i];
+        res->text_end = s.text_end;
+    }
     res->bytes = s.h_packed.p;
     res->file_off = reinterpret_cast<const uint64_t *>(s.h_file_off.p);
     res->n_blocks = st.n_blocks;
@@ -284,6 +334,7 @@ int fqtk_demuxer_create(fqtk_matcher *m, const fqtk_demux_config *cfg, fqtk_demu
         const int rc = alloc_slot_fixed(d, s);
         if (rc != FQTK_OK) return bail(rc);
     }
+    if (hipEventCreate(&d->ev_last_fmt) != hipSuccess) return bail(set_error(FQTK_EHIP, "hipEventCreate"));
     *out = d;
     return FQTK_OK;
 }
@@ -303,6 +354,18 @@ void fqtk_demuxer_destroy(fqtk_demuxer *d) {
         for (hipEvent_t e : {s.ev_h2d0, s.ev_h2d1, s.ev_fmt, s.ev_status, s.ev_d2h0, s.ev_d2h1}) if (e) (void)hipEventDestroy(e);
         for (hipEvent_t e : s.ev) if (e) (void)hipEventDestroy(e);
     }
+    if (d->fed) {
+        for (uint32_t i = 0; i < d->C.n_inputs; ++i) {
+            FedInput &F = d->fed[i];
+            if (F.stream) { (void)hipStreamSynchronize(F.stream); (void)hipStreamDestroy(F.stream); }
+            if (F.ev_moved) (void)hipEventDestroy(F.ev_moved);
+            F.arena[0].release(); F.arena[1].release(); F.comp.release(); F.d_members.release(); F.d_status.release(); F.d_lines.release();
+            F.h_status.release(); F.h_lines.release(); F.h_members.release();
+        }
+        delete[] d->fed;
+    }
+    if (d->d_crc_pow) (void)hipFree(d->d_crc_pow);
+    if (d->ev_last_fmt) (void)hipEventDestroy(d->ev_last_fmt);
     if (d->d_persist) (void)hipFree(d->d_persist);
     if (d->d_fs) (void)hipFree(d->d_fs);
     if (d->d_counts) (void)hipFree(d->d_counts);
@@ -313,8 +376,11 @@ void fqtk_demuxer_destroy(fqtk_demuxer *d) {
 
 uint32_t fqtk_demuxer_files_per_sample(const fqtk_demuxer *d) { return d ? d->C.n_files : 0; }
 
-int fqtk_demuxer_submit(fqtk_demuxer *d, int slot, const uint8_t *const *text, const uint64_t *text_len, uint32_t n) {
-    if (!d || !text || !text_len) return set_error(FQTK_EINVAL, "NULL argument");
+namespace {
+struct Window { const uint8_t *base; uint32_t lead, first_line; };   // (a window's length travels as text_len)
+}
+// One chunk: `text` (host buffers, copied in) or `win` (text already on the device).
+static int submit_common(fqtk_demuxer *d, int slot, const uint8_t *const *text, const uint64_t *text_len, const Window *win, uint32_t n) {
     if (slot < 0 || slot >= FQTK_DEMUX_SLOTS) return set_error(FQTK_EINVAL, "slot out of range");
     Slot &s = d->slots[slot];
     if (s.busy) return set_error(FQTK_EINVAL, "slot is busy: call fqtk_demuxer_collect() first");
@@ -322,7 +388,7 @@ int fqtk_demuxer_submit(fqtk_demuxer *d, int slot, const uint8_t *const *text, c
     const DevConfig &C = d->C;
     uint64_t sum_text = 0, seg_text = 0;
     for (uint32_t i = 0; i < C.n_inputs; ++i) {
-        if (!text[i] || text_len[i] == 0 || text_len[i] >= (1ull << 31)) return set_error(FQTK_EINVAL, "an input's text is empty or 2 GiB or more: use smaller chunks");
+        if ((!win && !text[i]) || text_len[i] == 0 || text_len[i] >= (1ull << 31)) return set_error(FQTK_EINVAL, "an input's text is empty or 2 GiB or more: use smaller chunks");
         sum_text += text_len[i];
     }
     for (uint32_t f = 0; f < C.n_files; ++f) seg_text += text_len[C.fseg[f].input];
@@ -348,16 +414,20 @@ int fqtk_demuxer_submit(fqtk_demuxer *d, int slot, const uint8_t *const *text, c
     for (uint32_t i = 0; i < C.n_inputs; ++i) {
         const uint32_t tiles = (uint32_t)((text_len[i] + kLineTile - 1) / kLineTile);
         max_tiles = std::max(max_tiles, tiles);
-        if ((rc = s.text[i].ensure((size_t)text_len[i] + 64)) != FQTK_OK) return rc;
+        if (!win && (rc = s.text[i].ensure((size_t)text_len[i] + 64)) != FQTK_OK) return rc;
         if ((rc = s.tile_cnt[i].ensure(tiles)) != FQTK_OK) return rc;
         if ((rc = s.ls[i].ensure(4 * (size_t)n + 2)) != FQTK_OK) return rc;
         if ((rc = s.rec[i].ensure(n)) != FQTK_OK) return rc;
-        T.text[i] = s.text[i].p;
+        T.text[i] = win ? win[i].base : s.text[i].p;
+        T.lead[i] = win ? win[i].lead : 0u;
+        T.first_line[i] = win ? win[i].first_line : 0u;
+        s.text_base[i] = T.text[i];
         T.len[i] = (uint32_t)text_len[i];
         T.tile_cnt[i] = s.tile_cnt[i].p;
         T.ls[i] = s.ls[i].p;
         T.rec[i] = s.rec[i].p;
     }
+    T.window = win ? 1u : 0u;
     const uint32_t n_tiles = (n + kTile - 1) / kTile;
     if ((rc = s.skip.ensure(n)) != FQTK_OK) return rc;
     if ((rc = s.bc_len.ensure(n)) != FQTK_OK) return rc;
@@ -369,7 +439,7 @@ int fqtk_demuxer_submit(fqtk_demuxer *d, int slot, const uint8_t *const *text, c
 
     // text in (copy stream)
     DX_TRY(hipEventRecord(s.ev_h2d0, d->s_in));
-    for (uint32_t i = 0; i < C.n_inputs; ++i)
+    for (uint32_t i = 0; i < C.n_inputs && !win; ++i)
         DX_TRY(hipMemcpyAsync(s.text[i].p, text[i], (size_t)text_len[i], hipMemcpyHostToDevice, d->s_in));
     DX_TRY(hipEventRecord(s.ev_h2d1, d->s_in));
 
@@ -424,15 +494,205 @@ int fqtk_demuxer_submit(fqtk_demuxer *d, int slot, const uint8_t *const *text, c
     DX_TRY(hipGetLastError());
     DX_TRY(hipEventRecord(s.ev[4], A));
     DX_TRY(hipEventRecord(s.ev_fmt, A));
+    DX_TRY(hipEventRecord(d->ev_last_fmt, A));
     // stream B
     DX_TRY(hipStreamWaitEvent(d->s_b, s.ev_fmt, 0));
     if ((rc = enqueue_compress(d, s)) != FQTK_OK) return rc;
     s.busy = true;
     s.flush_only = false;
+    s.fed = false;
     s.n = n;
     d->slot_of_chunk[0] = d->slot_of_chunk[1];
     d->slot_of_chunk[1] = slot;
     ++d->chunk_no;
+    d->chunks_submitted.fetch_add(1);
+    return FQTK_OK;
+}
+
+int fqtk_demuxer_submit(fqtk_demuxer *d, int slot, const uint8_t *const *text, const uint64_t *text_len, uint32_t n) {
+    if (!d || !text || !text_len) return set_error(FQTK_EINVAL, "NULL argument");
+    return submit_common(d, slot, text, text_len, nullptr, n);
+}
+
+// ---- BGZF inputs inflated on the device ---------------------------------------------------------------------------------
+int fqtk_demuxer_feed(fqtk_demuxer *d, uint32_t input, const uint8_t *bytes, uint64_t len, const fqtk_inflate_member *members,
+                      uint32_t n_members, int last, uint64_t *lines_available) {
+    if (!d || (n_members && (!bytes || !members))) return set_error(FQTK_EINVAL, "NULL argument");
+    if (input >= d->C.n_inputs) return set_error(FQTK_EINVAL, "input out of range");
+    DX_TRY(hipSetDevice(d->device));
+    {   // first feed of the run: the per-input state
+        std::lock_guard<std::mutex> lk(d->init_mu);
+        if (!d->fed) {
+            uint32_t pow[fqtk::inflate::kCrcPowWords];
+            fqtk::inflate::crc_pow_table(pow);
+            DX_TRY(hipMalloc(reinterpret_cast<void **>(&d->d_crc_pow), sizeof pow));
+            DX_TRY(hipMemcpy(d->d_crc_pow, pow, sizeof pow, hipMemcpyHostToDevice));
+            FedInput *f = new (std::nothrow) FedInput[d->C.n_inputs];
+            if (!f) return set_error(FQTK_ENOMEM, "out of host memory");
+            for (uint32_t i = 0; i < d->C.n_inputs; ++i) {
+                DX_TRY(hipStreamCreateWithFlags(&f[i].stream, hipStreamNonBlocking));
+                DX_TRY(hipEventCreateWithFlags(&f[i].ev_moved, hipEventDisableTiming));
+            }
+            d->fed = f;
+        }
+    }
+    FedInput &F = d->fed[input];
+    std::unique_lock<std::mutex> lk(F.mu);
+    if (F.ended) return set_error(FQTK_EINVAL, "the input's last members have been fed already");
+    uint64_t text_bytes = last ? 1 : 0;
+    for (uint32_t j = 0; j < n_members; ++j) {
+        if (members[j].isize > FQTK_INFLATE_MAX_ISIZE) return set_error(FQTK_EINVAL, "a BGZF member of more than 64 KiB of text");
+        text_bytes += members[j].isize;
+    }
+    int rc;
+    // room in the arena?  if not: what chunks have not consumed yet moves to the front of the other one
+    uint64_t live_from = F.members.empty() ? F.tail : F.members.front().off;
+    if (F.tail + text_bytes + kFedSlack > F.arena[F.cur].cap) {
+        const uint64_t live = F.tail - live_from;
+        const int other = 1 - F.cur;
+        // (FQTK_FED_ARENA_MIN: tests make the arenas small so that a short run changes arena many times)
+        static const uint64_t arena_min = [] { const char *e = std::getenv("FQTK_FED_ARENA_MIN"); return e && *e ? (uint64_t)std::strtoull(e, nullptr, 10) : (1ull << 30); }();
+        const uint64_t want = std::max<uint64_t>((live + text_bytes + kFedSlack) * 2, arena_min);
+        {
+            // Chunks whose record views point into the OTHER arena were submitted before this input last changed arenas:
+            // its old text may go, and this stream's copy may start, when they have been formatted.  (No lock against a
+            // submit in progress: a window is cut under F.mu, which this thread holds, and out of the current arena.)
+            const bool any = d->chunks_submitted.load() != 0;
+            if (any) DX_TRY(hipStreamWaitEvent(F.stream, d->ev_last_fmt, 0));
+            if (F.arena[other].cap < want) {
+                if (any) DX_TRY(hipEventSynchronize(d->ev_last_fmt));   // (freeing memory a kernel may still read)
+                if ((rc = F.arena[other].ensure((size_t)want)) != FQTK_OK) return rc;
+            }
+        }
+        const uint64_t shift = live_from & 15u;   // members keep their alignment modulo 16 (nothing depends on it; windows are aligned down anyway)
+        if (live) DX_TRY(hipMemcpyAsync(F.arena[other].p + shift, F.arena[F.cur].p + live_from, (size_t)live, hipMemcpyDeviceToDevice, F.stream));
+        DX_TRY(hipEventRecord(F.ev_moved, F.stream));
+        F.moved = true;
+        for (FedMember &m : F.members) m.off = m.off - live_from + shift;
+        F.cur = other;
+        F.tail = shift + live;
+    }
+    // the members' places, the copy in, the kernels, the counts back
+    if ((rc = F.h_members.ensure(n_members + 1)) != FQTK_OK) return rc;
+    if ((rc = F.d_members.ensure(n_members + 1)) != FQTK_OK) return rc;
+    if ((rc = F.d_status.ensure(n_members + 1)) != FQTK_OK) return rc;
+    if ((rc = F.d_lines.ensure(n_members + 1)) != FQTK_OK) return rc;
+    if ((rc = F.h_status.ensure(n_members + 1)) != FQTK_OK) return rc;
+    if ((rc = F.h_lines.ensure(n_members + 1)) != FQTK_OK) return rc;
+    if ((rc = F.comp.ensure((size_t)len + 16)) != FQTK_OK) return rc;
+    uint64_t at = F.tail;
+    for (uint32_t j = 0; j < n_members; ++j) {
+        F.h_members.p[j] = members[j];
+        F.h_members.p[j].out_off = at;
+        at += members[j].isize;
+    }
+    uint8_t *const arena = F.arena[F.cur].p;
+    F.tail = at + (last ? 1 : 0);   // the place is taken; the members count once they are inflated (below)
+    // The copy, the kernels and the wait run without the input's lock: chunks go on being cut out of what was fed before.
+    lk.unlock();
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (n_members) {
+        DX_TRY(hipMemcpyAsync(F.comp.p, bytes, (size_t)len, hipMemcpyHostToDevice, F.stream));
+        DX_TRY(hipMemcpyAsync(F.d_members.p, F.h_members.p, (size_t)n_members * sizeof(fqtk_inflate_member), hipMemcpyHostToDevice, F.stream));
+        DX_TRY(hipEventCreate(&e0));
+        DX_TRY(hipEventCreate(&e1));
+        DX_TRY(hipEventRecord(e0, F.stream));
+        DX_TRY(fqtk::inflate::inflate_launch(F.stream, F.comp.p, len, F.d_members.p, n_members, arena, F.d_status.p, F.d_lines.p, d->d_crc_pow));
+        DX_TRY(hipEventRecord(e1, F.stream));
+        DX_TRY(hipMemcpyAsync(F.h_status.p, F.d_status.p, (size_t)n_members * sizeof(uint32_t), hipMemcpyDeviceToHost, F.stream));
+        DX_TRY(hipMemcpyAsync(F.h_lines.p, F.d_lines.p, (size_t)n_members * sizeof(uint32_t), hipMemcpyDeviceToHost, F.stream));
+    }
+    if (last) {   // the text may end without a newline: one is added (a blank line more, if it does not)
+        hipLaunchKernelGGL(k_put_newline, dim3(1), dim3(1), 0, F.stream, arena + at);
+        DX_TRY(hipGetLastError());
+    }
+    DX_TRY(hipStreamSynchronize(F.stream));
+    if (e0) {
+        float ms = 0;
+        if (hipEventElapsedTime(&ms, e0, e1) == hipSuccess) { std::lock_guard<std::mutex> glk(d->stat_mu); d->inflate_s += ms * 1e-3; }
+        (void)hipEventDestroy(e0);
+        (void)hipEventDestroy(e1);
+    }
+    for (uint32_t j = 0; j < n_members; ++j)
+        if (F.h_status.p[j] != 0) {
+            static const char *const kWhat[12] = {"", "reserved block type", "stored block length check", "bad code lengths", "over-subscribed or incomplete Huffman code",
+                                                  "invalid code", "distance too far back", "more text than the member's ISIZE", "stream runs past the member",
+                                                  "less text than the member's ISIZE", "CRC mismatch", "bad member header"};
+            return set_error(FQTK_EINVAL, std::string("corrupt BGZF block ") + std::to_string(F.members_fed + j) + ": " + kWhat[std::min<uint32_t>(F.h_status.p[j], 11)]);
+        }
+    lk.lock();
+    for (uint32_t j = 0; j < n_members; ++j) {
+        F.members.push_back(FedMember{F.h_members.p[j].out_off, members[j].isize, F.h_lines.p[j], F.lines_total, F.text_total});
+        F.lines_total += F.h_lines.p[j];
+        F.text_total += members[j].isize;
+    }
+    F.members_fed += n_members;
+    if (last) {
+        if (F.members.empty()) F.members.push_back(FedMember{at, 0, 0, F.lines_total, F.text_total});
+        F.text_total += 1;
+        F.members.back().isize += 1;
+        F.members.back().lines += 1;
+        F.lines_total += 1;
+        F.ended = true;
+    }
+    if (lines_available) *lines_available = F.lines_total;
+    return FQTK_OK;
+}
+
+int fqtk_demuxer_submit_fed(fqtk_demuxer *d, int slot, uint32_t n) {
+    if (!d) return set_error(FQTK_EINVAL, "NULL argument");
+    if (!d->fed) return set_error(FQTK_EINVAL, "nothing has been fed");
+    if (n == 0 || n > d->max_chunk) return set_error(FQTK_EINVAL, "n_templates must be 1 .. max_chunk_templates");
+    std::lock_guard<std::mutex> glk(d->fed_mu);
+    Window win[FQTK_DEMUX_MAX_INPUTS];
+    uint64_t text_len[FQTK_DEMUX_MAX_INPUTS];
+    for (uint32_t i = 0; i < d->C.n_inputs; ++i) {
+        FedInput &F = d->fed[i];
+        std::lock_guard<std::mutex> lk(F.mu);
+        const uint64_t l0 = F.lines_consumed, l1 = l0 + 4ull * n;   // the chunk's lines: [l0, l1); newline l1 - 1 ends the last one
+        if (l1 > F.lines_total) return set_error(FQTK_EINVAL, "fewer lines have been fed than the chunk takes");
+        // members that end before line l0 begins are done with (newline l0 - 1 is not theirs, nor any later one)
+        while (F.members.size() > 1 && l0 > 0 && F.members.front().lines_before + F.members.front().lines <= l0 - 1) F.members.pop_front();
+        const FedMember &first = F.members.front();
+        size_t k = 0;
+        while (F.members[k].lines_before + F.members[k].lines < l1) ++k;   // the member that holds newline l1 - 1
+        const FedMember &lastm = F.members[k];
+        if (F.moved) DX_TRY(hipStreamWaitEvent(d->s_a, F.ev_moved, 0));   // the text may just have changed arena: behind that copy
+        const uint8_t *p = F.arena[F.cur].p + first.off;
+        const uint32_t lead = (uint32_t)(reinterpret_cast<uintptr_t>(p) & 15u);
+        win[i].base = p - lead;
+        win[i].lead = lead;
+        win[i].first_line = (uint32_t)(l0 - first.lines_before);
+        text_len[i] = lead + (lastm.off + lastm.isize - first.off);
+        d->slots[slot].win_pos[i] = first.pos - lead;   // (mod 2^64 for the first member: added back below)
+    }
+    const int rc = submit_common(d, slot, nullptr, text_len, win, n);
+    if (rc != FQTK_OK) return rc;
+    d->slots[slot].fed = true;
+    for (uint32_t i = 0; i < d->C.n_inputs; ++i) {
+        std::lock_guard<std::mutex> lk(d->fed[i].mu);
+        d->fed[i].lines_consumed += 4ull * n;
+    }
+    return FQTK_OK;
+}
+
+int fqtk_demuxer_fed_tail(fqtk_demuxer *d, uint32_t input, uint64_t pos, uint8_t *buf, size_t cap, uint64_t *n_bytes) {
+    if (!d || !d->fed || input >= d->C.n_inputs || !buf || !n_bytes) return set_error(FQTK_EINVAL, "nothing has been fed / bad argument");
+    DX_TRY(hipSetDevice(d->device));
+    FedInput &F = d->fed[input];
+    std::lock_guard<std::mutex> lk(F.mu);
+    *n_bytes = pos < F.text_total ? F.text_total - pos : 0;
+    if (*n_bytes == 0) return FQTK_OK;
+    if (F.members.empty() || pos < F.members.front().pos) return set_error(FQTK_EINVAL, "that text has been consumed");
+    const uint64_t off = F.members.front().off + (pos - F.members.front().pos);   // live members are contiguous in the arena
+    DX_TRY(hipMemcpy(buf, F.arena[F.cur].p + off, (size_t)std::min<uint64_t>(*n_bytes, cap), hipMemcpyDeviceToHost));
+    return FQTK_OK;
+}
+
+int fqtk_demuxer_inflate_seconds(fqtk_demuxer *d, double *seconds) {
+    if (!d || !seconds) return set_error(FQTK_EINVAL, "NULL argument");
+    std::lock_guard<std::mutex> glk(d->stat_mu);
+    *seconds = d->inflate_s;
     return FQTK_OK;
 }
 
@@ -464,7 +724,7 @@ int fqtk_demuxer_record_text(fqtk_demuxer *d, int slot, uint32_t input, uint32_t
     RecView r;
     DX_TRY(hipMemcpy(&r, s.rec[input].p + t, sizeof r, hipMemcpyDeviceToHost));
     const size_t n = std::min<size_t>(r.head_len, cap - 1);
-    if (n) DX_TRY(hipMemcpy(header, s.text[input].p + r.head_off, n, hipMemcpyDeviceToHost));
+    if (n) DX_TRY(hipMemcpy(header, s.text_base[input] + r.head_off, n, hipMemcpyDeviceToHost));
     header[n] = 0;
     if (n_bases) *n_bases = r.seq_len;
     return FQTK_OK;

@@ -14,6 +14,7 @@
 //     owner, no locks, input order preserved per file as in the sequential reference loop).
 // All matching goes through libfqtk_match.so; there is no CPU matching path here.
 #include <fcntl.h>
+#include <sys/mman.h>
 #include <sys/resource.h>
 #include <malloc.h>
 #include <sys/stat.h>
@@ -112,6 +113,7 @@ struct Options {
     unsigned long chunk_reads = 1ul << 17;
     bool chunk_given = false;
     bool host_output = false;        // --host-output: format and compress the records on the host (the reference's way)
+    bool host_inflate = false;       // --host-inflate: BGZF inputs are inflated by the reader threads even where the device could
 };
 
 const char *kUsage =
@@ -135,7 +137,10 @@ const char *kUsage =
     "                                              reference does) instead of on the GPU, which is the default: there the\n"
     "                                              inputs' text goes to the device, records are formatted and DEFLATE-compressed\n"
     "                                              in HBM and whole BGZF members come back (additive flag; alias --no-gpu-bgzf;\n"
-    "                                              --gpu-bgzf is accepted and means the default)\n";
+    "                                              --gpu-bgzf is accepted and means the default)\n"
+    "      --host-inflate                          inflate BGZF inputs on the host CPUs.  Default when every input is a BGZF file (bgzip,\n"
+    "                                              htslib, fqtk's own outputs) and one device is used: the compressed members go to\n"
+    "                                              the device and are inflated there (additive flag)\n";
 
 bool parse_ulong(const std::string &s, unsigned long *out) {
     if (s.empty()) return false;
@@ -222,6 +227,7 @@ Options parse_args(int argc, char **argv) {
         else if (a == "--chunk-reads") { num(&o.chunk_reads); o.chunk_given = true; }
         else if (a == "--gpu-bgzf") o.host_output = false;
         else if (a == "--host-output" || a == "--no-gpu-bgzf") o.host_output = true;
+        else if (a == "--host-inflate") o.host_inflate = true;
         else if (a == "--help" || a == "-h") { std::fputs(kUsage, stdout); std::exit(0); }
         else die("unexpected argument '" + a + "' found\n\n" + kUsage);
     }
@@ -449,6 +455,61 @@ void write_all(int fd, const uint8_t *p, size_t n, const std::string &path) {
     }
 }
 
+// A BGZF input whose members go to the device as they are (fqtk_demuxer_feed): the file is mapped, this walks the member
+// headers (18 bytes: gzip header with the 'BC' extra field, BSIZE) and trailers (CRC-32, ISIZE) and hands out runs of
+// whole members.  Nothing is inflated here.
+struct BgzfFile {
+    std::string path;
+    int fd = -1;
+    const uint8_t *map = nullptr;
+    size_t size = 0, pos = 0;
+    bool open(const std::string &p, std::string *err) {
+        path = p;
+        fd = ::open(p.c_str(), O_RDONLY | O_CLOEXEC);
+        struct stat st;
+        if (fd < 0 || fstat(fd, &st) != 0 || !S_ISREG(st.st_mode) || st.st_size <= 0) { *err = "Error opening input files for reading: " + p; return false; }
+        void *m = mmap(nullptr, (size_t)st.st_size, PROT_READ, MAP_PRIVATE, fd, 0);
+        if (m == MAP_FAILED) { *err = "Error opening input files for reading: " + p; return false; }
+        map = static_cast<const uint8_t *>(m);
+        size = (size_t)st.st_size;
+        madvise(m, size, MADV_SEQUENTIAL);
+        return true;
+    }
+    // is every member of the file a standard BGZF one?  (a look at the first few: the rest is checked as it is walked)
+    static bool looks_like_bgzf(const uint8_t *h, size_t n) {
+        return n >= 18 && h[0] == 0x1f && h[1] == 0x8b && h[2] == 8 && h[3] == 4 && h[10] == 6 && h[11] == 0 && h[12] == 'B' && h[13] == 'C' && h[14] == 2 && h[15] == 0;
+    }
+    // Members from pos on while the run stays below the limits (at least one).  [*from, *upto): their bytes in the map.
+    bool next_run(size_t max_bytes, size_t max_text, std::vector<fqtk_inflate_member> *out, size_t *from, size_t *upto, std::string *err) {
+        out->clear();
+        *from = pos;
+        size_t text = 0;
+        while (pos < size) {
+            const uint8_t *h = map + pos;
+            if (!looks_like_bgzf(h, size - pos)) { *err = "Unexpected error parsing FASTQs: " + path + " is not BGZF throughout (a member without the BC field at byte " + std::to_string(pos) + "): rerun with --host-inflate"; return false; }
+            const size_t bsize = (size_t)h[16] + ((size_t)h[17] << 8) + 1;
+            if (bsize < 26 || pos + bsize > size) { *err = "Unexpected error parsing FASTQs: bad BGZF block size in " + path; return false; }
+            uint32_t crc, isize;
+            std::memcpy(&crc, h + bsize - 8, 4);
+            std::memcpy(&isize, h + bsize - 4, 4);
+            if (isize > 65536) { *err = "Unexpected error parsing FASTQs: bad BGZF block (more than 64 KiB of text) in " + path; return false; }
+            if (!out->empty() && (pos + bsize - *from > max_bytes || text + isize > max_text)) break;
+            fqtk_inflate_member m;
+            std::memset(&m, 0, sizeof m);
+            m.payload_off = pos + 18 - *from;
+            m.payload_len = (uint32_t)(bsize - 26);
+            m.isize = isize;
+            m.crc = crc;
+            out->push_back(m);
+            text += isize;
+            pos += bsize;
+        }
+        *upto = pos;
+        return true;
+    }
+    bool at_end() const { return pos >= size; }
+};
+
 // Which configurations the device pipeline takes (the limits of include/fqtk_demux.h); anything else is formatted on the host.
 bool gpu_output_supported(const Plan &plan, std::string *why) {
     if (plan.rs.size() > FQTK_DEMUX_MAX_INPUTS) { *why = "more than " + std::to_string(FQTK_DEMUX_MAX_INPUTS) + " inputs"; return false; }
@@ -471,6 +532,19 @@ bool gpu_output_supported(const Plan &plan, std::string *why) {
         }
     }
     const uint32_t L = (uint32_t)samples[0].barcode.size();
+
+    // ---- BGZF inputs: their members go to the device compressed and are inflated there (fqtk_demuxer_feed), when every
+    // input is one and a single device takes all chunks (the fed text lives on one device)
+    std::vector<std::unique_ptr<BgzfFile>> bgzf_in;
+    bool fed_mode = G == 1 && !opt.host_inflate && !env_on("FQTK_HOST_INFLATE");
+    for (size_t i = 0; i < n_inputs && fed_mode; ++i) {
+        if (sources[i]->kind() != FastqSource::Kind::Bgzf) { fed_mode = false; break; }
+        std::string e;
+        bgzf_in.push_back(std::make_unique<BgzfFile>());
+        if (!bgzf_in.back()->open(opt.inputs[i], &e)) fed_mode = false;   // (a pipe: the reader threads inflate it)
+    }
+    if (!fed_mode) bgzf_in.clear();
+    else info("BGZF inputs: members are inflated on the device.");
 
     // ---- devices: matcher + record pipeline each (their bring-up overlaps the first reads and the file creation)
     std::vector<fqtk_matcher *> matchers(G, nullptr);
@@ -543,7 +617,7 @@ bool gpu_output_supported(const Plan &plan, std::string *why) {
     // unmapper mostly wait)
     const bool count_assist = n_large && std::min<size_t>(opt.threads, usable_cpus()) >= 16 && !env_on("FQTK_NO_COUNT_ASSISTANT");
     if (const char *e = std::getenv("FQTK_COPY_HELPERS")) n_helpers = std::min<size_t>(8, std::max<size_t>(1, (size_t)std::atoi(e)));
-    for (size_t i = 0; i < n_inputs; ++i) {
+    for (size_t i = 0; i < n_inputs && !fed_mode; ++i) {
         if (split_ok && sources[i]->mapped() && sources[i]->mapped_size() >= (1ull << 30)) {
             cuts[i] = std::make_unique<BoundedQueue<std::pair<FastqSource::RawCut, std::string>>>(2);
             for (size_t h = 0; h < n_helpers; ++h) helpers[i].push_back(std::make_unique<CopyHelper>());
@@ -719,9 +793,18 @@ bool gpu_output_supported(const Plan &plan, std::string *why) {
     };
     // ---- this thread: cuts the stream of chunks, chunk k to device k mod G; every device's own thread submits its chunks
     struct Job { size_t n = 0; uint64_t first_record = 0; std::vector<RawChunk> in; };
+    std::vector<uint64_t> fed_end(n_inputs, 0);   // (collector thread) fed text: where the last chunk collected left each input
     std::atomic<bool> first_submit{false};
     double t_first = 0;
     auto submit_chunk = [&](int g, int slot, uint64_t, Job &j) -> Flight {
+        if (fed_mode) {
+            const uint64_t th = tick();
+            if (fqtk_demuxer_submit_fed(demuxers[g], slot, (uint32_t)j.n) != FQTK_OK) die(std::string("GPU record pipeline: ") + fqtk_last_error());
+            g_times.main_handoff += tick() - th;
+            Flight f;
+            f.dev = g; f.slot = slot; f.n = (uint32_t)j.n; f.first_record = j.first_record;
+            return f;
+        }
         std::vector<const uint8_t *> text(n_inputs);
         std::vector<uint64_t> text_len(n_inputs);
         for (size_t i = 0; i < n_inputs; ++i) { text[i] = reinterpret_cast<const uint8_t *>(j.in[i].buf->data); text_len[i] = j.in[i].bytes; }
@@ -741,13 +824,112 @@ bool gpu_output_supported(const Plan &plan, std::string *why) {
         if (fqtk_demuxer_collect(demuxers[g], slot, &r) != FQTK_OK) die(std::string("GPU record pipeline: ") + fqtk_last_error());
         g_times.main_gpu_wait += tick() - t0;
         if (r.error) chunk_error(f, r);
+        if (r.text_end) for (size_t i = 0; i < n_inputs; ++i) fed_end[i] = r.text_end[i];
         write_result(r);
         blocks_total += r.n_blocks;
         skipped += r.n_skipped;
     };
     ChunkDispatcher<Job, Flight> dispatch(G, FQTK_DEMUX_SLOTS, submit_chunk, collect_chunk);
     uint64_t k = 0, records = 0, next_log = 1000000;
-    for (;; ++k) {
+    // ---- fed mode: a feeder thread per input hands runs of members to the device; this thread cuts chunks by line counts
+    std::mutex fmu;
+    std::condition_variable fcv;
+    std::vector<uint64_t> lines_fed(n_inputs, 0);
+    std::vector<char> fed_done(n_inputs, 0);
+    std::string feed_error;
+    uint64_t lines_taken = 0;   // per input: 4 x templates submitted
+    bool feed_stop = false;
+    if (fed_mode) {
+        // An input is fed again when it is less than two chunks ahead of the chunks cut so far.  A feed is a run of members of up
+        // to 32 MB / 256 MB of text: a member takes a wavefront a few milliseconds however many are in flight, and the device
+        // holds ~4 800 of them at once, so small feeds leave it idle (16 GB/s of text with 96 MB feeds, 3-4x that when full).
+        const uint64_t high_water = 4ull * chunk * 2;
+        for (size_t i = 0; i < n_inputs; ++i)
+            readers.emplace_back([&, i] {
+                BgzfFile &bf = *bgzf_in[i];
+                void *pin = nullptr;
+                size_t pin_cap = 0;
+                std::vector<fqtk_inflate_member> run;
+                auto fail = [&](const std::string &e) {
+                    std::lock_guard<std::mutex> lk(fmu);
+                    if (feed_error.empty()) feed_error = e;
+                    fed_done[i] = 1;
+                    fcv.notify_all();
+                };
+                for (;;) {
+                    {
+                        std::unique_lock<std::mutex> lk(fmu);
+                        fcv.wait(lk, [&] { return feed_stop || lines_fed[i] < lines_taken + high_water; });
+                        if (feed_stop) break;
+                    }
+                    size_t from = 0, upto = 0;
+                    std::string e;
+                    const uint64_t t0 = tick();
+                    static const size_t run_text = [] { const char *v = std::getenv("FQTK_FEED_TEXT_MB"); return (size_t)(v && *v ? std::atol(v) : 256) << 20; }();
+                    if (!bf.next_run(run_text / 4, run_text, &run, &from, &upto, &e)) { fail(e); break; }
+                    const size_t bytes = upto - from;
+                    if (bytes + 64 > pin_cap) {
+                        if (pin) fqtk_pinned_free(pin);
+                        pin_cap = bytes + bytes / 4 + 65536;
+                        if (fqtk_pinned_alloc(pin_cap, &pin) != FQTK_OK) { fail(std::string("cannot allocate page-locked memory: ") + fqtk_last_error()); break; }
+                    }
+                    if (bytes) std::memcpy(pin, bf.map + from, bytes);
+                    if (upto > (64u << 20)) madvise(const_cast<uint8_t *>(bf.map), (upto - (64u << 20)) & ~(size_t)4095, MADV_DONTNEED);
+                    g_times.reader_parse += tick() - t0;
+                    const bool last = bf.at_end();
+                    uint64_t fed = 0;
+                    const uint64_t t1 = tick();
+                    if (fqtk_demuxer_feed(demuxers[0], (uint32_t)i, static_cast<const uint8_t *>(pin), bytes, run.data(), (uint32_t)run.size(), last ? 1 : 0, &fed) != FQTK_OK) {
+                        fail("Unexpected error parsing FASTQs: " + std::string(fqtk_last_error()) + " in " + bf.path);
+                        break;
+                    }
+                    g_times.reader_push += tick() - t1;
+                    {
+                        std::lock_guard<std::mutex> lk(fmu);
+                        lines_fed[i] = fed;
+                        if (last) fed_done[i] = 1;
+                    }
+                    fcv.notify_all();
+                    if (last) break;
+                }
+                if (pin) fqtk_pinned_free(pin);
+            });
+        for (;; ++k) {
+            size_t n = chunk;
+            {
+                std::unique_lock<std::mutex> lk(fmu);
+                const uint64_t tw = tick();
+                fcv.wait(lk, [&] {
+                    if (!feed_error.empty()) return true;
+                    for (size_t i = 0; i < n_inputs; ++i)
+                        if (!fed_done[i] && lines_fed[i] < lines_taken + 4ull * chunk) return false;
+                    return true;
+                });
+                g_times.main_wait += tick() - tw;
+                if (!feed_error.empty()) die(feed_error);
+                for (size_t i = 0; i < n_inputs; ++i) n = std::min<size_t>(n, (size_t)((lines_fed[i] - lines_taken) / 4));
+            }
+            if (n == 0) break;
+            if (!first_submit.exchange(true)) t_first = now_s();
+            Job j;
+            j.n = n;
+            j.first_record = records;
+            dispatch.push(std::move(j));
+            records += n;
+            {
+                std::lock_guard<std::mutex> lk(fmu);
+                lines_taken += 4ull * n;
+            }
+            fcv.notify_all();
+            while (records >= next_log) { info("demultiplexed %llu records", (unsigned long long)next_log); next_log += 1000000; }
+        }
+        {
+            std::lock_guard<std::mutex> lk(fmu);
+            feed_stop = true;
+        }
+        fcv.notify_all();
+    }
+    for (; !fed_mode; ++k) {
         Job j;
         j.in.resize(n_inputs);
         for (size_t i = 0; i < n_inputs; ++i) {
@@ -768,8 +950,35 @@ bool gpu_output_supported(const Plan &plan, std::string *why) {
         while (records >= next_log) { info("demultiplexed %llu records", (unsigned long long)next_log); next_log += 1000000; }
     }
     for (auto &t : readers) t.join();
+    if (fed_mode && !feed_error.empty()) die(feed_error);
     info("Finished reading input FASTQs.");
     dispatch.finish();
+    if (fed_mode) {
+        // what lies behind the last record of every input: blank lines (and the newline the device added) -- anything else is
+        // a truncated record, or records the other inputs do not have
+        std::vector<uint8_t> tail(1u << 20);
+        for (size_t i = 0; i < n_inputs; ++i) {
+            uint64_t left = 0;
+            if (fqtk_demuxer_fed_tail(demuxers[0], (uint32_t)i, records ? fed_end[i] : 0, tail.data(), tail.size(), &left) != FQTK_OK) die(fqtk_last_error());
+            const size_t have = (size_t)std::min<uint64_t>(left, tail.size());
+            bool blank = true;
+            size_t lines = 0;
+            for (size_t q = 0; q < have; ++q) {
+                if (tail[q] == '\n') ++lines;
+                else if (tail[q] != '\r') blank = false;
+            }
+            if (blank && left <= tail.size()) continue;
+            const bool whole_file_fed = fed_done[i] && bgzf_in[i]->at_end();
+            if (lines >= 4 || !whole_file_fed) {
+                size_t short_one = 0;
+                for (size_t q = 0; q < n_inputs; ++q) if (q != i) short_one = q;
+                die("FASTQ sources out of sync at records: input " + opt.inputs[short_one] + " ended after a different number of records");
+            }
+            die("Unexpected error parsing FASTQs: truncated record at end of " + opt.inputs[i]);
+        }
+        double inf_s = 0;
+        if (g_timing && fqtk_demuxer_inflate_seconds(demuxers[0], &inf_s) == FQTK_OK) info("device seconds inflating BGZF members: %.3f", inf_s);
+    }
     for (size_t g = 0; g < G; ++g) {   // what is left in the files' open blocks
         fqtk_demux_result r;
         if (fqtk_demuxer_flush(demuxers[g], &r) != FQTK_OK) die(std::string("GPU record pipeline: ") + fqtk_last_error());

@@ -31,6 +31,7 @@
 #include <stddef.h>
 #include <stdint.h>
 
+#include "fqtk_inflate.h"
 #include "fqtk_match.h"
 
 #ifdef __cplusplus
@@ -83,6 +84,8 @@ typedef struct fqtk_demux_result {
     uint32_t n_skipped;        /* of them dropped for too few bases */
     int error;                 /* FQTK_DEMUX_ERR_* */
     uint32_t error_input, error_template, error_detail;
+    const uint64_t *text_end;  /* chunks of fed text (fqtk_demuxer_submit_fed): per input, the position in the input's whole text
+                                  of the byte behind the chunk's last record; NULL otherwise */
 } fqtk_demux_result;
 
 /* The matcher decides device and sample count; it must outlive the demuxer and is used by it (do not enqueue on it
@@ -103,6 +106,32 @@ int fqtk_demuxer_submit(fqtk_demuxer *d, int slot, const uint8_t *const *text, c
 /* Blocks until the text of the chunk on `slot` has been copied to the device: the caller's buffers may be reused
  * (the chunk itself is still in flight). */
 int fqtk_demuxer_text_done(fqtk_demuxer *d, int slot);
+
+/* ---- BGZF inputs inflated on the device (the input side of demux.rs:844-849) --------------------------------------------
+ * Instead of text the host may hand over the BGZF members of every input as they lie in the file (fqtk_inflate.h says
+ * what a member is): their text is inflated on the device, checked against the members' CRC-32 / ISIZE, and stays there;
+ * a chunk is cut out of it by line counts, so the host never sees the text.  A run either feeds or submits text.
+ *
+ * fqtk_demuxer_feed: `bytes` (len of them, page-locked for a fast copy) hold n_members members of input `input` in file
+ * order (members[j].payload_off is relative to bytes; out_off is ignored).  Blocks until they are inflated -- other
+ * inputs' feeds and the chunks in flight go on meanwhile (one thread per input may feed) -- and returns the number of lines
+ * (newlines) fed for this input so far.  `last` != 0 with the input's last members (n_members may be 0): a newline is
+ * added behind the text, so that a final line without one counts (the blank line this makes otherwise is the caller's to
+ * ignore).  FQTK_EINVAL with "corrupt BGZF block k: ..." when a member does not inflate or its CRC-32 / length is wrong. */
+int fqtk_demuxer_feed(fqtk_demuxer *d, uint32_t input, const uint8_t *bytes, uint64_t len, const fqtk_inflate_member *members,
+                      uint32_t n_members, int last, uint64_t *lines_fed);
+
+/* The next n_templates records (4 n_templates lines) of every input's fed text as one chunk on `slot`: as
+ * fqtk_demuxer_submit, but nothing is copied.  Every input must have been fed that many lines beyond what earlier chunks
+ * took.  The result's text_end says where each input's text was left. */
+int fqtk_demuxer_submit_fed(fqtk_demuxer *d, int slot, uint32_t n_templates);
+
+/* The fed text of `input` from position `pos` to its end (*n_bytes; the first min(*n_bytes, cap) of them in buf): what
+ * lies behind the last record (end-of-file checks).  Only text no chunk has consumed in full is still there. */
+int fqtk_demuxer_fed_tail(fqtk_demuxer *d, uint32_t input, uint64_t pos, uint8_t *buf, size_t cap, uint64_t *n_bytes);
+
+/* Device seconds spent inflating (all inputs). */
+int fqtk_demuxer_inflate_seconds(fqtk_demuxer *d, double *seconds);
 
 /* Waits for the chunk on `slot`.  FQTK_OK with res->error == 0: res holds the members to append to the files.
  * res->error != 0: nothing of the chunk was written into the result; the run cannot continue. */

@@ -1,0 +1,120 @@
+"""`fqtk demux` on BGZF inputs whose members are inflated on the device (fqtk_demuxer_feed / submit_fed,
+include/fqtk_demux.h; the reference reads every input through a gz-aware reader, demux.rs:844-849): outputs and metrics
+must equal those of the same run with --host-inflate (the reader threads inflate, the text crosses PCIe), over several
+chunks, inputs of very different record sizes (members and chunks never line up), a last line without a newline, blank
+lines at the end; corrupt members, truncated records and inputs of different lengths are the same errors."""
+import os
+import struct
+import zlib
+
+import numpy as np
+import pytest
+
+from tests import hostlib as H
+
+pytestmark = pytest.mark.gpu
+
+
+def _records(n, rng, lengths, prefix="q"):
+    acgt = np.frombuffer(b"ACGT", dtype=np.uint8)
+    out = []
+    for i in range(n):
+        L = int(rng.choice(lengths))
+        bases = acgt[rng.integers(0, 4, L)].tobytes().decode()
+        quals = "".join(chr(33 + int(q)) for q in rng.integers(2, 41, L))
+        out.append((f"{prefix}:{i} x", bases, quals))
+    return out
+
+
+def _text(records, last_newline=True):
+    t = "".join(f"@{h}\n{b}\n+\n{q}\n" for h, b, q in records)
+    return (t if last_newline else t[:-1]).encode()
+
+
+def _write_bgzf(path, text, level=5, member=None):
+    """BGZF file of `text`; `member`: text bytes per member (default: 65 280 like bgzip), small values make many members."""
+    if member is None:
+        data = H.bgzf(text, level)
+    else:
+        data = b""
+        for o in range(0, len(text), member):
+            piece = text[o:o + member]
+            c = zlib.compressobj(level, zlib.DEFLATED, -15)
+            payload = c.compress(piece) + c.flush()
+            data += (b"\x1f\x8b\x08\x04\0\0\0\0\0\xff\x06\0BC\x02\0" + struct.pack("<H", 18 + len(payload) + 8 - 1) + payload +
+                     struct.pack("<II", zlib.crc32(piece), len(piece)))
+        data += bytes.fromhex("1f8b08040000000000ff0600424302001b0003000000000000000000")
+    with open(path, "wb") as fh:
+        fh.write(data)
+    return str(path)
+
+
+def _meta(tmp, barcodes):
+    p = os.path.join(str(tmp), "meta.tsv")
+    with open(p, "w") as fh:
+        fh.write("sample_id\tbarcode\n" + "".join(f"S{i}\t{b}\n" for i, b in enumerate(barcodes)))
+    return p
+
+
+def _outputs(out):
+    return {f: H.read_fastq(out / f) for f in sorted(os.listdir(out)) if f.endswith(".fq.gz")}
+
+
+def test_device_inflate_equals_host_inflate_over_many_chunks(tmp_path, monkeypatch):
+    rng = np.random.default_rng(11)
+    n = 40_000
+    bcs = ["ACGTACGT", "TTGCAATG", "GGGGCCCC", "ATATATAT", "CGCGAATT"]
+    r1 = _records(n, rng, [150, 151, 36], "r")
+    i1 = [(h, (bcs[int(rng.integers(0, 5))] if rng.random() < 0.9 else "NNNNNNNN"), "F" * 8) for h, _, _ in r1]
+    r2 = [(h, b[::-1][:100], q[:100]) for h, b, q in _records(n, rng, [100], "r")]
+    f1 = _write_bgzf(tmp_path / "r1.fastq.gz", _text(r1, last_newline=False))                   # last line without '\n'
+    f2 = _write_bgzf(tmp_path / "i1.fastq.gz", _text(i1) + b"\n\n", member=3000)                # many small members, blank lines at the end
+    f3 = _write_bgzf(tmp_path / "r2.fastq.gz", _text(r2), level=1)
+    meta = _meta(tmp_path, bcs)
+    runs = {}
+    for name, extra in (("device", []), ("host", ["--host-inflate"]), ("device_small_arenas", [])):
+        out = tmp_path / name
+        # (arenas of 1 MB: the fed text changes arena every few chunks, windows straddle the move)
+        monkeypatch.setenv("FQTK_FED_ARENA_MIN", "1000000") if name == "device_small_arenas" else monkeypatch.delenv("FQTK_FED_ARENA_MIN", raising=False)
+        r = H.run_demux([f1, f2, f3], ["+T", "8B", "+T"], meta, out, threads=8, extra=["--chunk-reads", "3000"] + extra)
+        assert r.returncode == 0, r.stderr
+        assert ("inflated on the device" in r.stderr) == (name != "host"), r.stderr
+        runs[name] = (_outputs(out), open(out / "demux-metrics.txt").read())
+    assert runs["device"][1] == runs["host"][1]
+    assert runs["device"][0].keys() == runs["host"][0].keys()
+    for f in runs["host"][0]:
+        assert runs["device"][0][f] == runs["host"][0][f], f
+        assert runs["device_small_arenas"][0][f] == runs["host"][0][f], f
+    assert runs["device_small_arenas"][1] == runs["host"][1]
+    assert sum(len(v) for f, v in runs["device"][0].items() if ".R1." in f) == n
+
+
+def test_device_inflate_reports_what_the_host_path_reports(tmp_path):
+    rng = np.random.default_rng(12)
+    bcs = ["ACGTACGT", "TTGCAATG"]
+    meta = _meta(tmp_path, bcs)
+    n = 5000
+    r1 = _records(n, rng, [80], "r")
+    i1 = [(h, bcs[i & 1], "F" * 8) for i, (h, _, _) in enumerate(r1)]
+    good1 = _write_bgzf(tmp_path / "r1.fastq.gz", _text(r1))
+    good2 = _write_bgzf(tmp_path / "i1.fastq.gz", _text(i1), member=5000)
+    # (a) a corrupt member: one payload byte flipped in the middle of the file
+    raw = bytearray(open(good1, "rb").read())
+    raw[len(raw) // 2] ^= 0x10
+    bad = str(tmp_path / "bad.fastq.gz")
+    open(bad, "wb").write(bytes(raw))
+    r = H.run_demux([bad, good2], ["+T", "8B"], meta, tmp_path / "o1", threads=8, extra=["--chunk-reads", "1000"])
+    assert r.returncode != 0 and "corrupt BGZF block" in r.stderr, r.stderr
+    assert not list((tmp_path / "o1").glob("*.fq.gz"))
+    # (b) an input that ends early
+    short = _write_bgzf(tmp_path / "short.fastq.gz", _text(i1[:n - 7]), member=5000)
+    r = H.run_demux([good1, short], ["+T", "8B"], meta, tmp_path / "o2", threads=8, extra=["--chunk-reads", "1000"])
+    assert r.returncode != 0 and "out of sync" in r.stderr, r.stderr
+    # (c) a record cut off at the end of a file
+    cut = _write_bgzf(tmp_path / "cut.fastq.gz", _text(r1)[:-60])
+    r = H.run_demux([cut, good2], ["+T", "8B"], meta, tmp_path / "o3", threads=8, extra=["--chunk-reads", "1000"])
+    assert r.returncode != 0 and ("truncated record" in r.stderr or "out of sync" in r.stderr or "lengths differ" in r.stderr), r.stderr
+    # (d) the good pair demultiplexes
+    r = H.run_demux([good1, good2], ["+T", "8B"], meta, tmp_path / "o4", threads=8, extra=["--chunk-reads", "1000"])
+    assert r.returncode == 0 and "inflated on the device" in r.stderr, r.stderr
+    assert sum(len(v) for v in _outputs(tmp_path / "o4").values()) == n
