@@ -467,6 +467,10 @@ def main() -> int:
             scopes["bgzf_kernel"] = bgzf_bench.measure(blocks=2048, reps=3, where_list=("hbm",))
             scopes["bgzf_kernel"]["what"] = ("fqtk::bgzf::deflate_kernel alone: 2048 BGZF blocks of Illumina-style text in HBM -> DEFLATE payloads + CRC-32 in HBM "
                                              "(the compressor of scope E's output path, BgzfCompressor demux.rs:755-798); ratio = output / input")
+            import inflate_bench   # (tools/)
+            scopes["inflate_kernel"] = inflate_bench.measure(members=4096, reps=3)
+            scopes["inflate_kernel"]["what"] = ("fqtk::inflate::inflate_kernel + member_check_kernel alone: 4096 BGZF members (zlib -6, Illumina-style text) in HBM -> text, "
+                                                "CRC-32 / ISIZE check and newline counts in HBM (the decoder of scope E_bgzf's input path, demux.rs:844-849)")
             tmp = scope_bench.scratch_dir(args.e2e_templates * 900)
             try:
                 expect = None
@@ -494,6 +498,12 @@ def main() -> int:
                     scopes["E_gz"] = scope_bench.scope_e(n_e // 4, e_threads, True, tmp, exp4, inputs=(gz, meta))
                     scopes["E_gz"]["host_cpus_usable"] = host_cores
                     scopes["E_gz"]["gz_inputs"] = "one gzip member per file (level 1), decoded by several host threads per file"
+                    # BGZF inputs (bgzip / htslib / fqtk's own outputs): the members cross PCIe compressed and are inflated on the
+                    # device, one wavefront per member (include/fqtk_inflate.h, fqtk_demuxer_feed); the host never sees the text
+                    bgz = scope_bench.bgzf_repeated(sub)
+                    scopes["E_bgzf"] = scope_bench.scope_e(n_e // 4, e_threads, "bgzf", tmp, exp4, inputs=(bgz, meta))
+                    scopes["E_bgzf"]["host_cpus_usable"] = host_cores
+                    scopes["E_bgzf"]["gz_inputs"] = "BGZF (65 280-byte members, level 1), inflated on the device"
             finally:
                 shutil.rmtree(tmp, ignore_errors=True)
             out["scopes"] = scopes

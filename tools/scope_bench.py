@@ -273,6 +273,44 @@ def _gzip_repeated(args):
     return path + ".gz"
 
 
+def _bgzf_repeated(args):
+    path, block_bytes, reps = args
+    size = os.path.getsize(path)
+    assert size % block_bytes == 0
+    reps = reps or size // block_bytes
+    with open(path, "rb") as fh:
+        block = fh.read(block_bytes)
+    lib = C.CDLL(os.path.join(ROOT, "fqtk_amd", "lib", "libfqtk_host.so"))
+    body = bytearray()
+    for o in range(0, len(block), 64 * 65280):
+        data = block[o:o + 64 * 65280]
+        cap = len(data) + len(data) // 8 + 65536
+        out = (C.c_uint8 * cap)()
+        n = C.c_size_t()
+        assert lib.fqtk_host_bgzf(data, C.c_size_t(len(data)), 1, out, C.c_size_t(cap), C.byref(n)) == 0
+        body += bytes(out[:n.value - 28])                            # without the per-call EOF marker
+    with open(path + ".bgz", "wb") as fo:
+        for _ in range(reps):
+            fo.write(body)
+        fo.write(bytes([0x1f, 0x8b, 0x08, 0x04, 0, 0, 0, 0, 0, 0xff, 0x06, 0, 0x42, 0x43, 0x02, 0, 0x1b, 0, 0x03, 0, 0, 0, 0, 0, 0, 0, 0, 0]))
+    return path + ".bgz"
+
+
+def bgzf_repeated(paths, block_records=1_000_000, reps=None):
+    """path -> path.bgz: BGZF (members of 65 280 bytes of text, level 1, EOF marker: what bgzip writes) of a file that
+    repeats its first block_records records: the block's members are compressed once and written size / block times
+    (reps given: the file IS one block, and the BGZF file holds it reps times -- inputs larger than the scratch could hold as text)."""
+    from concurrent.futures import ProcessPoolExecutor
+    jobs = []
+    for p in paths:
+        with open(p, "rb") as fh:
+            head = fh.read(1 << 16)
+        rec = head.index(b"\n", head.index(b"\n", head.index(b"\n", head.index(b"\n") + 1) + 1) + 1) + 1   # fixed-width records
+        jobs.append((p, rec * block_records, reps))
+    with ProcessPoolExecutor(4) as ex:
+        return list(ex.map(_bgzf_repeated, jobs))
+
+
 def gzip_single_stream(paths, block_records=1_000_000):
     """path -> path.gz: ONE gzip member per file (one serial DEFLATE stream, level 1, what `gzip -1` / bcl2fastq write)
     of a file that repeats its first block_records records: the block is compressed once and its deflate blocks are
