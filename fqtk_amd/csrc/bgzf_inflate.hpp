@@ -119,7 +119,7 @@ struct Shared {
     uint16_t perm_d[32];
     uint8_t lens[320 + 8];     // the block's code lengths: hlit literal/length ones, then hdist distance ones
     uint32_t cl_tab[128];      // the code-length code: 7 index bits -> symbol << 16 | length (0: no such code)
-    uint32_t run[16];          // scratch of the builders
+    uint32_t own[64];          // per byte of the 64 being written: lane + 1 of a token that starts there
 };
 
 struct MemberArgs {
@@ -134,7 +134,8 @@ struct MemberArgs {
 // ---- the wave -------------------------------------------------------------------------------------------------------
 // W provides: lane() 0..63; ballot(bool) -> uint64; readlane(uint32 v, uint32 l) (l the same in all lanes);
 // uniform(uint32 v) (a value known to be the same in all lanes: the device keeps it in a scalar register);
-// scan_incl(uint32 v) inclusive prefix sum over the lanes; barrier() (LDS written before is visible to
+// scan_incl(uint32 v) inclusive prefix sum over the lanes; scan_max_incl(uint32 v) inclusive prefix maximum;
+// shuffle(uint32 v, uint32 l) lane l's v (l may differ between lanes); rcp(float) ~ 1 / x; barrier() (LDS written before is visible to
 // all lanes after); fence_global() (global stores issued by any lane before are visible to the loads of all lanes after);
 // atomic_inc_lds(uint16*/uint32*).
 
@@ -452,57 +453,98 @@ FQTK_UNROLL
                 const uint64_t bits = s ? (lo >> s) | ((uint64_t)d2 << (64u - s)) : lo;
                 Token t = decode_token<false>(S, bits);
                 uint64_t slow = w.ballot((t.flags & kTokSlow) != 0u);
-                // the chain of real tokens
-                uint32_t meta = t.nbits | (t.flags << 8);
+                // the chain of real tokens: one scalar step per token.  A lane's step is its token's bits; the rare ones (a long
+                // code to resolve, no code at all, end of block) step 0x80 -- out of the window -- so that the walk has ONE exit
+                // test, and are looked at behind it.
+                uint32_t meta = t.flags & (kTokSlow | kTokBad | kTokEob) ? 0x80u : t.nbits;
                 uint64_t chain = 0;
                 uint32_t cur = 0;
                 bool eob = false;
-                uint32_t bad = 0;
-                while (cur < 64u) {
-                    uint32_t m = w.readlane(meta, cur);
-                    if ((m >> 8) & kTokSlow) {
-                        // a long code on the chain: every lane that met one resolves it now (rare)
+                for (;;) {
+                    uint32_t m;
+                    do {
+                        m = w.readlane(meta, cur);
+                        chain |= 1ull << cur;
+                        cur += m;
+                    } while (cur < 64u);
+                    if (!(m & 0x80u)) break;
+                    cur -= 0x80u;   // a rare one: back on its lane
+                    if (slow) {     // long codes: every lane that met one resolves it now (once per window at most), the walk goes on from here
                         if ((slow >> lane) & 1ull) {
                             t = decode_token<true>(S, bits);
-                            meta = t.nbits | (t.flags << 8);
+                            meta = t.flags & (kTokBad | kTokEob) ? 0x80u : t.nbits;
                         }
                         slow = 0;
-                        m = w.readlane(meta, cur);
+                        continue;
                     }
-                    if ((m >> 8) & kTokBad) { bad = kErrBadCode; break; }
-                    chain |= 1ull << cur;
-                    cur += m & 0xFFu;
-                    if ((m >> 8) & kTokEob) { eob = true; break; }
+                    if (w.readlane(t.flags, cur) & kTokBad) return kErrBadCode;
+                    cur += w.readlane(t.nbits, cur);   // end of block
+                    eob = true;
+                    break;
                 }
-                if (bad) return bad;
                 const bool mine = ((chain >> lane) & 1ull) != 0ull;
                 const uint32_t my_out = mine ? t.outlen : 0u;
                 const uint32_t incl = w.scan_incl(my_out);
                 const uint32_t my_pos = out_pos + incl - my_out;
                 const uint32_t produced = w.readlane(incl, 63u);
                 if (out_pos + produced > a.isize) return kErrOutput;
-                if (mine && my_out == 1u && !(t.flags & kTokMatch)) a.out[my_pos] = (uint8_t)t.value;
-                uint64_t matches = w.ballot(mine && (t.flags & kTokMatch) != 0u);
-                while (matches) {
-                    const uint32_t l = (uint32_t)__builtin_ctzll(matches);
-                    matches &= matches - 1ull;
-                    const uint32_t len = w.readlane(t.outlen, l), dist = w.readlane(t.value, l), pos = w.readlane(my_pos, l);
-                    if (dist > pos) return kErrDistance;
-                    const uint32_t src = pos - dist;
-                    if (src + (len < dist ? len : dist) > safe) {
-                        w.fence_global();
-                        safe = pos;
-                    }
-                    if (dist >= len) {
-                        for (uint32_t k = lane; k < len; k += 64u) a.out[pos + k] = a.out[src + k];
-                    } else {
-                        // the source repeats with period dist: byte k is source byte k mod dist (k < 258, exact with 20 bits)
-                        const uint32_t inv = ((1u << 20) + dist - 1u) / dist;
-                        for (uint32_t k = lane; k < len; k += 64u) {
-                            const uint32_t q = (k * inv) >> 20;
-                            a.out[pos + k] = a.out[src + (k - q * dist)];
+                // ---- the window's bytes, 64 at a time, one lane per BYTE (not per token): who owns the byte (the last token that
+                // starts at or before it: a prefix maximum over the tokens' starting places), what it is (the owner's literal, or
+                // the byte `distance` back -- in memory already, or another byte of these 64, reached by pointer doubling), one
+                // coalesced store.  A match costs what a literal costs, and the wave waits for memory once per 64 bytes
+                // instead of once per match.
+                if (w.ballot(mine && (t.flags & kTokMatch) != 0u && t.value > my_pos)) return kErrDistance;
+                const uint32_t rel_start = my_pos - out_pos;                  // < 64 * 258
+                const uint32_t packed = ((t.flags & kTokMatch) ? 1u : 0u) | (rel_start << 1) | (t.value << 16);
+                const bool has_out = mine && my_out != 0u;
+                uint32_t carry = 0;                                           // lane + 1 of the token that owns the byte before these 64
+#ifdef FQTK_INFLATE_ABL_NOCOPY   // (developer ablation, tools/ab_inflate.sh: wrong output, same decoding)
+                for (uint32_t base = produced; base < produced; base += 64u) {
+#else
+                for (uint32_t base = 0; base < produced; base += 64u) {
+#endif
+                    S.own[lane] = 0u;
+                    w.barrier();
+                    if (has_out && rel_start >= base && rel_start < base + 64u) S.own[rel_start - base] = lane + 1u;
+                    w.barrier();
+                    uint32_t own = w.scan_max_incl(S.own[lane]);
+                    own = own > carry ? own : carry;
+                    carry = w.readlane(own, 63u);
+                    const uint32_t j = base + lane;
+                    const bool live = j < produced;
+                    const uint32_t info = w.shuffle(packed, own - 1u);        // (byte 0 starts a token: own >= 1)
+                    const uint32_t start = (info >> 1) & 0x7FFFu, val = info >> 16;
+                    uint32_t byte = val & 0xFFu;
+                    uint32_t ptr = lane;                                      // a byte that is known points at itself
+                    bool from_memory = false;
+                    uint32_t src_pos = 0;
+                    if (live && (info & 1u)) {
+                        const uint32_t k = j - start, dist = val;
+                        uint32_t off = k;
+                        if (k >= dist) {                                      // an overlapping match repeats its `dist` bytes: k mod dist (k, dist < 259)
+                            const uint32_t q = (uint32_t)((float)k * w.rcp((float)dist));   // (approximate: corrected below)
+                            int32_t r = (int32_t)k - (int32_t)(q * dist);
+                            if (r < 0) r += (int32_t)dist; else if (r >= (int32_t)dist) r -= (int32_t)dist;
+                            off = (uint32_t)r;
                         }
+                        const int32_t rel = (int32_t)(start + off) - (int32_t)dist;   // the source, counted from the window's first byte
+                        if (rel < (int32_t)base) { from_memory = true; src_pos = (uint32_t)((int32_t)out_pos + rel); }
+                        else ptr = (uint32_t)rel - base;
                     }
+                    if (w.ballot(from_memory && src_pos >= safe)) {           // stores that may still be on their way
+                        w.fence_global();
+                        safe = out_pos + base;
+                    }
+                    if (from_memory) byte = a.out[src_pos];
+                    for (;;) {                                                // ptr -> ptr of ptr until every byte points at a known one (<= 6 rounds)
+                        const uint32_t pp = w.shuffle(ptr, ptr);
+                        if (!w.ballot(pp != ptr)) break;
+                        ptr = pp;
+                    }
+                    byte = w.shuffle(byte, ptr);
+#ifndef FQTK_INFLATE_ABL_NOSTORE
+                    if (live) a.out[out_pos + j] = (uint8_t)byte;
+#endif
                 }
                 out_pos += produced;
                 bit += cur;

@@ -35,6 +35,18 @@ struct DeviceWave {
         v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xC, 0xF, false);   // row_bcast:31
         return v;
     }
+    __device__ inline uint32_t scan_max_incl(uint32_t v) const {
+        auto mx = [](uint32_t a, uint32_t b) { return a > b ? a : b; };
+        v = mx(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xF, 0xF, false));
+        v = mx(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xF, 0xF, false));
+        v = mx(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xF, 0xF, false));
+        v = mx(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xF, 0xF, false));
+        v = mx(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xA, 0xF, false));
+        v = mx(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xC, 0xF, false));
+        return v;
+    }
+    __device__ inline uint32_t shuffle(uint32_t v, uint32_t l) const { return (uint32_t)__builtin_amdgcn_ds_bpermute((int)(l << 2), (int)v); }
+    __device__ inline float rcp(float x) const { return __builtin_amdgcn_rcpf(x); }
     __device__ inline void barrier() const { __syncthreads(); }
     __device__ inline void fence_global() const { __threadfence_block(); }
 };

@@ -23,7 +23,7 @@ class WaveEmu {
     // runs body(lane) for the 64 lanes
     void run(const std::function<void(WaveEmu &)> &body) {
         body_ = &body;
-        stacks_.assign((size_t)kLanesPerWave * kStack, 0);
+        if (stacks_.empty()) stacks_.resize((size_t)kLanesPerWave * kStack);
         done_ = 0;
         for (int l = 0; l < kLanesPerWave; ++l) {
             getcontext(&ctx_[l]);
@@ -59,11 +59,19 @@ class WaveEmu {
         for (int l = 0; l <= cur_; ++l) s += (uint32_t)all[l];
         return s;
     }
+    uint32_t scan_max_incl(uint32_t v) {
+        const uint64_t *all = exchange(v);
+        uint32_t s = 0;
+        for (int l = 0; l <= cur_; ++l) s = (uint32_t)all[l] > s ? (uint32_t)all[l] : s;
+        return s;
+    }
+    uint32_t shuffle(uint32_t v, uint32_t l) { return (uint32_t)exchange(v)[l & 63u]; }
+    float rcp(float x) const { return 1.0f / x; }
     void barrier() { exchange(0); }
     void fence_global() { exchange(0); }
 
   private:
-    static constexpr size_t kStack = 256 * 1024;
+    static constexpr size_t kStack = 128 * 1024;
     static void trampoline(unsigned hi, unsigned lo) {
         WaveEmu *self = reinterpret_cast<WaveEmu *>(((uintptr_t)hi << 32) | (uintptr_t)lo);
         (*self->body_)(*self);

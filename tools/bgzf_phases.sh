@@ -3,7 +3,7 @@
 cd "$(dirname "$0")/.."
 cp fqtk_amd/lib/libfqtk_match.so /tmp/libfqtk_match.prod.so
 hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Iinclude -c -DFQTK_BGZF_PHASE_TIMES ${LZ_TIMES:+-DFQTK_BGZF_LZ_TIMES} $EXTRA_DEFS -o /tmp/bgzf_ph.o fqtk_amd/csrc/fqtk_bgzf.hip || exit 1
-hipcc --offload-arch=gfx950 -shared -fPIC -o fqtk_amd/lib/libfqtk_match.so fqtk_amd/lib/obj/fqtk_match.hip.o fqtk_amd/lib/obj/fqtk_demux.hip.o /tmp/bgzf_ph.o || exit 1
+hipcc --offload-arch=gfx950 -shared -fPIC -o fqtk_amd/lib/libfqtk_match.so fqtk_amd/lib/obj/fqtk_match.hip.o fqtk_amd/lib/obj/fqtk_demux.hip.o fqtk_amd/lib/obj/fqtk_inflate.hip.o /tmp/bgzf_ph.o || exit 1
 python - <<'PY'
 import ctypes as C, json, subprocess, sys
 sys.path.insert(0, ".")

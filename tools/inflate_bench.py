@@ -18,7 +18,7 @@ from fqtk_amd import _lib  # noqa: E402
 from tools.bgzf_bench import fastq_text  # noqa: E402
 
 
-def measure(members=8192, reps=5, level=6, const_qual=False):
+def measure(members=8192, reps=5, level=6, const_qual=False, check=True):
     import torch
     lib = _lib.load()
     rng = np.random.default_rng(1)
@@ -54,10 +54,11 @@ def measure(members=8192, reps=5, level=6, const_qual=False):
         dt = time.perf_counter() - t0
         if r:
             best = dt if best is None else min(best, dt)
-    assert int(d_stat.abs().sum().item()) == 0, "a member failed"
-    got = bytes(d_out[:len(uniq[0])].cpu().numpy())
-    assert got == uniq[0]
-    assert int(d_lines.sum().item()) == sum(uniq[i % len(uniq)].count(b"\n") for i in range(members))
+    if check:
+        assert int(d_stat.abs().sum().item()) == 0, "a member failed"
+        got = bytes(d_out[:len(uniq[0])].cpu().numpy())
+        assert got == uniq[0]
+        assert int(d_lines.sum().item()) == sum(uniq[i % len(uniq)].count(b"\n") for i in range(members))
     lib.fqtk_inflate_destroy(z)
     return {"members": members, "level": level, "text_bytes": out_off, "compressed_bytes": len(file_bytes), "ratio": round(len(file_bytes) / out_off, 4),
             "best_ms": round(best * 1e3, 3), "text_GBps": round(out_off / best / 1e9, 2), "compressed_GBps": round(len(file_bytes) / best / 1e9, 2)}
@@ -69,5 +70,6 @@ if __name__ == "__main__":
     ap.add_argument("--reps", type=int, default=5)
     ap.add_argument("--level", type=int, default=6)
     ap.add_argument("--const-qual", action="store_true")
+    ap.add_argument("--no-check", action="store_true", help="ablation builds (tools/ab_inflate.sh) decode wrong bytes")
     a = ap.parse_args()
-    print(json.dumps(measure(a.members, a.reps, a.level, a.const_qual)))
+    print(json.dumps(measure(a.members, a.reps, a.level, a.const_qual, not a.no_check)))
