@@ -126,7 +126,8 @@ struct MemberArgs {
     const uint32_t *in_words;  // 4-byte aligned address at or before the first byte of the DEFLATE payload
     uint32_t first_bit;        // bit offset of the payload from in_words (0, 8, 16 or 24)
     uint32_t payload_bits;     // length of the payload in bits (the trailer follows)
-    uint32_t readable_words;   // dwords that may be read from in_words (the caller's buffer ends there; past it reads as 0)
+    uint32_t readable_words;   // whole dwords that may be read from in_words (the caller's buffer ends behind them; past it reads as 0)
+    uint32_t tail_bytes;       // 0..3 bytes of the buffer behind those dwords (read one by one)
     uint8_t *out;              // isize bytes
     uint32_t isize;            // ISIZE of the member's trailer
 };
@@ -152,7 +153,15 @@ template <class W>
 struct Ring {
     uint32_t filled;   // uniform
     uint32_t pref;     // per lane
-    FQTK_HD inline uint32_t load(W &w, const MemberArgs &a, uint32_t d) const { return d < a.readable_words ? a.in_words[d] : 0u; }
+    FQTK_HD inline uint32_t load(W &w, const MemberArgs &a, uint32_t d) const {
+        if (d < a.readable_words) return a.in_words[d];
+        uint32_t v = 0;
+        if (d == a.readable_words) {   // the buffer's last, partial dword
+            const uint8_t *p = reinterpret_cast<const uint8_t *>(a.in_words + d);
+            for (uint32_t k = 0; k < a.tail_bytes; ++k) v |= (uint32_t)p[k] << (8u * k);
+        }
+        return v;
+    }
     FQTK_HD inline void reset(W &w, const MemberArgs &a, uint32_t bit) {
         filled = (bit >> 5) & ~63u;
         pref = load(w, a, filled + w.lane());

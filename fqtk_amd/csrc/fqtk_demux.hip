@@ -106,6 +106,7 @@ struct FedInput {
     PinBuf<fqtk_inflate_member> h_members;
     hipStream_t stream = nullptr;
     hipEvent_t ev_moved = nullptr;      // behind the copy of the last change of arena (chunks cut afterwards wait for it)
+    hipEvent_t ev_t0 = nullptr, ev_t1 = nullptr;   // around a feed's kernels
     bool moved = false;
     int cur = 0;
     uint64_t tail = 0;                  // bytes of arena[cur] in use
@@ -358,7 +359,7 @@ void fqtk_demuxer_destroy(fqtk_demuxer *d) {
         for (uint32_t i = 0; i < d->C.n_inputs; ++i) {
             FedInput &F = d->fed[i];
             if (F.stream) { (void)hipStreamSynchronize(F.stream); (void)hipStreamDestroy(F.stream); }
-            if (F.ev_moved) (void)hipEventDestroy(F.ev_moved);
+            for (hipEvent_t e : {F.ev_moved, F.ev_t0, F.ev_t1}) if (e) (void)hipEventDestroy(e);
             F.arena[0].release(); F.arena[1].release(); F.comp.release(); F.d_members.release(); F.d_status.release(); F.d_lines.release();
             F.h_status.release(); F.h_lines.release(); F.h_members.release();
         }
@@ -532,6 +533,8 @@ int fqtk_demuxer_feed(fqtk_demuxer *d, uint32_t input, const uint8_t *bytes, uin
             for (uint32_t i = 0; i < d->C.n_inputs; ++i) {
                 DX_TRY(hipStreamCreateWithFlags(&f[i].stream, hipStreamNonBlocking));
                 DX_TRY(hipEventCreateWithFlags(&f[i].ev_moved, hipEventDisableTiming));
+                DX_TRY(hipEventCreate(&f[i].ev_t0));
+                DX_TRY(hipEventCreate(&f[i].ev_t1));
             }
             d->fed = f;
         }
@@ -592,10 +595,10 @@ int fqtk_demuxer_feed(fqtk_demuxer *d, uint32_t input, const uint8_t *bytes, uin
     lk.unlock();
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (n_members) {
+        e0 = F.ev_t0;
+        e1 = F.ev_t1;
         DX_TRY(hipMemcpyAsync(F.comp.p, bytes, (size_t)len, hipMemcpyHostToDevice, F.stream));
         DX_TRY(hipMemcpyAsync(F.d_members.p, F.h_members.p, (size_t)n_members * sizeof(fqtk_inflate_member), hipMemcpyHostToDevice, F.stream));
-        DX_TRY(hipEventCreate(&e0));
-        DX_TRY(hipEventCreate(&e1));
         DX_TRY(hipEventRecord(e0, F.stream));
         DX_TRY(fqtk::inflate::inflate_launch(F.stream, F.comp.p, len, F.d_members.p, n_members, arena, F.d_status.p, F.d_lines.p, d->d_crc_pow));
         DX_TRY(hipEventRecord(e1, F.stream));
@@ -610,8 +613,6 @@ int fqtk_demuxer_feed(fqtk_demuxer *d, uint32_t input, const uint8_t *bytes, uin
     if (e0) {
         float ms = 0;
         if (hipEventElapsedTime(&ms, e0, e1) == hipSuccess) { std::lock_guard<std::mutex> glk(d->stat_mu); d->inflate_s += ms * 1e-3; }
-        (void)hipEventDestroy(e0);
-        (void)hipEventDestroy(e1);
     }
     for (uint32_t j = 0; j < n_members; ++j)
         if (F.h_status.p[j] != 0) {

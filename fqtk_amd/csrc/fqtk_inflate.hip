@@ -68,6 +68,7 @@ __global__ __launch_bounds__(64) void inflate_kernel(const uint8_t *in, uint64_t
         a.payload_bits = 8u * m.payload_len;
         const uint64_t words_left = (in_len - base) / 4u;   // whole dwords of the caller's buffer from `base` on
         a.readable_words = words_left > 0x7FFFFFFFull ? 0x7FFFFFFFu : (uint32_t)words_left;
+        a.tail_bytes = words_left > 0x7FFFFFFFull ? 0u : (uint32_t)((in_len - base) & 3u);
         a.out = out + m.out_off;
         a.isize = m.isize;
         DeviceWave w;

@@ -378,8 +378,8 @@ uint32_t fqtk_host_bgzf_crc_emulated(const uint8_t *in, uint32_t n) {
 int fqtk_host_bgzf_inflate_emulated(const uint8_t *payload, uint32_t payload_len, uint32_t isize, uint8_t *out, uint32_t misalign) {
     using namespace fqtk::inflate;
     misalign &= 3u;
-    const uint32_t words = (misalign + payload_len + 3u) / 4u;
-    std::vector<uint32_t> buf(words + 1u, 0xA5A5A5A5u);   // what lies behind the payload is not zero
+    const uint32_t words = (misalign + payload_len) / 4u;   // whole dwords; the rest are the buffer's tail bytes
+    std::vector<uint32_t> buf(words + 2u, 0xA5A5A5A5u);   // what lies behind the payload is not zero (and must not be read)
     std::memcpy(reinterpret_cast<uint8_t *>(buf.data()) + misalign, payload, payload_len);
     std::vector<uint8_t> mem(sizeof(Shared));
     Shared &S = *reinterpret_cast<Shared *>(mem.data());
@@ -388,6 +388,7 @@ int fqtk_host_bgzf_inflate_emulated(const uint8_t *payload, uint32_t payload_len
     a.first_bit = 8u * misalign;
     a.payload_bits = 8u * payload_len;
     a.readable_words = words;
+    a.tail_bytes = (misalign + payload_len) & 3u;
     a.out = out;
     a.isize = isize;
     uint32_t status[64];

@@ -59,7 +59,7 @@ int fqtk_inflate_create(int device, fqtk_inflate **out);
 void fqtk_inflate_destroy(fqtk_inflate *z);
 
 /* Enqueues `n` members on pipeline slot `slot` (0..FQTK_INFLATE_SLOTS-1, each its own HIP stream) and returns at once.
- * `in` (4-byte aligned; in_len bytes readable) holds the payloads, `out` receives the text; status[j] and lines[j]
+ * `in` (4-byte aligned; in_len bytes readable) holds the payloads, `out` receives the text (4 bytes of slack behind the last member's: the check reads whole dwords); status[j] and lines[j]
  * (number of '\n' in member j's text) are written for every member.  All of it must stay valid and device-accessible
  * until fqtk_inflate_wait(). */
 int fqtk_inflate_enqueue(fqtk_inflate *z, int slot, const uint8_t *in, uint64_t in_len, const fqtk_inflate_member *members,

@@ -102,11 +102,29 @@ def one(rng, it, tmp):
                 s = s[: max(0, len(s) - int(nprng.integers(1, 4)))]
             reads[i][t] = s
     files = []
-    gz = rng.random() < 0.5
+    kind = rng.choice(["plain", "gz", "bgzf", "bgzf"])   # bgzf: members inflated on the device (fqtk_demuxer_feed), cut into chunks by line counts
+    gz = kind == "gz"
+    member = rng.choice([300, 4000, 65280])            # text bytes per BGZF member: members and chunks never line up
     for i in range(n_inputs):
-        path = os.path.join(tmp, f"in{it}_{i}.fastq" + (".gz" if gz else ""))
+        path = os.path.join(tmp, f"in{it}_{i}.fastq" + (".gz" if kind != "plain" else ""))
         text = "".join(f"@q_{t} {i + 1}:N:0:0\n{reads[i][t]}\n+\n{'I' * len(reads[i][t])}\n" for t in range(n))
-        (gzip.open(path, "wt") if gz else open(path, "w")).write(text)
+        if kind == "bgzf":
+            import struct
+            import zlib
+            raw = text.encode()
+            if raw and rng.random() < 0.3:
+                raw = raw[:-1]                          # last line without a newline
+            data = b""
+            for o in range(0, len(raw), member):
+                piece = raw[o:o + member]
+                c = zlib.compressobj(rng.choice([0, 1, 6, 9]), zlib.DEFLATED, -15)
+                payload = c.compress(piece) + c.flush()
+                data += (b"\x1f\x8b\x08\x04\0\0\0\0\0\xff\x06\0BC\x02\0" + struct.pack("<H", 18 + len(payload) + 8 - 1) + payload +
+                         struct.pack("<II", zlib.crc32(piece), len(piece)))
+            data += bytes.fromhex("1f8b08040000000000ff0600424302001b0003000000000000000000")
+            open(path, "wb").write(data)
+        else:
+            (gzip.open(path, "wt") if gz else open(path, "w")).write(text)
         files.append(path)
     meta = os.path.join(tmp, f"meta{it}.tsv")
     open(meta, "w").write("sample_id\tbarcode\n" + "".join(f"S{i}\t{b}\n" for i, b in enumerate(barcodes)))
@@ -121,6 +139,8 @@ def one(rng, it, tmp):
     if EXE.endswith(".thread") and shutil.which("setarch"):   # TSan's shadow layout does not survive this kernel's ASLR range
         cmd = ["setarch", os.uname().machine, "-R"] + cmd
     env = dict(os.environ)
+    if kind == "bgzf" and rng.random() < 0.5:
+        env["FQTK_FED_ARENA_MIN"] = str(rng.choice([20000, 300000]))   # the fed text changes arena every few chunks
     if EXE.endswith(".thread"):
         env["TSAN_OPTIONS"] = "suppressions=" + os.path.join(ROOT, "tools", "tsan.supp") + ":report_signal_unsafe=0:second_deadlock_stack=1"
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env)
