@@ -324,6 +324,28 @@ FQTK_HD inline Token decode_token(const Shared &S, uint64_t bits) {
     return t;
 }
 
+// The common case in straight-line code: both look-ups are unconditional (a lane whose first code is a literal reads
+// some distance entry it does not use) and the token's fields are selected at the end -- the 64 lanes decode 64 different
+// bit positions, so every branch of a branchy version is taken by somebody and costs the wave its full length.
+FQTK_HD inline Token decode_token_fast(const Shared &S, uint64_t bits) {
+    const uint32_t e = S.lit[(uint32_t)bits & ((1u << kLitBits) - 1u)];
+    const uint32_t cl = e & 15u, ne = (e >> 4) & 15u, kind = (e >> 8) & 3u, val = e >> 16;
+    const uint32_t len = val + ((uint32_t)(bits >> cl) & ((1u << ne) - 1u));
+    const uint32_t u = cl + ne;   // <= 20
+    const uint32_t de = S.dist[(uint32_t)(bits >> u) & ((1u << kDistBits) - 1u)];
+    const uint32_t dcl = de & 15u, dne = (de >> 4) & 15u, dkind = (de >> 8) & 3u;
+    const uint32_t dist = (de >> 16) + ((uint32_t)(bits >> (u + dcl)) & ((1u << dne) - 1u));
+    const bool is_len = kind == kLen;
+    const bool slow = kind == kLong || (is_len && dkind == kLong);
+    const bool bad = !slow && (cl == 0u || (is_len && dcl == 0u));
+    Token t;
+    t.nbits = is_len ? u + dcl + dne : cl;
+    t.outlen = is_len ? len : (kind == kLit ? 1u : 0u);
+    t.value = is_len ? dist : val;
+    t.flags = slow ? kTokSlow : (bad ? kTokBad : (is_len ? kTokMatch : (kind == kEob ? kTokEob : 0u)));
+    return t;
+}
+
 // Decodes one member.  Returns its status (the same in all lanes); *out_bytes = bytes written.
 template <class W>
 FQTK_HD inline uint32_t inflate_member(W &w, Shared &S, const MemberArgs &a) {
@@ -333,7 +355,10 @@ FQTK_HD inline uint32_t inflate_member(W &w, Shared &S, const MemberArgs &a) {
     const uint32_t end_bit = a.first_bit + a.payload_bits;
     uint32_t out_pos = 0;                          // uniform
     uint32_t safe = 0;                             // output below this is visible to every lane's loads
+    uint32_t own_tag = 0;                          // rounds of 64 output bytes so far (24 bits are plenty: <= 65 536 bytes a member)
     ring.reset(w, a, bit);
+    S.own[lane] = 0u;   // (tag 0 is never a round's)
+    w.barrier();
     for (;;) {
         // ---- block header (RFC 1951 3.2.3): the same work in every lane
         ring.ensure(w, S, a, bit);
@@ -460,7 +485,7 @@ FQTK_UNROLL
                 const uint32_t d0 = S.ring[d & (kRingWords - 1u)], d1 = S.ring[(d + 1u) & (kRingWords - 1u)], d2 = S.ring[(d + 2u) & (kRingWords - 1u)];
                 const uint64_t lo = (uint64_t)d0 | ((uint64_t)d1 << 32);
                 const uint64_t bits = s ? (lo >> s) | ((uint64_t)d2 << (64u - s)) : lo;
-                Token t = decode_token<false>(S, bits);
+                Token t = decode_token_fast(S, bits);
                 uint64_t slow = w.ballot((t.flags & kTokSlow) != 0u);
                 // the chain of real tokens: one scalar step per token.  A lane's step is its token's bits; the rare ones (a long
                 // code to resolve, no code at all, end of block) step 0x80 -- out of the window -- so that the walk has ONE exit
@@ -512,11 +537,13 @@ FQTK_UNROLL
 #else
                 for (uint32_t base = 0; base < produced; base += 64u) {
 #endif
-                    S.own[lane] = 0u;
+                    // (entries carry the round's tag: a stale one reads as "no token starts here", and nothing is cleared)
+                    ++own_tag;
+                    if (has_out && rel_start >= base && rel_start < base + 64u) S.own[rel_start - base] = (own_tag << 8) | (lane + 1u);
                     w.barrier();
-                    if (has_out && rel_start >= base && rel_start < base + 64u) S.own[rel_start - base] = lane + 1u;
-                    w.barrier();
-                    uint32_t own = w.scan_max_incl(S.own[lane]);
+                    const uint32_t own_raw = S.own[lane];
+                    w.barrier();   // (read before the next round's writes)
+                    uint32_t own = w.scan_max_incl((own_raw >> 8) == own_tag ? (own_raw & 0xFFu) : 0u);
                     own = own > carry ? own : carry;
                     carry = w.readlane(own, 63u);
                     const uint32_t j = base + lane;

@@ -381,7 +381,7 @@ int fqtk_host_bgzf_inflate_emulated(const uint8_t *payload, uint32_t payload_len
     const uint32_t words = (misalign + payload_len) / 4u;   // whole dwords; the rest are the buffer's tail bytes
     std::vector<uint32_t> buf(words + 2u, 0xA5A5A5A5u);   // what lies behind the payload is not zero (and must not be read)
     std::memcpy(reinterpret_cast<uint8_t *>(buf.data()) + misalign, payload, payload_len);
-    std::vector<uint8_t> mem(sizeof(Shared));
+    std::vector<uint8_t> mem(sizeof(Shared), 0xC3);   // LDS holds whatever the last workgroup left
     Shared &S = *reinterpret_cast<Shared *>(mem.data());
     MemberArgs a;
     a.in_words = buf.data();
