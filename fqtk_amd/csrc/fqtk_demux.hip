@@ -148,6 +148,8 @@ struct fqtk_demuxer {
     uint32_t *d_crc_pow = nullptr;
     hipEvent_t ev_last_fmt = nullptr;   // ev_fmt of the latest chunk submitted (recorded again on stream A)
     double inflate_s = 0;
+    bool ranked = false;                // stream priorities in use
+    int feed_priority = 0;
 };
 
 namespace {
@@ -322,7 +324,20 @@ int fqtk_demuxer_create(fqtk_matcher *m, const fqtk_demux_config *cfg, fqtk_demu
     if (hipGetDeviceProperties(&prop, d->device) == hipSuccess && prop.multiProcessorCount > 0) d->num_cus = prop.multiProcessorCount;
     DX_OR_BAIL(fqtk::bgzf::deflate_prepare());
     static_assert(format_block_bytes(FQTK_DEMUX_MAX_INPUTS) <= 48 * 1024, "k_format: slot tables and record views of a group per wave fit the default LDS");
-    for (hipStream_t *st : {&d->s_in, &d->s_a, &d->s_b, &d->s_out}) DX_OR_BAIL(hipStreamCreateWithFlags(st, hipStreamNonBlocking));
+    {
+        // The chunk's streams rank above the feed streams of the device-side inflate (created at default priority): the decoder
+        // keeps thousands of wavefronts resident for milliseconds each, and a chunk's kernels should get the slots they free
+        // before the next run of members does (FQTK_STREAM_PRIORITY=0: all streams alike, for A/B runs).
+        int lo = 0, hi = 0;
+        const char *e = std::getenv("FQTK_STREAM_PRIORITY");
+        const bool ranked = !(e && e[0] == '0') && hipDeviceGetStreamPriorityRange(&lo, &hi) == hipSuccess && hi < lo;
+        d->feed_priority = ranked ? lo : 0;
+        d->ranked = ranked;
+        for (hipStream_t *st : {&d->s_in, &d->s_a, &d->s_b, &d->s_out}) {
+            if (ranked) DX_OR_BAIL(hipStreamCreateWithPriority(st, hipStreamNonBlocking, hi));
+            else DX_OR_BAIL(hipStreamCreateWithFlags(st, hipStreamNonBlocking));
+        }
+    }
     const size_t persist_bytes = (size_t)std::max<uint32_t>(d->n_cols, 1) * kPersist * kSlab;
     DX_OR_BAIL(hipMalloc(reinterpret_cast<void **>(&d->d_persist), persist_bytes));
     DX_OR_BAIL(hipMalloc(reinterpret_cast<void **>(&d->d_fs), (size_t)std::max<uint32_t>(d->n_cols, 1) * sizeof(FileState)));
@@ -531,7 +546,8 @@ int fqtk_demuxer_feed(fqtk_demuxer *d, uint32_t input, const uint8_t *bytes, uin
             FedInput *f = new (std::nothrow) FedInput[d->C.n_inputs];
             if (!f) return set_error(FQTK_ENOMEM, "out of host memory");
             for (uint32_t i = 0; i < d->C.n_inputs; ++i) {
-                DX_TRY(hipStreamCreateWithFlags(&f[i].stream, hipStreamNonBlocking));
+                if (d->ranked) DX_TRY(hipStreamCreateWithPriority(&f[i].stream, hipStreamNonBlocking, d->feed_priority));
+                else DX_TRY(hipStreamCreateWithFlags(&f[i].stream, hipStreamNonBlocking));
                 DX_TRY(hipEventCreateWithFlags(&f[i].ev_moved, hipEventDisableTiming));
                 DX_TRY(hipEventCreate(&f[i].ev_t0));
                 DX_TRY(hipEventCreate(&f[i].ev_t1));

@@ -39,6 +39,7 @@
 #include "../../../include/fqtk_demux.h"
 #include "../../../include/fqtk_match.h"
 #include "bgzf.hpp"
+#include "bgzf_walk.hpp"
 #include "chunk_dispatch.hpp"
 #include "chunk_schedule.hpp"
 #include "fastq_io.hpp"
@@ -454,61 +455,6 @@ void write_all(int fd, const uint8_t *p, size_t n, const std::string &path) {
         n -= (size_t)w;
     }
 }
-
-// A BGZF input whose members go to the device as they are (fqtk_demuxer_feed): the file is mapped, this walks the member
-// headers (18 bytes: gzip header with the 'BC' extra field, BSIZE) and trailers (CRC-32, ISIZE) and hands out runs of
-// whole members.  Nothing is inflated here.
-struct BgzfFile {
-    std::string path;
-    int fd = -1;
-    const uint8_t *map = nullptr;
-    size_t size = 0, pos = 0;
-    bool open(const std::string &p, std::string *err) {
-        path = p;
-        fd = ::open(p.c_str(), O_RDONLY | O_CLOEXEC);
-        struct stat st;
-        if (fd < 0 || fstat(fd, &st) != 0 || !S_ISREG(st.st_mode) || st.st_size <= 0) { *err = "Error opening input files for reading: " + p; return false; }
-        void *m = mmap(nullptr, (size_t)st.st_size, PROT_READ, MAP_PRIVATE, fd, 0);
-        if (m == MAP_FAILED) { *err = "Error opening input files for reading: " + p; return false; }
-        map = static_cast<const uint8_t *>(m);
-        size = (size_t)st.st_size;
-        madvise(m, size, MADV_SEQUENTIAL);
-        return true;
-    }
-    // is every member of the file a standard BGZF one?  (a look at the first few: the rest is checked as it is walked)
-    static bool looks_like_bgzf(const uint8_t *h, size_t n) {
-        return n >= 18 && h[0] == 0x1f && h[1] == 0x8b && h[2] == 8 && h[3] == 4 && h[10] == 6 && h[11] == 0 && h[12] == 'B' && h[13] == 'C' && h[14] == 2 && h[15] == 0;
-    }
-    // Members from pos on while the run stays below the limits (at least one).  [*from, *upto): their bytes in the map.
-    bool next_run(size_t max_bytes, size_t max_text, std::vector<fqtk_inflate_member> *out, size_t *from, size_t *upto, std::string *err) {
-        out->clear();
-        *from = pos;
-        size_t text = 0;
-        while (pos < size) {
-            const uint8_t *h = map + pos;
-            if (!looks_like_bgzf(h, size - pos)) { *err = "Unexpected error parsing FASTQs: " + path + " is not BGZF throughout (a member without the BC field at byte " + std::to_string(pos) + "): rerun with --host-inflate"; return false; }
-            const size_t bsize = (size_t)h[16] + ((size_t)h[17] << 8) + 1;
-            if (bsize < 26 || pos + bsize > size) { *err = "Unexpected error parsing FASTQs: bad BGZF block size in " + path; return false; }
-            uint32_t crc, isize;
-            std::memcpy(&crc, h + bsize - 8, 4);
-            std::memcpy(&isize, h + bsize - 4, 4);
-            if (isize > 65536) { *err = "Unexpected error parsing FASTQs: bad BGZF block (more than 64 KiB of text) in " + path; return false; }
-            if (!out->empty() && (pos + bsize - *from > max_bytes || text + isize > max_text)) break;
-            fqtk_inflate_member m;
-            std::memset(&m, 0, sizeof m);
-            m.payload_off = pos + 18 - *from;
-            m.payload_len = (uint32_t)(bsize - 26);
-            m.isize = isize;
-            m.crc = crc;
-            out->push_back(m);
-            text += isize;
-            pos += bsize;
-        }
-        *upto = pos;
-        return true;
-    }
-    bool at_end() const { return pos >= size; }
-};
 
 // Which configurations the device pipeline takes (the limits of include/fqtk_demux.h); anything else is formatted on the host.
 bool gpu_output_supported(const Plan &plan, std::string *why) {

@@ -10,6 +10,7 @@
 #include <vector>
 
 #include "bgzf.hpp"
+#include "bgzf_walk.hpp"
 #include "chunk_dispatch.hpp"
 #include "chunk_schedule.hpp"
 #include "fastq_io.hpp"
@@ -370,6 +371,29 @@ uint32_t fqtk_host_bgzf_crc_emulated(const uint8_t *in, uint32_t n) {
     for (int l = 0; l < kLanes; ++l) phase_crc(S, l, n);
     phase_crc_fold(S);
     return S.crc;
+}
+
+// The member walk of the device-inflate feeders (bgzf_walk.hpp): runs of whole members of `path` below max_bytes of file /
+// max_text of text each.  Writes up to cap rows of (run, payload offset in the file, payload bytes, ISIZE, CRC-32); returns the
+// number of members, -1 with *err when the file is not BGZF throughout / damaged.
+int64_t fqtk_host_bgzf_walk(const char *path, uint64_t max_bytes, uint64_t max_text, uint64_t *rows, size_t cap, char *err, size_t err_cap) {
+    fqtk_host::BgzfFile f;
+    std::string e;
+    auto fail = [&](const std::string &m) { if (err && err_cap) { std::strncpy(err, m.c_str(), err_cap - 1); err[err_cap - 1] = 0; } return (int64_t)-1; };
+    if (!f.open(path, &e)) return fail(e);
+    std::vector<fqtk_inflate_member> run;
+    int64_t n = 0;
+    uint64_t r = 0;
+    while (!f.at_end()) {
+        size_t from = 0, upto = 0;
+        if (!f.next_run((size_t)max_bytes, (size_t)max_text, &run, &from, &upto, &e)) return fail(e);
+        for (const fqtk_inflate_member &m : run) {
+            if ((size_t)n < cap) { rows[5 * n] = r; rows[5 * n + 1] = from + m.payload_off; rows[5 * n + 2] = m.payload_len; rows[5 * n + 3] = m.isize; rows[5 * n + 4] = m.crc; }
+            ++n;
+        }
+        ++r;
+    }
+    return n;
 }
 
 // A raw DEFLATE stream decoded by the BGZF input kernel's own code (csrc/bgzf_inflate.hpp: inflate_member, one wavefront per

@@ -213,3 +213,58 @@ def test_gpu_decoder_reports_bad_members_and_leaves_the_others_alone():
     finally:
         b.free()
         lib.fqtk_inflate_destroy(z)
+
+
+def _walk(path, max_bytes=1 << 20, max_text=4 << 20, cap=100000):
+    lib = C.CDLL(HOST)
+    fn = lib.fqtk_host_bgzf_walk
+    fn.restype = C.c_int64
+    fn.argtypes = [C.c_char_p, C.c_uint64, C.c_uint64, C.c_void_p, C.c_size_t, C.c_char_p, C.c_size_t]
+    rows = (C.c_uint64 * (5 * cap))()
+    err = C.create_string_buffer(512)
+    n = fn(str(path).encode(), max_bytes, max_text, rows, cap, err, 512)
+    if n < 0:
+        raise ValueError(err.value.decode())
+    return [tuple(rows[5 * i:5 * i + 5]) for i in range(n)]
+
+
+def test_member_walk_of_the_device_inflate_feeders(tmp_path):
+    """csrc/host/bgzf_walk.hpp (what `fqtk demux` hands to fqtk_demuxer_feed): every member of a BGZF file once, in order, with
+    the payload / CRC / ISIZE of its header and trailer; runs respect the byte and text limits; files that are not BGZF
+    throughout, or damaged, are refused with the reader's messages."""
+    rng = np.random.default_rng(9)
+    text = fastq_text(3000, rng)
+    pieces = [text[o:o + 20000] for o in range(0, len(text), 20000)]
+    data = b"".join(bgzf_member(p, 1 + i % 9) for i, p in enumerate(pieces)) + bytes.fromhex("1f8b08040000000000ff0600424302001b0003000000000000000000")
+    f = tmp_path / "a.fastq.gz"
+    f.write_bytes(data)
+    rows = _walk(f, max_bytes=50000, max_text=1 << 30)
+    assert len(rows) == len(pieces) + 1
+    got = b""
+    for run, off, plen, isize, crc in rows:
+        t = zlib.decompressobj(-15).decompress(data[off:off + plen])
+        assert len(t) == isize and zlib.crc32(t) == crc
+        got += t
+    assert got == text
+    runs = {}
+    for run, off, plen, isize, crc in rows:
+        runs.setdefault(run, []).append((off, plen, isize))
+    assert len(runs) > 3 and sorted(runs) == list(range(len(runs)))
+    for r, ms in runs.items():                                   # a run stays below the byte limit unless it is one member
+        span = ms[-1][0] + ms[-1][1] + 8 - (ms[0][0] - 18)
+        assert span <= 50000 or len(ms) == 1
+    small = _walk(f, max_bytes=1 << 30, max_text=45000)          # the text limit: two 20 000-byte members per run
+    assert max(sum(1 for r in small if r[0] == k) for k in {r[0] for r in small}) == 2
+    # an ordinary gzip member in the middle; a BSIZE that runs past the file; a member of more than 64 KiB of text
+    plain = gzip_member = b"\x1f\x8b\x08\x00\0\0\0\0\0\xff" + raw_deflate(b"hello\n") + struct.pack("<II", zlib.crc32(b"hello\n"), 6)
+    (tmp_path / "b.gz").write_bytes(bgzf_member(pieces[0]) + plain)
+    with pytest.raises(ValueError, match="not BGZF throughout"):
+        _walk(tmp_path / "b.gz")
+    (tmp_path / "c.gz").write_bytes(data[:len(data) // 2])
+    with pytest.raises(ValueError, match="bad BGZF block size|not BGZF throughout"):
+        _walk(tmp_path / "c.gz")
+    big = bytearray(bgzf_member(pieces[0]))
+    big[-4:] = struct.pack("<I", 70000)
+    (tmp_path / "d.gz").write_bytes(bytes(big))
+    with pytest.raises(ValueError, match="more than 64 KiB"):
+        _walk(tmp_path / "d.gz")
