@@ -47,6 +47,11 @@ namespace fqtk {
 namespace inflate {
 
 constexpr int kLitBits = 10, kDistBits = 8;
+#ifndef FQTK_INFLATE_SETS
+#define FQTK_INFLATE_SETS 2   // bit positions decoded per lane and window (1 or 2): tools/ab_inflate.sh "-DFQTK_INFLATE_SETS=1"
+#endif
+constexpr uint32_t kSets = FQTK_INFLATE_SETS;
+static_assert(kSets == 1 || kSets == 2, "one or two sets of 64 bit positions");
 constexpr uint32_t kRingWords = 256;   // 1 KiB of the compressed stream in LDS (dword d of the stream at ring[d & 255])
 
 // status of a member (written to status[member]; 0 = fine)
@@ -478,60 +483,95 @@ FQTK_UNROLL
             err = build_code<W, false>(w, S, S.lens + hlit, hdist);
             if (err) return err;
 
-            // ---- the block's tokens, 64 bit positions at a time
+            // ---- the block's tokens, kSets x 64 bit positions at a time: lane i takes bit i of every set of 64
             for (;;) {
-                ring.ensure(w, S, a, bit + 128u);
+                ring.ensure(w, S, a, bit + 64u * kSets + 64u);
                 const uint32_t b = bit + lane, d = b >> 5, s = b & 31u;
-                const uint32_t d0 = S.ring[d & (kRingWords - 1u)], d1 = S.ring[(d + 1u) & (kRingWords - 1u)], d2 = S.ring[(d + 2u) & (kRingWords - 1u)];
-                const uint64_t lo = (uint64_t)d0 | ((uint64_t)d1 << 32);
-                const uint64_t bits = s ? (lo >> s) | ((uint64_t)d2 << (64u - s)) : lo;
-                Token t = decode_token_fast(S, bits);
-                uint64_t slow = w.ballot((t.flags & kTokSlow) != 0u);
-                // the chain of real tokens: one scalar step per token.  A lane's step is its token's bits; the rare ones (a long
-                // code to resolve, no code at all, end of block) step 0x80 -- out of the window -- so that the walk has ONE exit
-                // test, and are looked at behind it.
-                uint32_t meta = t.flags & (kTokSlow | kTokBad | kTokEob) ? 0x80u : t.nbits;
-                uint64_t chain = 0;
+                uint32_t dw[2 * kSets + 1];
+                FQTK_UNROLL
+                for (uint32_t k = 0; k < 2u * kSets + 1u; ++k) dw[k] = S.ring[(d + k) & (kRingWords - 1u)];
+                uint64_t bits[kSets];
+                Token t[kSets];
+                uint64_t slow[kSets];
+                uint32_t meta[kSets];
+                // A lane's step in the walk below is its token's bits; the rare ones (a long code to resolve, no code at all, end of
+                // block) step 0x80 -- out of the window -- so that the walk has ONE exit test, and are looked at behind it.
+                FQTK_UNROLL
+                for (uint32_t q = 0; q < kSets; ++q) {
+                    const uint64_t lo = (uint64_t)dw[2 * q] | ((uint64_t)dw[2 * q + 1] << 32);
+                    bits[q] = s ? (lo >> s) | ((uint64_t)dw[2 * q + 2] << (64u - s)) : lo;
+                    t[q] = decode_token_fast(S, bits[q]);
+                    slow[q] = w.ballot((t[q].flags & kTokSlow) != 0u);
+                    meta[q] = t[q].flags & (kTokSlow | kTokBad | kTokEob) ? 0x80u : t[q].nbits;
+                }
+                // the chain of real tokens: one scalar step per token, set after set
+                uint64_t chain[kSets];
+                FQTK_UNROLL
+                for (uint32_t q = 0; q < kSets; ++q) chain[q] = 0;
                 uint32_t cur = 0;
                 bool eob = false;
                 for (;;) {
-                    uint32_t m;
-                    do {
-                        m = w.readlane(meta, cur);
-                        chain |= 1ull << cur;
-                        cur += m;
-                    } while (cur < 64u);
-                    if (!(m & 0x80u)) break;
-                    cur -= 0x80u;   // a rare one: back on its lane
-                    if (slow) {     // long codes: every lane that met one resolves it now (once per window at most), the walk goes on from here
-                        if ((slow >> lane) & 1ull) {
-                            t = decode_token<true>(S, bits);
-                            meta = t.flags & (kTokBad | kTokEob) ? 0x80u : t.nbits;
+                    uint32_t m = 0;
+                    FQTK_UNROLL
+                    for (uint32_t q = 0; q < kSets; ++q) {
+                        if (cur >= 64u * q && cur < 64u * (q + 1u)) {
+                            do {
+                                m = w.readlane(meta[q], cur - 64u * q);
+                                chain[q] |= 1ull << (cur - 64u * q);
+                                cur += m;
+                            } while (cur < 64u * (q + 1u));
                         }
-                        slow = 0;
-                        continue;
                     }
-                    if (w.readlane(t.flags, cur) & kTokBad) return kErrBadCode;
-                    cur += w.readlane(t.nbits, cur);   // end of block
+                    if (!(m & 0x80u)) break;
+                    cur -= 0x80u;   // a rare one: back on its position
+                    if (slow[0] | (kSets == 2 ? slow[kSets - 1] : 0ull)) {   // long codes: every lane that met one resolves it now (once per window at most)
+                        FQTK_UNROLL
+                        for (uint32_t q = 0; q < kSets; ++q) {
+                            if ((slow[q] >> lane) & 1ull) {
+                                t[q] = decode_token<true>(S, bits[q]);
+                                meta[q] = t[q].flags & (kTokBad | kTokEob) ? 0x80u : t[q].nbits;
+                            }
+                            slow[q] = 0;
+                        }
+                        continue;   // the walk goes on from here
+                    }
+                    const uint32_t cq = cur >> 6, cl = cur & 63u;
+                    const uint32_t f = kSets == 2 && cq ? w.readlane(t[kSets - 1].flags, cl) : w.readlane(t[0].flags, cl);
+                    if (f & kTokBad) return kErrBadCode;
+                    cur += kSets == 2 && cq ? w.readlane(t[kSets - 1].nbits, cl) : w.readlane(t[0].nbits, cl);   // end of block
                     eob = true;
                     break;
                 }
-                const bool mine = ((chain >> lane) & 1ull) != 0ull;
-                const uint32_t my_out = mine ? t.outlen : 0u;
-                const uint32_t incl = w.scan_incl(my_out);
-                const uint32_t my_pos = out_pos + incl - my_out;
-                const uint32_t produced = w.readlane(incl, 63u);
+                bool mine[kSets];
+                uint32_t my_out[kSets], my_pos[kSets];
+                uint32_t produced = 0;
+                FQTK_UNROLL
+                for (uint32_t q = 0; q < kSets; ++q) {
+                    mine[q] = ((chain[q] >> lane) & 1ull) != 0ull;
+                    my_out[q] = mine[q] ? t[q].outlen : 0u;
+                    const uint32_t incl = w.scan_incl(my_out[q]);
+                    my_pos[q] = out_pos + produced + incl - my_out[q];
+                    produced += w.readlane(incl, 63u);
+                }
                 if (out_pos + produced > a.isize) return kErrOutput;
                 // ---- the window's bytes, 64 at a time, one lane per BYTE (not per token): who owns the byte (the last token that
                 // starts at or before it: a prefix maximum over the tokens' starting places), what it is (the owner's literal, or
                 // the byte `distance` back -- in memory already, or another byte of these 64, reached by pointer doubling), one
                 // coalesced store.  A match costs what a literal costs, and the wave waits for memory once per 64 bytes
                 // instead of once per match.
-                if (w.ballot(mine && (t.flags & kTokMatch) != 0u && t.value > my_pos)) return kErrDistance;
-                const uint32_t rel_start = my_pos - out_pos;                  // < 64 * 258
-                const uint32_t packed = ((t.flags & kTokMatch) ? 1u : 0u) | (rel_start << 1) | (t.value << 16);
-                const bool has_out = mine && my_out != 0u;
-                uint32_t carry = 0;                                           // lane + 1 of the token that owns the byte before these 64
+                uint32_t rel_start[kSets], packed[kSets];
+                bool has_out[kSets], too_far = false;
+                FQTK_UNROLL
+                for (uint32_t q = 0; q < kSets; ++q) {
+                    const bool is_match = (t[q].flags & kTokMatch) != 0u;
+                    too_far = too_far || (mine[q] && is_match && t[q].value > my_pos[q]);
+                    rel_start[q] = my_pos[q] - out_pos;                       // < 128 * 258: 16 bits
+                    // kind | start << 1 | (distance - 1, or the literal) << 17
+                    packed[q] = (is_match ? 1u : 0u) | (rel_start[q] << 1) | ((is_match ? t[q].value - 1u : t[q].value) << 17);
+                    has_out[q] = mine[q] && my_out[q] != 0u;
+                }
+                if (w.ballot(too_far)) return kErrDistance;
+                uint32_t carry = 0;                                           // 1 + position of the token that owns the byte before these 64
 #ifdef FQTK_INFLATE_ABL_NOCOPY   // (developer ablation, tools/ab_inflate.sh: wrong output, same decoding)
                 for (uint32_t base = produced; base < produced; base += 64u) {
 #else
@@ -539,7 +579,9 @@ FQTK_UNROLL
 #endif
                     // (entries carry the round's tag: a stale one reads as "no token starts here", and nothing is cleared)
                     ++own_tag;
-                    if (has_out && rel_start >= base && rel_start < base + 64u) S.own[rel_start - base] = (own_tag << 8) | (lane + 1u);
+                    FQTK_UNROLL
+                    for (uint32_t q = 0; q < kSets; ++q)
+                        if (has_out[q] && rel_start[q] >= base && rel_start[q] < base + 64u) S.own[rel_start[q] - base] = (own_tag << 8) | (64u * q + lane + 1u);
                     w.barrier();
                     const uint32_t own_raw = S.own[lane];
                     w.barrier();   // (read before the next round's writes)
@@ -548,18 +590,22 @@ FQTK_UNROLL
                     carry = w.readlane(own, 63u);
                     const uint32_t j = base + lane;
                     const bool live = j < produced;
-                    const uint32_t info = w.shuffle(packed, own - 1u);        // (byte 0 starts a token: own >= 1)
-                    const uint32_t start = (info >> 1) & 0x7FFFu, val = info >> 16;
+                    uint32_t info = w.shuffle(packed[0], (own - 1u) & 63u);   // (byte 0 starts a token: own >= 1)
+                    if (kSets == 2) {
+                        const uint32_t info_b = w.shuffle(packed[kSets - 1], (own - 1u) & 63u);
+                        info = own > 64u ? info_b : info;
+                    }
+                    const uint32_t start = (info >> 1) & 0xFFFFu, val = info >> 17;
                     uint32_t byte = val & 0xFFu;
                     uint32_t ptr = lane;                                      // a byte that is known points at itself
                     bool from_memory = false;
                     uint32_t src_pos = 0;
                     if (live && (info & 1u)) {
-                        const uint32_t k = j - start, dist = val;
+                        const uint32_t k = j - start, dist = val + 1u;
                         uint32_t off = k;
                         if (k >= dist) {                                      // an overlapping match repeats its `dist` bytes: k mod dist (k, dist < 259)
-                            const uint32_t q = (uint32_t)((float)k * w.rcp((float)dist));   // (approximate: corrected below)
-                            int32_t r = (int32_t)k - (int32_t)(q * dist);
+                            const uint32_t qq = (uint32_t)((float)k * w.rcp((float)dist));   // (approximate: corrected below)
+                            int32_t r = (int32_t)k - (int32_t)(qq * dist);
                             if (r < 0) r += (int32_t)dist; else if (r >= (int32_t)dist) r -= (int32_t)dist;
                             off = (uint32_t)r;
                         }
