@@ -92,6 +92,42 @@ class Demuxer:
         self._keep[slot] = [arrs, texts]
         _check(self._lib.fqtk_demuxer_submit(self._h, slot, ptrs, lens, n_templates))
 
+    # ---- BGZF inputs inflated on the device (fqtk_demuxer_feed / submit_fed / fed_tail) -------------------------------
+    def feed(self, input_index: int, bgzf_bytes: bytes, last: bool = False) -> int:
+        """Hands the whole BGZF members in `bgzf_bytes` (as they lie in a file) of one input to the device; returns the number
+        of lines (newlines) fed for that input so far.  last: the input's final members (a newline is added behind the text)."""
+        import struct
+        members, pos = [], 0
+        while pos < len(bgzf_bytes):
+            bsize = struct.unpack_from("<H", bgzf_bytes, pos + 16)[0] + 1
+            crc, isize = struct.unpack_from("<II", bgzf_bytes, pos + bsize - 8)
+            members.append((pos + 18, bsize - 26, isize, crc))
+            pos += bsize
+        arr = (_lib.fqtk_inflate_member * max(len(members), 1))()
+        for k, (off, plen, isize, crc) in enumerate(members):
+            arr[k].payload_off, arr[k].payload_len, arr[k].isize, arr[k].crc = off, plen, isize, crc
+        buf = np.frombuffer(bgzf_bytes + b"\0" * 8, dtype=np.uint8)
+        fed = C.c_uint64(0)
+        _check(self._lib.fqtk_demuxer_feed(self._h, input_index, buf.ctypes.data, len(bgzf_bytes), arr, len(members),
+                                           1 if last else 0, C.byref(fed)))
+        return int(fed.value)
+
+    def submit_fed(self, slot: int, n_templates: int) -> None:
+        _check(self._lib.fqtk_demuxer_submit_fed(self._h, slot, n_templates))
+
+    def collect_fed(self, slot: int):
+        """(files, text_end per input) of a chunk of fed text."""
+        res = _lib.fqtk_demux_result()
+        _check(self._lib.fqtk_demuxer_collect(self._h, slot, C.byref(res)))
+        ends = [int(res.text_end[i]) for i in range(len(self.structures))] if res.text_end else None
+        return self._files(res), ends
+
+    def fed_tail(self, input_index: int, pos: int, cap: int = 1 << 16) -> bytes:
+        buf = (C.c_uint8 * cap)()
+        n = C.c_uint64(0)
+        _check(self._lib.fqtk_demuxer_fed_tail(self._h, input_index, pos, buf, cap, C.byref(n)))
+        return bytes(buf[:min(int(n.value), cap)])
+
     def _files(self, res) -> List[bytes]:
         if res.error:
             raise DemuxChunkError(res.error, res.error_input, res.error_template, res.error_detail,

@@ -327,3 +327,92 @@ def test_a_million_templates_cfg3_shape_counts_and_streams():
         total += len(recs) // 4
     assert total == n
     print("stage seconds:", d.stage_seconds())
+
+
+def _bgzf_of(text, member, rng):
+    """BGZF bytes of `text` in members of `member` bytes of text each (levels vary), without the EOF marker."""
+    import struct
+    out = b""
+    for o in range(0, len(text), member):
+        piece = text[o:o + member]
+        c = zlib.compressobj(int(rng.integers(0, 10)), zlib.DEFLATED, -15)
+        payload = c.compress(piece) + c.flush()
+        out += (b"\x1f\x8b\x08\x04\0\0\0\0\0\xff\x06\0BC\x02\0" + struct.pack("<H", 18 + len(payload) + 8 - 1) + payload +
+                struct.pack("<II", zlib.crc32(piece), len(piece)))
+    return out
+
+
+@pytest.mark.parametrize("member, feed_members", [(700, 5), (65280, 2), (4096, 1000)])
+def test_fed_bgzf_members_give_the_files_text_chunks_give(member, feed_members, monkeypatch):
+    """fqtk_demuxer_feed / submit_fed / fed_tail through the C ABI: members of every input go to the device compressed, chunks are
+    cut by line counts out of windows of whole members (which never line up with the chunks: inputs of 150- and 8-base reads,
+    members of 700 to 65 280 bytes), and the files must equal the ones the same templates give as host text -- also when the
+    fed text changes arena every few feeds, the last line has no newline, and blank lines follow the last record."""
+    monkeypatch.setenv("FQTK_FED_ARENA_MIN", "60000")
+    rng = np.random.default_rng(member)
+    structures, types = ["8B", "+T", "6M+T"], "TBM"
+    templates = make_templates(rng, 5000, BARCODES8, structures, header_kind=1)
+    texts = texts_of(templates, 0, len(templates), len(structures))
+    texts[1] = texts[1][:-1]            # the last line of input 1 ends with the file
+    texts[2] = texts[2] + b"\n\n"       # blank lines behind input 2's last record
+    m = BarcodeMatcher(BARCODES8, 1, 2, device=0)
+    d = Demuxer(m, structures, types, max_chunk_templates=700)
+    blobs = [_bgzf_of(t, member, rng) for t in texts]
+    # feed in runs of `feed_members` members per input, the inputs in turn; cut a chunk whenever every input has its lines
+    starts = []
+    for b in blobs:
+        pos, s = 0, []
+        while pos < len(b):
+            s.append(pos)
+            pos += int.from_bytes(b[pos + 16:pos + 18], "little") + 1
+        starts.append(s + [len(b)])
+    at = [0] * len(blobs)
+    fed = [0] * len(blobs)
+    done = [False] * len(blobs)
+    files = [bytearray() for _ in range(d.n_files)]
+    taken, slot, pending, ends = 0, 0, [], None
+    chunk = 700
+    while True:
+        for i, b in enumerate(blobs):
+            if not done[i] and fed[i] < 4 * (taken + chunk):
+                hi = min(at[i] + feed_members, len(starts[i]) - 1)
+                done[i] = hi == len(starts[i]) - 1
+                fed[i] = d.feed(i, b[starts[i][at[i]]:starts[i][hi]], last=done[i])
+                at[i] = hi
+        ready = all(done[i] or fed[i] >= 4 * (taken + chunk) for i in range(len(blobs)))
+        if not ready:
+            continue
+        n = min(chunk, min(fed[i] // 4 - taken for i in range(len(blobs))))
+        if n <= 0:
+            break
+        if len(pending) == 3:
+            got, ends = d.collect_fed(pending.pop(0))
+            for c, x in enumerate(got):
+                files[c] += x
+        d.submit_fed(slot % 3, n)
+        pending.append(slot % 3)
+        slot += 1
+        taken += n
+    while pending:
+        got, ends = d.collect_fed(pending.pop(0))
+        for c, x in enumerate(got):
+            files[c] += x
+    for c, x in enumerate(d.flush()):
+        files[c] += x
+    assert taken == len(templates)
+    want, counts, _ = expected_files(BARCODES8, 1, 2, structures, types, templates)
+    for c, w in enumerate(want):
+        assert gzip.decompress(bytes(files[c]) + H_BGZF_EOF) == w, f"file column {c}"
+    assert np.array_equal(d.counts(), counts)
+    # what lies behind the last record: the newline the device added (+ input 2's blank lines)
+    # (input 1's text ended without one: the added newline IS its last record's)
+    assert d.fed_tail(0, ends[0]) == b"\n" and d.fed_tail(1, ends[1]) == b"" and d.fed_tail(2, ends[2]) == b"\n\n\n"
+    # a corrupt member is refused with its number
+    bad = bytearray(_bgzf_of(texts[0][:3000], 1000, rng))
+    bad[40] ^= 0x55
+    d2 = Demuxer(BarcodeMatcher(BARCODES8, 1, 2, device=0), structures, types, max_chunk_templates=700)
+    with pytest.raises(Exception, match="corrupt BGZF block 0"):
+        d2.feed(0, bytes(bad), last=True)
+
+
+from fqtk_amd.demux import BGZF_EOF as H_BGZF_EOF  # noqa: E402
