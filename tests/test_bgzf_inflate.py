@@ -233,12 +233,12 @@ def test_member_walk_of_the_device_inflate_feeders(tmp_path):
     the payload / CRC / ISIZE of its header and trailer; runs respect the byte and text limits; files that are not BGZF
     throughout, or damaged, are refused with the reader's messages."""
     rng = np.random.default_rng(9)
-    text = fastq_text(3000, rng)
+    text = fastq_text(800, rng)
     pieces = [text[o:o + 20000] for o in range(0, len(text), 20000)]
     data = b"".join(bgzf_member(p, 1 + i % 9) for i, p in enumerate(pieces)) + bytes.fromhex("1f8b08040000000000ff0600424302001b0003000000000000000000")
     f = tmp_path / "a.fastq.gz"
     f.write_bytes(data)
-    rows = _walk(f, max_bytes=50000, max_text=1 << 30)
+    rows = _walk(f, max_bytes=20000, max_text=1 << 30)
     assert len(rows) == len(pieces) + 1
     got = b""
     for run, off, plen, isize, crc in rows:
@@ -249,10 +249,10 @@ def test_member_walk_of_the_device_inflate_feeders(tmp_path):
     runs = {}
     for run, off, plen, isize, crc in rows:
         runs.setdefault(run, []).append((off, plen, isize))
-    assert len(runs) > 3 and sorted(runs) == list(range(len(runs)))
+    assert len(runs) >= 3 and sorted(runs) == list(range(len(runs)))
     for r, ms in runs.items():                                   # a run stays below the byte limit unless it is one member
         span = ms[-1][0] + ms[-1][1] + 8 - (ms[0][0] - 18)
-        assert span <= 50000 or len(ms) == 1
+        assert span <= 20000 or len(ms) == 1
     small = _walk(f, max_bytes=1 << 30, max_text=45000)          # the text limit: two 20 000-byte members per run
     assert max(sum(1 for r in small if r[0] == k) for k in {r[0] for r in small}) == 2
     # an ordinary gzip member in the middle; a BSIZE that runs past the file; a member of more than 64 KiB of text
