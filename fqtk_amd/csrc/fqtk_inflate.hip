@@ -51,7 +51,12 @@ struct DeviceWave {
     __device__ inline void fence_global() const { __threadfence_block(); }
 };
 
-__global__ __launch_bounds__(64) void inflate_kernel(const uint8_t *in, uint64_t in_len, const fqtk_inflate_member *members, uint32_t n,
+#ifdef FQTK_INFLATE_WAVES   // (tools/ab_inflate.sh "-DFQTK_INFLATE_WAVES=5": registers capped so that that many wavefronts fit a SIMD)
+#define FQTK_INFLATE_OCCUPANCY __attribute__((amdgpu_waves_per_eu(FQTK_INFLATE_WAVES, FQTK_INFLATE_WAVES)))
+#else
+#define FQTK_INFLATE_OCCUPANCY
+#endif
+__global__ __launch_bounds__(64) FQTK_INFLATE_OCCUPANCY void inflate_kernel(const uint8_t *in, uint64_t in_len, const fqtk_inflate_member *members, uint32_t n,
                                                       uint8_t *out, uint32_t *status) {
     __shared__ Shared S;
     const uint32_t j = blockIdx.x;
