@@ -31,6 +31,14 @@ class fqtk_inflate_member(C.Structure):   # include/fqtk_inflate.h
 FQTK_INFLATE_SLOTS, FQTK_INFLATE_MAX_ISIZE, FQTK_INFLATE_ERR_CRC = 4, 65536, 10
 
 
+class fqtk_stream_chunk(C.Structure):   # include/fqtk_demux.h
+    _fields_ = [("start_bit", C.c_uint64), ("stop_bit", C.c_uint64)]
+
+
+class fqtk_stream_end(C.Structure):
+    _fields_ = [("status", C.c_uint32), ("final_block", C.c_uint32), ("n_bytes", C.c_uint64), ("end_bit", C.c_uint64)]
+
+
 # include/fqtk_demux.h
 class fqtk_demux_segment(C.Structure):
     _fields_ = [("offset", C.c_uint32), ("length", C.c_int32), ("kind", C.c_char)]
@@ -142,6 +150,8 @@ SIGNATURES = [
     ("fqtk_demuxer_submit_fed", C.c_int, [C.c_void_p, C.c_int, C.c_uint32]),
     ("fqtk_demuxer_fed_tail", C.c_int, [C.c_void_p, C.c_uint32, C.c_uint64, C.c_void_p, C.c_size_t, C.POINTER(C.c_uint64)]),
     ("fqtk_demuxer_inflate_seconds", C.c_int, [C.c_void_p, C.POINTER(C.c_double)]),
+    ("fqtk_demuxer_stream_decode", C.c_int, [C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint32, C.c_void_p]),
+    ("fqtk_demuxer_stream_commit", C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32, C.c_int, C.c_int, C.POINTER(C.c_uint64), C.POINTER(C.c_uint32), C.POINTER(C.c_uint64)]),
 ]
 
 

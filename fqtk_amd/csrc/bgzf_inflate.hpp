@@ -134,8 +134,14 @@ struct MemberArgs {
     uint32_t readable_words;   // whole dwords that may be read from in_words (the caller's buffer ends behind them; past it reads as 0)
     uint32_t tail_bytes;       // 0..3 bytes of the buffer behind those dwords (read one by one)
     uint8_t *out;              // isize bytes
-    uint32_t isize;            // ISIZE of the member's trailer
+    uint32_t isize;            // ISIZE of the member's trailer (stream mode: room in out_sym, in symbols)
+    // stream mode (inflate_member<W, true>: a stretch of ONE serial gzip stream, started at a block boundary somewhere inside it)
+    uint16_t *out_sym;         // symbols: < 256 a byte; 256 + j: byte j of the 32 KiB in front of the chunk, which it does not know
+    uint32_t stop_bit;         // the chunk ends at the first block boundary at or behind this bit (or with the final block)
 };
+// What a chunk of a stream came to (stream mode).
+struct StreamEnd { uint32_t n_sym, end_bit, final_block; };
+constexpr uint32_t kWindow = 32768;
 
 // ---- the wave -------------------------------------------------------------------------------------------------------
 // W provides: lane() 0..63; ballot(bool) -> uint64; readlane(uint32 v, uint32 l) (l the same in all lanes);
@@ -351,9 +357,14 @@ FQTK_HD inline Token decode_token_fast(const Shared &S, uint64_t bits) {
     return t;
 }
 
-// Decodes one member.  Returns its status (the same in all lanes); *out_bytes = bytes written.
-template <class W>
-FQTK_HD inline uint32_t inflate_member(W &w, Shared &S, const MemberArgs &a) {
+// Decodes one member.  Returns its status (the same in all lanes).
+// kStream: the same decoder on a piece of a SERIAL gzip stream (`gzip`, bcl2fastq: one member per file) -- it starts at a
+// block boundary inside the stream without the 32 KiB of text before it, so it writes 16-bit symbols (a byte, or "byte j of the
+// window I do not have"; a copy of such a symbol copies the reference), goes on from block to block and stops at the first
+// block boundary at or behind a.stop_bit.  The windows are handed down the chain of chunks afterwards (fqtk_inflate.hip),
+// the way host/parallel_gunzip.hpp does it on CPU threads.
+template <class W, bool kStream = false>
+FQTK_HD inline uint32_t inflate_member(W &w, Shared &S, const MemberArgs &a, StreamEnd *end = nullptr) {
     const uint32_t lane = w.lane();
     Ring<W> ring;
     uint32_t bit = a.first_bit;                    // uniform: next unread bit of the stream
@@ -381,7 +392,9 @@ FQTK_HD inline uint32_t inflate_member(W &w, Shared &S, const MemberArgs &a) {
             if (bit + 8u * len > end_bit) return kErrTruncated;
             if (out_pos + len > a.isize) return kErrOutput;
             const uint8_t *src = reinterpret_cast<const uint8_t *>(a.in_words) + (bit >> 3);
-            for (uint32_t k = lane; k < len; k += 64u) a.out[out_pos + k] = src[k];
+            for (uint32_t k = lane; k < len; k += 64u) {
+                if (kStream) a.out_sym[out_pos + k] = src[k]; else a.out[out_pos + k] = src[k];
+            }
             out_pos += len;
             bit += 8u * len;
             ring.reset(w, a, bit);
@@ -564,7 +577,7 @@ FQTK_UNROLL
                 FQTK_UNROLL
                 for (uint32_t q = 0; q < kSets; ++q) {
                     const bool is_match = (t[q].flags & kTokMatch) != 0u;
-                    too_far = too_far || (mine[q] && is_match && t[q].value > my_pos[q]);
+                    too_far = too_far || (mine[q] && is_match && t[q].value > my_pos[q] + (kStream ? kWindow : 0u));
                     rel_start[q] = my_pos[q] - out_pos;                       // < 128 * 258: 16 bits
                     // kind | start << 1 | (distance - 1, or the literal) << 17
                     packed[q] = (is_match ? 1u : 0u) | (rel_start[q] << 1) | ((is_match ? t[q].value - 1u : t[q].value) << 17);
@@ -610,14 +623,17 @@ FQTK_UNROLL
                             off = (uint32_t)r;
                         }
                         const int32_t rel = (int32_t)(start + off) - (int32_t)dist;   // the source, counted from the window's first byte
-                        if (rel < (int32_t)base) { from_memory = true; src_pos = (uint32_t)((int32_t)out_pos + rel); }
-                        else ptr = (uint32_t)rel - base;
+                        if (rel < (int32_t)base) {
+                            const int32_t sp = (int32_t)out_pos + rel;
+                            if (kStream && sp < 0) byte = 256u + (uint32_t)((int32_t)kWindow + sp);   // in front of the chunk: a reference
+                            else { from_memory = true; src_pos = (uint32_t)sp; }
+                        } else ptr = (uint32_t)rel - base;
                     }
                     if (w.ballot(from_memory && src_pos >= safe)) {           // stores that may still be on their way
                         w.fence_global();
                         safe = out_pos + base;
                     }
-                    if (from_memory) byte = a.out[src_pos];
+                    if (from_memory) byte = kStream ? (uint32_t)a.out_sym[src_pos] : (uint32_t)a.out[src_pos];
                     for (;;) {                                                // ptr -> ptr of ptr until every byte points at a known one (<= 6 rounds)
                         const uint32_t pp = w.shuffle(ptr, ptr);
                         if (!w.ballot(pp != ptr)) break;
@@ -625,7 +641,7 @@ FQTK_UNROLL
                     }
                     byte = w.shuffle(byte, ptr);
 #ifndef FQTK_INFLATE_ABL_NOSTORE
-                    if (live) a.out[out_pos + j] = (uint8_t)byte;
+                    if (live) { if (kStream) a.out_sym[out_pos + j] = (uint16_t)byte; else a.out[out_pos + j] = (uint8_t)byte; }
 #endif
                 }
                 out_pos += produced;
@@ -635,9 +651,12 @@ FQTK_UNROLL
             }
         }
         if (bit > end_bit) return kErrTruncated;
-        if (final_block) break;
+        if (final_block || (kStream && bit >= a.stop_bit)) {
+            if (kStream && end && lane == 0u) { end->n_sym = out_pos; end->end_bit = bit; end->final_block = final_block; }
+            break;
+        }
     }
-    if (out_pos != a.isize) return kErrLength;
+    if (!kStream && out_pos != a.isize) return kErrLength;
     return kOk;
 }
 

@@ -20,6 +20,7 @@
 #include <vector>
 
 #include "../../include/fqtk_demux.h"
+#include "bgzf_deflate.hpp"
 #include "bgzf_internal.hpp"
 #include "demux_kernels.hip.h"
 #include "inflate_internal.hpp"
@@ -116,6 +117,19 @@ struct FedInput {
     uint64_t members_fed = 0;
     uint64_t text_total = 0;            // bytes of text fed so far
     bool ended = false;
+    // a serial gzip stream in chunks (fqtk_demuxer_stream_decode / _commit)
+    DevBuf<uint16_t> sym;
+    DevBuf<uint8_t> windows;
+    DevBuf<fqtk::inflate::StreamChunk> d_chunks;
+    DevBuf<fqtk::inflate::StreamChunkEnd> d_ends;
+    DevBuf<unsigned long long> d_out_off;
+    DevBuf<uint32_t> d_crc;
+    PinBuf<fqtk::inflate::StreamChunk> h_chunks;
+    PinBuf<fqtk::inflate::StreamChunkEnd> h_ends;
+    PinBuf<unsigned long long> h_out_off;
+    PinBuf<uint32_t> h_crc;
+    uint8_t *d_last_window = nullptr;   // the 32 KiB of text behind the last committed chunk
+    uint32_t stream_chunks = 0;         // chunks of the decode in hand
 };
 constexpr uint64_t kFedSlack = 256;     // bytes kept free behind the text (the check kernel and the line index read whole dwords / 16 bytes)
 
@@ -377,6 +391,9 @@ void fqtk_demuxer_destroy(fqtk_demuxer *d) {
             for (hipEvent_t e : {F.ev_moved, F.ev_t0, F.ev_t1}) if (e) (void)hipEventDestroy(e);
             F.arena[0].release(); F.arena[1].release(); F.comp.release(); F.d_members.release(); F.d_status.release(); F.d_lines.release();
             F.h_status.release(); F.h_lines.release(); F.h_members.release();
+            F.sym.release(); F.windows.release(); F.d_chunks.release(); F.d_ends.release(); F.d_out_off.release(); F.d_crc.release();
+            F.h_chunks.release(); F.h_ends.release(); F.h_out_off.release(); F.h_crc.release();
+            if (F.d_last_window) (void)hipFree(F.d_last_window);
         }
         delete[] d->fed;
     }
@@ -530,12 +547,8 @@ int fqtk_demuxer_submit(fqtk_demuxer *d, int slot, const uint8_t *const *text, c
     return submit_common(d, slot, text, text_len, nullptr, n);
 }
 
-// ---- BGZF inputs inflated on the device ---------------------------------------------------------------------------------
-int fqtk_demuxer_feed(fqtk_demuxer *d, uint32_t input, const uint8_t *bytes, uint64_t len, const fqtk_inflate_member *members,
-                      uint32_t n_members, int last, uint64_t *lines_available) {
-    if (!d || (n_members && (!bytes || !members))) return set_error(FQTK_EINVAL, "NULL argument");
-    if (input >= d->C.n_inputs) return set_error(FQTK_EINVAL, "input out of range");
-    DX_TRY(hipSetDevice(d->device));
+// The per-input state of fed text: made by the first feed of the run.
+static int fed_init(fqtk_demuxer *d) {
     {   // first feed of the run: the per-input state
         std::lock_guard<std::mutex> lk(d->init_mu);
         if (!d->fed) {
@@ -555,16 +568,13 @@ int fqtk_demuxer_feed(fqtk_demuxer *d, uint32_t input, const uint8_t *bytes, uin
             d->fed = f;
         }
     }
-    FedInput &F = d->fed[input];
-    std::unique_lock<std::mutex> lk(F.mu);
-    if (F.ended) return set_error(FQTK_EINVAL, "the input's last members have been fed already");
-    uint64_t text_bytes = last ? 1 : 0;
-    for (uint32_t j = 0; j < n_members; ++j) {
-        if (members[j].isize > FQTK_INFLATE_MAX_ISIZE) return set_error(FQTK_EINVAL, "a BGZF member of more than 64 KiB of text");
-        text_bytes += members[j].isize;
-    }
+    return FQTK_OK;
+}
+
+// Room for text_bytes more text of an input (its mutex held): when the arena is full, what chunks have not consumed yet moves to the
+// front of the other arena.
+static int fed_make_room(fqtk_demuxer *d, FedInput &F, uint64_t text_bytes) {
     int rc;
-    // room in the arena?  if not: what chunks have not consumed yet moves to the front of the other one
     uint64_t live_from = F.members.empty() ? F.tail : F.members.front().off;
     if (F.tail + text_bytes + kFedSlack > F.arena[F.cur].cap) {
         const uint64_t live = F.tail - live_from;
@@ -591,6 +601,29 @@ int fqtk_demuxer_feed(fqtk_demuxer *d, uint32_t input, const uint8_t *bytes, uin
         F.cur = other;
         F.tail = shift + live;
     }
+    return FQTK_OK;
+}
+
+// ---- BGZF inputs inflated on the device ---------------------------------------------------------------------------------
+int fqtk_demuxer_feed(fqtk_demuxer *d, uint32_t input, const uint8_t *bytes, uint64_t len, const fqtk_inflate_member *members,
+                      uint32_t n_members, int last, uint64_t *lines_available) {
+    if (!d || (n_members && (!bytes || !members))) return set_error(FQTK_EINVAL, "NULL argument");
+    if (input >= d->C.n_inputs) return set_error(FQTK_EINVAL, "input out of range");
+    DX_TRY(hipSetDevice(d->device));
+    {
+        const int rc0 = fed_init(d);
+        if (rc0 != FQTK_OK) return rc0;
+    }
+    FedInput &F = d->fed[input];
+    std::unique_lock<std::mutex> lk(F.mu);
+    if (F.ended) return set_error(FQTK_EINVAL, "the input's last members have been fed already");
+    uint64_t text_bytes = last ? 1 : 0;
+    for (uint32_t j = 0; j < n_members; ++j) {
+        if (members[j].isize > FQTK_INFLATE_MAX_ISIZE) return set_error(FQTK_EINVAL, "a BGZF member of more than 64 KiB of text");
+        text_bytes += members[j].isize;
+    }
+    int rc;
+    if ((rc = fed_make_room(d, F, text_bytes)) != FQTK_OK) return rc;
     // the members' places, the copy in, the kernels, the counts back
     if ((rc = F.h_members.ensure(n_members + 1)) != FQTK_OK) return rc;
     if ((rc = F.d_members.ensure(n_members + 1)) != FQTK_OK) return rc;
@@ -690,6 +723,149 @@ int fqtk_demuxer_submit_fed(fqtk_demuxer *d, int slot, uint32_t n) {
         std::lock_guard<std::mutex> lk(d->fed[i].mu);
         d->fed[i].lines_consumed += 4ull * n;
     }
+    return FQTK_OK;
+}
+
+// ---- serial gzip inputs (one member per file: gzip, bcl2fastq) decoded on the device in chunks ------------------------------
+int fqtk_demuxer_stream_decode(fqtk_demuxer *d, uint32_t input, const uint8_t *bytes, uint64_t len, const fqtk_stream_chunk *chunks, uint32_t n,
+                               fqtk_stream_end *ends) {
+    if (!d || !bytes || !chunks || !ends || n == 0) return set_error(FQTK_EINVAL, "NULL argument / no chunks");
+    if (input >= d->C.n_inputs) return set_error(FQTK_EINVAL, "input out of range");
+    if (len >= (1ull << 29)) return set_error(FQTK_EINVAL, "a stretch of 512 MiB or more: use shorter stretches");
+    DX_TRY(hipSetDevice(d->device));
+    int rc;
+    if ((rc = fed_init(d)) != FQTK_OK) return rc;
+    FedInput &F = d->fed[input];
+    if ((rc = F.comp.ensure((size_t)len + 16)) != FQTK_OK) return rc;
+    if ((rc = F.h_chunks.ensure(n)) != FQTK_OK) return rc;
+    if ((rc = F.d_chunks.ensure(n)) != FQTK_OK) return rc;
+    if ((rc = F.h_ends.ensure(n)) != FQTK_OK) return rc;
+    if ((rc = F.d_ends.ensure(n)) != FQTK_OK) return rc;
+    // room for every chunk's symbols: FASTQ text deflates 3-7 : 1; twelve times the chunk's compressed bytes (+ a block's worth) is
+    // given, and a chunk that needs more reports FQTK_INFLATE_ERR_OUTPUT (the caller then cuts the stretch shorter)
+    uint64_t sym_total = 0;
+    for (uint32_t k = 0; k < n; ++k) {
+        const uint64_t stop = chunks[k].stop_bit == ~0ull ? len * 8u : chunks[k].stop_bit;
+        if (chunks[k].start_bit > len * 8u || stop < chunks[k].start_bit) return set_error(FQTK_EINVAL, "a chunk outside the stretch");
+        const uint64_t cbytes = (stop - chunks[k].start_bit) / 8u + 65536u;
+        const uint64_t cap = std::min<uint64_t>(cbytes * 12u + 262144u, 0xFFFFFF00ull);
+        F.h_chunks.p[k] = fqtk::inflate::StreamChunk{chunks[k].start_bit, chunks[k].stop_bit, sym_total, (uint32_t)cap, 0u};
+        sym_total += (cap + 7u) & ~7ull;
+    }
+    if ((rc = F.sym.ensure((size_t)sym_total + 64)) != FQTK_OK) return rc;
+    DX_TRY(hipMemcpyAsync(F.comp.p, bytes, (size_t)len, hipMemcpyHostToDevice, F.stream));
+    DX_TRY(hipMemcpyAsync(F.d_chunks.p, F.h_chunks.p, (size_t)n * sizeof(fqtk::inflate::StreamChunk), hipMemcpyHostToDevice, F.stream));
+    DX_TRY(hipEventRecord(F.ev_t0, F.stream));
+    DX_TRY(fqtk::inflate::stream_decode_launch(F.stream, F.comp.p, len, F.d_chunks.p, n, F.sym.p, F.d_ends.p));
+    DX_TRY(hipEventRecord(F.ev_t1, F.stream));
+    DX_TRY(hipMemcpyAsync(F.h_ends.p, F.d_ends.p, (size_t)n * sizeof(fqtk::inflate::StreamChunkEnd), hipMemcpyDeviceToHost, F.stream));
+    DX_TRY(hipStreamSynchronize(F.stream));
+    {
+        float ms = 0;
+        if (hipEventElapsedTime(&ms, F.ev_t0, F.ev_t1) == hipSuccess) { std::lock_guard<std::mutex> glk(d->stat_mu); d->inflate_s += ms * 1e-3; }
+    }
+    for (uint32_t k = 0; k < n; ++k) {
+        ends[k].status = F.h_ends.p[k].status;
+        ends[k].final_block = F.h_ends.p[k].final_block;
+        ends[k].n_bytes = F.h_ends.p[k].n_sym;
+        ends[k].end_bit = F.h_ends.p[k].end_bit;
+    }
+    F.stream_chunks = n;
+    return FQTK_OK;
+}
+
+int fqtk_demuxer_stream_commit(fqtk_demuxer *d, uint32_t input, uint32_t n_accept, int member_start, int last, uint64_t *lines_fed, uint32_t *crc32,
+                               uint64_t *n_text) {
+    if (!d || !d->fed || input >= d->C.n_inputs) return set_error(FQTK_EINVAL, "nothing decoded / input out of range");
+    DX_TRY(hipSetDevice(d->device));
+    FedInput &F = d->fed[input];
+    if (n_accept > F.stream_chunks) return set_error(FQTK_EINVAL, "more chunks accepted than decoded");
+    std::unique_lock<std::mutex> lk(F.mu);
+    if (F.ended) return set_error(FQTK_EINVAL, "the input has ended already");
+    int rc;
+    uint64_t total = 0;
+    if ((rc = F.h_out_off.ensure(n_accept + 1)) != FQTK_OK) return rc;
+    if ((rc = F.d_out_off.ensure(n_accept + 1)) != FQTK_OK) return rc;
+    for (uint32_t k = 0; k < n_accept; ++k) total += F.h_ends.p[k].n_sym;
+    const uint64_t text_bytes = total + (last ? 1 : 0);
+    if ((rc = fed_make_room(d, F, text_bytes)) != FQTK_OK) return rc;
+    const uint64_t at = F.tail;
+    {
+        uint64_t o = at;
+        for (uint32_t k = 0; k < n_accept; ++k) { F.h_out_off.p[k] = o; o += F.h_ends.p[k].n_sym; }
+    }
+    const uint32_t n_pieces = (uint32_t)((total + 65535u) / 65536u);
+    if ((rc = F.h_members.ensure(n_pieces + 1)) != FQTK_OK) return rc;
+    if ((rc = F.d_members.ensure(n_pieces + 1)) != FQTK_OK) return rc;
+    if ((rc = F.d_status.ensure(n_pieces + 1)) != FQTK_OK) return rc;
+    if ((rc = F.d_lines.ensure(n_pieces + 1)) != FQTK_OK) return rc;
+    if ((rc = F.h_lines.ensure(n_pieces + 1)) != FQTK_OK) return rc;
+    if ((rc = F.d_crc.ensure(n_pieces + 1)) != FQTK_OK) return rc;
+    if ((rc = F.h_crc.ensure(n_pieces + 1)) != FQTK_OK) return rc;
+    if ((rc = F.windows.ensure((size_t)(n_accept + 1) * fqtk::inflate::kStreamWindow)) != FQTK_OK) return rc;
+    if (!F.d_last_window) {
+        DX_TRY(hipMalloc(reinterpret_cast<void **>(&F.d_last_window), fqtk::inflate::kStreamWindow));
+        DX_TRY(hipMemsetAsync(F.d_last_window, 0, fqtk::inflate::kStreamWindow, F.stream));
+    }
+    for (uint32_t p = 0; p < n_pieces; ++p) {
+        fqtk_inflate_member m;
+        std::memset(&m, 0, sizeof m);
+        m.out_off = at + (uint64_t)p * 65536u;
+        m.isize = (uint32_t)std::min<uint64_t>(65536u, total - (uint64_t)p * 65536u);
+        F.h_members.p[p] = m;
+    }
+    uint8_t *const arena = F.arena[F.cur].p;
+    F.tail = at + text_bytes;
+    lk.unlock();
+    if (n_accept) {
+        // the window in front of the first chunk: none at the start of a member, else what the last commit left
+        if (member_start) DX_TRY(hipMemsetAsync(F.windows.p, 0, fqtk::inflate::kStreamWindow, F.stream));
+        else DX_TRY(hipMemcpyAsync(F.windows.p, F.d_last_window, fqtk::inflate::kStreamWindow, hipMemcpyDeviceToDevice, F.stream));
+        DX_TRY(hipMemcpyAsync(F.d_out_off.p, F.h_out_off.p, (size_t)n_accept * sizeof(unsigned long long), hipMemcpyHostToDevice, F.stream));
+        // (window n_accept -- the text behind the last accepted chunk -- comes out of the same chain: the next commit starts from it)
+        DX_TRY(fqtk::inflate::stream_resolve_launch(F.stream, F.d_chunks.p, F.d_ends.p, n_accept, reinterpret_cast<const uint64_t *>(F.d_out_off.p), F.sym.p, F.windows.p, arena));
+        DX_TRY(hipMemcpyAsync(F.d_last_window, F.windows.p + (size_t)n_accept * fqtk::inflate::kStreamWindow, fqtk::inflate::kStreamWindow, hipMemcpyDeviceToDevice, F.stream));
+    }
+    if (n_pieces) {
+        DX_TRY(hipMemcpyAsync(F.d_members.p, F.h_members.p, (size_t)n_pieces * sizeof(fqtk_inflate_member), hipMemcpyHostToDevice, F.stream));
+        DX_TRY(hipMemsetAsync(F.d_status.p, 0, (size_t)n_pieces * sizeof(uint32_t), F.stream));
+        DX_TRY(fqtk::inflate::pieces_check_launch(F.stream, F.d_members.p, n_pieces, arena, F.d_status.p, F.d_lines.p, F.d_crc.p, d->d_crc_pow));
+        DX_TRY(hipMemcpyAsync(F.h_lines.p, F.d_lines.p, (size_t)n_pieces * sizeof(uint32_t), hipMemcpyDeviceToHost, F.stream));
+        DX_TRY(hipMemcpyAsync(F.h_crc.p, F.d_crc.p, (size_t)n_pieces * sizeof(uint32_t), hipMemcpyDeviceToHost, F.stream));
+    }
+    if (last) {
+        hipLaunchKernelGGL(k_put_newline, dim3(1), dim3(1), 0, F.stream, arena + at + total);
+        DX_TRY(hipGetLastError());
+    }
+    DX_TRY(hipStreamSynchronize(F.stream));
+    // CRC-32 of the committed text: the pieces' values folded (crc(A || B) = crc(A) * x^(8 |B|) + crc(B), bgzf_deflate.hpp)
+    uint32_t crc = 0;
+    {
+        static const uint32_t pow_full = fqtk::bgzf::crc_x_pow(8u * 65536u);
+        for (uint32_t p = 0; p < n_pieces; ++p) {
+            const uint32_t len_p = F.h_members.p[p].isize;
+            crc = fqtk::bgzf::crc_gf_mul(crc, len_p == 65536u ? pow_full : fqtk::bgzf::crc_x_pow(8u * len_p)) ^ F.h_crc.p[p];
+        }
+    }
+    lk.lock();
+    for (uint32_t p = 0; p < n_pieces; ++p) {
+        F.members.push_back(FedMember{F.h_members.p[p].out_off, F.h_members.p[p].isize, F.h_lines.p[p], F.lines_total, F.text_total});
+        F.lines_total += F.h_lines.p[p];
+        F.text_total += F.h_members.p[p].isize;
+    }
+    F.members_fed += n_pieces;
+    if (last) {
+        if (F.members.empty()) F.members.push_back(FedMember{at + total, 0, 0, F.lines_total, F.text_total});
+        F.text_total += 1;
+        F.members.back().isize += 1;
+        F.members.back().lines += 1;
+        F.lines_total += 1;
+        F.ended = true;
+    }
+    F.stream_chunks = 0;
+    if (lines_fed) *lines_fed = F.lines_total;
+    if (crc32) *crc32 = crc;
+    if (n_text) *n_text = total;
     return FQTK_OK;
 }
 

@@ -89,7 +89,7 @@ __global__ __launch_bounds__(64) FQTK_INFLATE_OCCUPANCY void inflate_kernel(cons
 // (bgzf_deflate.hpp: crc_gf_mul; the powers come from a table made once per handle).
 constexpr uint32_t kSlice = 264, kSliceWords = kSlice / 4, kSliceStride = kSliceWords + 1;   // 256 x 264 >= 3 + 65 536
 __global__ __launch_bounds__(256) void member_check_kernel(const fqtk_inflate_member *members, uint32_t n, const uint8_t *out,
-                                                           uint32_t *status, uint32_t *lines, const uint32_t *crc_pow) {
+                                                           uint32_t *status, uint32_t *lines, const uint32_t *crc_pow, uint32_t *crc_out) {
     extern __shared__ uint32_t lds[];
     uint32_t *tab = lds, *part = lds + 256, *cnt = lds + 260, *text = lds + 264;
     const uint32_t j = blockIdx.x, lane = threadIdx.x;
@@ -137,10 +137,104 @@ __global__ __launch_bounds__(256) void member_check_kernel(const fqtk_inflate_me
     if (lane == 0) {
         const uint32_t crc = part[0] ^ part[1] ^ part[2] ^ part[3];
         lines[j] = cnt[0] + cnt[1] + cnt[2] + cnt[3];
-        if (st == kOk && crc != m.crc) status[j] = kErrCrc;
+        if (crc_out) crc_out[j] = crc;   // (pieces of a stream: the caller folds them into the member's CRC)
+        else if (st == kOk && crc != m.crc) status[j] = kErrCrc;
     }
 }
 constexpr size_t kCheckLds = (264 + 256 * kSliceStride) * sizeof(uint32_t);
+
+// ---- a serial gzip stream in chunks (stream mode of inflate_member; host/parallel_gunzip.hpp is the CPU form of the same plan) -----
+// One wavefront per chunk: from the chunk's block boundary to the first block boundary at or behind the next chunk's, 16-bit symbols out.
+__global__ __launch_bounds__(64) void stream_kernel(const uint8_t *in, uint64_t in_len, const StreamChunk *chunks, uint32_t n, uint16_t *sym, StreamChunkEnd *ends) {
+    __shared__ Shared S;
+    __shared__ StreamEnd end;
+    const uint32_t j = blockIdx.x;
+    if (j >= n) return;
+    const StreamChunk c = chunks[j];
+    if (threadIdx.x == 0) { end.n_sym = 0; end.end_bit = 0; end.final_block = 0; }
+    __syncthreads();
+    const uint64_t base_word = c.start_bit >> 5;
+    uint32_t st = kErrTruncated;
+    if (base_word * 4u < in_len) {
+        MemberArgs a;
+        a.in_words = reinterpret_cast<const uint32_t *>(in) + base_word;
+        a.first_bit = (uint32_t)(c.start_bit & 31u);
+        const uint64_t bytes_left = in_len - base_word * 4u;
+        const uint64_t bits_left = bytes_left * 8u;
+        a.payload_bits = (uint32_t)(bits_left > 0xFFFFFF00ull ? 0xFFFFFF00ull : bits_left) - a.first_bit;
+        a.readable_words = (uint32_t)(bytes_left / 4u > 0x7FFFFFFFull ? 0x7FFFFFFFull : bytes_left / 4u);
+        a.tail_bytes = (uint32_t)(bytes_left & 3u);
+        a.out = nullptr;
+        a.isize = c.cap;
+        a.out_sym = sym + c.sym_off;
+        const uint64_t stop_rel = c.stop_bit - base_word * 32u;
+        a.stop_bit = c.stop_bit == ~0ull || stop_rel > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)stop_rel;
+        DeviceWave w;
+        st = inflate_member<DeviceWave, true>(w, S, a, &end);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        StreamChunkEnd e;
+        e.status = st;
+        e.final_block = end.final_block;
+        e.n_sym = end.n_sym;
+        e.end_bit = base_word * 32u + end.end_bit;
+        ends[j] = e;
+    }
+}
+
+__device__ inline uint32_t resolve_symbol(uint32_t s, const uint8_t *window) { return s < 256u ? s : (uint32_t)window[(s - 256u) & (kWindow - 1u)]; }
+
+// The windows down the chain: windows[k] = the 32 KiB of text in front of chunk k (windows[0] is given; windows[n] = behind the last chunk).  One workgroup,
+// chunk after chunk: 32 symbols per lane and chunk.
+__global__ __launch_bounds__(1024) void window_chain_kernel(const StreamChunk *chunks, const StreamChunkEnd *ends, uint32_t n, const uint16_t *sym, uint8_t *windows) {
+    for (uint32_t k = 0; k < n; ++k) {
+        const uint8_t *w0 = windows + (size_t)k * kWindow;
+        uint8_t *w1 = windows + (size_t)(k + 1u) * kWindow;
+        const uint16_t *s = sym + chunks[k].sym_off;
+        const uint32_t ns = ends[k].n_sym;
+        for (uint32_t j = threadIdx.x; j < kWindow; j += 1024u) {
+            const int64_t p = (int64_t)ns - (int64_t)kWindow + (int64_t)j;   // position in chunk k's text of byte j of the next window
+            w1[j] = p >= 0 ? (uint8_t)resolve_symbol(s[p], w0) : w0[kWindow + p];
+        }
+        __threadfence_block();
+        __syncthreads();
+    }
+}
+
+// Every chunk's symbols to bytes, side by side: text[out_off[k] + i].
+__global__ __launch_bounds__(256) void stream_resolve_kernel(const StreamChunk *chunks, const StreamChunkEnd *ends, const uint64_t *out_off, const uint16_t *sym,
+                                                             const uint8_t *windows, uint8_t *text) {
+    const uint32_t k = blockIdx.y;
+    const uint16_t *s = sym + chunks[k].sym_off;
+    const uint8_t *w = windows + (size_t)k * kWindow;
+    uint8_t *t = text + out_off[k];
+    const uint32_t ns = ends[k].n_sym;
+    // four symbols per lane and step where the text is aligned (it is, up to the chunk's first bytes)
+    for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < ns; i += gridDim.x * 256u) t[i] = (uint8_t)resolve_symbol(s[i], w);
+}
+
+hipError_t stream_decode_launch(hipStream_t stream, const uint8_t *in, uint64_t in_len, const StreamChunk *chunks, uint32_t n, uint16_t *sym, StreamChunkEnd *ends) {
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(stream_kernel, dim3(n), dim3(64), 0, stream, in, in_len, chunks, n, sym, ends);
+    return hipGetLastError();
+}
+hipError_t stream_resolve_launch(hipStream_t stream, const StreamChunk *chunks, const StreamChunkEnd *ends, uint32_t n, const uint64_t *out_off, const uint16_t *sym,
+                                 uint8_t *windows, uint8_t *text) {
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(window_chain_kernel, dim3(1), dim3(1024), 0, stream, chunks, ends, n, sym, windows);
+    hipLaunchKernelGGL(stream_resolve_kernel, dim3(64, n), dim3(256), 0, stream, chunks, ends, out_off, sym, (const uint8_t *)windows, text);
+    return hipGetLastError();
+}
+// CRC-32 and newlines of pieces of text that is already in place (members[j].out_off / isize; nothing else of a member is used)
+hipError_t pieces_check_launch(hipStream_t stream, const fqtk_inflate_member *pieces, uint32_t n, const uint8_t *text, uint32_t *status_zero, uint32_t *lines, uint32_t *crc,
+                               const uint32_t *crc_pow_dev) {
+    if (n == 0) return hipSuccess;
+    static const hipError_t prepared = hipFuncSetAttribute(reinterpret_cast<const void *>(member_check_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kCheckLds);
+    if (prepared != hipSuccess) return prepared;
+    hipLaunchKernelGGL(member_check_kernel, dim3(n), dim3(256), kCheckLds, stream, pieces, n, text, status_zero, lines, crc_pow_dev, crc);
+    return hipGetLastError();
+}
 
 void crc_pow_table(uint32_t *pow) {
     for (uint32_t k = 0; k < 256u; ++k) pow[k] = bgzf::crc_x_pow(8u * kSlice * k);
@@ -153,7 +247,7 @@ hipError_t inflate_launch(hipStream_t stream, const uint8_t *in, uint64_t in_len
     static const hipError_t prepared = hipFuncSetAttribute(reinterpret_cast<const void *>(member_check_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kCheckLds);
     if (prepared != hipSuccess) return prepared;
     hipLaunchKernelGGL(inflate_kernel, dim3(n), dim3(64), 0, stream, in, in_len, members, n, out, status);
-    hipLaunchKernelGGL(member_check_kernel, dim3(n), dim3(256), kCheckLds, stream, members, n, (const uint8_t *)out, status, lines, crc_pow_dev);
+    hipLaunchKernelGGL(member_check_kernel, dim3(n), dim3(256), kCheckLds, stream, members, n, (const uint8_t *)out, status, lines, crc_pow_dev, (uint32_t *)nullptr);
     return hipGetLastError();
 }
 

@@ -423,6 +423,39 @@ int fqtk_host_bgzf_inflate_emulated(const uint8_t *payload, uint32_t payload_len
     return (int)status[0];
 }
 
+// A piece of a serial DEFLATE stream decoded by the device decoder's stream mode (inflate_member<W, true>) on the wave emulator:
+// from bit `start_bit` of data (a block boundary) to the first block boundary at or behind stop_bit, into 16-bit symbols
+// (< 256: a byte; 256 + j: byte j of the 32 KiB in front of the piece).  Returns the status; res = {symbols, end bit, final block}.
+int fqtk_host_inflate_stream_emulated(const uint8_t *data, uint32_t len, uint32_t start_bit, uint32_t stop_bit, uint16_t *sym, uint32_t cap, uint32_t *res) {
+    using namespace fqtk::inflate;
+    const uint32_t words = len / 4u;
+    std::vector<uint32_t> buf(words + 2u, 0xA5A5A5A5u);
+    std::memcpy(buf.data(), data, len);
+    std::vector<uint8_t> mem(sizeof(Shared), 0xC3);
+    Shared &S = *reinterpret_cast<Shared *>(mem.data());
+    MemberArgs a;
+    std::memset(&a, 0, sizeof a);
+    a.in_words = buf.data() + (start_bit >> 5);   // (the device wrapper rebases a chunk the same way)
+    a.first_bit = start_bit & 31u;
+    a.payload_bits = 8u * len - (start_bit & ~31u) - a.first_bit;
+    a.readable_words = words - (start_bit >> 5);
+    a.tail_bytes = len & 3u;
+    a.out = nullptr;
+    a.isize = cap;
+    a.out_sym = sym;
+    a.stop_bit = stop_bit - (start_bit & ~31u);
+    uint32_t status[64];
+    StreamEnd end = {0, 0, 0};
+    fqtk_host::WaveEmu wave;
+    wave.run([&](fqtk_host::WaveEmu &w) { status[w.lane()] = inflate_member<fqtk_host::WaveEmu, true>(w, S, a, &end); });
+    for (int l = 1; l < 64; ++l)
+        if (status[l] != status[0]) return -1;
+    res[0] = end.n_sym;
+    res[1] = end.end_bit + (start_bit & ~31u);
+    res[2] = end.final_block;
+    return (int)status[0];
+}
+
 // One output record the way the GPU record pipeline states it (csrc/record_format.hpp: header plan + pieces), built
 // from strings: `header` is the first input's header, bsegs / msegs the sample / molecular barcode segments, bases and
 // quals the segment the file takes.  Returns the record's length (also what the sizing sink says), -1 - HeaderError for

@@ -112,6 +112,23 @@ class Demuxer:
                                            1 if last else 0, C.byref(fed)))
         return int(fed.value)
 
+    def stream_decode(self, input_index: int, data: bytes, chunks):
+        """chunks: [(start_bit, stop_bit | None)] of a serial DEFLATE stream in `data`.  Returns [(status, final, n_bytes, end_bit)]."""
+        arr = (_lib.fqtk_stream_chunk * len(chunks))()
+        for k, (a, b) in enumerate(chunks):
+            arr[k].start_bit, arr[k].stop_bit = a, (0xFFFFFFFFFFFFFFFF if b is None else b)
+        ends = (_lib.fqtk_stream_end * len(chunks))()
+        buf = np.frombuffer(data + b"\0" * 8, dtype=np.uint8)
+        _check(self._lib.fqtk_demuxer_stream_decode(self._h, input_index, buf.ctypes.data, len(data), arr, len(chunks), ends))
+        return [(int(e.status), int(e.final_block), int(e.n_bytes), int(e.end_bit)) for e in ends]
+
+    def stream_commit(self, input_index: int, n_accept: int, member_start: bool, last: bool):
+        """(lines fed so far, CRC-32 of the committed text, its length)"""
+        fed, crc, n = C.c_uint64(0), C.c_uint32(0), C.c_uint64(0)
+        _check(self._lib.fqtk_demuxer_stream_commit(self._h, input_index, n_accept, 1 if member_start else 0, 1 if last else 0,
+                                                    C.byref(fed), C.byref(crc), C.byref(n)))
+        return int(fed.value), int(crc.value), int(n.value)
+
     def submit_fed(self, slot: int, n_templates: int) -> None:
         _check(self._lib.fqtk_demuxer_submit_fed(self._h, slot, n_templates))
 

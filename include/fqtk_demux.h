@@ -130,6 +130,30 @@ int fqtk_demuxer_submit_fed(fqtk_demuxer *d, int slot, uint32_t n_templates);
  * lies behind the last record (end-of-file checks).  Only text no chunk has consumed in full is still there. */
 int fqtk_demuxer_fed_tail(fqtk_demuxer *d, uint32_t input, uint64_t pos, uint8_t *buf, size_t cap, uint64_t *n_bytes);
 
+/* ---- serial gzip inputs (`gzip`, bcl2fastq: one member per file) decoded on the device in chunks ---------------------------
+ * A gzip member is ONE bit stream; what makes it parallel is host/parallel_gunzip.hpp's plan, moved onto the device: the host
+ * finds places where a DEFLATE block starts (a bit offset whose dynamic-Huffman header parses into two complete codes), every
+ * chunk between two such places is decoded by a wavefront of its own WITHOUT the 32 KiB of text before it (16-bit symbols:
+ * a byte, or a reference into that unknown window), the caller accepts a chunk only if the chunk before it ended on exactly
+ * the bit it started at, and the accepted chunks' windows are then handed down the chain and everything is resolved to
+ * bytes in the input's fed text (where fqtk_demuxer_submit_fed cuts chunks of templates out of it).
+ *
+ * fqtk_demuxer_stream_decode: `bytes` (len < 512 MiB, page-locked for a fast copy) are a stretch of the file; chunk k
+ * starts at bit chunks[k].start_bit of them -- chunk 0 at a bit the caller KNOWS to be a block boundary (the member's first
+ * block, or where the last accepted chunk ended), the others at places it found -- and stops at the first block boundary
+ * at or behind chunks[k].stop_bit (~0: at the member's final block).  Blocks until every chunk is decoded and says how
+ * each ended (status: FQTK_INFLATE_ERR_*, FQTK_INFLATE_ERR_OUTPUT when the chunk's room for symbols -- twelve times its
+ * compressed size -- was too small).
+ * fqtk_demuxer_stream_commit: the first n_accept chunks of that decode become text (member_start != 0: chunk 0 began a gzip
+ * member, nothing lies in front of it; last: as in fqtk_demuxer_feed).  Returns the lines fed so far, and CRC-32 and length
+ * of the committed text for the caller to fold into the member's (zlib's crc32_combine) and compare with the trailer. */
+typedef struct fqtk_stream_chunk { uint64_t start_bit, stop_bit; } fqtk_stream_chunk;
+typedef struct fqtk_stream_end { uint32_t status, final_block; uint64_t n_bytes, end_bit; } fqtk_stream_end;
+int fqtk_demuxer_stream_decode(fqtk_demuxer *d, uint32_t input, const uint8_t *bytes, uint64_t len, const fqtk_stream_chunk *chunks, uint32_t n,
+                               fqtk_stream_end *ends);
+int fqtk_demuxer_stream_commit(fqtk_demuxer *d, uint32_t input, uint32_t n_accept, int member_start, int last, uint64_t *lines_fed, uint32_t *crc32,
+                               uint64_t *n_text);
+
 /* Device seconds spent inflating (all inputs). */
 int fqtk_demuxer_inflate_seconds(fqtk_demuxer *d, double *seconds);
 

@@ -416,3 +416,42 @@ def test_fed_bgzf_members_give_the_files_text_chunks_give(member, feed_members, 
 
 
 from fqtk_amd.demux import BGZF_EOF as H_BGZF_EOF  # noqa: E402
+
+
+def test_a_serial_deflate_stream_decoded_in_chunks_on_the_device():
+    """fqtk_demuxer_stream_decode / stream_commit: one DEFLATE stream (what `gzip` writes) cut at block boundaries, every chunk
+    decoded by a wavefront without the 32 KiB before it (most of a chunk's symbols are references into that unknown window),
+    windows handed down the chain, text / line counts / CRC-32 as zlib gives them -- in two commits (the second starts from the
+    window the first one left), with a chunk that is refused in between."""
+    rng = np.random.default_rng(21)
+    structures = ["+T"]
+    templates = make_templates(rng, 6000, BARCODES8, structures, header_kind=0)
+    text = texts_of(templates, 0, len(templates), 1)[0]
+    parts = [text[o:o + 50000] for o in range(0, len(text), 50000)]
+    c = zlib.compressobj(6, zlib.DEFLATED, -15)
+    comp, bounds = b"", [0]
+    for p in parts[:-1]:
+        comp += c.compress(p) + c.flush(zlib.Z_SYNC_FLUSH)
+        bounds.append(len(comp) * 8)
+    comp += c.compress(parts[-1]) + c.flush()
+    assert len(bounds) >= 8
+    m = BarcodeMatcher(BARCODES8, 1, 2, device=0)
+    d = Demuxer(m, ["8B+T"], "T", max_chunk_templates=4096)
+    half = len(bounds) // 2
+    # first stretch: chunks 0 .. half-1, plus a chunk that starts at a place that is no block boundary (it must not be accepted)
+    chunks = [(bounds[k], bounds[k + 1]) for k in range(half)] + [(bounds[half] + 3, bounds[half + 1])]
+    ends = d.stream_decode(0, comp, chunks)
+    for k in range(half):
+        assert ends[k][0] == 0 and ends[k][3] == bounds[k + 1] and ends[k][2] == len(parts[k]), (k, ends[k])
+    assert ends[half][0] != 0 or ends[half][3] != bounds[half + 1] or ends[half][2] != len(parts[half])
+    fed, crc1, n1 = d.stream_commit(0, half, member_start=True, last=False)
+    assert n1 == sum(len(p) for p in parts[:half]) and crc1 == zlib.crc32(b"".join(parts[:half]))
+    assert fed == b"".join(parts[:half]).count(b"\n")
+    # second stretch: the rest, from where the first ended
+    chunks = [(bounds[k], bounds[k + 1] if k + 1 < len(bounds) else None) for k in range(half, len(bounds))]
+    ends = d.stream_decode(0, comp, chunks)
+    assert all(e[0] == 0 for e in ends) and ends[-1][1] == 1
+    fed, crc2, n2 = d.stream_commit(0, len(chunks), member_start=False, last=True)
+    assert n1 + n2 == len(text) and fed == text.count(b"\n") + 1
+    assert crc2 == zlib.crc32(b"".join(parts[half:]))
+    assert d.fed_tail(0, 0, cap=len(text) + 16) == text + b"\n"
