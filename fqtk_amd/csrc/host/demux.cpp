@@ -115,6 +115,7 @@ struct Options {
     bool chunk_given = false;
     bool host_output = false;        // --host-output: format and compress the records on the host (the reference's way)
     bool host_inflate = false;       // --host-inflate: BGZF inputs are inflated by the reader threads even where the device could
+    bool gpu_gunzip = false;         // --gpu-gunzip: single-stream gzip inputs are decoded on the device in chunks
 };
 
 const char *kUsage =
@@ -141,7 +142,10 @@ const char *kUsage =
     "                                              --gpu-bgzf is accepted and means the default)\n"
     "      --host-inflate                          inflate BGZF inputs on the host CPUs.  Default when every input is a BGZF file (bgzip,\n"
     "                                              htslib, fqtk's own outputs) and one device is used: the compressed members go to\n"
-    "                                              the device and are inflated there (additive flag)\n";
+    "                                              the device and are inflated there (additive flag)\n"
+    "      --gpu-gunzip                            decode single-stream gzip inputs (gzip, bcl2fastq: one member per file) on the\n"
+    "                                              device too: the host only looks for places where a DEFLATE block starts, a wavefront\n"
+    "                                              per chunk decodes between them, windows are handed down the chain (additive flag)\n";
 
 bool parse_ulong(const std::string &s, unsigned long *out) {
     if (s.empty()) return false;
@@ -229,6 +233,7 @@ Options parse_args(int argc, char **argv) {
         else if (a == "--gpu-bgzf") o.host_output = false;
         else if (a == "--host-output" || a == "--no-gpu-bgzf") o.host_output = true;
         else if (a == "--host-inflate") o.host_inflate = true;
+        else if (a == "--gpu-gunzip") o.gpu_gunzip = true;
         else if (a == "--help" || a == "-h") { std::fputs(kUsage, stdout); std::exit(0); }
         else die("unexpected argument '" + a + "' found\n\n" + kUsage);
     }
@@ -464,6 +469,25 @@ bool gpu_output_supported(const Plan &plan, std::string *why) {
     return true;
 }
 
+// Length of the gzip member header at p (RFC 1952 2.3; fast_inflate.hpp parses the same fields), 0 if there is none.
+size_t gzip_header_len(const uint8_t *p, size_t n) {
+    if (n < 18 || p[0] != 0x1f || p[1] != 0x8b || p[2] != 8 || (p[3] & 0xE0)) return 0;
+    const uint8_t flg = p[3];
+    size_t at = 10;
+    if (flg & 4) {
+        if (at + 2 > n) return 0;
+        at += 2 + ((size_t)p[at] | ((size_t)p[at + 1] << 8));
+    }
+    for (int f = 8; f <= 16; f <<= 1) {
+        if (!(flg & f)) continue;
+        const void *z = at < n ? std::memchr(p + at, 0, n - at) : nullptr;
+        if (!z) return 0;
+        at = (size_t)(static_cast<const uint8_t *>(z) - p) + 1;
+    }
+    if (flg & 2) at += 2;
+    return at < n ? at : 0;
+}
+
 [[noreturn]] void run_gpu_output(const Options &opt, const Plan &plan, const std::vector<Sample> &samples,
                                  std::vector<std::unique_ptr<FastqSource>> &sources, bool skip_few) {
     const size_t n_inputs = plan.rs.size(), S = samples.size(), G = opt.devices.size();
@@ -481,15 +505,21 @@ bool gpu_output_supported(const Plan &plan, std::string *why) {
 
     // ---- BGZF inputs: their members go to the device compressed and are inflated there (fqtk_demuxer_feed), when every
     // input is one and a single device takes all chunks (the fed text lives on one device)
-    std::vector<std::unique_ptr<BgzfFile>> bgzf_in;
+    std::vector<std::unique_ptr<BgzfFile>> bgzf_in;   // (the mapped file of every fed input, BGZF or serial gzip)
+    std::vector<char> is_serial_gz(n_inputs, 0);
+    const bool gpu_gunzip = opt.gpu_gunzip || env_on("FQTK_GPU_GUNZIP");
     bool fed_mode = G == 1 && !opt.host_inflate && !env_on("FQTK_HOST_INFLATE");
+    size_t n_serial = 0;
     for (size_t i = 0; i < n_inputs && fed_mode; ++i) {
-        if (sources[i]->kind() != FastqSource::Kind::Bgzf) { fed_mode = false; break; }
+        const FastqSource::Kind kd = sources[i]->kind();
+        if (kd == FastqSource::Kind::Gzip && gpu_gunzip) { is_serial_gz[i] = 1; ++n_serial; }
+        else if (kd != FastqSource::Kind::Bgzf) { fed_mode = false; break; }
         std::string e;
         bgzf_in.push_back(std::make_unique<BgzfFile>());
         if (!bgzf_in.back()->open(opt.inputs[i], &e)) fed_mode = false;   // (a pipe: the reader threads inflate it)
     }
-    if (!fed_mode) bgzf_in.clear();
+    if (!fed_mode) { bgzf_in.clear(); n_serial = 0; }
+    else if (n_serial) info("gzip inputs: decoded on the device in chunks (BGZF members: one wavefront each).");
     else info("BGZF inputs: members are inflated on the device.");
 
     // ---- devices: matcher + record pipeline each (their bring-up overlaps the first reads and the file creation)
@@ -802,6 +832,144 @@ bool gpu_output_supported(const Plan &plan, std::string *why) {
                     fed_done[i] = 1;
                     fcv.notify_all();
                 };
+                if (is_serial_gz[i]) {
+                    // ---- a serial gzip file: stretches of chunks between block starts this thread (and its helpers) finds, decoded
+                    // by a wavefront each without their windows, accepted where the chain of block boundaries proves the parse
+                    // (host/parallel_gunzip.hpp's rule), resolved on the device.  A stretch takes the device about as long as ONE
+                    // chunk takes a wavefront (~0.2 s per MiB of compressed FASTQ), so stretches are long: up to 1024 chunks.
+                    static const size_t kChunkBytes = [] { const char *v = std::getenv("FQTK_GZ_DEVICE_CHUNK_KB"); return (size_t)(v && *v ? std::atol(v) : 1024) << 10; }();
+                    static const size_t kMaxChunks = [] { const char *v = std::getenv("FQTK_GZ_DEVICE_CHUNKS"); return (size_t)(v && *v ? std::atol(v) : 1024); }();
+                    const unsigned searchers = std::max(1u, std::min(8u, (unsigned)(usable_cpus() / std::max<size_t>(1, n_serial))));
+                    std::vector<std::unique_ptr<SpecInflate>> finders;
+                    for (unsigned q = 0; q < searchers; ++q) { finders.push_back(std::make_unique<SpecInflate>()); finders.back()->attach(bf.map, bf.size); }
+                    const uint64_t file_bits = (uint64_t)bf.size * 8u;
+                    const uint64_t gz_high_water = 4ull * chunk * 12;
+                    size_t pos = 0;                 // byte of the current member's header
+                    size_t chunk_bytes = kChunkBytes, stretch_chunks = std::min<size_t>(128, kMaxChunks);
+                    bool all_done = false;
+                    while (!all_done) {
+                        const size_t hl = gzip_header_len(bf.map + pos, bf.size - pos);
+                        if (hl == 0) { fail("Unexpected error parsing FASTQs: corrupt gzip stream: " + std::string(pos ? "bad member header" : "not a gzip file") + " in " + bf.path); return; }
+                        uint64_t verified = (uint64_t)(pos + hl) * 8u;   // a block starts here: the member's first
+                        bool member_start = true;
+                        uint32_t crc_acc = 0;
+                        uint64_t size_acc = 0;
+                        for (bool member_done = false; !member_done;) {
+                            {
+                                std::unique_lock<std::mutex> lk(fmu);
+                                fcv.wait(lk, [&] { return feed_stop || lines_fed[i] < lines_taken + gz_high_water; });
+                                if (feed_stop) { if (pin) fqtk_pinned_free(pin); return; }
+                            }
+                            const uint64_t t0 = tick();
+                            // where the chunks of this stretch start: the verified bit, then what the searches find behind every chunk_bytes
+                            std::vector<uint64_t> found(stretch_chunks + 1, ~0ull);
+                            found[0] = verified;
+                            {
+                                std::atomic<size_t> next{1};
+                                auto work = [&](unsigned q) {
+                                    for (size_t k; (k = next.fetch_add(1)) <= stretch_chunks;) {
+                                        const uint64_t nominal = verified + (uint64_t)k * chunk_bytes * 8u;
+                                        if (nominal + 16384u * 8u >= file_bits) break;
+                                        found[k] = finders[q]->find_block_start(nominal, std::min<uint64_t>(nominal + (uint64_t)chunk_bytes * 8u, file_bits));
+                                    }
+                                };
+                                std::vector<std::thread> th;
+                                for (unsigned q = 1; q < searchers; ++q) th.emplace_back(work, q);
+                                work(0);
+                                for (auto &t : th) t.join();
+                            }
+                            std::vector<uint64_t> starts;   // strictly increasing
+                            starts.push_back(verified);
+                            bool to_end = false;
+                            for (size_t k = 1; k <= stretch_chunks; ++k) {
+                                const uint64_t nominal = verified + (uint64_t)k * chunk_bytes * 8u;
+                                if (nominal + 16384u * 8u >= file_bits) { to_end = true; break; }
+                                if (found[k] != ~0ull && found[k] > starts.back()) starts.push_back(found[k]);
+                            }
+                            // the last start found only ends the chunk before it (it opens the next stretch), unless the file ends here
+                            const size_t n_chunks = to_end ? starts.size() : std::max<size_t>(1, starts.size() - 1);
+                            const uint64_t stop_last = to_end || starts.size() == 1 ? ~0ull : starts.back();
+                            const size_t b0 = (size_t)(verified / 8u) & ~(size_t)3;
+                            const size_t b1 = stop_last == ~0ull ? bf.size : std::min<size_t>(bf.size, (size_t)(stop_last / 8u) + 131072);
+                            const size_t bytes = b1 - b0;
+                            if (bytes >= (500u << 20)) { fail("internal error: a stretch of 500 MB or more in " + bf.path); return; }
+                            if (bytes + 64 > pin_cap) {
+                                if (pin) fqtk_pinned_free(pin);
+                                pin_cap = bytes + bytes / 4 + 65536;
+                                if (fqtk_pinned_alloc(pin_cap, &pin) != FQTK_OK) { pin = nullptr; fail(std::string("cannot allocate page-locked memory: ") + fqtk_last_error()); return; }
+                            }
+                            std::memcpy(pin, bf.map + b0, bytes);
+                            std::vector<fqtk_stream_chunk> cs(n_chunks);
+                            for (size_t k = 0; k < n_chunks; ++k) {
+                                cs[k].start_bit = starts[k] - (uint64_t)b0 * 8u;
+                                cs[k].stop_bit = k + 1 < n_chunks ? starts[k + 1] - (uint64_t)b0 * 8u : (stop_last == ~0ull ? ~0ull : stop_last - (uint64_t)b0 * 8u);
+                            }
+                            g_times.reader_parse += tick() - t0;
+                            const uint64_t t1 = tick();
+                            std::vector<fqtk_stream_end> ends(n_chunks);
+                            if (fqtk_demuxer_stream_decode(demuxers[0], (uint32_t)i, static_cast<const uint8_t *>(pin), bytes, cs.data(), (uint32_t)n_chunks, ends.data()) != FQTK_OK) {
+                                fail(std::string("GPU record pipeline: ") + fqtk_last_error());
+                                return;
+                            }
+                            // a chunk counts if it decoded and the chunk before it, itself accepted, ended on exactly the bit it started at
+                            size_t n_accept = 0;
+                            for (size_t k = 0; k < n_chunks; ++k) {
+                                if (ends[k].status != 0 || ends[k].end_bit > (uint64_t)bytes * 8u) break;
+                                if (k && ends[k - 1].end_bit != cs[k].start_bit) break;
+                                n_accept = k + 1;
+                                if (ends[k].final_block) break;
+                            }
+                            if (n_accept == 0) {
+                                if (ends[0].status == 7 && chunk_bytes > (64u << 10)) { chunk_bytes /= 2; continue; }   // more text than its room: shorter chunks
+                                static const char *const kWhat[12] = {"", "reserved block type", "stored block length check", "bad code lengths", "over-subscribed or incomplete Huffman code",
+                                                                      "invalid code", "distance too far back", "a block that expands more than a chunk has room for", "stream runs past the end of the file",
+                                                                      "", "", ""};
+                                fail("Unexpected error parsing FASTQs: corrupt gzip stream: " + std::string(kWhat[std::min<uint32_t>(ends[0].status, 11)]) + " in " + bf.path);
+                                return;
+                            }
+                            const fqtk_stream_end &le = ends[n_accept - 1];
+                            verified = (uint64_t)b0 * 8u + le.end_bit;
+                            bool last = false;
+                            size_t trailer = 0;
+                            if (le.final_block) {
+                                trailer = (size_t)((verified + 7u) / 8u);
+                                if (trailer + 8 > bf.size) { fail("Unexpected error parsing FASTQs: corrupt gzip stream: truncated trailer in " + bf.path); return; }
+                                const size_t nx = trailer + 8;
+                                last = !(nx + 10 <= bf.size && bf.map[nx] == 0x1f && bf.map[nx + 1] == 0x8b);   // (trailing garbage is ignored, as zlib's gzread does)
+                            }
+                            uint64_t fed = 0, n_text = 0;
+                            uint32_t crc = 0;
+                            if (fqtk_demuxer_stream_commit(demuxers[0], (uint32_t)i, (uint32_t)n_accept, member_start ? 1 : 0, last ? 1 : 0, &fed, &crc, &n_text) != FQTK_OK) {
+                                fail(std::string("GPU record pipeline: ") + fqtk_last_error());
+                                return;
+                            }
+                            g_times.reader_push += tick() - t1;
+                            member_start = false;
+                            crc_acc = (uint32_t)crc32_combine(crc_acc, crc, (z_off_t)n_text);
+                            size_acc += n_text;
+                            if (le.final_block) {
+                                uint32_t want_crc, want_size;
+                                std::memcpy(&want_crc, bf.map + trailer, 4);
+                                std::memcpy(&want_size, bf.map + trailer + 4, 4);
+                                if (want_crc != crc_acc) { fail("Unexpected error parsing FASTQs: corrupt gzip stream: CRC mismatch in " + bf.path); return; }
+                                if (want_size != (uint32_t)size_acc) { fail("Unexpected error parsing FASTQs: corrupt gzip stream: length mismatch in " + bf.path); return; }
+                                member_done = true;
+                                pos = trailer + 8;
+                                if (last) { all_done = true; bf.pos = bf.size; }
+                            }
+                            {
+                                std::lock_guard<std::mutex> lk(fmu);
+                                lines_fed[i] = fed;
+                                if (last) fed_done[i] = 1;
+                            }
+                            fcv.notify_all();
+                            if (n_accept == n_chunks) stretch_chunks = std::min(kMaxChunks, stretch_chunks * 2);
+                            if (b0 > (64u << 20)) madvise(const_cast<uint8_t *>(bf.map), (b0 - (64u << 20)) & ~(size_t)4095, MADV_DONTNEED);
+                        }
+                    }
+                    if (pin) fqtk_pinned_free(pin);
+                    return;
+                }
                 for (;;) {
                     {
                         std::unique_lock<std::mutex> lk(fmu);

@@ -118,3 +118,48 @@ def test_device_inflate_reports_what_the_host_path_reports(tmp_path):
     r = H.run_demux([good1, good2], ["+T", "8B"], meta, tmp_path / "o4", threads=8, extra=["--chunk-reads", "1000"])
     assert r.returncode == 0 and "inflated on the device" in r.stderr, r.stderr
     assert sum(len(v) for v in _outputs(tmp_path / "o4").values()) == n
+
+
+def test_serial_gzip_inputs_decoded_on_the_device_equal_the_host_decoders(tmp_path, monkeypatch):
+    """--gpu-gunzip: `gzip`-style inputs (one member per file; also two members back to back, and a BGZF file among them) are cut
+    into chunks at block starts the host finds, decoded on the device without their windows and resolved there.  Outputs and
+    metrics must equal the host decoders' (fast_inflate.hpp / parallel_gunzip.hpp), with chunks of 16 KiB so that a small file
+    is many chunks and several stretches; CRC-32 / ISIZE of every member are still checked."""
+    import gzip
+    rng = np.random.default_rng(31)
+    n = 30_000
+    bcs = ["ACGTACGT", "TTGCAATG", "GGGGCCCC", "ATATATAT"]
+    r1 = _records(n, rng, [150, 101], "r")
+    i1 = [(h, (bcs[int(rng.integers(0, 4))] if rng.random() < 0.9 else "NNNNNNNN"), "F" * 8) for h, _, _ in r1]
+    r2 = [(h, b[:75], q[:75]) for h, b, q in _records(n, rng, [75], "r")]
+    t1, ti, t2 = _text(r1), _text(i1), _text(r2)
+    f1 = str(tmp_path / "r1.fastq.gz")
+    with open(f1, "wb") as fh:
+        fh.write(gzip.compress(t1, 6))
+    half = t2[:len(t2) // 2].rfind(b"\n@") + 1
+    f3 = str(tmp_path / "r2.fastq.gz")                                      # two gzip members back to back
+    with open(f3, "wb") as fh:
+        fh.write(gzip.compress(t2[:half], 1) + gzip.compress(t2[half:], 9))
+    f2 = _write_bgzf(tmp_path / "i1.fastq.gz", ti, member=5000)              # a BGZF file next to them
+    meta = _meta(tmp_path, bcs)
+    monkeypatch.setenv("FQTK_GZ_DEVICE_CHUNK_KB", "16")
+    monkeypatch.setenv("FQTK_GZ_DEVICE_CHUNKS", "40")
+    runs = {}
+    for name, extra in (("device", ["--gpu-gunzip"]), ("host", ["--host-inflate"])):
+        out = tmp_path / name
+        r = H.run_demux([f1, f2, f3], ["+T", "8B", "+T"], meta, out, threads=8, extra=["--chunk-reads", "4000"] + extra)
+        assert r.returncode == 0, r.stderr
+        assert ("decoded on the device in chunks" in r.stderr) == (name == "device"), r.stderr
+        runs[name] = (_outputs(out), open(out / "demux-metrics.txt").read())
+    assert runs["device"][1] == runs["host"][1]
+    for f in runs["host"][0]:
+        assert runs["device"][0][f] == runs["host"][0][f], f
+    assert sum(len(v) for f, v in runs["device"][0].items() if ".R1." in f) == n
+    # a flipped bit in the middle of the stream: the chain breaks, the stream fails to parse, or the member's CRC does
+    raw = bytearray(open(f1, "rb").read())
+    raw[len(raw) // 2] ^= 0x04
+    bad = str(tmp_path / "bad.fastq.gz")
+    open(bad, "wb").write(bytes(raw))
+    r = H.run_demux([bad, f2, f3], ["+T", "8B", "+T"], meta, tmp_path / "o_bad", threads=8, extra=["--chunk-reads", "4000", "--gpu-gunzip"])
+    assert r.returncode != 0 and ("corrupt gzip stream" in r.stderr or "parsing FASTQs" in r.stderr), r.stderr
+    assert not list((tmp_path / "o_bad").glob("*.fq.gz"))
