@@ -837,15 +837,54 @@ size_t gzip_header_len(const uint8_t *p, size_t n) {
                     // by a wavefront each without their windows, accepted where the chain of block boundaries proves the parse
                     // (host/parallel_gunzip.hpp's rule), resolved on the device.  A stretch takes the device about as long as ONE
                     // chunk takes a wavefront (~0.2 s per MiB of compressed FASTQ), so stretches are long: up to 1024 chunks.
-                    static const size_t kChunkBytes = [] { const char *v = std::getenv("FQTK_GZ_DEVICE_CHUNK_KB"); return (size_t)(v && *v ? std::atol(v) : 1024) << 10; }();
-                    static const size_t kMaxChunks = [] { const char *v = std::getenv("FQTK_GZ_DEVICE_CHUNKS"); return (size_t)(v && *v ? std::atol(v) : 1024); }();
+                    static const size_t kChunkBytes = [] { const char *v = std::getenv("FQTK_GZ_DEVICE_CHUNK_KB"); return (size_t)(v && *v ? std::atol(v) : 512) << 10; }();
+                    // (a stretch stays below 448 MiB: the device counts a chunk's bits from the stretch's first byte in 32 bits)
+                    static const size_t kMaxChunks = [] { const char *v = std::getenv("FQTK_GZ_DEVICE_CHUNKS"); return std::min<size_t>((size_t)(v && *v ? std::atol(v) : 1024), (448u << 20) / kChunkBytes); }();
                     const unsigned searchers = std::max(1u, std::min(8u, (unsigned)(usable_cpus() / std::max<size_t>(1, n_serial))));
-                    std::vector<std::unique_ptr<SpecInflate>> finders;
-                    for (unsigned q = 0; q < searchers; ++q) { finders.push_back(std::make_unique<SpecInflate>()); finders.back()->attach(bf.map, bf.size); }
                     const uint64_t file_bits = (uint64_t)bf.size * 8u;
-                    const uint64_t gz_high_water = 4ull * chunk * 12;
+                    static const size_t kChunkBytes0 = kChunkBytes;
+                    // slot k = the first block start at or behind byte k * chunk_bytes of the file (~0: none before the next slot);
+                    // the searchers fill the slots in order, a bounded distance ahead of what has been decoded
+                    const size_t n_slots = bf.size > 16384 ? (bf.size - 16384) / kChunkBytes0 + 1 : 1;   // (a header needs room: the file's end belongs to the last chunk)
+                    std::vector<uint64_t> slot_start(n_slots, ~0ull);
+                    std::vector<char> slot_done(n_slots, 0);
+                    std::mutex smu;
+                    std::condition_variable scv;
+                    size_t search_from = 0, search_next = 1;
+                    bool search_stop = false;
+                    slot_done[0] = 1;
+                    std::vector<std::thread> search_threads;
+                    for (unsigned q = 0; q < searchers; ++q)
+                        search_threads.emplace_back([&] {
+                            SpecInflate finder;
+                            finder.attach(bf.map, bf.size);
+                            for (;;) {
+                                size_t slot;
+                                {
+                                    std::unique_lock<std::mutex> lk(smu);
+                                    scv.wait(lk, [&] { return search_stop || (search_next < n_slots && search_next < search_from + 4096); });
+                                    if (search_stop || search_next >= n_slots) return;
+                                    slot = search_next++;
+                                }
+                                const uint64_t nominal = (uint64_t)slot * kChunkBytes0 * 8u;
+                                const uint64_t r = finder.find_block_start(nominal, std::min<uint64_t>(nominal + (uint64_t)kChunkBytes0 * 8u, file_bits));
+                                {
+                                    std::lock_guard<std::mutex> lk(smu);
+                                    slot_start[slot] = r;
+                                    slot_done[slot] = 1;
+                                }
+                                scv.notify_all();
+                            }
+                        });
+                    struct StopSearch {
+                        std::mutex &m; std::condition_variable &cv; bool &stop; std::vector<std::thread> &th;
+                        ~StopSearch() { { std::lock_guard<std::mutex> lk(m); stop = true; } cv.notify_all(); for (auto &t : th) t.join(); }
+                    } stop_search{smu, scv, search_stop, search_threads};
+                    const uint64_t gz_high_water = 4ull * chunk * (uint64_t)env_num("FQTK_GZ_DEVICE_AHEAD", 40);   // (a stretch is ~10-30 chunks of templates: one may decode while one is consumed)
+                    size_t n_stretches = 0, n_chunks_total = 0, n_refused = 0;
                     size_t pos = 0;                 // byte of the current member's header
-                    size_t chunk_bytes = kChunkBytes, stretch_chunks = std::min<size_t>(128, kMaxChunks);
+                    const size_t chunk_bytes = kChunkBytes;
+                    size_t stretch_chunks = std::min<size_t>(256, kMaxChunks);
                     bool all_done = false;
                     while (!all_done) {
                         const size_t hl = gzip_header_len(bf.map + pos, bf.size - pos);
@@ -861,30 +900,31 @@ size_t gzip_header_len(const uint8_t *p, size_t n) {
                                 if (feed_stop) { if (pin) fqtk_pinned_free(pin); return; }
                             }
                             const uint64_t t0 = tick();
-                            // where the chunks of this stretch start: the verified bit, then what the searches find behind every chunk_bytes
+                            // where the chunks of this stretch start: the verified bit, then what the searchers -- who run ahead of the
+                            // decoding, at every chunk_bytes of the file, whatever is verified -- have found behind it
                             std::vector<uint64_t> found(stretch_chunks + 1, ~0ull);
                             found[0] = verified;
                             {
-                                std::atomic<size_t> next{1};
-                                auto work = [&](unsigned q) {
-                                    for (size_t k; (k = next.fetch_add(1)) <= stretch_chunks;) {
-                                        const uint64_t nominal = verified + (uint64_t)k * chunk_bytes * 8u;
-                                        if (nominal + 16384u * 8u >= file_bits) break;
-                                        found[k] = finders[q]->find_block_start(nominal, std::min<uint64_t>(nominal + (uint64_t)chunk_bytes * 8u, file_bits));
-                                    }
-                                };
-                                std::vector<std::thread> th;
-                                for (unsigned q = 1; q < searchers; ++q) th.emplace_back(work, q);
-                                work(0);
-                                for (auto &t : th) t.join();
+                                const size_t first_slot = (size_t)(verified / 8u / chunk_bytes) + 1;   // searches start at slot * chunk_bytes
+                                std::unique_lock<std::mutex> lk(smu);
+                                search_from = first_slot;   // (slots before it are of no use any more: the searchers may move on)
+                                scv.notify_all();
+                                for (size_t k = 1; k <= stretch_chunks; ++k) {
+                                    const size_t slot = first_slot + k - 1;
+                                    if (slot >= n_slots) break;
+                                    scv.wait(lk, [&] { return slot_done[slot] != 0; });
+                                    found[k] = slot_start[slot];
+                                }
                             }
                             std::vector<uint64_t> starts;   // strictly increasing
                             starts.push_back(verified);
                             bool to_end = false;
-                            for (size_t k = 1; k <= stretch_chunks; ++k) {
-                                const uint64_t nominal = verified + (uint64_t)k * chunk_bytes * 8u;
-                                if (nominal + 16384u * 8u >= file_bits) { to_end = true; break; }
-                                if (found[k] != ~0ull && found[k] > starts.back()) starts.push_back(found[k]);
+                            {
+                                const size_t first_slot = (size_t)(verified / 8u / chunk_bytes) + 1;
+                                for (size_t k = 1; k <= stretch_chunks; ++k) {
+                                    if (first_slot + k - 1 >= n_slots) { to_end = true; break; }
+                                    if (found[k] != ~0ull && found[k] > starts.back()) starts.push_back(found[k]);
+                                }
                             }
                             // the last start found only ends the chunk before it (it opens the next stretch), unless the file ends here
                             const size_t n_chunks = to_end ? starts.size() : std::max<size_t>(1, starts.size() - 1);
@@ -920,7 +960,6 @@ size_t gzip_header_len(const uint8_t *p, size_t n) {
                                 if (ends[k].final_block) break;
                             }
                             if (n_accept == 0) {
-                                if (ends[0].status == 7 && chunk_bytes > (64u << 10)) { chunk_bytes /= 2; continue; }   // more text than its room: shorter chunks
                                 static const char *const kWhat[12] = {"", "reserved block type", "stored block length check", "bad code lengths", "over-subscribed or incomplete Huffman code",
                                                                       "invalid code", "distance too far back", "a block that expands more than a chunk has room for", "stream runs past the end of the file",
                                                                       "", "", ""};
@@ -964,10 +1003,12 @@ size_t gzip_header_len(const uint8_t *p, size_t n) {
                             }
                             fcv.notify_all();
                             if (n_accept == n_chunks) stretch_chunks = std::min(kMaxChunks, stretch_chunks * 2);
+                            ++n_stretches; n_chunks_total += n_chunks; n_refused += n_chunks - n_accept;
                             if (b0 > (64u << 20)) madvise(const_cast<uint8_t *>(bf.map), (b0 - (64u << 20)) & ~(size_t)4095, MADV_DONTNEED);
                         }
                     }
                     if (pin) fqtk_pinned_free(pin);
+                    if (g_timing) info("(timing) gzip input %zu: %zu chunks in %zu stretches decoded on the device, %zu refused (their stretch was cut there).", i, n_chunks_total, n_stretches, n_refused);
                     return;
                 }
                 for (;;) {

@@ -14,6 +14,12 @@ inline bool env_on(const char *name) {
     return v && *v && !(v[0] == '0' && v[1] == 0);
 }
 
+// A number from the environment (A/B runs), or the default.
+inline long env_num(const char *name, long dflt) {
+    const char *v = std::getenv(name);
+    return v && *v ? std::atol(v) : dflt;
+}
+
 // CPUs this process can really use: the affinity mask, capped by the cgroup CPU quota (containers often show every
 // logical CPU of the host under a quota of a few: threads beyond the quota only take turns).
 inline unsigned usable_cpus() {
