@@ -498,6 +498,10 @@ def main() -> int:
                     scopes["E_gz"] = scope_bench.scope_e(n_e // 4, e_threads, True, tmp, exp4, inputs=(gz, meta))
                     scopes["E_gz"]["host_cpus_usable"] = host_cores
                     scopes["E_gz"]["gz_inputs"] = "one gzip member per file (level 1), decoded by several host threads per file"
+                    # the same gzip files decoded on the device in chunks (--gpu-gunzip, opt-in: on a 16-CPU host the host's decoders are as fast)
+                    scopes["E_gz_device"] = scope_bench.scope_e(n_e // 4, e_threads, True, tmp, exp4, extra_args=("--gpu-gunzip",), inputs=(gz, meta), out_name="out_gzdev")
+                    scopes["E_gz_device"]["host_cpus_usable"] = host_cores
+                    scopes["E_gz_device"]["gz_inputs"] = "one gzip member per file (level 1): block starts found by host threads, chunks decoded by a wavefront each, windows resolved on the device"
                     # BGZF inputs (bgzip / htslib / fqtk's own outputs): the members cross PCIe compressed and are inflated on the
                     # device, one wavefront per member (include/fqtk_inflate.h, fqtk_demuxer_feed); the host never sees the text
                     bgz = scope_bench.bgzf_repeated(sub)
