@@ -752,6 +752,8 @@ int fqtk_demuxer_stream_decode(fqtk_demuxer *d, uint32_t input, const uint8_t *b
         F.h_chunks.p[k] = fqtk::inflate::StreamChunk{chunks[k].start_bit, chunks[k].stop_bit, sym_total, (uint32_t)cap, 0u};
         sym_total += (cap + 7u) & ~7ull;
     }
+    // (a stretch grows to twice its first size: room for that at once, allocating gigabytes takes tens of milliseconds)
+    if (F.sym.cap < sym_total + 64 && (rc = F.sym.ensure((size_t)std::min<uint64_t>(2 * sym_total, 12ull << 30) + 64)) != FQTK_OK) return rc;
     if ((rc = F.sym.ensure((size_t)sym_total + 64)) != FQTK_OK) return rc;
     DX_TRY(hipMemcpyAsync(F.comp.p, bytes, (size_t)len, hipMemcpyHostToDevice, F.stream));
     DX_TRY(hipMemcpyAsync(F.d_chunks.p, F.h_chunks.p, (size_t)n * sizeof(fqtk::inflate::StreamChunk), hipMemcpyHostToDevice, F.stream));

@@ -884,7 +884,7 @@ size_t gzip_header_len(const uint8_t *p, size_t n) {
                     size_t n_stretches = 0, n_chunks_total = 0, n_refused = 0;
                     size_t pos = 0;                 // byte of the current member's header
                     const size_t chunk_bytes = kChunkBytes;
-                    size_t stretch_chunks = std::min<size_t>(256, kMaxChunks);
+                    size_t stretch_chunks = std::min<size_t>(448, kMaxChunks);   // (then twice that: every growth reallocates the device's symbol buffer)
                     bool all_done = false;
                     while (!all_done) {
                         const size_t hl = gzip_header_len(bf.map + pos, bf.size - pos);
@@ -933,12 +933,14 @@ size_t gzip_header_len(const uint8_t *p, size_t n) {
                             const size_t b1 = stop_last == ~0ull ? bf.size : std::min<size_t>(bf.size, (size_t)(stop_last / 8u) + 131072);
                             const size_t bytes = b1 - b0;
                             if (bytes >= (500u << 20)) { fail("internal error: a stretch of 500 MB or more in " + bf.path); return; }
-                            if (bytes + 64 > pin_cap) {
+                            if (bytes + 64 > pin_cap) {   // (once: sized for the longest stretch this file can have)
                                 if (pin) fqtk_pinned_free(pin);
-                                pin_cap = bytes + bytes / 4 + 65536;
+                                pin_cap = std::max<size_t>(bytes + 64, std::min<size_t>(bf.size, kMaxChunks * chunk_bytes + (1u << 20)) + 65536);
                                 if (fqtk_pinned_alloc(pin_cap, &pin) != FQTK_OK) { pin = nullptr; fail(std::string("cannot allocate page-locked memory: ") + fqtk_last_error()); return; }
                             }
+                            const uint64_t tc0 = tick();
                             std::memcpy(pin, bf.map + b0, bytes);
+                            const uint64_t tc1 = tick();
                             std::vector<fqtk_stream_chunk> cs(n_chunks);
                             for (size_t k = 0; k < n_chunks; ++k) {
                                 cs[k].start_bit = starts[k] - (uint64_t)b0 * 8u;
@@ -951,6 +953,7 @@ size_t gzip_header_len(const uint8_t *p, size_t n) {
                                 fail(std::string("GPU record pipeline: ") + fqtk_last_error());
                                 return;
                             }
+                            const uint64_t t_dec = tick();
                             // a chunk counts if it decoded and the chunk before it, itself accepted, ended on exactly the bit it started at
                             size_t n_accept = 0;
                             for (size_t k = 0; k < n_chunks; ++k) {
@@ -983,6 +986,8 @@ size_t gzip_header_len(const uint8_t *p, size_t n) {
                                 return;
                             }
                             g_times.reader_push += tick() - t1;
+                            if (g_timing) info("(timing) gzip input %zu: stretch of %zu chunks (%zu MB): search + plan %.0f ms, copy %.0f ms, decode %.0f ms, commit %.0f ms, %zu accepted.", i, n_chunks,
+                                               bytes >> 20, (tc0 - t0) / 1e6, (tc1 - tc0) / 1e6, (t_dec - t1) / 1e6, (tick() - t_dec) / 1e6, n_accept);
                             member_start = false;
                             crc_acc = (uint32_t)crc32_combine(crc_acc, crc, (z_off_t)n_text);
                             size_acc += n_text;
