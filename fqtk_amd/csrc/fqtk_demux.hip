@@ -573,7 +573,7 @@ static int fed_init(fqtk_demuxer *d) {
 
 // Room for text_bytes more text of an input (its mutex held): when the arena is full, what chunks have not consumed yet moves to the
 // front of the other arena.
-static int fed_make_room(fqtk_demuxer *d, FedInput &F, uint64_t text_bytes) {
+static int fed_make_room(fqtk_demuxer *d, FedInput &F, uint64_t text_bytes, bool tight = false) {
     int rc;
     uint64_t live_from = F.members.empty() ? F.tail : F.members.front().off;
     if (F.tail + text_bytes + kFedSlack > F.arena[F.cur].cap) {
@@ -581,7 +581,9 @@ static int fed_make_room(fqtk_demuxer *d, FedInput &F, uint64_t text_bytes) {
         const int other = 1 - F.cur;
         // (FQTK_FED_ARENA_MIN: tests make the arenas small so that a short run changes arena many times)
         static const uint64_t arena_min = [] { const char *e = std::getenv("FQTK_FED_ARENA_MIN"); return e && *e ? (uint64_t)std::strtoull(e, nullptr, 10) : (1ull << 30); }();
-        const uint64_t want = std::max<uint64_t>((live + text_bytes + kFedSlack) * 2, arena_min);
+        // (tight: gigabytes of text at a time -- a serial gzip stream's stretches -- take an arena that holds one of them and what is
+        //  live, and change arena with every stretch: the copy of the live text is milliseconds, a larger allocation 0.1 s per GB)
+        const uint64_t want = std::max<uint64_t>(tight ? (live + text_bytes) + (live + text_bytes) / 4 + kFedSlack : (live + text_bytes + kFedSlack) * 2, arena_min);
         {
             // Chunks whose record views point into the OTHER arena were submitted before this input last changed arenas:
             // its old text may go, and this stream's copy may start, when they have been formatted.  (No lock against a
@@ -741,19 +743,17 @@ int fqtk_demuxer_stream_decode(fqtk_demuxer *d, uint32_t input, const uint8_t *b
     if ((rc = F.d_chunks.ensure(n)) != FQTK_OK) return rc;
     if ((rc = F.h_ends.ensure(n)) != FQTK_OK) return rc;
     if ((rc = F.d_ends.ensure(n)) != FQTK_OK) return rc;
-    // room for every chunk's symbols: FASTQ text deflates 3-7 : 1; twelve times the chunk's compressed bytes (+ a block's worth) is
+    // room for every chunk's symbols: FASTQ text deflates 3-7 : 1; eight times the chunk's compressed bytes (+ a block's worth) is
     // given, and a chunk that needs more reports FQTK_INFLATE_ERR_OUTPUT (the caller then cuts the stretch shorter)
     uint64_t sym_total = 0;
     for (uint32_t k = 0; k < n; ++k) {
         const uint64_t stop = chunks[k].stop_bit == ~0ull ? len * 8u : chunks[k].stop_bit;
         if (chunks[k].start_bit > len * 8u || stop < chunks[k].start_bit) return set_error(FQTK_EINVAL, "a chunk outside the stretch");
         const uint64_t cbytes = (stop - chunks[k].start_bit) / 8u + 65536u;
-        const uint64_t cap = std::min<uint64_t>(cbytes * 12u + 262144u, 0xFFFFFF00ull);
+        const uint64_t cap = std::min<uint64_t>(cbytes * 8u + 262144u, 0xFFFFFF00ull);
         F.h_chunks.p[k] = fqtk::inflate::StreamChunk{chunks[k].start_bit, chunks[k].stop_bit, sym_total, (uint32_t)cap, 0u};
         sym_total += (cap + 7u) & ~7ull;
     }
-    // (a stretch grows to twice its first size: room for that at once, allocating gigabytes takes tens of milliseconds)
-    if (F.sym.cap < sym_total + 64 && (rc = F.sym.ensure((size_t)std::min<uint64_t>(2 * sym_total, 12ull << 30) + 64)) != FQTK_OK) return rc;
     if ((rc = F.sym.ensure((size_t)sym_total + 64)) != FQTK_OK) return rc;
     DX_TRY(hipMemcpyAsync(F.comp.p, bytes, (size_t)len, hipMemcpyHostToDevice, F.stream));
     DX_TRY(hipMemcpyAsync(F.d_chunks.p, F.h_chunks.p, (size_t)n * sizeof(fqtk::inflate::StreamChunk), hipMemcpyHostToDevice, F.stream));
@@ -790,7 +790,7 @@ int fqtk_demuxer_stream_commit(fqtk_demuxer *d, uint32_t input, uint32_t n_accep
     if ((rc = F.d_out_off.ensure(n_accept + 1)) != FQTK_OK) return rc;
     for (uint32_t k = 0; k < n_accept; ++k) total += F.h_ends.p[k].n_sym;
     const uint64_t text_bytes = total + (last ? 1 : 0);
-    if ((rc = fed_make_room(d, F, text_bytes)) != FQTK_OK) return rc;
+    if ((rc = fed_make_room(d, F, text_bytes, text_bytes > (512ull << 20))) != FQTK_OK) return rc;
     const uint64_t at = F.tail;
     {
         uint64_t o = at;

@@ -836,10 +836,12 @@ size_t gzip_header_len(const uint8_t *p, size_t n) {
                     // ---- a serial gzip file: stretches of chunks between block starts this thread (and its helpers) finds, decoded
                     // by a wavefront each without their windows, accepted where the chain of block boundaries proves the parse
                     // (host/parallel_gunzip.hpp's rule), resolved on the device.  A stretch takes the device about as long as ONE
-                    // chunk takes a wavefront (~0.2 s per MiB of compressed FASTQ), so stretches are long: up to 1024 chunks.
+                    // chunk takes a wavefront (~0.1 s), so stretches are long -- 448 chunks of 512 KiB: 1.4 GB of text per 0.1 s -- but no
+                    // longer: the device's buffers follow the stretch (symbols 16 bytes per compressed byte, two arenas of text), and
+                    // allocating device memory costs ~0.1 s per GB (FQTK_TIMING=1 prints every stretch's clock).
                     static const size_t kChunkBytes = [] { const char *v = std::getenv("FQTK_GZ_DEVICE_CHUNK_KB"); return (size_t)(v && *v ? std::atol(v) : 512) << 10; }();
                     // (a stretch stays below 448 MiB: the device counts a chunk's bits from the stretch's first byte in 32 bits)
-                    static const size_t kMaxChunks = [] { const char *v = std::getenv("FQTK_GZ_DEVICE_CHUNKS"); return std::min<size_t>((size_t)(v && *v ? std::atol(v) : 1024), (448u << 20) / kChunkBytes); }();
+                    static const size_t kMaxChunks = [] { const char *v = std::getenv("FQTK_GZ_DEVICE_CHUNKS"); return std::min<size_t>((size_t)(v && *v ? std::atol(v) : 448), (448u << 20) / kChunkBytes); }();
                     const unsigned searchers = std::max(1u, std::min(8u, (unsigned)(usable_cpus() / std::max<size_t>(1, n_serial))));
                     const uint64_t file_bits = (uint64_t)bf.size * 8u;
                     static const size_t kChunkBytes0 = kChunkBytes;
@@ -884,7 +886,7 @@ size_t gzip_header_len(const uint8_t *p, size_t n) {
                     size_t n_stretches = 0, n_chunks_total = 0, n_refused = 0;
                     size_t pos = 0;                 // byte of the current member's header
                     const size_t chunk_bytes = kChunkBytes;
-                    size_t stretch_chunks = std::min<size_t>(448, kMaxChunks);   // (then twice that: every growth reallocates the device's symbol buffer)
+                    size_t stretch_chunks = std::min<size_t>(448, kMaxChunks);
                     bool all_done = false;
                     while (!all_done) {
                         const size_t hl = gzip_header_len(bf.map + pos, bf.size - pos);

@@ -142,7 +142,7 @@ int fqtk_demuxer_fed_tail(fqtk_demuxer *d, uint32_t input, uint64_t pos, uint8_t
  * starts at bit chunks[k].start_bit of them -- chunk 0 at a bit the caller KNOWS to be a block boundary (the member's first
  * block, or where the last accepted chunk ended), the others at places it found -- and stops at the first block boundary
  * at or behind chunks[k].stop_bit (~0: at the member's final block).  Blocks until every chunk is decoded and says how
- * each ended (status: FQTK_INFLATE_ERR_*, FQTK_INFLATE_ERR_OUTPUT when the chunk's room for symbols -- twelve times its
+ * each ended (status: FQTK_INFLATE_ERR_*, FQTK_INFLATE_ERR_OUTPUT when the chunk's room for symbols -- eight times its
  * compressed size -- was too small).
  * fqtk_demuxer_stream_commit: the first n_accept chunks of that decode become text (member_start != 0: chunk 0 began a gzip
  * member, nothing lies in front of it; last: as in fqtk_demuxer_feed).  Returns the lines fed so far, and CRC-32 and length
