@@ -495,13 +495,14 @@ def main() -> int:
                     scopes["E_host"] = scope_bench.scope_e(n_e // 4, e_threads, False, tmp, exp4, extra_args=("--host-output",), inputs=(sub, meta))
                     scopes["E_host"]["host_cpus_usable"] = host_cores
                     gz = scope_bench.gzip_single_stream(sub)
+                    # single-stream gzip inputs: decoded on the device in chunks (the default from 64 MB of .gz), and by the host's decoders
                     scopes["E_gz"] = scope_bench.scope_e(n_e // 4, e_threads, True, tmp, exp4, inputs=(gz, meta))
                     scopes["E_gz"]["host_cpus_usable"] = host_cores
-                    scopes["E_gz"]["gz_inputs"] = "one gzip member per file (level 1), decoded by several host threads per file"
-                    # the same gzip files decoded on the device in chunks (--gpu-gunzip, opt-in: on a 16-CPU host the host's decoders are as fast)
-                    scopes["E_gz_device"] = scope_bench.scope_e(n_e // 4, e_threads, True, tmp, exp4, extra_args=("--gpu-gunzip",), inputs=(gz, meta), out_name="out_gzdev")
-                    scopes["E_gz_device"]["host_cpus_usable"] = host_cores
-                    scopes["E_gz_device"]["gz_inputs"] = "one gzip member per file (level 1): block starts found by host threads, chunks decoded by a wavefront each, windows resolved on the device"
+                    scopes["E_gz"]["gz_inputs"] = ("one gzip member per file (level 1): block starts found by host threads, chunks decoded by a wavefront each without "
+                                                   "their windows, windows and CRC-32 resolved on the device")
+                    scopes["E_gz_host"] = scope_bench.scope_e(n_e // 4, e_threads, True, tmp, exp4, extra_args=("--host-inflate",), inputs=(gz, meta), out_name="out_gzhost")
+                    scopes["E_gz_host"]["host_cpus_usable"] = host_cores
+                    scopes["E_gz_host"]["gz_inputs"] = "the same files decoded by several host threads per file (host/parallel_gunzip.hpp)"
                     # BGZF inputs (bgzip / htslib / fqtk's own outputs): the members cross PCIe compressed and are inflated on the
                     # device, one wavefront per member (include/fqtk_inflate.h, fqtk_demuxer_feed); the host never sees the text
                     bgz = scope_bench.bgzf_repeated(sub)

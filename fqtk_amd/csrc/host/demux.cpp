@@ -140,12 +140,11 @@ const char *kUsage =
     "                                              inputs' text goes to the device, records are formatted and DEFLATE-compressed\n"
     "                                              in HBM and whole BGZF members come back (additive flag; alias --no-gpu-bgzf;\n"
     "                                              --gpu-bgzf is accepted and means the default)\n"
-    "      --host-inflate                          inflate BGZF inputs on the host CPUs.  Default when every input is a BGZF file (bgzip,\n"
-    "                                              htslib, fqtk's own outputs) and one device is used: the compressed members go to\n"
-    "                                              the device and are inflated there (additive flag)\n"
-    "      --gpu-gunzip                            decode single-stream gzip inputs (gzip, bcl2fastq: one member per file) on the\n"
-    "                                              device too: the host only looks for places where a DEFLATE block starts, a wavefront\n"
-    "                                              per chunk decodes between them, windows are handed down the chain (additive flag)\n";
+    "      --host-inflate                          inflate compressed inputs on the host CPUs.  Default when every input is compressed and one\n"
+    "                                              device is used: BGZF members (bgzip, htslib, fqtk's own outputs) go to the device as they\n"
+    "                                              are, a wavefront each; serial gzip files (gzip, bcl2fastq), from 64 MB of them, in chunks\n"
+    "                                              between DEFLATE block starts the host finds, windows handed down the chain (additive flag)\n"
+    "      --gpu-gunzip                            serial gzip inputs on the device whatever their size (additive flag)\n";
 
 bool parse_ulong(const std::string &s, unsigned long *out) {
     if (s.empty()) return false;
@@ -507,7 +506,17 @@ size_t gzip_header_len(const uint8_t *p, size_t n) {
     // input is one and a single device takes all chunks (the fed text lives on one device)
     std::vector<std::unique_ptr<BgzfFile>> bgzf_in;   // (the mapped file of every fed input, BGZF or serial gzip)
     std::vector<char> is_serial_gz(n_inputs, 0);
-    const bool gpu_gunzip = opt.gpu_gunzip || env_on("FQTK_GPU_GUNZIP");
+    // serial gzip inputs go to the device when asked for (--gpu-gunzip), or by themselves when there is enough of them for the chunks to
+    // fill it (64 MB of .gz in all; below that the host's decoders are done before the device's buffers are allocated)
+    bool gpu_gunzip = opt.gpu_gunzip || env_on("FQTK_GPU_GUNZIP");
+    if (!gpu_gunzip && !env_on("FQTK_NO_GPU_GUNZIP")) {
+        uint64_t gz_bytes = 0;
+        for (size_t i = 0; i < n_inputs; ++i) {
+            struct stat st;
+            if (sources[i]->kind() == FastqSource::Kind::Gzip && stat(opt.inputs[i].c_str(), &st) == 0 && S_ISREG(st.st_mode)) gz_bytes += (uint64_t)st.st_size;
+        }
+        gpu_gunzip = gz_bytes >= (64ull << 20);
+    }
     bool fed_mode = G == 1 && !opt.host_inflate && !env_on("FQTK_HOST_INFLATE");
     size_t n_serial = 0;
     for (size_t i = 0; i < n_inputs && fed_mode; ++i) {

@@ -28,10 +28,10 @@ def test_bench_line_carries_scopes_create_time_cpu_rows_and_the_full_parity_gate
                     "--e2e-templates", "4000000", "--e2e-threads", "8"]))
     assert d["n_gpus"] == 1 and d["unit"] == "M reads/s" and d["value"] > 0
     assert "bit-exact" in d["config"]["parity"] and "count vector of all 3000000 reads" in d["config"]["parity"]
-    assert set(d["scopes"]) == {"K", "B", "B_packed", "bgzf_kernel", "inflate_kernel", "E", "E_host", "E_gz", "E_gz_device", "E_bgzf"}
+    assert set(d["scopes"]) == {"K", "B", "B_packed", "bgzf_kernel", "inflate_kernel", "E", "E_host", "E_gz", "E_gz_host", "E_bgzf"}
     assert d["scopes"]["bgzf_kernel"]["hbm"]["GB_per_s_in"] > 5 and 0.2 < d["scopes"]["bgzf_kernel"]["hbm"]["ratio"] < 0.5
     assert d["scopes"]["B_packed"]["M_reads_per_s"] > 0 and d["scopes"]["B_packed"]["packed_bytes_per_read"] == 8
-    for k, n in (("E", 4000000), ("E_host", 1000000), ("E_gz", 1000000), ("E_gz_device", 1000000), ("E_bgzf", 1000000)):   # device output (default), host output, gzip inputs, BGZF inputs inflated on the device
+    for k, n in (("E", 4000000), ("E_host", 1000000), ("E_gz", 1000000), ("E_gz_host", 1000000), ("E_bgzf", 1000000)):   # device output (default), host output, gzip inputs, BGZF inputs inflated on the device
         assert d["scopes"][k]["templates"] == n and d["scopes"][k]["metrics_vs_oracle"] == "per-sample counts identical"
         assert d["scopes"][k]["peak_rss_MB"] > 0 and d["scopes"][k]["output_files"] == 771
     assert d["scopes"]["E"]["M_templates_per_s_steady"] > 0 and d["scopes"]["E_gz"]["M_templates_per_s_steady"] > 0

@@ -102,7 +102,7 @@ def one(rng, it, tmp):
                 s = s[: max(0, len(s) - int(nprng.integers(1, 4)))]
             reads[i][t] = s
     files = []
-    kind = rng.choice(["plain", "gz", "bgzf", "bgzf"])   # bgzf: members inflated on the device (fqtk_demuxer_feed), cut into chunks by line counts
+    kind = rng.choice(["plain", "gz", "gz", "bgzf", "bgzf"])   # bgzf: members inflated on the device (fqtk_demuxer_feed), cut into chunks by line counts
     gz = kind == "gz"
     member = rng.choice([300, 4000, 65280])            # text bytes per BGZF member: members and chunks never line up
     for i in range(n_inputs):
@@ -139,6 +139,12 @@ def one(rng, it, tmp):
     if EXE.endswith(".thread") and shutil.which("setarch"):   # TSan's shadow layout does not survive this kernel's ASLR range
         cmd = ["setarch", os.uname().machine, "-R"] + cmd
     env = dict(os.environ)
+    if kind == "gz" and rng.random() < 0.7:
+        env["FQTK_GPU_GUNZIP"] = "1"                                  # serial gzip decoded on the device in chunks
+        env["FQTK_GZ_DEVICE_CHUNK_KB"] = str(rng.choice([4, 16, 64, 512]))
+        env["FQTK_GZ_DEVICE_CHUNKS"] = str(rng.choice([3, 20, 448]))
+        if rng.random() < 0.5:
+            env["FQTK_FED_ARENA_MIN"] = str(rng.choice([20000, 300000]))
     if kind == "bgzf" and rng.random() < 0.5:
         env["FQTK_FED_ARENA_MIN"] = str(rng.choice([20000, 300000]))   # the fed text changes arena every few chunks
     if EXE.endswith(".thread"):
