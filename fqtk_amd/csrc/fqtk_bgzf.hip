@@ -215,7 +215,7 @@ __device__ void phase_cl_code_wave(Shared &S, int lane) {   // lane = 0 .. 63 of
 
 __global__ __launch_bounds__(kLanes) __attribute__((amdgpu_waves_per_eu(kLanes / 256, kLanes / 256)))   // one workgroup per CU (LDS): registers are free
 void deflate_kernel(const fqtk_bgzf_block *blocks, uint32_t n_blocks, const uint32_t *n_blocks_dev,
-                                                         uint32_t *out_len, uint32_t *crc_out, uint32_t *tok_all, uint32_t level) {
+                                                         uint32_t *out_len, uint32_t *crc_out, uint32_t *tok_all, uint32_t level, uint32_t *next_block) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem_raw[];
     Shared &S = *reinterpret_cast<Shared *>(smem_raw);
     const int lane = (int)threadIdx.x;
@@ -228,7 +228,18 @@ void deflate_kernel(const fqtk_bgzf_block *blocks, uint32_t n_blocks, const uint
     if (lane == 0) S.effort = effort_of_level(level);
     if (crc_out) crc_tables(S, lane);
     __syncthreads();
-    for (uint32_t j = blockIdx.x; j < n_blocks; j += gridDim.x) {
+    // Which block a workgroup takes next: with a counter (next_block, zeroed by the caller) the workgroups that HAVE a CU share out
+    // all the blocks -- a workgroup needs a CU's whole LDS, and when other kernels' wavefronts sit on some CUs (the input decoders
+    // of fqtk_inflate.hip live for milliseconds to a tenth of a second) the workgroups queued for those CUs would otherwise keep
+    // their 1 / gridDim.x of the blocks waiting; without one, round robin.
+    __shared__ uint32_t next_j;
+    for (uint32_t j = blockIdx.x;; ) {
+        if (next_block) {
+            if (lane == 0) next_j = atomicAdd(next_block, 1u);
+            __syncthreads();
+            j = next_j;
+        }
+        if (j >= n_blocks) break;
         const uint8_t *in = blocks[j].in;
         uint8_t *out = blocks[j].out;
         const uint32_t n = blocks[j].n_in;
@@ -334,6 +345,7 @@ void deflate_kernel(const fqtk_bgzf_block *blocks, uint32_t n_blocks, const uint
         if (lane == 0) out_len[j] = bytes;
         __syncthreads();   // S is reused by the next block
         FQTK_PHASE_MARK(9);
+        if (!next_block) j += gridDim.x;
     }
 }
 #undef FQTK_PHASE_MARK
@@ -348,9 +360,13 @@ hipError_t deflate_prepare() {
     return hipFuncSetAttribute(reinterpret_cast<const void *>(deflate_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(Shared));
 }
 hipError_t deflate_launch(hipStream_t stream, uint32_t groups, const fqtk_bgzf_block *blocks, const uint32_t *n_blocks_dev,
-                          uint32_t *out_len, uint32_t *crc, uint32_t *tok, int level) {
+                          uint32_t *out_len, uint32_t *crc, uint32_t *tok, int level, uint32_t *next_block) {
+    if (next_block) {
+        const hipError_t e = hipMemsetAsync(next_block, 0, sizeof(uint32_t), stream);
+        if (e != hipSuccess) return e;
+    }
     hipLaunchKernelGGL(deflate_kernel, dim3(groups), dim3(kLanes), sizeof(Shared), stream, blocks, 0u, n_blocks_dev, out_len, crc, tok,
-                       level <= 0 ? 0u : (uint32_t)level);
+                       level <= 0 ? 0u : (uint32_t)level, next_block);
     return hipGetLastError();
 }
 }  // namespace bgzf
@@ -437,7 +453,7 @@ int fqtk_bgzf_deflate_enqueue(fqtk_bgzf *z, int slot, const fqtk_bgzf_block *blo
     BGZF_TRY(hipSetDevice(z->device));
     const uint32_t grid = n < (uint32_t)z->num_cus ? n : (uint32_t)z->num_cus;   // one workgroup per CU (107 KiB of LDS each)
     hipLaunchKernelGGL(fqtk::bgzf::deflate_kernel, dim3(grid), dim3(fqtk::bgzf::kLanes), sizeof(fqtk::bgzf::Shared),
-                       z->streams[slot], blocks, n, (const uint32_t *)nullptr, out_len, (uint32_t *)nullptr, z->d_tok[slot], 5u);
+                       z->streams[slot], blocks, n, (const uint32_t *)nullptr, out_len, (uint32_t *)nullptr, z->d_tok[slot], 5u, (uint32_t *)nullptr);
     BGZF_TRY(hipGetLastError());
     z->busy[slot] = true;
     return FQTK_OK;
