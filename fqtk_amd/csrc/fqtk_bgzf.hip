@@ -265,6 +265,7 @@ void deflate_kernel(const fqtk_bgzf_block *blocks, uint32_t n_blocks, const uint
             const uint32_t raw = phase_store(S, lane, in, n, out);
             if (lane == 0) out_len[j] = raw;
             __syncthreads();
+            if (!next_block) j += gridDim.x;
             continue;
         }
         phase_count(S, lane, n);

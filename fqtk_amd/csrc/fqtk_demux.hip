@@ -131,7 +131,6 @@ struct FedInput {
     PinBuf<uint32_t> h_crc;
     uint8_t *d_last_window = nullptr;   // the 32 KiB of text behind the last committed chunk
     uint32_t stream_chunks = 0;         // chunks of the decode in hand
-    bool stream_fenced = false;         // the stream has been made anew with the CU share of stream decoding
 };
 constexpr uint64_t kFedSlack = 256;     // bytes kept free behind the text (the check kernel and the line index read whole dwords / 16 bytes)
 
@@ -558,8 +557,9 @@ int fqtk_demuxer_submit(fqtk_demuxer *d, int slot, const uint8_t *const *text, c
 // A decoder's stream.  cu_share = k in 1..7: it may use only the CUs whose number is below k modulo 8.  A decoder wavefront lives for
 // milliseconds (a BGZF member) to a tenth of a second (a chunk of a serial gzip stream) and is dispatched to whatever CU has
 // room, while a DEFLATE workgroup needs a CU's whole LDS: without a fence every CU holds some decoder wave most of the time and the
-// compressor waits for one to drain.  Measured at 64 M templates: gzip inputs 16.9 -> 20.0-20.3 M templates/s steady with 3 or 5
-// of every 8 CUs (the default for inputs that are decoded as streams: 5), BGZF inputs 39.6 -> 38.5-38.7 (default: no fence).
+// compressor waits for one to drain.  FQTK_FEED_CUS=k, an A/B switch: at 64 M templates, one box, gzip inputs went 16.9 -> 20.0-20.3 M
+// templates/s steady with 3 or 5 of every 8 CUs and BGZF inputs 39.6 -> 38.5-38.7; as a default for gzip inputs it took the bench
+// line's 16 M-template run from 11.3 to 6.5 M templates/s wall on another box: not a default.
 static int make_feed_stream(fqtk_demuxer *d, hipStream_t *out, long cu_share) {
     if (cu_share > 0 && cu_share < 8) {
         uint32_t mask[16];
@@ -772,16 +772,6 @@ int fqtk_demuxer_stream_decode(fqtk_demuxer *d, uint32_t input, const uint8_t *b
     int rc;
     if ((rc = fed_init(d)) != FQTK_OK) return rc;
     FedInput &F = d->fed[input];
-    if (!F.stream_fenced) {   // this input is decoded as a stream: its wavefronts live long, its stream gets 5 of every 8 CUs
-        const char *e = std::getenv("FQTK_FEED_CUS");
-        if (!(e && *e)) {
-            DX_TRY(hipStreamSynchronize(F.stream));
-            DX_TRY(hipStreamDestroy(F.stream));
-            F.stream = nullptr;
-            if ((rc = make_feed_stream(d, &F.stream, 5)) != FQTK_OK) return rc;
-        }
-        F.stream_fenced = true;
-    }
     if ((rc = F.comp.ensure((size_t)len + 16)) != FQTK_OK) return rc;
     if ((rc = F.h_chunks.ensure(n)) != FQTK_OK) return rc;
     if ((rc = F.d_chunks.ensure(n)) != FQTK_OK) return rc;
