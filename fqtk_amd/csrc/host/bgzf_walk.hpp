@@ -70,4 +70,24 @@ struct BgzfFile {
     bool at_end() const { return pos >= size; }
 };
 
+// Length of the gzip member header at p (RFC 1952 2.3; fast_inflate.hpp parses the same fields), 0 if there is none.
+inline size_t gzip_header_len(const uint8_t *p, size_t n) {
+    if (n < 18 || p[0] != 0x1f || p[1] != 0x8b || p[2] != 8 || (p[3] & 0xE0)) return 0;
+    const uint8_t flg = p[3];
+    size_t at = 10;
+    if (flg & 4) {
+        if (at + 2 > n) return 0;
+        at += 2 + ((size_t)p[at] | ((size_t)p[at + 1] << 8));
+    }
+    for (int f = 8; f <= 16; f <<= 1) {
+        if (!(flg & f)) continue;
+        const void *z = at < n ? std::memchr(p + at, 0, n - at) : nullptr;
+        if (!z) return 0;
+        at = (size_t)(static_cast<const uint8_t *>(z) - p) + 1;
+    }
+    if (flg & 2) at += 2;
+    return at < n ? at : 0;
+}
+
+
 }  // namespace fqtk_host

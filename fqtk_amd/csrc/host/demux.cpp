@@ -468,25 +468,6 @@ bool gpu_output_supported(const Plan &plan, std::string *why) {
     return true;
 }
 
-// Length of the gzip member header at p (RFC 1952 2.3; fast_inflate.hpp parses the same fields), 0 if there is none.
-size_t gzip_header_len(const uint8_t *p, size_t n) {
-    if (n < 18 || p[0] != 0x1f || p[1] != 0x8b || p[2] != 8 || (p[3] & 0xE0)) return 0;
-    const uint8_t flg = p[3];
-    size_t at = 10;
-    if (flg & 4) {
-        if (at + 2 > n) return 0;
-        at += 2 + ((size_t)p[at] | ((size_t)p[at + 1] << 8));
-    }
-    for (int f = 8; f <= 16; f <<= 1) {
-        if (!(flg & f)) continue;
-        const void *z = at < n ? std::memchr(p + at, 0, n - at) : nullptr;
-        if (!z) return 0;
-        at = (size_t)(static_cast<const uint8_t *>(z) - p) + 1;
-    }
-    if (flg & 2) at += 2;
-    return at < n ? at : 0;
-}
-
 [[noreturn]] void run_gpu_output(const Options &opt, const Plan &plan, const std::vector<Sample> &samples,
                                  std::vector<std::unique_ptr<FastqSource>> &sources, bool skip_few) {
     const size_t n_inputs = plan.rs.size(), S = samples.size(), G = opt.devices.size();

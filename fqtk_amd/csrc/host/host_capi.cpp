@@ -373,6 +373,9 @@ uint32_t fqtk_host_bgzf_crc_emulated(const uint8_t *in, uint32_t n) {
     return S.crc;
 }
 
+// Length of the gzip member header at data (bgzf_walk.hpp: what the serial-gzip feeders of `fqtk demux` skip), 0 if there is none.
+uint64_t fqtk_host_gzip_header_len(const uint8_t *data, size_t n) { return (uint64_t)fqtk_host::gzip_header_len(data, n); }
+
 // The member walk of the device-inflate feeders (bgzf_walk.hpp): runs of whole members of `path` below max_bytes of file /
 // max_text of text each.  Writes up to cap rows of (run, payload offset in the file, payload bytes, ISIZE, CRC-32); returns the
 // number of members, -1 with *err when the file is not BGZF throughout / damaged.

@@ -271,3 +271,35 @@ def test_member_walk_of_the_device_inflate_feeders(tmp_path):
     (tmp_path / "d.gz").write_bytes(bytes(big))
     with pytest.raises(ValueError, match="more than 64 KiB"):
         _walk(tmp_path / "d.gz")
+
+
+def test_gzip_member_headers_as_the_serial_gzip_feeders_skip_them():
+    """bgzf_walk.hpp gzip_header_len (RFC 1952 2.3): FEXTRA, FNAME, FCOMMENT and FHCRC in every combination; what is no gzip
+    header, reserved flags and truncated headers give 0."""
+    lib = C.CDLL(HOST)
+    fn = lib.fqtk_host_gzip_header_len
+    fn.restype = C.c_uint64
+    fn.argtypes = [C.c_char_p, C.c_size_t]
+    body = raw_deflate(b"ACGT\n" * 10) + struct.pack("<II", zlib.crc32(b"ACGT\n" * 10), 50)
+    for flg in range(0, 32):
+        if flg & 1:                       # FTEXT changes nothing
+            pass
+        head = bytes([0x1f, 0x8b, 8, flg, 0, 0, 0, 0, 0, 3])
+        if flg & 4:
+            head += struct.pack("<H", 5) + b"extra"
+        if flg & 8:
+            head += b"name.fastq\0"
+        if flg & 16:
+            head += b"a comment\0"
+        if flg & 2:
+            head += b"\x12\x34"
+        data = head + body
+        assert fn(data, len(data)) == len(head), flg
+        assert zlib.decompressobj(-15).decompress(data[len(head):-8]) == b"ACGT\n" * 10
+    ok = bytes([0x1f, 0x8b, 8, 0, 0, 0, 0, 0, 0, 3]) + body
+    assert fn(ok, len(ok)) == 10
+    assert fn(b"@read\nACGT\n+\nIIII\n" * 3, 54) == 0                      # plain text
+    assert fn(bytes([0x1f, 0x8b, 8, 0x20]) + ok[4:], len(ok)) == 0           # a reserved flag
+    assert fn(bytes([0x1f, 0x8b, 9]) + ok[3:], len(ok)) == 0                 # not DEFLATE
+    trunc = bytes([0x1f, 0x8b, 8, 8, 0, 0, 0, 0, 0, 3]) + b"a name without its end" * 2
+    assert fn(trunc, len(trunc)) == 0
