@@ -497,6 +497,24 @@ bool gpu_output_supported(const Plan &plan, std::string *why) {
             if (sources[i]->kind() == FastqSource::Kind::Gzip && stat(opt.inputs[i].c_str(), &st) == 0 && S_ISREG(st.st_mode)) gz_bytes += (uint64_t)st.st_size;
         }
         gpu_gunzip = gz_bytes >= (64ull << 20);
+        // ... and only files the chunks can be cut out of: a dynamic-Huffman block must start somewhere in the second and third MiB
+        // of every one of them (a file of stored blocks, or of blocks of many MB, stays with the host's decoders, which need no cuts)
+        for (size_t i = 0; i < n_inputs && gpu_gunzip; ++i) {
+            if (sources[i]->kind() != FastqSource::Kind::Gzip) continue;
+            BgzfFile probe;
+            std::string e;
+            if (!probe.open(opt.inputs[i], &e)) { gpu_gunzip = false; break; }
+            if (probe.size > (4u << 20)) {
+                SpecInflate finder;
+                finder.attach(probe.map, probe.size);
+                if (finder.find_block_start(8ull << 20, 24ull << 20) == ~0ull) {
+                    info("No DEFLATE block starts in the second and third MiB of %s: gzip inputs are decoded on the host.", opt.inputs[i].c_str());
+                    gpu_gunzip = false;
+                }
+            }
+            munmap(const_cast<uint8_t *>(probe.map), probe.size);
+            ::close(probe.fd);
+        }
     }
     bool fed_mode = G == 1 && !opt.host_inflate && !env_on("FQTK_HOST_INFLATE");
     size_t n_serial = 0;
@@ -924,7 +942,7 @@ bool gpu_output_supported(const Plan &plan, std::string *why) {
                             const size_t b0 = (size_t)(verified / 8u) & ~(size_t)3;
                             const size_t b1 = stop_last == ~0ull ? bf.size : std::min<size_t>(bf.size, (size_t)(stop_last / 8u) + 131072);
                             const size_t bytes = b1 - b0;
-                            if (bytes >= (500u << 20)) { fail("internal error: a stretch of 500 MB or more in " + bf.path); return; }
+                            if (bytes >= (500u << 20)) { fail("Unexpected error parsing FASTQs: no DEFLATE block start found in 500 MB of " + bf.path + ": rerun with --host-inflate"); return; }
                             if (bytes + 64 > pin_cap) {   // (once: sized for the longest stretch this file can have)
                                 if (pin) fqtk_pinned_free(pin);
                                 pin_cap = std::max<size_t>(bytes + 64, std::min<size_t>(bf.size, kMaxChunks * chunk_bytes + (1u << 20)) + 65536);

@@ -163,3 +163,28 @@ def test_serial_gzip_inputs_decoded_on_the_device_equal_the_host_decoders(tmp_pa
     r = H.run_demux([bad, f2, f3], ["+T", "8B", "+T"], meta, tmp_path / "o_bad", threads=8, extra=["--chunk-reads", "4000", "--gpu-gunzip"])
     assert r.returncode != 0 and ("corrupt gzip stream" in r.stderr or "parsing FASTQs" in r.stderr), r.stderr
     assert not list((tmp_path / "o_bad").glob("*.fq.gz"))
+
+
+def test_gzip_files_without_block_starts_to_cut_at_stay_with_the_host_decoders(tmp_path):
+    """From 64 MB of .gz the serial gzip inputs go to the device by themselves -- unless a file gives the chunks nothing to be cut
+    at: a stream of stored blocks (level 0) has no dynamic-Huffman header anywhere, the probe says so and the host's decoders,
+    which need no cuts, take the run."""
+    import gzip
+    rng = np.random.default_rng(41)
+    bcs = ["ACGTACGT", "TTGCAATG"]
+    n = 9000
+    acgt = np.frombuffer(b"ACGT", dtype=np.uint8)
+    recs = []
+    for i in range(n):
+        bases = bcs[i & 1] + acgt[rng.integers(0, 4, 4000)].tobytes().decode()
+        recs.append((f"r:{i} x", bases, "F" * len(bases)))
+    text = _text(recs)
+    assert len(text) > (66 << 20)
+    f = str(tmp_path / "stored.fastq.gz")
+    with open(f, "wb") as fh:
+        fh.write(gzip.compress(text, 0))
+    meta = _meta(tmp_path, bcs)
+    r = H.run_demux([f], ["8B+T"], meta, tmp_path / "out", threads=8)
+    assert r.returncode == 0, r.stderr
+    assert "gzip inputs are decoded on the host" in r.stderr and "decoded on the device in chunks" not in r.stderr, r.stderr
+    assert sum(len(v) for v in _outputs(tmp_path / "out").values()) == n
