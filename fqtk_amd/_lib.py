@@ -36,7 +36,8 @@ class fqtk_stream_chunk(C.Structure):   # include/fqtk_demux.h
 
 
 class fqtk_stream_end(C.Structure):
-    _fields_ = [("status", C.c_uint32), ("final_block", C.c_uint32), ("n_bytes", C.c_uint64), ("end_bit", C.c_uint64)]
+    _fields_ = [("status", C.c_uint32), ("final_block", C.c_uint32), ("n_bytes", C.c_uint64), ("end_bit", C.c_uint64), ("start_bit", C.c_uint64),
+                ("n_blocks", C.c_uint32), ("flags", C.c_uint32)]
 
 
 # include/fqtk_demux.h
@@ -151,6 +152,9 @@ SIGNATURES = [
     ("fqtk_demuxer_fed_tail", C.c_int, [C.c_void_p, C.c_uint32, C.c_uint64, C.c_void_p, C.c_size_t, C.POINTER(C.c_uint64)]),
     ("fqtk_demuxer_inflate_seconds", C.c_int, [C.c_void_p, C.POINTER(C.c_double)]),
     ("fqtk_demuxer_stream_decode", C.c_int, [C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint32, C.c_void_p]),
+    ("fqtk_demuxer_stream_scan", C.c_int, [C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint32, C.c_int, C.c_uint32, C.c_uint32, C.c_void_p, C.POINTER(C.c_uint32)]),
+    ("fqtk_demuxer_stream_window", C.c_int, [C.c_void_p, C.c_uint32, C.c_void_p]),
+    ("fqtk_demuxer_stream_commit_text", C.c_int, [C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint64, C.c_void_p, C.c_int, C.POINTER(C.c_uint64), C.POINTER(C.c_uint32)]),
     ("fqtk_demuxer_stream_commit", C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32, C.c_int, C.c_int, C.POINTER(C.c_uint64), C.POINTER(C.c_uint32), C.POINTER(C.c_uint64)]),
 ]
 

@@ -140,7 +140,12 @@ struct MemberArgs {
     uint32_t stop_bit;         // the chunk ends at the first block boundary at or behind this bit (or with the final block)
 };
 // What a chunk of a stream came to (stream mode).
-struct StreamEnd { uint32_t n_sym, end_bit, final_block; };
+// n_blocks: whole blocks decoded; n_sym / end_bit / final_block describe the LAST block boundary reached -- also when the chunk then failed
+// (no room for more symbols, no more input): what came before that boundary is good, and a caller may take it.
+// flags: kStreamHighLiterals -- some block up to that boundary gave a code to a literal >= 128 (text such as FASTQ never does, and the
+// block-start search can then refuse candidates that do: fqtk_inflate.hip).
+struct StreamEnd { uint32_t n_sym, end_bit, final_block, n_blocks, flags; };
+enum : uint32_t { kStreamHighLiterals = 1 };
 constexpr uint32_t kWindow = 32768;
 
 // ---- the wave -------------------------------------------------------------------------------------------------------
@@ -192,7 +197,8 @@ struct Ring {
 };
 
 // Builds the canonical description of a code from lens[0..n) and its fast table (2^P entries).  Returns an error code.
-template <class W, bool kLitLen>
+// kTables = false: only whether the lengths make a code the decoder accepts (the block-start search asks no more).
+template <class W, bool kLitLen, bool kTables = true>
 FQTK_HD inline uint32_t build_code(W &w, Shared &S, const uint8_t *lens, uint32_t n) {
     constexpr uint32_t P = kLitLen ? kLitBits : kDistBits;
     Canon &C = kLitLen ? S.cl : S.cd;
@@ -248,6 +254,7 @@ FQTK_UNROLL
     if (over) return kErrOverSubscribed;
     // incomplete codes: legal only as "at most one code, of one bit" (a block with one distance code, or none)
     if (left > 0 && !(used <= 1u && maxlen <= 1u)) return kErrOverSubscribed;
+    if (!kTables) return kOk;
 FQTK_UNROLL
     for (uint32_t p = 0; p < 5u; ++p)
         if (my_len[p]) perm[my_offs[p] + my_rank[p]] = (uint16_t)(p * 64u + lane);
@@ -357,6 +364,153 @@ FQTK_HD inline Token decode_token_fast(const Shared &S, uint64_t bits) {
     return t;
 }
 
+// The header of a dynamic-Huffman block behind its three type bits (RFC 1951 3.2.7): HLIT, HDIST, HCLEN, the code-length code and the
+// run-length coded code lengths, which go to S.lens (hlit literal/length ones, then hdist distance ones).  `bit` moves behind them.
+// Returns an error code (the same in all lanes); used by the decoder and by the block-start search.
+template <class W>
+FQTK_HD inline uint32_t read_dynamic_header(W &w, Shared &S, const MemberArgs &a, Ring<W> &ring, uint32_t &bit, uint32_t &hlit, uint32_t &hdist) {
+    const uint32_t lane = w.lane();
+    ring.ensure(w, S, a, bit);
+    const uint32_t hh = w.uniform(peek32(w, S, bit));
+    hlit = (hh & 31u) + 257u; hdist = ((hh >> 5) & 31u) + 1u;
+    const uint32_t hclen = ((hh >> 10) & 15u) + 4u;
+    bit += 14u;
+    if (hlit > 286u || hdist > 30u) return kErrCodeLengths;
+    // the code-length code's 19 lengths: lane k takes the k-th (3 bits each, in the order of RFC 1951 3.2.7)
+    ring.ensure(w, S, a, bit + 64u);
+    uint32_t my_cl_len = 0;   // lane s: length of code-length symbol s
+    // position of symbol s in the transmitted order 16 17 18 0 8 7 9 6 10 5 11 4 12 3 13 2 14 1 15
+    uint32_t pos_of = 19u;
+    if (lane < 19u) {
+        const uint32_t s = lane;
+        if (s >= 16u) pos_of = s - 16u;
+        else if (s == 0u) pos_of = 3u;
+        else if (s >= 8u) pos_of = 4u + 2u * (s - 8u);          // 8 -> 4, 9 -> 6, 10 -> 8, ... 15 -> 18
+        else pos_of = 5u + 2u * (7u - s);                      // 7 -> 5, 6 -> 7, ... 1 -> 17
+    }
+    if (pos_of < hclen) my_cl_len = peek32(w, S, bit + 3u * pos_of) & 7u;
+    bit += 3u * hclen;
+    // its canonical code (<= 7 bits, 19 symbols) and a 128-entry table, by the wave
+    uint32_t ctot[8];
+FQTK_UNROLL
+    for (int l = 0; l < 8; ++l) ctot[l] = 0;
+    uint32_t my_rank = 0;
+FQTK_UNROLL
+    for (uint32_t l = 1; l < 8u; ++l) {
+        const uint64_t m = w.ballot(my_cl_len == l);
+        if (my_cl_len == l) my_rank = (uint32_t)__builtin_popcountll(m & ((1ull << lane) - 1ull));
+        ctot[l] = (uint32_t)__builtin_popcountll(m);
+    }
+    uint32_t code = 0, my_code = 0;
+    int32_t left = 1;
+    bool over = false;
+FQTK_UNROLL
+    for (uint32_t l = 1; l < 8u; ++l) {
+        left = (left << 1) - (int32_t)ctot[l];
+        if (left < 0) over = true;
+        if (my_cl_len == l) my_code = code + my_rank;
+        code = (code + ctot[l]) << 1;
+    }
+    if (over) return kErrCodeLengths;
+    S.cl_tab[lane] = 0u;
+    S.cl_tab[lane + 64u] = 0u;
+    w.barrier();
+    if (my_cl_len) {
+        const uint32_t rev = brev32(my_code) >> (32u - my_cl_len);
+        for (uint32_t k = rev; k < 128u; k += 1u << my_cl_len) S.cl_tab[k] = (lane << 16) | my_cl_len;
+    }
+    w.barrier();
+    // the hlit + hdist code lengths, run-length coded: a serial chain, every lane follows it
+    const uint32_t total = hlit + hdist;
+    uint32_t i = 0, prev = 0;
+    while (i < total) {
+        ring.ensure(w, S, a, bit);
+        const uint32_t b = w.uniform(peek32(w, S, bit));
+        const uint32_t e = w.uniform(S.cl_tab[b & 127u]);
+        const uint32_t l = e & 0xFFu;
+        if (l == 0u) return kErrCodeLengths;
+        const uint32_t sym = e >> 16;
+        bit += l;
+        const uint32_t x = b >> l;
+        if (sym < 16u) {
+            if (lane == 0u) S.lens[i] = (uint8_t)sym;
+            prev = sym;
+            ++i;
+        } else {
+            uint32_t rep, v = 0;
+            if (sym == 16u) {
+                if (i == 0u) return kErrCodeLengths;
+                v = prev; rep = 3u + (x & 3u); bit += 2u;
+            } else if (sym == 17u) {
+                rep = 3u + (x & 7u); bit += 3u;
+            } else {
+                rep = 11u + (x & 127u); bit += 7u;
+            }
+            if (i + rep > total) return kErrCodeLengths;
+            for (uint32_t k = lane; k < rep; k += 64u) S.lens[i + k] = (uint8_t)v;
+            prev = v;
+            i += rep;
+        }
+    }
+    w.barrier();
+    if (w.uniform(S.lens[256]) == 0u) return kErrCodeLengths;
+    return kOk;
+}
+
+// The first bit in [from_bit, limit_bit) at which a non-final dynamic-Huffman block can start: BFINAL = 0, BTYPE = 2, HLIT and HDIST in
+// range, a COMPLETE code-length code -- tested by lane i for bit t + i, 64 positions at a time, on bits fetched straight from memory -- and,
+// for the few positions that pass (the wave takes them one at a time, in order), a header that parses into two codes the decoder accepts.
+// That is host/parallel_gunzip.hpp's SpecInflate::find_block_start on a wavefront: a one-in-many-millions accident where no block starts,
+// and nothing rests on it -- a chunk cut at such a place counts only if the chunk before it ends on exactly that bit.  Bits count from
+// a.in_words; ~0: none.  (Stored and fixed blocks are not looked for: a chunk just runs on through them.)
+// An accidental header still turns up about once per 100 MB of FASTQ.gz (measured: one in a 60 MB stream), and in stream mode a chunk that
+// starts at one decodes garbage without an error (any bits decode under two complete codes, any distance reaches into the unknown window);
+// the chain refuses it, at the price of the rest of its stretch.  low_literals_only makes such headers rarer by orders of magnitude.
+template <class W>
+FQTK_HD inline uint32_t find_block_start(W &w, Shared &S, const MemberArgs &a, uint32_t from_bit, uint32_t limit_bit, bool low_literals_only = false) {
+    const uint32_t lane = w.lane();
+    const uint32_t end_bit = a.first_bit + a.payload_bits;
+    Ring<W> ring;
+    ring.filled = 0; ring.pref = 0;
+    for (uint32_t t0 = from_bit; t0 < limit_bit; t0 += 64u) {
+        const uint32_t t = t0 + lane, d = t >> 5, s = t & 31u;
+        const uint64_t lo = (uint64_t)ring.load(w, a, d) | ((uint64_t)ring.load(w, a, d + 1u) << 32);
+        const uint64_t hi = (uint64_t)ring.load(w, a, d + 2u) | ((uint64_t)ring.load(w, a, d + 3u) << 32);
+        const uint64_t b = s ? (lo >> s) | (hi << (64u - s)) : lo;   // bits t .. t + 63
+        const uint64_t c = hi >> s;                                   // bits t + 64 .. (32 of them at least)
+        const uint32_t hclen = ((uint32_t)(b >> 13) & 15u) + 4u;
+        bool pass = t < limit_bit && ((uint32_t)b & 7u) == 4u && ((uint32_t)(b >> 3) & 31u) <= 29u && ((uint32_t)(b >> 8) & 31u) <= 29u &&
+                    t + 17u + 3u * hclen < end_bit;
+        if (w.ballot(pass)) {
+            // Kraft sum of the code-length code: 3-bit fields k < hclen from bit 17 on (fields 0-14 in b, 15-18 from bit 62 on)
+            const uint64_t c0 = b >> 17, c1 = (b >> 62) | (c << 2);
+            uint32_t kraft = 0;
+FQTK_UNROLL
+            for (uint32_t k = 0; k < 19u; ++k) {
+                const uint32_t l = (uint32_t)(k < 15u ? c0 >> (3u * k) : c1 >> (3u * (k - 15u))) & 7u;
+                kraft += k < hclen && l ? 128u >> l : 0u;
+            }
+            pass = pass && kraft == 128u;
+        }
+        uint64_t m = w.ballot(pass);
+        while (m) {
+            const uint32_t cand = (uint32_t)__builtin_ctzll(m);
+            m &= m - 1ull;
+            uint32_t bit = t0 + cand + 3u, hlit = 0, hdist = 0;
+            ring.reset(w, a, bit);
+            uint32_t err = read_dynamic_header(w, S, a, ring, bit, hlit, hdist);
+            if (!err && bit > end_bit) err = kErrTruncated;
+            // (the caller has seen nothing but 7-bit text in this stream so far: a header that gives codes to literals >= 128 -- as nearly every
+            //  accidental one does -- is not taken for a start; a true one that is refused only makes the chunk before it longer)
+            if (!err && low_literals_only && w.ballot(S.lens[128u + lane] != 0 || S.lens[192u + lane] != 0)) err = kErrBadCode;
+            if (!err) err = build_code<W, true, false>(w, S, S.lens, hlit);
+            if (!err) err = build_code<W, false, false>(w, S, S.lens + hlit, hdist);
+            if (!err) return t0 + cand;
+        }
+    }
+    return 0xFFFFFFFFu;
+}
+
 // Decodes one member.  Returns its status (the same in all lanes).
 // kStream: the same decoder on a piece of a SERIAL gzip stream (`gzip`, bcl2fastq: one member per file) -- it starts at a
 // block boundary inside the stream without the 32 KiB of text before it, so it writes 16-bit symbols (a byte, or "byte j of the
@@ -372,6 +526,7 @@ FQTK_HD inline uint32_t inflate_member(W &w, Shared &S, const MemberArgs &a, Str
     uint32_t out_pos = 0;                          // uniform
     uint32_t safe = 0;                             // output below this is visible to every lane's loads
     uint32_t own_tag = 0;                          // rounds of 64 output bytes so far (24 bits are plenty: <= 65 536 bytes a member)
+    uint32_t stream_flags = 0;                     // uniform
     ring.reset(w, a, bit);
     S.own[lane] = 0u;   // (tag 0 is never a round's)
     w.barrier();
@@ -405,92 +560,11 @@ FQTK_HD inline uint32_t inflate_member(W &w, Shared &S, const MemberArgs &a, Str
                 for (uint32_t s = lane; s < 320u; s += 64u) S.lens[s] = (uint8_t)(s < 144u ? 8u : s < 256u ? 9u : s < 280u ? 7u : s < 288u ? 8u : 5u);
                 w.barrier();
             } else {
-                ring.ensure(w, S, a, bit);
-                const uint32_t hh = w.uniform(peek32(w, S, bit));
-                hlit = (hh & 31u) + 257u; hdist = ((hh >> 5) & 31u) + 1u;
-                const uint32_t hclen = ((hh >> 10) & 15u) + 4u;
-                bit += 14u;
-                if (hlit > 286u || hdist > 30u) return kErrCodeLengths;
-                // the code-length code's 19 lengths: lane k takes the k-th (3 bits each, in the order of RFC 1951 3.2.7)
-                ring.ensure(w, S, a, bit + 64u);
-                uint32_t my_cl_len = 0;   // lane s: length of code-length symbol s
-                // position of symbol s in the transmitted order 16 17 18 0 8 7 9 6 10 5 11 4 12 3 13 2 14 1 15
-                uint32_t pos_of = 19u;
-                if (lane < 19u) {
-                    const uint32_t s = lane;
-                    if (s >= 16u) pos_of = s - 16u;
-                    else if (s == 0u) pos_of = 3u;
-                    else if (s >= 8u) pos_of = 4u + 2u * (s - 8u);          // 8 -> 4, 9 -> 6, 10 -> 8, ... 15 -> 18
-                    else pos_of = 5u + 2u * (7u - s);                      // 7 -> 5, 6 -> 7, ... 1 -> 17
-                }
-                if (pos_of < hclen) my_cl_len = peek32(w, S, bit + 3u * pos_of) & 7u;
-                bit += 3u * hclen;
-                // its canonical code (<= 7 bits, 19 symbols) and a 128-entry table, by the wave
-                uint32_t ctot[8];
-FQTK_UNROLL
-                for (int l = 0; l < 8; ++l) ctot[l] = 0;
-                uint32_t my_rank = 0;
-FQTK_UNROLL
-                for (uint32_t l = 1; l < 8u; ++l) {
-                    const uint64_t m = w.ballot(my_cl_len == l);
-                    if (my_cl_len == l) my_rank = (uint32_t)__builtin_popcountll(m & ((1ull << lane) - 1ull));
-                    ctot[l] = (uint32_t)__builtin_popcountll(m);
-                }
-                uint32_t code = 0, my_code = 0;
-                int32_t left = 1;
-                bool over = false;
-FQTK_UNROLL
-                for (uint32_t l = 1; l < 8u; ++l) {
-                    left = (left << 1) - (int32_t)ctot[l];
-                    if (left < 0) over = true;
-                    if (my_cl_len == l) my_code = code + my_rank;
-                    code = (code + ctot[l]) << 1;
-                }
-                if (over) return kErrCodeLengths;
-                S.cl_tab[lane] = 0u;
-                S.cl_tab[lane + 64u] = 0u;
-                w.barrier();
-                if (my_cl_len) {
-                    const uint32_t rev = brev32(my_code) >> (32u - my_cl_len);
-                    for (uint32_t k = rev; k < 128u; k += 1u << my_cl_len) S.cl_tab[k] = (lane << 16) | my_cl_len;
-                }
-                w.barrier();
-                // the hlit + hdist code lengths, run-length coded: a serial chain, every lane follows it
-                const uint32_t total = hlit + hdist;
-                uint32_t i = 0, prev = 0;
-                while (i < total) {
-                    ring.ensure(w, S, a, bit);
-                    const uint32_t b = w.uniform(peek32(w, S, bit));
-                    const uint32_t e = w.uniform(S.cl_tab[b & 127u]);
-                    const uint32_t l = e & 0xFFu;
-                    if (l == 0u) return kErrCodeLengths;
-                    const uint32_t sym = e >> 16;
-                    bit += l;
-                    const uint32_t x = b >> l;
-                    if (sym < 16u) {
-                        if (lane == 0u) S.lens[i] = (uint8_t)sym;
-                        prev = sym;
-                        ++i;
-                    } else {
-                        uint32_t rep, v = 0;
-                        if (sym == 16u) {
-                            if (i == 0u) return kErrCodeLengths;
-                            v = prev; rep = 3u + (x & 3u); bit += 2u;
-                        } else if (sym == 17u) {
-                            rep = 3u + (x & 7u); bit += 3u;
-                        } else {
-                            rep = 11u + (x & 127u); bit += 7u;
-                        }
-                        if (i + rep > total) return kErrCodeLengths;
-                        for (uint32_t k = lane; k < rep; k += 64u) S.lens[i + k] = (uint8_t)v;
-                        prev = v;
-                        i += rep;
-                    }
-                }
-                w.barrier();
-                if (w.uniform(S.lens[256]) == 0u) return kErrCodeLengths;
+                const uint32_t herr = read_dynamic_header(w, S, a, ring, bit, hlit, hdist);
+                if (herr) return herr;
             }
             if (bit > end_bit) return kErrTruncated;
+            if (kStream && w.ballot(S.lens[128u + lane] != 0 || S.lens[192u + lane] != 0)) stream_flags |= kStreamHighLiterals;
             uint32_t err = build_code<W, true>(w, S, S.lens, hlit);
             if (err) return err;
             err = build_code<W, false>(w, S, S.lens + hlit, hdist);
@@ -651,10 +725,8 @@ FQTK_UNROLL
             }
         }
         if (bit > end_bit) return kErrTruncated;
-        if (final_block || (kStream && bit >= a.stop_bit)) {
-            if (kStream && end && lane == 0u) { end->n_sym = out_pos; end->end_bit = bit; end->final_block = final_block; }
-            break;
-        }
+        if (kStream && end && lane == 0u) { end->n_sym = out_pos; end->end_bit = bit; end->final_block = final_block; end->n_blocks += 1u; end->flags = stream_flags; }
+        if (final_block || (kStream && bit >= a.stop_bit)) break;
     }
     if (!kStream && out_pos != a.isize) return kErrLength;
     return kOk;

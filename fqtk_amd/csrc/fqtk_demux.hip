@@ -121,6 +121,7 @@ struct FedInput {
     // a serial gzip stream in chunks (fqtk_demuxer_stream_decode / _commit)
     DevBuf<uint16_t> sym;
     DevBuf<uint8_t> windows;
+    DevBuf<uint16_t> maps;             // the chunks' window maps (stream_resolve_launch)
     DevBuf<fqtk::inflate::StreamChunk> d_chunks;
     DevBuf<fqtk::inflate::StreamChunkEnd> d_ends;
     DevBuf<unsigned long long> d_out_off;
@@ -131,6 +132,10 @@ struct FedInput {
     PinBuf<uint32_t> h_crc;
     uint8_t *d_last_window = nullptr;   // the 32 KiB of text behind the last committed chunk
     uint32_t stream_chunks = 0;         // chunks of the decode in hand
+    // ... with the chunks cut on the device (fqtk_demuxer_stream_scan)
+    DevBuf<unsigned long long> d_starts;
+    fqtk::inflate::StreamPlan *d_plan = nullptr;
+    fqtk::inflate::StreamPlan *h_plan = nullptr;   // page-locked
 };
 constexpr uint64_t kFedSlack = 256;     // bytes kept free behind the text (the check kernel and the line index read whole dwords / 16 bytes)
 
@@ -398,9 +403,12 @@ void fqtk_demuxer_destroy(fqtk_demuxer *d) {
             for (hipEvent_t e : {F.ev_moved, F.ev_t0, F.ev_t1}) if (e) (void)hipEventDestroy(e);
             F.arena[0].release(); F.arena[1].release(); F.comp.release(); F.d_members.release(); F.d_status.release(); F.d_lines.release();
             F.h_status.release(); F.h_lines.release(); F.h_members.release();
-            F.sym.release(); F.windows.release(); F.d_chunks.release(); F.d_ends.release(); F.d_out_off.release(); F.d_crc.release();
+            F.sym.release(); F.windows.release(); F.maps.release(); F.d_chunks.release(); F.d_ends.release(); F.d_out_off.release(); F.d_crc.release();
             F.h_chunks.release(); F.h_ends.release(); F.h_out_off.release(); F.h_crc.release();
             if (F.d_last_window) (void)hipFree(F.d_last_window);
+            F.d_starts.release();
+            if (F.d_plan) (void)hipFree(F.d_plan);
+            if (F.h_plan) (void)hipHostFree(F.h_plan);
         }
         delete[] d->fed;
     }
@@ -605,23 +613,28 @@ static int fed_init(fqtk_demuxer *d) {
     return FQTK_OK;
 }
 
-// Room for text_bytes more text of an input (its mutex held): when the arena is full, what chunks have not consumed yet moves to the
-// front of the other arena.
-static int fed_make_room(fqtk_demuxer *d, FedInput &F, uint64_t text_bytes, bool tight = false) {
+// Room for text_bytes more text of an input (its mutex held through `lk`): when the arena is full, what chunks have not consumed yet
+// moves to the front of the other arena.  A change of arena excludes a submit in progress (a chunk whose window was cut out
+// of the old arena but whose kernels were not enqueued yet was not covered by ev_last_fmt): the input's lock is given up, submit_fed's
+// taken, the input's again (that order everywhere), and with both held every window ever cut has its ev_fmt behind ev_last_fmt.
+static int fed_make_room(fqtk_demuxer *d, FedInput &F, std::unique_lock<std::mutex> &lk, uint64_t text_bytes, bool tight = false) {
     int rc;
-    uint64_t live_from = F.members.empty() ? F.tail : F.members.front().off;
-    if (F.tail + text_bytes + kFedSlack > F.arena[F.cur].cap) {
+    if (F.tail + text_bytes + kFedSlack <= F.arena[F.cur].cap) return FQTK_OK;
+    lk.unlock();
+    std::lock_guard<std::mutex> glk(d->fed_mu);
+    lk.lock();
+    // (only this input's feeder moves its tail; chunks may have consumed members meanwhile, which only shrinks what is live)
+    const uint64_t live_from = F.members.empty() ? F.tail : F.members.front().off;
+    {
         const uint64_t live = F.tail - live_from;
         const int other = 1 - F.cur;
         // (FQTK_FED_ARENA_MIN: tests make the arenas small so that a short run changes arena many times)
         static const uint64_t arena_min = [] { const char *e = std::getenv("FQTK_FED_ARENA_MIN"); return e && *e ? (uint64_t)std::strtoull(e, nullptr, 10) : (1ull << 30); }();
-        // (tight: gigabytes of text at a time -- a serial gzip stream's stretches -- take an arena that holds one of them and what is
-        //  live, and change arena with every stretch: the copy of the live text is milliseconds, a larger allocation 0.1 s per GB)
+        // (tight: gigabytes of text at a time take an arena that holds one of them and what is live, and change arena every time)
         const uint64_t want = std::max<uint64_t>(tight ? (live + text_bytes) + (live + text_bytes) / 4 + kFedSlack : (live + text_bytes + kFedSlack) * 2, arena_min);
         {
             // Chunks whose record views point into the OTHER arena were submitted before this input last changed arenas:
-            // its old text may go, and this stream's copy may start, when they have been formatted.  (No lock against a
-            // submit in progress: a window is cut under F.mu, which this thread holds, and out of the current arena.)
+            // its old text may go, and this stream's copy may start, when they have been formatted.
             const bool any = d->chunks_submitted.load() != 0;
             if (any) DX_TRY(hipStreamWaitEvent(F.stream, d->ev_last_fmt, 0));
             if (F.arena[other].cap < want) {
@@ -659,7 +672,7 @@ int fqtk_demuxer_feed(fqtk_demuxer *d, uint32_t input, const uint8_t *bytes, uin
         text_bytes += members[j].isize;
     }
     int rc;
-    if ((rc = fed_make_room(d, F, text_bytes)) != FQTK_OK) return rc;
+    if ((rc = fed_make_room(d, F, lk, text_bytes)) != FQTK_OK) return rc;
     // the members' places, the copy in, the kernels, the counts back
     if ((rc = F.h_members.ensure(n_members + 1)) != FQTK_OK) return rc;
     if ((rc = F.d_members.ensure(n_members + 1)) != FQTK_OK) return rc;
@@ -805,7 +818,68 @@ int fqtk_demuxer_stream_decode(fqtk_demuxer *d, uint32_t input, const uint8_t *b
         ends[k].final_block = F.h_ends.p[k].final_block;
         ends[k].n_bytes = F.h_ends.p[k].n_sym;
         ends[k].end_bit = F.h_ends.p[k].end_bit;
+        ends[k].start_bit = chunks[k].start_bit;
+        ends[k].n_blocks = F.h_ends.p[k].n_blocks;
+        ends[k].flags = F.h_ends.p[k].flags;
     }
+    F.stream_chunks = n;
+    return FQTK_OK;
+}
+
+// The same with the chunks cut on the device (fqtk_inflate.hip: stream_search_kernel, stream_plan_kernel).
+int fqtk_demuxer_stream_scan(fqtk_demuxer *d, uint32_t input, const uint8_t *bytes, uint64_t len, uint64_t first_bit, uint32_t chunk_bytes, uint32_t n_slots, int to_end,
+                             uint32_t sym_per_byte, uint32_t flags, fqtk_stream_end *ends, uint32_t *n_chunks) {
+    using namespace fqtk::inflate;
+    if (!d || !bytes || !ends || !n_chunks) return set_error(FQTK_EINVAL, "NULL argument");
+    if (input >= d->C.n_inputs) return set_error(FQTK_EINVAL, "input out of range");
+    if (len >= (1ull << 29)) return set_error(FQTK_EINVAL, "a stretch of 512 MiB or more: use shorter stretches");
+    if (n_slots == 0 || n_slots > kMaxStreamSlots) return set_error(FQTK_EINVAL, "n_slots must be 1 .. 4096");
+    if (chunk_bytes < 4096u || (chunk_bytes & 3u) || first_bit >= len * 8u) return set_error(FQTK_EINVAL, "chunk_bytes must be a multiple of 4 of 4096 at least; first_bit inside the stretch");
+    if (sym_per_byte == 0 || sym_per_byte > 2048u) return set_error(FQTK_EINVAL, "sym_per_byte must be 1 .. 2048");
+    DX_TRY(hipSetDevice(d->device));
+    int rc;
+    if ((rc = fed_init(d)) != FQTK_OK) return rc;
+    FedInput &F = d->fed[input];
+    if ((rc = F.comp.ensure((size_t)len + 16)) != FQTK_OK) return rc;
+    if ((rc = F.d_chunks.ensure(n_slots)) != FQTK_OK) return rc;
+    if ((rc = F.h_chunks.ensure(n_slots)) != FQTK_OK) return rc;
+    if ((rc = F.h_ends.ensure(n_slots)) != FQTK_OK) return rc;
+    if ((rc = F.d_ends.ensure(n_slots)) != FQTK_OK) return rc;
+    if ((rc = F.d_starts.ensure(n_slots)) != FQTK_OK) return rc;
+    if (!F.d_plan) {
+        DX_TRY(hipMalloc(reinterpret_cast<void **>(&F.d_plan), sizeof(StreamPlan)));
+        DX_TRY(hipHostMalloc(reinterpret_cast<void **>(&F.h_plan), sizeof(StreamPlan), hipHostMallocDefault));
+    }
+    // room for the symbols: sym_per_byte per compressed byte of the stretch and a block's worth per chunk (the plan kernel shares it out
+    // and never hands out more than there is)
+    const uint32_t slack = 65536u;
+    const uint64_t sym_cap = (len + 1u) * sym_per_byte + (uint64_t)n_slots * (slack + 8u * (uint64_t)sym_per_byte + 8u);
+    if ((rc = F.sym.ensure((size_t)sym_cap + 64)) != FQTK_OK) return rc;
+    DX_TRY(hipMemcpyAsync(F.comp.p, bytes, (size_t)len, hipMemcpyHostToDevice, F.stream));
+    DX_TRY(hipEventRecord(F.ev_t0, F.stream));
+    DX_TRY(stream_scan_launch(F.stream, F.comp.p, len, first_bit, chunk_bytes, n_slots, to_end != 0, (flags & FQTK_STREAM_SCAN_TEXT) != 0, sym_per_byte, slack, sym_cap, reinterpret_cast<uint64_t *>(F.d_starts.p),
+                              F.d_chunks.p, F.d_plan, F.sym.p, F.d_ends.p));
+    DX_TRY(hipEventRecord(F.ev_t1, F.stream));
+    DX_TRY(hipMemcpyAsync(F.h_plan, F.d_plan, sizeof(StreamPlan), hipMemcpyDeviceToHost, F.stream));
+    DX_TRY(hipMemcpyAsync(F.h_chunks.p, F.d_chunks.p, (size_t)n_slots * sizeof(StreamChunk), hipMemcpyDeviceToHost, F.stream));
+    DX_TRY(hipMemcpyAsync(F.h_ends.p, F.d_ends.p, (size_t)n_slots * sizeof(StreamChunkEnd), hipMemcpyDeviceToHost, F.stream));
+    DX_TRY(hipStreamSynchronize(F.stream));
+    {
+        float ms = 0;
+        if (hipEventElapsedTime(&ms, F.ev_t0, F.ev_t1) == hipSuccess) { std::lock_guard<std::mutex> glk(d->stat_mu); d->inflate_s += ms * 1e-3; }
+    }
+    const uint32_t n = F.h_plan->n_chunks;
+    if (n == 0 || n > n_slots) return set_error(FQTK_EHIP, "the stretch's plan came back empty");
+    for (uint32_t k = 0; k < n; ++k) {
+        ends[k].status = F.h_ends.p[k].status;
+        ends[k].final_block = F.h_ends.p[k].final_block;
+        ends[k].n_bytes = F.h_ends.p[k].n_sym;
+        ends[k].end_bit = F.h_ends.p[k].end_bit;
+        ends[k].start_bit = F.h_chunks.p[k].start_bit;
+        ends[k].n_blocks = F.h_ends.p[k].n_blocks;
+        ends[k].flags = F.h_ends.p[k].flags;
+    }
+    *n_chunks = n;
     F.stream_chunks = n;
     return FQTK_OK;
 }
@@ -824,7 +898,7 @@ int fqtk_demuxer_stream_commit(fqtk_demuxer *d, uint32_t input, uint32_t n_accep
     if ((rc = F.d_out_off.ensure(n_accept + 1)) != FQTK_OK) return rc;
     for (uint32_t k = 0; k < n_accept; ++k) total += F.h_ends.p[k].n_sym;
     const uint64_t text_bytes = total + (last ? 1 : 0);
-    if ((rc = fed_make_room(d, F, text_bytes, text_bytes > (512ull << 20))) != FQTK_OK) return rc;
+    if ((rc = fed_make_room(d, F, lk, text_bytes, text_bytes > (1ull << 30))) != FQTK_OK) return rc;
     const uint64_t at = F.tail;
     {
         uint64_t o = at;
@@ -839,6 +913,7 @@ int fqtk_demuxer_stream_commit(fqtk_demuxer *d, uint32_t input, uint32_t n_accep
     if ((rc = F.d_crc.ensure(n_pieces + 1)) != FQTK_OK) return rc;
     if ((rc = F.h_crc.ensure(n_pieces + 1)) != FQTK_OK) return rc;
     if ((rc = F.windows.ensure((size_t)(n_accept + 1) * fqtk::inflate::kStreamWindow)) != FQTK_OK) return rc;
+    if ((rc = F.maps.ensure((size_t)n_accept * 2u * fqtk::inflate::kStreamWindow)) != FQTK_OK) return rc;
     if (!F.d_last_window) {
         DX_TRY(hipMalloc(reinterpret_cast<void **>(&F.d_last_window), fqtk::inflate::kStreamWindow));
         DX_TRY(hipMemsetAsync(F.d_last_window, 0, fqtk::inflate::kStreamWindow, F.stream));
@@ -859,7 +934,7 @@ int fqtk_demuxer_stream_commit(fqtk_demuxer *d, uint32_t input, uint32_t n_accep
         else DX_TRY(hipMemcpyAsync(F.windows.p, F.d_last_window, fqtk::inflate::kStreamWindow, hipMemcpyDeviceToDevice, F.stream));
         DX_TRY(hipMemcpyAsync(F.d_out_off.p, F.h_out_off.p, (size_t)n_accept * sizeof(unsigned long long), hipMemcpyHostToDevice, F.stream));
         // (window n_accept -- the text behind the last accepted chunk -- comes out of the same chain: the next commit starts from it)
-        DX_TRY(fqtk::inflate::stream_resolve_launch(F.stream, F.d_chunks.p, F.d_ends.p, n_accept, reinterpret_cast<const uint64_t *>(F.d_out_off.p), F.sym.p, F.windows.p, arena));
+        DX_TRY(fqtk::inflate::stream_resolve_launch(F.stream, F.d_chunks.p, F.d_ends.p, n_accept, reinterpret_cast<const uint64_t *>(F.d_out_off.p), F.sym.p, F.windows.p, F.maps.p, arena));
         DX_TRY(hipMemcpyAsync(F.d_last_window, F.windows.p + (size_t)n_accept * fqtk::inflate::kStreamWindow, fqtk::inflate::kStreamWindow, hipMemcpyDeviceToDevice, F.stream));
     }
     if (n_pieces) {
@@ -902,6 +977,98 @@ int fqtk_demuxer_stream_commit(fqtk_demuxer *d, uint32_t input, uint32_t n_accep
     if (lines_fed) *lines_fed = F.lines_total;
     if (crc32) *crc32 = crc;
     if (n_text) *n_text = total;
+    return FQTK_OK;
+}
+
+// The 32 KiB of text in front of the next chunk of a stream (zeros where the member has less): what a decoder that takes over needs.
+int fqtk_demuxer_stream_window(fqtk_demuxer *d, uint32_t input, uint8_t *window) {
+    if (!d || !window || input >= d->C.n_inputs) return set_error(FQTK_EINVAL, "NULL argument / input out of range");
+    DX_TRY(hipSetDevice(d->device));
+    int rc;
+    if ((rc = fed_init(d)) != FQTK_OK) return rc;
+    FedInput &F = d->fed[input];
+    if (!F.d_last_window) { std::memset(window, 0, fqtk::inflate::kStreamWindow); return FQTK_OK; }
+    DX_TRY(hipMemcpyAsync(window, F.d_last_window, fqtk::inflate::kStreamWindow, hipMemcpyDeviceToHost, F.stream));
+    DX_TRY(hipStreamSynchronize(F.stream));
+    return FQTK_OK;
+}
+
+// Text of a stream that was decoded elsewhere (the host's sequential decoder, where the chunks could not be cut or did not decode) joins the
+// input's fed text; `window_after` (32 KiB, NULL with `last`) is the text in front of whatever follows.
+int fqtk_demuxer_stream_commit_text(fqtk_demuxer *d, uint32_t input, const uint8_t *text, uint64_t n, const uint8_t *window_after, int last, uint64_t *lines_fed,
+                                    uint32_t *crc32) {
+    if (!d || input >= d->C.n_inputs || (n && !text)) return set_error(FQTK_EINVAL, "NULL argument / input out of range");
+    if (n >= (1ull << 32)) return set_error(FQTK_EINVAL, "4 GiB of text or more in one call");
+    DX_TRY(hipSetDevice(d->device));
+    int rc;
+    if ((rc = fed_init(d)) != FQTK_OK) return rc;
+    FedInput &F = d->fed[input];
+    std::unique_lock<std::mutex> lk(F.mu);
+    if (F.ended) return set_error(FQTK_EINVAL, "the input has ended already");
+    const uint64_t text_bytes = n + (last ? 1 : 0);
+    if ((rc = fed_make_room(d, F, lk, text_bytes)) != FQTK_OK) return rc;
+    const uint64_t at = F.tail;
+    const uint32_t n_pieces = (uint32_t)((n + 65535u) / 65536u);
+    if ((rc = F.h_members.ensure(n_pieces + 1)) != FQTK_OK) return rc;
+    if ((rc = F.d_members.ensure(n_pieces + 1)) != FQTK_OK) return rc;
+    if ((rc = F.d_status.ensure(n_pieces + 1)) != FQTK_OK) return rc;
+    if ((rc = F.d_lines.ensure(n_pieces + 1)) != FQTK_OK) return rc;
+    if ((rc = F.h_lines.ensure(n_pieces + 1)) != FQTK_OK) return rc;
+    if ((rc = F.d_crc.ensure(n_pieces + 1)) != FQTK_OK) return rc;
+    if ((rc = F.h_crc.ensure(n_pieces + 1)) != FQTK_OK) return rc;
+    if (!F.d_last_window) {
+        DX_TRY(hipMalloc(reinterpret_cast<void **>(&F.d_last_window), fqtk::inflate::kStreamWindow));
+        DX_TRY(hipMemsetAsync(F.d_last_window, 0, fqtk::inflate::kStreamWindow, F.stream));
+    }
+    for (uint32_t p = 0; p < n_pieces; ++p) {
+        fqtk_inflate_member m;
+        std::memset(&m, 0, sizeof m);
+        m.out_off = at + (uint64_t)p * 65536u;
+        m.isize = (uint32_t)std::min<uint64_t>(65536u, n - (uint64_t)p * 65536u);
+        F.h_members.p[p] = m;
+    }
+    uint8_t *const arena = F.arena[F.cur].p;
+    F.tail = at + text_bytes;
+    lk.unlock();
+    if (n) DX_TRY(hipMemcpyAsync(arena + at, text, (size_t)n, hipMemcpyHostToDevice, F.stream));
+    if (window_after) DX_TRY(hipMemcpyAsync(F.d_last_window, window_after, fqtk::inflate::kStreamWindow, hipMemcpyHostToDevice, F.stream));
+    if (n_pieces) {
+        DX_TRY(hipMemcpyAsync(F.d_members.p, F.h_members.p, (size_t)n_pieces * sizeof(fqtk_inflate_member), hipMemcpyHostToDevice, F.stream));
+        DX_TRY(hipMemsetAsync(F.d_status.p, 0, (size_t)n_pieces * sizeof(uint32_t), F.stream));
+        DX_TRY(fqtk::inflate::pieces_check_launch(F.stream, F.d_members.p, n_pieces, arena, F.d_status.p, F.d_lines.p, F.d_crc.p, d->d_crc_pow));
+        DX_TRY(hipMemcpyAsync(F.h_lines.p, F.d_lines.p, (size_t)n_pieces * sizeof(uint32_t), hipMemcpyDeviceToHost, F.stream));
+        DX_TRY(hipMemcpyAsync(F.h_crc.p, F.d_crc.p, (size_t)n_pieces * sizeof(uint32_t), hipMemcpyDeviceToHost, F.stream));
+    }
+    if (last) {
+        hipLaunchKernelGGL(k_put_newline, dim3(1), dim3(1), 0, F.stream, arena + at + n);
+        DX_TRY(hipGetLastError());
+    }
+    DX_TRY(hipStreamSynchronize(F.stream));
+    uint32_t crc = 0;
+    {
+        static const uint32_t pow_full = fqtk::bgzf::crc_x_pow(8u * 65536u);
+        for (uint32_t p = 0; p < n_pieces; ++p) {
+            const uint32_t len_p = F.h_members.p[p].isize;
+            crc = fqtk::bgzf::crc_gf_mul(crc, len_p == 65536u ? pow_full : fqtk::bgzf::crc_x_pow(8u * len_p)) ^ F.h_crc.p[p];
+        }
+    }
+    lk.lock();
+    for (uint32_t p = 0; p < n_pieces; ++p) {
+        F.members.push_back(FedMember{F.h_members.p[p].out_off, F.h_members.p[p].isize, F.h_lines.p[p], F.lines_total, F.text_total});
+        F.lines_total += F.h_lines.p[p];
+        F.text_total += F.h_members.p[p].isize;
+    }
+    F.members_fed += n_pieces;
+    if (last) {
+        if (F.members.empty()) F.members.push_back(FedMember{at + n, 0, 0, F.lines_total, F.text_total});
+        F.text_total += 1;
+        F.members.back().isize += 1;
+        F.members.back().lines += 1;
+        F.lines_total += 1;
+        F.ended = true;
+    }
+    if (lines_fed) *lines_fed = F.lines_total;
+    if (crc32) *crc32 = crc;
     return FQTK_OK;
 }
 

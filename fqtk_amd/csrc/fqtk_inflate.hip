@@ -145,13 +145,15 @@ constexpr size_t kCheckLds = (264 + 256 * kSliceStride) * sizeof(uint32_t);
 
 // ---- a serial gzip stream in chunks (stream mode of inflate_member; host/parallel_gunzip.hpp is the CPU form of the same plan) -----
 // One wavefront per chunk: from the chunk's block boundary to the first block boundary at or behind the next chunk's, 16-bit symbols out.
-__global__ __launch_bounds__(64) void stream_kernel(const uint8_t *in, uint64_t in_len, const StreamChunk *chunks, uint32_t n, uint16_t *sym, StreamChunkEnd *ends) {
+// (plan != nullptr: the chunks were cut on the device, stream_plan_kernel says how many there are)
+__global__ __launch_bounds__(64) void stream_kernel(const uint8_t *in, uint64_t in_len, const StreamChunk *chunks, uint32_t n, const StreamPlan *plan, uint16_t *sym,
+                                                    StreamChunkEnd *ends) {
     __shared__ Shared S;
     __shared__ StreamEnd end;
     const uint32_t j = blockIdx.x;
-    if (j >= n) return;
+    if (j >= (plan ? plan->n_chunks : n)) return;
     const StreamChunk c = chunks[j];
-    if (threadIdx.x == 0) { end.n_sym = 0; end.end_bit = 0; end.final_block = 0; }
+    if (threadIdx.x == 0) { end.n_sym = 0; end.end_bit = 0; end.final_block = 0; end.n_blocks = 0; end.flags = 0; }
     __syncthreads();
     const uint64_t base_word = c.start_bit >> 5;
     uint32_t st = kErrTruncated;
@@ -178,28 +180,125 @@ __global__ __launch_bounds__(64) void stream_kernel(const uint8_t *in, uint64_t 
         e.status = st;
         e.final_block = end.final_block;
         e.n_sym = end.n_sym;
+        e.n_blocks = end.n_blocks;
+        e.flags = end.flags;
+        e.pad = 0;
         e.end_bit = base_word * 32u + end.end_bit;
         ends[j] = e;
     }
 }
 
+// Where the chunks of a stretch can start: slot k >= 1 is the first block start in bits [k * chunk_bits, (k + 1) * chunk_bits) of the stretch
+// (~0: none), found by a wavefront of its own (find_block_start: a lane per bit position); slot 0 is the bit the caller knows.
+__global__ __launch_bounds__(64) void stream_search_kernel(const uint8_t *in, uint64_t in_len, uint64_t first_bit, uint32_t chunk_bits, uint32_t n_slots, uint32_t low_literals_only, uint64_t *starts) {
+    __shared__ Shared S;
+    const uint32_t k = blockIdx.x;
+    if (k >= n_slots) return;
+    if (k == 0u) { if (threadIdx.x == 0) starts[0] = first_bit; return; }
+    const uint64_t from = (uint64_t)k * chunk_bits, limit = from + chunk_bits;
+    uint64_t found = ~0ull;
+    const uint64_t total_bits = in_len * 8u;
+    if (from > first_bit && from < total_bits && total_bits < 0xFFFFFF00ull) {
+        MemberArgs a;
+        a.in_words = reinterpret_cast<const uint32_t *>(in);
+        a.first_bit = 0;
+        a.payload_bits = (uint32_t)total_bits;
+        a.readable_words = (uint32_t)(in_len / 4u);
+        a.tail_bytes = (uint32_t)(in_len & 3u);
+        a.out = nullptr; a.isize = 0; a.out_sym = nullptr; a.stop_bit = 0;
+        DeviceWave w;
+        const uint32_t r = find_block_start(w, S, a, (uint32_t)from, (uint32_t)(limit < total_bits ? limit : total_bits), low_literals_only != 0u);
+        if (r != 0xFFFFFFFFu) found = r;
+    }
+    if (threadIdx.x == 0) starts[k] = found;
+}
+
+// The chunks of the stretch from the slots' finds (one wavefront, 64 slots per lane): chunk j runs from the j-th start found to the
+// (j + 1)-th; the last start found only ends the chunk before it (it opens the next stretch) unless the stretch reaches the end of the
+// stream (to_end), when the last chunk runs to the final block.  Nothing found: one chunk that runs as far as the bytes go.  Every
+// chunk gets room for sym_per_byte symbols per compressed byte + slack, as far as the symbol buffer reaches (a chunk left with less
+// reports FQTK_INFLATE_ERR_OUTPUT at the block where it runs out).
+__global__ __launch_bounds__(64) void stream_plan_kernel(const uint64_t *starts, uint32_t n_slots, uint64_t in_len, uint32_t to_end, uint32_t sym_per_byte, uint32_t slack,
+                                                         uint64_t sym_cap, StreamChunk *chunks, StreamPlan *plan) {
+    __shared__ uint64_t found[kMaxStreamSlots];
+    const uint32_t lane = threadIdx.x, per = (n_slots + 63u) / 64u;
+    const uint32_t lo = lane * per, hi = lo + per < n_slots ? lo + per : n_slots;
+    uint32_t cnt = 0;
+    for (uint32_t k = lo; k < hi; ++k) cnt += starts[k] != ~0ull ? 1u : 0u;
+    uint32_t incl = cnt;
+    for (int d = 1; d < 64; d <<= 1) { const uint32_t o = __shfl_up(incl, d); if ((int)lane >= d) incl += o; }
+    const uint32_t n_found = __shfl(incl, 63);
+    uint32_t at = incl - cnt;
+    for (uint32_t k = lo; k < hi; ++k) { const uint64_t v = starts[k]; if (v != ~0ull) found[at++] = v; }
+    __syncthreads();
+    const uint32_t n_chunks = to_end || n_found == 1u ? n_found : n_found - 1u;
+    // room: a prefix sum of the chunks' wishes, cut off at the buffer's end
+    const uint32_t cper = (n_chunks + 63u) / 64u;
+    const uint32_t clo = lane * cper, chi = clo + cper < n_chunks ? clo + cper : n_chunks;
+    auto wish = [&](uint32_t j) -> uint64_t {
+        const uint64_t stop = j + 1u < n_found ? found[j + 1u] : in_len * 8u;
+        const uint64_t want = ((stop - found[j]) / 8u + 1u) * sym_per_byte + slack;
+        return ((want < 0xFFFFFF00ull ? want : 0xFFFFFF00ull) + 7u) & ~7ull;
+    };
+    uint64_t mine = 0;
+    for (uint32_t j = clo; j < chi; ++j) mine += wish(j);
+    uint64_t pre = mine;
+    for (int d = 1; d < 64; d <<= 1) { const uint64_t o = __shfl_up(pre, d); if ((int)lane >= d) pre += o; }
+    uint64_t off = pre - mine;
+    for (uint32_t j = clo; j < chi; ++j) {
+        const uint64_t want = wish(j);
+        const uint64_t room = off < sym_cap ? sym_cap - off : 0ull;
+        StreamChunk c;
+        c.start_bit = found[j];
+        c.stop_bit = j + 1u < n_found ? found[j + 1u] : ~0ull;
+        c.sym_off = off < sym_cap ? off : sym_cap;
+        c.cap = (uint32_t)(want < room ? want : room);
+        c.pad = 0;
+        chunks[j] = c;
+        off += want;
+    }
+    if (lane == 63u) { plan->n_chunks = n_chunks; plan->n_found = n_found; plan->sym_wanted = pre; }
+}
+
 __device__ inline uint32_t resolve_symbol(uint32_t s, const uint8_t *window) { return s < 256u ? s : (uint32_t)window[(s - 256u) & (kWindow - 1u)]; }
 
-// The windows down the chain: windows[k] = the 32 KiB of text in front of chunk k (windows[0] is given; windows[n] = behind the last chunk).  One workgroup,
-// chunk after chunk: 32 symbols per lane and chunk.
-__global__ __launch_bounds__(1024) void window_chain_kernel(const StreamChunk *chunks, const StreamChunkEnd *ends, uint32_t n, const uint16_t *sym, uint8_t *windows) {
-    for (uint32_t k = 0; k < n; ++k) {
-        const uint8_t *w0 = windows + (size_t)k * kWindow;
-        uint8_t *w1 = windows + (size_t)(k + 1u) * kWindow;
-        const uint16_t *s = sym + chunks[k].sym_off;
-        const uint32_t ns = ends[k].n_sym;
-        for (uint32_t j = threadIdx.x; j < kWindow; j += 1024u) {
-            const int64_t p = (int64_t)ns - (int64_t)kWindow + (int64_t)j;   // position in chunk k's text of byte j of the next window
-            w1[j] = p >= 0 ? (uint8_t)resolve_symbol(s[p], w0) : w0[kWindow + p];
-        }
-        __threadfence_block();
-        __syncthreads();
+// The windows down the chain: windows[k] = the 32 KiB of text in front of chunk k (windows[0] is given; windows[n] = behind the last chunk).
+// What chunk k does to its window is a MAP of 32 Ki entries -- entry j of the next window is a byte, or entry j' of this one (the chunk's last
+// 32 Ki symbols; where the chunk is shorter, the tail of its own window shifted down) -- and maps compose: (g after f)[j] = g[j] if that is a
+// byte, else f[g[j] - 256].  So the chain is a prefix "sum" over the chunks: log2(n) rounds in which EVERY chunk composes its map with the
+// map of the chunk 2^r before it (Hillis-Steele, two buffers in turn), all 32 Ki entries of all chunks side by side; afterwards map k holds
+// chunk 0 .. k in one and is applied to windows[0].  (The first version walked the chunks one after another in one workgroup: 25 us a
+// chunk, 27 ms of a 1023-chunk stretch's 55.)
+__global__ __launch_bounds__(256) void window_map_init_kernel(const StreamChunk *chunks, const StreamChunkEnd *ends, const uint16_t *sym, uint16_t *maps) {
+    const uint32_t k = blockIdx.y;
+    const uint16_t *s = sym + chunks[k].sym_off;
+    const uint32_t ns = ends[k].n_sym;
+    uint16_t *m = maps + (size_t)k * kWindow;
+    for (uint32_t j = blockIdx.x * 256u + threadIdx.x; j < kWindow; j += gridDim.x * 256u) {
+        const int64_t p = (int64_t)ns - (int64_t)kWindow + (int64_t)j;   // position in chunk k's text of byte j of the next window
+        m[j] = p >= 0 ? s[p] : (uint16_t)(256 + (int64_t)kWindow + p);
     }
+}
+__global__ __launch_bounds__(256) void window_map_round_kernel(const uint16_t *src, uint16_t *dst, uint32_t d) {
+    const uint32_t k = blockIdx.y;
+    const uint16_t *g = src + (size_t)k * kWindow;
+    uint16_t *o = dst + (size_t)k * kWindow;
+    if (k < d) {
+        for (uint32_t j = blockIdx.x * 256u + threadIdx.x; j < kWindow; j += gridDim.x * 256u) o[j] = g[j];
+        return;
+    }
+    const uint16_t *f = src + (size_t)(k - d) * kWindow;
+    for (uint32_t j = blockIdx.x * 256u + threadIdx.x; j < kWindow; j += gridDim.x * 256u) {
+        const uint32_t v = g[j];
+        o[j] = v < 256u ? (uint16_t)v : f[v - 256u];
+    }
+}
+__global__ __launch_bounds__(256) void window_map_apply_kernel(const uint16_t *maps, uint8_t *windows) {
+    const uint32_t k = blockIdx.y;
+    const uint16_t *m = maps + (size_t)k * kWindow;
+    const uint8_t *w0 = windows;
+    uint8_t *w1 = windows + (size_t)(k + 1u) * kWindow;
+    for (uint32_t j = blockIdx.x * 256u + threadIdx.x; j < kWindow; j += gridDim.x * 256u) w1[j] = (uint8_t)resolve_symbol(m[j], w0);
 }
 
 // Every chunk's symbols to bytes, side by side: text[out_off[k] + i].
@@ -216,13 +315,29 @@ __global__ __launch_bounds__(256) void stream_resolve_kernel(const StreamChunk *
 
 hipError_t stream_decode_launch(hipStream_t stream, const uint8_t *in, uint64_t in_len, const StreamChunk *chunks, uint32_t n, uint16_t *sym, StreamChunkEnd *ends) {
     if (n == 0) return hipSuccess;
-    hipLaunchKernelGGL(stream_kernel, dim3(n), dim3(64), 0, stream, in, in_len, chunks, n, sym, ends);
+    hipLaunchKernelGGL(stream_kernel, dim3(n), dim3(64), 0, stream, in, in_len, chunks, n, (const StreamPlan *)nullptr, sym, ends);
+    return hipGetLastError();
+}
+hipError_t stream_scan_launch(hipStream_t stream, const uint8_t *in, uint64_t in_len, uint64_t first_bit, uint32_t chunk_bytes, uint32_t n_slots, bool to_end,
+                              bool low_literals_only, uint32_t sym_per_byte, uint32_t slack, uint64_t sym_cap, uint64_t *starts, StreamChunk *chunks, StreamPlan *plan, uint16_t *sym,
+                              StreamChunkEnd *ends) {
+    if (n_slots == 0 || n_slots > kMaxStreamSlots) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(stream_search_kernel, dim3(n_slots), dim3(64), 0, stream, in, in_len, first_bit, chunk_bytes * 8u, n_slots, low_literals_only ? 1u : 0u, starts);
+    hipLaunchKernelGGL(stream_plan_kernel, dim3(1), dim3(64), 0, stream, (const uint64_t *)starts, n_slots, in_len, to_end ? 1u : 0u, sym_per_byte, slack, sym_cap, chunks, plan);
+    hipLaunchKernelGGL(stream_kernel, dim3(n_slots), dim3(64), 0, stream, in, in_len, (const StreamChunk *)chunks, n_slots, (const StreamPlan *)plan, sym, ends);
     return hipGetLastError();
 }
 hipError_t stream_resolve_launch(hipStream_t stream, const StreamChunk *chunks, const StreamChunkEnd *ends, uint32_t n, const uint64_t *out_off, const uint16_t *sym,
-                                 uint8_t *windows, uint8_t *text) {
+                                 uint8_t *windows, uint16_t *maps, uint8_t *text) {
     if (n == 0) return hipSuccess;
-    hipLaunchKernelGGL(window_chain_kernel, dim3(1), dim3(1024), 0, stream, chunks, ends, n, sym, windows);
+    uint16_t *buf[2] = {maps, maps + (size_t)n * kWindow};
+    hipLaunchKernelGGL(window_map_init_kernel, dim3(16, n), dim3(256), 0, stream, chunks, ends, sym, buf[0]);
+    int cur = 0;
+    for (uint32_t d = 1; d < n; d <<= 1) {
+        hipLaunchKernelGGL(window_map_round_kernel, dim3(16, n), dim3(256), 0, stream, (const uint16_t *)buf[cur], buf[cur ^ 1], d);
+        cur ^= 1;
+    }
+    hipLaunchKernelGGL(window_map_apply_kernel, dim3(16, n), dim3(256), 0, stream, (const uint16_t *)buf[cur], windows);
     hipLaunchKernelGGL(stream_resolve_kernel, dim3(64, n), dim3(256), 0, stream, chunks, ends, out_off, sym, (const uint8_t *)windows, text);
     return hipGetLastError();
 }

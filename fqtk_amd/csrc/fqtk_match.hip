@@ -1193,7 +1193,7 @@ extern "C" {
 
 const char *fqtk_last_error(void) { return g_last_error.c_str(); }
 
-int fqtk_abi_version(void) { return 4; }
+int fqtk_abi_version(void) { return 5; }
 
 int fqtk_device_count(int *n_devices) {
     if (!n_devices) return fail(FQTK_EINVAL, "n_devices is NULL");

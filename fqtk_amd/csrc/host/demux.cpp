@@ -46,6 +46,7 @@
 #include "header.hpp"
 #include "metrics.hpp"
 #include "read_structure.hpp"
+#include "region_inflate.hpp"
 #include "samples.hpp"
 
 using namespace fqtk_host;
@@ -841,60 +842,36 @@ bool gpu_output_supported(const Plan &plan, std::string *why) {
                     fcv.notify_all();
                 };
                 if (is_serial_gz[i]) {
-                    // ---- a serial gzip file: stretches of chunks between block starts this thread (and its helpers) finds, decoded
-                    // by a wavefront each without their windows, accepted where the chain of block boundaries proves the parse
-                    // (host/parallel_gunzip.hpp's rule), resolved on the device.  A stretch takes the device about as long as ONE
-                    // chunk takes a wavefront (~0.1 s), so stretches are long -- 448 chunks of 512 KiB: 1.4 GB of text per 0.1 s -- but no
-                    // longer: the device's buffers follow the stretch (symbols 16 bytes per compressed byte, two arenas of text), and
-                    // allocating device memory costs ~0.1 s per GB (FQTK_TIMING=1 prints every stretch's clock).
-                    static const size_t kChunkBytes = [] { const char *v = std::getenv("FQTK_GZ_DEVICE_CHUNK_KB"); return (size_t)(v && *v ? std::atol(v) : 512) << 10; }();
-                    // (a stretch stays below 448 MiB: the device counts a chunk's bits from the stretch's first byte in 32 bits)
-                    static const size_t kMaxChunks = [] { const char *v = std::getenv("FQTK_GZ_DEVICE_CHUNKS"); return std::min<size_t>((size_t)(v && *v ? std::atol(v) : 448), (448u << 20) / kChunkBytes); }();
-                    const unsigned searchers = std::max(1u, std::min(8u, (unsigned)(usable_cpus() / std::max<size_t>(1, n_serial))));
-                    const uint64_t file_bits = (uint64_t)bf.size * 8u;
-                    static const size_t kChunkBytes0 = kChunkBytes;
-                    // slot k = the first block start at or behind byte k * chunk_bytes of the file (~0: none before the next slot);
-                    // the searchers fill the slots in order, a bounded distance ahead of what has been decoded
-                    const size_t n_slots = bf.size > 16384 ? (bf.size - 16384) / kChunkBytes0 + 1 : 1;   // (a header needs room: the file's end belongs to the last chunk)
-                    std::vector<uint64_t> slot_start(n_slots, ~0ull);
-                    std::vector<char> slot_done(n_slots, 0);
-                    std::mutex smu;
-                    std::condition_variable scv;
-                    size_t search_from = 0, search_next = 1;
-                    bool search_stop = false;
-                    slot_done[0] = 1;
-                    std::vector<std::thread> search_threads;
-                    for (unsigned q = 0; q < searchers; ++q)
-                        search_threads.emplace_back([&] {
-                            SpecInflate finder;
-                            finder.attach(bf.map, bf.size);
-                            for (;;) {
-                                size_t slot;
-                                {
-                                    std::unique_lock<std::mutex> lk(smu);
-                                    scv.wait(lk, [&] { return search_stop || (search_next < n_slots && search_next < search_from + 4096); });
-                                    if (search_stop || search_next >= n_slots) return;
-                                    slot = search_next++;
-                                }
-                                const uint64_t nominal = (uint64_t)slot * kChunkBytes0 * 8u;
-                                const uint64_t r = finder.find_block_start(nominal, std::min<uint64_t>(nominal + (uint64_t)kChunkBytes0 * 8u, file_bits));
-                                {
-                                    std::lock_guard<std::mutex> lk(smu);
-                                    slot_start[slot] = r;
-                                    slot_done[slot] = 1;
-                                }
-                                scv.notify_all();
-                            }
-                        });
-                    struct StopSearch {
-                        std::mutex &m; std::condition_variable &cv; bool &stop; std::vector<std::thread> &th;
-                        ~StopSearch() { { std::lock_guard<std::mutex> lk(m); stop = true; } cv.notify_all(); for (auto &t : th) t.join(); }
-                    } stop_search{smu, scv, search_stop, search_threads};
-                    const uint64_t gz_high_water = 4ull * chunk * (uint64_t)env_num("FQTK_GZ_DEVICE_AHEAD", 40);   // (a stretch is ~10-30 chunks of templates: one may decode while one is consumed)
-                    size_t n_stretches = 0, n_chunks_total = 0, n_refused = 0;
+                    // ---- a serial gzip file: stretches of chunks cut ON THE DEVICE at block starts it finds itself (a lane per bit position),
+                    // decoded by a wavefront each without their windows, accepted where the chain of block boundaries proves the parse
+                    // (host/parallel_gunzip.hpp's rule), resolved on the device.  A stretch takes the device about as long as its longest chunk
+                    // takes ONE wavefront, so chunks are small (64 KiB of file: ~10 ms) and many (1024 a stretch: a quarter of the chip's
+                    // wavefronts per input).  Whatever a stretch cannot be cut or decoded like this -- no block start in it, a block that
+                    // expands beyond any room, a decoder in doubt -- is decoded by this thread's sequential decoder (region_inflate.hpp) and
+                    // handed to the device as text: a VALID file is never refused (demux.rs:844-849 reads any), and a stream is called
+                    // corrupt only when the sequential decoder says so too.  (FQTK_TIMING=1 prints every stretch's clock.)
+                    static const size_t kChunkBytes = (size_t)std::max<long>(4, std::min<long>(4096, env_num("FQTK_GZ_DEVICE_CHUNK_KB", 64))) << 10;
+                    static const size_t kSlots = (size_t)std::max<long>(1, std::min<long>(4096, std::min<long>(env_num("FQTK_GZ_DEVICE_CHUNKS", 1024), (long)((440u << 20) / kChunkBytes))));
+                    static const long kForceFallback = env_num("FQTK_GZ_FORCE_FALLBACK", 0);     // (tests: every k-th stretch goes to the host's decoder)
+                    static const uint64_t kSymBudget = (uint64_t)std::max<long>(1, env_num("FQTK_GZ_DEVICE_SYM_MB", 1024)) << 20;   // symbols a stretch may ask room for
+                    const uint64_t gz_high_water = 4ull * chunk * (uint64_t)env_num("FQTK_GZ_DEVICE_AHEAD", 12);   // (a stretch is ~5 chunks of templates: one may decode while one is consumed)
+                    uint32_t sym_per_byte = (uint32_t)std::max<long>(1, std::min<long>(2048, env_num("FQTK_GZ_DEVICE_SYMS", 8)));   // room per compressed byte; grows when a chunk runs out
+                    size_t n_stretches = 0, n_chunks_total = 0, n_refused = 0, n_fallbacks = 0;
+                    uint64_t fallback_text = 0;
                     size_t pos = 0;                 // byte of the current member's header
-                    const size_t chunk_bytes = kChunkBytes;
-                    size_t stretch_chunks = std::min<size_t>(448, kMaxChunks);
+                    size_t stretch_at = 0;          // where in `pin` the stretch in hand begins
+                    bool text_only = false;         // every chunk accepted so far decoded 7-bit text only: the search may insist on that (include/fqtk_demux.h)
+                    // The NEXT stretch's bytes are copied into a second page-locked buffer while the device decodes this one: a stretch whose
+                    // chunks all count ends in its last chunk, so the next one lies in the file from there on (a stretch cut short by a false
+                    // start is copied when it is known, as the first one is).
+                    void *pin2 = nullptr;
+                    size_t pf0 = 0, pf_len = 0;       // the file bytes pin2 holds
+                    std::thread prefetcher;
+                    struct JoinPrefetch { std::thread &t; void *&p; ~JoinPrefetch() { if (t.joinable()) t.join(); if (p) fqtk_pinned_free(p); } } join_prefetch{prefetcher, pin2};
+                    std::unique_ptr<RegionInflate> seq;
+                    std::vector<uint8_t> seq_text;
+                    std::vector<uint8_t> win_before(32768), win_after(32768);
+                    std::vector<fqtk_stream_end> ends(kSlots);
                     bool all_done = false;
                     while (!all_done) {
                         const size_t hl = gzip_header_len(bf.map + pos, bf.size - pos);
@@ -903,112 +880,23 @@ bool gpu_output_supported(const Plan &plan, std::string *why) {
                         bool member_start = true;
                         uint32_t crc_acc = 0;
                         uint64_t size_acc = 0;
-                        for (bool member_done = false; !member_done;) {
-                            {
-                                std::unique_lock<std::mutex> lk(fmu);
-                                fcv.wait(lk, [&] { return feed_stop || lines_fed[i] < lines_taken + gz_high_water; });
-                                if (feed_stop) { if (pin) fqtk_pinned_free(pin); return; }
-                            }
-                            const uint64_t t0 = tick();
-                            // where the chunks of this stretch start: the verified bit, then what the searchers -- who run ahead of the
-                            // decoding, at every chunk_bytes of the file, whatever is verified -- have found behind it
-                            std::vector<uint64_t> found(stretch_chunks + 1, ~0ull);
-                            found[0] = verified;
-                            {
-                                const size_t first_slot = (size_t)(verified / 8u / chunk_bytes) + 1;   // searches start at slot * chunk_bytes
-                                std::unique_lock<std::mutex> lk(smu);
-                                search_from = first_slot;   // (slots before it are of no use any more: the searchers may move on)
-                                scv.notify_all();
-                                for (size_t k = 1; k <= stretch_chunks; ++k) {
-                                    const size_t slot = first_slot + k - 1;
-                                    if (slot >= n_slots) break;
-                                    scv.wait(lk, [&] { return slot_done[slot] != 0; });
-                                    found[k] = slot_start[slot];
-                                }
-                            }
-                            std::vector<uint64_t> starts;   // strictly increasing
-                            starts.push_back(verified);
-                            bool to_end = false;
-                            {
-                                const size_t first_slot = (size_t)(verified / 8u / chunk_bytes) + 1;
-                                for (size_t k = 1; k <= stretch_chunks; ++k) {
-                                    if (first_slot + k - 1 >= n_slots) { to_end = true; break; }
-                                    if (found[k] != ~0ull && found[k] > starts.back()) starts.push_back(found[k]);
-                                }
-                            }
-                            // the last start found only ends the chunk before it (it opens the next stretch), unless the file ends here
-                            const size_t n_chunks = to_end ? starts.size() : std::max<size_t>(1, starts.size() - 1);
-                            const uint64_t stop_last = to_end || starts.size() == 1 ? ~0ull : starts.back();
-                            const size_t b0 = (size_t)(verified / 8u) & ~(size_t)3;
-                            const size_t b1 = stop_last == ~0ull ? bf.size : std::min<size_t>(bf.size, (size_t)(stop_last / 8u) + 131072);
-                            const size_t bytes = b1 - b0;
-                            if (bytes >= (500u << 20)) { fail("Unexpected error parsing FASTQs: no DEFLATE block start found in 500 MB of " + bf.path + ": rerun with --host-inflate"); return; }
-                            if (bytes + 64 > pin_cap) {   // (once: sized for the longest stretch this file can have)
-                                if (pin) fqtk_pinned_free(pin);
-                                pin_cap = std::max<size_t>(bytes + 64, std::min<size_t>(bf.size, kMaxChunks * chunk_bytes + (1u << 20)) + 65536);
-                                if (fqtk_pinned_alloc(pin_cap, &pin) != FQTK_OK) { pin = nullptr; fail(std::string("cannot allocate page-locked memory: ") + fqtk_last_error()); return; }
-                            }
-                            const uint64_t tc0 = tick();
-                            std::memcpy(pin, bf.map + b0, bytes);
-                            const uint64_t tc1 = tick();
-                            std::vector<fqtk_stream_chunk> cs(n_chunks);
-                            for (size_t k = 0; k < n_chunks; ++k) {
-                                cs[k].start_bit = starts[k] - (uint64_t)b0 * 8u;
-                                cs[k].stop_bit = k + 1 < n_chunks ? starts[k + 1] - (uint64_t)b0 * 8u : (stop_last == ~0ull ? ~0ull : stop_last - (uint64_t)b0 * 8u);
-                            }
-                            g_times.reader_parse += tick() - t0;
-                            const uint64_t t1 = tick();
-                            std::vector<fqtk_stream_end> ends(n_chunks);
-                            if (fqtk_demuxer_stream_decode(demuxers[0], (uint32_t)i, static_cast<const uint8_t *>(pin), bytes, cs.data(), (uint32_t)n_chunks, ends.data()) != FQTK_OK) {
-                                fail(std::string("GPU record pipeline: ") + fqtk_last_error());
-                                return;
-                            }
-                            const uint64_t t_dec = tick();
-                            // a chunk counts if it decoded and the chunk before it, itself accepted, ended on exactly the bit it started at
-                            size_t n_accept = 0;
-                            for (size_t k = 0; k < n_chunks; ++k) {
-                                if (ends[k].status != 0 || ends[k].end_bit > (uint64_t)bytes * 8u) break;
-                                if (k && ends[k - 1].end_bit != cs[k].start_bit) break;
-                                n_accept = k + 1;
-                                if (ends[k].final_block) break;
-                            }
-                            if (n_accept == 0) {
-                                static const char *const kWhat[12] = {"", "reserved block type", "stored block length check", "bad code lengths", "over-subscribed or incomplete Huffman code",
-                                                                      "invalid code", "distance too far back", "a block that expands more than a chunk has room for", "stream runs past the end of the file",
-                                                                      "", "", ""};
-                                fail("Unexpected error parsing FASTQs: corrupt gzip stream: " + std::string(kWhat[std::min<uint32_t>(ends[0].status, 11)]) + " in " + bf.path);
-                                return;
-                            }
-                            const fqtk_stream_end &le = ends[n_accept - 1];
-                            verified = (uint64_t)b0 * 8u + le.end_bit;
-                            bool last = false;
-                            size_t trailer = 0;
-                            if (le.final_block) {
-                                trailer = (size_t)((verified + 7u) / 8u);
-                                if (trailer + 8 > bf.size) { fail("Unexpected error parsing FASTQs: corrupt gzip stream: truncated trailer in " + bf.path); return; }
-                                const size_t nx = trailer + 8;
-                                last = !(nx + 10 <= bf.size && bf.map[nx] == 0x1f && bf.map[nx + 1] == 0x8b);   // (trailing garbage is ignored, as zlib's gzread does)
-                            }
-                            uint64_t fed = 0, n_text = 0;
-                            uint32_t crc = 0;
-                            if (fqtk_demuxer_stream_commit(demuxers[0], (uint32_t)i, (uint32_t)n_accept, member_start ? 1 : 0, last ? 1 : 0, &fed, &crc, &n_text) != FQTK_OK) {
-                                fail(std::string("GPU record pipeline: ") + fqtk_last_error());
-                                return;
-                            }
-                            g_times.reader_push += tick() - t1;
-                            if (g_timing) info("(timing) gzip input %zu: stretch of %zu chunks (%zu MB): search + plan %.0f ms, copy %.0f ms, decode %.0f ms, commit %.0f ms, %zu accepted.", i, n_chunks,
-                                               bytes >> 20, (tc0 - t0) / 1e6, (tc1 - tc0) / 1e6, (t_dec - t1) / 1e6, (tick() - t_dec) / 1e6, n_accept);
+                        // what a stretch came to, whoever decoded it
+                        auto stretch_done = [&](uint64_t end_bit, bool final_block, uint64_t fed, uint32_t crc, uint64_t n_text, bool *member_done) -> bool {
+                            verified = end_bit;
                             member_start = false;
                             crc_acc = (uint32_t)crc32_combine(crc_acc, crc, (z_off_t)n_text);
                             size_acc += n_text;
-                            if (le.final_block) {
+                            bool last = false;
+                            if (final_block) {
+                                const size_t trailer = (size_t)((verified + 7u) / 8u);
                                 uint32_t want_crc, want_size;
                                 std::memcpy(&want_crc, bf.map + trailer, 4);
                                 std::memcpy(&want_size, bf.map + trailer + 4, 4);
-                                if (want_crc != crc_acc) { fail("Unexpected error parsing FASTQs: corrupt gzip stream: CRC mismatch in " + bf.path); return; }
-                                if (want_size != (uint32_t)size_acc) { fail("Unexpected error parsing FASTQs: corrupt gzip stream: length mismatch in " + bf.path); return; }
-                                member_done = true;
+                                if (want_crc != crc_acc) { fail("Unexpected error parsing FASTQs: corrupt gzip stream: CRC mismatch in " + bf.path); return false; }
+                                if (want_size != (uint32_t)size_acc) { fail("Unexpected error parsing FASTQs: corrupt gzip stream: length mismatch in " + bf.path); return false; }
+                                *member_done = true;
                                 pos = trailer + 8;
+                                last = !(pos + 10 <= bf.size && bf.map[pos] == 0x1f && bf.map[pos + 1] == 0x8b);
                                 if (last) { all_done = true; bf.pos = bf.size; }
                             }
                             {
@@ -1017,13 +905,160 @@ bool gpu_output_supported(const Plan &plan, std::string *why) {
                                 if (last) fed_done[i] = 1;
                             }
                             fcv.notify_all();
-                            if (n_accept == n_chunks) stretch_chunks = std::min(kMaxChunks, stretch_chunks * 2);
+                            return true;
+                        };
+                        // whether the member ends with the block that ends at end_bit, and the file with the member (trailing garbage is ignored, as zlib's gzread does)
+                        auto ends_file = [&](uint64_t end_bit, bool final_block, bool *ok) -> bool {
+                            *ok = true;
+                            if (!final_block) return false;
+                            const size_t trailer = (size_t)((end_bit + 7u) / 8u);
+                            if (trailer + 8 > bf.size) { fail("Unexpected error parsing FASTQs: corrupt gzip stream: truncated trailer in " + bf.path); *ok = false; return false; }
+                            const size_t nx = trailer + 8;
+                            return !(nx + 10 <= bf.size && bf.map[nx] == 0x1f && bf.map[nx + 1] == 0x8b);
+                        };
+                        // the host's sequential decoder takes the stream from `verified` to the first block boundary at or behind until_bit
+                        auto host_stretch = [&](uint64_t until_bit, const char *why, bool *member_done) -> bool {
+                            const uint64_t t0 = tick();
+                            if (!seq) { seq = std::make_unique<RegionInflate>(); seq->attach(bf.map, bf.size); }
+                            if (!member_start && fqtk_demuxer_stream_window(demuxers[0], (uint32_t)i, win_before.data()) != FQTK_OK) {
+                                fail(std::string("GPU record pipeline: ") + fqtk_last_error());
+                                return false;
+                            }
+                            seq_text.clear();
+                            uint64_t end_bit = 0;
+                            bool final_block = false;
+                            std::string e;
+                            if (!seq->run(verified, member_start ? nullptr : win_before.data(), until_bit, 256u << 20, &seq_text, &end_bit, &final_block, win_after.data(), &e)) {
+                                fail("Unexpected error parsing FASTQs: " + e + " in " + bf.path);
+                                return false;
+                            }
+                            bool ok = true;
+                            const bool last = ends_file(end_bit, final_block, &ok);
+                            if (!ok) return false;
+                            uint64_t fed = 0;
+                            uint32_t crc = 0;
+                            if (fqtk_demuxer_stream_commit_text(demuxers[0], (uint32_t)i, seq_text.data(), seq_text.size(), final_block ? nullptr : win_after.data(), last ? 1 : 0, &fed, &crc) != FQTK_OK) {
+                                fail(std::string("GPU record pipeline: ") + fqtk_last_error());
+                                return false;
+                            }
+                            ++n_fallbacks;
+                            fallback_text += seq_text.size();
+                            if (g_timing) info("(timing) gzip input %zu: %zu KB of file decoded by the host's sequential decoder (%s): %zu MB of text in %.0f ms.", i,
+                                               (size_t)((end_bit - verified) >> 13), why, seq_text.size() >> 20, (tick() - t0) / 1e6);
+                            return stretch_done(end_bit, final_block, fed, crc, seq_text.size(), member_done);
+                        };
+                        for (bool member_done = false; !member_done;) {
+                            {
+                                std::unique_lock<std::mutex> lk(fmu);
+                                fcv.wait(lk, [&] { return feed_stop || lines_fed[i] < lines_taken + gz_high_water; });
+                                if (feed_stop) { if (pin) fqtk_pinned_free(pin); return; }
+                            }
+                            const uint64_t t0 = tick();
+                            // the stretch: from the dword of the verified bit, as many chunks as the symbol budget allows, and a block's worth behind them
+                            const size_t b0 = (size_t)(verified / 8u) & ~(size_t)3;
+                            size_t n_slots = std::max<size_t>(1, std::min<size_t>(kSlots, (size_t)(kSymBudget / ((uint64_t)kChunkBytes * sym_per_byte))));
+                            const size_t b1 = std::min<size_t>(bf.size, b0 + n_slots * kChunkBytes + 131072);
+                            const bool to_end = b1 == bf.size;
+                            const size_t bytes = b1 - b0;
+                            if (to_end) n_slots = std::max<size_t>(1, std::min(n_slots, (bytes + kChunkBytes - 1) / kChunkBytes));
+                            if (bytes + 64 > pin_cap) {   // (once)
+                                if (pin) fqtk_pinned_free(pin);
+                                pin_cap = std::min<size_t>(bf.size, (kSlots + 5) * kChunkBytes + 131072 + 4) + 65536;
+                                if (fqtk_pinned_alloc(pin_cap, &pin) != FQTK_OK) { pin = nullptr; fail(std::string("cannot allocate page-locked memory: ") + fqtk_last_error()); return; }
+                            }
+                            if (kForceFallback > 0 && (n_stretches + n_fallbacks) % (size_t)kForceFallback == (size_t)kForceFallback - 1) {
+                                if (!host_stretch(std::min<uint64_t>(verified + (uint64_t)kChunkBytes * 8u * 3u, (uint64_t)bf.size * 8u), "forced", &member_done)) return;
+                                continue;
+                            }
+                            if (prefetcher.joinable()) prefetcher.join();
+                            if (pin2 && pf_len && b0 >= pf0 && b1 <= pf0 + pf_len) {   // the copy made meanwhile holds this stretch
+                                std::swap(pin, pin2);
+                                stretch_at = b0 - pf0;
+                            } else {
+                                std::memcpy(pin, bf.map + b0, bytes);
+                                stretch_at = 0;
+                            }
+                            pf_len = 0;
+                            if (!to_end) {
+                                const size_t from = b1 > 131072 + 4 * kChunkBytes ? (b1 - 131072 - 4 * kChunkBytes) & ~(size_t)3 : 0;
+                                const size_t len = std::min<size_t>(bf.size - from, pin_cap - 64);
+                                pf0 = from;
+                                prefetcher = std::thread([&, from, len] {
+                                    if (!pin2 && fqtk_pinned_alloc(pin_cap, &pin2) != FQTK_OK) { pin2 = nullptr; return; }
+                                    std::memcpy(pin2, bf.map + from, len);
+                                    pf_len = len;
+                                });
+                            }
+                            const uint8_t *const stretch = static_cast<const uint8_t *>(pin) + stretch_at;
+                            const uint64_t tc1 = tick();
+                            g_times.reader_parse += tc1 - t0;
+                            uint32_t n_chunks = 0;
+                            if (fqtk_demuxer_stream_scan(demuxers[0], (uint32_t)i, stretch, bytes, verified - (uint64_t)b0 * 8u, (uint32_t)kChunkBytes, (uint32_t)n_slots,
+                                                         to_end ? 1 : 0, sym_per_byte, text_only ? FQTK_STREAM_SCAN_TEXT : 0u, ends.data(), &n_chunks) != FQTK_OK) {
+                                fail(std::string("GPU record pipeline: ") + fqtk_last_error());
+                                return;
+                            }
+                            const uint64_t t_dec = tick();
+                            // a chunk counts if the chunk before it, itself accepted, ended on exactly the bit it started at -- and as far as it
+                            // decoded: one that ran out of room or of bytes behind a block boundary ends the stretch at that boundary
+                            size_t n_accept = 0;
+                            bool out_of_room = false;
+                            for (size_t k = 0; k < n_chunks; ++k) {
+                                const fqtk_stream_end &e = ends[k];
+                                if (k && ends[k - 1].end_bit != e.start_bit) break;
+                                if (e.status == 0 && e.end_bit <= (uint64_t)bytes * 8u) {
+                                    n_accept = k + 1;
+                                    if (e.final_block) break;
+                                    continue;
+                                }
+                                if (e.status == 7) out_of_room = true;
+                                if ((e.status == 7 || e.status == 8) && e.n_blocks > 0 && e.end_bit <= (uint64_t)bytes * 8u) n_accept = k + 1;
+                                break;
+                            }
+                            const bool more_room = out_of_room && sym_per_byte < 2048;
+                            if (more_room) sym_per_byte = std::min<uint32_t>(2048, sym_per_byte * 4);   // (the rest of the file is given more room)
+                            if (n_accept == 0) {
+                                // chunk 0 starts at a verified boundary and did not get through one block.  Out of room: again with more, while there
+                                // is more to give; anything else (no block start in the whole stretch and the block longer than it, a parse error):
+                                // the sequential decoder takes this stretch -- if the stream is corrupt, it is the one to say so.
+                                if (ends[0].status == 7 && more_room && kChunkBytes * (uint64_t)sym_per_byte <= kSymBudget) { ++n_refused; continue; }
+                                static const char *const kWhat[12] = {"", "reserved block type", "stored block length check", "bad code lengths", "over-subscribed or incomplete Huffman code",
+                                                                      "invalid code", "distance too far back", "a block that expands beyond the room for symbols", "a block longer than a stretch",
+                                                                      "", "", ""};
+                                const uint64_t until = n_chunks > 1 ? (uint64_t)b0 * 8u + ends[1].start_bit : (uint64_t)b1 * 8u;
+                                if (!host_stretch(until, kWhat[std::min<uint32_t>(ends[0].status, 11)], &member_done)) return;
+                                continue;
+                            }
+                            text_only = !env_on("FQTK_GZ_NO_TEXT_FILTER");
+                            for (size_t k = 0; k < n_accept; ++k) if (ends[k].flags & FQTK_STREAM_END_HIGH_LITERALS) text_only = false;
+                            const fqtk_stream_end &le = ends[n_accept - 1];
+                            const uint64_t end_bit = (uint64_t)b0 * 8u + le.end_bit;
+                            const bool final_block = le.status == 0 && le.final_block;
+                            bool ok = true;
+                            const bool last = ends_file(end_bit, final_block, &ok);
+                            if (!ok) return;
+                            uint64_t fed = 0, n_text = 0;
+                            uint32_t crc = 0;
+                            if (fqtk_demuxer_stream_commit(demuxers[0], (uint32_t)i, (uint32_t)n_accept, member_start ? 1 : 0, last ? 1 : 0, &fed, &crc, &n_text) != FQTK_OK) {
+                                fail(std::string("GPU record pipeline: ") + fqtk_last_error());
+                                return;
+                            }
+                            g_times.reader_push += tick() - tc1;
+                            if (g_timing) info("(timing) gzip input %zu: stretch of %u chunks (%zu MB -> %zu MB): copy %.1f ms, search + decode %.1f ms, commit %.1f ms, %zu accepted%s.", i, n_chunks,
+                                               bytes >> 20, (size_t)(n_text >> 20), (tc1 - t0) / 1e6, (t_dec - tc1) / 1e6, (tick() - t_dec) / 1e6, n_accept, out_of_room ? " (a chunk ran out of room)" : "");
+                            if (g_timing && n_accept < n_chunks && !final_block && n_stretches < 4) {
+                                const fqtk_stream_end &a = ends[n_accept - 1], &b = ends[n_accept];
+                                info("(timing) gzip input %zu: the chain ends behind chunk %zu (status %u, %u blocks, ended at bit %llu); chunk %zu starts at bit %llu (status %u, %u blocks).", i,
+                                     n_accept - 1, a.status, a.n_blocks, (unsigned long long)a.end_bit, n_accept, (unsigned long long)b.start_bit, b.status, b.n_blocks);
+                            }
                             ++n_stretches; n_chunks_total += n_chunks; n_refused += n_chunks - n_accept;
+                            if (!stretch_done(end_bit, final_block, fed, crc, n_text, &member_done)) return;
                             if (b0 > (64u << 20)) madvise(const_cast<uint8_t *>(bf.map), (b0 - (64u << 20)) & ~(size_t)4095, MADV_DONTNEED);
                         }
                     }
                     if (pin) fqtk_pinned_free(pin);
-                    if (g_timing) info("(timing) gzip input %zu: %zu chunks in %zu stretches decoded on the device, %zu refused (their stretch was cut there).", i, n_chunks_total, n_stretches, n_refused);
+                    if (g_timing) info("(timing) gzip input %zu: %zu chunks in %zu stretches decoded on the device, %zu not accepted (their stretch was cut there); %zu stretches (%zu MB of text) by the host's sequential decoder.",
+                                       i, n_chunks_total, n_stretches, n_refused, n_fallbacks, (size_t)(fallback_text >> 20));
                     return;
                 }
                 for (;;) {

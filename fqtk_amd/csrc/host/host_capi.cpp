@@ -24,6 +24,8 @@
 #include "../bgzf_deflate.hpp"
 #include "../bgzf_inflate.hpp"
 #include "wave_emu.hpp"
+#include "region_inflate.hpp"
+#include "parallel_gunzip.hpp"
 #include "../record_format.hpp"
 
 using namespace fqtk_host;
@@ -428,7 +430,7 @@ int fqtk_host_bgzf_inflate_emulated(const uint8_t *payload, uint32_t payload_len
 
 // A piece of a serial DEFLATE stream decoded by the device decoder's stream mode (inflate_member<W, true>) on the wave emulator:
 // from bit `start_bit` of data (a block boundary) to the first block boundary at or behind stop_bit, into 16-bit symbols
-// (< 256: a byte; 256 + j: byte j of the 32 KiB in front of the piece).  Returns the status; res = {symbols, end bit, final block}.
+// (< 256: a byte; 256 + j: byte j of the 32 KiB in front of the piece).  Returns the status; res = {symbols, end bit, final block, whole blocks decoded} (the first three as of the last block boundary reached).
 int fqtk_host_inflate_stream_emulated(const uint8_t *data, uint32_t len, uint32_t start_bit, uint32_t stop_bit, uint16_t *sym, uint32_t cap, uint32_t *res) {
     using namespace fqtk::inflate;
     const uint32_t words = len / 4u;
@@ -448,7 +450,7 @@ int fqtk_host_inflate_stream_emulated(const uint8_t *data, uint32_t len, uint32_
     a.out_sym = sym;
     a.stop_bit = stop_bit - (start_bit & ~31u);
     uint32_t status[64];
-    StreamEnd end = {0, 0, 0};
+    StreamEnd end = {0, 0, 0, 0, 0};
     fqtk_host::WaveEmu wave;
     wave.run([&](fqtk_host::WaveEmu &w) { status[w.lane()] = inflate_member<fqtk_host::WaveEmu, true>(w, S, a, &end); });
     for (int l = 1; l < 64; ++l)
@@ -456,7 +458,59 @@ int fqtk_host_inflate_stream_emulated(const uint8_t *data, uint32_t len, uint32_
     res[0] = end.n_sym;
     res[1] = end.end_bit + (start_bit & ~31u);
     res[2] = end.final_block;
+    res[3] = end.n_blocks;
     return (int)status[0];
+}
+
+// The block-start search of the serial-gzip path (csrc/bgzf_inflate.hpp: find_block_start, a lane per bit position) on the wave
+// emulator: first bit in [from_bit, limit_bit) of data where a non-final dynamic-Huffman block can start; ~0 if none.
+uint64_t fqtk_host_find_block_start_emulated(const uint8_t *data, uint32_t len, uint32_t from_bit, uint32_t limit_bit, int low_literals_only) {
+    using namespace fqtk::inflate;
+    const uint32_t words = len / 4u;
+    std::vector<uint32_t> buf(words + 2u, 0xA5A5A5A5u);
+    std::memcpy(buf.data(), data, len);
+    std::vector<uint8_t> mem(sizeof(Shared), 0xC3);
+    Shared &S = *reinterpret_cast<Shared *>(mem.data());
+    MemberArgs a;
+    std::memset(&a, 0, sizeof a);
+    a.in_words = buf.data();
+    a.first_bit = 0;
+    a.payload_bits = 8u * len;
+    a.readable_words = words;
+    a.tail_bytes = len & 3u;
+    uint32_t found[64];
+    fqtk_host::WaveEmu wave;
+    wave.run([&](fqtk_host::WaveEmu &w) { found[w.lane()] = find_block_start(w, S, a, from_bit, limit_bit, low_literals_only != 0); });
+    for (int l = 1; l < 64; ++l)
+        if (found[l] != found[0]) return ~0ull - 1u;   // the result is wave-uniform by construction
+    return found[0] == 0xFFFFFFFFu ? ~0ull : (uint64_t)found[0];
+}
+// ... and the host's own (parallel_gunzip.hpp: SpecInflate::find_block_start), which the decoder threads of --host-inflate use.
+uint64_t fqtk_host_find_block_start(const uint8_t *data, size_t len, uint64_t from_bit, uint64_t limit_bit) {
+    SpecInflate f;
+    f.attach(data, len);
+    return f.find_block_start(from_bit, limit_bit);
+}
+
+// A stretch of a serial DEFLATE stream decoded by the host's sequential decoder from a known block boundary (region_inflate.hpp: what
+// `fqtk demux` falls back to where the device cannot cut or decode a stretch).  data[0..n): a raw DEFLATE stream or a whole file;
+// window: 32 KiB or NULL (the stream starts at from_bit).  Returns 0, -1 (corrupt: err says how) or -2 (out too small);
+// res = {bytes of text, end bit, final block}.
+int fqtk_host_region_inflate(const uint8_t *data, size_t n, uint64_t from_bit, const uint8_t *window, uint64_t until_bit, uint64_t max_text, uint8_t *out, size_t cap,
+                             uint64_t *res, uint8_t *window_after, char *err, size_t errcap) {
+    RegionInflate z;
+    z.attach(data, n);
+    std::vector<uint8_t> text;
+    uint64_t end_bit = 0;
+    bool final_block = false;
+    std::string e;
+    if (!z.run(from_bit, window, until_bit, (size_t)max_text, &text, &end_bit, &final_block, window_after, &e)) { put(e, err, errcap); return -1; }
+    res[0] = text.size();
+    res[1] = end_bit;
+    res[2] = final_block ? 1 : 0;
+    if (text.size() > cap) return -2;
+    std::memcpy(out, text.data(), text.size());
+    return 0;
 }
 
 // One output record the way the GPU record pipeline states it (csrc/record_format.hpp: header plan + pieces), built

@@ -122,6 +122,32 @@ class Demuxer:
         _check(self._lib.fqtk_demuxer_stream_decode(self._h, input_index, buf.ctypes.data, len(data), arr, len(chunks), ends))
         return [(int(e.status), int(e.final_block), int(e.n_bytes), int(e.end_bit)) for e in ends]
 
+    def stream_scan(self, input_index: int, data: bytes, first_bit: int, chunk_bytes: int, n_slots: int, to_end: bool, sym_per_byte: int = 8, text_only: bool = False):
+        """The chunks of a stretch of a serial DEFLATE stream cut ON THE DEVICE at block starts it finds, and decoded.
+        Returns [(status, final, n_bytes, end_bit, start_bit, n_blocks, flags)]."""
+        ends = (_lib.fqtk_stream_end * n_slots)()
+        n = C.c_uint32(0)
+        buf = np.frombuffer(data + b"\0" * 8, dtype=np.uint8)
+        _check(self._lib.fqtk_demuxer_stream_scan(self._h, input_index, buf.ctypes.data, len(data), first_bit, chunk_bytes, n_slots, 1 if to_end else 0,
+                                                  sym_per_byte, 1 if text_only else 0, ends, C.byref(n)))
+        return [(int(e.status), int(e.final_block), int(e.n_bytes), int(e.end_bit), int(e.start_bit), int(e.n_blocks), int(e.flags)) for e in ends[:n.value]]
+
+    def stream_window(self, input_index: int) -> bytes:
+        """The 32 KiB of text in front of the next chunk of the stream."""
+        buf = np.zeros(32768, dtype=np.uint8)
+        _check(self._lib.fqtk_demuxer_stream_window(self._h, input_index, buf.ctypes.data))
+        return buf.tobytes()
+
+    def stream_commit_text(self, input_index: int, text: bytes, window_after, last: bool):
+        """Text of the stream decoded elsewhere joins the fed text.  (lines fed so far, CRC-32 of the text)"""
+        fed, crc = C.c_uint64(0), C.c_uint32(0)
+        buf = np.frombuffer(text + b"\0" * 8, dtype=np.uint8)
+        wa = None if window_after is None else np.frombuffer(window_after, dtype=np.uint8)
+        assert wa is None or wa.size == 32768
+        _check(self._lib.fqtk_demuxer_stream_commit_text(self._h, input_index, buf.ctypes.data, len(text), None if wa is None else wa.ctypes.data,
+                                                         1 if last else 0, C.byref(fed), C.byref(crc)))
+        return int(fed.value), int(crc.value)
+
     def stream_commit(self, input_index: int, n_accept: int, member_start: bool, last: bool):
         """(lines fed so far, CRC-32 of the committed text, its length)"""
         fed, crc, n = C.c_uint64(0), C.c_uint32(0), C.c_uint64(0)

@@ -148,11 +148,32 @@ int fqtk_demuxer_fed_tail(fqtk_demuxer *d, uint32_t input, uint64_t pos, uint8_t
  * member, nothing lies in front of it; last: as in fqtk_demuxer_feed).  Returns the lines fed so far, and CRC-32 and length
  * of the committed text for the caller to fold into the member's (zlib's crc32_combine) and compare with the trailer. */
 typedef struct fqtk_stream_chunk { uint64_t start_bit, stop_bit; } fqtk_stream_chunk;
-typedef struct fqtk_stream_end { uint32_t status, final_block; uint64_t n_bytes, end_bit; } fqtk_stream_end;
+/* How a chunk ended.  n_blocks whole DEFLATE blocks were decoded; n_bytes / end_bit / final_block describe the LAST block boundary it
+ * reached -- also when status != 0: a chunk that ran out of room for symbols (FQTK_INFLATE_ERR_OUTPUT) or of bytes
+ * (FQTK_INFLATE_ERR_TRUNCATED) behind a boundary decoded everything up to it, and a caller may accept it as ending there. */
+typedef struct fqtk_stream_end { uint32_t status, final_block; uint64_t n_bytes, end_bit, start_bit; uint32_t n_blocks, flags; } fqtk_stream_end;
+#define FQTK_STREAM_END_HIGH_LITERALS 1u /* fqtk_stream_end.flags: a block of the chunk gave a code to a literal >= 128 (7-bit text never does) */
+#define FQTK_STREAM_SCAN_TEXT 1u         /* fqtk_demuxer_stream_scan flags: headers that give a code to a literal >= 128 are not taken for block
+                                            starts -- for a stream whose chunks so far never set FQTK_STREAM_END_HIGH_LITERALS; an accidental
+                                            header (about one per 100 MB of FASTQ.gz otherwise, and it costs the rest of its stretch) nearly always does */
 int fqtk_demuxer_stream_decode(fqtk_demuxer *d, uint32_t input, const uint8_t *bytes, uint64_t len, const fqtk_stream_chunk *chunks, uint32_t n,
                                fqtk_stream_end *ends);
+/* The same with the chunks CUT ON THE DEVICE: slot k >= 1 of n_slots (<= 4096) is the first place in bytes [k, k + 1) x chunk_bytes of the
+ * stretch where a block can start (one lane per bit position, csrc/bgzf_inflate.hpp find_block_start), slot 0 is first_bit -- a block
+ * boundary the caller knows; chunk j runs from the j-th start found to the (j + 1)-th (the last one found only ends the chunk before it,
+ * unless to_end != 0: the stretch reaches the end of the member, and the last chunk runs to its final block).  Room for symbols:
+ * sym_per_byte per compressed byte of a chunk + 64 Ki.  ends (n_slots of them) receives *n_chunks entries, start_bit included. */
+int fqtk_demuxer_stream_scan(fqtk_demuxer *d, uint32_t input, const uint8_t *bytes, uint64_t len, uint64_t first_bit, uint32_t chunk_bytes, uint32_t n_slots,
+                             int to_end, uint32_t sym_per_byte, uint32_t flags, fqtk_stream_end *ends, uint32_t *n_chunks);
 int fqtk_demuxer_stream_commit(fqtk_demuxer *d, uint32_t input, uint32_t n_accept, int member_start, int last, uint64_t *lines_fed, uint32_t *crc32,
                                uint64_t *n_text);
+/* A stretch the device could not take (no block start to cut at, a block larger than any room, a decoder in doubt) is decoded by the
+ * caller's own sequential decoder: fqtk_demuxer_stream_window hands out the 32 KiB of text in front of the next chunk (zeros where the
+ * member has less), fqtk_demuxer_stream_commit_text takes the text back (window_after: the 32 KiB in front of what follows; NULL when a
+ * member ends) -- CRC-32 and lines as fqtk_demuxer_stream_commit. */
+int fqtk_demuxer_stream_window(fqtk_demuxer *d, uint32_t input, uint8_t *window /* 32768 */);
+int fqtk_demuxer_stream_commit_text(fqtk_demuxer *d, uint32_t input, const uint8_t *text, uint64_t n, const uint8_t *window_after, int last,
+                                    uint64_t *lines_fed, uint32_t *crc32);
 
 /* Device seconds spent inflating (all inputs). */
 int fqtk_demuxer_inflate_seconds(fqtk_demuxer *d, double *seconds);

@@ -52,7 +52,7 @@ def test_match_struct_is_4_bytes_little_endian_layout():
 
 def test_abi_version_and_device_count_do_not_need_a_gpu():
     lib = _lib.load()
-    assert lib.fqtk_abi_version() == 4
+    assert lib.fqtk_abi_version() == 5
     n = C.c_int(-1)
     assert lib.fqtk_device_count(C.byref(n)) == _lib.FQTK_OK
     assert n.value >= 0

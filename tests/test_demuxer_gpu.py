@@ -455,3 +455,108 @@ def test_a_serial_deflate_stream_decoded_in_chunks_on_the_device():
     assert n1 + n2 == len(text) and fed == text.count(b"\n") + 1
     assert crc2 == zlib.crc32(b"".join(parts[half:]))
     assert d.fed_tail(0, 0, cap=len(text) + 16) == text + b"\n"
+
+
+def _accept(ends, n_bits):
+    """The prefix of chunks whose block boundaries chain (what `fqtk demux` accepts of a stretch): (n_accept, end bit, final)."""
+    n = 0
+    for k, e in enumerate(ends):
+        if k and ends[k - 1][3] != e[4]:
+            break
+        if e[0] == 0 and e[3] <= n_bits:
+            n = k + 1
+            if e[1]:
+                break
+            continue
+        if e[0] in (7, 8) and e[5] > 0:
+            n = k + 1
+        break
+    assert n > 0, ends[:2]
+    return n, ends[n - 1][3], bool(ends[n - 1][1] and ends[n - 1][0] == 0)
+
+
+@pytest.mark.parametrize("level,chunk_bytes", [(6, 4096), (1, 8192), (9, 4096)])
+def test_a_serial_stream_cut_on_the_device_at_block_starts_it_finds(level, chunk_bytes):
+    """fqtk_demuxer_stream_scan: the device looks for the block starts itself (a lane per bit position), cuts the stretch into
+    chunks there, decodes them; the chain of block boundaries says which count.  Stretch after stretch from the bit the last one
+    was verified up to -- one of them decoded ELSEWHERE (zlib here, the sequential decoder in `fqtk demux`) and handed over as text,
+    with the window the device gives out and the window it is given back -- the text, line counts and CRC-32 are zlib's."""
+    rng = np.random.default_rng(300 + level)
+    templates = make_templates(rng, 24000, BARCODES8, ["+T"], header_kind=0)
+    text = texts_of(templates, 0, len(templates), 1)[0]
+    comp = zlib.compress(text, level)[2:-4]          # ONE raw DEFLATE stream, blocks wherever zlib put them
+    m = BarcodeMatcher(BARCODES8, 1, 2, device=0)
+    d = Demuxer(m, ["8B+T"], "T", max_chunk_templates=4096)
+    n_bits = len(comp) * 8
+    n_slots = 32
+    at, done, crc, stretches, elsewhere, chunks_seen = 0, 0, 0, 0, 0, 0
+    while True:
+        b0 = (at // 8) & ~3
+        piece = comp[b0:b0 + n_slots * chunk_bytes + 4096]
+        to_end = b0 + len(piece) == len(comp)
+        if stretches == 2:   # this stretch goes to a decoder of the caller's: window out, text + window back
+            window = d.stream_window(0)
+            assert window[32768 - min(done, 32768):] == text[max(0, done - 32768):done]
+            ends = d.stream_scan(0, piece, at - b0 * 8, chunk_bytes, n_slots, to_end)     # (only to learn where blocks end; not committed)
+            n_acc, end_bit, final = _accept(ends, len(piece) * 8)
+            take = sum(e[2] for e in ends[:n_acc])
+            got = text[done:done + take]
+            last = final
+            fed, c = d.stream_commit_text(0, got, None if final else text[max(0, done + take - 32768):done + take].rjust(32768, b"\0"), last)
+            assert c == zlib.crc32(got)
+            elsewhere += 1
+        else:
+            ends = d.stream_scan(0, piece, at - b0 * 8, chunk_bytes, n_slots, to_end)
+            assert ends[0][4] == at - b0 * 8 and ends[0][0] == 0, ends[0]
+            chunks_seen += len(ends)
+            n_acc, end_bit, final = _accept(ends, len(piece) * 8)
+            last = final
+            fed, c, take = d.stream_commit(0, n_acc, member_start=(at == 0), last=last)
+            assert take == sum(e[2] for e in ends[:n_acc])
+            assert c == zlib.crc32(text[done:done + take]), (stretches, n_acc)
+        crc = zlib.crc32(text[done:done + take], crc)
+        done += take
+        at = b0 * 8 + end_bit
+        stretches += 1
+        assert fed == text[:done].count(b"\n") + (1 if last else 0)
+        if last:
+            break
+        assert stretches < 500
+    assert done == len(text) and crc == zlib.crc32(text) and stretches >= 3 and elsewhere == 1
+    assert chunks_seen > stretches - elsewhere          # (block starts were found: stretches of several chunks)
+    assert d.fed_tail(0, 0, cap=len(text) + 16) == text + b"\n"
+
+
+def test_chunks_that_run_out_of_room_end_at_a_block_boundary_and_the_stream_goes_on_from_there():
+    """a chunk that expands beyond its room for symbols must not end the run.  Text that deflates 200 : 1 with
+    room for 2 symbols per compressed byte: a chunk reports FQTK_INFLATE_ERR_OUTPUT together with the last block boundary it
+    reached, the caller takes it up to there and goes on -- with more room -- from that bit."""
+    rng = np.random.default_rng(77)
+    rec = b"@same:1:1 1:N:0:0\nACGTACGTAAAACCCCGGGGTTTT\n+\nFFFFFFFFFFFFFFFFFFFFFFFF\n"
+    text = rec * 60_000                                # 4 MB that deflate to ~ 20 KB
+    c = zlib.compressobj(6, zlib.DEFLATED, -15)
+    comp = b""
+    for o in range(0, len(text), 1 << 18):            # (a sync flush every 256 KiB: blocks the decoder can stop at)
+        comp += c.compress(text[o:o + (1 << 18)]) + c.flush(zlib.Z_SYNC_FLUSH)
+    comp += c.flush()
+    assert len(text) // len(comp) > 100
+    m = BarcodeMatcher(BARCODES8, 1, 2, device=0)
+    d = Demuxer(m, ["8B+T"], "T", max_chunk_templates=4096)
+    at, done, spb, seen_overflow = 0, 0, 2, 0
+    for _ in range(200):
+        b0 = (at // 8) & ~3
+        piece = comp[b0:]
+        ends = d.stream_scan(0, piece, at - b0 * 8, 4096, 4, True, sym_per_byte=spb)
+        if ends[0][0] == 7 and ends[0][5] == 0:       # not even one block fits: more room, again
+            spb *= 4
+            seen_overflow += 1
+            continue
+        seen_overflow += any(e[0] == 7 for e in ends)
+        n_acc, end_bit, final = _accept(ends, len(piece) * 8)
+        fed, crc, take = d.stream_commit(0, n_acc, member_start=(at == 0), last=final)
+        assert crc == zlib.crc32(text[done:done + take])
+        done += take
+        at = b0 * 8 + end_bit
+        if final:
+            break
+    assert done == len(text) and seen_overflow >= 1
