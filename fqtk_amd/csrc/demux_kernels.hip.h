@@ -65,6 +65,26 @@ struct ChunkStatus {
     uint32_t end_off[FQTK_DEMUX_MAX_INPUTS];   // offset in the input's text of the byte behind the chunk's last record
     uint32_t n_blocks, n_skipped, max_bc_len, pad;
 };
+// What fqtk_demuxer_record_text needs of a chunk that failed, saved in the slot's own memory while the chunk's text is still there (fed
+// chunks are windows of an input's arena, which may be reused or freed before the host gets to word the error: ADVICE r04): header and
+// number of bases, in every input, of the template err_key names and of the one the matcher's length error names.
+constexpr uint32_t kErrTextHead = 256;
+struct ErrorText { uint32_t t, head_len, seq_len, valid; uint8_t head[kErrTextHead]; };   // [2][n_inputs]: candidate 0 = err_key's template, 1 = matcher_err's
+__global__ void k_save_error_text(TextSet T, uint32_t n_inputs, uint32_t n, const ChunkStatus *st, ErrorText *out) {
+    const uint32_t c = blockIdx.x / n_inputs, i = blockIdx.x % n_inputs;
+    const unsigned long long key = c == 0u ? st->err_key : st->matcher_err;
+    ErrorText &e = out[c * n_inputs + i];
+    if (key == kNoError) { if (threadIdx.x == 0) e.valid = 0; return; }
+    const uint32_t t = c == 0u ? (uint32_t)(key >> 24) : (uint32_t)key;
+    if (t >= n) { if (threadIdx.x == 0) e.valid = 0; return; }
+    const RecView r = T.rec[i][t];
+    const uint32_t hl = r.head_len < kErrTextHead ? r.head_len : kErrTextHead;
+    // (a chunk whose text does not hold its lines has no record views worth reading: offsets are checked against the text)
+    const bool ok = (uint64_t)r.head_off + hl <= (uint64_t)T.len[i];
+    for (uint32_t k = threadIdx.x; k < hl; k += blockDim.x) e.head[k] = ok ? T.text[i][r.head_off + k] : (uint8_t)'?';
+    if (threadIdx.x == 0) { e.t = t; e.head_len = hl; e.seq_len = r.seq_len; e.valid = 1; }
+}
+
 // Order of the errors of ONE template = the order the reference meets them in: its per-input iterators are zipped
 // (demux.rs:285-343, 946-951), so input 0's record is parsed AND length-checked before input 1's is looked at -- for the
 // record-level stages (0 = malformed record, 1 = too few bases) the input ranks above the stage (class 0); the

@@ -79,6 +79,7 @@ struct Slot {
     DevBuf<unsigned long long> pos, file_off;
     ChunkStatus *d_status = nullptr;
     uint32_t *d_next_block = nullptr;      // the compressor's work counter
+    ErrorText *d_err_text = nullptr;       // fed chunks: the offending records' headers, saved while the window's arena holds them
     ChunkStatus *h_status = nullptr;       // page-locked
     PinBuf<unsigned long long> h_file_off;
     PinBuf<uint8_t> h_packed;
@@ -179,6 +180,8 @@ namespace {
 int alloc_slot_fixed(fqtk_demuxer *d, Slot &s) {
     DX_TRY(hipMalloc(reinterpret_cast<void **>(&s.d_status), sizeof(ChunkStatus)));
     DX_TRY(hipMalloc(reinterpret_cast<void **>(&s.d_next_block), sizeof(uint32_t)));
+    DX_TRY(hipMalloc(reinterpret_cast<void **>(&s.d_err_text), 2 * FQTK_DEMUX_MAX_INPUTS * sizeof(ErrorText)));
+    DX_TRY(hipMemset(s.d_err_text, 0, 2 * FQTK_DEMUX_MAX_INPUTS * sizeof(ErrorText)));
     DX_TRY(hipHostMalloc(reinterpret_cast<void **>(&s.h_status), sizeof(ChunkStatus), hipHostMallocDefault));
     for (hipEvent_t *e : {&s.ev_h2d0, &s.ev_h2d1, &s.ev_fmt, &s.ev_status, &s.ev_d2h0, &s.ev_d2h1}) DX_TRY(hipEventCreate(e));
     for (int k = 0; k < kStageEvents; ++k) DX_TRY(hipEventCreate(&s.ev[k]));
@@ -392,6 +395,7 @@ void fqtk_demuxer_destroy(fqtk_demuxer *d) {
         s.pos.release(); s.file_off.release(); s.h_file_off.release(); s.h_packed.release();
         if (s.d_status) (void)hipFree(s.d_status);
         if (s.d_next_block) (void)hipFree(s.d_next_block);
+        if (s.d_err_text) (void)hipFree(s.d_err_text);
         if (s.h_status) (void)hipHostFree(s.h_status);
         for (hipEvent_t e : {s.ev_h2d0, s.ev_h2d1, s.ev_fmt, s.ev_status, s.ev_d2h0, s.ev_d2h1}) if (e) (void)hipEventDestroy(e);
         for (hipEvent_t e : s.ev) if (e) (void)hipEventDestroy(e);
@@ -541,6 +545,10 @@ static int submit_common(fqtk_demuxer *d, int slot, const uint8_t *const *text, 
                        s.rec_off.p, s.tile_tot.p, s.fc.p, d->d_persist, s.slabs.p, s.d_status);
     DX_TRY(hipGetLastError());
     DX_TRY(hipEventRecord(s.ev[4], A));
+    if (T.window) {   // (before ev_fmt: the arena the window lies in may be reused once that event is reached)
+        hipLaunchKernelGGL(k_save_error_text, dim3(2 * C.n_inputs), dim3(64), 0, A, T, C.n_inputs, n, (const ChunkStatus *)s.d_status, s.d_err_text);
+        DX_TRY(hipGetLastError());
+    }
     DX_TRY(hipEventRecord(s.ev_fmt, A));
     DX_TRY(hipEventRecord(d->ev_last_fmt, A));
     // stream B
@@ -1077,6 +1085,7 @@ int fqtk_demuxer_fed_tail(fqtk_demuxer *d, uint32_t input, uint64_t pos, uint8_t
     DX_TRY(hipSetDevice(d->device));
     FedInput &F = d->fed[input];
     std::lock_guard<std::mutex> lk(F.mu);
+    if (pos == ~0ull) pos = F.text_total > cap ? F.text_total - cap : 0;   // (the last `cap` bytes of the text)
     *n_bytes = pos < F.text_total ? F.text_total - pos : 0;
     if (*n_bytes == 0) return FQTK_OK;
     if (F.members.empty() || pos < F.members.front().pos) return set_error(FQTK_EINVAL, "that text has been consumed");
@@ -1117,6 +1126,19 @@ int fqtk_demuxer_record_text(fqtk_demuxer *d, int slot, uint32_t input, uint32_t
     Slot &s = d->slots[slot];
     if (t >= s.n) return set_error(FQTK_EINVAL, "template index out of range");
     DX_TRY(hipSetDevice(d->device));
+    if (s.fed) {   // the window's arena may be gone: what the chunk saved of its offending records
+        ErrorText e[2];
+        for (int c = 0; c < 2; ++c) DX_TRY(hipMemcpy(&e[c], s.d_err_text + (size_t)c * d->C.n_inputs + input, sizeof(ErrorText), hipMemcpyDeviceToHost));
+        for (int c = 0; c < 2; ++c)
+            if (e[c].valid && e[c].t == t) {
+                const size_t n = std::min<size_t>(e[c].head_len, cap - 1);
+                std::memcpy(header, e[c].head, n);
+                header[n] = 0;
+                if (n_bases) *n_bases = e[c].seq_len;
+                return FQTK_OK;
+            }
+        return set_error(FQTK_EINVAL, "a chunk of fed text keeps the text of the templates its errors name only");
+    }
     RecView r;
     DX_TRY(hipMemcpy(&r, s.rec[input].p + t, sizeof r, hipMemcpyDeviceToHost));
     const size_t n = std::min<size_t>(r.head_len, cap - 1);

@@ -23,30 +23,48 @@ struct BgzfFile {
     int fd = -1;
     const uint8_t *map = nullptr;
     size_t size = 0, pos = 0;
+    BgzfFile() = default;
+    BgzfFile(const BgzfFile &) = delete;
+    BgzfFile &operator=(const BgzfFile &) = delete;
+    ~BgzfFile() { close_file(); }
+    void close_file() {
+        if (map) munmap(const_cast<uint8_t *>(map), size);
+        if (fd >= 0) ::close(fd);
+        map = nullptr;
+        fd = -1;
+        size = pos = 0;
+    }
     bool open(const std::string &p, std::string *err) {
+        close_file();
         path = p;
         fd = ::open(p.c_str(), O_RDONLY | O_CLOEXEC);
         struct stat st;
-        if (fd < 0 || fstat(fd, &st) != 0 || !S_ISREG(st.st_mode) || st.st_size <= 0) { *err = "Error opening input files for reading: " + p; return false; }
+        if (fd < 0 || fstat(fd, &st) != 0 || !S_ISREG(st.st_mode) || st.st_size <= 0) { *err = "Error opening input files for reading: " + p; close_file(); return false; }
         void *m = mmap(nullptr, (size_t)st.st_size, PROT_READ, MAP_PRIVATE, fd, 0);
-        if (m == MAP_FAILED) { *err = "Error opening input files for reading: " + p; return false; }
+        if (m == MAP_FAILED) { *err = "Error opening input files for reading: " + p; close_file(); return false; }
         map = static_cast<const uint8_t *>(m);
         size = (size_t)st.st_size;
         madvise(m, size, MADV_SEQUENTIAL);
         return true;
     }
-    // is every member of the file a standard BGZF one?  (a look at the first few: the rest is checked as it is walked)
+    // a standard BGZF member's header?  (every member is looked at as it is walked: a member that is none ends the run before it)
     static bool looks_like_bgzf(const uint8_t *h, size_t n) {
         return n >= 18 && h[0] == 0x1f && h[1] == 0x8b && h[2] == 8 && h[3] == 4 && h[10] == 6 && h[11] == 0 && h[12] == 'B' && h[13] == 'C' && h[14] == 2 && h[15] == 0;
     }
-    // Members from pos on while the run stays below the limits (at least one).  [*from, *upto): their bytes in the map.
+    // Members from pos on while they are BGZF members and the run stays below the limits (at least one).  [*from, *upto): their bytes in the map.
     bool next_run(size_t max_bytes, size_t max_text, std::vector<fqtk_inflate_member> *out, size_t *from, size_t *upto, std::string *err) {
         out->clear();
         *from = pos;
         size_t text = 0;
         while (pos < size) {
             const uint8_t *h = map + pos;
-            if (!looks_like_bgzf(h, size - pos)) { *err = "Unexpected error parsing FASTQs: " + path + " is not BGZF throughout (a member without the BC field at byte " + std::to_string(pos) + "): rerun with --host-inflate"; return false; }
+            if (!looks_like_bgzf(h, size - pos)) {
+                // a gzip member without the BC field (`cat a.bgz b.gz`), or whatever else lies behind the BGZF members: the run ends here and the
+                // caller looks at it (a serial member is decoded in chunks; what is no gzip member is ignored, as gzread does)
+                if (!out->empty()) break;
+                *err = "Unexpected error parsing FASTQs: " + path + " holds no BGZF member at byte " + std::to_string(pos);
+                return false;
+            }
             const size_t bsize = (size_t)h[16] + ((size_t)h[17] << 8) + 1;
             if (bsize < 26 || pos + bsize > size) { *err = "Unexpected error parsing FASTQs: bad BGZF block size in " + path; return false; }
             uint32_t crc, isize;

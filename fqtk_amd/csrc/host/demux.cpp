@@ -98,11 +98,42 @@ std::atomic<bool> g_dying{false};
     std::_Exit(0);
 }
 
+bool g_timing = false;   // FQTK_TIMING: clocks of the stages in the log
+
+// (FQTK_TIMING: the anonymous resident memory right now, in MB -- pinned staging and what the HIP runtime keeps on the host)
+size_t rss_anon_mb() {
+    size_t kb = 0;
+    if (FILE *f = std::fopen("/proc/self/status", "r")) {
+        char buf[256];
+        while (std::fgets(buf, sizeof buf, f))
+            if (!std::strncmp(buf, "RssAnon:", 8)) kb = (size_t)std::strtoull(buf + 8, nullptr, 10);
+        std::fclose(f);
+    }
+    return kb >> 10;
+}
+
 // (end of a run: what it cost the host)
 void report_footprint(size_t n_files) {
     rusage ru;
     if (getrusage(RUSAGE_SELF, &ru) == 0)
         info("Host footprint: peak resident set %.1f MB, %zu output files open at once.", ru.ru_maxrss / 1024.0, n_files);
+    if (g_timing) {   // what the kernel has to take apart when the process ends, and when that starts (wall clock)
+        std::string line;
+        if (FILE *f = std::fopen("/proc/self/status", "r")) {
+            char buf[256];
+            while (std::fgets(buf, sizeof buf, f))
+                if (!std::strncmp(buf, "VmRSS", 5) || !std::strncmp(buf, "RssAnon", 7) || !std::strncmp(buf, "RssFile", 7) || !std::strncmp(buf, "RssShmem", 8) || !std::strncmp(buf, "VmLck", 5) || !std::strncmp(buf, "VmPin", 5)) {
+                    std::string t(buf);
+                    while (!t.empty() && (t.back() == '\n' || t.back() == ' ')) t.pop_back();
+                    for (char &c : t) if (c == '\t') c = ' ';
+                    line += (line.empty() ? "" : "; ") + t;
+                }
+            std::fclose(f);
+        }
+        timespec ts;
+        clock_gettime(CLOCK_REALTIME, &ts);
+        info("(timing) at the end: %s; epoch %.3f", line.c_str(), ts.tv_sec + ts.tv_nsec * 1e-9);
+    }
 }
 
 struct Options {
@@ -311,7 +342,6 @@ struct StageTimes {   // FQTK_TIMING=1: where the host threads spend their time 
     std::atomic<uint64_t> main_wait{0}, main_gpu_wait{0}, main_handoff{0}, reader_parse{0}, reader_push{0};
 };
 StageTimes g_times;
-bool g_timing = false;
 inline uint64_t tick() { return g_timing ? (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count() : 0; }
 
 struct CompressJob {
@@ -513,8 +543,6 @@ bool gpu_output_supported(const Plan &plan, std::string *why) {
                     gpu_gunzip = false;
                 }
             }
-            munmap(const_cast<uint8_t *>(probe.map), probe.size);
-            ::close(probe.fd);
         }
     }
     bool fed_mode = G == 1 && !opt.host_inflate && !env_on("FQTK_HOST_INFLATE");
@@ -548,7 +576,7 @@ bool gpu_output_supported(const Plan &plan, std::string *why) {
             if (fqtk_matcher_create(bc.data(), (uint32_t)S, L, (uint8_t)opt.max_mismatches, (uint8_t)opt.min_mismatch_delta, opt.devices[g], &matchers[g]) != FQTK_OK)
                 die(std::string("cannot create the GPU barcode matcher: ") + fqtk_last_error());
             fqtk_matcher_set_sample_ids(matchers[g], ids.data());
-            if (g_timing) info("(timing) matcher on device %d created.", opt.devices[g]);
+            if (g_timing) info("(timing) matcher on device %d created; anonymous resident memory %zu MB.", opt.devices[g], rss_anon_mb());
             fqtk_demux_config cfg;
             std::memset(&cfg, 0, sizeof cfg);
             cfg.n_inputs = (uint32_t)n_inputs;
@@ -562,6 +590,7 @@ bool gpu_output_supported(const Plan &plan, std::string *why) {
             if (fqtk_demuxer_create(matchers[g], &cfg, &demuxers[g]) != FQTK_OK) die(std::string("cannot set up the GPU record pipeline: ") + fqtk_last_error());
             info("GPU barcode matcher and record pipeline ready on device %d (%llu memo entries).", opt.devices[g],
                  (unsigned long long)fqtk_matcher_memo_entries(matchers[g]));
+            if (g_timing) info("(timing) anonymous resident memory: %zu MB.", rss_anon_mb());
         }
     });
 
@@ -823,6 +852,8 @@ bool gpu_output_supported(const Plan &plan, std::string *why) {
     std::vector<char> fed_done(n_inputs, 0);
     std::string feed_error;
     uint64_t lines_taken = 0;   // per input: 4 x templates submitted
+    std::vector<uint64_t> blank_tail(n_inputs, 0);   // lines at an input's end that are no record (see below)
+    bool tails_looked_at = false;
     bool feed_stop = false;
     if (fed_mode) {
         // An input is fed again when it is less than two chunks ahead of the chunks cut so far.  A feed is a run of members of up
@@ -841,7 +872,7 @@ bool gpu_output_supported(const Plan &plan, std::string *why) {
                     fed_done[i] = 1;
                     fcv.notify_all();
                 };
-                if (is_serial_gz[i]) {
+                {   // (state of the serial-gzip members of this input: a BGZF file may hold one too)
                     // ---- a serial gzip file: stretches of chunks cut ON THE DEVICE at block starts it finds itself (a lane per bit position),
                     // decoded by a wavefront each without their windows, accepted where the chain of block boundaries proves the parse
                     // (host/parallel_gunzip.hpp's rule), resolved on the device.  A stretch takes the device about as long as its longest chunk
@@ -858,7 +889,7 @@ bool gpu_output_supported(const Plan &plan, std::string *why) {
                     uint32_t sym_per_byte = (uint32_t)std::max<long>(1, std::min<long>(2048, env_num("FQTK_GZ_DEVICE_SYMS", 8)));   // room per compressed byte; grows when a chunk runs out
                     size_t n_stretches = 0, n_chunks_total = 0, n_refused = 0, n_fallbacks = 0;
                     uint64_t fallback_text = 0;
-                    size_t pos = 0;                 // byte of the current member's header
+                    size_t &pos = bf.pos;           // byte of the current member's header
                     size_t stretch_at = 0;          // where in `pin` the stretch in hand begins
                     bool text_only = false;         // every chunk accepted so far decoded 7-bit text only: the search may insist on that (include/fqtk_demux.h)
                     // The NEXT stretch's bytes are copied into a second page-locked buffer while the device decodes this one: a stretch whose
@@ -873,9 +904,10 @@ bool gpu_output_supported(const Plan &plan, std::string *why) {
                     std::vector<uint8_t> win_before(32768), win_after(32768);
                     std::vector<fqtk_stream_end> ends(kSlots);
                     bool all_done = false;
-                    while (!all_done) {
+                    // one gzip member that is no BGZF member, from its header at bf.pos on; false: the run is over (fail() has been called, or the chunks are all cut)
+                    auto serial_member = [&]() -> bool {
                         const size_t hl = gzip_header_len(bf.map + pos, bf.size - pos);
-                        if (hl == 0) { fail("Unexpected error parsing FASTQs: corrupt gzip stream: " + std::string(pos ? "bad member header" : "not a gzip file") + " in " + bf.path); return; }
+                        if (hl == 0) { fail("Unexpected error parsing FASTQs: corrupt gzip stream: " + std::string(pos ? "bad member header" : "not a gzip file") + " in " + bf.path); return false; }
                         uint64_t verified = (uint64_t)(pos + hl) * 8u;   // a block starts here: the member's first
                         bool member_start = true;
                         uint32_t crc_acc = 0;
@@ -951,7 +983,7 @@ bool gpu_output_supported(const Plan &plan, std::string *why) {
                             {
                                 std::unique_lock<std::mutex> lk(fmu);
                                 fcv.wait(lk, [&] { return feed_stop || lines_fed[i] < lines_taken + gz_high_water; });
-                                if (feed_stop) { if (pin) fqtk_pinned_free(pin); return; }
+                                if (feed_stop) { return false; }
                             }
                             const uint64_t t0 = tick();
                             // the stretch: from the dword of the verified bit, as many chunks as the symbol budget allows, and a block's worth behind them
@@ -964,10 +996,10 @@ bool gpu_output_supported(const Plan &plan, std::string *why) {
                             if (bytes + 64 > pin_cap) {   // (once)
                                 if (pin) fqtk_pinned_free(pin);
                                 pin_cap = std::min<size_t>(bf.size, (kSlots + 5) * kChunkBytes + 131072 + 4) + 65536;
-                                if (fqtk_pinned_alloc(pin_cap, &pin) != FQTK_OK) { pin = nullptr; fail(std::string("cannot allocate page-locked memory: ") + fqtk_last_error()); return; }
+                                if (fqtk_pinned_alloc(pin_cap, &pin) != FQTK_OK) { pin = nullptr; fail(std::string("cannot allocate page-locked memory: ") + fqtk_last_error()); return false; }
                             }
                             if (kForceFallback > 0 && (n_stretches + n_fallbacks) % (size_t)kForceFallback == (size_t)kForceFallback - 1) {
-                                if (!host_stretch(std::min<uint64_t>(verified + (uint64_t)kChunkBytes * 8u * 3u, (uint64_t)bf.size * 8u), "forced", &member_done)) return;
+                                if (!host_stretch(std::min<uint64_t>(verified + (uint64_t)kChunkBytes * 8u * 3u, (uint64_t)bf.size * 8u), "forced", &member_done)) return false;
                                 continue;
                             }
                             if (prefetcher.joinable()) prefetcher.join();
@@ -996,7 +1028,7 @@ bool gpu_output_supported(const Plan &plan, std::string *why) {
                             if (fqtk_demuxer_stream_scan(demuxers[0], (uint32_t)i, stretch, bytes, verified - (uint64_t)b0 * 8u, (uint32_t)kChunkBytes, (uint32_t)n_slots,
                                                          to_end ? 1 : 0, sym_per_byte, text_only ? FQTK_STREAM_SCAN_TEXT : 0u, ends.data(), &n_chunks) != FQTK_OK) {
                                 fail(std::string("GPU record pipeline: ") + fqtk_last_error());
-                                return;
+                                return false;
                             }
                             const uint64_t t_dec = tick();
                             // a chunk counts if the chunk before it, itself accepted, ended on exactly the bit it started at -- and as far as it
@@ -1026,7 +1058,7 @@ bool gpu_output_supported(const Plan &plan, std::string *why) {
                                                                       "invalid code", "distance too far back", "a block that expands beyond the room for symbols", "a block longer than a stretch",
                                                                       "", "", ""};
                                 const uint64_t until = n_chunks > 1 ? (uint64_t)b0 * 8u + ends[1].start_bit : (uint64_t)b1 * 8u;
-                                if (!host_stretch(until, kWhat[std::min<uint32_t>(ends[0].status, 11)], &member_done)) return;
+                                if (!host_stretch(until, kWhat[std::min<uint32_t>(ends[0].status, 11)], &member_done)) return false;
                                 continue;
                             }
                             text_only = !env_on("FQTK_GZ_NO_TEXT_FILTER");
@@ -1036,12 +1068,12 @@ bool gpu_output_supported(const Plan &plan, std::string *why) {
                             const bool final_block = le.status == 0 && le.final_block;
                             bool ok = true;
                             const bool last = ends_file(end_bit, final_block, &ok);
-                            if (!ok) return;
+                            if (!ok) return false;
                             uint64_t fed = 0, n_text = 0;
                             uint32_t crc = 0;
                             if (fqtk_demuxer_stream_commit(demuxers[0], (uint32_t)i, (uint32_t)n_accept, member_start ? 1 : 0, last ? 1 : 0, &fed, &crc, &n_text) != FQTK_OK) {
                                 fail(std::string("GPU record pipeline: ") + fqtk_last_error());
-                                return;
+                                return false;
                             }
                             g_times.reader_push += tick() - tc1;
                             if (g_timing) info("(timing) gzip input %zu: stretch of %u chunks (%zu MB -> %zu MB): copy %.1f ms, search + decode %.1f ms, commit %.1f ms, %zu accepted%s.", i, n_chunks,
@@ -1052,52 +1084,64 @@ bool gpu_output_supported(const Plan &plan, std::string *why) {
                                      n_accept - 1, a.status, a.n_blocks, (unsigned long long)a.end_bit, n_accept, (unsigned long long)b.start_bit, b.status, b.n_blocks);
                             }
                             ++n_stretches; n_chunks_total += n_chunks; n_refused += n_chunks - n_accept;
-                            if (!stretch_done(end_bit, final_block, fed, crc, n_text, &member_done)) return;
+                            if (!stretch_done(end_bit, final_block, fed, crc, n_text, &member_done)) return false;
                             if (b0 > (64u << 20)) madvise(const_cast<uint8_t *>(bf.map), (b0 - (64u << 20)) & ~(size_t)4095, MADV_DONTNEED);
                         }
+                        return true;
+                    };
+                    auto more_members = [&] { return bf.pos + 18 <= bf.size && bf.map[bf.pos] == 0x1f && bf.map[bf.pos + 1] == 0x8b; };
+                    void *run_pin = nullptr;           // (runs of BGZF members have their own staging: the stretches' buffers are in use by the prefetcher)
+                    size_t run_pin_cap = 0;
+                    struct FreeRunPin { void *&p; ~FreeRunPin() { if (p) fqtk_pinned_free(p); } } free_run_pin{run_pin};
+                    for (;;) {
+                        if (!BgzfFile::looks_like_bgzf(bf.map + bf.pos, bf.size - bf.pos)) {
+                            // a gzip member without the BC field (`cat a.bgz b.gz`, or the whole file): one serial stream, decoded in chunks
+                            if (!serial_member()) break;
+                            if (all_done) break;
+                            continue;
+                        }
+                        {
+                            std::unique_lock<std::mutex> lk(fmu);
+                            fcv.wait(lk, [&] { return feed_stop || lines_fed[i] < lines_taken + high_water; });
+                            if (feed_stop) break;
+                        }
+                        size_t from = 0, upto = 0;
+                        std::string e;
+                        const uint64_t t0 = tick();
+                        static const size_t run_text = [] { const char *v = std::getenv("FQTK_FEED_TEXT_MB"); return (size_t)(v && *v ? std::atol(v) : 256) << 20; }();
+                        if (!bf.next_run(run_text / 4, run_text, &run, &from, &upto, &e)) { fail(e); break; }
+                        const size_t bytes = upto - from;
+                        if (bytes + 64 > run_pin_cap) {
+                            if (run_pin) fqtk_pinned_free(run_pin);
+                            run_pin_cap = bytes + bytes / 4 + 65536;
+                            if (fqtk_pinned_alloc(run_pin_cap, &run_pin) != FQTK_OK) { run_pin = nullptr; fail(std::string("cannot allocate page-locked memory: ") + fqtk_last_error()); break; }
+                        }
+                        if (bytes) std::memcpy(run_pin, bf.map + from, bytes);
+                        if (upto > (64u << 20)) madvise(const_cast<uint8_t *>(bf.map), (upto - (64u << 20)) & ~(size_t)4095, MADV_DONTNEED);
+                        g_times.reader_parse += tick() - t0;
+                        const bool last = !more_members();   // (what is no gzip member behind the last one is ignored, as zlib's gzread and the host path do)
+                        uint64_t fed = 0;
+                        const uint64_t t1 = tick();
+                        if (fqtk_demuxer_feed(demuxers[0], (uint32_t)i, static_cast<const uint8_t *>(run_pin), bytes, run.data(), (uint32_t)run.size(), last ? 1 : 0, &fed) != FQTK_OK) {
+                            fail("Unexpected error parsing FASTQs: " + std::string(fqtk_last_error()) + " in " + bf.path);
+                            break;
+                        }
+                        g_times.reader_push += tick() - t1;
+                        if (last) bf.pos = bf.size;
+                        {
+                            std::lock_guard<std::mutex> lk(fmu);
+                            lines_fed[i] = fed;
+                            if (last) fed_done[i] = 1;
+                        }
+                        fcv.notify_all();
+                        if (last) break;
                     }
+                    if (prefetcher.joinable()) prefetcher.join();
                     if (pin) fqtk_pinned_free(pin);
-                    if (g_timing) info("(timing) gzip input %zu: %zu chunks in %zu stretches decoded on the device, %zu not accepted (their stretch was cut there); %zu stretches (%zu MB of text) by the host's sequential decoder.",
-                                       i, n_chunks_total, n_stretches, n_refused, n_fallbacks, (size_t)(fallback_text >> 20));
-                    return;
+                    if (g_timing && (n_stretches || n_fallbacks))
+                        info("(timing) gzip input %zu: %zu chunks in %zu stretches decoded on the device, %zu not accepted (their stretch was cut there); %zu stretches (%zu MB of text) by the host's sequential decoder.",
+                             i, n_chunks_total, n_stretches, n_refused, n_fallbacks, (size_t)(fallback_text >> 20));
                 }
-                for (;;) {
-                    {
-                        std::unique_lock<std::mutex> lk(fmu);
-                        fcv.wait(lk, [&] { return feed_stop || lines_fed[i] < lines_taken + high_water; });
-                        if (feed_stop) break;
-                    }
-                    size_t from = 0, upto = 0;
-                    std::string e;
-                    const uint64_t t0 = tick();
-                    static const size_t run_text = [] { const char *v = std::getenv("FQTK_FEED_TEXT_MB"); return (size_t)(v && *v ? std::atol(v) : 256) << 20; }();
-                    if (!bf.next_run(run_text / 4, run_text, &run, &from, &upto, &e)) { fail(e); break; }
-                    const size_t bytes = upto - from;
-                    if (bytes + 64 > pin_cap) {
-                        if (pin) fqtk_pinned_free(pin);
-                        pin_cap = bytes + bytes / 4 + 65536;
-                        if (fqtk_pinned_alloc(pin_cap, &pin) != FQTK_OK) { fail(std::string("cannot allocate page-locked memory: ") + fqtk_last_error()); break; }
-                    }
-                    if (bytes) std::memcpy(pin, bf.map + from, bytes);
-                    if (upto > (64u << 20)) madvise(const_cast<uint8_t *>(bf.map), (upto - (64u << 20)) & ~(size_t)4095, MADV_DONTNEED);
-                    g_times.reader_parse += tick() - t0;
-                    const bool last = bf.at_end();
-                    uint64_t fed = 0;
-                    const uint64_t t1 = tick();
-                    if (fqtk_demuxer_feed(demuxers[0], (uint32_t)i, static_cast<const uint8_t *>(pin), bytes, run.data(), (uint32_t)run.size(), last ? 1 : 0, &fed) != FQTK_OK) {
-                        fail("Unexpected error parsing FASTQs: " + std::string(fqtk_last_error()) + " in " + bf.path);
-                        break;
-                    }
-                    g_times.reader_push += tick() - t1;
-                    {
-                        std::lock_guard<std::mutex> lk(fmu);
-                        lines_fed[i] = fed;
-                        if (last) fed_done[i] = 1;
-                    }
-                    fcv.notify_all();
-                    if (last) break;
-                }
-                if (pin) fqtk_pinned_free(pin);
             });
         for (;; ++k) {
             size_t n = chunk;
@@ -1112,10 +1156,29 @@ bool gpu_output_supported(const Plan &plan, std::string *why) {
                 });
                 g_times.main_wait += tick() - tw;
                 if (!feed_error.empty()) die(feed_error);
-                for (size_t i = 0; i < n_inputs; ++i) n = std::min<size_t>(n, (size_t)((lines_fed[i] - lines_taken) / 4));
+                bool all_fed = true;
+                for (size_t i = 0; i < n_inputs; ++i) all_fed = all_fed && fed_done[i];
+                if (all_fed && !tails_looked_at) {
+                    // Every input is in: the host path drops up to three blank lines behind the last record (fastq_io.hpp: next_raw),
+                    // and the device has added a newline to every text -- three blank lines and that one would make a record of four
+                    // blank lines here.  Such a tail does not count.
+                    tails_looked_at = true;
+                    for (size_t i = 0; i < n_inputs; ++i) {
+                        const uint64_t left_lines = lines_fed[i] - lines_taken;
+                        if (left_lines < 4 || left_lines % 4) continue;
+                        uint8_t last[16];
+                        uint64_t have = 0;
+                        if (fqtk_demuxer_fed_tail(demuxers[0], (uint32_t)i, ~0ull, last, sizeof last, &have) != FQTK_OK) die(fqtk_last_error());
+                        size_t q = (size_t)std::min<uint64_t>(have, sizeof last), newlines = 0;
+                        while (q > 0 && (last[q - 1] == '\n' || last[q - 1] == '\r')) newlines += last[--q] == '\n';
+                        // (four blank lines: four newlines with nothing but '\r' between them, behind the newline that ends the last record -- or the text's start)
+                        if (newlines >= 5 || (newlines == 4 && q == 0 && have <= sizeof last)) blank_tail[i] = 4;
+                    }
+                }
+                for (size_t i = 0; i < n_inputs; ++i) n = std::min<size_t>(n, (size_t)((lines_fed[i] - lines_taken - blank_tail[i]) / 4));
             }
             if (n == 0) break;
-            if (!first_submit.exchange(true)) t_first = now_s();
+            if (!first_submit.exchange(true)) { t_first = now_s(); if (g_timing) info("(timing) first chunk cut; anonymous resident memory %zu MB.", rss_anon_mb()); }
             Job j;
             j.n = n;
             j.first_record = records;
@@ -1172,11 +1235,15 @@ bool gpu_output_supported(const Plan &plan, std::string *why) {
                 if (tail[q] == '\n') ++lines;
                 else if (tail[q] != '\r') blank = false;
             }
-            if (blank && left <= tail.size()) continue;
+            // (up to three blank lines behind the last record, as the host path allows -- fastq_io.hpp: next_raw --, and the newline the device added)
+            if (blank && left <= tail.size() && lines <= 4) continue;
             const bool whole_file_fed = fed_done[i] && bgzf_in[i]->at_end();
             if (lines >= 4 || !whole_file_fed) {
-                size_t short_one = 0;
-                for (size_t q = 0; q < n_inputs; ++q) if (q != i) short_one = q;
+                // records the other inputs do not have: name an input that ended first
+                size_t short_one = i == 0 ? (n_inputs > 1 ? 1 : 0) : 0;
+                uint64_t fewest = ~0ull;
+                for (size_t q = 0; q < n_inputs; ++q)
+                    if (q != i && lines_fed[q] < fewest) { fewest = lines_fed[q]; short_one = q; }
                 die("FASTQ sources out of sync at records: input " + opt.inputs[short_one] + " ended after a different number of records");
             }
             die("Unexpected error parsing FASTQs: truncated record at end of " + opt.inputs[i]);

@@ -380,7 +380,7 @@ uint64_t fqtk_host_gzip_header_len(const uint8_t *data, size_t n) { return (uint
 
 // The member walk of the device-inflate feeders (bgzf_walk.hpp): runs of whole members of `path` below max_bytes of file /
 // max_text of text each.  Writes up to cap rows of (run, payload offset in the file, payload bytes, ISIZE, CRC-32); returns the
-// number of members, -1 with *err when the file is not BGZF throughout / damaged.
+// number of members, -1 with *err when a run is asked for where no BGZF member lies / the file is damaged.
 int64_t fqtk_host_bgzf_walk(const char *path, uint64_t max_bytes, uint64_t max_text, uint64_t *rows, size_t cap, char *err, size_t err_cap) {
     fqtk_host::BgzfFile f;
     std::string e;

@@ -127,7 +127,8 @@ int fqtk_demuxer_feed(fqtk_demuxer *d, uint32_t input, const uint8_t *bytes, uin
 int fqtk_demuxer_submit_fed(fqtk_demuxer *d, int slot, uint32_t n_templates);
 
 /* The fed text of `input` from position `pos` to its end (*n_bytes; the first min(*n_bytes, cap) of them in buf): what
- * lies behind the last record (end-of-file checks).  Only text no chunk has consumed in full is still there. */
+ * lies behind the last record (end-of-file checks).  pos == ~0: the text's last min(cap, its length) bytes.  Only text no chunk has
+ * consumed in full is still there. */
 int fqtk_demuxer_fed_tail(fqtk_demuxer *d, uint32_t input, uint64_t pos, uint8_t *buf, size_t cap, uint64_t *n_bytes);
 
 /* ---- serial gzip inputs (`gzip`, bcl2fastq: one member per file) decoded on the device in chunks ---------------------------

@@ -261,10 +261,12 @@ def test_member_walk_of_the_device_inflate_feeders(tmp_path):
     # an ordinary gzip member in the middle; a BSIZE that runs past the file; a member of more than 64 KiB of text
     plain = gzip_member = b"\x1f\x8b\x08\x00\0\0\0\0\0\xff" + raw_deflate(b"hello\n") + struct.pack("<II", zlib.crc32(b"hello\n"), 6)
     (tmp_path / "b.gz").write_bytes(bgzf_member(pieces[0]) + plain)
-    with pytest.raises(ValueError, match="not BGZF throughout"):
+    # (the run ends in front of the ordinary member: the feeder of `fqtk demux` decodes that one as a serial stream; asked for a run
+    #  there, the walk says that no BGZF member lies there)
+    with pytest.raises(ValueError, match="holds no BGZF member at byte %d" % len(bgzf_member(pieces[0]))):
         _walk(tmp_path / "b.gz")
     (tmp_path / "c.gz").write_bytes(data[:len(data) // 2])
-    with pytest.raises(ValueError, match="bad BGZF block size|not BGZF throughout"):
+    with pytest.raises(ValueError, match="bad BGZF block size|holds no BGZF member"):
         _walk(tmp_path / "c.gz")
     big = bytearray(bgzf_member(pieces[0]))
     big[-4:] = struct.pack("<I", 70000)

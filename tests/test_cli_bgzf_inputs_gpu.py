@@ -295,3 +295,84 @@ def test_a_large_gzip_input_with_a_run_of_identical_records_takes_the_device_pat
     want = _outputs(tmp_path / "out_host")
     for k in want:
         assert got[k] == want[k], k
+
+
+def test_a_bgzf_file_with_an_ordinary_gzip_member_in_it_stays_on_the_device(tmp_path, monkeypatch):
+    """`cat a.bgz b.gz c.bgz` is BGZF by its first member only.  The feeder takes runs of BGZF members while there are
+    BGZF members and decodes a member without the BC field as the serial stream it is (in chunks, on the device) -- nothing dies
+    mid-run with partial outputs; what lies behind the last member and is no gzip member is ignored, as the host path ignores it."""
+    import gzip
+    rng = np.random.default_rng(61)
+    bcs = ["ACGTACGT", "TTGCAATG", "GGGGCCCC"]
+    n = 21_000
+    r1 = _records(n, rng, [120, 75], "r")
+    i1 = [(h, bcs[k % 3], "F" * 8) for k, (h, _, _) in enumerate(r1)]
+    t1, ti = _text(r1), _text(i1)
+    a = t1[:len(t1) // 3].rfind(b"\n@") + 1
+    b = t1[:2 * len(t1) // 3].rfind(b"\n@") + 1
+    eof = bytes.fromhex("1f8b08040000000000ff0600424302001b0003000000000000000000")
+    part1 = open(_write_bgzf(tmp_path / "p1.gz", t1[:a]), "rb").read()
+    part3 = open(_write_bgzf(tmp_path / "p3.gz", t1[b:], member=7000), "rb").read()
+    assert part1.endswith(eof) and part3.endswith(eof)
+    f1 = str(tmp_path / "mixed.fastq.gz")                      # BGZF members (their EOF marker too), an ordinary member, BGZF members, rubbish
+    with open(f1, "wb") as fh:
+        fh.write(part1 + gzip.compress(t1[a:b], 6) + part3 + b"\0\0trailing bytes that are no gzip member")
+    f2 = _write_bgzf(tmp_path / "i1.fastq.gz", ti, member=5000)
+    meta = _meta(tmp_path, bcs)
+    monkeypatch.setenv("FQTK_GZ_DEVICE_CHUNK_KB", "8")
+    monkeypatch.setenv("FQTK_GZ_DEVICE_CHUNKS", "16")
+    runs = {}
+    for name, extra in (("device", []), ("host", ["--host-inflate"])):
+        r = H.run_demux([f1, f2], ["+T", "8B"], meta, tmp_path / name, threads=8, extra=["--chunk-reads", "3000"] + extra)
+        assert r.returncode == 0, r.stderr
+        assert ("inflated on the device" in r.stderr) == (name == "device"), r.stderr
+        runs[name] = (_outputs(tmp_path / name), open(tmp_path / name / "demux-metrics.txt").read())
+    assert runs["device"][1] == runs["host"][1]
+    for f in runs["host"][0]:
+        assert runs["device"][0][f] == runs["host"][0][f], f
+    assert sum(len(v) for f, v in runs["device"][0].items()) == n
+
+
+def test_fed_text_ends_like_the_host_path_ends_it_and_names_the_right_inputs(tmp_path, monkeypatch):
+    """the end-of-input rules of fed text are the host path's -- up to three blank lines behind the last record are
+    dropped (fastq_io.hpp: next_raw), a fourth makes a record of blank lines, which is malformed; of three inputs the one that ended
+    first is the one named; a malformed record in the middle of a run is reported with ITS header although the arenas of the fed
+    text (1 MB here) have been reused many times since."""
+    rng = np.random.default_rng(62)
+    bcs = ["ACGTACGT", "TTGCAATG"]
+    n = 6000
+    r1 = _records(n, rng, [60], "r")
+    i1 = [(h, bcs[k & 1], "F" * 8) for k, (h, _, _) in enumerate(r1)]
+    r2 = [(h, b[:40], q[:40]) for h, b, q in r1]
+    meta = _meta(tmp_path, bcs)
+    base = ["+T", "8B", "+T"]
+
+    def both(files, tag):
+        out = {}
+        for name, extra in (("device", []), ("host", ["--host-inflate"])):
+            r = H.run_demux(files, base, meta, tmp_path / (tag + name), threads=8, extra=["--chunk-reads", "1000"] + extra)
+            out[name] = r
+        return out
+
+    # three blank lines behind every input's last record: fine on both paths, same outputs
+    f = [_write_bgzf(tmp_path / f"a{k}.gz", _text(x) + b"\n\n\n", member=9000) for k, x in enumerate((r1, i1, r2))]
+    rr = both(f, "blank3")
+    assert rr["device"].returncode == 0 and rr["host"].returncode == 0, (rr["device"].stderr, rr["host"].stderr)
+    assert _outputs(tmp_path / "blank3device") == _outputs(tmp_path / "blank3host")
+    # four: a record of blank lines, malformed on both paths
+    f = [_write_bgzf(tmp_path / f"b{k}.gz", _text(x) + b"\n\n\n\n", member=9000) for k, x in enumerate((r1, i1, r2))]
+    rr = both(f, "blank4")
+    assert rr["device"].returncode != 0 and rr["host"].returncode != 0
+    assert "expected '@'" in rr["device"].stderr and "expected '@'" in rr["host"].stderr, (rr["device"].stderr, rr["host"].stderr)
+    # the middle input ends 9 records early: it is the one named
+    f = [_write_bgzf(tmp_path / "c0.gz", _text(r1)), _write_bgzf(tmp_path / "c1.gz", _text(i1[:n - 9])), _write_bgzf(tmp_path / "c2.gz", _text(r2))]
+    rr = both(f, "short")
+    for name in ("device", "host"):
+        assert rr[name].returncode != 0 and "out of sync" in rr[name].stderr and "c1.gz" in rr[name].stderr, (name, rr[name].stderr)
+    # a read too short for its structure in the middle of the run, arenas of 1 MB: the message names that read
+    short = list(r1)
+    short[3300] = ("the:short:one x", "ACG", "FFF")
+    f = [_write_bgzf(tmp_path / "d0.gz", _text(short), member=4000), _write_bgzf(tmp_path / "d1.gz", _text(i1), member=4000), _write_bgzf(tmp_path / "d2.gz", _text(r2), member=4000)]
+    monkeypatch.setenv("FQTK_FED_ARENA_MIN", "1000000")
+    r = H.run_demux(f, ["10M+T", "8B", "+T"], meta, tmp_path / "tooshort", threads=8, extra=["--chunk-reads", "500"])
+    assert r.returncode != 0 and "Read the:short:one x had too few bases to demux 3 vs. 11 needed" in r.stderr, r.stderr
