@@ -891,6 +891,8 @@ bool gpu_output_supported(const Plan &plan, std::string *why) {
                     uint64_t fallback_text = 0;
                     size_t &pos = bf.pos;           // byte of the current member's header
                     size_t stretch_at = 0;          // where in `pin` the stretch in hand begins
+                    // (the first stretches are short: a quarter of a stretch holds the first chunk of templates, and the record pipeline starts that much sooner)
+                    size_t ramp_slots = std::min<size_t>(kSlots, (size_t)std::max<long>(1, env_num("FQTK_GZ_DEVICE_FIRST_CHUNKS", 256)));
                     bool text_only = false;         // every chunk accepted so far decoded 7-bit text only: the search may insist on that (include/fqtk_demux.h)
                     // The NEXT stretch's bytes are copied into a second page-locked buffer while the device decodes this one: a stretch whose
                     // chunks all count ends in its last chunk, so the next one lies in the file from there on (a stretch cut short by a false
@@ -988,7 +990,8 @@ bool gpu_output_supported(const Plan &plan, std::string *why) {
                             const uint64_t t0 = tick();
                             // the stretch: from the dword of the verified bit, as many chunks as the symbol budget allows, and a block's worth behind them
                             const size_t b0 = (size_t)(verified / 8u) & ~(size_t)3;
-                            size_t n_slots = std::max<size_t>(1, std::min<size_t>(kSlots, (size_t)(kSymBudget / ((uint64_t)kChunkBytes * sym_per_byte))));
+                            size_t n_slots = std::max<size_t>(1, std::min<size_t>(ramp_slots, (size_t)(kSymBudget / ((uint64_t)kChunkBytes * sym_per_byte))));
+                            ramp_slots = std::min(kSlots, ramp_slots * 2);
                             const size_t b1 = std::min<size_t>(bf.size, b0 + n_slots * kChunkBytes + 131072);
                             const bool to_end = b1 == bf.size;
                             const size_t bytes = b1 - b0;

@@ -24,27 +24,40 @@ def _line(r):
 
 @pytest.mark.gpu
 def test_bench_line_carries_scopes_create_time_cpu_rows_and_the_full_parity_gate():
-    d = _line(_run(["--reads", "3000000", "--steps", "3", "--warmup", "1", "--cpu-seconds", "1",
-                    "--e2e-templates", "4000000", "--e2e-threads", "8"]))
-    assert d["n_gpus"] == 1 and d["unit"] == "M reads/s" and d["value"] > 0
+    r = _run(["--reads", "3000000", "--steps", "3", "--warmup", "1", "--cpu-seconds", "1", "--e2e-templates", "4000000", "--e2e-threads", "8"])
+    line = r.stdout.strip().splitlines()[-1]
+    d = _line(r)
+    # the line fits the tail its consumer keeps, and carries every field of the contract and every scope as numbers
+    assert len(line) < 2000, len(line)
+    assert d["n_gpus"] == 1 and d["unit"] == "M reads/s" and d["value"] > 0 and d["higher_is_better"] is True and d["dtype"] == "u8"
     assert "bit-exact" in d["config"]["parity"] and "count vector of all 3000000 reads" in d["config"]["parity"]
-    assert set(d["scopes"]) == {"K", "B", "B_packed", "bgzf_kernel", "inflate_kernel", "E", "E_host", "E_gz", "E_gz_host", "E_bgzf"}
-    assert d["scopes"]["bgzf_kernel"]["hbm"]["GB_per_s_in"] > 5 and 0.2 < d["scopes"]["bgzf_kernel"]["hbm"]["ratio"] < 0.5
-    assert d["scopes"]["B_packed"]["M_reads_per_s"] > 0 and d["scopes"]["B_packed"]["packed_bytes_per_read"] == 8
-    for k, n in (("E", 4000000), ("E_host", 1000000), ("E_gz", 1000000), ("E_gz_host", 1000000), ("E_bgzf", 1000000)):   # device output (default), host output, gzip inputs, BGZF inputs inflated on the device
-        assert d["scopes"][k]["templates"] == n and d["scopes"][k]["metrics_vs_oracle"] == "per-sample counts identical"
-        assert d["scopes"][k]["peak_rss_MB"] > 0 and d["scopes"][k]["output_files"] == 771
-    assert d["scopes"]["E"]["M_templates_per_s_steady"] > 0 and d["scopes"]["E_gz"]["M_templates_per_s_steady"] > 0
-    assert d["scopes"]["E_host"]["extra_args"] == ["--host-output"] and d["scopes"]["E_gz"]["gz_inputs"]
-    assert d["scopes"]["B"]["M_reads_per_s"] > 0 and d["scopes"]["B"]["GB_per_s_over_pcie"] > 0
-    assert any("inflated on the device" in t for t in d["scopes"]["E_bgzf"]["timeline"]) and d["scopes"]["inflate_kernel"]["text_GBps"] > 5
-    assert d["create_ms"] > 0
+    assert d["config"]["workload"].startswith("cfg3")
+    assert set(d["scopes"]) == {"B", "B_packed", "bgzf_kernel_GBps", "inflate_kernel_GBps", "E", "E_host", "E_gz", "E_gz_host", "E_bgzf", "is"}
+    for k, n in (("E", 4), ("E_host", 1), ("E_gz", 1), ("E_gz_host", 1), ("E_bgzf", 1)):
+        wall, steady, m = d["scopes"][k]
+        assert m == n and wall > 0 and (steady is None or steady > 0)
+    assert d["scopes"]["bgzf_kernel_GBps"] > 5 and d["scopes"]["inflate_kernel_GBps"] > 5 and d["scopes"]["B"] > 0 and d["scopes"]["B_packed"] > 0
+    assert d["create_ms"] > 0 and "gpu_over_cpu" not in json.dumps(d)
     cb = d["cpu_baseline"]
-    assert cb["cores"] == 1 and cb["kind"] == "port" and cb["value"] > 0
-    assert cb["cache_off_1core"]["value"] > 0 and cb["all_cores"]["cores"] >= 1
+    assert cb["cores"] == 1 and cb["kind"] == "port" and cb["value"] > 0 and cb["cache_off"] > 0 and cb["all_cores"][1] >= 1 and "oracle/ref_literal.c" in cb["sample"]
     rf = d["roofline"]
     assert rf["bound"] == "hbm" and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-4
     assert rf["kernel_ms"] <= d["ms_per_step"] * 1.05
+    # the whole record is in the side file the line names
+    full = json.load(open(os.path.join(ROOT, d["detail"])))
+    assert full["value"] == d["value"] and full["roofline"]["frac"] == rf["frac"]
+    assert set(full["scopes"]) == {"K", "B", "B_packed", "bgzf_kernel", "inflate_kernel", "E", "E_host", "E_gz", "E_gz_host", "E_bgzf"}
+    sc = full["scopes"]
+    assert sc["bgzf_kernel"]["hbm"]["GB_per_s_in"] > 5 and 0.2 < sc["bgzf_kernel"]["hbm"]["ratio"] < 0.5
+    assert sc["B_packed"]["M_reads_per_s"] > 0 and sc["B_packed"]["packed_bytes_per_read"] == 8
+    for k, n in (("E", 4000000), ("E_host", 1000000), ("E_gz", 1000000), ("E_gz_host", 1000000), ("E_bgzf", 1000000)):   # device output (default), host output, gzip inputs, BGZF inputs inflated on the device
+        assert sc[k]["templates"] == n and sc[k]["metrics_vs_oracle"] == "per-sample counts identical"
+        assert sc[k]["peak_rss_MB"] > 0 and sc[k]["output_files"] == 771
+    assert sc["E"]["M_templates_per_s_steady"] > 0 and sc["E_gz"]["M_templates_per_s_steady"] > 0
+    assert sc["E_host"]["extra_args"] == ["--host-output"] and sc["E_gz"]["gz_inputs"]
+    assert sc["B"]["M_reads_per_s"] > 0 and sc["B"]["GB_per_s_over_pcie"] > 0
+    assert any("inflated on the device" in t for t in sc["E_bgzf"]["timeline"]) and sc["inflate_kernel"]["text_GBps"] > 5
+    assert full["cpu_baseline"]["cache_off_1core"]["value"] > 0 and full["cpu_baseline"]["all_cores"]["cores"] >= 1
 
 
 @pytest.mark.gpu

@@ -32,8 +32,8 @@ run() {   # name, extra args
     local rc=$?
     local t1=$(date +%s.%N)
     local steady=$(grep -o "([0-9.]* M templates/s)" $O/$name.err | tr -d '()' | cut -d' ' -f1)
-    local t_end=$(grep -o "epoch [0-9.]*" $O/$name.err | cut -d' ' -f2)
-    local t_log=$(grep "at the end" $O/$name.err | sed 's/^\[ *\([0-9.]*\) .*/\1/')
+    local t_end=$(grep -o "epoch [0-9.]*" $O/$name.err | tail -1 | cut -d' ' -f2)
+    local t_log=$(grep "at the end" $O/$name.err | tail -1 | sed 's/^\[ *\([0-9.]*\) .*/\1/')
     [ -n "$t_end" ] && echo "$name: before main $(awk -v a=$t0 -v e=$t_end -v l=$t_log 'BEGIN { printf "%.3f", e - l - a }') s, main $t_log s, after the last line $(awk -v b=$t1 -v e=$t_end 'BEGIN { printf "%.3f", b - e }') s" | tee -a $O/summary.txt
     echo "$name rc=$rc $(awk -v a=$t0 -v b=$t1 -v n=$N 'BEGIN { printf "wall_s=%.3f M_templates_per_s_wall=%.2f", b - a, n / (b - a) / 1e6 }') steady=$steady" | tee -a $O/summary.txt
     md5sum $D/out_$name/demux-metrics.txt | cut -c1-32 >> $O/summary.txt
