@@ -115,7 +115,10 @@ def build(force: bool = False, verbose: bool = False) -> None:
             obj = os.path.join(objdir, os.path.basename(src) + ".o")
             objs.append(obj)
             if force or _stale(obj, [src] + deps_common):
-                jobs.append([HIPCC, f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-I", INCLUDE, "-c", "-o", obj] + extra + extra_defs + [src])
+                # (-fvisibility-inlines-hidden: the library's copies of inline C++ functions -- std::unique_lock::unlock ... -- are its own; a
+                #  C-ABI library neither exports them nor takes the executable's, which under TSan are instrumented while the lock they pair
+                #  with was taken in here, unseen: "unlock of an unlocked mutex")
+                jobs.append([HIPCC, f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-fvisibility-inlines-hidden", "-I", INCLUDE, "-c", "-o", obj] + extra + extra_defs + [src])
         links.append((os.path.join(LIBDIR, name), objs))
 
     def run(cmd):
@@ -127,7 +130,7 @@ def build(force: bool = False, verbose: bool = False) -> None:
         list(ex.map(run, jobs))
     for out, objs in links:
         if force or _stale(out, objs):
-            run([HIPCC, f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", out] + objs)
+            run([HIPCC, f"--offload-arch={ARCH}", "-shared", "-fPIC", "-Wl,-Bsymbolic-functions", "-o", out] + objs)
     open(stamp, "w").write(" ".join(extra_defs))
     build_host(force=force, verbose=verbose)
 

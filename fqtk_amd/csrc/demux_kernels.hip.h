@@ -534,45 +534,57 @@ __global__ __launch_bounds__(256) void k_descs(DevConfig C, const FileChunk *fc,
 }
 
 // ---- formatting -----------------------------------------------------------------------------------------------------------
-// One wavefront per kFormatGroup consecutive templates.  First the lanes fetch what the group's templates need (plan,
-// sample, the record views of all inputs -> LDS, per output file the record's place): the dependent look-ups of the whole
-// group in one round trip.  Then the wave takes the records one by one:
-//   1. the record's SLOT TABLE (record_format.hpp: record_slot) -- lane s works out slot s in closed form from the plan,
-//      a wave prefix sum places the slots, the table goes to LDS (start, source, kind per slot; <= 62 slots);
-//   2. the body: every lane takes whole dwords of the file's block that lie inside ONE slot -- a binary search over the
-//      slot starts (six LDS reads), two aligned dwords of the source and one v_alignbyte -- 256 bytes per pass;
-//   3. the seams: lane j takes the dword that holds the first byte of slot j (and two more lanes the record's first and
-//      last dword), byte by byte -- literals, slot boundaries and the ragged ends of the record, ONE pass per record.
-// ~250 wave-instructions per 360-byte record.  Round 3 offered every piece of the record to all 64 lanes x 8 byte positions
-// each (a gather sink: no serial lane, no table, but ~1 200 wave-instructions per record, 108 VGPRs: 740 us per chunk of
-// 262 144 templates, the second-largest device stage of a run); before that one lane listed the pieces (805 us).
+// One wavefront per kFormatGroup = 16 consecutive templates; per output file their sixteen records are worked on TOGETHER wherever the
+// work is the same for all of them:
+//   A. the SLOT TABLES (record_format.hpp: record_slot_with) of all sixteen records at once -- a lane per (record, slot): the slot in
+//      closed form from the template's plan, a prefix sum over the lanes of one record places it; tables in LDS (start, source, kind);
+//   B. the BODY, record by record (its place in the file's block is wave-uniform): every lane takes whole dwords of the block that lie
+//      inside ONE span slot -- a binary search over the slot starts, two aligned dwords of the source, one v_alignbyte -- two dwords
+//      per lane and pass, loads before stores.  Dwords that are NOT of that kind -- they hold a literal, straddle two slots, or the
+//      record begins / ends inside them: about one in six -- are only LISTED (ballot, a queue in LDS);
+//   C. the SEAMS of all sixteen records, a lane per listed dword, byte by byte.
+// Round 4 did A and C per record -- a wave pass each in which sixteen to twenty-five lanes had something to do: 549 VALU + 416 SALU
+// wave-instructions per record, 672 us per chunk of 262 144 templates (the second-largest device stage of a run); round 3 offered every
+// piece to all lanes (740 us); before that one lane listed the pieces (805 us).
+// Records of more slots than sixteen (more than two barcode segments) go through in groups of eight or four: the tables hold 256 slots.
 constexpr int kFormatWaves = 4;
 constexpr uint32_t kFormatGroup = 16;
-constexpr uint32_t kFormatSlots = 64;   // record_slots(nb, nm) + 6 <= 64: a lane per slot, six more for the seams (fqtk_demuxer_create)
-struct WaveScratch {
-    fmt::Span b[kMaxSegs], m[kMaxSegs];
-    uint32_t start[kFormatSlots + 1];   // byte offset of every slot in the record; [n_slots] = the record's length
-    uint32_t src[kFormatSlots];         // span: offset in its input's text; literal: the bytes
-    uint32_t info[kFormatSlots];        // input | kind << 16
+constexpr uint32_t kFormatSlots = 64;     // record_slots(nb, nm) <= 64: a lane per slot of one record at least (fqtk_demuxer_create)
+constexpr uint32_t kFormatTable = 256;    // slots in the tables: 16 records x 16 slots, 8 x 32 or 4 x 64
+constexpr uint32_t kSeamQueue = 512;      // listed dwords (flushed when fewer than 128 places are free)
+struct RecParam {                         // where a record of the batch in hand goes (phase C: a lane per listed dword looks its record up)
+    unsigned long long base0, base1;      // the block its first byte lies in, and the next one
+    uint32_t in0a;                        // offset in that block of the dword-aligned start of its first dword
+    uint32_t a, total, flags;             // bytes in front of it in that dword; its length; 1: "<n>:N:0:" (not "<n>:"), 2: two blocks at most
+    uint32_t q, c, nb, slab_base, par, pad;   // (records longer than two blocks: file_byte's general arithmetic)
 };
-// dynamic LDS: the inputs' text pointers (one copy per workgroup), then per wave: WaveScratch, RecView rec[n_inputs][kFormatGroup]
+struct WaveScratch {
+    uint32_t planw[kFormatGroup][4];      // the templates' header plans
+    uint32_t start[kFormatTable + kFormatGroup];   // [record][P + 1]: byte offset of every slot in its record; [P] = the record's length
+    uint32_t src[kFormatTable];           // span: offset in its input's text; literal: the bytes
+    uint32_t info[kFormatTable];          // input | kind << 16
+    RecParam rp[kFormatGroup];
+    uint32_t queue[kSeamQueue];           // record of the batch << 24 | dword of its block range
+};
+// dynamic LDS: the inputs' text pointers and the barcode segments' places (one copy per workgroup), then per wave: WaveScratch, RecView rec[n_inputs][kFormatGroup]
+constexpr size_t kFormatBlockHead = FQTK_DEMUX_MAX_INPUTS * sizeof(uint64_t) + 2 * kMaxSegs * sizeof(fmt::SegPos);
 __host__ __device__ constexpr size_t format_wave_bytes(uint32_t n_inputs) { return (sizeof(WaveScratch) + (size_t)n_inputs * kFormatGroup * sizeof(RecView) + 15u) & ~(size_t)15u; }
-__host__ __device__ constexpr size_t format_block_bytes(uint32_t n_inputs) { return FQTK_DEMUX_MAX_INPUTS * sizeof(uint64_t) + kFormatWaves * format_wave_bytes(n_inputs); }
+__host__ __device__ constexpr size_t format_block_bytes(uint32_t n_inputs) { return ((kFormatBlockHead + 15u) & ~(size_t)15u) + kFormatWaves * format_wave_bytes(n_inputs); }
 
-#ifndef FQTK_FORMAT_WAVES_PER_EU
-#define FQTK_FORMAT_WAVES_PER_EU 8
-#endif
-__global__ __launch_bounds__(64 * kFormatWaves) __attribute__((amdgpu_waves_per_eu(FQTK_FORMAT_WAVES_PER_EU, 8))) void k_format(TextSet T, DevConfig C, uint32_t n, const uint32_t *res, const uint8_t *skip,
+__global__ __launch_bounds__(64 * kFormatWaves) void k_format(TextSet T, DevConfig C, uint32_t n, const uint32_t *res, const uint8_t *skip,
                                                                const TemplatePlan *plans, const uint32_t *rec_off, const uint32_t *tile_tot,
                                                                const FileChunk *fc, uint8_t *persist, uint8_t *slabs, const ChunkStatus *st) {
     if (st->err_key != kNoError) return;
     extern __shared__ __attribute__((aligned(16))) uint8_t fmt_lds[];
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
-    // the inputs' text pointers where a lane can index them by a slot's input
+    // what a lane indexes by a value of its own: the inputs' text pointers, the barcode segments' places
     const uint8_t **text_of = reinterpret_cast<const uint8_t **>(fmt_lds);
+    fmt::SegPos *bseg_lds = reinterpret_cast<fmt::SegPos *>(fmt_lds + FQTK_DEMUX_MAX_INPUTS * sizeof(uint64_t)), *mseg_lds = bseg_lds + kMaxSegs;
     if (threadIdx.x < C.n_inputs) text_of[threadIdx.x] = T.text[threadIdx.x];
+    if (threadIdx.x >= 64u && threadIdx.x - 64u < C.n_b) bseg_lds[threadIdx.x - 64u] = C.bseg[threadIdx.x - 64u];
+    if (threadIdx.x >= 128u && threadIdx.x - 128u < C.n_m) mseg_lds[threadIdx.x - 128u] = C.mseg[threadIdx.x - 128u];
     __syncthreads();
-    uint8_t *mine_lds = fmt_lds + FQTK_DEMUX_MAX_INPUTS * sizeof(uint64_t) + (size_t)wave * format_wave_bytes(C.n_inputs);
+    uint8_t *mine_lds = fmt_lds + ((kFormatBlockHead + 15u) & ~(size_t)15u) + (size_t)wave * format_wave_bytes(C.n_inputs);
     WaveScratch &W = *reinterpret_cast<WaveScratch *>(mine_lds);
     RecView *recs = reinterpret_cast<RecView *>(mine_lds + sizeof(WaveScratch));   // [input][template of the group]
     const uint32_t t0 = (blockIdx.x * kFormatWaves + wave) * kFormatGroup;
@@ -581,25 +593,35 @@ __global__ __launch_bounds__(64 * kFormatWaves) __attribute__((amdgpu_waves_per_
     const uint32_t cps = C.n_files + 1u, cols = (C.n_samples + 1u) * cps, tile = t0 / kTile;   // (the group divides the tile)
     const bool valid = lane < kFormatGroup && t < n && !skip[t];
     uint32_t s = 0;
-    TemplatePlan tp;
-    tp.h.name_len = tp.h.copy_off = tp.h.copy_len = 0;
-    tp.h.kind = tp.h.tail = tp.h.msep = tp.h.err = 0;
-    tp.base_len = 0;
-    if (valid) {
-        const uint32_t idx = res[t] & 0xFFFFu;
-        s = idx == FQTK_NO_MATCH ? C.n_samples : idx;
-        tp = plans[t];
+    if (lane < kFormatGroup) {
+        TemplatePlan tp;
+        tp.h.name_len = tp.h.copy_off = tp.h.copy_len = 0;
+        tp.h.kind = tp.h.tail = tp.h.msep = tp.h.err = 0;
+        if (valid) {
+            const uint32_t idx = res[t] & 0xFFFFu;
+            s = idx == FQTK_NO_MATCH ? C.n_samples : idx;
+            tp = plans[t];
+        }
+        W.planw[lane][0] = tp.h.name_len;
+        W.planw[lane][1] = tp.h.copy_off;
+        W.planw[lane][2] = tp.h.copy_len;
+        W.planw[lane][3] = (uint32_t)tp.h.kind | ((uint32_t)tp.h.tail << 8) | ((uint32_t)tp.h.msep << 16);
     }
     // the record views of the group: lane = (input, template) pairs, so that the loads go out side by side
     for (uint32_t k = lane; k < C.n_inputs * kFormatGroup; k += 64u) {
         const uint32_t i = k / kFormatGroup, g = k - i * kFormatGroup;
-        if (t0 + g < n) recs[k] = T.rec[i][t0 + g];
+        RecView v;
+        v.head_off = v.head_len = v.seq_off = v.seq_len = v.qual_off = 0;
+        if (t0 + g < n) v = T.rec[i][t0 + g];
+        recs[k] = v;
     }
     const uint64_t live = __ballot(valid);
     if (!live) return;
-    const uint32_t plan_w0 = tp.h.name_len, plan_w1 = tp.h.copy_off, plan_w2 = tp.h.copy_len;
-    const uint32_t plan_w3 = (uint32_t)tp.h.kind | ((uint32_t)tp.h.tail << 8) | ((uint32_t)tp.h.msep << 16);
+    __builtin_amdgcn_wave_barrier();
+    __threadfence_block();
     const uint32_t n_slots = fmt::record_slots(C.n_b, C.n_m);
+    const uint32_t logP = n_slots <= 16u ? 4u : (n_slots <= 32u ? 5u : 6u), P = 1u << logP, R = kFormatTable >> logP;   // slots per record in the tables; records per batch
+    const uint8_t *safe = text_of[0];   // (what a lane with nothing to load loads)
     for (uint32_t f = 0; f < C.n_files; ++f) {
         uint32_t my_q = 0, my_nb = 0, my_slab = 0, my_par = 0;   // where this lane's record of file f goes
         if (valid) {
@@ -613,185 +635,199 @@ __global__ __launch_bounds__(64 * kFormatWaves) __attribute__((amdgpu_waves_per_
         // "<n>:" and "<n>:N:0:" of this file (wave-uniform; which one a record takes depends on its header)
         uint32_t num0[4], num2[4];
         const uint32_t num0_len = fmt::number_literal(fsg.read_num, 0, num0), num2_len = fmt::number_literal(fsg.read_num, 2, num2);
-        for (uint64_t todo = live; todo;) {
-            const int i = __ffsll((unsigned long long)todo) - 1;   // wave-uniform
-            todo &= todo - 1;
-            fmt::HeaderPlan h;
-            h.name_len = (uint32_t)__builtin_amdgcn_readlane((int)plan_w0, i);
-            h.copy_off = (uint32_t)__builtin_amdgcn_readlane((int)plan_w1, i);
-            h.copy_len = (uint32_t)__builtin_amdgcn_readlane((int)plan_w2, i);
-            const uint32_t w3 = (uint32_t)__builtin_amdgcn_readlane((int)plan_w3, i);
-            h.kind = (uint8_t)w3;
-            h.tail = (uint8_t)(w3 >> 8);
-            h.msep = (uint8_t)(w3 >> 16);
-            h.err = 0;
-            const uint32_t c = (uint32_t)__builtin_amdgcn_readlane((int)s, i) * C.n_files + f;
-            const uint32_t q = (uint32_t)__builtin_amdgcn_readlane((int)my_q, i);
-            FileChunk x;
-            x.rem = x.n_emit = x.blk_base = x.new_rem = 0;
-            x.chunk_only = C.no_carry;
-            x.nb = (uint32_t)__builtin_amdgcn_readlane((int)my_nb, i);
-            x.slab_base = (uint32_t)__builtin_amdgcn_readlane((int)my_slab, i);
-            x.par = (uint32_t)__builtin_amdgcn_readlane((int)my_par, i);
-            // the barcode segments' spans: one lane each
-            if (lane < C.n_b) {
-                const RecView r = recs[C.bseg[lane].input * kFormatGroup + (uint32_t)i];
-                uint32_t lo, hi;
-                fmt::segment_span(C.bseg[lane].offset, C.bseg[lane].length, r.seq_len, &lo, &hi);
-                W.b[lane] = fmt::Span{C.bseg[lane].input, r.seq_off + lo, hi - lo};
-            } else if (lane >= 32u && lane - 32u < C.n_m) {
-                const uint32_t b = lane - 32u;
-                const RecView r = recs[C.mseg[b].input * kFormatGroup + (uint32_t)i];
-                uint32_t lo, hi;
-                fmt::segment_span(C.mseg[b].offset, C.mseg[b].length, r.seq_len, &lo, &hi);
-                W.m[b] = fmt::Span{C.mseg[b].input, r.seq_off + lo, hi - lo};
-            }
+        auto number_byte = [&](bool number0, uint32_t k) -> uint32_t {
+            const uint32_t w = number0 ? (k < 4 ? num0[0] : (k < 8 ? num0[1] : (k < 12 ? num0[2] : num0[3])))
+                                       : (k < 4 ? num2[0] : (k < 8 ? num2[1] : (k < 12 ? num2[2] : num2[3])));
+            return (w >> (8u * (k & 3u))) & 0xFFu;
+        };
+        // the last slot of record rr that starts at or before rq (rq < the record's length): empty slots share their successor's start and lose
+        auto slot_at = [&](uint32_t rr, uint32_t rq) -> uint32_t {
+            const uint32_t *st0 = W.start + rr * (P + 1u);
+            uint32_t p = 0;
+            for (uint32_t step = P >> 1; step; step >>= 1)
+                if (st0[p + step] <= rq) p += step;
+            return p;
+        };
+        uint32_t n_queued = 0;   // wave-uniform
+        // ---- C. the listed dwords, a lane each: byte by byte -- literals, slot boundaries, the ragged ends of a record
+        auto flush_seams = [&]() {
             __builtin_amdgcn_wave_barrier();
             __threadfence_block();
-            const RecView r = recs[fsg.input * kFormatGroup + (uint32_t)i];
-            uint32_t lo, hi;
-            fmt::segment_span(fsg.offset, fsg.length, r.seq_len, &lo, &hi);
-            const uint32_t head_off = recs[(uint32_t)i].head_off;
-            const bool number0 = h.kind == 0;
-            // ---- 1. the slot table: lane s = slot s ----------------------------------------------------------------------
-            fmt::Slot z;
-            z.len = 0; z.kind = fmt::kLiteral; z.input = 0; z.off = 0; z.lit = 0;
-            if (lane < n_slots)
-                z = fmt::record_slot(lane, h, head_off, number0 ? num0_len : num2_len, W.b, C.n_b, W.m, C.n_m,
-                                     fmt::Span{fsg.input, r.seq_off + lo, hi - lo}, fmt::Span{fsg.input, r.qual_off + lo, hi - lo});
-            uint32_t incl = z.len;   // inclusive prefix sum over the lanes
+            for (uint32_t g0 = 0; g0 < n_queued; g0 += 64u) {
+                const bool mine = g0 + lane < n_queued;
+                const uint32_t e = mine ? W.queue[g0 + lane] : 0u;
+                const uint32_t rr = e >> 24, sd = e & 0xFFFFFFu;
+                const RecParam rp = W.rp[rr];
+                const uint32_t a = rp.a, total = rp.total;
+                const bool number0 = (rp.flags & 1u) != 0u;
+                const uint32_t *st0 = W.start + rr * (P + 1u);
+                const uint32_t tb = rr << logP;
+                const uint8_t *sbyte[4];
+                uint32_t slit[4], shave = 0;
+                {
+                    uint32_t p = slot_at(rr, mine && 4u * sd >= a ? 4u * sd - a : 0u);
 #pragma unroll
-            for (int d = 1; d < 64; d <<= 1) {
-                const uint32_t up = __shfl_up(incl, d);
-                if (lane >= (uint32_t)d) incl += up;
-            }
-            const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
-            W.start[lane] = incl - z.len;
-            if (lane == 63) W.start[64] = total;
-            W.src[lane] = z.kind == fmt::kSpan ? z.off : z.lit;
-            W.info[lane] = z.input | (z.kind << 16);
-            __builtin_amdgcn_wave_barrier();
-            __threadfence_block();
-            // One byte of the record: slot p holds record position rq.
-            auto byte_of = [&](uint32_t p, uint32_t rq) -> uint32_t {
-                const uint32_t inf = W.info[p], k = rq - W.start[p], sv = W.src[p];
-                if ((inf >> 16) == fmt::kSpan) return text_of[inf & 0xFFFFu][sv + k];
-                if ((inf >> 16) == fmt::kLiteral) return (sv >> (8u * k)) & 0xFFu;
-                const uint32_t w = number0 ? (k < 4 ? num0[0] : (k < 8 ? num0[1] : (k < 12 ? num0[2] : num0[3])))
-                                           : (k < 4 ? num2[0] : (k < 8 ? num2[1] : (k < 12 ? num2[2] : num2[3])));
-                return (w >> (8u * (k & 3u))) & 0xFFu;
-            };
-            // the last slot that starts at or before rq (rq < total): empty slots share their successor's start and lose
-            auto slot_at = [&](uint32_t rq) -> uint32_t {
-                uint32_t p = 0;
-#pragma unroll
-                for (uint32_t step = 32; step; step >>= 1)
-                    if (p + step < kFormatSlots && W.start[p + step] <= rq) p += step;
-                return p;
-            };
-            const uint32_t a = q & 3u;                    // the record starts `a` bytes into a dword of its block
-            // Where a byte of the record goes: the record begins in block q / kBlock of its file's chunk and may run on into
-            // the next one (both bases are wave-uniform; records longer than a block take file_byte's general arithmetic).
-            const uint32_t kth0 = q / kBlock, in0 = q - kth0 * kBlock;
-            uint8_t *const base0 = block_base(x, c, kth0, persist, slabs), *const base1 = block_base(x, c, kth0 + 1u, persist, slabs);
-            const bool two_blocks_at_most = in0 + total <= 2u * kBlock;
-            auto dst_of = [&](uint32_t pos /* bytes from the dword-aligned start of the record's first dword */) -> uint8_t * {
-                const uint32_t o = in0 - a + pos;   // offset inside block kth0
-                if (two_blocks_at_most) return o < kBlock ? base0 + o : base1 + (o - kBlock);
-                return file_byte(x, c, q - a + pos, persist, slabs);
-            };
-            const uint32_t n_dw = (a + total + 3u) >> 2;  // dwords of the block it touches
-            // A wave's record is a chain of dependent round trips (slot look-ups in LDS, then the text in HBM): the look-ups
-            // and loads of TWO body passes (512 bytes: a whole record of 150-base reads) and of the seams are worked out and
-            // issued together, branch-free -- a lane with nothing to do reads the first input's first bytes -- and only then
-            // anything is stored.  (Taken one after another they cost ~10 us per record: three HBM round trips.)
-            const uint8_t *safe = text_of[0];
-            // ---- 2. the body: dwords that lie inside one slot ---------------------------------------------------------------
-            auto body_plan = [&](uint32_t d, bool &ok, const uint32_t *&aw, uint32_t &mis, uint32_t &p_out, uint32_t &rq_out) {
-                const uint32_t rq = 4u * d - a;           // record position of the dword's first byte (wraps for d = 0, a > 0)
-                const bool inside = d < n_dw && 4u * d >= a && rq + 4u <= total;
-                const uint32_t p = slot_at(inside ? rq : 0u);
-                const uint32_t inf = W.info[p];
-                ok = inside && rq + 4u <= W.start[p + 1] && (inf >> 16) == fmt::kSpan;   // (literals and the digits: the seams)
-                const uint8_t *sp = ok ? text_of[inf & 0xFFFFu] + W.src[p] + (rq - W.start[p]) : safe;
-                mis = (uint32_t)(reinterpret_cast<uintptr_t>(sp) & 3u);
-                aw = reinterpret_cast<const uint32_t *>(sp - mis);
-                p_out = p;
-                rq_out = rq;
-            };
-            auto body_word = [&](bool, uint32_t w0, uint32_t w1, uint32_t mis, uint32_t, uint32_t) -> uint32_t {
-                return __builtin_amdgcn_alignbyte(w1, w0, mis);   // (every text buffer has 64 bytes of slack behind it)
-            };
-            bool ok0, ok1;
-            const uint32_t *aw0, *aw1;
-            uint32_t mis0, mis1, bp0, bp1, brq0, brq1;
-            body_plan(lane, ok0, aw0, mis0, bp0, brq0);
-            body_plan(64u + lane, ok1, aw1, mis1, bp1, brq1);
-            // ---- 3. the seams: the dword of every slot's first byte, the record's first and last dword ----------------------
-            uint32_t rq0 = 0xFFFFFFFFu;                   // a record position inside the dword this lane takes
-            const uint32_t num_slot = 4u + 2u * C.n_m, num_start = W.start[num_slot], num_len = W.start[num_slot + 1u] - num_start;
-            if (lane < n_slots) { if (z.len) rq0 = incl - z.len; }
-            else if (lane == n_slots) rq0 = 0;
-            else if (lane == n_slots + 1u) rq0 = total - 1u;
-            else if (lane < n_slots + 6u) {               // the inner dwords of "<n>:N:0:" (<= 15 bytes: four more dwords at most)
-                const uint32_t off = 4u * (lane - n_slots - 1u);
-                if (off < num_len) rq0 = num_start + off;
-            }
-            const bool seam = rq0 != 0xFFFFFFFFu && total != 0u;
-            const uint32_t sd = seam ? (a + rq0) >> 2 : 0u;
-            const uint8_t *sbyte[4];
-            uint32_t slit[4], shave = 0;
-            {
-                uint32_t p = slot_at(seam && 4u * sd >= a ? 4u * sd - a : 0u);
-#pragma unroll
-                for (uint32_t k = 0; k < 4u; ++k) {
-                    const uint32_t pos = 4u * sd + k;
-                    const bool in = seam && pos >= a && pos - a < total;
-                    const uint32_t rq = in ? pos - a : 0u;
-                    while (in && p + 1u < kFormatSlots && W.start[p + 1] <= rq) ++p;
-                    const uint32_t inf = W.info[p], kk = rq - W.start[p], sv = W.src[p];
-                    const bool span = in && (inf >> 16) == fmt::kSpan;
-                    sbyte[k] = span ? text_of[inf & 0xFFFFu] + sv + kk : safe;
-                    uint32_t lit = (sv >> (8u * (kk & 3u))) & 0xFFu;
-                    if ((inf >> 16) == fmt::kNumber) {
-                        const uint32_t w = number0 ? (kk < 4 ? num0[0] : (kk < 8 ? num0[1] : (kk < 12 ? num0[2] : num0[3])))
-                                                   : (kk < 4 ? num2[0] : (kk < 8 ? num2[1] : (kk < 12 ? num2[2] : num2[3])));
-                        lit = (w >> (8u * (kk & 3u))) & 0xFFu;
+                    for (uint32_t k = 0; k < 4u; ++k) {
+                        const uint32_t pos = 4u * sd + k;
+                        const bool in = mine && pos >= a && pos - a < total;
+                        const uint32_t rq = in ? pos - a : 0u;
+                        while (in && p + 1u < P && st0[p + 1u] <= rq) ++p;
+                        const uint32_t inf = W.info[tb + p], kk = rq - st0[p], sv = W.src[tb + p];
+                        const bool span = in && (inf >> 16) == fmt::kSpan;
+                        sbyte[k] = span ? text_of[inf & 0xFFFFu] + sv + kk : safe;
+                        uint32_t lit = (sv >> (8u * (kk & 3u))) & 0xFFu;
+                        if ((inf >> 16) == fmt::kNumber) lit = number_byte(number0, kk & 15u);
+                        slit[k] = span ? 0x100u : lit;        // 0x100: the byte comes from the text
+                        if (in) shave |= 1u << k;
                     }
-                    slit[k] = span ? 0x100u : lit;        // 0x100: the byte comes from the text
-                    if (in) shave |= 1u << k;
+                }
+                uint32_t sb[4];
+#pragma unroll
+                for (uint32_t k = 0; k < 4u; ++k) sb[k] = *sbyte[k];
+                if (shave) {
+                    uint32_t word = 0;
+#pragma unroll
+                    for (uint32_t k = 0; k < 4u; ++k) word |= ((slit[k] & 0x100u) ? sb[k] : slit[k]) << (8u * k);
+                    uint8_t *dst;
+                    {
+                        const uint32_t o = rp.in0a + 4u * sd;   // offset inside the record's first block
+                        if (rp.flags & 2u) {
+                            dst = o < kBlock ? reinterpret_cast<uint8_t *>(rp.base0) + o : reinterpret_cast<uint8_t *>(rp.base1) + (o - kBlock);
+                        } else {
+                            FileChunk x;
+                            x.rem = x.n_emit = x.blk_base = x.new_rem = 0;
+                            x.chunk_only = C.no_carry;
+                            x.nb = rp.nb; x.slab_base = rp.slab_base; x.par = rp.par;
+                            dst = file_byte(x, rp.c, rp.q - a + 4u * sd, persist, slabs);
+                        }
+                    }
+                    if (shave == 15u) {
+                        *reinterpret_cast<uint32_t *>(dst) = word;
+                    } else {
+#pragma unroll
+                        for (uint32_t k = 0; k < 4u; ++k)
+                            if (shave & (1u << k)) dst[k] = (uint8_t)(word >> (8u * k));
+                    }
                 }
             }
-            // every load of the record, then the stores
-            const uint32_t w00 = aw0[0], w01 = aw0[1], w10 = aw1[0], w11 = aw1[1];
-            uint32_t sb[4];
-#pragma unroll
-            for (uint32_t k = 0; k < 4u; ++k) sb[k] = *sbyte[k];
-            if (ok0) *reinterpret_cast<uint32_t *>(dst_of(4u * lane)) = body_word(ok0, w00, w01, mis0, bp0, brq0);
-            if (ok1) *reinterpret_cast<uint32_t *>(dst_of(4u * (64u + lane))) = body_word(ok1, w10, w11, mis1, bp1, brq1);
-            if (shave) {
-                uint32_t word = 0;
-#pragma unroll
-                for (uint32_t k = 0; k < 4u; ++k) word |= ((slit[k] & 0x100u) ? sb[k] : slit[k]) << (8u * k);
-                uint8_t *dst = dst_of(4u * sd);
-                if (shave == 15u) {
-                    *reinterpret_cast<uint32_t *>(dst) = word;
-                } else {
-#pragma unroll
-                    for (uint32_t k = 0; k < 4u; ++k)
-                        if (shave & (1u << k)) dst[k] = (uint8_t)(word >> (8u * k));
+            n_queued = 0;
+            __builtin_amdgcn_wave_barrier();
+        };
+        for (uint32_t rb = 0; rb < kFormatGroup; rb += R) {
+            const uint64_t batch = (live >> rb) & ((R < 64u ? (1ull << R) : 0ull) - 1ull);
+            if (!batch) continue;
+            // ---- A. the slot tables of the batch: lane = (record, slot) ----------------------------------------------------
+            for (uint32_t pass = 0; pass < kFormatTable / 64u; ++pass) {
+                const uint32_t idx = pass * 64u + lane, rr = idx >> logP, sl = idx & (P - 1u), r = rb + rr;
+                const bool on = ((batch >> rr) & 1ull) != 0ull && sl < n_slots;
+                fmt::Slot z;
+                z.len = 0; z.kind = fmt::kLiteral; z.input = 0; z.off = 0; z.lit = 0;
+                if (on) {
+                    fmt::HeaderPlan h;
+                    h.name_len = W.planw[r][0];
+                    h.copy_off = W.planw[r][1];
+                    h.copy_len = W.planw[r][2];
+                    const uint32_t w3 = W.planw[r][3];
+                    h.kind = (uint8_t)w3;
+                    h.tail = (uint8_t)(w3 >> 8);
+                    h.msep = (uint8_t)(w3 >> 16);
+                    h.err = 0;
+                    auto seg_span = [&](const fmt::SegPos &sp) -> fmt::Span {
+                        const RecView v = recs[sp.input * kFormatGroup + r];
+                        uint32_t lo, hi;
+                        fmt::segment_span(sp.offset, sp.length, v.seq_len, &lo, &hi);
+                        return fmt::Span{sp.input, v.seq_off + lo, hi - lo};
+                    };
+                    const RecView v = recs[fsg.input * kFormatGroup + r];
+                    uint32_t lo, hi;
+                    fmt::segment_span(fsg.offset, fsg.length, v.seq_len, &lo, &hi);
+                    z = fmt::record_slot_with(sl, h, recs[r].head_off, h.kind == 0 ? num0_len : num2_len,
+                                              [&](uint32_t i) { return seg_span(bseg_lds[i]); }, C.n_b, [&](uint32_t i) { return seg_span(mseg_lds[i]); }, C.n_m,
+                                              fmt::Span{fsg.input, v.seq_off + lo, hi - lo}, fmt::Span{fsg.input, v.qual_off + lo, hi - lo});
                 }
-            }
-            // records of more than 512 bytes (long reads): the rest of the body, 256 bytes per pass
-            for (uint32_t d0 = 128u; d0 < n_dw; d0 += 64u) {
-                bool ok;
-                const uint32_t *aw;
-                uint32_t mis, bp, brq;
-                body_plan(d0 + lane, ok, aw, mis, bp, brq);
-                const uint32_t w0 = aw[0], w1 = aw[1];
-                if (ok) *reinterpret_cast<uint32_t *>(dst_of(4u * (d0 + lane))) = body_word(ok, w0, w1, mis, bp, brq);
+                uint32_t incl = z.len;   // inclusive prefix sum over the lanes of one record
+                for (uint32_t d = 1; d < P; d <<= 1) {
+                    const uint32_t up = __shfl_up(incl, d);
+                    if (sl >= d) incl += up;
+                }
+                W.start[rr * (P + 1u) + sl] = incl - z.len;
+                if (sl == P - 1u) W.start[rr * (P + 1u) + P] = incl;
+                W.src[idx] = z.kind == fmt::kSpan ? z.off : z.lit;
+                W.info[idx] = z.input | (z.kind << 16);
             }
             __builtin_amdgcn_wave_barrier();
+            __threadfence_block();
+            // ---- B. the bodies, record by record --------------------------------------------------------------------------
+            for (uint64_t todo = batch; todo;) {
+                const uint32_t rr = (uint32_t)(__ffsll((unsigned long long)todo) - 1);   // wave-uniform
+                todo &= todo - 1;
+                const int i = (int)(rb + rr);
+                const uint32_t c = (uint32_t)__builtin_amdgcn_readlane((int)s, i) * C.n_files + f;
+                const uint32_t q = (uint32_t)__builtin_amdgcn_readlane((int)my_q, i);
+                FileChunk x;
+                x.rem = x.n_emit = x.blk_base = x.new_rem = 0;
+                x.chunk_only = C.no_carry;
+                x.nb = (uint32_t)__builtin_amdgcn_readlane((int)my_nb, i);
+                x.slab_base = (uint32_t)__builtin_amdgcn_readlane((int)my_slab, i);
+                x.par = (uint32_t)__builtin_amdgcn_readlane((int)my_par, i);
+                const uint32_t *st0 = W.start + rr * (P + 1u);
+                const uint32_t tb = rr << logP;
+                const uint32_t total = (uint32_t)__builtin_amdgcn_readfirstlane((int)st0[P]);
+                const uint32_t a = q & 3u;                    // the record starts `a` bytes into a dword of its block
+                // Where a byte of the record goes: the record begins in block q / kBlock of its file's chunk and may run on into
+                // the next one (both bases are wave-uniform; records longer than a block take file_byte's general arithmetic).
+                const uint32_t kth0 = q / kBlock, in0 = q - kth0 * kBlock;
+                uint8_t *const base0 = block_base(x, c, kth0, persist, slabs), *const base1 = block_base(x, c, kth0 + 1u, persist, slabs);
+                const bool two_blocks_at_most = in0 + total <= 2u * kBlock;
+                if (lane == 0) {
+                    RecParam rp;
+                    rp.base0 = reinterpret_cast<unsigned long long>(base0);
+                    rp.base1 = reinterpret_cast<unsigned long long>(base1);
+                    rp.in0a = in0 - a;
+                    rp.a = a;
+                    rp.total = total;
+                    rp.flags = ((W.planw[i][3] & 0xFFu) == 0u ? 1u : 0u) | (two_blocks_at_most ? 2u : 0u);
+                    rp.q = q; rp.c = c; rp.nb = x.nb; rp.slab_base = x.slab_base; rp.par = x.par; rp.pad = 0;
+                    W.rp[rr] = rp;
+                }
+                auto dst_of = [&](uint32_t pos /* bytes from the dword-aligned start of the record's first dword */) -> uint8_t * {
+                    const uint32_t o = in0 - a + pos;   // offset inside block kth0
+                    if (two_blocks_at_most) return o < kBlock ? base0 + o : base1 + (o - kBlock);
+                    return file_byte(x, c, q - a + pos, persist, slabs);
+                };
+                const uint32_t n_dw = (a + total + 3u) >> 2;  // dwords of the block it touches
+                // a dword that lies inside one span slot is copied here; any other dword of the record is listed
+                auto body_plan = [&](uint32_t d, bool &ok, bool &seam, const uint32_t *&aw, uint32_t &mis) {
+                    const uint32_t rq = 4u * d - a;           // record position of the dword's first byte (wraps for d = 0, a > 0)
+                    const bool inside = d < n_dw && 4u * d >= a && rq + 4u <= total;
+                    const uint32_t p = slot_at(rr, inside ? rq : 0u);
+                    const uint32_t inf = W.info[tb + p];
+                    ok = inside && rq + 4u <= st0[p + 1u] && (inf >> 16) == fmt::kSpan;
+                    seam = d < n_dw && !ok;
+                    const uint8_t *sp = ok ? text_of[inf & 0xFFFFu] + W.src[tb + p] + (rq - st0[p]) : safe;
+                    mis = (uint32_t)(reinterpret_cast<uintptr_t>(sp) & 3u);
+                    aw = reinterpret_cast<const uint32_t *>(sp - mis);
+                };
+                auto list = [&](bool seam, uint32_t d) {
+                    const uint64_t m = __ballot(seam);
+                    if (seam) W.queue[n_queued + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = (rr << 24) | d;
+                    n_queued += (uint32_t)__popcll(m);
+                };
+                for (uint32_t d0 = 0; d0 < n_dw; d0 += 128u) {   // 512 bytes per pass: a whole record of 150-base reads
+                    bool ok0, ok1, seam0, seam1;
+                    const uint32_t *aw0, *aw1;
+                    uint32_t mis0, mis1;
+                    body_plan(d0 + lane, ok0, seam0, aw0, mis0);
+                    body_plan(d0 + 64u + lane, ok1, seam1, aw1, mis1);
+                    const uint32_t w00 = aw0[0], w01 = aw0[1], w10 = aw1[0], w11 = aw1[1];   // (every text buffer has 64 bytes of slack behind it)
+                    list(seam0, d0 + lane);
+                    list(seam1, d0 + 64u + lane);
+                    if (ok0) *reinterpret_cast<uint32_t *>(dst_of(4u * (d0 + lane))) = __builtin_amdgcn_alignbyte(w01, w00, mis0);
+                    if (ok1) *reinterpret_cast<uint32_t *>(dst_of(4u * (d0 + 64u + lane))) = __builtin_amdgcn_alignbyte(w11, w10, mis1);
+                    if (n_queued + 128u > kSeamQueue) flush_seams();
+                }
+            }
+            flush_seams();
         }
     }
 }

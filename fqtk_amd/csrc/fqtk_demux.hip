@@ -326,7 +326,7 @@ int fqtk_demuxer_create(fqtk_matcher *m, const fqtk_demux_config *cfg, fqtk_demu
         if (b.length >= 0) C.fixed_bc_len += (uint32_t)b.length; else C.variable_bc = 1;
     }
     for (const auto &b : by_type[2]) C.mseg[C.n_m++] = fqtk::fmt::SegPos{b.input, b.offset, b.length};
-    if (fqtk::fmt::max_pieces(C.n_b, C.n_m) > (uint32_t)fqtk::fmt::kMaxPieces || fqtk::fmt::record_slots(C.n_b, C.n_m) + 6u > kFormatSlots) {
+    if (fqtk::fmt::max_pieces(C.n_b, C.n_m) > (uint32_t)fqtk::fmt::kMaxPieces || fqtk::fmt::record_slots(C.n_b, C.n_m) > kFormatSlots) {
         delete d;
         return set_error(FQTK_EINVAL, "too many barcode segments for one record (sample + molecular: at most 23)");
     }

@@ -172,8 +172,11 @@ FQTK_HD inline uint32_t number_literal(uint32_t read_num, uint32_t header_kind, 
     for (uint32_t i = 0; i < n; ++i) w[i >> 2] |= (uint32_t)d[i] << (8 * (i & 3u));
     return n;
 }
-FQTK_HD inline Slot record_slot(uint32_t s, const HeaderPlan &p, uint32_t head_off, uint32_t number_len,
-                                const Span *bsegs, uint32_t nb, const Span *msegs, uint32_t nm, const Span &bases, const Span &quals) {
+// (bseg_of(i) / mseg_of(i): the span of sample / molecular barcode segment i -- from an array, or worked out where it is asked for:
+//  k_format's lanes each take one slot of one of sixteen records and have no room for sixteen arrays of spans)
+template <typename BFn, typename MFn>
+FQTK_HD inline Slot record_slot_with(uint32_t s, const HeaderPlan &p, uint32_t head_off, uint32_t number_len, BFn bseg_of, uint32_t nb, MFn mseg_of, uint32_t nm,
+                                     const Span &bases, const Span &quals) {
     Slot z;
     z.len = 0; z.kind = kLiteral; z.input = 0; z.off = 0; z.lit = 0;
     auto lit1 = [&](uint32_t byte, bool on) { z.kind = kLiteral; z.lit = byte; z.len = on ? 1u : 0u; };
@@ -184,20 +187,24 @@ FQTK_HD inline Slot record_slot(uint32_t s, const HeaderPlan &p, uint32_t head_o
     else if (s == 2) lit1(p.msep, nm != 0);
     else if (s < b1) {
         const uint32_t i = (s - 3u) >> 1;
-        if (((s - 3u) & 1u) == 0) lit1('+', i != 0); else span(msegs[i].input, msegs[i].off, msegs[i].len);
+        if (((s - 3u) & 1u) == 0) lit1('+', i != 0); else { const Span m = mseg_of(i); span(m.input, m.off, m.len); }
     } else if (s == b1) lit1(' ', true);
     else if (s == b1 + 1u) { z.kind = kNumber; z.len = p.kind != 1 ? number_len : 0u; }
     else if (s == b1 + 2u) span(0, head_off + p.copy_off, p.kind != 0 ? p.copy_len : 0u);
     else if (s == b1 + 3u) lit1(p.tail, p.kind != 0 && p.tail != 0);
     else if (s < b3) {
         const uint32_t i = (s - b2) >> 1;
-        if (((s - b2) & 1u) == 0) lit1('+', i != 0); else span(bsegs[i].input, bsegs[i].off, bsegs[i].len);
+        if (((s - b2) & 1u) == 0) lit1('+', i != 0); else { const Span b = bseg_of(i); span(b.input, b.off, b.len); }
     } else if (s == b3) lit1('\n', true);
     else if (s == b3 + 1u) span(bases.input, bases.off, bases.len);
     else if (s == b3 + 2u) { z.kind = kLiteral; z.lit = (uint32_t)'\n' | ((uint32_t)'+' << 8) | ((uint32_t)'\n' << 16); z.len = 3; }
     else if (s == b3 + 3u) span(quals.input, quals.off, quals.len);
     else if (s == b3 + 4u) lit1('\n', true);
     return z;
+}
+FQTK_HD inline Slot record_slot(uint32_t s, const HeaderPlan &p, uint32_t head_off, uint32_t number_len,
+                                const Span *bsegs, uint32_t nb, const Span *msegs, uint32_t nm, const Span &bases, const Span &quals) {
+    return record_slot_with(s, p, head_off, number_len, [&](uint32_t i) { return bsegs[i]; }, nb, [&](uint32_t i) { return msegs[i]; }, nm, bases, quals);
 }
 
 // Length of that record from sums alone (the placement kernel sizes every record of a chunk before any is written):

@@ -102,25 +102,37 @@ def one(rng, it, tmp):
                 s = s[: max(0, len(s) - int(nprng.integers(1, 4)))]
             reads[i][t] = s
     files = []
-    kind = rng.choice(["plain", "gz", "gz", "bgzf", "bgzf"])   # bgzf: members inflated on the device (fqtk_demuxer_feed), cut into chunks by line counts
+    # bgzf: members inflated on the device (fqtk_demuxer_feed), cut into chunks by line counts; mixed: a BGZF file with ordinary gzip members
+    # in it (`cat a.bgz b.gz`): the feeder decodes those as serial streams, in chunks, between its runs of BGZF members
+    kind = rng.choice(["plain", "gz", "gz", "bgzf", "bgzf", "mixed"])
     gz = kind == "gz"
     member = rng.choice([300, 4000, 65280])            # text bytes per BGZF member: members and chunks never line up
     for i in range(n_inputs):
         path = os.path.join(tmp, f"in{it}_{i}.fastq" + (".gz" if kind != "plain" else ""))
+        gz = kind == "gz"
         text = "".join(f"@q_{t} {i + 1}:N:0:0\n{reads[i][t]}\n+\n{'I' * len(reads[i][t])}\n" for t in range(n))
-        if kind == "bgzf":
+        if kind in ("bgzf", "mixed"):
             import struct
             import zlib
             raw = text.encode()
             if raw and rng.random() < 0.3:
                 raw = raw[:-1]                          # last line without a newline
             data = b""
-            for o in range(0, len(raw), member):
+            o = 0
+            while o < len(raw):
+                if kind == "mixed" and o and rng.random() < 0.15:   # an ordinary gzip member of up to 40 KB of text (any level; a sync flush now and then)
+                    piece = raw[o:o + rng.randint(1, 40000)]
+                    c = zlib.compressobj(rng.choice([0, 1, 6, 9]), zlib.DEFLATED, 31)
+                    half = len(piece) // 2
+                    data += c.compress(piece[:half]) + (c.flush(zlib.Z_SYNC_FLUSH) if rng.random() < 0.5 else b"") + c.compress(piece[half:]) + c.flush()
+                    o += len(piece)
+                    continue
                 piece = raw[o:o + member]
                 c = zlib.compressobj(rng.choice([0, 1, 6, 9]), zlib.DEFLATED, -15)
                 payload = c.compress(piece) + c.flush()
                 data += (b"\x1f\x8b\x08\x04\0\0\0\0\0\xff\x06\0BC\x02\0" + struct.pack("<H", 18 + len(payload) + 8 - 1) + payload +
                          struct.pack("<II", zlib.crc32(piece), len(piece)))
+                o += len(piece)
             data += bytes.fromhex("1f8b08040000000000ff0600424302001b0003000000000000000000")
             open(path, "wb").write(data)
         else:
@@ -145,7 +157,15 @@ def one(rng, it, tmp):
         env["FQTK_GZ_DEVICE_CHUNKS"] = str(rng.choice([3, 20, 448]))
         if rng.random() < 0.5:
             env["FQTK_FED_ARENA_MIN"] = str(rng.choice([20000, 300000]))
-    if kind == "bgzf" and rng.random() < 0.5:
+    if kind in ("gz", "mixed"):
+        if rng.random() < 0.3:
+            env["FQTK_GZ_FORCE_FALLBACK"] = str(rng.choice([1, 2, 3]))   # every k-th stretch by the host's sequential decoder
+        if rng.random() < 0.3:
+            env["FQTK_GZ_DEVICE_SYMS"] = str(rng.choice([1, 2]))         # chunks run out of room for symbols and end at a block boundary
+        if kind == "mixed":
+            env["FQTK_GZ_DEVICE_CHUNK_KB"] = str(rng.choice([4, 16, 64]))
+            env["FQTK_GZ_DEVICE_CHUNKS"] = str(rng.choice([2, 20, 448]))
+    if kind in ("bgzf", "mixed") and rng.random() < 0.5:
         env["FQTK_FED_ARENA_MIN"] = str(rng.choice([20000, 300000]))   # the fed text changes arena every few chunks
     if EXE.endswith(".thread"):
         env["TSAN_OPTIONS"] = "suppressions=" + os.path.join(ROOT, "tools", "tsan.supp") + ":report_signal_unsafe=0:second_deadlock_stack=1"
