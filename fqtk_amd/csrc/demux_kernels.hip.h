@@ -538,20 +538,25 @@ __global__ __launch_bounds__(256) void k_descs(DevConfig C, const FileChunk *fc,
 // work is the same for all of them:
 //   A. the SLOT TABLES (record_format.hpp: record_slot_with) of all sixteen records at once -- a lane per (record, slot): the slot in
 //      closed form from the template's plan, a prefix sum over the lanes of one record places it; tables in LDS (start, source, kind);
-//   B. the BODY, record by record (its place in the file's block is wave-uniform): every lane takes whole dwords of the block that lie
-//      inside ONE span slot -- a binary search over the slot starts, two aligned dwords of the source, one v_alignbyte -- two dwords
-//      per lane and pass, loads before stores.  Dwords that are NOT of that kind -- they hold a literal, straddle two slots, or the
-//      record begins / ends inside them: about one in six -- are only LISTED (ballot, a queue in LDS);
+//   B. the BODY: a lane per dword of ANY of the sixteen records (their dwords counted through: a search over sixteen prefix sums says
+//      whose a lane's is) -- dwords of a file's block that lie inside ONE span slot: a binary search over the record's slot starts, two
+//      aligned dwords of the source, one v_alignbyte; two dwords per lane and pass, loads before stores, no pass depends on another.
+//      Dwords that are NOT of that kind -- they hold a literal, straddle two slots, or the record begins / ends inside them: about
+//      one in six -- are only LISTED (ballot, a queue in LDS);
 //   C. the SEAMS of all sixteen records, a lane per listed dword, byte by byte.
-// Round 4 did A and C per record -- a wave pass each in which sixteen to twenty-five lanes had something to do: 549 VALU + 416 SALU
-// wave-instructions per record, 672 us per chunk of 262 144 templates (the second-largest device stage of a run); round 3 offered every
+// Round 4 did all three per record -- passes in which sixteen to twenty-five lanes had something to do, and a chain of dependent LDS and HBM
+// round trips per record that four waves per SIMD did not hide: 549 VALU + 416 SALU wave-instructions per record, 672 us per chunk of
+// 262 144 templates (the second-largest device stage of a run); round 3 offered every
 // piece to all lanes (740 us); before that one lane listed the pieces (805 us).
 // Records of more slots than sixteen (more than two barcode segments) go through in groups of eight or four: the tables hold 256 slots.
 constexpr int kFormatWaves = 4;
 constexpr uint32_t kFormatGroup = 16;
 constexpr uint32_t kFormatSlots = 64;     // record_slots(nb, nm) <= 64: a lane per slot of one record at least (fqtk_demuxer_create)
 constexpr uint32_t kFormatTable = 256;    // slots in the tables: 16 records x 16 slots, 8 x 32 or 4 x 64
-constexpr uint32_t kSeamQueue = 512;      // listed dwords (flushed when fewer than 128 places are free)
+#ifndef FQTK_FORMAT_QUEUE
+#define FQTK_FORMAT_QUEUE 512
+#endif
+constexpr uint32_t kSeamQueue = FQTK_FORMAT_QUEUE;      // listed dwords (flushed when fewer than 128 places are free)
 struct RecParam {                         // where a record of the batch in hand goes (phase C: a lane per listed dword looks its record up)
     unsigned long long base0, base1;      // the block its first byte lies in, and the next one
     uint32_t in0a;                        // offset in that block of the dword-aligned start of its first dword
@@ -560,7 +565,7 @@ struct RecParam {                         // where a record of the batch in hand
 };
 struct WaveScratch {
     uint32_t planw[kFormatGroup][4];      // the templates' header plans
-    uint32_t start[kFormatTable + kFormatGroup];   // [record][P + 1]: byte offset of every slot in its record; [P] = the record's length
+    uint32_t start[kFormatTable + 4 * kFormatGroup];   // [record][P + 4] (rows 16-byte aligned): byte offset of every slot in its record; [P] = the record's length
     uint32_t src[kFormatTable];           // span: offset in its input's text; literal: the bytes
     uint32_t info[kFormatTable];          // input | kind << 16
     RecParam rp[kFormatGroup];
@@ -571,7 +576,11 @@ constexpr size_t kFormatBlockHead = FQTK_DEMUX_MAX_INPUTS * sizeof(uint64_t) + 2
 __host__ __device__ constexpr size_t format_wave_bytes(uint32_t n_inputs) { return (sizeof(WaveScratch) + (size_t)n_inputs * kFormatGroup * sizeof(RecView) + 15u) & ~(size_t)15u; }
 __host__ __device__ constexpr size_t format_block_bytes(uint32_t n_inputs) { return ((kFormatBlockHead + 15u) & ~(size_t)15u) + kFormatWaves * format_wave_bytes(n_inputs); }
 
-__global__ __launch_bounds__(64 * kFormatWaves) void k_format(TextSet T, DevConfig C, uint32_t n, const uint32_t *res, const uint8_t *skip,
+#ifndef FQTK_FORMAT_OCC   // registers capped so that that many wavefronts fit a SIMD (tools/ab_format.sh: 3 -> 4 took the kernel from 523 to 408 us; 5 and 6 spill)
+#define FQTK_FORMAT_OCC 4
+#endif
+#define FQTK_FORMAT_OCCUPANCY __attribute__((amdgpu_waves_per_eu(FQTK_FORMAT_OCC, 8)))
+__global__ __launch_bounds__(64 * kFormatWaves) FQTK_FORMAT_OCCUPANCY void k_format(TextSet T, DevConfig C, uint32_t n, const uint32_t *res, const uint8_t *skip,
                                                                const TemplatePlan *plans, const uint32_t *rec_off, const uint32_t *tile_tot,
                                                                const FileChunk *fc, uint8_t *persist, uint8_t *slabs, const ChunkStatus *st) {
     if (st->err_key != kNoError) return;
@@ -620,7 +629,7 @@ __global__ __launch_bounds__(64 * kFormatWaves) void k_format(TextSet T, DevConf
     __builtin_amdgcn_wave_barrier();
     __threadfence_block();
     const uint32_t n_slots = fmt::record_slots(C.n_b, C.n_m);
-    const uint32_t logP = n_slots <= 16u ? 4u : (n_slots <= 32u ? 5u : 6u), P = 1u << logP, R = kFormatTable >> logP;   // slots per record in the tables; records per batch
+    const uint32_t logP = n_slots <= 16u ? 4u : (n_slots <= 32u ? 5u : 6u), P = 1u << logP, R = kFormatTable >> logP, PS = P + 4u;   // slots per record in the tables; records per batch; a record's row of starts
     const uint8_t *safe = text_of[0];   // (what a lane with nothing to load loads)
     for (uint32_t f = 0; f < C.n_files; ++f) {
         uint32_t my_q = 0, my_nb = 0, my_slab = 0, my_par = 0;   // where this lane's record of file f goes
@@ -642,7 +651,7 @@ __global__ __launch_bounds__(64 * kFormatWaves) void k_format(TextSet T, DevConf
         };
         // the last slot of record rr that starts at or before rq (rq < the record's length): empty slots share their successor's start and lose
         auto slot_at = [&](uint32_t rr, uint32_t rq) -> uint32_t {
-            const uint32_t *st0 = W.start + rr * (P + 1u);
+            const uint32_t *st0 = W.start + rr * PS;
             uint32_t p = 0;
             for (uint32_t step = P >> 1; step; step >>= 1)
                 if (st0[p + step] <= rq) p += step;
@@ -660,7 +669,7 @@ __global__ __launch_bounds__(64 * kFormatWaves) void k_format(TextSet T, DevConf
                 const RecParam rp = W.rp[rr];
                 const uint32_t a = rp.a, total = rp.total;
                 const bool number0 = (rp.flags & 1u) != 0u;
-                const uint32_t *st0 = W.start + rr * (P + 1u);
+                const uint32_t *st0 = W.start + rr * PS;
                 const uint32_t tb = rr << logP;
                 const uint8_t *sbyte[4];
                 uint32_t slit[4], shave = 0;
@@ -750,82 +759,122 @@ __global__ __launch_bounds__(64 * kFormatWaves) void k_format(TextSet T, DevConf
                     const uint32_t up = __shfl_up(incl, d);
                     if (sl >= d) incl += up;
                 }
-                W.start[rr * (P + 1u) + sl] = incl - z.len;
-                if (sl == P - 1u) W.start[rr * (P + 1u) + P] = incl;
+                W.start[rr * PS + sl] = incl - z.len;
+                if (sl == P - 1u) W.start[rr * PS + P] = incl;
                 W.src[idx] = z.kind == fmt::kSpan ? z.off : z.lit;
                 W.info[idx] = z.input | (z.kind << 16);
             }
             __builtin_amdgcn_wave_barrier();
             __threadfence_block();
-            // ---- B. the bodies, record by record --------------------------------------------------------------------------
-            for (uint64_t todo = batch; todo;) {
-                const uint32_t rr = (uint32_t)(__ffsll((unsigned long long)todo) - 1);   // wave-uniform
-                todo &= todo - 1;
-                const int i = (int)(rb + rr);
-                const uint32_t c = (uint32_t)__builtin_amdgcn_readlane((int)s, i) * C.n_files + f;
-                const uint32_t q = (uint32_t)__builtin_amdgcn_readlane((int)my_q, i);
+            // ---- B. the bodies of the batch: a lane per dword of any of its records -----------------------------------------
+            // where the records go (the lanes that hold their templates work it out, each for its own), and how many dwords each touches
+            uint32_t my_ndw = 0;
+            if (lane >= rb && lane < rb + R && ((live >> lane) & 1ull)) {
+                const uint32_t rr = lane - rb;
+                const uint32_t c = s * C.n_files + f, q = my_q;
                 FileChunk x;
                 x.rem = x.n_emit = x.blk_base = x.new_rem = 0;
                 x.chunk_only = C.no_carry;
-                x.nb = (uint32_t)__builtin_amdgcn_readlane((int)my_nb, i);
-                x.slab_base = (uint32_t)__builtin_amdgcn_readlane((int)my_slab, i);
-                x.par = (uint32_t)__builtin_amdgcn_readlane((int)my_par, i);
-                const uint32_t *st0 = W.start + rr * (P + 1u);
-                const uint32_t tb = rr << logP;
-                const uint32_t total = (uint32_t)__builtin_amdgcn_readfirstlane((int)st0[P]);
+                x.nb = my_nb; x.slab_base = my_slab; x.par = my_par;
+                const uint32_t total = W.start[rr * PS + P];
                 const uint32_t a = q & 3u;                    // the record starts `a` bytes into a dword of its block
-                // Where a byte of the record goes: the record begins in block q / kBlock of its file's chunk and may run on into
-                // the next one (both bases are wave-uniform; records longer than a block take file_byte's general arithmetic).
+                // the record begins in block q / kBlock of its file's chunk and may run on into the next one (records longer than a
+                // block take file_byte's general arithmetic)
                 const uint32_t kth0 = q / kBlock, in0 = q - kth0 * kBlock;
-                uint8_t *const base0 = block_base(x, c, kth0, persist, slabs), *const base1 = block_base(x, c, kth0 + 1u, persist, slabs);
-                const bool two_blocks_at_most = in0 + total <= 2u * kBlock;
-                if (lane == 0) {
-                    RecParam rp;
-                    rp.base0 = reinterpret_cast<unsigned long long>(base0);
-                    rp.base1 = reinterpret_cast<unsigned long long>(base1);
-                    rp.in0a = in0 - a;
-                    rp.a = a;
-                    rp.total = total;
-                    rp.flags = ((W.planw[i][3] & 0xFFu) == 0u ? 1u : 0u) | (two_blocks_at_most ? 2u : 0u);
-                    rp.q = q; rp.c = c; rp.nb = x.nb; rp.slab_base = x.slab_base; rp.par = x.par; rp.pad = 0;
-                    W.rp[rr] = rp;
+                RecParam rp;
+                rp.base0 = reinterpret_cast<unsigned long long>(block_base(x, c, kth0, persist, slabs));
+                rp.base1 = reinterpret_cast<unsigned long long>(block_base(x, c, kth0 + 1u, persist, slabs));
+                rp.in0a = in0 - a;
+                rp.a = a;
+                rp.total = total;
+                rp.flags = ((W.planw[lane][3] & 0xFFu) == 0u ? 1u : 0u) | (in0 + total <= 2u * kBlock ? 2u : 0u);
+                rp.q = q; rp.c = c; rp.nb = x.nb; rp.slab_base = x.slab_base; rp.par = x.par; rp.pad = 0;
+                W.rp[rr] = rp;
+                my_ndw = total ? (a + total + 3u) >> 2 : 0u;  // dwords of the block it touches
+            }
+            uint32_t dw_incl = my_ndw;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) {
+                const uint32_t up = __shfl_up(dw_incl, d);
+                if (lane >= (uint32_t)d) dw_incl += up;
+            }
+            const uint32_t dw_total = (uint32_t)__builtin_amdgcn_readlane((int)dw_incl, 63);
+            // first dword of every record of the batch among the batch's dwords: wave-uniform, kept in scalar registers
+            uint32_t dwb[kFormatGroup];
+#pragma unroll
+            for (uint32_t k = 0; k < kFormatGroup; ++k)
+                dwb[k] = k < R ? (uint32_t)__builtin_amdgcn_readlane((int)(dw_incl - my_ndw), (int)(rb + (k < R ? k : 0u))) : 0xFFFFFFFFu;
+            __builtin_amdgcn_wave_barrier();
+            __threadfence_block();
+            // a dword that lies inside one span slot is copied here; any other dword of a record is listed
+            auto body_plan = [&](uint32_t g, bool &ok, bool &seam, const uint32_t *&aw, uint32_t &mis, uint8_t *&dst, uint32_t &entry) {
+                // No look-up here waits for another of its kind (a wave waited 62 % of its cycles in the version that searched LDS step by
+                // step): whose dword it is comes from sixteen scalar compares, its slot from ONE read of the record's sixteen starts.
+                const bool have = g < dw_total;
+                const uint32_t gq = have ? g : 0u;
+                uint32_t rr = 0, first = 0;                   // the last record whose first dword is at or before g (empty ones share their successor's and lose)
+#pragma unroll
+                for (uint32_t k = 1; k < kFormatGroup; ++k) {
+                    const bool at = dwb[k] <= gq;
+                    rr += at ? 1u : 0u;
+                    first = at ? dwb[k] : first;
                 }
-                auto dst_of = [&](uint32_t pos /* bytes from the dword-aligned start of the record's first dword */) -> uint8_t * {
-                    const uint32_t o = in0 - a + pos;   // offset inside block kth0
-                    if (two_blocks_at_most) return o < kBlock ? base0 + o : base1 + (o - kBlock);
-                    return file_byte(x, c, q - a + pos, persist, slabs);
-                };
-                const uint32_t n_dw = (a + total + 3u) >> 2;  // dwords of the block it touches
-                // a dword that lies inside one span slot is copied here; any other dword of the record is listed
-                auto body_plan = [&](uint32_t d, bool &ok, bool &seam, const uint32_t *&aw, uint32_t &mis) {
-                    const uint32_t rq = 4u * d - a;           // record position of the dword's first byte (wraps for d = 0, a > 0)
-                    const bool inside = d < n_dw && 4u * d >= a && rq + 4u <= total;
-                    const uint32_t p = slot_at(rr, inside ? rq : 0u);
-                    const uint32_t inf = W.info[tb + p];
-                    ok = inside && rq + 4u <= st0[p + 1u] && (inf >> 16) == fmt::kSpan;
-                    seam = d < n_dw && !ok;
-                    const uint8_t *sp = ok ? text_of[inf & 0xFFFFu] + W.src[tb + p] + (rq - st0[p]) : safe;
-                    mis = (uint32_t)(reinterpret_cast<uintptr_t>(sp) & 3u);
-                    aw = reinterpret_cast<const uint32_t *>(sp - mis);
-                };
-                auto list = [&](bool seam, uint32_t d) {
-                    const uint64_t m = __ballot(seam);
-                    if (seam) W.queue[n_queued + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = (rr << 24) | d;
-                    n_queued += (uint32_t)__popcll(m);
-                };
-                for (uint32_t d0 = 0; d0 < n_dw; d0 += 128u) {   // 512 bytes per pass: a whole record of 150-base reads
-                    bool ok0, ok1, seam0, seam1;
-                    const uint32_t *aw0, *aw1;
-                    uint32_t mis0, mis1;
-                    body_plan(d0 + lane, ok0, seam0, aw0, mis0);
-                    body_plan(d0 + 64u + lane, ok1, seam1, aw1, mis1);
-                    const uint32_t w00 = aw0[0], w01 = aw0[1], w10 = aw1[0], w11 = aw1[1];   // (every text buffer has 64 bytes of slack behind it)
-                    list(seam0, d0 + lane);
-                    list(seam1, d0 + 64u + lane);
-                    if (ok0) *reinterpret_cast<uint32_t *>(dst_of(4u * (d0 + lane))) = __builtin_amdgcn_alignbyte(w01, w00, mis0);
-                    if (ok1) *reinterpret_cast<uint32_t *>(dst_of(4u * (d0 + 64u + lane))) = __builtin_amdgcn_alignbyte(w11, w10, mis1);
-                    if (n_queued + 128u > kSeamQueue) flush_seams();
+                const uint32_t d = gq - first;
+                const RecParam &rp = W.rp[rr];
+                const uint32_t a = rp.a, total = rp.total, flags = rp.flags;
+                const uint32_t *st0 = W.start + rr * PS;
+                const uint32_t tb = rr << logP;
+                const uint32_t rq = 4u * d - a;               // record position of the dword's first byte (wraps for d = 0, a > 0)
+                const bool inside = have && 4u * d >= a && rq + 4u <= total;
+                const uint32_t rqs = inside ? rq : 0u;
+                uint32_t p = 0;
+                if (P == 16u) {                               // (wave-uniform) the last slot that starts at or before rq: counted
+                    const uint4 s0 = *reinterpret_cast<const uint4 *>(st0), s1 = *reinterpret_cast<const uint4 *>(st0 + 4), s2 = *reinterpret_cast<const uint4 *>(st0 + 8),
+                                s3 = *reinterpret_cast<const uint4 *>(st0 + 12);
+                    p = (s0.y <= rqs) + (s0.z <= rqs) + (s0.w <= rqs) + (s1.x <= rqs) + (s1.y <= rqs) + (s1.z <= rqs) + (s1.w <= rqs) + (s2.x <= rqs) + (s2.y <= rqs) +
+                        (s2.z <= rqs) + (s2.w <= rqs) + (s3.x <= rqs) + (s3.y <= rqs) + (s3.z <= rqs) + (s3.w <= rqs);
+                } else {
+                    p = slot_at(rr, rqs);
                 }
+                const uint32_t inf = W.info[tb + p], st_p = st0[p], st_p1 = st0[p + 1u], srcv = W.src[tb + p];
+                ok = inside && rq + 4u <= st_p1 && (inf >> 16) == fmt::kSpan;
+                seam = have && !ok;
+                entry = (rr << 24) | d;
+                const uint8_t *sp = ok ? text_of[inf & 0xFFFFu] + srcv + (rq - st_p) : safe;
+                mis = (uint32_t)(reinterpret_cast<uintptr_t>(sp) & 3u);
+                aw = reinterpret_cast<const uint32_t *>(sp - mis);
+                dst = nullptr;
+                if (ok) {
+                    const uint32_t o = rp.in0a + 4u * d;      // offset inside the record's first block
+                    if (flags & 2u) {
+                        dst = o < kBlock ? reinterpret_cast<uint8_t *>(rp.base0) + o : reinterpret_cast<uint8_t *>(rp.base1) + (o - kBlock);
+                    } else {
+                        FileChunk x;
+                        x.rem = x.n_emit = x.blk_base = x.new_rem = 0;
+                        x.chunk_only = C.no_carry;
+                        x.nb = rp.nb; x.slab_base = rp.slab_base; x.par = rp.par;
+                        dst = file_byte(x, rp.c, rp.q - a + 4u * d, persist, slabs);
+                    }
+                }
+            };
+            auto list = [&](bool seam, uint32_t entry) {
+                const uint64_t m = __ballot(seam);
+                if (seam) W.queue[n_queued + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = entry;
+                n_queued += (uint32_t)__popcll(m);
+            };
+            for (uint32_t g0 = 0; g0 < dw_total; g0 += 128u) {   // 512 bytes per pass, of whichever records; loads before stores
+                bool ok0, ok1, seam0, seam1;
+                const uint32_t *aw0, *aw1;
+                uint32_t mis0, mis1, e0, e1;
+                uint8_t *dst0, *dst1;
+                body_plan(g0 + lane, ok0, seam0, aw0, mis0, dst0, e0);
+                body_plan(g0 + 64u + lane, ok1, seam1, aw1, mis1, dst1, e1);
+                const uint32_t w00 = aw0[0], w01 = aw0[1], w10 = aw1[0], w11 = aw1[1];   // (every text buffer has 64 bytes of slack behind it)
+                list(seam0, e0);
+                list(seam1, e1);
+                if (ok0) *reinterpret_cast<uint32_t *>(dst0) = __builtin_amdgcn_alignbyte(w01, w00, mis0);
+                if (ok1) *reinterpret_cast<uint32_t *>(dst1) = __builtin_amdgcn_alignbyte(w11, w10, mis1);
+                if (n_queued + 128u > kSeamQueue) flush_seams();
             }
             flush_seams();
         }
