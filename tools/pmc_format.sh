@@ -15,11 +15,14 @@ scope_bench.make_inputs("$D", 8000000, False, repeat_first_block=True)
 PY
 export FQTK_CLEAN_EXIT=1
 CMD="$R/fqtk_amd/bin/fqtk demux -i $D/R1.fastq $D/I1.fastq $D/I2.fastq $D/R2.fastq -r 150T 8B 8B 150T -s $D/meta.tsv -o $D/out -t 16 --compression-level 0"
-pass() { n=$1; shift; timeout 300 rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d $O/$n -o p -- $CMD > $O/$n.log 2>&1 || echo "pass $n failed"; rm -rf $D/out; }
+pass() { n=$1; shift; timeout 90 rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d $O/$n -o p -- $CMD > $O/$n.log 2>&1 || echo "pass $n failed"; rm -rf $D/out; }
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -o run -- $CMD > $O/stats.log 2>&1; rm -rf $D/out
 pass sq SQ_INSTS_VALU SQ_INSTS_SALU SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_INSTS_LDS
-pass mem FETCH_SIZE WRITE_SIZE TCP_TCC_READ_REQ_sum TCP_TCC_WRITE_REQ_sum
-pass mem2 TCC_EA0_RDREQ_sum TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_64B_sum TCC_REQ_sum
+# (round 5: the memory-counter passes of this command hung on the pool's boxes -- three timeouts, 15 GPU-minutes; they run only when asked for: MEM_PASSES=1)
+if [ -n "$MEM_PASSES" ]; then
+pass mem FETCH_SIZE WRITE_SIZE
+pass mem2 TCP_TCC_READ_REQ_sum TCP_TCC_WRITE_REQ_sum
+fi
 pass vm SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SMEM SQ_INST_LEVEL_VMEM SQ_WAVES SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS
 rm -rf $D
 python - <<PY
