@@ -165,17 +165,19 @@ const char *kUsage =
     "  -c, --compression-level <N>                 [default: 5]\n"
     "  -S, --skip-reasons <REASON>...              too-few-bases\n"
     "      --device <N>                            GPU to use [default: 0] (additive flag)\n"
-    "      --devices <A,B,..>                      several GPUs: chunk k is matched on devices[k mod G] (additive flag)\n"
+    "      --devices <A,B,..>                      several GPUs: chunk k is matched on devices[k mod G] (additive flag).  Compressed inputs are\n"
+    "                                              then inflated by the host's reader threads (text that was inflated on one device lives there)\n"
     "      --chunk-reads <N>                       templates per GPU chunk [default: 262144; 131072 with --host-output] (additive flag)\n"
     "      --host-output                           parse, format and BGZF-compress the records on the host CPUs (as the\n"
     "                                              reference does) instead of on the GPU, which is the default: there the\n"
     "                                              inputs' text goes to the device, records are formatted and DEFLATE-compressed\n"
     "                                              in HBM and whole BGZF members come back (additive flag; alias --no-gpu-bgzf;\n"
     "                                              --gpu-bgzf is accepted and means the default)\n"
-    "      --host-inflate                          inflate compressed inputs on the host CPUs.  Default when every input is compressed and one\n"
+    "      --host-inflate                          inflate compressed inputs on the host CPUs.  Without it, when every input is compressed and one\n"
     "                                              device is used: BGZF members (bgzip, htslib, fqtk's own outputs) go to the device as they\n"
-    "                                              are, a wavefront each; serial gzip files (gzip, bcl2fastq), from 64 MB of them, in chunks\n"
-    "                                              between DEFLATE block starts the host finds, windows handed down the chain (additive flag)\n"
+    "                                              are, a wavefront each; serial gzip files (gzip, bcl2fastq), from 64 MB of them, in chunks of\n"
+    "                                              64 KiB cut at DEFLATE block starts the device finds, windows handed down the chain; what cannot\n"
+    "                                              be cut or decoded like that is decoded by a host thread -- any valid file is read (additive flag)\n"
     "      --gpu-gunzip                            serial gzip inputs on the device whatever their size (additive flag)\n";
 
 bool parse_ulong(const std::string &s, unsigned long *out) {
@@ -555,7 +557,13 @@ bool gpu_output_supported(const Plan &plan, std::string *why) {
         bgzf_in.push_back(std::make_unique<BgzfFile>());
         if (!bgzf_in.back()->open(opt.inputs[i], &e)) fed_mode = false;   // (a pipe: the reader threads inflate it)
     }
-    if (!fed_mode) { bgzf_in.clear(); n_serial = 0; }
+    if (!fed_mode) {
+        bool compressed = false;
+        for (size_t i = 0; i < n_inputs; ++i) compressed = compressed || sources[i]->kind() == FastqSource::Kind::Bgzf || sources[i]->kind() == FastqSource::Kind::Gzip;
+        if (G > 1 && compressed && !opt.host_inflate) info("%zu devices: compressed inputs are inflated by the host's reader threads.", G);
+        bgzf_in.clear();
+        n_serial = 0;
+    }
     else if (n_serial) info("gzip inputs: decoded on the device in chunks (BGZF members: one wavefront each).");
     else info("BGZF inputs: members are inflated on the device.");
 

@@ -376,3 +376,27 @@ def test_fed_text_ends_like_the_host_path_ends_it_and_names_the_right_inputs(tmp
     monkeypatch.setenv("FQTK_FED_ARENA_MIN", "1000000")
     r = H.run_demux(f, ["10M+T", "8B", "+T"], meta, tmp_path / "tooshort", threads=8, extra=["--chunk-reads", "500"])
     assert r.returncode != 0 and "Read the:short:one x had too few bases to demux 3 vs. 11 needed" in r.stderr, r.stderr
+
+
+def test_several_devices_take_compressed_inputs_through_the_host_readers(tmp_path):
+    """text inflated on one device lives there, so `--devices a,b` (chunk k to device k mod G) inflates BGZF and
+    gzip inputs on the host's reader threads -- and says so.  Same outputs as one device, which inflates on the device."""
+    import gzip
+    rng = np.random.default_rng(71)
+    bcs = ["ACGTACGT", "TTGCAATG", "GGGGCCCC"]
+    n = 12_000
+    r1 = _records(n, rng, [100, 60], "r")
+    i1 = [(h, bcs[k % 3], "F" * 8) for k, (h, _, _) in enumerate(r1)]
+    f1 = _write_bgzf(tmp_path / "r1.fastq.gz", _text(r1))
+    f2 = str(tmp_path / "i1.fastq.gz")
+    with open(f2, "wb") as fh:
+        fh.write(gzip.compress(_text(i1), 6))
+    meta = _meta(tmp_path, bcs)
+    one = H.run_demux([f1, f2], ["+T", "8B"], meta, tmp_path / "one", threads=8, extra=["--chunk-reads", "2000", "--gpu-gunzip"])
+    assert one.returncode == 0 and "decoded on the device in chunks" in one.stderr, one.stderr
+    two = H.run_demux([f1, f2], ["+T", "8B"], meta, tmp_path / "two", threads=8, extra=["--chunk-reads", "2000", "--devices", "0,0"])
+    assert two.returncode == 0, two.stderr
+    assert "inflated by the host's reader threads" in two.stderr and "on the device" not in two.stderr.split("inflated by the host")[1][:200]
+    a, b = _outputs(tmp_path / "one"), _outputs(tmp_path / "two")
+    assert a.keys() == b.keys() and all(a[k] == b[k] for k in a)
+    assert open(tmp_path / "one" / "demux-metrics.txt").read() == open(tmp_path / "two" / "demux-metrics.txt").read()

@@ -3,9 +3,9 @@
 # key) and with IUPAC bytes in the READ (each such read takes a wave-cooperative scan of all samples).
 # Rates are per READ; the generator's knobs are per base (16 bases).
 cd "$(dirname "$0")/.."
-row() { FQTK_SYNTH_PDOT=$2 FQTK_SYNTH_PIUPAC=$3 python bench.py --steps 10 --warmup 2 --cpu-seconds 0 --parity windows --no-scopes $4 2>/dev/null | grep "^{" | tail -1 | python -c "
-import sys,json
-d=json.loads(sys.stdin.readline()); r=d['roofline']
+row() { FQTK_SYNTH_PDOT=$2 FQTK_SYNTH_PIUPAC=$3 python bench.py --steps 10 --warmup 2 --cpu-seconds 0 --parity windows --no-scopes $4 >/dev/null 2>&1 && python -c "
+import json
+d=json.load(open('gpurun_out/bench_detail.json')); r=d['roofline']
 print(json.dumps({'row': '$1', 'G_reads_s': round(d['value']/1000,1), 'frac': r['frac'], 'kernel_ms': r['kernel_ms'], 'kernel': r['kernel'], 'parity': d['config']['parity']}))"; }
 row "cfg3, no non-canonical reads" 0 0
 row "cfg3, 1% of reads carry a dot" 0.00063 0
