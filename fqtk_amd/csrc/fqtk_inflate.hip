@@ -56,13 +56,65 @@ struct DeviceWave {
 #else
 #define FQTK_INFLATE_OCCUPANCY
 #endif
+// CRC-32 (RFC 1952 8.) and newline count of the text a wavefront has just written, by that wavefront: lane k takes the k-th of 64 slices
+// (whole 16-byte pieces of the dword-aligned stream; the bytes come back out of the L2 they were written to a moment ago), byte by byte through
+// the table in LDS, and the slices' values -- each multiplied by x^(8 * bytes behind it) -- XOR to the member's (bgzf_deflate.hpp: crc_gf_mul; the
+// powers are member_check_kernel's table: x^(8 * 264 * j), x^(8 * r)).  ~6 k wave-instructions per 64 KiB member beside the ~65 k that decode it;
+// the separate check kernel (256 lanes per member, text staged in LDS) cost 1.0 ms per launch beside the decoder's 4.5 (r04_pipeline_bgzf_inputs_kernel_stats.csv).
+constexpr uint32_t kSlice = 264, kSliceWords = kSlice / 4, kSliceStride = kSliceWords + 1;   // 256 x 264 >= 3 + 65 536
+__device__ inline void wave_crc_and_lines(const uint8_t *text, uint32_t isize, const uint32_t *tab /* LDS, 256 */, const uint32_t *crc_pow, uint32_t *crc_out, uint32_t *lines_out) {
+    const uint32_t lane = threadIdx.x;
+    const uint32_t a = (uint32_t)(reinterpret_cast<uintptr_t>(text) & 3u), end = a + isize;   // the text is bytes [a, end) of the aligned stream
+    const uint8_t *src = text - a;
+    const uint32_t S = (((end + 63u) >> 6) + 15u) & ~15u;                                     // bytes per slice: 64 of them cover the stream
+    const uint32_t lo0 = lane * S, lo = lo0 < a ? a : lo0, hi = lo0 + S < end ? lo0 + S : end;
+    uint32_t c = 0xFFFFFFFFu, nl = 0;
+    auto step = [&](uint32_t b) { nl += b == 0x0Au ? 1u : 0u; c = tab[(c ^ b) & 0xFFu] ^ (c >> 8); };
+    uint32_t q = lo;
+    for (; q < hi && (q & 15u); ++q) step(src[q]);                                            // up to the first whole piece
+    for (uint32_t k = 0; k < S; k += 16u) {                                                   // (the same trip count in every lane)
+        if (q + 16u <= hi) {
+            const uint4 v = *reinterpret_cast<const uint4 *>(src + q);
+            const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+#pragma unroll
+                for (int b = 0; b < 4; ++b) step((w[i] >> (8 * b)) & 0xFFu);
+            }
+            q += 16u;
+        }
+    }
+    for (; q < hi; ++q) step(src[q]);                                                          // what is left of the last piece
+    uint32_t mine = 0;
+    if (lo < hi) {
+        c = ~c;
+        const uint32_t behind = end - hi;                                                      // <= 65 536 + 3: 264 * j + r
+        const uint32_t j = behind / kSlice, r = behind - j * kSlice;
+        if (behind) {
+            if (j) c = bgzf::crc_gf_mul(c, crc_pow[j]);
+            if (r) c = bgzf::crc_gf_mul(c, crc_pow[256u + r]);
+        }
+        mine = c;
+    }
+    for (int d = 32; d >= 1; d >>= 1) { mine ^= __shfl_xor(mine, d); nl += __shfl_xor(nl, d); }
+    *crc_out = mine;
+    *lines_out = nl;
+}
+
 __global__ __launch_bounds__(64) FQTK_INFLATE_OCCUPANCY void inflate_kernel(const uint8_t *in, uint64_t in_len, const fqtk_inflate_member *members, uint32_t n,
-                                                      uint8_t *out, uint32_t *status) {
+                                                      uint8_t *out, uint32_t *status, uint32_t *lines, const uint32_t *crc_pow) {
     __shared__ Shared S;
+    __shared__ uint32_t crc_tab[256];
     const uint32_t j = blockIdx.x;
     if (j >= n) return;
+    for (uint32_t k = threadIdx.x; k < 256u; k += 64u) {
+        uint32_t c = k;
+#pragma unroll
+        for (int b = 0; b < 8; ++b) c = (c & 1u) ? (c >> 1) ^ 0xEDB88320u : (c >> 1);
+        crc_tab[k] = c;
+    }
     const fqtk_inflate_member m = members[j];
-    uint32_t st;
+    uint32_t st, nl = 0;
     if (m.isize > FQTK_INFLATE_MAX_ISIZE || m.payload_off > in_len || (uint64_t)m.payload_len > in_len - m.payload_off) {
         st = kErrTruncated;
     } else {
@@ -78,8 +130,17 @@ __global__ __launch_bounds__(64) FQTK_INFLATE_OCCUPANCY void inflate_kernel(cons
         a.isize = m.isize;
         DeviceWave w;
         st = inflate_member(w, S, a);
+        if (st == kOk && crc_pow != nullptr) {   // the member's check, by the wavefront that wrote the text
+            uint32_t crc = 0;
+            if (m.isize) {
+                __threadfence_block();           // (the stores of the last rounds: visible to this wave's loads)
+                __syncthreads();
+                wave_crc_and_lines(out + m.out_off, m.isize, crc_tab, crc_pow, &crc, &nl);
+            }
+            if (crc != m.crc) st = kErrCrc;
+        }
     }
-    if (threadIdx.x == 0) status[j] = st;
+    if (threadIdx.x == 0) { status[j] = st; if (lines) lines[j] = nl; }
 }
 
 // CRC-32 of every member's text (RFC 1952 8.) and its number of newlines, one workgroup of 256 lanes per member.  The
@@ -87,7 +148,6 @@ __global__ __launch_bounds__(64) FQTK_INFLATE_OCCUPANCY void inflate_kernel(cons
 // slices of kSlice bytes laid kSlice / 4 + 1 dwords apart (lane k's dword j sits in bank 3 k + j: no conflicts); lane k
 // takes slice k byte by byte, and the slices' values -- each multiplied by x^(8 * bytes behind it) -- XOR to the member's CRC
 // (bgzf_deflate.hpp: crc_gf_mul; the powers come from a table made once per handle).
-constexpr uint32_t kSlice = 264, kSliceWords = kSlice / 4, kSliceStride = kSliceWords + 1;   // 256 x 264 >= 3 + 65 536
 __global__ __launch_bounds__(256) void member_check_kernel(const fqtk_inflate_member *members, uint32_t n, const uint8_t *out,
                                                            uint32_t *status, uint32_t *lines, const uint32_t *crc_pow, uint32_t *crc_out) {
     extern __shared__ uint32_t lds[];
@@ -361,8 +421,8 @@ hipError_t inflate_launch(hipStream_t stream, const uint8_t *in, uint64_t in_len
     if (n == 0) return hipSuccess;
     static const hipError_t prepared = hipFuncSetAttribute(reinterpret_cast<const void *>(member_check_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kCheckLds);
     if (prepared != hipSuccess) return prepared;
-    hipLaunchKernelGGL(inflate_kernel, dim3(n), dim3(64), 0, stream, in, in_len, members, n, out, status);
-    hipLaunchKernelGGL(member_check_kernel, dim3(n), dim3(256), kCheckLds, stream, members, n, (const uint8_t *)out, status, lines, crc_pow_dev, (uint32_t *)nullptr);
+    // (CRC-32 and newline count by the wavefront that wrote the text: no second kernel, no second pass over the text from HBM)
+    hipLaunchKernelGGL(inflate_kernel, dim3(n), dim3(64), 0, stream, in, in_len, members, n, out, status, lines, crc_pow_dev);
     return hipGetLastError();
 }
 
