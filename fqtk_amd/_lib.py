@@ -153,6 +153,7 @@ SIGNATURES = [
     ("fqtk_demuxer_inflate_seconds", C.c_int, [C.c_void_p, C.POINTER(C.c_double)]),
     ("fqtk_demuxer_stream_decode", C.c_int, [C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint32, C.c_void_p]),
     ("fqtk_demuxer_stream_scan", C.c_int, [C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint32, C.c_int, C.c_uint32, C.c_uint32, C.c_void_p, C.POINTER(C.c_uint32)]),
+    ("fqtk_demuxer_stream_reserve", C.c_int, [C.c_void_p, C.c_uint32, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint64]),
     ("fqtk_demuxer_stream_window", C.c_int, [C.c_void_p, C.c_uint32, C.c_void_p]),
     ("fqtk_demuxer_stream_commit_text", C.c_int, [C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint64, C.c_void_p, C.c_int, C.POINTER(C.c_uint64), C.POINTER(C.c_uint32)]),
     ("fqtk_demuxer_stream_commit", C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32, C.c_int, C.c_int, C.POINTER(C.c_uint64), C.POINTER(C.c_uint32), C.POINTER(C.c_uint64)]),

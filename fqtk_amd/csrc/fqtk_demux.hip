@@ -9,6 +9,9 @@
 // A copy stream moves the text in, another the packed members out.  Three chunks may be in flight (slots).
 #include <hip/hip_runtime.h>
 
+#include <chrono>
+#include <cstdio>
+
 #include <algorithm>
 #include <atomic>
 #include <cstdlib>
@@ -137,6 +140,7 @@ struct FedInput {
     DevBuf<unsigned long long> d_starts;
     fqtk::inflate::StreamPlan *d_plan = nullptr;
     fqtk::inflate::StreamPlan *h_plan = nullptr;   // page-locked
+    uint32_t scans = 0;
 };
 constexpr uint64_t kFedSlack = 256;     // bytes kept free behind the text (the check kernel and the line index read whole dwords / 16 bytes)
 
@@ -834,6 +838,39 @@ int fqtk_demuxer_stream_decode(fqtk_demuxer *d, uint32_t input, const uint8_t *b
     return FQTK_OK;
 }
 
+// Room for the stretches to come, made once: growing a device buffer later means hipFree, which waits for the whole device (measured in a
+// run whose stretches ramped 16 -> 32 -> 64 MB: 130-150 ms per growth of the symbol buffer, 40-70 ms per growth of an arena).
+static uint64_t stream_sym_cap(uint64_t len, uint32_t n_slots, uint32_t sym_per_byte) {
+    return (len + 1u) * sym_per_byte + (uint64_t)n_slots * (65536u + 8u * (uint64_t)sym_per_byte + 8u);
+}
+int fqtk_demuxer_stream_reserve(fqtk_demuxer *d, uint32_t input, uint64_t max_len, uint32_t max_slots, uint32_t sym_per_byte, uint64_t arena_bytes) {
+    using namespace fqtk::inflate;
+    if (!d || input >= d->C.n_inputs) return set_error(FQTK_EINVAL, "NULL argument / input out of range");
+    if (max_len >= (1ull << 29) || max_slots == 0 || max_slots > kMaxStreamSlots || sym_per_byte == 0 || sym_per_byte > 2048u) return set_error(FQTK_EINVAL, "stretch geometry out of range");
+    DX_TRY(hipSetDevice(d->device));
+    int rc;
+    if ((rc = fed_init(d)) != FQTK_OK) return rc;
+    FedInput &F = d->fed[input];
+    std::lock_guard<std::mutex> lk(F.mu);
+    if ((rc = F.comp.ensure((size_t)max_len + 16)) != FQTK_OK) return rc;
+    if ((rc = F.sym.ensure((size_t)stream_sym_cap(max_len, max_slots, sym_per_byte) + 64)) != FQTK_OK) return rc;
+    if ((rc = F.d_chunks.ensure(max_slots)) != FQTK_OK) return rc;
+    if ((rc = F.h_chunks.ensure(max_slots)) != FQTK_OK) return rc;
+    if ((rc = F.h_ends.ensure(max_slots)) != FQTK_OK) return rc;
+    if ((rc = F.d_ends.ensure(max_slots)) != FQTK_OK) return rc;
+    if ((rc = F.d_starts.ensure(max_slots)) != FQTK_OK) return rc;
+    if ((rc = F.h_out_off.ensure(max_slots + 1)) != FQTK_OK) return rc;
+    if ((rc = F.d_out_off.ensure(max_slots + 1)) != FQTK_OK) return rc;
+    if ((rc = F.windows.ensure((size_t)(max_slots + 1) * kStreamWindow)) != FQTK_OK) return rc;
+    if ((rc = F.maps.ensure((size_t)max_slots * 2u * kStreamWindow)) != FQTK_OK) return rc;
+    if (arena_bytes) {
+        if (F.tail != 0 || !F.members.empty()) return set_error(FQTK_EINVAL, "arenas are reserved before anything is fed");
+        for (int k = 0; k < 2; ++k)
+            if ((rc = F.arena[k].ensure((size_t)arena_bytes)) != FQTK_OK) return rc;
+    }
+    return FQTK_OK;
+}
+
 // The same with the chunks cut on the device (fqtk_inflate.hip: stream_search_kernel, stream_plan_kernel).
 int fqtk_demuxer_stream_scan(fqtk_demuxer *d, uint32_t input, const uint8_t *bytes, uint64_t len, uint64_t first_bit, uint32_t chunk_bytes, uint32_t n_slots, int to_end,
                              uint32_t sym_per_byte, uint32_t flags, fqtk_stream_end *ends, uint32_t *n_chunks) {
@@ -848,6 +885,8 @@ int fqtk_demuxer_stream_scan(fqtk_demuxer *d, uint32_t input, const uint8_t *byt
     int rc;
     if ((rc = fed_init(d)) != FQTK_OK) return rc;
     FedInput &F = d->fed[input];
+    static const bool timing = std::getenv("FQTK_TIMING") != nullptr;
+    const auto t_begin = std::chrono::steady_clock::now();
     if ((rc = F.comp.ensure((size_t)len + 16)) != FQTK_OK) return rc;
     if ((rc = F.d_chunks.ensure(n_slots)) != FQTK_OK) return rc;
     if ((rc = F.h_chunks.ensure(n_slots)) != FQTK_OK) return rc;
@@ -861,8 +900,9 @@ int fqtk_demuxer_stream_scan(fqtk_demuxer *d, uint32_t input, const uint8_t *byt
     // room for the symbols: sym_per_byte per compressed byte of the stretch and a block's worth per chunk (the plan kernel shares it out
     // and never hands out more than there is)
     const uint32_t slack = 65536u;
-    const uint64_t sym_cap = (len + 1u) * sym_per_byte + (uint64_t)n_slots * (slack + 8u * (uint64_t)sym_per_byte + 8u);
+    const uint64_t sym_cap = stream_sym_cap(len, n_slots, sym_per_byte);
     if ((rc = F.sym.ensure((size_t)sym_cap + 64)) != FQTK_OK) return rc;
+    const auto t_alloc = std::chrono::steady_clock::now();
     DX_TRY(hipMemcpyAsync(F.comp.p, bytes, (size_t)len, hipMemcpyHostToDevice, F.stream));
     DX_TRY(hipEventRecord(F.ev_t0, F.stream));
     DX_TRY(stream_scan_launch(F.stream, F.comp.p, len, first_bit, chunk_bytes, n_slots, to_end != 0, (flags & FQTK_STREAM_SCAN_TEXT) != 0, sym_per_byte, slack, sym_cap, reinterpret_cast<uint64_t *>(F.d_starts.p),
@@ -875,6 +915,11 @@ int fqtk_demuxer_stream_scan(fqtk_demuxer *d, uint32_t input, const uint8_t *byt
     {
         float ms = 0;
         if (hipEventElapsedTime(&ms, F.ev_t0, F.ev_t1) == hipSuccess) { std::lock_guard<std::mutex> glk(d->stat_mu); d->inflate_s += ms * 1e-3; }
+        if (timing && F.scans++ < 3) {
+            const auto t_end = std::chrono::steady_clock::now();
+            std::fprintf(stderr, "(timing) stream scan %u of input %u: buffers %.1f ms, copy in + kernels + results %.1f ms (the kernels: %.1f ms)\n", F.scans, input,
+                         std::chrono::duration<double, std::milli>(t_alloc - t_begin).count(), std::chrono::duration<double, std::milli>(t_end - t_alloc).count(), ms);
+        }
     }
     const uint32_t n = F.h_plan->n_chunks;
     if (n == 0 || n > n_slots) return set_error(FQTK_EHIP, "the stretch's plan came back empty");

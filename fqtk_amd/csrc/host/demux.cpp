@@ -505,9 +505,13 @@ bool gpu_output_supported(const Plan &plan, std::string *why) {
                                  std::vector<std::unique_ptr<FastqSource>> &sources, bool skip_few) {
     const size_t n_inputs = plan.rs.size(), S = samples.size(), G = opt.devices.size();
     size_t chunk = std::max<unsigned long>(1, opt.chunk_given ? opt.chunk_reads : 262144ul);
+    std::vector<size_t> per_record_of(n_inputs, 0);   // bytes of text per record, judged by every input's first MiB
     {   // a chunk's text must stay below 2 GiB per input (32-bit offsets on the device): long reads get smaller chunks
         size_t per_record = 0;
-        for (auto &src : sources) per_record = std::max(per_record, src->estimate_raw_bytes(1024) / 1024);
+        for (size_t i = 0; i < sources.size(); ++i) {
+            per_record_of[i] = sources[i]->estimate_raw_bytes(1024) / 1024;
+            per_record = std::max(per_record, per_record_of[i]);
+        }
         const size_t fit = per_record ? std::max<size_t>(1, (768ull << 20) / per_record) : chunk;
         if (fit < chunk) {
             info("Records of about %zu bytes: %zu templates per chunk instead of %zu.", per_record, fit, chunk);
@@ -914,10 +918,23 @@ bool gpu_output_supported(const Plan &plan, std::string *why) {
                     std::vector<uint8_t> win_before(32768), win_after(32768);
                     std::vector<fqtk_stream_end> ends(kSlots);
                     bool all_done = false;
+                    bool reserved = false;
                     // one gzip member that is no BGZF member, from its header at bf.pos on; false: the run is over (fail() has been called, or the chunks are all cut)
                     auto serial_member = [&]() -> bool {
                         const size_t hl = gzip_header_len(bf.map + pos, bf.size - pos);
                         if (hl == 0) { fail("Unexpected error parsing FASTQs: corrupt gzip stream: " + std::string(pos ? "bad member header" : "not a gzip file") + " in " + bf.path); return false; }
+                        if (!reserved && pos == 0) {
+                            // the device's buffers for whole stretches, and arenas for the text the feeder may be ahead by plus a stretch's (eight times its
+                            // bytes: more only grows them later), made now: a buffer that grows in mid-run is freed first, and that waits for the device
+                            reserved = true;
+                            const uint64_t stretch_bytes = std::min<uint64_t>(bf.size, (uint64_t)kSlots * kChunkBytes + 131072);
+                            const uint64_t ahead_text = (gz_high_water / 4u) * (uint64_t)std::max<size_t>(16, per_record_of[i]);
+                            const uint64_t arena = std::min<uint64_t>((ahead_text + stretch_bytes * 8u) * 2u + (64u << 20), (uint64_t)bf.size * 24u + (64u << 20));
+                            if (fqtk_demuxer_stream_reserve(demuxers[0], (uint32_t)i, stretch_bytes + 8, (uint32_t)kSlots, sym_per_byte, kSlots >= 64 ? arena : 0) != FQTK_OK) {
+                                fail(std::string("GPU record pipeline: ") + fqtk_last_error());
+                                return false;
+                            }
+                        }
                         uint64_t verified = (uint64_t)(pos + hl) * 8u;   // a block starts here: the member's first
                         bool member_start = true;
                         uint32_t crc_acc = 0;

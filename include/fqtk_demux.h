@@ -168,6 +168,10 @@ int fqtk_demuxer_stream_scan(fqtk_demuxer *d, uint32_t input, const uint8_t *byt
                              int to_end, uint32_t sym_per_byte, uint32_t flags, fqtk_stream_end *ends, uint32_t *n_chunks);
 int fqtk_demuxer_stream_commit(fqtk_demuxer *d, uint32_t input, uint32_t n_accept, int member_start, int last, uint64_t *lines_fed, uint32_t *crc32,
                                uint64_t *n_text);
+/* Optional, before the first stretch of an input: device buffers for stretches of up to max_len bytes in max_slots chunks at
+ * sym_per_byte, and two arenas of arena_bytes for the input's text (0: as needed).  Buffers that grow in the middle of a run are freed
+ * and allocated again, and a free waits for the whole device (0.05-0.15 s each time, measured). */
+int fqtk_demuxer_stream_reserve(fqtk_demuxer *d, uint32_t input, uint64_t max_len, uint32_t max_slots, uint32_t sym_per_byte, uint64_t arena_bytes);
 /* A stretch the device could not take (no block start to cut at, a block larger than any room, a decoder in doubt) is decoded by the
  * caller's own sequential decoder: fqtk_demuxer_stream_window hands out the 32 KiB of text in front of the next chunk (zeros where the
  * member has less), fqtk_demuxer_stream_commit_text takes the text back (window_after: the 32 KiB in front of what follows; NULL when a
