@@ -41,13 +41,11 @@ namespace {
 
 thread_local std::string g_last_error;
 
-#ifdef FQTK_DEV_ABLATE
-// developer switches: set and neither empty nor "0"
+// switches of tests and A/B runs: set and neither empty nor "0"
 bool env_flag(const char *name) {
     const char *v = std::getenv(name);
     return v && *v && !(v[0] == '0' && v[1] == '\0');
 }
-#endif
 
 int fail(int code, const std::string &msg) {
     g_last_error = msg;
@@ -157,6 +155,8 @@ struct fqtk_matcher {
     void *d_memo = nullptr;
     uint32_t *d_hot = nullptr;               // hot subset (0-mismatch entries) for the LDS table
     uint32_t hot_mask = 0;
+    uint32_t *d_filter = nullptr;            // presence filter over all keys of the hash table (memo_hash.hpp), kept in LDS with the hot table
+    uint32_t filter_bits = 0;                // log2 of its bits; 0 = none (then the hot table is single-choice)
     uint32_t memo_mask = 0;
     int memo_kw = 1;   // key words per entry (fqtk::memo_key_words)
     // direct-indexed form (L <= 10; memo_hash.hpp): flat result array + LDS cache of its exact-match entries;
@@ -287,6 +287,7 @@ int launch_memo_vec(const fqtk_matcher *m, fqtk::MemoParams Q, hipStream_t strea
     size_t shmem = 256 * sizeof(uint32_t);
     if (direct) shmem += Q.hot2 ? ((size_t)8 << Q.hot2_bits) : 0;
     else if (Q.hot_mask) shmem += (size_t)(Q.hot_mask + 1) * (KW == 4 ? 32 : (KW >= 2 ? 16 : 8));
+    if (!direct && Q.filter_bits) shmem += (size_t)1 << (Q.filter_bits - 3u);
     if (P.counts && P.lds_hist) shmem += (size_t)(P.S + 1) * sizeof(uint32_t);
     {   // the expected-barcode planes for the wave scan of non-canonical reads, while two workgroups still fit a CU
         const size_t with_tab = ((shmem + 15) & ~(size_t)15) + (size_t)P.S * 16;
@@ -714,6 +715,8 @@ int launch_memo(const fqtk_matcher *m, const fqtk::MatchParams &P, hipStream_t s
         Q.mask = m->memo_mask;
         Q.hot = m->d_hot;
         Q.hot_mask = m->hot_mask;
+        Q.filter = m->d_filter;
+        Q.filter_bits = m->d_filter ? m->filter_bits : 0u;
         Q.direct = m->d_direct;
         Q.hot2 = m->d_hot2;
         Q.hot2_bits = m->hot2_bits;
@@ -1146,24 +1149,88 @@ int build_memo(fqtk_matcher *m, const std::vector<std::vector<uint8_t>> &enc) {
                        owner[p] < 0 ? 0u : ents[(size_t)owner[p]].val, spill[p] != 0);
         break;
     }
-    // hot table for LDS: 0-mismatch entries in the low bits of their FIRST slot's number (it is only a cache: an entry
-    // that finds the slot taken -- low sample index first -- is simply served by the global table)
+    // hot table for LDS: 0-mismatch entries (it is only a cache: an entry that finds no place is served by the global table).
+    // Round 5: where the exact-match entries are few (any plain table: S of them), the hot table is TWO-choice -- slot h1 or h2 of the key's
+    // two full hashes, filled to 40 % at most, so that every entry finds a place in a table a quarter of the single-choice one's size -- and
+    // the LDS it leaves goes to a PRESENCE FILTER over all keys of the memo (memo_hash.hpp): a read that is in no slot of the table never
+    // gathers.  Tables whose exact-match entries fill the LDS budget anyway (IUPAC expansions) keep the single-choice table and no filter.
     {
         const uint32_t slot_bytes = (uint32_t)wps * 4;
-        uint32_t hot_slots = fqtk::kHotBytes / slot_bytes;
         uint64_t n_hot = 0;
         for (const Entry &e : ents) n_hot += ((e.val >> 16) & 0xFFu) == 0;
-        while (hot_slots > 64 && hot_slots / 2 >= n_hot * 8) hot_slots >>= 1;   // single choice: an eighth full at most while LDS allows
-        if (n_hot) {
+        std::vector<size_t> order;
+        for (size_t i = 0; i < ents.size(); ++i) if (((ents[i].val >> 16) & 0xFFu) == 0) order.push_back(i);
+        std::stable_sort(order.begin(), order.end(), [&](size_t a, size_t b) {
+            return (ents[a].val & 0xFFFFu) < (ents[b].val & 0xFFFFu);   // low sample index first
+        });
+        auto full_hashes = [&](size_t i, uint32_t &h1, uint32_t &h2) {
+            h1 = fqtk::memo_hash1_full(keys[i][0], keys[i][1], keys[i][2], keys[i][3]);
+            h2 = fqtk::memo_hash2_full(keys[i][0], keys[i][1], keys[i][2], keys[i][3]);
+        };
+        // two-choice + filter?
+        uint32_t two_slots = 64;
+        while ((uint64_t)two_slots * 2 < n_hot * 5) two_slots <<= 1;            // load <= 0.4
+        uint32_t fbits = 0;
+        // (keys of one word -- barcodes of up to ten bases -- do without: their tables are a few thousand 8-byte slots that the L1s hold, a
+        //  gather there costs less than the second hash and the three LDS reads; measured on one box, tools/ab_filter.sh: cfg 4 pinned 324 -> 290
+        //  G reads/s, cfg 2 281 -> 286; with two key words and more: cfg 3 pinned 196 -> 219, 12+12 129 -> 144, 16+16 92 -> 107)
+        if (n_hot && kw >= 2 && (uint64_t)two_slots * slot_bytes <= fqtk::kHotBytes / 2 && !env_flag("FQTK_MEMO_NO_FILTER")) {
+            uint64_t fbytes = 4096;
+            while (fbytes * 2 + (uint64_t)two_slots * slot_bytes <= fqtk::kHotBytes) fbytes <<= 1;
+            if (fbytes * 8 >= ents.size() * 4)                                             // four bits per key at least, or it filters nothing
+                for (uint64_t b = fbytes * 8; b > 1; b >>= 1) ++fbits;
+        }
+        bool two_choice = false;
+        if (fbits) {
+            const uint32_t hmask = two_slots - 1;
+            std::vector<int64_t> own(two_slots, -1);
+            bool ok = true;
+            uint64_t rng = 0x2545F4914F6CDD1Dull;
+            for (size_t i : order) {
+                int64_t cur = (int64_t)i;
+                uint32_t h1, h2;
+                full_hashes((size_t)cur, h1, h2);
+                uint32_t pos = own[h1 & hmask] < 0 ? (h1 & hmask) : (h2 & hmask);
+                for (int kick = 0;; ++kick) {
+                    if (own[pos] < 0) { own[pos] = cur; break; }
+                    if (kick == 500) { ok = false; break; }
+                    std::swap(cur, own[pos]);
+                    full_hashes((size_t)cur, h1, h2);
+                    rng = rng * 6364136223846793005ull + 1442695040888963407ull;
+                    const uint32_t a1 = h1 & hmask, a2 = h2 & hmask;
+                    pos = (a1 == pos) ? a2 : ((a2 == pos) ? a1 : ((rng >> 33) & 1 ? a1 : a2));
+                    if (a1 == a2 && kick > 8) { ok = false; break; }
+                }
+                if (!ok) break;
+            }
+            if (ok) {
+                std::vector<uint32_t> hot((size_t)two_slots * wps, 0u);
+                for (uint32_t p = 0; p < two_slots; ++p)
+                    write_slot(&hot[(size_t)p * wps], kw, own[p] < 0 ? nullptr : keys[(size_t)own[p]].data(), own[p] < 0 ? 0u : ents[(size_t)own[p]].val, false);
+                std::vector<uint32_t> filt((size_t)1 << (fbits - 5), 0u);
+                for (size_t i = 0; i < ents.size(); ++i) {
+                    uint32_t h1, h2;
+                    full_hashes(i, h1, h2);
+                    const uint32_t p1 = fqtk::memo_filter_pos1(h1, fbits), p2 = fqtk::memo_filter_pos2(h2, fbits);
+                    filt[p1 >> 5] |= 1u << (p1 & 31u);
+                    filt[p2 >> 5] |= 1u << (p2 & 31u);
+                }
+                HIP_TRY(hipMalloc(reinterpret_cast<void **>(&m->d_hot), hot.size() * sizeof(uint32_t)));
+                HIP_TRY(hipMemcpy(m->d_hot, hot.data(), hot.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+                HIP_TRY(hipMalloc(reinterpret_cast<void **>(&m->d_filter), filt.size() * sizeof(uint32_t)));
+                HIP_TRY(hipMemcpy(m->d_filter, filt.data(), filt.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+                m->hot_mask = hmask;
+                m->filter_bits = fbits;
+                two_choice = true;
+            }
+        }
+        if (n_hot && !two_choice) {   // single choice, in the low bits of the entry's FIRST slot's number
+            uint32_t hot_slots = fqtk::kHotBytes / slot_bytes;
+            while (hot_slots > 64 && hot_slots / 2 >= n_hot * 8) hot_slots >>= 1;   // an eighth full at most while LDS allows
             const uint32_t hmask = hot_slots - 1;
             std::vector<uint32_t> hot((size_t)hot_slots * wps, 0u);
             std::vector<uint8_t> used(hot_slots, 0);
             for (uint32_t p = 0; p < hot_slots; ++p) write_slot(&hot[(size_t)p * wps], kw, nullptr, 0u, false);
-            std::vector<size_t> order;
-            for (size_t i = 0; i < ents.size(); ++i) if (((ents[i].val >> 16) & 0xFFu) == 0) order.push_back(i);
-            std::stable_sort(order.begin(), order.end(), [&](size_t a, size_t b) {
-                return (ents[a].val & 0xFFFFu) < (ents[b].val & 0xFFFFu);   // low sample index first
-            });
             for (size_t i : order) {
                 uint32_t a1, a2;
                 slots_of(i, mask, a1, a2);
@@ -1336,6 +1403,7 @@ void fqtk_matcher_destroy(fqtk_matcher *m) {
     }
     if (m->d_memo) (void)hipFree(m->d_memo);
     if (m->d_hot) (void)hipFree(m->d_hot);
+    if (m->d_filter) (void)hipFree(m->d_filter);
     for (auto &e : m->stream_work) e.second.release();
     if (m->d_direct) (void)hipFree(m->d_direct);
     if (m->d_hot2) (void)hipFree(m->d_hot2);

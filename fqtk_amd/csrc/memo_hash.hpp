@@ -84,21 +84,33 @@ FQTK_HD inline uint32_t memo_limb_sum2(uint32_t lo, uint32_t hi, uint32_t ext, u
     const uint32_t f = ext2 >> 24;
     return mul24(a, 0xD6E8FFu) + mul24(b, 0x2C1B3Du) + mul24(c, 0x7F4A7Du) + mul24(d, 0x51ED27u) + mul24(e, 0xC4CEB9u) + mul24(f, 0x3243F7u);
 }
-FQTK_HD inline uint32_t memo_slot1(uint32_t lo, uint32_t hi, uint32_t ext, uint32_t ext2, uint32_t mask) {
+// (the whole 32 bits of the two hashes: a slot is their low bits; the LDS presence filter takes other bits of both)
+FQTK_HD inline uint32_t memo_hash1_full(uint32_t lo, uint32_t hi, uint32_t ext, uint32_t ext2) {
     uint32_t h = memo_limb_sum(lo, hi, ext, ext2);
     h ^= h >> 15;
     h = mul24(h, 0x2C1B3Du) + (h >> 9);
     h ^= h >> 13;
-    return h & mask;
+    return h;
 }
-// (the kernels work this one out only in the rare wave that needs a second probe)
-FQTK_HD inline uint32_t memo_slot2(uint32_t lo, uint32_t hi, uint32_t ext, uint32_t ext2, uint32_t mask) {
+FQTK_HD inline uint32_t memo_hash2_full(uint32_t lo, uint32_t hi, uint32_t ext, uint32_t ext2) {
     uint32_t g = memo_limb_sum2(lo, hi, ext, ext2);
     g ^= g >> 14;
     g = mul24(g, 0x9E3779u) + (g >> 10);
     g ^= g >> 12;
-    return g & mask;
+    return g;
 }
+FQTK_HD inline uint32_t memo_slot1(uint32_t lo, uint32_t hi, uint32_t ext, uint32_t ext2, uint32_t mask) { return memo_hash1_full(lo, hi, ext, ext2) & mask; }
+// (the kernels work this one out only in the rare wave that needs a second probe -- or for every read, when the table has a presence filter)
+FQTK_HD inline uint32_t memo_slot2(uint32_t lo, uint32_t hi, uint32_t ext, uint32_t ext2, uint32_t mask) { return memo_hash2_full(lo, hi, ext, ext2) & mask; }
+
+// ---- presence filter of the hash-table form (round 5) ------------------------------------------------------------------------
+// Every key of the memo sets two bits of a bit array that the kernel keeps in LDS next to the hot table: bit filter_pos1(h1) and bit
+// filter_pos2(h2) of the key's two full hashes.  A read whose two bits are not both set is in no slot of the table -- its result is
+// None without a look at the table (no false negatives: the builder and the kernel compute the same two positions from the same
+// functions).  What it is for: a gather into the table costs one 64-byte request per lane, and the reads that are NOT in the memo --
+// one read in ten of a real run is no sample's barcode -- used to pay it only to learn that.  log2_bits <= 19 (64 KiB).
+FQTK_HD inline uint32_t memo_filter_pos1(uint32_t h1_full, uint32_t log2_bits) { return (h1_full >> 11) & ((1u << log2_bits) - 1u); }
+FQTK_HD inline uint32_t memo_filter_pos2(uint32_t h2_full, uint32_t log2_bits) { return (mul24(h2_full >> 7, 0x5BD1E9u) >> 4) & ((1u << log2_bits) - 1u); }
 FQTK_HD inline void memo_hash2(uint32_t lo, uint32_t hi, uint32_t ext, uint32_t ext2, uint32_t mask,
                                uint32_t &s1, uint32_t &s2) {
     s1 = memo_slot1(lo, hi, ext, ext2, mask);

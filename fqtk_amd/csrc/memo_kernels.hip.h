@@ -40,6 +40,8 @@ struct MemoParams {
     const uint32_t *hot;      // hot subset (exact matches) in the same slot format, copied to LDS
     uint32_t mask;            // n_slots - 1
     uint32_t hot_mask;        // hot slots - 1 (0 = no hot table)
+    const uint32_t *filter;   // presence filter over ALL keys of the table (memo_hash.hpp), copied to LDS behind the hot table; NULL = none
+    uint32_t filter_bits;     // log2 of its bits (0 = none).  With a filter the hot table is TWO-choice: slot h1 & hot_mask or h2 & hot_mask
     // direct-indexed form (short barcodes, memo_hash.hpp): `slots` then holds only the N-containing entries
     const void *direct;       // [memo_direct_entries(L)] uint16 (packed) or uint32 results, indexed by the read itself
     const uint32_t *hot2;     // [2 << hot2_bits] LDS cache of the exact-match entries (two-slot buckets), or NULL
@@ -282,16 +284,19 @@ void memo_kernel(const MemoParams Q) {
     // the hit lanes masked off, which shrinks the gather traffic by the hit rate.
     const uint32_t hot_words = DIRECT ? (Q.hot2 ? (2u << Q.hot2_bits) : 0u)
                                       : (Q.hot_mask ? (Q.hot_mask + 1) * (KW == 4 ? 8u : (KW >= 2 ? 4u : 2u)) : 0u);
+    const uint32_t filter_words = (!DIRECT && Q.filter_bits) ? 1u << (Q.filter_bits - 5u) : 0u;
     uint32_t *lds_hot = smem + 256;
-    uint32_t *lds_hist = lds_hot + hot_words;
+    uint32_t *lds_filter = lds_hot + hot_words;
+    uint32_t *lds_hist = lds_filter + filter_words;
     const uint32_t bins = P.S + 1;
     // [S][1][4] planes for the wave scan of non-canonical reads (L <= 20: one word), 16-byte aligned behind the histogram
-    uint32_t *lds_tab = P.scan_tab_lds ? smem + ((256u + hot_words + ((P.counts && P.lds_hist) ? bins : 0u) + 3u) & ~3u) : nullptr;
+    uint32_t *lds_tab = P.scan_tab_lds ? smem + ((256u + hot_words + filter_words + ((P.counts && P.lds_hist) ? bins : 0u) + 3u) & ~3u) : nullptr;
 
     const uint32_t tid = threadIdx.x;
     if (tid < 256) lds_lut[tid] = P.lut[tid];
     const uint32_t *hot_src = DIRECT ? Q.hot2 : Q.hot;
     for (uint32_t w = tid; w < hot_words; w += kMemoBlock) lds_hot[w] = hot_src[w];
+    for (uint32_t w = tid; w < filter_words; w += kMemoBlock) lds_filter[w] = Q.filter[w];
     if (P.counts && P.lds_hist)
         for (uint32_t b = tid; b < bins; b += kMemoBlock) lds_hist[b] = 0;
     if (lds_tab)
@@ -495,10 +500,34 @@ void memo_kernel(const MemoParams Q) {
             // The FIRST slot only: the second comes from an independent hash of its own (memo_slot2) that only the rare wave
             // with a spilled key works out, and the LDS hot table is single-choice (the few exact-match entries that lose
             // their slot to another are served by the global table): a dozen VALU operations and one LDS read fewer per read.
-            uint32_t s1[R];
+            uint32_t s1[R], hf1[R];
 #pragma unroll
-            for (int r = 0; r < R; ++r)
-                s1[r] = memo_slot1(key[r][0], KW >= 2 ? key[r][1] : 0u, KW >= 3 ? key[r][2] : 0u, KW >= 4 ? key[r][3] : 0u, Q.mask);
+            for (int r = 0; r < R; ++r) {
+                hf1[r] = memo_hash1_full(key[r][0], KW >= 2 ? key[r][1] : 0u, KW >= 3 ? key[r][2] : 0u, KW >= 4 ? key[r][3] : 0u);
+                s1[r] = hf1[r] & Q.mask;
+            }
+            // With a presence filter (wave-uniform; tables whose exact-match entries leave LDS for one): the second hash of every read -- it
+            // names the read's second hot slot and its second filter bit --, and `absent`: a read that is in no slot of the table.
+            const bool filtered = Q.filter_bits != 0u && !(ABL & 16);
+            uint32_t hf2[R];
+            bool absent[R];
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                absent[r] = false;
+                hf2[r] = filtered ? memo_hash2_full(key[r][0], KW >= 2 ? key[r][1] : 0u, KW >= 3 ? key[r][2] : 0u, KW >= 4 ? key[r][3] : 0u) : 0u;
+            }
+            auto filter_probe = [&]() {   // (after the hot table: a read found there needs no filter)
+                uint32_t w1[R], w2[R], p1[R], p2[R];
+#pragma unroll
+                for (int r = 0; r < R; ++r) {
+                    p1[r] = memo_filter_pos1(hf1[r], Q.filter_bits);
+                    p2[r] = memo_filter_pos2(hf2[r], Q.filter_bits);
+                    w1[r] = lds_filter[p1[r] >> 5];
+                    w2[r] = lds_filter[p2[r] >> 5];
+                }
+#pragma unroll
+                for (int r = 0; r < R; ++r) absent[r] = !hit[r] && !(((w1[r] >> (p1[r] & 31u)) & (w2[r] >> (p2[r] & 31u))) & 1u);
+            };
             auto second_slot = [&](int r) {
                 const uint32_t s2 = memo_slot2(key[r][0], KW >= 2 ? key[r][1] : 0u, KW >= 3 ? key[r][2] : 0u, KW >= 4 ? key[r][3] : 0u, Q.mask);
                 return (ABL & 32) ? (s2 & 0xFFu) : ((ABL & 128) ? (s1[r] ^ 1u) : s2);
@@ -536,7 +565,21 @@ void memo_kernel(const MemoParams Q) {
                         hit[r] = slot_hit(h1[r], r);
                         res[r] = hit[r] ? slot_val(h1[r], n1[r]) : kMemoEmpty;
                     }
+                    if (filtered) {   // the second choice
+#pragma unroll
+                        for (int r = 0; r < R; ++r) {
+                            h1[r] = *reinterpret_cast<const u32x4v *>(hbase + ((hf2[r] & Q.hot_mask) << kSlotShift));
+                            if constexpr (KW == 4) n1[r] = *reinterpret_cast<const u32x4v *>(hbase + ((hf2[r] & Q.hot_mask) << kSlotShift) + 16);
+                            else n1[r] = h1[r];
+                        }
+                        arrived4(h1);
+                        if constexpr (KW == 4) arrived4(n1);
+#pragma unroll
+                        for (int r = 0; r < R; ++r)
+                            if (!hit[r] && slot_hit(h1[r], r)) { hit[r] = true; res[r] = slot_val(h1[r], n1[r]); }
+                    }
                 }
+                if (filtered) filter_probe();
                 clk.mark(2);   // LDS hot table
                 if constexpr (ABL & 1) {
 #pragma unroll
@@ -550,7 +593,7 @@ void memo_kernel(const MemoParams Q) {
                     u32x4v e[R], f[R];
 #pragma unroll
                     for (int r = 0; r < R; ++r) {
-                        const uint32_t off = (hit[r] ? 0u : g1[r]) << kSlotShift;
+                        const uint32_t off = ((hit[r] || absent[r]) ? 0u : g1[r]) << kSlotShift;
                         e[r] = *reinterpret_cast<const u32x4v *>(gbase + off);
                         if constexpr (KW == 4) f[r] = *reinterpret_cast<const u32x4v *>(gbase + off + 16); else f[r] = e[r];
                     }
@@ -559,8 +602,8 @@ void memo_kernel(const MemoParams Q) {
 #pragma unroll
                     for (int r = 0; r < R; ++r) {
                         const bool k = slot_hit(e[r], r);
-                        if (!hit[r] && k) res[r] = slot_val(e[r], f[r]);
-                        again[r] = !hit[r] && !k && slot_spill(e[r], f[r]) && !(ABL & 64);
+                        if (!hit[r] && !absent[r] && k) res[r] = slot_val(e[r], f[r]);
+                        again[r] = !hit[r] && !absent[r] && !k && slot_spill(e[r], f[r]) && !(ABL & 64);
                         any_again |= again[r];
                     }
                     if (__ballot(any_again)) {   // wave-uniform
@@ -588,7 +631,16 @@ void memo_kernel(const MemoParams Q) {
                         hit[r] = h1[r].x == key[r][0];
                         res[r] = hit[r] ? h1[r].y : kMemoEmpty;
                     }
+                    if (filtered) {   // the second choice
+#pragma unroll
+                        for (int r = 0; r < R; ++r) h1[r] = reinterpret_cast<const u32x2v *>(lds_hot)[hf2[r] & Q.hot_mask];
+                        arrived2(h1);
+#pragma unroll
+                        for (int r = 0; r < R; ++r)
+                            if (!hit[r] && h1[r].x == key[r][0]) { hit[r] = true; res[r] = h1[r].y; }
+                    }
                 }
+                if (filtered) filter_probe();
                 clk.mark(2);   // LDS hot table
                 if constexpr (ABL & 1) {
 #pragma unroll
@@ -597,13 +649,13 @@ void memo_kernel(const MemoParams Q) {
                     bool again[R], any_again = false;
                     u32x2v e[R];
 #pragma unroll
-                    for (int r = 0; r < R; ++r) e[r] = reinterpret_cast<const u32x2v *>(Q.slots)[hit[r] ? 0u : g1[r]];
+                    for (int r = 0; r < R; ++r) e[r] = reinterpret_cast<const u32x2v *>(Q.slots)[(hit[r] || absent[r]) ? 0u : g1[r]];
                     arrived2(e);
 #pragma unroll
                     for (int r = 0; r < R; ++r) {
                         const bool k = (e[r].x & 0x7FFFFFFFu) == key[r][0];
-                        if (!hit[r] && k) res[r] = e[r].y;
-                        again[r] = !hit[r] && !k && (e[r].x >> 31) != 0 && !(ABL & 64);
+                        if (!hit[r] && !absent[r] && k) res[r] = e[r].y;
+                        again[r] = !hit[r] && !absent[r] && !k && (e[r].x >> 31) != 0 && !(ABL & 64);
                         any_again |= again[r];
                     }
                     if (__ballot(any_again)) {   // wave-uniform

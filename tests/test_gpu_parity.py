@@ -887,3 +887,44 @@ def test_packed_entry_equals_the_ascii_entry_and_the_oracle_on_every_config(k):
     got2, _ = m.assign_batch_packed(p2, e2, r2, slot=1)
     ref2, _ = m.assign_batch(clean)
     assert np.array_equal(got2.view(np.uint32), ref2.view(np.uint32))
+
+
+@pytest.mark.parametrize("L,iupac", [(16, False), (24, False), (32, False), (14, True)])
+def test_presence_filter_of_the_table_form_never_changes_a_result(L, iupac, monkeypatch):
+    """Round 5: where a hash-table memo's exact-match entries are few, the kernel keeps a two-choice hot table and a PRESENCE FILTER over
+    all memo keys in LDS, and a read whose two filter bits are not both set is None without a look at the table (memo_hash.hpp).  A filter
+    must have no false negatives: the same reads through the table form with the filter, without it (FQTK_MEMO_NO_FILTER=1 at create)
+    and through the oracle -- 30 % of them random (in no slot of the table: the reads the filter answers), the rest samples with
+    substitutions and no-calls (barcode_matching.rs:119-186)."""
+    rng = np.random.default_rng(900 + L)
+    S = 384
+    alphabet = list("ACGT") if not iupac else list("ACGTACGTACGTRYKMN")
+    seen = set()
+    while len(seen) < S:
+        seen.add("".join(rng.choice(alphabet, size=L)))
+    bcs = sorted(seen)
+    n = 200_000
+    acgtn = np.frombuffer(b"ACGTN", dtype=np.uint8)
+    plain = np.frombuffer(b"ACGT", dtype=np.uint8)
+    src = np.stack([np.frombuffer(b.encode(), dtype=np.uint8) for b in bcs])[rng.integers(0, S, size=n)]
+    src = np.where(np.isin(src, plain), src, plain[rng.integers(0, 4, size=src.shape)])      # (a read of a degenerate sample: some base it allows, or not)
+    obs = np.where(rng.random((n, L)) < 0.985, src, acgtn[rng.integers(0, 5, size=(n, L))])
+    rnd = rng.random(n) < 0.3
+    obs[rnd] = plain[rng.integers(0, 4, size=(int(rnd.sum()), L))]
+    obs = np.ascontiguousarray(obs)
+    lit = O.RefLiteral(bcs, 1, 2, True)
+    i, b, nx, c = lit.assign_batch(obs)
+    results = {}
+    for name, off in (("filter", ""), ("no filter", "1")):
+        monkeypatch.setenv("FQTK_MEMO_NO_FILTER", off)
+        gm = BarcodeMatcher(bcs, 1, 2, True)
+        if gm.memo_kind == BarcodeMatcher.MEMO_LDS:
+            gm.memo_kind = BarcodeMatcher.MEMO_TABLE
+        assert gm.memo_kind == BarcodeMatcher.MEMO_TABLE, (name, gm.memo_kind)
+        got, counts = gm.assign_batch(obs)
+        assert np.array_equal(got["idx"], i) and np.array_equal(got["best"], b) and np.array_equal(got["next"], nx), name
+        assert np.array_equal(counts, c), name
+        results[name] = got
+    assert np.array_equal(results["filter"].view(np.uint32), results["no filter"].view(np.uint32))
+    assert int((i == 0xFFFF).sum()) > n // 5          # (the random reads are unmatched: the filter had something to answer)
+    _loaded_native()
