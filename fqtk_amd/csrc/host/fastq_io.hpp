@@ -494,6 +494,9 @@ class FastqSource {
             *eof = *avail == 0;
             return true;
         }
+        // (the producer reports damage ONCE, as its last piece, and ends: whoever asks again -- `fqtk demux` judges the record size by the
+        //  first MiB before its reader threads start -- gets the same answer, not an empty queue to wait on for ever)
+        if (!failed_.empty()) { *err = failed_; return false; }
         while (cur_pos_ == cur_end_ && !eof_) {
             Piece pc;
             {
@@ -503,7 +506,7 @@ class FastqSource {
                 q_.pop_front();
             }
             cv_space_.notify_one();
-            if (!pc.error.empty()) { *err = pc.error; return false; }
+            if (!pc.error.empty()) { failed_ = pc.error; *err = pc.error; return false; }
             if (pc.eof) { eof_ = true; break; }
             cur_ = std::move(pc.buf);
             cur_pos_ = pc.head;
@@ -524,6 +527,7 @@ class FastqSource {
             map_unmapped_ = upto;
         }
     }
+    std::string failed_;                    // the producer's error, once it has been taken off the queue
     size_t map_unmapped_ = 0;
     std::atomic<size_t> cut_released_{0};   // end offset of the last cut its consumer is done with
     size_t cut_unmap_step_ = 64u << 20;     // (tests shrink it: set_cut_unmap_step)
@@ -678,6 +682,7 @@ class FastqSource {
     // Makes the next piece current.  The unparsed rest of the current one (the beginning of a record) is moved in
     // front of it -- into the head room every piece comes with, or, if a record is longer than that, into a copy.
     bool next_piece(std::string *err) {
+        if (!failed_.empty()) { *err = failed_; return false; }
         Piece pc;
         {
             std::unique_lock<std::mutex> lk(mu_);
@@ -686,7 +691,7 @@ class FastqSource {
             q_.pop_front();
         }
         cv_space_.notify_one();
-        if (!pc.error.empty()) { *err = pc.error; return false; }
+        if (!pc.error.empty()) { failed_ = pc.error; *err = pc.error; return false; }
         if (pc.eof) { eof_ = true; return true; }
         if (pc.len == 0) return true;   // (a BGZF round that only read more input)
         const size_t rest = cur_ ? cur_end_ - cur_pos_ : 0;

@@ -595,6 +595,21 @@ int64_t fqtk_host_read_raw(const char *path, uint64_t batch, char *out, size_t c
     return (int64_t)calls;
 }
 
+// What `fqtk demux` does with every input before its reader threads start: judge the record size by the first MiB
+// (estimate_raw_bytes), then read.  Returns the records of the first next_raw call, or -1 with *err -- and must RETURN when the input
+// is damaged: the producer reports an error once, and the estimate used to swallow it (the reader then waited on an empty queue).
+int64_t fqtk_host_estimate_then_read(const char *path, uint64_t batch, uint64_t *estimate, char *err, size_t errcap) {
+    FastqSource src;
+    std::string e;
+    if (!src.open(path, &e)) { put(e, err, errcap); return -1; }
+    *estimate = src.estimate_raw_bytes(1024);
+    HeapRaw buf;
+    buf.grow(1 << 16, 0);
+    size_t n = 0, bytes = 0;
+    if (!src.next_raw((size_t)batch, &buf, &n, &bytes, &e)) { put(e, err, errcap); return -1; }
+    return (int64_t)n;
+}
+
 // Drives ChunkSchedule the way `fqtk demux` does -- one submitter, chunks collected in order, completions arriving
 // whenever `order` says (order[i] != 0: try to collect one chunk before the next submit) -- and checks what the
 // pipeline relies on.  Returns 0, or the number of the first rule broken:

@@ -400,3 +400,41 @@ def test_several_devices_take_compressed_inputs_through_the_host_readers(tmp_pat
     a, b = _outputs(tmp_path / "one"), _outputs(tmp_path / "two")
     assert a.keys() == b.keys() and all(a[k] == b[k] for k in a)
     assert open(tmp_path / "one" / "demux-metrics.txt").read() == open(tmp_path / "two" / "demux-metrics.txt").read()
+
+
+def test_damaged_gzip_streams_end_the_run_the_way_the_host_decoders_end_it(tmp_path, monkeypatch):
+    """A flipped bit anywhere in a serial gzip input -- the member header, a block header, the middle of a block, the trailer -- must end
+    the run with an error and no outputs, or (a bit the format ignores) change nothing: the device's chunked decoder never hangs on
+    garbage, never reports success where the host's decoders report damage, and never reports damage where they do not."""
+    import gzip
+    rng = np.random.default_rng(81)
+    bcs = ["ACGTACGT", "TTGCAATG"]
+    n = 12_000
+    r1 = _records(n, rng, [90], "r")
+    r1 = [(h, bcs[k & 1] + b, "F" * 8 + q) for k, (h, b, q) in enumerate(r1)]
+    good = gzip.compress(_text(r1), 6)
+    meta = _meta(tmp_path, bcs)
+    monkeypatch.setenv("FQTK_GZ_DEVICE_CHUNK_KB", "8")
+    monkeypatch.setenv("FQTK_GZ_DEVICE_CHUNKS", "12")
+    positions = [3, 9, 11, 40, len(good) // 3, len(good) // 2, len(good) // 2 + 4097, len(good) - 9, len(good) - 3] + [int(x) for x in rng.integers(12, len(good) - 8, 5)]
+    agree_fail = agree_ok = 0
+    for k, at in enumerate(positions):
+        bad = bytearray(good)
+        bad[at] ^= 1 << int(rng.integers(0, 8))
+        f = str(tmp_path / f"bad{k}.fastq.gz")
+        open(f, "wb").write(bytes(bad))
+        rc = {}
+        for name, extra in (("device", ["--gpu-gunzip"]), ("host", ["--host-inflate"])):
+            out = tmp_path / f"o{k}_{name}"
+            r = H.run_demux([f], ["8B+T"], meta, out, threads=6, extra=["--chunk-reads", "3000"] + extra)
+            rc[name] = r.returncode
+            if r.returncode != 0:
+                assert not list(out.glob("*.fq.gz")), (at, name, r.stderr[-300:])
+                assert "parsing FASTQs" in r.stderr or "gzip" in r.stderr or "expected" in r.stderr or "differ" in r.stderr, (at, name, r.stderr[-300:])
+        assert (rc["device"] == 0) == (rc["host"] == 0), (at, rc)
+        if rc["device"] == 0:
+            assert _outputs(tmp_path / f"o{k}_device") == _outputs(tmp_path / f"o{k}_host"), at
+            agree_ok += 1
+        else:
+            agree_fail += 1
+    assert agree_fail >= 8

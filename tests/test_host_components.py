@@ -552,3 +552,33 @@ def test_reader_teardown_after_a_parse_error_mid_file_with_parallel_decoders(tmp
     for _ in range(5):
         with pytest.raises(ValueError, match="lengths differ"):
             H.fastq_digest(p, batch=1000)
+
+
+@pytest.mark.timeout(120)
+def test_a_damaged_gzip_input_is_an_error_for_everyone_who_asks_not_a_wait_for_ever(tmp_path):
+    """Round 5 (found by the damaged-stream runs of tests/test_cli_bgzf_inputs_gpu.py): `fqtk demux` judges the record size of every
+    input by its first MiB before the reader threads start; a decoder that fails reports its error ONCE, as the last piece of its
+    queue -- the estimate took it, and the reader waited on an empty queue for ever.  The error now stays with the source."""
+    import ctypes as C
+    import gzip
+    text = "".join(f"@r{i} x\nACGTACGTAC\n+\nFFFFFFFFFF\n" for i in range(20000)).encode()
+    good = gzip.compress(text, 6)
+    fn = H.lib().fqtk_host_estimate_then_read
+    fn.restype = C.c_int64
+    def run(data):
+        p = tmp_path / "x.fastq.gz"
+        p.write_bytes(data)
+        est = C.c_uint64(0)
+        err = C.create_string_buffer(512)
+        n = fn(str(p).encode(), C.c_uint64(1000), C.byref(est), err, C.c_size_t(512))
+        return n, est.value, err.value.decode()
+    n, est, err = run(good)
+    assert n == 1000 and est > 1000 * 20 and err == ""
+    for at, bit in ((3, 2), (11, 3), (40, 4), (len(good) // 2, 0)):
+        bad = bytearray(good)
+        bad[at] ^= 1 << bit
+        n, est, err = run(bytes(bad))
+        assert (n == -1 and "gzip" in err) or n == 1000, (at, n, err)       # damaged at the start: an error, at once; further in: the first records still come
+    bad = bytearray(good)
+    bad[3] ^= 4
+    assert run(bytes(bad))[0] == -1
