@@ -438,3 +438,51 @@ def test_damaged_gzip_streams_end_the_run_the_way_the_host_decoders_end_it(tmp_p
         else:
             agree_fail += 1
     assert agree_fail >= 8
+
+
+def test_damaged_bgzf_and_truncated_inputs_end_the_run_on_both_paths(tmp_path, monkeypatch):
+    """The same for BGZF files (a flipped bit in a member's header, payload, CRC-32 or ISIZE; the file cut off in a member, behind a
+    member, in the EOF marker) and for serial gzip files cut short: the device path and the host path agree on whether the run
+    succeeds, a failed run leaves no outputs, nothing hangs."""
+    import gzip
+    rng = np.random.default_rng(82)
+    bcs = ["ACGTACGT", "TTGCAATG"]
+    n = 9000
+    r1 = _records(n, rng, [80], "r")
+    r1 = [(h, bcs[k & 1] + b, "F" * 8 + q) for k, (h, b, q) in enumerate(r1)]
+    text = _text(r1)
+    bg = open(_write_bgzf(tmp_path / "good.bgz.gz", text, member=20000), "rb").read()
+    gz = gzip.compress(text, 6)
+    meta = _meta(tmp_path, bcs)
+    monkeypatch.setenv("FQTK_GZ_DEVICE_CHUNK_KB", "8")
+    monkeypatch.setenv("FQTK_GZ_DEVICE_CHUNKS", "12")
+    cases = []
+    for at in (3, 12, 16, 17, 30, len(bg) // 2, len(bg) - 28 - 8, len(bg) - 28 - 2, len(bg) - 20):
+        b = bytearray(bg)
+        b[at] ^= 1 << int(rng.integers(0, 8))
+        cases.append(("bgzf flip %d " % at, bytes(b)))
+    for cut in (len(bg) - 28, len(bg) - 29, len(bg) - 10, len(bg) // 2, 17, 1):
+        cases.append(("bgzf cut %d" % cut, bg[:cut]))
+    for cut in (len(gz) - 1, len(gz) - 8, len(gz) - 9, len(gz) // 2, 20, 9):
+        cases.append(("gzip cut %d" % cut, gz[:cut]))
+    fails = 0
+    for k, (what, data) in enumerate(cases):
+        f = str(tmp_path / f"c{k}.fastq.gz")
+        open(f, "wb").write(data)
+        rc = {}
+        for name, extra in (("device", ["--gpu-gunzip"]), ("host", ["--host-inflate"])):
+            out = tmp_path / f"o{k}_{name}"
+            r = H.run_demux([f], ["8B+T"], meta, out, threads=6, extra=["--chunk-reads", "2000"] + extra)
+            rc[name] = r.returncode
+            if r.returncode != 0:
+                assert not list(out.glob("*.fq.gz")), (what, name, r.stderr[-300:])
+        # (the device path reads a member's header as RFC 1952 says -- a flag that announces a name, a comment, a header CRC moves the start of
+        #  the DEFLATE stream, as it does for the reference's flate2 -- where the host's BGZF walk goes by BSIZE alone: on a damaged FLG byte the
+        #  device path may refuse what the host path lets through, never the other way round)
+        strict_only = what.startswith("bgzf flip 3 ")
+        assert (rc["device"] == 0) == (rc["host"] == 0) or (strict_only and rc["device"] != 0), (what, rc)
+        if rc["device"] == 0:
+            assert rc["host"] == 0 and _outputs(tmp_path / f"o{k}_device") == _outputs(tmp_path / f"o{k}_host"), what
+        else:
+            fails += 1
+    assert fails >= 12
