@@ -486,3 +486,47 @@ def test_damaged_bgzf_and_truncated_inputs_end_the_run_on_both_paths(tmp_path, m
         else:
             fails += 1
     assert fails >= 12
+
+
+def test_serial_gzip_inputs_end_like_the_host_path_ends_them(tmp_path, monkeypatch):
+    """The end-of-input rules once more, for serial gzip inputs decoded on the device: a last line without a newline, three blank
+    lines (dropped), four (a malformed record), inputs of different lengths (the shorter one is named) -- as the host decoders."""
+    import gzip
+    rng = np.random.default_rng(91)
+    bcs = ["ACGTACGT", "TTGCAATG"]
+    n = 5000
+    r1 = _records(n, rng, [70], "r")
+    i1 = [(h, bcs[k & 1], "F" * 8) for k, (h, _, _) in enumerate(r1)]
+    meta = _meta(tmp_path, bcs)
+    monkeypatch.setenv("FQTK_GZ_DEVICE_CHUNK_KB", "8")
+    monkeypatch.setenv("FQTK_GZ_DEVICE_CHUNKS", "8")
+
+    def gz(name, data, level=6):
+        p = str(tmp_path / name)
+        open(p, "wb").write(gzip.compress(data, level))
+        return p
+
+    def both(files, tag):
+        out = {}
+        for name, extra in (("device", ["--gpu-gunzip"]), ("host", ["--host-inflate"])):
+            out[name] = H.run_demux(files, ["+T", "8B"], meta, tmp_path / (tag + name), threads=8, extra=["--chunk-reads", "900"] + extra)
+        return out
+
+    for tag, tail1, tail2, ok in (("nonl", b"", b"", True), ("b3", b"\n\n\n", b"\n\n\n", True), ("b2b0", b"\n\n", b"", True), ("b4", b"\n\n\n\n", b"\n\n\n\n", False)):
+        t1 = _text(r1, last_newline=bool(tail1) or tag != "nonl") + tail1
+        t2 = _text(i1, last_newline=bool(tail2) or tag != "nonl") + tail2
+        rr = both([gz(tag + "_1.fastq.gz", t1), gz(tag + "_2.fastq.gz", t2, 1)], tag)
+        for name in ("device", "host"):
+            assert (rr[name].returncode == 0) == ok, (tag, name, rr[name].stderr[-300:])
+        if ok:
+            assert _outputs(tmp_path / (tag + "device")) == _outputs(tmp_path / (tag + "host")), tag
+            assert "decoded on the device in chunks" in rr["device"].stderr
+        else:
+            assert "expected '@'" in rr["device"].stderr and "expected '@'" in rr["host"].stderr
+    rr = both([gz("s_1.fastq.gz", _text(r1)), gz("s_2.fastq.gz", _text(i1[:n - 11]))], "short")
+    for name in ("device", "host"):
+        assert rr[name].returncode != 0 and "out of sync" in rr[name].stderr and "s_2.fastq.gz" in rr[name].stderr, (name, rr[name].stderr[-300:])
+    rr = both([gz("c_1.fastq.gz", _text(r1)[:-30]), gz("c_2.fastq.gz", _text(i1))], "cut")
+    for name in ("device", "host"):
+        assert rr[name].returncode != 0, name
+        assert "truncated record" in rr[name].stderr or "out of sync" in rr[name].stderr or "lengths differ" in rr[name].stderr, (name, rr[name].stderr[-300:])
