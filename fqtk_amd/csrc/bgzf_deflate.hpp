@@ -590,10 +590,11 @@ FQTK_HD inline uint32_t match_cost(uint32_t len, uint32_t dist) {   // half-bits
 
 // P1b: greedy LZ77 over this lane's slice; tokens to tok[t * kLanes + lane].  Deterministic: reads the tables
 // of P1a and the lane's own state only.
-struct LzLane { uint32_t p, end, nt, avg16, effort, pending; uint64_t cheap; };   // avg16: the block's average literal cost, half-bits x 16; cheap: phase_index's mask
+struct LzLane { uint32_t p, end, nt, avg16, effort, pending, miss; uint64_t cheap; };   // miss: literals since the lane's last match (lz_step's skipping); avg16: the block's average literal cost, half-bits x 16; cheap: phase_index's mask
 FQTK_HD inline void lz_begin(Shared &S, int lane, uint32_t n, LzLane &st, uint64_t cheap_mask) {
     st.cheap = cheap_mask;
     st.pending = 0;
+    st.miss = 0;
     st.p = (uint32_t)lane * kChunk;
     st.end = st.p + kChunk < n ? st.p + kChunk : n;
     st.nt = 0;
@@ -610,6 +611,12 @@ __device__ unsigned long long g_lz_cycles[10];   // setup, candidate reads + lit
 #define FQTK_LZ_MARK(k) do { const uint64_t now_ = __builtin_readcyclecounter(); lz_acc[k] += now_ - lz_t; lz_t = now_; } while (0)
 #else
 #define FQTK_LZ_MARK(k) do { } while (0)
+#endif
+#ifndef FQTK_BGZF_SKIP
+#define FQTK_BGZF_SKIP 1   // unprobed literals deep inside cheap runs (lz_step); 0: every position is probed (tools/ab_bgzf.sh "" "-DFQTK_BGZF_SKIP=0")
+#endif
+#ifndef FQTK_BGZF_SKIP_SHIFT
+#define FQTK_BGZF_SKIP_SHIFT 2   // one unprobed literal more per 2^this literals since the lane's last match (GB/s in / output on binned qualities: 3: 71.4 / +0.1 %, 2: 73.0 / +0.5 %, 1: 74.3 / +1.3 %; none: 67.2)
 #endif
 #ifndef FQTK_BGZF_ABL
 #define FQTK_BGZF_ABL 0   // developer ablations of the LZ phase (tools/bgzf_phases.sh); 0 in the product
@@ -755,6 +762,7 @@ FQTK_HD inline void lz_take(Shared &S, int lane, uint32_t n, uint32_t *tok, LzLa
     if (!(FQTK_BGZF_ABL & 2)) tok[st.nt * kLanes + (uint32_t)lane] = match_token(mlen, mdist, p - (uint32_t)lane * kChunk);
     ++st.nt;
     st.pending = (FQTK_BGZF_ABL & 4) ? 0u : 2u;   // (a match is at least four bytes long: three positions skipped)
+    st.miss = 0;
     st.p = p + mlen;
 }
 
@@ -832,6 +840,35 @@ FQTK_HD inline bool lz_step(Shared &S, int lane, uint32_t n, uint32_t *tok, LzLa
     }
     if (!(FQTK_BGZF_ABL & 1)) FQTK_BGZF_ADD(&S.freq_ll[wb & 0xFFu], 1u);
     st.p = p + 2;
+#if FQTK_BGZF_SKIP
+    // Deep inside a run of literals that are cheap as literals -- a sequence line: 150 random bases, no repeat of them pays for its distance code
+    // before twelve bases, and one of twelve is a once-in-five-hundred-positions accident -- the positions behind these two are taken as
+    // literals UNPROBED, the more of them the longer the run has lasted (one per four literals since the lane's last match, six at most; their
+    // bytes are in the twelve this step has read).  A wave's step count is that of its slowest lanes, and those are the lanes in sequence
+    // lines: 32 steps of a 64-byte slice become ~14.  A true repeat that starts inside such a run is found a few bases late; the region
+    // tables hold every position regardless (phase_index), so nothing becomes unfindable.  The first literals of a run are probed as before.
+    st.miss += 2u;
+    {
+        uint32_t extra = st.miss >> (st.effort ? FQTK_BGZF_SKIP_SHIFT : FQTK_BGZF_SKIP_SHIFT - 1u);   // (--compression-level 1-3: sooner)
+        extra = extra < 6u ? extra : 6u;
+        const uint32_t left = st.end - st.p;                              // (st.p <= st.end here)
+        extra = extra < left ? extra : left;
+        if (st.p + extra + 4u > n) extra = 0;                             // (the block's last bytes take the plain path)
+        if (back != 2u) extra = 0;
+        if (extra) {                                                      // (left > 0: the shift below stays under 64)
+            const uint32_t cheap_bits = (uint32_t)(st.cheap >> (st.p - (uint32_t)lane * kChunk)) & 0x3Fu;
+            const uint32_t run = ctz32(~cheap_bits | 0x40u);              // cheap positions in a row from st.p on (<= 6)
+            extra = extra < run ? extra : run;
+        }
+        for (uint32_t k = 0; k < extra; ++k) {
+            const uint32_t idx = 4u + k;                                  // byte of r: two positions back + p, p + 1 + k more
+            const uint32_t wsel = idx < 8u ? r[1] : r[2];
+            if (!(FQTK_BGZF_ABL & 1)) FQTK_BGZF_ADD(&S.freq_ll[(wsel >> (8u * (idx & 3u))) & 0xFFu], 1u);
+        }
+        st.p += extra;
+        st.miss += extra;
+    }
+#endif
     FQTK_LZ_MARK(7);
     return true;
 }
