@@ -371,7 +371,7 @@ FQTK_HD inline uint32_t load_le32(const uint8_t *p) {
 // three candidates, 102 GB/s with none).  The check bits travel with every table entry, so a candidate's bytes are only
 // read when its gram (almost certainly) is the position's own.
 #ifndef FQTK_BGZF_CHEAP4
-#define FQTK_BGZF_CHEAP4 28u
+#define FQTK_BGZF_CHEAP4 37u
 #endif
 constexpr uint32_t kCheap4 = FQTK_BGZF_CHEAP4;
 FQTK_HD inline uint32_t gram_hash(uint32_t w, uint32_t w4, bool cheap) {
@@ -590,16 +590,21 @@ FQTK_HD inline uint32_t match_cost(uint32_t len, uint32_t dist) {   // half-bits
 
 // P1b: greedy LZ77 over this lane's slice; tokens to tok[t * kLanes + lane].  Deterministic: reads the tables
 // of P1a and the lane's own state only.
-struct LzLane { uint32_t p, end, nt, avg16, effort, pending, miss; uint64_t cheap; };   // miss: literals since the lane's last match (lz_step's skipping); avg16: the block's average literal cost, half-bits x 16; cheap: phase_index's mask
+struct LzLane { uint32_t p, end, nt, avg16, effort, pending, miss, open; uint64_t cheap; };   // open: a match still being compared (lz_step), (candidate + 1) << 9 | bytes so far; miss: literals since the lane's last match (lz_step's skipping); avg16: the block's average literal cost, half-bits x 16; cheap: phase_index's mask
 FQTK_HD inline void lz_begin(Shared &S, int lane, uint32_t n, LzLane &st, uint64_t cheap_mask) {
     st.cheap = cheap_mask;
     st.pending = 0;
     st.miss = 0;
+    st.open = 0;
     st.p = (uint32_t)lane * kChunk;
     st.end = st.p + kChunk < n ? st.p + kChunk : n;
     st.nt = 0;
     st.effort = S.effort;
     st.avg16 = n ? (uint32_t)(((uint64_t)S.lit_total << 4) / n) : 0u;
+#if defined(__HIP_DEVICE_COMPILE__)   // (the same for every lane: scalar registers)
+    st.effort = __builtin_amdgcn_readfirstlane(st.effort);
+    st.avg16 = __builtin_amdgcn_readfirstlane(st.avg16);
+#endif
     // (the lane's own table already holds the slice before this one: phase_index of the lane before)
     (void)S;
 }
@@ -612,18 +617,30 @@ __device__ unsigned long long g_lz_cycles[10];   // setup, candidate reads + lit
 #else
 #define FQTK_LZ_MARK(k) do { } while (0)
 #endif
+#if defined(FQTK_BGZF_LZ_COUNTS) && defined(FQTK_BGZF_PHASE_TIMES) && defined(__HIP_DEVICE_COMPILE__)   // (events per WAVEFRONT: the first active lane counts; tools/bgzf_phases.sh with LZ_COUNTS=1)
+#define FQTK_LZ_COUNT(k) do { if (__lane_id() == (unsigned)__ffsll((unsigned long long)__ballot(1)) - 1u) atomicAdd(&g_lz_cycles[k], 1ull); } while (0)
+#else
+#define FQTK_LZ_COUNT(k) do { } while (0)
+#endif
+#if defined(FQTK_BGZF_TRACE) && !defined(__HIP_DEVICE_COMPILE__)   // (CPU study, tools/bgzf_lockstep.py: what every lane did in every step, to stderr)
+struct LzTraceAt { int lane = 0, step = 0; };
+inline LzTraceAt g_lz_at;
+#define FQTK_LZ_TRACE(fmt, ...) fprintf(stderr, "LZ %d %d " fmt "\n", g_lz_at.lane, g_lz_at.step, __VA_ARGS__)
+#else
+#define FQTK_LZ_TRACE(fmt, ...) do { } while (0)
+#endif
 #ifndef FQTK_BGZF_SKIP
 #define FQTK_BGZF_SKIP 1   // unprobed literals deep inside cheap runs (lz_step); 0: every position is probed (tools/ab_bgzf.sh "" "-DFQTK_BGZF_SKIP=0")
 #endif
-#ifndef FQTK_BGZF_SKIP_SHIFT
-#define FQTK_BGZF_SKIP_SHIFT 2   // one unprobed literal more per 2^this literals since the lane's last match (GB/s in / output on binned qualities: 3: 71.4 / +0.1 %, 2: 73.0 / +0.5 %, 1: 74.3 / +1.3 %; none: 67.2)
+#ifndef FQTK_BGZF_SKIP_AFTER
+#define FQTK_BGZF_SKIP_AFTER 6u   // literals since the lane's last match before any goes unprobed (tools/ab_bgzf.sh, tools/bgzf_ratio.py; GB/s in / output on binned qualities: 6: 75.5 / +0.6 %, 8: 75.0 / +0.4 %, 12: 73.8 / +0.2 %; one more per four literals instead: 74.8 / +0.5 %; none: 69)
 #endif
 #ifndef FQTK_BGZF_ABL
 #define FQTK_BGZF_ABL 0   // developer ablations of the LZ phase (tools/bgzf_phases.sh); 0 in the product
 #endif
 // A position's look-up comes in three parts, so that a step can have the look-ups of TWO positions in flight (lz_step):
 // the table entries of its gram (lz_probe), the candidates they stand for (lz_candidates), and -- only when there is one --
-// the comparison of the bytes (lz_match).
+// the comparison of the bytes (lz_first, lz_rest).
 struct LzProbe { uint32_t near_slot, mine_near, mine, e_near, e_min, e_max; };
 FQTK_HD inline void lz_probe(Shared &S, int lane, uint32_t p, const LzLane &st, uint32_t w, uint32_t w4, LzProbe &pr) {
     const bool cheap = ((st.cheap >> (p - (uint32_t)lane * kChunk)) & 1ull) != 0;   // (what for_grams found: literal costs and p + 8 <= n)
@@ -680,19 +697,42 @@ FQTK_HD inline bool lz_first(Shared &S, uint32_t p, uint32_t w, const uint32_t (
     }
     return real && !(FQTK_BGZF_ABL & 32);
 }
-// The best of the candidates at position p: length and distance (0 = none pays for itself).
+// How far a match at p may run: past the end of the lane's slice (phase_reach; --compression-level 1-3: it may not, 7 % faster).
+FQTK_HD inline uint32_t lz_max_len(uint32_t n, uint32_t p, const LzLane &st) {
+#ifdef FQTK_BGZF_NO_REACH   // (study: matches cut at the slice's end, as before phase_reach existed)
+    uint32_t maxl = st.end - p;
+#else
+    uint32_t maxl = st.effort ? n - p : st.end - p;
+#endif
+    maxl = maxl < 258u ? maxl : 258u;
+    if ((FQTK_BGZF_ABL & 8) && maxl > 8u) maxl = 8u;
+    return maxl;
+}
+// Sixteen bytes of a comparison, each side a run of aligned words: how many of them are equal (16: all).
+FQTK_HD inline uint32_t lz_round(Shared &S, uint32_t q, uint32_t p) {
+    FQTK_LZ_COUNT(3);
+    uint32_t a[4], b[4];
+    buf_run<4>(S.buf, q, a);
+    buf_run<4>(S.buf, p, b);
+    const uint32_t x0 = a[0] ^ b[0], x1 = a[1] ^ b[1], x2 = a[2] ^ b[2], x3 = a[3] ^ b[3];
+    if (!(x0 | x1 | x2 | x3)) return 16u;
+    return x0 ? ctz32(x0) >> 3 : (x1 ? 4 + (ctz32(x1) >> 3) : (x2 ? 8 + (ctz32(x2) >> 3) : 12 + (ctz32(x3) >> 3)));
+}
+#ifndef FQTK_BGZF_OPEN_ROUNDS
+#define FQTK_BGZF_OPEN_ROUNDS 1u   // rounds of sixteen bytes a candidate is compared for inside the step that found it (lz_rest); 0xFFFFu: to its end, as until round 5
+#endif
+#ifndef FQTK_BGZF_OPEN_STEP
+#define FQTK_BGZF_OPEN_STEP 1u     // rounds per step of a match that is still being compared (lz_step)
+#endif
+// The best of the candidates at position p: length and distance (0 = none pays for itself).  open: the candidate was still equal
+// after FQTK_BGZF_OPEN_ROUNDS rounds -- forty bytes: it is the match, whatever the others are, and how long it is the lane's
+// next steps find out (lz_step).
 FQTK_HD inline void lz_rest(Shared &S, uint32_t n, uint32_t p, const LzLane &st, uint32_t w, uint32_t w4, const uint32_t (&qpos)[kCands],
-                            const uint32_t (&first)[kCands], uint32_t &mlen, uint32_t &mdist) {
+                            const uint32_t (&first)[kCands], uint32_t &mlen, uint32_t &mdist, bool &open) {
     uint32_t msave = 0;
     mlen = mdist = 0;
-#ifdef FQTK_BGZF_NO_REACH   // (study: matches cut at the slice's end, as before phase_reach existed)
-    uint32_t maxl = st.end - p < 258u ? st.end - p : 258u;
-#else
-    // a match may run past the end of the lane's slice: phase_reach (--compression-level 1-3: it may not; 7 % faster)
-    uint32_t maxl = st.effort ? n - p : st.end - p;
-    maxl = maxl < 258u ? maxl : 258u;
-#endif
-    if ((FQTK_BGZF_ABL & 8) && maxl > 8u) maxl = 8u;
+    open = false;
+    const uint32_t maxl = lz_max_len(n, p, st);
     uint32_t second[kCands];
 #if defined(__HIP_DEVICE_COMPILE__)
 #pragma unroll
@@ -724,31 +764,28 @@ FQTK_HD inline void lz_rest(Shared &S, uint32_t n, uint32_t p, const LzLane &st,
             l = 4u + (ctz32(x4) >> 3);
         } else {
             l = 8;
+            uint32_t rounds = 0;
             while (l < maxl) {
-                uint32_t a[4], b[4];
-                buf_run<4>(S.buf, q + l, a);
-                buf_run<4>(S.buf, p + l, b);
-                const uint32_t x0 = a[0] ^ b[0], x1 = a[1] ^ b[1], x2 = a[2] ^ b[2], x3 = a[3] ^ b[3];
-                if (x0 | x1 | x2 | x3) {
-                    l += x0 ? ctz32(x0) >> 3 : (x1 ? 4 + (ctz32(x1) >> 3) : (x2 ? 8 + (ctz32(x2) >> 3) : 12 + (ctz32(x3) >> 3)));
-                    break;
-                }
-                l += 16;
+                if (rounds == FQTK_BGZF_OPEN_ROUNDS) { open = true; break; }
+                const uint32_t same = lz_round(S, q + l, p + l);
+                l += same;
+                ++rounds;
+                if (same != 16u) break;
+            }
+            if (open) {
+                FQTK_LZ_TRACE("C %d %u", c, l);
+                mlen = l;
+                mdist = p - q;
+                return;
             }
         }
         if (l > maxl) l = maxl;
+        FQTK_LZ_TRACE("C %d %u", c, l);
         if (l < (uint32_t)kMinMatch) continue;
         const uint32_t lit = l == 4 ? lit8[4] : (l == 5 ? lit8[5] : (l == 6 ? lit8[6] : (l == 7 ? lit8[7] : lit8[8] + (((l - 8) * st.avg16) >> 4))));
         const uint32_t cost = match_cost(l, p - q);
         if (lit > cost && lit - cost > msave) { msave = lit - cost; mlen = l; mdist = p - q; }
     }
-}
-
-FQTK_HD inline void lz_match(Shared &S, uint32_t n, uint32_t p, const LzLane &st, uint32_t w, uint32_t w4, const uint32_t (&qpos)[kCands],
-                             uint32_t &mlen, uint32_t &mdist) {
-    uint32_t first[kCands];
-    mlen = mdist = 0;
-    if (lz_first(S, p, w, qpos, first)) lz_rest(S, n, p, st, w, w4, qpos, first, mlen, mdist);
 }
 
 // A match at p is taken: its token stored (phase_reach counts its symbols).  The last two positions it skips are recent
@@ -778,6 +815,29 @@ FQTK_HD inline bool lz_step(Shared &S, int lane, uint32_t n, uint32_t *tok, LzLa
 ) {
     if (st.p >= st.end) return false;
     const uint32_t p = st.p;
+    if (st.open) {
+        // A match that was still equal when the step that found it ended: FQTK_BGZF_OPEN_STEP more rounds in every step, until the
+        // bytes differ or the match is full.  (Compared to its end inside ONE step, a long match -- the run of a quality line, a
+        // line copied whole -- held the other 63 lanes of the wavefront up for sixteen rounds; now they go on with their own steps
+        // and pay for two rounds.  tools/bgzf_lockstep.py: the rounds a wavefront runs per step.)
+        const uint32_t q = (st.open >> 9) - 1u, maxl = lz_max_len(n, p, st);
+        uint32_t l = st.open & 511u;
+        bool done = l >= maxl;
+        for (uint32_t k = 0; k < FQTK_BGZF_OPEN_STEP && !done; ++k) {
+            const uint32_t same = lz_round(S, q + l, p + l);
+            l += same;
+            done = same != 16u || l >= maxl;
+        }
+        FQTK_LZ_TRACE("O %u", (l - (st.open & 511u) + 15u) / 16u);
+        if (done) {
+            FQTK_LZ_COUNT(4);
+            st.open = 0;
+            lz_take(S, lane, n, tok, st, p, l < maxl ? l : maxl, p - q);
+        } else {
+            st.open = ((q + 1u) << 9) | l;
+        }
+        return true;
+    }
     if (p + 4 > n) {   // the block's last three bytes: literals
         if (!(FQTK_BGZF_ABL & 1)) FQTK_BGZF_ADD(&S.freq_ll[buf_byte(S.buf, p)], 1u);
         st.p = p + 1;
@@ -791,7 +851,9 @@ FQTK_HD inline bool lz_step(Shared &S, int lane, uint32_t n, uint32_t *tok, LzLa
     buf_run<3>(S.buf, p - back, r);
     const uint32_t wa = bytes_at(r[0], r[1], back), wa4 = bytes_at(r[1], r[2], back);
     const uint32_t wb = bytes_at(r[0], r[1], back + 1u), wb4 = bytes_at(r[1], r[2], back + 1u);
+    FQTK_LZ_COUNT(0);
     if (st.pending) {
+        FQTK_LZ_COUNT(5);
 #if defined(__HIP_DEVICE_COMPILE__)
 #pragma unroll
 #endif
@@ -811,46 +873,71 @@ FQTK_HD inline bool lz_step(Shared &S, int lane, uint32_t n, uint32_t *tok, LzLa
     }
     S.near_tab[a.near_slot] = (uint16_t)a.mine_near;
     if (two) S.near_tab[b.near_slot] = (uint16_t)b.mine_near;
-    uint32_t qpos[kCands], mlen = 0, mdist = 0;
     // (A lazy step -- take the literal when the next position holds a longer match that saves more, zlib's levels 4-9 -- was
     //  measured on the CPU run of these phases: 0.0 % / -0.4 % of the output on varied / binned qualities.  Not kept.)
-    if (lz_candidates(lane, p, a, qpos)) {
-        if (FQTK_BGZF_ABL & 16) st.avg16 += qpos[0] + qpos[1] + qpos[2]; else   // (ablation: the candidates are worked out, nothing is compared)
-        lz_match(S, n, p, st, wa, wa4, qpos, mlen, mdist);
+    // Both positions' candidates are fetched and their first four bytes compared; then ONE pass through the match code serves
+    // whichever position the lane needs it for -- p when p has a real candidate, else p + 1.  (A wavefront runs that code whenever
+    // one of its 64 lanes has a real candidate, and with a pass per position it ran it twice in nearly every step.)  The lane
+    // whose candidate at p turns out not to pay for itself while p + 1 has one too takes a second pass: the output is the same
+    // as with a pass per position.
+    uint32_t qa[kCands], qb[kCands], fa[kCands], fb[kCands], mlen = 0, mdist = 0;
+    bool real_a = false, real_b = false;
+    if (lz_candidates(lane, p, a, qa)) {
+        if (FQTK_BGZF_ABL & 16) st.avg16 += qa[0] + qa[1] + qa[2]; else   // (ablation: the candidates are worked out, nothing is compared)
+        real_a = lz_first(S, p, wa, qa, fa);
+    }
+    if (two && lz_candidates(lane, p + 1, b, qb)) {
+        if (FQTK_BGZF_ABL & 16) st.avg16 += qb[0] + qb[1] + qb[2]; else
+        real_b = lz_first(S, p + 1, wb, qb, fb);
+    }
+    uint32_t mp = p;
+    bool still_equal = false;
+    if (real_a || real_b) {
+        FQTK_LZ_COUNT(1);
+        uint32_t qs[kCands], fs[kCands];
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+        for (int c = 0; c < kCands; ++c) { qs[c] = real_a ? qa[c] : qb[c]; fs[c] = real_a ? fa[c] : fb[c]; }
+        mp = real_a ? p : p + 1u;
+        FQTK_LZ_TRACE("R %d", real_a ? 0 : 1);
+        lz_rest(S, n, mp, st, real_a ? wa : wb, real_a ? wa4 : wb4, qs, fs, mlen, mdist, still_equal);
+        if (real_a && real_b && !mlen) {
+            FQTK_LZ_COUNT(2);
+            mp = p + 1u;
+            FQTK_LZ_TRACE("R %d", 2);
+            lz_rest(S, n, mp, st, wb, wb4, qb, fb, mlen, mdist, still_equal);
+        }
     }
     FQTK_LZ_MARK(2);
+    if (!(mlen && mp == p) && !(FQTK_BGZF_ABL & 1)) FQTK_BGZF_ADD(&S.freq_ll[wa & 0xFFu], 1u);
+    FQTK_LZ_TRACE("S %u %d", mlen, (int)(st.pending != 0));
+    if (still_equal) {   // (the lane stays at the match's position: its next steps take the first branch above)
+        st.p = mp;
+        st.open = ((mp - mdist + 1u) << 9) | mlen;
+        return true;
+    }
     if (mlen) {
-        lz_take(S, lane, n, tok, st, p, mlen, mdist);
+        FQTK_LZ_COUNT(4);
+        lz_take(S, lane, n, tok, st, mp, mlen, mdist);
         FQTK_LZ_MARK(6);
         return true;
     }
-    if (!(FQTK_BGZF_ABL & 1)) FQTK_BGZF_ADD(&S.freq_ll[wa & 0xFFu], 1u);
     st.p = p + 1;
-    FQTK_LZ_MARK(7);
     if (!two) return true;
-    if (lz_candidates(lane, p + 1, b, qpos)) {
-        if (FQTK_BGZF_ABL & 16) st.avg16 += qpos[0] + qpos[1] + qpos[2]; else
-        lz_match(S, n, p + 1, st, wb, wb4, qpos, mlen, mdist);
-    }
-    FQTK_LZ_MARK(2);
-    if (mlen) {
-        lz_take(S, lane, n, tok, st, p + 1, mlen, mdist);
-        FQTK_LZ_MARK(6);
-        return true;
-    }
     if (!(FQTK_BGZF_ABL & 1)) FQTK_BGZF_ADD(&S.freq_ll[wb & 0xFFu], 1u);
     st.p = p + 2;
 #if FQTK_BGZF_SKIP
     // Deep inside a run of literals that are cheap as literals -- a sequence line: 150 random bases, no repeat of them pays for its distance code
     // before twelve bases, and one of twelve is a once-in-five-hundred-positions accident -- the positions behind these two are taken as
-    // literals UNPROBED, the more of them the longer the run has lasted (one per four literals since the lane's last match, six at most; their
-    // bytes are in the twelve this step has read).  A wave's step count is that of its slowest lanes, and those are the lanes in sequence
-    // lines: 32 steps of a 64-byte slice become ~14.  A true repeat that starts inside such a run is found a few bases late; the region
-    // tables hold every position regardless (phase_index), so nothing becomes unfindable.  The first literals of a run are probed as before.
+    // literals UNPROBED: none while the run is young (six literals since the lane's last match), then two, then six per step (their bytes are
+    // in the twelve this step has read).  A wave's step count is that of its slowest lanes, and those are the lanes in sequence lines: 32 steps
+    // of a 64-byte slice become 10.  A true repeat that starts inside such a run is found a few bases late; the region tables hold every
+    // position regardless (phase_index), so nothing becomes unfindable.  The first literals of a run are probed as before.
     // (Skipping in ANY run of literals -- varied qualities are one -- was measured too: output +2.2 % / +2.4 %.  Not taken.)
     st.miss += 2u;
     {
-        uint32_t extra = st.miss >> (st.effort ? FQTK_BGZF_SKIP_SHIFT : FQTK_BGZF_SKIP_SHIFT - 1u);   // (--compression-level 1-3: sooner)
+        uint32_t extra = st.miss < FQTK_BGZF_SKIP_AFTER ? 0u : st.miss - FQTK_BGZF_SKIP_AFTER + 2u;
         extra = extra < 6u ? extra : 6u;
         const uint32_t left = st.end - st.p;                              // (st.p <= st.end here)
         extra = extra < left ? extra : left;
@@ -895,7 +982,13 @@ FQTK_HD inline void phase_lz(Shared &S, int lane, uint32_t n, uint32_t *tok, uin
     // (Token-major instead -- an inner loop over literals until the lane has a real candidate, then the match code run by all
     //  lanes that got that far together -- was measured: 40 instead of 55 GB/s.  The lanes' literal runs do not line up, and
     //  every round waits for the longest.)
+#if defined(FQTK_BGZF_TRACE) && !defined(__HIP_DEVICE_COMPILE__)
+    g_lz_at.lane = lane;
+    g_lz_at.step = 0;
+    while (lz_step(S, lane, n, tok, st)) { ++g_lz_at.step; }
+#else
     while (lz_step(S, lane, n, tok, st)) {}
+#endif
 #endif
     lz_end(S, lane, st);
 }
