@@ -486,6 +486,15 @@ FQTK_HD inline void phase_count(Shared &S, int lane, uint32_t n) {
 #pragma unroll
 #endif
         for (int i = 0; i < 4; ++i) v[i] = S.buf[buf_word((g >> 2) + (uint32_t)i)];
+#ifndef FQTK_BGZF_NO_COUNT_RUNS
+        // (sixteen equal bytes -- inside the run of a quality line -- are one addition: 27 lanes of a wavefront stand in quality lines, and
+        //  where those hold one value they all add to ONE counter, sixteen times each)
+        const uint32_t rep = (v[0] & 0xFFu) * 0x01010101u;
+        if (g + 16u <= hi && ((v[0] ^ rep) | (v[1] ^ rep) | (v[2] ^ rep) | (v[3] ^ rep)) == 0u) {
+            FQTK_BGZF_ADD(&S.byte_cnt[v[0] & 0xFFu], 16u);
+            continue;
+        }
+#endif
 #if defined(__HIP_DEVICE_COMPILE__)
 #pragma unroll
 #endif

@@ -16,7 +16,7 @@ namespace bgzf {
 
 #ifdef FQTK_BGZF_PHASE_TIMES
 // Developer build (tools/bgzf_phases.sh): 100 MHz ticks spent in each phase, summed over all blocks by lane 0.
-__device__ unsigned long long g_phase_ticks[12];   // [10] = the parallel part of the code construction
+__device__ unsigned long long g_phase_ticks[13];   // [10] = the parallel part of the code construction, [12] = the LZ phase without phase_reach
 #define FQTK_PHASE_MARK(k) do { if (lane == 0) { const uint64_t now = wall_clock64(); atomicAdd(&g_phase_ticks[k], (unsigned long long)(now - t_mark)); t_mark = now; } } while (0)
 #else
 #define FQTK_PHASE_MARK(k) do { } while (0)
@@ -278,6 +278,7 @@ void deflate_kernel(const fqtk_bgzf_block *blocks, uint32_t n_blocks, const uint
         FQTK_PHASE_MARK(1);
         phase_lz(S, lane, n, tok, cheap_mask);
         __syncthreads();
+        FQTK_PHASE_MARK(12);
         {
             uint32_t span;
             phase_reach(S, lane, tok, &span);
@@ -394,8 +395,8 @@ struct fqtk_bgzf {
 extern "C" {
 
 #ifdef FQTK_BGZF_PHASE_TIMES
-int fqtk_bgzf_dev_phase_ticks(unsigned long long *out12) {
-    return hipMemcpyFromSymbol(out12, HIP_SYMBOL(fqtk::bgzf::g_phase_ticks), 12 * sizeof(unsigned long long)) == hipSuccess ? 0 : 1;
+int fqtk_bgzf_dev_phase_ticks(unsigned long long *out13) {
+    return hipMemcpyFromSymbol(out13, HIP_SYMBOL(fqtk::bgzf::g_phase_ticks), 13 * sizeof(unsigned long long)) == hipSuccess ? 0 : 1;
 }
 int fqtk_bgzf_dev_lz_cycles(unsigned long long *out10) {
     return hipMemcpyFromSymbol(out10, HIP_SYMBOL(fqtk::bgzf::g_lz_cycles), 10 * sizeof(unsigned long long)) == hipSuccess ? 0 : 1;

@@ -33,8 +33,9 @@ def main():
     ap.add_argument("--blocks", type=int, default=4096)
     ap.add_argument("--reps", type=int, default=5)
     ap.add_argument("--const-qual", action="store_true", help="every quality 'I' (scope E's synthetic records: long runs)")
+    ap.add_argument("--hbm-only", action="store_true", help="no pass with the input in pinned host memory (tools/bgzf_phases.sh: the kernel's own phases)")
     a = ap.parse_args()
-    print(json.dumps(measure(a.blocks, a.reps, a.const_qual)))
+    print(json.dumps(measure(a.blocks, a.reps, a.const_qual, ("hbm",) if a.hbm_only else ("hbm", "pinned_host"))))
 
 
 def measure(blocks=4096, reps=5, const_qual=False, where_list=("hbm", "pinned_host")):

@@ -11,12 +11,12 @@ import runpy
 from fqtk_amd import _lib
 lib = _lib.load()
 import os
-sys.argv = ["bgzf_bench.py"] + os.environ.get("BENCH_ARGS", "").split()
+sys.argv = ["bgzf_bench.py", "--hbm-only"] + os.environ.get("BENCH_ARGS", "").split()
 runpy.run_path("tools/bgzf_bench.py", run_name="__main__")
-t = (C.c_ulonglong * 12)()
+t = (C.c_ulonglong * 13)()
 assert lib.fqtk_bgzf_dev_phase_ticks(t) == 0
-names = ["load", "index", "count + literal costs", "lz + reach", "clear + rank", "code lengths (two lanes)", "code-length runs + 19-symbol code || count bits", "offsets", "emit", "store", "header bits", "canonical codes"]
-tot = sum(t[:12])
+names = ["load", "index", "count + literal costs", "reach", "clear + rank", "code lengths (two lanes)", "code-length runs + 19-symbol code || count bits", "offsets", "emit", "store", "header bits", "canonical codes", "lz"]
+tot = sum(t[:13])
 for k, nme in enumerate(names):
     print(f"{nme:28s} {100.0 * t[k] / tot:5.1f} %")
 z = (C.c_ulonglong * 10)()
@@ -24,7 +24,7 @@ assert lib.fqtk_bgzf_dev_lz_cycles(z) == 0
 if os.environ.get("LZ_COUNTS"):   # events per wavefront (the first active lane counts), over every launch of the run above
     steps = max(z[0], 1)
     print(f"lz, wavefront events per step: match passes {z[1] / steps:.3f}, second passes {z[2] / steps:.3f}, extension rounds {z[3] / steps:.3f}, "
-          f"matches taken {z[4] / steps:.3f}, pending inserts {z[5] / steps:.3f}; steps per wavefront: {z[0] / (16.0 * 4096 * 12):.1f} (twelve launches of 4096 blocks)")
+          f"matches taken {z[4] / steps:.3f}, pending inserts {z[5] / steps:.3f}; steps per wavefront: {z[0] / (16.0 * 4096 * 6):.1f} (six launches of 4096 blocks)")
 elif os.environ.get("LZ_TIMES"):
     waves, steps = max(z[9], 1), max(z[8], 1)
     print(f"lz, per wave: {steps / waves:.0f} steps; history preload {z[4] / waves:.0f} cycles; cycles per step: table reads {z[0] / steps:.0f}, "
