@@ -42,6 +42,9 @@
 namespace fqtk {
 namespace bgzf {
 
+#ifndef FQTK_BGZF_MID
+#define FQTK_BGZF_MID(k) do { } while (0)   // (tools/bgzf_phases.sh: a mark inside a phase)
+#endif
 #ifndef FQTK_BGZF_LANES
 #define FQTK_BGZF_LANES 1024   // (overridable for studies: tools/ab_bgzf.sh, tools/bgzf_ratio.py -DFQTK_BGZF_LANES=512)
 #endif
@@ -1083,7 +1086,49 @@ FQTK_HD inline void phase_clear_out(Shared &S, int lane) {
     if (lane < 32) S.len_d[lane] = 0;
     if (lane < kNumCl) S.freq_cl[lane] = 0;
     if (lane == 0) S.freq_ll[256] = 1;   // end of block (read through count_of below: no barrier needed)
+    FQTK_BGZF_MID(13);
     auto count_of = [&](int sym) -> uint32_t { return sym == 256 ? 1u : S.freq_ll[sym]; };
+#if defined(__HIP_DEVICE_COMPILE__)
+    // A symbol's rank = how many used symbols have a smaller (count, symbol).  The wavefronts that rank (five for the literal/length
+    // symbols, a sixth for the distance symbols) hold ALL the keys in registers -- key = count << 9 | symbol, unused: all ones, lane l of
+    // register k = symbol 64 k + l -- and every lane compares its own key with each of them, handed round by v_readlane: three
+    // instructions per comparison and no memory.  (The loop over LDS that the CPU tests run -- 286 dependent rounds of read, compare,
+    // add -- was 7 % of the kernel: 14 us of a block's 200.)
+    static_assert(kLanes >= 384 && kNumLitLen <= 320 && kNumDist <= 64, "five wavefronts rank the literal/length symbols, the sixth the distance symbols");
+    if (lane < 320) {
+        uint32_t keys[5];
+#pragma unroll
+        for (int k = 0; k < 5; ++k) {
+            const int sym = 64 * k + (lane & 63);
+            const uint32_t c = sym < kNumLitLen ? count_of(sym) : 0u;
+            keys[k] = c ? (c << 9) | (uint32_t)sym : 0xFFFFFFFFu;
+        }
+        const uint32_t c = lane < kNumLitLen ? count_of(lane) : 0u;
+        const uint32_t key = c ? (c << 9) | (uint32_t)lane : 0u;   // (unused: smaller than every key, ranks nothing)
+        uint32_t rank = 0;
+#pragma unroll
+        for (int k = 0; k < 5; ++k)
+#pragma unroll   // (a lane number in a register costs v_readlane its wait states after every scalar add)
+            for (int l = 0; l < 64; ++l) rank += (uint32_t)__builtin_amdgcn_readlane((int)keys[k], l) < key ? 1u : 0u;
+        if (c) {
+            S.sorted[rank] = (uint16_t)lane;
+            S.weight[rank] = c;   // (the leaves of the code builder, in its order)
+            FQTK_BGZF_ADD(&S.m_ll, 1u);
+        }
+    } else if (lane < 384) {
+        const int d = lane - 320;
+        const uint32_t c = d < kNumDist ? S.freq_d[d] : 0u;
+        const uint32_t mine = c ? (c << 9) | (uint32_t)d : 0xFFFFFFFFu, key = c ? mine : 0u;
+        uint32_t rank = 0;
+#pragma unroll
+        for (int l = 0; l < kNumDist; ++l) rank += (uint32_t)__builtin_amdgcn_readlane((int)mine, l) < key ? 1u : 0u;
+        if (c) {
+            S.sorted_d[rank] = (uint16_t)d;
+            S.weight_d[rank] = c;
+            FQTK_BGZF_ADD(&S.m_d, 1u);
+        }
+    }
+#else
     for (int sym = lane; sym < kNumLitLen; sym += kLanes) {
         const uint32_t c = count_of(sym);
         if (!c) continue;
@@ -1117,6 +1162,7 @@ FQTK_HD inline void phase_clear_out(Shared &S, int lane) {
             FQTK_BGZF_ADD(&S.m_d, 1u);
         }
     }
+#endif
 }
 
 // P2b (two lanes): the code lengths of both codes -- the serial part: the two-queue tree construction and the depth pass

@@ -8,19 +8,24 @@
 
 #include "../../include/fqtk_bgzf.h"
 #include "../../include/fqtk_match.h"
+#ifdef FQTK_BGZF_PHASE_TIMES
+// Developer build (tools/bgzf_phases.sh): 100 MHz ticks spent in each phase, summed over all blocks by lane 0.
+namespace fqtk {
+namespace bgzf {
+__device__ unsigned long long g_phase_ticks[16];   // [10] = the parallel part of the code construction, [12] = the LZ phase without phase_reach, [13..15] = marks inside phases
+__shared__ unsigned long long s_t_mark;            // (lane 0's last mark)
+}
+}
+#define FQTK_PHASE_MARK(k) do { if (lane == 0) { const unsigned long long now = wall_clock64(); atomicAdd(&fqtk::bgzf::g_phase_ticks[k], now - fqtk::bgzf::s_t_mark); fqtk::bgzf::s_t_mark = now; } } while (0)
+#define FQTK_BGZF_MID(k) FQTK_PHASE_MARK(k)   // (a mark inside a phase function of bgzf_deflate.hpp: lane 0's own way through it)
+#else
+#define FQTK_PHASE_MARK(k) do { } while (0)
+#endif
 #include "bgzf_deflate.hpp"
 #include "bgzf_internal.hpp"
 
 namespace fqtk {
 namespace bgzf {
-
-#ifdef FQTK_BGZF_PHASE_TIMES
-// Developer build (tools/bgzf_phases.sh): 100 MHz ticks spent in each phase, summed over all blocks by lane 0.
-__device__ unsigned long long g_phase_ticks[13];   // [10] = the parallel part of the code construction, [12] = the LZ phase without phase_reach
-#define FQTK_PHASE_MARK(k) do { if (lane == 0) { const uint64_t now = wall_clock64(); atomicAdd(&g_phase_ticks[k], (unsigned long long)(now - t_mark)); t_mark = now; } } while (0)
-#else
-#define FQTK_PHASE_MARK(k) do { } while (0)
-#endif
 
 // The code lengths of the two big codes (huffman_lengths of bgzf_deflate.hpp, the one-lane form the CPU tests run), in four
 // steps with the serial part cut down to what is serial: (a) the two-queue tree construction by one lane per code -- the
@@ -221,7 +226,7 @@ void deflate_kernel(const fqtk_bgzf_block *blocks, uint32_t n_blocks, const uint
     const int lane = (int)threadIdx.x;
     uint32_t *tok = tok_all + (size_t)blockIdx.x * kTokensPerBlock;   // token scratch of this workgroup
 #ifdef FQTK_BGZF_PHASE_TIMES
-    uint64_t t_mark = wall_clock64();
+    if (lane == 0) s_t_mark = wall_clock64();
 #endif
     if (n_blocks_dev) n_blocks = *n_blocks_dev;   // (the record pipeline learns the count on the device)
     if (blockIdx.x >= n_blocks) return;
@@ -312,8 +317,10 @@ void deflate_kernel(const fqtk_bgzf_block *blocks, uint32_t n_blocks, const uint
         FQTK_PHASE_MARK(11);
         phase_cl_runs(S, lane);
         __syncthreads();
+        FQTK_PHASE_MARK(14);
         phase_cl_emit(S, lane);
         __syncthreads();
+        FQTK_PHASE_MARK(15);
         if (lane < 64) phase_cl_code_wave(S, lane);   // the first wavefront builds the 19-symbol code ...
         phase_count_bits(S, lane, n, tok);      // ... while all lanes add up the bits of their tokens (needs the two big codes only)
         __syncthreads();
@@ -395,8 +402,8 @@ struct fqtk_bgzf {
 extern "C" {
 
 #ifdef FQTK_BGZF_PHASE_TIMES
-int fqtk_bgzf_dev_phase_ticks(unsigned long long *out13) {
-    return hipMemcpyFromSymbol(out13, HIP_SYMBOL(fqtk::bgzf::g_phase_ticks), 13 * sizeof(unsigned long long)) == hipSuccess ? 0 : 1;
+int fqtk_bgzf_dev_phase_ticks(unsigned long long *out16) {
+    return hipMemcpyFromSymbol(out16, HIP_SYMBOL(fqtk::bgzf::g_phase_ticks), 16 * sizeof(unsigned long long)) == hipSuccess ? 0 : 1;
 }
 int fqtk_bgzf_dev_lz_cycles(unsigned long long *out10) {
     return hipMemcpyFromSymbol(out10, HIP_SYMBOL(fqtk::bgzf::g_lz_cycles), 10 * sizeof(unsigned long long)) == hipSuccess ? 0 : 1;

@@ -13,10 +13,10 @@ lib = _lib.load()
 import os
 sys.argv = ["bgzf_bench.py", "--hbm-only"] + os.environ.get("BENCH_ARGS", "").split()
 runpy.run_path("tools/bgzf_bench.py", run_name="__main__")
-t = (C.c_ulonglong * 13)()
+t = (C.c_ulonglong * 16)()
 assert lib.fqtk_bgzf_dev_phase_ticks(t) == 0
-names = ["load", "index", "count + literal costs", "reach", "clear + rank", "code lengths (two lanes)", "code-length runs + 19-symbol code || count bits", "offsets", "emit", "store", "header bits", "canonical codes", "lz"]
-tot = sum(t[:13])
+names = ["load", "index", "count + literal costs", "reach", "rank", "code lengths (two lanes)", "19-symbol code || count bits", "offsets", "emit", "store", "header bits", "canonical codes", "lz", "clear (inside clear + rank, lane 0)", "code-length runs", "code-length symbols"]
+tot = sum(t[:16])
 for k, nme in enumerate(names):
     print(f"{nme:28s} {100.0 * t[k] / tot:5.1f} %")
 z = (C.c_ulonglong * 10)()
