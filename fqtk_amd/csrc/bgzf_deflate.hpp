@@ -1031,7 +1031,7 @@ FQTK_HD inline void phase_reach(Shared &S, int lane, uint32_t *tok, uint32_t *sp
     uint32_t first = 0, cut = 0;
     if (start > lo) {
         const uint32_t stop = start < reach ? start : reach;
-        uint32_t m = 0, next = nm ? tok[(uint32_t)lane] : 0u;
+        uint32_t m = 0, next = tok[(uint32_t)lane];   // (read whether or not there is a token: a load behind a condition is a branch, and row 0 of the lane's column always exists)
         uint32_t next_pos = nm ? lo + token_off(next) : 0xFFFFFFFFu;
         for (uint32_t p = lo; p < stop;) {
             if (p == next_pos) {
@@ -1050,7 +1050,7 @@ FQTK_HD inline void phase_reach(Shared &S, int lane, uint32_t *tok, uint32_t *sp
                 }
                 p += len;
                 ++m;
-                next = m < nm ? tok[m * kLanes + (uint32_t)lane] : 0u;
+                next = tok[(m < nm ? m : 0u) * kLanes + (uint32_t)lane];
                 next_pos = m < nm ? lo + token_off(next) : 0xFFFFFFFFu;
             } else {
                 FQTK_BGZF_ADD(&S.freq_ll[buf_byte(S.buf, p)], 0xFFFFFFFFu);
@@ -1065,7 +1065,7 @@ FQTK_HD inline void phase_reach(Shared &S, int lane, uint32_t *tok, uint32_t *sp
 #if defined(__HIP_DEVICE_COMPILE__)
 #pragma unroll
 #endif
-        for (uint32_t k = 0; k < 4u; ++k) t[k] = m0 + k < nm ? tok[(m0 + k) * kLanes + (uint32_t)lane] : 0u;
+        for (uint32_t k = 0; k < 4u; ++k) t[k] = tok[(m0 + k < nm ? m0 + k : m0) * kLanes + (uint32_t)lane];   // (four unconditional reads in flight; the rows past the last are not looked at)
 #if defined(__HIP_DEVICE_COMPILE__)
 #pragma unroll
 #endif
@@ -1188,7 +1188,6 @@ FQTK_HD inline void phase_codes(Shared &S, int lane) {
 }
 // Run-length coding of the hlit + hdist lengths (RFC 1951 3.2.7: 16 = repeat the previous length 3-6 times, 17 = 3-10
 // zeros, 18 = 11-138 zeros).  A run of equal lengths is coded by the lane of its first position.
-FQTK_HD inline uint32_t cl_length_at(const Shared &S, uint32_t i) { return i < S.hlit ? S.len_ll[i] : S.len_d[i - S.hlit]; }
 // symbols a run of r lengths of value v is coded with; out != nullptr: they are written (symbol, extra-bit value)
 FQTK_HD inline uint32_t cl_code_run(uint32_t v, uint32_t r, uint8_t *sym, uint8_t *extra) {
     uint32_t n = 0, left = r;
@@ -1207,10 +1206,19 @@ FQTK_HD inline uint32_t cl_code_run(uint32_t v, uint32_t r, uint8_t *sym, uint8_
 }
 // P2d (all lanes): the runs
 FQTK_HD inline void phase_cl_runs(Shared &S, int lane) {
-    const uint32_t total = S.hlit + S.hdist;
+    // (hlit and total in registers: read through S at every use they cost a dependent LDS round trip each time -- the stores below may alias them
+    //  as far as the compiler knows -- and this phase was 11 us of a block's 200)
+    const uint32_t hlit = S.hlit, total = hlit + S.hdist;
+    // (one UNCONDITIONAL read behind a selected address: `i < hlit ? S.len_ll[i] : S.len_d[i - hlit]` compiles to a branch around each read -- a
+    //  load is not moved across a condition -- and eight of those in a row were sixteen dependent round trips per round of the loop below)
+    auto length_at = [&](uint32_t i) -> uint32_t {
+        const uint32_t j = i < total ? i : total - 1u;
+        const uint8_t *at = j < hlit ? S.len_ll + j : S.len_d + (j - hlit);
+        return *at;
+    };
     for (uint32_t i = (uint32_t)lane; i < total; i += kLanes) {
-        const uint32_t v = cl_length_at(S, i);
-        if (i && cl_length_at(S, i - 1) == v) { S.run_syms[i] = 0; continue; }
+        const uint32_t v = length_at(i);
+        if (i && length_at(i - 1) == v) { S.run_syms[i] = 0; continue; }
         // the run's length, eight lengths per round trip (a run of unused symbols is up to 138+ long, and a lane that walks it
         // one read at a time holds up the whole workgroup)
         uint32_t r = 1;
@@ -1219,7 +1227,11 @@ FQTK_HD inline void phase_cl_runs(Shared &S, int lane) {
 #if defined(__HIP_DEVICE_COMPILE__)
 #pragma unroll
 #endif
-            for (uint32_t k = 0; k < 8u; ++k) vals[k] = i + r + k < total ? cl_length_at(S, i + r + k) : 0xFFFFFFFFu;
+            for (uint32_t k = 0; k < 8u; ++k) vals[k] = length_at(i + r + k);
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+            for (uint32_t k = 0; k < 8u; ++k) vals[k] = i + r + k < total ? vals[k] : 0xFFFFFFFFu;
             uint32_t k = 0;
 #if defined(__HIP_DEVICE_COMPILE__)
 #pragma unroll
@@ -1234,7 +1246,7 @@ FQTK_HD inline void phase_cl_runs(Shared &S, int lane) {
 }
 // P2e (all lanes): every run's symbols go to their place in the coded sequence; symbol counts for the code-length code
 FQTK_HD inline void phase_cl_emit(Shared &S, int lane) {
-    const uint32_t total = S.hlit + S.hdist;
+    const uint32_t hlit = S.hlit, total = hlit + S.hdist;
     for (uint32_t i = (uint32_t)lane; i < total; i += kLanes) {
         const uint32_t n = S.run_syms[i];
         if (!n) continue;
@@ -1245,7 +1257,7 @@ FQTK_HD inline void phase_cl_emit(Shared &S, int lane) {
 #endif
         for (uint32_t j = 0; j < (i >> 1); ++j) { const uint32_t two = pairs[j]; off += (two & 0xFFFFu) + (two >> 16); }
         if (i & 1u) off += S.run_syms[i - 1u];
-        cl_code_run(cl_length_at(S, i), S.run_len[i], S.cl_sym + off, S.cl_extra + off);
+        cl_code_run(i < hlit ? S.len_ll[i] : S.len_d[i - hlit], S.run_len[i], S.cl_sym + off, S.cl_extra + off);
         for (uint32_t k = 0; k < n; ++k) FQTK_BGZF_ADD(&S.freq_cl[S.cl_sym[off + k]], 1u);
         FQTK_BGZF_ADD(&S.n_cl, n);
     }
@@ -1268,19 +1280,24 @@ FQTK_HD inline void phase_cl_code(Shared &S) {
     w.finish();
     S.fixed_header_bits = w.bitpos();
 }
-FQTK_HD inline uint32_t cl_symbol_bits(const Shared &S, uint32_t k) {
-    const uint32_t s = S.cl_sym[k];
-    return S.len_cl[s] + (s == 16 ? 2u : (s == 17 ? 3u : (s == 18 ? 7u : 0u)));
-}
 // P2g (all lanes): the coded lengths, one symbol per lane
 FQTK_HD inline void phase_cl_bits(Shared &S, int lane) {
     const uint32_t n = S.n_cl;
+    if ((uint32_t)lane >= n) return;
+    // what each of the 19 symbols costs, four bits apiece in three words (14 at most: a 7-bit code + 7 extra bits): the sum over the symbols
+    // before a lane's own then needs ONE read per symbol -- the symbol -- instead of a second, dependent one for its length
+    uint32_t cost[3] = {0, 0, 0};
+    for (uint32_t sy = 0; sy < (uint32_t)kNumCl; ++sy)
+        cost[sy >> 3] |= (S.len_cl[sy] + (sy == 16 ? 2u : (sy == 17 ? 3u : (sy == 18 ? 7u : 0u)))) << (4u * (sy & 7u));
     for (uint32_t k = (uint32_t)lane; k < n; k += kLanes) {
         uint32_t pos = S.fixed_header_bits;
 #if defined(__HIP_DEVICE_COMPILE__)
 #pragma unroll 8
 #endif
-        for (uint32_t j = 0; j < k; ++j) pos += cl_symbol_bits(S, j);
+        for (uint32_t j = 0; j < k; ++j) {
+            const uint32_t sy = S.cl_sym[j];
+            pos += ((sy < 8u ? cost[0] : (sy < 16u ? cost[1] : cost[2])) >> (4u * (sy & 7u))) & 15u;
+        }
         const uint32_t s = S.cl_sym[k];
         BitWriter w;
         w.start(out_image(S), pos);
@@ -1300,7 +1317,7 @@ FQTK_HD inline void walk_tokens(Shared &S, int lane, uint32_t n, const uint32_t 
     const uint32_t lo = (uint32_t)lane * kChunk;
     const uint32_t span = S.span[lane], hi = span >> 16;
     const uint32_t nm = S.ntok[lane] & 0xFFu;
-    uint32_t m = S.ntok[lane] >> 8, next = m < nm ? tok[m * kLanes + (uint32_t)lane] : 0u;
+    uint32_t m = S.ntok[lane] >> 8, next = tok[(m < nm ? m : 0u) * kLanes + (uint32_t)lane];   // (unconditional reads: see phase_reach)
     uint32_t next_pos = m < nm ? lo + token_off(next) : 0xFFFFFFFFu;
     (void)n;
     uint32_t have = 0xFFFFFFFFu, word = 0;
@@ -1331,7 +1348,7 @@ FQTK_HD inline void walk_tokens(Shared &S, int lane, uint32_t n, const uint32_t 
         on_match(len, token_dist(next));
         p += len;
         ++m;
-        next = m < nm ? tok[m * kLanes + (uint32_t)lane] : 0u;
+        next = tok[(m < nm ? m : 0u) * kLanes + (uint32_t)lane];
         next_pos = m < nm ? lo + token_off(next) : 0xFFFFFFFFu;
     }
 }
