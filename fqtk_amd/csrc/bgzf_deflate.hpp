@@ -194,7 +194,7 @@ struct BitWriter {
     uint32_t nacc;     // number of valid low bits in acc (including the offset inside the first word)
     uint32_t word;
     FQTK_HD void start(uint32_t *w, uint32_t bitpos) { words = w; word = bitpos >> 5; nacc = bitpos & 31u; acc = 0; }
-    FQTK_HD void put(uint32_t value, uint32_t nbits) {   // nbits <= 24
+    FQTK_HD void put(uint32_t value, uint32_t nbits) {   // nbits <= 32 (31 pending bits + 32 fit the 64-bit accumulator)
         acc |= (uint64_t)value << nacc;
         nacc += nbits;
         if (nacc >= 32) {
@@ -1178,6 +1178,7 @@ FQTK_HD inline void phase_code_lengths(Shared &S, int lane) {
 FQTK_HD inline void phase_codes(Shared &S, int lane) {
     if (lane < kNumLitLen) {
         S.code_ll[lane] = canonical_code_of(S.len_ll, lane, S.bl_count, 15);
+        S.freq_ll[lane] = (uint32_t)S.code_ll[lane] | ((uint32_t)S.len_ll[lane] << 16);   // (the counts are done with: code and length side by side, ONE read per token in phase_emit)
         if (lane >= 257 && S.len_ll[lane]) FQTK_BGZF_MAX(&S.hlit, (uint32_t)lane + 1u);
     }
     const int d = lane - (kLanes >= 512 ? 320 : 0);
@@ -1312,8 +1313,8 @@ FQTK_HD inline void phase_cl_bits(Shared &S, int lane) {
 
 // A lane's tokens in order: the matches of its slice (global scratch, [m][lane]) and the literal bytes between them.
 // visit(literal byte) / visit(len, dist).
-template <typename OnLit, typename OnMatch>
-FQTK_HD inline void walk_tokens(Shared &S, int lane, uint32_t n, const uint32_t *tok, OnLit on_lit, OnMatch on_match) {
+template <typename OnLit, typename OnWord, typename OnMatch>
+FQTK_HD inline void walk_tokens(Shared &S, int lane, uint32_t n, const uint32_t *tok, OnLit on_lit, OnWord on_word, OnMatch on_match) {
     const uint32_t lo = (uint32_t)lane * kChunk;
     const uint32_t span = S.span[lane], hi = span >> 16;
     const uint32_t nm = S.ntok[lane] & 0xFFu;
@@ -1333,11 +1334,7 @@ FQTK_HD inline void walk_tokens(Shared &S, int lane, uint32_t n, const uint32_t 
             on_lit((word >> (8 * (p & 3u))) & 0xFFu);
         }
         for (; p + 4u <= lim; p += 4u) {     // whole words: the four table look-ups of a round go out together
-            const uint32_t four = S.buf[buf_word(p >> 2)];
-            on_lit(four & 0xFFu);
-            on_lit((four >> 8) & 0xFFu);
-            on_lit((four >> 16) & 0xFFu);
-            on_lit(four >> 24);
+            on_word(S.buf[buf_word(p >> 2)]);
         }
         for (; p < lim; ++p) {
             if ((p >> 2) != have) { have = p >> 2; word = S.buf[buf_word(have)]; }
@@ -1358,6 +1355,7 @@ FQTK_HD inline void phase_count_bits(Shared &S, int lane, uint32_t n, const uint
     uint32_t bits = 0;
     walk_tokens(S, lane, n, tok,
                 [&](uint32_t lit) { bits += S.len_ll[lit]; },
+                [&](uint32_t four) { bits += S.len_ll[four & 0xFFu] + S.len_ll[(four >> 8) & 0xFFu] + S.len_ll[(four >> 16) & 0xFFu] + S.len_ll[four >> 24]; },
                 [&](uint32_t len, uint32_t dist) {
                     uint32_t sym, ne, ev;
                     length_symbol(len, sym, ne, ev);
@@ -1381,11 +1379,17 @@ FQTK_HD inline void phase_emit(Shared &S, int lane, uint32_t n, const uint32_t *
     BitWriter w;
     w.start(out_image(S), S.lane_bits[lane]);
     walk_tokens(S, lane, n, tok,
-                [&](uint32_t lit) { w.put(S.code_ll[lit], S.len_ll[lit]); },
+                [&](uint32_t lit) { const uint32_t e = S.freq_ll[lit]; w.put(e & 0xFFFFu, e >> 16); },
+                [&](uint32_t four) {   // four literals: their codes joined two and two (30 bits at most) -- two appends, each with its test for a full word, instead of four
+                    const uint32_t e0 = S.freq_ll[four & 0xFFu], e1 = S.freq_ll[(four >> 8) & 0xFFu], e2 = S.freq_ll[(four >> 16) & 0xFFu], e3 = S.freq_ll[four >> 24];
+                    w.put((e0 & 0xFFFFu) | ((e1 & 0xFFFFu) << (e0 >> 16)), (e0 >> 16) + (e1 >> 16));
+                    w.put((e2 & 0xFFFFu) | ((e3 & 0xFFFFu) << (e2 >> 16)), (e2 >> 16) + (e3 >> 16));
+                },
                 [&](uint32_t len, uint32_t dist) {
                     uint32_t sym, ne, ev;
                     length_symbol(len, sym, ne, ev);
-                    w.put(S.code_ll[sym], S.len_ll[sym]);
+                    const uint32_t e = S.freq_ll[sym];
+                    w.put(e & 0xFFFFu, e >> 16);
                     if (ne) w.put(ev, ne);
                     dist_symbol(dist, sym, ne, ev);
                     w.put(S.code_d[sym], S.len_d[sym]);
