@@ -447,6 +447,7 @@ FQTK_HD inline void phase_load(Shared &S, int lane, const uint8_t *in, uint32_t 
     for (uint32_t i = (uint32_t)lane; i < 288; i += kLanes) S.freq_ll[i] = 0;
     if (lane < 32) S.freq_d[lane] = 0;
     if (lane < 256) S.byte_cnt[lane] = 0;
+    S.span[lane] = 0;   // (until the LZ phase: kCountCopies - 1 more sets of byte counters, phase_count)
     if (lane == 0) { S.lit_total = 0; S.m_ll = 0; S.m_d = 0; S.n_cl = 0; S.hlit = 257; S.hdist = 1; }
     if ((reinterpret_cast<uintptr_t>(in) & 3u) == 0) {
         const uint32_t nw = n >> 2;
@@ -480,7 +481,17 @@ FQTK_HD inline void phase_load(Shared &S, int lane, const uint8_t *in, uint32_t 
 // once, as aligned words.  (The four bases are nearly half of FASTQ text and 64 lanes of a wave hammer their four counters
 // -- yet counting them in a packed register per lane and adding once per slice was SLOWER, 36.6 against 38.4 GB/s,
 // tools/ab_bgzf.sh: same-address LDS atomics are cheap, the extra selects are not.)
+#ifndef FQTK_BGZF_COUNT_COPIES
+#define FQTK_BGZF_COUNT_COPIES 4   // (1: every lane adds to the one set; tools/ab_bgzf.sh)
+#endif
+constexpr uint32_t kCountCopies = FQTK_BGZF_COUNT_COPIES;   // sets of byte counters: S.byte_cnt and, in S.span (unused until the LZ phase), kCountCopies - 1 more
+static_assert(kCountCopies >= 1 && (kCountCopies & (kCountCopies - 1u)) == 0 && (kCountCopies - 1u) * 256u <= (uint32_t)kLanes, "the extra sets live in S.span");
+FQTK_HD inline uint32_t *count_set(Shared &S, int lane) {   // neighbouring lanes stand in the same line of text and count the same few values: each its own set
+    const uint32_t k = (uint32_t)lane & (kCountCopies - 1u);
+    return k ? S.span + (k - 1u) * 256u : S.byte_cnt;
+}
 FQTK_HD inline void phase_count(Shared &S, int lane, uint32_t n) {
+    uint32_t *cnt = count_set(S, lane);
     const uint32_t lo = (uint32_t)lane * kChunk;
     const uint32_t hi = lo + kChunk < n ? lo + kChunk : n;
     for (uint32_t g = lo; g < hi; g += 16u) {
@@ -494,7 +505,7 @@ FQTK_HD inline void phase_count(Shared &S, int lane, uint32_t n) {
         //  where those hold one value they all add to ONE counter, sixteen times each)
         const uint32_t rep = (v[0] & 0xFFu) * 0x01010101u;
         if (g + 16u <= hi && ((v[0] ^ rep) | (v[1] ^ rep) | (v[2] ^ rep) | (v[3] ^ rep)) == 0u) {
-            FQTK_BGZF_ADD(&S.byte_cnt[v[0] & 0xFFu], 16u);
+            FQTK_BGZF_ADD(&cnt[v[0] & 0xFFu], 16u);
             continue;
         }
 #endif
@@ -502,7 +513,7 @@ FQTK_HD inline void phase_count(Shared &S, int lane, uint32_t n) {
 #pragma unroll
 #endif
         for (uint32_t k = 0; k < 16u; ++k)
-            if (g + k < hi) FQTK_BGZF_ADD(&S.byte_cnt[(v[k >> 2] >> (8 * (k & 3u))) & 0xFFu], 1u);
+            if (g + k < hi) FQTK_BGZF_ADD(&cnt[(v[k >> 2] >> (8 * (k & 3u))) & 0xFFu], 1u);
     }
 }
 
@@ -579,7 +590,8 @@ FQTK_HD inline uint32_t log2_halfbits(uint32_t x) {   // ~ 2 * log2(x), x >= 1
 }
 FQTK_HD inline void phase_literal_costs(Shared &S, int lane, uint32_t n) {   // lane = byte value
     if (lane >= 256) return;
-    const uint32_t c = S.byte_cnt[lane];
+    uint32_t c = S.byte_cnt[lane];
+    for (uint32_t k = 1; k < kCountCopies; ++k) c += S.span[(k - 1u) * 256u + (uint32_t)lane];
     uint32_t cost = 30;
     if (c) {
         const uint32_t a = log2_halfbits(n), b = log2_halfbits(c);
