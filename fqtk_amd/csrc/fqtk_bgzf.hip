@@ -48,8 +48,12 @@ __device__ void code_tree(const CodeJob &J) {   // (a): one lane
     uint32_t li = 0, ii = m, made = m;
     for (uint32_t k = 0; k + 1u < m; ++k) {
         // the two smallest of the leaf queue's and the internal queue's first two (a leaf wins a tie, as in huffman_lengths)
-        uint32_t wl0 = li < m ? J.weight[li] : kInf, wl1 = li + 1u < m ? J.weight[li + 1u] : kInf;
-        uint32_t wi0 = ii < made ? J.weight[ii] : kInf, wi1 = ii + 1u < made ? J.weight[ii + 1u] : kInf;
+        // (four UNCONDITIONAL reads -- the array has room past both queues' ends -- and the selection behind them: `li < m ? J.weight[li] : kInf`
+        //  is a branch around a read with a wait of its own, and four of them were four dependent round trips per merge: 14 us of a block's 180
+        //  on this one lane while 1022 waited)
+        const uint32_t rl0 = J.weight[li], rl1 = J.weight[li + 1u], ri0 = J.weight[ii], ri1 = J.weight[ii + 1u];
+        uint32_t wl0 = li < m ? rl0 : kInf, wl1 = li + 1u < m ? rl1 : kInf;
+        uint32_t wi0 = ii < made ? ri0 : kInf, wi1 = ii + 1u < made ? ri1 : kInf;
         uint32_t pick[2], w[2];
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
