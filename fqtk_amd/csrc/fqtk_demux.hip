@@ -61,7 +61,12 @@ struct PinBuf {   // grow-only page-locked host buffer
         if (want <= cap) return FQTK_OK;
         if (p) { DX_TRY(hipHostFree(p)); p = nullptr; cap = 0; }
         const size_t n = want + want / 4 + 64;
+        static const bool timing = std::getenv("FQTK_TIMING") != nullptr;
+        const auto t0 = std::chrono::steady_clock::now();
         DX_TRY(hipHostMalloc(reinterpret_cast<void **>(&p), n * sizeof(T), hipHostMallocDefault));
+        if (timing && n * sizeof(T) >= (8u << 20))
+            std::fprintf(stderr, "(timing) page-locked buffer of %zu MB: %.1f ms, done at epoch %.3f\n", (n * sizeof(T)) >> 20, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(),
+                         std::chrono::duration<double>(std::chrono::system_clock::now().time_since_epoch()).count());
         cap = n;
         return FQTK_OK;
     }

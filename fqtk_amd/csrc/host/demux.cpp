@@ -99,6 +99,17 @@ std::atomic<bool> g_dying{false};
 }
 
 bool g_timing = false;   // FQTK_TIMING: clocks of the stages in the log
+// (FQTK_TIMING: where a run's first second goes -- page-locking costs 0.2-0.4 s per GB, and while one call is at it every other HIP call of the process waits.
+//  Measured at the end of round 5: a first buffer of the first stretch's size and the full-size ones made by the prefetching thread cut the first chunk by 40 ms and
+//  cost the steady rate 4 % -- the same wall clock; not kept.)
+static int pinned_alloc_timed(size_t bytes, void **out) {
+    const auto t0 = std::chrono::steady_clock::now();
+    const int rc = fqtk_pinned_alloc(bytes, out);
+    if (g_timing && bytes >= (8u << 20))
+        std::fprintf(stderr, "(timing) page-locked allocation of %zu MB: %.1f ms, done at epoch %.3f\n", bytes >> 20, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(),
+                     std::chrono::duration<double>(std::chrono::system_clock::now().time_since_epoch()).count());
+    return rc;
+}
 
 // (FQTK_TIMING: the anonymous resident memory right now, in MB -- pinned staging and what the HIP runtime keeps on the host)
 size_t rss_anon_mb() {
@@ -441,7 +452,7 @@ struct PinnedRaw : RawBuffer {
     ~PinnedRaw() override { if (data) fqtk_pinned_free(data); }
     bool grow(size_t want, size_t keep) override {
         void *p = nullptr;
-        if (fqtk_pinned_alloc(want, &p) != FQTK_OK) return false;
+        if (pinned_alloc_timed(want, &p) != FQTK_OK) return false;
         if (keep) std::memcpy(p, data, keep);
         if (data) fqtk_pinned_free(data);
         data = static_cast<char *>(p);
@@ -1024,7 +1035,7 @@ bool gpu_output_supported(const Plan &plan, std::string *why) {
                             if (bytes + 64 > pin_cap) {   // (once)
                                 if (pin) fqtk_pinned_free(pin);
                                 pin_cap = std::min<size_t>(bf.size, (kSlots + 5) * kChunkBytes + 131072 + 4) + 65536;
-                                if (fqtk_pinned_alloc(pin_cap, &pin) != FQTK_OK) { pin = nullptr; fail(std::string("cannot allocate page-locked memory: ") + fqtk_last_error()); return false; }
+                                if (pinned_alloc_timed(pin_cap, &pin) != FQTK_OK) { pin = nullptr; fail(std::string("cannot allocate page-locked memory: ") + fqtk_last_error()); return false; }
                             }
                             if (kForceFallback > 0 && (n_stretches + n_fallbacks) % (size_t)kForceFallback == (size_t)kForceFallback - 1) {
                                 if (!host_stretch(std::min<uint64_t>(verified + (uint64_t)kChunkBytes * 8u * 3u, (uint64_t)bf.size * 8u), "forced", &member_done)) return false;
@@ -1044,7 +1055,7 @@ bool gpu_output_supported(const Plan &plan, std::string *why) {
                                 const size_t len = std::min<size_t>(bf.size - from, pin_cap - 64);
                                 pf0 = from;
                                 prefetcher = std::thread([&, from, len] {
-                                    if (!pin2 && fqtk_pinned_alloc(pin_cap, &pin2) != FQTK_OK) { pin2 = nullptr; return; }
+                                    if (!pin2 && pinned_alloc_timed(pin_cap, &pin2) != FQTK_OK) { pin2 = nullptr; return; }
                                     std::memcpy(pin2, bf.map + from, len);
                                     pf_len = len;
                                 });
@@ -1142,7 +1153,7 @@ bool gpu_output_supported(const Plan &plan, std::string *why) {
                         if (bytes + 64 > run_pin_cap) {
                             if (run_pin) fqtk_pinned_free(run_pin);
                             run_pin_cap = bytes + bytes / 4 + 65536;
-                            if (fqtk_pinned_alloc(run_pin_cap, &run_pin) != FQTK_OK) { run_pin = nullptr; fail(std::string("cannot allocate page-locked memory: ") + fqtk_last_error()); break; }
+                            if (pinned_alloc_timed(run_pin_cap, &run_pin) != FQTK_OK) { run_pin = nullptr; fail(std::string("cannot allocate page-locked memory: ") + fqtk_last_error()); break; }
                         }
                         if (bytes) std::memcpy(run_pin, bf.map + from, bytes);
                         if (upto > (64u << 20)) madvise(const_cast<uint8_t *>(bf.map), (upto - (64u << 20)) & ~(size_t)4095, MADV_DONTNEED);
@@ -1728,7 +1739,7 @@ int main(int argc, char **argv) {
             if (b.obs) fqtk_pinned_free(b.obs);
             void *p = nullptr;
             b.obs_cap = n * stride + (n * stride) / 4 + 64;
-            if (fqtk_pinned_alloc(b.obs_cap, &p) != FQTK_OK) die(fqtk_last_error());
+            if (pinned_alloc_timed(b.obs_cap, &p) != FQTK_OK) die(fqtk_last_error());
             b.obs = (uint8_t *)p;
         }
         if (n > b.n_cap) {
@@ -1736,8 +1747,8 @@ int main(int argc, char **argv) {
             if (b.lens) fqtk_pinned_free(b.lens);
             void *p = nullptr, *q = nullptr;
             b.n_cap = n + n / 4 + 16;
-            if (fqtk_pinned_alloc(b.n_cap * sizeof(fqtk_match_t), &p) != FQTK_OK) die(fqtk_last_error());
-            if (fqtk_pinned_alloc(b.n_cap * sizeof(uint32_t), &q) != FQTK_OK) die(fqtk_last_error());
+            if (pinned_alloc_timed(b.n_cap * sizeof(fqtk_match_t), &p) != FQTK_OK) die(fqtk_last_error());
+            if (pinned_alloc_timed(b.n_cap * sizeof(uint32_t), &q) != FQTK_OK) die(fqtk_last_error());
             b.out = (fqtk_match_t *)p;
             b.lens = (uint32_t *)q;
         }
