@@ -743,14 +743,14 @@ FQTK_HD inline uint32_t lz_round(Shared &S, uint32_t q, uint32_t p) {
     return x0 ? ctz32(x0) >> 3 : (x1 ? 4 + (ctz32(x1) >> 3) : (x2 ? 8 + (ctz32(x2) >> 3) : 12 + (ctz32(x3) >> 3)));
 }
 #ifndef FQTK_BGZF_OPEN_ROUNDS
-#define FQTK_BGZF_OPEN_ROUNDS 1u   // rounds of sixteen bytes a candidate is compared for inside the step that found it (lz_rest); 0xFFFFu: to its end, as until round 5
+#define FQTK_BGZF_OPEN_ROUNDS 0u   // rounds of sixteen bytes a candidate is compared for inside the step that found it (lz_rest); 0xFFFFu: to its end, as until round 5.  (GB/s in on varied / binned / constant qualities, output on binned ones: 1: 96.0 / 81.5 / 102.2; 0: 99.8 / 91.8 / 107.7, +0.6 %)
 #endif
 #ifndef FQTK_BGZF_OPEN_STEP
 #define FQTK_BGZF_OPEN_STEP 1u     // rounds per step of a match that is still being compared (lz_step)
 #endif
 // The best of the candidates at position p: length and distance (0 = none pays for itself).  open: the candidate was still equal
-// after FQTK_BGZF_OPEN_ROUNDS rounds -- forty bytes: it is the match, whatever the others are, and how long it is the lane's
-// next steps find out (lz_step).
+// after FQTK_BGZF_OPEN_ROUNDS rounds : it is the match, whatever the others are, and how long it is the lane's
+// next steps find out (lz_step).  With no round at all inside the step (the default) that is the first candidate whose eight bytes are the position's.
 FQTK_HD inline void lz_rest(Shared &S, uint32_t n, uint32_t p, const LzLane &st, uint32_t w, uint32_t w4, const uint32_t (&qpos)[kCands],
                             const uint32_t (&first)[kCands], uint32_t &mlen, uint32_t &mdist, bool &open) {
     uint32_t msave = 0;

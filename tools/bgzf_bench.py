@@ -33,9 +33,10 @@ def main():
     ap.add_argument("--blocks", type=int, default=4096)
     ap.add_argument("--reps", type=int, default=5)
     ap.add_argument("--const-qual", action="store_true", help="every quality 'I' (scope E's synthetic records: long runs)")
+    ap.add_argument("--binned-qual", action="store_true", help="qualities as a NovaSeq writes them: mostly F, now and then : , # (short runs; tools/bgzf_ratio.py's second text)")
     ap.add_argument("--hbm-only", action="store_true", help="no pass with the input in pinned host memory (tools/bgzf_phases.sh: the kernel's own phases)")
     a = ap.parse_args()
-    print(json.dumps(measure(a.blocks, a.reps, a.const_qual, ("hbm",) if a.hbm_only else ("hbm", "pinned_host"))))
+    print(json.dumps(measure(a.blocks, a.reps, "binned" if a.binned_qual else a.const_qual, ("hbm",) if a.hbm_only else ("hbm", "pinned_host"))))
 
 
 def measure(blocks=4096, reps=5, const_qual=False, where_list=("hbm", "pinned_host")):
@@ -44,7 +45,7 @@ def measure(blocks=4096, reps=5, const_qual=False, where_list=("hbm", "pinned_ho
     import torch
     lib = _lib.load()
     rng = np.random.default_rng(1)
-    text = fastq_text(4000, rng, b"I") if const_qual else fastq_text(4000, rng)
+    text = fastq_text(4000, rng, b"F" * 40 + b":,#") if const_qual == "binned" else (fastq_text(4000, rng, b"I") if const_qual else fastq_text(4000, rng))
     uniq = [text[o:o + 65280] for o in range(0, len(text) - 65280, 65280)]
     n = blocks
     host_in = np.zeros((n, 65536), dtype=np.uint8)
