@@ -268,15 +268,16 @@ __global__ __launch_bounds__(256) void k_records(TextSet T, DevConfig C, uint32_
         const uint8_t *x = T.text[i];
         const uint32_t *ls = T.ls[i] + 4u * t;
         const uint32_t s0 = ls[0], s1 = ls[1], s2 = ls[2], s3 = ls[3], s4 = ls[4];
-        auto line_len = [&](uint32_t a, uint32_t b) {   // [a, b - 1) without the newline, without a trailing '\r'
-            uint32_t l = b - 1u - a;
-            if (l && x[a + l - 1u] == '\r') --l;
-            return l;
-        };
-        const uint32_t hl = line_len(s0, s1), ql = line_len(s3, s4), pl = line_len(s2, s3);
-        uint32_t sl = line_len(s1, s2);
-        if (hl == 0 || x[s0] != '@') report(st, t, 0, i, FQTK_DEMUX_ERR_NO_AT);
-        else if (pl == 0 || x[s2] != '+') report(st, t, 0, i, FQTK_DEMUX_ERR_NO_PLUS);
+        // [a, b - 1) without the newline, without a trailing '\r'.  The six bytes looked at -- the four lines' last ones, the '@' and the '+' -- are
+        // read TOGETHER and unconditionally (an empty line reads its own newline): `if (l && x[...] == '\r')` is a branch around a read with a
+        // wait of its own, and six of those per input were six dependent round trips to the L2 per template.
+        const uint32_t l0 = s1 - 1u - s0, l1 = s2 - 1u - s1, l2 = s3 - 1u - s2, l3 = s4 - 1u - s3;
+        const uint8_t e0 = x[s0 + (l0 ? l0 - 1u : 0u)], e1 = x[s1 + (l1 ? l1 - 1u : 0u)], e2 = x[s2 + (l2 ? l2 - 1u : 0u)], e3 = x[s3 + (l3 ? l3 - 1u : 0u)];
+        const uint8_t at = x[s0], plus = x[s2];
+        const uint32_t hl = l0 - (l0 && e0 == '\r' ? 1u : 0u), ql = l3 - (l3 && e3 == '\r' ? 1u : 0u), pl = l2 - (l2 && e2 == '\r' ? 1u : 0u);
+        uint32_t sl = l1 - (l1 && e1 == '\r' ? 1u : 0u);
+        if (hl == 0 || at != '@') report(st, t, 0, i, FQTK_DEMUX_ERR_NO_AT);
+        else if (pl == 0 || plus != '+') report(st, t, 0, i, FQTK_DEMUX_ERR_NO_PLUS);
         else if (sl != ql) report(st, t, 0, i, FQTK_DEMUX_ERR_QUAL_LEN);
         if (ql < sl) sl = ql;   // (an error anyway; keeps every later access inside both lines)
         RecView r;
@@ -343,7 +344,7 @@ __global__ __launch_bounds__(1024) void k_plan_rank(TextSet T, DevConfig C, uint
                                                     TemplatePlan *plans, uint32_t *rec_off /* [n_files][n] */,
                                                     uint32_t *tile_tot /* [tiles][cols] */, ChunkStatus *st) {
     if (no_records(st)) return;
-    __shared__ uint32_t s_key[kTile];
+    __shared__ __attribute__((aligned(16))) uint32_t s_key[kTile];
     __shared__ uint32_t s_len[kRankGroup][kTile];
     const uint32_t i = threadIdx.x, tile = blockIdx.x, t = tile * kTile + i;
     const uint32_t cps = C.n_files + 1u, cols = (C.n_samples + 1u) * cps;
@@ -394,17 +395,26 @@ __global__ __launch_bounds__(1024) void k_plan_rank(TextSet T, DevConfig C, uint
         uint32_t before[kRankGroup] = {0, 0}, tot[kRankGroup] = {0, 0};
         cnt_before = 0;
         cnt_tot = 0;
+        // Eight templates' keys per round (two 16-byte reads, the same address in every lane), then only the lanes that have their own key among
+        // them read lengths -- a template shares its sample with two or three of the tile's 1024.  (One key per round was a dependent LDS round trip per
+        // template of the tile, 1024 in a row; everything read unconditionally and summed by selection was as slow: ~15 k vector instructions per wavefront.)
         if (key != 0xFFFFFFFFu)
-            for (uint32_t j = 0; j < kTile; ++j) {
-                if (s_key[j] != key) continue;
-                const bool b4 = j < i;
-                cnt_tot += 1u;
-                cnt_before += b4 ? 1u : 0u;
+            for (uint32_t j = 0; j < kTile; j += 8u) {
+                const uint4 ka = *reinterpret_cast<const uint4 *>(s_key + j), kb = *reinterpret_cast<const uint4 *>(s_key + j + 4u);
+                uint32_t hit = (ka.x == key ? 1u : 0u) | (ka.y == key ? 2u : 0u) | (ka.z == key ? 4u : 0u) | (ka.w == key ? 8u : 0u) |
+                               (kb.x == key ? 16u : 0u) | (kb.y == key ? 32u : 0u) | (kb.z == key ? 64u : 0u) | (kb.w == key ? 128u : 0u);
+                while (hit) {
+                    const uint32_t jj = j + (uint32_t)__ffs((int)hit) - 1u;
+                    hit &= hit - 1u;
+                    const bool b4 = jj < i;
+                    cnt_tot += 1u;
+                    cnt_before += b4 ? 1u : 0u;
 #pragma unroll
-                for (uint32_t f = 0; f < kRankGroup; ++f) {
-                    const uint32_t l = s_len[f][j];
-                    tot[f] += l;
-                    before[f] += b4 ? l : 0u;
+                    for (uint32_t f = 0; f < kRankGroup; ++f) {
+                        const uint32_t l = s_len[f][jj];
+                        tot[f] += l;
+                        before[f] += b4 ? l : 0u;
+                    }
                 }
             }
         if (key != 0xFFFFFFFFu) {
@@ -431,11 +441,19 @@ __global__ __launch_bounds__(1024) void k_plan_rank(TextSet T, DevConfig C, uint
 __global__ __launch_bounds__(256) void k_column_scan(uint32_t *tile_tot, uint32_t n_tiles, uint32_t cols, uint32_t *chunk_tot) {
     const uint32_t c = blockIdx.x * 256u + threadIdx.x;
     if (c >= cols) return;
+    // (eight tiles' values are read before any is written back: read, write, read in place is one memory round trip per tile -- 256 in a row, 61 us
+    //  of a chunk for 1155 lanes' worth of additions)
     uint32_t run = 0;
-    for (uint32_t tl = 0; tl < n_tiles; ++tl) {
-        const uint32_t v = tile_tot[(size_t)tl * cols + c];
-        tile_tot[(size_t)tl * cols + c] = run;
-        run += v;
+    for (uint32_t tl = 0; tl < n_tiles; tl += 8u) {
+        uint32_t v[8];
+#pragma unroll
+        for (uint32_t u = 0; u < 8u; ++u) v[u] = tile_tot[(size_t)(tl + u < n_tiles ? tl + u : n_tiles - 1u) * cols + c];
+#pragma unroll
+        for (uint32_t u = 0; u < 8u; ++u)
+            if (tl + u < n_tiles) {
+                tile_tot[(size_t)(tl + u) * cols + c] = run;
+                run += v[u];
+            }
     }
     chunk_tot[c] = run;
 }

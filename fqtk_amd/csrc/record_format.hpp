@@ -53,22 +53,43 @@ FQTK_HD inline HeaderPlan plan_header(const uint8_t *h, uint32_t len, bool have_
     p.tail = 0;
     p.msep = ':';
     p.err = kHeaderOk;
-    uint32_t sp = len;
+    // The line's first space, the colons in front of it, the colons behind it and where the first of those stands.
+    uint32_t sp = len, name_colons = 0, colons = 0, first_at = len;
+#if defined(__HIP_DEVICE_COMPILE__)
+    // (Sixteen bytes per round, four unaligned dword reads in flight -- every text buffer has 64 bytes of slack behind it --, the bytes looked at
+    //  in order by selection.  Byte by byte with an early exit, each byte was a dependent round trip to the L2: some fifty-five of them per
+    //  template, and k_plan_rank's 150 us per chunk were mostly this.)
+    for (uint32_t base = 0; base < len; base += 16u) {
+        uint32_t w[4];
+#pragma unroll
+        for (uint32_t k = 0; k < 4u; ++k) w[k] = *reinterpret_cast<const uint32_t *>(h + base + 4u * k);
+#pragma unroll
+        for (uint32_t j = 0; j < 16u; ++j) {
+            const uint32_t c = (w[j >> 2] >> (8u * (j & 3u))) & 0xFFu, pos = base + j;
+            const bool in = pos < len, before_space = sp == len;
+            const bool colon = in && c == ':';
+            name_colons += colon && before_space ? 1u : 0u;
+            first_at = colon && !before_space && first_at == len ? pos : first_at;
+            colons += colon && !before_space ? 1u : 0u;
+            sp = in && before_space && c == ' ' ? pos : sp;
+        }
+    }
+#else
     for (uint32_t i = 0; i < len; ++i)
         if (h[i] == ' ') { sp = i; break; }
+    for (uint32_t i = 0; i < sp; ++i) name_colons += h[i] == ':';
+    for (uint32_t i = sp + 1; i < len; ++i)
+        if (h[i] == ':') { if (first_at == len) first_at = i; ++colons; }
+#endif
     p.name_len = sp;
     if (have_molecular) {   // demux.rs:188-211
-        uint32_t colons = 0;
-        for (uint32_t i = 0; i < sp; ++i) colons += h[i] == ':';
-        if (colons > 7) { p.err = kTooManyNameSegments; return p; }
-        p.msep = colons == 7 ? '+' : ':';
+        if (name_colons > 7) { p.err = kTooManyNameSegments; return p; }
+        p.msep = name_colons == 7 ? '+' : ':';
     }
     if (sp == len) return p;   // no comment: "<n>:N:0:"
     const uint32_t c0 = sp + 1, clen = len - c0;
     if (clen == 0) { p.err = kEmptyComment; return p; }
-    uint32_t colons = 0, first = clen;
-    for (uint32_t i = 0; i < clen; ++i)
-        if (h[c0 + i] == ':') { if (first == clen) first = i; ++colons; }
+    const uint32_t first = first_at == len ? clen : first_at - c0;
     const uint8_t last = h[len - 1];
     if (colons < 3) {   // demux.rs:227-232
         p.kind = 1;
