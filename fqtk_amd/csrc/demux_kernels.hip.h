@@ -189,52 +189,60 @@ __global__ __launch_bounds__(256) void k_count_lines(TextSet T) {
 
 // exclusive prefix sum of an input's tile counts, in place; the total = its number of lines
 __global__ __launch_bounds__(1024) void k_scan_tiles(TextSet T, ChunkStatus *st) {
-    __shared__ uint32_t sh[1024];
-    __shared__ uint32_t carry;
+    __shared__ uint32_t sh[2][16];
     const uint32_t in = blockIdx.x;
     const uint32_t n_tiles = (T.len[in] + kLineTile - 1) / kLineTile;
     uint32_t *a = T.tile_cnt[in];
-    if (threadIdx.x == 0) carry = 0;
-    __syncthreads();
-    for (uint32_t base = 0; base < n_tiles; base += 1024) {
+    // (a wavefront's prefix sum by shuffles, the sixteen wavefronts' totals through LDS -- two sets in turn, so ONE barrier per 1024 tiles; the
+    //  doubling scan over LDS took twenty-two, and this kernel is one workgroup per input: all latency)
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    uint32_t carry = 0;   // (the same in every lane)
+    for (uint32_t base = 0, round = 0; base < n_tiles; base += 1024, round ^= 1u) {
         const uint32_t i = base + threadIdx.x;
-        const uint32_t v = i < n_tiles ? a[i] : 0;
-        sh[threadIdx.x] = v;
-        __syncthreads();
-        for (uint32_t d = 1; d < 1024; d <<= 1) {
-            const uint32_t add = threadIdx.x >= d ? sh[threadIdx.x - d] : 0;
-            __syncthreads();
-            sh[threadIdx.x] += add;
-            __syncthreads();
+        const uint32_t v = a[i < n_tiles ? i : n_tiles - 1u] * (i < n_tiles ? 1u : 0u);
+        uint32_t incl = v;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint32_t up = __shfl_up(incl, d);
+            if (lane >= (uint32_t)d) incl += up;
         }
-        const uint32_t incl = sh[threadIdx.x], c0 = carry;
-        if (i < n_tiles) a[i] = c0 + incl - v;
+        if (lane == 63u) sh[round][wave] = incl;
         __syncthreads();
-        if (threadIdx.x == 1023) carry = c0 + incl;
-        __syncthreads();
+        uint32_t before_waves = 0, total = 0;
+#pragma unroll
+        for (uint32_t w = 0; w < 16u; ++w) {
+            const uint32_t tw = sh[round][w];
+            before_waves += w < wave ? tw : 0u;
+            total += tw;
+        }
+        if (i < n_tiles) a[i] = carry + before_waves + incl - v;
+        carry += total;
     }
     if (threadIdx.x == 0) st->n_lines[in] = carry;
 }
 
 // ls[k + 1] = offset of the byte after newline k (k < max_lines)
 __global__ __launch_bounds__(256) void k_line_starts(TextSet T, uint32_t max_lines) {
-    __shared__ uint32_t sh[256];
+    __shared__ uint32_t sh[4];
     const uint32_t in = blockIdx.y, tile = blockIdx.x;
     if ((uint64_t)tile * kLineTile >= T.len[in]) return;
     uint32_t m[4];
     const uint32_t c = lane_newlines(tile_bytes(T.text[in], T.len[in], tile, threadIdx.x, T.lead[in]), m);
-    sh[threadIdx.x] = c;
-    __syncthreads();
-    for (uint32_t d = 1; d < 256; d <<= 1) {
-        const uint32_t add = threadIdx.x >= d ? sh[threadIdx.x - d] : 0;
-        __syncthreads();
-        sh[threadIdx.x] += add;
-        __syncthreads();
+    // inclusive prefix sum of the 256 lanes' counts: by shuffles inside a wavefront, the four wavefronts' totals through LDS (one barrier; the doubling
+    // scan over LDS took sixteen)
+    uint32_t incl = c;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t up = __shfl_up(incl, d);
+        if ((threadIdx.x & 63u) >= (uint32_t)d) incl += up;
     }
+    if ((threadIdx.x & 63u) == 63u) sh[threadIdx.x >> 6] = incl;
+    __syncthreads();
+    for (uint32_t w = 0; w < (threadIdx.x >> 6); ++w) incl += sh[w];
     // newline number k of the window ends the chunk's line k - first_line (the window's lines before first_line and
     // behind the chunk's last one belong to other chunks)
     const uint32_t first = T.first_line[in];
-    uint32_t k = T.tile_cnt[in][tile] + sh[threadIdx.x] - c;
+    uint32_t k = T.tile_cnt[in][tile] + incl - c;
     uint32_t *ls = T.ls[in];
     if (tile == 0 && threadIdx.x == 0 && first == 0u) ls[0] = T.lead[in];
     const uint32_t off = tile * kLineTile + threadIdx.x * 16u;
