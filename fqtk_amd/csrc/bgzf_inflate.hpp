@@ -345,14 +345,23 @@ FQTK_HD inline Token decode_token(const Shared &S, uint64_t bits) {
 // The common case in straight-line code: both look-ups are unconditional (a lane whose first code is a literal reads
 // some distance entry it does not use) and the token's fields are selected at the end -- the 64 lanes decode 64 different
 // bit positions, so every branch of a branchy version is taken by somebody and costs the wave its full length.
-FQTK_HD inline Token decode_token_fast(const Shared &S, uint64_t bits) {
-    const uint32_t e = S.lit[(uint32_t)bits & ((1u << kLitBits) - 1u)];
+// 32 bits of a 64-bit window from bit s < 32 on: one v_alignbit_b32 (a 64-bit shift is two to four times a 32-bit instruction)
+FQTK_HD inline uint32_t funnel32(uint32_t hi, uint32_t lo, uint32_t s) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_alignbit(hi, lo, s);
+#else
+    return (uint32_t)((((uint64_t)hi << 32) | lo) >> (s & 31u));
+#endif
+}
+FQTK_HD inline Token decode_token_fast(const Shared &S, uint32_t b0, uint32_t b1) {   // the 64 bits from the token's first one on, low word first
+    const uint32_t e = S.lit[b0 & ((1u << kLitBits) - 1u)];
     const uint32_t cl = e & 15u, ne = (e >> 4) & 15u, kind = (e >> 8) & 3u, val = e >> 16;
-    const uint32_t len = val + ((uint32_t)(bits >> cl) & ((1u << ne) - 1u));
-    const uint32_t u = cl + ne;   // <= 20
-    const uint32_t de = S.dist[(uint32_t)(bits >> u) & ((1u << kDistBits) - 1u)];
+    const uint32_t len = val + (funnel32(b1, b0, cl) & ((1u << ne) - 1u));
+    const uint32_t u = cl + ne;   // <= 28
+    const uint32_t dbits = funnel32(b1, b0, u);   // the distance code, its extra bits behind it: 15 + 13 of these 32
+    const uint32_t de = S.dist[dbits & ((1u << kDistBits) - 1u)];
     const uint32_t dcl = de & 15u, dne = (de >> 4) & 15u, dkind = (de >> 8) & 3u;
-    const uint32_t dist = (de >> 16) + ((uint32_t)(bits >> (u + dcl)) & ((1u << dne) - 1u));
+    const uint32_t dist = (de >> 16) + ((dbits >> dcl) & ((1u << dne) - 1u));
     const bool is_len = kind == kLen;
     const bool slow = kind == kLong || (is_len && dkind == kLong);
     const bool bad = !slow && (cl == 0u || (is_len && dcl == 0u));
@@ -585,9 +594,9 @@ FQTK_HD inline uint32_t inflate_member(W &w, Shared &S, const MemberArgs &a, Str
                 // block) step 0x80 -- out of the window -- so that the walk has ONE exit test, and are looked at behind it.
                 FQTK_UNROLL
                 for (uint32_t q = 0; q < kSets; ++q) {
-                    const uint64_t lo = (uint64_t)dw[2 * q] | ((uint64_t)dw[2 * q + 1] << 32);
-                    bits[q] = s ? (lo >> s) | ((uint64_t)dw[2 * q + 2] << (64u - s)) : lo;
-                    t[q] = decode_token_fast(S, bits[q]);
+                    const uint32_t b0 = funnel32(dw[2 * q + 1], dw[2 * q], s), b1 = funnel32(dw[2 * q + 2], dw[2 * q + 1], s);   // (s < 32; s = 0: the words themselves)
+                    bits[q] = (uint64_t)b0 | ((uint64_t)b1 << 32);
+                    t[q] = decode_token_fast(S, b0, b1);
                     slow[q] = w.ballot((t[q].flags & kTokSlow) != 0u);
                     meta[q] = t[q].flags & (kTokSlow | kTokBad | kTokEob) ? 0x80u : t[q].nbits;
                 }
