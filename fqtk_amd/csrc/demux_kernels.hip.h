@@ -910,35 +910,43 @@ __global__ __launch_bounds__(64 * kFormatWaves) FQTK_FORMAT_OCCUPANCY void k_for
 // ---- packing ------------------------------------------------------------------------------------------------------------
 // BGZF member = 18-byte header (BSIZE), DEFLATE payload, CRC-32 and length of the uncompressed block.
 // pos[j] = byte offset of member j in the packed result; file_off[c] = offset of file c's first member.
-__global__ __launch_bounds__(1024) void k_pack_scan(DevConfig C, const FileChunk *fc, const uint32_t *out_len, unsigned long long *pos,
-                                                    unsigned long long *file_off, ChunkStatus *st) {
-    __shared__ unsigned long long sh[1024];
-    __shared__ unsigned long long carry;
+// (256 lanes: a workgroup of 1024 needs a CU with NOTHING else on it when the input decoders' wavefronts -- four per SIMD, the register file's
+//  worth -- are about, and waited 0.3 ms per chunk for one in runs from BGZF inputs; four wavefronts fit wherever one decoder wavefront per SIMD
+//  has ended.  The prefix sum by shuffles and one barrier per 256 blocks.)
+constexpr uint32_t kPackScanLanes = 256;
+__global__ __launch_bounds__(kPackScanLanes) void k_pack_scan(DevConfig C, const FileChunk *fc, const uint32_t *out_len, unsigned long long *pos,
+                                                              unsigned long long *file_off, ChunkStatus *st) {
+    __shared__ uint32_t sh[2][kPackScanLanes / 64];
     const uint32_t nblk = st->n_blocks;
-    if (threadIdx.x == 0) carry = 0;
-    __syncthreads();
-    for (uint32_t base = 0; base < nblk; base += 1024) {
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    unsigned long long carry = 0;   // (the same in every lane)
+    for (uint32_t base = 0, round = 0; base < nblk; base += kPackScanLanes, round ^= 1u) {
         const uint32_t j = base + threadIdx.x;
-        const unsigned long long v = j < nblk ? 26ull + out_len[j] : 0ull;
-        sh[threadIdx.x] = v;
-        __syncthreads();
-        for (uint32_t d = 1; d < 1024; d <<= 1) {
-            const unsigned long long a = threadIdx.x >= d ? sh[threadIdx.x - d] : 0ull;
-            __syncthreads();
-            sh[threadIdx.x] += a;
-            __syncthreads();
+        const uint32_t v = j < nblk ? 26u + out_len[j < nblk ? j : 0u] : 0u;   // (a member is < 64 KiB: 256 of them fit 32 bits)
+        uint32_t incl = v;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint32_t up = __shfl_up(incl, d);
+            if (lane >= (uint32_t)d) incl += up;
         }
-        const unsigned long long c0 = carry;
-        if (j < nblk) pos[j] = c0 + sh[threadIdx.x] - v;
+        if (lane == 63u) sh[round][wave] = incl;
         __syncthreads();
-        if (threadIdx.x == 1023) carry = c0 + sh[1023];
-        __syncthreads();
+        uint32_t before_waves = 0, total = 0;
+#pragma unroll
+        for (uint32_t w = 0; w < kPackScanLanes / 64; ++w) {
+            const uint32_t tw = sh[round][w];
+            before_waves += w < wave ? tw : 0u;
+            total += tw;
+        }
+        if (j < nblk) pos[j] = carry + before_waves + incl - v;
+        carry += total;
     }
     const unsigned long long total = carry;
     if (threadIdx.x == 0) { st->total_bytes = total; pos[nblk] = total; }
+    __threadfence();
     __syncthreads();
     const uint32_t n_cols = (C.n_samples + 1u) * C.n_files;
-    for (uint32_t c = threadIdx.x; c <= n_cols; c += 1024) {
+    for (uint32_t c = threadIdx.x; c <= n_cols; c += kPackScanLanes) {
         const uint32_t b = fc[c].blk_base;
         file_off[c] = b < nblk ? pos[b] : total;
     }

@@ -223,7 +223,7 @@ int enqueue_compress(fqtk_demuxer *d, Slot &s) {
     DX_TRY(fqtk::bgzf::deflate_launch(d->s_b, (uint32_t)d->num_cus, s.desc.p, &s.d_status->n_blocks, s.out_len.p, s.crc.p, d->d_tok, d->level,
                                       d->dynamic_blocks ? s.d_next_block : nullptr));
     DX_TRY(hipEventRecord(s.ev[6], d->s_b));
-    hipLaunchKernelGGL(k_pack_scan, dim3(1), dim3(1024), 0, d->s_b, d->C, s.fc.p, s.out_len.p, s.pos.p, s.file_off.p, s.d_status);
+    hipLaunchKernelGGL(k_pack_scan, dim3(1), dim3(kPackScanLanes), 0, d->s_b, d->C, s.fc.p, s.out_len.p, s.pos.p, s.file_off.p, s.d_status);
     DX_TRY(hipGetLastError());
     hipLaunchKernelGGL(k_pack_copy, dim3((uint32_t)d->num_cus * 4), dim3(256), 0, d->s_b, s.desc.p, s.out_len.p, s.crc.p, s.pos.p, s.packed.p, s.d_status);
     DX_TRY(hipGetLastError());
