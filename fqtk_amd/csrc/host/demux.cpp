@@ -874,6 +874,7 @@ bool gpu_output_supported(const Plan &plan, std::string *why) {
     std::vector<uint64_t> lines_fed(n_inputs, 0);
     std::vector<char> fed_done(n_inputs, 0);
     std::string feed_error;
+    size_t staged_inputs = 0;   // feeders that have their page-locked staging (they start the device together)
     uint64_t lines_taken = 0;   // per input: 4 x templates submitted
     std::vector<uint64_t> blank_tail(n_inputs, 0);   // lines at an input's end that are no record (see below)
     bool tails_looked_at = false;
@@ -1132,6 +1133,25 @@ bool gpu_output_supported(const Plan &plan, std::string *why) {
                     void *run_pin = nullptr;           // (runs of BGZF members have their own staging: the stretches' buffers are in use by the prefetcher)
                     size_t run_pin_cap = 0;
                     struct FreeRunPin { void *&p; ~FreeRunPin() { if (p) fqtk_pinned_free(p); } } free_run_pin{run_pin};
+                    // A serial gzip input's two staging buffers are page-locked HERE, and no input starts the device before every input has its own: a
+                    // page-locking call that runs beside kernels and copies takes 0.1-0.3 s for 64 MB instead of 0.01-0.03 (it waits for the device's work in
+                    // flight, and every other HIP call of the process waits for it) -- on a box whose memory a test-suite had just been through, the eight of them
+                    // kept a run's FIRST chunk until 1.1-1.3 s and put the run behind the host decoders' (tools/gz_ab.sh after pytest: 2.1-2.3 s against 1.7-1.8).
+                    {
+                        bool staged_ok = true;
+                        if (!BgzfFile::looks_like_bgzf(bf.map + bf.pos, bf.size - bf.pos)) {
+                            pin_cap = std::min<size_t>(bf.size, (kSlots + 5) * kChunkBytes + 131072 + 4) + 65536;
+                            if (pinned_alloc_timed(pin_cap, &pin) != FQTK_OK) { pin = nullptr; pin_cap = 0; staged_ok = false; }
+                            else if (pinned_alloc_timed(pin_cap, &pin2) != FQTK_OK) pin2 = nullptr;   // (then stretches are copied when they are due)
+                        }
+                        {
+                            std::unique_lock<std::mutex> lk(fmu);
+                            ++staged_inputs;
+                            fcv.notify_all();
+                            fcv.wait(lk, [&] { return staged_inputs >= n_inputs; });
+                        }
+                        if (!staged_ok) fail(std::string("cannot allocate page-locked memory: ") + fqtk_last_error());
+                    }
                     for (;;) {
                         if (!BgzfFile::looks_like_bgzf(bf.map + bf.pos, bf.size - bf.pos)) {
                             // a gzip member without the BC field (`cat a.bgz b.gz`, or the whole file): one serial stream, decoded in chunks
