@@ -198,6 +198,14 @@ int alloc_slot_fixed(fqtk_demuxer *d, Slot &s) {
     if ((rc = s.fc.ensure((size_t)d->n_cols + 1)) != FQTK_OK) return rc;
     if ((rc = s.file_off.ensure((size_t)d->n_cols + 1)) != FQTK_OK) return rc;
     if ((rc = s.h_file_off.ensure((size_t)d->n_cols + 1)) != FQTK_OK) return rc;
+    // room for a chunk's members to come back into, made NOW, while the device is idle: grown at the slot's first collect -- beside the next chunks' kernels and
+    // copies -- a 33 MB page-locking call took 0.1-0.3 s on a box with tired memory and held every other HIP call of the process up meanwhile (it still grows
+    // there when a chunk's members are more than this: FQTK_DEMUX_PACKED_MB)
+    {
+        const char *e = std::getenv("FQTK_DEMUX_PACKED_MB");
+        const long mb = e && *e ? std::atol(e) : 32;
+        if (mb > 0 && (rc = s.h_packed.ensure((size_t)mb << 20)) != FQTK_OK) return rc;
+    }
     if ((rc = s.chunk_tot.ensure(d->cols)) != FQTK_OK) return rc;
     return FQTK_OK;
 }

@@ -1143,6 +1143,11 @@ bool gpu_output_supported(const Plan &plan, std::string *why) {
                             pin_cap = std::min<size_t>(bf.size, (kSlots + 5) * kChunkBytes + 131072 + 4) + 65536;
                             if (pinned_alloc_timed(pin_cap, &pin) != FQTK_OK) { pin = nullptr; pin_cap = 0; staged_ok = false; }
                             else if (pinned_alloc_timed(pin_cap, &pin2) != FQTK_OK) pin2 = nullptr;   // (then stretches are copied when they are due)
+                        } else {   // a BGZF file: the staging of its runs of members (a run is a quarter of FQTK_FEED_TEXT_MB of file at most)
+                            const char *v = std::getenv("FQTK_FEED_TEXT_MB");
+                            const size_t run_bytes = std::min<size_t>(bf.size - bf.pos, ((size_t)(v && *v ? std::atol(v) : 256) << 20) / 4);
+                            run_pin_cap = run_bytes + run_bytes / 4 + 65536;
+                            if (pinned_alloc_timed(run_pin_cap, &run_pin) != FQTK_OK) { run_pin = nullptr; run_pin_cap = 0; }   // (made when the first run is due, then)
                         }
                         {
                             std::unique_lock<std::mutex> lk(fmu);
