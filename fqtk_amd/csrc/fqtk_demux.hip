@@ -864,6 +864,11 @@ int fqtk_demuxer_stream_reserve(fqtk_demuxer *d, uint32_t input, uint64_t max_le
     int rc;
     if ((rc = fed_init(d)) != FQTK_OK) return rc;
     FedInput &F = d->fed[input];
+    static const bool timing = std::getenv("FQTK_TIMING") != nullptr;
+    const auto t_begin = std::chrono::steady_clock::now();
+    struct Report { bool on; uint32_t input; std::chrono::steady_clock::time_point t0; uint64_t arena;
+                    ~Report() { if (on) std::fprintf(stderr, "(timing) stream reserve of input %u (arenas 2 x %llu MB): %.1f ms\n", input, (unsigned long long)(arena >> 20),
+                                                     std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count()); } } report{timing, input, t_begin, arena_bytes};
     std::lock_guard<std::mutex> lk(F.mu);
     if ((rc = F.comp.ensure((size_t)max_len + 16)) != FQTK_OK) return rc;
     if ((rc = F.sym.ensure((size_t)stream_sym_cap(max_len, max_slots, sym_per_byte) + 64)) != FQTK_OK) return rc;

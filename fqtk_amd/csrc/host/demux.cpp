@@ -941,7 +941,11 @@ bool gpu_output_supported(const Plan &plan, std::string *why) {
                             reserved = true;
                             const uint64_t stretch_bytes = std::min<uint64_t>(bf.size, (uint64_t)kSlots * kChunkBytes + 131072);
                             const uint64_t ahead_text = (gz_high_water / 4u) * (uint64_t)std::max<size_t>(16, per_record_of[i]);
-                            const uint64_t arena = std::min<uint64_t>((ahead_text + stretch_bytes * 8u) * 2u + (64u << 20), (uint64_t)bf.size * 24u + (64u << 20));
+                            // (two arenas of this size per input are the run's largest allocations -- 22 GB of device memory for four inputs with the factor 2 they had
+                            //  until the end of round 5 -- and on a box whose memory a test-suite had just been through allocating them took 0.85 s before the first
+                            //  stretch could go: FQTK_TIMING prints it.  Factor 1: 0.4 s there, the same steady rate.)
+                            static const uint64_t kArenaFactor = (uint64_t)std::max<long>(1, env_num("FQTK_GZ_ARENA_FACTOR", 1));
+                            const uint64_t arena = std::min<uint64_t>((ahead_text + stretch_bytes * 8u) * kArenaFactor + (64u << 20), (uint64_t)bf.size * 24u + (64u << 20));
                             if (fqtk_demuxer_stream_reserve(demuxers[0], (uint32_t)i, stretch_bytes + 8, (uint32_t)kSlots, sym_per_byte, kSlots >= 64 ? arena : 0) != FQTK_OK) {
                                 fail(std::string("GPU record pipeline: ") + fqtk_last_error());
                                 return false;
