@@ -41,6 +41,11 @@ class fqtk_stream_end(C.Structure):
 
 
 # include/fqtk_demux.h
+class fqtk_fed_window(C.Structure):   # a cut of an input's fed text (fqtk_demuxer_fed_cut -> fqtk_demuxer_submit_windows)
+    _fields_ = [("home", C.c_void_p), ("input", C.c_uint32), ("lead", C.c_uint32), ("first_line", C.c_uint32), ("n_templates", C.c_uint32),
+                ("base", C.c_void_p), ("len", C.c_uint64), ("pos", C.c_uint64)]
+
+
 class fqtk_demux_segment(C.Structure):
     _fields_ = [("offset", C.c_uint32), ("length", C.c_int32), ("kind", C.c_char)]
 
@@ -149,6 +154,8 @@ SIGNATURES = [
     ("fqtk_demuxer_stage_name", C.c_char_p, [C.c_int]),
     ("fqtk_demuxer_feed", C.c_int, [C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint32, C.c_int, C.POINTER(C.c_uint64)]),
     ("fqtk_demuxer_submit_fed", C.c_int, [C.c_void_p, C.c_int, C.c_uint32]),
+    ("fqtk_demuxer_fed_cut", C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32, C.POINTER(fqtk_fed_window)]),
+    ("fqtk_demuxer_submit_windows", C.c_int, [C.c_void_p, C.c_int, C.POINTER(fqtk_fed_window), C.c_uint32]),
     ("fqtk_demuxer_fed_tail", C.c_int, [C.c_void_p, C.c_uint32, C.c_uint64, C.c_void_p, C.c_size_t, C.POINTER(C.c_uint64)]),
     ("fqtk_demuxer_inflate_seconds", C.c_int, [C.c_void_p, C.POINTER(C.c_double)]),
     ("fqtk_demuxer_stream_decode", C.c_int, [C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint32, C.c_void_p]),

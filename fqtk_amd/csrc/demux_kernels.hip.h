@@ -68,7 +68,8 @@ struct ChunkStatus {
 // What fqtk_demuxer_record_text needs of a chunk that failed, saved in the slot's own memory while the chunk's text is still there (fed
 // chunks are windows of an input's arena, which may be reused or freed before the host gets to word the error: ADVICE r04): header and
 // number of bases, in every input, of the template err_key names and of the one the matcher's length error names.
-constexpr uint32_t kErrTextHead = 256;
+// (4096 header bytes are kept: as many as the caller's buffer of an error message takes from a chunk of host text -- ADVICE r05: 256 cut a long header short)
+constexpr uint32_t kErrTextHead = 4096;
 struct ErrorText { uint32_t t, head_len, seq_len, valid; uint8_t head[kErrTextHead]; };   // [2][n_inputs]: candidate 0 = err_key's template, 1 = matcher_err's
 __global__ void k_save_error_text(TextSet T, uint32_t n_inputs, uint32_t n, const ChunkStatus *st, ErrorText *out) {
     const uint32_t c = blockIdx.x / n_inputs, i = blockIdx.x % n_inputs;

@@ -14,6 +14,7 @@
 
 #include <algorithm>
 #include <atomic>
+#include <condition_variable>
 #include <cstdlib>
 #include <cstring>
 #include <deque>
@@ -127,6 +128,8 @@ struct FedInput {
     uint64_t members_fed = 0;
     uint64_t text_total = 0;            // bytes of text fed so far
     bool ended = false;
+    uint32_t pins = 0;                  // windows cut (fqtk_demuxer_fed_cut) and not yet taken by a submit: the text stays where it is meanwhile
+    std::condition_variable cv_pins;
     // a serial gzip stream in chunks (fqtk_demuxer_stream_decode / _commit)
     DevBuf<uint16_t> sym;
     DevBuf<uint8_t> windows;
@@ -446,7 +449,9 @@ void fqtk_demuxer_destroy(fqtk_demuxer *d) {
 uint32_t fqtk_demuxer_files_per_sample(const fqtk_demuxer *d) { return d ? d->C.n_files : 0; }
 
 namespace {
-struct Window { const uint8_t *base; uint32_t lead, first_line; };   // (a window's length travels as text_len)
+// (a window's length travels as text_len; copy_from: the window lies in another demuxer's arena -- on device copy_dev -- and is copied into the slot's own
+//  text buffer first, base being where it lies there)
+struct Window { const uint8_t *base; uint32_t lead, first_line; const uint8_t *copy_from; int copy_dev; };
 }
 // One chunk: `text` (host buffers, copied in) or `win` (text already on the device).
 static int submit_common(fqtk_demuxer *d, int slot, const uint8_t *const *text, const uint64_t *text_len, const Window *win, uint32_t n) {
@@ -483,11 +488,12 @@ static int submit_common(fqtk_demuxer *d, int slot, const uint8_t *const *text, 
     for (uint32_t i = 0; i < C.n_inputs; ++i) {
         const uint32_t tiles = (uint32_t)((text_len[i] + kLineTile - 1) / kLineTile);
         max_tiles = std::max(max_tiles, tiles);
-        if (!win && (rc = s.text[i].ensure((size_t)text_len[i] + 64)) != FQTK_OK) return rc;
+        const bool own_copy = !win || win[i].copy_from;
+        if (own_copy && (rc = s.text[i].ensure((size_t)text_len[i] + 64)) != FQTK_OK) return rc;
         if ((rc = s.tile_cnt[i].ensure(tiles)) != FQTK_OK) return rc;
         if ((rc = s.ls[i].ensure(4 * (size_t)n + 2)) != FQTK_OK) return rc;
         if ((rc = s.rec[i].ensure(n)) != FQTK_OK) return rc;
-        T.text[i] = win ? win[i].base : s.text[i].p;
+        T.text[i] = own_copy ? s.text[i].p : win[i].base;
         T.lead[i] = win ? win[i].lead : 0u;
         T.first_line[i] = win ? win[i].first_line : 0u;
         s.text_base[i] = T.text[i];
@@ -508,8 +514,11 @@ static int submit_common(fqtk_demuxer *d, int slot, const uint8_t *const *text, 
 
     // text in (copy stream)
     DX_TRY(hipEventRecord(s.ev_h2d0, d->s_in));
-    for (uint32_t i = 0; i < C.n_inputs && !win; ++i)
-        DX_TRY(hipMemcpyAsync(s.text[i].p, text[i], (size_t)text_len[i], hipMemcpyHostToDevice, d->s_in));
+    for (uint32_t i = 0; i < C.n_inputs; ++i) {
+        if (!win) DX_TRY(hipMemcpyAsync(s.text[i].p, text[i], (size_t)text_len[i], hipMemcpyHostToDevice, d->s_in));
+        else if (win[i].copy_from && win[i].copy_dev == d->device) DX_TRY(hipMemcpyAsync(s.text[i].p, win[i].copy_from, (size_t)text_len[i], hipMemcpyDeviceToDevice, d->s_in));
+        else if (win[i].copy_from) DX_TRY(hipMemcpyPeerAsync(s.text[i].p, d->device, win[i].copy_from, win[i].copy_dev, (size_t)text_len[i], d->s_in));   // over xGMI
+    }
     DX_TRY(hipEventRecord(s.ev_h2d1, d->s_in));
 
     // stream A
@@ -645,9 +654,17 @@ static int fed_init(fqtk_demuxer *d) {
 static int fed_make_room(fqtk_demuxer *d, FedInput &F, std::unique_lock<std::mutex> &lk, uint64_t text_bytes, bool tight = false) {
     int rc;
     if (F.tail + text_bytes + kFedSlack <= F.arena[F.cur].cap) return FQTK_OK;
-    lk.unlock();
-    std::lock_guard<std::mutex> glk(d->fed_mu);
-    lk.lock();
+    // (... and windows that were cut -- fqtk_demuxer_fed_cut -- but not yet taken by a submit: they name places in these arenas.  With both locks
+    //  held and no window pinned, every window ever cut has either been copied out or has its chunk's ev_fmt behind ev_last_fmt.)
+    std::unique_lock<std::mutex> glk(d->fed_mu, std::defer_lock);
+    for (;;) {
+        lk.unlock();
+        glk.lock();
+        lk.lock();
+        if (F.pins == 0) break;
+        glk.unlock();
+        F.cv_pins.wait(lk, [&] { return F.pins == 0; });
+    }
     // (only this input's feeder moves its tail; chunks may have consumed members meanwhile, which only shrinks what is live)
     const uint64_t live_from = F.members.empty() ? F.tail : F.members.front().off;
     {
@@ -763,41 +780,126 @@ int fqtk_demuxer_feed(fqtk_demuxer *d, uint32_t input, const uint8_t *bytes, uin
     return FQTK_OK;
 }
 
+// The next n records of an input's fed text: where they lie.  The window is pinned (F.pins) until a submit has taken it.
+int fqtk_demuxer_fed_cut(fqtk_demuxer *home, uint32_t input, uint32_t n, fqtk_fed_window *out) {
+    if (!home || !out) return set_error(FQTK_EINVAL, "NULL argument");
+    if (!home->fed) return set_error(FQTK_EINVAL, "nothing has been fed");
+    if (input >= home->C.n_inputs) return set_error(FQTK_EINVAL, "input out of range");
+    if (n == 0 || n > home->max_chunk) return set_error(FQTK_EINVAL, "n_templates must be 1 .. max_chunk_templates");
+    FedInput &F = home->fed[input];
+    std::lock_guard<std::mutex> lk(F.mu);
+    const uint64_t l0 = F.lines_consumed, l1 = l0 + 4ull * n;   // the chunk's lines: [l0, l1); newline l1 - 1 ends the last one
+    if (l1 > F.lines_total) return set_error(FQTK_EINVAL, "fewer lines have been fed than the chunk takes");
+    // members that end before line l0 begins are done with (newline l0 - 1 is not theirs, nor any later one)
+    while (F.members.size() > 1 && l0 > 0 && F.members.front().lines_before + F.members.front().lines <= l0 - 1) F.members.pop_front();
+    const FedMember &first = F.members.front();
+    size_t k = 0;
+    while (F.members[k].lines_before + F.members[k].lines < l1) ++k;   // the member that holds newline l1 - 1
+    const FedMember &lastm = F.members[k];
+    const uint8_t *p = F.arena[F.cur].p + first.off;
+    const uint32_t lead = (uint32_t)(reinterpret_cast<uintptr_t>(p) & 15u);
+    out->home = home;
+    out->input = input;
+    out->lead = lead;
+    out->first_line = (uint32_t)(l0 - first.lines_before);
+    out->n_templates = n;
+    out->base = p - lead;
+    out->len = lead + (lastm.off + lastm.isize - first.off);
+    out->pos = first.pos - lead;   // (mod 2^64 for the first member: added back with the chunk's end_off)
+    F.lines_consumed = l1;
+    ++F.pins;
+    return FQTK_OK;
+}
+
+namespace {
+// Device `dev` reads `peer`'s memory directly over xGMI where the platform lets it (otherwise the runtime stages a peer copy through the host).
+void allow_peer(int dev, int peer) {
+    static std::mutex mu;
+    static std::vector<std::pair<int, int>> done;
+    std::lock_guard<std::mutex> lk(mu);
+    for (const auto &p : done) if (p.first == dev && p.second == peer) return;
+    done.emplace_back(dev, peer);
+    int can = 0;
+    if (hipDeviceCanAccessPeer(&can, dev, peer) == hipSuccess && can) (void)hipDeviceEnablePeerAccess(peer, 0);
+    (void)hipGetLastError();   // (already enabled: fine)
+}
+void unpin(const fqtk_fed_window &w) {
+    FedInput &F = w.home->fed[w.input];
+    {
+        std::lock_guard<std::mutex> lk(F.mu);
+        if (F.pins) --F.pins;
+    }
+    F.cv_pins.notify_all();
+}
+}  // namespace
+
+int fqtk_demuxer_submit_windows(fqtk_demuxer *d, int slot, const fqtk_fed_window *w, uint32_t n) {
+    if (!d || !w) return set_error(FQTK_EINVAL, "NULL argument");
+    if (slot < 0 || slot >= FQTK_DEMUX_SLOTS) return set_error(FQTK_EINVAL, "slot out of range");
+    const uint32_t n_inputs = d->C.n_inputs;
+    for (uint32_t i = 0; i < n_inputs; ++i) {
+        if (!w[i].home || !w[i].home->fed || w[i].input != i || w[i].n_templates != n || w[i].home->C.n_inputs != n_inputs)
+            return set_error(FQTK_EINVAL, "window i must be a cut of input i, of n_templates records, out of a demuxer of the same configuration");
+    }
+    DX_TRY(hipSetDevice(d->device));
+    if (d->slots[slot].busy) {
+        for (uint32_t i = 0; i < n_inputs; ++i) unpin(w[i]);
+        return set_error(FQTK_EINVAL, "slot is busy: call fqtk_demuxer_collect() first");
+    }
+    for (uint32_t i = 0; i < n_inputs; ++i) if (w[i].home->device != d->device) allow_peer(d->device, w[i].home->device);
+    Window win[FQTK_DEMUX_MAX_INPUTS];
+    uint64_t text_len[FQTK_DEMUX_MAX_INPUTS];
+    int rc;
+    {
+        // (a chunk run where some of its text lives: no arena of d's may change between here and the chunk's ev_fmt being recorded)
+        std::lock_guard<std::mutex> glk(d->fed_mu);
+        for (uint32_t i = 0; i < n_inputs; ++i) {
+            FedInput &F = w[i].home->fed[i];
+            const bool local = w[i].home == d;
+            {
+                std::lock_guard<std::mutex> lk(F.mu);
+                // the text may just have changed arena: behind that copy (another device's stream: its event is waited for here)
+                if (F.moved && local) DX_TRY(hipStreamWaitEvent(d->s_a, F.ev_moved, 0));
+                else if (F.moved) DX_TRY(hipEventSynchronize(F.ev_moved));
+            }
+            win[i].lead = w[i].lead;
+            win[i].first_line = w[i].first_line;
+            win[i].base = w[i].base;
+            win[i].copy_from = local ? nullptr : w[i].base;
+            win[i].copy_dev = w[i].home->device;
+            text_len[i] = w[i].len;
+            d->slots[slot].win_pos[i] = w[i].pos;
+        }
+        rc = submit_common(d, slot, nullptr, text_len, win, n);
+        if (rc == FQTK_OK) d->slots[slot].fed = true;
+    }
+    // windows of d's own text are covered by ev_last_fmt from here on; the others once their copies are done
+    bool remote = false;
+    for (uint32_t i = 0; i < n_inputs; ++i) remote = remote || w[i].home != d;
+    hipError_t e = hipSuccess;
+    if (rc == FQTK_OK && remote) e = hipEventSynchronize(d->slots[slot].ev_h2d1);
+    for (uint32_t i = 0; i < n_inputs; ++i) unpin(w[i]);
+    if (rc != FQTK_OK) return rc;
+    if (e != hipSuccess) return set_error(FQTK_EHIP, std::string("copy of a chunk's text between devices: ") + hipGetErrorString(e));
+    return FQTK_OK;
+}
+
 int fqtk_demuxer_submit_fed(fqtk_demuxer *d, int slot, uint32_t n) {
     if (!d) return set_error(FQTK_EINVAL, "NULL argument");
     if (!d->fed) return set_error(FQTK_EINVAL, "nothing has been fed");
+    if (slot < 0 || slot >= FQTK_DEMUX_SLOTS) return set_error(FQTK_EINVAL, "slot out of range");
+    if (d->slots[slot].busy) return set_error(FQTK_EINVAL, "slot is busy: call fqtk_demuxer_collect() first");
     if (n == 0 || n > d->max_chunk) return set_error(FQTK_EINVAL, "n_templates must be 1 .. max_chunk_templates");
-    std::lock_guard<std::mutex> glk(d->fed_mu);
-    Window win[FQTK_DEMUX_MAX_INPUTS];
-    uint64_t text_len[FQTK_DEMUX_MAX_INPUTS];
-    for (uint32_t i = 0; i < d->C.n_inputs; ++i) {
-        FedInput &F = d->fed[i];
-        std::lock_guard<std::mutex> lk(F.mu);
-        const uint64_t l0 = F.lines_consumed, l1 = l0 + 4ull * n;   // the chunk's lines: [l0, l1); newline l1 - 1 ends the last one
-        if (l1 > F.lines_total) return set_error(FQTK_EINVAL, "fewer lines have been fed than the chunk takes");
-        // members that end before line l0 begins are done with (newline l0 - 1 is not theirs, nor any later one)
-        while (F.members.size() > 1 && l0 > 0 && F.members.front().lines_before + F.members.front().lines <= l0 - 1) F.members.pop_front();
-        const FedMember &first = F.members.front();
-        size_t k = 0;
-        while (F.members[k].lines_before + F.members[k].lines < l1) ++k;   // the member that holds newline l1 - 1
-        const FedMember &lastm = F.members[k];
-        if (F.moved) DX_TRY(hipStreamWaitEvent(d->s_a, F.ev_moved, 0));   // the text may just have changed arena: behind that copy
-        const uint8_t *p = F.arena[F.cur].p + first.off;
-        const uint32_t lead = (uint32_t)(reinterpret_cast<uintptr_t>(p) & 15u);
-        win[i].base = p - lead;
-        win[i].lead = lead;
-        win[i].first_line = (uint32_t)(l0 - first.lines_before);
-        text_len[i] = lead + (lastm.off + lastm.isize - first.off);
-        d->slots[slot].win_pos[i] = first.pos - lead;   // (mod 2^64 for the first member: added back below)
-    }
-    const int rc = submit_common(d, slot, nullptr, text_len, win, n);
-    if (rc != FQTK_OK) return rc;
-    d->slots[slot].fed = true;
-    for (uint32_t i = 0; i < d->C.n_inputs; ++i) {
+    for (uint32_t i = 0; i < d->C.n_inputs; ++i) {   // (nothing is cut unless every input has the lines)
         std::lock_guard<std::mutex> lk(d->fed[i].mu);
-        d->fed[i].lines_consumed += 4ull * n;
+        if (d->fed[i].lines_consumed + 4ull * n > d->fed[i].lines_total) return set_error(FQTK_EINVAL, "fewer lines have been fed than the chunk takes");
     }
-    return FQTK_OK;
+    fqtk_fed_window w[FQTK_DEMUX_MAX_INPUTS];
+    for (uint32_t i = 0; i < d->C.n_inputs; ++i) {
+        const int rc = fqtk_demuxer_fed_cut(d, i, n, &w[i]);
+        if (rc != FQTK_OK) { for (uint32_t q = 0; q < i; ++q) unpin(w[q]); return rc; }
+    }
+    return fqtk_demuxer_submit_windows(d, slot, w, n);
 }
 
 // ---- serial gzip inputs (one member per file: gzip, bcl2fastq) decoded on the device in chunks ------------------------------
@@ -918,7 +1020,10 @@ int fqtk_demuxer_stream_scan(fqtk_demuxer *d, uint32_t input, const uint8_t *byt
     // room for the symbols: sym_per_byte per compressed byte of the stretch and a block's worth per chunk (the plan kernel shares it out
     // and never hands out more than there is)
     const uint32_t slack = 65536u;
-    const uint64_t sym_cap = stream_sym_cap(len, n_slots, sym_per_byte);
+    // (the 128 KiB the caller adds behind the last slot's bytes only let the last chunk run to its block's end: they get the base room, not sym_per_byte times it --
+    //  at 2048 symbols per byte that tail alone asked for half a gigabyte)
+    const uint64_t body = std::min<uint64_t>(len, (uint64_t)n_slots * chunk_bytes);
+    const uint64_t sym_cap = stream_sym_cap(body, n_slots, sym_per_byte) + (len - body) * std::min<uint32_t>(sym_per_byte, 8u);
     if ((rc = F.sym.ensure((size_t)sym_cap + 64)) != FQTK_OK) return rc;
     const auto t_alloc = std::chrono::steady_clock::now();
     DX_TRY(hipMemcpyAsync(F.comp.p, bytes, (size_t)len, hipMemcpyHostToDevice, F.stream));

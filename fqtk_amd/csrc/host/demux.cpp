@@ -20,6 +20,7 @@
 #include <sys/stat.h>
 #include <unistd.h>
 
+#include <algorithm>
 #include <atomic>
 #include <chrono>
 #include <condition_variable>
@@ -176,16 +177,17 @@ const char *kUsage =
     "  -c, --compression-level <N>                 [default: 5]\n"
     "  -S, --skip-reasons <REASON>...              too-few-bases\n"
     "      --device <N>                            GPU to use [default: 0] (additive flag)\n"
-    "      --devices <A,B,..>                      several GPUs: chunk k is matched on devices[k mod G] (additive flag).  Compressed inputs are\n"
-    "                                              then inflated by the host's reader threads (text that was inflated on one device lives there)\n"
+    "      --devices <A,B,..>                      several GPUs: chunk k is matched, formatted and compressed on devices[k mod G] (additive flag).\n"
+    "                                              Compressed inputs stay on the devices: every input is inflated on one of them (largest file first, to the\n"
+    "                                              least loaded), and a chunk's text goes from there to the chunk's device over xGMI\n"
     "      --chunk-reads <N>                       templates per GPU chunk [default: 262144; 131072 with --host-output] (additive flag)\n"
     "      --host-output                           parse, format and BGZF-compress the records on the host CPUs (as the\n"
     "                                              reference does) instead of on the GPU, which is the default: there the\n"
     "                                              inputs' text goes to the device, records are formatted and DEFLATE-compressed\n"
     "                                              in HBM and whole BGZF members come back (additive flag; alias --no-gpu-bgzf;\n"
     "                                              --gpu-bgzf is accepted and means the default)\n"
-    "      --host-inflate                          inflate compressed inputs on the host CPUs.  Without it, when every input is compressed and one\n"
-    "                                              device is used: BGZF members (bgzip, htslib, fqtk's own outputs) go to the device as they\n"
+    "      --host-inflate                          inflate compressed inputs on the host CPUs.  Without it, when every input is compressed:\n"
+    "                                              BGZF members (bgzip, htslib, fqtk's own outputs) go to the device as they\n"
     "                                              are, a wavefront each; serial gzip files (gzip, bcl2fastq), from 64 MB of them, in chunks of\n"
     "                                              64 KiB cut at DEFLATE block starts the device finds, windows handed down the chain; what cannot\n"
     "                                              be cut or decoded like that is decoded by a host thread -- any valid file is read (additive flag)\n"
@@ -531,8 +533,10 @@ bool gpu_output_supported(const Plan &plan, std::string *why) {
     }
     const uint32_t L = (uint32_t)samples[0].barcode.size();
 
-    // ---- BGZF inputs: their members go to the device compressed and are inflated there (fqtk_demuxer_feed), when every
-    // input is one and a single device takes all chunks (the fed text lives on one device)
+    // ---- BGZF inputs: their members go to a device compressed and are inflated there (fqtk_demuxer_feed), when every input is
+    // one.  With several devices every input has a HOME device -- the one that inflates it and keeps its text --, the chunks
+    // are cut out of the homes' texts in order and chunk k's windows are copied to device k mod G over xGMI where they are
+    // not at home there (include/fqtk_demux.h: fqtk_demuxer_fed_cut / fqtk_demuxer_submit_windows)
     std::vector<std::unique_ptr<BgzfFile>> bgzf_in;   // (the mapped file of every fed input, BGZF or serial gzip)
     std::vector<char> is_serial_gz(n_inputs, 0);
     // serial gzip inputs go to the device when asked for (--gpu-gunzip), or by themselves when there is enough of them for the chunks to
@@ -562,7 +566,7 @@ bool gpu_output_supported(const Plan &plan, std::string *why) {
             }
         }
     }
-    bool fed_mode = G == 1 && !opt.host_inflate && !env_on("FQTK_HOST_INFLATE");
+    bool fed_mode = !opt.host_inflate && !env_on("FQTK_HOST_INFLATE");
     size_t n_serial = 0;
     for (size_t i = 0; i < n_inputs && fed_mode; ++i) {
         const FastqSource::Kind kd = sources[i]->kind();
@@ -572,15 +576,30 @@ bool gpu_output_supported(const Plan &plan, std::string *why) {
         bgzf_in.push_back(std::make_unique<BgzfFile>());
         if (!bgzf_in.back()->open(opt.inputs[i], &e)) fed_mode = false;   // (a pipe: the reader threads inflate it)
     }
+    // the inputs' homes: largest file first, each to the device with the fewest bytes so far (one device: all on it)
+    std::vector<size_t> home_of(n_inputs, 0);
     if (!fed_mode) {
-        bool compressed = false;
-        for (size_t i = 0; i < n_inputs; ++i) compressed = compressed || sources[i]->kind() == FastqSource::Kind::Bgzf || sources[i]->kind() == FastqSource::Kind::Gzip;
-        if (G > 1 && compressed && !opt.host_inflate) info("%zu devices: compressed inputs are inflated by the host's reader threads.", G);
         bgzf_in.clear();
         n_serial = 0;
+    } else {
+        std::vector<size_t> order(n_inputs);
+        for (size_t i = 0; i < n_inputs; ++i) order[i] = i;
+        std::stable_sort(order.begin(), order.end(), [&](size_t a, size_t b) { return bgzf_in[a]->size > bgzf_in[b]->size; });
+        std::vector<uint64_t> load(G, 0);
+        for (size_t i : order) {
+            size_t best = 0;
+            for (size_t g = 1; g < G; ++g) if (load[g] < load[best]) best = g;
+            home_of[i] = best;
+            load[best] += (uint64_t)bgzf_in[i]->size + 1;
+        }
+        if (n_serial) info("gzip inputs: decoded on the device in chunks (BGZF members: one wavefront each).");
+        else info("BGZF inputs: members are inflated on the device.");
+        if (G > 1) {
+            std::string where;
+            for (size_t i = 0; i < n_inputs; ++i) where += (i ? ", " : "") + std::to_string(opt.devices[home_of[i]]);
+            info("%zu devices: input i is inflated on device [%s] and its text stays there; chunk k's text goes to device k mod %zu from device to device.", G, where.c_str(), G);
+        }
     }
-    else if (n_serial) info("gzip inputs: decoded on the device in chunks (BGZF members: one wavefront each).");
-    else info("BGZF inputs: members are inflated on the device.");
 
     // ---- devices: matcher + record pipeline each (their bring-up overlaps the first reads and the file creation)
     std::vector<fqtk_matcher *> matchers(G, nullptr);
@@ -829,14 +848,14 @@ bool gpu_output_supported(const Plan &plan, std::string *why) {
         }
     };
     // ---- this thread: cuts the stream of chunks, chunk k to device k mod G; every device's own thread submits its chunks
-    struct Job { size_t n = 0; uint64_t first_record = 0; std::vector<RawChunk> in; };
+    struct Job { size_t n = 0; uint64_t first_record = 0; std::vector<RawChunk> in; std::vector<fqtk_fed_window> win; };
     std::vector<uint64_t> fed_end(n_inputs, 0);   // (collector thread) fed text: where the last chunk collected left each input
     std::atomic<bool> first_submit{false};
     double t_first = 0;
     auto submit_chunk = [&](int g, int slot, uint64_t, Job &j) -> Flight {
         if (fed_mode) {
             const uint64_t th = tick();
-            if (fqtk_demuxer_submit_fed(demuxers[g], slot, (uint32_t)j.n) != FQTK_OK) die(std::string("GPU record pipeline: ") + fqtk_last_error());
+            if (fqtk_demuxer_submit_windows(demuxers[g], slot, j.win.data(), (uint32_t)j.n) != FQTK_OK) die(std::string("GPU record pipeline: ") + fqtk_last_error());
             g_times.main_handoff += tick() - th;
             Flight f;
             f.dev = g; f.slot = slot; f.n = (uint32_t)j.n; f.first_record = j.first_record;
@@ -887,6 +906,7 @@ bool gpu_output_supported(const Plan &plan, std::string *why) {
         for (size_t i = 0; i < n_inputs; ++i)
             readers.emplace_back([&, i] {
                 BgzfFile &bf = *bgzf_in[i];
+                fqtk_demuxer *const home = demuxers[home_of[i]];   // the device that inflates this input and keeps its text
                 void *pin = nullptr;
                 size_t pin_cap = 0;
                 std::vector<fqtk_inflate_member> run;
@@ -910,7 +930,10 @@ bool gpu_output_supported(const Plan &plan, std::string *why) {
                     static const long kForceFallback = env_num("FQTK_GZ_FORCE_FALLBACK", 0);     // (tests: every k-th stretch goes to the host's decoder)
                     static const uint64_t kSymBudget = (uint64_t)std::max<long>(1, env_num("FQTK_GZ_DEVICE_SYM_MB", 1024)) << 20;   // symbols a stretch may ask room for
                     const uint64_t gz_high_water = 4ull * chunk * (uint64_t)env_num("FQTK_GZ_DEVICE_AHEAD", 12);   // (a stretch is ~5 chunks of templates: one may decode while one is consumed)
-                    uint32_t sym_per_byte = (uint32_t)std::max<long>(1, std::min<long>(2048, env_num("FQTK_GZ_DEVICE_SYMS", 8)));   // room per compressed byte; grows when a chunk runs out
+                    const uint32_t sym_base = (uint32_t)std::max<long>(1, std::min<long>(2048, env_num("FQTK_GZ_DEVICE_SYMS", 8)));
+                    uint32_t sym_per_byte = sym_base;   // room per compressed byte: x4 when a chunk runs out, back down by halves after 4 stretches that fit (a run of poly-N
+                                                        // reads with constant qualities deflates 1000 : 1 for a megabyte; the rest of the file must not pay for it)
+                    size_t stretches_that_fit = 0;
                     size_t n_stretches = 0, n_chunks_total = 0, n_refused = 0, n_fallbacks = 0;
                     uint64_t fallback_text = 0;
                     size_t &pos = bf.pos;           // byte of the current member's header
@@ -918,6 +941,7 @@ bool gpu_output_supported(const Plan &plan, std::string *why) {
                     // (the first stretches are short: a quarter of a stretch holds the first chunk of templates, and the record pipeline starts that much sooner)
                     size_t ramp_slots = std::min<size_t>(kSlots, (size_t)std::max<long>(1, env_num("FQTK_GZ_DEVICE_FIRST_CHUNKS", 256)));
                     bool text_only = false;         // every chunk accepted so far decoded 7-bit text only: the search may insist on that (include/fqtk_demux.h)
+                    bool high_literals = false;     // ... and once a chunk of this input gave a code to a literal >= 128, it never does again
                     // The NEXT stretch's bytes are copied into a second page-locked buffer while the device decodes this one: a stretch whose
                     // chunks all count ends in its last chunk, so the next one lies in the file from there on (a stretch cut short by a false
                     // start is copied when it is known, as the first one is).
@@ -946,7 +970,7 @@ bool gpu_output_supported(const Plan &plan, std::string *why) {
                             //  stretch could go: FQTK_TIMING prints it.  Factor 1: 0.4 s there, the same steady rate.)
                             static const uint64_t kArenaFactor = (uint64_t)std::max<long>(1, env_num("FQTK_GZ_ARENA_FACTOR", 1));
                             const uint64_t arena = std::min<uint64_t>((ahead_text + stretch_bytes * 8u) * kArenaFactor + (64u << 20), (uint64_t)bf.size * 24u + (64u << 20));
-                            if (fqtk_demuxer_stream_reserve(demuxers[0], (uint32_t)i, stretch_bytes + 8, (uint32_t)kSlots, sym_per_byte, kSlots >= 64 ? arena : 0) != FQTK_OK) {
+                            if (fqtk_demuxer_stream_reserve(home, (uint32_t)i, stretch_bytes + 8, (uint32_t)kSlots, sym_per_byte, kSlots >= 64 ? arena : 0) != FQTK_OK) {
                                 fail(std::string("GPU record pipeline: ") + fqtk_last_error());
                                 return false;
                             }
@@ -995,7 +1019,7 @@ bool gpu_output_supported(const Plan &plan, std::string *why) {
                         auto host_stretch = [&](uint64_t until_bit, const char *why, bool *member_done) -> bool {
                             const uint64_t t0 = tick();
                             if (!seq) { seq = std::make_unique<RegionInflate>(); seq->attach(bf.map, bf.size); }
-                            if (!member_start && fqtk_demuxer_stream_window(demuxers[0], (uint32_t)i, win_before.data()) != FQTK_OK) {
+                            if (!member_start && fqtk_demuxer_stream_window(home, (uint32_t)i, win_before.data()) != FQTK_OK) {
                                 fail(std::string("GPU record pipeline: ") + fqtk_last_error());
                                 return false;
                             }
@@ -1003,7 +1027,8 @@ bool gpu_output_supported(const Plan &plan, std::string *why) {
                             uint64_t end_bit = 0;
                             bool final_block = false;
                             std::string e;
-                            if (!seq->run(verified, member_start ? nullptr : win_before.data(), until_bit, 256u << 20, &seq_text, &end_bit, &final_block, win_after.data(), &e)) {
+                            if (!seq->run(verified, member_start ? nullptr : win_before.data(), until_bit, 256u << 20, &seq_text, &end_bit, &final_block, win_after.data(), &e,
+                                          (size_t)std::min<uint64_t>(size_acc, 32768u))) {
                                 fail("Unexpected error parsing FASTQs: " + e + " in " + bf.path);
                                 return false;
                             }
@@ -1012,7 +1037,7 @@ bool gpu_output_supported(const Plan &plan, std::string *why) {
                             if (!ok) return false;
                             uint64_t fed = 0;
                             uint32_t crc = 0;
-                            if (fqtk_demuxer_stream_commit_text(demuxers[0], (uint32_t)i, seq_text.data(), seq_text.size(), final_block ? nullptr : win_after.data(), last ? 1 : 0, &fed, &crc) != FQTK_OK) {
+                            if (fqtk_demuxer_stream_commit_text(home, (uint32_t)i, seq_text.data(), seq_text.size(), final_block ? nullptr : win_after.data(), last ? 1 : 0, &fed, &crc) != FQTK_OK) {
                                 fail(std::string("GPU record pipeline: ") + fqtk_last_error());
                                 return false;
                             }
@@ -1069,7 +1094,7 @@ bool gpu_output_supported(const Plan &plan, std::string *why) {
                             const uint64_t tc1 = tick();
                             g_times.reader_parse += tc1 - t0;
                             uint32_t n_chunks = 0;
-                            if (fqtk_demuxer_stream_scan(demuxers[0], (uint32_t)i, stretch, bytes, verified - (uint64_t)b0 * 8u, (uint32_t)kChunkBytes, (uint32_t)n_slots,
+                            if (fqtk_demuxer_stream_scan(home, (uint32_t)i, stretch, bytes, verified - (uint64_t)b0 * 8u, (uint32_t)kChunkBytes, (uint32_t)n_slots,
                                                          to_end ? 1 : 0, sym_per_byte, text_only ? FQTK_STREAM_SCAN_TEXT : 0u, ends.data(), &n_chunks) != FQTK_OK) {
                                 fail(std::string("GPU record pipeline: ") + fqtk_last_error());
                                 return false;
@@ -1092,7 +1117,9 @@ bool gpu_output_supported(const Plan &plan, std::string *why) {
                                 break;
                             }
                             const bool more_room = out_of_room && sym_per_byte < 2048;
-                            if (more_room) sym_per_byte = std::min<uint32_t>(2048, sym_per_byte * 4);   // (the rest of the file is given more room)
+                            if (more_room) sym_per_byte = std::min<uint32_t>(2048, sym_per_byte * 4);   // (the next stretches are given more room)
+                            if (out_of_room) stretches_that_fit = 0;
+                            else if (sym_per_byte > sym_base && ++stretches_that_fit >= 4) { sym_per_byte = std::max(sym_base, sym_per_byte / 2); stretches_that_fit = 0; }
                             if (n_accept == 0) {
                                 // chunk 0 starts at a verified boundary and did not get through one block.  Out of room: again with more, while there
                                 // is more to give; anything else (no block start in the whole stretch and the block longer than it, a parse error):
@@ -1105,8 +1132,8 @@ bool gpu_output_supported(const Plan &plan, std::string *why) {
                                 if (!host_stretch(until, kWhat[std::min<uint32_t>(ends[0].status, 11)], &member_done)) return false;
                                 continue;
                             }
-                            text_only = !env_on("FQTK_GZ_NO_TEXT_FILTER");
-                            for (size_t k = 0; k < n_accept; ++k) if (ends[k].flags & FQTK_STREAM_END_HIGH_LITERALS) text_only = false;
+                            for (size_t k = 0; k < n_accept; ++k) if (ends[k].flags & FQTK_STREAM_END_HIGH_LITERALS) high_literals = true;
+                            text_only = !high_literals && !env_on("FQTK_GZ_NO_TEXT_FILTER");
                             const fqtk_stream_end &le = ends[n_accept - 1];
                             const uint64_t end_bit = (uint64_t)b0 * 8u + le.end_bit;
                             const bool final_block = le.status == 0 && le.final_block;
@@ -1115,7 +1142,7 @@ bool gpu_output_supported(const Plan &plan, std::string *why) {
                             if (!ok) return false;
                             uint64_t fed = 0, n_text = 0;
                             uint32_t crc = 0;
-                            if (fqtk_demuxer_stream_commit(demuxers[0], (uint32_t)i, (uint32_t)n_accept, member_start ? 1 : 0, last ? 1 : 0, &fed, &crc, &n_text) != FQTK_OK) {
+                            if (fqtk_demuxer_stream_commit(home, (uint32_t)i, (uint32_t)n_accept, member_start ? 1 : 0, last ? 1 : 0, &fed, &crc, &n_text) != FQTK_OK) {
                                 fail(std::string("GPU record pipeline: ") + fqtk_last_error());
                                 return false;
                             }
@@ -1159,7 +1186,10 @@ bool gpu_output_supported(const Plan &plan, std::string *why) {
                             fcv.notify_all();
                             fcv.wait(lk, [&] { return staged_inputs >= n_inputs; });
                         }
-                        if (!staged_ok) fail(std::string("cannot allocate page-locked memory: ") + fqtk_last_error());
+                        if (!staged_ok) {   // (after the barrier: the other feeders are not left waiting)
+                            fail(std::string("cannot allocate page-locked memory: ") + fqtk_last_error());
+                            return;
+                        }
                     }
                     for (;;) {
                         if (!BgzfFile::looks_like_bgzf(bf.map + bf.pos, bf.size - bf.pos)) {
@@ -1190,7 +1220,7 @@ bool gpu_output_supported(const Plan &plan, std::string *why) {
                         const bool last = !more_members();   // (what is no gzip member behind the last one is ignored, as zlib's gzread and the host path do)
                         uint64_t fed = 0;
                         const uint64_t t1 = tick();
-                        if (fqtk_demuxer_feed(demuxers[0], (uint32_t)i, static_cast<const uint8_t *>(run_pin), bytes, run.data(), (uint32_t)run.size(), last ? 1 : 0, &fed) != FQTK_OK) {
+                        if (fqtk_demuxer_feed(home, (uint32_t)i, static_cast<const uint8_t *>(run_pin), bytes, run.data(), (uint32_t)run.size(), last ? 1 : 0, &fed) != FQTK_OK) {
                             fail("Unexpected error parsing FASTQs: " + std::string(fqtk_last_error()) + " in " + bf.path);
                             break;
                         }
@@ -1236,7 +1266,7 @@ bool gpu_output_supported(const Plan &plan, std::string *why) {
                         if (left_lines < 4 || left_lines % 4) continue;
                         uint8_t last[16];
                         uint64_t have = 0;
-                        if (fqtk_demuxer_fed_tail(demuxers[0], (uint32_t)i, ~0ull, last, sizeof last, &have) != FQTK_OK) die(fqtk_last_error());
+                        if (fqtk_demuxer_fed_tail(demuxers[home_of[i]], (uint32_t)i, ~0ull, last, sizeof last, &have) != FQTK_OK) die(fqtk_last_error());
                         size_t q = (size_t)std::min<uint64_t>(have, sizeof last), newlines = 0;
                         while (q > 0 && (last[q - 1] == '\n' || last[q - 1] == '\r')) newlines += last[--q] == '\n';
                         // (four blank lines: four newlines with nothing but '\r' between them, behind the newline that ends the last record -- or the text's start)
@@ -1250,6 +1280,10 @@ bool gpu_output_supported(const Plan &plan, std::string *why) {
             Job j;
             j.n = n;
             j.first_record = records;
+            // the chunk's windows are cut HERE, in chunk order (the devices' threads submit in any order): where the next n records of every input lie at its home
+            j.win.resize(n_inputs);
+            for (size_t i = 0; i < n_inputs; ++i)
+                if (fqtk_demuxer_fed_cut(demuxers[home_of[i]], (uint32_t)i, (uint32_t)n, &j.win[i]) != FQTK_OK) die(std::string("GPU record pipeline: ") + fqtk_last_error());
             dispatch.push(std::move(j));
             records += n;
             {
@@ -1295,7 +1329,7 @@ bool gpu_output_supported(const Plan &plan, std::string *why) {
         std::vector<uint8_t> tail(1u << 20);
         for (size_t i = 0; i < n_inputs; ++i) {
             uint64_t left = 0;
-            if (fqtk_demuxer_fed_tail(demuxers[0], (uint32_t)i, records ? fed_end[i] : 0, tail.data(), tail.size(), &left) != FQTK_OK) die(fqtk_last_error());
+            if (fqtk_demuxer_fed_tail(demuxers[home_of[i]], (uint32_t)i, records ? fed_end[i] : 0, tail.data(), tail.size(), &left) != FQTK_OK) die(fqtk_last_error());
             const size_t have = (size_t)std::min<uint64_t>(left, tail.size());
             bool blank = true;
             size_t lines = 0;
@@ -1316,8 +1350,10 @@ bool gpu_output_supported(const Plan &plan, std::string *why) {
             }
             die("Unexpected error parsing FASTQs: truncated record at end of " + opt.inputs[i]);
         }
-        double inf_s = 0;
-        if (g_timing && fqtk_demuxer_inflate_seconds(demuxers[0], &inf_s) == FQTK_OK) info("device seconds inflating BGZF members: %.3f", inf_s);
+        for (size_t g = 0; g < G && g_timing; ++g) {
+            double inf_s = 0;
+            if (fqtk_demuxer_inflate_seconds(demuxers[g], &inf_s) == FQTK_OK) info("device %d: seconds inflating BGZF members / gzip chunks: %.3f", opt.devices[g], inf_s);
+        }
     }
     for (size_t g = 0; g < G; ++g) {   // what is left in the files' open blocks
         fqtk_demux_result r;

@@ -25,14 +25,18 @@ class RegionInflate : public FastInflate {
     // Decodes whole blocks from bit `from_bit` (a block boundary) until the first block boundary at or behind `until_bit`, or the
     // member's final block, or -- at a block boundary -- `max_text` bytes of text; a single block larger than that is decoded whole.
     // window: the 32 KiB of text in front of from_bit (window[32767] = the byte right before it); nullptr: the member starts here.
+    // window_valid: how many of them -- counted from the window's END -- the member really has in front of from_bit (a member that has
+    // decoded less than 32 KiB so far: the rest of the window is filler, and a distance that reaches into it is "too far back" here as
+    // in the streaming decoder, not a copy of zeros that fails the CRC much later: ADVICE r05).
     // text receives the bytes (appended); *end_bit the boundary reached, *final_block whether it ended the member;
     // window_after (32 KiB) the text in front of end_bit.  false: the stream is corrupt there (*err says how).
     bool run(uint64_t from_bit, const uint8_t *window, uint64_t until_bit, size_t max_text, std::vector<uint8_t> *text, uint64_t *end_bit, bool *final_block,
-             uint8_t *window_after, std::string *err) {
+             uint8_t *window_after, std::string *err, size_t window_valid = kWindow) {
         uint8_t *base = obuf_.data();
         if (window) {
-            std::memcpy(base, window, kWindow);
-            hist_ = kWindow;
+            const size_t valid = window_valid < kWindow ? window_valid : kWindow;
+            std::memcpy(base, window + (kWindow - valid), valid);
+            hist_ = valid;
         } else {
             hist_ = 0;
         }

@@ -158,6 +158,17 @@ class Demuxer:
     def submit_fed(self, slot: int, n_templates: int) -> None:
         _check(self._lib.fqtk_demuxer_submit_fed(self._h, slot, n_templates))
 
+    def fed_cut(self, input_index: int, n_templates: int):
+        """The next n_templates records of this demuxer's fed text of one input: a window any demuxer of the same configuration may run."""
+        w = _lib.fqtk_fed_window()
+        _check(self._lib.fqtk_demuxer_fed_cut(self._h, input_index, n_templates, C.byref(w)))
+        return w
+
+    def submit_windows(self, slot: int, windows, n_templates: int) -> None:
+        """One chunk out of windows[i] (a cut of input i at its home demuxer, fed_cut); windows of other demuxers are copied device to device."""
+        arr = (_lib.fqtk_fed_window * len(windows))(*windows)
+        _check(self._lib.fqtk_demuxer_submit_windows(self._h, slot, arr, n_templates))
+
     def collect_fed(self, slot: int):
         """(files, text_end per input) of a chunk of fed text."""
         res = _lib.fqtk_demux_result()

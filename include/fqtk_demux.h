@@ -126,6 +126,33 @@ int fqtk_demuxer_feed(fqtk_demuxer *d, uint32_t input, const uint8_t *bytes, uin
  * took.  The result's text_end says where each input's text was left. */
 int fqtk_demuxer_submit_fed(fqtk_demuxer *d, int slot, uint32_t n_templates);
 
+/* ---- fed text and several devices (`fqtk demux --devices a,b,..`, SURVEY.md 8e: chunk k runs on device k mod G) ------------
+ * Every input has ONE home demuxer: the one its compressed bytes are fed to (fqtk_demuxer_feed, fqtk_demuxer_stream_*), whose
+ * device inflates them and keeps the text.  Chunks of templates are cut out of that text IN ORDER -- one thread, input by
+ * input -- with fqtk_demuxer_fed_cut, and a cut chunk may then be run by ANY demuxer made with the same configuration
+ * (fqtk_demuxer_submit_windows, on that demuxer's own submit thread): a window whose home is the running demuxer is used
+ * where it lies, a window of another demuxer is copied device to device (xGMI between two devices) into the slot's own text
+ * buffer first -- the call returns when those copies are done.  A window stays valid, and holds its home's text in place,
+ * from the cut until the submit that takes it has returned; every window cut must be submitted exactly once.
+ * fqtk_demuxer_submit_fed(d, slot, n) is the cut of every input of d followed by the submit on d itself.
+ * (The reference's readers are per input and feed one loop, demux.rs:928-934,844-849: nothing ties an input's decoding to
+ *  the place its templates are matched and written from.) */
+typedef struct fqtk_fed_window {
+    fqtk_demuxer *home;      /* whose fed text this is */
+    uint32_t input;          /* which input's */
+    uint32_t lead;           /* bytes in front of the first member's text at base (base is 16-byte aligned) */
+    uint32_t first_line;     /* the chunk's first line is this line of the window */
+    uint32_t n_templates;    /* the cut's */
+    const uint8_t *base;     /* device address on home's device */
+    uint64_t len;            /* bytes of the window from base */
+    uint64_t pos;            /* position of base in the input's whole text */
+} fqtk_fed_window;
+/* The next n_templates records (4 n_templates lines) of `input`'s text fed to `home`.  FQTK_EINVAL when fewer lines have been fed. */
+int fqtk_demuxer_fed_cut(fqtk_demuxer *home, uint32_t input, uint32_t n_templates, fqtk_fed_window *out);
+/* One chunk on `slot` of d out of windows[0 .. n_inputs) (window i of input i, all cut with the same n_templates), as
+ * fqtk_demuxer_submit_fed.  The result's text_end says where each input's text was left. */
+int fqtk_demuxer_submit_windows(fqtk_demuxer *d, int slot, const fqtk_fed_window *windows, uint32_t n_templates);
+
 /* The fed text of `input` from position `pos` to its end (*n_bytes; the first min(*n_bytes, cap) of them in buf): what
  * lies behind the last record (end-of-file checks).  pos == ~0: the text's last min(cap, its length) bytes.  Only text no chunk has
  * consumed in full is still there. */

@@ -378,28 +378,105 @@ def test_fed_text_ends_like_the_host_path_ends_it_and_names_the_right_inputs(tmp
     assert r.returncode != 0 and "Read the:short:one x had too few bases to demux 3 vs. 11 needed" in r.stderr, r.stderr
 
 
-def test_several_devices_take_compressed_inputs_through_the_host_readers(tmp_path):
-    """text inflated on one device lives there, so `--devices a,b` (chunk k to device k mod G) inflates BGZF and
-    gzip inputs on the host's reader threads -- and says so.  Same outputs as one device, which inflates on the device."""
+def _device_lists():
+    """`--devices` values of the several-device tests: one GPU twice and three times (two / three record pipelines with their own
+    arenas, streams and submit threads on the same device: every code path but the xGMI hop itself), and the box's real devices when
+    it has more than one."""
+    import ctypes
+    lists = ["0,0", "0,0,0"]
+    try:
+        hip = ctypes.CDLL("libamdhip64.so")
+        n = ctypes.c_int(0)
+        if hip.hipGetDeviceCount(ctypes.byref(n)) == 0 and n.value > 1:
+            lists.append(",".join(str(d) for d in range(min(n.value, 4))))
+    except OSError:
+        pass
+    return lists
+
+
+def test_several_devices_keep_compressed_inputs_on_the_devices(tmp_path, monkeypatch):
+    """`--devices a,b` must not switch the device decoders off.  Every input has a home device that inflates it
+    (BGZF members, serial gzip chunks) and keeps its text; chunks are cut out of the homes' texts in order and chunk k's windows are
+    copied to device k mod G (fqtk_demuxer_fed_cut / fqtk_demuxer_submit_windows).  Same outputs and metrics as one device and as the
+    host's decoders -- also with arenas of 1 MB, where the text changes arena while windows of it are waiting for their device."""
     import gzip
     rng = np.random.default_rng(71)
     bcs = ["ACGTACGT", "TTGCAATG", "GGGGCCCC"]
-    n = 12_000
+    n = 24_000
     r1 = _records(n, rng, [100, 60], "r")
-    i1 = [(h, bcs[k % 3], "F" * 8) for k, (h, _, _) in enumerate(r1)]
-    f1 = _write_bgzf(tmp_path / "r1.fastq.gz", _text(r1))
+    i1 = [(h, bcs[k % 3] if rng.random() < 0.9 else "NNNNNNNN", "F" * 8) for k, (h, _, _) in enumerate(r1)]
+    r2 = [(h, b[:50], q[:50]) for h, b, q in _records(n, rng, [50], "r")]
+    f1 = _write_bgzf(tmp_path / "r1.fastq.gz", _text(r1, last_newline=False))
     f2 = str(tmp_path / "i1.fastq.gz")
     with open(f2, "wb") as fh:
         fh.write(gzip.compress(_text(i1), 6))
+    f3 = _write_bgzf(tmp_path / "r2.fastq.gz", _text(r2) + b"\n\n", member=3000)
     meta = _meta(tmp_path, bcs)
-    one = H.run_demux([f1, f2], ["+T", "8B"], meta, tmp_path / "one", threads=8, extra=["--chunk-reads", "2000", "--gpu-gunzip"])
+    monkeypatch.setenv("FQTK_GZ_DEVICE_CHUNK_KB", "16")
+    monkeypatch.setenv("FQTK_GZ_DEVICE_CHUNKS", "8")
+    base = ["--chunk-reads", "1000", "--gpu-gunzip"]
+    host = H.run_demux([f1, f2, f3], ["+T", "8B", "+T"], meta, tmp_path / "host", threads=8, extra=["--chunk-reads", "1000", "--host-inflate"])
+    assert host.returncode == 0, host.stderr
+    one = H.run_demux([f1, f2, f3], ["+T", "8B", "+T"], meta, tmp_path / "one", threads=8, extra=base)
     assert one.returncode == 0 and "decoded on the device in chunks" in one.stderr, one.stderr
-    two = H.run_demux([f1, f2], ["+T", "8B"], meta, tmp_path / "two", threads=8, extra=["--chunk-reads", "2000", "--devices", "0,0"])
-    assert two.returncode == 0, two.stderr
-    assert "inflated by the host's reader threads" in two.stderr and "on the device" not in two.stderr.split("inflated by the host")[1][:200]
-    a, b = _outputs(tmp_path / "one"), _outputs(tmp_path / "two")
-    assert a.keys() == b.keys() and all(a[k] == b[k] for k in a)
-    assert open(tmp_path / "one" / "demux-metrics.txt").read() == open(tmp_path / "two" / "demux-metrics.txt").read()
+    want, want_metrics = _outputs(tmp_path / "host"), open(tmp_path / "host" / "demux-metrics.txt").read()
+    a = _outputs(tmp_path / "one")
+    assert a.keys() == want.keys() and all(a[k] == want[k] for k in want)
+    for devs in _device_lists():
+        for arena_min in (None, "1000000"):
+            tag = "d" + devs.replace(",", "") + ("s" if arena_min else "")
+            monkeypatch.setenv("FQTK_FED_ARENA_MIN", arena_min) if arena_min else monkeypatch.delenv("FQTK_FED_ARENA_MIN", raising=False)
+            r = H.run_demux([f1, f2, f3], ["+T", "8B", "+T"], meta, tmp_path / tag, threads=8, extra=base + ["--devices", devs])
+            assert r.returncode == 0, r.stderr
+            assert "decoded on the device in chunks" in r.stderr and "host's reader threads" not in r.stderr, r.stderr
+            assert f"{len(devs.split(','))} devices: input i is inflated on device [" in r.stderr, r.stderr
+            b = _outputs(tmp_path / tag)
+            assert b.keys() == want.keys(), (devs, arena_min)
+            for k in want:
+                assert b[k] == want[k], (devs, arena_min, k)
+            assert open(tmp_path / tag / "demux-metrics.txt").read() == want_metrics
+    monkeypatch.delenv("FQTK_FED_ARENA_MIN", raising=False)
+    # BGZF inputs only
+    f2b = _write_bgzf(tmp_path / "i1b.fastq.gz", _text(i1), member=5000)
+    r = H.run_demux([f1, f2b, f3], ["+T", "8B", "+T"], meta, tmp_path / "bg", threads=8, extra=["--chunk-reads", "1500", "--devices", "0,0"])
+    assert r.returncode == 0 and "BGZF inputs: members are inflated on the device." in r.stderr, r.stderr
+    b = _outputs(tmp_path / "bg")
+    assert all(b[k] == want[k] for k in want) and open(tmp_path / "bg" / "demux-metrics.txt").read() == want_metrics
+
+
+def test_several_devices_report_what_one_device_reports(tmp_path):
+    """Damaged, short and truncated compressed inputs with `--devices 0,0`: the errors of one device (whatever device holds the text)."""
+    rng = np.random.default_rng(72)
+    bcs = ["ACGTACGT", "TTGCAATG"]
+    meta = _meta(tmp_path, bcs)
+    n = 6000
+    r1 = _records(n, rng, [80], "r")
+    i1 = [(h, bcs[i & 1], "F" * 8) for i, (h, _, _) in enumerate(r1)]
+    good1 = _write_bgzf(tmp_path / "r1.fastq.gz", _text(r1))
+    good2 = _write_bgzf(tmp_path / "i1.fastq.gz", _text(i1), member=5000)
+    extra = ["--chunk-reads", "1000", "--devices", "0,0"]
+    raw = bytearray(open(good1, "rb").read())
+    raw[len(raw) // 2] ^= 0x10
+    bad = str(tmp_path / "bad.fastq.gz")
+    open(bad, "wb").write(bytes(raw))
+    r = H.run_demux([bad, good2], ["+T", "8B"], meta, tmp_path / "o1", threads=8, extra=extra)
+    assert r.returncode != 0 and "corrupt BGZF block" in r.stderr, r.stderr
+    assert not list((tmp_path / "o1").glob("*.fq.gz"))
+    short = _write_bgzf(tmp_path / "short.fastq.gz", _text(i1[:n - 7]), member=5000)
+    r = H.run_demux([good1, short], ["+T", "8B"], meta, tmp_path / "o2", threads=8, extra=extra)
+    assert r.returncode != 0 and "out of sync" in r.stderr and "short.fastq.gz" in r.stderr, r.stderr
+    cut = _write_bgzf(tmp_path / "cut.fastq.gz", _text(r1)[:-60])
+    r = H.run_demux([cut, good2], ["+T", "8B"], meta, tmp_path / "o3", threads=8, extra=extra)
+    assert r.returncode != 0 and ("truncated record" in r.stderr or "out of sync" in r.stderr or "lengths differ" in r.stderr), r.stderr
+    # a read too short for its structure in the middle of the run: the message names the record (its text was saved by the chunk's device)
+    r1s = list(r1)
+    r1s[3500] = ("the:short:one x", "ACG", "FFF")
+    shorty = _write_bgzf(tmp_path / "shorty.fastq.gz", _text(r1s))
+    r = H.run_demux([shorty, good2], ["10M+T", "8B"], meta, tmp_path / "o4", threads=8, extra=extra)
+    assert r.returncode != 0 and "Read the:short:one x had too few bases to demux 3 vs. 11 needed" in r.stderr, r.stderr
+    r = H.run_demux([good1, good2], ["+T", "8B"], meta, tmp_path / "o5", threads=8, extra=extra)
+    assert r.returncode == 0 and "inflated on the device" in r.stderr, r.stderr
+    assert sum(len(v) for v in _outputs(tmp_path / "o5").values()) == n
 
 
 def test_damaged_gzip_streams_end_the_run_the_way_the_host_decoders_end_it(tmp_path, monkeypatch):

@@ -560,3 +560,72 @@ def test_chunks_that_run_out_of_room_end_at_a_block_boundary_and_the_stream_goes
         if final:
             break
     assert done == len(text) and seen_overflow >= 1
+
+
+@pytest.mark.parametrize("n_dev, member", [(2, 900), (3, 65280)])
+def test_fed_text_of_several_home_demuxers_runs_on_any_of_them(n_dev, member, monkeypatch):
+    """SURVEY 8e for compressed inputs (`fqtk demux --devices a,b,..`): input i is fed to its HOME demuxer (i mod G), chunks are cut out
+    of the homes' texts in order (fqtk_demuxer_fed_cut) and chunk k is run by demuxer k mod G (fqtk_demuxer_submit_windows), which
+    copies the windows that are not its own device to device.  G demuxers on ONE GPU here -- own arenas, streams and slots each --;
+    the files (every chunk ends its blocks: carry_blocks = 0) must hold what the same templates give as host text, in order, also while
+    the fed text changes arena every few feeds."""
+    monkeypatch.setenv("FQTK_FED_ARENA_MIN", "60000")
+    rng = np.random.default_rng(100 + n_dev)
+    structures, types = ["8B", "+T", "6M+T"], "TBM"
+    templates = make_templates(rng, 6000, BARCODES8, structures, header_kind=1)
+    texts = texts_of(templates, 0, len(templates), len(structures))
+    texts[1] = texts[1][:-1]
+    blobs = [_bgzf_of(t, member, rng) for t in texts]
+    ms = [BarcodeMatcher(BARCODES8, 1, 2, device=0) for _ in range(n_dev)]
+    ds = [Demuxer(m, structures, types, max_chunk_templates=500, carry_blocks=False) for m in ms]
+    home = [i % n_dev for i in range(len(blobs))]
+    starts = []
+    for b in blobs:
+        pos, s = 0, []
+        while pos < len(b):
+            s.append(pos)
+            pos += int.from_bytes(b[pos + 16:pos + 18], "little") + 1
+        starts.append(s + [len(b)])
+    at, fed, done = [0] * len(blobs), [0] * len(blobs), [False] * len(blobs)
+    files = [bytearray() for _ in range(ds[0].n_files)]
+    taken, k, pending, chunk = 0, 0, [], 500
+    while True:
+        for i, b in enumerate(blobs):
+            if not done[i] and fed[i] < 4 * (taken + 2 * chunk):
+                hi = min(at[i] + 7, len(starts[i]) - 1)
+                done[i] = hi == len(starts[i]) - 1
+                fed[i] = ds[home[i]].feed(i, b[starts[i][at[i]]:starts[i][hi]], last=done[i])
+                at[i] = hi
+        if not all(done[i] or fed[i] >= 4 * (taken + chunk) for i in range(len(blobs))):
+            continue
+        n = min(chunk, min(fed[i] // 4 - taken for i in range(len(blobs))))
+        if n <= 0:
+            break
+        # (cut and submitted at once: a window pins its home's text, and a feed of this same thread that had to move it would wait for
+        #  ever -- the CLI tests, where feeders and submitters are threads, hold windows across feeds)
+        wins = [ds[home[i]].fed_cut(i, n) for i in range(len(blobs))]
+        taken += n
+        if len(pending) == 3 * n_dev:
+            g, slot = pending.pop(0)
+            for c, x in enumerate(ds[g].collect_fed(slot)[0]):
+                files[c] += x
+        g, slot = k % n_dev, (k // n_dev) % 3
+        ds[g].submit_windows(slot, wins, n)
+        pending.append((g, slot))
+        k += 1
+    while pending:
+        g, slot = pending.pop(0)
+        for c, x in enumerate(ds[g].collect_fed(slot)[0]):
+            files[c] += x
+    for d in ds:
+        for c, x in enumerate(d.flush()):
+            files[c] += x
+    assert taken == len(templates) and k >= 12
+    want, counts, _ = expected_files(BARCODES8, 1, 2, structures, types, templates)
+    for c, w in enumerate(want):
+        assert gzip.decompress(bytes(files[c]) + H_BGZF_EOF) == w, f"file column {c}"
+    assert np.array_equal(sum(d.counts() for d in ds), counts)
+    # a window is a cut of ITS input, of the chunk's size
+    d0 = ds[0]
+    with pytest.raises(Exception, match="fewer lines|nothing has been fed"):
+        d0.fed_cut(0, 400)
