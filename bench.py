@@ -7,9 +7,12 @@ Workload at N=1: BASELINE.json configs[2] -- the config the north_star target is
 (6.4 GB of observed barcodes + 1.6 GB of results in HBM).  A "step" = one pass of the hot path
 (fqtk_matcher_assign_batch_device through the C ABI) over the rank's HBM-resident batch.
 
-`value` is scope K (inputs resident in HBM).  The same JSON line carries, never conflated
-with it: `scopes.B` (C ABI with pinned host buffers, PCIe inclusive), `scopes.E` (the `fqtk demux` binary,
+`value` is scope K (inputs resident in HBM; the line says `"scope": "K"`).  The same JSON line carries, never
+conflated with it: `scopes.B` (C ABI with pinned host buffers, PCIe inclusive), `scopes.E` (the `fqtk demux` binary,
 files -> files), `create_ms` (memo build at fqtk_matcher_create) and the CPU rows C1 / cache-off / all-cores.
+With N > 1 ranks (or FQTK_BENCH_DEVICES=a,b,.. on one rank: the same device may be named several times) rank 0 also runs
+scope B through one matcher per device and scope E through `fqtk demux --devices a,b,..` (plain and BGZF inputs): all three
+scopes per GPU count.
 
 Multi-GPU: reads shard across ranks with no data-path collective; the only collective is the final
 per-sample count all-reduce over RCCL.  `--scaling weak` (default): every rank owns a full batch;
@@ -399,6 +402,12 @@ def main() -> int:
             checked += m
         parity = f"bit-exact vs oracle on {checked} reads (3 windows of rank 0's shard)"
 
+    # the ranks are done with each other: the process group goes NOW, on every rank at once (rank 0 goes on alone with the scopes and
+    # the CPU rows, the others leave)
+    rccl_ranks = dist.get_world_size() if use_dist else 1
+    if use_dist:
+        dist.barrier()
+        dist.destroy_process_group()
     out = None
     if rank == 0:
         value = job_reads * args.steps / elapsed / 1e6
@@ -409,7 +418,7 @@ def main() -> int:
             "value": round(value, 2),
             "unit": "M reads/s",
             "n_gpus": world,
-            "rccl_ranks": dist.get_world_size() if use_dist else 1,   # the process group the counts were all-reduced over
+            "rccl_ranks": rccl_ranks,   # the process group the counts were all-reduced over
             "reads_per_step_per_rank": per_rank_reads,
             "steps": args.steps,
             "warmup": args.warmup,
@@ -454,7 +463,16 @@ def main() -> int:
                 "algorithmic_bytes_per_read": bytes_per_read,
             },
         }
-        if world == 1 and not args.no_scopes:
+        dev_list = list(range(world)) if world > 1 else None
+        if world == 1 and os.environ.get("FQTK_BENCH_DEVICES"):   # one rank, several record pipelines / matchers (a one-GPU box: "0,0")
+            dev_list = [int(x) for x in os.environ["FQTK_BENCH_DEVICES"].split(",")]
+        if dev_list is not None and len(dev_list) > 1 and not args.no_scopes:
+            # ---- scopes B and E over all the job's devices, from this one process (the other ranks are done with their GPUs) ----
+            import scope_bench
+            del d_obs, d_out
+            torch.cuda.empty_cache()
+            out["scopes"] = device_scopes(scope_bench, args, dev_list, workload, value, pool, host_cores)
+        elif world == 1 and not args.no_scopes:
             import scope_bench
             scopes = {"K": {"M_reads_per_s": round(value, 1), "what": "this line's `value`"}}
             del d_obs, d_out
@@ -486,27 +504,32 @@ def main() -> int:
                 scopes["E"] = scope_bench.scope_e(n_e, e_threads, args.e2e_gz, tmp, expect, repeat_first_block=rep)
                 scopes["E"]["host_cpus_usable"] = host_cores
                 if rep and not args.e2e_gz and n_e >= 4_000_000 and n_e % 4_000_000 == 0:
-                    # a quarter of the same inputs for the two slower rows: the reference's division of labour
-                    # (--host-output: host threads parse, format and libdeflate-compress) and single-stream gzip inputs
                     paths = [os.path.join(tmp, x) for x in ("R1.fastq", "I1.fastq", "I2.fastq", "R2.fastq")]
                     meta = os.path.join(tmp, "meta.tsv")
+                    # a quarter of the same inputs for the reference's division of labour (--host-output: host threads parse, format and
+                    # libdeflate-compress; 3 M templates/s)
                     sub = scope_bench.prefix_inputs(tmp, paths, 1, 4)
                     exp4 = None if expect is None else expect // np.uint64(4)
                     scopes["E_host"] = scope_bench.scope_e(n_e // 4, e_threads, False, tmp, exp4, extra_args=("--host-output",), inputs=(sub, meta))
                     scopes["E_host"]["host_cpus_usable"] = host_cores
-                    gz = scope_bench.gzip_single_stream(sub)
+                    shutil.rmtree(os.path.dirname(sub[0]), ignore_errors=True)
+                    # compressed inputs at the FULL size of row E (16 M-template runs are a second long and mostly start-up):
+                    # the same text as one gzip member per file and as BGZF; the plain files go first (scratch is RAM)
+                    gz = scope_bench.gzip_single_stream(paths)
+                    bgz = scope_bench.bgzf_repeated(paths)
+                    for q in paths:
+                        os.unlink(q)
                     # single-stream gzip inputs: decoded on the device in chunks (the default from 64 MB of .gz), and by the host's decoders
-                    scopes["E_gz"] = scope_bench.scope_e(n_e // 4, e_threads, True, tmp, exp4, inputs=(gz, meta))
+                    scopes["E_gz"] = scope_bench.scope_e(n_e, e_threads, True, tmp, expect, inputs=(gz, meta))
                     scopes["E_gz"]["host_cpus_usable"] = host_cores
                     scopes["E_gz"]["gz_inputs"] = ("one gzip member per file (level 1): block starts found on the device (a lane per bit position), chunks of 64 KiB decoded by a wavefront each without "
                                                    "their windows, windows and CRC-32 resolved on the device")
-                    scopes["E_gz_host"] = scope_bench.scope_e(n_e // 4, e_threads, True, tmp, exp4, extra_args=("--host-inflate",), inputs=(gz, meta), out_name="out_gzhost")
+                    scopes["E_gz_host"] = scope_bench.scope_e(n_e, e_threads, True, tmp, expect, extra_args=("--host-inflate",), inputs=(gz, meta), out_name="out_gzhost")
                     scopes["E_gz_host"]["host_cpus_usable"] = host_cores
                     scopes["E_gz_host"]["gz_inputs"] = "the same files decoded by several host threads per file (host/parallel_gunzip.hpp)"
                     # BGZF inputs (bgzip / htslib / fqtk's own outputs): the members cross PCIe compressed and are inflated on the
                     # device, one wavefront per member (include/fqtk_inflate.h, fqtk_demuxer_feed); the host never sees the text
-                    bgz = scope_bench.bgzf_repeated(sub)
-                    scopes["E_bgzf"] = scope_bench.scope_e(n_e // 4, e_threads, "bgzf", tmp, exp4, inputs=(bgz, meta))
+                    scopes["E_bgzf"] = scope_bench.scope_e(n_e, e_threads, "bgzf", tmp, expect, inputs=(bgz, meta))
                     scopes["E_bgzf"]["host_cpus_usable"] = host_cores
                     scopes["E_bgzf"]["gz_inputs"] = "BGZF (65 280-byte members, level 1), inflated on the device"
             finally:
@@ -519,8 +542,6 @@ def main() -> int:
     if pool is not None:
         pool.close()
         pool.join()
-    if use_dist:
-        dist.destroy_process_group()
     if rank == 0:
         # RCCL prints its version banner through C stdio, which is flushed at exit: push it out now so
         # that the JSON line is the LAST thing on stdout
@@ -528,6 +549,51 @@ def main() -> int:
         ctypes.CDLL(None).fflush(None)
         print(json.dumps(one_line(out)), flush=True)
     return 0
+
+
+def device_scopes(scope_bench, args, dev_list, workload, value_k, pool, host_cores):
+    """Scopes B and E with the job's devices (SURVEY.md 8e): B = one matcher, one host thread and two page-locked slots per device;
+    E = ONE `fqtk demux --devices a,b,..` process -- chunk k runs on device k mod G; plain inputs are read by the host's reader
+    threads, BGZF inputs are inflated on their home devices and go to the chunk's device over xGMI -- files to files, its metrics
+    file checked against the oracle's counts."""
+    devs = ",".join(str(d) for d in dev_list)
+    scopes = {"K": {"M_reads_per_s": round(value_k, 1), "what": "this line's `value`"}, "devices": devs}
+    scopes["B"] = scope_bench.scope_b_devices(args.config, dev_list, n_chunk=8_000_000, workload=workload)
+    n_e = args.e2e_templates
+    tmp = scope_bench.scratch_dir(n_e * 900)
+    try:
+        rep = n_e > 1_000_000 and n_e % 1_000_000 == 0
+        uniq = 1_000_000 if rep else n_e
+        expect = None
+        if pool is None and args.config == 3:
+            import multiprocessing as mp
+            from oracle import oracle as O
+            O.build(native=True)
+            pool = mp.get_context("spawn").Pool(max(1, min(32, host_cores)))
+            own_pool = True
+        else:
+            own_pool = False
+        if pool is not None and args.config == 3:
+            res = pool.map(_parity_worker, [(3, 1, 2, 0, lo, min(lo + 250_000, uniq), 0, None) for lo in range(0, uniq, 250_000)])
+            expect = sum((r[1] for r in res), np.zeros(385, dtype=np.uint64)) * np.uint64(n_e // uniq)
+        if own_pool:
+            pool.close()
+            pool.join()
+        e_threads = args.e2e_threads or max(5, min(32, host_cores))
+        scopes["E"] = scope_bench.scope_e(n_e, e_threads, False, tmp, expect, extra_args=("--devices", devs), repeat_first_block=rep)
+        scopes["E"]["host_cpus_usable"] = host_cores
+        if rep:
+            paths = [os.path.join(tmp, x) for x in ("R1.fastq", "I1.fastq", "I2.fastq", "R2.fastq")]
+            meta = os.path.join(tmp, "meta.tsv")
+            bgz = scope_bench.bgzf_repeated(paths)
+            for q in paths:
+                os.unlink(q)
+            scopes["E_bgzf"] = scope_bench.scope_e(n_e, e_threads, "bgzf", tmp, expect, extra_args=("--devices", devs), inputs=(bgz, meta))
+            scopes["E_bgzf"]["host_cpus_usable"] = host_cores
+            scopes["E_bgzf"]["gz_inputs"] = "BGZF (65 280-byte members, level 1): every input inflated on its home device, chunk k's text to device k mod G device to device"
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    return scopes
 
 
 def one_line(out: dict) -> dict:
@@ -543,6 +609,7 @@ def one_line(out: dict) -> dict:
         detail = None
     line = {k: out[k] for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
                                 "dtype", "data") if k in out}
+    line["scope"] = "K"   # what `value` is: barcodes resident in HBM, results left there (B and E: `scopes`)
     for k in ("rccl_ranks", "create_ms"):
         if k in out:
             line[k] = out[k]
@@ -575,6 +642,8 @@ def one_line(out: dict) -> dict:
             short["bgzf_kernel_GBps"] = sc["bgzf_kernel"].get("hbm", {}).get("GB_per_s_in")
         if "inflate_kernel" in sc:   # GB/s of text out (inflate_kernel + check alone)
             short["inflate_kernel_GBps"] = sc["inflate_kernel"].get("text_GBps")
+        if "devices" in sc:          # B and E* ran over these devices (N > 1 ranks, or FQTK_BENCH_DEVICES)
+            short["devices"] = sc["devices"]
         short["is"] = "B*: M reads/s host->host; E*: fqtk demux files->files [M templates/s wall, steady, M templates], counts = oracle's"
         line["scopes"] = short
     if detail:

@@ -30,10 +30,11 @@ def test_bench_line_carries_scopes_create_time_cpu_rows_and_the_full_parity_gate
     # the line fits the tail its consumer keeps, and carries every field of the contract and every scope as numbers
     assert len(line) < 2000, len(line)
     assert d["n_gpus"] == 1 and d["unit"] == "M reads/s" and d["value"] > 0 and d["higher_is_better"] is True and d["dtype"] == "u8"
+    assert d["scope"] == "K"   # what `value` is, next to it
     assert "bit-exact" in d["config"]["parity"] and "count vector of all 3000000 reads" in d["config"]["parity"]
     assert d["config"]["workload"].startswith("cfg3")
     assert set(d["scopes"]) == {"B", "B_packed", "bgzf_kernel_GBps", "inflate_kernel_GBps", "E", "E_host", "E_gz", "E_gz_host", "E_bgzf", "is"}
-    for k, n in (("E", 4), ("E_host", 1), ("E_gz", 1), ("E_gz_host", 1), ("E_bgzf", 1)):
+    for k, n in (("E", 4), ("E_host", 1), ("E_gz", 4), ("E_gz_host", 4), ("E_bgzf", 4)):   # the compressed-input rows at row E's size
         wall, steady, m = d["scopes"][k]
         assert m == n and wall > 0 and (steady is None or steady > 0)
     assert d["scopes"]["bgzf_kernel_GBps"] > 5 and d["scopes"]["inflate_kernel_GBps"] > 5 and d["scopes"]["B"] > 0 and d["scopes"]["B_packed"] > 0
@@ -50,7 +51,7 @@ def test_bench_line_carries_scopes_create_time_cpu_rows_and_the_full_parity_gate
     sc = full["scopes"]
     assert sc["bgzf_kernel"]["hbm"]["GB_per_s_in"] > 5 and 0.2 < sc["bgzf_kernel"]["hbm"]["ratio"] < 0.5
     assert sc["B_packed"]["M_reads_per_s"] > 0 and sc["B_packed"]["packed_bytes_per_read"] == 8
-    for k, n in (("E", 4000000), ("E_host", 1000000), ("E_gz", 1000000), ("E_gz_host", 1000000), ("E_bgzf", 1000000)):   # device output (default), host output, gzip inputs, BGZF inputs inflated on the device
+    for k, n in (("E", 4000000), ("E_host", 1000000), ("E_gz", 4000000), ("E_gz_host", 4000000), ("E_bgzf", 4000000)):   # device output (default), host output, gzip inputs, BGZF inputs inflated on the device
         assert sc[k]["templates"] == n and sc[k]["metrics_vs_oracle"] == "per-sample counts identical"
         assert sc[k]["peak_rss_MB"] > 0 and sc[k]["output_files"] == 771
     assert sc["E"]["M_templates_per_s_steady"] > 0 and sc["E_gz"]["M_templates_per_s_steady"] > 0
@@ -67,6 +68,22 @@ def test_rccl_path_with_one_rank_allreduced_counts_match_the_oracle():
     assert d["n_gpus"] == 1 and "count vector of all 4000000 reads" in d["config"]["parity"]
 
 
+def _check_device_scopes(d, devices):
+    """The N-device line carries all three scopes: K = value, B through one matcher per device, E through ONE
+    `fqtk demux --devices ..` process from plain and from BGZF inputs (inflated on the devices), counts = the oracle's."""
+    sc = d["scopes"]
+    assert sc["devices"] == devices and sc["B"] > 0
+    for k in ("E", "E_bgzf"):
+        wall, steady, m = sc[k]
+        assert m == 4 and wall > 0 and steady > 0
+    full = json.load(open(os.path.join(ROOT, d["detail"])))["scopes"]
+    assert full["B"]["devices"] == [int(x) for x in devices.split(",")]
+    for k in ("E", "E_bgzf"):
+        assert full[k]["extra_args"] == ["--devices", devices] and full[k]["metrics_vs_oracle"] == "per-sample counts identical"
+    assert any("inflated on the device" in t for t in full["E_bgzf"]["timeline"])
+    assert not any("host's reader threads" in t for t in full["E_bgzf"]["timeline"])
+
+
 @pytest.mark.gpu
 def test_gpus_n_launches_n_ranks_itself_or_refuses():
     import torch
@@ -74,13 +91,24 @@ def test_gpus_n_launches_n_ranks_itself_or_refuses():
     if have >= 2:
         for scaling in ("weak", "strong"):
             d = _line(_run(["--gpus", "2", "--reads", "4000000", "--steps", "2", "--warmup", "1", "--cpu-seconds", "0",
-                            "--scaling", scaling, "--parity", "full"]))
+                            "--scaling", scaling, "--parity", "full", "--e2e-templates", "4000000", "--e2e-threads", "8"]))
             assert d["n_gpus"] == 2 and d["scaling"] == scaling and len(d["roofline"]["kernel_ms_per_rank"]) == 2
             assert d["config"]["reads_per_step_whole_job"] == (8000000 if scaling == "weak" else 4000000)
             assert "count vector of all" in d["config"]["parity"]
+            _check_device_scopes(d, "0,1")
     else:
         r = _run(["--gpus", str(have + 1), "--reads", "1000000"])
         assert r.returncode == 2 and "refusing" in r.stderr and not r.stdout.strip()
+
+
+@pytest.mark.gpu
+def test_scopes_b_and_e_over_several_devices_from_one_rank():
+    """FQTK_BENCH_DEVICES=0,0: what rank 0 of an N > 1 job does for scopes B and E, on a one-GPU box (two matchers / two record
+    pipelines on the same device)."""
+    d = _line(_run(["--reads", "3000000", "--steps", "2", "--warmup", "1", "--cpu-seconds", "0", "--e2e-templates", "4000000", "--e2e-threads", "8"],
+                   env={"FQTK_BENCH_DEVICES": "0,0"}))
+    assert d["n_gpus"] == 1 and d["scope"] == "K"
+    _check_device_scopes(d, "0,0")
 
 
 def test_gpus_n_without_gpus_refuses_loudly_and_prints_no_json_line():

@@ -70,6 +70,79 @@ def scope_b(cfg_id=3, n_chunk=8_000_000, chunks=12, matcher=None, workload=None)
             "GB_per_s_over_pcie": round(reads * (cfg.stride + 4) / dt / 1e9, 2)}
 
 
+def scope_b_devices(cfg_id, devices, n_chunk=8_000_000, chunks=12, workload=None):
+    """Scope B over several devices ("report per-GPU-count reads/sec for all three scopes"): one matcher per entry of
+    `devices` (table replicated), each driven by its own host thread over its own two page-locked slots -- the reads are sharded,
+    nothing is exchanged.  All threads start together; reads of all devices / the time until the last one is done."""
+    import threading
+    cfg = synth.CONFIGS[cfg_id]
+    w = workload or synth.Workload(cfg)
+    lib = _lib.load()
+    G = len(devices)
+    ms = [BarcodeMatcher(w.barcodes, cfg.max_mismatches, cfg.min_mismatch_delta, device=d) for d in devices]
+    host = [w.fill_host(s * n_chunk, n_chunk) for s in range(2)]
+    bufs = []
+    for g in range(G):
+        per = []
+        for s in range(2):
+            po, pr = C.c_void_p(), C.c_void_p()
+            assert lib.fqtk_pinned_alloc(n_chunk * cfg.stride, C.byref(po)) == 0, _lib.last_error()
+            assert lib.fqtk_pinned_alloc(n_chunk * 4, C.byref(pr)) == 0, _lib.last_error()
+            C.memmove(po, host[s].ctypes.data, host[s].nbytes)
+            per.append((po, pr))
+        bufs.append(per)
+    errors = []
+
+    def one_pass(g, n_chunks, barrier):
+        try:
+            m = ms[g]
+            if barrier is not None:
+                barrier.wait()
+            for c in range(n_chunks):
+                s = c % 2
+                if c >= 2:
+                    assert lib.fqtk_matcher_wait(m.handle, s) == 0, _lib.last_error()
+                assert lib.fqtk_matcher_enqueue(m.handle, s, bufs[g][s][0], cfg.stride, None, n_chunk, bufs[g][s][1]) == 0, _lib.last_error()
+            for s in range(min(2, n_chunks)):
+                assert lib.fqtk_matcher_wait(m.handle, s) == 0, _lib.last_error()
+        except BaseException as e:   # noqa: BLE001 -- reported by the caller
+            errors.append(e)
+            if barrier is not None:
+                barrier.abort()
+
+    try:
+        for g in range(G):
+            one_pass(g, 2, None)   # warm-up (staging buffers are made on first use)
+        assert not errors, errors
+        dt = float("inf")
+        for _rep in range(3):
+            barrier = threading.Barrier(G + 1)
+            ts = [threading.Thread(target=one_pass, args=(g, chunks, barrier)) for g in range(G)]
+            for t in ts:
+                t.start()
+            barrier.wait()
+            t0 = time.perf_counter()
+            for t in ts:
+                t.join()
+            dt = min(dt, time.perf_counter() - t0)
+            assert not errors, errors
+        ref, _ = ms[0].assign_batch(w.fill_host(n_chunk, 100_000), counts=False)
+        for g in range(G):   # every device's results are the matcher's
+            got = np.ctypeslib.as_array(C.cast(bufs[g][1][1], C.POINTER(C.c_uint32)), (n_chunk,))[:100_000].copy()
+            assert np.array_equal(got, ref.view(np.uint32)), f"scope B results of device {devices[g]} differ from the synchronous path"
+    finally:
+        for per in bufs:
+            for po, pr in per:
+                lib.fqtk_pinned_free(po)
+                lib.fqtk_pinned_free(pr)
+        for m in ms:
+            m.close()
+    reads = n_chunk * chunks * G
+    return {"what": f"{G} matchers (devices {','.join(map(str, devices))}), a host thread and 2 pinned slots each: host SoA barcodes -> host results, PCIe inclusive",
+            "workload": cfg.name, "devices": list(devices), "reads": reads, "chunk_reads": n_chunk, "seconds": round(dt, 4),
+            "M_reads_per_s": round(reads / dt / 1e6, 1), "GB_per_s_over_pcie": round(reads * (cfg.stride + 4) / dt / 1e9, 2)}
+
+
 def scope_b_packed(cfg_id=3, n_chunk=8_000_000, chunks=12, matcher=None, workload=None, threads=0):
     """Scope B with 4 bits per base over the link (fqtk_pack_barcodes + fqtk_matcher_enqueue_packed).  The PACKER RUNS INSIDE
     THE CLOCK (a rate the box cannot feed is not a rate): every chunk's ASCII rows are packed by `threads` host
