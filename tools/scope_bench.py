@@ -325,7 +325,7 @@ def prefix_inputs(tmp, paths, frac_num, frac_den, sub="sub"):
 
 
 def _gzip_repeated(args):
-    path, block_bytes = args
+    path, block_bytes, reps = args
     import zlib as _z
     size = os.path.getsize(path)
     assert size % block_bytes == 0
@@ -333,7 +333,8 @@ def _gzip_repeated(args):
         block = fh.read(block_bytes)
     c = _z.compressobj(1, _z.DEFLATED, -15)
     body = c.compress(block) + c.flush(_z.Z_FULL_FLUSH)      # whole deflate blocks, byte-aligned, window reset: repeatable
-    reps = size // block_bytes
+    reps = reps or size // block_bytes
+    size = reps * block_bytes
     crc = 0
     for _ in range(reps):
         crc = _z.crc32(block, crc)
@@ -384,17 +385,18 @@ def bgzf_repeated(paths, block_records=1_000_000, reps=None):
         return list(ex.map(_bgzf_repeated, jobs))
 
 
-def gzip_single_stream(paths, block_records=1_000_000):
+def gzip_single_stream(paths, block_records=1_000_000, reps=None):
     """path -> path.gz: ONE gzip member per file (one serial DEFLATE stream, level 1, what `gzip -1` / bcl2fastq write)
     of a file that repeats its first block_records records: the block is compressed once and its deflate blocks are
-    repeated inside the stream, which takes seconds instead of the minute `gzip -1` needs for 12 GB."""
+    repeated inside the stream, which takes seconds instead of the minute `gzip -1` needs for 12 GB
+    (reps given: the file IS one block, and the stream holds it reps times)."""
     from concurrent.futures import ProcessPoolExecutor
     jobs = []
     for p in paths:
         with open(p, "rb") as fh:
             head = fh.read(1 << 16)
         rec = head.index(b"\n", head.index(b"\n", head.index(b"\n", head.index(b"\n") + 1) + 1) + 1) + 1   # fixed-width records
-        jobs.append((p, rec * block_records))
+        jobs.append((p, rec * block_records, reps))
     with ProcessPoolExecutor(4) as ex:
         return list(ex.map(_gzip_repeated, jobs))
 
