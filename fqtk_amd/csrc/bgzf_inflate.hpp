@@ -46,7 +46,13 @@
 namespace fqtk {
 namespace inflate {
 
-constexpr int kLitBits = 10, kDistBits = 8;
+#ifndef FQTK_INFLATE_LIT_BITS
+#define FQTK_INFLATE_LIT_BITS 9    // index bits of the literal/length table: 2 KiB of LDS; longer codes are resolved canonically when the chain meets one.
+                                   // (10 bits, 4 KiB, until round 6: 89 GB/s of text against 94 with 9 bits, 103 with 9 bits and six wavefronts a SIMD --
+                                   //  24 576 members, zlib -6, tools/ab_inflate.sh "-DFQTK_INFLATE_LIT_BITS=10"; profiles/r06_ab_inflate.txt)
+#endif
+constexpr int kLitBits = FQTK_INFLATE_LIT_BITS, kDistBits = 8;
+static_assert(kLitBits >= 8 && kLitBits <= 11, "the code-length code's 128-entry table and the member check's 256-entry CRC table share the literal table's room");
 #ifndef FQTK_INFLATE_SETS
 #define FQTK_INFLATE_SETS 2   // bit positions decoded per lane and window (1 or 2): tools/ab_inflate.sh "-DFQTK_INFLATE_SETS=1"
 #endif
@@ -114,7 +120,10 @@ struct Canon {
     uint16_t cnt[16];
 };
 
-// Everything a member's wavefront shares (LDS on the device: ~8.5 KiB, 16 wavefronts per CU).
+// Everything a member's wavefront shares (LDS on the device: 7.6 KiB -- how many wavefronts a CU holds is this number, and the decoder
+// lives on wavefronts in flight: every window is one long chain of dependent look-ups, a scalar walk and a round trip to memory).
+// The code-length code's table (a block header's business) lives in the literal table's room, which is built after it is done with;
+// so does the CRC table of the member check (fqtk_inflate.hip), which runs when the decoder is.
 struct Shared {
     uint32_t ring[kRingWords];
     uint32_t lit[1u << kLitBits];
@@ -123,7 +132,6 @@ struct Shared {
     uint16_t perm_l[288 + 32]; // symbols ordered by (code length, symbol)
     uint16_t perm_d[32];
     uint8_t lens[320 + 8];     // the block's code lengths: hlit literal/length ones, then hdist distance ones
-    uint32_t cl_tab[128];      // the code-length code: 7 index bits -> symbol << 16 | length (0: no such code)
     uint32_t own[64];          // per byte of the 64 being written: lane + 1 of a token that starts there
 };
 
@@ -346,6 +354,16 @@ FQTK_HD inline Token decode_token(const Shared &S, uint64_t bits) {
 // some distance entry it does not use) and the token's fields are selected at the end -- the 64 lanes decode 64 different
 // bit positions, so every branch of a branchy version is taken by somebody and costs the wave its full length.
 // 32 bits of a 64-bit window from bit s < 32 on: one v_alignbit_b32 (a 64-bit shift is two to four times a 32-bit instruction)
+// A value the optimiser must take as it is HERE (device builds): work that hangs on it stays in the branch that asks for it.
+FQTK_HD inline uint64_t opaque64(uint64_t v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    uint32_t lo = (uint32_t)v, hi = (uint32_t)(v >> 32);
+    asm volatile("" : "+v"(lo), "+v"(hi));
+    return (uint64_t)lo | ((uint64_t)hi << 32);
+#else
+    return v;
+#endif
+}
 FQTK_HD inline uint32_t funnel32(uint32_t hi, uint32_t lo, uint32_t s) {
 #if defined(__HIP_DEVICE_COMPILE__)
     return __builtin_amdgcn_alignbit(hi, lo, s);
@@ -421,12 +439,13 @@ FQTK_UNROLL
         code = (code + ctot[l]) << 1;
     }
     if (over) return kErrCodeLengths;
-    S.cl_tab[lane] = 0u;
-    S.cl_tab[lane + 64u] = 0u;
+    uint32_t *const cl_tab = S.lit;   // the code-length code: 7 index bits -> symbol << 16 | length (0: no such code); 128 entries of the literal table's room
+    cl_tab[lane] = 0u;
+    cl_tab[lane + 64u] = 0u;
     w.barrier();
     if (my_cl_len) {
         const uint32_t rev = brev32(my_code) >> (32u - my_cl_len);
-        for (uint32_t k = rev; k < 128u; k += 1u << my_cl_len) S.cl_tab[k] = (lane << 16) | my_cl_len;
+        for (uint32_t k = rev; k < 128u; k += 1u << my_cl_len) cl_tab[k] = (lane << 16) | my_cl_len;
     }
     w.barrier();
     // the hlit + hdist code lengths, run-length coded: a serial chain, every lane follows it
@@ -435,7 +454,7 @@ FQTK_UNROLL
     while (i < total) {
         ring.ensure(w, S, a, bit);
         const uint32_t b = w.uniform(peek32(w, S, bit));
-        const uint32_t e = w.uniform(S.cl_tab[b & 127u]);
+        const uint32_t e = w.uniform(cl_tab[b & 127u]);
         const uint32_t l = e & 0xFFu;
         if (l == 0u) return kErrCodeLengths;
         const uint32_t sym = e >> 16;
@@ -624,7 +643,10 @@ FQTK_HD inline uint32_t inflate_member(W &w, Shared &S, const MemberArgs &a, Str
                         FQTK_UNROLL
                         for (uint32_t q = 0; q < kSets; ++q) {
                             if ((slow[q] >> lane) & 1ull) {
-                                t[q] = decode_token<true>(S, bits[q]);
+                                // (opaque: the canonical look-up -- fourteen compares per code -- depends on nothing the walk changes, and the
+                                //  compiler otherwise computes it for every lane of EVERY window in front of the walk: ~90 of a window's ~300
+                                //  vector instructions for a path one window in hundreds takes)
+                                t[q] = decode_token<true>(S, opaque64(bits[q]));
                                 meta[q] = t[q].flags & (kTokBad | kTokEob) ? 0x80u : t[q].nbits;
                             }
                             slow[q] = 0;
@@ -645,11 +667,41 @@ FQTK_HD inline uint32_t inflate_member(W &w, Shared &S, const MemberArgs &a, Str
                 for (uint32_t q = 0; q < kSets; ++q) {
                     mine[q] = ((chain[q] >> lane) & 1ull) != 0ull;
                     my_out[q] = mine[q] ? t[q].outlen : 0u;
-                    const uint32_t incl = w.scan_incl(my_out[q]);
-                    my_pos[q] = out_pos + produced + incl - my_out[q];
-                    produced += w.readlane(incl, 63u);
+                }
+                if (kSets == 2) {
+                    // both sets' prefix sums in ONE scan: a token makes 258 bytes at most, 64 of them 16 512 -- sixteen bits a set
+                    const uint32_t incl = w.scan_incl(my_out[0] | (my_out[kSets - 1] << 16));
+                    const uint32_t tot = w.readlane(incl, 63u), tot0 = tot & 0xFFFFu;
+                    my_pos[0] = out_pos + (incl & 0xFFFFu) - my_out[0];
+                    my_pos[kSets - 1] = out_pos + tot0 + (incl >> 16) - my_out[kSets - 1];
+                    produced = tot0 + (tot >> 16);
+                } else {
+                    const uint32_t incl = w.scan_incl(my_out[0]);
+                    my_pos[0] = out_pos + incl - my_out[0];
+                    produced = w.readlane(incl, 63u);
                 }
                 if (out_pos + produced > a.isize) return kErrOutput;
+                // ---- a window of literals only (most windows of text: bases, qualities): every token is one byte, the prefix sum says
+                // where -- a lane per token stores it, and the machinery below (owners, sources, pointer doubling: ~70 vector
+                // instructions per 64 bytes) is for the windows that hold a match
+                {
+                    bool match_here = false;
+                    FQTK_UNROLL
+                    for (uint32_t q = 0; q < kSets; ++q) match_here = match_here || (mine[q] && (t[q].flags & kTokMatch) != 0u);
+                    if (!w.ballot(match_here)) {
+                        FQTK_UNROLL
+                        for (uint32_t q = 0; q < kSets; ++q) {
+#ifndef FQTK_INFLATE_ABL_NOSTORE
+                            if (my_out[q]) { if (kStream) a.out_sym[my_pos[q]] = (uint16_t)t[q].value; else a.out[my_pos[q]] = (uint8_t)t[q].value; }
+#endif
+                        }
+                        out_pos += produced;
+                        bit += cur;
+                        if (eob) break;
+                        if (bit > end_bit) return kErrTruncated;
+                        continue;
+                    }
+                }
                 // ---- the window's bytes, 64 at a time, one lane per BYTE (not per token): who owns the byte (the last token that
                 // starts at or before it: a prefix maximum over the tokens' starting places), what it is (the owner's literal, or
                 // the byte `distance` back -- in memory already, or another byte of these 64, reached by pointer doubling), one

@@ -51,11 +51,13 @@ struct DeviceWave {
     __device__ inline void fence_global() const { __threadfence_block(); }
 };
 
-#ifdef FQTK_INFLATE_WAVES   // (tools/ab_inflate.sh "-DFQTK_INFLATE_WAVES=5": registers capped so that that many wavefronts fit a SIMD)
-#define FQTK_INFLATE_OCCUPANCY __attribute__((amdgpu_waves_per_eu(FQTK_INFLATE_WAVES, FQTK_INFLATE_WAVES)))
-#else
-#define FQTK_INFLATE_OCCUPANCY
+// Wavefronts per SIMD the decoders are compiled for (registers capped at 512 / that; tools/ab_inflate.sh "-DFQTK_INFLATE_WAVES=5").  A window of
+// the decoder is one chain of dependent LDS look-ups, a scalar walk and, where a match reaches back, a round trip to memory: what keeps a
+// SIMD busy is other wavefronts.  Six fit since round 6 (5.8 KB of LDS a wavefront, 80 registers); seven spill nothing but measure 3 % lower.
+#ifndef FQTK_INFLATE_WAVES
+#define FQTK_INFLATE_WAVES 6
 #endif
+#define FQTK_INFLATE_OCCUPANCY __attribute__((amdgpu_waves_per_eu(FQTK_INFLATE_WAVES, FQTK_INFLATE_WAVES)))
 // CRC-32 (RFC 1952 8.) and newline count of the text a wavefront has just written, by that wavefront: lane k takes the k-th of 64 slices
 // (whole 16-byte pieces of the dword-aligned stream; the bytes come back out of the L2 they were written to a moment ago), byte by byte through
 // the table in LDS, and the slices' values -- each multiplied by x^(8 * bytes behind it) -- XOR to the member's (bgzf_deflate.hpp: crc_gf_mul; the
@@ -104,15 +106,8 @@ __device__ inline void wave_crc_and_lines(const uint8_t *text, uint32_t isize, c
 __global__ __launch_bounds__(64) FQTK_INFLATE_OCCUPANCY void inflate_kernel(const uint8_t *in, uint64_t in_len, const fqtk_inflate_member *members, uint32_t n,
                                                       uint8_t *out, uint32_t *status, uint32_t *lines, const uint32_t *crc_pow) {
     __shared__ Shared S;
-    __shared__ uint32_t crc_tab[256];
     const uint32_t j = blockIdx.x;
     if (j >= n) return;
-    for (uint32_t k = threadIdx.x; k < 256u; k += 64u) {
-        uint32_t c = k;
-#pragma unroll
-        for (int b = 0; b < 8; ++b) c = (c & 1u) ? (c >> 1) ^ 0xEDB88320u : (c >> 1);
-        crc_tab[k] = c;
-    }
     const fqtk_inflate_member m = members[j];
     uint32_t st, nl = 0;
     if (m.isize > FQTK_INFLATE_MAX_ISIZE || m.payload_off > in_len || (uint64_t)m.payload_len > in_len - m.payload_off) {
@@ -134,6 +129,14 @@ __global__ __launch_bounds__(64) FQTK_INFLATE_OCCUPANCY void inflate_kernel(cons
             uint32_t crc = 0;
             if (m.isize) {
                 __threadfence_block();           // (the stores of the last rounds: visible to this wave's loads)
+                __syncthreads();
+                uint32_t *const crc_tab = S.lit; // (the decoder is done with its tables: the CRC's 256 entries take their room)
+                for (uint32_t k = threadIdx.x; k < 256u; k += 64u) {
+                    uint32_t c = k;
+#pragma unroll
+                    for (int b = 0; b < 8; ++b) c = (c & 1u) ? (c >> 1) ^ 0xEDB88320u : (c >> 1);
+                    crc_tab[k] = c;
+                }
                 __syncthreads();
                 wave_crc_and_lines(out + m.out_off, m.isize, crc_tab, crc_pow, &crc, &nl);
             }
@@ -206,7 +209,7 @@ constexpr size_t kCheckLds = (264 + 256 * kSliceStride) * sizeof(uint32_t);
 // ---- a serial gzip stream in chunks (stream mode of inflate_member; host/parallel_gunzip.hpp is the CPU form of the same plan) -----
 // One wavefront per chunk: from the chunk's block boundary to the first block boundary at or behind the next chunk's, 16-bit symbols out.
 // (plan != nullptr: the chunks were cut on the device, stream_plan_kernel says how many there are)
-__global__ __launch_bounds__(64) void stream_kernel(const uint8_t *in, uint64_t in_len, const StreamChunk *chunks, uint32_t n, const StreamPlan *plan, uint16_t *sym,
+__global__ __launch_bounds__(64) FQTK_INFLATE_OCCUPANCY void stream_kernel(const uint8_t *in, uint64_t in_len, const StreamChunk *chunks, uint32_t n, const StreamPlan *plan, uint16_t *sym,
                                                     StreamChunkEnd *ends) {
     __shared__ Shared S;
     __shared__ StreamEnd end;

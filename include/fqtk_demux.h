@@ -110,7 +110,8 @@ int fqtk_demuxer_text_done(fqtk_demuxer *d, int slot);
 /* ---- BGZF inputs inflated on the device (the input side of demux.rs:844-849) --------------------------------------------
  * Instead of text the host may hand over the BGZF members of every input as they lie in the file (fqtk_inflate.h says
  * what a member is): their text is inflated on the device, checked against the members' CRC-32 / ISIZE, and stays there;
- * a chunk is cut out of it by line counts, so the host never sees the text.  A run either feeds or submits text.
+ * a chunk is cut out of it by line counts, so the host never sees the text.  A run either feeds or submits text.  (Several
+ * devices: every input is fed to ONE demuxer, see fqtk_demuxer_fed_cut below.)
  *
  * fqtk_demuxer_feed: `bytes` (len of them, page-locked for a fast copy) hold n_members members of input `input` in file
  * order (members[j].payload_off is relative to bytes; out_off is ignored).  Blocks until they are inflated -- other
