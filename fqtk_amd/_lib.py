@@ -43,7 +43,7 @@ class fqtk_stream_end(C.Structure):
 # include/fqtk_demux.h
 class fqtk_fed_window(C.Structure):   # a cut of an input's fed text (fqtk_demuxer_fed_cut -> fqtk_demuxer_submit_windows)
     _fields_ = [("home", C.c_void_p), ("input", C.c_uint32), ("lead", C.c_uint32), ("first_line", C.c_uint32), ("n_templates", C.c_uint32),
-                ("base", C.c_void_p), ("len", C.c_uint64), ("pos", C.c_uint64)]
+                ("base", C.c_void_p), ("len", C.c_uint64), ("pos", C.c_uint64), ("arena", C.c_uint32), ("reserved", C.c_uint32)]
 
 
 class fqtk_demux_segment(C.Structure):

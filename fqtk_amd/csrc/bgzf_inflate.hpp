@@ -498,12 +498,15 @@ template <class W>
 FQTK_HD inline uint32_t find_block_start(W &w, Shared &S, const MemberArgs &a, uint32_t from_bit, uint32_t limit_bit, bool low_literals_only = false) {
     const uint32_t lane = w.lane();
     const uint32_t end_bit = a.first_bit + a.payload_bits;
+    // The bits come through the ring in LDS, 64 dwords a refill, like the decoder's (until round 6 every lane fetched its four dwords from
+    // memory for every 64 positions: a round trip to the L2 per step, 5 ms of a 1023-chunk stretch's 20).
     Ring<W> ring;
-    ring.filled = 0; ring.pref = 0;
+    ring.reset(w, a, from_bit);
     for (uint32_t t0 = from_bit; t0 < limit_bit; t0 += 64u) {
+        ring.ensure(w, S, a, t0);   // dwords up to (t0 >> 5) + 7: lane 63 reads (t0 + 63 >> 5) + 3
         const uint32_t t = t0 + lane, d = t >> 5, s = t & 31u;
-        const uint64_t lo = (uint64_t)ring.load(w, a, d) | ((uint64_t)ring.load(w, a, d + 1u) << 32);
-        const uint64_t hi = (uint64_t)ring.load(w, a, d + 2u) | ((uint64_t)ring.load(w, a, d + 3u) << 32);
+        const uint64_t lo = (uint64_t)S.ring[d & (kRingWords - 1u)] | ((uint64_t)S.ring[(d + 1u) & (kRingWords - 1u)] << 32);
+        const uint64_t hi = (uint64_t)S.ring[(d + 2u) & (kRingWords - 1u)] | ((uint64_t)S.ring[(d + 3u) & (kRingWords - 1u)] << 32);
         const uint64_t b = s ? (lo >> s) | (hi << (64u - s)) : lo;   // bits t .. t + 63
         const uint64_t c = hi >> s;                                   // bits t + 64 .. (32 of them at least)
         const uint32_t hclen = ((uint32_t)(b >> 13) & 15u) + 4u;
@@ -534,6 +537,8 @@ FQTK_UNROLL
             if (!err) err = build_code<W, true, false>(w, S, S.lens, hlit);
             if (!err) err = build_code<W, false, false>(w, S, S.lens + hlit, hdist);
             if (!err) return t0 + cand;
+            ring.reset(w, a, t0);      // (the header's parse moved the ring: back to the search's place)
+            ring.ensure(w, S, a, t0);
         }
     }
     return 0xFFFFFFFFu;

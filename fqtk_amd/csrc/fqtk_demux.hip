@@ -118,6 +118,8 @@ struct FedInput {
     PinBuf<fqtk_inflate_member> h_members;
     hipStream_t stream = nullptr;
     hipEvent_t ev_moved = nullptr;      // behind the copy of the last change of arena (chunks cut afterwards wait for it)
+    hipEvent_t ev_reader[2] = {};       // per arena: behind the formatting of the latest chunk that runs on a window of it where it lies (the home's own chunks)
+    bool has_reader[2] = {false, false};
     hipEvent_t ev_t0 = nullptr, ev_t1 = nullptr;   // around a feed's kernels
     bool moved = false;
     int cur = 0;
@@ -154,6 +156,13 @@ constexpr uint64_t kFedSlack = 256;     // bytes kept free behind the text (the 
 
 __global__ void k_put_newline(uint8_t *p) { *p = 0x0A; }
 
+// Text from one arena to the other, 16 bytes a lane and step (both addresses 16-byte aligned).  A kernel, not hipMemcpyAsync: the runtime gives a
+// device-to-device copy inside ONE device to a DMA engine, which moved the 2 GB a serial gzip input has live at 25-30 GB/s -- 70-80 ms in which
+// the input's stream did nothing else, every fifth stretch (FQTK_TIMING, round 6); the CUs move it at the memory's rate.
+__global__ __launch_bounds__(256) void k_copy16(uint4 *dst, const uint4 *src, uint64_t n16) {
+    for (uint64_t i = (uint64_t)blockIdx.x * 256u + threadIdx.x; i < n16; i += (uint64_t)gridDim.x * 256u) dst[i] = src[i];
+}
+
 }  // namespace
 
 struct fqtk_demuxer {
@@ -179,7 +188,6 @@ struct fqtk_demuxer {
     std::mutex init_mu, stat_mu;
     std::atomic<uint64_t> chunks_submitted{0};
     uint32_t *d_crc_pow = nullptr;
-    hipEvent_t ev_last_fmt = nullptr;   // ev_fmt of the latest chunk submitted (recorded again on stream A)
     double inflate_s = 0;
     bool dynamic_blocks = false;        // FQTK_DYNAMIC_BLOCKS=1 (A/B runs): the compressor's workgroups share the blocks out with a counter instead of
                                         // round robin (measured with decoder wavefronts on the CUs: 14.3 vs 16.9 M templates/s steady from gzip inputs, 45.0 vs 47.2 from text)
@@ -398,7 +406,6 @@ int fqtk_demuxer_create(fqtk_matcher *m, const fqtk_demux_config *cfg, fqtk_demu
         const int rc = alloc_slot_fixed(d, s);
         if (rc != FQTK_OK) return bail(rc);
     }
-    if (hipEventCreate(&d->ev_last_fmt) != hipSuccess) return bail(set_error(FQTK_EHIP, "hipEventCreate"));
     *out = d;
     return FQTK_OK;
 }
@@ -424,7 +431,7 @@ void fqtk_demuxer_destroy(fqtk_demuxer *d) {
         for (uint32_t i = 0; i < d->C.n_inputs; ++i) {
             FedInput &F = d->fed[i];
             if (F.stream) { (void)hipStreamSynchronize(F.stream); (void)hipStreamDestroy(F.stream); }
-            for (hipEvent_t e : {F.ev_moved, F.ev_t0, F.ev_t1}) if (e) (void)hipEventDestroy(e);
+            for (hipEvent_t e : {F.ev_moved, F.ev_t0, F.ev_t1, F.ev_reader[0], F.ev_reader[1]}) if (e) (void)hipEventDestroy(e);
             F.arena[0].release(); F.arena[1].release(); F.comp.release(); F.d_members.release(); F.d_status.release(); F.d_lines.release();
             F.h_status.release(); F.h_lines.release(); F.h_members.release();
             F.sym.release(); F.windows.release(); F.maps.release(); F.d_chunks.release(); F.d_ends.release(); F.d_out_off.release(); F.d_crc.release();
@@ -437,7 +444,6 @@ void fqtk_demuxer_destroy(fqtk_demuxer *d) {
         delete[] d->fed;
     }
     if (d->d_crc_pow) (void)hipFree(d->d_crc_pow);
-    if (d->ev_last_fmt) (void)hipEventDestroy(d->ev_last_fmt);
     if (d->d_persist) (void)hipFree(d->d_persist);
     if (d->d_fs) (void)hipFree(d->d_fs);
     if (d->d_counts) (void)hipFree(d->d_counts);
@@ -516,7 +522,12 @@ static int submit_common(fqtk_demuxer *d, int slot, const uint8_t *const *text, 
     DX_TRY(hipEventRecord(s.ev_h2d0, d->s_in));
     for (uint32_t i = 0; i < C.n_inputs; ++i) {
         if (!win) DX_TRY(hipMemcpyAsync(s.text[i].p, text[i], (size_t)text_len[i], hipMemcpyHostToDevice, d->s_in));
-        else if (win[i].copy_from && win[i].copy_dev == d->device) DX_TRY(hipMemcpyAsync(s.text[i].p, win[i].copy_from, (size_t)text_len[i], hipMemcpyDeviceToDevice, d->s_in));
+        else if (win[i].copy_from && win[i].copy_dev == d->device) {   // (two pipelines on one device: the CUs copy -- k_copy16 says why; both ends are 16-byte aligned)
+            const uint64_t n16 = (text_len[i] + 15u) / 16u;
+            hipLaunchKernelGGL(k_copy16, dim3((uint32_t)std::min<uint64_t>((n16 + 255u) / 256u, (uint64_t)d->num_cus * 8u)), dim3(256), 0, d->s_in,
+                               reinterpret_cast<uint4 *>(s.text[i].p), reinterpret_cast<const uint4 *>(win[i].copy_from), n16);
+            DX_TRY(hipGetLastError());
+        }
         else if (win[i].copy_from) DX_TRY(hipMemcpyPeerAsync(s.text[i].p, d->device, win[i].copy_from, win[i].copy_dev, (size_t)text_len[i], d->s_in));   // over xGMI
     }
     DX_TRY(hipEventRecord(s.ev_h2d1, d->s_in));
@@ -576,7 +587,6 @@ static int submit_common(fqtk_demuxer *d, int slot, const uint8_t *const *text, 
         DX_TRY(hipGetLastError());
     }
     DX_TRY(hipEventRecord(s.ev_fmt, A));
-    DX_TRY(hipEventRecord(d->ev_last_fmt, A));
     // stream B
     DX_TRY(hipStreamWaitEvent(d->s_b, s.ev_fmt, 0));
     if ((rc = enqueue_compress(d, s)) != FQTK_OK) return rc;
@@ -638,6 +648,7 @@ static int fed_init(fqtk_demuxer *d) {
                     if (rc1 != FQTK_OK) return rc1;
                 }
                 DX_TRY(hipEventCreateWithFlags(&f[i].ev_moved, hipEventDisableTiming));
+                for (int k = 0; k < 2; ++k) DX_TRY(hipEventCreateWithFlags(&f[i].ev_reader[k], hipEventDisableTiming));
                 DX_TRY(hipEventCreate(&f[i].ev_t0));
                 DX_TRY(hipEventCreate(&f[i].ev_t1));
             }
@@ -649,13 +660,15 @@ static int fed_init(fqtk_demuxer *d) {
 
 // Room for text_bytes more text of an input (its mutex held through `lk`): when the arena is full, what chunks have not consumed yet
 // moves to the front of the other arena.  A change of arena excludes a submit in progress (a chunk whose window was cut out
-// of the old arena but whose kernels were not enqueued yet was not covered by ev_last_fmt): the input's lock is given up, submit_fed's
-// taken, the input's again (that order everywhere), and with both held every window ever cut has its ev_fmt behind ev_last_fmt.
+// of the old arena but whose kernels were not enqueued yet was not covered by the event waited for): the input's lock is given up, submit_fed's
+// taken, the input's again (that order everywhere), and with both held every window ever cut has its ev_fmt behind its arena's ev_reader.
 static int fed_make_room(fqtk_demuxer *d, FedInput &F, std::unique_lock<std::mutex> &lk, uint64_t text_bytes, bool tight = false) {
     int rc;
     if (F.tail + text_bytes + kFedSlack <= F.arena[F.cur].cap) return FQTK_OK;
     // (... and windows that were cut -- fqtk_demuxer_fed_cut -- but not yet taken by a submit: they name places in these arenas.  With both locks
-    //  held and no window pinned, every window ever cut has either been copied out or has its chunk's ev_fmt behind ev_last_fmt.)
+    //  held and no window pinned, every window ever cut has either been copied out or has its chunk's ev_fmt behind its arena's ev_reader.)
+    static const bool timing = std::getenv("FQTK_TIMING") != nullptr;
+    const auto t_begin = std::chrono::steady_clock::now();
     std::unique_lock<std::mutex> glk(d->fed_mu, std::defer_lock);
     for (;;) {
         lk.unlock();
@@ -665,6 +678,10 @@ static int fed_make_room(fqtk_demuxer *d, FedInput &F, std::unique_lock<std::mut
         glk.unlock();
         F.cv_pins.wait(lk, [&] { return F.pins == 0; });
     }
+    const auto t_locked = std::chrono::steady_clock::now();
+    struct Report { bool on; std::chrono::steady_clock::time_point t0, t1; ~Report() { if (on) { const auto t2 = std::chrono::steady_clock::now();
+        if (std::chrono::duration<double, std::milli>(t2 - t0).count() > 10.0) std::fprintf(stderr, "(timing) change of arena: %.1f ms for the locks and the windows in flight, %.1f ms for the rest\n",
+            std::chrono::duration<double, std::milli>(t1 - t0).count(), std::chrono::duration<double, std::milli>(t2 - t1).count()); } } } report{timing, t_begin, t_locked};
     // (only this input's feeder moves its tail; chunks may have consumed members meanwhile, which only shrinks what is live)
     const uint64_t live_from = F.members.empty() ? F.tail : F.members.front().off;
     {
@@ -675,17 +692,28 @@ static int fed_make_room(fqtk_demuxer *d, FedInput &F, std::unique_lock<std::mut
         // (tight: gigabytes of text at a time take an arena that holds one of them and what is live, and change arena every time)
         const uint64_t want = std::max<uint64_t>(tight ? (live + text_bytes) + (live + text_bytes) / 4 + kFedSlack : (live + text_bytes + kFedSlack) * 2, arena_min);
         {
-            // Chunks whose record views point into the OTHER arena were submitted before this input last changed arenas:
-            // its old text may go, and this stream's copy may start, when they have been formatted.
-            const bool any = d->chunks_submitted.load() != 0;
-            if (any) DX_TRY(hipStreamWaitEvent(F.stream, d->ev_last_fmt, 0));
-            if (F.arena[other].cap < want) {
-                if (any) DX_TRY(hipEventSynchronize(d->ev_last_fmt));   // (freeing memory a kernel may still read)
-                if ((rc = F.arena[other].ensure((size_t)want)) != FQTK_OK) return rc;
+            // Chunks whose record views point into the OTHER arena were cut before this input last changed arenas: its old text may go, and
+            // this stream's copy may start, when the LAST of them has been formatted -- that arena's own event (until round 6 the event of the
+            // latest chunk submitted anywhere: every change of arena then waited for the three chunks in flight, 30-60 ms in which the feeder
+            // decoded nothing -- a quarter of a serial gzip input's time; the chunks that read the other arena finished a whole arena ago).
+            if (F.has_reader[other]) DX_TRY(hipStreamWaitEvent(F.stream, F.ev_reader[other], 0));
+            // The other arena is taken as it is when it HOLDS what must go in (what is live, the new text, the slack); only one that does not
+            // is freed and made again, with room to spare (`want`).  Until round 6 every arena below `want` -- twice the need -- was made again: a
+            // serial gzip input whose arenas had been reserved for the need (stream_reserve) freed and allocated one every few stretches, 35-110 ms
+            // each time with the whole device waiting.
+            const uint64_t need = 16u + live + text_bytes + kFedSlack;
+            if (F.arena[other].cap < need) {
+                if (F.has_reader[other]) DX_TRY(hipEventSynchronize(F.ev_reader[other]));   // (freeing memory a kernel may still read)
+                if ((rc = F.arena[other].ensure((size_t)std::max(want, need))) != FQTK_OK) return rc;
             }
         }
         const uint64_t shift = live_from & 15u;   // members keep their alignment modulo 16 (nothing depends on it; windows are aligned down anyway)
-        if (live) DX_TRY(hipMemcpyAsync(F.arena[other].p + shift, F.arena[F.cur].p + live_from, (size_t)live, hipMemcpyDeviceToDevice, F.stream));
+        if (live) {   // (from the 16-byte boundary at or before the first live byte: the bytes in front of it are the arena's own, and nobody's over there)
+            const uint64_t n16 = (shift + live + 15u) / 16u;
+            hipLaunchKernelGGL(k_copy16, dim3((uint32_t)std::min<uint64_t>((n16 + 255u) / 256u, (uint64_t)d->num_cus * 8u)), dim3(256), 0, F.stream,
+                               reinterpret_cast<uint4 *>(F.arena[other].p), reinterpret_cast<const uint4 *>(F.arena[F.cur].p + (live_from - shift)), n16);
+            DX_TRY(hipGetLastError());
+        }
         DX_TRY(hipEventRecord(F.ev_moved, F.stream));
         F.moved = true;
         for (FedMember &m : F.members) m.off = m.off - live_from + shift;
@@ -806,6 +834,8 @@ int fqtk_demuxer_fed_cut(fqtk_demuxer *home, uint32_t input, uint32_t n, fqtk_fe
     out->base = p - lead;
     out->len = lead + (lastm.off + lastm.isize - first.off);
     out->pos = first.pos - lead;   // (mod 2^64 for the first member: added back with the chunk's end_off)
+    out->arena = (uint32_t)F.cur;
+    out->reserved = 0;
     F.lines_consumed = l1;
     ++F.pins;
     return FQTK_OK;
@@ -871,9 +901,18 @@ int fqtk_demuxer_submit_windows(fqtk_demuxer *d, int slot, const fqtk_fed_window
             d->slots[slot].win_pos[i] = w[i].pos;
         }
         rc = submit_common(d, slot, nullptr, text_len, win, n);
-        if (rc == FQTK_OK) d->slots[slot].fed = true;
+        if (rc == FQTK_OK) {
+            d->slots[slot].fed = true;
+            for (uint32_t i = 0; i < n_inputs; ++i) {   // behind the chunk's formatting on stream A: the arena's latest reader
+                if (w[i].home != d) continue;
+                FedInput &F = d->fed[i];
+                const uint32_t ar = w[i].arena & 1u;
+                DX_TRY(hipEventRecord(F.ev_reader[ar], d->s_a));
+                F.has_reader[ar] = true;
+            }
+        }
     }
-    // windows of d's own text are covered by ev_last_fmt from here on; the others once their copies are done
+    // windows of d's own text are covered by their arena's ev_reader from here on; the others once their copies are done
     bool remote = false;
     for (uint32_t i = 0; i < n_inputs; ++i) remote = remote || w[i].home != d;
     hipError_t e = hipSuccess;

@@ -926,10 +926,23 @@ bool gpu_output_supported(const Plan &plan, std::string *why) {
                     // handed to the device as text: a VALID file is never refused (demux.rs:844-849 reads any), and a stream is called
                     // corrupt only when the sequential decoder says so too.  (FQTK_TIMING=1 prints every stretch's clock.)
                     static const size_t kChunkBytes = (size_t)std::max<long>(4, std::min<long>(4096, env_num("FQTK_GZ_DEVICE_CHUNK_KB", 64))) << 10;
-                    static const size_t kSlots = (size_t)std::max<long>(1, std::min<long>(4096, std::min<long>(env_num("FQTK_GZ_DEVICE_CHUNKS", 1024), (long)((440u << 20) / kChunkBytes))));
+                    static const size_t kSlotsMax = (size_t)std::max<long>(1, std::min<long>(4096, std::min<long>(env_num("FQTK_GZ_DEVICE_CHUNKS", 2048), (long)((440u << 20) / kChunkBytes))));
                     static const long kForceFallback = env_num("FQTK_GZ_FORCE_FALLBACK", 0);     // (tests: every k-th stretch goes to the host's decoder)
                     static const uint64_t kSymBudget = (uint64_t)std::max<long>(1, env_num("FQTK_GZ_DEVICE_SYM_MB", 1024)) << 20;   // symbols a stretch may ask room for
-                    const uint64_t gz_high_water = 4ull * chunk * (uint64_t)env_num("FQTK_GZ_DEVICE_AHEAD", 12);   // (a stretch is ~5 chunks of templates: one may decode while one is consumed)
+                    // A stretch takes the device as long as its slowest chunk takes one wavefront -- 20-25 ms whether it has 1023 chunks or 2047 (measured, round 6:
+                    // 28 -> 37 M templates/s steady with twice the chunks) -- so stretches are as large as they are useful: about kStretchChunks chunks of TEMPLATES
+                    // of this input (a stretch of an index read's file, 60 bytes a record, would otherwise be 58 chunks of templates, decoded long before anyone
+                    // asks, in arenas to match), 2048 chunks of file at most; the feeder may be two such stretches ahead of the chunks cut.
+                    static const uint64_t kStretchChunks = (uint64_t)std::max<long>(1, env_num("FQTK_GZ_STRETCH_TEMPLATE_CHUNKS", 8));
+                    const uint64_t gz_high_water = 4ull * chunk * (uint64_t)env_num("FQTK_GZ_DEVICE_AHEAD", 16);
+                    const uint64_t stretch_text_target = kStretchChunks * chunk * (uint64_t)std::max<size_t>(16, per_record_of[i]);
+                    auto slots_for = [&](double text_per_byte) {   // chunks of file whose text is the target's
+                        const double want = (double)stretch_text_target / (text_per_byte * (double)kChunkBytes);
+                        return (size_t)std::max<double>(std::min<double>(want, (double)kSlotsMax), (double)std::min<size_t>(64, kSlotsMax));
+                    };
+                    const size_t kSlots = std::min(kSlotsMax, std::max<size_t>(slots_for(3.0), std::min<size_t>(64, kSlotsMax)));   // this input's most (its buffers are sized by it): text of 3 : 1 at least
+                    size_t slots_now = slots_for(6.0);                       // ... and what a stretch takes: by the ratio measured so far (FASTQ.gz: 4-7 : 1)
+                    uint64_t text_seen = 0, bytes_seen = 0;
                     const uint32_t sym_base = (uint32_t)std::max<long>(1, std::min<long>(2048, env_num("FQTK_GZ_DEVICE_SYMS", 8)));
                     uint32_t sym_per_byte = sym_base;   // room per compressed byte: x4 when a chunk runs out, back down by halves after 4 stretches that fit (a run of poly-N
                                                         // reads with constant qualities deflates 1000 : 1 for a megabyte; the rest of the file must not pay for it)
@@ -965,11 +978,14 @@ bool gpu_output_supported(const Plan &plan, std::string *why) {
                             reserved = true;
                             const uint64_t stretch_bytes = std::min<uint64_t>(bf.size, (uint64_t)kSlots * kChunkBytes + 131072);
                             const uint64_t ahead_text = (gz_high_water / 4u) * (uint64_t)std::max<size_t>(16, per_record_of[i]);
+                            // (an arena holds what the feeder may be ahead by, the stretch just committed and the one to come: the target's text -- 12 : 1 at most
+                            //  of a stretch's bytes -- with a quarter to spare; one that turns out too small is made again when it must be, fqtk_demuxer's fed_make_room)
+                            const uint64_t stretch_text = std::min<uint64_t>(stretch_bytes * 12u, stretch_text_target + stretch_text_target / 4u);
                             // (two arenas of this size per input are the run's largest allocations -- 22 GB of device memory for four inputs with the factor 2 they had
                             //  until the end of round 5 -- and on a box whose memory a test-suite had just been through allocating them took 0.85 s before the first
                             //  stretch could go: FQTK_TIMING prints it.  Factor 1: 0.4 s there, the same steady rate.)
                             static const uint64_t kArenaFactor = (uint64_t)std::max<long>(1, env_num("FQTK_GZ_ARENA_FACTOR", 1));
-                            const uint64_t arena = std::min<uint64_t>((ahead_text + stretch_bytes * 8u) * kArenaFactor + (64u << 20), (uint64_t)bf.size * 24u + (64u << 20));
+                            const uint64_t arena = std::min<uint64_t>((ahead_text + 2u * stretch_text) * kArenaFactor + (64u << 20), (uint64_t)bf.size * 24u + (64u << 20));
                             if (fqtk_demuxer_stream_reserve(home, (uint32_t)i, stretch_bytes + 8, (uint32_t)kSlots, sym_per_byte, kSlots >= 64 ? arena : 0) != FQTK_OK) {
                                 fail(std::string("GPU record pipeline: ") + fqtk_last_error());
                                 return false;
@@ -1056,7 +1072,7 @@ bool gpu_output_supported(const Plan &plan, std::string *why) {
                             const uint64_t t0 = tick();
                             // the stretch: from the dword of the verified bit, as many chunks as the symbol budget allows, and a block's worth behind them
                             const size_t b0 = (size_t)(verified / 8u) & ~(size_t)3;
-                            size_t n_slots = std::max<size_t>(1, std::min<size_t>(ramp_slots, (size_t)(kSymBudget / ((uint64_t)kChunkBytes * sym_per_byte))));
+                            size_t n_slots = std::max<size_t>(1, std::min<size_t>(std::min(ramp_slots, slots_now), (size_t)(kSymBudget / ((uint64_t)kChunkBytes * sym_per_byte))));
                             ramp_slots = std::min(kSlots, ramp_slots * 2);
                             const size_t b1 = std::min<size_t>(bf.size, b0 + n_slots * kChunkBytes + 131072);
                             const bool to_end = b1 == bf.size;
@@ -1155,6 +1171,9 @@ bool gpu_output_supported(const Plan &plan, std::string *why) {
                                      n_accept - 1, a.status, a.n_blocks, (unsigned long long)a.end_bit, n_accept, (unsigned long long)b.start_bit, b.status, b.n_blocks);
                             }
                             ++n_stretches; n_chunks_total += n_chunks; n_refused += n_chunks - n_accept;
+                            text_seen += n_text;
+                            bytes_seen += (end_bit - verified) / 8u;
+                            if (bytes_seen >= (1u << 20)) slots_now = std::min(kSlots, slots_for(std::max(1.0, (double)text_seen / (double)bytes_seen)));
                             if (!stretch_done(end_bit, final_block, fed, crc, n_text, &member_done)) return false;
                             if (b0 > (64u << 20)) madvise(const_cast<uint8_t *>(bf.map), (b0 - (64u << 20)) & ~(size_t)4095, MADV_DONTNEED);
                         }
@@ -1280,11 +1299,13 @@ bool gpu_output_supported(const Plan &plan, std::string *why) {
             Job j;
             j.n = n;
             j.first_record = records;
-            // the chunk's windows are cut HERE, in chunk order (the devices' threads submit in any order): where the next n records of every input lie at its home
-            j.win.resize(n_inputs);
-            for (size_t i = 0; i < n_inputs; ++i)
-                if (fqtk_demuxer_fed_cut(demuxers[home_of[i]], (uint32_t)i, (uint32_t)n, &j.win[i]) != FQTK_OK) die(std::string("GPU record pipeline: ") + fqtk_last_error());
-            dispatch.push(std::move(j));
+            // the chunk's windows are cut by THIS thread, in chunk order (the devices' threads submit in any order) -- where the next n records of every
+            // input lie at its home -- once the chunk's slot is free (chunk_dispatch.hpp: a window pins its input's text until it is submitted)
+            dispatch.push(std::move(j), [&](Job &jj) {
+                jj.win.resize(n_inputs);
+                for (size_t i = 0; i < n_inputs; ++i)
+                    if (fqtk_demuxer_fed_cut(demuxers[home_of[i]], (uint32_t)i, (uint32_t)jj.n, &jj.win[i]) != FQTK_OK) die(std::string("GPU record pipeline: ") + fqtk_last_error());
+            });
             records += n;
             {
                 std::lock_guard<std::mutex> lk(fmu);

@@ -147,6 +147,7 @@ typedef struct fqtk_fed_window {
     const uint8_t *base;     /* device address on home's device */
     uint64_t len;            /* bytes of the window from base */
     uint64_t pos;            /* position of base in the input's whole text */
+    uint32_t arena, reserved; /* (the home's: which of its buffers the window lies in) */
 } fqtk_fed_window;
 /* The next n_templates records (4 n_templates lines) of `input`'s text fed to `home`.  FQTK_EINVAL when fewer lines have been fed. */
 int fqtk_demuxer_fed_cut(fqtk_demuxer *home, uint32_t input, uint32_t n_templates, fqtk_fed_window *out);

@@ -383,14 +383,12 @@ def _device_lists():
     arenas, streams and submit threads on the same device: every code path but the xGMI hop itself), and the box's real devices when
     it has more than one."""
     import ctypes
+    from fqtk_amd import _lib
     lists = ["0,0", "0,0,0"]
-    try:
-        hip = ctypes.CDLL("libamdhip64.so")
-        n = ctypes.c_int(0)
-        if hip.hipGetDeviceCount(ctypes.byref(n)) == 0 and n.value > 1:
-            lists.append(",".join(str(d) for d in range(min(n.value, 4))))
-    except OSError:
-        pass
+    n = ctypes.c_int(0)
+    _lib.load().fqtk_device_count(ctypes.byref(n))   # (through the product library: it loads the HIP runtime this process is to use)
+    if n.value > 1:
+        lists.append(",".join(str(d) for d in range(min(n.value, 4))))
     return lists
 
 

@@ -27,9 +27,9 @@ for rep in $(seq 1 $REPS); do
     rm -rf $D/out
     if [ -n "$L" ]; then export LD_LIBRARY_PATH=$R/$L; else unset LD_LIBRARY_PATH; fi
     t0=$(date +%s%N)
-    env $ENVS FQTK_TIMING=1 $CMD 2> $O/run.err
+    env $ENVS FQTK_TIMING=1 $CMD 2> $O/run_$KIND.err
     t1=$(date +%s%N)
-    echo "[$KIND lib=${L:-product}] wall $(( (t1 - t0) / 1000000 )) ms; $(grep -o 'from the first chunk.*M templates/s)' $O/run.err); inflating $(grep -o 'gzip chunks: [0-9.]*' $O/run.err | head -1)" | tee -a $O/summary_$KIND.txt
+    echo "[$KIND lib=${L:-product}] wall $(( (t1 - t0) / 1000000 )) ms; $(grep -o 'from the first chunk.*M templates/s)' $O/run_$KIND.err); inflating $(grep -o 'gzip chunks: [0-9.]*' $O/run.err | head -1)" | tee -a $O/summary_$KIND.txt
   done
 done
 unset LD_LIBRARY_PATH
