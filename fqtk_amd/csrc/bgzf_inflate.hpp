@@ -494,8 +494,25 @@ FQTK_UNROLL
 // An accidental header still turns up about once per 100 MB of FASTQ.gz (measured: one in a 60 MB stream), and in stream mode a chunk that
 // starts at one decodes garbage without an error (any bits decode under two complete codes, any distance reaches into the unknown window);
 // the chain refuses it, at the price of the rest of its stretch.  low_literals_only makes such headers rarer by orders of magnitude.
+// Kraft sums of four 3-bit code lengths at a time (the code-length code has seven index bits: a length l weighs 128 >> l, none weighs 0): entry
+// g of 4096 is the weight of the four lengths in g's twelve bits, saturated at 255 (four lengths of 1 weigh 256: no complete code has them).
+// The block-start search tests the code-length code of EVERY candidate position for completeness -- nineteen extract / shift / select / add
+// steps per lane and window until round 6, five look-ups now.  Built by the wavefront that searches (64 entries per lane).
+constexpr uint32_t kKraftLutBytes = 4096;
 template <class W>
-FQTK_HD inline uint32_t find_block_start(W &w, Shared &S, const MemberArgs &a, uint32_t from_bit, uint32_t limit_bit, bool low_literals_only = false) {
+FQTK_HD inline void build_kraft_lut(W &w, uint8_t *lut) {
+    for (uint32_t g = w.lane(); g < kKraftLutBytes; g += 64u) {
+        uint32_t sum = 0;
+FQTK_UNROLL
+        for (uint32_t k = 0; k < 4u; ++k) { const uint32_t l = (g >> (3u * k)) & 7u; sum += l ? 128u >> l : 0u; }
+        lut[g] = (uint8_t)(sum > 255u ? 255u : sum);
+    }
+    w.barrier();
+}
+
+template <class W>
+FQTK_HD inline uint32_t find_block_start(W &w, Shared &S, const MemberArgs &a, uint32_t from_bit, uint32_t limit_bit, bool low_literals_only = false,
+                                         const uint8_t *kraft_lut = nullptr) {
     const uint32_t lane = w.lane();
     const uint32_t end_bit = a.first_bit + a.payload_bits;
     // The bits come through the ring in LDS, 64 dwords a refill, like the decoder's (until round 6 every lane fetched its four dwords from
@@ -516,10 +533,19 @@ FQTK_HD inline uint32_t find_block_start(W &w, Shared &S, const MemberArgs &a, u
             // Kraft sum of the code-length code: 3-bit fields k < hclen from bit 17 on (fields 0-14 in b, 15-18 from bit 62 on)
             const uint64_t c0 = b >> 17, c1 = (b >> 62) | (c << 2);
             uint32_t kraft = 0;
+            if (kraft_lut) {
+                // the lengths that are there: 3 * hclen bits of c0 (fields 0-14) and c1 (fields 15-18); what lies behind them weighs nothing
+                const uint32_t nb = 3u * hclen;                                   // 12 .. 57
+                const uint64_t f0 = nb >= 45u ? c0 & ((1ull << 45) - 1ull) : c0 & ((1ull << nb) - 1ull);
+                const uint32_t f1 = nb > 45u ? (uint32_t)c1 & ((1u << (nb - 45u)) - 1u) : 0u;
+                kraft = (uint32_t)kraft_lut[(uint32_t)f0 & 0xFFFu] + (uint32_t)kraft_lut[(uint32_t)(f0 >> 12) & 0xFFFu] + (uint32_t)kraft_lut[(uint32_t)(f0 >> 24) & 0xFFFu] +
+                        (uint32_t)kraft_lut[(uint32_t)(f0 >> 36) & 0x1FFu] + (uint32_t)kraft_lut[f1 & 0xFFFu];
+            } else {
 FQTK_UNROLL
-            for (uint32_t k = 0; k < 19u; ++k) {
-                const uint32_t l = (uint32_t)(k < 15u ? c0 >> (3u * k) : c1 >> (3u * (k - 15u))) & 7u;
-                kraft += k < hclen && l ? 128u >> l : 0u;
+                for (uint32_t k = 0; k < 19u; ++k) {
+                    const uint32_t l = (uint32_t)(k < 15u ? c0 >> (3u * k) : c1 >> (3u * (k - 15u))) & 7u;
+                    kraft += k < hclen && l ? 128u >> l : 0u;
+                }
             }
             pass = pass && kraft == 128u;
         }
@@ -528,7 +554,9 @@ FQTK_UNROLL
             const uint32_t cand = (uint32_t)__builtin_ctzll(m);
             m &= m - 1ull;
             uint32_t bit = t0 + cand + 3u, hlit = 0, hdist = 0;
-            ring.reset(w, a, bit);
+            // (the header is read through the SAME ring, which only ever moves forward: a header is 2 300 bits at most -- 72 dwords -- and the
+            //  ring keeps 256, so the search's own place is still in it afterwards; a ring started afresh for every candidate, and again for
+            //  the search, was two round trips to memory per candidate -- one in seven windows has one)
             uint32_t err = read_dynamic_header(w, S, a, ring, bit, hlit, hdist);
             if (!err && bit > end_bit) err = kErrTruncated;
             // (the caller has seen nothing but 7-bit text in this stream so far: a header that gives codes to literals >= 128 -- as nearly every
@@ -537,8 +565,6 @@ FQTK_UNROLL
             if (!err) err = build_code<W, true, false>(w, S, S.lens, hlit);
             if (!err) err = build_code<W, false, false>(w, S, S.lens + hlit, hdist);
             if (!err) return t0 + cand;
-            ring.reset(w, a, t0);      // (the header's parse moved the ring: back to the search's place)
-            ring.ensure(w, S, a, t0);
         }
     }
     return 0xFFFFFFFFu;

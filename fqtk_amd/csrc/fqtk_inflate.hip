@@ -255,6 +255,7 @@ __global__ __launch_bounds__(64) FQTK_INFLATE_OCCUPANCY void stream_kernel(const
 // (~0: none), found by a wavefront of its own (find_block_start: a lane per bit position); slot 0 is the bit the caller knows.
 __global__ __launch_bounds__(64) void stream_search_kernel(const uint8_t *in, uint64_t in_len, uint64_t first_bit, uint32_t chunk_bits, uint32_t n_slots, uint32_t low_literals_only, uint64_t *starts) {
     __shared__ Shared S;
+    __shared__ uint8_t kraft_lut[kKraftLutBytes];
     const uint32_t k = blockIdx.x;
     if (k >= n_slots) return;
     if (k == 0u) { if (threadIdx.x == 0) starts[0] = first_bit; return; }
@@ -270,7 +271,8 @@ __global__ __launch_bounds__(64) void stream_search_kernel(const uint8_t *in, ui
         a.tail_bytes = (uint32_t)(in_len & 3u);
         a.out = nullptr; a.isize = 0; a.out_sym = nullptr; a.stop_bit = 0;
         DeviceWave w;
-        const uint32_t r = find_block_start(w, S, a, (uint32_t)from, (uint32_t)(limit < total_bits ? limit : total_bits), low_literals_only != 0u);
+        build_kraft_lut(w, kraft_lut);
+        const uint32_t r = find_block_start(w, S, a, (uint32_t)from, (uint32_t)(limit < total_bits ? limit : total_bits), low_literals_only != 0u, kraft_lut);
         if (r != 0xFFFFFFFFu) found = r;
     }
     if (threadIdx.x == 0) starts[k] = found;

@@ -479,8 +479,12 @@ uint64_t fqtk_host_find_block_start_emulated(const uint8_t *data, uint32_t len, 
     a.readable_words = words;
     a.tail_bytes = len & 3u;
     uint32_t found[64];
+    std::vector<uint8_t> kraft(kKraftLutBytes, 0xEE);   // (the device's: built by the searching wavefront, then five look-ups per candidate)
     fqtk_host::WaveEmu wave;
-    wave.run([&](fqtk_host::WaveEmu &w) { found[w.lane()] = find_block_start(w, S, a, from_bit, limit_bit, low_literals_only != 0); });
+    wave.run([&](fqtk_host::WaveEmu &w) {
+        build_kraft_lut(w, kraft.data());
+        found[w.lane()] = find_block_start(w, S, a, from_bit, limit_bit, low_literals_only != 0, kraft.data());
+    });
     for (int l = 1; l < 64; ++l)
         if (found[l] != found[0]) return ~0ull - 1u;   // the result is wave-uniform by construction
     return found[0] == 0xFFFFFFFFu ? ~0ull : (uint64_t)found[0];
