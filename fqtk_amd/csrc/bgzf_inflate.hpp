@@ -158,7 +158,7 @@ constexpr uint32_t kWindow = 32768;
 
 // ---- the wave -------------------------------------------------------------------------------------------------------
 // W provides: lane() 0..63; ballot(bool) -> uint64; readlane(uint32 v, uint32 l) (l the same in all lanes);
-// uniform(uint32 v) (a value known to be the same in all lanes: the device keeps it in a scalar register);
+// uniform(uint32 v) (a value known to be the same in all lanes: the device keeps it in a scalar register); set_bit64(uint64 &m, bit) m |= 1 << bit, both wave-uniform;
 // scan_incl(uint32 v) inclusive prefix sum over the lanes; scan_max_incl(uint32 v) inclusive prefix maximum;
 // shuffle(uint32 v, uint32 l) lane l's v (l may differ between lanes); rcp(float) ~ 1 / x; barrier() (LDS written before is visible to
 // all lanes after); fence_global() (global stores issued by any lane before are visible to the loads of all lanes after);
@@ -661,11 +661,17 @@ FQTK_HD inline uint32_t inflate_member(W &w, Shared &S, const MemberArgs &a, Str
                     FQTK_UNROLL
                     for (uint32_t q = 0; q < kSets; ++q) {
                         if (cur >= 64u * q && cur < 64u * (q + 1u)) {
-                            do {
-                                m = w.readlane(meta[q], cur - 64u * q);
-                                chain[q] |= 1ull << (cur - 64u * q);
-                                cur += m;
-                            } while (cur < 64u * (q + 1u));
+                            // (four steps per turn of the loop: a step is a v_readlane and four scalar instructions, and a TAKEN branch costs
+                            //  as much again -- three of four are now branches that fall through)
+                            for (;;) {
+#define FQTK_WALK_STEP                                                      \
+                                m = w.readlane(meta[q], cur - 64u * q);     \
+                                w.set_bit64(chain[q], cur - 64u * q);       \
+                                cur += m;                                   \
+                                if (cur >= 64u * (q + 1u)) break;
+                                FQTK_WALK_STEP FQTK_WALK_STEP FQTK_WALK_STEP FQTK_WALK_STEP
+#undef FQTK_WALK_STEP
+                            }
                         }
                     }
                     if (!(m & 0x80u)) break;

@@ -24,6 +24,8 @@ struct DeviceWave {
         return (uint32_t)__builtin_amdgcn_readlane((int)v, (int)__builtin_amdgcn_readfirstlane((int)l));
     }
     __device__ inline uint32_t uniform(uint32_t v) const { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
+    // m |= 1 << bit for a wave-uniform m and bit: one scalar instruction (the compiler writes s_lshl_b64 + s_or_b64)
+    __device__ inline void set_bit64(uint64_t &m, uint32_t bit) const { asm("s_bitset1_b64 %0, %1" : "+s"(m) : "s"(bit)); }
     // inclusive prefix sum over the 64 lanes in registers (DPP): within rows of 16 by shifts, then the rows' totals
     // (row_bcast:15 into rows 1 and 3, row_bcast:31 into rows 2 and 3)
     __device__ inline uint32_t scan_incl(uint32_t v) const {

@@ -53,6 +53,7 @@ class WaveEmu {
     }
     uint32_t readlane(uint32_t v, uint32_t l) { return (uint32_t)exchange(v)[l & 63u]; }
     uint32_t uniform(uint32_t v) { return v; }
+    void set_bit64(uint64_t &m, uint32_t bit) { m |= 1ull << (bit & 63u); }   // (the device: one s_bitset1_b64 on a scalar register pair)
     uint32_t scan_incl(uint32_t v) {
         const uint64_t *all = exchange(v);
         uint32_t s = 0;
