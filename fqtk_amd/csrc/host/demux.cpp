@@ -822,7 +822,7 @@ bool gpu_output_supported(const Plan &plan, std::string *why) {
 
     // ---- collector: chunks in order
     // Every device has its own submit thread, one collector takes the chunks back in order: chunk_dispatch.hpp.
-    struct Flight { int dev = 0, slot = 0; uint32_t n = 0; uint64_t first_record = 0; };
+    struct Flight { int dev = 0, slot = 0; uint32_t n = 0; uint64_t first_record = 0; fqtk_demux_result res{}; };
     uint64_t blocks_total = 0, skipped = 0;
     auto chunk_error = [&](const Flight &f, const fqtk_demux_result &r) {
         const uint64_t rec = f.first_record + r.error_template;
@@ -866,26 +866,38 @@ bool gpu_output_supported(const Plan &plan, std::string *why) {
         for (size_t i = 0; i < n_inputs; ++i) { text[i] = reinterpret_cast<const uint8_t *>(j.in[i].buf->data); text_len[i] = j.in[i].bytes; }
         const uint64_t th = tick();
         if (fqtk_demuxer_submit(demuxers[g], slot, text.data(), text_len.data(), (uint32_t)j.n) != FQTK_OK) die(std::string("GPU record pipeline: ") + fqtk_last_error());
-        // (the chunk counts as submitted only once its text has left the host buffers: they go back to the readers here)
+        // (the chunk counts as submitted only once its text has left the host buffers: they go back to the readers here.  Round 6 tried queueing the
+        //  next chunk's copy behind this one before waiting -- a fourth page-locked buffer per input and device -- to close the gap a submit leaves
+        //  on the link: 52.4 / 48.6 / 46.8 against 53.6 / 45.4 / 49.6 M templates/s on one box, alternating: the readers are the bound, not the gap)
         if (fqtk_demuxer_text_done(demuxers[g], slot) != FQTK_OK) die(std::string("GPU record pipeline: ") + fqtk_last_error());
-        g_times.main_handoff += tick() - th;
         for (size_t i = 0; i < n_inputs; ++i) free_bufs[i]->push(j.in[i].buf);
+        g_times.main_handoff += tick() - th;
         Flight f;
         f.dev = g; f.slot = slot; f.n = (uint32_t)j.n; f.first_record = j.first_record;
         return f;
     };
+    // The collector waits for the chunk and brings its members home; the RETIRE thread has the writers append them, and only then is the chunk's slot free
+    // (its page-locked buffers are what the writers read): the next chunk's wait and device-to-host copy run beside the appends.  Measured on one box,
+    // alternating with FQTK_NO_RETIRE_THREAD=1 (one thread does both, as until round 6), 64 M templates: plain 56.6 / 53.7 against 57.0 / 55.8, BGZF 59.4 / 57.5
+    // against 58.7 / 57.5, gzip 36.2 / 36.6 against 35.7 / 36.7 M templates/s -- no difference at 16 CPUs: the appends are not what a chunk waits for.
     auto collect_chunk = [&](int g, int slot, uint64_t, Flight &f) {
-        fqtk_demux_result r;
+        fqtk_demux_result &r = f.res;
         const uint64_t t0 = tick();
         if (fqtk_demuxer_collect(demuxers[g], slot, &r) != FQTK_OK) die(std::string("GPU record pipeline: ") + fqtk_last_error());
         g_times.main_gpu_wait += tick() - t0;
         if (r.error) chunk_error(f, r);
         if (r.text_end) for (size_t i = 0; i < n_inputs; ++i) fed_end[i] = r.text_end[i];
-        write_result(r);
-        blocks_total += r.n_blocks;
-        skipped += r.n_skipped;
     };
-    ChunkDispatcher<Job, Flight> dispatch(G, FQTK_DEMUX_SLOTS, submit_chunk, collect_chunk);
+    auto retire_chunk = [&](int, int, uint64_t, Flight &f) {
+        write_result(f.res);
+        blocks_total += f.res.n_blocks;
+        skipped += f.res.n_skipped;
+    };
+    const bool retire_apart = !env_on("FQTK_NO_RETIRE_THREAD");   // (A/B runs: the collector writes too, as it did)
+    ChunkDispatcher<Job, Flight> dispatch(G, FQTK_DEMUX_SLOTS, submit_chunk,
+                                          retire_apart ? ChunkDispatcher<Job, Flight>::CollectFn(collect_chunk)
+                                                       : ChunkDispatcher<Job, Flight>::CollectFn([&](int g, int slot, uint64_t k, Flight &f) { collect_chunk(g, slot, k, f); retire_chunk(g, slot, k, f); }),
+                                          retire_apart ? ChunkDispatcher<Job, Flight>::RetireFn(retire_chunk) : nullptr);
     uint64_t k = 0, records = 0, next_log = 1000000;
     // ---- fed mode: a feeder thread per input hands runs of members to the device; this thread cuts chunks by line counts
     std::mutex fmu;
@@ -902,7 +914,9 @@ bool gpu_output_supported(const Plan &plan, std::string *why) {
         // An input is fed again when it is less than two chunks ahead of the chunks cut so far.  A feed is a run of members of up
         // to 32 MB / 256 MB of text: a member takes a wavefront a few milliseconds however many are in flight, and the device
         // holds ~4 800 of them at once, so small feeds leave it idle (16 GB/s of text with 96 MB feeds, 3-4x that when full).
-        const uint64_t high_water = 4ull * chunk * 2;
+        // (six chunks since round 6; with two the cutter waited 0.9 s of a 64 M-template run's 1.1 for the feeders -- a run of members is three chunks of
+        //  templates and takes its input's feeder 15 ms to copy, send and inflate -- and 0.1 s with six or eight: 59.0-59.7 -> 60.7-61.2 M templates/s)
+        const uint64_t high_water = 4ull * chunk * (uint64_t)std::max<long>(1, env_num("FQTK_FEED_AHEAD", 6));
         for (size_t i = 0; i < n_inputs; ++i)
             readers.emplace_back([&, i] {
                 BgzfFile &bf = *bgzf_in[i];

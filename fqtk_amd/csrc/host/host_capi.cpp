@@ -672,7 +672,9 @@ int fqtk_host_chunk_dispatch_check(uint64_t devices, uint64_t slots, uint64_t n_
     std::vector<int> in_submit(devices, 0);
     std::vector<uint8_t> submitted(n_chunks, 0), collected(n_chunks, 0);
     int broken = 0, saw_overlap = 0;
-    uint64_t next_collect = 0;
+    uint64_t next_collect = 0, next_retire = 0;
+    const bool with_retire = (seed & 1u) != 0;
+    std::vector<uint8_t> gathered(n_chunks, 0);
     auto rnd = [seed](uint64_t k, uint64_t salt) { uint64_t x = (k + 1) * 0x9E3779B97F4A7C15ull ^ (seed + salt) * 0xBF58476D1CE4E5B9ull; x ^= x >> 29; x *= 0x94D049BB133111EBull; return (x >> 40) % 300; };
     auto flag = [&](int rule) { if (!broken) broken = rule; };
     {
@@ -707,9 +709,21 @@ int fqtk_host_chunk_dispatch_check(uint64_t devices, uint64_t slots, uint64_t n_
                 if (m.k != k || m.payload != k * 7 + 1) flag(4);
                 const size_t cell = (size_t)dev * slots + (size_t)slot;
                 if (busy[cell] != (int64_t)k) flag(1);
+                if (with_retire) { if (k < n_chunks && gathered[k]++) flag(6); return; }   // (the slot stays taken until the chunk has retired)
                 busy[cell] = -1;
                 if (k < n_chunks && collected[k]++) flag(4);
-            });
+            },
+            // odd seeds: a third stage on its own thread (the record pipeline's writers), in order, behind the collection; the slot is free only then
+            with_retire ? ChunkDispatcher<Job, Meta>::RetireFn([&](int dev, int slot, uint64_t k, Meta &m) {
+                std::this_thread::sleep_for(std::chrono::microseconds(rnd(k, 5)));
+                std::lock_guard<std::mutex> lk(mu);
+                if (k != next_retire++) flag(6);
+                if (k >= n_chunks || gathered[k] != 1 || m.k != k) flag(6);
+                const size_t cell = (size_t)dev * slots + (size_t)slot;
+                if (busy[cell] != (int64_t)k) flag(1);
+                busy[cell] = -1;
+                if (k < n_chunks && collected[k]++) flag(4);
+            }) : ChunkDispatcher<Job, Meta>::RetireFn(nullptr));
         for (uint64_t k = 0; k < n_chunks; ++k) {
             if (rnd(k, 3) < 30) std::this_thread::sleep_for(std::chrono::microseconds(rnd(k, 4)));   // a reader that stalls now and then
             d.push(Job{k * 7 + 1});
