@@ -380,12 +380,14 @@ int fqtk_demuxer_create(fqtk_matcher *m, const fqtk_demux_config *cfg, fqtk_demu
     DX_OR_BAIL(fqtk::bgzf::deflate_prepare());
     static_assert(format_block_bytes(FQTK_DEMUX_MAX_INPUTS) <= 48 * 1024, "k_format: slot tables and record views of a group per wave fit the default LDS");
     {
-        // FQTK_STREAM_PRIORITY=1 (A/B runs): the chunk's streams rank above the feed streams of the device-side inflate.  Measured
-        // on 64 M templates from BGZF inputs, one box, twice each: 39.4 / 39.1 M templates/s steady with, 39.9 / 38.8 without --
-        // the decoder's wavefronts are resident for milliseconds and take all of a CU's LDS; what frees up goes to whoever fits.
+        // The chunk's streams rank above the feed streams of the device-side inflate (FQTK_STREAM_PRIORITY=0: all streams equal, as until round 6).
+        // Round 4 measured nothing either way (39.4 / 39.1 against 39.9 / 38.8 M templates/s from BGZF inputs: the decoder's wavefronts took all of
+        // a CU's LDS then); with the decoder at 5.8 KB a wavefront and the feeders well ahead of the chunks it pays: same box, alternating, 64 M
+        // templates: serial gzip 35.5 / 36.0 -> 38.3 / 39.3 (a second box: 35.2-36.1 -> 39.6-40.0), BGZF 59.4 / 61.1 -> 62.0 / 63.0; plain text has no feed
+        // streams (profiles/r06_stream_priority_ab.txt).
         int lo = 0, hi = 0;
         const char *e = std::getenv("FQTK_STREAM_PRIORITY");
-        const bool ranked = e && e[0] == '1' && hipDeviceGetStreamPriorityRange(&lo, &hi) == hipSuccess && hi < lo;
+        const bool ranked = !(e && e[0] == '0') && hipDeviceGetStreamPriorityRange(&lo, &hi) == hipSuccess && hi < lo;
         { const char *sb = std::getenv("FQTK_DYNAMIC_BLOCKS"); d->dynamic_blocks = sb && sb[0] == '1'; }
         d->feed_priority = ranked ? lo : 0;
         d->ranked = ranked;
