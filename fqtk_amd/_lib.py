@@ -146,6 +146,7 @@ SIGNATURES = [
     ("fqtk_demuxer_files_per_sample", C.c_uint32, [C.c_void_p]),
     ("fqtk_demuxer_submit", C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_uint64), C.c_uint32]),
     ("fqtk_demuxer_collect", C.c_int, [C.c_void_p, C.c_int, C.POINTER(fqtk_demux_result)]),
+    ("fqtk_demuxer_collect_begin", C.c_int, [C.c_void_p, C.c_int]),
     ("fqtk_demuxer_text_done", C.c_int, [C.c_void_p, C.c_int]),
     ("fqtk_demuxer_record_text", C.c_int, [C.c_void_p, C.c_int, C.c_uint32, C.c_uint32, C.c_char_p, C.c_size_t, C.POINTER(C.c_uint32)]),
     ("fqtk_demuxer_flush", C.c_int, [C.c_void_p, C.POINTER(fqtk_demux_result)]),

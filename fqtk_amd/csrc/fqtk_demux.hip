@@ -95,6 +95,7 @@ struct Slot {
     hipEvent_t ev_h2d0 = nullptr, ev_h2d1 = nullptr, ev_fmt = nullptr, ev_status = nullptr, ev_d2h0 = nullptr, ev_d2h1 = nullptr;
     hipEvent_t ev[kStageEvents] = {};
     bool busy = false, flush_only = false;
+    bool d2h_issued = false;               // fqtk_demuxer_collect_begin has enqueued the copy home of the chunk's members
     uint32_t n = 0, stride = 0;
     uint64_t win_pos[FQTK_DEMUX_MAX_INPUTS] = {};           // fed text: position of text_base in the input's whole text
     uint64_t text_end[FQTK_DEMUX_MAX_INPUTS] = {};          // ... and of the byte behind the chunk's last record
@@ -259,6 +260,18 @@ void add_elapsed(double *acc, hipEvent_t a, hipEvent_t b) {
     else (void)hipGetLastError();
 }
 
+// The chunk's packed members on their way home (its status is in: total_bytes says how many).
+int issue_d2h(fqtk_demuxer *d, Slot &s) {
+    const ChunkStatus &st = *s.h_status;
+    int rc;
+    if ((rc = s.h_packed.ensure((size_t)st.total_bytes + 16)) != FQTK_OK) return rc;
+    DX_TRY(hipEventRecord(s.ev_d2h0, d->s_out));
+    if (st.total_bytes) DX_TRY(hipMemcpyAsync(s.h_packed.p, s.packed.p, (size_t)st.total_bytes, hipMemcpyDeviceToHost, d->s_out));
+    DX_TRY(hipEventRecord(s.ev_d2h1, d->s_out));
+    s.d2h_issued = true;
+    return FQTK_OK;
+}
+
 int fill_result(fqtk_demuxer *d, Slot &s, fqtk_demux_result *res) {
     std::memset(res, 0, sizeof *res);
     DX_TRY(hipEventSynchronize(s.ev_status));
@@ -289,10 +302,8 @@ int fill_result(fqtk_demuxer *d, Slot &s, fqtk_demux_result *res) {
     }
     if (st.err_key == kNoError && st.n_blocks > s.max_blocks) return set_error(FQTK_EINVAL, "internal error: more blocks than the chunk's bound");
     int rc;
-    if ((rc = s.h_packed.ensure((size_t)st.total_bytes + 16)) != FQTK_OK) return rc;
-    DX_TRY(hipEventRecord(s.ev_d2h0, d->s_out));
-    if (st.total_bytes) DX_TRY(hipMemcpyAsync(s.h_packed.p, s.packed.p, (size_t)st.total_bytes, hipMemcpyDeviceToHost, d->s_out));
-    DX_TRY(hipEventRecord(s.ev_d2h1, d->s_out));
+    if (!s.d2h_issued && (rc = issue_d2h(d, s)) != FQTK_OK) return rc;
+    s.d2h_issued = false;
     DX_TRY(hipEventSynchronize(s.ev_d2h1));
     add_elapsed(&d->stage_s[7], s.ev_d2h0, s.ev_d2h1);
     if (s.fed && !s.flush_only) {
@@ -1308,6 +1319,22 @@ int fqtk_demuxer_inflate_seconds(fqtk_demuxer *d, double *seconds) {
     std::lock_guard<std::mutex> glk(d->stat_mu);
     *seconds = d->inflate_s;
     return FQTK_OK;
+}
+
+// First half of a collect, for callers that overlap it with the second half of the chunk before: waits for the chunk's kernels and status and
+// enqueues the copy home of its members, without waiting for the copy.
+int fqtk_demuxer_collect_begin(fqtk_demuxer *d, int slot) {
+    if (!d) return set_error(FQTK_EINVAL, "NULL argument");
+    if (slot < 0 || slot >= FQTK_DEMUX_SLOTS) return set_error(FQTK_EINVAL, "slot out of range");
+    Slot &s = d->slots[slot];
+    if (!s.busy) return set_error(FQTK_EINVAL, "nothing was submitted on this slot");
+    if (s.d2h_issued) return FQTK_OK;
+    DX_TRY(hipSetDevice(d->device));
+    DX_TRY(hipEventSynchronize(s.ev_status));
+    const ChunkStatus &st = *s.h_status;
+    // (a chunk that failed, or one whose status makes no sense, brings nothing home: fqtk_demuxer_collect says what happened)
+    if (st.err_key != kNoError || st.matcher_err != kNoError || st.n_blocks > s.max_blocks) return FQTK_OK;
+    return issue_d2h(d, s);
 }
 
 int fqtk_demuxer_collect(fqtk_demuxer *d, int slot, fqtk_demux_result *res) {

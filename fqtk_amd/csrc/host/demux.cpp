@@ -880,15 +880,18 @@ bool gpu_output_supported(const Plan &plan, std::string *why) {
     // (its page-locked buffers are what the writers read): the next chunk's wait and device-to-host copy run beside the appends.  Measured on one box,
     // alternating with FQTK_NO_RETIRE_THREAD=1 (one thread does both, as until round 6), 64 M templates: plain 56.6 / 53.7 against 57.0 / 55.8, BGZF 59.4 / 57.5
     // against 58.7 / 57.5, gzip 36.2 / 36.6 against 35.7 / 36.7 M templates/s -- no difference at 16 CPUs: the appends are not what a chunk waits for.
-    auto collect_chunk = [&](int g, int slot, uint64_t, Flight &f) {
+    auto collect_chunk = [&](int g, int slot, uint64_t, Flight &) {   // (the chunk's kernels are through and its members are on their way home)
+        const uint64_t t0 = tick();
+        if (fqtk_demuxer_collect_begin(demuxers[g], slot) != FQTK_OK) die(std::string("GPU record pipeline: ") + fqtk_last_error());
+        g_times.main_gpu_wait += tick() - t0;
+    };
+    auto retire_chunk = [&](int g, int slot, uint64_t, Flight &f) {
         fqtk_demux_result &r = f.res;
         const uint64_t t0 = tick();
         if (fqtk_demuxer_collect(demuxers[g], slot, &r) != FQTK_OK) die(std::string("GPU record pipeline: ") + fqtk_last_error());
         g_times.main_gpu_wait += tick() - t0;
         if (r.error) chunk_error(f, r);
         if (r.text_end) for (size_t i = 0; i < n_inputs; ++i) fed_end[i] = r.text_end[i];
-    };
-    auto retire_chunk = [&](int, int, uint64_t, Flight &f) {
         write_result(f.res);
         blocks_total += f.res.n_blocks;
         skipped += f.res.n_skipped;

@@ -215,6 +215,10 @@ int fqtk_demuxer_inflate_seconds(fqtk_demuxer *d, double *seconds);
 /* Waits for the chunk on `slot`.  FQTK_OK with res->error == 0: res holds the members to append to the files.
  * res->error != 0: nothing of the chunk was written into the result; the run cannot continue. */
 int fqtk_demuxer_collect(fqtk_demuxer *d, int slot, fqtk_demux_result *res);
+/* Optional first half of the collect of `slot`: waits for the chunk's kernels and enqueues the copy of its members to the host without
+ * waiting for it; fqtk_demuxer_collect then only waits for that copy.  One thread may begin chunk k + 1 while another finishes chunk k
+ * (csrc/host/demux.cpp: collector and retire thread), so that a chunk's copy home runs beside the appends of the chunk before. */
+int fqtk_demuxer_collect_begin(fqtk_demuxer *d, int slot);
 
 /* For wording an error: header (without '@', at most cap - 1 bytes, NUL-terminated) and number of bases of template
  * `template_index` in input `input` of the chunk last collected on `slot` (its text is still in device memory until
