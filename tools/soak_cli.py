@@ -231,10 +231,11 @@ if __name__ == "__main__":
     ap.add_argument("--exe", default="", help="another build of the binary, e.g. fqtk_amd/bin/fqtk.thread (python -m fqtk_amd.build --sanitize=thread): "
                                               "its stderr is scanned for sanitizer reports")
     ap.add_argument("--host-output", action="store_true", help="every run with --host-output (records formatted and compressed by the host threads; default: on the device)")
+    ap.add_argument("--devices", default="", help="every run with --devices <this> (e.g. 0,0: two record pipelines on one GPU; compressed inputs at their home pipelines)")
     a = ap.parse_args()
     if a.exe:
         EXE = os.path.abspath(a.exe)
-    EXTRA[:] = ["--host-output"] if a.host_output else []
+    EXTRA[:] = (["--host-output"] if a.host_output else []) + (["--devices", a.devices] if a.devices else [])
     rng = random.Random(a.seed)
     tmp = tempfile.mkdtemp(prefix="fqtk_soak_", dir="/tmp")
     tally = {}
