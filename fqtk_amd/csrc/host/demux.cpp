@@ -963,7 +963,10 @@ bool gpu_output_supported(const Plan &plan, std::string *why) {
                     const uint32_t sym_base = (uint32_t)std::max<long>(1, std::min<long>(2048, env_num("FQTK_GZ_DEVICE_SYMS", 8)));
                     uint32_t sym_per_byte = sym_base;   // room per compressed byte: x4 when a chunk runs out, back down by halves after 4 stretches that fit (a run of poly-N
                                                         // reads with constant qualities deflates 1000 : 1 for a megabyte; the rest of the file must not pay for it)
-                    size_t stretches_that_fit = 0;
+                    size_t stretches_that_fit = 0, fits_at_floor = 0;
+                    uint32_t sym_floor = sym_base;     // ... but not below twice the room that last ran out: an input that deflates 15 : 1 throughout (an index read's file through
+                                                       // `gzip -6`) would otherwise come back down to 8, lose a stretch, go up again -- every fifth stretch; the floor itself halves after
+                                                       // 32 stretches that fit at it, so a burst's room is given back in the end
                     size_t n_stretches = 0, n_chunks_total = 0, n_refused = 0, n_fallbacks = 0;
                     uint64_t fallback_text = 0;
                     size_t &pos = bf.pos;           // byte of the current member's header
@@ -1151,8 +1154,17 @@ bool gpu_output_supported(const Plan &plan, std::string *why) {
                             }
                             const bool more_room = out_of_room && sym_per_byte < 2048;
                             if (more_room) sym_per_byte = std::min<uint32_t>(2048, sym_per_byte * 4);   // (the next stretches are given more room)
-                            if (out_of_room) stretches_that_fit = 0;
-                            else if (sym_per_byte > sym_base && ++stretches_that_fit >= 4) { sym_per_byte = std::max(sym_base, sym_per_byte / 2); stretches_that_fit = 0; }
+                            if (out_of_room) {
+                                const uint32_t failed = more_room ? sym_per_byte / 4u : sym_per_byte;   // (the room the stretch had)
+                                sym_floor = std::max(sym_floor, std::min<uint32_t>(2048u, failed * 2u));
+                                stretches_that_fit = fits_at_floor = 0;
+                            } else if (sym_per_byte > sym_floor) {
+                                if (++stretches_that_fit >= 4) { sym_per_byte = std::max(sym_floor, sym_per_byte / 2); stretches_that_fit = 0; }
+                            } else if (sym_floor > sym_base && ++fits_at_floor >= 32) {
+                                sym_floor = std::max(sym_base, sym_floor / 2);
+                                sym_per_byte = std::max(sym_floor, sym_per_byte / 2);
+                                fits_at_floor = 0;
+                            }
                             if (n_accept == 0) {
                                 // chunk 0 starts at a verified boundary and did not get through one block.  Out of room: again with more, while there
                                 // is more to give; anything else (no block start in the whole stretch and the block longer than it, a parse error):
