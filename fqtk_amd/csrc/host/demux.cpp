@@ -17,8 +17,11 @@
 #include <sys/mman.h>
 #include <sys/resource.h>
 #include <malloc.h>
+#include <sys/prctl.h>
 #include <sys/stat.h>
+#include <sys/wait.h>
 #include <unistd.h>
+#include <csignal>
 
 #include <algorithm>
 #include <atomic>
@@ -92,11 +95,45 @@ std::atomic<bool> g_dying{false};
 // Everything is on disk and closed.  The process ends here: tearing the HIP runtime down through destructors and
 // atexit handlers costs ~0.25 s and frees nothing the OS does not free.  FQTK_CLEAN_EXIT=1 takes the long way (tools
 // that write their output at exit, like rocprofv3, need it).
+// ... and even `_Exit` takes the kernel 0.1-0.5 s: the process's pages behind the HIP runtime's queues (2.2 GB), its page-locked buffers (0.2 ms
+// per MB to let go, as to lock) and 20 GB of device mappings are taken apart before `wait()` returns to whoever started the run -- a fifth of a
+// 64 M-template run's wall clock (round 5: "after the last line 0.25-0.5 s").  So the run happens in a CHILD of the process the user started
+// (main() forks before anything else exists); when every file is closed the child says so down a pipe, closes its standard streams and ends, and the
+// parent returns at once with the child's status while the kernel clears up behind it.  A run that fails, or is killed, ends the old way: the parent
+// waits for the child and passes its status on.  FQTK_FOREGROUND=1 (and FQTK_CLEAN_EXIT=1, which tools that write at exit need): no child.
+int g_done_fd = -1;
 [[noreturn]] void end_process() {
     std::fflush(stdout);
     std::fflush(stderr);
     if (env_on("FQTK_CLEAN_EXIT")) std::exit(0);
+    if (g_done_fd >= 0) {
+        const unsigned char ok = 0;
+        if (::write(g_done_fd, &ok, 1) == 1) { ::close(g_done_fd); ::close(0); ::close(1); ::close(2); }
+    }
     std::_Exit(0);
+}
+
+pid_t g_child = -1;
+void forward_signal(int sig) { if (g_child > 0) ::kill(g_child, sig); }
+// The parent's whole life: wait for the child's "done" byte (-> 0) or for its end (-> its status).
+[[noreturn]] void supervise(pid_t child, int fd) {
+    g_child = child;
+    for (int sig : {SIGINT, SIGTERM, SIGHUP, SIGQUIT}) {
+        struct sigaction sa;
+        std::memset(&sa, 0, sizeof sa);
+        sa.sa_handler = forward_signal;
+        sigaction(sig, &sa, nullptr);
+    }
+    unsigned char b = 0;
+    ssize_t r;
+    do r = ::read(fd, &b, 1); while (r < 0 && errno == EINTR);
+    if (r == 1) std::_Exit((int)b);
+    int st = 0;
+    pid_t w;
+    do w = ::waitpid(child, &st, 0); while (w < 0 && errno == EINTR);
+    if (w == child && WIFEXITED(st)) std::_Exit(WEXITSTATUS(st));
+    if (w == child && WIFSIGNALED(st)) { signal(WTERMSIG(st), SIG_DFL); ::raise(WTERMSIG(st)); std::_Exit(128 + WTERMSIG(st)); }
+    std::_Exit(1);
 }
 
 bool g_timing = false;   // FQTK_TIMING: clocks of the stages in the log
@@ -1470,6 +1507,20 @@ bool gpu_output_supported(const Plan &plan, std::string *why) {
 
 int main(int argc, char **argv) {
     now_s();
+    if (!env_on("FQTK_FOREGROUND") && !env_on("FQTK_CLEAN_EXIT") && argc >= 2 && std::string(argv[1]) == "demux") {
+        int fds[2];
+        if (::pipe(fds) == 0) {
+            const pid_t pid = ::fork();
+            if (pid > 0) { ::close(fds[1]); supervise(pid, fds[0]); }
+            if (pid == 0) {
+                ::close(fds[0]);
+                ::fcntl(fds[1], F_SETFD, FD_CLOEXEC);
+                g_done_fd = fds[1];
+                ::prctl(PR_SET_PDEATHSIG, SIGTERM);   // (a parent that is killed outright takes the run with it)
+                if (::getppid() == 1) std::_Exit(1);   // (... also one that was gone before the line above)
+            } else { ::close(fds[0]); ::close(fds[1]); }   // (no child to be had: the run happens here)
+        }
+    }
     // Batches of decoded input and blocks of output are tens of MB each and come and go all the time: by default
     // glibc maps and unmaps every one of them, and every fresh page is a fault plus 4 KB of zeroes (measured on
     // gzip inputs: a third of the reader threads' time).  Keep them on the heap, where a freed block is reused.
