@@ -446,7 +446,8 @@ def scope_e(n, threads, gz, tmp, expect_counts=None, extra_args=(), repeat_first
             "extra_args": list(extra_args),
             "gz_inputs": gz, "seconds": round(dt, 3), "M_templates_per_s": round(n / dt / 1e6, 3),
             "M_templates_per_s_steady": steady,
-            "seconds_is": "wall clock of the whole process: start-up, GPU bring-up, demux, flush, exit",
+            "seconds_is": "wall clock of the command: start-up, GPU bring-up, demux, flush, every file closed, return to the caller (since round 6 the run happens in a "
+                          "child process that reports when every file is closed; the kernel's clearing-up of its GPU context, 0.15-0.3 s, goes on behind the return)",
             "M_input_records_per_s": round(4 * n / dt / 1e6, 3),
             "input_MB": round(in_bytes / 1e6, 1), "output_MB": round(out_bytes / 1e6, 1), "output_files": len(out_files),
             "peak_rss_MB": peak_rss_mb,
