@@ -650,8 +650,9 @@ bool gpu_output_supported(const Plan &plan, std::string *why) {
         for (const ReadSegment &g : r.segments)
             segments.push_back(fqtk_demux_segment{(uint32_t)g.offset, g.has_length() ? (int32_t)g.length : -1, (char)g.kind});
     }
-    std::thread gpu_init([&] {
-        for (size_t g = 0; g < G; ++g) {
+    // (several devices: each is brought up by a thread of its own -- a device's context, code objects, memo and pipeline buffers take 0.17-0.22 s, and
+    //  eight of them one after another were 1.5 s before the first chunk; the first device alone first: it initialises the runtime)
+    auto bring_up = [&](size_t g) {
             if (fqtk_matcher_create(bc.data(), (uint32_t)S, L, (uint8_t)opt.max_mismatches, (uint8_t)opt.min_mismatch_delta, opt.devices[g], &matchers[g]) != FQTK_OK)
                 die(std::string("cannot create the GPU barcode matcher: ") + fqtk_last_error());
             fqtk_matcher_set_sample_ids(matchers[g], ids.data());
@@ -670,7 +671,12 @@ bool gpu_output_supported(const Plan &plan, std::string *why) {
             info("GPU barcode matcher and record pipeline ready on device %d (%llu memo entries).", opt.devices[g],
                  (unsigned long long)fqtk_matcher_memo_entries(matchers[g]));
             if (g_timing) info("(timing) anonymous resident memory: %zu MB.", rss_anon_mb());
-        }
+    };
+    std::thread gpu_init([&] {
+        bring_up(0);
+        std::vector<std::thread> rest;
+        for (size_t g = 1; g < G; ++g) rest.emplace_back(bring_up, g);
+        for (auto &t : rest) t.join();
     });
 
     // ---- readers
