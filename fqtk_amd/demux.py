@@ -191,6 +191,10 @@ class Demuxer:
         self.skipped += int(res.n_skipped)
         return [raw[int(res.file_off[c]):int(res.file_off[c + 1])] for c in range(int(res.n_files))]
 
+    def collect_begin(self, slot: int) -> None:
+        """Optional first half of collect(): the chunk's kernels are waited for and the copy home of its members starts."""
+        _check(self._lib.fqtk_demuxer_collect_begin(self._h, slot))
+
     def collect(self, slot: int) -> List[bytes]:
         res = _lib.fqtk_demux_result()
         _check(self._lib.fqtk_demuxer_collect(self._h, slot, C.byref(res)))

@@ -629,3 +629,40 @@ def test_fed_text_of_several_home_demuxers_runs_on_any_of_them(n_dev, member, mo
     d0 = ds[0]
     with pytest.raises(Exception, match="fewer lines|nothing has been fed"):
         d0.fed_cut(0, 400)
+
+
+def test_collect_in_two_halves_gives_what_collect_gives():
+    """fqtk_demuxer_collect_begin (the chunk's copy home starts) + fqtk_demuxer_collect (waits for it) == fqtk_demuxer_collect alone; a second begin is
+    a no-op, a begin on a slot nothing was submitted on is refused, and a chunk that FAILED brings nothing home but reports through collect as before."""
+    rng = np.random.default_rng(77)
+    structures, types = ["8B+T", "+T"], "T"
+    templates = make_templates(rng, 1500, BARCODES8, structures, header_kind=1)
+    want, counts, _ = expected_files(BARCODES8, 1, 2, structures, types, templates)
+    for halves in (False, True):
+        m = BarcodeMatcher(BARCODES8, 1, 2, device=0)
+        d = Demuxer(m, structures, types, max_chunk_templates=500)
+        files = [bytearray() for _ in range(d.n_files)]
+        for k, lo in enumerate(range(0, 1500, 500)):
+            d.submit(k % 3, texts_of(templates, lo, lo + 500, len(structures)), 500)
+        for k in range(3):
+            if halves:
+                d.collect_begin(k)
+                d.collect_begin(k)          # (already on its way)
+            for c, x in enumerate(d.collect(k)):
+                files[c] += x
+        for c, x in enumerate(d.flush()):
+            files[c] += x
+        for c, w in enumerate(want):
+            assert gzip.decompress(bytes(files[c]) + H_BGZF_EOF) == w, (halves, c)
+        assert np.array_equal(d.counts(), counts)
+        with pytest.raises(Exception, match="nothing was submitted"):
+            d.collect_begin(1)
+    # a chunk with a malformed record: begin succeeds and brings nothing, collect reports the record
+    m = BarcodeMatcher(BARCODES8, 1, 2, device=0)
+    d = Demuxer(m, ["8B+T"], "T", max_chunk_templates=10)
+    bad = b"@a x\nACGTACGTAA\n+\nFFFFFFFFFF\n" + b"b x\nACGTACGTAA\n+\nFFFFFFFFFF\n"
+    d.submit(0, [bad], 2)
+    d.collect_begin(0)
+    with pytest.raises(DemuxChunkError) as ei:
+        d.collect(0)
+    assert ei.value.kind == 1 and ei.value.template == 1

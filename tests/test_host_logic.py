@@ -164,3 +164,37 @@ def test_every_device_has_its_own_submit_thread_and_chunks_come_back_in_order():
         assert fn(C.c_uint64(devices), C.c_uint64(slots), C.c_uint64(n), C.c_uint64(seed), C.byref(overlap)) == 0, (devices, slots, n)
         if devices > 1 and n >= 100:
             assert overlap.value == 1, "the devices' submits never overlapped"
+
+
+def test_the_run_in_a_child_process_passes_status_and_messages_on(tmp_path):
+    """`fqtk demux` runs in a child of the process the user starts (csrc/host/demux.cpp: main, supervise, end_process): the parent returns when
+    the child reports that every file is closed -- or, when the run fails, waits for the child and passes its status on.  Without a GPU the run
+    fails at the matcher (this library has no CPU path): exit status 1, the message on stderr, the partial outputs removed -- the same with
+    FQTK_FOREGROUND=1, where no child is made.  With a GPU both forms succeed and leave the same files."""
+    import os
+    import subprocess
+    ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(ROOT, "fqtk_amd", "bin", "fqtk")
+    if not os.path.exists(exe):
+        pytest.skip("fqtk binary not built")
+    meta = tmp_path / "meta.tsv"
+    meta.write_text("sample_id\tbarcode\nS0\tACGTACGT\nS1\tTTGCAATG\n")
+    fq = tmp_path / "r.fq"
+    fq.write_text("@r1 x\nACGTACGTAAAA\n+\nFFFFFFFFFFFF\n@r2 x\nTTGCAATGCCCC\n+\nFFFFFFFFFFFF\n")
+    seen = {}
+    for name, env in (("child", {}), ("foreground", {"FQTK_FOREGROUND": "1"})):
+        out = tmp_path / name
+        r = subprocess.run([exe, "demux", "-i", str(fq), "-r", "8B+T", "-s", str(meta), "-o", str(out), "-t", "5"],
+                           capture_output=True, text=True, timeout=120, env=dict(os.environ, **env))
+        seen[name] = (r.returncode, sorted(os.listdir(out)) if out.exists() else [])
+        if r.returncode != 0:
+            assert r.returncode == 1 and "no HIP device" in r.stderr, r.stderr
+            assert not [f for f in seen[name][1] if f.endswith(".fq.gz")], "partial outputs must be removed"
+        else:
+            assert "demux-metrics.txt" in seen[name][1] and "S0.R1.fq.gz" in seen[name][1]
+    assert seen["child"] == seen["foreground"]
+    # usage errors come back through the parent as well
+    r = subprocess.run([exe, "demux", "--no-such-flag"], capture_output=True, text=True, timeout=60)
+    assert r.returncode == 1 and "unexpected argument" in r.stderr
+    r = subprocess.run([exe, "demux", "--help"], capture_output=True, text=True, timeout=60)
+    assert r.returncode == 0 and "Usage: fqtk demux" in r.stdout
