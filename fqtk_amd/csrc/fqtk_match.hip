@@ -175,7 +175,7 @@ struct fqtk_matcher {
     uint32_t *d_ldsm = nullptr;
     fqtk::LdsMemoParams ldsm{};                // image / masks / salt (m is filled per launch)
     int ldsm_kw = 0;
-    bool ldsm_pow2 = true;
+    int ldsm_form = fqtk::kLdsFormPow2;        // kLdsFormAny / kLdsFormPow2 / kLdsFormMph
     mutable std::vector<const void *> ldsm_big_lds_ok;   // kernels already allowed > 64 KiB LDS on this device
     int memo_kind_wanted = 0;                  // 0 = best available, 1 = force the HBM/L2 table (tests, A/B)
     size_t ldsm_lds_bytes = 0;                 // image + LUT (histogram added at launch)
@@ -438,7 +438,7 @@ int launch_memo_vec(const fqtk_matcher *m, fqtk::MemoParams Q, hipStream_t strea
     return FQTK_OK;
 }
 
-template <int KW, bool POW2>
+template <int KW, int FORM>
 int launch_lds_memo(const fqtk_matcher *m, fqtk::LdsMemoParams Q, hipStream_t stream, bool second_pass = false) {
     const fqtk::MatchParams &P = Q.m;
     const uintptr_t base = reinterpret_cast<uintptr_t>(P.obs);
@@ -502,7 +502,7 @@ int launch_lds_memo(const fqtk_matcher *m, fqtk::LdsMemoParams Q, hipStream_t st
 #define FQTK_LDSM_LAUNCH_I(V, RR, LENS, PF, IDX)                                                           \
     do {                                                                                                   \
         if constexpr ((V) <= 0 || KW == ((V) >= 7 ? 4 : ((V) >= 5 ? 3 : ((V) >= 3 ? 2 : 1)))) {           \
-            auto kern = fqtk::lds_memo_kernel<V, KW, RR, POW2, LENS, PF, IDX>;                             \
+            auto kern = fqtk::lds_memo_kernel<V, KW, RR, FORM, LENS, PF, IDX>;                             \
             /* > 64 KiB of dynamic LDS must be allowed per kernel AND per device: remembered per matcher */ \
             const void *fn = reinterpret_cast<const void *>(kern);                                         \
             if (shmem > 64 * 1024 &&                                                                       \
@@ -588,6 +588,23 @@ int launch_lds_memo(const fqtk_matcher *m, fqtk::LdsMemoParams Q, hipStream_t st
     return FQTK_OK;
 }
 
+// The LDS form's instantiation for this matcher's key width and table form.
+int dispatch_lds_memo(const fqtk_matcher *m, const fqtk::LdsMemoParams &Q, hipStream_t stream, bool second_pass) {
+    using namespace fqtk;
+    switch (m->ldsm_kw * 4 + m->ldsm_form) {
+        case 1 * 4 + kLdsFormPow2: return launch_lds_memo<1, kLdsFormPow2>(m, Q, stream, second_pass);
+        case 1 * 4 + kLdsFormAny: return launch_lds_memo<1, kLdsFormAny>(m, Q, stream, second_pass);
+        case 2 * 4 + kLdsFormPow2: return launch_lds_memo<2, kLdsFormPow2>(m, Q, stream, second_pass);
+        case 2 * 4 + kLdsFormAny: return launch_lds_memo<2, kLdsFormAny>(m, Q, stream, second_pass);
+        case 3 * 4 + kLdsFormPow2: return launch_lds_memo<3, kLdsFormPow2>(m, Q, stream, second_pass);
+        case 3 * 4 + kLdsFormAny: return launch_lds_memo<3, kLdsFormAny>(m, Q, stream, second_pass);
+        case 3 * 4 + kLdsFormMph: return launch_lds_memo<3, kLdsFormMph>(m, Q, stream, second_pass);
+        case 4 * 4 + kLdsFormPow2: return launch_lds_memo<4, kLdsFormPow2>(m, Q, stream, second_pass);
+        case 4 * 4 + kLdsFormAny: return launch_lds_memo<4, kLdsFormAny>(m, Q, stream, second_pass);
+        default: return fail(FQTK_EINVAL, "lds memo: no kernel for this key width and table form");
+    }
+}
+
 // Second pass of a memo launch, over the reads the memo kernel listed (a byte other than A C G T N . in them).
 // LDS form (plain A/C/G/T samples by construction): the memo again, with the reads' ambiguity codes spelled as N.
 // Table form: the scan kernel, one lane per listed read.
@@ -596,16 +613,7 @@ int launch_second_pass(const fqtk_matcher *m, const fqtk::MatchParams &P0, hipSt
         fqtk::LdsMemoParams Q = m->ldsm;
         Q.m = P0;
         Q.m.lens = nullptr;   // only reads of length L are ever listed
-        switch (m->ldsm_kw * 2 + (m->ldsm_pow2 ? 1 : 0)) {
-            case 3: return launch_lds_memo<1, true>(m, Q, stream, true);
-            case 2: return launch_lds_memo<1, false>(m, Q, stream, true);
-            case 5: return launch_lds_memo<2, true>(m, Q, stream, true);
-            case 4: return launch_lds_memo<2, false>(m, Q, stream, true);
-            case 7: return launch_lds_memo<3, true>(m, Q, stream, true);
-            case 6: return launch_lds_memo<3, false>(m, Q, stream, true);
-            case 9: return launch_lds_memo<4, true>(m, Q, stream, true);
-            default: return launch_lds_memo<4, false>(m, Q, stream, true);
-        }
+        return dispatch_lds_memo(m, Q, stream, true);
     }
     const fqtk::MatchParams &P = P0;
     const uint32_t grid = (uint32_t)m->num_cus * 8;   // a workgroup takes whole segments; empty ones cost it one scalar load
@@ -697,16 +705,7 @@ int launch_memo(const fqtk_matcher *m, const fqtk::MatchParams &P, hipStream_t s
     if (m->use_cache && m->d_ldsm && m->memo_kind_wanted != 1) {
         fqtk::LdsMemoParams Q = m->ldsm;
         Q.m = P;
-        switch (m->ldsm_kw * 2 + (m->ldsm_pow2 ? 1 : 0)) {
-            case 3: return launch_lds_memo<1, true>(m, Q, stream);
-            case 2: return launch_lds_memo<1, false>(m, Q, stream);
-            case 5: return launch_lds_memo<2, true>(m, Q, stream);
-            case 4: return launch_lds_memo<2, false>(m, Q, stream);
-            case 7: return launch_lds_memo<3, true>(m, Q, stream);
-            case 6: return launch_lds_memo<3, false>(m, Q, stream);
-            case 9: return launch_lds_memo<4, true>(m, Q, stream);
-            default: return launch_lds_memo<4, false>(m, Q, stream);
-        }
+        return dispatch_lds_memo(m, Q, stream, false);
     }
     if (m->use_cache && m->d_memo) {
         fqtk::MemoParams Q;
@@ -909,13 +908,25 @@ int build_lds_memo(fqtk_matcher *m, const std::vector<fqtk::LdsEntry> &ents,
 #else
     fqtk::LdsMemoPlan plan = fqtk::plan_lds_memo(m->S, m->L, ents, enc, salt_offset);
 #endif
+    // four-byte cuckoo slots have no room for it (12+12 dual indexes of 384 samples): three-byte entries behind a perfect hash.
+    // FQTK_LDS_MPH=0: never (the HBM/L2 table serves such shapes, as before round 6); =2: wherever it can be planned (A/B)
+    {
+        const char *e = std::getenv("FQTK_LDS_MPH");
+        const int mode = e ? std::atoi(e) : 1;
+        if ((mode == 1 && !plan.ok) || mode == 2) {
+            fqtk::LdsMemoPlan mph = fqtk::plan_lds_memo_mph(m->S, m->L, ents, enc, salt_offset);
+            if (mph.ok) plan = std::move(mph);
+        }
+    }
     if (!plan.ok) return FQTK_OK;   // not of that shape / does not fit: the HBM/L2 table serves
     HIP_TRY(hipMalloc(reinterpret_cast<void **>(&m->d_ldsm), plan.image.size() * 4));
     HIP_TRY(hipMemcpy(m->d_ldsm, plan.image.data(), plan.image.size() * 4, hipMemcpyHostToDevice));
     m->ldsm.image = m->d_ldsm;
-    m->ldsm.slot_mask_b = plan.slot_mask_b;
+    m->ldsm.slot_mask_b = plan.mph ? plan.bucket_mask : plan.slot_mask_b;
+    m->ldsm.t8_off_b = plan.t8_off_b;
+    m->ldsm.aux_off_b = plan.aux_off_b;
     m->ldsm.n_slots = plan.n_slots;
-    m->ldsm_pow2 = plan.pow2;
+    m->ldsm_form = plan.mph ? fqtk::kLdsFormMph : (plan.pow2 ? fqtk::kLdsFormPow2 : fqtk::kLdsFormAny);
     m->ldsm.idx_bits = plan.idx_bits;
     m->ldsm.image_words = (uint32_t)plan.image.size();
     m->ldsm.skey_off_b = plan.skey_off_b;

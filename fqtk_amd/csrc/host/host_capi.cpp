@@ -232,7 +232,9 @@ int64_t fqtk_host_load_samples(const char *path, char *err, size_t errcap) {
 
 
 // Plans the LDS-resident memo from `n_ents` (key[4], val) entries and the S x L encoded sample barcodes.
-// meta = {ok, n_slots, slot_mask_b, idx_bits, skey_off_b, salt, kw, key_stride, pow2, image_words}.
+// meta (16 words) = {ok, n_slots, slot_mask_b, idx_bits, skey_off_b, salt, kw, key_stride, pow2, image_words,
+//                    mph, t8_off_b, aux_off_b, bucket_mask, max_displacement, 0}.
+// salt_trials < 0: the minimal-perfect-hash form (plan_lds_memo_mph) instead of the cuckoo form.
 // Returns 0 (also when the memo is not of the LDS shape: meta[0] = 0), -2 if `image` is too small.
 int fqtk_host_plan_lds_memo(uint32_t S, uint32_t L, const uint8_t *enc, uint64_t n_ents, const uint32_t *keys,
                             const uint32_t *vals, uint32_t *image, uint64_t cap_words, uint32_t *meta,
@@ -244,9 +246,11 @@ int fqtk_host_plan_lds_memo(uint32_t S, uint32_t L, const uint8_t *enc, uint64_t
         for (int w = 0; w < 4; ++w) ents[i].k[w] = keys[4 * i + w];
         ents[i].val = vals[i];
     }
-    const fqtk::LdsMemoPlan p = fqtk::plan_lds_memo(S, L, ents, e, salt_offset, salt_trials);
-    const uint32_t m[10] = {p.ok ? 1u : 0u, p.n_slots, p.slot_mask_b, p.idx_bits, p.skey_off_b, p.salt,
-                            (uint32_t)p.kw, (uint32_t)p.key_stride, p.pow2 ? 1u : 0u, (uint32_t)p.image.size()};
+    const fqtk::LdsMemoPlan p = salt_trials < 0 ? fqtk::plan_lds_memo_mph(S, L, ents, e, salt_offset)
+                                                : fqtk::plan_lds_memo(S, L, ents, e, salt_offset, salt_trials);
+    const uint32_t m[16] = {p.ok ? 1u : 0u, p.n_slots, p.slot_mask_b, p.idx_bits, p.skey_off_b, p.salt,
+                            (uint32_t)p.kw, (uint32_t)p.key_stride, p.pow2 ? 1u : 0u, (uint32_t)p.image.size(),
+                            p.mph ? 1u : 0u, p.t8_off_b, p.aux_off_b, p.bucket_mask, p.max_displacement, 0u};
     std::memcpy(meta, m, sizeof m);
     if (!p.ok) return 0;
     if (p.image.size() > cap_words) return -2;
@@ -261,6 +265,7 @@ void fqtk_host_lds_memo_lookup(const uint32_t *image, const uint32_t *meta, uint
     p.image.assign(image, image + meta[9]);
     p.n_slots = meta[1]; p.slot_mask_b = meta[2]; p.idx_bits = meta[3]; p.skey_off_b = meta[4];
     p.salt = meta[5]; p.kw = (int)meta[6]; p.key_stride = (int)meta[7]; p.pow2 = meta[8] != 0;
+    p.mph = meta[10] != 0; p.t8_off_b = meta[11]; p.aux_off_b = meta[12]; p.bucket_mask = meta[13];
     for (uint64_t i = 0; i < n; ++i) out[i] = fqtk::lds_memo_lookup(p, keys + 4 * i);
 }
 

@@ -27,6 +27,11 @@
 //
 // One workgroup of 1024 lanes per CU (two when the table is small): the table is loaded once per
 // workgroup; without gathers 16 waves/CU stream as fast as 32 (measured).
+//
+// FORM of the entry table (a template parameter): kLdsFormAny / kLdsFormPow2 = the three-choice cuckoo table above, its slot count
+// any number / a power of two; kLdsFormMph (round 6, three key words) = a minimal perfect hash over three-byte entries
+// (memo_hash.hpp, lds_memo_plan.hpp plan_lds_memo_mph): ds_read_u16 of the key's bucket displacement, ds_read_u16 + ds_read_u8 of
+// the ONE slot the key can live in, the same check against the sample's key -- for the tables whose four-byte slots overflow LDS.
 #pragma once
 #include <type_traits>
 
@@ -38,6 +43,7 @@ namespace fqtk {
 #define FQTK_LDS_BLOCK 1024
 #endif
 constexpr int kLdsBlock = FQTK_LDS_BLOCK;
+constexpr int kLdsFormAny = 0, kLdsFormPow2 = 1, kLdsFormMph = 2;
 // Developer ablations of the look-up (tools/ab_ldsm_ablate.sh), compile-time: 1 = no table look-up at all (the
 // result is a fold of the key), 2 = no histogram, 4 = the first candidate is taken unverified.  0 in the product.
 #ifndef FQTK_LDSM_ABL
@@ -46,7 +52,7 @@ constexpr int kLdsBlock = FQTK_LDS_BLOCK;
 struct LdsMemoParams {
     MatchParams m;
     const uint32_t *image;    // [n_slots] entries, then (S + 1) sample keys of key_stride words each
-    uint32_t slot_mask_b;     // (n_slots - 1) << 2: byte-address mask of the entry table (power-of-two tables)
+    uint32_t slot_mask_b;     // (n_slots - 1) << 2: byte-address mask of the entry table (power-of-two tables); kLdsFormMph: buckets - 1
     uint32_t n_slots;         // slot count (any-size tables: slot = hash16 * n_slots >> 16)
     uint32_t idx_bits;        // IB
     uint32_t image_words;     // dwords to stage into LDS
@@ -55,6 +61,8 @@ struct LdsMemoParams {
     uint32_t hist_shift;      // the LDS histogram holds 1 << hist_shift copies of every bin (lane & mask picks one):
                               // with few samples the lanes of a wave pile up on a few counters, and same-address
                               // LDS atomics of one instruction run one after the other
+    uint32_t t8_off_b;        // kLdsFormMph: byte offset of the entries' third bytes (the first two, 16-bit words, sit at byte 0) ...
+    uint32_t aux_off_b;       // ... and of the buckets' 16-bit displacements
 };
 
 // Raw LDS accesses by BYTE ADDRESS.  The kernel has no static LDS, so its dynamic LDS starts at address
@@ -65,6 +73,12 @@ typedef __attribute__((address_space(3))) const u32x2v lds_u2;
 typedef __attribute__((address_space(3))) const u32x4v lds_u4;
 __device__ __forceinline__ uint32_t lds_word(uint32_t byte_addr) {
     return *reinterpret_cast<lds_u32 *>((uintptr_t)byte_addr);
+}
+__device__ __forceinline__ uint32_t lds_half(uint32_t byte_addr) {
+    return *reinterpret_cast<__attribute__((address_space(3))) const uint16_t *>((uintptr_t)byte_addr);
+}
+__device__ __forceinline__ uint32_t lds_byte(uint32_t byte_addr) {
+    return *reinterpret_cast<__attribute__((address_space(3))) const uint8_t *>((uintptr_t)byte_addr);
 }
 __device__ __forceinline__ void lds_atomic_inc(uint32_t byte_addr) {
     __hip_atomic_fetch_add(reinterpret_cast<__attribute__((address_space(3))) uint32_t *>((uintptr_t)byte_addr), 1u,
@@ -86,10 +100,11 @@ __device__ __forceinline__ uint32_t lane_select(uint64_t mask, uint32_t a, uint3
 // of the worklist it owns, 64 reads at a time -- spells their ambiguity codes as N (spell_ambiguity_codes_as_n:
 // this form exists for plain A/C/G/T samples only) and looks them up like any other read.  What is left
 // non-canonical then (bytes of no IUPAC meaning) is scanned in place by its wave.
-template <int VEC, int KW, int R, bool POW2, bool LENS = false, bool PF = false, bool INDEXED = false>   // LENS: see memo_kernel
+template <int VEC, int KW, int R, int FORM, bool LENS = false, bool PF = false, bool INDEXED = false>   // LENS: see memo_kernel
 __global__ __launch_bounds__(kLdsBlock) __attribute__((amdgpu_waves_per_eu(4, 8)))
 void lds_memo_kernel(const LdsMemoParams Q) {
     static_assert(!INDEXED || (VEC <= 0 && !LENS && !PF), "the second pass gathers single rows");
+    static_assert(FORM != kLdsFormMph || KW == 3, "the perfect-hash form is planned for three key words");
     const MatchParams &P = Q.m;
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
     // LDS: [entry table | sample keys | spread LUT (fallback scan) | histogram]; the entry table sits
@@ -239,15 +254,33 @@ void lds_memo_kernel(const LdsMemoParams Q) {
             }
             return diff == 0 ? (e & res_mask) : kMemoEmpty;
         };
+        // the same check for a three-byte entry of the perfect-hash form: idx 0-8 | best 9 | next 10-14 | xnib 15-17 | pos 18-22
+        auto verify_mph = [&](int r, uint32_t e) -> uint32_t {
+            const uint32_t ka = Q.skey_off_b + (e & ((1u << kMphIdxBits) - 1u)) * (KS * 4u);
+            const uint32_t tsh = __builtin_amdgcn_ubfe(e, 15, 3) << ((e >> 16) & 28u);
+            const u32x4v sk = *reinterpret_cast<lds_u4 *>((uintptr_t)ka);
+            const bool w1 = (e & (1u << 21)) != 0, w2 = (e & (1u << 22)) != 0;
+            const uint32_t diff = (key[r][0] ^ sk.x ^ ((w1 || w2) ? 0u : tsh)) | (key[r][1] ^ sk.y ^ ((w1 && !w2) ? tsh : 0u)) |
+                                  (key[r][2] ^ sk.z ^ ((w2 && !w1) ? tsh : 0u));
+            return diff == 0 ? mph_entry_result(e) : kMemoEmpty;
+        };
 #pragma unroll
         for (int r = 0; r < R; ++r) {
             encode_nibbles<NWD, (VEC >= 1), false>(words[r], kc, kv, key[r], bflag[r]);
             if constexpr ((FQTK_LDSM_ABL & 1) != 0) { res[r] = (key[r][0] ^ (KW >= 2 ? key[r][1] : 0u)) | 0xFFFFu; continue; }
+            if constexpr (FORM == kLdsFormMph) {
+                uint32_t ha, hb;
+                mph_hashes(key[r][0], key[r][1], key[r][2], 0u, Q.salt, ha, hb);
+                const uint32_t d = lds_half(Q.aux_off_b + ((ha & Q.slot_mask_b) << 1));
+                const uint32_t slot = mph_slot(ha, hb, d, Q.n_slots);
+                res[r] = verify_mph(r, lds_half(slot << 1) | (lds_byte(Q.t8_off_b + slot) << 16));
+                continue;
+            }
             uint32_t h1, h2, h3, fps;
             memo_hash3(key[r][0], KW >= 2 ? key[r][1] : 0u, KW >= 3 ? key[r][2] : 0u, KW >= 4 ? key[r][3] : 0u, Q.salt, h1, h2, h3, fps);
             (void)h3;
             uint32_t a1, a2, a3;
-            lds_slots(POW2, h1, h2, Q.slot_mask_b, Q.n_slots, a1, a2, a3);
+            lds_slots(FORM == kLdsFormPow2, h1, h2, Q.slot_mask_b, Q.n_slots, a1, a2, a3);
             const uint32_t e1 = lds_word(a1), e2 = lds_word(a2), e3 = lds_word(a3);
             // fingerprint matches as LANE MASKS (SGPR pairs): the "more than one match" test below is
             // then scalar ALU + one scalar branch instead of per-lane selects

@@ -233,4 +233,42 @@ FQTK_HD inline void lds_slots(bool pow2, uint32_t h, uint32_t g, uint32_t slot_m
     else { a1 = lds_slot_any(h & 0xFFFFu, n_slots); a2 = lds_slot_any(g & 0xFFFFu, n_slots); a3 = lds_slot_any(h >> 16, n_slots); }
 }
 
+// ---- LDS form with a minimal perfect hash: ONE probe, three-byte entries (round 6) ------------------------------------------------
+// For plain-A/C/G/T tables whose entries do not fit one CU's LDS as four-byte cuckoo slots at a workable load -- 384 samples x 24 bases
+// (a 12+12 dual index): 37 248 entries, 175 KB at load 0.85.  A hash-and-displace function built on the host (lds_memo_plan.hpp) sends
+// every key of the memo to a slot of its own in a table 3 % larger than the key set, so an entry needs no fingerprint: the read's one
+// candidate is verified against its sample's key exactly like a cuckoo candidate (a read that is NOT in the memo lands on some other
+// key's entry, or an empty one, and fails that check).  Entry, 24 bits: [0, 9) idx | 9 best | 10-14 next | 15-17 xnib | 18-22 pos
+// (the nibble that differs from the sample's, and where); stored as a 16-bit and an 8-bit array so that no read is unaligned.
+constexpr uint32_t kMphIdxBits = 9;                    // S + 1 <= 512
+constexpr uint32_t kMphMaxDisplacement = 65535;        // a bucket's displacement is a 16-bit word
+FQTK_HD constexpr uint32_t mph_entry_fields(uint32_t idx, uint32_t best, uint32_t next, uint32_t xnib, uint32_t pos) {
+    return idx | (best << 9) | (next << 10) | (xnib << 15) | (pos << 18);
+}
+FQTK_HD constexpr uint32_t mph_entry_result(uint32_t e) {   // the fqtk_match_t word: idx | best << 16 | next << 24
+    return (e & 511u) | (((e >> 9) & 1u) << 16) | (((e >> 10) & 31u) << 24);
+}
+// two independent 32-bit hashes of the key (the limb sums of the hash-table form, a salt in each)
+FQTK_HD inline void mph_hashes(uint32_t k0, uint32_t k1, uint32_t k2, uint32_t k3, uint32_t salt, uint32_t &a, uint32_t &b) {
+    a = memo_limb_sum(k0, k1, k2, k3) + salt;
+    a ^= a >> 15;
+    a = mul24(a, 0x2C1B3Du) + (a >> 9);
+    a ^= a >> 13;
+    b = memo_limb_sum2(k0, k1, k2, k3) + (salt ^ 0xA54FF53Au);
+    b ^= b >> 14;
+    b = mul24(b, 0x9E3779u) + (b >> 10);
+    b ^= b >> 12;
+}
+FQTK_HD inline uint32_t mph_mulhi(uint32_t x, uint32_t y) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __umulhi(x, y);
+#else
+    return (uint32_t)(((uint64_t)x * y) >> 32);
+#endif
+}
+// bucket = a & bucket_mask; the bucket's displacement d (16 bits) moves all its keys together: slot = floor((b + d * step) * n_slots / 2^32)
+FQTK_HD inline uint32_t mph_slot(uint32_t a, uint32_t b, uint32_t d, uint32_t n_slots) {
+    return mph_mulhi(b + mul24(d, (a >> 9) | 1u), n_slots);
+}
+
 }  // namespace fqtk

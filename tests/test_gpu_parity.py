@@ -193,6 +193,37 @@ def test_lds_form_with_any_size_table_384_samples_x_20_bases():
         _compare(bcs, 1, 2, obs)
 
 
+@pytest.mark.parametrize("S,L", [(384, 24), (440, 23), (300, 17)])
+def test_lds_form_behind_a_perfect_hash_for_12_plus_12_dual_indexes(S, L, monkeypatch):
+    """384 samples x 24 bases: 37 248 memo entries are more four-byte cuckoo slots than LDS has; round 6 gives such tables an LDS
+    form of three-byte entries behind a minimal perfect hash (lds_memo_plan.hpp plan_lds_memo_mph) -- the HBM/L2 table served them
+    before.  Packed and padded strides, reads with ambiguity codes / junk (second pass) and no-calls, counts; and the same reads
+    through the table form.  FQTK_LDS_MPH=2 selects the form wherever it can be planned (300 x 17 fits the cuckoo form too)."""
+    rng = np.random.default_rng(S + L)
+    seen = set()
+    while len(seen) < S:
+        seen.add("".join(rng.choice(list("ACGT"), size=L)))
+    bcs = sorted(seen)
+    monkeypatch.setenv("FQTK_LDS_MPH", "0")
+    if (S, L) == (384, 24):
+        assert BarcodeMatcher(bcs, 1, 2).memo_kind == BarcodeMatcher.MEMO_TABLE, "no other LDS form has room for this table"
+    monkeypatch.setenv("FQTK_LDS_MPH", "2" if S == 300 else "1")
+    m = BarcodeMatcher(bcs, 1, 2)
+    assert m.memo_kind == BarcodeMatcher.MEMO_LDS and m.memo_entries == S * (1 + 4 * L)
+    n = 50021
+    noise = np.frombuffer(b"ACGTNacgtn.R-", dtype=np.uint8)
+    for stride in (L, (L + 3) // 4 * 4, L + 5):
+        obs = noise[rng.integers(0, len(noise), size=(n, stride))]
+        bc = np.stack([np.frombuffer(b.encode(), dtype=np.uint8) for b in bcs])[rng.integers(0, S, size=n)]
+        keep = rng.random((n, L)) < 0.975
+        obs[:, :L] = np.where(keep, bc, obs[:, :L])
+        _compare(bcs, 1, 2, obs)
+        # a variable-length batch (the LENS instantiations): shorter reads are None whatever their bytes say
+        lens = np.where(rng.random(n) < 0.9, L, rng.integers(0, L + 1, size=n)).astype(np.uint32)
+        got, _ = _compare(bcs, 1, 2, obs, lens)
+        assert np.all(got["idx"][lens < L] == 0xFFFF) and (got["idx"][lens == L] != 0xFFFF).mean() > 0.4
+
+
 def test_memo_path_handles_non_canonical_reads_in_every_lane_position():
     """IUPAC / unknown bytes in the READ cannot use the memo: the wave-cooperative fallback must give
     the scan kernel's answer wherever such reads sit in the wavefront, including all 64 lanes."""

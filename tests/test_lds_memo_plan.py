@@ -46,7 +46,7 @@ def _plan(barcodes, mm, delta, salt_offset=0, salt_trials=8):
     keys = np.ascontiguousarray(_keys(cand))
     enc = np.ascontiguousarray(np.stack([O.ENC[np.frombuffer(b.upper().encode(), dtype=np.uint8)] for b in barcodes]).astype(np.uint8))
     image = np.zeros(48 * 1024, dtype=np.uint32)
-    meta = np.zeros(10, dtype=np.uint32)
+    meta = np.zeros(16, dtype=np.uint32)
     lib = hostlib.lib()
     rc = lib.fqtk_host_plan_lds_memo(C.c_uint32(S), C.c_uint32(L), enc.ctypes.data_as(C.c_void_p), C.c_uint64(len(keys)),
                                      keys.ctypes.data_as(C.c_void_p), np.ascontiguousarray(vals).ctypes.data_as(C.c_void_p),
@@ -132,3 +132,45 @@ def test_table_that_needs_every_lds_slot_uses_the_any_size_mapping():
     idx, best, nxt, _ = O.RefLiteral(barcodes, 1, 2, True).assign_batch(probe)
     want = np.where(idx == O.NONE_IDX, NONE, idx.astype(np.uint32) | (best.astype(np.uint32) << 16) | (nxt.astype(np.uint32) << 24)).astype(np.uint32)
     assert np.array_equal(_lookup(meta, image, _keys(probe)), want)
+
+
+def _random_barcodes(n, L, seed):
+    rng = np.random.default_rng(seed)
+    seen = set()
+    while len(seen) < n:
+        seen.add("".join(rng.choice(list("ACGT"), size=L)))
+    return sorted(seen), rng
+
+
+@pytest.mark.parametrize("S,L", [(384, 24), (400, 22), (60, 17), (2, 24)])
+def test_minimal_perfect_hash_form_for_tables_the_cuckoo_slots_have_no_room_for(S, L):
+    """384 samples x 24 bases (12+12 dual index): 37 248 entries are 170 KB of four-byte cuckoo slots at a workable load -- no LDS
+    form until round 6.  plan_lds_memo_mph: a hash-and-displace perfect hash (one 16-bit displacement per bucket), three-byte
+    entries, ONE candidate per read, verified against its sample's key.  Every stored key resolves to its entry; everything else
+    -- neighbours two substitutions away, random strings -- to None."""
+    barcodes, rng = _random_barcodes(S, L, 7 * S + L)
+    if S == 384 and L == 24:
+        assert _plan(barcodes, 1, 2)[0][0] == 0, "the cuckoo form has no room for this table (else this form is not needed)"
+    meta, image, cand, keys, vals = _plan(barcodes, 1, 2, salt_trials=-1)
+    assert meta[0] == 1 and meta[10] == 1 and meta[6] == 3 and meta[8] == 0
+    n_slots, t8_off, aux_off, skey_off, buckets = int(meta[1]), int(meta[11]), int(meta[12]), int(meta[4]), int(meta[13]) + 1
+    assert len(vals) <= n_slots and buckets & (buckets - 1) == 0
+    assert 2 * n_slots <= t8_off and t8_off + n_slots <= aux_off and aux_off + 2 * buckets <= skey_off and skey_off % 16 == 0
+    assert int(meta[9]) * 4 == skey_off + (S + 1) * 16
+    assert int(meta[9]) * 4 + 1024 + (S + 1) * 4 <= 160 * 1024
+    assert np.array_equal(_lookup(meta, image, keys), vals)
+    n = 20000
+    rnd = np.frombuffer(b"ACGTN", dtype=np.uint8)[rng.integers(0, 5, size=(n, L))]
+    near = cand[rng.integers(0, len(cand), n)].copy()
+    near[np.arange(n), rng.integers(0, L, n)] = np.frombuffer(b"ACGTN", dtype=np.uint8)[rng.integers(0, 5, n)]
+    probe = np.concatenate([rnd, near])
+    idx, best, nxt, _ = O.RefLiteral(barcodes, 1, 2, True).assign_batch(probe)
+    want = np.where(idx == O.NONE_IDX, NONE, idx.astype(np.uint32) | (best.astype(np.uint32) << 16) | (nxt.astype(np.uint32) << 24)).astype(np.uint32)
+    assert np.array_equal(_lookup(meta, image, _keys(probe)), want)
+
+
+def test_shapes_the_minimal_perfect_hash_form_does_not_cover():
+    assert _plan(_random_barcodes(40, 16, 1)[0], 1, 2, salt_trials=-1)[0][0] == 0    # two key words: the cuckoo form's
+    assert _plan(_random_barcodes(40, 25, 2)[0], 1, 2, salt_trials=-1)[0][0] == 0    # four key words
+    assert _plan(_random_barcodes(512, 18, 3)[0], 1, 2, salt_trials=-1)[0][0] == 0   # S + 1 > 512: no room in the index field
+    assert _plan(["ACGTACGTACGTACGTACGN", "TTTTGGGGTTTTGGGGTTTT"], 1, 1, salt_trials=-1)[0][0] == 0   # N in a sample
