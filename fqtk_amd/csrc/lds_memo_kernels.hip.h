@@ -95,11 +95,10 @@ __device__ __forceinline__ uint32_t lane_select(uint64_t mask, uint32_t a, uint3
 // looked up, so a wave always has a load in flight while it computes.  With R = 1 this is the stream shape
 // the memory system likes best (tools/hbm_stream.hip: one 1-KiB request per wave at a time, 256 tiles = a
 // 4-MiB window sweeping the buffer) without the compute latency serialised behind every load.
-// INDEXED: the second pass.  The first pass (any instantiation without it) lists the reads that carry a byte other
-// than A C G T N . and gives them a placeholder result; this one takes the listed reads -- each wave the segments
-// of the worklist it owns, 64 reads at a time -- spells their ambiguity codes as N (spell_ambiguity_codes_as_n:
-// this form exists for plain A/C/G/T samples only) and looks them up like any other read.  What is left
-// non-canonical then (bytes of no IUPAC meaning) is scanned in place by its wave.
+// INDEXED: the second pass.  The first pass (any instantiation without it) lists the reads that carry a byte of no IUPAC
+// meaning (ambiguity codes and '.' get N's code where they stand: recode_flagged_bytes; until round 6 they were listed too)
+// and gives them a placeholder result; this one takes the listed reads -- each wave the segments of the worklist it owns, 64
+// reads at a time -- and scans them in place, a wave per read.
 template <int VEC, int KW, int R, int FORM, bool LENS = false, bool PF = false, bool INDEXED = false>   // LENS: see memo_kernel
 __global__ __launch_bounds__(kLdsBlock) __attribute__((amdgpu_waves_per_eu(4, 8)))
 void lds_memo_kernel(const LdsMemoParams Q) {
@@ -264,9 +263,33 @@ void lds_memo_kernel(const LdsMemoParams Q) {
                                   (key[r][2] ^ sk.z ^ ((w2 && !w1) ? tsh : 0u));
             return diff == 0 ? mph_entry_result(e) : kMemoEmpty;
         };
+        // ---- ASCII -> codes; the rare bytes that are not A C G T N get their codes where they stand (recode_flagged_bytes: this
+        //      form is for plain A/C/G/T samples only), behind wave-uniform branches: one test per tile, one per word of a tile that
+        //      holds such a byte, ~30 instructions for that word.  bflag is left set only by bytes of no IUPAC meaning.
+        uint32_t cw[R][NWD], xw[R][NWD];
+        uint32_t any_odd = 0;
 #pragma unroll
         for (int r = 0; r < R; ++r) {
-            encode_nibbles<NWD, (VEC >= 1), false>(words[r], kc, kv, key[r], bflag[r]);
+            encode_codes<NWD, (VEC >= 1)>(words[r], kc, kv, cw[r], xw[r]);
+            bflag[r] = 0;
+#pragma unroll
+            for (int w = 0; w < NWD; ++w) bflag[r] |= xw[r][w];
+            any_odd |= bflag[r];
+        }
+        if (__builtin_amdgcn_uicmp(any_odd, 0u, 33 /* ne */)) {   // wave-uniform
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                bflag[r] = 0;
+#pragma unroll
+                for (int w = 0; w < NWD; ++w) {
+                    if (__builtin_amdgcn_uicmp(xw[r][w], 0u, 33)) xw[r][w] = recode_flagged_bytes(words[r][w], xw[r][w], cw[r][w], ((VEC >= 1) && w < NWD - 1) ? 0x07070707u : kc[w]);
+                    bflag[r] |= xw[r][w];
+                }
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            assemble_key<NWD>(cw[r], key[r]);
             if constexpr ((FQTK_LDSM_ABL & 1) != 0) { res[r] = (key[r][0] ^ (KW >= 2 ? key[r][1] : 0u)) | 0xFFFFu; continue; }
             if constexpr (FORM == kLdsFormMph) {
                 uint32_t ha, hb;
@@ -325,8 +348,8 @@ void lds_memo_kernel(const LdsMemoParams Q) {
         if (__builtin_amdgcn_uicmp(any_bad, 0u, 33 /* ne */)) {   // wave-uniform; one test per tile
 #pragma unroll
             for (int r = 0; r < R; ++r) {
-                // '.' no-calls were looked up under N's key already: only IUPAC / junk bytes need the scan
-                const uint32_t really = (live[r] && bflag[r]) ? noncanonical_beyond_dots<NWD>(words[r], kc, kv) : 0u;
+                // no-calls and ambiguity codes were looked up under N's key already: only bytes of no IUPAC meaning need the scan
+                const uint32_t really = (live[r] && bflag[r]) ? 1u : 0u;
                 uint64_t todo = __builtin_amdgcn_uicmp(really, 0u, 33);
                 if constexpr (!INDEXED)
                     todo = defer_to_second_pass(P, work_seg, work_fill, todo, really != 0u, t * tile + local[r], res[r], words[r]);   // normally all of them
@@ -405,8 +428,6 @@ void lds_memo_kernel(const LdsMemoParams Q) {
                     for (int r = 0; r < R; ++r)
                         if (live[r]) load_words<1, VEC, kRowWords>(P, row[r], nwords, words[r]);
                 }
-#pragma unroll
-                for (int r = 0; r < R; ++r) spell_ambiguity_codes_as_n<NWD>(words[r]);
                 compute(0, words, live, res);
 #pragma unroll
                 for (int r = 0; r < R; ++r)
