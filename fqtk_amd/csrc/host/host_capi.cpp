@@ -269,6 +269,17 @@ void fqtk_host_lds_memo_lookup(const uint32_t *image, const uint32_t *meta, uint
     for (uint64_t i = 0; i < n; ++i) out[i] = fqtk::lds_memo_lookup(p, keys + 4 * i);
 }
 
+// The LDS forms' encode of n read words (four bases each; csrc/memo_hash.hpp: encode_word, then recode_flagged_bytes for a word
+// with a byte that is not A C G T N): codes[i] = the word's four codes, junk[i] = 0x80 in every byte of no IUPAC meaning.
+void fqtk_host_recode_words(const uint32_t *words, uint64_t n, uint32_t code_mask, uint32_t byte_mask, uint32_t *codes, uint32_t *junk) {
+    for (uint64_t i = 0; i < n; ++i) {
+        uint32_t c, x;
+        fqtk::encode_word(words[i], code_mask, byte_mask, c, x);
+        junk[i] = x ? fqtk::recode_flagged_bytes(words[i], x, c, code_mask) : 0u;
+        codes[i] = c;
+    }
+}
+
 // Plans the direct-indexed memo (csrc/direct_memo_plan.hpp) from n_ents no-call-free entries given as
 // unfolded key words (lo = bases 0-7, hi = bases 8-9) + result words, then replays the kernel's lookup for
 // n_q query keys: out[i] = result word or 0xFFFFFFFF, cached[i] = 1 when the LDS cache answered.

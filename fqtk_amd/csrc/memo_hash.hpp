@@ -49,6 +49,67 @@ inline uint32_t memo_code_of(char ch) {   // host mirror (the builder only sees 
     return ((uint32_t)(uint8_t)ch >> 1) & 7u;
 }
 
+// v_perm_b32: byte j of the result is byte sel[j] of the eight bytes {hi : lo} for sel[j] in 0..7, 0x00 for 12, 0xFF above 12
+// (8..11, sign bytes, are not used here).  The host's copy is for the CPU tests of the code below.
+FQTK_HD inline uint32_t perm_b32(uint32_t hi, uint32_t lo, uint32_t sel) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_perm(hi, lo, sel);
+#else
+    const uint64_t pool = ((uint64_t)hi << 32) | lo;
+    uint32_t out = 0;
+    for (int j = 0; j < 4; ++j) {
+        const uint32_t s = (sel >> (8 * j)) & 0xFFu;
+        const uint32_t byte = s <= 7 ? (uint32_t)(pool >> (8 * s)) & 0xFFu : (s > 12 ? 0xFFu : 0u);
+        out |= byte << (8 * j);
+    }
+    return out;
+#endif
+}
+// One word of a read (four bases) -> its codes c and x = nonzero in every byte that is not one of A C G T N, either case
+// (code_mask / byte_mask: 0x07070707 / 0xDFDFDFDF cut down to the word's real bases).
+FQTK_HD inline void encode_word(uint32_t w, uint32_t code_mask, uint32_t byte_mask, uint32_t &c, uint32_t &x) {
+    c = (w >> 1) & code_mask;
+    x = (w ^ perm_b32(kCodePoolHi, kCodePoolLo, c)) & byte_mask;
+}
+
+// Plain-A/C/G/T sample tables only (the LDS forms: no sample base covers two bases).  An observed base mismatches an expected
+// one iff observed_mask & ~expected_mask != 0 (bitenc.rs:432-459), so against single-base samples EVERY observed code of two
+// or more bases -- M R W S Y K V H D B as much as N -- mismatches every sample, and 'U' is 'T' (mod.rs:26-46).  The no-call
+// prefilter (barcode_matching.rs:171) cannot tell them apart either: with no N in any sample it passes reads of <=
+// max_mismatches no-calls, and a read of k such bases is k mismatches from every sample anyway (None, like the prefilter's
+// answer).  So such a read has the memo entry of the read with N's code (7) in those places.  This gives the flagged bytes of
+// ONE word (x: nonzero in them; w: the word; c: its codes) those codes where they stand, in the look-up's own pass: '.' has
+// code 7 from the encode already; the ten ambiguity letters get 7, U / u keep T's 2, by a 32-entry table of four v_perm_b32
+// pools indexed with the letter's low five bits (a selector byte above 12 -- any byte outside 0x40..0x7F -- reads 0xFF).
+// Returns 0x80 in every byte that is STILL non-canonical: a byte of no IUPAC meaning (its mask is 0: it MATCHES everything),
+// which only the scan resolves.  Rounds 2-5 listed every read with an ambiguity code for a second launch (which spelled the
+// codes as N and looked the read up again) or scanned it in place: at 1 % of reads with such a byte that cost 24 % of the
+// kernel's rate, at 10 % 49 %; now 5 % and 26 % (profiles/r06_cliff.jsonl).  Wave-uniform callers: only words in which SOME
+// lane has a flagged byte come here (~10 instructions when those are all '.', ~35 otherwise).
+FQTK_HD inline uint32_t recode_flagged_bytes(uint32_t w, uint32_t x, uint32_t &c, uint32_t code_mask) {
+    const uint32_t flagged = ((x & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | x;                       // bit 7 in every flagged byte
+    const uint32_t t = w ^ 0x2E2E2E2Eu;
+    const uint32_t rest = flagged & (((t & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | t) & 0x80808080u;   // ... that is not '.'
+#if defined(__HIP_DEVICE_COMPILE__)
+    if (!__builtin_amdgcn_uicmp(rest, 0u, 33 /* ne */)) return 0u;                        // wave-uniform: only no-call dots here
+#else
+    if (!rest) return 0u;
+#endif
+    // code by (byte & 0x1F); 0x80 = no IUPAC meaning:    @ A B C | D E F G     H I J K | L M N O     P Q R S | T U V W     X Y Z [ | \\ ] ^ _
+    constexpr uint32_t p0lo = 0x01070080u, p0hi = 0x03808007u, p1lo = 0x07808007u, p1hi = 0x80070780u;
+    constexpr uint32_t p2lo = 0x07078080u, p2hi = 0x07070202u, p3lo = 0x80800780u, p3hi = 0x80808080u;
+    const uint32_t sel = (w & 0xC7C7C7C7u) ^ 0x40404040u;                                 // letters: byte & 7; anything else: > 12
+    const uint32_t t0 = perm_b32(p0hi, p0lo, sel), t1 = perm_b32(p1hi, p1lo, sel);
+    const uint32_t t2 = perm_b32(p2hi, p2lo, sel), t3 = perm_b32(p3hi, p3lo, sel);
+    // byte j of the pool its bits 3 and 4 name: selector j picks the first word's byte j, j + 4 the second's
+    const uint32_t by3 = 0x03020100u | ((w >> 1) & 0x04040404u), by4 = 0x03020100u | ((w >> 2) & 0x04040404u);
+    const uint32_t t01 = perm_b32(t1, t0, by3), t23 = perm_b32(t3, t2, by3);
+    const uint32_t lut = perm_b32(t23, t01, by4);
+    // the table is right for the word's other bytes as well (A C G T N; '.' reads 0xFF: code 7): every code of the word from it
+    c = lut & code_mask;
+    return lut & rest;
+}
+
 // Two-choice (cuckoo) placement: a key lives in slot h1 or slot h2, nowhere else, so a lookup is two
 // INDEPENDENT loads issued back to back -- no probe loop, no divergence, one memory round trip.
 // 24-bit multiplies only: v_mul_u32_u24 / v_mad_u32_u24 issue at the full VALU rate on gfx950, while

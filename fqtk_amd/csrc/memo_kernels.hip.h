@@ -100,9 +100,7 @@ __device__ __forceinline__ void encode_codes(const uint32_t (&words)[kRowWords],
 #pragma unroll
     for (int w = 0; w < NWD; ++w) {
         const bool full = FULL && w < NWD - 1;
-        c[w] = (words[w] >> 1) & (full ? 0x07070707u : kc[w]);
-        const uint32_t e = __builtin_amdgcn_perm(kCodePoolHi, kCodePoolLo, c[w]);
-        x[w] = (words[w] ^ e) & (full ? 0xDFDFDFDFu : kv[w]);
+        encode_word(words[w], full ? 0x07070707u : kc[w], full ? 0xDFDFDFDFu : kv[w], c[w], x[w]);
     }
 }
 template <int NWD>
@@ -111,40 +109,6 @@ __device__ __forceinline__ void assemble_key(const uint32_t (&c)[NWD], uint32_t 
     key[1] = NWD >= 4 ? ((c[NWD >= 4 ? 3 : 0] << 4) | c[NWD >= 3 ? 2 : 0]) : (NWD == 3 ? c[NWD >= 3 ? 2 : 0] : 0u);
     key[2] = NWD >= 6 ? ((c[NWD >= 6 ? 5 : 0] << 4) | c[NWD >= 5 ? 4 : 0]) : (NWD == 5 ? c[NWD >= 5 ? 4 : 0] : 0u);
     key[3] = NWD >= 8 ? ((c[NWD >= 8 ? 7 : 0] << 4) | c[NWD >= 7 ? 6 : 0]) : (NWD == 7 ? c[NWD >= 7 ? 6 : 0] : 0u);
-}
-
-// Plain-A/C/G/T sample tables only (the LDS forms: no sample base covers two bases).  An observed base mismatches an expected
-// one iff observed_mask & ~expected_mask != 0 (bitenc.rs:432-459), so against single-base samples EVERY observed code of two
-// or more bases -- M R W S Y K V H D B as much as N -- mismatches every sample, and 'U' is 'T' (mod.rs:26-46).  The no-call
-// prefilter (barcode_matching.rs:171) cannot tell them apart either: with no N in any sample it passes reads of <=
-// max_mismatches no-calls, and a read of k such bases is k mismatches from every sample anyway (None, like the prefilter's
-// answer).  So such a read has the memo entry of the read with N's code (7) in those places.  This gives the flagged bytes of
-// ONE word (x: nonzero in them; w: the word; c: its codes) those codes where they stand, in the look-up's own pass: '.' has
-// code 7 from the encode already; the ten ambiguity letters get 7, U / u keep T's 2, by a 32-entry table of four v_perm_b32
-// pools indexed with the letter's low five bits (a selector byte above 12 -- any byte outside 0x40..0x7F -- reads 0xFF).
-// Returns 0x80 in every byte that is STILL non-canonical: a byte of no IUPAC meaning (its mask is 0: it MATCHES everything),
-// which only the scan resolves.  Rounds 2-5 listed every read with an ambiguity code for a second launch (which spelled the
-// codes as N and looked the read up again) or scanned it in place: at 1 % of reads with such a byte that cost 24 % of the
-// kernel's rate, at 10 % 49 %; now 5 % and 26 % (profiles/r06_cliff.jsonl).  Wave-uniform callers: only words in which SOME
-// lane has a flagged byte come here (~10 instructions when those are all '.', ~35 otherwise).
-__device__ __forceinline__ uint32_t recode_flagged_bytes(uint32_t w, uint32_t x, uint32_t &c, uint32_t code_mask) {
-    const uint32_t flagged = ((x & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | x;                       // bit 7 in every flagged byte
-    const uint32_t t = w ^ 0x2E2E2E2Eu;
-    const uint32_t rest = flagged & (((t & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | t) & 0x80808080u;   // ... that is not '.'
-    if (!__builtin_amdgcn_uicmp(rest, 0u, 33 /* ne */)) return 0u;                        // wave-uniform: only no-call dots here
-    // code by (byte & 0x1F); 0x80 = no IUPAC meaning:    @ A B C | D E F G     H I J K | L M N O     P Q R S | T U V W     X Y Z [ | \ ] ^ _
-    constexpr uint32_t p0lo = 0x01070080u, p0hi = 0x03808007u, p1lo = 0x07808007u, p1hi = 0x80070780u;
-    constexpr uint32_t p2lo = 0x07078080u, p2hi = 0x07070202u, p3lo = 0x80800780u, p3hi = 0x80808080u;
-    const uint32_t sel = (w & 0xC7C7C7C7u) ^ 0x40404040u;                                 // letters: byte & 7; anything else: > 12
-    const uint32_t t0 = __builtin_amdgcn_perm(p0hi, p0lo, sel), t1 = __builtin_amdgcn_perm(p1hi, p1lo, sel);
-    const uint32_t t2 = __builtin_amdgcn_perm(p2hi, p2lo, sel), t3 = __builtin_amdgcn_perm(p3hi, p3lo, sel);
-    // byte j of the pool its bits 3 and 4 name: selector j picks the first word's byte j, j + 4 the second's
-    const uint32_t by3 = 0x03020100u | ((w >> 1) & 0x04040404u), by4 = 0x03020100u | ((w >> 2) & 0x04040404u);
-    const uint32_t t01 = __builtin_amdgcn_perm(t1, t0, by3), t23 = __builtin_amdgcn_perm(t3, t2, by3);
-    const uint32_t lut = __builtin_amdgcn_perm(t23, t01, by4);
-    // the table is right for the word's other bytes as well (A C G T N; '.' reads 0xFF: code 7): every code of the word from it
-    c = lut & code_mask;
-    return lut & rest;
 }
 
 // (best, second) packed keys -> result word (barcode_matching.rs:150-159).

@@ -174,3 +174,41 @@ def test_shapes_the_minimal_perfect_hash_form_does_not_cover():
     assert _plan(_random_barcodes(40, 25, 2)[0], 1, 2, salt_trials=-1)[0][0] == 0    # four key words
     assert _plan(_random_barcodes(512, 18, 3)[0], 1, 2, salt_trials=-1)[0][0] == 0   # S + 1 > 512: no room in the index field
     assert _plan(["ACGTACGTACGTACGTACGN", "TTTTGGGGTTTTGGGGTTTT"], 1, 1, salt_trials=-1)[0][0] == 0   # N in a sample
+
+
+def test_codes_of_reads_with_ambiguity_codes_and_junk_bytes():
+    """The LDS forms look a read with ambiguity codes up under N's code in their places (csrc/memo_hash.hpp recode_flagged_bytes:
+    against plain A/C/G/T samples a code of two or more bases mismatches every sample, as N does; U is T) and only a byte of no
+    IUPAC meaning -- mask 0: it matches everything (bitenc.rs:432-459) -- is left for the scan.  Every byte value at every position
+    of a word, alone and among other odd bytes, against the oracle's encoding table; pad positions (masks cut down) read as absent."""
+    rng = np.random.default_rng(6)
+    others = np.frombuffer(b"ACGTNacgtn.RYKMSWBDHVUurykm#xX@[`{\x00\x7f\x80\xff-*0 ", dtype=np.uint8)
+    rows = []
+    for j in range(4):
+        for v in range(256):
+            for k in range(6):
+                b = others[rng.integers(0, len(others), 4)] if k else np.frombuffer(b"ACGT", dtype=np.uint8).copy()
+                b = b.copy()
+                b[j] = v
+                rows.append(b)
+    rows.append(np.frombuffer(b"....", dtype=np.uint8))
+    rows.append(np.frombuffer(b"NnNn", dtype=np.uint8))
+    by = np.stack(rows).astype(np.uint8)
+    words = np.ascontiguousarray(by).view("<u4").reshape(-1).copy()
+    enc = O.ENC[by]                                                    # 4-bit masks: A 1, C 2, G 4, T 8
+    want_junk = enc == 0
+    single = {1: 0, 2: 1, 8: 2, 4: 3}                                  # the key's codes: A 0, C 1, T 2, G 3; anything wider: N's 7
+    want_code = np.vectorize(lambda m: single.get(int(m), 7))(enc)
+    lib = hostlib.lib()
+    for code_mask, byte_mask, keep in ((0x07070707, 0xDFDFDFDF, 4), (0x00000707, 0x0000DFDF, 2), (0x00000007, 0x000000DF, 1)):
+        codes = np.zeros(len(words), dtype=np.uint32)
+        junk = np.zeros(len(words), dtype=np.uint32)
+        lib.fqtk_host_recode_words(words.ctypes.data_as(C.c_void_p), C.c_uint64(len(words)), C.c_uint32(code_mask), C.c_uint32(byte_mask),
+                                   codes.ctypes.data_as(C.c_void_p), junk.ctypes.data_as(C.c_void_p))
+        got_code = codes.view(np.uint8).reshape(-1, 4)
+        got_junk = junk.view(np.uint8).reshape(-1, 4)
+        assert np.all((got_junk == 0) | (got_junk == 0x80))
+        assert np.array_equal(got_junk[:, :keep] != 0, want_junk[:, :keep])
+        assert not got_junk[:, keep:].any() and not got_code[:, keep:].any()          # pad positions: absent
+        clean = ~want_junk[:, :keep].any(axis=1)                                       # (a read with a junk byte goes to the scan)
+        assert np.array_equal(got_code[:, :keep][clean], want_code[:, :keep][clean])
