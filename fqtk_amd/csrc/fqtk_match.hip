@@ -141,6 +141,7 @@ struct fqtk_matcher {
     int device = 0;
     uint32_t S = 0, L = 0, NW = 0;
     uint32_t max_mm = 0, delta = 0, max_ns = 0;
+    bool plain_samples = false;                // every base of every sample is one of A C G T
     int num_cus = 256;
     uint32_t *d_table = nullptr;
     uint32_t *d_lut = nullptr;
@@ -757,6 +758,7 @@ fqtk::MatchParams make_params(const fqtk_matcher *m, const void *d_obs, uint32_t
     P.nocall_limit = m->max_mm + m->max_ns;
     P.lds_hist = (m->S + 1 <= fqtk::kMaxLdsHist) ? 1u : 0u;
     P.scan_tab_lds = 0;   // the memo launchers turn it on when the table fits their LDS budget
+    P.plain_samples = m->plain_samples ? 1u : 0u;
     P.work = nullptr;     // launch() attaches the worklist for the memo kernels
     P.work_n = nullptr;
     P.work_cap = 0;
@@ -1329,6 +1331,7 @@ int fqtk_matcher_create(const char *const *barcodes, uint32_t n_samples, uint32_
     std::vector<uint32_t> table((size_t)n_samples * m->NW * 4, 0u);
     std::vector<std::vector<uint8_t>> enc(n_samples, std::vector<uint8_t>(barcode_len));
     uint32_t max_ns = 0;
+    bool plain = true;
     m->barcodes_upper.resize(n_samples);
     for (uint32_t s = 0; s < n_samples; ++s) {
         uint32_t ns = 0;
@@ -1339,6 +1342,7 @@ int fqtk_matcher_create(const char *const *barcodes, uint32_t n_samples, uint32_
             if (b == 'N' || b == 'n' || b == '.') ns++;
             const uint8_t e = enc_byte(b);
             enc[s][i] = e;
+            plain = plain && (e == 1 || e == 2 || e == 4 || e == 8);
             const uint32_t w = i / 32, bit = i % 32;
             for (uint32_t j = 0; j < 4; ++j)
                 if (!((e >> j) & 1u)) table[((size_t)s * m->NW + w) * 4 + j] |= (1u << bit);
@@ -1346,6 +1350,7 @@ int fqtk_matcher_create(const char *const *barcodes, uint32_t n_samples, uint32_
         max_ns = std::max(max_ns, ns);
     }
     m->max_ns = max_ns;
+    m->plain_samples = plain;
 
     std::vector<uint32_t> lut(256);
     for (int b = 0; b < 256; ++b) {

@@ -47,6 +47,7 @@ struct MatchParams {
     uint32_t nocall_limit;       // max_mismatches + max_ns_in_barcodes (barcode_matching.rs:171)
     uint32_t lds_hist;           // 1: histogram in LDS, 0: global atomics
     uint32_t scan_tab_lds;       // memo kernels: 1 = the wave scan of non-canonical reads finds the table in LDS
+    uint32_t plain_samples;      // 1 = every base of every sample is one of A C G T: a read's ambiguity codes read as N (memo kernels)
     // Non-canonical reads (IUPAC / junk bytes in the READ) are not in the memo.  Every wave of a memo kernel owns
     // one segment of `work` and appends the indices of its such reads there -- no atomics: one counter on one
     // address serialises in L2 at ~8 ns per wave that has anything to add, 25 x the kernel's own time at 1 % of

@@ -58,19 +58,31 @@ struct MemoParams {
 // the first (memo_nibble_shift is the host's view of that order).  kc / kv are the two masks above cut
 // down to the real bases of a word (pad positions encode as 'A' = 0 = absent); FULL says all words but
 // the last are complete, so only the last one needs its masks from SGPRs.
+// plain_samples (wave-uniform; every sample base is one of A C G T): the odd bytes of a read get their codes where they stand
+// (memo_hash.hpp recode_flagged_bytes: ambiguity codes and '.' read as N, U as T) and `bad` is left set only by bytes of no
+// IUPAC meaning -- behind one wave-uniform test per read slot and one per word in which some lane holds such a byte.
 template <int NWD, bool FULL, bool FOLD>
 __device__ __forceinline__ void encode_nibbles(const uint32_t (&words)[kRowWords], const uint32_t (&kc)[NWD],
-                                               const uint32_t (&kv)[NWD], uint32_t (&key)[4], uint32_t &bad, uint32_t &lo_unf, uint32_t &c2) {
+                                               const uint32_t (&kv)[NWD], uint32_t (&key)[4], uint32_t &bad, uint32_t &lo_unf, uint32_t &c2,
+                                               bool plain_samples = false) {
     static_assert(!FOLD || NWD == 3, "the fold is for the 9-10 base keys only");
     static_assert(NWD >= 1 && NWD <= 8, "at most 32 bases");
-    uint32_t c[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    uint32_t c[8] = {0, 0, 0, 0, 0, 0, 0, 0}, x[NWD];
     bad = 0;
 #pragma unroll
     for (int w = 0; w < NWD; ++w) {
         const bool full = FULL && w < NWD - 1;
-        c[w] = (words[w] >> 1) & (full ? 0x07070707u : kc[w]);
-        const uint32_t e = __builtin_amdgcn_perm(kCodePoolHi, kCodePoolLo, c[w]);
-        bad |= (words[w] ^ e) & (full ? 0xDFDFDFDFu : kv[w]);
+        encode_word(words[w], full ? 0x07070707u : kc[w], full ? 0xDFDFDFDFu : kv[w], c[w], x[w]);
+        bad |= x[w];
+    }
+    if (plain_samples && __builtin_amdgcn_uicmp(bad, 0u, 33 /* ne */)) {   // wave-uniform
+        bad = 0;
+#pragma unroll
+        for (int w = 0; w < NWD; ++w) {
+            const bool full = FULL && w < NWD - 1;
+            if (__builtin_amdgcn_uicmp(x[w], 0u, 33)) x[w] = recode_flagged_bytes(words[w], x[w], c[w], full ? 0x07070707u : kc[w]);
+            bad |= x[w];
+        }
     }
     key[0] = NWD >= 2 ? ((c[1] << 4) | c[0]) : c[0];
     lo_unf = key[0];    // bases 0-7 before the fold, and the codes of bases 8.. : what memo_direct_index reads
@@ -89,7 +101,7 @@ template <int NWD, bool FULL, bool FOLD>
 __device__ __forceinline__ void encode_nibbles(const uint32_t (&words)[kRowWords], const uint32_t (&kc)[NWD],
                                                const uint32_t (&kv)[NWD], uint32_t (&key)[4], uint32_t &bad) {
     uint32_t lo_unf, c2;
-    encode_nibbles<NWD, FULL, FOLD>(words, kc, kv, key, bad, lo_unf, c2);
+    encode_nibbles<NWD, FULL, FOLD>(words, kc, kv, key, bad, lo_unf, c2, false);
 }
 
 // The same encode with the per-word pieces kept (the LDS forms: see recode_flagged_bytes): c[w] = the four codes of word w,
@@ -376,7 +388,7 @@ void memo_kernel(const MemoParams Q) {
 #pragma unroll
         for (int r = 0; r < R; ++r) {
             uint32_t b, lo_unf, c2;
-            encode_nibbles<NWD, (VEC >= 1 && !(ABL & 2)), FOLD>(words[r], kc, kv, key[r], b, lo_unf, c2);
+            encode_nibbles<NWD, (VEC >= 1 && !(ABL & 2)), FOLD>(words[r], kc, kv, key[r], b, lo_unf, c2, P.plain_samples != 0u);
             bad[r] = b != 0 && live[r];
             if constexpr (LENS) bad[r] = bad[r] && words[r][kLenWord] == L;
             if constexpr (DIRECT) {

@@ -13,5 +13,7 @@ row "cfg3, 10% of reads carry a dot" 0.0066 0
 row "cfg3, 0.1% of reads carry an IUPAC byte" 0 0.0000625
 row "cfg3, 1% of reads carry an IUPAC byte" 0 0.00063
 row "cfg3, 10% of reads carry an IUPAC byte" 0 0.0066
+row "cfg3 table form, no non-canonical reads" 0 0 --memo-table
 row "cfg3 table form, 1% dot" 0.00063 0 --memo-table
 row "cfg3 table form, 1% IUPAC" 0 0.00063 --memo-table
+row "cfg3 table form, 10% IUPAC" 0 0.0066 --memo-table
