@@ -266,14 +266,11 @@ void lds_memo_kernel(const LdsMemoParams Q) {
         // ---- ASCII -> codes; the rare bytes that are not A C G T N get their codes where they stand (recode_flagged_bytes: this
         //      form is for plain A/C/G/T samples only), behind wave-uniform branches: one test per tile, one per word of a tile that
         //      holds such a byte, ~30 instructions for that word.  bflag is left set only by bytes of no IUPAC meaning.
-        uint32_t cw[R][NWD], xw[R][NWD];
+        uint32_t cw[R][NWD];
         uint32_t any_odd = 0;
 #pragma unroll
         for (int r = 0; r < R; ++r) {
-            encode_codes<NWD, (VEC >= 1)>(words[r], kc, kv, cw[r], xw[r]);
-            bflag[r] = 0;
-#pragma unroll
-            for (int w = 0; w < NWD; ++w) bflag[r] |= xw[r][w];
+            encode_codes<NWD, (VEC >= 1)>(words[r], kc, kv, cw[r], bflag[r]);
             any_odd |= bflag[r];
         }
         if (__builtin_amdgcn_uicmp(any_odd, 0u, 33 /* ne */)) {   // wave-uniform
@@ -282,8 +279,10 @@ void lds_memo_kernel(const LdsMemoParams Q) {
                 bflag[r] = 0;
 #pragma unroll
                 for (int w = 0; w < NWD; ++w) {
-                    if (__builtin_amdgcn_uicmp(xw[r][w], 0u, 33)) xw[r][w] = recode_flagged_bytes(words[r][w], xw[r][w], cw[r][w], ((VEC >= 1) && w < NWD - 1) ? 0x07070707u : kc[w]);
-                    bflag[r] |= xw[r][w];
+                    const bool full = (VEC >= 1) && w < NWD - 1;
+                    uint32_t x = flagged_bytes_of_word(words[r][w], cw[r][w], full ? 0xDFDFDFDFu : kv[w]);
+                    if (__builtin_amdgcn_uicmp(x, 0u, 33)) x = recode_flagged_bytes(words[r][w], x, cw[r][w], full ? 0x07070707u : kc[w]);
+                    bflag[r] |= x;
                 }
             }
         }

@@ -67,21 +67,23 @@ __device__ __forceinline__ void encode_nibbles(const uint32_t (&words)[kRowWords
                                                bool plain_samples = false) {
     static_assert(!FOLD || NWD == 3, "the fold is for the 9-10 base keys only");
     static_assert(NWD >= 1 && NWD <= 8, "at most 32 bases");
-    uint32_t c[8] = {0, 0, 0, 0, 0, 0, 0, 0}, x[NWD];
+    uint32_t c[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     bad = 0;
 #pragma unroll
     for (int w = 0; w < NWD; ++w) {
         const bool full = FULL && w < NWD - 1;
-        encode_word(words[w], full ? 0x07070707u : kc[w], full ? 0xDFDFDFDFu : kv[w], c[w], x[w]);
-        bad |= x[w];
+        uint32_t x;
+        encode_word(words[w], full ? 0x07070707u : kc[w], full ? 0xDFDFDFDFu : kv[w], c[w], x);
+        bad |= x;
     }
     if (plain_samples && __builtin_amdgcn_uicmp(bad, 0u, 33 /* ne */)) {   // wave-uniform
         bad = 0;
 #pragma unroll
         for (int w = 0; w < NWD; ++w) {
             const bool full = FULL && w < NWD - 1;
-            if (__builtin_amdgcn_uicmp(x[w], 0u, 33)) x[w] = recode_flagged_bytes(words[w], x[w], c[w], full ? 0x07070707u : kc[w]);
-            bad |= x[w];
+            uint32_t x = (words[w] ^ perm_b32(kCodePoolHi, kCodePoolLo, c[w])) & (full ? 0xDFDFDFDFu : kv[w]);   // (the byte-wise test again)
+            if (__builtin_amdgcn_uicmp(x, 0u, 33)) x = recode_flagged_bytes(words[w], x, c[w], full ? 0x07070707u : kc[w]);
+            bad |= x;
         }
     }
     key[0] = NWD >= 2 ? ((c[1] << 4) | c[0]) : c[0];
@@ -104,16 +106,23 @@ __device__ __forceinline__ void encode_nibbles(const uint32_t (&words)[kRowWords
     encode_nibbles<NWD, FULL, FOLD>(words, kc, kv, key, bad, lo_unf, c2, false);
 }
 
-// The same encode with the per-word pieces kept (the LDS forms: see recode_flagged_bytes): c[w] = the four codes of word w,
-// x[w] = nonzero in every byte of it that is not one of A C G T N (either case).
+// The same encode with the words' codes kept apart (the LDS forms: see recode_flagged_bytes): c[w] = the four codes of word w,
+// bad = nonzero when some byte is not one of A C G T N (either case).  flagged_bytes_of_word: that test for ONE word again, byte
+// by byte -- the rare wave that needs it recomputes it (two instructions a word) so that the others do not carry it.
 template <int NWD, bool FULL>
 __device__ __forceinline__ void encode_codes(const uint32_t (&words)[kRowWords], const uint32_t (&kc)[NWD], const uint32_t (&kv)[NWD],
-                                             uint32_t (&c)[NWD], uint32_t (&x)[NWD]) {
+                                             uint32_t (&c)[NWD], uint32_t &bad) {
+    bad = 0;
 #pragma unroll
     for (int w = 0; w < NWD; ++w) {
         const bool full = FULL && w < NWD - 1;
-        encode_word(words[w], full ? 0x07070707u : kc[w], full ? 0xDFDFDFDFu : kv[w], c[w], x[w]);
+        uint32_t x;
+        encode_word(words[w], full ? 0x07070707u : kc[w], full ? 0xDFDFDFDFu : kv[w], c[w], x);
+        bad |= x;
     }
+}
+__device__ __forceinline__ uint32_t flagged_bytes_of_word(uint32_t w, uint32_t c, uint32_t byte_mask) {
+    return (w ^ perm_b32(kCodePoolHi, kCodePoolLo, c)) & byte_mask;
 }
 template <int NWD>
 __device__ __forceinline__ void assemble_key(const uint32_t (&c)[NWD], uint32_t (&key)[4]) {
