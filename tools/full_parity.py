@@ -93,4 +93,9 @@ def main():
 
 
 if __name__ == "__main__":
-    sys.exit(main())
+    rc = main()
+    # Everything is checked and printed: leave without the interpreter's teardown of torch and the HIP runtime, which has ended in
+    # SIGSEGV once in some forty runs of this tool on the pool's boxes (round 6; after the result line, nothing of ours on the stack).
+    sys.stdout.flush()
+    sys.stderr.flush()
+    os._exit(rc)
