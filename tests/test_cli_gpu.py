@@ -273,6 +273,45 @@ def test_synthetic_multi_chunk_gz_inputs_match_the_oracle(tmp_path):
     assert [int(r[2]) for r in rows] == [int(c) for c in counts]
 
 
+def test_plate_of_384_samples_with_12_plus_12_dual_indexes(tmp_path):
+    """I1 12B + R1 40T + I2 12B, 384 samples: the matcher inside the record pipeline serves this plate from the LDS form of
+    three-byte entries behind a perfect hash (round 6; the HBM/L2 table before), and index reads with ambiguity codes, '.' and
+    bytes of no meaning go through its first-pass recode / second pass.  Per-sample records in input order and the metrics file
+    against the oracle's assignments."""
+    from oracle import oracle as O
+    rng = np.random.default_rng(1212)
+    seen = set()
+    while len(seen) < 384:
+        seen.add("".join(rng.choice(list("ACGT"), size=24)))
+    barcodes = sorted(seen)
+    n = 40_000
+    bc = np.stack([np.frombuffer(b.encode(), dtype=np.uint8) for b in barcodes])[rng.integers(0, 384, n)].copy()
+    flip = rng.random(bc.shape) < 0.02
+    bc[flip] = np.frombuffer(b"ACGTN", dtype=np.uint8)[rng.integers(0, 5, int(flip.sum()))]
+    odd = rng.random(bc.shape) < 0.004
+    bc[odd] = np.frombuffer(b"RYKMSWBDHVU.ryn", dtype=np.uint8)[rng.integers(0, 15, int(odd.sum()))]
+    bc[rng.random(n) < 0.05] = np.frombuffer(b"ACGT", dtype=np.uint8)[rng.integers(0, 4, 24)]
+    t1 = np.frombuffer(b"ACGT", dtype=np.uint8)[rng.integers(0, 4, size=(n, 40))]
+    i1 = [bytes(bc[i, :12]).decode() for i in range(n)]
+    i2 = [bytes(bc[i, 12:]).decode() for i in range(n)]
+    r1 = [bytes(t1[i]).decode() for i in range(n)]
+    ins = [H.fastq_file(tmp_path, "i1", "q", i1, gz=True), H.fastq_file(tmp_path, "r1", "q", r1, gz=True), H.fastq_file(tmp_path, "i2", "q", i2, gz=True)]
+    meta = os.path.join(str(tmp_path), "metadata.tsv")
+    with open(meta, "w") as fh:
+        fh.write("sample_id\tbarcode\n" + "".join(f"S{i:03}\t{b}\n" for i, b in enumerate(barcodes)))
+    out = tmp_path / "output"
+    _ok(H.run_demux(ins, ["12B", "40T", "12B"], meta, out, threads=8, extra=["--chunk-reads", "9000"]))
+    idx, _, _, counts = O.RefLiteral(barcodes, 1, 2, True).assign_batch(np.ascontiguousarray(bc))
+    rows = [l.split("\t") for l in open(out / "demux-metrics.txt").read().splitlines()[1:]]
+    assert len(rows) == 385 and [int(r[2]) for r in rows] == [int(c) for c in counts]
+    assert 0.5 < 1 - counts[-1] / n < 0.97
+    for s in list(np.unique(idx[idx != 0xFFFF])[:20]) + [0xFFFF]:
+        name = "unmatched" if s == 0xFFFF else f"S{int(s):03}"
+        sel = np.nonzero(idx == s)[0]
+        exp = [(f"q_{i} 1:N:0:{i1[i]}+{i2[i]}", r1[i], ";" * 40) for i in sel]
+        assert H.read_fastq(out / f"{name}.R1.fq.gz") == exp
+
+
 def test_cfg5_shape_1536_iupac_samples_inline_barcode_plus_template(tmp_path):
     """cfg 5 shape end to end: 1536 IUPAC-degenerate samples (1537 output files: the CLI must raise its
     fd limit), `10B+T` with variable-length templates, counts and routing checked against the oracle."""
