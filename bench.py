@@ -202,8 +202,11 @@ def self_launch(n_gpus: int) -> int:
 def main() -> int:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=2)
+    # defaults: a timed region of 70 ms on cfg 3.  The device's clocks take tens of milliseconds to settle after the idle stretch of the
+    # matcher's creation: 10 steps after 2 warm-up steps (the defaults until the end of round 6) read 1-3 % under the rate of 200 or 1000
+    # steps on the same box, 50 after 10 read the same (profiles/r06_bench_window.txt)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--config", type=int, default=3, help="BASELINE.json config id (1-5), default 3")
     ap.add_argument("--reads", type=int, default=0, help="reads per rank per step (default: the config's N)")
     ap.add_argument("--scaling", choices=("weak", "strong"), default="weak",

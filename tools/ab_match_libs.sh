@@ -8,7 +8,7 @@ cp fqtk_amd/lib/libfqtk_match.so /tmp/product_libfqtk_match.so
 for rep in $(seq 1 $REPS); do
   for L in "$@"; do
     if [ -n "$L" ]; then cp fqtk_amd/lib/$L/libfqtk_match.so fqtk_amd/lib/libfqtk_match.so; else cp /tmp/product_libfqtk_match.so fqtk_amd/lib/libfqtk_match.so; fi
-    python bench.py --steps 20 --warmup 3 --cpu-seconds 0 --no-verify --no-scopes ${BENCH_ARGS} > /tmp/ab_line.json 2>/dev/null
+    python bench.py --steps 50 --warmup 10 --cpu-seconds 0 --no-verify --no-scopes ${BENCH_ARGS} > /tmp/ab_line.json 2>/dev/null
     python -c "
 import json; d=json.load(open('/tmp/ab_line.json')); print('lib=${L:-product}', 'G_reads_s', round(d['value']/1000,1), 'frac', d['roofline']['frac'], 'kernel_ms', d['roofline']['kernel_ms'])"
   done

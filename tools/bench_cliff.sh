@@ -3,7 +3,7 @@
 # key) and with IUPAC bytes in the READ (each such read takes a wave-cooperative scan of all samples).
 # Rates are per READ; the generator's knobs are per base (16 bases).
 cd "$(dirname "$0")/.."
-row() { FQTK_SYNTH_PDOT=$2 FQTK_SYNTH_PIUPAC=$3 python bench.py --steps 10 --warmup 2 --cpu-seconds 0 --parity windows --no-scopes $4 >/dev/null 2>&1 && python -c "
+row() { FQTK_SYNTH_PDOT=$2 FQTK_SYNTH_PIUPAC=$3 python bench.py --steps 50 --warmup 10 --cpu-seconds 0 --parity windows --no-scopes $4 >/dev/null 2>&1 && python -c "
 import json
 d=json.load(open('gpurun_out/bench_detail.json')); r=d['roofline']
 print(json.dumps({'row': '$1', 'G_reads_s': round(d['value']/1000,1), 'frac': r['frac'], 'kernel_ms': r['kernel_ms'], 'kernel': r['kernel'], 'parity': d['config']['parity']}))"; }

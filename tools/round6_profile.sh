@@ -17,7 +17,7 @@ if has bench; then
   FQTK_BENCH_DEVICES=0,0 python bench.py --steps 20 --warmup 5 --cpu-seconds 0 > $O/bench_line_devices00.json 2> $O/bench_devices00.err; cp gpurun_out/bench_detail.json $O/bench_detail_devices00.json 2>/dev/null
 fi
 if has matrix; then
-  STEPS=10 bash tools/bench_matrix.sh > $O/bench_matrix.jsonl 2> /dev/null
+  bash tools/bench_matrix.sh > $O/bench_matrix.jsonl 2> /dev/null
   bash tools/bench_cliff.sh > $O/cliff.jsonl 2> /dev/null
   echo "== bench_custom 384 24 1 2" > $O/bench_custom.txt; timeout 300 python tools/bench_custom.py 384 24 1 2 >> $O/bench_custom.txt 2>&1
 fi
