@@ -297,10 +297,19 @@ def main() -> int:
         matcher.assign_batch_device(d_obs.data_ptr(), cfg.stride, n, d_out.data_ptr(), d_counts.data_ptr(),
                                     d_lens=d_lens.data_ptr() if d_lens is not None else 0, stream=stream)
 
-    settle_steps = max(0, 10 - args.warmup)   # (untimed) with fewer than 10 warm-up steps asked for: launches until the device's clocks
-    for _ in range(settle_steps):             # have settled after the idle stretch of the matcher's creation (profiles/r06_bench_window.txt)
+    # (untimed) launches until the device's clocks have settled after the idle stretch of the matcher's creation: 60 ms of them, less the
+    # warm-up steps asked for (profiles/r06_bench_window.txt: 14 ms of cfg 3, or 50 steps of cfg 2's 0.2 ms, read 1-15 % under the sustained rate)
+    step()
+    torch.cuda.synchronize()                  # (the first launch: lazy initialisation)
+    t_one = time.perf_counter()
+    step()
+    torch.cuda.synchronize()
+    t_one = max(time.perf_counter() - t_one, 1e-5)
+    settle_steps = min(2000, max(0, int(0.06 / t_one) - args.warmup))
+    for _ in range(settle_steps):
         step()
     torch.cuda.synchronize()
+    settle_steps += 2
     for _ in range(args.warmup):
         step()
         torch.cuda.synchronize()   # (untimed) a matcher adapts between batches -- the worklist for reads with IUPAC /
