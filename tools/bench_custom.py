@@ -38,10 +38,15 @@ for kind in (2, 1):
     for _ in range(2):
         m.assign_batch_device(d.data_ptr(), stride, n, out.data_ptr(), cnt.data_ptr(), stream=st)
     torch.cuda.synchronize()
+    t = time.perf_counter()   # (untimed) 60 ms of launches: the device's clocks settle (profiles/r06_bench_window.txt)
+    while time.perf_counter() - t < 0.06:
+        for _ in range(10):
+            m.assign_batch_device(d.data_ptr(), stride, n, out.data_ptr(), cnt.data_ptr(), stream=st)
+        torch.cuda.synchronize()
     t = time.perf_counter()
-    for _ in range(5):
+    for _ in range(20):
         m.assign_batch_device(d.data_ptr(), stride, n, out.data_ptr(), cnt.data_ptr(), stream=st)
     torch.cuda.synchronize()
-    dt = (time.perf_counter() - t) / 5
+    dt = (time.perf_counter() - t) / 20
     print(f"S={S} L={L} mm={mm} memo_kind={m.memo_kind} entries={m.memo_entries}: {n / dt / 1e9:.1f} G reads/s, "
           f"{n * (stride + 4) / dt / 1e9:.0f} GB/s")
