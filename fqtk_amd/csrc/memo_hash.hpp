@@ -84,7 +84,7 @@ FQTK_HD inline void encode_word(uint32_t w, uint32_t code_mask, uint32_t byte_ma
 // Returns 0x80 in every byte that is STILL non-canonical: a byte of no IUPAC meaning (its mask is 0: it MATCHES everything),
 // which only the scan resolves.  Rounds 2-5 listed every read with an ambiguity code for a second launch (which spelled the
 // codes as N and looked the read up again) or scanned it in place: at 1 % of reads with such a byte that cost 24 % of the
-// kernel's rate, at 10 % 49 %; now 5 % and 26 % (profiles/r06_cliff.jsonl).  Wave-uniform callers: only words in which SOME
+// kernel's rate, at 10 % 49 %; now 5-7 % and 26-29 % (profiles/r06_cliff.jsonl).  Wave-uniform callers: only words in which SOME
 // lane has a flagged byte come here (~10 instructions when those are all '.', ~35 otherwise).
 FQTK_HD inline uint32_t recode_flagged_bytes(uint32_t w, uint32_t x, uint32_t &c, uint32_t code_mask) {
     const uint32_t flagged = ((x & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | x;                       // bit 7 in every flagged byte
