@@ -602,6 +602,7 @@ int dispatch_lds_memo(const fqtk_matcher *m, const fqtk::LdsMemoParams &Q, hipSt
         case 3 * 4 + kLdsFormMph: return launch_lds_memo<3, kLdsFormMph>(m, Q, stream, second_pass);
         case 4 * 4 + kLdsFormPow2: return launch_lds_memo<4, kLdsFormPow2>(m, Q, stream, second_pass);
         case 4 * 4 + kLdsFormAny: return launch_lds_memo<4, kLdsFormAny>(m, Q, stream, second_pass);
+        case 4 * 4 + kLdsFormMph: return launch_lds_memo<4, kLdsFormMph>(m, Q, stream, second_pass);
         default: return fail(FQTK_EINVAL, "lds memo: no kernel for this key width and table form");
     }
 }

@@ -29,7 +29,7 @@
 // workgroup; without gathers 16 waves/CU stream as fast as 32 (measured).
 //
 // FORM of the entry table (a template parameter): kLdsFormAny / kLdsFormPow2 = the three-choice cuckoo table above, its slot count
-// any number / a power of two; kLdsFormMph (round 6, three key words) = a minimal perfect hash over three-byte entries
+// any number / a power of two; kLdsFormMph (round 6, three and four key words) = a minimal perfect hash over three-byte entries
 // (memo_hash.hpp, lds_memo_plan.hpp plan_lds_memo_mph): ds_read_u16 of the key's bucket displacement, ds_read_u16 + ds_read_u8 of
 // the ONE slot the key can live in, the same check against the sample's key -- for the tables whose four-byte slots overflow LDS.
 #pragma once
@@ -103,7 +103,7 @@ template <int VEC, int KW, int R, int FORM, bool LENS = false, bool PF = false, 
 __global__ __launch_bounds__(kLdsBlock) __attribute__((amdgpu_waves_per_eu(4, 8)))
 void lds_memo_kernel(const LdsMemoParams Q) {
     static_assert(!INDEXED || (VEC <= 0 && !LENS && !PF), "the second pass gathers single rows");
-    static_assert(FORM != kLdsFormMph || KW == 3, "the perfect-hash form is planned for three key words");
+    static_assert(FORM != kLdsFormMph || KW >= 3, "the perfect-hash form is planned for three and four key words");
     const MatchParams &P = Q.m;
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
     // LDS: [entry table | sample keys | spread LUT (fallback scan) | histogram]; the entry table sits
@@ -259,8 +259,9 @@ void lds_memo_kernel(const LdsMemoParams Q) {
             const uint32_t tsh = __builtin_amdgcn_ubfe(e, 15, 3) << ((e >> 16) & 28u);
             const u32x4v sk = *reinterpret_cast<lds_u4 *>((uintptr_t)ka);
             const bool w1 = (e & (1u << 21)) != 0, w2 = (e & (1u << 22)) != 0;
-            const uint32_t diff = (key[r][0] ^ sk.x ^ ((w1 || w2) ? 0u : tsh)) | (key[r][1] ^ sk.y ^ ((w1 && !w2) ? tsh : 0u)) |
-                                  (key[r][2] ^ sk.z ^ ((w2 && !w1) ? tsh : 0u));
+            uint32_t diff = (key[r][0] ^ sk.x ^ ((w1 || w2) ? 0u : tsh)) | (key[r][1] ^ sk.y ^ ((w1 && !w2) ? tsh : 0u)) |
+                            (key[r][2] ^ sk.z ^ ((w2 && !w1) ? tsh : 0u));
+            if constexpr (KW == 4) diff |= key[r][3] ^ sk.w ^ ((w1 && w2) ? tsh : 0u);
             return diff == 0 ? mph_entry_result(e) : kMemoEmpty;
         };
         // ---- ASCII -> codes; the rare bytes that are not A C G T N get their codes where they stand (recode_flagged_bytes: this
@@ -292,7 +293,7 @@ void lds_memo_kernel(const LdsMemoParams Q) {
             if constexpr ((FQTK_LDSM_ABL & 1) != 0) { res[r] = (key[r][0] ^ (KW >= 2 ? key[r][1] : 0u)) | 0xFFFFu; continue; }
             if constexpr (FORM == kLdsFormMph) {
                 uint32_t ha, hb;
-                mph_hashes(key[r][0], key[r][1], key[r][2], 0u, Q.salt, ha, hb);
+                mph_hashes(key[r][0], key[r][1], key[r][2], KW >= 4 ? key[r][3] : 0u, Q.salt, ha, hb);
                 const uint32_t d = lds_half(Q.aux_off_b + ((ha & Q.slot_mask_b) << 1));
                 const uint32_t slot = mph_slot(ha, hb, d, Q.n_slots);
                 res[r] = verify_mph(r, lds_half(slot << 1) | (lds_byte(Q.t8_off_b + slot) << 16));

@@ -223,14 +223,14 @@ inline LdsMemoPlan plan_lds_memo(uint32_t S, uint32_t L, const std::vector<LdsEn
     return best;
 }
 
-// The minimal-perfect-hash form (memo_hash.hpp): for key widths of three words whose entries do not fit as cuckoo slots.
+// The minimal-perfect-hash form (memo_hash.hpp): for key widths of three and four words whose entries do not fit as cuckoo slots.
 // Hash-and-displace: the keys are dealt into buckets by one hash; the buckets, largest first, each take the first displacement d
 // (a 16-bit word kept in LDS) under which mph_slot sends all their keys to free slots.  ok = false: not of the shape, or no room.
 inline LdsMemoPlan plan_lds_memo_mph(uint32_t S, uint32_t L, const std::vector<LdsEntry> &ents,
                                      const std::vector<std::vector<uint8_t>> &enc, uint32_t salt_offset = 0) {
     LdsMemoPlan plan;
-    if (S < 2 || ents.empty() || L <= 16 || L > 24 || S + 1 > (1u << kMphIdxBits)) return plan;
-    const int kw = 3, ks = 4;
+    if (S < 2 || ents.empty() || L <= 16 || L > kMemoMaxLen || S + 1 > (1u << kMphIdxBits)) return plan;
+    const int kw = L <= 24 ? 3 : 4, ks = 4;
     std::vector<uint32_t> skeys;
     std::vector<LdsRelEntry> rel;
     if (!lds_relative_entries(S, L, ents, enc, kw, ks, skeys, rel)) return plan;

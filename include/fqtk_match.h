@@ -110,7 +110,7 @@ uint64_t fqtk_matcher_memo_candidates(const fqtk_matcher *m);
  *   FQTK_MEMO_TABLE  two-choice hash table in HBM/L2 + LDS hot subset (any sample alphabet, any max_mismatches)
  *   FQTK_MEMO_LDS    one-dword entries, whole table resident in each CU's LDS -- built when all sample
  *                    barcodes are plain A/C/G/T, max_mismatches <= 1 and the table fits 160 KiB; for barcodes
- *                    of 17-24 bases whose dwords do not fit (384 samples x 12+12), three-byte entries behind a
+ *                    of 17-32 bases whose dwords do not fit (384 samples x 12+12), three-byte entries behind a
  *                    minimal perfect hash
  * fqtk_matcher_memo_kind() reports the form the next batch will use; fqtk_matcher_set_memo_kind(m,
  * FQTK_MEMO_TABLE) pins the HBM/L2 form, FQTK_MEMO_LDS (the default) means "best available". */

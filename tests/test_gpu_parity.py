@@ -193,7 +193,7 @@ def test_lds_form_with_any_size_table_384_samples_x_20_bases():
         _compare(bcs, 1, 2, obs)
 
 
-@pytest.mark.parametrize("S,L", [(384, 24), (440, 23), (300, 17)])
+@pytest.mark.parametrize("S,L", [(384, 24), (440, 23), (300, 17), (330, 30), (300, 32)])
 def test_lds_form_behind_a_perfect_hash_for_12_plus_12_dual_indexes(S, L, monkeypatch):
     """384 samples x 24 bases: 37 248 memo entries are more four-byte cuckoo slots than LDS has; round 6 gives such tables an LDS
     form of three-byte entries behind a minimal perfect hash (lds_memo_plan.hpp plan_lds_memo_mph) -- the HBM/L2 table served them

@@ -142,7 +142,7 @@ def _random_barcodes(n, L, seed):
     return sorted(seen), rng
 
 
-@pytest.mark.parametrize("S,L", [(384, 24), (400, 22), (60, 17), (2, 24)])
+@pytest.mark.parametrize("S,L", [(384, 24), (400, 22), (60, 17), (2, 24), (340, 32), (330, 29), (40, 25)])
 def test_minimal_perfect_hash_form_for_tables_the_cuckoo_slots_have_no_room_for(S, L):
     """384 samples x 24 bases (12+12 dual index): 37 248 entries are 170 KB of four-byte cuckoo slots at a workable load -- no LDS
     form until round 6.  plan_lds_memo_mph: a hash-and-displace perfect hash (one 16-bit displacement per bucket), three-byte
@@ -152,7 +152,7 @@ def test_minimal_perfect_hash_form_for_tables_the_cuckoo_slots_have_no_room_for(
     if S == 384 and L == 24:
         assert _plan(barcodes, 1, 2)[0][0] == 0, "the cuckoo form has no room for this table (else this form is not needed)"
     meta, image, cand, keys, vals = _plan(barcodes, 1, 2, salt_trials=-1)
-    assert meta[0] == 1 and meta[10] == 1 and meta[6] == 3 and meta[8] == 0
+    assert meta[0] == 1 and meta[10] == 1 and meta[6] == (3 if L <= 24 else 4) and meta[8] == 0
     n_slots, t8_off, aux_off, skey_off, buckets = int(meta[1]), int(meta[11]), int(meta[12]), int(meta[4]), int(meta[13]) + 1
     assert len(vals) <= n_slots and buckets & (buckets - 1) == 0
     assert 2 * n_slots <= t8_off and t8_off + n_slots <= aux_off and aux_off + 2 * buckets <= skey_off and skey_off % 16 == 0
@@ -171,7 +171,7 @@ def test_minimal_perfect_hash_form_for_tables_the_cuckoo_slots_have_no_room_for(
 
 def test_shapes_the_minimal_perfect_hash_form_does_not_cover():
     assert _plan(_random_barcodes(40, 16, 1)[0], 1, 2, salt_trials=-1)[0][0] == 0    # two key words: the cuckoo form's
-    assert _plan(_random_barcodes(40, 25, 2)[0], 1, 2, salt_trials=-1)[0][0] == 0    # four key words
+    assert _plan(_random_barcodes(384, 32, 2)[0], 1, 2, salt_trials=-1)[0][0] == 0   # 16+16 x 384: 49 536 entries, no room even at three bytes
     assert _plan(_random_barcodes(512, 18, 3)[0], 1, 2, salt_trials=-1)[0][0] == 0   # S + 1 > 512: no room in the index field
     assert _plan(["ACGTACGTACGTACGTACGN", "TTTTGGGGTTTTGGGGTTTT"], 1, 1, salt_trials=-1)[0][0] == 0   # N in a sample
 
