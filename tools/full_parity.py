@@ -20,11 +20,20 @@ sys.path.insert(0, ROOT)
 DT = np.dtype([("idx", "<u2"), ("best", "u1"), ("next", "u1")])
 
 
+def _config(spec):
+    """A BASELINE config by its number, or "S,L,reads": S plain samples of L bases, one mismatch, delta 2 (--custom)."""
+    from fqtk_amd import synth
+    if isinstance(spec, int):
+        return synth.CONFIGS[spec]
+    S, L, n = (int(x) for x in spec.split(","))
+    return synth._cfg(9, f"custom {S} samples x {L} bases, {n} reads", n, S, L, 1, 2)
+
+
 def _check(args):
     cfg_id, lo, hi, path = args
     from fqtk_amd import synth
     from oracle import oracle as O
-    cfg = synth.CONFIGS[cfg_id]
+    cfg = _config(cfg_id)
     w = synth.Workload(cfg)
     lit = O.RefLiteral(w.barcodes, cfg.max_mismatches, cfg.min_mismatch_delta, True)
     got = np.memmap(path, dtype=DT, mode="r")
@@ -48,10 +57,12 @@ def main():
     ap.add_argument("--procs", type=int, default=0)
     ap.add_argument("--no-cache", action="store_true")
     ap.add_argument("--table", action="store_true", help="pin the HBM/L2 table form of the memo")
+    ap.add_argument("--custom", default="", help="S,L,reads: a table of S plain samples of L bases instead of a BASELINE config")
     a = ap.parse_args()
     import torch
     from fqtk_amd import BarcodeMatcher, synth
-    cfg = synth.CONFIGS[a.config]
+    spec = a.custom if a.custom else a.config
+    cfg = _config(spec)
     n = a.reads or cfg.n_reads
     procs = a.procs or max(1, min(64, (os.cpu_count() or 2) // 2))
     w = synth.Workload(cfg)
@@ -76,7 +87,7 @@ def main():
     gpu_counts = d_counts.cpu().numpy().astype(np.uint64)
     del d_obs, d_out
     bounds = np.linspace(0, n, procs + 1).astype(np.int64)
-    jobs = [(a.config, int(bounds[i]), int(bounds[i + 1]), path) for i in range(procs) if bounds[i] < bounds[i + 1]]
+    jobs = [(spec, int(bounds[i]), int(bounds[i + 1]), path) for i in range(procs) if bounds[i] < bounds[i + 1]]
     t0 = time.perf_counter()
     with mp.get_context("spawn").Pool(len(jobs)) as pool:
         res = pool.map(_check, jobs)
