@@ -198,3 +198,18 @@ def test_the_run_in_a_child_process_passes_status_and_messages_on(tmp_path):
     assert r.returncode == 1 and "unexpected argument" in r.stderr
     r = subprocess.run([exe, "demux", "--help"], capture_output=True, text=True, timeout=60)
     assert r.returncode == 0 and "Usage: fqtk demux" in r.stdout
+
+
+def test_the_committed_hbm_traffic_is_of_the_current_kernel_sources():
+    """bench.py reports roofline.traffic from profiles/pmc_traffic.json only when that file was measured on the kernel sources of this
+    tree (their digest is in it); after a change to the matcher's kernels the counter passes are run again (tools/profile_bench.sh) and
+    the file committed -- or the line says traffic: null."""
+    import json
+    import os
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    import bench
+    have = json.load(open(os.path.join(root, "profiles", "pmc_traffic.json")))["cfg3"]
+    assert have["kernel_sources_sha1"] == bench.kernel_sources_digest(), "run tools/profile_bench.sh on a GPU box and commit profiles/pmc_traffic.json"
+    assert 0.99 < have["traffic_bytes_per_launch"] / (have["reads_per_launch"] * 20) < 1.05   # 16 bytes in + 4 out per read
